@@ -1,0 +1,321 @@
+#!/usr/bin/env python3
+"""Generate the golden input/output vectors under tests/golden/ by running the
+reference implementation (/root/reference, read-only) on small synthetic
+interaction streams.
+
+Runs ONLY in the build container (the reference never travels to the GPU box).
+What it records is data: inputs, expected outputs, library versions.  Model
+weights are not stored - they are regenerated from tests/golden/_weights.py.
+
+Third-party boundary: the reference imports `torch_scatter.scatter_max`
+(tiger/model/utils.py:7,15), which is not installed and not vendored.  Its
+published semantics (per-segment max plus the position of that max) are restated
+below as `scatter_max`; among equal maxima the FIRST position wins, which is the
+torch_scatter CPU behaviour.  Everything downstream of that tie rule is
+therefore "parity unpinned" by the reference itself and pinned by these vectors.
+
+usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path.insert(0, HERE)
+from _weights import golden_param  # noqa: E402
+
+
+def _install_scatter_max():
+    mod = types.ModuleType('torch_scatter')
+
+    def scatter_max(src, index, dim=-1, out=None, dim_size=None):
+        n = int(index.max().item()) + 1 if dim_size is None else dim_size
+        mx = torch.full((n,), float('-inf'), dtype=src.dtype).scatter_reduce(
+            0, index, src, 'amax', include_self=True)
+        pos = torch.arange(len(src))
+        cand = torch.where(src == mx[index], pos, torch.full_like(pos, len(src)))
+        arg = torch.full((n,), len(src), dtype=torch.long).scatter_reduce(
+            0, index, cand, 'amin', include_self=True)
+        return mx, arg
+
+    mod.scatter_max = scatter_max
+    sys.modules['torch_scatter'] = mod
+
+
+_install_scatter_max()
+sys.path.insert(0, '/root/reference')
+from tiger.data.data_loader import GraphCollator, InteractionData  # noqa: E402
+from tiger.data.graph import Graph  # noqa: E402
+from tiger.model.feature_getter import NumericalFeature  # noqa: E402
+from tiger.model.restarters import SeqRestarter, StaticRestarter  # noqa: E402
+from tiger.model.tiger import TIGER  # noqa: E402
+from tiger.model.utils import anonymized_reindex, select_latest_nids  # noqa: E402
+
+VERSIONS = np.array([f'torch={torch.__version__}', f'numpy={np.__version__}',
+                     'reference=yzhang1918/www2023tiger@v1.0.1',
+                     'scatter_max=stand-in(first-index-wins)'])
+
+
+def make_stream(seed, n_u, n_i, E, T, integer_ts=True):
+    """Bipartite stream, ids: 0 = padding, users 1..n_u, items n_u+1..n_u+n_i."""
+    rs = np.random.RandomState(seed)
+    pu = 1.0 / np.arange(1, n_u + 1) ** 0.8
+    pi = 1.0 / np.arange(1, n_i + 1) ** 1.0
+    src = rs.choice(n_u, E, p=pu / pu.sum()) + 1
+    dst = rs.choice(n_i, E, p=pi / pi.sum()) + 1 + n_u
+    ts = np.sort(rs.uniform(0, T, E))
+    if integer_ts:
+        ts = np.floor(ts)
+    eids = np.arange(1, E + 1)
+    return src.astype(np.int64), dst.astype(np.int64), ts.astype(np.float64), eids.astype(np.int64)
+
+
+# --------------------------------------------------------------------------- sampler
+def gen_sampler():
+    out = {'versions': VERSIONS}
+    src, dst, ts, eids = make_stream(11, 30, 12, 1500, 400.0)  # many duplicate ts
+    # a few self-describing corner cases appended: a node with one event, id gaps
+    src = np.concatenate([src, [45, 45]])
+    dst = np.concatenate([dst, [47, 45]])  # (45,45): self loop
+    ts = np.concatenate([ts, [401.0, 402.0]])
+    eids = np.concatenate([eids, [1501, 1502]])
+    labels = np.zeros(len(src), dtype=np.int64)
+    data = InteractionData(src, dst, ts, eids, labels, seed=0, eval=True)
+    out.update(src=src, dst=dst, ts=ts, eids=eids)
+    rs = np.random.RandomState(5)
+    n_nodes = max(src.max(), dst.max()) + 1
+    Q = 400
+    q_nids = rs.randint(0, n_nodes, Q).astype(np.int64)
+    q_ts = rs.choice(np.concatenate([ts, ts + 0.5, [0.0, -1.0, 1e9]]), Q).astype(np.float64)
+    # force exact-hit queries (strict '<'), empty histories, over-full histories
+    q_nids[:40] = src[rs.randint(0, len(src), 40)]
+    q_ts[:40] = ts[rs.randint(0, len(ts), 40)]
+    q_nids[40:50] = 0
+    q_nids[50:60] = 46  # node id that never occurs
+    out.update(q_nids=q_nids, q_ts=q_ts)
+    for strategy in ('recent_edges', 'recent_nodes'):
+        for K in (1, 5, 10, 40):
+            g = Graph.from_data(data, strategy=strategy, seed=3)
+            res = g.sample_temporal_neighbor(q_nids, q_ts, K)
+            for nm, a in zip(('nbr', 'eid', 'ts', 'dir'), res):
+                out[f'{strategy}_K{K}_{nm}'] = a
+    # uniform consumes the graph's RandomState per non-empty query, in query order
+    for K in (5, 10):
+        g = Graph.from_data(data, strategy='uniform', seed=3)
+        for rep in range(2):  # second call continues the same stream
+            res = g.sample_temporal_neighbor(q_nids, q_ts, K)
+            for nm, a in zip(('nbr', 'eid', 'ts', 'dir'), res):
+                out[f'uniform_K{K}_rep{rep}_{nm}'] = a
+    g = Graph.from_data(data, strategy='recent_edges', seed=3)
+    out['num_node'] = np.int64(g.num_node)
+    # float32-rounded query timestamps (restart path, restarters.py:70)
+    q32 = q_ts.astype(np.float32)
+    res = g.get_history(q_nids, q32, 8)
+    for nm, a in zip(('nbr', 'eid', 'ts', 'dir'), res):
+        out[f'hist32_H8_{nm}'] = a
+    # select_latest_nids with ties; both float32 and float64 timestamps
+    for i, (n, dt) in enumerate(((64, np.float32), (300, np.float64), (7, np.float32))):
+        ids = rs.randint(0, 20, n).astype(np.int64)
+        t = np.floor(rs.uniform(0, 6, n)).astype(dt)
+        u, idx = select_latest_nids(torch.from_numpy(ids), torch.from_numpy(t))
+        out[f'sel{i}_ids'] = ids
+        out[f'sel{i}_ts'] = t
+        out[f'sel{i}_unique'] = u.numpy()
+        out[f'sel{i}_index'] = idx.numpy()
+    # anonymized_reindex on real histories and on a hand-made block
+    hist = g.get_history(q_nids, q_ts, 12)[0]
+    out['anon_in'] = hist
+    out['anon_out'] = anonymized_reindex(hist)
+    hand = np.array([[0, 0, 0, 0], [0, 0, 0, 9], [3, 3, 3, 3], [1, 2, 1, 2], [0, 5, 6, 5], [4, 3, 2, 1]])
+    out['anon2_in'] = hand
+    out['anon2_out'] = anonymized_reindex(hand)
+    np.savez_compressed(os.path.join(HERE, 'sampler.npz'), **out)
+    print('sampler.npz', sum(v.nbytes for v in out.values()) // 1024, 'KiB raw')
+
+
+# --------------------------------------------------------------------------- model
+def build_reference_model(cfg, nfeats, efeats, graph, n_edges):
+    d = cfg['d']
+    fg = NumericalFeature(None if nfeats is None else torch.from_numpy(nfeats).float(),
+                          None if efeats is None else torch.from_numpy(efeats).float(),
+                          dim=d, register_buffer=True, device=torch.device('cpu'))
+    fg.n_nodes = graph.num_node
+    fg.n_edges = n_edges
+    if cfg['restarter'] == 'seq':
+        rst = SeqRestarter(raw_feat_getter=fg, graph=graph, hist_len=cfg['H'], n_head=2, dropout=0.1)
+    else:
+        rst = StaticRestarter(raw_feat_getter=fg, graph=graph)
+    model = TIGER(raw_feat_getter=fg, graph=graph, restarter=rst, n_neighbors=cfg['K'],
+                  hit_type=cfg.get('hit', 'bin'), n_layers=1, n_head=2, dropout=0.1,
+                  msg_src=cfg['msg_src'], upd_src=cfg['upd_src'],
+                  msg_tsfm_type=cfg.get('tsfm', 'id'), mem_update_type=cfg.get('upd_fn', 'gru'),
+                  tgn_mode=True, msg_last_only=True)
+    names, shapes = [], []
+    with torch.no_grad():
+        for name, p in model.named_parameters():  # de-duplicated by identity
+            p.copy_(torch.from_numpy(golden_param(name, p.shape, cfg['wseed'])))
+            names.append(name)
+            shapes.append(list(p.shape))
+    model.eval()
+    return model, names, shapes
+
+
+def snapshot(model, out, tag):
+    out[f'{tag}_left_vals'] = model.left_memory.vals.numpy().copy()
+    out[f'{tag}_left_ts'] = model.left_memory.update_ts.numpy().copy()
+    out[f'{tag}_right_vals'] = model.right_memory.vals.numpy().copy()
+    out[f'{tag}_right_ts'] = model.right_memory.update_ts.numpy().copy()
+    has = np.array(sorted(int(x) for x in model.msg_store.nodes_with_messages), dtype=np.int64)
+    out[f'{tag}_has_msg'] = has
+    out[f'{tag}_msg_vals'] = model.msg_store.node_msg_vals.numpy()[has].copy()
+    out[f'{tag}_msg_ts'] = model.msg_store.node_msg_ts.numpy()[has].copy()
+
+
+def gen_model(name, cfg):
+    d = cfg['d']
+    src, dst, ts, eids = make_stream(cfg['seed'], cfg['n_u'], cfg['n_i'], cfg['E'], cfg['T'],
+                                     integer_ts=cfg.get('integer_ts', True))
+    E = len(src)
+    n_nodes = int(max(src.max(), dst.max())) + 1
+    rs = np.random.RandomState(cfg['seed'] + 100)
+    nfeats = efeats = None
+    if cfg.get('nfeat', 'rand') == 'rand':
+        nfeats = rs.standard_normal((n_nodes, d)).astype(np.float32) * 0.5
+        nfeats[0] = 0
+    elif cfg.get('nfeat') == 'zero':
+        nfeats = np.zeros((n_nodes, d), dtype=np.float32)
+    if cfg.get('efeat', 'rand') == 'rand':
+        efeats = rs.standard_normal((E + 1, cfg.get('d_e', d))).astype(np.float32)
+        efeats[0] = 0
+    labels = np.zeros(E, dtype=np.int64)
+    neg = rs.randint(cfg['n_u'] + 1, n_nodes, E).astype(np.int64)
+    data = InteractionData(src, dst, ts, eids, labels, seed=0, eval=True, neg_dst=neg)
+    graph = Graph.from_data(data, strategy='recent_edges', seed=0)
+    model, pnames, pshapes = build_reference_model(cfg, nfeats, efeats, graph, E)
+    collator = GraphCollator(graph, cfg['K'], 1, restarter=cfg['restarter'], hist_len=cfg.get('H'))
+
+    out = {'versions': VERSIONS, 'src': src, 'dst': dst, 'ts': ts, 'eids': eids, 'neg': neg,
+           'n_nodes': np.int64(n_nodes), 'param_names': np.array(pnames),
+           'param_shapes': np.array([','.join(map(str, s)) for s in pshapes]),
+           'cfg': np.array([f'{k}={v}' for k, v in sorted(cfg.items())])}
+    if nfeats is not None and cfg.get('nfeat') != 'zero':
+        out['nfeats'] = nfeats
+    if efeats is not None:
+        out['efeats'] = efeats
+
+    B = cfg['B']
+    n_batches = cfg['n_batches']
+    restart_at = cfg.get('restart_at', -1)
+    restarting = False
+    uptodate = set()
+    with torch.no_grad():
+        for b in range(n_batches):
+            lo, hi = b * B, min((b + 1) * B, E)
+            batch = [data[i] for i in range(lo, hi)]
+            s, dd, ng, t, ee, _, cg = collator(batch)
+            tag = f'b{b}'
+            # ---- collator outputs
+            out[f'{tag}_l1_nids'] = cg.layers[1][0].numpy().copy()
+            out[f'{tag}_l1_eids'] = cg.layers[1][1].numpy().copy()
+            out[f'{tag}_l1_ts'] = cg.layers[1][2].numpy().copy()
+            out[f'{tag}_involved'] = cg.np_computation_graph_nodes.copy()
+            rd = cg.restart_data
+            out[f'{tag}_rd_index'] = rd.index.numpy().copy()
+            out[f'{tag}_rd_nids'] = rd.nids.numpy().copy()
+            out[f'{tag}_rd_ts'] = rd.ts.numpy().copy()
+            if cfg['restarter'] == 'seq':
+                out[f'{tag}_rd_hist_nids'] = rd.hist_nids.numpy().copy()
+                out[f'{tag}_rd_anon'] = rd.anonymized_ids.numpy().copy()
+                out[f'{tag}_rd_hist_eids'] = rd.hist_eids.numpy().copy()
+                out[f'{tag}_rd_hist_ts'] = rd.hist_ts.numpy().copy()
+                out[f'{tag}_rd_hist_dirs'] = rd.hist_dirs.numpy().copy()
+            else:
+                out[f'{tag}_rd_prev_ts'] = rd.prev_ts.numpy().copy()
+            for nm, h in zip(('src_hits', 'dst_hits', 'neg_src_hits', 'neg_dst_hits'), cg.hit_data):
+                out[f'{tag}_{nm}'] = h.numpy().copy()
+            # ---- lazy restart exactly as train_self_supervised.py:152-163
+            if b == restart_at:
+                restarting = True
+                uptodate = set()
+                model.msg_store.clear()
+            if restarting:
+                involved = cg.np_computation_graph_nodes
+                r_nodes = np.array(sorted(set(involved.tolist()) - uptodate), dtype=np.int64)
+                r_nids = torch.from_numpy(r_nodes).long()
+                r_ts = torch.full((len(r_nids),), t.min().item())
+                out[f'{tag}_restart_nids'] = r_nodes
+                out[f'{tag}_restart_ts'] = r_ts.numpy().copy()
+                if len(r_nids):
+                    hl, hr, pt = model.restarter_fn(r_nids, r_ts)
+                    out[f'{tag}_restart_h_left'] = hl.numpy().copy()
+                    out[f'{tag}_restart_h_right'] = hr.numpy().copy()
+                    out[f'{tag}_restart_prev_ts'] = pt.numpy().copy()
+                model.restart(r_nids, r_ts)
+                uptodate.update(r_nodes.tolist())
+                snapshot(model, out, f'{tag}_afterrestart')
+            # ---- the batch itself (tiger.py:174-290)
+            loss, h_left, pos, negs, hpl, hpr = model.contrast_learning(s, dd, ng, t, ee, cg)
+            out[f'{tag}_loss'] = np.float32(loss.item())
+            out[f'{tag}_h_left'] = h_left.numpy().copy()
+            out[f'{tag}_pos_scores'] = pos.numpy().copy()
+            out[f'{tag}_neg_scores'] = negs.numpy().copy()
+            out[f'{tag}_h_prev_left'] = hpl.numpy().copy()
+            out[f'{tag}_h_prev_right'] = hpr.numpy().copy()
+            # ---- mutual-learning surrogate (tiger.py:576-590)
+            index = cg.restart_data.index
+            u_nids = torch.cat([s, dd])[index]
+            u_ts = t.repeat(2)[index]
+            sl, sr, spt = model.restarter_fn(u_nids, u_ts, cg)
+            out[f'{tag}_sur_left'] = sl.numpy().copy()
+            out[f'{tag}_sur_right'] = sr.numpy().copy()
+            out[f'{tag}_sur_prev_ts'] = spt.numpy().copy()
+            targets = torch.cat([hpl[index], hpr[index]], 0)
+            preds = torch.cat([sl, sr], 0)
+            valid = torch.where(~(targets == 0).all(1))[0]
+            ml = model.mutual_loss_fn(preds[valid], targets[valid]).item() if len(valid) else 0.0
+            out[f'{tag}_mutual_loss'] = np.float32(ml)
+            if b < cfg.get('state_batches', n_batches):
+                snapshot(model, out, tag)
+        # flush_msg (tiger.py:444-455): consume everything that is pending
+        model.flush_msg()
+        snapshot(model, out, 'flushed')
+    np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
+    print(f'{name}.npz', sum(v.nbytes for v in out.values()) // 1024, 'KiB raw')
+
+
+SCENARIOS = {
+    # C1-like plumbing case: seq restarter, msg=left upd=right (CLI defaults)
+    'seq_lr_d8': dict(d=8, n_u=40, n_i=15, E=600, T=300.0, B=40, n_batches=12, K=5, H=8, seed=1, wseed=1,
+                      restarter='seq', msg_src='left', upd_src='right', restart_at=7),
+    # C2-like: msg=left upd=left; static restarter as in C3; wider edge features than memory
+    'static_ll_d16': dict(d=16, d_e=12, n_u=60, n_i=25, E=900, T=500.0, B=64, n_batches=10, K=10, seed=2, wseed=2,
+                          restarter='static', msg_src='left', upd_src='left', restart_at=6),
+    # msg=right upd=right (TGN-style), no feature tables at all (LastFM-style, C4)
+    'seq_rr_d8_nofeat': dict(d=8, n_u=30, n_i=30, E=500, T=1.0e6, B=50, n_batches=8, K=10, H=12, seed=3, wseed=3,
+                             integer_ts=False, nfeat=None, efeat=None,
+                             restarter='seq', msg_src='right', upd_src='right', restart_at=5),
+    # Wikipedia-shaped micro case: d=172, zero node features, large time deltas
+    'static_ll_d172': dict(d=172, n_u=30, n_i=10, E=240, T=2.6e6, B=30, n_batches=6, K=10, seed=4, wseed=4,
+                           nfeat='zero', restarter='static', msg_src='left', upd_src='left',
+                           restart_at=4, state_batches=3),
+    'seq_lr_d172': dict(d=172, n_u=24, n_i=8, E=160, T=2.6e6, B=20, n_batches=5, K=10, H=40, seed=5, wseed=5,
+                        nfeat='zero', restarter='seq', msg_src='left', upd_src='right',
+                        restart_at=3, state_batches=2),
+    # non-default message transforms / updater
+    'mlp_merge_d8': dict(d=8, n_u=30, n_i=12, E=300, T=200.0, B=30, n_batches=6, K=5, H=6, seed=6, wseed=6,
+                         restarter='seq', msg_src='left', upd_src='right', tsfm='mlp', upd_fn='merge'),
+    'linear_gru_d8': dict(d=8, n_u=30, n_i=12, E=300, T=200.0, B=30, n_batches=6, K=5, seed=7, wseed=7,
+                          restarter='static', msg_src='right', upd_src='left', tsfm='linear', hit='vec'),
+}
+
+if __name__ == '__main__':
+    only = sys.argv[1:]
+    if not only or 'sampler' in only:
+        gen_sampler()
+    for nm, cfg in SCENARIOS.items():
+        if not only or nm in only:
+            gen_model(nm, cfg)
