@@ -1,0 +1,341 @@
+/*
+ * tiger_hip.h - C ABI of libtiger_hip.so, the MI355X (gfx950) engine for the
+ * TIGER event-batch hot path (temporal neighbour sampling -> mailbox consume +
+ * GRU -> temporal-attention embedding -> memory / mailbox write-back -> restart).
+ *
+ * The reference (yzhang1918/www2023tiger @ v1.0.1) has no FFI: its boundary is
+ * the Python class API of tiger.data.graph / tiger.model.*.  Each entry point
+ * below names the reference code (file:line, relative to the reference root) whose
+ * body it replaces; www2023tiger_amd/ keeps the reference's Python signatures and
+ * binds these symbols with ctypes.
+ *
+ * Conventions
+ *  - plain C: pointers + sizes; no C++ types, no exceptions cross the boundary.
+ *  - every array argument is a raw DEVICE pointer into caller-owned memory unless
+ *    its name ends in _host; the library never allocates or frees user-visible
+ *    memory - scratch comes from the caller-provided workspace `ws` (16-byte
+ *    aligned) whose size the matching *_workspace_bytes() call returns.
+ *  - `stream` is a hipStream_t passed as void*; every call is asynchronous on it
+ *    and performs no host synchronisation (safe to capture into a hipGraph).
+ *  - return value: TG_OK or a negative TG_E* code for argument/shape errors.
+ *    Data-dependent invariants (the reference's ValueErrors) are
+ *    checked on device and OR-ed into the caller's `err` word (TG_ERR_* bits),
+ *    which the Python shim reads when it needs the reference's exception.
+ *  - ids are int64 at the boundary (the reference's dtype); timestamps are float64
+ *    on the sampler side and float32 on the model side, exactly as in the reference.
+ *  - all feature widths (d, d_e) must be multiples of 4 (16-byte rows).
+ */
+#ifndef TIGER_HIP_H
+#define TIGER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TG_ABI_VERSION 1
+
+/* status codes */
+#define TG_OK 0
+#define TG_EINVAL (-1)      /* bad argument / shape */
+#define TG_EUNSUPPORTED (-2) /* valid in the reference, not built here */
+#define TG_EWORKSPACE (-3)  /* workspace too small */
+#define TG_EHIP (-4)        /* a HIP runtime call failed (tg_last_hip_error) */
+
+/* device-side invariant bits OR-ed into *err (reference exception in brackets) */
+#define TG_ERR_PAST_MEMORY 1u      /* memory.py:45-46  'You are not allowed to modify past memory.' */
+#define TG_ERR_DUPLICATE_IDS 2u    /* memory.py:47-48  'Duplicate node ids are not allowed.' */
+#define TG_ERR_UNUSED_MESSAGE 4u   /* memory.py:85-87  'Node #n has unused messages.' */
+#define TG_ERR_MSG_BEFORE_MEM 8u   /* message_modules.py:158-159 */
+#define TG_ERR_MSG_TS_MISMATCH 16u /* tiger.py:325-327 (msg_src == left) */
+#define TG_ERR_EVENT_BEFORE_MEM 32u /* tiger.py:437-438 */
+
+int tg_abi_version(void);
+/* text of the last HIP runtime error seen by this thread ("" if none) */
+const char* tg_last_hip_error(void);
+
+/* ------------------------------------------------------------------------- */
+/* Temporal CSR (replaces Graph.__init__/from_data/data2adjlist,              */
+/* tiger/data/graph.py:11-42,226-241)                                         */
+/* ------------------------------------------------------------------------- */
+typedef struct tg_tcsr {
+  int64_t num_node;      /* max id + 1; id 0 is the padding node */
+  int64_t num_entry;     /* 2 * num_events */
+  const int64_t* indptr; /* [num_node + 1] */
+  const double* ts;      /* [num_entry]  float64 event time, ascending per node */
+  const int32_t* nbr;    /* [num_entry]  the other endpoint */
+  const int32_t* eid;    /* [num_entry]  edge id in bits 0..30, bit 31 = "owner is dst" flag */
+} tg_tcsr;
+
+/* Host-side build (initialisation only): stable per-node sort by time of the
+ * 2E (neighbour, eid, t, flag) entries.  All pointers are HOST pointers.
+ * Returns TG_EINVAL if an id is negative / >= num_node or an eid needs more than 31 bits. */
+int tg_tcsr_build_host(int64_t num_events, const int64_t* src_host, const int64_t* dst_host,
+                       const double* ts_host, const int64_t* eid_host, int64_t num_node,
+                       int64_t* indptr_host, double* ts_out_host, int32_t* nbr_out_host,
+                       int32_t* eid_out_host);
+
+/* Graph.sample_temporal_neighbor(strategy='recent_edges') and Graph.get_history
+ * (graph.py:67-127,150-155): per query the last K entries with ts < t (strict),
+ * left padded with zeros.  out_dir may be NULL.  If mark_bitmap != NULL every query
+ * id and every sampled neighbour id (padding 0 included) is also set in that
+ * n-node bitmap (fusion of GraphCollator.collate_memory_nodes' set.update,
+ * data_loader.py:109-113). */
+int tg_sample_recent_edges(const tg_tcsr* g, int64_t n_query, const int64_t* nids, const double* ts,
+                           int32_t K, int64_t* out_nbr, int64_t* out_eid, float* out_ts,
+                           int64_t* out_dir, uint64_t* mark_bitmap, void* stream);
+
+/* strategy='recent_nodes' (graph.py:129-143): last occurrence of each distinct
+ * neighbour, most recent K of those, ascending in time, left padded. */
+int tg_sample_recent_nodes(const tg_tcsr* g, int64_t n_query, const int64_t* nids, const double* ts,
+                           int32_t K, int64_t* out_nbr, int64_t* out_eid, float* out_ts,
+                           int64_t* out_dir, void* stream);
+
+/* strategy='uniform' (graph.py:101-115): K draws of numpy's legacy
+ * RandomState.randint(0, len, K) per non-empty query IN QUERY ORDER, sorted by time.
+ * `mt_state` is the 624-word MT19937 key followed by the position word (625 uint32,
+ * device memory), advanced in place so consecutive calls continue the stream. */
+int tg_sample_uniform(const tg_tcsr* g, int64_t n_query, const int64_t* nids, const double* ts,
+                      int32_t K, uint32_t* mt_state, int64_t* out_nbr, int64_t* out_eid, float* out_ts,
+                      int64_t* out_dir, void* stream);
+
+/* GraphCollator.check_in_window's comparison (data_loader.py:61-67):
+ * out[b,k] = (center[b] == nbr[b,k]) as float32. */
+int tg_hits(int64_t B, int32_t K, const int64_t* center, const int64_t* nbr, float* out, void* stream);
+
+/* anonymized_reindex (tiger/model/utils.py:19-27) on an [n, H] id matrix. */
+int tg_anonymized_reindex(int64_t n, int32_t H, const int64_t* hist_nids, int64_t* out, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Sorted-unique compaction on an n-node bitmap                               */
+/* ------------------------------------------------------------------------- */
+/* number of uint64 words of a bitmap over n_nodes ids */
+int64_t tg_bitmap_words(int64_t n_nodes);
+int tg_bitmap_mark(int64_t n, const int64_t* ids, uint64_t* bitmap, int64_t n_nodes, void* stream);
+/* Reads the bitmap back as the sorted id list (replaces np.sort(list(set)),
+ * data_loader.py:121, and the dense local_index of data_classes.py:163-165):
+ *   rank[w]    = number of set bits in words [0, w)          (uint32[words + 1])
+ *   out_ids[r] = r-th smallest set id                        (capacity `cap`)
+ *   *out_count = number of set bits
+ * local index of id i  =  rank[i>>6] + popcount(bitmap[i>>6] & ((1<<(i&63))-1)).
+ * If and_bitmap != NULL a second list is produced for (bitmap & and_bitmap):
+ * and_rank / and_ids / and_count and, per element, its position in the first list
+ * (and_pos) - this is the "outdated = involved ∩ has-message" set of
+ * MessageStoreNoGradLastOnly.get_outdated_node_ids (memory.py:108-126). */
+size_t tg_unique_compact_workspace_bytes(int64_t n_nodes);
+int tg_unique_compact(const uint64_t* bitmap, int64_t n_nodes, uint32_t* rank, int64_t* out_ids,
+                      int32_t* out_count, int64_t cap, const uint64_t* and_bitmap, uint32_t* and_rank,
+                      int64_t* and_ids, int32_t* and_pos, int32_t* and_count, void* ws, size_t ws_bytes,
+                      void* stream);
+
+/* select_latest_nids (tiger/model/utils.py:10-16): sorted unique ids of nids[0..n)
+ * and, per id, the position of its maximum timestamp, FIRST position among ties.
+ * ts_is_f64 selects const double* / const float* for `ts`.  out_* have capacity n. */
+size_t tg_select_latest_workspace_bytes(int64_t n, int64_t n_nodes);
+int tg_select_latest(int64_t n, const int64_t* nids, const void* ts, int32_t ts_is_f64, int64_t n_nodes,
+                     int64_t* out_unique, int64_t* out_index, int32_t* out_count, void* ws,
+                     size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Model description shared by the dense / memory entry points               */
+/* ------------------------------------------------------------------------- */
+typedef struct tg_linear {   /* torch.nn.Linear: y = x W^T + b, W [out, in] row-major */
+  const float* w;
+  const float* b;
+} tg_linear;
+
+enum { TG_SRC_LEFT = 0, TG_SRC_RIGHT = 1 };
+enum { TG_TSFM_ID = 0, TG_TSFM_LINEAR = 1, TG_TSFM_MLP = 2 };
+enum { TG_UPD_GRU = 0, TG_UPD_MERGE = 1 };
+
+typedef struct tg_model {
+  /* sizes */
+  int64_t n_nodes;
+  int32_t d;        /* memory = node-feature = time-encoding width (tiger.py:58-61) */
+  int32_t d_e;      /* edge-feature width (== d when there is no edge table)     */
+  int32_t n_neighbors;
+  int32_t n_head;
+  int32_t msg_src;  /* TG_SRC_*  (tiger.py:87) */
+  int32_t upd_src;  /* TG_SRC_*  (tiger.py:88) */
+  int32_t tsfm;     /* TG_TSFM_* (tiger.py:109-117) */
+  int32_t upd_fn;   /* TG_UPD_*  (tiger.py:120-125) */
+  /* state: Memory (memory.py:12-52) x2, mailbox MessageStoreNoGradLastOnly (memory.py:55-138) */
+  float* left_vals;   /* [n_nodes, d] */
+  float* left_ts;     /* [n_nodes]    */
+  uint8_t* left_active;
+  float* right_vals;
+  float* right_ts;
+  uint8_t* right_active;
+  float* msg_vals;    /* [n_nodes, 3d + d_e] */
+  float* msg_ts;      /* [n_nodes] */
+  uint64_t* has_msg;  /* bitmap over n_nodes: replaces the Python set nodes_with_messages */
+  /* raw feature tables (feature_getter.py:25-106); NULL => zeros */
+  const float* nfeats; /* [n_nodes, d]   */
+  const float* efeats; /* [n_edges+1, d_e] */
+  /* TimeEncode (time_encoding.py:13-14) */
+  const float* te_freq;
+  const float* te_phase;
+  /* message transform (message_modules.py:29-55): fn.1 and (mlp) fn.4 */
+  tg_linear tsfm1, tsfm2;
+  /* GRUCell (update_modules.py:33): weight_ih [3d, msg], weight_hh [3d, d] */
+  const float *gru_w_ih, *gru_w_hh, *gru_b_ih, *gru_b_hh;
+  /* MergeUpdater (update_modules.py:43): MergeLayer fc1 [d, msg+d], fc2 [d, d] */
+  tg_linear upd_fc1, upd_fc2;
+  /* TemporalAttention (temporal_agg_modules.py:196-235) */
+  const float *attn_wq, *attn_wk, *attn_wv; /* [2d,2d], [2d,2d+d_e], [2d,2d+d_e] */
+  const float* attn_b_in;                   /* [6d] */
+  tg_linear attn_out;                       /* [2d,2d] */
+  tg_linear attn_fc1, attn_fc2;             /* merger: [d,3d], [d,d] */
+} tg_model;
+
+/* TimeEncode.forward (time_encoding.py:24-26): out[i,:] = cos(fl32(ts[i]*w) + phi) */
+int tg_time_encode(int64_t n, const float* ts, int32_t d, const float* freq, const float* phase,
+                   float* out, void* stream);
+
+/* Memory.get (memory.py:36-39) / F.embedding: out[i,:] = table[ids[i],:], ts_out optional */
+int tg_gather_rows(int64_t n, const int64_t* ids, int32_t width, const float* table, float* out,
+                   const float* ts_table, float* ts_out, void* stream);
+
+/* Memory.set (memory.py:41-52): table[ids[i]] = vals[src_index ? src_index[i] : i],
+ * ts likewise, active = 1.  n may come from the device (n_dev != NULL, n = capacity).
+ * With check != 0 the monotonic-time test sets TG_ERR_PAST_MEMORY in *err. */
+int tg_memory_scatter(int64_t n, const int32_t* n_dev, const int64_t* ids, const int64_t* src_index,
+                      int32_t width, const float* vals, const float* ts, float* table, float* ts_table,
+                      uint8_t* active, int32_t check, uint32_t* err, void* stream);
+
+/* torch.nn.Linear forward on dense rows: out[n, out_f] = act(x[n, in_f] W^T + b)
+ * (message functions message_modules.py:29-55, MergeLayer basic_modules.py:16-19). */
+int tg_linear_fwd(int64_t n, const float* x, int32_t in_f, const tg_linear* lin, int32_t out_f, int32_t relu,
+                  float* out, void* stream);
+
+/* torch.nn.GRUCell forward on dense rows (GRUUpdater.forward, update_modules.py:33-37):
+ * x [n, xw] messages, h [n, d] old memory, out [n, d]. */
+int tg_gru_fwd(int64_t n, const float* x, int32_t xw, const float* h, int32_t d, const float* w_ih,
+               const float* w_hh, const float* b_ih, const float* b_hh, float* out, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* STEP 1-2: consume pending messages (tiger.py:208-221,292-356)              */
+/* ------------------------------------------------------------------------- */
+/* reprs[u,:] = right_vals[involved[u],:] for u < *n_involved
+ * (tiger.py:214, LastMessageAggregatorNoGradLastOnly gather message_modules.py:155-156) */
+int tg_mailbox_consume_gather(const tg_model* m, const int64_t* involved, const int32_t* n_involved,
+                              int64_t cap, float* reprs, void* stream);
+
+/* h(t'+) for the outdated nodes: msgs = tsfm(mailbox[ids]); h = updater(upd_mem[ids], msgs);
+ * reprs[out_pos[o],:] = h.  Also checks the mailbox/memory time invariants.
+ * (tiger.py:319-336,352-355; update_modules.py:30-47; message_modules.py:20-55) */
+size_t tg_apply_messages_workspace_bytes(const tg_model* m, int64_t cap);
+int tg_apply_messages(const tg_model* m, const int64_t* outdated, const int32_t* out_pos,
+                      const int32_t* n_outdated, int64_t cap, float* reprs, uint32_t* err, void* ws,
+                      size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* STEP 3: temporal-attention embedding, one layer                            */
+/* (temporal_agg_modules.py:29-83,186-235; basic_modules.py:16-19)            */
+/* ------------------------------------------------------------------------- */
+/* reprs [U,d] are the involved nodes' h(t'+); (bitmap, rank) give the local index.
+ * centre ids nids[Q], query times ts[Q] (float32), neighbours l1_* [Q,K].
+ * out [Q,d]. */
+size_t tg_temporal_attn_workspace_bytes(const tg_model* m, int64_t Q);
+int tg_temporal_attn_fwd(const tg_model* m, int64_t Q, const int64_t* nids, const float* ts,
+                         const int64_t* l1_nids, const int64_t* l1_eids, const float* l1_ts,
+                         const float* reprs, const uint64_t* bitmap, const uint32_t* rank, float* out,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* STEP 4-6: write-back (tiger.py:229-255,396-442; memory.py:77-106)          */
+/* ------------------------------------------------------------------------- */
+/* STEP 4: for every unique positive node that is outdated: right memory <- its
+ * h(t'+) row of reprs, update_ts <- mailbox ts, has-message bit cleared. */
+int tg_consume_update_right(const tg_model* m, const int64_t* upos, const int32_t* n_upos, int64_t cap,
+                            const float* reprs, const uint64_t* bitmap, const uint32_t* rank,
+                            uint32_t* err, void* stream);
+/* STEP 5: build the two raw messages of the winning event of each unique positive
+ * node and write mailbox row, mailbox ts and has-message bit.  `index` is the
+ * select_latest position into cat[src,dst]. */
+int tg_store_events(const tg_model* m, int64_t B, const int64_t* src, const int64_t* dst, const float* ts,
+                    const int64_t* eids, const int64_t* upos, const int64_t* index, const int32_t* n_upos,
+                    uint32_t* err, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Restarters (restarters.py:36-114,254-277) and TIGER.restart (tiger.py:594-609) */
+/* ------------------------------------------------------------------------- */
+typedef struct tg_seq_restarter {
+  int32_t hist_len;
+  int32_t n_head;
+  const float* te_freq;  /* the restarter's own TimeEncode (restarters.py:27) */
+  const float* te_phase;
+  const float* anony_emb; /* [hist_len+1, d] */
+  const float* in_proj_w; /* [3*dm, dm], dm = 3d + d_e + d */
+  const float* in_proj_b;
+  tg_linear out_proj;     /* [dm, dm] */
+  tg_linear out_fn;       /* [d, dm]  */
+  tg_linear fc1, fc2;     /* merger: [d, d + dm - d], [d, d] */
+} tg_seq_restarter;
+
+size_t tg_restart_seq_workspace_bytes(const tg_model* m, const tg_seq_restarter* r, int64_t n);
+/* SeqRestarter.forward given the collated history (hist_* [n,H], anonymized ids):
+ * h_left, h_right [n,d], prev_ts [n]. */
+int tg_restart_seq_fwd(const tg_model* m, const tg_seq_restarter* r, int64_t n, const int64_t* nids,
+                       const int64_t* hist_nids, const int64_t* anon_ids, const int64_t* hist_eids,
+                       const float* hist_ts, const int64_t* hist_dirs, float* h_left, float* h_right,
+                       float* prev_ts, void* ws, size_t ws_bytes, void* stream);
+
+/* TIGER.restart's state update (tiger.py:603,608-609): clear has-message bits of
+ * nids, then left/right memory rows and timestamps <- (h_left, h_right, prev_ts)
+ * with skip_check semantics. */
+int tg_restart_apply(const tg_model* m, int64_t n, const int64_t* nids, const float* h_left,
+                     const float* h_right, const float* prev_ts, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Fused streaming step: collate + STEP 1-6 of TIGE.contrast_learning         */
+/* (data_loader.py:77-131 + tiger.py:196-255) with no host round trip.         */
+/* ------------------------------------------------------------------------- */
+typedef struct tg_step_io {
+  int64_t B;
+  const int64_t* src;   /* [B] */
+  const int64_t* dst;   /* [B] */
+  const int64_t* neg;   /* [B] */
+  const double* ts;     /* [B] float64 event times (sampler side) */
+  const int64_t* eids;  /* [B] */
+  /* outputs (all optional except h) */
+  float* h;             /* [3B, d] temporal embeddings of cat[src,dst,neg]; rows [0,2B) = h_left */
+  int64_t* l1_nids;     /* [3B, K] */
+  int64_t* l1_eids;     /* [3B, K] */
+  float* l1_ts;         /* [3B, K] */
+  int64_t* involved;    /* [3B*(K+1)] capacity */
+  int32_t* counts;      /* [4]: n_involved, n_outdated, n_unique_pos, reserved */
+  float* h_prev_left;   /* [2B, d] restarter targets (tiger.py:248-251) or NULL */
+  float* h_prev_right;  /* [2B, d] or NULL */
+  uint32_t* err;        /* invariant word */
+  /* Resident-stream mode: when offset_dev != NULL, src/dst/neg/ts/eids point at the
+   * whole time-ordered stream in HBM and the batch is elements [*offset_dev, *offset_dev+B);
+   * with advance != 0 the step ends by adding B to *offset_dev, so a captured hipGraph of
+   * one step replays the whole stream with no host work (train_self_supervised.py:143). */
+  int64_t* offset_dev;
+  int32_t advance;
+  int32_t reserved;
+  void* profiler;       /* tg_profiler* or NULL: records an event after every stage */
+} tg_step_io;
+
+/* Per-stage timer of tg_stream_step (HIP events on the step's stream).  Stage names:
+ * tg_profiler_stage_name(i), i < tg_profiler_num_stages().  tg_profiler_read waits for
+ * the last event and returns the elapsed milliseconds of every stage of the last step
+ * that ran with this profiler attached.  Not capturable into a hipGraph. */
+typedef struct tg_profiler tg_profiler;
+tg_profiler* tg_profiler_create(void);
+void tg_profiler_destroy(tg_profiler* p);
+int tg_profiler_num_stages(void);
+const char* tg_profiler_stage_name(int stage);
+int tg_profiler_read(tg_profiler* p, float* ms_out);
+
+size_t tg_stream_step_workspace_bytes(const tg_model* m, int64_t B);
+int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, void* ws, size_t ws_bytes,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TIGER_HIP_H */

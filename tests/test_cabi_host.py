@@ -1,0 +1,78 @@
+"""CPU-only checks of the boundary: the library loads, exports every symbol the header
+declares, and the host-side T-CSR build matches the oracle's graph."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, 'include', 'tiger_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(tg_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from www2023tiger_amd import _lib
+    names = header_functions()
+    assert len(names) >= 25
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f'{n} declared in tiger_hip.h but not exported'
+        assert n in _lib.SIGNATURES, f'{n} has no ctypes signature'
+    assert set(_lib.SIGNATURES) == set(names)
+    assert _lib.lib.tg_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    """ctypes mirrors must have the C struct sizes (all-8-byte fields after the int32 block)."""
+    from www2023tiger_amd import _lib
+    assert ctypes.sizeof(_lib.TgTcsr) == 6 * 8
+    assert ctypes.sizeof(_lib.TgLinear) == 16
+    assert ctypes.sizeof(_lib.TgModel) == 8 + 8 * 4 + 8 * 13 + 2 * 16 + 4 * 8 + 2 * 16 + 4 * 8 + 3 * 16
+    assert ctypes.sizeof(_lib.TgStepIo) == 18 * 8
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from www2023tiger_amd import _lib
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_lib.TigerHipError, match='no CPU fallback'):
+        _lib._load()
+
+
+def test_tcsr_host_build_matches_oracle():
+    from oracle import tiger_oracle as O
+    from www2023tiger_amd.data.graph import Graph
+    rs = np.random.RandomState(0)
+    E, n = 5000, 97
+    src = rs.randint(1, 60, E)
+    dst = rs.randint(60, n, E)
+    ts = np.floor(rs.uniform(0, 300, E))  # NOT sorted: exercises the per-node stable sort
+    eids = np.arange(1, E + 1)
+    g = Graph.from_arrays(src, dst, ts, eids, strategy='recent_edges')
+    o = O.OracleGraph(src, dst, ts, eids)
+    assert g.num_node == o.num_node
+    np.testing.assert_array_equal(g._h_indptr, o.indptr)
+    np.testing.assert_array_equal(g._h_ts, o.ts)
+    np.testing.assert_array_equal(g._h_nbr, o.nbr)
+    np.testing.assert_array_equal(g._h_eid.view(np.uint32) & 0x7FFFFFFF, o.eid)
+    np.testing.assert_array_equal(g._h_eid.view(np.uint32) >> 31, o.dir)
+    # the adjacency-list constructor (reference signature) builds the same arrays
+    adj = [[] for _ in range(g.num_node)]
+    for s, d, t, e in zip(src, dst, ts, eids):
+        adj[s].append((d, e, t, 0))
+        adj[d].append((s, e, t, 1))
+    g2 = Graph(adj, strategy='recent_edges')
+    for a in ('_h_indptr', '_h_ts', '_h_nbr', '_h_eid'):
+        np.testing.assert_array_equal(getattr(g, a), getattr(g2, a))
+
+
+def test_tcsr_build_rejects_bad_ids():
+    from www2023tiger_amd import _lib
+    from www2023tiger_amd.data.graph import Graph
+    with pytest.raises(_lib.TigerHipError):
+        Graph.from_arrays(np.array([1, 2]), np.array([3, 4]), np.array([0.0, 1.0]), np.array([1, 2 ** 31]))

@@ -1,0 +1,327 @@
+"""Parity of the HIP path (through the C ABI) with the golden vectors of the reference
+and with the CPU oracle.  Needs a real MI355X: every test is marked gpu.
+
+Bars: integer / index outputs bit-exact; float32 embeddings and memory state within
+1e-4 relative (max |a-b| / max(1, max|ref|)) - the tolerance BASELINE.json's north_star
+states ("within 1e-4 relative fp32 and bit-exact neighbor indices")."""
+import numpy as np
+import pytest
+import torch
+
+from _util import MODEL_FIXTURES, fixture_params, fixture_tables, load, n_batches, parse_cfg, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def dev():
+    return torch.device('cuda', 0)
+
+
+def build_hip_model(z, cfg, strategy='recent_edges'):
+    from www2023tiger_amd.data.data_loader import GraphCollator
+    from www2023tiger_amd.data.graph import Graph
+    from www2023tiger_amd.model.feature_getter import NumericalFeature
+    from www2023tiger_amd.model.restarters import SeqRestarter, StaticRestarter
+    from www2023tiger_amd.model.tiger import TIGER
+    n_nodes, nfeats, efeats = fixture_tables(z, cfg)
+    g = Graph.from_arrays(z['src'], z['dst'], z['ts'], z['eids'], strategy=strategy, seed=0, device=dev())
+    assert g.num_node == n_nodes
+    fg = NumericalFeature(None if nfeats is None else torch.from_numpy(nfeats),
+                          None if efeats is None else torch.from_numpy(efeats), dim=cfg['d'], device=dev())
+    fg.n_nodes, fg.n_edges = n_nodes, len(z['src'])
+    if cfg['restarter'] == 'seq':
+        rst = SeqRestarter(raw_feat_getter=fg, graph=g, hist_len=cfg['H'], n_head=2, dropout=0.1)
+    else:
+        rst = StaticRestarter(raw_feat_getter=fg, graph=g)
+    model = TIGER(raw_feat_getter=fg, graph=g, restarter=rst, n_neighbors=cfg['K'], hit_type=cfg.get('hit', 'bin'),
+                  n_layers=1, n_head=2, dropout=0.1, msg_src=cfg['msg_src'], upd_src=cfg['upd_src'],
+                  msg_tsfm_type=cfg.get('tsfm', 'id'), mem_update_type=cfg.get('upd_fn', 'gru'))
+    params = fixture_params(z, cfg)
+    own = dict(model.named_parameters())
+    assert set(own) == set(params), set(own) ^ set(params)
+    with torch.no_grad():
+        for k, v in params.items():
+            own[k].copy_(torch.from_numpy(v))
+    model = model.to(dev()).eval()
+    coll = GraphCollator(g, cfg['K'], 1, restarter=cfg['restarter'], hist_len=cfg.get('H'))
+    return model, g, coll
+
+
+# ------------------------------------------------------------------------------ sampler
+@pytest.fixture(scope='module')
+def samp():
+    return load('sampler')
+
+
+def _graph(z, strategy):
+    from www2023tiger_amd.data.graph import Graph
+    return Graph.from_arrays(z['src'], z['dst'], z['ts'], z['eids'], strategy=strategy, seed=3, device=dev())
+
+
+@pytest.mark.parametrize('strategy', ['recent_edges', 'recent_nodes'])
+@pytest.mark.parametrize('K', [1, 5, 10, 40])
+def test_sampler_bit_exact(samp, strategy, K):
+    g = _graph(samp, strategy)
+    assert g.num_node == int(samp['num_node'])
+    res = g.sample_temporal_neighbor(samp['q_nids'], samp['q_ts'], K)
+    for nm, a in zip(('nbr', 'eid', 'ts', 'dir'), res):
+        exp = samp[f'{strategy}_K{K}_{nm}']
+        assert a.dtype == exp.dtype and a.shape == exp.shape
+        np.testing.assert_array_equal(a, exp, err_msg=nm)
+
+
+def test_graph_from_adj_list_matches_from_arrays(samp):
+    from www2023tiger_amd.data.graph import Graph
+    n = int(samp['num_node'])
+    adj = [[] for _ in range(n)]
+    for s, d, t, e in zip(samp['src'], samp['dst'], samp['ts'], samp['eids']):
+        adj[s].append((d, e, t, 0))
+        adj[d].append((s, e, t, 1))
+    g = Graph(adj, strategy='recent_edges', seed=3, device=dev())
+    res = g.sample_temporal_neighbor(samp['q_nids'], samp['q_ts'], 10)
+    for nm, a in zip(('nbr', 'eid', 'ts', 'dir'), res):
+        np.testing.assert_array_equal(a, samp[f'recent_edges_K10_{nm}'], err_msg=nm)
+
+
+@pytest.mark.parametrize('K', [5, 10])
+def test_sampler_uniform_mt19937_stream(samp, K):
+    """Draws must follow numpy's legacy RandomState.randint stream (two consecutive calls).
+    Entries with equal timestamps may be ordered differently from numpy's argsort (its tie
+    order is implementation defined), so rows are compared as time-sorted multisets."""
+    g = _graph(samp, 'uniform')
+    for rep in range(2):
+        res = g.sample_temporal_neighbor(samp['q_nids'], samp['q_ts'], K)
+        exp = [samp[f'uniform_K{K}_rep{rep}_{nm}'] for nm in ('nbr', 'eid', 'ts', 'dir')]
+        np.testing.assert_array_equal(res[2], exp[2])  # timestamps: sorted, identical
+        for r in range(len(res[0])):
+            got = sorted(zip(res[2][r].tolist(), res[1][r].tolist(), res[0][r].tolist(), res[3][r].tolist()))
+            want = sorted(zip(exp[2][r].tolist(), exp[1][r].tolist(), exp[0][r].tolist(), exp[3][r].tolist()))
+            assert got == want, (rep, r)
+
+
+def test_history_float32_queries(samp):
+    g = _graph(samp, 'recent_edges')
+    res = g.get_history(samp['q_nids'], samp['q_ts'].astype(np.float32), 8)
+    for nm, a in zip(('nbr', 'eid', 'ts', 'dir'), res):
+        np.testing.assert_array_equal(a, samp[f'hist32_H8_{nm}'])
+
+
+@pytest.mark.parametrize('i', [0, 1, 2])
+def test_select_latest(samp, i):
+    from www2023tiger_amd import hip_ops
+    u, idx = hip_ops.select_latest_nids(torch.from_numpy(samp[f'sel{i}_ids']).to(dev()),
+                                        torch.from_numpy(samp[f'sel{i}_ts']).to(dev()))
+    np.testing.assert_array_equal(u.cpu().numpy(), samp[f'sel{i}_unique'])
+    np.testing.assert_array_equal(idx.cpu().numpy(), samp[f'sel{i}_index'])
+
+
+def test_select_latest_large_bitmap_multiblock():
+    """n_nodes large enough for the three-phase scan (more than one 2048-word tile)."""
+    from oracle import tiger_oracle as O
+    from www2023tiger_amd import hip_ops
+    rs = np.random.RandomState(0)
+    n_nodes = 700_000
+    ids = rs.randint(0, n_nodes, 50_000).astype(np.int64)
+    ids[:5000] = rs.randint(0, 300, 5000)
+    ts = np.floor(rs.uniform(0, 50, len(ids)))
+    u, idx = hip_ops.select_latest_nids(torch.from_numpy(ids).to(dev()), torch.from_numpy(ts).to(dev()), n_nodes)
+    eu, ei = O.select_latest_nids(ids, ts)
+    np.testing.assert_array_equal(u.cpu().numpy(), eu)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ei)
+
+
+def test_anonymized_reindex(samp):
+    from www2023tiger_amd import hip_ops
+    for k in ('anon', 'anon2'):
+        out = hip_ops.anonymized_reindex(torch.from_numpy(samp[f'{k}_in']).to(dev()))
+        np.testing.assert_array_equal(out.cpu().numpy(), samp[f'{k}_out'])
+
+
+def test_empty_inputs():
+    from www2023tiger_amd import hip_ops
+    z = load('sampler')
+    g = _graph(z, 'recent_edges')
+    res = g.sample_temporal_neighbor(np.zeros(0, dtype=np.int64), np.zeros(0), 5)
+    assert all(r.shape == (0, 5) for r in res)
+    u, idx = hip_ops.select_latest_nids(torch.zeros(0, dtype=torch.int64, device=dev()),
+                                        torch.zeros(0, device=dev()))
+    assert len(u) == 0 and len(idx) == 0
+
+
+# ------------------------------------------------------------------------------ dense kernels
+@pytest.mark.parametrize('n,in_f,out_f', [(1, 8, 4), (37, 172, 344), (300, 516, 172), (129, 860, 516), (64, 64, 64)])
+def test_linear_fwd_vs_torch(n, in_f, out_f):
+    from www2023tiger_amd.model.dense import linear_forward
+    torch.manual_seed(n)
+    layer = torch.nn.Linear(in_f, out_f)
+    x = torch.randn(n, in_f)
+    ref = torch.relu(layer(x)).detach().numpy()
+    out = linear_forward(layer.to(dev()), x.to(dev()), relu=True).cpu().numpy()
+    assert rel_err(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize('n,d,xw', [(1, 8, 32), (200, 172, 688), (131, 100, 400), (513, 16, 60)])
+def test_gru_fwd_vs_torch(n, d, xw):
+    from www2023tiger_amd.model.dense import gru_forward
+    torch.manual_seed(d)
+    cell = torch.nn.GRUCell(xw, d)
+    x, h = torch.randn(n, xw), torch.randn(n, d)
+    ref = cell(x, h).detach().numpy()
+    out = gru_forward(cell.to(dev()), x.to(dev()), h.to(dev())).cpu().numpy()
+    assert rel_err(out, ref) < 1e-5
+
+
+def test_time_encode_rounding():
+    """cos(fl32(dt*w)+phi) at large dt: an FMA-contracted product is off by up to 4e-2."""
+    from www2023tiger_amd import hip_ops
+    d = 172
+    w = torch.from_numpy((1 / 10 ** np.linspace(0, 9, d)).astype(np.float32))
+    phi = torch.linspace(-0.5, 0.5, d)
+    ts = torch.tensor([0.0, 1.0, 12345.678, 2.3e6, 2.68e6, 1.37e8])
+    ref = torch.cos(ts.unsqueeze(-1) * w + phi).numpy()
+    out = hip_ops.time_encode(ts.to(dev()), w.to(dev()), phi.to(dev())).cpu().numpy()
+    assert np.abs(out - ref).max() < 5e-7
+
+
+# ------------------------------------------------------------------------------ collation
+@pytest.mark.parametrize('name', MODEL_FIXTURES)
+def test_collator_bit_exact(name):
+    z = load(name)
+    cfg = parse_cfg(z)
+    _, g, coll = build_hip_model(z, cfg)
+    B = cfg['B']
+    for b in range(n_batches(z)):
+        sl = slice(b * B, min((b + 1) * B, len(z['src'])))
+        out = coll.collate_arrays(*(z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')))
+        cg = out[-1]
+        tag = f'b{b}'
+        np.testing.assert_array_equal(cg.layers[1][0].cpu().numpy(), z[f'{tag}_l1_nids'])
+        np.testing.assert_array_equal(cg.layers[1][1].cpu().numpy(), z[f'{tag}_l1_eids'])
+        np.testing.assert_array_equal(cg.layers[1][2].cpu().numpy(), z[f'{tag}_l1_ts'])
+        np.testing.assert_array_equal(cg.np_computation_graph_nodes, z[f'{tag}_involved'])
+        li = cg.local_index.cpu().numpy()
+        np.testing.assert_array_equal(li[z[f'{tag}_involved']], np.arange(len(z[f'{tag}_involved'])))
+        rd = cg.restart_data
+        np.testing.assert_array_equal(rd.index.cpu().numpy(), z[f'{tag}_rd_index'])
+        np.testing.assert_array_equal(rd.nids.cpu().numpy(), z[f'{tag}_rd_nids'])
+        np.testing.assert_array_equal(rd.ts.cpu().numpy(), z[f'{tag}_rd_ts'])
+        if cfg['restarter'] == 'seq':
+            for f, k in (('hist_nids', 'rd_hist_nids'), ('anonymized_ids', 'rd_anon'), ('hist_eids', 'rd_hist_eids'),
+                         ('hist_ts', 'rd_hist_ts'), ('hist_dirs', 'rd_hist_dirs')):
+                np.testing.assert_array_equal(getattr(rd, f).cpu().numpy(), z[f'{tag}_{k}'], err_msg=k)
+        else:
+            np.testing.assert_array_equal(rd.prev_ts.cpu().numpy(), z[f'{tag}_rd_prev_ts'])
+        for f in ('src_hits', 'dst_hits', 'neg_src_hits', 'neg_dst_hits'):
+            np.testing.assert_array_equal(getattr(cg.hit_data, f).cpu().numpy(), z[f'{tag}_{f}'], err_msg=f)
+
+
+# ------------------------------------------------------------------------------ full stream
+def check_state(model, z, tag):
+    L, R, S = model.left_memory, model.right_memory, model.msg_store
+    assert rel_err(L.vals.cpu().numpy(), z[f'{tag}_left_vals']) < TOL, tag
+    assert rel_err(R.vals.cpu().numpy(), z[f'{tag}_right_vals']) < TOL, tag
+    np.testing.assert_array_equal(L.update_ts.cpu().numpy(), z[f'{tag}_left_ts'])
+    np.testing.assert_array_equal(R.update_ts.cpu().numpy(), z[f'{tag}_right_ts'])
+    has = np.array(sorted(S.nodes_with_messages), dtype=np.int64)
+    np.testing.assert_array_equal(has, z[f'{tag}_has_msg'])
+    assert rel_err(S.node_msg_vals.cpu().numpy()[has], z[f'{tag}_msg_vals']) < TOL, tag
+    np.testing.assert_array_equal(S.node_msg_ts.cpu().numpy()[has], z[f'{tag}_msg_ts'])
+
+
+def run_stream(name, fused):
+    z = load(name)
+    cfg = parse_cfg(z)
+    model, g, coll = build_hip_model(z, cfg)
+    B = cfg['B']
+    restarting, uptodate = False, set()
+    for b in range(n_batches(z)):
+        sl = slice(b * B, min((b + 1) * B, len(z['src'])))
+        src, dst, neg, ts, eids = (z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids'))
+        tag = f'b{b}'
+        s_t, d_t, n_t, t_t, e_t, _, cg = coll.collate_arrays(src, dst, neg, ts, eids)
+        if b == cfg.get('restart_at', -1):  # lazy restart, train_self_supervised.py:152-163
+            restarting, uptodate = True, set()
+            model.msg_store.clear()
+        if restarting:
+            r = np.array(sorted(set(cg.np_computation_graph_nodes.tolist()) - uptodate), dtype=np.int64)
+            np.testing.assert_array_equal(r, z[f'{tag}_restart_nids'])
+            r_nids = torch.from_numpy(r).to(dev())
+            r_ts = torch.full((len(r),), float(np.float32(ts.min())), device=dev())
+            if len(r):
+                hl, hr, pt = model.restarter_fn(r_nids, r_ts)
+                assert rel_err(hl.cpu().numpy(), z[f'{tag}_restart_h_left']) < TOL
+                assert rel_err(hr.cpu().numpy(), z[f'{tag}_restart_h_right']) < TOL
+                np.testing.assert_array_equal(pt.cpu().numpy(), z[f'{tag}_restart_prev_ts'])
+            model.restart(r_nids, r_ts)
+            uptodate.update(r.tolist())
+            check_state(model, z, f'{tag}_afterrestart')
+        if fused:
+            buf = model.stream_step(src, dst, neg, ts, eids, want_prev=True)
+            nb = len(src)
+            counts = buf.counts.cpu().numpy()
+            np.testing.assert_array_equal(buf.l1_nids.cpu().numpy(), z[f'{tag}_l1_nids'])
+            np.testing.assert_array_equal(buf.l1_eids.cpu().numpy(), z[f'{tag}_l1_eids'])
+            np.testing.assert_array_equal(buf.l1_ts.cpu().numpy(), z[f'{tag}_l1_ts'])
+            np.testing.assert_array_equal(buf.involved.cpu().numpy()[:counts[0]], z[f'{tag}_involved'])
+            assert counts[2] == len(z[f'{tag}_rd_nids'])
+            assert rel_err(buf.h[:2 * nb].cpu().numpy(), z[f'{tag}_h_left']) < TOL, (b, 'h_left')
+            assert rel_err(buf.h_prev_left.cpu().numpy(), z[f'{tag}_h_prev_left']) < TOL
+            assert rel_err(buf.h_prev_right.cpu().numpy(), z[f'{tag}_h_prev_right']) < TOL
+        else:
+            loss, h_left, ps, ns, hpl, hpr = model.contrast_learning(s_t, d_t, n_t, t_t, e_t, cg)
+            for k, v in (('h_left', h_left), ('pos_scores', ps), ('neg_scores', ns), ('h_prev_left', hpl),
+                         ('h_prev_right', hpr)):
+                assert rel_err(v.cpu().numpy(), z[f'{tag}_{k}']) < TOL, (b, k)
+            assert abs(float(loss) - float(z[f'{tag}_loss'])) < 1e-4
+            # mutual-learning surrogate on the collated restart data (tiger.py:576-590)
+            idx = cg.restart_data.index
+            u_n = torch.cat([s_t, d_t]).to(dev())[idx]
+            u_t = t_t.to(dev()).repeat(2)[idx]
+            sl_, sr_, spt = model.restarter_fn(u_n, u_t, cg)
+            assert rel_err(sl_.cpu().numpy(), z[f'{tag}_sur_left']) < TOL
+            assert rel_err(sr_.cpu().numpy(), z[f'{tag}_sur_right']) < TOL
+            np.testing.assert_array_equal(spt.cpu().numpy().reshape(z[f'{tag}_sur_prev_ts'].shape),
+                                          z[f'{tag}_sur_prev_ts'])
+        if f'{tag}_left_vals' in z.files:
+            check_state(model, z, tag)
+    model.flush_msg()
+    check_state(model, z, 'flushed')
+
+
+@pytest.mark.parametrize('name', MODEL_FIXTURES)
+def test_stream_reference_api(name):
+    """GraphCollator -> TIGER.contrast_learning / restart / flush_msg, the reference's call sequence."""
+    run_stream(name, fused=False)
+
+
+@pytest.mark.parametrize('name', MODEL_FIXTURES)
+def test_stream_fused_step(name):
+    """tg_stream_step (collate + STEP 1-6 behind one C call), the benchmarked path."""
+    run_stream(name, fused=True)
+
+
+def test_invariant_errors_surface_as_value_errors():
+    """memory.py:45-46: writing a memory row back in time must raise, as in the reference."""
+    from www2023tiger_amd.model.memory import Memory
+    m = Memory(10, 8).to(dev())
+    ids = torch.tensor([1, 2], device=dev())
+    m.set(ids, torch.ones(2, 8, device=dev()), torch.tensor([5.0, 5.0], device=dev()))
+    with pytest.raises(ValueError, match='past memory'):
+        m.set(ids, torch.ones(2, 8, device=dev()), torch.tensor([4.0, 6.0], device=dev()))
+    with pytest.raises(ValueError, match='Duplicate'):
+        m.set(torch.tensor([3, 3], device=dev()), torch.ones(2, 8, device=dev()), torch.tensor([9.0, 9.0], device=dev()))
+
+
+def test_state_dict_keys_match_reference():
+    z = load('seq_lr_d8')
+    cfg = parse_cfg(z)
+    model, _, _ = build_hip_model(z, cfg)
+    keys = set(model.state_dict().keys())
+    for k in ('left_memory.vals', 'left_memory.update_ts', 'left_memory.active_mask', 'right_memory.vals',
+              'msg_memory.vals', 'upd_memory.update_ts', 'time_encoder.basis_freq',
+              'msg_aggregate_fn.time_encoder.phase', 'temporal_embedding_fn.time_encoder.basis_freq',
+              'right_mem_updater.cell.weight_ih', 'temporal_embedding_fn.fns.0.mha_fn.q_proj_weight',
+              'restarter_fn.mha_fn.in_proj_weight', 'restarter_fn.anony_emb.weight'):
+        assert k in keys, k
+    assert not any('node_msg' in k or 'nfeats' in k or 'has_msg' in k for k in keys)  # non-persistent buffers

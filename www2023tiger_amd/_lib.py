@@ -1,0 +1,158 @@
+"""ctypes binding of libtiger_hip.so (include/tiger_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a symbol is absent
+the import of this module raises, and every op of the package fails with it.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libtiger_hip.so')
+
+TG_OK, TG_EINVAL, TG_EUNSUPPORTED, TG_EWORKSPACE, TG_EHIP = 0, -1, -2, -3, -4
+ERR_PAST_MEMORY, ERR_DUPLICATE_IDS, ERR_UNUSED_MESSAGE = 1, 2, 4
+ERR_MSG_BEFORE_MEM, ERR_MSG_TS_MISMATCH, ERR_EVENT_BEFORE_MEM = 8, 16, 32
+
+# the reference's exception text for each device-side invariant bit
+ERR_TEXT = {
+    ERR_PAST_MEMORY: 'You are not allowed to modify past memory.',
+    ERR_DUPLICATE_IDS: 'Duplicate node ids are not allowed.',
+    ERR_UNUSED_MESSAGE: 'Node has unused messages.',
+    ERR_MSG_BEFORE_MEM: 'Messages happened later than memory updating.',
+    ERR_MSG_TS_MISMATCH: "Messages' ts should be equal to last update ts when using left memory as msg source.",
+    ERR_EVENT_BEFORE_MEM: 'Events occur before the udpated memory.',
+}
+
+vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
+
+
+class TgTcsr(C.Structure):
+    _fields_ = [('num_node', i64), ('num_entry', i64), ('indptr', vp), ('ts', vp), ('nbr', vp), ('eid', vp)]
+
+
+class TgLinear(C.Structure):
+    _fields_ = [('w', vp), ('b', vp)]
+
+
+class TgModel(C.Structure):
+    _fields_ = [
+        ('n_nodes', i64), ('d', i32), ('d_e', i32), ('n_neighbors', i32), ('n_head', i32),
+        ('msg_src', i32), ('upd_src', i32), ('tsfm', i32), ('upd_fn', i32),
+        ('left_vals', vp), ('left_ts', vp), ('left_active', vp),
+        ('right_vals', vp), ('right_ts', vp), ('right_active', vp),
+        ('msg_vals', vp), ('msg_ts', vp), ('has_msg', vp),
+        ('nfeats', vp), ('efeats', vp), ('te_freq', vp), ('te_phase', vp),
+        ('tsfm1', TgLinear), ('tsfm2', TgLinear),
+        ('gru_w_ih', vp), ('gru_w_hh', vp), ('gru_b_ih', vp), ('gru_b_hh', vp),
+        ('upd_fc1', TgLinear), ('upd_fc2', TgLinear),
+        ('attn_wq', vp), ('attn_wk', vp), ('attn_wv', vp), ('attn_b_in', vp),
+        ('attn_out', TgLinear), ('attn_fc1', TgLinear), ('attn_fc2', TgLinear),
+    ]
+
+
+class TgSeqRestarter(C.Structure):
+    _fields_ = [
+        ('hist_len', i32), ('n_head', i32), ('te_freq', vp), ('te_phase', vp), ('anony_emb', vp),
+        ('in_proj_w', vp), ('in_proj_b', vp), ('out_proj', TgLinear), ('out_fn', TgLinear),
+        ('fc1', TgLinear), ('fc2', TgLinear),
+    ]
+
+
+class TgStepIo(C.Structure):
+    _fields_ = [
+        ('B', i64), ('src', vp), ('dst', vp), ('neg', vp), ('ts', vp), ('eids', vp),
+        ('h', vp), ('l1_nids', vp), ('l1_eids', vp), ('l1_ts', vp), ('involved', vp), ('counts', vp),
+        ('h_prev_left', vp), ('h_prev_right', vp), ('err', vp),
+        ('offset_dev', vp), ('advance', i32), ('reserved', i32), ('profiler', vp),
+    ]
+
+
+P = C.POINTER
+# name -> (restype, argtypes); every symbol include/tiger_hip.h declares
+SIGNATURES = {
+    'tg_abi_version': (C.c_int, []),
+    'tg_last_hip_error': (C.c_char_p, []),
+    'tg_tcsr_build_host': (C.c_int, [i64, vp, vp, vp, vp, i64, vp, vp, vp, vp]),
+    'tg_sample_recent_edges': (C.c_int, [P(TgTcsr), i64, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
+    'tg_sample_recent_nodes': (C.c_int, [P(TgTcsr), i64, vp, vp, i32, vp, vp, vp, vp, vp]),
+    'tg_sample_uniform': (C.c_int, [P(TgTcsr), i64, vp, vp, i32, vp, vp, vp, vp, vp, vp]),
+    'tg_hits': (C.c_int, [i64, i32, vp, vp, vp, vp]),
+    'tg_anonymized_reindex': (C.c_int, [i64, i32, vp, vp, vp]),
+    'tg_bitmap_words': (i64, [i64]),
+    'tg_bitmap_mark': (C.c_int, [i64, vp, vp, i64, vp]),
+    'tg_unique_compact_workspace_bytes': (sz, [i64]),
+    'tg_unique_compact': (C.c_int, [vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'tg_select_latest_workspace_bytes': (sz, [i64, i64]),
+    'tg_select_latest': (C.c_int, [i64, vp, vp, i32, i64, vp, vp, vp, vp, sz, vp]),
+    'tg_time_encode': (C.c_int, [i64, vp, i32, vp, vp, vp, vp]),
+    'tg_gather_rows': (C.c_int, [i64, vp, i32, vp, vp, vp, vp, vp]),
+    'tg_memory_scatter': (C.c_int, [i64, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp]),
+    'tg_linear_fwd': (C.c_int, [i64, vp, i32, P(TgLinear), i32, i32, vp, vp]),
+    'tg_gru_fwd': (C.c_int, [i64, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]),
+    'tg_mailbox_consume_gather': (C.c_int, [P(TgModel), vp, vp, i64, vp, vp]),
+    'tg_apply_messages_workspace_bytes': (sz, [P(TgModel), i64]),
+    'tg_apply_messages': (C.c_int, [P(TgModel), vp, vp, vp, i64, vp, vp, vp, sz, vp]),
+    'tg_temporal_attn_workspace_bytes': (sz, [P(TgModel), i64]),
+    'tg_temporal_attn_fwd': (C.c_int, [P(TgModel), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'tg_consume_update_right': (C.c_int, [P(TgModel), vp, vp, i64, vp, vp, vp, vp, vp]),
+    'tg_store_events': (C.c_int, [P(TgModel), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'tg_restart_seq_workspace_bytes': (sz, [P(TgModel), P(TgSeqRestarter), i64]),
+    'tg_restart_seq_fwd': (C.c_int, [P(TgModel), P(TgSeqRestarter), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'tg_restart_apply': (C.c_int, [P(TgModel), i64, vp, vp, vp, vp, vp]),
+    'tg_profiler_create': (vp, []),
+    'tg_profiler_destroy': (None, [vp]),
+    'tg_profiler_num_stages': (C.c_int, []),
+    'tg_profiler_stage_name': (C.c_char_p, [C.c_int]),
+    'tg_profiler_read': (C.c_int, [vp, vp]),
+    'tg_stream_step_workspace_bytes': (sz, [P(TgModel), i64]),
+    'tg_stream_step': (C.c_int, [P(TgModel), P(TgTcsr), P(TgStepIo), vp, sz, vp]),
+}
+
+
+class TigerHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise TigerHipError(
+            f'{LIB_PATH} is missing: build it with `python __graft_entry__.py` (or `make -C www2023tiger_amd/csrc`). '
+            'There is no CPU fallback for the HIP path.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export the symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.tg_abi_version() != 1:
+        raise TigerHipError('libtiger_hip.so ABI version mismatch')
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=''):
+    if rc == TG_OK:
+        return
+    names = {TG_EINVAL: 'invalid argument', TG_EUNSUPPORTED: 'unsupported configuration',
+             TG_EWORKSPACE: 'workspace too small', TG_EHIP: 'HIP error'}
+    msg = names.get(rc, f'error {rc}')
+    if rc == TG_EHIP:
+        msg += ': ' + lib.tg_last_hip_error().decode()
+    raise TigerHipError(f'{what}: {msg}')
+
+
+def ptr(t):
+    """device (or host) pointer of a torch tensor / numpy array, None -> NULL"""
+    if t is None:
+        return None
+    if hasattr(t, 'data_ptr'):
+        return t.data_ptr()
+    return t.ctypes.data
+
+
+def raise_invariants(word: int):
+    """Turn the device-side invariant word into the reference's ValueError."""
+    for bit, text in ERR_TEXT.items():
+        if word & bit:
+            raise ValueError(text)

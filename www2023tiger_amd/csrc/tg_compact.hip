@@ -1,0 +1,283 @@
+// Sorted-unique compaction on node bitmaps (a5, a8, a10, a12).
+// Replaces np.sort(list(set)) (data_loader.py:109-121), the dense local_index
+// (data_classes.py:163-165), the Python-set intersection of get_outdated_node_ids
+// (memory.py:108-126) and torch.unique + scatter_max (tiger/model/utils.py:10-16).
+// A bitmap over node ids is its own sorted order, so no sort is needed: ranks are
+// prefix popcounts.
+#include "tg_common.h"
+
+namespace tg {
+
+constexpr int CB = 256;          // threads per block
+constexpr int WPT = 8;           // bitmap words per thread
+constexpr int TILE = CB * WPT;   // words per block
+
+__global__ void k_mark(int64_t n, const int64_t* __restrict__ ids, uint64_t* __restrict__ bm, int64_t n_nodes) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t id = ids[i];
+    if (id < 0 || id >= n_nodes) continue;
+    const uint64_t bit = 1ull << (id & 63);
+    uint64_t* w = bm + (id >> 6);
+    if ((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) == 0)
+      atomicOr((unsigned long long*)w, bit);
+  }
+}
+
+// exclusive scan of one value per thread over a 256-thread block; returns the block total in *total
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wave /*[4]*/, uint32_t* total) {
+  const int lane = lane_id();
+  const int wv = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int o = 1; o < TG_WAVE; o <<= 1) {
+    const uint32_t t = __shfl_up(inc, o, TG_WAVE);
+    if (lane >= o) inc += t;
+  }
+  if (lane == TG_WAVE - 1) s_wave[wv] = inc;
+  __syncthreads();
+  uint32_t base = 0;
+  uint32_t tot = 0;
+#pragma unroll
+  for (int i = 0; i < CB / TG_WAVE; ++i) {
+    const uint32_t s = s_wave[i];
+    if (i < wv) base += s;
+    tot += s;
+  }
+  *total = tot;
+  __syncthreads();
+  return base + inc - v;
+}
+
+// phase A: per-block popcount totals (both lists)
+__global__ void __launch_bounds__(CB) k_bm_block_sums(const uint64_t* __restrict__ bm, const uint64_t* __restrict__ hm,
+                                                      int64_t W, uint32_t* __restrict__ blk1, uint32_t* __restrict__ blk2) {
+  __shared__ uint32_t s_w[2][CB / TG_WAVE];
+  const int64_t w0 = (int64_t)blockIdx.x * TILE + (int64_t)threadIdx.x * WPT;
+  uint32_t c1 = 0, c2 = 0;
+#pragma unroll
+  for (int k = 0; k < WPT; ++k) {
+    const int64_t w = w0 + k;
+    if (w < W) {
+      const uint64_t a = bm[w];
+      c1 += __popcll(a);
+      if (hm) c2 += __popcll(a & hm[w]);
+    }
+  }
+  uint32_t t1, t2;
+  block_excl_scan(c1, s_w[0], &t1);
+  block_excl_scan(c2, s_w[1], &t2);
+  if (threadIdx.x == 0) {
+    blk1[blockIdx.x] = t1;
+    blk2[blockIdx.x] = t2;
+  }
+}
+
+// phase B: one block turns block totals into exclusive block offsets and writes the counts
+__global__ void __launch_bounds__(CB) k_bm_scan_blocks(uint32_t* __restrict__ blk1, uint32_t* __restrict__ blk2, int nblk,
+                                                       int32_t* __restrict__ count1, int32_t* __restrict__ count2) {
+  __shared__ uint32_t s_w[2][CB / TG_WAVE];
+  uint32_t run1 = 0, run2 = 0;
+  for (int base = 0; base < nblk; base += CB) {
+    const int i = base + threadIdx.x;
+    const uint32_t v1 = i < nblk ? blk1[i] : 0, v2 = i < nblk ? blk2[i] : 0;
+    uint32_t t1, t2;
+    const uint32_t e1 = block_excl_scan(v1, s_w[0], &t1);
+    const uint32_t e2 = block_excl_scan(v2, s_w[1], &t2);
+    if (i < nblk) {
+      blk1[i] = run1 + e1;
+      blk2[i] = run2 + e2;
+    }
+    run1 += t1;
+    run2 += t2;
+  }
+  if (threadIdx.x == 0) {
+    if (count1) *count1 = (int32_t)run1;
+    if (count2) *count2 = (int32_t)run2;
+  }
+}
+
+// phase C: per-word ranks + id emission.  With gridDim.x == 1 it is the whole algorithm.
+__global__ void __launch_bounds__(CB) k_bm_emit(const uint64_t* __restrict__ bm, const uint64_t* __restrict__ hm, int64_t W,
+                                                const uint32_t* __restrict__ blk1, const uint32_t* __restrict__ blk2,
+                                                uint32_t* __restrict__ rank1, int64_t* __restrict__ ids1,
+                                                int32_t* __restrict__ count1, int64_t cap,
+                                                uint32_t* __restrict__ rank2, int64_t* __restrict__ ids2,
+                                                int32_t* __restrict__ pos2, int32_t* __restrict__ count2) {
+  __shared__ uint32_t s_w[2][CB / TG_WAVE];
+  const bool single = (gridDim.x == 1);
+  const int64_t w0 = (int64_t)blockIdx.x * TILE + (int64_t)threadIdx.x * WPT;
+  uint64_t a[WPT], b[WPT];
+  uint32_t c1 = 0, c2 = 0;
+#pragma unroll
+  for (int k = 0; k < WPT; ++k) {
+    const int64_t w = w0 + k;
+    a[k] = (w < W) ? bm[w] : 0ull;
+    b[k] = (hm && w < W) ? (a[k] & hm[w]) : 0ull;
+    c1 += __popcll(a[k]);
+    c2 += __popcll(b[k]);
+  }
+  uint32_t t1, t2;
+  uint32_t r1 = block_excl_scan(c1, s_w[0], &t1) + (single ? 0u : blk1[blockIdx.x]);
+  uint32_t r2 = block_excl_scan(c2, s_w[1], &t2) + (single ? 0u : blk2[blockIdx.x]);
+  if (single && threadIdx.x == 0) {
+    if (count1) *count1 = (int32_t)t1;
+    if (count2) *count2 = (int32_t)t2;
+  }
+#pragma unroll
+  for (int k = 0; k < WPT; ++k) {
+    const int64_t w = w0 + k;
+    if (w >= W) break;
+    rank1[w] = r1;
+    if (rank2) rank2[w] = r2;
+    uint64_t m = a[k];
+    uint32_t r = r1;
+    while (m) {
+      const int bit = __ffsll((unsigned long long)m) - 1;
+      if (ids1 && (int64_t)r < cap) ids1[r] = w * 64 + bit;
+      ++r;
+      m &= m - 1;
+    }
+    m = b[k];
+    r = r2;
+    while (m) {
+      const int bit = __ffsll((unsigned long long)m) - 1;
+      if ((int64_t)r < cap) {
+        if (ids2) ids2[r] = w * 64 + bit;
+        if (pos2) pos2[r] = (int32_t)(r1 + (uint32_t)__popcll(a[k] & ((1ull << bit) - 1ull)));
+      }
+      ++r;
+      m &= m - 1;
+    }
+    r1 += __popcll(a[k]);
+    r2 += __popcll(b[k]);
+  }
+  // sentinel entries rank[W] = totals
+  if (single) {
+    if (threadIdx.x == 0) {
+      rank1[W] = t1;
+      if (rank2) rank2[W] = t2;
+    }
+  } else if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    rank1[W] = blk1[blockIdx.x] + t1;
+    if (rank2) rank2[W] = blk2[blockIdx.x] + t2;
+  }
+}
+
+template <typename T>
+__global__ void k_sel_max(int64_t n, const int64_t* __restrict__ nids, const T* __restrict__ ts,
+                          const uint64_t* __restrict__ bm, const uint32_t* __restrict__ rank,
+                          unsigned long long* __restrict__ best) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    atomicMax(best + bm_rank(bm, rank, nids[i]), (unsigned long long)orderable(ts[i]));
+}
+
+template <typename T>
+__global__ void k_sel_min(int64_t n, const int64_t* __restrict__ nids, const T* __restrict__ ts,
+                          const uint64_t* __restrict__ bm, const uint32_t* __restrict__ rank,
+                          const unsigned long long* __restrict__ best, unsigned int* __restrict__ best_idx) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t r = bm_rank(bm, rank, nids[i]);
+    if ((unsigned long long)orderable(ts[i]) == best[r]) atomicMin(best_idx + r, (unsigned int)i);
+  }
+}
+
+__global__ void k_sel_out(const int32_t* __restrict__ count, int64_t cap, const unsigned int* __restrict__ best_idx,
+                          int64_t* __restrict__ out_index) {
+  const int64_t n = *count;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n && i < cap; i += (int64_t)gridDim.x * blockDim.x)
+    out_index[i] = (int64_t)best_idx[i];
+}
+
+static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// scratch of the scan itself: two uint32 block-total arrays
+static size_t scan_ws_bytes(int64_t W) { return 2 * align16((size_t)cdiv(W, TILE) * sizeof(uint32_t)); }
+
+int unique_compact_launch(const uint64_t* bm, int64_t n_nodes, uint32_t* rank, int64_t* ids, int32_t* count,
+                          int64_t cap, const uint64_t* hm, uint32_t* rank2, int64_t* ids2, int32_t* pos2,
+                          int32_t* count2, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int64_t W = (n_nodes + 63) / 64;
+  const int nblk = (int)cdiv(W, TILE);
+  if (ws_bytes < scan_ws_bytes(W)) return TG_EWORKSPACE;
+  uint32_t* blk1 = (uint32_t*)ws;
+  uint32_t* blk2 = (uint32_t*)((char*)ws + align16((size_t)nblk * sizeof(uint32_t)));
+  if (nblk > 1) {
+    hipLaunchKernelGGL(k_bm_block_sums, dim3(nblk), dim3(CB), 0, st, bm, hm, W, blk1, blk2);
+    hipLaunchKernelGGL(k_bm_scan_blocks, dim3(1), dim3(CB), 0, st, blk1, blk2, nblk, count, count2);
+  }
+  hipLaunchKernelGGL(k_bm_emit, dim3(nblk), dim3(CB), 0, st, bm, hm, W, blk1, blk2, rank, ids, count, cap, rank2, ids2,
+                     pos2, count2);
+  return check_launch("tg_unique_compact");
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+extern "C" int64_t tg_bitmap_words(int64_t n_nodes) { return (n_nodes + 63) / 64; }
+
+extern "C" int tg_bitmap_mark(int64_t n, const int64_t* ids, uint64_t* bitmap, int64_t n_nodes, void* stream) {
+  if (n < 0 || n_nodes <= 0 || !bitmap) return TG_EINVAL;
+  if (n == 0) return TG_OK;
+  if (!ids) return TG_EINVAL;
+  hipLaunchKernelGGL(k_mark, dim3(flat_grid(n, 256)), dim3(256), 0, as_stream(stream), n, ids, bitmap, n_nodes);
+  return check_launch("tg_bitmap_mark");
+}
+
+extern "C" size_t tg_unique_compact_workspace_bytes(int64_t n_nodes) { return scan_ws_bytes((n_nodes + 63) / 64); }
+
+extern "C" int tg_unique_compact(const uint64_t* bitmap, int64_t n_nodes, uint32_t* rank, int64_t* out_ids,
+                                 int32_t* out_count, int64_t cap, const uint64_t* and_bitmap, uint32_t* and_rank,
+                                 int64_t* and_ids, int32_t* and_pos, int32_t* and_count, void* ws, size_t ws_bytes,
+                                 void* stream) {
+  if (!bitmap || n_nodes <= 0 || !rank || cap < 0) return TG_EINVAL;
+  return unique_compact_launch(bitmap, n_nodes, rank, out_ids, out_count, cap, and_bitmap, and_rank, and_ids, and_pos,
+                               and_count, ws, ws_bytes, as_stream(stream));
+}
+
+// workspace layout of tg_select_latest: bitmap | rank | best (u64[n]) | best_idx (u32[n]) | scan scratch
+extern "C" size_t tg_select_latest_workspace_bytes(int64_t n, int64_t n_nodes) {
+  const int64_t W = (n_nodes + 63) / 64;
+  return align16((size_t)W * 8) + align16((size_t)(W + 1) * 4) + align16((size_t)n * 8) + align16((size_t)n * 4) +
+         scan_ws_bytes(W);
+}
+
+extern "C" int tg_select_latest(int64_t n, const int64_t* nids, const void* ts, int32_t ts_is_f64, int64_t n_nodes,
+                                int64_t* out_unique, int64_t* out_index, int32_t* out_count, void* ws, size_t ws_bytes,
+                                void* stream) {
+  if (n < 0 || n_nodes <= 0 || !out_count) return TG_EINVAL;
+  if (n > 0 && (!nids || !ts || !out_unique || !out_index)) return TG_EINVAL;
+  if (ws_bytes < tg_select_latest_workspace_bytes(n, n_nodes) || !ws) return TG_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  const int64_t W = (n_nodes + 63) / 64;
+  char* p = (char*)ws;
+  uint64_t* bm = (uint64_t*)p;
+  p += align16((size_t)W * 8);
+  uint32_t* rank = (uint32_t*)p;
+  p += align16((size_t)(W + 1) * 4);
+  unsigned long long* best = (unsigned long long*)p;
+  p += align16((size_t)n * 8);
+  unsigned int* best_idx = (unsigned int*)p;
+  p += align16((size_t)n * 4);
+  hipError_t e = hipMemsetAsync(bm, 0, (size_t)W * 8, st);
+  if (e == hipSuccess && n > 0) e = hipMemsetAsync(best, 0, (size_t)n * 8, st);
+  if (e == hipSuccess && n > 0) e = hipMemsetAsync(best_idx, 0xff, (size_t)n * 4, st);
+  if (e != hipSuccess) {
+    set_hip_error(e, "tg_select_latest memset");
+    return TG_EHIP;
+  }
+  if (n > 0) hipLaunchKernelGGL(k_mark, dim3(flat_grid(n, 256)), dim3(256), 0, st, n, nids, bm, n_nodes);
+  int rc = unique_compact_launch(bm, n_nodes, rank, out_unique, out_count, n, nullptr, nullptr, nullptr, nullptr,
+                                 nullptr, p, scan_ws_bytes(W), st);
+  if (rc != TG_OK || n == 0) return rc;
+  const unsigned g = flat_grid(n, 256);
+  if (ts_is_f64) {
+    hipLaunchKernelGGL(k_sel_max<double>, dim3(g), dim3(256), 0, st, n, nids, (const double*)ts, bm, rank, best);
+    hipLaunchKernelGGL(k_sel_min<double>, dim3(g), dim3(256), 0, st, n, nids, (const double*)ts, bm, rank, best, best_idx);
+  } else {
+    hipLaunchKernelGGL(k_sel_max<float>, dim3(g), dim3(256), 0, st, n, nids, (const float*)ts, bm, rank, best);
+    hipLaunchKernelGGL(k_sel_min<float>, dim3(g), dim3(256), 0, st, n, nids, (const float*)ts, bm, rank, best, best_idx);
+  }
+  hipLaunchKernelGGL(k_sel_out, dim3(g), dim3(256), 0, st, out_count, n, best_idx, out_index);
+  return check_launch("tg_select_latest");
+}

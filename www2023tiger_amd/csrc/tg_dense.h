@@ -1,0 +1,54 @@
+// Dense building blocks on the gfx950 matrix cores: float32-in / float32-accumulate MFMA
+// (v_mfma_f32_32x32x2_f32).  The path must match a float32 CPU reference to 1e-4
+// relative, so bf16/fp8 MFMA are not an option; the f32 MFMA is bit-for-bit a k-ordered
+// fmaf chain.
+#pragma once
+#include "tg_common.h"
+
+namespace tg {
+
+// one K-slice of the A operand: rows optionally gathered through `idx`
+struct ASeg {
+  const float* p;
+  int64_t ld;          // row stride in floats
+  int w;               // width (multiple of 4)
+  const int64_t* idx;  // nullable: row m reads table row idx[m]
+};
+
+// C[m, n] = act(alpha * (sum_k A[m,k] * W(n,k) + bias[n])), A = [a0 | a1]
+struct GemmArgs {
+  int64_t m_cap;
+  const int32_t* m_dev;  // nullable: live row count on device (<= m_cap)
+  int n, k;
+  ASeg a0, a1;
+  const float* w;
+  int64_t ldw;
+  int w_kmajor;  // 0: W[n*ldw + k] (torch Linear)   1: W[k*ldw + n]
+  const float* bias;
+  float* c;
+  int64_t ldc;
+  const int32_t* c_rows;     // nullable: output row m is written to row c_rows[m]
+  const uint8_t* row_valid;  // nullable: rows with 0 are written as zeros
+  float alpha;
+  int relu;
+  int nbatch;                // batched over blockIdx: per-batch element offsets below
+  int64_t a0_bs, w_bs, bias_bs, c_bs;
+};
+
+int gemm_launch(const GemmArgs& g, hipStream_t st);
+
+struct GruArgs {
+  int64_t cap;
+  const int32_t* n_dev;
+  int d, xw;
+  ASeg x;  // messages  [*, xw]
+  ASeg h;  // old memory [*, d]
+  const float *w_ih, *w_hh, *b_ih, *b_hh;
+  float* out;
+  int64_t ldo;
+  const int32_t* out_rows;  // nullable
+};
+
+int gru_launch(const GruArgs& g, hipStream_t st);
+
+}  // namespace tg

@@ -1,0 +1,430 @@
+// Temporal CSR + temporal neighbour sampling kernels.
+// Reference: tiger/data/graph.py:11-155,226-241; tiger/data/data_loader.py:61-75;
+// tiger/model/utils.py:19-27.  Integer work: results are bit-exact.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "tg_common.h"
+
+namespace tg {
+
+static thread_local std::string g_hip_error;
+void set_hip_error(hipError_t e, const char* what) {
+  g_hip_error = std::string(what) + ": " + hipGetErrorString(e);
+}
+
+}  // namespace tg
+
+extern "C" int tg_abi_version(void) { return TG_ABI_VERSION; }
+extern "C" const char* tg_last_hip_error(void) { return tg::g_hip_error.c_str(); }
+
+// ---------------------------------------------------------------------------------
+// Host-side T-CSR build (initialisation, graph.py:30-36 + data2adjlist :226-241).
+// Entry 2i is event i seen from src (flag 0), entry 2i+1 is event i seen from dst
+// (flag 1); a counting sort by owner keeps that order, then each node's run is
+// stably sorted by time if it is not already ascending.
+// ---------------------------------------------------------------------------------
+extern "C" int tg_tcsr_build_host(int64_t E, const int64_t* src, const int64_t* dst, const double* ts,
+                                  const int64_t* eid, int64_t num_node, int64_t* indptr, double* ts_out,
+                                  int32_t* nbr_out, int32_t* eid_out) {
+  if (E < 0 || num_node <= 0 || num_node > 0x7fffffffLL) return TG_EINVAL;
+  for (int64_t i = 0; i < E; ++i) {
+    if (src[i] < 0 || src[i] >= num_node || dst[i] < 0 || dst[i] >= num_node) return TG_EINVAL;
+    if (eid[i] < 0 || eid[i] > 0x7fffffffLL) return TG_EINVAL;
+  }
+  std::fill(indptr, indptr + num_node + 1, (int64_t)0);
+  for (int64_t i = 0; i < E; ++i) {
+    indptr[src[i] + 1]++;
+    indptr[dst[i] + 1]++;
+  }
+  for (int64_t n = 0; n < num_node; ++n) indptr[n + 1] += indptr[n];
+  std::vector<int64_t> cur(indptr, indptr + num_node);
+  for (int64_t i = 0; i < E; ++i) {
+    int64_t p = cur[src[i]]++;
+    ts_out[p] = ts[i];
+    nbr_out[p] = (int32_t)dst[i];
+    eid_out[p] = (int32_t)eid[i];
+    p = cur[dst[i]]++;
+    ts_out[p] = ts[i];
+    nbr_out[p] = (int32_t)src[i];
+    eid_out[p] = (int32_t)((uint32_t)eid[i] | 0x80000000u);
+  }
+  std::vector<int64_t> perm;
+  std::vector<double> t_tmp;
+  std::vector<int32_t> a_tmp, b_tmp;
+  for (int64_t n = 0; n < num_node; ++n) {
+    const int64_t lo = indptr[n], hi = indptr[n + 1];
+    bool sorted = true;
+    for (int64_t p = lo + 1; p < hi; ++p)
+      if (ts_out[p] < ts_out[p - 1]) {
+        sorted = false;
+        break;
+      }
+    if (sorted) continue;
+    const int64_t len = hi - lo;
+    perm.resize(len);
+    std::iota(perm.begin(), perm.end(), (int64_t)0);
+    std::stable_sort(perm.begin(), perm.end(),
+                     [&](int64_t a, int64_t b) { return ts_out[lo + a] < ts_out[lo + b]; });
+    t_tmp.assign(ts_out + lo, ts_out + hi);
+    a_tmp.assign(nbr_out + lo, nbr_out + hi);
+    b_tmp.assign(eid_out + lo, eid_out + hi);
+    for (int64_t k = 0; k < len; ++k) {
+      ts_out[lo + k] = t_tmp[perm[k]];
+      nbr_out[lo + k] = a_tmp[perm[k]];
+      eid_out[lo + k] = b_tmp[perm[k]];
+    }
+  }
+  return TG_OK;
+}
+
+namespace tg {
+
+// number of entries of node `nid` with ts < t  (np.searchsorted(..., side='left'), graph.py:51)
+__device__ __forceinline__ int64_t prefix_end(const tg_tcsr& g, int64_t nid, double t, int64_t* start) {
+  if (nid < 0 || nid >= g.num_node) {
+    *start = 0;
+    return 0;
+  }
+  int64_t lo = g.indptr[nid], hi = g.indptr[nid + 1];
+  *start = lo;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (g.ts[mid] < t)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// set bit `id`, skipping the atomic when the bit is already visible
+__device__ __forceinline__ void mark_bit(uint64_t* bm, int64_t id) {
+  const uint64_t bit = 1ull << (id & 63);
+  uint64_t* w = bm + (id >> 6);
+  if ((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) == 0) atomicOr((unsigned long long*)w, bit);
+}
+
+// G lanes cooperate on one query: all run the binary search on the same addresses
+// (broadcast loads), then copy the K-entry tail with one lane per slot.
+template <int G>
+__global__ void __launch_bounds__(256) k_sample_recent_edges(tg_tcsr g, int64_t Q, const int64_t* __restrict__ nids,
+                                                             const double* __restrict__ qts, int K,
+                                                             int64_t* __restrict__ o_nbr, int64_t* __restrict__ o_eid,
+                                                             float* __restrict__ o_ts, int64_t* __restrict__ o_dir,
+                                                             uint64_t* __restrict__ mark) {
+  constexpr int GPB = 256 / G;
+  const int sub = threadIdx.x % G;
+  for (int64_t q = (int64_t)blockIdx.x * GPB + threadIdx.x / G; q < Q; q += (int64_t)gridDim.x * GPB) {
+    const int64_t nid = nids[q];
+    int64_t start;
+    const int64_t end = prefix_end(g, nid, qts[q], &start);
+    bool pad = false;
+    for (int j = sub; j < K; j += G) {
+      const int64_t p = end - K + j;
+      int64_t nb = 0, ed = 0, dr = 0;
+      float tt = 0.f;
+      if (p >= start) {
+        nb = g.nbr[p];
+        const uint32_t e = (uint32_t)g.eid[p];
+        ed = (int64_t)(e & 0x7fffffffu);
+        dr = (int64_t)(e >> 31);
+        tt = (float)g.ts[p];
+      }
+      const int64_t o = q * K + j;
+      o_nbr[o] = nb;
+      o_eid[o] = ed;
+      o_ts[o] = tt;
+      if (o_dir) o_dir[o] = dr;
+      if (mark) {
+        if (nb == 0)
+          pad = true;
+        else
+          mark_bit(mark, nb);
+      }
+    }
+    if (mark) {
+      if (sub == 0 && nid >= 0 && nid < g.num_node) mark_bit(mark, nid);
+      if (pad) mark_bit(mark, 0);
+    }
+  }
+}
+
+// One wavefront per query.  Walk the prefix backwards 64 entries at a time; an entry
+// is kept if no more recent entry (this chunk or earlier chunks) has the same
+// neighbour.  The j-th kept entry (j = 0 most recent) lands in output slot K-1-j.
+__global__ void __launch_bounds__(256) k_sample_recent_nodes(tg_tcsr g, int64_t Q, const int64_t* __restrict__ nids,
+                                                             const double* __restrict__ qts, int K,
+                                                             int64_t* __restrict__ o_nbr, int64_t* __restrict__ o_eid,
+                                                             float* __restrict__ o_ts, int64_t* __restrict__ o_dir) {
+  __shared__ int s_new[4][TG_WAVE];
+  const int lane = lane_id();
+  const int wv = threadIdx.x >> 6;
+  for (int64_t q = (int64_t)blockIdx.x * 4 + wv; q < Q; q += (int64_t)gridDim.x * 4) {
+    int64_t start;
+    const int64_t end = prefix_end(g, nids[q], qts[q], &start);
+    int c = 0;        // wave-uniform: number collected so far
+    int mycol = -1;   // lane j holds the neighbour id of the j-th collected entry
+    for (int64_t chunk_end = end; chunk_end > start && c < K; chunk_end -= TG_WAVE) {
+      const int64_t p = chunk_end - 1 - lane;
+      const bool valid = p >= start;
+      const int v = valid ? g.nbr[p] : -1;
+      bool isnew = valid;
+      for (int i = 0; i < TG_WAVE; ++i) {
+        const int vi = __shfl(v, i, TG_WAVE);
+        if (i < lane && vi == v) isnew = false;
+      }
+      for (int j = 0; j < c; ++j) {
+        const int cj = __shfl(mycol, j, TG_WAVE);
+        if (cj == v) isnew = false;
+      }
+      const unsigned long long m = __ballot(isnew);
+      const int slot = c + __popcll(m & ((1ull << lane) - 1ull));
+      if (isnew && slot < K) {
+        const uint32_t e = (uint32_t)g.eid[p];
+        const int64_t o = q * K + (K - 1 - slot);
+        o_nbr[o] = v;
+        o_eid[o] = (int64_t)(e & 0x7fffffffu);
+        o_ts[o] = (float)g.ts[p];
+        if (o_dir) o_dir[o] = (int64_t)(e >> 31);
+        if (slot < TG_WAVE) s_new[wv][slot] = v;
+      }
+      const int nnew = __popcll(m);
+      __builtin_amdgcn_wave_barrier();
+      if (lane >= c && lane < c + nnew && lane < K) mycol = s_new[wv][lane];
+      __builtin_amdgcn_wave_barrier();
+      c += nnew;
+    }
+    if (c > K) c = K;
+    for (int j = lane; j < K - c; j += TG_WAVE) {  // left padding
+      const int64_t o = q * K + j;
+      o_nbr[o] = 0;
+      o_eid[o] = 0;
+      o_ts[o] = 0.f;
+      if (o_dir) o_dir[o] = 0;
+    }
+  }
+}
+
+// ---- MT19937 exactly as numpy's legacy RandomState (randomkit) ---------------------
+__device__ __forceinline__ void mt_regen(uint32_t* key, int lane) {
+  // sequential dependency of distance 397/227: regenerate in three independent
+  // stripes so that the wave can work in parallel inside a stripe.
+  constexpr uint32_t UP = 0x80000000u, LO = 0x7fffffffu, MA = 0x9908b0dfu;
+  for (int base = 0; base < 227; base += TG_WAVE) {  // kk in [0,227): uses key[kk+397] (old)
+    const int kk = base + lane;
+    uint32_t y = 0;
+    if (kk < 227) y = (key[kk] & UP) | (key[kk + 1] & LO);
+    __builtin_amdgcn_wave_barrier();
+    if (kk < 227) key[kk] = key[kk + 397] ^ (y >> 1) ^ ((y & 1u) ? MA : 0u);
+    __builtin_amdgcn_wave_barrier();
+  }
+  // kk in [227,623): uses key[kk-227] (new); split so a stripe never reads what it writes
+  for (int seg = 227; seg < 623; seg += 227) {
+    const int seg_end = (seg + 227 < 623) ? seg + 227 : 623;
+    for (int base = seg; base < seg_end; base += TG_WAVE) {
+      const int kk = base + lane;
+      uint32_t y = 0;
+      if (kk < seg_end) y = (key[kk] & UP) | (key[kk + 1] & LO);
+      __builtin_amdgcn_wave_barrier();
+      if (kk < seg_end) key[kk] = key[kk - 227] ^ (y >> 1) ^ ((y & 1u) ? MA : 0u);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (lane == 0) {
+    const uint32_t y = (key[623] & UP) | (key[0] & LO);
+    key[623] = key[396] ^ (y >> 1) ^ ((y & 1u) ? MA : 0u);
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+
+// The random stream is consumed per non-empty query in query order (graph.py:103),
+// and randint's masked rejection makes the draw count data dependent, so ONE wavefront
+// walks the queries.  Lane 0 draws; all lanes help regenerate the state and copy.
+__global__ void __launch_bounds__(64) k_sample_uniform(tg_tcsr g, int64_t Q, const int64_t* __restrict__ nids,
+                                                       const double* __restrict__ qts, int K, uint32_t* mt_state,
+                                                       int64_t* __restrict__ o_nbr, int64_t* __restrict__ o_eid,
+                                                       float* __restrict__ o_ts, int64_t* __restrict__ o_dir) {
+  __shared__ uint32_t key[624];
+  __shared__ int s_pos;
+  __shared__ int64_t s_sel[TG_WAVE];
+  const int lane = lane_id();
+  for (int i = lane; i < 624; i += TG_WAVE) key[i] = mt_state[i];
+  if (lane == 0) s_pos = (int)mt_state[624];
+  __builtin_amdgcn_wave_barrier();
+  for (int64_t q = 0; q < Q; ++q) {
+    int64_t start;
+    const int64_t end = prefix_end(g, nids[q], qts[q], &start);
+    const int64_t len = end - start;
+    if (len == 0) {
+      for (int j = lane; j < K; j += TG_WAVE) {
+        const int64_t o = q * K + j;
+        o_nbr[o] = 0;
+        o_eid[o] = 0;
+        o_ts[o] = 0.f;
+        if (o_dir) o_dir[o] = 0;
+      }
+      continue;
+    }
+    // numpy _rand_int64 / _bounded_uint64 with use_masked: rng = len-1; rng == 0 draws
+    // nothing; rng <= 0xFFFFFFFF uses 32-bit draws masked to the next power of two - 1.
+    const uint64_t rng = (uint64_t)(len - 1);
+    uint32_t mask = (uint32_t)rng;
+    mask |= mask >> 1;
+    mask |= mask >> 2;
+    mask |= mask >> 4;
+    mask |= mask >> 8;
+    mask |= mask >> 16;
+    for (int k = 0; k < K; ++k) {
+      uint32_t val = 0;
+      if (rng != 0) {
+        bool done = false;  // wave-uniform via LDS
+        while (!done) {
+          if (s_pos == 624) {
+            mt_regen(key, lane);
+            if (lane == 0) s_pos = 0;
+            __builtin_amdgcn_wave_barrier();
+          }
+          val = mt_temper(key[s_pos]) & mask;
+          __builtin_amdgcn_wave_barrier();
+          if (lane == 0) s_pos = s_pos + 1;
+          __builtin_amdgcn_wave_barrier();
+          done = val <= (uint32_t)rng;
+        }
+      }
+      if (lane == 0) s_sel[k] = start + (int64_t)val;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // stable insertion sort by time (numpy's argsort on <= 16 elements is insertion sort)
+    if (lane == 0) {
+      for (int a = 1; a < K; ++a) {
+        const int64_t x = s_sel[a];
+        const double tx = g.ts[x];
+        int b = a - 1;
+        while (b >= 0 && g.ts[s_sel[b]] > tx) {
+          s_sel[b + 1] = s_sel[b];
+          --b;
+        }
+        s_sel[b + 1] = x;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane; j < K; j += TG_WAVE) {
+      const int64_t p = s_sel[j];
+      const uint32_t e = (uint32_t)g.eid[p];
+      const int64_t o = q * K + j;
+      o_nbr[o] = g.nbr[p];
+      o_eid[o] = (int64_t)(e & 0x7fffffffu);
+      o_ts[o] = (float)g.ts[p];
+      if (o_dir) o_dir[o] = (int64_t)(e >> 31);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int i = lane; i < 624; i += TG_WAVE) mt_state[i] = key[i];
+  if (lane == 0) mt_state[624] = (uint32_t)s_pos;
+}
+
+__global__ void k_hits(int64_t n, int K, const int64_t* __restrict__ center, const int64_t* __restrict__ nbr,
+                       float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (center[i / K] == nbr[i]) ? 1.f : 0.f;
+}
+
+// one wavefront per row, lane = column (H <= 64).  id x is numbered
+// 1 + #{distinct ids whose last occurrence lies to the right of x's last occurrence}.
+__global__ void __launch_bounds__(256) k_anon_reindex(int64_t n, int H, const int64_t* __restrict__ in,
+                                                      int64_t* __restrict__ out) {
+  const int lane = lane_id();
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.x * 4) {
+    const int64_t v = lane < H ? in[r * H + lane] : -1;
+    int last = lane;       // last column holding the same id
+    for (int i = 0; i < H; ++i) {
+      const int64_t vi = __shfl(v, i, TG_WAVE);
+      if (vi == v && i > last) last = i;
+    }
+    const bool is_last = (lane < H) && (last == lane);
+    const unsigned long long m = __ballot(is_last);
+    const unsigned long long right = (last >= 63) ? 0ull : (m >> (last + 1));
+    const int64_t code = 1 + __popcll(right);
+    if (lane < H) out[r * H + lane] = (v == 0) ? 0 : code;
+  }
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+static int sample_args_ok(const tg_tcsr* g, int64_t Q, const void* a, const void* b, int K, const void* o1,
+                          const void* o2, const void* o3) {
+  if (!g || Q < 0 || K <= 0) return 0;
+  if (Q > 0 && (!a || !b || !o1 || !o2 || !o3)) return 0;
+  return 1;
+}
+
+extern "C" int tg_sample_recent_edges(const tg_tcsr* g, int64_t Q, const int64_t* nids, const double* ts, int32_t K,
+                                      int64_t* o_nbr, int64_t* o_eid, float* o_ts, int64_t* o_dir, uint64_t* mark,
+                                      void* stream) {
+  if (!sample_args_ok(g, Q, nids, ts, K, o_nbr, o_eid, o_ts)) return TG_EINVAL;
+  if (Q == 0) return TG_OK;
+  if (K <= 16) {
+    const unsigned grid = flat_grid(Q, 256 / 16);
+    hipLaunchKernelGGL(k_sample_recent_edges<16>, dim3(grid), dim3(256), 0, as_stream(stream), *g, Q, nids, ts, K,
+                       o_nbr, o_eid, o_ts, o_dir, mark);
+  } else {
+    const unsigned grid = flat_grid(Q, 256 / 64);
+    hipLaunchKernelGGL(k_sample_recent_edges<64>, dim3(grid), dim3(256), 0, as_stream(stream), *g, Q, nids, ts, K,
+                       o_nbr, o_eid, o_ts, o_dir, mark);
+  }
+  return check_launch("tg_sample_recent_edges");
+}
+
+extern "C" int tg_sample_recent_nodes(const tg_tcsr* g, int64_t Q, const int64_t* nids, const double* ts, int32_t K,
+                                      int64_t* o_nbr, int64_t* o_eid, float* o_ts, int64_t* o_dir, void* stream) {
+  if (!sample_args_ok(g, Q, nids, ts, K, o_nbr, o_eid, o_ts)) return TG_EINVAL;
+  if (K > TG_WAVE) return TG_EUNSUPPORTED;
+  if (Q == 0) return TG_OK;
+  hipLaunchKernelGGL(k_sample_recent_nodes, dim3(flat_grid(Q, 4)), dim3(256), 0, as_stream(stream), *g, Q, nids, ts,
+                     K, o_nbr, o_eid, o_ts, o_dir);
+  return check_launch("tg_sample_recent_nodes");
+}
+
+extern "C" int tg_sample_uniform(const tg_tcsr* g, int64_t Q, const int64_t* nids, const double* ts, int32_t K,
+                                 uint32_t* mt_state, int64_t* o_nbr, int64_t* o_eid, float* o_ts, int64_t* o_dir,
+                                 void* stream) {
+  if (!sample_args_ok(g, Q, nids, ts, K, o_nbr, o_eid, o_ts) || !mt_state) return TG_EINVAL;
+  // numpy sorts the K draws with argsort: insertion sort (stable) only up to 16
+  // elements; beyond that the tie order is implementation defined.
+  if (K > 16) return TG_EUNSUPPORTED;
+  if (Q == 0) return TG_OK;
+  hipLaunchKernelGGL(k_sample_uniform, dim3(1), dim3(64), 0, as_stream(stream), *g, Q, nids, ts, K, mt_state, o_nbr,
+                     o_eid, o_ts, o_dir);
+  return check_launch("tg_sample_uniform");
+}
+
+extern "C" int tg_hits(int64_t B, int32_t K, const int64_t* center, const int64_t* nbr, float* out, void* stream) {
+  if (B < 0 || K <= 0) return TG_EINVAL;
+  if (B == 0) return TG_OK;
+  if (!center || !nbr || !out) return TG_EINVAL;
+  hipLaunchKernelGGL(k_hits, dim3(flat_grid(B * K, 256)), dim3(256), 0, as_stream(stream), B * K, K, center, nbr, out);
+  return check_launch("tg_hits");
+}
+
+extern "C" int tg_anonymized_reindex(int64_t n, int32_t H, const int64_t* in, int64_t* out, void* stream) {
+  if (n < 0 || H <= 0) return TG_EINVAL;
+  if (H > TG_WAVE) return TG_EUNSUPPORTED;
+  if (n == 0) return TG_OK;
+  if (!in || !out) return TG_EINVAL;
+  hipLaunchKernelGGL(k_anon_reindex, dim3(flat_grid(n, 4)), dim3(256), 0, as_stream(stream), n, H, in, out);
+  return check_launch("tg_anonymized_reindex");
+}

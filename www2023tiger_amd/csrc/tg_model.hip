@@ -1,0 +1,688 @@
+// STEP 1-3 of TIGE.contrast_learning on device: message consumption + memory update
+// (tiger/model/tiger.py:208-221,292-356) and the one-layer temporal graph attention
+// (tiger/model/temporal_agg_modules.py:29-83,186-235).  SURVEY.md K6, K8; a13-a18.
+//
+// Attention is restructured around the fact that there is ONE query per centre and K
+// keys: instead of projecting every key/value row (24*K*d^2 flop per centre) the query
+// is folded through Wk (g_h = Wk_h^T q_h), scores are plain dot products with the raw
+// key rows, the softmax-weighted raw rows are summed first and projected through Wv
+// once.  q.bk is constant over keys and cancels in the softmax; sum(a)=1 carries bv.
+// Mathematically identical, ~5x fewer flops, and the K*3d key rows are touched once by
+// a gather kernel instead of being materialised for a GEMM.
+#include "tg_dense.h"
+
+namespace tg {
+
+static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+struct Carver {
+  char* p;
+  size_t left;
+  bool ok = true;
+  Carver(void* ws, size_t bytes) : p((char*)ws), left(bytes) {}
+  template <typename T>
+  T* take(size_t count) {
+    const size_t b = align16(count * sizeof(T));
+    if (b > left || !p) {
+      ok = false;
+      return nullptr;
+    }
+    T* r = (T*)p;
+    p += b;
+    left -= b;
+    return r;
+  }
+};
+
+// ---- invariants of compute_messages (message_modules.py:158-159, tiger.py:325-327) ----
+__global__ void k_check_messages(tg_model m, const int64_t* __restrict__ outdated, const int32_t* __restrict__ n_dev,
+                                 int64_t cap, uint32_t* __restrict__ err) {
+  const int64_t n = min((int64_t)*n_dev, cap);
+  const float* mem_ts = (m.msg_src == TG_SRC_LEFT) ? m.left_ts : m.right_ts;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t id = outdated[i];
+    const float mts = m.msg_ts[id], last = mem_ts[id];
+    if (last > mts) atomicOr(err, TG_ERR_MSG_BEFORE_MEM);
+    if (m.msg_src == TG_SRC_LEFT && !(mts == last)) atomicOr(err, TG_ERR_MSG_TS_MISMATCH);
+  }
+}
+
+// centre rows: c_i = reprs[local(nid_i)] + nfeat[nid_i]   (temporal_agg_modules.py:48-50)
+__global__ void k_attn_centres(int64_t Q, int d4, const int64_t* __restrict__ nids, const float4* __restrict__ reprs,
+                               const uint64_t* __restrict__ bm, const uint32_t* __restrict__ rank,
+                               const float4* __restrict__ nf, float4* __restrict__ out) {
+  const int64_t total = Q * d4;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / d4;
+    const int c = (int)(t - i * d4);
+    const int64_t id = nids[i];
+    float4 v = reprs[(int64_t)bm_rank(bm, rank, id) * d4 + c];
+    if (nf) {
+      const float4 f = nf[id * d4 + c];
+      v.x += f.x; v.y += f.y; v.z += f.z; v.w += f.w;
+    }
+    out[t] = v;
+  }
+}
+
+// qconst[n] = bq[n] + sum_j Wq[n, d + j] * cos(phase[j])   (the TE(0) half of the query)
+__global__ void __launch_bounds__(256) k_attn_qconst(int d, const float* __restrict__ wq, const float* __restrict__ bq,
+                                                     const float* __restrict__ freq, const float* __restrict__ phase,
+                                                     float* __restrict__ out) {
+  const int lane = lane_id();
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= 2 * d) return;
+  float acc = 0.f;
+  for (int j = lane; j < d; j += TG_WAVE) acc += wq[(int64_t)n * 2 * d + d + j] * time_enc(0.f, freq[j], phase[j]);
+  acc = wave_sum(acc);
+  if (lane == 0) out[n] = acc + bq[n];
+}
+
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ void axpby4(float4& s, float a, float b, float4 x) {
+  s.x = s.x * a + b * x.x;
+  s.y = s.y * a + b * x.y;
+  s.z = s.z * a + b * x.z;
+  s.w = s.w * a + b * x.w;
+}
+
+// One wavefront per centre.  Streams its K neighbour rows once: node part
+// reprs[local]+nfeat, edge part efeat, time part cos(dt*w+phi); per head an online
+// softmax over the keys accumulates the weighted raw row.  Rows are float4 per lane
+// (NV float4 per segment per lane, i.e. widths up to 256*NV).
+template <int NH, int NV>
+__global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const float* __restrict__ ts,
+                                                   const int64_t* __restrict__ l1_nids,
+                                                   const int64_t* __restrict__ l1_eids, const float* __restrict__ l1_ts,
+                                                   const float4* __restrict__ reprs, const uint64_t* __restrict__ bm,
+                                                   const uint32_t* __restrict__ rank, const float4* __restrict__ G,
+                                                   float4* __restrict__ S, uint8_t* __restrict__ valid) {
+  const int lane = lane_id();
+  const int d4 = m.d / 4, e4 = m.d_e / 4, K = m.n_neighbors;
+  const int kv4 = 2 * d4 + e4;
+  const float4* nf = reinterpret_cast<const float4*>(m.nfeats);
+  const float4* ef = reinterpret_cast<const float4*>(m.efeats);
+  const float4* fq = reinterpret_cast<const float4*>(m.te_freq);
+  const float4* ph = reinterpret_cast<const float4*>(m.te_phase);
+  float4 w4[NV], p4[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int c = lane + v * TG_WAVE;
+    w4[v] = c < d4 ? fq[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    p4[v] = c < d4 ? ph[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < Q; i += (int64_t)gridDim.x * 4) {
+    float4 g[NH][3][NV], acc[NH][3][NV];
+    float mx[NH], l[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      mx[h] = -INFINITY;
+      l[h] = 0.f;
+      const float4* gh = G + ((int64_t)i * NH + h) * kv4;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int c = lane + v * TG_WAVE;
+        g[h][0][v] = c < d4 ? gh[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        g[h][1][v] = c < e4 ? gh[d4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        g[h][2][v] = c < d4 ? gh[d4 + e4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        acc[h][0][v] = acc[h][1][v] = acc[h][2][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    const float t_i = ts[i];
+    bool any = false;
+    for (int k = 0; k < K; ++k) {
+      const int64_t nb = l1_nids[i * K + k];
+      if (nb == 0) continue;  // padding key is masked (temporal_agg_modules.py:80); wave-uniform
+      any = true;
+      const int64_t u = bm_rank(bm, rank, nb);
+      const int64_t eid = l1_eids[i * K + k];
+      const float dt = t_i - l1_ts[i * K + k];
+      float4 x[3][NV];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int c = lane + v * TG_WAVE;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, t = a;
+        if (c < d4) {
+          a = reprs[u * d4 + c];
+          if (nf) {
+            const float4 f = nf[nb * d4 + c];
+            a.x += f.x; a.y += f.y; a.z += f.z; a.w += f.w;
+          }
+          t = make_float4(time_enc(dt, w4[v].x, p4[v].x), time_enc(dt, w4[v].y, p4[v].y),
+                          time_enc(dt, w4[v].z, p4[v].z), time_enc(dt, w4[v].w, p4[v].w));
+        }
+        if (ef && c < e4) b = ef[eid * e4 + c];
+        x[0][v] = a;
+        x[1][v] = b;
+        x[2][v] = t;
+      }
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        float p = 0.f;
+#pragma unroll
+        for (int sgm = 0; sgm < 3; ++sgm)
+#pragma unroll
+          for (int v = 0; v < NV; ++v) p += dot4(g[h][sgm][v], x[sgm][v]);
+        p = wave_sum(p);
+        const float mn = fmaxf(mx[h], p);
+        const float a = expf(mx[h] - mn), b = expf(p - mn);
+        l[h] = l[h] * a + b;
+        mx[h] = mn;
+#pragma unroll
+        for (int sgm = 0; sgm < 3; ++sgm)
+#pragma unroll
+          for (int v = 0; v < NV; ++v) axpby4(acc[h][sgm][v], a, b, x[sgm][v]);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const float inv = any ? 1.f / l[h] : 0.f;
+      float4* sh = S + ((int64_t)i * NH + h) * kv4;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int c = lane + v * TG_WAVE;
+        float4 a = acc[h][0][v], b = acc[h][1][v], t = acc[h][2][v];
+        a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
+        b.x *= inv; b.y *= inv; b.z *= inv; b.w *= inv;
+        t.x *= inv; t.y *= inv; t.z *= inv; t.w *= inv;
+        if (c < d4) {
+          sh[c] = a;
+          sh[d4 + e4 + c] = t;
+        }
+        if (c < e4) sh[d4 + c] = b;
+      }
+    }
+    if (lane == 0) valid[i] = any ? 1 : 0;
+  }
+}
+
+static int attn_dims_ok(const tg_model* m) {
+  if (!m || m->d <= 0 || (m->d % 4) || m->d_e <= 0 || (m->d_e % 4) || m->n_neighbors <= 0) return 0;
+  if (m->n_head <= 0 || (2 * m->d) % m->n_head || ((2 * m->d / m->n_head) % 4)) return 0;
+  return 1;
+}
+
+struct AttnWs {
+  float *cc, *qp, *g, *s, *o, *hh, *t, *qconst;
+  uint8_t* valid;
+};
+
+static bool carve_attn(const tg_model* m, int64_t Q, Carver& cv, AttnWs& w) {
+  const int d = m->d, kvw = 2 * m->d + m->d_e, nh = m->n_head;
+  w.cc = cv.take<float>((size_t)Q * d);
+  w.qp = cv.take<float>((size_t)Q * 2 * d);
+  w.g = cv.take<float>((size_t)Q * nh * kvw);
+  w.s = cv.take<float>((size_t)Q * nh * kvw);
+  w.o = cv.take<float>((size_t)Q * 2 * d);
+  w.hh = cv.take<float>((size_t)Q * 2 * d);
+  w.t = cv.take<float>((size_t)Q * d);
+  w.qconst = cv.take<float>((size_t)2 * d);
+  w.valid = cv.take<uint8_t>((size_t)Q);
+  return cv.ok;
+}
+
+static size_t attn_ws_bytes(const tg_model* m, int64_t Q) {
+  const size_t d = m->d, kvw = 2 * m->d + m->d_e, nh = m->n_head;
+  return align16(Q * d * 4) * 2 + align16(Q * 2 * d * 4) * 3 + align16(Q * nh * kvw * 4) * 2 + align16(2 * d * 4) +
+         align16(Q);
+}
+
+}  // namespace tg
+struct tg_profiler;
+static inline void prof_mark(tg_profiler* p, int i, hipStream_t st);
+namespace tg {
+constexpr int ST_ATTN_FIRST = 5;  // == ST_ATTN_PREP (checked by a static_assert below)
+
+int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float* ts, const int64_t* l1_nids,
+                 const int64_t* l1_eids, const float* l1_ts, const float* reprs, const uint64_t* bm,
+                 const uint32_t* rank, float* out, const AttnWs& w, hipStream_t st, tg_profiler* pf = nullptr) {
+  int stage = ST_ATTN_FIRST;
+  prof_mark(pf, stage++, st);
+  const int d = m->d, d_e = m->d_e, kvw = 2 * d + d_e, nh = m->n_head, dh = 2 * d / nh, E = 2 * d;
+  hipLaunchKernelGGL(k_attn_centres, dim3(flat_grid(Q * (d / 4), 256)), dim3(256), 0, st, Q, d / 4, nids,
+                     (const float4*)reprs, bm, rank, (const float4*)m->nfeats, (float4*)w.cc);
+  hipLaunchKernelGGL(k_attn_qconst, dim3((unsigned)cdiv(2 * d, 4)), dim3(256), 0, st, d, m->attn_wq, m->attn_b_in,
+                     m->te_freq, m->te_phase, w.qconst);
+  int rc;
+  GemmArgs g{};
+  // q = (Wq [c | TE(0)] + bq) / sqrt(dh)          (F.multi_head_attention_forward scaling)
+  prof_mark(pf, stage++, st);
+  g = GemmArgs{};
+  g.m_cap = Q; g.n = E; g.k = d;
+  g.a0 = ASeg{w.cc, d, d, nullptr};
+  g.w = m->attn_wq; g.ldw = E; g.bias = w.qconst;
+  g.c = w.qp; g.ldc = E; g.alpha = 1.0f / sqrtf((float)dh); g.nbatch = 1;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  // g_h = Wk_h^T q_h   (k-major weight view: B[k][n] = Wk[h*dh + k][n])
+  prof_mark(pf, stage++, st);
+  g = GemmArgs{};
+  g.m_cap = Q; g.n = kvw; g.k = dh;
+  g.a0 = ASeg{w.qp, E, dh, nullptr}; g.a0_bs = dh;
+  g.w = m->attn_wk; g.ldw = kvw; g.w_kmajor = 1; g.w_bs = (int64_t)dh * kvw;
+  g.c = w.g; g.ldc = (int64_t)nh * kvw; g.c_bs = kvw; g.alpha = 1.f; g.nbatch = nh;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  // gather + scores + softmax + weighted raw sum
+  prof_mark(pf, stage++, st);
+  const int nv = (int)cdiv(std::max(d, d_e) / 4, TG_WAVE);
+  const unsigned cgrid = flat_grid(Q, 4);
+#define TG_CORE(NH_, NV_)                                                                                          \
+  hipLaunchKernelGGL((k_attn_core<NH_, NV_>), dim3(cgrid), dim3(256), 0, st, *m, Q, ts, l1_nids, l1_eids, l1_ts,   \
+                     (const float4*)reprs, bm, rank, (const float4*)w.g, (float4*)w.s, w.valid)
+  if (nh == 2 && nv == 1) TG_CORE(2, 1);
+  else if (nh == 2 && nv == 2) TG_CORE(2, 2);
+  else if (nh == 1 && nv == 1) TG_CORE(1, 1);
+  else if (nh == 4 && nv == 1) TG_CORE(4, 1);
+  else return TG_EUNSUPPORTED;
+#undef TG_CORE
+  // o_h = Wv_h s_h + bv_h
+  prof_mark(pf, stage++, st);
+  g = GemmArgs{};
+  g.m_cap = Q; g.n = dh; g.k = kvw;
+  g.a0 = ASeg{w.s, (int64_t)nh * kvw, kvw, nullptr}; g.a0_bs = kvw;
+  g.w = m->attn_wv; g.ldw = kvw; g.w_bs = (int64_t)dh * kvw;
+  g.bias = m->attn_b_in + 2 * E; g.bias_bs = dh;
+  g.c = w.o; g.ldc = E; g.c_bs = dh; g.alpha = 1.f; g.nbatch = nh;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  // h = Wo o + bo, zeroed for centres without neighbours (temporal_agg_modules.py:224-231)
+  prof_mark(pf, stage++, st);
+  g = GemmArgs{};
+  g.m_cap = Q; g.n = E; g.k = E;
+  g.a0 = ASeg{w.o, E, E, nullptr};
+  g.w = m->attn_out.w; g.ldw = E; g.bias = m->attn_out.b;
+  g.c = w.hh; g.ldc = E; g.row_valid = w.valid; g.alpha = 1.f; g.nbatch = 1;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  // z = fc2(relu(fc1([h | c])))   (MergeLayer, basic_modules.py:16-19)
+  prof_mark(pf, stage++, st);
+  g = GemmArgs{};
+  g.m_cap = Q; g.n = d; g.k = E + d;
+  g.a0 = ASeg{w.hh, E, E, nullptr}; g.a1 = ASeg{w.cc, d, d, nullptr};
+  g.w = m->attn_fc1.w; g.ldw = E + d; g.bias = m->attn_fc1.b;
+  g.c = w.t; g.ldc = d; g.relu = 1; g.alpha = 1.f; g.nbatch = 1;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  prof_mark(pf, stage++, st);
+  g = GemmArgs{};
+  g.m_cap = Q; g.n = d; g.k = d;
+  g.a0 = ASeg{w.t, d, d, nullptr};
+  g.w = m->attn_fc2.w; g.ldw = d; g.bias = m->attn_fc2.b;
+  g.c = out; g.ldc = d; g.alpha = 1.f; g.nbatch = 1;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  return check_launch("tg_temporal_attn_fwd");
+}
+
+// ---- message transform + updater ------------------------------------------------------
+struct ApplyWs {
+  float *t0, *t1, *t2;
+};
+
+static size_t apply_ws_bytes(const tg_model* m, int64_t cap) {
+  const size_t mw = 3 * (size_t)m->d + m->d_e;
+  size_t b = 0;
+  if (m->tsfm == TG_TSFM_MLP) b += align16(cap * (mw / 2) * 4);
+  if (m->tsfm != TG_TSFM_ID) b += align16(cap * mw * 4);
+  if (m->upd_fn == TG_UPD_MERGE) b += align16(cap * (size_t)m->d * 4);
+  return b + 16;
+}
+
+int apply_messages(const tg_model* m, const int64_t* outdated, const int32_t* out_pos, const int32_t* n_dev,
+                   int64_t cap, float* reprs, uint32_t* err, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int d = m->d, mw = 3 * m->d + m->d_e;
+  Carver cv(ws, ws_bytes);
+  ApplyWs w{};
+  if (m->tsfm == TG_TSFM_MLP) w.t0 = cv.take<float>((size_t)cap * (mw / 2));
+  if (m->tsfm != TG_TSFM_ID) w.t1 = cv.take<float>((size_t)cap * mw);
+  if (m->upd_fn == TG_UPD_MERGE) w.t2 = cv.take<float>((size_t)cap * d);
+  if (!cv.ok) return TG_EWORKSPACE;
+  hipLaunchKernelGGL(k_check_messages, dim3(flat_grid(cap, 256)), dim3(256), 0, st, *m, outdated, n_dev, cap, err);
+  int rc;
+  ASeg x{m->msg_vals, mw, mw, outdated};  // raw messages gathered from the mailbox
+  if (m->tsfm == TG_TSFM_LINEAR || m->tsfm == TG_TSFM_MLP) {
+    if (m->tsfm == TG_TSFM_MLP && ((mw / 2) % 4)) return TG_EUNSUPPORTED;
+    GemmArgs g{};
+    g.m_cap = cap; g.m_dev = n_dev; g.k = mw; g.a0 = x; g.alpha = 1.f; g.nbatch = 1;
+    g.w = m->tsfm1.w; g.ldw = mw; g.bias = m->tsfm1.b;
+    if (m->tsfm == TG_TSFM_MLP) {
+      g.n = mw / 2; g.c = w.t0; g.ldc = mw / 2; g.relu = 1;
+      if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+      g = GemmArgs{};
+      g.m_cap = cap; g.m_dev = n_dev; g.k = mw / 2; g.a0 = ASeg{w.t0, mw / 2, mw / 2, nullptr};
+      g.w = m->tsfm2.w; g.ldw = mw / 2; g.bias = m->tsfm2.b; g.alpha = 1.f; g.nbatch = 1;
+    }
+    g.n = mw; g.c = w.t1; g.ldc = mw; g.relu = 0;
+    if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+    x = ASeg{w.t1, mw, mw, nullptr};
+  }
+  const float* upd_vals = (m->upd_src == TG_SRC_LEFT) ? m->left_vals : m->right_vals;
+  ASeg h{upd_vals, d, d, outdated};
+  if (m->upd_fn == TG_UPD_GRU) {
+    GruArgs a{};
+    a.cap = cap; a.n_dev = n_dev; a.d = d; a.xw = mw; a.x = x; a.h = h;
+    a.w_ih = m->gru_w_ih; a.w_hh = m->gru_w_hh; a.b_ih = m->gru_b_ih; a.b_hh = m->gru_b_hh;
+    a.out = reprs; a.ldo = d; a.out_rows = out_pos;
+    return gru_launch(a, st);
+  }
+  GemmArgs g{};  // MergeUpdater: fc2(relu(fc1([msg | mem])))
+  g.m_cap = cap; g.m_dev = n_dev; g.n = d; g.k = mw + d; g.a0 = x; g.a1 = h;
+  g.w = m->upd_fc1.w; g.ldw = mw + d; g.bias = m->upd_fc1.b; g.c = w.t2; g.ldc = d; g.relu = 1; g.alpha = 1.f; g.nbatch = 1;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  g = GemmArgs{};
+  g.m_cap = cap; g.m_dev = n_dev; g.n = d; g.k = d; g.a0 = ASeg{w.t2, d, d, nullptr};
+  g.w = m->upd_fc2.w; g.ldw = d; g.bias = m->upd_fc2.b; g.c = reprs; g.ldc = d; g.c_rows = out_pos; g.alpha = 1.f; g.nbatch = 1;
+  return gemm_launch(g, st);
+}
+
+// unified positive-node dedup of the fused step: float32 timestamps, winner = latest ts,
+// first position among ties.  best[rank(node)] = max over positions of (ts_key << 32 | ~pos).
+__global__ void k_pos_max(int64_t B, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                          const float* __restrict__ ts, const uint64_t* __restrict__ bm,
+                          const uint32_t* __restrict__ rank, unsigned long long* __restrict__ best) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * B; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i < B ? i : i - B;
+    const int64_t node = i < B ? src[e] : dst[e];
+    const unsigned long long key = (orderable(ts[e]) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)i);
+    atomicMax(best + bm_rank(bm, rank, node), key);
+  }
+}
+
+__global__ void k_pos_winners(int64_t B, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                              const float* __restrict__ ts, const uint64_t* __restrict__ bm,
+                              const uint32_t* __restrict__ rank, const unsigned long long* __restrict__ best,
+                              int64_t* __restrict__ upos, int64_t* __restrict__ index, int32_t* __restrict__ count) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * B; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i < B ? i : i - B;
+    const int64_t node = i < B ? src[e] : dst[e];
+    const unsigned long long key = (orderable(ts[e]) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)i);
+    if (best[bm_rank(bm, rank, node)] == key) {
+      const int slot = atomicAdd(count, 1);
+      upos[slot] = node;
+      index[slot] = i;
+    }
+  }
+}
+
+// batch slice -> query arrays: nids3 = cat[src, dst, neg], ts3 = tile(ts, 3) (float64 for the
+// sampler, float32 for the model, data_loader.py:79-81,92), eids copy.  `off` (nullable)
+// is the device-resident element offset of the batch inside the stream arrays.
+__global__ void k_build_queries(int64_t B, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                                const int64_t* __restrict__ neg, const double* __restrict__ ts,
+                                const int64_t* __restrict__ eids, const int64_t* __restrict__ off,
+                                int64_t* __restrict__ nids3, double* __restrict__ ts3, float* __restrict__ ts3f,
+                                int64_t* __restrict__ eids_b) {
+  const int64_t o = off ? *off : 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * B; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i % B;
+    const int r = (int)(i / B);
+    nids3[i] = r == 0 ? src[o + e] : (r == 1 ? dst[o + e] : neg[o + e]);
+    const double t = ts[o + e];
+    ts3[i] = t;
+    ts3f[i] = (float)t;
+    if (r == 0) eids_b[e] = eids[o + e];
+  }
+}
+
+__global__ void k_advance(int64_t* off, int64_t B) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *off += B;
+}
+
+int unique_compact_launch(const uint64_t* bm, int64_t n_nodes, uint32_t* rank, int64_t* ids, int32_t* count,
+                          int64_t cap, const uint64_t* hm, uint32_t* rank2, int64_t* ids2, int32_t* pos2,
+                          int32_t* count2, void* ws, size_t ws_bytes, hipStream_t st);
+
+}  // namespace tg
+
+using namespace tg;
+
+extern "C" size_t tg_temporal_attn_workspace_bytes(const tg_model* m, int64_t Q) {
+  if (!attn_dims_ok(m) || Q < 0) return 0;
+  return attn_ws_bytes(m, Q) + 64;
+}
+
+extern "C" int tg_temporal_attn_fwd(const tg_model* m, int64_t Q, const int64_t* nids, const float* ts,
+                                    const int64_t* l1_nids, const int64_t* l1_eids, const float* l1_ts,
+                                    const float* reprs, const uint64_t* bitmap, const uint32_t* rank, float* out,
+                                    void* ws, size_t ws_bytes, void* stream) {
+  if (!attn_dims_ok(m) || Q < 0) return TG_EINVAL;
+  if (Q == 0) return TG_OK;
+  if (!nids || !ts || !l1_nids || !l1_eids || !l1_ts || !reprs || !bitmap || !rank || !out) return TG_EINVAL;
+  Carver cv(ws, ws_bytes);
+  AttnWs w{};
+  if (!carve_attn(m, Q, cv, w)) return TG_EWORKSPACE;
+  return attn_forward(m, Q, nids, ts, l1_nids, l1_eids, l1_ts, reprs, bitmap, rank, out, w, as_stream(stream));
+}
+
+extern "C" int tg_linear_fwd(int64_t n, const float* x, int32_t in_f, const tg_linear* lin, int32_t out_f, int32_t relu,
+                             float* out, void* stream) {
+  if (n < 0 || in_f <= 0 || (in_f % 4) || out_f <= 0 || !lin) return TG_EINVAL;
+  if (n == 0) return TG_OK;
+  if (!x || !lin->w || !out) return TG_EINVAL;
+  GemmArgs g{};
+  g.m_cap = n; g.n = out_f; g.k = in_f; g.a0 = ASeg{x, in_f, in_f, nullptr};
+  g.w = lin->w; g.ldw = in_f; g.bias = lin->b; g.c = out; g.ldc = out_f; g.relu = relu; g.alpha = 1.f; g.nbatch = 1;
+  return gemm_launch(g, as_stream(stream));
+}
+
+extern "C" int tg_gru_fwd(int64_t n, const float* x, int32_t xw, const float* h, int32_t d, const float* w_ih,
+                          const float* w_hh, const float* b_ih, const float* b_hh, float* out, void* stream) {
+  if (n < 0 || d <= 0 || (d % 4) || xw <= 0 || (xw % 4)) return TG_EINVAL;
+  if (n == 0) return TG_OK;
+  if (!x || !h || !w_ih || !w_hh || !b_ih || !b_hh || !out) return TG_EINVAL;
+  GruArgs a{};
+  a.cap = n; a.d = d; a.xw = xw; a.x = ASeg{x, xw, xw, nullptr}; a.h = ASeg{h, d, d, nullptr};
+  a.w_ih = w_ih; a.w_hh = w_hh; a.b_ih = b_ih; a.b_hh = b_hh; a.out = out; a.ldo = d;
+  return gru_launch(a, as_stream(stream));
+}
+
+extern "C" size_t tg_apply_messages_workspace_bytes(const tg_model* m, int64_t cap) {
+  if (!attn_dims_ok(m) || cap < 0) return 0;
+  return apply_ws_bytes(m, cap);
+}
+
+extern "C" int tg_apply_messages(const tg_model* m, const int64_t* outdated, const int32_t* out_pos,
+                                 const int32_t* n_outdated, int64_t cap, float* reprs, uint32_t* err, void* ws,
+                                 size_t ws_bytes, void* stream) {
+  if (!attn_dims_ok(m) || cap < 0) return TG_EINVAL;
+  if (cap == 0) return TG_OK;
+  if (!outdated || !out_pos || !n_outdated || !reprs || !err) return TG_EINVAL;
+  return apply_messages(m, outdated, out_pos, n_outdated, cap, reprs, err, ws, ws_bytes, as_stream(stream));
+}
+
+// ---------------------------------------------------------------------------------
+// Fused streaming step
+// ---------------------------------------------------------------------------------
+namespace tg {
+enum Stage : int {
+  ST_QUERIES = 0, ST_SAMPLE, ST_COMPACT, ST_GATHER, ST_UPDATE, ST_ATTN_PREP, ST_ATTN_Q, ST_ATTN_G, ST_ATTN_CORE,
+  ST_ATTN_V, ST_ATTN_O, ST_ATTN_FC1, ST_ATTN_FC2, ST_DEDUP, ST_WRITE_RIGHT, ST_STORE_EVENTS, ST_WRITE_LEFT, ST_COUNT
+};
+static const char* const kStageNames[ST_COUNT] = {
+    "build_queries", "sample_recent_edges", "unique_compact", "gather_right_memory", "apply_messages(gru)",
+    "attn_centres+qconst", "attn_gemm_q", "attn_gemm_g", "attn_core(gather+softmax)", "attn_gemm_v", "attn_gemm_out",
+    "attn_gemm_fc1", "attn_gemm_fc2", "dedup_positive", "write_right_memory", "store_events", "write_left_memory"};
+static_assert(ST_ATTN_PREP == ST_ATTN_FIRST, "attention stage numbering");
+}  // namespace tg
+
+struct tg_profiler {
+  hipEvent_t ev[tg::ST_COUNT + 1];
+  bool armed;
+};
+
+static inline void prof_mark(tg_profiler* p, int i, hipStream_t st) {
+  if (p) hipEventRecord(p->ev[i], st);
+}
+
+extern "C" tg_profiler* tg_profiler_create(void) {
+  tg_profiler* p = new tg_profiler();
+  p->armed = false;
+  for (int i = 0; i <= ST_COUNT; ++i)
+    if (hipEventCreate(&p->ev[i]) != hipSuccess) {
+      delete p;
+      return nullptr;
+    }
+  return p;
+}
+extern "C" void tg_profiler_destroy(tg_profiler* p) {
+  if (!p) return;
+  for (int i = 0; i <= ST_COUNT; ++i) hipEventDestroy(p->ev[i]);
+  delete p;
+}
+extern "C" int tg_profiler_num_stages(void) { return ST_COUNT; }
+extern "C" const char* tg_profiler_stage_name(int stage) {
+  return (stage >= 0 && stage < ST_COUNT) ? kStageNames[stage] : "";
+}
+extern "C" int tg_profiler_read(tg_profiler* p, float* ms_out) {
+  if (!p || !ms_out || !p->armed) return TG_EINVAL;
+  hipError_t e = hipEventSynchronize(p->ev[ST_COUNT]);
+  if (e != hipSuccess) {
+    set_hip_error(e, "tg_profiler_read");
+    return TG_EHIP;
+  }
+  for (int i = 0; i < ST_COUNT; ++i) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]);
+    ms_out[i] = ms;
+  }
+  return TG_OK;
+}
+
+struct StepWs {
+  uint64_t* bm;              // involved bitmap            (zeroed every step)
+  unsigned long long* best;  // per involved rank          (zeroed every step)
+  int32_t* counts;           // [4]                        (zeroed every step)
+  size_t zero_bytes;         // size of the contiguous zeroed region starting at bm
+  uint32_t *rank, *rank_out;
+  int64_t *nids3, *eids, *involved, *outdated, *upos, *index;
+  double* ts3;
+  float *ts3f, *l1_ts, *reprs;
+  int64_t *l1_nids, *l1_eids;
+  int32_t* out_pos;
+  void* scan_ws;
+  size_t scan_bytes;
+  AttnWs attn;
+  void* apply_ws;
+  size_t apply_bytes;
+};
+
+static bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w) {
+  const int64_t Q = 3 * B, K = m->n_neighbors, cap = Q * (K + 1);
+  const int64_t W = (m->n_nodes + 63) / 64;
+  char* z0 = cv.p;
+  w.bm = cv.take<uint64_t>((size_t)W);
+  w.best = cv.take<unsigned long long>((size_t)cap);
+  w.counts = cv.take<int32_t>(4);
+  w.zero_bytes = cv.ok ? (size_t)(cv.p - z0) : 0;
+  w.rank = cv.take<uint32_t>((size_t)W + 1);
+  w.rank_out = cv.take<uint32_t>((size_t)W + 1);
+  w.nids3 = cv.take<int64_t>((size_t)Q);
+  w.eids = cv.take<int64_t>((size_t)B);
+  w.ts3 = cv.take<double>((size_t)Q);
+  w.ts3f = cv.take<float>((size_t)Q);
+  w.l1_nids = cv.take<int64_t>((size_t)Q * K);
+  w.l1_eids = cv.take<int64_t>((size_t)Q * K);
+  w.l1_ts = cv.take<float>((size_t)Q * K);
+  w.involved = cv.take<int64_t>((size_t)cap);
+  w.outdated = cv.take<int64_t>((size_t)cap);
+  w.out_pos = cv.take<int32_t>((size_t)cap);
+  w.upos = cv.take<int64_t>((size_t)2 * B);
+  w.index = cv.take<int64_t>((size_t)2 * B);
+  w.reprs = cv.take<float>((size_t)cap * m->d);
+  w.scan_bytes = tg_unique_compact_workspace_bytes(m->n_nodes);
+  w.scan_ws = cv.take<char>(w.scan_bytes);
+  if (!carve_attn(m, Q, cv, w.attn)) return false;
+  w.apply_bytes = apply_ws_bytes(m, cap);
+  w.apply_ws = cv.take<char>(w.apply_bytes);
+  return cv.ok;
+}
+
+extern "C" size_t tg_stream_step_workspace_bytes(const tg_model* m, int64_t B) {
+  if (!attn_dims_ok(m) || B <= 0 || m->n_nodes <= 0) return 0;
+  const size_t Q = 3 * (size_t)B, K = m->n_neighbors, cap = Q * (K + 1), W = (m->n_nodes + 63) / 64;
+  size_t b = align16(W * 8) + align16(cap * 8) + 16 + 2 * align16((W + 1) * 4) + align16(Q * 8) * 2 + align16(B * 8) +
+             align16(Q * 4) + align16(Q * K * 8) * 2 + align16(Q * K * 4) + align16(cap * 8) * 2 + align16(cap * 4) +
+             align16(2 * B * 8) * 2 + align16(cap * m->d * 4) + align16(tg_unique_compact_workspace_bytes(m->n_nodes)) +
+             attn_ws_bytes(m, Q) + align16(apply_ws_bytes(m, cap));
+  return b + 256;
+}
+
+extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, void* ws, size_t ws_bytes,
+                              void* stream) {
+  if (!attn_dims_ok(m) || !g || !io || io->B <= 0) return TG_EINVAL;
+  if (!io->src || !io->dst || !io->neg || !io->ts || !io->eids || !io->h || !io->err) return TG_EINVAL;
+  if (g->num_node != m->n_nodes) return TG_EINVAL;
+  hipStream_t st = as_stream(stream);
+  tg_profiler* pf = (tg_profiler*)io->profiler;
+  const int64_t B = io->B, Q = 3 * B, K = m->n_neighbors, cap = Q * (K + 1);
+  Carver cv(ws, ws_bytes);
+  StepWs w{};
+  if (!carve_step(m, B, cv, w)) return TG_EWORKSPACE;
+  prof_mark(pf, ST_QUERIES, st);
+  hipError_t e = hipMemsetAsync(w.bm, 0, w.zero_bytes, st);
+  if (e != hipSuccess) {
+    set_hip_error(e, "tg_stream_step memset");
+    return TG_EHIP;
+  }
+  int rc;
+  // ---- collate (data_loader.py:77-131): queries, temporal neighbours, involved set
+  hipLaunchKernelGGL(k_build_queries, dim3(flat_grid(Q, 256)), dim3(256), 0, st, B, io->src, io->dst, io->neg, io->ts,
+                     io->eids, io->offset_dev, w.nids3, w.ts3, w.ts3f, w.eids);
+  const int64_t* src = w.nids3;
+  const int64_t* dst = w.nids3 + B;
+  prof_mark(pf, ST_SAMPLE, st);
+  int64_t* l1n = io->l1_nids ? io->l1_nids : w.l1_nids;
+  int64_t* l1e = io->l1_eids ? io->l1_eids : w.l1_eids;
+  float* l1t = io->l1_ts ? io->l1_ts : w.l1_ts;
+  if ((rc = tg_sample_recent_edges(g, Q, w.nids3, w.ts3, (int32_t)K, l1n, l1e, l1t, nullptr, w.bm, stream)) != TG_OK)
+    return rc;
+  prof_mark(pf, ST_COMPACT, st);
+  int64_t* involved = io->involved ? io->involved : w.involved;
+  // involved = sorted(set(...)); outdated = involved & has-message (memory.py:108-126)
+  if ((rc = unique_compact_launch(w.bm, m->n_nodes, w.rank, involved, w.counts + 0, cap, m->has_msg, w.rank_out,
+                                  w.outdated, w.out_pos, w.counts + 1, w.scan_ws, w.scan_bytes, st)) != TG_OK)
+    return rc;
+  prof_mark(pf, ST_GATHER, st);
+  // ---- STEP 1-2: reprs = right_memory[involved]; outdated rows <- updater(...)
+  if ((rc = tg_mailbox_consume_gather(m, involved, w.counts + 0, cap, w.reprs, stream)) != TG_OK) return rc;
+  prof_mark(pf, ST_UPDATE, st);
+  if ((rc = apply_messages(m, w.outdated, w.out_pos, w.counts + 1, cap, w.reprs, io->err, w.apply_ws, w.apply_bytes,
+                           st)) != TG_OK)
+    return rc;
+  // ---- STEP 3: temporal embeddings of cat[src, dst, neg]
+  if ((rc = attn_forward(m, Q, w.nids3, w.ts3f, l1n, l1e, l1t, w.reprs, w.bm, w.rank, io->h, w.attn, st, pf)) != TG_OK)
+    return rc;
+  prof_mark(pf, ST_DEDUP, st);
+  // ---- dedup of positive nodes (select_latest_nids on float32 ts, tiger.py:232,419; memory.py:98)
+  hipLaunchKernelGGL(k_pos_max, dim3(flat_grid(2 * B, 256)), dim3(256), 0, st, B, src, dst, w.ts3f, w.bm, w.rank, w.best);
+  hipLaunchKernelGGL(k_pos_winners, dim3(flat_grid(2 * B, 256)), dim3(256), 0, st, B, src, dst, w.ts3f, w.bm, w.rank,
+                     w.best, w.upos, w.index, w.counts + 2);
+  prof_mark(pf, ST_WRITE_RIGHT, st);
+  // ---- STEP 4: consumed positive nodes -> right memory
+  if ((rc = tg_consume_update_right(m, w.upos, w.counts + 2, 2 * B, w.reprs, w.bm, w.rank, io->err, stream)) != TG_OK)
+    return rc;
+  prof_mark(pf, ST_STORE_EVENTS, st);
+  // ---- STEP 5: mailbox <- messages of this batch (reads message memory after STEP 4, before STEP 6)
+  if ((rc = tg_store_events(m, B, src, dst, w.ts3f, w.eids, w.upos, w.index, w.counts + 2, io->err, stream)) != TG_OK)
+    return rc;
+  prof_mark(pf, ST_WRITE_LEFT, st);
+  // ---- side outputs for the restarter (tiger.py:248-251)
+  if (io->h_prev_left) {
+    if ((rc = tg_gather_rows(2 * B, w.nids3, m->d, m->left_vals, io->h_prev_left, nullptr, nullptr, stream)) != TG_OK)
+      return rc;
+  }
+  if (io->h_prev_right) {
+    if ((rc = tg_gather_rows(2 * B, w.nids3, m->d, m->right_vals, io->h_prev_right, nullptr, nullptr, stream)) != TG_OK)
+      return rc;
+  }
+  // ---- STEP 6: left memory <- h(t-) of the winning occurrence of each positive node
+  if ((rc = tg_memory_scatter(2 * B, w.counts + 2, w.upos, w.index, m->d, io->h, w.ts3f, m->left_vals, m->left_ts,
+                              m->left_active, 1, io->err, stream)) != TG_OK)
+    return rc;
+  if (io->counts) {
+    e = hipMemcpyAsync(io->counts, w.counts, 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) {
+      set_hip_error(e, "tg_stream_step counts copy");
+      return TG_EHIP;
+    }
+  }
+  if (io->offset_dev && io->advance) hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, io->offset_dev, B);
+  prof_mark(pf, ST_COUNT, st);
+  if (pf) pf->armed = true;
+  return check_launch("tg_stream_step");
+}

@@ -1,0 +1,241 @@
+// SeqRestarter forward (tiger/model/restarters.py:51-114).
+//
+// The reference runs a full self-attention over the last H events and then takes the
+// MEAN over the H outputs.  The mean is linear, so only the column means of the
+// attention matrix are needed:  mean_t(out_t) = Wo concat_h(Wv_h (sum_s abar_h[s] x_s) + bv_h) + bo
+// with abar_h[s] = (1/H) sum_t A_h[t,s]  (rows of A sum to one, so bv passes through).
+// Q and K still need every position (H x H scores); V and the output projection collapse
+// to one row per node.  Identical maths, ~half the flops.
+#include "tg_dense.h"
+
+namespace tg {
+
+static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// X[(i,t), :] = [nfeat[src] | nfeat[dst] | anony_emb[anon] | efeat[eid] | TE_r(ts_last - ts_t)],
+// with the first dm-d columns of the last event zeroed (restarters.py:98-103).
+__global__ void k_seq_build(tg_model m, tg_seq_restarter r, int64_t n, const int64_t* __restrict__ nids,
+                            const int64_t* __restrict__ h_n, const int64_t* __restrict__ anon,
+                            const int64_t* __restrict__ h_e, const float* __restrict__ h_t,
+                            const int64_t* __restrict__ h_d, float4* __restrict__ X, float* __restrict__ prev_ts) {
+  const int H = r.hist_len, d4 = m.d / 4, e4 = m.d_e / 4;
+  const int row4 = 4 * d4 + e4;
+  const int64_t total = n * H * row4;
+  const float4* nf = reinterpret_cast<const float4*>(m.nfeats);
+  const float4* ef = reinterpret_cast<const float4*>(m.efeats);
+  const float4* ae = reinterpret_cast<const float4*>(r.anony_emb);
+  const float4* fq = reinterpret_cast<const float4*>(r.te_freq);
+  const float4* ph = reinterpret_cast<const float4*>(r.te_phase);
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t rowi = t / row4;
+    const int c = (int)(t - rowi * row4);
+    const int64_t i = rowi / H;
+    const int pos = (int)(rowi - i * H);
+    const bool last = pos == H - 1;
+    float4 v = z;
+    if (c >= 3 * d4 + e4) {
+      const int cc = c - 3 * d4 - e4;
+      const float dt = h_t[i * H + H - 1] - h_t[rowi];
+      const float4 w = fq[cc], q = ph[cc];
+      v = make_float4(time_enc(dt, w.x, q.x), time_enc(dt, w.y, q.y), time_enc(dt, w.z, q.z), time_enc(dt, w.w, q.w));
+    } else if (!last) {
+      if (c < 2 * d4) {
+        if (nf) {
+          const int64_t dir = h_d[rowi];
+          const int64_t self = nids[i], oth = h_n[rowi];
+          // dir == 1: the query node was the destination (graph.py:239-240)
+          const int64_t s_n = dir ? self : oth, d_n = dir ? oth : self;
+          v = c < d4 ? nf[s_n * d4 + c] : nf[d_n * d4 + (c - d4)];
+        }
+      } else if (c < 3 * d4) {
+        v = ae[anon[rowi] * d4 + (c - 2 * d4)];
+      } else if (ef) {
+        v = ef[h_e[rowi] * e4 + (c - 3 * d4)];
+      }
+    }
+    X[t] = v;
+    if (c == 0 && last) prev_ts[i] = h_t[rowi];
+  }
+}
+
+// One block per (node, head): scores = q k^T / sqrt(dh) over the H x H grid, key padding
+// mask, row softmax, column mean.  qk is [n*H, 2*dm] = [q | k].
+template <int HMAX>
+__global__ void __launch_bounds__(256) k_seq_scores(int64_t n, int H, int dm, int nh, const float* __restrict__ qk,
+                                                    const int64_t* __restrict__ h_n, float* __restrict__ abar) {
+  constexpr int CH = 32;                   // dh chunk staged per iteration
+  constexpr int PPT = (HMAX * HMAX + 255) / 256;  // (t,s) pairs per thread
+  __shared__ float sq[HMAX][CH + 1], sk[HMAX][CH + 1];
+  __shared__ float sc[HMAX][HMAX + 1];
+  const int64_t i = blockIdx.x / nh;
+  const int h = blockIdx.x % nh;
+  const int dh = dm / nh;
+  const int tid = threadIdx.x;
+  float acc[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) acc[j] = 0.f;
+  const float* base = qk + (int64_t)i * H * 2 * dm + (int64_t)h * dh;
+  for (int c0 = 0; c0 < dh; c0 += CH) {
+    for (int f = tid; f < H * CH; f += 256) {
+      const int row = f / CH, cc = f % CH;
+      const bool ok = c0 + cc < dh;
+      sq[row][cc] = ok ? base[(int64_t)row * 2 * dm + c0 + cc] : 0.f;
+      sk[row][cc] = ok ? base[(int64_t)row * 2 * dm + dm + c0 + cc] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int p = tid + j * 256;
+      if (p < H * H) {
+        const int t = p / H, s = p % H;
+        float a = acc[j];
+#pragma unroll
+        for (int cc = 0; cc < CH; ++cc) a += sq[t][cc] * sk[s][cc];
+        acc[j] = a;
+      }
+    }
+    __syncthreads();
+  }
+  const float scale = 1.0f / sqrtf((float)dh);
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int p = tid + j * 256;
+    if (p < H * H) {
+      const int t = p / H, s = p % H;
+      const bool masked = (s != H - 1) && (h_n[i * H + s] == 0);  // restarters.py:86-87
+      sc[t][s] = masked ? -INFINITY : acc[j] * scale;
+    }
+  }
+  __syncthreads();
+  if (tid < H) {  // row softmax
+    float mx = -INFINITY;
+    for (int s = 0; s < H; ++s) mx = fmaxf(mx, sc[tid][s]);
+    float sum = 0.f;
+    for (int s = 0; s < H; ++s) {
+      const float e = expf(sc[tid][s] - mx);
+      sc[tid][s] = e;
+      sum += e;
+    }
+    const float inv = 1.f / sum;
+    for (int s = 0; s < H; ++s) sc[tid][s] *= inv;
+  }
+  __syncthreads();
+  if (tid < H) {  // column mean
+    float a = 0.f;
+    for (int t = 0; t < H; ++t) a += sc[t][tid];
+    abar[((int64_t)i * nh + h) * H + tid] = a / (float)H;
+  }
+}
+
+// xbar[i, h, :] = sum_s abar[i, h, s] * X[(i, s), :]
+__global__ void k_seq_mix(int64_t n, int H, int row4, int nh, const float* __restrict__ abar,
+                          const float4* __restrict__ X, float4* __restrict__ xbar) {
+  const int64_t total = n * nh * row4;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(t % row4);
+    const int64_t ih = t / row4;
+    const int64_t i = ih / nh;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < H; ++s) {
+      const float w = abar[ih * H + s];
+      const float4 x = X[((int64_t)i * H + s) * row4 + c];
+      a.x += w * x.x; a.y += w * x.y; a.z += w * x.z; a.w += w * x.w;
+    }
+    xbar[t] = a;
+  }
+}
+
+struct SeqWs {
+  float *x, *qk, *abar, *xbar, *o, *om;
+};
+
+static bool carve_seq(const tg_model* m, const tg_seq_restarter* r, int64_t n, char* p, size_t bytes, SeqWs& w) {
+  const size_t dm = 4 * (size_t)m->d + m->d_e, H = r->hist_len, nh = r->n_head;
+  size_t need[6] = {align16(n * H * dm * 4), align16(n * H * 2 * dm * 4), align16(n * nh * H * 4),
+                    align16(n * nh * dm * 4), align16(n * dm * 4), align16(n * dm * 4)};
+  float** out[6] = {&w.x, &w.qk, &w.abar, &w.xbar, &w.o, &w.om};
+  size_t off = 0;
+  for (int k = 0; k < 6; ++k) {
+    if (off + need[k] > bytes) return false;
+    *out[k] = (float*)(p + off);
+    off += need[k];
+  }
+  return true;
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+static int seq_ok(const tg_model* m, const tg_seq_restarter* r) {
+  if (!m || !r || m->d <= 0 || (m->d % 4) || m->d_e <= 0 || (m->d_e % 4)) return 0;
+  const int dm = 4 * m->d + m->d_e;
+  if (r->hist_len <= 0 || r->n_head <= 0 || dm % r->n_head || ((dm / r->n_head) % 4)) return 0;
+  return 1;
+}
+
+extern "C" size_t tg_restart_seq_workspace_bytes(const tg_model* m, const tg_seq_restarter* r, int64_t n) {
+  if (!seq_ok(m, r) || n < 0) return 0;
+  const size_t dm = 4 * (size_t)m->d + m->d_e, H = r->hist_len, nh = r->n_head;
+  return align16(n * H * dm * 4) + align16(n * H * 2 * dm * 4) + align16(n * nh * H * 4) + align16(n * nh * dm * 4) +
+         2 * align16(n * dm * 4) + 64;
+}
+
+extern "C" int tg_restart_seq_fwd(const tg_model* m, const tg_seq_restarter* r, int64_t n, const int64_t* nids,
+                                  const int64_t* h_n, const int64_t* anon, const int64_t* h_e, const float* h_t,
+                                  const int64_t* h_d, float* h_left, float* h_right, float* prev_ts, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  if (!seq_ok(m, r) || n < 0) return TG_EINVAL;
+  if (r->hist_len > 64) return TG_EUNSUPPORTED;
+  if (n == 0) return TG_OK;
+  if (!nids || !h_n || !anon || !h_e || !h_t || !h_d || !h_left || !h_right || !prev_ts) return TG_EINVAL;
+  SeqWs w{};
+  if (!ws || !carve_seq(m, r, n, (char*)ws, ws_bytes, w)) return TG_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  const int d = m->d, dm = 4 * m->d + m->d_e, H = r->hist_len, nh = r->n_head, dh = dm / nh;
+  hipLaunchKernelGGL(k_seq_build, dim3(flat_grid(n * H * (dm / 4), 256)), dim3(256), 0, st, *m, *r, n, nids, h_n, anon,
+                     h_e, h_t, h_d, (float4*)w.x, prev_ts);
+  int rc;
+  GemmArgs g{};
+  // [q | k] = X Win[0:2dm]^T + b[0:2dm]
+  g.m_cap = n * H; g.n = 2 * dm; g.k = dm; g.a0 = ASeg{w.x, dm, dm, nullptr};
+  g.w = r->in_proj_w; g.ldw = dm; g.bias = r->in_proj_b; g.c = w.qk; g.ldc = 2 * dm; g.alpha = 1.f; g.nbatch = 1;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  if (H <= 40)
+    hipLaunchKernelGGL((k_seq_scores<40>), dim3((unsigned)(n * nh)), dim3(256), 0, st, n, H, dm, nh, w.qk, h_n, w.abar);
+  else
+    hipLaunchKernelGGL((k_seq_scores<64>), dim3((unsigned)(n * nh)), dim3(256), 0, st, n, H, dm, nh, w.qk, h_n, w.abar);
+  hipLaunchKernelGGL(k_seq_mix, dim3(flat_grid(n * nh * (dm / 4), 256)), dim3(256), 0, st, n, H, dm / 4, nh, w.abar,
+                     (const float4*)w.x, (float4*)w.xbar);
+  // o[:, h] = Wv_h xbar_h + bv_h
+  g = GemmArgs{};
+  g.m_cap = n; g.n = dh; g.k = dm; g.a0 = ASeg{w.xbar, (int64_t)nh * dm, dm, nullptr}; g.a0_bs = dm;
+  g.w = r->in_proj_w + (int64_t)2 * dm * dm; g.ldw = dm; g.w_bs = (int64_t)dh * dm;
+  g.bias = r->in_proj_b + 2 * dm; g.bias_bs = dh; g.c = w.o; g.ldc = dm; g.c_bs = dh; g.alpha = 1.f; g.nbatch = nh;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  // relu(mean_t out_t) = relu(Wo o + bo)
+  g = GemmArgs{};
+  g.m_cap = n; g.n = dm; g.k = dm; g.a0 = ASeg{w.o, dm, dm, nullptr};
+  g.w = r->out_proj.w; g.ldw = dm; g.bias = r->out_proj.b; g.c = w.om; g.ldc = dm; g.relu = 1; g.alpha = 1.f; g.nbatch = 1;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  // h(t'-) = out_fn(...)
+  g = GemmArgs{};
+  g.m_cap = n; g.n = d; g.k = dm; g.a0 = ASeg{w.om, dm, dm, nullptr};
+  g.w = r->out_fn.w; g.ldw = dm; g.bias = r->out_fn.b; g.c = h_left; g.ldc = d; g.alpha = 1.f; g.nbatch = 1;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  // h(t'+) = merger(h_left, last_event_feat) where last_event_feat is all zeros: the
+  // reference takes a VIEW of full_vals and zeroes it in place before use
+  // (restarters.py:102-103), so only the first d columns of fc1 contribute.
+  g = GemmArgs{};
+  g.m_cap = n; g.n = d; g.k = d; g.a0 = ASeg{h_left, d, d, nullptr};
+  g.w = r->fc1.w; g.ldw = dm; g.bias = r->fc1.b; g.c = w.om; g.ldc = d; g.relu = 1; g.alpha = 1.f; g.nbatch = 1;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  g = GemmArgs{};
+  g.m_cap = n; g.n = d; g.k = d; g.a0 = ASeg{w.om, d, d, nullptr};
+  g.w = r->fc2.w; g.ldw = d; g.bias = r->fc2.b; g.c = h_right; g.ldc = d; g.alpha = 1.f; g.nbatch = 1;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  // NB: the reference's invalid_rows mask can never fire (mask[:, -1] is cleared before
+  // .all(1), restarters.py:86-88), so nothing is zeroed here either.
+  return check_launch("tg_restart_seq_fwd");
+}

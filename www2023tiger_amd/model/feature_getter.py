@@ -1,0 +1,47 @@
+"""Mirror of tiger/model/feature_getter.py (NumericalFeature)."""
+from typing import Optional
+
+import torch
+from torch import Tensor, nn
+
+from .. import hip_ops
+
+
+class NumericalFeature(nn.Module):
+    """Raw node / edge feature tables.  A missing table means zeros of width `dim`
+    (feature_getter.py:81-85,95-99).  The HIP engine reads the tables in place; the
+    get_* methods are the standalone lookups (tg_gather_rows)."""
+
+    def __init__(self, nfeats: Optional[Tensor], efeats: Optional[Tensor], dim: int, *, use_tsfm: bool = False,
+                 register_buffer: bool = True, device: torch.device = None):
+        super().__init__()
+        if use_tsfm:
+            raise NotImplementedError('use_tsfm is never enabled by init_model (init_utils.py:137-139)')
+        self.pin_mem = register_buffer
+        self.device = device
+        self.use_tsfm = use_tsfm
+        self.out_dim = dim
+        self.n_nodes = self.n_edges = None
+        nd = ed = None
+        if nfeats is not None:
+            self.n_nodes, nd = nfeats.shape
+        if efeats is not None:
+            self.n_edges, ed = efeats.shape
+        # buffers are non-persistent like the reference (not part of the state_dict)
+        self.register_buffer('nfeats', None if nfeats is None else nfeats.float().contiguous(), persistent=False)
+        self.register_buffer('efeats', None if efeats is None else efeats.float().contiguous(), persistent=False)
+        self.nfeat_dim = nd if nd else dim
+        self.efeat_dim = ed if ed else dim
+
+    def _lookup(self, table, ids, width):
+        if table is None:
+            return torch.zeros(*ids.shape, width, device=ids.device)
+        if table.device != ids.device:
+            table = table.to(ids.device)
+        return hip_ops.gather_rows(table, ids)
+
+    def get_node_embeddings(self, nids: Tensor) -> Tensor:
+        return self._lookup(self.nfeats, nids, self.out_dim)
+
+    def get_edge_embeddings(self, eids: Tensor) -> Tensor:
+        return self._lookup(self.efeats, eids, self.out_dim)

@@ -1,0 +1,436 @@
+"""Mirror of tiger/model/tiger.py: `TIGE` / `TIGER` with the reference's constructor,
+method names, buffer/parameter names (state_dict compatible, alias keys included),
+executed by libtiger_hip.so.
+
+Two ways to run a batch:
+  * `contrast_learning(src, dst, neg, ts, eids, computation_graph)` - the reference
+    signature; the collator's ComputationGraph supplies neighbours and the involved
+    set, STEP 1-6 run as HIP entry points, STEP 7 (score head + BCE) in torch.
+  * `stream_step(src, dst, neg, ts64, eids)` - collation and STEP 1-6 fused behind one
+    C call (tg_stream_step) with no host synchronisation; the benchmarked path.
+Forward only: gradients are not propagated through the HIP kernels (the training
+tail is the next scope row, SURVEY.md s8 f 1).
+"""
+import ctypes as C
+from typing import Optional, Tuple, Union
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+
+from .. import hip_ops
+from .._lib import TgLinear, TgModel, TgStepIo, check, lib, ptr
+from ..hip_ops import stream_ptr
+from .basic_modules import MergeLayer
+from .memory import Memory, MessageStoreNoGradLastOnly
+from .message_modules import (IdentityMessageFunction, LastMessageAggregatorNoGradLastOnly, LinearMessageFunction,
+                              MLPMessageFunction)
+from .temporal_agg_modules import GraphAttnEmbedding
+from .time_encoding import TimeEncode
+from .update_modules import GRUUpdater, MergeUpdater
+from .utils import select_latest_nids
+
+_TSFM = {'id': 0, 'linear': 1, 'mlp': 2}
+_UPD = {'gru': 0, 'merge': 1}
+
+
+class TIGE(nn.Module):
+    def __init__(self, *, raw_feat_getter, graph, n_neighbors: int = 20, n_layers: int = 2, n_head: int = 2,
+                 dropout: float = 0.1, msg_src: str, upd_src: str, msg_tsfm_type: str = 'id',
+                 mem_update_type: str = 'gru', tgn_mode: bool = True, msg_last_only: bool = True,
+                 hit_type: str = 'none'):
+        super().__init__()
+        if not msg_last_only:
+            raise NotImplementedError('only the last-message mailbox is built (init_utils.py:166)')
+        self.raw_feat_getter = raw_feat_getter
+        self.n_nodes = raw_feat_getter.n_nodes
+        self.nfeat_dim = raw_feat_getter.nfeat_dim
+        self.efeat_dim = raw_feat_getter.efeat_dim
+        self.time_encoder = TimeEncode(dim=self.nfeat_dim)
+        self.tfeat_dim = self.time_encoder.dim
+        self.memory_dim = self.nfeat_dim
+        self.raw_msg_dim = self.memory_dim * 2 + self.efeat_dim + self.tfeat_dim
+        self.n_neighbors, self.n_layers, self.n_head = n_neighbors, n_layers, n_head
+        self.msg_src, self.upd_src = msg_src, upd_src
+        self.tgn_mode, self.msg_last_only = True, True
+        self._sanity_check()
+
+        self.left_memory = Memory(self.n_nodes, self.memory_dim)
+        self.right_memory = Memory(self.n_nodes, self.memory_dim)
+        self.msg_store = MessageStoreNoGradLastOnly(self.n_nodes, dim=self.raw_msg_dim)
+        # module aliases: they appear as extra state_dict keys exactly as in the reference
+        self.msg_memory = self.left_memory if msg_src == 'left' else self.right_memory
+        self.upd_memory = self.left_memory if upd_src == 'left' else self.right_memory
+        self.msg_aggregate_fn = LastMessageAggregatorNoGradLastOnly(raw_feat_getter=raw_feat_getter,
+                                                                   time_encoder=self.time_encoder)
+        fn = {'id': IdentityMessageFunction, 'linear': LinearMessageFunction, 'mlp': MLPMessageFunction}
+        if msg_tsfm_type not in fn:
+            raise NotImplementedError(msg_tsfm_type)
+        self.msg_tsfm_type = msg_tsfm_type
+        self.msg_transform_fn = fn[msg_tsfm_type](raw_msg_dim=self.raw_msg_dim)
+        self.msg_dim = self.msg_transform_fn.output_size
+        if mem_update_type == 'gru':
+            self.right_mem_updater = GRUUpdater(self.msg_dim, self.memory_dim)
+        elif mem_update_type == 'merge':
+            self.right_mem_updater = MergeUpdater(self.msg_dim, self.memory_dim)
+        else:
+            raise NotImplementedError(mem_update_type)
+        self.mem_update_type = mem_update_type
+        self.temporal_embedding_fn = GraphAttnEmbedding(raw_feat_getter=raw_feat_getter,
+                                                        time_encoder=self.time_encoder, graph=graph,
+                                                        n_neighbors=n_neighbors, n_layers=n_layers, n_head=n_head,
+                                                        dropout=dropout)
+        self.hit_type = hit_type
+        if hit_type == 'vec':
+            merge_dim = self.nfeat_dim + self.n_neighbors
+        elif hit_type == 'bin':
+            self.hit_embedding = nn.Embedding(2, self.nfeat_dim)
+            merge_dim = self.nfeat_dim
+        elif hit_type == 'count':
+            self.hit_embedding = nn.Embedding(self.n_neighbors + 1, self.nfeat_dim)
+            merge_dim = self.nfeat_dim
+        else:
+            merge_dim = self.nfeat_dim
+        self.score_fn = MergeLayer(merge_dim, merge_dim, self.nfeat_dim, 1, dropout=dropout)
+        self.contrast_loss_fn = nn.BCEWithLogitsLoss()
+        self._struct_cache = None
+        self._step_ws = {}
+
+    def _sanity_check(self):
+        if self.msg_src not in {'left', 'right'}:
+            raise ValueError(f'Invalid msg_src={self.msg_src}')
+        if self.upd_src not in {'left', 'right'}:
+            raise ValueError(f'Invalid upd_src={self.upd_src}')
+
+    # ---- plumbing ---------------------------------------------------------------------
+    @property
+    def graph(self):
+        return self.temporal_embedding_fn.graph
+
+    @graph.setter
+    def graph(self, new_obj):
+        self.temporal_embedding_fn.graph = new_obj
+
+    @property
+    def device(self):
+        return self.msg_memory.device
+
+    def _apply(self, fn, *a, **kw):  # .to() / .cuda() move every tensor: pointers change
+        self._struct_cache = None
+        self._step_ws = {}
+        return super()._apply(fn, *a, **kw)
+
+    def invalidate_struct(self):
+        self._struct_cache = None
+
+    def model_struct(self) -> TgModel:
+        """tg_model view of this module's tensors (cached until tensors are re-homed)."""
+        if self._struct_cache is not None:
+            return self._struct_cache
+        lin = lambda l: TgLinear(ptr(l.weight), ptr(l.bias))
+        nul = TgLinear(None, None)
+        fg, att = self.raw_feat_getter, self.temporal_embedding_fn.fns[0]
+        for t in (fg.nfeats, fg.efeats):
+            if t is not None and t.device != self.device:
+                raise RuntimeError('feature tables must live on the model device (--no_feat_buffer is not supported)')
+        tsfm1 = tsfm2 = nul
+        if self.msg_tsfm_type == 'linear':
+            tsfm1 = lin(self.msg_transform_fn.fn[1])
+        elif self.msg_tsfm_type == 'mlp':
+            tsfm1, tsfm2 = lin(self.msg_transform_fn.fn[1]), lin(self.msg_transform_fn.fn[4])
+        gru = [None] * 4
+        fc1 = fc2 = nul
+        if self.mem_update_type == 'gru':
+            c = self.right_mem_updater.cell
+            gru = [ptr(c.weight_ih), ptr(c.weight_hh), ptr(c.bias_ih), ptr(c.bias_hh)]
+        else:
+            fc1, fc2 = lin(self.right_mem_updater.fn.fc1), lin(self.right_mem_updater.fn.fc2)
+        L, R, S = self.left_memory, self.right_memory, self.msg_store
+        mha = att.mha_fn
+        m = TgModel(self.n_nodes, self.memory_dim, self.efeat_dim, self.n_neighbors, self.n_head,
+                    0 if self.msg_src == 'left' else 1, 0 if self.upd_src == 'left' else 1,
+                    _TSFM[self.msg_tsfm_type], _UPD[self.mem_update_type],
+                    ptr(L.vals), ptr(L.update_ts), ptr(L.active_mask), ptr(R.vals), ptr(R.update_ts), ptr(R.active_mask),
+                    ptr(S.node_msg_vals), ptr(S.node_msg_ts), ptr(S.has_msg_bits),
+                    ptr(fg.nfeats), ptr(fg.efeats), ptr(self.time_encoder.basis_freq), ptr(self.time_encoder.phase),
+                    tsfm1, tsfm2, gru[0], gru[1], gru[2], gru[3], fc1, fc2,
+                    ptr(mha.q_proj_weight), ptr(mha.k_proj_weight), ptr(mha.v_proj_weight), ptr(mha.in_proj_bias),
+                    lin(mha.out_proj), lin(att.merger.fc1), lin(att.merger.fc2))
+        self._struct_cache = m
+        return m
+
+    def _ws(self, key, nbytes) -> Tensor:
+        t = self._step_ws.get(key)
+        if t is None or t.numel() < nbytes or t.device != self.device:
+            t = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=self.device)
+            self._step_ws[key] = t
+        return t
+
+    # ---- STEP 1-2 -----------------------------------------------------------------------
+    def _consume(self, bitmap: Tensor, cap: int, err: Tensor):
+        """involved / outdated decoding + reprs = right_memory[involved] with outdated rows
+        replaced by updater(upd_memory, msg_fn(mailbox)) (tiger.py:208-221)."""
+        m = self.model_struct()
+        dev = self.device
+        comp = hip_ops.unique_compact(bitmap, self.n_nodes, cap, and_bitmap=self.msg_store.has_msg_bits)
+        reprs = torch.empty(cap, self.memory_dim, dtype=torch.float32, device=dev)
+        s = stream_ptr(dev)
+        check(lib.tg_mailbox_consume_gather(C.byref(m), ptr(comp['ids']), ptr(comp['count']), cap, ptr(reprs), s),
+              'tg_mailbox_consume_gather')
+        nbytes = int(lib.tg_apply_messages_workspace_bytes(C.byref(m), cap))
+        ws = self._ws('apply', nbytes)
+        check(lib.tg_apply_messages(C.byref(m), ptr(comp['and_ids']), ptr(comp['and_pos']), ptr(comp['and_count']),
+                                    cap, ptr(reprs), ptr(err), ptr(ws), ws.numel(), s), 'tg_apply_messages')
+        return comp, reprs
+
+    def compute_messages(self, node_ids: Union[Tensor, np.ndarray, None] = None):
+        """tiger.py:292-337 standalone form: (outdated ids, transformed messages, message ts)."""
+        outdated = self.msg_store.get_outdated_node_ids(node_ids).to(self.device)
+        if len(outdated) == 0:
+            return outdated, None, None
+        last = self.msg_memory.update_ts[outdated]
+        raw, ts = self.msg_aggregate_fn(outdated, last, self.msg_store.node_messages)
+        if self.msg_src == 'left' and not (ts == last).all().item():
+            raise ValueError("Messages' ts should be equal to last update ts when using left memory as msg source.")
+        return outdated, self.msg_transform_fn(raw.detach()), ts
+
+    # ---- the batch ----------------------------------------------------------------------
+    @torch.no_grad()
+    def contrast_learning(self, src_ids: Tensor, dst_ids: Tensor, neg_dst_ids: Tensor, ts: Tensor, eids: Tensor,
+                          computation_graph) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
+        """tiger.py:174-290 -> (contrast_loss, h_left, pos_scores, neg_scores, h_prev_left, h_prev_right)"""
+        cg = computation_graph
+        dev = self.device
+        m = self.model_struct()
+        s = stream_ptr(dev)
+        bs, d = len(src_ids), self.memory_dim
+        src_ids, dst_ids, neg_dst_ids, eids = (x.to(dev).long().contiguous() for x in
+                                               (src_ids, dst_ids, neg_dst_ids, eids))
+        ts = ts.to(dev).float().contiguous()
+        pos = torch.cat([src_ids, dst_ids])
+        batch_ids = torch.cat([pos, neg_dst_ids])
+        ts2, ts3 = ts.repeat(2), ts.repeat(3)
+        err = hip_ops.new_err(dev)
+        cap = 3 * bs * (self.n_neighbors + 1)
+        comp, reprs = self._consume(cg.bitmap, cap, err)  # STEP 1-2
+        h_all = self.temporal_embedding_fn.compute_embedding_with_computation_graph(  # STEP 3
+            reprs, batch_ids, ts3, cg, m, comp['rank'])
+        upos, index = hip_ops.select_latest_nids(pos, ts2, self.n_nodes)  # dedup (tiger.py:232,419; memory.py:98)
+        n_upos = torch.tensor([len(upos)], dtype=torch.int32, device=dev)
+        check(lib.tg_consume_update_right(C.byref(m), ptr(upos), ptr(n_upos), len(upos), ptr(reprs), ptr(cg.bitmap),
+                                          ptr(comp['rank']), ptr(err), s), 'tg_consume_update_right')  # STEP 4
+        check(lib.tg_store_events(C.byref(m), bs, ptr(src_ids), ptr(dst_ids), ptr(ts), ptr(eids), ptr(upos),
+                                  ptr(index), ptr(n_upos), ptr(err), s), 'tg_store_events')  # STEP 5
+        h_prev_left = hip_ops.gather_rows(self.left_memory.vals, pos)  # restarter targets (tiger.py:248-251)
+        h_prev_right = hip_ops.gather_rows(self.right_memory.vals, pos)
+        h_left = h_all[:2 * bs]
+        hip_ops.memory_scatter(self.left_memory.vals, self.left_memory.update_ts, self.left_memory.active_mask,
+                               upos, h_all, ts2, src_index=index, check_past=True, err=err)  # STEP 6
+        hip_ops.raise_if_err(err)
+        # STEP 7 (tiger.py:257-288): score head, plain torch (outside the accelerated path)
+        x, y, neg_y = h_all.reshape(3, bs, d)
+        pos_scores, neg_scores = self._scores(x, y, neg_y, cg.hit_data)
+        labels = torch.cat([torch.ones_like(pos_scores), torch.zeros_like(neg_scores)])
+        loss = self.contrast_loss_fn(torch.cat([pos_scores, neg_scores]), labels)
+        return loss, h_left, pos_scores, neg_scores, h_prev_left, h_prev_right
+
+    def _scores(self, x, y, neg_y, hit_data):
+        if self.hit_type in ('vec', 'bin', 'count'):
+            sh, dh, nsh, ndh = hit_data
+        if self.hit_type == 'vec':
+            xp, yp = torch.cat([x, sh], 1), torch.cat([y, dh], 1)
+            xn, yn = torch.cat([x, nsh], 1), torch.cat([neg_y, ndh], 1)
+        elif self.hit_type in ('bin', 'count'):
+            red = (lambda t: t.max(1).values.long()) if self.hit_type == 'bin' else (lambda t: t.sum(1).long())
+            e = self.hit_embedding
+            xp, yp, xn, yn = x + e(red(sh)), y + e(red(dh)), x + e(red(nsh)), neg_y + e(red(ndh))
+        else:
+            xp = xn = x
+            yp, yn = y, neg_y
+        return self.score_fn(xp, yp).squeeze(1), self.score_fn(xn, yn).squeeze(1)
+
+    # ---- fused path ---------------------------------------------------------------------
+    class StepBuffers:
+        """Static device buffers of one batch size: inputs, outputs and the workspace of
+        tg_stream_step; reused every step so the call sequence can be graph-captured."""
+
+        def __init__(self, model: 'TIGE', B: int, want_prev: bool, resident=None):
+            """resident = (src, dst, neg, ts64, eids) device tensors of the WHOLE stream: the
+            step then reads batch [offset, offset+B) and advances `offset` on device."""
+            dev, d, K = model.device, model.memory_dim, model.n_neighbors
+            self.B = B
+            i64 = dict(dtype=torch.int64, device=dev)
+            self.offset = None
+            if resident is None:
+                self.src, self.dst, self.neg, self.eids = (torch.zeros(B, **i64) for _ in range(4))
+                self.ts = torch.zeros(B, dtype=torch.float64, device=dev)
+            else:
+                self.src, self.dst, self.neg, self.ts, self.eids = resident
+                assert self.ts.dtype == torch.float64 and all(t.is_contiguous() for t in resident)
+                self.offset = torch.zeros(1, **i64)
+            self.h = torch.zeros(3 * B, d, dtype=torch.float32, device=dev)
+            self.l1_nids = torch.zeros(3 * B, K, **i64)
+            self.l1_eids = torch.zeros(3 * B, K, **i64)
+            self.l1_ts = torch.zeros(3 * B, K, dtype=torch.float32, device=dev)
+            self.involved = torch.zeros(3 * B * (K + 1), **i64)
+            self.counts = torch.zeros(4, dtype=torch.int32, device=dev)
+            self.err = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.h_prev_left = torch.zeros(2 * B, d, dtype=torch.float32, device=dev) if want_prev else None
+            self.h_prev_right = torch.zeros(2 * B, d, dtype=torch.float32, device=dev) if want_prev else None
+            m = model.model_struct()
+            nbytes = int(lib.tg_stream_step_workspace_bytes(C.byref(m), B))
+            if nbytes == 0:
+                raise RuntimeError('tg_stream_step: unsupported model dimensions')
+            self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self.io = TgStepIo(B, ptr(self.src), ptr(self.dst), ptr(self.neg), ptr(self.ts), ptr(self.eids),
+                               ptr(self.h), ptr(self.l1_nids), ptr(self.l1_eids), ptr(self.l1_ts), ptr(self.involved),
+                               ptr(self.counts), ptr(self.h_prev_left), ptr(self.h_prev_right), ptr(self.err),
+                               ptr(self.offset), 1 if resident is not None else 0, 0, None)
+
+        def attach_profiler(self, prof):
+            self.io.profiler = prof
+
+        def load(self, src, dst, neg, ts, eids):
+            self.src.copy_(src, non_blocking=True)
+            self.dst.copy_(dst, non_blocking=True)
+            self.neg.copy_(neg, non_blocking=True)
+            self.ts.copy_(ts, non_blocking=True)
+            self.eids.copy_(eids, non_blocking=True)
+
+    def step_buffers(self, B: int, want_prev: bool = False) -> 'TIGE.StepBuffers':
+        key = ('step', B, want_prev)
+        buf = self._step_ws.get(key)
+        if buf is None:
+            buf = TIGE.StepBuffers(self, B, want_prev)
+            self._step_ws[key] = buf
+        return buf
+
+    def launch_step(self, buf: 'TIGE.StepBuffers'):
+        """Enqueue collate + STEP 1-6 for the batch already in `buf` (no host sync)."""
+        m = self.model_struct()
+        g = self.graph.tcsr
+        check(lib.tg_stream_step(C.byref(m), C.byref(g), C.byref(buf.io), ptr(buf.ws), buf.ws.numel(),
+                                 stream_ptr(self.device)), 'tg_stream_step')
+
+    @torch.no_grad()
+    def stream_step(self, src, dst, neg, ts, eids, want_prev: bool = False, check_invariants: bool = True):
+        """Fused collate + STEP 1-6 (data_loader.py:77-131 + tiger.py:196-255).
+        ts are the float64 event times.  Returns the StepBuffers (h = embeddings of
+        cat[src,dst,neg]; rows [0,2B) are h_left)."""
+        dev = self.device
+        to = lambda x, dt: torch.as_tensor(x).to(dev, dt)
+        buf = self.step_buffers(len(src), want_prev)
+        buf.load(to(src, torch.int64), to(dst, torch.int64), to(neg, torch.int64), to(ts, torch.float64),
+                 to(eids, torch.int64))
+        self.launch_step(buf)
+        if check_invariants:
+            word = int(buf.err.item())
+            if word:
+                buf.err.zero_()
+                from .._lib import raise_invariants
+                raise_invariants(word & 0xFFFFFFFF)
+        return buf
+
+    # ---- remaining reference methods -----------------------------------------------------
+    @torch.no_grad()
+    def update_right_memory(self, node_ids: Tensor, new_vals: Tensor, ts: Tensor):
+        self.right_memory.set(node_ids, new_vals, ts)
+
+    @torch.no_grad()
+    def update_left_memory(self, node_ids: Tensor, new_vals: Tensor, ts: Tensor):
+        node_ids, index = select_latest_nids(node_ids, ts, self.n_nodes)
+        self.left_memory.set(node_ids, new_vals[index], ts[index])
+
+    @torch.no_grad()
+    def flush_msg(self):
+        """tiger.py:444-455: consume every pending message into the right memory."""
+        dev = self.device
+        m = self.model_struct()
+        err = hip_ops.new_err(dev)
+        bits = self.msg_store.has_msg_bits
+        comp, reprs = self._consume(bits, self.n_nodes, err)  # involved == outdated == all pending nodes
+        n = int(comp['count'].item())
+        if n:
+            ids = comp['ids'][:n]
+            mts = self.msg_store.node_msg_ts[ids]
+            self.right_memory.set(ids, reprs[:n], mts)
+            self.msg_store.clear(ids)
+        hip_ops.raise_if_err(err)
+
+    def reset(self):
+        self.left_memory.clear()
+        self.right_memory.clear()
+        self.msg_store.clear()
+
+    def save_memory_state(self):
+        return (self.left_memory.clone(), self.right_memory.clone(), self.msg_store.clone())
+
+    def load_memory_state(self, data):
+        self.left_memory, self.right_memory, self.msg_store = data
+        self.msg_memory = self.left_memory if self.msg_src == 'left' else self.right_memory
+        self.upd_memory = self.left_memory if self.upd_src == 'left' else self.right_memory
+        self._struct_cache = None
+
+
+class TIGER(TIGE):
+    def __init__(self, *, raw_feat_getter, graph, restarter, n_neighbors: int = 20, n_layers: int = 2,
+                 n_head: int = 2, dropout: float = 0.1, msg_src: str, upd_src: str, msg_tsfm_type: str = 'id',
+                 mem_update_type: str = 'gru', tgn_mode: bool = True, msg_last_only: bool = True,
+                 hit_type: str = 'vec'):
+        super().__init__(raw_feat_getter=raw_feat_getter, graph=graph, n_neighbors=n_neighbors, n_layers=n_layers,
+                         n_head=n_head, dropout=dropout, msg_src=msg_src, upd_src=upd_src,
+                         msg_tsfm_type=msg_tsfm_type, mem_update_type=mem_update_type, tgn_mode=tgn_mode,
+                         msg_last_only=msg_last_only, hit_type=hit_type)
+        self.restarter_fn = restarter
+        self.restarter_fn.model_struct_fn = self.model_struct
+        self.mutual_loss_fn = nn.MSELoss()
+
+    def forward(self, *args, **kwargs):
+        return self.contrast_and_mutual_learning(*args, **kwargs)
+
+    @torch.no_grad()
+    def contrast_and_mutual_learning(self, src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph,
+                                     contrast_only: bool = False):
+        """tiger.py:547-592"""
+        contrast_loss, *_, h_prev_left, h_prev_right = self.contrast_learning(
+            src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph)
+        if contrast_only:
+            return contrast_loss, torch.tensor(0, device=contrast_loss.device)
+        dev = self.device
+        index = computation_graph.restart_data.index
+        unique_nids = torch.cat([src_ids, dst_ids]).to(dev)[index]
+        unique_ts = ts.to(dev).float().repeat(2)[index]
+        sur_left, sur_right, _ = self.restarter_fn(unique_nids, unique_ts, computation_graph)
+        targets = torch.cat([h_prev_left[index], h_prev_right[index]], 0)
+        preds = torch.cat([sur_left, sur_right], 0)
+        valid_rows = torch.where(~(targets == 0).all(1))[0]
+        if len(valid_rows):
+            mutual_loss = self.mutual_loss_fn(preds[valid_rows], targets[valid_rows])
+        else:
+            mutual_loss = torch.tensor(0, device=dev)
+        return contrast_loss, mutual_loss
+
+    @torch.no_grad()
+    def restart(self, nids: Tensor, ts: Tensor, mix: float = 0.):
+        """tiger.py:594-609: fill both memories with the surrogate state."""
+        if len(nids) == 0:
+            return
+        dev = self.device
+        nids = nids.to(dev).long().contiguous()
+        h_left, h_right, prev_ts = self.restarter_fn(nids, ts.to(dev))
+        if mix > 0:
+            h_left = mix * h_left + (1 - mix) * self.left_memory.vals[nids]
+            h_right = mix * h_right + (1 - mix) * self.right_memory.vals[nids]
+        m = self.model_struct()
+        check(lib.tg_restart_apply(C.byref(m), nids.numel(), ptr(nids), ptr(h_left.contiguous()),
+                                   ptr(h_right.contiguous()), ptr(prev_ts.contiguous()), stream_ptr(dev)),
+              'tg_restart_apply')
+
+    @property
+    def graph(self):
+        return self.temporal_embedding_fn.graph
+
+    @graph.setter
+    def graph(self, new_obj):
+        self.temporal_embedding_fn.graph = new_obj
+        self.restarter_fn.graph = new_obj
