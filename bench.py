@@ -153,12 +153,13 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch steps eagerly instead of replaying a hipGraph')
+    ap.add_argument('--force-dist', action='store_true', help='run the multi-GPU code path even with one rank')
     args = ap.parse_args()
     cfg = dict(C2)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or args.force_dist:
         from www2023tiger_amd import dist as tdist
         return tdist.bench_main(args, cfg, make_stream, build_models, rank, local_rank, world)
 

@@ -204,6 +204,10 @@ int tg_gather_rows(int64_t n, const int64_t* ids, int32_t width, const float* ta
 int tg_memory_scatter(int64_t n, const int32_t* n_dev, const int64_t* ids, const int64_t* src_index,
                       int32_t width, const float* vals, const float* ts, float* table, float* ts_table,
                       uint8_t* active, int32_t check, uint32_t* err, void* stream);
+/* same, with separate row indices for vals (val_index) and ts (ts_index) */
+int tg_memory_scatter2(int64_t n, const int32_t* n_dev, const int64_t* ids, const int64_t* val_index,
+                       const int64_t* ts_index, int32_t width, const float* vals, const float* ts, float* table,
+                       float* ts_table, uint8_t* active, int32_t check, uint32_t* err, void* stream);
 
 /* torch.nn.Linear forward on dense rows: out[n, out_f] = act(x[n, in_f] W^T + b)
  * (message functions message_modules.py:29-55, MergeLayer basic_modules.py:16-19). */
@@ -252,6 +256,9 @@ int tg_temporal_attn_fwd(const tg_model* m, int64_t Q, const int64_t* nids, cons
 int tg_consume_update_right(const tg_model* m, const int64_t* upos, const int32_t* n_upos, int64_t cap,
                             const float* reprs, const uint64_t* bitmap, const uint32_t* rank,
                             uint32_t* err, void* stream);
+/* same, reading node upos[p]'s new row at rows[row_index[p]] instead of reprs[local(upos[p])] */
+int tg_consume_update_right_rows(const tg_model* m, const int64_t* upos, const int32_t* n_upos, int64_t cap,
+                                 const float* rows, const int64_t* row_index, uint32_t* err, void* stream);
 /* STEP 5: build the two raw messages of the winning event of each unique positive
  * node and write mailbox row, mailbox ts and has-message bit.  `index` is the
  * select_latest position into cat[src,dst]. */
@@ -316,8 +323,12 @@ typedef struct tg_step_io {
    * one step replays the whole stream with no host work (train_self_supervised.py:143). */
   int64_t* offset_dev;
   int32_t advance;
-  int32_t reserved;
+  /* embed_only != 0: stop after STEP 3 (no state is written).  Used by the multi-GPU
+   * path, where every rank embeds its own shard of the batch and the write-back runs on
+   * the all-gathered rows (www2023tiger_amd/dist.py). */
+  int32_t embed_only;
   void* profiler;       /* tg_profiler* or NULL: records an event after every stage */
+  float* h_new;         /* [2B, d] or NULL: h(t'+) of cat[src,dst] (the rows STEP 4 would write) */
 } tg_step_io;
 
 /* Per-stage timer of tg_stream_step (HIP events on the step's stream).  Stage names:

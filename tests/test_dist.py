@@ -1,0 +1,195 @@
+"""Multi-GPU host logic (www2023tiger_amd/dist.py): shard plan, row mapping, the
+all-gather exchange and the replicated write-back.
+
+* CPU, world_size 2, gloo: the runner drives an oracle-backed compute object; the result
+  must equal the single-process oracle on the same global batches (bit for bit - the same
+  float32 ops run in both).
+* GPU (one card, two ranks sharing it, gloo staging): the HIP backend under the same
+  runner must reproduce the single-GPU engine on the global batch.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as tdist
+import torch.multiprocessing as mp
+
+from _util import fixture_params, fixture_tables, load, parse_cfg, rel_err
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def test_owner_table_and_plan():
+    from www2023tiger_amd.dist import ShardPlan, balanced_owner_table
+    rs = np.random.RandomState(0)
+    n_nodes, world, cap = 200, 4, 64
+    p = 1.0 / np.arange(1, 101)
+    dst_all = rs.choice(100, 5000, p=p / p.sum()) + 100
+    owner = balanced_owner_table(n_nodes, dst_all, world)
+    assert owner.min() >= 0 and owner.max() < world
+    load = np.bincount(owner[dst_all], minlength=world)
+    deg = np.bincount(dst_all, minlength=n_nodes)
+    assert load.max() <= max(deg.max(), 1.05 * load.mean() + deg.max() * 0.0 + 1) or load.max() <= 1.1 * load.mean()
+    dst = dst_all[:128]
+    plan = ShardPlan(dst, owner, world, cap)
+    assert plan.counts.sum() == 128
+    seen = np.concatenate(plan.local_idx)
+    assert sorted(seen.tolist()) == list(range(128))          # every event embedded exactly once
+    for r in range(world):
+        assert (owner[dst[plan.local_idx[r]]] == r).all()       # on the owner of its dst
+        assert (np.diff(plan.local_idx[r]) > 0).all()           # stream order kept inside a shard
+    assert len(set(plan.left_row.tolist())) == 256 and len(set(plan.new_row.tolist())) == 256
+    assert not set(plan.left_row.tolist()) & set(plan.new_row.tolist())
+    with pytest.raises(ValueError):
+        ShardPlan(dst, owner, world, 8)
+
+
+# ------------------------------------------------------------------------------ oracle backend (CPU)
+class OracleBackend:
+    """Splits OracleTIGER.contrast_learning (tiger.py:196-255) into the two halves the
+    runner needs.  Test-only: uses oracle/ as the compute."""
+
+    def __init__(self, orc, K, restarter):
+        from oracle import tiger_oracle as O
+        self.O, self.orc, self.K, self.restarter = O, orc, K, restarter
+
+    def embed(self, src, dst, neg, ts, eids):
+        O, m = self.O, self.orc
+        if len(src) == 0:
+            z = torch.zeros(0, m.d)
+            return z, z
+        cg = O.collate(m.graph, src, dst, neg, ts, self.K, 'static')
+        t32 = torch.from_numpy(np.asarray(ts)).float()
+        involved = cg['involved']
+        outdated, h_new, _ = m.consume(involved)
+        reprs = m.right_vals[torch.from_numpy(involved)].clone()
+        if len(outdated):
+            reprs[torch.from_numpy(cg['local_index'][outdated])] = h_new
+        nids3 = np.concatenate([src, dst, neg])
+        h = m.embed(reprs, cg['local_index'], nids3, t32.repeat(3), cg['l1_nids'], cg['l1_eids'], cg['l1_ts'])
+        pos = np.concatenate([src, dst])
+        return h[:2 * len(src)], reprs[torch.from_numpy(cg['local_index'][pos])]
+
+    def writeback(self, src, dst, ts, eids, rows, left_row, new_row):
+        O, m = self.O, self.orc
+        t32 = torch.from_numpy(np.asarray(ts)).float()
+        pos = np.concatenate([src, dst])
+        ts2 = t32.repeat(2)
+        ids, idx = O.select_latest_nids(pos, ts2.numpy())
+        had = m.has_msg[ids]
+        if had.any():  # STEP 4
+            sel = ids[had]
+            m.has_msg[sel] = False
+            m._mem_set(m.right_vals, m.right_ts, torch.from_numpy(sel), rows[torch.from_numpy(new_row[idx[had]])],
+                       m.msg_ts[torch.from_numpy(sel)])
+        m.store_events(src, dst, t32, eids)  # STEP 5
+        m._mem_set(m.left_vals, m.left_ts, torch.from_numpy(ids), rows[torch.from_numpy(left_row[idx])],
+                   ts2[torch.from_numpy(idx)])  # STEP 6
+
+
+def _make_oracle(z, cfg):
+    from oracle import tiger_oracle as O
+    n_nodes, nfeats, efeats = fixture_tables(z, cfg)
+    g = O.OracleGraph(z['src'], z['dst'], z['ts'], z['eids'])
+    return O.OracleTIGER(fixture_params(z, cfg), g, n_nodes=n_nodes, dim=cfg['d'], nfeats=nfeats, efeats=efeats,
+                         n_neighbors=cfg['K'], msg_src=cfg['msg_src'], upd_src=cfg['upd_src'], restarter='static')
+
+
+def _cpu_worker(rank, world, port, name, Bg, n_batches, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    tdist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from www2023tiger_amd.dist import ShardedRunner, balanced_owner_table
+    z = load(name)
+    cfg = parse_cfg(z)
+    orc = _make_oracle(z, cfg)
+    owner = balanced_owner_table(int(z['n_nodes']), z['dst'], world)
+    runner = ShardedRunner(OracleBackend(orc, cfg['K'], 'static'), owner, rank, world, cap=Bg)
+    for b in range(n_batches):
+        sl = slice(b * Bg, (b + 1) * Bg)
+        runner.step(*(z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')))
+    np.savez(os.path.join(out_dir, f'rank{rank}.npz'), left=orc.left_vals.numpy(), right=orc.right_vals.numpy(),
+             left_ts=orc.left_ts.numpy(), right_ts=orc.right_ts.numpy(), msg=orc.msg_vals.numpy(),
+             msg_ts=orc.msg_ts.numpy(), has=orc.has_msg)
+    tdist.destroy_process_group()
+
+
+def test_sharded_equals_single_process_cpu_gloo(tmp_path):
+    name, Bg, n_batches, world = 'static_ll_d16', 96, 6, 2
+    mp.spawn(_cpu_worker, args=(world, free_port(), name, Bg, n_batches, str(tmp_path)), nprocs=world, join=True)
+    from oracle import tiger_oracle as O
+    z = load(name)
+    cfg = parse_cfg(z)
+    ref = _make_oracle(z, cfg)
+    for b in range(n_batches):
+        sl = slice(b * Bg, (b + 1) * Bg)
+        a = [z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        ref.contrast_learning(*a, O.collate(ref.graph, a[0], a[1], a[2], a[3], cfg['K'], 'static'))
+    want = dict(left=ref.left_vals.numpy(), right=ref.right_vals.numpy(), left_ts=ref.left_ts.numpy(),
+                right_ts=ref.right_ts.numpy(), msg_ts=ref.msg_ts.numpy(), has=ref.has_msg)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f'rank{r}.npz'))
+        for k, v in want.items():
+            np.testing.assert_array_equal(got[k], v, err_msg=f'rank {r} {k}')
+        np.testing.assert_array_equal(got['msg'][ref.has_msg], ref.msg_vals.numpy()[ref.has_msg])
+
+
+# ------------------------------------------------------------------------------ HIP backend (GPU)
+def _gpu_worker(rank, world, port, name, Bg, n_batches, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    tdist.init_process_group('gloo', rank=rank, world_size=world)
+    from test_hip_parity import build_hip_model
+    from www2023tiger_amd.dist import HipBackend, ShardedRunner, balanced_owner_table
+    z = load(name)
+    cfg = parse_cfg(z)
+    model, _, _ = build_hip_model(z, cfg)
+    owner = balanced_owner_table(int(z['n_nodes']), z['dst'], world)
+    backend = HipBackend(model, cap=Bg)
+    runner = ShardedRunner(backend, owner, rank, world, cap=Bg)
+    for b in range(n_batches):
+        sl = slice(b * Bg, (b + 1) * Bg)
+        runner.step(*(z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')))
+    backend.check_invariants()
+    np.savez(os.path.join(out_dir, f'rank{rank}.npz'), left=model.left_memory.vals.cpu().numpy(),
+             right=model.right_memory.vals.cpu().numpy(), left_ts=model.left_memory.update_ts.cpu().numpy(),
+             right_ts=model.right_memory.update_ts.cpu().numpy(), msg=model.msg_store.node_msg_vals.cpu().numpy(),
+             msg_ts=model.msg_store.node_msg_ts.cpu().numpy(),
+             has=np.array(sorted(model.msg_store.nodes_with_messages), dtype=np.int64))
+    tdist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['static_ll_d16', 'seq_rr_d8_nofeat'])
+def test_sharded_equals_single_gpu(tmp_path, name):
+    from test_hip_parity import build_hip_model
+    Bg, n_batches, world = 100, 4, 2
+    mp.spawn(_gpu_worker, args=(world, free_port(), name, Bg, n_batches, str(tmp_path)), nprocs=world, join=True)
+    z = load(name)
+    cfg = parse_cfg(z)
+    model, _, _ = build_hip_model(z, cfg)
+    for b in range(n_batches):
+        sl = slice(b * Bg, (b + 1) * Bg)
+        model.stream_step(*(z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')))
+    has = np.array(sorted(model.msg_store.nodes_with_messages), dtype=np.int64)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f'rank{r}.npz'))
+        np.testing.assert_array_equal(got['left_ts'], model.left_memory.update_ts.cpu().numpy())
+        np.testing.assert_array_equal(got['right_ts'], model.right_memory.update_ts.cpu().numpy())
+        np.testing.assert_array_equal(got['has'], has)
+        np.testing.assert_array_equal(got['msg_ts'], model.msg_store.node_msg_ts.cpu().numpy())
+        assert rel_err(got['left'], model.left_memory.vals.cpu().numpy()) < 1e-6
+        assert rel_err(got['right'], model.right_memory.vals.cpu().numpy()) < 1e-6
+        assert rel_err(got['msg'][has], model.msg_store.node_msg_vals.cpu().numpy()[has]) < 1e-6

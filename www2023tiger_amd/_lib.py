@@ -63,7 +63,7 @@ class TgStepIo(C.Structure):
         ('B', i64), ('src', vp), ('dst', vp), ('neg', vp), ('ts', vp), ('eids', vp),
         ('h', vp), ('l1_nids', vp), ('l1_eids', vp), ('l1_ts', vp), ('involved', vp), ('counts', vp),
         ('h_prev_left', vp), ('h_prev_right', vp), ('err', vp),
-        ('offset_dev', vp), ('advance', i32), ('reserved', i32), ('profiler', vp),
+        ('offset_dev', vp), ('advance', i32), ('embed_only', i32), ('profiler', vp), ('h_new', vp),
     ]
 
 
@@ -87,6 +87,8 @@ SIGNATURES = {
     'tg_time_encode': (C.c_int, [i64, vp, i32, vp, vp, vp, vp]),
     'tg_gather_rows': (C.c_int, [i64, vp, i32, vp, vp, vp, vp, vp]),
     'tg_memory_scatter': (C.c_int, [i64, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp]),
+    'tg_memory_scatter2': (C.c_int, [i64, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp]),
+    'tg_consume_update_right_rows': (C.c_int, [P(TgModel), vp, vp, i64, vp, vp, vp, vp]),
     'tg_linear_fwd': (C.c_int, [i64, vp, i32, P(TgLinear), i32, i32, vp, vp]),
     'tg_gru_fwd': (C.c_int, [i64, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]),
     'tg_mailbox_consume_gather': (C.c_int, [P(TgModel), vp, vp, i64, vp, vp]),

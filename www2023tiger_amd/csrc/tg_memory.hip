@@ -32,7 +32,8 @@ __global__ void k_gather_rows(int64_t n, const int32_t* __restrict__ n_dev, cons
 }
 
 __global__ void k_memory_scatter(int64_t n, const int32_t* __restrict__ n_dev, const int64_t* __restrict__ ids,
-                                 const int64_t* __restrict__ src_index, int w4, const float4* __restrict__ vals,
+                                 const int64_t* __restrict__ src_index, const int64_t* __restrict__ ts_index, int w4,
+                                 const float4* __restrict__ vals,
                                  const float* __restrict__ ts, float4* __restrict__ table, float* __restrict__ ts_table,
                                  uint8_t* __restrict__ active, int check, uint32_t* __restrict__ err) {
   if (n_dev) n = min(n, (int64_t)*n_dev);
@@ -44,7 +45,7 @@ __global__ void k_memory_scatter(int64_t n, const int32_t* __restrict__ n_dev, c
     const int64_t s = src_index ? src_index[i] : i;
     table[id * w4 + c] = vals[s * w4 + c];
     if (c == 0) {
-      const float nt = ts[s];
+      const float nt = ts[ts_index ? ts_index[i] : s];
       if (check && ts_table[id] > nt) atomicOr(err, TG_ERR_PAST_MEMORY);
       ts_table[id] = nt;
       if (active) active[id] = 1;
@@ -57,7 +58,9 @@ __global__ void __launch_bounds__(256) k_consume_update_right(tg_model m, const 
                                                               const int32_t* __restrict__ n_upos, int64_t cap,
                                                               const float4* __restrict__ reprs,
                                                               const uint64_t* __restrict__ bm,
-                                                              const uint32_t* __restrict__ rank, uint32_t* __restrict__ err) {
+                                                              const uint32_t* __restrict__ rank,
+                                                              const int64_t* __restrict__ row_index,
+                                                              uint32_t* __restrict__ err) {
   const int64_t n = min((int64_t)*n_upos, cap);
   const int lane = lane_id();
   const int w4 = m.d / 4;
@@ -65,8 +68,8 @@ __global__ void __launch_bounds__(256) k_consume_update_right(tg_model m, const 
   for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < n; p += (int64_t)gridDim.x * 4) {
     const int64_t id = upos[p];
     if (!bm_test(m.has_msg, id)) continue;  // not outdated: nothing to consume (wave-uniform)
-    const uint32_t u = bm_rank(bm, rank, id);
-    for (int c = lane; c < w4; c += TG_WAVE) right[id * w4 + c] = reprs[(int64_t)u * w4 + c];
+    const int64_t u = row_index ? row_index[p] : (int64_t)bm_rank(bm, rank, id);
+    for (int c = lane; c < w4; c += TG_WAVE) right[id * w4 + c] = reprs[u * w4 + c];
     if (lane == 0) {
       const float mts = m.msg_ts[id];
       if (m.right_ts[id] > mts) atomicOr(err, TG_ERR_PAST_MEMORY);
@@ -199,8 +202,22 @@ extern "C" int tg_memory_scatter(int64_t n, const int32_t* n_dev, const int64_t*
   if (n == 0) return TG_OK;
   if (!ids || !vals || !ts || !table || !ts_table || (check && !err)) return TG_EINVAL;
   hipLaunchKernelGGL(k_memory_scatter, dim3(flat_grid(n * (width / 4), 256)), dim3(256), 0, as_stream(stream), n, n_dev,
-                     ids, src_index, width / 4, (const float4*)vals, ts, (float4*)table, ts_table, active, check, err);
+                     ids, src_index, (const int64_t*)nullptr, width / 4, (const float4*)vals, ts, (float4*)table, ts_table,
+                     active, check, err);
   return check_launch("tg_memory_scatter");
+}
+
+extern "C" int tg_memory_scatter2(int64_t n, const int32_t* n_dev, const int64_t* ids, const int64_t* val_index,
+                                  const int64_t* ts_index, int32_t width, const float* vals, const float* ts,
+                                  float* table, float* ts_table, uint8_t* active, int32_t check, uint32_t* err,
+                                  void* stream) {
+  if (n < 0 || width <= 0 || (width % 4) != 0) return TG_EINVAL;
+  if (n == 0) return TG_OK;
+  if (!ids || !vals || !ts || !table || !ts_table || (check && !err)) return TG_EINVAL;
+  hipLaunchKernelGGL(k_memory_scatter, dim3(flat_grid(n * (width / 4), 256)), dim3(256), 0, as_stream(stream), n, n_dev,
+                     ids, val_index, ts_index, width / 4, (const float4*)vals, ts, (float4*)table, ts_table, active, check,
+                     err);
+  return check_launch("tg_memory_scatter2");
 }
 
 extern "C" int tg_mailbox_consume_gather(const tg_model* m, const int64_t* involved, const int32_t* n_involved,
@@ -221,8 +238,18 @@ extern "C" int tg_consume_update_right(const tg_model* m, const int64_t* upos, c
   if (cap == 0) return TG_OK;
   if (!upos || !n_upos || !reprs || !bitmap || !rank || !err) return TG_EINVAL;
   hipLaunchKernelGGL(k_consume_update_right, dim3(flat_grid(cap, 4)), dim3(256), 0, as_stream(stream), *m, upos, n_upos,
-                     cap, (const float4*)reprs, bitmap, rank, err);
+                     cap, (const float4*)reprs, bitmap, rank, (const int64_t*)nullptr, err);
   return check_launch("tg_consume_update_right");
+}
+
+extern "C" int tg_consume_update_right_rows(const tg_model* m, const int64_t* upos, const int32_t* n_upos, int64_t cap,
+                                            const float* rows, const int64_t* row_index, uint32_t* err, void* stream) {
+  if (!model_ok(m) || cap < 0) return TG_EINVAL;
+  if (cap == 0) return TG_OK;
+  if (!upos || !n_upos || !rows || !row_index || !err) return TG_EINVAL;
+  hipLaunchKernelGGL(k_consume_update_right, dim3(flat_grid(cap, 4)), dim3(256), 0, as_stream(stream), *m, upos, n_upos,
+                     cap, (const float4*)rows, (const uint64_t*)nullptr, (const uint32_t*)nullptr, row_index, err);
+  return check_launch("tg_consume_update_right_rows");
 }
 
 extern "C" int tg_store_events(const tg_model* m, int64_t B, const int64_t* src, const int64_t* dst, const float* ts,

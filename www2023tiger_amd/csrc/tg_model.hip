@@ -648,6 +648,20 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
   if ((rc = attn_forward(m, Q, w.nids3, w.ts3f, l1n, l1e, l1t, w.reprs, w.bm, w.rank, io->h, w.attn, st, pf)) != TG_OK)
     return rc;
   prof_mark(pf, ST_DEDUP, st);
+  if (io->h_new) {  // h(t'+) rows of cat[src, dst]: reprs[local(node)]
+    hipLaunchKernelGGL(k_attn_centres, dim3(flat_grid(2 * B * (m->d / 4), 256)), dim3(256), 0, st, 2 * B, m->d / 4,
+                       w.nids3, (const float4*)w.reprs, w.bm, w.rank, (const float4*)nullptr, (float4*)io->h_new);
+  }
+  if (io->embed_only) {
+    if (io->counts) {
+      e = hipMemcpyAsync(io->counts, w.counts, 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) {
+        set_hip_error(e, "tg_stream_step counts copy");
+        return TG_EHIP;
+      }
+    }
+    return check_launch("tg_stream_step(embed_only)");
+  }
   // ---- dedup of positive nodes (select_latest_nids on float32 ts, tiger.py:232,419; memory.py:98)
   hipLaunchKernelGGL(k_pos_max, dim3(flat_grid(2 * B, 256)), dim3(256), 0, st, B, src, dst, w.ts3f, w.bm, w.rank, w.best);
   hipLaunchKernelGGL(k_pos_winners, dim3(flat_grid(2 * B, 256)), dim3(256), 0, st, B, src, dst, w.ts3f, w.bm, w.rank,

@@ -254,7 +254,7 @@ class TIGE(nn.Module):
         """Static device buffers of one batch size: inputs, outputs and the workspace of
         tg_stream_step; reused every step so the call sequence can be graph-captured."""
 
-        def __init__(self, model: 'TIGE', B: int, want_prev: bool, resident=None):
+        def __init__(self, model: 'TIGE', B: int, want_prev: bool, resident=None, embed_only: bool = False):
             """resident = (src, dst, neg, ts64, eids) device tensors of the WHOLE stream: the
             step then reads batch [offset, offset+B) and advances `offset` on device."""
             dev, d, K = model.device, model.memory_dim, model.n_neighbors
@@ -277,6 +277,7 @@ class TIGE(nn.Module):
             self.err = torch.zeros(1, dtype=torch.int32, device=dev)
             self.h_prev_left = torch.zeros(2 * B, d, dtype=torch.float32, device=dev) if want_prev else None
             self.h_prev_right = torch.zeros(2 * B, d, dtype=torch.float32, device=dev) if want_prev else None
+            self.h_new = torch.zeros(2 * B, d, dtype=torch.float32, device=dev) if embed_only else None
             m = model.model_struct()
             nbytes = int(lib.tg_stream_step_workspace_bytes(C.byref(m), B))
             if nbytes == 0:
@@ -285,7 +286,8 @@ class TIGE(nn.Module):
             self.io = TgStepIo(B, ptr(self.src), ptr(self.dst), ptr(self.neg), ptr(self.ts), ptr(self.eids),
                                ptr(self.h), ptr(self.l1_nids), ptr(self.l1_eids), ptr(self.l1_ts), ptr(self.involved),
                                ptr(self.counts), ptr(self.h_prev_left), ptr(self.h_prev_right), ptr(self.err),
-                               ptr(self.offset), 1 if resident is not None else 0, 0, None)
+                               ptr(self.offset), 1 if resident is not None else 0, 1 if embed_only else 0, None,
+                               ptr(self.h_new))
 
         def attach_profiler(self, prof):
             self.io.profiler = prof
