@@ -79,13 +79,14 @@ int tg_tcsr_build_host(int64_t num_events, const int64_t* src_host, const int64_
 
 /* Graph.sample_temporal_neighbor(strategy='recent_edges') and Graph.get_history
  * (graph.py:67-127,150-155): per query the last K entries with ts < t (strict),
- * left padded with zeros.  out_dir may be NULL.  If mark_bitmap != NULL every query
- * id and every sampled neighbour id (padding 0 included) is also set in that
- * n-node bitmap (fusion of GraphCollator.collate_memory_nodes' set.update,
- * data_loader.py:109-113). */
+ * left padded with zeros.  out_dir may be NULL.  If mark_flags != NULL every query
+ * id and every sampled neighbour id (padding 0 included) is also flagged in that
+ * byte array (uint8[tg_flag_bytes(n_nodes)], zeroed by the caller; plain stores, no
+ * atomics) - the fusion of GraphCollator.collate_memory_nodes' set.update
+ * (data_loader.py:109-113); tg_unique_compact packs the flags into the node bitmap. */
 int tg_sample_recent_edges(const tg_tcsr* g, int64_t n_query, const int64_t* nids, const double* ts,
                            int32_t K, int64_t* out_nbr, int64_t* out_eid, float* out_ts,
-                           int64_t* out_dir, uint64_t* mark_bitmap, void* stream);
+                           int64_t* out_dir, uint8_t* mark_flags, void* stream);
 
 /* strategy='recent_nodes' (graph.py:129-143): last occurrence of each distinct
  * neighbour, most recent K of those, ascending in time, left padded. */
@@ -114,7 +115,11 @@ int tg_anonymized_reindex(int64_t n, int32_t H, const int64_t* hist_nids, int64_
 /* number of uint64 words of a bitmap over n_nodes ids */
 int64_t tg_bitmap_words(int64_t n_nodes);
 int tg_bitmap_mark(int64_t n, const int64_t* ids, uint64_t* bitmap, int64_t n_nodes, void* stream);
-/* Reads the bitmap back as the sorted id list (replaces np.sort(list(set)),
+/* byte-flag form of the same set (one uint8 per node, padded to a multiple of 64) */
+int64_t tg_flag_bytes(int64_t n_nodes);
+int tg_flags_mark(int64_t n, const int64_t* ids, uint8_t* flags, int64_t n_nodes, void* stream);
+/* If flags != NULL they are first packed into `bitmap` (which is then an output).
+ * Reads the bitmap back as the sorted id list (replaces np.sort(list(set)),
  * data_loader.py:121, and the dense local_index of data_classes.py:163-165):
  *   rank[w]    = number of set bits in words [0, w)          (uint32[words + 1])
  *   out_ids[r] = r-th smallest set id                        (capacity `cap`)
@@ -125,7 +130,7 @@ int tg_bitmap_mark(int64_t n, const int64_t* ids, uint64_t* bitmap, int64_t n_no
  * (and_pos) - this is the "outdated = involved ∩ has-message" set of
  * MessageStoreNoGradLastOnly.get_outdated_node_ids (memory.py:108-126). */
 size_t tg_unique_compact_workspace_bytes(int64_t n_nodes);
-int tg_unique_compact(const uint64_t* bitmap, int64_t n_nodes, uint32_t* rank, int64_t* out_ids,
+int tg_unique_compact(const uint8_t* flags, uint64_t* bitmap, int64_t n_nodes, uint32_t* rank, int64_t* out_ids,
                       int32_t* out_count, int64_t cap, const uint64_t* and_bitmap, uint32_t* and_rank,
                       int64_t* and_ids, int32_t* and_pos, int32_t* and_count, void* ws, size_t ws_bytes,
                       void* stream);

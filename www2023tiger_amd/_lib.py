@@ -81,7 +81,9 @@ SIGNATURES = {
     'tg_bitmap_words': (i64, [i64]),
     'tg_bitmap_mark': (C.c_int, [i64, vp, vp, i64, vp]),
     'tg_unique_compact_workspace_bytes': (sz, [i64]),
-    'tg_unique_compact': (C.c_int, [vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'tg_unique_compact': (C.c_int, [vp, vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'tg_flag_bytes': (i64, [i64]),
+    'tg_flags_mark': (C.c_int, [i64, vp, vp, i64, vp]),
     'tg_select_latest_workspace_bytes': (sz, [i64, i64]),
     'tg_select_latest': (C.c_int, [i64, vp, vp, i32, i64, vp, vp, vp, vp, sz, vp]),
     'tg_time_encode': (C.c_int, [i64, vp, i32, vp, vp, vp, vp]),

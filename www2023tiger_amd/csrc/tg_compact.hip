@@ -8,9 +8,7 @@
 
 namespace tg {
 
-constexpr int CB = 256;          // threads per block
-constexpr int WPT = 8;           // bitmap words per thread
-constexpr int TILE = CB * WPT;   // words per block
+constexpr int CB = 256;  // threads per block = bitmap words per block
 
 __global__ void k_mark(int64_t n, const int64_t* __restrict__ ids, uint64_t* __restrict__ bm, int64_t n_nodes) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -20,6 +18,14 @@ __global__ void k_mark(int64_t n, const int64_t* __restrict__ ids, uint64_t* __r
     uint64_t* w = bm + (id >> 6);
     if ((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) == 0)
       atomicOr((unsigned long long*)w, bit);
+  }
+}
+
+// byte flags: plain stores, no atomics (all writers store the same value)
+__global__ void k_mark_flags(int64_t n, const int64_t* __restrict__ ids, uint8_t* __restrict__ flags, int64_t n_nodes) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t id = ids[i];
+    if (id >= 0 && id < n_nodes) flags[id] = 1;
   }
 }
 
@@ -48,31 +54,52 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wave
   return base + inc - v;
 }
 
-// phase A: per-block popcount totals (both lists)
-__global__ void __launch_bounds__(CB) k_bm_block_sums(const uint64_t* __restrict__ bm, const uint64_t* __restrict__ hm,
-                                                      int64_t W, uint32_t* __restrict__ blk1, uint32_t* __restrict__ blk2) {
+// 8 flag bytes (each 0/1) -> 8 bits
+__device__ __forceinline__ uint64_t pack8(uint64_t x) { return ((x & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56; }
+
+// phase A: one thread per bitmap word.  Optionally packs 64 flag bytes into the word first
+// (the bitmap is then an OUTPUT).  Writes block-relative exclusive ranks and block totals.
+__global__ void __launch_bounds__(CB) k_bm_pack_scan(const uint8_t* __restrict__ flags, uint64_t* __restrict__ bm,
+                                                     const uint64_t* __restrict__ hm, int64_t W,
+                                                     uint32_t* __restrict__ rank1, uint32_t* __restrict__ rank2,
+                                                     uint32_t* __restrict__ blk1, uint32_t* __restrict__ blk2,
+                                                     int32_t* __restrict__ count1, int32_t* __restrict__ count2) {
   __shared__ uint32_t s_w[2][CB / TG_WAVE];
-  const int64_t w0 = (int64_t)blockIdx.x * TILE + (int64_t)threadIdx.x * WPT;
-  uint32_t c1 = 0, c2 = 0;
+  const int64_t w = (int64_t)blockIdx.x * CB + threadIdx.x;
+  uint64_t a = 0, b = 0;
+  if (w < W) {
+    if (flags) {
+      const uint4* f = reinterpret_cast<const uint4*>(flags + w * 64);
 #pragma unroll
-  for (int k = 0; k < WPT; ++k) {
-    const int64_t w = w0 + k;
-    if (w < W) {
-      const uint64_t a = bm[w];
-      c1 += __popcll(a);
-      if (hm) c2 += __popcll(a & hm[w]);
+      for (int q = 0; q < 4; ++q) {
+        const uint4 v = f[q];
+        const uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+        a |= (pack8(lo) | (pack8(hi) << 8)) << (16 * q);
+      }
+      bm[w] = a;
+    } else {
+      a = bm[w];
     }
+    if (hm) b = a & hm[w];
   }
   uint32_t t1, t2;
-  block_excl_scan(c1, s_w[0], &t1);
-  block_excl_scan(c2, s_w[1], &t2);
+  const uint32_t r1 = block_excl_scan((uint32_t)__popcll(a), s_w[0], &t1);
+  const uint32_t r2 = block_excl_scan((uint32_t)__popcll(b), s_w[1], &t2);
+  if (w < W) {
+    rank1[w] = r1;
+    if (rank2) rank2[w] = r2;
+  }
   if (threadIdx.x == 0) {
     blk1[blockIdx.x] = t1;
     blk2[blockIdx.x] = t2;
+    if (gridDim.x == 1) {
+      if (count1) *count1 = (int32_t)t1;
+      if (count2) *count2 = (int32_t)t2;
+    }
   }
 }
 
-// phase B: one block turns block totals into exclusive block offsets and writes the counts
+// phase B (only when more than one block): block totals -> exclusive block offsets + counts
 __global__ void __launch_bounds__(CB) k_bm_scan_blocks(uint32_t* __restrict__ blk1, uint32_t* __restrict__ blk2, int nblk,
                                                        int32_t* __restrict__ count1, int32_t* __restrict__ count2) {
   __shared__ uint32_t s_w[2][CB / TG_WAVE];
@@ -96,70 +123,41 @@ __global__ void __launch_bounds__(CB) k_bm_scan_blocks(uint32_t* __restrict__ bl
   }
 }
 
-// phase C: per-word ranks + id emission.  With gridDim.x == 1 it is the whole algorithm.
+// phase C: one wavefront per word, one lane per bit: coalesced emission of the id lists;
+// also turns the block-relative ranks into global ones.
 __global__ void __launch_bounds__(CB) k_bm_emit(const uint64_t* __restrict__ bm, const uint64_t* __restrict__ hm, int64_t W,
-                                                const uint32_t* __restrict__ blk1, const uint32_t* __restrict__ blk2,
-                                                uint32_t* __restrict__ rank1, int64_t* __restrict__ ids1,
-                                                int32_t* __restrict__ count1, int64_t cap,
-                                                uint32_t* __restrict__ rank2, int64_t* __restrict__ ids2,
-                                                int32_t* __restrict__ pos2, int32_t* __restrict__ count2) {
-  __shared__ uint32_t s_w[2][CB / TG_WAVE];
-  const bool single = (gridDim.x == 1);
-  const int64_t w0 = (int64_t)blockIdx.x * TILE + (int64_t)threadIdx.x * WPT;
-  uint64_t a[WPT], b[WPT];
-  uint32_t c1 = 0, c2 = 0;
-#pragma unroll
-  for (int k = 0; k < WPT; ++k) {
-    const int64_t w = w0 + k;
-    a[k] = (w < W) ? bm[w] : 0ull;
-    b[k] = (hm && w < W) ? (a[k] & hm[w]) : 0ull;
-    c1 += __popcll(a[k]);
-    c2 += __popcll(b[k]);
-  }
-  uint32_t t1, t2;
-  uint32_t r1 = block_excl_scan(c1, s_w[0], &t1) + (single ? 0u : blk1[blockIdx.x]);
-  uint32_t r2 = block_excl_scan(c2, s_w[1], &t2) + (single ? 0u : blk2[blockIdx.x]);
-  if (single && threadIdx.x == 0) {
-    if (count1) *count1 = (int32_t)t1;
-    if (count2) *count2 = (int32_t)t2;
-  }
-#pragma unroll
-  for (int k = 0; k < WPT; ++k) {
-    const int64_t w = w0 + k;
-    if (w >= W) break;
-    rank1[w] = r1;
-    if (rank2) rank2[w] = r2;
-    uint64_t m = a[k];
-    uint32_t r = r1;
-    while (m) {
-      const int bit = __ffsll((unsigned long long)m) - 1;
-      if (ids1 && (int64_t)r < cap) ids1[r] = w * 64 + bit;
-      ++r;
-      m &= m - 1;
-    }
-    m = b[k];
-    r = r2;
-    while (m) {
-      const int bit = __ffsll((unsigned long long)m) - 1;
-      if ((int64_t)r < cap) {
-        if (ids2) ids2[r] = w * 64 + bit;
-        if (pos2) pos2[r] = (int32_t)(r1 + (uint32_t)__popcll(a[k] & ((1ull << bit) - 1ull)));
+                                                int multi, const uint32_t* __restrict__ blk1,
+                                                const uint32_t* __restrict__ blk2, uint32_t* __restrict__ rank1,
+                                                int64_t* __restrict__ ids1, int64_t cap, uint32_t* __restrict__ rank2,
+                                                int64_t* __restrict__ ids2, int32_t* __restrict__ pos2,
+                                                const int32_t* __restrict__ count1, const int32_t* __restrict__ count2) {
+  const int lane = lane_id();
+  const uint64_t below = (1ull << lane) - 1ull;
+  for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < W; w += (int64_t)gridDim.x * 4) {
+    const int64_t blk = w / CB;
+    const uint64_t a = bm[w];
+    const uint32_t r1 = rank1[w] + (multi ? blk1[blk] : 0u);
+    const uint32_t mine = r1 + (uint32_t)__popcll(a & below);
+    const bool set1 = (a >> lane) & 1ull;
+    if (set1 && ids1 && (int64_t)mine < cap) ids1[mine] = w * 64 + lane;
+    uint32_t r2 = 0;
+    if (rank2) {
+      const uint64_t b = hm ? (a & hm[w]) : 0ull;
+      r2 = rank2[w] + (multi ? blk2[blk] : 0u);
+      const uint32_t m2 = r2 + (uint32_t)__popcll(b & below);
+      if (((b >> lane) & 1ull) && (int64_t)m2 < cap) {
+        if (ids2) ids2[m2] = w * 64 + lane;
+        if (pos2) pos2[m2] = (int32_t)mine;
       }
-      ++r;
-      m &= m - 1;
     }
-    r1 += __popcll(a[k]);
-    r2 += __popcll(b[k]);
+    if (multi && lane == 0) {
+      rank1[w] = r1;
+      if (rank2) rank2[w] = r2;
+    }
   }
-  // sentinel entries rank[W] = totals
-  if (single) {
-    if (threadIdx.x == 0) {
-      rank1[W] = t1;
-      if (rank2) rank2[W] = t2;
-    }
-  } else if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-    rank1[W] = blk1[blockIdx.x] + t1;
-    if (rank2) rank2[W] = blk2[blockIdx.x] + t2;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // sentinel entries rank[W] = totals
+    rank1[W] = (uint32_t)*count1;
+    if (rank2) rank2[W] = (uint32_t)*count2;
   }
 }
 
@@ -191,22 +189,26 @@ __global__ void k_sel_out(const int32_t* __restrict__ count, int64_t cap, const 
 static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 // scratch of the scan itself: two uint32 block-total arrays
-static size_t scan_ws_bytes(int64_t W) { return 2 * align16((size_t)cdiv(W, TILE) * sizeof(uint32_t)); }
+static size_t scan_ws_bytes(int64_t W) { return 2 * align16((size_t)cdiv(W, CB) * sizeof(uint32_t)) + 32; }
 
-int unique_compact_launch(const uint64_t* bm, int64_t n_nodes, uint32_t* rank, int64_t* ids, int32_t* count,
-                          int64_t cap, const uint64_t* hm, uint32_t* rank2, int64_t* ids2, int32_t* pos2,
-                          int32_t* count2, void* ws, size_t ws_bytes, hipStream_t st) {
+// flags (nullable): u8[W*64] marks to pack into `bm` first (bm is then written, not read)
+int unique_compact_launch(const uint8_t* flags, uint64_t* bm, int64_t n_nodes, uint32_t* rank, int64_t* ids,
+                          int32_t* count, int64_t cap, const uint64_t* hm, uint32_t* rank2, int64_t* ids2,
+                          int32_t* pos2, int32_t* count2, void* ws, size_t ws_bytes, hipStream_t st) {
   const int64_t W = (n_nodes + 63) / 64;
-  const int nblk = (int)cdiv(W, TILE);
-  if (ws_bytes < scan_ws_bytes(W)) return TG_EWORKSPACE;
+  const int nblk = (int)cdiv(W, CB);
+  if (ws_bytes < scan_ws_bytes(W) || !ws) return TG_EWORKSPACE;
   uint32_t* blk1 = (uint32_t*)ws;
   uint32_t* blk2 = (uint32_t*)((char*)ws + align16((size_t)nblk * sizeof(uint32_t)));
-  if (nblk > 1) {
-    hipLaunchKernelGGL(k_bm_block_sums, dim3(nblk), dim3(CB), 0, st, bm, hm, W, blk1, blk2);
-    hipLaunchKernelGGL(k_bm_scan_blocks, dim3(1), dim3(CB), 0, st, blk1, blk2, nblk, count, count2);
-  }
-  hipLaunchKernelGGL(k_bm_emit, dim3(nblk), dim3(CB), 0, st, bm, hm, W, blk1, blk2, rank, ids, count, cap, rank2, ids2,
-                     pos2, count2);
+  int32_t* spare = (int32_t*)((char*)ws + 2 * align16((size_t)nblk * sizeof(uint32_t)));
+  if (!count) count = spare;       // the emit kernel needs the totals for the sentinel
+  if (!count2) count2 = spare + 1;
+  hipLaunchKernelGGL(k_bm_pack_scan, dim3(nblk), dim3(CB), 0, st, flags, bm, hm, W, rank, rank2, blk1, blk2, count,
+                     count2);
+  if (nblk > 1) hipLaunchKernelGGL(k_bm_scan_blocks, dim3(1), dim3(CB), 0, st, blk1, blk2, nblk, count, count2);
+  hipLaunchKernelGGL(k_bm_emit, dim3(flat_grid(W, 4)), dim3(CB), 0, st, (const uint64_t*)bm, hm, W, nblk > 1 ? 1 : 0,
+                     (const uint32_t*)blk1, (const uint32_t*)blk2, rank, ids, cap, rank2, ids2, pos2,
+                     (const int32_t*)count, (const int32_t*)count2);
   return check_launch("tg_unique_compact");
 }
 
@@ -226,20 +228,30 @@ extern "C" int tg_bitmap_mark(int64_t n, const int64_t* ids, uint64_t* bitmap, i
 
 extern "C" size_t tg_unique_compact_workspace_bytes(int64_t n_nodes) { return scan_ws_bytes((n_nodes + 63) / 64); }
 
-extern "C" int tg_unique_compact(const uint64_t* bitmap, int64_t n_nodes, uint32_t* rank, int64_t* out_ids,
-                                 int32_t* out_count, int64_t cap, const uint64_t* and_bitmap, uint32_t* and_rank,
-                                 int64_t* and_ids, int32_t* and_pos, int32_t* and_count, void* ws, size_t ws_bytes,
-                                 void* stream) {
+extern "C" int tg_unique_compact(const uint8_t* flags, uint64_t* bitmap, int64_t n_nodes, uint32_t* rank,
+                                 int64_t* out_ids, int32_t* out_count, int64_t cap, const uint64_t* and_bitmap,
+                                 uint32_t* and_rank, int64_t* and_ids, int32_t* and_pos, int32_t* and_count, void* ws,
+                                 size_t ws_bytes, void* stream) {
   if (!bitmap || n_nodes <= 0 || !rank || cap < 0) return TG_EINVAL;
-  return unique_compact_launch(bitmap, n_nodes, rank, out_ids, out_count, cap, and_bitmap, and_rank, and_ids, and_pos,
-                               and_count, ws, ws_bytes, as_stream(stream));
+  return unique_compact_launch(flags, bitmap, n_nodes, rank, out_ids, out_count, cap, and_bitmap, and_rank, and_ids,
+                               and_pos, and_count, ws, ws_bytes, as_stream(stream));
 }
 
-// workspace layout of tg_select_latest: bitmap | rank | best (u64[n]) | best_idx (u32[n]) | scan scratch
+extern "C" int64_t tg_flag_bytes(int64_t n_nodes) { return ((n_nodes + 63) / 64) * 64; }
+
+extern "C" int tg_flags_mark(int64_t n, const int64_t* ids, uint8_t* flags, int64_t n_nodes, void* stream) {
+  if (n < 0 || n_nodes <= 0 || !flags) return TG_EINVAL;
+  if (n == 0) return TG_OK;
+  if (!ids) return TG_EINVAL;
+  hipLaunchKernelGGL(k_mark_flags, dim3(flat_grid(n, 256)), dim3(256), 0, as_stream(stream), n, ids, flags, n_nodes);
+  return check_launch("tg_flags_mark");
+}
+
+// workspace layout of tg_select_latest: flags | bitmap | rank | best (u64[n]) | best_idx (u32[n]) | scan scratch
 extern "C" size_t tg_select_latest_workspace_bytes(int64_t n, int64_t n_nodes) {
   const int64_t W = (n_nodes + 63) / 64;
-  return align16((size_t)W * 8) + align16((size_t)(W + 1) * 4) + align16((size_t)n * 8) + align16((size_t)n * 4) +
-         scan_ws_bytes(W);
+  return align16((size_t)W * 64) + align16((size_t)W * 8) + align16((size_t)(W + 1) * 4) + align16((size_t)n * 8) +
+         align16((size_t)n * 4) + scan_ws_bytes(W);
 }
 
 extern "C" int tg_select_latest(int64_t n, const int64_t* nids, const void* ts, int32_t ts_is_f64, int64_t n_nodes,
@@ -251,6 +263,8 @@ extern "C" int tg_select_latest(int64_t n, const int64_t* nids, const void* ts, 
   hipStream_t st = as_stream(stream);
   const int64_t W = (n_nodes + 63) / 64;
   char* p = (char*)ws;
+  uint8_t* flags = (uint8_t*)p;
+  p += align16((size_t)W * 64);
   uint64_t* bm = (uint64_t*)p;
   p += align16((size_t)W * 8);
   uint32_t* rank = (uint32_t*)p;
@@ -259,15 +273,15 @@ extern "C" int tg_select_latest(int64_t n, const int64_t* nids, const void* ts, 
   p += align16((size_t)n * 8);
   unsigned int* best_idx = (unsigned int*)p;
   p += align16((size_t)n * 4);
-  hipError_t e = hipMemsetAsync(bm, 0, (size_t)W * 8, st);
+  hipError_t e = hipMemsetAsync(flags, 0, (size_t)W * 64, st);
   if (e == hipSuccess && n > 0) e = hipMemsetAsync(best, 0, (size_t)n * 8, st);
   if (e == hipSuccess && n > 0) e = hipMemsetAsync(best_idx, 0xff, (size_t)n * 4, st);
   if (e != hipSuccess) {
     set_hip_error(e, "tg_select_latest memset");
     return TG_EHIP;
   }
-  if (n > 0) hipLaunchKernelGGL(k_mark, dim3(flat_grid(n, 256)), dim3(256), 0, st, n, nids, bm, n_nodes);
-  int rc = unique_compact_launch(bm, n_nodes, rank, out_unique, out_count, n, nullptr, nullptr, nullptr, nullptr,
+  if (n > 0) hipLaunchKernelGGL(k_mark_flags, dim3(flat_grid(n, 256)), dim3(256), 0, st, n, nids, flags, n_nodes);
+  int rc = unique_compact_launch(flags, bm, n_nodes, rank, out_unique, out_count, n, nullptr, nullptr, nullptr, nullptr,
                                  nullptr, p, scan_ws_bytes(W), st);
   if (rc != TG_OK || n == 0) return rc;
   const unsigned g = flat_grid(n, 256);

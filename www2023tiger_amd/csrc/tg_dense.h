@@ -47,6 +47,7 @@ struct GruArgs {
   float* out;
   int64_t ldo;
   const int32_t* out_rows;  // nullable
+  int dbg;                  // diagnostic ablation bits, 0 in production
 };
 
 int gru_launch(const GruArgs& g, hipStream_t st);

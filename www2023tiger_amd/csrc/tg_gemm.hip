@@ -10,6 +10,9 @@
 // the next tile's global loads are issued before the MFMAs of the current one.
 // blockIdx -> tile mapping keeps all N-tiles (and batches) of one M-tile on the same
 // XCD (blocks b and b+8 share an L2), so gathered A rows are fetched from HBM once.
+#include <cstdlib>
+#include <type_traits>
+
 #include "tg_dense.h"
 
 namespace tg {
@@ -50,39 +53,50 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
   const int K = g.k, N = g.n, kw0 = g.a0.w;
 
   const int ar = tid >> 3, ac4 = (tid & 7) * 4;  // A (and row-major W) tile coordinates
-  int64_t row0[WM], row1[WM];
-  bool rok[WM];
+  // Branch-free staging: every load is issued unconditionally from a clamped (valid) address,
+  // so the compiler can keep two tiles in flight behind counted vmcnt waits.  Rows past M and
+  // weight rows past N only feed outputs that are never stored; only k >= K needs zeros.
+  const float* arow0[WM];
+  const float* arow1[WM];
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
-    const int64_t m = m0 + ar + i * 32;
-    rok[i] = m < M;
-    row0[i] = (rok[i] && g.a0.idx) ? g.a0.idx[m] : m;
-    row1[i] = (rok[i] && g.a1.p && g.a1.idx) ? g.a1.idx[m] : m;
+    const int64_t m = min(m0 + ar + i * 32, M - 1);
+    arow0[i] = a0p + (g.a0.idx ? g.a0.idx[m] : m) * g.a0.ld;
+    arow1[i] = g.a1.p ? g.a1.p + (g.a1.idx ? g.a1.idx[m] : m) * g.a1.ld - kw0 : arow0[i];
   }
-  float4 ra[WM], rb[WN];
-  auto load = [&](int kt) {
+  const float* wrow[WN];
+#pragma unroll
+  for (int i = 0; i < WN; ++i) {
+    if (!g.w_kmajor) {
+      wrow[i] = wp + (int64_t)min(n0 + ar + i * 32, N - 1) * g.ldw;
+    } else {
+      const int f = tid + i * 256;
+      wrow[i] = wp + min(n0 + (f % (BN / 4)) * 4, N - 4);  // column offset; the k row is added per tile
+    }
+  }
+  float4 ra0[WM], rb0[WN], ra1[WM], rb1[WN];  // two tiles in flight (global -> registers)
+  auto load = [&](int kt, float4* ra, float4* rb) {
     const int k = kt * BK + ac4;
+    const bool kin = k < K;
+    const int kc = kin ? k : 0;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
-      float4 v = zero4();
-      if (rok[i] && k < K) v = (k < kw0) ? ldg4(a0p + row0[i] * g.a0.ld + k) : ldg4(g.a1.p + row1[i] * g.a1.ld + (k - kw0));
-      ra[i] = v;
+      const float4 v = ldg4((kc < kw0 ? arow0[i] : arow1[i]) + kc);
+      ra[i] = kin ? v : zero4();
     }
 #pragma unroll
     for (int i = 0; i < WN; ++i) {
-      float4 v = zero4();
       if (!g.w_kmajor) {
-        const int n = n0 + ar + i * 32;
-        if (n < N && k < K) v = ldg4(wp + (int64_t)n * g.ldw + k);
+        const float4 v = ldg4(wrow[i] + kc);
+        rb[i] = kin ? v : zero4();
       } else {
-        const int f = tid + i * 256;
-        const int kk = kt * BK + f / (BN / 4), n = n0 + (f % (BN / 4)) * 4;
-        if (kk < K && n < N) v = ldg4(wp + (int64_t)kk * g.ldw + n);
+        const int kk = kt * BK + (tid + i * 256) / (BN / 4);
+        const float4 v = ldg4(wrow[i] + (int64_t)min(kk, K - 1) * g.ldw);
+        rb[i] = kk < K ? v : zero4();
       }
-      rb[i] = v;
     }
   };
-  auto store = [&](int buf) {
+  auto store = [&](int buf, const float4* ra, const float4* rb) {
 #pragma unroll
     for (int i = 0; i < WM; ++i) sts4(As[buf][ar + i * 32], ac4, ra[i]);
 #pragma unroll
@@ -105,16 +119,33 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   const int nkt = (K + BK - 1) / BK;
-  load(0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    store(buf);
-    __syncthreads();
-    if (kt + 1 < nkt) load(kt + 1);
+  auto compute = [&](int buf, int half) {
     const float* ap = &As[buf][wm * 32 + fr][fk];
     const float* bp = &Bs[buf][wn * 32 + fr][fk];
 #pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc, 0, 0, 0);
+    for (int ks = half * (BK / 4); ks < (half + 1) * (BK / 4); ++ks)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc, 0, 0, 0);
+  };
+  // Software pipeline: tile t is multiplied out of LDS[t&1] while tile t+1 moves registers -> LDS
+  // (its ds_writes sit BETWEEN the two MFMA halves so they issue under the matrix pipe) and
+  // tile t+2 travels global -> registers.  One barrier per tile.
+  load(0, ra0, rb0);
+  if (nkt > 1) load(1, ra1, rb1);
+  store(0, ra0, rb0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; kt += 2) {
+    if (kt + 2 < nkt) load(kt + 2, ra0, rb0);
+    compute(0, 0);
+    if (kt + 1 < nkt) store(1, ra1, rb1);
+    compute(0, 1);
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      if (kt + 3 < nkt) load(kt + 3, ra1, rb1);
+      compute(1, 0);
+      if (kt + 2 < nkt) store(0, ra0, rb0);
+      compute(1, 1);
+      __syncthreads();
+    }
   }
   const int n = n0 + wn * 32 + fr;
   if (n >= N) return;
@@ -150,8 +181,12 @@ int gemm_launch(const GemmArgs& g, hipStream_t st) {
 // columns and accumulates four planes per column: r and z over K = [x | h], i_n over x
 // only, h_n over h only (no wasted MFMAs on the zero blocks of a packed [4d, 5d] weight).
 // ---------------------------------------------------------------------------------
+// diagnostic only (TG_GRU_DBG & 16): per-block s_memtime stamps {entry, loop start, loop end, exit}
+__device__ unsigned long long g_gru_trace[2048 * 4];
+
 __global__ void __launch_bounds__(256) k_gru(GruArgs g) {
   constexpr int BM = 128;
+  const unsigned long long t_entry = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
   __shared__ float As[2][BM][LDK];
   __shared__ float Bs[2][3][32][LDK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -166,38 +201,38 @@ __global__ void __launch_bounds__(256) k_gru(GruArgs g) {
   if (m0 >= M) return;
   const int j0 = nt * 32;
   const int ar = tid >> 3, ac4 = (tid & 7) * 4;
-  int64_t rx[4], rh[4];
-  bool rok[4];
+  // branch-free staging (see k_gemm): clamped addresses, zeros only for k past the segment
+  const float* xrow[4];
+  const float* hrow[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int64_t m = m0 + ar + i * 32;
-    rok[i] = m < M;
-    rx[i] = (rok[i] && g.x.idx) ? g.x.idx[m] : m;
-    rh[i] = (rok[i] && g.h.idx) ? g.h.idx[m] : m;
+    const int64_t m = min(m0 + ar + i * 32, M - 1);
+    xrow[i] = g.x.p + (g.x.idx ? g.x.idx[m] : m) * g.x.ld;
+    hrow[i] = g.h.p + (g.h.idx ? g.h.idx[m] : m) * g.h.ld;
   }
+  const int jc = min(j0 + ar, d - 1);
   const int nkx = (xw + BK - 1) / BK, nkh = (d + BK - 1) / BK;
   const int nkt = nkx + nkh;
-  float4 ra[4], rb[3];
-  auto load = [&](int t) {
+  float4 ra0[4], rb0[3], ra1[4], rb1[3];
+  auto load = [&](int t, float4* ra, float4* rb) {
     const bool hp = t >= nkx;
     const int k = (hp ? t - nkx : t) * BK + ac4;
     const int width = hp ? d : xw;
+    const bool kin = k < width;
+    const int kc = kin ? k : 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float4 v = zero4();
-      if (rok[i] && k < width) v = hp ? ldg4(g.h.p + rh[i] * g.h.ld + k) : ldg4(g.x.p + rx[i] * g.x.ld + k);
-      ra[i] = v;
+      const float4 v = ldg4((hp ? hrow[i] : xrow[i]) + kc);
+      ra[i] = kin ? v : zero4();
     }
-    const int j = j0 + ar;
-    const float* wbase = hp ? g.w_hh : g.w_ih;
+    const float* wbase = (hp ? g.w_hh : g.w_ih) + (int64_t)jc * width + kc;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      float4 v = zero4();
-      if (j < d && k < width) v = ldg4(wbase + ((int64_t)i * d + j) * width + k);
-      rb[i] = v;
+      const float4 v = ldg4(wbase + (int64_t)i * d * width);
+      rb[i] = kin ? v : zero4();
     }
   };
-  auto store = [&](int buf) {
+  auto store = [&](int buf, const float4* ra, const float4* rb) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) sts4(As[buf][ar + i * 32], ac4, ra[i]);
 #pragma unroll
@@ -207,36 +242,108 @@ __global__ void __launch_bounds__(256) k_gru(GruArgs g) {
   f32x16 acc_r, acc_z, acc_in, acc_hn;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc_r[i] = acc_z[i] = acc_in[i] = acc_hn[i] = 0.f;
-  load(0);
-  for (int t = 0; t < nkt; ++t) {
-    const int buf = t & 1;
-    store(buf);
+  const int dbg = g.dbg;  // bit 16: record s_memtime stamps (diagnostic build knob, 0 in production)
+  // ---- hand-scheduled tile step ------------------------------------------------------
+  // A CU pulls only ~10 B/clk through its vector-memory path, and a wave issues in order: a
+  // burst of 7 global loads (or 28 ds_writes) in front of the MFMAs stalls the matrix pipe
+  // until the memory queue drains (measured: loop = MFMA + loads + stores, nothing hidden).
+  // So the memory work of the OTHER tiles is threaded between the MFMAs of this tile, one
+  // op per MFMA slot, and the order is pinned with sched_barrier:
+  //   first half  (4 k-step pairs): 7 global loads of tile t+2,
+  //   second half (4 k-step pairs): 7 float4 ds_writes of tile t+1 into the other LDS buffer,
+  // while the operand fragments of the next k-step pair are read one pair ahead.
+  struct Frag {
+    float a0, a1, b00, b01, b10, b11, b20, b21;
+  };
+  auto read_pair = [&](int buf, int p, Frag& f) {  // k-steps 2p and 2p+1 of the tile in LDS[buf]
+    const float* ap = &As[buf][wave * 32 + fr][fk + 4 * p];
+    const float* b0 = &Bs[buf][0][fr][fk + 4 * p];
+    const float* b1 = &Bs[buf][1][fr][fk + 4 * p];
+    const float* b2 = &Bs[buf][2][fr][fk + 4 * p];
+    f.a0 = ap[0]; f.a1 = ap[2];
+    f.b00 = b0[0]; f.b01 = b0[2];
+    f.b10 = b1[0]; f.b11 = b1[2];
+    f.b20 = b2[0]; f.b21 = b2[2];
+  };
+  auto load_one = [&](int t, int i, float4* ra, float4* rb) {  // i-th of the 7 float4 of tile t
+    const bool hp = t >= nkx;
+    const int k = (hp ? t - nkx : t) * BK + ac4;
+    const int width = hp ? d : xw;
+    const bool kin = k < width;
+    const int kc = kin ? k : 0;
+    // raw load from a clamped address; columns past the segment are zeroed when the tile is
+    // written to LDS (store_one), so nothing consumes the load result here
+    if (i < 4)
+      ra[i] = ldg4((hp ? hrow[i] : xrow[i]) + kc);
+    else
+      rb[i - 4] = ldg4((hp ? g.w_hh : g.w_ih) + ((int64_t)(i - 4) * d + jc) * width + kc);
+  };
+  auto store_one = [&](int buf, int t, int i, const float4* ra, const float4* rb) {  // tile t's i-th float4
+    const bool hp = t >= nkx;
+    const bool kin = (hp ? t - nkx : t) * BK + ac4 < (hp ? d : xw);
+    if (i < 4)
+      sts4(As[buf][ar + i * 32], ac4, kin ? ra[i] : zero4());
+    else
+      sts4(Bs[buf][i - 4][ar], ac4, kin ? rb[i - 4] : zero4());
+  };
+#define TG_SB() __builtin_amdgcn_sched_barrier(0)
+  auto tile = [&](auto hp_tag, int buf, int t, float4* la, float4* lb, const float4* sa, const float4* sb) {
+    constexpr bool HP = decltype(hp_tag)::value;
+    const int tl = min(t + 2, nkt - 1);  // past the end: a redundant reload keeps the block branch-free
+    Frag cur, nxt;
+    read_pair(buf, 0, cur);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int m0i = (p & 3) * 2, m1i = m0i + 1;  // memory-op slots of this pair: 0..6 used
+      acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a0, cur.b00, acc_r, 0, 0, 0);
+      if (p < 7) read_pair(buf, p + 1, nxt);
+      TG_SB();
+      acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a0, cur.b10, acc_z, 0, 0, 0);
+      TG_SB();
+      if (HP) acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a0, cur.b20, acc_hn, 0, 0, 0);
+      else acc_in = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a0, cur.b20, acc_in, 0, 0, 0);
+      if (p < 4) load_one(tl, m0i, la, lb);
+      else store_one(buf ^ 1, t + 1, m0i, sa, sb);
+      TG_SB();
+      acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a1, cur.b01, acc_r, 0, 0, 0);
+      TG_SB();
+      acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a1, cur.b11, acc_z, 0, 0, 0);
+      TG_SB();
+      if (HP) acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a1, cur.b21, acc_hn, 0, 0, 0);
+      else acc_in = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a1, cur.b21, acc_in, 0, 0, 0);
+      if (m1i < 7) {
+        if (p < 4) load_one(tl, m1i, la, lb);
+        else store_one(buf ^ 1, t + 1, m1i, sa, sb);
+      }
+      TG_SB();
+      cur = nxt;
+    }
     __syncthreads();
-    if (t + 1 < nkt) load(t + 1);
-    const float* ap = &As[buf][wave * 32 + fr][fk];
-    const float* b0 = &Bs[buf][0][fr][fk];
-    const float* b1 = &Bs[buf][1][fr][fk];
-    const float* b2 = &Bs[buf][2][fr][fk];
-    if (t < nkx) {
+  };
+#undef TG_SB
+  using HP0 = std::integral_constant<bool, false>;
+  using HP1 = std::integral_constant<bool, true>;
+  // prologue: tile 0 -> LDS[0]; tile 1 -> registers R1
 #pragma unroll
-      for (int ks = 0; ks < BK / 2; ++ks) {
-        const float a = ap[2 * ks];
-        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[2 * ks], acc_r, 0, 0, 0);
-        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[2 * ks], acc_z, 0, 0, 0);
-        acc_in = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2[2 * ks], acc_in, 0, 0, 0);
-      }
-    } else {
+  for (int i = 0; i < 7; ++i) load_one(0, i, ra0, rb0);
 #pragma unroll
-      for (int ks = 0; ks < BK / 2; ++ks) {
-        const float a = ap[2 * ks];
-        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0[2 * ks], acc_r, 0, 0, 0);
-        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[2 * ks], acc_z, 0, 0, 0);
-        acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2[2 * ks], acc_hn, 0, 0, 0);
-      }
+  for (int i = 0; i < 7; ++i) load_one(min(1, nkt - 1), i, ra1, rb1);
+#pragma unroll
+  for (int i = 0; i < 7; ++i) store_one(0, 0, i, ra0, rb0);
+  __syncthreads();
+  const unsigned long long t_loop0 = (dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
+  for (int t = 0; t < nkt; t += 2) {
+    // even tile: multiply LDS[0]; load tile t+2 -> R0; store tile t+1 (R1) -> LDS[1]
+    if (t < nkx) tile(HP0{}, 0, t, ra0, rb0, ra1, rb1);
+    else tile(HP1{}, 0, t, ra0, rb0, ra1, rb1);
+    if (t + 1 < nkt) {
+      if (t + 1 < nkx) tile(HP0{}, 1, t + 1, ra1, rb1, ra0, rb0);
+      else tile(HP1{}, 1, t + 1, ra1, rb1, ra0, rb0);
     }
   }
-  const int j = j0 + fr;
-  if (j >= d) return;
+  const unsigned long long t_loop1 = (dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
+  const int j = min(j0 + fr, d - 1);
+  const bool jok = j0 + fr < d;
   const float br = g.b_ih[j] + g.b_hh[j];
   const float bz = g.b_ih[d + j] + g.b_hh[d + j];
   const float bin = g.b_ih[2 * d + j], bhn = g.b_hh[2 * d + j];
@@ -250,8 +357,18 @@ __global__ void __launch_bounds__(256) k_gru(GruArgs g) {
     const float zg = sigmoidf_(acc_z[r] + bz);
     const float ng = tanhf(acc_in[r] + bin + rg * (acc_hn[r] + bhn));
     const int64_t orow = g.out_rows ? (int64_t)g.out_rows[m] : m;
-    g.out[orow * g.ldo + j] = (1.f - zg) * ng + zg * hold;
+    if (jok) g.out[orow * g.ldo + j] = (1.f - zg) * ng + zg * hold;
   }
+  if ((dbg & 16) && tid == 0 && blockIdx.x < 2048) {
+    g_gru_trace[blockIdx.x * 4 + 0] = t_entry;
+    g_gru_trace[blockIdx.x * 4 + 1] = t_loop0;
+    g_gru_trace[blockIdx.x * 4 + 2] = t_loop1;
+    g_gru_trace[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
+  }
+}
+
+extern "C" int tg_debug_gru_trace(unsigned long long* out_host, int n_blocks) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_gru_trace), sizeof(unsigned long long) * 4 * n_blocks) == hipSuccess ? 0 : -4;
 }
 
 int gru_launch(const GruArgs& g, hipStream_t st) {
@@ -260,7 +377,10 @@ int gru_launch(const GruArgs& g, hipStream_t st) {
   const int64_t MT = cdiv(g.cap, 128);
   const int NT = (g.d + 31) / 32;
   const int64_t grid = 8 * cdiv(MT, 8) * NT;
-  hipLaunchKernelGGL(k_gru, dim3((unsigned)grid), dim3(256), 0, st, g);
+  static const int dbg = getenv("TG_GRU_DBG") ? atoi(getenv("TG_GRU_DBG")) : 0;  // diagnostic ablation only
+  GruArgs a = g;
+  a.dbg = dbg;
+  hipLaunchKernelGGL(k_gru, dim3((unsigned)grid), dim3(256), 0, st, a);
   return check_launch("gru");
 }
 

@@ -101,12 +101,6 @@ __device__ __forceinline__ int64_t prefix_end(const tg_tcsr& g, int64_t nid, dou
   return lo;
 }
 
-// set bit `id`, skipping the atomic when the bit is already visible
-__device__ __forceinline__ void mark_bit(uint64_t* bm, int64_t id) {
-  const uint64_t bit = 1ull << (id & 63);
-  uint64_t* w = bm + (id >> 6);
-  if ((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) == 0) atomicOr((unsigned long long*)w, bit);
-}
 
 // G lanes cooperate on one query: all run the binary search on the same addresses
 // (broadcast loads), then copy the K-entry tail with one lane per slot.
@@ -115,14 +109,13 @@ __global__ void __launch_bounds__(256) k_sample_recent_edges(tg_tcsr g, int64_t 
                                                              const double* __restrict__ qts, int K,
                                                              int64_t* __restrict__ o_nbr, int64_t* __restrict__ o_eid,
                                                              float* __restrict__ o_ts, int64_t* __restrict__ o_dir,
-                                                             uint64_t* __restrict__ mark) {
+                                                             uint8_t* __restrict__ mark) {
   constexpr int GPB = 256 / G;
   const int sub = threadIdx.x % G;
   for (int64_t q = (int64_t)blockIdx.x * GPB + threadIdx.x / G; q < Q; q += (int64_t)gridDim.x * GPB) {
     const int64_t nid = nids[q];
     int64_t start;
     const int64_t end = prefix_end(g, nid, qts[q], &start);
-    bool pad = false;
     for (int j = sub; j < K; j += G) {
       const int64_t p = end - K + j;
       int64_t nb = 0, ed = 0, dr = 0;
@@ -139,17 +132,9 @@ __global__ void __launch_bounds__(256) k_sample_recent_edges(tg_tcsr g, int64_t 
       o_eid[o] = ed;
       o_ts[o] = tt;
       if (o_dir) o_dir[o] = dr;
-      if (mark) {
-        if (nb == 0)
-          pad = true;
-        else
-          mark_bit(mark, nb);
-      }
+      if (mark) mark[nb] = 1;  // byte flag, plain store: every writer stores the same value, no atomics
     }
-    if (mark) {
-      if (sub == 0 && nid >= 0 && nid < g.num_node) mark_bit(mark, nid);
-      if (pad) mark_bit(mark, 0);
-    }
+    if (mark && sub == 0 && nid >= 0 && nid < g.num_node) mark[nid] = 1;
   }
 }
 
@@ -373,7 +358,7 @@ static int sample_args_ok(const tg_tcsr* g, int64_t Q, const void* a, const void
 }
 
 extern "C" int tg_sample_recent_edges(const tg_tcsr* g, int64_t Q, const int64_t* nids, const double* ts, int32_t K,
-                                      int64_t* o_nbr, int64_t* o_eid, float* o_ts, int64_t* o_dir, uint64_t* mark,
+                                      int64_t* o_nbr, int64_t* o_eid, float* o_ts, int64_t* o_dir, uint8_t* mark,
                                       void* stream) {
   if (!sample_args_ok(g, Q, nids, ts, K, o_nbr, o_eid, o_ts)) return TG_EINVAL;
   if (Q == 0) return TG_OK;

@@ -90,6 +90,9 @@ __device__ __forceinline__ void axpby4(float4& s, float a, float b, float4 x) {
 // reprs[local]+nfeat, edge part efeat, time part cos(dt*w+phi); per head an online
 // softmax over the keys accumulates the weighted raw row.  Rows are float4 per lane
 // (NV float4 per segment per lane, i.e. widths up to 256*NV).
+// Latency structure: lane k first resolves key k's metadata (neighbour id -> local row via
+// the rank popcount, edge id, dt) for all K keys at once, the per-key loop then only
+// broadcasts it, and the raw rows of key k+1 are requested before key k is reduced.
 template <int NH, int NV>
 __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const float* __restrict__ ts,
                                                    const int64_t* __restrict__ l1_nids,
@@ -104,14 +107,27 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
   const float4* ef = reinterpret_cast<const float4*>(m.efeats);
   const float4* fq = reinterpret_cast<const float4*>(m.te_freq);
   const float4* ph = reinterpret_cast<const float4*>(m.te_phase);
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 w4[NV], p4[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const int c = lane + v * TG_WAVE;
-    w4[v] = c < d4 ? fq[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-    p4[v] = c < d4 ? ph[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    w4[v] = c < d4 ? fq[c] : z4;
+    p4[v] = c < d4 ? ph[c] : z4;
   }
   for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < Q; i += (int64_t)gridDim.x * 4) {
+    // ---- per-key metadata, one key per lane
+    int64_t nb_l = 0, eid_l = 0;
+    float dt_l = 0.f;
+    int u_l = 0;
+    if (lane < K) {
+      nb_l = l1_nids[i * K + lane];
+      eid_l = l1_eids[i * K + lane];
+      dt_l = ts[i] - l1_ts[i * K + lane];
+      if (nb_l != 0) u_l = (int)bm_rank(bm, rank, nb_l);
+    }
+    unsigned long long live = __ballot(nb_l != 0);  // padding keys are masked (temporal_agg_modules.py:80)
+    const bool any = live != 0ull;
     float4 g[NH][3][NV], acc[NH][3][NV];
     float mx[NH], l[NH];
 #pragma unroll
@@ -122,40 +138,44 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const int c = lane + v * TG_WAVE;
-        g[h][0][v] = c < d4 ? gh[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-        g[h][1][v] = c < e4 ? gh[d4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
-        g[h][2][v] = c < d4 ? gh[d4 + e4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
-        acc[h][0][v] = acc[h][1][v] = acc[h][2][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        g[h][0][v] = c < d4 ? gh[c] : z4;
+        g[h][1][v] = c < e4 ? gh[d4 + c] : z4;
+        g[h][2][v] = c < d4 ? gh[d4 + e4 + c] : z4;
+        acc[h][0][v] = acc[h][1][v] = acc[h][2][v] = z4;
       }
     }
-    const float t_i = ts[i];
-    bool any = false;
-    for (int k = 0; k < K; ++k) {
-      const int64_t nb = l1_nids[i * K + k];
-      if (nb == 0) continue;  // padding key is masked (temporal_agg_modules.py:80); wave-uniform
-      any = true;
-      const int64_t u = bm_rank(bm, rank, nb);
-      const int64_t eid = l1_eids[i * K + k];
-      const float dt = t_i - l1_ts[i * K + k];
+    float4 ya[NV], yn[NV], yb[NV];  // raw rows of the NEXT key (in flight)
+    auto fetch = [&](int k) {
+      const int64_t u = __shfl(u_l, k, TG_WAVE);
+      const int64_t nb = __shfl(nb_l, k, TG_WAVE);
+      const int64_t eid = __shfl(eid_l, k, TG_WAVE);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int c = lane + v * TG_WAVE;
+        ya[v] = c < d4 ? reprs[u * d4 + c] : z4;
+        yn[v] = (nf && c < d4) ? nf[nb * d4 + c] : z4;
+        yb[v] = (ef && c < e4) ? ef[eid * e4 + c] : z4;
+      }
+    };
+    int k = live ? (__ffsll(live) - 1) : -1;
+    if (k >= 0) fetch(k);
+    while (k >= 0) {
+      live &= live - 1;
+      const int kn = live ? (__ffsll(live) - 1) : -1;
+      const float dt = __shfl(dt_l, k, TG_WAVE);
       float4 x[3][NV];
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const int c = lane + v * TG_WAVE;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, t = a;
-        if (c < d4) {
-          a = reprs[u * d4 + c];
-          if (nf) {
-            const float4 f = nf[nb * d4 + c];
-            a.x += f.x; a.y += f.y; a.z += f.z; a.w += f.w;
-          }
-          t = make_float4(time_enc(dt, w4[v].x, p4[v].x), time_enc(dt, w4[v].y, p4[v].y),
-                          time_enc(dt, w4[v].z, p4[v].z), time_enc(dt, w4[v].w, p4[v].w));
-        }
-        if (ef && c < e4) b = ef[eid * e4 + c];
+        float4 a = ya[v];
+        a.x += yn[v].x; a.y += yn[v].y; a.z += yn[v].z; a.w += yn[v].w;
         x[0][v] = a;
-        x[1][v] = b;
-        x[2][v] = t;
+        x[1][v] = yb[v];
+        x[2][v] = c < d4 ? make_float4(time_enc(dt, w4[v].x, p4[v].x), time_enc(dt, w4[v].y, p4[v].y),
+                                       time_enc(dt, w4[v].z, p4[v].z), time_enc(dt, w4[v].w, p4[v].w))
+                         : z4;
       }
+      if (kn >= 0) fetch(kn);  // next key's rows travel while this key is reduced
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         float p = 0.f;
@@ -173,6 +193,7 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
 #pragma unroll
           for (int v = 0; v < NV; ++v) axpby4(acc[h][sgm][v], a, b, x[sgm][v]);
       }
+      k = kn;
     }
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
@@ -198,6 +219,7 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
 
 static int attn_dims_ok(const tg_model* m) {
   if (!m || m->d <= 0 || (m->d % 4) || m->d_e <= 0 || (m->d_e % 4) || m->n_neighbors <= 0) return 0;
+  if (m->n_neighbors > TG_WAVE) return 0;  // one key per lane in k_attn_core
   if (m->n_head <= 0 || (2 * m->d) % m->n_head || ((2 * m->d / m->n_head) % 4)) return 0;
   return 1;
 }
@@ -423,9 +445,9 @@ __global__ void k_advance(int64_t* off, int64_t B) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *off += B;
 }
 
-int unique_compact_launch(const uint64_t* bm, int64_t n_nodes, uint32_t* rank, int64_t* ids, int32_t* count,
-                          int64_t cap, const uint64_t* hm, uint32_t* rank2, int64_t* ids2, int32_t* pos2,
-                          int32_t* count2, void* ws, size_t ws_bytes, hipStream_t st);
+int unique_compact_launch(const uint8_t* flags, uint64_t* bm, int64_t n_nodes, uint32_t* rank, int64_t* ids,
+                          int32_t* count, int64_t cap, const uint64_t* hm, uint32_t* rank2, int64_t* ids2,
+                          int32_t* pos2, int32_t* count2, void* ws, size_t ws_bytes, hipStream_t st);
 
 }  // namespace tg
 
@@ -544,10 +566,11 @@ extern "C" int tg_profiler_read(tg_profiler* p, float* ms_out) {
 }
 
 struct StepWs {
-  uint64_t* bm;              // involved bitmap            (zeroed every step)
+  uint8_t* flags;            // involved byte flags        (zeroed every step)
   unsigned long long* best;  // per involved rank          (zeroed every step)
   int32_t* counts;           // [4]                        (zeroed every step)
-  size_t zero_bytes;         // size of the contiguous zeroed region starting at bm
+  size_t zero_bytes;         // size of the contiguous zeroed region starting at flags
+  uint64_t* bm;              // involved bitmap, packed from the flags
   uint32_t *rank, *rank_out;
   int64_t *nids3, *eids, *involved, *outdated, *upos, *index;
   double* ts3;
@@ -565,10 +588,11 @@ static bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w) {
   const int64_t Q = 3 * B, K = m->n_neighbors, cap = Q * (K + 1);
   const int64_t W = (m->n_nodes + 63) / 64;
   char* z0 = cv.p;
-  w.bm = cv.take<uint64_t>((size_t)W);
+  w.flags = cv.take<uint8_t>((size_t)W * 64);
   w.best = cv.take<unsigned long long>((size_t)cap);
   w.counts = cv.take<int32_t>(4);
   w.zero_bytes = cv.ok ? (size_t)(cv.p - z0) : 0;
+  w.bm = cv.take<uint64_t>((size_t)W);
   w.rank = cv.take<uint32_t>((size_t)W + 1);
   w.rank_out = cv.take<uint32_t>((size_t)W + 1);
   w.nids3 = cv.take<int64_t>((size_t)Q);
@@ -595,7 +619,7 @@ static bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w) {
 extern "C" size_t tg_stream_step_workspace_bytes(const tg_model* m, int64_t B) {
   if (!attn_dims_ok(m) || B <= 0 || m->n_nodes <= 0) return 0;
   const size_t Q = 3 * (size_t)B, K = m->n_neighbors, cap = Q * (K + 1), W = (m->n_nodes + 63) / 64;
-  size_t b = align16(W * 8) + align16(cap * 8) + 16 + 2 * align16((W + 1) * 4) + align16(Q * 8) * 2 + align16(B * 8) +
+  size_t b = align16(W * 64) + align16(W * 8) + align16(cap * 8) + 16 + 2 * align16((W + 1) * 4) + align16(Q * 8) * 2 + align16(B * 8) +
              align16(Q * 4) + align16(Q * K * 8) * 2 + align16(Q * K * 4) + align16(cap * 8) * 2 + align16(cap * 4) +
              align16(2 * B * 8) * 2 + align16(cap * m->d * 4) + align16(tg_unique_compact_workspace_bytes(m->n_nodes)) +
              attn_ws_bytes(m, Q) + align16(apply_ws_bytes(m, cap));
@@ -614,7 +638,7 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
   StepWs w{};
   if (!carve_step(m, B, cv, w)) return TG_EWORKSPACE;
   prof_mark(pf, ST_QUERIES, st);
-  hipError_t e = hipMemsetAsync(w.bm, 0, w.zero_bytes, st);
+  hipError_t e = hipMemsetAsync(w.flags, 0, w.zero_bytes, st);
   if (e != hipSuccess) {
     set_hip_error(e, "tg_stream_step memset");
     return TG_EHIP;
@@ -629,12 +653,12 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
   int64_t* l1n = io->l1_nids ? io->l1_nids : w.l1_nids;
   int64_t* l1e = io->l1_eids ? io->l1_eids : w.l1_eids;
   float* l1t = io->l1_ts ? io->l1_ts : w.l1_ts;
-  if ((rc = tg_sample_recent_edges(g, Q, w.nids3, w.ts3, (int32_t)K, l1n, l1e, l1t, nullptr, w.bm, stream)) != TG_OK)
+  if ((rc = tg_sample_recent_edges(g, Q, w.nids3, w.ts3, (int32_t)K, l1n, l1e, l1t, nullptr, w.flags, stream)) != TG_OK)
     return rc;
   prof_mark(pf, ST_COMPACT, st);
   int64_t* involved = io->involved ? io->involved : w.involved;
   // involved = sorted(set(...)); outdated = involved & has-message (memory.py:108-126)
-  if ((rc = unique_compact_launch(w.bm, m->n_nodes, w.rank, involved, w.counts + 0, cap, m->has_msg, w.rank_out,
+  if ((rc = unique_compact_launch(w.flags, w.bm, m->n_nodes, w.rank, involved, w.counts + 0, cap, m->has_msg, w.rank_out,
                                   w.outdated, w.out_pos, w.counts + 1, w.scan_ws, w.scan_bytes, st)) != TG_OK)
     return rc;
   prof_mark(pf, ST_GATHER, st);

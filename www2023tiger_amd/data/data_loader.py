@@ -3,7 +3,7 @@
 
 Per batch the reference makes 6 Python-loop sampler calls on the host
 (data_loader.py:77-168).  Here one sampler launch covers cat[src,dst,neg] and
-marks the involved-node bitmap in the same kernel, the sorted unique set and the
+flags the involved nodes in the same kernel, the sorted unique set and the
 local index come from a prefix-popcount over that bitmap, restart histories are a
 second launch, and (under the default recent_edges strategy) the four hit
 matrices are row blocks of the first launch's output.
@@ -36,12 +36,12 @@ class GraphCollator:
     def collate_memory_nodes(self, nids3: torch.Tensor, ts3: torch.Tensor):
         g, K = self.graph, self.n_neighbors
         dev = g.device
-        bitmap = hip_ops.new_bitmap(self.n_nodes, dev)
-        l_n, l_e, l_t, _ = g.sample_device(nids3, ts3, K, mark_bitmap=bitmap, want_dirs=False)
+        flags = hip_ops.new_flags(self.n_nodes, dev)
+        l_n, l_e, l_t, _ = g.sample_device(nids3, ts3, K, mark_flags=flags, want_dirs=False)
         cap = nids3.numel() * (K + 1)
-        comp = hip_ops.unique_compact(bitmap, self.n_nodes, cap)
+        comp = hip_ops.unique_compact(None, self.n_nodes, cap, flags=flags)
         layers = [(nids3, None, None), (l_n, l_e, l_t)]
-        return layers, bitmap, comp
+        return layers, comp['bitmap'], comp
 
     def collate_restart_data(self, pos: torch.Tensor, ts2: torch.Tensor):
         g = self.graph

@@ -116,7 +116,7 @@ class Graph:
 
     # ---- sampling -------------------------------------------------------------------
     def sample_device(self, nids: Tensor, ts: Tensor, n_neighbors: int, strategy: Optional[str] = None,
-                      mark_bitmap: Optional[Tensor] = None, want_dirs: bool = True
+                      mark_flags: Optional[Tensor] = None, want_dirs: bool = True
                       ) -> Tuple[Tensor, Tensor, Tensor, Optional[Tensor]]:
         """Device-tensor form of sample_temporal_neighbor: nids int64[Q], ts float64[Q]."""
         strategy = self.strategy if strategy is None else strategy
@@ -133,7 +133,7 @@ class Graph:
         s = stream_ptr(dev)
         if strategy == 'recent_edges':
             check(lib.tg_sample_recent_edges(C.byref(g), Q, ptr(nids), ptr(ts), K, ptr(o_n), ptr(o_e), ptr(o_t),
-                                             ptr(o_d), ptr(mark_bitmap), s), 'tg_sample_recent_edges')
+                                             ptr(o_d), ptr(mark_flags), s), 'tg_sample_recent_edges')
         elif strategy == 'recent_nodes':
             check(lib.tg_sample_recent_nodes(C.byref(g), Q, ptr(nids), ptr(ts), K, ptr(o_n), ptr(o_e), ptr(o_t),
                                              ptr(o_d), s), 'tg_sample_recent_nodes')
@@ -142,10 +142,10 @@ class Graph:
                                         ptr(o_e), ptr(o_t), ptr(o_d), s), 'tg_sample_uniform')
         else:
             raise NotImplementedError(strategy)
-        if mark_bitmap is not None and strategy != 'recent_edges':
-            from ..hip_ops import bitmap_mark
-            bitmap_mark(nids, mark_bitmap, self.num_node)
-            bitmap_mark(o_n.reshape(-1), mark_bitmap, self.num_node)
+        if mark_flags is not None and strategy != 'recent_edges':
+            from ..hip_ops import flags_mark
+            flags_mark(nids, mark_flags, self.num_node)
+            flags_mark(o_n.reshape(-1), mark_flags, self.num_node)
         return o_n, o_e, o_t, o_d
 
     def sample_temporal_neighbor(self, nids: np.ndarray, ts: np.ndarray, n_neighbors: int = 20,

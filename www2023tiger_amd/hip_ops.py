@@ -42,11 +42,25 @@ def bitmap_mark(ids: Tensor, bitmap: Tensor, n_nodes: int):
     check(lib.tg_bitmap_mark(ids.numel(), ptr(ids), ptr(bitmap), n_nodes, stream_ptr(ids.device)), 'tg_bitmap_mark')
 
 
-def unique_compact(bitmap: Tensor, n_nodes: int, cap: int, and_bitmap: Optional[Tensor] = None):
-    """-> dict(rank, ids, count [, and_rank, and_ids, and_pos, and_count]); lists have capacity `cap`."""
-    dev = bitmap.device
+def new_flags(n_nodes: int, device) -> Tensor:
+    """zeroed byte flags, one per node (padded to a multiple of 64)"""
+    return torch.zeros(int(lib.tg_flag_bytes(n_nodes)), dtype=torch.uint8, device=device)
+
+
+def flags_mark(ids: Tensor, flags: Tensor, n_nodes: int):
+    ids = _i64(ids)
+    check(lib.tg_flags_mark(ids.numel(), ptr(ids), ptr(flags), n_nodes, stream_ptr(ids.device)), 'tg_flags_mark')
+
+
+def unique_compact(bitmap: Optional[Tensor], n_nodes: int, cap: int, and_bitmap: Optional[Tensor] = None,
+                   flags: Optional[Tensor] = None):
+    """-> dict(bitmap, rank, ids, count [, and_rank, and_ids, and_pos, and_count]); lists have
+    capacity `cap`.  Either `bitmap` (input) or `flags` (packed into a fresh bitmap) is given."""
+    dev = (bitmap if bitmap is not None else flags).device
+    if bitmap is None:
+        bitmap = torch.empty(bitmap_words(n_nodes), dtype=torch.int64, device=dev)
     W = bitmap_words(n_nodes)
-    out = dict(rank=torch.empty(W + 1, dtype=torch.int32, device=dev),
+    out = dict(bitmap=bitmap, rank=torch.empty(W + 1, dtype=torch.int32, device=dev),
                ids=torch.empty(cap, dtype=torch.int64, device=dev),
                count=torch.zeros(1, dtype=torch.int32, device=dev))
     a = [None] * 4
@@ -58,7 +72,7 @@ def unique_compact(bitmap: Tensor, n_nodes: int, cap: int, and_bitmap: Optional[
         a = [out['and_rank'], out['and_ids'], out['and_pos'], out['and_count']]
     nbytes = int(lib.tg_unique_compact_workspace_bytes(n_nodes))
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
-    check(lib.tg_unique_compact(ptr(bitmap), n_nodes, ptr(out['rank']), ptr(out['ids']), ptr(out['count']), cap,
+    check(lib.tg_unique_compact(ptr(flags), ptr(bitmap), n_nodes, ptr(out['rank']), ptr(out['ids']), ptr(out['count']), cap,
                                 ptr(and_bitmap), ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(a[3]), ptr(ws), ws.numel(),
                                 stream_ptr(dev)), 'tg_unique_compact')
     return out

@@ -172,7 +172,7 @@ class TIGE(nn.Module):
         replaced by updater(upd_memory, msg_fn(mailbox)) (tiger.py:208-221)."""
         m = self.model_struct()
         dev = self.device
-        comp = hip_ops.unique_compact(bitmap, self.n_nodes, cap, and_bitmap=self.msg_store.has_msg_bits)
+        comp = hip_ops.unique_compact(bitmap, self.n_nodes, cap, and_bitmap=self.msg_store.has_msg_bits)  # bitmap is an input here
         reprs = torch.empty(cap, self.memory_dim, dtype=torch.float32, device=dev)
         s = stream_ptr(dev)
         check(lib.tg_mailbox_consume_gather(C.byref(m), ptr(comp['ids']), ptr(comp['count']), cap, ptr(reprs), s),
