@@ -72,4 +72,33 @@ __device__ __forceinline__ uint64_t orderable(float x) {
   return (uint64_t)u;
 }
 
+
+// ---- internal launchers shared between translation units (not part of the C ABI) ----
+// sampler with the batch -> query expansion fused in (data_loader.py:79-81,92,128)
+int sample_batch_launch(const tg_tcsr* g, int64_t B, const int64_t* src, const int64_t* dst, const int64_t* neg,
+                        const double* ts, const int64_t* eids, const int64_t* off, int32_t K, int64_t* nids3,
+                        float* ts3f, int64_t* eids_b, int64_t* o_nbr, int64_t* o_eid, float* o_ts, uint8_t* mark,
+                        hipStream_t st);
+// reprs <- right memory rows of the involved nodes, plus the message/memory time invariants
+int consume_gather_check_launch(const tg_model* m, const int64_t* involved, const int32_t* n_involved, int64_t cap,
+                                float* reprs, const int64_t* outdated, const int32_t* n_outdated, uint32_t* err,
+                                hipStream_t st);
+// STEP 4-6 in two launches (phase 0 then 1); the tail work (counts copy, stream offset advance)
+// rides on phase 1
+struct WritebackArgs {
+  int64_t B;
+  const int64_t *src, *dst, *eids, *upos, *index;
+  const float* ts;          // [>= 2B] float32 event times tiled over cat[src,dst]
+  const int32_t* n_upos;
+  const float* reprs;       // h(t'+) rows, indexed by local rank (bitmap, rank)
+  const uint64_t* bm;
+  const uint32_t* rank;
+  const float* h;           // [>= 2B, d] embeddings of cat[src,dst]
+  uint32_t* err;
+  const int32_t* counts_src;  // nullable: 4 ints copied to counts_dst
+  int32_t* counts_dst;
+  int64_t* offset_dev;        // nullable: += B
+};
+int writeback_launch(const tg_model* m, const WritebackArgs& a, int phase, hipStream_t st);
+
 }  // namespace tg

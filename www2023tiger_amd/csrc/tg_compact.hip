@@ -99,6 +99,66 @@ __global__ void __launch_bounds__(CB) k_bm_pack_scan(const uint8_t* __restrict__
   }
 }
 
+// Small graphs (<= 256 words = 16384 nodes): pack + scan + emit in ONE block.
+__global__ void __launch_bounds__(CB) k_bm_small(const uint8_t* __restrict__ flags, uint64_t* __restrict__ bm,
+                                                 const uint64_t* __restrict__ hm, int W, uint32_t* __restrict__ rank1,
+                                                 int64_t* __restrict__ ids1, int32_t* __restrict__ count1, int64_t cap,
+                                                 uint32_t* __restrict__ rank2, int64_t* __restrict__ ids2,
+                                                 int32_t* __restrict__ pos2, int32_t* __restrict__ count2) {
+  __shared__ uint32_t s_w[2][CB / TG_WAVE];
+  __shared__ uint64_t s_a[CB], s_b[CB];
+  __shared__ uint32_t s_r1[CB], s_r2[CB];
+  const int w = threadIdx.x;
+  uint64_t a = 0, b = 0;
+  if (w < W) {
+    if (flags) {
+      const uint4* f = reinterpret_cast<const uint4*>(flags + (int64_t)w * 64);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint4 v = f[q];
+        const uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+        a |= (pack8(lo) | (pack8(hi) << 8)) << (16 * q);
+      }
+      bm[w] = a;
+    } else {
+      a = bm[w];
+    }
+    if (hm) b = a & hm[w];
+  }
+  uint32_t t1, t2;
+  const uint32_t r1 = block_excl_scan((uint32_t)__popcll(a), s_w[0], &t1);
+  const uint32_t r2 = block_excl_scan((uint32_t)__popcll(b), s_w[1], &t2);
+  s_a[w] = a;
+  s_b[w] = b;
+  s_r1[w] = r1;
+  s_r2[w] = r2;
+  if (w < W) {
+    rank1[w] = r1;
+    if (rank2) rank2[w] = r2;
+  }
+  if (w == 0) {
+    rank1[W] = t1;
+    if (rank2) rank2[W] = t2;
+    if (count1) *count1 = (int32_t)t1;
+    if (count2) *count2 = (int32_t)t2;
+  }
+  __syncthreads();
+  const int lane = lane_id();
+  const uint64_t below = (1ull << lane) - 1ull;
+  for (int ww = threadIdx.x >> 6; ww < W; ww += CB / TG_WAVE) {
+    const uint64_t wa = s_a[ww], wb = s_b[ww];
+    const uint32_t mine = s_r1[ww] + (uint32_t)__popcll(wa & below);
+    if (((wa >> lane) & 1ull) && ids1 && (int64_t)mine < cap) ids1[mine] = (int64_t)ww * 64 + lane;
+    if (rank2) {
+      const uint32_t m2 = s_r2[ww] + (uint32_t)__popcll(wb & below);
+      if (((wb >> lane) & 1ull) && (int64_t)m2 < cap) {
+        if (ids2) ids2[m2] = (int64_t)ww * 64 + lane;
+        if (pos2) pos2[m2] = (int32_t)mine;
+      }
+    }
+  }
+}
+
 // phase B (only when more than one block): block totals -> exclusive block offsets + counts
 __global__ void __launch_bounds__(CB) k_bm_scan_blocks(uint32_t* __restrict__ blk1, uint32_t* __restrict__ blk2, int nblk,
                                                        int32_t* __restrict__ count1, int32_t* __restrict__ count2) {
@@ -203,6 +263,11 @@ int unique_compact_launch(const uint8_t* flags, uint64_t* bm, int64_t n_nodes, u
   int32_t* spare = (int32_t*)((char*)ws + 2 * align16((size_t)nblk * sizeof(uint32_t)));
   if (!count) count = spare;       // the emit kernel needs the totals for the sentinel
   if (!count2) count2 = spare + 1;
+  if (nblk == 1) {
+    hipLaunchKernelGGL(k_bm_small, dim3(1), dim3(CB), 0, st, flags, bm, hm, (int)W, rank, ids, count, cap, rank2, ids2,
+                       pos2, count2);
+    return check_launch("tg_unique_compact");
+  }
   hipLaunchKernelGGL(k_bm_pack_scan, dim3(nblk), dim3(CB), 0, st, flags, bm, hm, W, rank, rank2, blk1, blk2, count,
                      count2);
   if (nblk > 1) hipLaunchKernelGGL(k_bm_scan_blocks, dim3(1), dim3(CB), 0, st, blk1, blk2, nblk, count, count2);

@@ -75,42 +75,35 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
     }
   }
   float4 ra0[WM], rb0[WN], ra1[WM], rb1[WN];  // two tiles in flight (global -> registers)
-  auto load = [&](int kt, float4* ra, float4* rb) {
+  const int nkt = (K + BK - 1) / BK;
+  // i-th staged float4 of tile kt (i < WM: A, else W): raw load from a clamped address; columns
+  // past K are zeroed when the tile is written to LDS, so nothing waits on the load here
+  auto load_one = [&](int kt, int i, float4* ra, float4* rb) {
     const int k = kt * BK + ac4;
-    const bool kin = k < K;
-    const int kc = kin ? k : 0;
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-      const float4 v = ldg4((kc < kw0 ? arow0[i] : arow1[i]) + kc);
-      ra[i] = kin ? v : zero4();
-    }
-#pragma unroll
-    for (int i = 0; i < WN; ++i) {
-      if (!g.w_kmajor) {
-        const float4 v = ldg4(wrow[i] + kc);
-        rb[i] = kin ? v : zero4();
-      } else {
-        const int kk = kt * BK + (tid + i * 256) / (BN / 4);
-        const float4 v = ldg4(wrow[i] + (int64_t)min(kk, K - 1) * g.ldw);
-        rb[i] = kk < K ? v : zero4();
-      }
+    const int kc = k < K ? k : 0;
+    if (i < WM) {
+      ra[i] = ldg4((kc < kw0 ? arow0[i] : arow1[i]) + kc);
+    } else if (!g.w_kmajor) {
+      rb[i - WM] = ldg4(wrow[i - WM] + kc);
+    } else {
+      const int kk = kt * BK + (tid + (i - WM) * 256) / (BN / 4);
+      rb[i - WM] = ldg4(wrow[i - WM] + (int64_t)min(kk, K - 1) * g.ldw);
     }
   };
-  auto store = [&](int buf, const float4* ra, const float4* rb) {
-#pragma unroll
-    for (int i = 0; i < WM; ++i) sts4(As[buf][ar + i * 32], ac4, ra[i]);
-#pragma unroll
-    for (int i = 0; i < WN; ++i) {
-      if (!g.w_kmajor) {
-        sts4(Bs[buf][ar + i * 32], ac4, rb[i]);
-      } else {
-        const int f = tid + i * 256;
-        const int kk = f / (BN / 4), nn = (f % (BN / 4)) * 4;
-        Bs[buf][nn][kk] = rb[i].x;
-        Bs[buf][nn + 1][kk] = rb[i].y;
-        Bs[buf][nn + 2][kk] = rb[i].z;
-        Bs[buf][nn + 3][kk] = rb[i].w;
-      }
+  auto store_one = [&](int buf, int kt, int i, const float4* ra, const float4* rb) {
+    const bool kin = kt * BK + ac4 < K;
+    if (i < WM) {
+      sts4(As[buf][ar + i * 32], ac4, kin ? ra[i] : zero4());
+    } else if (!g.w_kmajor) {
+      sts4(Bs[buf][ar + (i - WM) * 32], ac4, kin ? rb[i - WM] : zero4());
+    } else {
+      const int f = tid + (i - WM) * 256;
+      const int kk = f / (BN / 4), nn = (f % (BN / 4)) * 4;
+      const float4 v = (kt * BK + kk < K) ? rb[i - WM] : zero4();
+      Bs[buf][nn][kk] = v.x;
+      Bs[buf][nn + 1][kk] = v.y;
+      Bs[buf][nn + 2][kk] = v.z;
+      Bs[buf][nn + 3][kk] = v.w;
     }
   };
   const int wm = wave / WN, wn = wave % WN;
@@ -118,34 +111,46 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  const int nkt = (K + BK - 1) / BK;
-  auto compute = [&](int buf, int half) {
+  // Hand-scheduled tile step (same idea as k_gru): the CU's vector-memory path and the
+  // in-order wave make bursts of loads / ds_writes stall the matrix pipe, so tile t+2's
+  // global loads and tile t+1's LDS writes are threaded between the MFMAs of tile t, with
+  // the operand fragments read one k-step pair ahead.  One barrier per tile.
+  constexpr int NOPS = WM + WN;
+  static_assert(NOPS <= 4, "one memory op per k-step pair in each half");
+  auto tile = [&](int buf, int kt, float4* la, float4* lb, const float4* sa, const float4* sb) {
+    const int tl = min(kt + 2, nkt - 1);
     const float* ap = &As[buf][wm * 32 + fr][fk];
     const float* bp = &Bs[buf][wn * 32 + fr][fk];
+    float a0 = ap[0], a1 = ap[2], b0 = bp[0], b1 = bp[2];
 #pragma unroll
-    for (int ks = half * (BK / 4); ks < (half + 1) * (BK / 4); ++ks)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc, 0, 0, 0);
+    for (int pr = 0; pr < 8; ++pr) {
+      float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+      if (pr < 7) {
+        na0 = ap[4 * pr + 4]; na1 = ap[4 * pr + 6];
+        nb0 = bp[4 * pr + 4]; nb1 = bp[4 * pr + 6];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
+      if ((pr & 3) < NOPS) {
+        if (pr < 4) load_one(tl, pr & 3, la, lb);
+        else store_one(buf ^ 1, kt + 1, pr & 3, sa, sb);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+    }
+    __syncthreads();
   };
-  // Software pipeline: tile t is multiplied out of LDS[t&1] while tile t+1 moves registers -> LDS
-  // (its ds_writes sit BETWEEN the two MFMA halves so they issue under the matrix pipe) and
-  // tile t+2 travels global -> registers.  One barrier per tile.
-  load(0, ra0, rb0);
-  if (nkt > 1) load(1, ra1, rb1);
-  store(0, ra0, rb0);
+#pragma unroll
+  for (int i = 0; i < NOPS; ++i) load_one(0, i, ra0, rb0);
+#pragma unroll
+  for (int i = 0; i < NOPS; ++i) load_one(min(1, nkt - 1), i, ra1, rb1);
+#pragma unroll
+  for (int i = 0; i < NOPS; ++i) store_one(0, 0, i, ra0, rb0);
   __syncthreads();
   for (int kt = 0; kt < nkt; kt += 2) {
-    if (kt + 2 < nkt) load(kt + 2, ra0, rb0);
-    compute(0, 0);
-    if (kt + 1 < nkt) store(1, ra1, rb1);
-    compute(0, 1);
-    __syncthreads();
-    if (kt + 1 < nkt) {
-      if (kt + 3 < nkt) load(kt + 3, ra1, rb1);
-      compute(1, 0);
-      if (kt + 2 < nkt) store(0, ra0, rb0);
-      compute(1, 1);
-      __syncthreads();
-    }
+    tile(0, kt, ra0, rb0, ra1, rb1);
+    if (kt + 1 < nkt) tile(1, kt + 1, ra1, rb1, ra0, rb0);
   }
   const int n = n0 + wn * 32 + fr;
   if (n >= N) return;

@@ -138,6 +138,67 @@ __global__ void __launch_bounds__(256) k_sample_recent_edges(tg_tcsr g, int64_t 
   }
 }
 
+// Fused form used by tg_stream_step: query q of cat[src,dst,neg] is built on the fly from the
+// batch arrays (optionally at a device-resident stream offset) and also written out for the
+// later stages (ids, float32 times, edge ids).
+template <int G>
+__global__ void __launch_bounds__(256) k_sample_batch(tg_tcsr g, int64_t B, const int64_t* __restrict__ src,
+                                                      const int64_t* __restrict__ dst, const int64_t* __restrict__ neg,
+                                                      const double* __restrict__ ts, const int64_t* __restrict__ eids,
+                                                      const int64_t* __restrict__ off, int K,
+                                                      int64_t* __restrict__ nids3, float* __restrict__ ts3f,
+                                                      int64_t* __restrict__ eids_b, int64_t* __restrict__ o_nbr,
+                                                      int64_t* __restrict__ o_eid, float* __restrict__ o_ts,
+                                                      uint8_t* __restrict__ mark) {
+  constexpr int GPB = 256 / G;
+  const int sub = threadIdx.x % G;
+  const int64_t o = off ? *off : 0;
+  const int64_t Q = 3 * B;
+  for (int64_t q = (int64_t)blockIdx.x * GPB + threadIdx.x / G; q < Q; q += (int64_t)gridDim.x * GPB) {
+    const int64_t e = q % B;
+    const int r = (int)(q / B);
+    const int64_t nid = r == 0 ? src[o + e] : (r == 1 ? dst[o + e] : neg[o + e]);
+    const double t = ts[o + e];
+    if (sub == 0) {
+      nids3[q] = nid;
+      ts3f[q] = (float)t;
+      if (r == 0) eids_b[e] = eids[o + e];
+    }
+    int64_t start;
+    const int64_t end = prefix_end(g, nid, t, &start);
+    for (int j = sub; j < K; j += G) {
+      const int64_t p = end - K + j;
+      int64_t nb = 0, ed = 0;
+      float tt = 0.f;
+      if (p >= start) {
+        nb = g.nbr[p];
+        ed = (int64_t)((uint32_t)g.eid[p] & 0x7fffffffu);
+        tt = (float)g.ts[p];
+      }
+      const int64_t w = q * K + j;
+      o_nbr[w] = nb;
+      o_eid[w] = ed;
+      o_ts[w] = tt;
+      mark[nb] = 1;
+    }
+    if (sub == 0 && nid >= 0 && nid < g.num_node) mark[nid] = 1;
+  }
+}
+
+int sample_batch_launch(const tg_tcsr* g, int64_t B, const int64_t* src, const int64_t* dst, const int64_t* neg,
+                        const double* ts, const int64_t* eids, const int64_t* off, int32_t K, int64_t* nids3,
+                        float* ts3f, int64_t* eids_b, int64_t* o_nbr, int64_t* o_eid, float* o_ts, uint8_t* mark,
+                        hipStream_t st) {
+  const int64_t Q = 3 * B;
+  if (K <= 16)
+    hipLaunchKernelGGL(k_sample_batch<16>, dim3(flat_grid(Q, 16)), dim3(256), 0, st, *g, B, src, dst, neg, ts, eids,
+                       off, K, nids3, ts3f, eids_b, o_nbr, o_eid, o_ts, mark);
+  else
+    hipLaunchKernelGGL(k_sample_batch<64>, dim3(flat_grid(Q, 4)), dim3(256), 0, st, *g, B, src, dst, neg, ts, eids,
+                       off, K, nids3, ts3f, eids_b, o_nbr, o_eid, o_ts, mark);
+  return check_launch("sample_batch");
+}
+
 // One wavefront per query.  Walk the prefix backwards 64 entries at a time; an entry
 // is kept if no more recent entry (this chunk or earlier chunks) has the same
 // neighbour.  The j-th kept entry (j = 0 most recent) lands in output slot K-1-j.

@@ -143,6 +143,154 @@ __global__ void __launch_bounds__(256) k_store_events(tg_model m, int64_t B, con
   }
 }
 
+// reprs[u] = right_memory[involved[u]] fused with the invariants of compute_messages
+// (message_modules.py:158-159, tiger.py:325-327) over the outdated list.
+__global__ void k_consume_gather_check(tg_model m, const int64_t* __restrict__ involved,
+                                       const int32_t* __restrict__ n_involved, int64_t cap, float4* __restrict__ reprs,
+                                       const int64_t* __restrict__ outdated, const int32_t* __restrict__ n_outdated,
+                                       uint32_t* __restrict__ err) {
+  const int w4 = m.d / 4;
+  const int64_t n = min((int64_t)*n_involved, cap);
+  const int64_t total = n * w4;
+  const float4* right = reinterpret_cast<const float4*>(m.right_vals);
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = tid; t < total; t += nth) {
+    const int64_t i = t / w4;
+    reprs[t] = right[involved[i] * w4 + (t - i * w4)];
+  }
+  const int64_t no = min((int64_t)*n_outdated, cap);
+  const float* mem_ts = (m.msg_src == TG_SRC_LEFT) ? m.left_ts : m.right_ts;
+  for (int64_t i = tid; i < no; i += nth) {
+    const int64_t id = outdated[i];
+    const float mts = m.msg_ts[id], last = mem_ts[id];
+    if (last > mts) atomicOr(err, TG_ERR_MSG_BEFORE_MEM);
+    if (m.msg_src == TG_SRC_LEFT && !(mts == last)) atomicOr(err, TG_ERR_MSG_TS_MISMATCH);
+  }
+}
+
+// ---- fused write-back (tiger.py:229-255).  Hazards: STEP 5 reads the message memory
+// rows of BOTH endpoints, STEP 4 writes right-memory rows and STEP 6 left-memory rows of
+// other nodes in other waves, so a kernel boundary must separate STEP 5 from whichever
+// step writes the message memory:  msg_src=left  -> [4 + 5] | [6],  msg_src=right -> [4] | [5 + 6].
+__device__ __forceinline__ void wb_step4(const tg_model& m, int64_t id, int64_t u, const float4* __restrict__ reprs,
+                                         uint32_t* err, int lane) {
+  if (!bm_test(m.has_msg, id)) return;  // wave-uniform
+  const int w4 = m.d / 4;
+  float4* right = reinterpret_cast<float4*>(m.right_vals);
+  for (int c = lane; c < w4; c += TG_WAVE) right[id * w4 + c] = reprs[u * w4 + c];
+  if (lane == 0) {
+    const float mts = m.msg_ts[id];
+    if (m.right_ts[id] > mts) atomicOr(err, TG_ERR_PAST_MEMORY);
+    m.right_ts[id] = mts;
+    if (m.right_active) m.right_active[id] = 1;
+    atomicAnd((unsigned long long*)(m.has_msg + (id >> 6)), ~(1ull << (id & 63)));
+  }
+}
+
+__device__ __forceinline__ void wb_step5(const tg_model& m, int64_t B, const int64_t* __restrict__ src,
+                                         const int64_t* __restrict__ dst, const float* __restrict__ ts,
+                                         const int64_t* __restrict__ eids, int64_t own, int64_t idx, uint32_t* err,
+                                         int lane) {
+  const int d4 = m.d / 4, e4 = m.d_e / 4;
+  const int row4 = 3 * d4 + e4;
+  const float* mem_ts = (m.msg_src == TG_SRC_LEFT) ? m.left_ts : m.right_ts;
+  const float4* mem = reinterpret_cast<const float4*>((m.msg_src == TG_SRC_LEFT) ? m.left_vals : m.right_vals);
+  const float4* nf = reinterpret_cast<const float4*>(m.nfeats);
+  const float4* ef = reinterpret_cast<const float4*>(m.efeats);
+  const float4* fq = reinterpret_cast<const float4*>(m.te_freq);
+  const float4* ph = reinterpret_cast<const float4*>(m.te_phase);
+  float4* box = reinterpret_cast<float4*>(m.msg_vals);
+  const int64_t e = idx < B ? idx : idx - B;
+  const int64_t other = idx < B ? dst[e] : src[e];
+  const float t = ts[e];
+  const float dt = t - mem_ts[own];
+  const int64_t eid = eids[e];
+  for (int c = lane; c < row4; c += TG_WAVE) {
+    float4 v;
+    if (c < 2 * d4) {
+      const int64_t node = c < d4 ? own : other;
+      const int cc = c < d4 ? c : c - d4;
+      v = mem[node * d4 + cc];
+      if (nf) {
+        const float4 f = nf[node * d4 + cc];
+        v.x += f.x; v.y += f.y; v.z += f.z; v.w += f.w;
+      }
+    } else if (c < 2 * d4 + e4) {
+      v = ef ? ef[eid * e4 + (c - 2 * d4)] : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      const int cc = c - 2 * d4 - e4;
+      const float4 w = fq[cc], q = ph[cc];
+      v = make_float4(time_enc(dt, w.x, q.x), time_enc(dt, w.y, q.y), time_enc(dt, w.z, q.z), time_enc(dt, w.w, q.w));
+    }
+    box[own * row4 + c] = v;
+  }
+  if (lane == 0) {
+    const uint64_t bit = 1ull << (own & 63);
+    const unsigned long long old = atomicOr((unsigned long long*)(m.has_msg + (own >> 6)), bit);
+    if (old & bit) atomicOr(err, TG_ERR_UNUSED_MESSAGE);
+    m.msg_ts[own] = t;
+  }
+}
+
+__device__ __forceinline__ void wb_step6(const tg_model& m, int64_t id, int64_t idx, const float4* __restrict__ h,
+                                         const float* __restrict__ ts, uint32_t* err, int lane) {
+  const int w4 = m.d / 4;
+  float4* left = reinterpret_cast<float4*>(m.left_vals);
+  for (int c = lane; c < w4; c += TG_WAVE) left[id * w4 + c] = h[idx * w4 + c];
+  if (lane == 0) {
+    const float nt = ts[idx];
+    if (m.left_ts[id] > nt) atomicOr(err, TG_ERR_PAST_MEMORY);
+    m.left_ts[id] = nt;
+    if (m.left_active) m.left_active[id] = 1;
+  }
+}
+
+template <int PHASE>
+__global__ void __launch_bounds__(256) k_writeback(tg_model m, WritebackArgs a) {
+  const int lane = lane_id();
+  const int64_t B = a.B;
+  const int64_t n = min((int64_t)*a.n_upos, 2 * B);
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (int64_t)gridDim.x * 4;
+  const bool left_src = m.msg_src == TG_SRC_LEFT;
+  const bool do5 = (PHASE == 0) ? left_src : !left_src;
+  if (do5) {  // tiger.py:437-438 over all 2B positions
+    const float* mem_ts = left_src ? m.left_ts : m.right_ts;
+    for (int64_t i = wave0 * TG_WAVE + lane; i < 2 * B; i += nwave * TG_WAVE) {
+      const int64_t e = i < B ? i : i - B;
+      const int64_t node = i < B ? a.src[e] : a.dst[e];
+      if (mem_ts[node] > a.ts[e]) atomicOr(a.err, TG_ERR_EVENT_BEFORE_MEM);
+    }
+  }
+  for (int64_t p = wave0; p < n; p += nwave) {
+    const int64_t id = a.upos[p], idx = a.index[p];
+    if (PHASE == 0) wb_step4(m, id, (int64_t)bm_rank(a.bm, a.rank, id), reinterpret_cast<const float4*>(a.reprs), a.err, lane);
+    if (do5) wb_step5(m, B, a.src, a.dst, a.ts, a.eids, id, idx, a.err, lane);
+    if (PHASE == 1) wb_step6(m, id, idx, reinterpret_cast<const float4*>(a.h), a.ts, a.err, lane);
+  }
+  if (PHASE == 1 && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (a.counts_dst)
+      for (int i = 0; i < 4; ++i) a.counts_dst[i] = a.counts_src[i];
+    if (a.offset_dev) *a.offset_dev += B;
+  }
+}
+
+int consume_gather_check_launch(const tg_model* m, const int64_t* involved, const int32_t* n_involved, int64_t cap,
+                                float* reprs, const int64_t* outdated, const int32_t* n_outdated, uint32_t* err,
+                                hipStream_t st) {
+  hipLaunchKernelGGL(k_consume_gather_check, dim3(flat_grid(cap * (m->d / 4), 256)), dim3(256), 0, st, *m, involved,
+                     n_involved, cap, (float4*)reprs, outdated, n_outdated, err);
+  return check_launch("consume_gather_check");
+}
+
+int writeback_launch(const tg_model* m, const WritebackArgs& a, int phase, hipStream_t st) {
+  const unsigned grid = flat_grid(2 * a.B, 4);
+  if (phase == 0)
+    hipLaunchKernelGGL(k_writeback<0>, dim3(grid), dim3(256), 0, st, *m, a);
+  else
+    hipLaunchKernelGGL(k_writeback<1>, dim3(grid), dim3(256), 0, st, *m, a);
+  return check_launch("writeback");
+}
+
 // TIGER.restart state update (tiger.py:603,608-609)
 __global__ void k_restart_apply(tg_model m, int64_t n, const int64_t* __restrict__ nids,
                                 const float4* __restrict__ hl, const float4* __restrict__ hr,

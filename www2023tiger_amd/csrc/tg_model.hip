@@ -48,11 +48,27 @@ __global__ void k_check_messages(tg_model m, const int64_t* __restrict__ outdate
 }
 
 // centre rows: c_i = reprs[local(nid_i)] + nfeat[nid_i]   (temporal_agg_modules.py:48-50)
-__global__ void k_attn_centres(int64_t Q, int d4, const int64_t* __restrict__ nids, const float4* __restrict__ reprs,
-                               const uint64_t* __restrict__ bm, const uint32_t* __restrict__ rank,
-                               const float4* __restrict__ nf, float4* __restrict__ out) {
+// The last `qblocks` blocks of the grid instead compute the constant half of the query
+// projection, qconst[n] = bq[n] + sum_j Wq[n, d + j] * cos(phase[j])   (TE(0) = cos(phi)).
+__global__ void __launch_bounds__(256) k_attn_centres(int64_t Q, int d4, const int64_t* __restrict__ nids,
+                                                      const float4* __restrict__ reprs, const uint64_t* __restrict__ bm,
+                                                      const uint32_t* __restrict__ rank, const float4* __restrict__ nf,
+                                                      float4* __restrict__ out, int qblocks, const float* __restrict__ wq,
+                                                      const float* __restrict__ bq, const float* __restrict__ freq,
+                                                      const float* __restrict__ phase, float* __restrict__ qconst) {
+  const int cblocks = (int)gridDim.x - qblocks;
+  if ((int)blockIdx.x >= cblocks) {
+    const int d = d4 * 4, lane = lane_id();
+    const int n = ((int)blockIdx.x - cblocks) * 4 + (threadIdx.x >> 6);
+    if (n >= 2 * d) return;
+    float acc = 0.f;
+    for (int j = lane; j < d; j += TG_WAVE) acc += wq[(int64_t)n * 2 * d + d + j] * time_enc(0.f, freq[j], phase[j]);
+    acc = wave_sum(acc);
+    if (lane == 0) qconst[n] = acc + bq[n];
+    return;
+  }
   const int64_t total = Q * d4;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)cblocks * blockDim.x) {
     const int64_t i = t / d4;
     const int c = (int)(t - i * d4);
     const int64_t id = nids[i];
@@ -63,19 +79,6 @@ __global__ void k_attn_centres(int64_t Q, int d4, const int64_t* __restrict__ ni
     }
     out[t] = v;
   }
-}
-
-// qconst[n] = bq[n] + sum_j Wq[n, d + j] * cos(phase[j])   (the TE(0) half of the query)
-__global__ void __launch_bounds__(256) k_attn_qconst(int d, const float* __restrict__ wq, const float* __restrict__ bq,
-                                                     const float* __restrict__ freq, const float* __restrict__ phase,
-                                                     float* __restrict__ out) {
-  const int lane = lane_id();
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= 2 * d) return;
-  float acc = 0.f;
-  for (int j = lane; j < d; j += TG_WAVE) acc += wq[(int64_t)n * 2 * d + d + j] * time_enc(0.f, freq[j], phase[j]);
-  acc = wave_sum(acc);
-  if (lane == 0) out[n] = acc + bq[n];
 }
 
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
@@ -261,10 +264,10 @@ int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float*
   int stage = ST_ATTN_FIRST;
   prof_mark(pf, stage++, st);
   const int d = m->d, d_e = m->d_e, kvw = 2 * d + d_e, nh = m->n_head, dh = 2 * d / nh, E = 2 * d;
-  hipLaunchKernelGGL(k_attn_centres, dim3(flat_grid(Q * (d / 4), 256)), dim3(256), 0, st, Q, d / 4, nids,
-                     (const float4*)reprs, bm, rank, (const float4*)m->nfeats, (float4*)w.cc);
-  hipLaunchKernelGGL(k_attn_qconst, dim3((unsigned)cdiv(2 * d, 4)), dim3(256), 0, st, d, m->attn_wq, m->attn_b_in,
-                     m->te_freq, m->te_phase, w.qconst);
+  const int qblocks = (int)cdiv(2 * d, 4);
+  hipLaunchKernelGGL(k_attn_centres, dim3(flat_grid(Q * (d / 4), 256) + qblocks), dim3(256), 0, st, Q, d / 4, nids,
+                     (const float4*)reprs, bm, rank, (const float4*)m->nfeats, (float4*)w.cc, qblocks, m->attn_wq,
+                     m->attn_b_in, m->te_freq, m->te_phase, w.qconst);
   int rc;
   GemmArgs g{};
   // q = (Wq [c | TE(0)] + bq) / sqrt(dh)          (F.multi_head_attention_forward scaling)
@@ -346,7 +349,8 @@ static size_t apply_ws_bytes(const tg_model* m, int64_t cap) {
 }
 
 int apply_messages(const tg_model* m, const int64_t* outdated, const int32_t* out_pos, const int32_t* n_dev,
-                   int64_t cap, float* reprs, uint32_t* err, void* ws, size_t ws_bytes, hipStream_t st) {
+                   int64_t cap, float* reprs, uint32_t* err, void* ws, size_t ws_bytes, hipStream_t st,
+                   bool checked_already = false) {
   const int d = m->d, mw = 3 * m->d + m->d_e;
   Carver cv(ws, ws_bytes);
   ApplyWs w{};
@@ -354,7 +358,8 @@ int apply_messages(const tg_model* m, const int64_t* outdated, const int32_t* ou
   if (m->tsfm != TG_TSFM_ID) w.t1 = cv.take<float>((size_t)cap * mw);
   if (m->upd_fn == TG_UPD_MERGE) w.t2 = cv.take<float>((size_t)cap * d);
   if (!cv.ok) return TG_EWORKSPACE;
-  hipLaunchKernelGGL(k_check_messages, dim3(flat_grid(cap, 256)), dim3(256), 0, st, *m, outdated, n_dev, cap, err);
+  if (!checked_already)
+    hipLaunchKernelGGL(k_check_messages, dim3(flat_grid(cap, 256)), dim3(256), 0, st, *m, outdated, n_dev, cap, err);
   int rc;
   ASeg x{m->msg_vals, mw, mw, outdated};  // raw messages gathered from the mailbox
   if (m->tsfm == TG_TSFM_LINEAR || m->tsfm == TG_TSFM_MLP) {
@@ -516,9 +521,9 @@ enum Stage : int {
   ST_ATTN_V, ST_ATTN_O, ST_ATTN_FC1, ST_ATTN_FC2, ST_DEDUP, ST_WRITE_RIGHT, ST_STORE_EVENTS, ST_WRITE_LEFT, ST_COUNT
 };
 static const char* const kStageNames[ST_COUNT] = {
-    "build_queries", "sample_recent_edges", "unique_compact", "gather_right_memory", "apply_messages(gru)",
+    "zero_flags", "sample_recent_edges", "unique_compact", "gather_right_memory", "apply_messages(gru)",
     "attn_centres+qconst", "attn_gemm_q", "attn_gemm_g", "attn_core(gather+softmax)", "attn_gemm_v", "attn_gemm_out",
-    "attn_gemm_fc1", "attn_gemm_fc2", "dedup_positive", "write_right_memory", "store_events", "write_left_memory"};
+    "attn_gemm_fc1", "attn_gemm_fc2", "dedup_positive", "writeback_phase0", "restarter_targets", "writeback_phase1"};
 static_assert(ST_ATTN_PREP == ST_ATTN_FIRST, "attention stage numbering");
 }  // namespace tg
 
@@ -644,17 +649,16 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
     return TG_EHIP;
   }
   int rc;
-  // ---- collate (data_loader.py:77-131): queries, temporal neighbours, involved set
-  hipLaunchKernelGGL(k_build_queries, dim3(flat_grid(Q, 256)), dim3(256), 0, st, B, io->src, io->dst, io->neg, io->ts,
-                     io->eids, io->offset_dev, w.nids3, w.ts3, w.ts3f, w.eids);
-  const int64_t* src = w.nids3;
-  const int64_t* dst = w.nids3 + B;
+  // ---- collate (data_loader.py:77-131): queries + temporal neighbours + involved flags, one launch
   prof_mark(pf, ST_SAMPLE, st);
   int64_t* l1n = io->l1_nids ? io->l1_nids : w.l1_nids;
   int64_t* l1e = io->l1_eids ? io->l1_eids : w.l1_eids;
   float* l1t = io->l1_ts ? io->l1_ts : w.l1_ts;
-  if ((rc = tg_sample_recent_edges(g, Q, w.nids3, w.ts3, (int32_t)K, l1n, l1e, l1t, nullptr, w.flags, stream)) != TG_OK)
+  if ((rc = sample_batch_launch(g, B, io->src, io->dst, io->neg, io->ts, io->eids, io->offset_dev, (int32_t)K, w.nids3,
+                                w.ts3f, w.eids, l1n, l1e, l1t, w.flags, st)) != TG_OK)
     return rc;
+  const int64_t* src = w.nids3;
+  const int64_t* dst = w.nids3 + B;
   prof_mark(pf, ST_COMPACT, st);
   int64_t* involved = io->involved ? io->involved : w.involved;
   // involved = sorted(set(...)); outdated = involved & has-message (memory.py:108-126)
@@ -662,11 +666,13 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
                                   w.outdated, w.out_pos, w.counts + 1, w.scan_ws, w.scan_bytes, st)) != TG_OK)
     return rc;
   prof_mark(pf, ST_GATHER, st);
-  // ---- STEP 1-2: reprs = right_memory[involved]; outdated rows <- updater(...)
-  if ((rc = tg_mailbox_consume_gather(m, involved, w.counts + 0, cap, w.reprs, stream)) != TG_OK) return rc;
+  // ---- STEP 1-2: reprs = right_memory[involved] (+ invariants); outdated rows <- updater(...)
+  if ((rc = consume_gather_check_launch(m, involved, w.counts + 0, cap, w.reprs, w.outdated, w.counts + 1, io->err,
+                                        st)) != TG_OK)
+    return rc;
   prof_mark(pf, ST_UPDATE, st);
   if ((rc = apply_messages(m, w.outdated, w.out_pos, w.counts + 1, cap, w.reprs, io->err, w.apply_ws, w.apply_bytes,
-                           st)) != TG_OK)
+                           st, true)) != TG_OK)
     return rc;
   // ---- STEP 3: temporal embeddings of cat[src, dst, neg]
   if ((rc = attn_forward(m, Q, w.nids3, w.ts3f, l1n, l1e, l1t, w.reprs, w.bm, w.rank, io->h, w.attn, st, pf)) != TG_OK)
@@ -674,7 +680,9 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
   prof_mark(pf, ST_DEDUP, st);
   if (io->h_new) {  // h(t'+) rows of cat[src, dst]: reprs[local(node)]
     hipLaunchKernelGGL(k_attn_centres, dim3(flat_grid(2 * B * (m->d / 4), 256)), dim3(256), 0, st, 2 * B, m->d / 4,
-                       w.nids3, (const float4*)w.reprs, w.bm, w.rank, (const float4*)nullptr, (float4*)io->h_new);
+                       w.nids3, (const float4*)w.reprs, w.bm, w.rank, (const float4*)nullptr, (float4*)io->h_new, 0,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (float*)nullptr);
   }
   if (io->embed_only) {
     if (io->counts) {
@@ -690,16 +698,17 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
   hipLaunchKernelGGL(k_pos_max, dim3(flat_grid(2 * B, 256)), dim3(256), 0, st, B, src, dst, w.ts3f, w.bm, w.rank, w.best);
   hipLaunchKernelGGL(k_pos_winners, dim3(flat_grid(2 * B, 256)), dim3(256), 0, st, B, src, dst, w.ts3f, w.bm, w.rank,
                      w.best, w.upos, w.index, w.counts + 2);
+  // ---- STEP 4-6 (tiger.py:229-255) in two launches; STEP 5 shares a launch with whichever of
+  // STEP 4 / STEP 6 does not write the message memory (see tg_memory.hip)
+  WritebackArgs wa{};
+  wa.B = B; wa.src = src; wa.dst = dst; wa.eids = w.eids; wa.upos = w.upos; wa.index = w.index; wa.ts = w.ts3f;
+  wa.n_upos = w.counts + 2; wa.reprs = w.reprs; wa.bm = w.bm; wa.rank = w.rank; wa.h = io->h; wa.err = io->err;
+  wa.counts_src = io->counts ? w.counts : nullptr; wa.counts_dst = io->counts;
+  wa.offset_dev = (io->offset_dev && io->advance) ? io->offset_dev : nullptr;
   prof_mark(pf, ST_WRITE_RIGHT, st);
-  // ---- STEP 4: consumed positive nodes -> right memory
-  if ((rc = tg_consume_update_right(m, w.upos, w.counts + 2, 2 * B, w.reprs, w.bm, w.rank, io->err, stream)) != TG_OK)
-    return rc;
+  if ((rc = writeback_launch(m, wa, 0, st)) != TG_OK) return rc;
   prof_mark(pf, ST_STORE_EVENTS, st);
-  // ---- STEP 5: mailbox <- messages of this batch (reads message memory after STEP 4, before STEP 6)
-  if ((rc = tg_store_events(m, B, src, dst, w.ts3f, w.eids, w.upos, w.index, w.counts + 2, io->err, stream)) != TG_OK)
-    return rc;
-  prof_mark(pf, ST_WRITE_LEFT, st);
-  // ---- side outputs for the restarter (tiger.py:248-251)
+  // ---- side outputs for the restarter (tiger.py:248-251): after STEP 4, before STEP 6
   if (io->h_prev_left) {
     if ((rc = tg_gather_rows(2 * B, w.nids3, m->d, m->left_vals, io->h_prev_left, nullptr, nullptr, stream)) != TG_OK)
       return rc;
@@ -708,18 +717,8 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
     if ((rc = tg_gather_rows(2 * B, w.nids3, m->d, m->right_vals, io->h_prev_right, nullptr, nullptr, stream)) != TG_OK)
       return rc;
   }
-  // ---- STEP 6: left memory <- h(t-) of the winning occurrence of each positive node
-  if ((rc = tg_memory_scatter(2 * B, w.counts + 2, w.upos, w.index, m->d, io->h, w.ts3f, m->left_vals, m->left_ts,
-                              m->left_active, 1, io->err, stream)) != TG_OK)
-    return rc;
-  if (io->counts) {
-    e = hipMemcpyAsync(io->counts, w.counts, 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) {
-      set_hip_error(e, "tg_stream_step counts copy");
-      return TG_EHIP;
-    }
-  }
-  if (io->offset_dev && io->advance) hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, io->offset_dev, B);
+  prof_mark(pf, ST_WRITE_LEFT, st);
+  if ((rc = writeback_launch(m, wa, 1, st)) != TG_OK) return rc;
   prof_mark(pf, ST_COUNT, st);
   if (pf) pf->armed = true;
   return check_launch("tg_stream_step");
