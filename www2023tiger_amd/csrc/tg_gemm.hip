@@ -352,17 +352,25 @@ __global__ void __launch_bounds__(256) k_gru(GruArgs g) {
   const float br = g.b_ih[j] + g.b_hh[j];
   const float bz = g.b_ih[d + j] + g.b_hh[d + j];
   const float bin = g.b_ih[2 * d + j], bhn = g.b_hh[2 * d + j];
+  // branch-free epilogue: all 16 old-memory values are requested up front (rows clamped),
+  // only the final store is predicated
+  float hold_v[16];
+  int64_t orow_v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t m = min(m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk, M - 1);
+    const int64_t hr = g.h.idx ? g.h.idx[m] : m;
+    hold_v[r] = g.h.p[hr * g.h.ld + j];
+    orow_v[r] = g.out_rows ? (int64_t)g.out_rows[m] : m;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int64_t m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-    if (m >= M) continue;
-    const int64_t hr = g.h.idx ? g.h.idx[m] : m;
-    const float hold = g.h.p[hr * g.h.ld + j];
+    const float hold = hold_v[r];
     const float rg = sigmoidf_(acc_r[r] + br);
     const float zg = sigmoidf_(acc_z[r] + bz);
     const float ng = tanhf(acc_in[r] + bin + rg * (acc_hn[r] + bhn));
-    const int64_t orow = g.out_rows ? (int64_t)g.out_rows[m] : m;
-    if (jok) g.out[orow * g.ldo + j] = (1.f - zg) * ng + zg * hold;
+    if (jok && m < M) g.out[orow_v[r] * g.ldo + j] = (1.f - zg) * ng + zg * hold;
   }
   if ((dbg & 16) && tid == 0 && blockIdx.x < 2048) {
     g_gru_trace[blockIdx.x * 4 + 0] = t_entry;

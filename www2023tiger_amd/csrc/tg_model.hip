@@ -81,12 +81,19 @@ __global__ void __launch_bounds__(256) k_attn_centres(int64_t Q, int d4, const i
   }
 }
 
-__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-__device__ __forceinline__ void axpby4(float4& s, float a, float b, float4 x) {
-  s.x = s.x * a + b * x.x;
-  s.y = s.y * a + b * x.y;
-  s.z = s.z * a + b * x.z;
-  s.w = s.w * a + b * x.w;
+// explicit fma: the library is built with -ffp-contract=off (only the time encoding needs the
+// unfused product), so contractions are spelled out where they are wanted
+__device__ __forceinline__ float dot4(float4 a, float4 b, float acc) {
+  return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, fmaf(a.x, b.x, acc))));
+}
+__device__ __forceinline__ void axpy4(float4& s, float b, float4 x) {
+  s.x = fmaf(b, x.x, s.x);
+  s.y = fmaf(b, x.y, s.y);
+  s.z = fmaf(b, x.z, s.z);
+  s.w = fmaf(b, x.w, s.w);
+}
+__device__ __forceinline__ void scale4(float4& s, float a) {
+  s.x *= a; s.y *= a; s.z *= a; s.w *= a;
 }
 
 // One wavefront per centre.  Streams its K neighbour rows once: node part
@@ -185,16 +192,25 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
 #pragma unroll
         for (int sgm = 0; sgm < 3; ++sgm)
 #pragma unroll
-          for (int v = 0; v < NV; ++v) p += dot4(g[h][sgm][v], x[sgm][v]);
-        p = wave_sum(p);
-        const float mn = fmaxf(mx[h], p);
-        const float a = expf(mx[h] - mn), b = expf(p - mn);
-        l[h] = l[h] * a + b;
-        mx[h] = mn;
+          for (int v = 0; v < NV; ++v) p = dot4(g[h][sgm][v], x[sgm][v], p);
+        p = wave_sum(p);  // wave-uniform
+        float b = 1.f;
+        if (p > mx[h]) {  // new running maximum: rescale what has been accumulated (uniform branch)
+          const float a = expf(mx[h] - p);
+          l[h] *= a;
+#pragma unroll
+          for (int sgm = 0; sgm < 3; ++sgm)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) scale4(acc[h][sgm][v], a);
+          mx[h] = p;
+        } else {
+          b = expf(p - mx[h]);
+        }
+        l[h] += b;
 #pragma unroll
         for (int sgm = 0; sgm < 3; ++sgm)
 #pragma unroll
-          for (int v = 0; v < NV; ++v) axpby4(acc[h][sgm][v], a, b, x[sgm][v]);
+          for (int v = 0; v < NV; ++v) axpy4(acc[h][sgm][v], b, x[sgm][v]);
       }
       k = kn;
     }
