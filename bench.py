@@ -154,6 +154,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='launch steps eagerly instead of replaying a hipGraph')
     ap.add_argument('--force-dist', action='store_true', help='run the multi-GPU code path even with one rank')
+    ap.add_argument('--dist-graphs', action='store_true',
+                    help='multi-GPU: replay captured hipGraphs around the all-gather (experimental; default eager)')
     args = ap.parse_args()
     cfg = dict(C2)
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -217,17 +219,30 @@ def main():
         'store_events': P * (4 * (3 * d + d_e) + 4) + 2 * B * 4 * d + B * 4 * d_e,
     }
     flops_by_stage = {'apply_messages(gru)': 2.0 * O_ * 3 * d * ((3 * d + d_e) + d)}
+    kernel_of_stage = {'apply_messages(gru)': 'tg::k_gru', 'attn_core(gather+softmax)': 'tg::k_attn_core<2, 1>',
+                       'gather_right_memory': 'tg::k_consume_gather_check', 'sample_recent_edges': 'tg::k_sample_batch<16>'}
     name = names[dom]
     t_s = stage_ms[dom] * 1e-3
-    if name in bytes_by_stage:
+    # fabric/HBM bytes per launch of that kernel from the committed PMC passes (profiles/r01_hbm_traffic.json,
+    # collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command); null if not recorded
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')))
+        traffic = tj['kernels'].get(kernel_of_stage.get(name, ''), {}).get('bytes_per_launch')
+    except (OSError, ValueError):
+        pass
+    if name in flops_by_stage:  # the GRU kernel is MFMA-bound at C2 (3.7 GFLOP vs 17 MB): price it against f32 MFMA
+        ach = flops_by_stage[name] / t_s / 1e12
+        roof = dict(bound='mfma', kernel=name, achieved=ach, peak=157.3, unit='TFLOP/s', frac=ach / 157.3,
+                    traffic=traffic, avg_ms=float(stage_ms[dom]), algorithmic_flops=float(flops_by_stage[name]),
+                    algorithmic_bytes=float(bytes_by_stage[name]),
+                    hbm_gbs=bytes_by_stage[name] / t_s / 1e9)
+    elif name in bytes_by_stage:
         ach = bytes_by_stage[name] / t_s / 1e9
         roof = dict(bound='hbm', kernel=name, achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS,
-                    traffic=None, avg_ms=float(stage_ms[dom]), algorithmic_bytes=float(bytes_by_stage[name]))
-        if name in flops_by_stage:
-            roof['mfma_tflops'] = flops_by_stage[name] / t_s / 1e12
-            roof['mfma_peak_tflops'] = 157.3
+                    traffic=traffic, avg_ms=float(stage_ms[dom]), algorithmic_bytes=float(bytes_by_stage[name]))
     else:
-        roof = dict(bound='hbm', kernel=name, achieved=None, peak=HBM_PEAK_GBS, unit='GB/s', frac=None, traffic=None,
+        roof = dict(bound='hbm', kernel=name, achieved=None, peak=HBM_PEAK_GBS, unit='GB/s', frac=None, traffic=traffic,
                     avg_ms=float(stage_ms[dom]))
     out = dict(metric='processed interaction-events/sec (memory+aggregate+embed), Wikipedia d=172',
                value=events_per_s, unit='events/s', n_gpus=1, steps=args.steps, warmup=args.warmup,

@@ -351,6 +351,29 @@ size_t tg_stream_step_workspace_bytes(const tg_model* m, int64_t B);
 int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, void* ws, size_t ws_bytes,
                    void* stream);
 
+/* ------------------------------------------------------------------------- */
+/* Multi-GPU: replicated write-back of a GLOBAL batch from all-gathered rows  */
+/* (www2023tiger_amd/dist.py; STEP 4-6 of tiger.py:229-255 for every event of */
+/* the global batch, the embeddings having been computed on other ranks)      */
+/* ------------------------------------------------------------------------- */
+typedef struct tg_writeback_io {
+  int64_t Bg;               /* events of the global batch */
+  const int64_t* src;       /* resident global stream (or the batch itself when offset_dev == NULL) */
+  const int64_t* dst;
+  const double* ts;
+  const int64_t* eids;
+  int64_t* offset_dev;      /* element offset of this batch in the stream arrays; += Bg when advance != 0 */
+  int32_t advance;
+  int32_t reserved;
+  const float* rows;        /* gathered rows [*, d] */
+  const int64_t* left_row;  /* [.., 2Bg] row of h(t-) for position i of cat[src,dst], at element 2*offset + i */
+  const int64_t* new_row;   /* [.., 2Bg] row of h(t'+) likewise */
+  uint32_t* err;
+} tg_writeback_io;
+
+size_t tg_stream_writeback_workspace_bytes(const tg_model* m, int64_t Bg);
+int tg_stream_writeback(const tg_model* m, const tg_writeback_io* io, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

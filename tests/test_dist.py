@@ -51,6 +51,17 @@ def test_owner_table_and_plan():
     assert not set(plan.left_row.tolist()) & set(plan.new_row.tolist())
     with pytest.raises(ValueError):
         ShardPlan(dst, owner, world, 8)
+    # capacity-balanced plan: exactly Bg/world events per rank, owner placement kept while there is room
+    bal = ShardPlan(dst, owner, world, 32, balance=True, layout=(5 * 32, 0, 3 * 32, 32))
+    assert bal.counts.tolist() == [32] * world
+    moved = bal.rank_of != owner[dst]
+    for r in range(world):  # an event only leaves its owner when the owner's shard is full
+        if moved[owner[dst] == r].any():
+            assert (bal.rank_of == r).sum() == 32
+    assert sorted(np.concatenate(bal.local_idx).tolist()) == list(range(128))
+    rows = np.concatenate([bal.left_row, bal.new_row])
+    assert len(set(rows.tolist())) == 512 and rows.max() < world * 5 * 32
+    assert ((bal.left_row % (5 * 32)) < 2 * 32).all() and ((bal.new_row % (5 * 32)) >= 3 * 32).all()
 
 
 # ------------------------------------------------------------------------------ oracle backend (CPU)
@@ -190,6 +201,58 @@ def test_sharded_equals_single_gpu(tmp_path, name):
         np.testing.assert_array_equal(got['right_ts'], model.right_memory.update_ts.cpu().numpy())
         np.testing.assert_array_equal(got['has'], has)
         np.testing.assert_array_equal(got['msg_ts'], model.msg_store.node_msg_ts.cpu().numpy())
+        assert rel_err(got['left'], model.left_memory.vals.cpu().numpy()) < 1e-6
+        assert rel_err(got['right'], model.right_memory.vals.cpu().numpy()) < 1e-6
+        assert rel_err(got['msg'][has], model.msg_store.node_msg_vals.cpu().numpy()[has]) < 1e-6
+
+
+def _gpu_resident_worker(rank, world, port, name, B, n_steps, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    tdist.init_process_group('gloo', rank=rank, world_size=world)
+    from test_hip_parity import build_hip_model
+    from www2023tiger_amd.dist import ResidentShardedStream, balanced_owner_table
+    z = load(name)
+    cfg = parse_cfg(z)
+    model, _, _ = build_hip_model(z, cfg)
+    stream = {k: z[k] for k in ('src', 'dst', 'neg', 'ts', 'eids')}
+    owner = balanced_owner_table(int(z['n_nodes']), z['dst'], world)
+    rs = ResidentShardedStream(model, stream, owner, rank, world, B, n_steps)
+    rs.step()                     # eager
+    torch.cuda.synchronize()
+    rs.capture()                  # remaining steps replay the two captured hipGraphs
+    for _ in range(n_steps - 1):
+        rs.step()
+    rs.check_invariants()
+    np.savez(os.path.join(out_dir, f'rank{rank}.npz'), left=model.left_memory.vals.cpu().numpy(),
+             right=model.right_memory.vals.cpu().numpy(), left_ts=model.left_memory.update_ts.cpu().numpy(),
+             right_ts=model.right_memory.update_ts.cpu().numpy(), msg=model.msg_store.node_msg_vals.cpu().numpy(),
+             msg_ts=model.msg_store.node_msg_ts.cpu().numpy(),
+             has=np.array(sorted(model.msg_store.nodes_with_messages), dtype=np.int64))
+    tdist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_resident_sharded_stream_graph_replay_equals_single_gpu(tmp_path):
+    """The production multi-GPU loop (balanced shards, resident stream, two hipGraphs + one
+    all-gather per step) against the single-GPU fused step on the same global batches."""
+    from test_hip_parity import build_hip_model
+    name, B, n_steps, world = 'static_ll_d16', 48, 6, 2
+    mp.spawn(_gpu_resident_worker, args=(world, free_port(), name, B, n_steps, str(tmp_path)), nprocs=world, join=True)
+    z = load(name)
+    cfg = parse_cfg(z)
+    model, _, _ = build_hip_model(z, cfg)
+    Bg = B * world
+    for b in range(n_steps):
+        sl = slice(b * Bg, (b + 1) * Bg)
+        model.stream_step(*(z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')))
+    has = np.array(sorted(model.msg_store.nodes_with_messages), dtype=np.int64)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f'rank{r}.npz'))
+        np.testing.assert_array_equal(got['left_ts'], model.left_memory.update_ts.cpu().numpy())
+        np.testing.assert_array_equal(got['right_ts'], model.right_memory.update_ts.cpu().numpy())
+        np.testing.assert_array_equal(got['has'], has)
         assert rel_err(got['left'], model.left_memory.vals.cpu().numpy()) < 1e-6
         assert rel_err(got['right'], model.right_memory.vals.cpu().numpy()) < 1e-6
         assert rel_err(got['msg'][has], model.msg_store.node_msg_vals.cpu().numpy()[has]) < 1e-6

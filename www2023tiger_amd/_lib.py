@@ -67,6 +67,13 @@ class TgStepIo(C.Structure):
     ]
 
 
+class TgWritebackIo(C.Structure):
+    _fields_ = [
+        ('Bg', i64), ('src', vp), ('dst', vp), ('ts', vp), ('eids', vp), ('offset_dev', vp), ('advance', i32),
+        ('reserved', i32), ('rows', vp), ('left_row', vp), ('new_row', vp), ('err', vp),
+    ]
+
+
 P = C.POINTER
 # name -> (restype, argtypes); every symbol include/tiger_hip.h declares
 SIGNATURES = {
@@ -110,6 +117,8 @@ SIGNATURES = {
     'tg_profiler_read': (C.c_int, [vp, vp]),
     'tg_stream_step_workspace_bytes': (sz, [P(TgModel), i64]),
     'tg_stream_step': (C.c_int, [P(TgModel), P(TgTcsr), P(TgStepIo), vp, sz, vp]),
+    'tg_stream_writeback_workspace_bytes': (sz, [P(TgModel), i64]),
+    'tg_stream_writeback': (C.c_int, [P(TgModel), P(TgWritebackIo), vp, sz, vp]),
 }
 
 

@@ -128,6 +128,12 @@ struct WritebackArgs {
   const int32_t* counts_src;  // nullable: 4 ints copied to counts_dst
   int32_t* counts_dst;
   int64_t* offset_dev;        // nullable: += B
+  // multi-GPU write-back: rows come from the all-gathered buffer instead of (reprs, h):
+  // position idx of cat[src,dst] reads row new_row[po + idx] / left_row[po + idx] of `rows`,
+  // po = 2 * *plan_off (the plan arrays are resident for the whole stream)
+  const float* rows;
+  const int64_t *new_row, *left_row;
+  const int64_t* plan_off;
 };
 int writeback_launch(const tg_model* m, const WritebackArgs& a, int phase, hipStream_t st);
 

@@ -232,11 +232,12 @@ __device__ __forceinline__ void wb_step5(const tg_model& m, int64_t B, const int
   }
 }
 
-__device__ __forceinline__ void wb_step6(const tg_model& m, int64_t id, int64_t idx, const float4* __restrict__ h,
-                                         const float* __restrict__ ts, uint32_t* err, int lane) {
+__device__ __forceinline__ void wb_step6(const tg_model& m, int64_t id, int64_t idx, int64_t hrow,
+                                         const float4* __restrict__ h, const float* __restrict__ ts, uint32_t* err,
+                                         int lane) {
   const int w4 = m.d / 4;
   float4* left = reinterpret_cast<float4*>(m.left_vals);
-  for (int c = lane; c < w4; c += TG_WAVE) left[id * w4 + c] = h[idx * w4 + c];
+  for (int c = lane; c < w4; c += TG_WAVE) left[id * w4 + c] = h[hrow * w4 + c];
   if (lane == 0) {
     const float nt = ts[idx];
     if (m.left_ts[id] > nt) atomicOr(err, TG_ERR_PAST_MEMORY);
@@ -261,11 +262,22 @@ __global__ void __launch_bounds__(256) k_writeback(tg_model m, WritebackArgs a) 
       if (mem_ts[node] > a.ts[e]) atomicOr(a.err, TG_ERR_EVENT_BEFORE_MEM);
     }
   }
+  const int64_t po = a.plan_off ? 2 * *a.plan_off : 0;
   for (int64_t p = wave0; p < n; p += nwave) {
     const int64_t id = a.upos[p], idx = a.index[p];
-    if (PHASE == 0) wb_step4(m, id, (int64_t)bm_rank(a.bm, a.rank, id), reinterpret_cast<const float4*>(a.reprs), a.err, lane);
+    if (PHASE == 0) {
+      if (a.rows)
+        wb_step4(m, id, a.new_row[po + idx], reinterpret_cast<const float4*>(a.rows), a.err, lane);
+      else
+        wb_step4(m, id, (int64_t)bm_rank(a.bm, a.rank, id), reinterpret_cast<const float4*>(a.reprs), a.err, lane);
+    }
     if (do5) wb_step5(m, B, a.src, a.dst, a.ts, a.eids, id, idx, a.err, lane);
-    if (PHASE == 1) wb_step6(m, id, idx, reinterpret_cast<const float4*>(a.h), a.ts, a.err, lane);
+    if (PHASE == 1) {
+      if (a.rows)
+        wb_step6(m, id, idx, a.left_row[po + idx], reinterpret_cast<const float4*>(a.rows), a.ts, a.err, lane);
+      else
+        wb_step6(m, id, idx, idx, reinterpret_cast<const float4*>(a.h), a.ts, a.err, lane);
+    }
   }
   if (PHASE == 1 && blockIdx.x == 0 && threadIdx.x == 0) {
     if (a.counts_dst)

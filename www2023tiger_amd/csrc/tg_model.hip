@@ -549,7 +549,7 @@ struct tg_profiler {
 };
 
 static inline void prof_mark(tg_profiler* p, int i, hipStream_t st) {
-  if (p) hipEventRecord(p->ev[i], st);
+  if (p) (void)hipEventRecord(p->ev[i], st);
 }
 
 extern "C" tg_profiler* tg_profiler_create(void) {
@@ -564,7 +564,7 @@ extern "C" tg_profiler* tg_profiler_create(void) {
 }
 extern "C" void tg_profiler_destroy(tg_profiler* p) {
   if (!p) return;
-  for (int i = 0; i <= ST_COUNT; ++i) hipEventDestroy(p->ev[i]);
+  for (int i = 0; i <= ST_COUNT; ++i) (void)hipEventDestroy(p->ev[i]);
   delete p;
 }
 extern "C" int tg_profiler_num_stages(void) { return ST_COUNT; }
@@ -580,7 +580,7 @@ extern "C" int tg_profiler_read(tg_profiler* p, float* ms_out) {
   }
   for (int i = 0; i < ST_COUNT; ++i) {
     float ms = 0.f;
-    hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]);
+    (void)hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]);
     ms_out[i] = ms;
   }
   return TG_OK;
@@ -708,6 +708,7 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
         return TG_EHIP;
       }
     }
+    if (io->offset_dev && io->advance) hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, io->offset_dev, B);
     return check_launch("tg_stream_step(embed_only)");
   }
   // ---- dedup of positive nodes (select_latest_nids on float32 ts, tiger.py:232,419; memory.py:98)
@@ -738,4 +739,102 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
   prof_mark(pf, ST_COUNT, st);
   if (pf) pf->armed = true;
   return check_launch("tg_stream_step");
+}
+
+// ---------------------------------------------------------------------------------
+// Multi-GPU write-back of a global batch (see include/tiger_hip.h)
+// ---------------------------------------------------------------------------------
+namespace tg {
+// batch slice -> positive-node arrays + float32 times, and flag the positive nodes
+__global__ void k_wb_prepare(int64_t Bg, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                             const double* __restrict__ ts, const int64_t* __restrict__ eids,
+                             const int64_t* __restrict__ off, int64_t* __restrict__ pos, float* __restrict__ ts2f,
+                             int64_t* __restrict__ eids_b, uint8_t* __restrict__ flags) {
+  const int64_t o = off ? *off : 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * Bg; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i < Bg ? i : i - Bg;
+    const int64_t node = i < Bg ? src[o + e] : dst[o + e];
+    pos[i] = node;
+    ts2f[i] = (float)ts[o + e];
+    flags[node] = 1;
+    if (i < Bg) eids_b[e] = eids[o + e];
+  }
+}
+}  // namespace tg
+
+struct WbWs {
+  uint8_t* flags;
+  unsigned long long* best;
+  int32_t* counts;
+  size_t zero_bytes;
+  uint64_t* bm;
+  uint32_t* rank;
+  int64_t *pos, *eids, *uniq, *upos, *index;
+  float* ts2f;
+  void* scan_ws;
+  size_t scan_bytes;
+};
+
+static bool carve_wb(const tg_model* m, int64_t Bg, Carver& cv, WbWs& w) {
+  const int64_t W = (m->n_nodes + 63) / 64;
+  char* z0 = cv.p;
+  w.flags = cv.take<uint8_t>((size_t)W * 64);
+  w.best = cv.take<unsigned long long>((size_t)2 * Bg);
+  w.counts = cv.take<int32_t>(4);
+  w.zero_bytes = cv.ok ? (size_t)(cv.p - z0) : 0;
+  w.bm = cv.take<uint64_t>((size_t)W);
+  w.rank = cv.take<uint32_t>((size_t)W + 1);
+  w.pos = cv.take<int64_t>((size_t)2 * Bg);
+  w.eids = cv.take<int64_t>((size_t)Bg);
+  w.uniq = cv.take<int64_t>((size_t)2 * Bg);
+  w.upos = cv.take<int64_t>((size_t)2 * Bg);
+  w.index = cv.take<int64_t>((size_t)2 * Bg);
+  w.ts2f = cv.take<float>((size_t)2 * Bg);
+  w.scan_bytes = tg_unique_compact_workspace_bytes(m->n_nodes);
+  w.scan_ws = cv.take<char>(w.scan_bytes);
+  return cv.ok;
+}
+
+extern "C" size_t tg_stream_writeback_workspace_bytes(const tg_model* m, int64_t Bg) {
+  if (!attn_dims_ok(m) || Bg <= 0) return 0;
+  const size_t W = (m->n_nodes + 63) / 64, n2 = 2 * (size_t)Bg;
+  return align16(W * 64) + align16(n2 * 8) + 16 + align16(W * 8) + align16((W + 1) * 4) + 4 * align16(n2 * 8) +
+         align16(Bg * 8) + align16(n2 * 4) + align16(tg_unique_compact_workspace_bytes(m->n_nodes)) + 256;
+}
+
+extern "C" int tg_stream_writeback(const tg_model* m, const tg_writeback_io* io, void* ws, size_t ws_bytes,
+                                   void* stream) {
+  if (!attn_dims_ok(m) || !io || io->Bg <= 0) return TG_EINVAL;
+  if (!io->src || !io->dst || !io->ts || !io->eids || !io->rows || !io->left_row || !io->new_row || !io->err)
+    return TG_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const int64_t Bg = io->Bg;
+  Carver cv(ws, ws_bytes);
+  WbWs w{};
+  if (!carve_wb(m, Bg, cv, w)) return TG_EWORKSPACE;
+  hipError_t e = hipMemsetAsync(w.flags, 0, w.zero_bytes, st);
+  if (e != hipSuccess) {
+    set_hip_error(e, "tg_stream_writeback memset");
+    return TG_EHIP;
+  }
+  hipLaunchKernelGGL(k_wb_prepare, dim3(flat_grid(2 * Bg, 256)), dim3(256), 0, st, Bg, io->src, io->dst, io->ts, io->eids,
+                     io->offset_dev, w.pos, w.ts2f, w.eids, w.flags);
+  int rc;
+  if ((rc = unique_compact_launch(w.flags, w.bm, m->n_nodes, w.rank, w.uniq, w.counts + 0, 2 * Bg, nullptr, nullptr,
+                                  nullptr, nullptr, nullptr, w.scan_ws, w.scan_bytes, st)) != TG_OK)
+    return rc;
+  const int64_t* src = w.pos;
+  const int64_t* dst = w.pos + Bg;
+  hipLaunchKernelGGL(k_pos_max, dim3(flat_grid(2 * Bg, 256)), dim3(256), 0, st, Bg, src, dst, w.ts2f, w.bm, w.rank, w.best);
+  hipLaunchKernelGGL(k_pos_winners, dim3(flat_grid(2 * Bg, 256)), dim3(256), 0, st, Bg, src, dst, w.ts2f, w.bm, w.rank,
+                     w.best, w.upos, w.index, w.counts + 2);
+  WritebackArgs wa{};
+  wa.B = Bg; wa.src = src; wa.dst = dst; wa.eids = w.eids; wa.upos = w.upos; wa.index = w.index; wa.ts = w.ts2f;
+  wa.n_upos = w.counts + 2; wa.err = io->err;
+  wa.rows = io->rows; wa.new_row = io->new_row; wa.left_row = io->left_row; wa.plan_off = io->offset_dev;
+  if ((rc = writeback_launch(m, wa, 0, st)) != TG_OK) return rc;
+  if ((rc = writeback_launch(m, wa, 1, st)) != TG_OK) return rc;
+  // phase 1 itself reads the offset (plan_off), so it is advanced by a separate launch
+  if (io->offset_dev && io->advance) hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, io->offset_dev, Bg);
+  return check_launch("tg_stream_writeback");
 }

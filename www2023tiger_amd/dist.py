@@ -17,9 +17,8 @@ different algorithm and is not what this file implements.
 """
 import ctypes as C
 import json
-import os
 import time
-from typing import Callable, Dict, List, Optional, Tuple
+from typing import Optional, Tuple
 
 import numpy as np
 import torch
@@ -47,12 +46,44 @@ def balanced_owner_table(n_nodes: int, dst: np.ndarray, world: int) -> np.ndarra
 
 class ShardPlan:
     """Where every event of one global batch is embedded and where its rows land in the
-    gathered tensor G[world, kind(0 = h_left, 1 = h_new), role(0 = src, 1 = dst), cap, d]."""
+    gathered buffer.  Rank r's send buffer holds `rows_per_rank` rows; the h(t-) row of
+    (role, slot) is at left_base + role*role_stride + slot and the h(t'+) row at
+    new_base + role*role_stride + slot.
 
-    def __init__(self, dst: np.ndarray, owner: np.ndarray, world: int, cap: int):
+    balance=False: an event runs on owner[dst] (shards are ragged, bounded by `cap`).
+    balance=True : every rank gets exactly Bg/world events - an event runs on owner[dst]
+                   while that rank has room and spills to the least loaded rank otherwise.
+                   State is replicated, so placement only affects load, never results;
+                   exact balance gives static shapes (one captured hipGraph per rank)."""
+
+    def __init__(self, dst: np.ndarray, owner: np.ndarray, world: int, cap: int, balance: bool = False,
+                 layout: Optional[Tuple[int, int, int, int]] = None):
         Bg = len(dst)
         self.Bg, self.world, self.cap = Bg, world, cap
-        rank_of = owner[dst]
+        pref = owner[dst]
+        if balance:
+            if Bg % world:
+                raise ValueError('balanced plan needs the global batch to divide by the world size')
+            per = Bg // world
+            if per > cap:
+                raise ValueError(f'shard of {per} events exceeds capacity {cap}')
+            rank_of = np.empty(Bg, dtype=np.int64)
+            room = np.full(world, per, dtype=np.int64)
+            spill = []
+            for e in range(Bg):  # stream order
+                r = pref[e]
+                if room[r] > 0:
+                    rank_of[e] = r
+                    room[r] -= 1
+                else:
+                    spill.append(e)
+            for e in spill:
+                r = int(np.argmax(room))  # most room first (ties -> lowest rank)
+                rank_of[e] = r
+                room[r] -= 1
+        else:
+            rank_of = pref
+        self.rank_of = rank_of
         self.counts = np.bincount(rank_of, minlength=world).astype(np.int64)
         if self.counts.max() > cap:
             raise ValueError(f'shard of {self.counts.max()} events exceeds capacity {cap}')
@@ -61,22 +92,25 @@ class ShardPlan:
         slot = np.empty(Bg, dtype=np.int64)
         slot[order] = np.arange(Bg) - np.repeat(starts, self.counts)
         self.local_idx = [order[starts[r]:starts[r] + self.counts[r]] for r in range(world)]
+        rows_per_rank, left_base, new_base, role_stride = layout or (4 * cap, 0, 2 * cap, cap)
         role = np.repeat(np.array([0, 1]), Bg)
         r2, s2 = np.tile(rank_of, 2), np.tile(slot, 2)
-        self.left_row = ((r2 * 2 + 0) * 2 + role) * cap + s2   # [2Bg] row of h_left for position i of cat[src,dst]
-        self.new_row = ((r2 * 2 + 1) * 2 + role) * cap + s2    # [2Bg] row of h(t'+)
+        self.left_row = r2 * rows_per_rank + left_base + role * role_stride + s2  # [2Bg], position i of cat[src,dst]
+        self.new_row = r2 * rows_per_rank + new_base + role * role_stride + s2
 
 
-def all_gather_rows(send: torch.Tensor, world: int, group=None) -> torch.Tensor:
-    """send [2, 2, cap, d] -> [world, 2, 2, cap, d].  On RCCL the gather runs on device;
-    gloo (CPU tests, or two ranks sharing one GPU) stages through host memory."""
-    out = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+def all_gather_rows(send: torch.Tensor, world: int, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """send [...] -> [world, ...].  On RCCL the gather runs on device; gloo (CPU tests, or
+    two ranks sharing one GPU) stages through host memory."""
+    if out is None:
+        out = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
     if tdist.get_backend(group) == 'nccl':
         tdist.all_gather_into_tensor(out, send.contiguous(), group=group)
         return out
     parts = [torch.empty(send.shape, dtype=send.dtype) for _ in range(world)]
     tdist.all_gather(parts, send.detach().cpu().contiguous(), group=group)
-    return torch.stack(parts).to(send.device)
+    out.copy_(torch.stack(parts).to(send.device))
+    return out
 
 
 class ShardedRunner:
@@ -84,11 +118,13 @@ class ShardedRunner:
     `backend` supplies the two compute halves (HipBackend in production; the CPU tests
     plug in an oracle-backed object to exercise this host logic under gloo)."""
 
-    def __init__(self, backend, owner: np.ndarray, rank: int, world: int, cap: int, group=None):
+    def __init__(self, backend, owner: np.ndarray, rank: int, world: int, cap: int, group=None,
+                 balance: bool = False):
         self.backend, self.owner, self.rank, self.world, self.cap, self.group = backend, owner, rank, world, cap, group
+        self.balance = balance
 
     def plan(self, dst: np.ndarray) -> ShardPlan:
-        return ShardPlan(np.asarray(dst), self.owner, self.world, self.cap)
+        return ShardPlan(np.asarray(dst), self.owner, self.world, self.cap, balance=self.balance)
 
     def step(self, src, dst, neg, ts, eids, plan: Optional[ShardPlan] = None):
         """Arrays of the GLOBAL batch (host numpy).  Returns this rank's local embeddings."""
@@ -105,16 +141,17 @@ class ShardedRunner:
 
 
 class HipBackend:
-    """The two halves on the HIP engine: tg_stream_step(embed_only) and the row-indexed
-    write-back entry points."""
+    """The two halves on the HIP engine, driven with host arrays (ragged shards allowed):
+    tg_stream_step(embed_only) and tg_stream_writeback."""
 
     def __init__(self, model, cap: int):
         from . import hip_ops
-        from ._lib import check, lib, ptr
+        from ._lib import TgWritebackIo, check, lib, ptr
         self.model, self.cap = model, cap
-        self.hip_ops, self.check, self.lib, self.ptr = hip_ops, check, lib, ptr
+        self.hip_ops, self.check, self.lib, self.ptr, self.WbIo = hip_ops, check, lib, ptr, TgWritebackIo
         self.buf = model.StepBuffers(model, cap, False, embed_only=True)
         self.err = hip_ops.new_err(model.device)
+        self._wb_ws = None
 
     def _dev(self, a, dt):
         return torch.as_tensor(a).to(self.model.device, dt).contiguous()
@@ -122,8 +159,7 @@ class HipBackend:
     def embed(self, src, dst, neg, ts, eids):
         n, buf = len(src), self.buf
         if n == 0:
-            d = self.model.memory_dim
-            z = torch.zeros(0, d, device=self.model.device)
+            z = torch.zeros(0, self.model.memory_dim, device=self.model.device)
             return z, z
         buf.src[:n], buf.dst[:n], buf.neg[:n] = (self._dev(x, torch.int64) for x in (src, dst, neg))
         buf.ts[:n], buf.eids[:n] = self._dev(ts, torch.float64), self._dev(eids, torch.int64)
@@ -132,28 +168,113 @@ class HipBackend:
         return buf.h[:2 * n], buf.h_new[:2 * n]
 
     def writeback(self, src, dst, ts, eids, rows, left_row, new_row):
-        m, lib, ptr, check = self.model, self.lib, self.ptr, self.check
-        dev = m.device
+        m, lib, ptr = self.model, self.lib, self.ptr
         Bg = len(src)
-        s, d_, e = (self._dev(x, torch.int64) for x in (src, dst, eids))
-        t32 = self._dev(np.asarray(ts, dtype=np.float64), torch.float64).float()
-        pos, ts2 = torch.cat([s, d_]), t32.repeat(2)
-        upos, index = self.hip_ops.select_latest_nids(pos, ts2, m.n_nodes)
-        n = len(upos)
-        n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
-        rows_new = self._dev(new_row, torch.int64)[index].contiguous()
-        rows_left = self._dev(left_row, torch.int64)[index].contiguous()
         ms = m.model_struct()
-        st = self.hip_ops.stream_ptr(dev)
-        rows = rows.contiguous()
-        check(lib.tg_consume_update_right_rows(C.byref(ms), ptr(upos), ptr(n_dev), n, ptr(rows), ptr(rows_new),
-                                               ptr(self.err), st), 'tg_consume_update_right_rows')
-        check(lib.tg_store_events(C.byref(ms), Bg, ptr(s), ptr(d_), ptr(t32), ptr(e), ptr(upos), ptr(index),
-                                  ptr(n_dev), ptr(self.err), st), 'tg_store_events')
-        L = m.left_memory
-        check(lib.tg_memory_scatter2(n, None, ptr(upos), ptr(rows_left), ptr(index), m.memory_dim, ptr(rows),
-                                     ptr(ts2), ptr(L.vals), ptr(L.update_ts), ptr(L.active_mask), 1, ptr(self.err),
-                                     st), 'tg_memory_scatter2')
+        keep = [self._dev(src, torch.int64), self._dev(dst, torch.int64), self._dev(ts, torch.float64),
+                self._dev(eids, torch.int64), rows.contiguous(), self._dev(left_row, torch.int64),
+                self._dev(new_row, torch.int64)]
+        nbytes = int(lib.tg_stream_writeback_workspace_bytes(C.byref(ms), Bg))
+        if self._wb_ws is None or self._wb_ws.numel() < nbytes:
+            self._wb_ws = torch.empty(nbytes, dtype=torch.uint8, device=m.device)
+        io = self.WbIo(Bg, ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), None, 0, 0, ptr(keep[4]),
+                       ptr(keep[5]), ptr(keep[6]), ptr(self.err))
+        self.check(lib.tg_stream_writeback(C.byref(ms), C.byref(io), ptr(self._wb_ws), self._wb_ws.numel(),
+                                           self.hip_ops.stream_ptr(m.device)), 'tg_stream_writeback')
+
+    def check_invariants(self):
+        self.hip_ops.raise_if_err(self.err)
+        self.hip_ops.raise_if_err(self.buf.err)
+
+
+class ResidentShardedStream:
+    """Production form for a stream that is resident in HBM: balanced plans are prepared for
+    every step up front, each rank's shard of the stream and the global stream sit on the
+    device, and a step is  [hipGraph: embed shard] -> all-gather -> [hipGraph: write-back].
+    Send buffer per rank: 5B rows = [h(t-) src | h(t-) dst | h(neg) | h(t'+) src | h(t'+) dst]
+    (the step writes its outputs straight into it)."""
+
+    def __init__(self, model, stream: dict, owner: np.ndarray, rank: int, world: int, B: int, n_steps: int,
+                 group=None, use_graphs: bool = True):
+        from . import hip_ops
+        from ._lib import TgWritebackIo, check, lib, ptr
+        self.model, self.rank, self.world, self.B, self.group = model, rank, world, B, group
+        self.check, self.lib, self.ptr, self.hip_ops = check, lib, ptr, hip_ops
+        dev, d = model.device, model.memory_dim
+        Bg = B * world
+        self.Bg, self.n_steps = Bg, n_steps
+        layout = (5 * B, 0, 3 * B, B)
+        keys = ('src', 'dst', 'neg', 'ts', 'eids')
+        local = {k: [] for k in keys}
+        left_rows, new_rows = [], []
+        for b in range(n_steps):
+            sl = slice(b * Bg, (b + 1) * Bg)
+            plan = ShardPlan(stream['dst'][sl], owner, world, B, balance=True, layout=layout)
+            li = plan.local_idx[rank]
+            for k in keys:
+                local[k].append(stream[k][sl][li])
+            left_rows.append(plan.left_row)
+            new_rows.append(plan.new_row)
+        tod = lambda a, dt: torch.from_numpy(np.ascontiguousarray(np.concatenate(a))).to(dev, dt)
+        self.local = tuple(tod(local[k], torch.float64 if k == 'ts' else torch.int64) for k in keys)
+        n_ev = n_steps * Bg
+        self.glob = tuple(torch.from_numpy(np.ascontiguousarray(stream[k][:n_ev])).to(dev)
+                          for k in ('src', 'dst', 'ts', 'eids'))
+        self.left_row, self.new_row = tod(left_rows, torch.int64), tod(new_rows, torch.int64)
+        self.send = torch.zeros(5 * B, d, dtype=torch.float32, device=dev)
+        self.gathered = torch.zeros(world, 5 * B, d, dtype=torch.float32, device=dev)
+        self.buf = model.StepBuffers(model, B, False, resident=self.local, embed_only=True, h_out=self.send[:3 * B],
+                                     h_new_out=self.send[3 * B:])
+        self.err = hip_ops.new_err(dev)
+        ms = model.model_struct()
+        nbytes = int(lib.tg_stream_writeback_workspace_bytes(C.byref(ms), Bg))
+        self.wb_ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.wb_off = torch.zeros(1, dtype=torch.int64, device=dev)
+        g = self.glob
+        self.wb_io = TgWritebackIo(Bg, ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(g[3]), ptr(self.wb_off), 1, 0,
+                                   ptr(self.gathered), ptr(self.left_row), ptr(self.new_row), ptr(self.err))
+        self.g_embed = self.g_wb = None
+        self.use_graphs = use_graphs
+        self.steps_done = 0
+
+    def _launch_wb(self):
+        ms = self.model.model_struct()
+        self.check(self.lib.tg_stream_writeback(C.byref(ms), C.byref(self.wb_io), self.ptr(self.wb_ws),
+                                                self.wb_ws.numel(), self.hip_ops.stream_ptr(self.model.device)),
+                   'tg_stream_writeback')
+
+    def capture(self):
+        """Capture both halves into hipGraphs (call after at least one eager step)."""
+        side = torch.cuda.Stream(device=self.model.device)
+        off_e, off_w = self.buf.offset.clone(), self.wb_off.clone()
+        self.g_embed, self.g_wb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_embed, stream=side):
+            self.model.launch_step(self.buf)
+        with torch.cuda.graph(self.g_wb, stream=side):
+            self._launch_wb()
+        self.buf.offset.copy_(off_e)  # capture does not execute, but be explicit
+        self.wb_off.copy_(off_w)
+
+    def step(self, debug: bool = False):
+        assert self.steps_done < self.n_steps, 'resident stream exhausted'
+
+        def mark(what):
+            if debug:
+                torch.cuda.synchronize()
+                print(f'[dist debug] step {self.steps_done} {what} ok', flush=True)
+        if self.g_embed is not None:
+            self.g_embed.replay()
+        else:
+            self.model.launch_step(self.buf)
+        mark('embed')
+        all_gather_rows(self.send, self.world, self.group, out=self.gathered)
+        mark('all_gather')
+        if self.g_wb is not None:
+            self.g_wb.replay()
+        else:
+            self._launch_wb()
+        mark('writeback')
+        self.steps_done += 1
 
     def check_invariants(self):
         self.hip_ops.raise_if_err(self.err)
@@ -175,26 +296,36 @@ def bench_main(args, cfg, make_stream, build_models, rank, local_rank, world):
     stream = make_stream(cfg['n_u'], cfg['n_i'], E, cfg['T'] * E / cfg['E'], seed=0, d_e=d)  # identical on every rank
     model, _ = build_models(stream, d, K, cfg['msg_src'], cfg['upd_src'], restarter='static', device=str(dev))
     owner = balanced_owner_table(stream['n_nodes'], stream['dst'], world)
-    cap = int(B * 1.5) + 64
-    runner = ShardedRunner(HipBackend(model, cap), owner, rank, world, cap)
-    keys = ('src', 'dst', 'neg', 'ts', 'eids')
-    batches = [[stream[k][b * Bg:(b + 1) * Bg] for k in keys] for b in range(n_steps)]
-    plans = [runner.plan(b[1]) for b in batches]  # input preparation, outside the timed region
-    max_shard = max(int(p.counts.max()) for p in plans)
-    for b in range(args.warmup):
-        runner.step(*batches[b], plan=plans[b])
+    use_graphs = bool(getattr(args, 'dist_graphs', False)) and not args.no_graph
+    rs = ResidentShardedStream(model, stream, owner, rank, world, B, n_steps, use_graphs=use_graphs)
+    spilled = 0.0
+    for b in range(min(n_steps, 50)):  # how often the owner's shard was full (reported, not timed)
+        sl = slice(b * Bg, (b + 1) * Bg)
+        p = ShardPlan(stream['dst'][sl], owner, world, B, balance=True)
+        spilled += float((p.rank_of != owner[stream['dst'][sl]]).mean())
+    spilled /= min(n_steps, 50)
+    import os
+    debug = bool(os.environ.get('TG_DIST_DEBUG'))
+    n_eager = min(2, args.warmup)
+    for _ in range(n_eager):
+        rs.step(debug)
+    torch.cuda.synchronize()
+    if use_graphs:
+        rs.capture()
+    for _ in range(args.warmup - n_eager):
+        rs.step(debug)
     torch.cuda.synchronize()
     tdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for b in range(args.warmup, n_steps):
-        runner.step(*batches[b], plan=plans[b])
+    for _ in range(args.steps):
+        rs.step()
     torch.cuda.synchronize()
     tdist.barrier()
     torch.cuda.synchronize()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     tdist.all_reduce(dt, op=tdist.ReduceOp.MAX)
-    runner.backend.check_invariants()
+    rs.check_invariants()
     dt = float(dt.item())
     if rank == 0:
         out = dict(metric='processed interaction-events/sec (memory+aggregate+embed), Wikipedia d=172',
@@ -204,8 +335,10 @@ def bench_main(args, cfg, make_stream, build_models, rank, local_rank, world):
                    config=dict(workload=cfg['name'], batch_per_gpu=B, global_batch=Bg, dim=d, n_neighbors=K,
                                msg_src=cfg['msg_src'], upd_src=cfg['upd_src'], n_nodes=stream['n_nodes'], events=E,
                                mode='stream (no_grad) STEP 1-6',
-                               parallelism=f'dst-owner event shards x{world}, replicated state, 1 RCCL all-gather/batch',
-                               max_shard_events=max_shard),
+                               parallelism=f'dst-owner event shards x{world} (capacity-balanced), replicated state, '
+                                           f'1 RCCL all-gather of {5 * B}x{d} f32 rows per rank per batch',
+                               spilled_event_fraction=round(spilled, 4),
+                               launch='2 hipGraphs + 1 all-gather per step' if use_graphs else 'eager launches + 1 all-gather per step'),
                    roofline=None, cpu_baseline=None)
         print(json.dumps(out))
     tdist.destroy_process_group()

@@ -254,7 +254,8 @@ class TIGE(nn.Module):
         """Static device buffers of one batch size: inputs, outputs and the workspace of
         tg_stream_step; reused every step so the call sequence can be graph-captured."""
 
-        def __init__(self, model: 'TIGE', B: int, want_prev: bool, resident=None, embed_only: bool = False):
+        def __init__(self, model: 'TIGE', B: int, want_prev: bool, resident=None, embed_only: bool = False,
+                     h_out=None, h_new_out=None):
             """resident = (src, dst, neg, ts64, eids) device tensors of the WHOLE stream: the
             step then reads batch [offset, offset+B) and advances `offset` on device."""
             dev, d, K = model.device, model.memory_dim, model.n_neighbors
@@ -268,7 +269,8 @@ class TIGE(nn.Module):
                 self.src, self.dst, self.neg, self.ts, self.eids = resident
                 assert self.ts.dtype == torch.float64 and all(t.is_contiguous() for t in resident)
                 self.offset = torch.zeros(1, **i64)
-            self.h = torch.zeros(3 * B, d, dtype=torch.float32, device=dev)
+            # h_out / h_new_out: caller-owned output rows (e.g. slices of an all-gather send buffer)
+            self.h = h_out if h_out is not None else torch.zeros(3 * B, d, dtype=torch.float32, device=dev)
             self.l1_nids = torch.zeros(3 * B, K, **i64)
             self.l1_eids = torch.zeros(3 * B, K, **i64)
             self.l1_ts = torch.zeros(3 * B, K, dtype=torch.float32, device=dev)
@@ -277,7 +279,8 @@ class TIGE(nn.Module):
             self.err = torch.zeros(1, dtype=torch.int32, device=dev)
             self.h_prev_left = torch.zeros(2 * B, d, dtype=torch.float32, device=dev) if want_prev else None
             self.h_prev_right = torch.zeros(2 * B, d, dtype=torch.float32, device=dev) if want_prev else None
-            self.h_new = torch.zeros(2 * B, d, dtype=torch.float32, device=dev) if embed_only else None
+            self.h_new = h_new_out if h_new_out is not None else (
+                torch.zeros(2 * B, d, dtype=torch.float32, device=dev) if embed_only else None)
             m = model.model_struct()
             nbytes = int(lib.tg_stream_step_workspace_bytes(C.byref(m), B))
             if nbytes == 0:
