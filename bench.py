@@ -34,6 +34,19 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s s
 # BASELINE.json configs[1]; Wikipedia: 8227 users, 1000 items, 157474 events
 C2 = dict(name='C2 JODIE-Wikipedia-shaped synthetic', n_u=8227, n_i=1000, E=157474, T=2.68e6, d=172, K=10, B=1024,
           msg_src='left', upd_src='left')
+# the other BASELINE configs: parity-test shapes, selectable for profiling runs only
+WORKLOADS = {
+    'c2': C2,
+    'c3': dict(name='C3 JODIE-Reddit-shaped synthetic', n_u=10000, n_i=984, E=672447, T=2.68e6, d=172, K=10, B=4096,
+               msg_src='left', upd_src='right'),
+    'c4': dict(name='C4 JODIE-LastFM-shaped synthetic (no feature tables)', n_u=980, n_i=1000, E=1293103, T=1.37e8, d=100,
+               K=10, B=8192, msg_src='left', upd_src='right', no_feats=True),
+    # C5 scaled to one GPU-box host: 10 M nodes as in BASELINE, 4 M events (the state tables are full size:
+    # 2 x 10.2 GB memories + 41 GB mailbox), d=256, B=65536 - the HBM-roofline configuration
+    'c5s': dict(name='C5 synthetic 10M nodes d=256 B=65536 (stream shortened to 4M events)', n_u=9000000, n_i=1000000,
+                E=4000000, T=4.0e6, d=256, K=10, B=65536, msg_src='left', upd_src='right', no_feats=True,
+                integer_ts=False),
+}
 
 
 def make_stream(n_u, n_i, E, T, seed=0, d_e=172, integer_ts=True, with_efeats=True):
@@ -73,17 +86,18 @@ def build_models(stream, d, K, msg_src, upd_src, restarter='static', hist_len=40
     nfeats = np.zeros((n_nodes, d), dtype=np.float32) if zero_nfeats else None  # JODIE node features are all zero
     efeats = stream['efeats']
     torch.manual_seed(seed)
-    fg = NumericalFeature(None if nfeats is None else torch.from_numpy(nfeats),
-                          None if efeats is None else torch.from_numpy(efeats), dim=d, device=dev)
-    fg.n_nodes, fg.n_edges = n_nodes, len(stream['src'])
-    if restarter == 'seq':
-        rst = SeqRestarter(raw_feat_getter=fg, graph=g, hist_len=hist_len, n_head=2, dropout=0.1)
-    else:
-        rst = StaticRestarter(raw_feat_getter=fg, graph=g)
-    model = TIGER(raw_feat_getter=fg, graph=g, restarter=rst, n_neighbors=K, hit_type='bin', n_layers=1, n_head=2,
-                  dropout=0.1, msg_src=msg_src, upd_src=upd_src)
-    with torch.no_grad():  # non-trivial time-encoder phase so the cos path is exercised
-        model.time_encoder.phase.uniform_(-0.5, 0.5)
+    with torch.device(dev):  # parameters and the (possibly tens of GB of) state tables are born on the GPU
+        fg = NumericalFeature(None if nfeats is None else torch.from_numpy(nfeats).to(dev),
+                              None if efeats is None else torch.from_numpy(efeats).to(dev), dim=d, device=dev)
+        fg.n_nodes, fg.n_edges = n_nodes, len(stream['src'])
+        if restarter == 'seq':
+            rst = SeqRestarter(raw_feat_getter=fg, graph=g, hist_len=hist_len, n_head=2, dropout=0.1)
+        else:
+            rst = StaticRestarter(raw_feat_getter=fg, graph=g)
+        model = TIGER(raw_feat_getter=fg, graph=g, restarter=rst, n_neighbors=K, hit_type='bin', n_layers=1, n_head=2,
+                      dropout=0.1, msg_src=msg_src, upd_src=upd_src)
+        with torch.no_grad():  # non-trivial time-encoder phase so the cos path is exercised
+            model.time_encoder.phase.uniform_(-0.5, 0.5)
     model = model.to(dev).eval()
     oracle = None
     if with_oracle:
@@ -152,12 +166,13 @@ def main():
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS), help='c2 is the benchmarked configuration')
     ap.add_argument('--no-graph', action='store_true', help='launch steps eagerly instead of replaying a hipGraph')
     ap.add_argument('--force-dist', action='store_true', help='run the multi-GPU code path even with one rank')
     ap.add_argument('--dist-graphs', action='store_true',
                     help='multi-GPU: replay captured hipGraphs around the all-gather (experimental; default eager)')
     args = ap.parse_args()
-    cfg = dict(C2)
+    cfg = dict(WORKLOADS[args.workload])
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -170,8 +185,11 @@ def main():
     B, K, d = cfg['B'], cfg['K'], cfg['d']
     n_batches = args.warmup + args.steps + 4
     E = max(cfg['E'], n_batches * B)
-    stream = make_stream(cfg['n_u'], cfg['n_i'], E, cfg['T'] * E / cfg['E'], seed=0, d_e=d)
-    model, _ = build_models(stream, d, K, cfg['msg_src'], cfg['upd_src'], restarter='static', device='cuda:0')
+    no_feats = bool(cfg.get('no_feats'))
+    stream = make_stream(cfg['n_u'], cfg['n_i'], E, cfg['T'] * E / cfg['E'], seed=0, d_e=d,
+                         integer_ts=cfg.get('integer_ts', True), with_efeats=not no_feats)
+    model, _ = build_models(stream, d, K, cfg['msg_src'], cfg['upd_src'], restarter='static', device='cuda:0',
+                            zero_nfeats=not no_feats)
     resident = tuple(torch.from_numpy(stream[k]).to(dev) for k in ('src', 'dst', 'neg', 'ts', 'eids'))
     buf = model.StepBuffers(model, B, False, resident=resident)
 
@@ -212,10 +230,11 @@ def main():
     # algorithmic HBM bytes per launch (SURVEY.md s8 d), with the measured U/O/P of this run
     Q = 3 * B
     d_e = d
+    fe = 0 if no_feats else 1  # feature tables present?
     bytes_by_stage = {
         'gather_right_memory': U * 4 * d * 2,                                   # read rows + compact write
         'apply_messages(gru)': O_ * (4 * (3 * d + d_e) + 4) + O_ * (4 * d + 4) + O_ * 4 * d,  # mailbox + upd rows + write
-        'attn_core(gather+softmax)': Q * K * 4 * (d_e + d + d) + Q * 2 * (2 * d + d_e) * 4 * 2,  # efeat+nfeat+reprs rows, G in, S out
+        'attn_core(gather+softmax)': Q * K * 4 * (fe * d_e + fe * d + d) + Q * 2 * (2 * d + d_e) * 4 * 2,  # efeat+nfeat+reprs rows, G in, S out
         'store_events': P * (4 * (3 * d + d_e) + 4) + 2 * B * 4 * d + B * 4 * d_e,
     }
     flops_by_stage = {'apply_messages(gru)': 2.0 * O_ * 3 * d * ((3 * d + d_e) + d)}
@@ -254,7 +273,7 @@ def main():
                            involved_per_batch=float(U), outdated_per_batch=float(O_), unique_pos_per_batch=float(P)),
                roofline=roof,
                stages_ms={n: round(float(v), 5) for n, v in zip(names, stage_ms)})
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and args.workload == 'c2':
         out['cpu_baseline'] = cpu_baseline(stream, cfg, model)
     print(json.dumps(out))
 

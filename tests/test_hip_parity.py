@@ -325,3 +325,73 @@ def test_state_dict_keys_match_reference():
               'restarter_fn.mha_fn.in_proj_weight', 'restarter_fn.anony_emb.weight'):
         assert k in keys, k
     assert not any('node_msg' in k or 'nfeats' in k or 'has_msg' in k for k in keys)  # non-persistent buffers
+
+
+# ------------------------------------------------------------------------------ larger shapes vs the oracle
+def _oracle_vs_fused(stream, d, K, B, n_batches, msg_src, upd_src, zero_nfeats=True):
+    import bench
+    from oracle import tiger_oracle as O
+    model, orc = bench.build_models(stream, d, K, msg_src, upd_src, with_oracle=True, zero_nfeats=zero_nfeats)
+    worst = 0.0
+    for b in range(n_batches):
+        sl = slice(b * B, (b + 1) * B)
+        a = [stream[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        buf = model.stream_step(*a)
+        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], K, 'static')
+        ref = orc.stream_step(*a, cg).numpy()
+        np.testing.assert_array_equal(buf.l1_nids.cpu().numpy(), cg['l1_nids'])
+        np.testing.assert_array_equal(buf.l1_eids.cpu().numpy(), cg['l1_eids'])
+        counts = buf.counts.cpu().numpy()
+        np.testing.assert_array_equal(buf.involved.cpu().numpy()[:counts[0]], cg['involved'])
+        worst = max(worst, rel_err(buf.h[:2 * B].cpu().numpy(), ref))
+    has = np.array(sorted(model.msg_store.nodes_with_messages), dtype=np.int64)
+    np.testing.assert_array_equal(has, np.nonzero(orc.has_msg)[0])
+    assert rel_err(model.left_memory.vals.cpu().numpy(), orc.left_vals.numpy()) < TOL
+    assert rel_err(model.right_memory.vals.cpu().numpy(), orc.right_vals.numpy()) < TOL
+    assert rel_err(model.msg_store.node_msg_vals.cpu().numpy()[has], orc.msg_vals.numpy()[has]) < TOL
+    np.testing.assert_array_equal(model.left_memory.update_ts.cpu().numpy(), orc.left_ts.numpy())
+    assert worst < TOL, worst
+
+
+def test_c2_full_size_batches_match_oracle():
+    """BASELINE configs[1] at full size (Wikipedia-shaped, d=172, B=1024, K=10): 5 batches."""
+    import bench
+    c = bench.C2
+    stream = bench.make_stream(c['n_u'], c['n_i'], 20000, c['T'] * 20000 / c['E'], seed=1, d_e=c['d'])
+    _oracle_vs_fused(stream, c['d'], c['K'], c['B'], 5, c['msg_src'], c['upd_src'])
+
+
+def test_large_sparse_graph_multiblock_compaction_matches_oracle():
+    """300 k nodes: the involved / outdated compaction takes the three-phase (multi-block) path;
+    no feature tables, d=100 (LastFM-style widths)."""
+    import bench
+    stream = bench.make_stream(250000, 50000, 12000, 5.0e5, seed=2, d_e=100, with_efeats=False)
+    _oracle_vs_fused(stream, 100, 10, 2048, 4, 'left', 'right', zero_nfeats=False)
+
+
+def test_sampler_properties_at_scale():
+    """Size-independent properties on a 1 M-event graph: sampled timestamps are ascending, strictly
+    earlier than the query, left padded, and a wider K extends a narrower one on the left."""
+    import bench
+    from www2023tiger_amd.data.graph import Graph
+    st = bench.make_stream(20000, 3000, 1_000_000, 1.0e7, seed=3, with_efeats=False)
+    g = Graph.from_arrays(st['src'], st['dst'], st['ts'], st['eids'], strategy='recent_edges', device=dev())
+    rs = np.random.RandomState(0)
+    q = rs.randint(0, st['n_nodes'], 200_000).astype(np.int64)
+    t = rs.uniform(0, 1.05e7, len(q))
+    n10, e10, t10, d10 = g.sample_temporal_neighbor(q, t, 10)
+    n40, e40, t40, _ = g.sample_temporal_neighbor(q, t, 40)
+    np.testing.assert_array_equal(n40[:, -10:], n10)
+    np.testing.assert_array_equal(e40[:, -10:], e10)
+    valid = n10 != 0
+    assert (t10[valid] < t[:, None].repeat(10, 1)[valid].astype(np.float32) + 1e-3).all()
+    both = valid[:, 1:] & valid[:, :-1]
+    assert (np.diff(t10, axis=1)[both] >= 0).all()                              # ascending in time
+    assert ((~valid)[:, 1:] <= (~valid)[:, :-1]).all()                          # pads only on the left
+    src_of = {int(e): (int(s), int(dd)) for e, s, dd in zip(st['eids'][:2000], st['src'][:2000], st['dst'][:2000])}
+    for i in np.nonzero(valid.any(1))[0][:500]:                                 # edge ids join query node and neighbour
+        for k in np.nonzero(valid[i])[0]:
+            if int(e10[i, k]) in src_of:
+                s, dd = src_of[int(e10[i, k])]
+                assert {int(q[i]), int(n10[i, k])} == {s, dd}
+                assert d10[i, k] == (1 if int(q[i]) == dd else 0)

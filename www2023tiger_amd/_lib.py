@@ -6,6 +6,10 @@ the import of this module raises, and every op of the package fails with it.
 import ctypes as C
 import os
 
+# torch first: its wheel bundles the HIP runtime (libamdhip64) that owns the tensors and streams
+# handed to the library; loading libtiger_hip.so before it would bind a second runtime copy.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libtiger_hip.so')
 
