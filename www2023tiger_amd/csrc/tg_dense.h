@@ -47,7 +47,8 @@ struct GruArgs {
   float* out;
   int64_t ldo;
   const int32_t* out_rows;  // nullable
-  int dbg;                  // diagnostic ablation bits, 0 in production
+  int dbg;                  // diagnostic bits, 0 in production
+  int64_t rows_hint;        // upper bound of live rows known on the host (0 = unknown), picks the tile height
 };
 
 int gru_launch(const GruArgs& g, hipStream_t st);

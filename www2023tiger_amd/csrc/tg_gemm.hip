@@ -189,12 +189,26 @@ int gemm_launch(const GemmArgs& g, hipStream_t st) {
 // diagnostic only (TG_GRU_DBG & 16): per-block s_memtime stamps {entry, loop start, loop end, exit}
 __device__ unsigned long long g_gru_trace[2048 * 4];
 
-__global__ void __launch_bounds__(256) k_gru(GruArgs g) {
-  constexpr int BM = 128;
+template <int NW, int KS>
+__global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
+  // NW wavefronts stack 32-row MFMA tiles (BM = 32 NW rows per block); with KS = 2 a second
+  // group of NW wavefronts takes the other half of every tile's k-steps into its own
+  // accumulators (summed through LDS at the end), which puts two independent instruction
+  // streams on every SIMD: a single wave drives the f32 matrix pipe to only ~65 % here.
+  constexpr int THREADS = 64 * NW * KS;
+  constexpr int BM = 32 * NW;
+  constexpr int RP = THREADS / 8;              // tile rows staged per pass (8 threads per 32-float row)
+  constexpr int NA = BM / RP;                  // activation float4 per thread per tile
+  constexpr int NBL = (96 + RP - 1) / RP;      // weight float4 per thread per tile (3 planes x 32 rows)
+  constexpr int NOPS = NA + NBL;
+  constexpr int PP = 8 / KS;                   // k-step pairs per wave per tile
+  static_assert(BM % RP == 0 && NOPS <= (PP / 2) * 3, "three memory-op slots per k-step pair");
   const unsigned long long t_entry = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
   __shared__ float As[2][BM][LDK];
   __shared__ float Bs[2][3][32][LDK];
+  __shared__ float red[KS == 2 ? 4 : 1][KS == 2 ? NW : 1][16][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rw = wave % NW, ks = wave / NW;
   const int d = g.d, xw = g.xw;
   const int NT = (d + 31) / 32;
   const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
@@ -207,61 +221,35 @@ __global__ void __launch_bounds__(256) k_gru(GruArgs g) {
   const int j0 = nt * 32;
   const int ar = tid >> 3, ac4 = (tid & 7) * 4;
   // branch-free staging (see k_gemm): clamped addresses, zeros only for k past the segment
-  const float* xrow[4];
-  const float* hrow[4];
+  const float* xrow[NA];
+  const float* hrow[NA];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int64_t m = min(m0 + ar + i * 32, M - 1);
+  for (int i = 0; i < NA; ++i) {
+    const int64_t m = min(m0 + ar + i * RP, M - 1);
     xrow[i] = g.x.p + (g.x.idx ? g.x.idx[m] : m) * g.x.ld;
     hrow[i] = g.h.p + (g.h.idx ? g.h.idx[m] : m) * g.h.ld;
   }
-  const int jc = min(j0 + ar, d - 1);
   const int nkx = (xw + BK - 1) / BK, nkh = (d + BK - 1) / BK;
   const int nkt = nkx + nkh;
-  float4 ra0[4], rb0[3], ra1[4], rb1[3];
-  auto load = [&](int t, float4* ra, float4* rb) {
-    const bool hp = t >= nkx;
-    const int k = (hp ? t - nkx : t) * BK + ac4;
-    const int width = hp ? d : xw;
-    const bool kin = k < width;
-    const int kc = kin ? k : 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float4 v = ldg4((hp ? hrow[i] : xrow[i]) + kc);
-      ra[i] = kin ? v : zero4();
-    }
-    const float* wbase = (hp ? g.w_hh : g.w_ih) + (int64_t)jc * width + kc;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const float4 v = ldg4(wbase + (int64_t)i * d * width);
-      rb[i] = kin ? v : zero4();
-    }
-  };
-  auto store = [&](int buf, const float4* ra, const float4* rb) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sts4(As[buf][ar + i * 32], ac4, ra[i]);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) sts4(Bs[buf][i][ar], ac4, rb[i]);
-  };
+  float4 ra0[NA], rb0[NBL], ra1[NA], rb1[NBL];
   const int fr = lane & 31, fk = lane >> 5;
   f32x16 acc_r, acc_z, acc_in, acc_hn;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc_r[i] = acc_z[i] = acc_in[i] = acc_hn[i] = 0.f;
-  const int dbg = g.dbg;  // bit 16: record s_memtime stamps (diagnostic build knob, 0 in production)
+  const int dbg = g.dbg;  // bit 16: record s_memtime stamps (diagnostic knob, 0 in production)
   // ---- hand-scheduled tile step ------------------------------------------------------
   // A CU pulls only ~10 B/clk through its vector-memory path, and a wave issues in order: a
-  // burst of 7 global loads (or 28 ds_writes) in front of the MFMAs stalls the matrix pipe
-  // until the memory queue drains (measured: loop = MFMA + loads + stores, nothing hidden).
-  // So the memory work of the OTHER tiles is threaded between the MFMAs of this tile, one
-  // op per MFMA slot, and the order is pinned with sched_barrier:
-  //   first half  (4 k-step pairs): 7 global loads of tile t+2,
-  //   second half (4 k-step pairs): 7 float4 ds_writes of tile t+1 into the other LDS buffer,
-  // while the operand fragments of the next k-step pair are read one pair ahead.
+  // burst of global loads (or ds_writes) in front of the MFMAs stalls the matrix pipe until
+  // the memory queue drains (measured: loop = MFMA + loads + stores, nothing hidden).  So the
+  // memory work of the OTHER tiles is threaded between the MFMAs of this tile and the order
+  // is pinned with sched_barrier: during the first half of a wave's k-step pairs the global
+  // loads of tile t+2, during the second half the ds_writes of tile t+1 into the other LDS
+  // buffer, while the operand fragments of the next pair are read one pair ahead.
   struct Frag {
     float a0, a1, b00, b01, b10, b11, b20, b21;
   };
   auto read_pair = [&](int buf, int p, Frag& f) {  // k-steps 2p and 2p+1 of the tile in LDS[buf]
-    const float* ap = &As[buf][wave * 32 + fr][fk + 4 * p];
+    const float* ap = &As[buf][rw * 32 + fr][fk + 4 * p];
     const float* b0 = &Bs[buf][0][fr][fk + 4 * p];
     const float* b1 = &Bs[buf][1][fr][fk + 4 * p];
     const float* b2 = &Bs[buf][2][fr][fk + 4 * p];
@@ -270,56 +258,64 @@ __global__ void __launch_bounds__(256) k_gru(GruArgs g) {
     f.b10 = b1[0]; f.b11 = b1[2];
     f.b20 = b2[0]; f.b21 = b2[2];
   };
-  auto load_one = [&](int t, int i, float4* ra, float4* rb) {  // i-th of the 7 float4 of tile t
+  auto load_one = [&](int t, int i, float4* ra, float4* rb) {  // i-th staged float4 of tile t
     const bool hp = t >= nkx;
     const int k = (hp ? t - nkx : t) * BK + ac4;
     const int width = hp ? d : xw;
-    const bool kin = k < width;
-    const int kc = kin ? k : 0;
+    const int kc = k < width ? k : 0;
     // raw load from a clamped address; columns past the segment are zeroed when the tile is
     // written to LDS (store_one), so nothing consumes the load result here
-    if (i < 4)
+    if (i < NA) {
       ra[i] = ldg4((hp ? hrow[i] : xrow[i]) + kc);
-    else
-      rb[i - 4] = ldg4((hp ? g.w_hh : g.w_ih) + ((int64_t)(i - 4) * d + jc) * width + kc);
+    } else {
+      const int L = min(ar + (i - NA) * RP, 95);  // row of the [3 planes x 32] weight tile
+      const int jc = min(j0 + (L & 31), d - 1);
+      rb[i - NA] = ldg4((hp ? g.w_hh : g.w_ih) + ((int64_t)(L >> 5) * d + jc) * width + kc);
+    }
   };
   auto store_one = [&](int buf, int t, int i, const float4* ra, const float4* rb) {  // tile t's i-th float4
     const bool hp = t >= nkx;
     const bool kin = (hp ? t - nkx : t) * BK + ac4 < (hp ? d : xw);
-    if (i < 4)
-      sts4(As[buf][ar + i * 32], ac4, kin ? ra[i] : zero4());
-    else
-      sts4(Bs[buf][i - 4][ar], ac4, kin ? rb[i - 4] : zero4());
+    if (i < NA) {
+      sts4(As[buf][ar + i * RP], ac4, kin ? ra[i] : zero4());
+    } else {
+      const int L = ar + (i - NA) * RP;
+      if (L < 96) sts4(Bs[buf][L >> 5][L & 31], ac4, kin ? rb[i - NA] : zero4());
+    }
   };
 #define TG_SB() __builtin_amdgcn_sched_barrier(0)
   auto tile = [&](auto hp_tag, int buf, int t, float4* la, float4* lb, const float4* sa, const float4* sb) {
     constexpr bool HP = decltype(hp_tag)::value;
     const int tl = min(t + 2, nkt - 1);  // past the end: a redundant reload keeps the block branch-free
+    const int p0 = ks * PP;              // this wave's share of the tile's k-step pairs
     Frag cur, nxt;
-    read_pair(buf, 0, cur);
+    read_pair(buf, p0, cur);
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int m0i = (p & 3) * 2, m1i = m0i + 1;  // memory-op slots of this pair: 0..6 used
+    for (int q = 0; q < PP; ++q) {
+      const int op0 = (q % (PP / 2)) * 3;  // up to three memory-op slots per pair; NOPS of them are used
+      auto memop = [&](int i) {
+        if (i < NOPS) {
+          if (q < PP / 2) load_one(tl, i, la, lb);
+          else store_one(buf ^ 1, t + 1, i, sa, sb);
+        }
+      };
       acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a0, cur.b00, acc_r, 0, 0, 0);
-      if (p < 7) read_pair(buf, p + 1, nxt);
+      if (q < PP - 1) read_pair(buf, p0 + q + 1, nxt);
       TG_SB();
       acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a0, cur.b10, acc_z, 0, 0, 0);
+      memop(op0);
       TG_SB();
       if (HP) acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a0, cur.b20, acc_hn, 0, 0, 0);
       else acc_in = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a0, cur.b20, acc_in, 0, 0, 0);
-      if (p < 4) load_one(tl, m0i, la, lb);
-      else store_one(buf ^ 1, t + 1, m0i, sa, sb);
       TG_SB();
       acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a1, cur.b01, acc_r, 0, 0, 0);
+      memop(op0 + 1);
       TG_SB();
       acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a1, cur.b11, acc_z, 0, 0, 0);
       TG_SB();
       if (HP) acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a1, cur.b21, acc_hn, 0, 0, 0);
       else acc_in = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a1, cur.b21, acc_in, 0, 0, 0);
-      if (m1i < 7) {
-        if (p < 4) load_one(tl, m1i, la, lb);
-        else store_one(buf ^ 1, t + 1, m1i, sa, sb);
-      }
+      memop(op0 + 2);
       TG_SB();
       cur = nxt;
     }
@@ -330,11 +326,11 @@ __global__ void __launch_bounds__(256) k_gru(GruArgs g) {
   using HP1 = std::integral_constant<bool, true>;
   // prologue: tile 0 -> LDS[0]; tile 1 -> registers R1
 #pragma unroll
-  for (int i = 0; i < 7; ++i) load_one(0, i, ra0, rb0);
+  for (int i = 0; i < NOPS; ++i) load_one(0, i, ra0, rb0);
 #pragma unroll
-  for (int i = 0; i < 7; ++i) load_one(min(1, nkt - 1), i, ra1, rb1);
+  for (int i = 0; i < NOPS; ++i) load_one(min(1, nkt - 1), i, ra1, rb1);
 #pragma unroll
-  for (int i = 0; i < 7; ++i) store_one(0, 0, i, ra0, rb0);
+  for (int i = 0; i < NOPS; ++i) store_one(0, 0, i, ra0, rb0);
   __syncthreads();
   const unsigned long long t_loop0 = (dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
   for (int t = 0; t < nkt; t += 2) {
@@ -347,6 +343,26 @@ __global__ void __launch_bounds__(256) k_gru(GruArgs g) {
     }
   }
   const unsigned long long t_loop1 = (dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
+  if (KS == 2) {  // fold the second k-group's partial sums into the first
+    if (ks == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        red[0][rw][r][lane] = acc_r[r];
+        red[1][rw][r][lane] = acc_z[r];
+        red[2][rw][r][lane] = acc_in[r];
+        red[3][rw][r][lane] = acc_hn[r];
+      }
+    }
+    __syncthreads();
+    if (ks == 1) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc_r[r] += red[0][rw][r][lane];
+      acc_z[r] += red[1][rw][r][lane];
+      acc_in[r] += red[2][rw][r][lane];
+      acc_hn[r] += red[3][rw][r][lane];
+    }
+  }
   const int j = min(j0 + fr, d - 1);
   const bool jok = j0 + fr < d;
   const float br = g.b_ih[j] + g.b_hh[j];
@@ -358,14 +374,14 @@ __global__ void __launch_bounds__(256) k_gru(GruArgs g) {
   int64_t orow_v[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int64_t m = min(m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk, M - 1);
+    const int64_t m = min(m0 + rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk, M - 1);
     const int64_t hr = g.h.idx ? g.h.idx[m] : m;
     hold_v[r] = g.h.p[hr * g.h.ld + j];
     orow_v[r] = g.out_rows ? (int64_t)g.out_rows[m] : m;
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int64_t m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+    const int64_t m = m0 + rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
     const float hold = hold_v[r];
     const float rg = sigmoidf_(acc_r[r] + br);
     const float zg = sigmoidf_(acc_z[r] + bz);
@@ -387,13 +403,20 @@ extern "C" int tg_debug_gru_trace(unsigned long long* out_host, int n_blocks) {
 int gru_launch(const GruArgs& g, hipStream_t st) {
   if (g.cap <= 0) return TG_OK;
   if (g.d <= 0 || (g.d % 4) || g.xw <= 0 || (g.xw % 4)) return TG_EINVAL;
-  const int64_t MT = cdiv(g.cap, 128);
-  const int NT = (g.d + 31) / 32;
-  const int64_t grid = 8 * cdiv(MT, 8) * NT;
-  static const int dbg = getenv("TG_GRU_DBG") ? atoi(getenv("TG_GRU_DBG")) : 0;  // diagnostic ablation only
+  static const int dbg = getenv("TG_GRU_DBG") ? atoi(getenv("TG_GRU_DBG")) : 0;  // bit 16: trace stamps
+  static const int force_nw = getenv("TG_GRU_NW") ? atoi(getenv("TG_GRU_NW")) : 0;  // tuning knob
   GruArgs a = g;
   a.dbg = dbg;
-  hipLaunchKernelGGL(k_gru, dim3((unsigned)grid), dim3(256), 0, st, a);
+  const int NT = (g.d + 31) / 32;
+  // small problems (at most ~64k live rows): 64-row blocks double the block count so that two
+  // blocks share a CU and cover each other's stalls; large ones keep 128 rows (half the weight traffic)
+  (void)force_nw;
+  static const int ks_knob = getenv("TG_GRU_KS") ? atoi(getenv("TG_GRU_KS")) : 2;  // tuning knob
+  const int64_t grid = 8 * cdiv(cdiv(g.cap, 128), 8) * NT;
+  if (ks_knob == 2)
+    hipLaunchKernelGGL((k_gru<4, 2>), dim3((unsigned)grid), dim3(512), 0, st, a);
+  else
+    hipLaunchKernelGGL((k_gru<4, 1>), dim3((unsigned)grid), dim3(256), 0, st, a);
   return check_launch("gru");
 }
 

@@ -401,6 +401,7 @@ int apply_messages(const tg_model* m, const int64_t* outdated, const int32_t* ou
     a.cap = cap; a.n_dev = n_dev; a.d = d; a.xw = mw; a.x = x; a.h = h;
     a.w_ih = m->gru_w_ih; a.w_hh = m->gru_w_hh; a.b_ih = m->gru_b_ih; a.b_hh = m->gru_b_hh;
     a.out = reprs; a.ldo = d; a.out_rows = out_pos;
+    a.rows_hint = std::min<int64_t>(cap, m->n_nodes);
     return gru_launch(a, st);
   }
   GemmArgs g{};  // MergeUpdater: fc2(relu(fc1([msg | mem])))
