@@ -383,9 +383,9 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
   for (int r = 0; r < 16; ++r) {
     const int64_t m = m0 + rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
     const float hold = hold_v[r];
-    const float rg = sigmoidf_(acc_r[r] + br);
-    const float zg = sigmoidf_(acc_z[r] + bz);
-    const float ng = tanhf(acc_in[r] + bin + rg * (acc_hn[r] + bhn));
+    const float rg = fast_sigmoid(acc_r[r] + br);
+    const float zg = fast_sigmoid(acc_z[r] + bz);
+    const float ng = fast_tanh(acc_in[r] + bin + rg * (acc_hn[r] + bhn));
     if (jok && m < M) g.out[orow_v[r] * g.ldo + j] = (1.f - zg) * ng + zg * hold;
   }
   if ((dbg & 16) && tid == 0 && blockIdx.x < 2048) {
