@@ -99,16 +99,18 @@ __global__ void __launch_bounds__(CB) k_bm_pack_scan(const uint8_t* __restrict__
   }
 }
 
-// Small graphs (<= 256 words = 16384 nodes): pack + scan + emit in ONE block.
-__global__ void __launch_bounds__(CB) k_bm_small(const uint8_t* __restrict__ flags, uint64_t* __restrict__ bm,
+// Small graphs (<= 1024 words = 65536 nodes): pack + scan + emit in ONE 1024-thread block.
+constexpr int SB = 1024;
+__global__ void __launch_bounds__(SB) k_bm_small(const uint8_t* __restrict__ flags, uint64_t* __restrict__ bm,
                                                  const uint64_t* __restrict__ hm, int W, uint32_t* __restrict__ rank1,
                                                  int64_t* __restrict__ ids1, int32_t* __restrict__ count1, int64_t cap,
                                                  uint32_t* __restrict__ rank2, int64_t* __restrict__ ids2,
                                                  int32_t* __restrict__ pos2, int32_t* __restrict__ count2) {
-  __shared__ uint32_t s_w[2][CB / TG_WAVE];
-  __shared__ uint64_t s_a[CB], s_b[CB];
-  __shared__ uint32_t s_r1[CB], s_r2[CB];
-  const int w = threadIdx.x;
+  constexpr int NWV = SB / TG_WAVE;
+  __shared__ uint32_t s_w1[NWV], s_w2[NWV];
+  __shared__ uint64_t s_a[SB], s_b[SB];
+  __shared__ uint32_t s_r1[SB], s_r2[SB];
+  const int w = threadIdx.x, lane = lane_id(), wv = threadIdx.x >> 6;
   uint64_t a = 0, b = 0;
   if (w < W) {
     if (flags) {
@@ -125,9 +127,34 @@ __global__ void __launch_bounds__(CB) k_bm_small(const uint8_t* __restrict__ fla
     }
     if (hm) b = a & hm[w];
   }
-  uint32_t t1, t2;
-  const uint32_t r1 = block_excl_scan((uint32_t)__popcll(a), s_w[0], &t1);
-  const uint32_t r2 = block_excl_scan((uint32_t)__popcll(b), s_w[1], &t2);
+  // block-wide exclusive scan of both popcounts: wave scan, then the 16 wave totals
+  uint32_t i1 = (uint32_t)__popcll(a), i2 = (uint32_t)__popcll(b);
+  const uint32_t c1 = i1, c2 = i2;
+#pragma unroll
+  for (int o = 1; o < TG_WAVE; o <<= 1) {
+    const uint32_t t1 = __shfl_up(i1, o, TG_WAVE), t2 = __shfl_up(i2, o, TG_WAVE);
+    if (lane >= o) {
+      i1 += t1;
+      i2 += t2;
+    }
+  }
+  if (lane == TG_WAVE - 1) {
+    s_w1[wv] = i1;
+    s_w2[wv] = i2;
+  }
+  __syncthreads();
+  uint32_t base1 = 0, base2 = 0, t1 = 0, t2 = 0;
+#pragma unroll
+  for (int i = 0; i < NWV; ++i) {
+    const uint32_t x1 = s_w1[i], x2 = s_w2[i];
+    if (i < wv) {
+      base1 += x1;
+      base2 += x2;
+    }
+    t1 += x1;
+    t2 += x2;
+  }
+  const uint32_t r1 = base1 + i1 - c1, r2 = base2 + i2 - c2;
   s_a[w] = a;
   s_b[w] = b;
   s_r1[w] = r1;
@@ -143,9 +170,8 @@ __global__ void __launch_bounds__(CB) k_bm_small(const uint8_t* __restrict__ fla
     if (count2) *count2 = (int32_t)t2;
   }
   __syncthreads();
-  const int lane = lane_id();
   const uint64_t below = (1ull << lane) - 1ull;
-  for (int ww = threadIdx.x >> 6; ww < W; ww += CB / TG_WAVE) {
+  for (int ww = wv; ww < W; ww += NWV) {  // one wavefront per word, one lane per bit
     const uint64_t wa = s_a[ww], wb = s_b[ww];
     const uint32_t mine = s_r1[ww] + (uint32_t)__popcll(wa & below);
     if (((wa >> lane) & 1ull) && ids1 && (int64_t)mine < cap) ids1[mine] = (int64_t)ww * 64 + lane;
@@ -263,8 +289,8 @@ int unique_compact_launch(const uint8_t* flags, uint64_t* bm, int64_t n_nodes, u
   int32_t* spare = (int32_t*)((char*)ws + 2 * align16((size_t)nblk * sizeof(uint32_t)));
   if (!count) count = spare;       // the emit kernel needs the totals for the sentinel
   if (!count2) count2 = spare + 1;
-  if (nblk == 1) {
-    hipLaunchKernelGGL(k_bm_small, dim3(1), dim3(CB), 0, st, flags, bm, hm, (int)W, rank, ids, count, cap, rank2, ids2,
+  if (W <= SB) {
+    hipLaunchKernelGGL(k_bm_small, dim3(1), dim3(SB), 0, st, flags, bm, hm, (int)W, rank, ids, count, cap, rank2, ids2,
                        pos2, count2);
     return check_launch("tg_unique_compact");
   }
