@@ -334,6 +334,11 @@ typedef struct tg_step_io {
   int32_t embed_only;
   void* profiler;       /* tg_profiler* or NULL: records an event after every stage */
   float* h_new;         /* [2B, d] or NULL: h(t'+) of cat[src,dst] (the rows STEP 4 would write) */
+  /* ws_is_clean != 0: the caller guarantees that the first tg_stream_step_zero_bytes() bytes of
+   * the workspace are zero (freshly zero-filled, or left by a previous completed full step, which
+   * always cleans up after itself); the step then skips its initial memset launch. */
+  int32_t ws_is_clean;
+  int32_t reserved;
 } tg_step_io;
 
 /* Per-stage timer of tg_stream_step (HIP events on the step's stream).  Stage names:
@@ -348,6 +353,8 @@ const char* tg_profiler_stage_name(int stage);
 int tg_profiler_read(tg_profiler* p, float* ms_out);
 
 size_t tg_stream_step_workspace_bytes(const tg_model* m, int64_t B);
+/* size of the leading workspace region that must be zero when a step starts */
+size_t tg_stream_step_zero_bytes(const tg_model* m, int64_t B);
 int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, void* ws, size_t ws_bytes,
                    void* stream);
 

@@ -68,6 +68,7 @@ class TgStepIo(C.Structure):
         ('h', vp), ('l1_nids', vp), ('l1_eids', vp), ('l1_ts', vp), ('involved', vp), ('counts', vp),
         ('h_prev_left', vp), ('h_prev_right', vp), ('err', vp),
         ('offset_dev', vp), ('advance', i32), ('embed_only', i32), ('profiler', vp), ('h_new', vp),
+        ('ws_is_clean', i32), ('reserved', i32),
     ]
 
 
@@ -120,6 +121,7 @@ SIGNATURES = {
     'tg_profiler_stage_name': (C.c_char_p, [C.c_int]),
     'tg_profiler_read': (C.c_int, [vp, vp]),
     'tg_stream_step_workspace_bytes': (sz, [P(TgModel), i64]),
+    'tg_stream_step_zero_bytes': (sz, [P(TgModel), i64]),
     'tg_stream_step': (C.c_int, [P(TgModel), P(TgTcsr), P(TgStepIo), vp, sz, vp]),
     'tg_stream_writeback_workspace_bytes': (sz, [P(TgModel), i64]),
     'tg_stream_writeback': (C.c_int, [P(TgModel), P(TgWritebackIo), vp, sz, vp]),

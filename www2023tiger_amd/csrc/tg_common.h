@@ -143,6 +143,12 @@ struct WritebackArgs {
   const float* rows;
   const int64_t *new_row, *left_row;
   const int64_t* plan_off;
+  // self-cleaning of the step workspace by the last kernel (nullable): flags[0, flag_bytes) = 0,
+  // best[0, counts[0]) = 0, counts[0..3] = 0 (after the copy to counts_dst)
+  uint8_t* clean_flags;
+  int64_t flag_bytes;
+  unsigned long long* clean_best;
+  int32_t* clean_counts;
 };
 int writeback_launch(const tg_model* m, const WritebackArgs& a, int phase, hipStream_t st);
 

@@ -279,10 +279,20 @@ __global__ void __launch_bounds__(256) k_writeback(tg_model m, WritebackArgs a) 
         wb_step6(m, id, idx, idx, reinterpret_cast<const float4*>(a.h), a.ts, a.err, lane);
     }
   }
-  if (PHASE == 1 && blockIdx.x == 0 && threadIdx.x == 0) {
-    if (a.counts_dst)
-      for (int i = 0; i < 4; ++i) a.counts_dst[i] = a.counts_src[i];
-    if (a.offset_dev) *a.offset_dev += B;
+  if (PHASE == 1) {
+    if (a.clean_flags) {  // leave the step workspace zeroed for the next step (saves its memset launch)
+      const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+      uint4* f = reinterpret_cast<uint4*>(a.clean_flags);
+      for (int64_t i = tid; i < a.flag_bytes / 16; i += nth) f[i] = make_uint4(0u, 0u, 0u, 0u);
+      const int64_t nb = a.clean_counts[0];  // involved count: only ranks below it were touched
+      for (int64_t i = tid; i < nb; i += nth) a.clean_best[i] = 0ull;
+    }
+    // counts need no reset: the compaction overwrites [0] and [1], k_pos_max zeroes [2]
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      if (a.counts_dst)
+        for (int i = 0; i < 4; ++i) a.counts_dst[i] = a.counts_src[i];
+      if (a.offset_dev) *a.offset_dev += B;
+    }
   }
 }
 

@@ -418,7 +418,9 @@ int apply_messages(const tg_model* m, const int64_t* outdated, const int32_t* ou
 // first position among ties.  best[rank(node)] = max over positions of (ts_key << 32 | ~pos).
 __global__ void k_pos_max(int64_t B, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
                           const float* __restrict__ ts, const uint64_t* __restrict__ bm,
-                          const uint32_t* __restrict__ rank, unsigned long long* __restrict__ best) {
+                          const uint32_t* __restrict__ rank, unsigned long long* __restrict__ best,
+                          int32_t* __restrict__ winner_count) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *winner_count = 0;  // k_pos_winners (next launch) counts into it
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * B; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t e = i < B ? i : i - B;
     const int64_t node = i < B ? src[e] : dst[e];
@@ -648,6 +650,12 @@ extern "C" size_t tg_stream_step_workspace_bytes(const tg_model* m, int64_t B) {
   return b + 256;
 }
 
+extern "C" size_t tg_stream_step_zero_bytes(const tg_model* m, int64_t B) {
+  if (!attn_dims_ok(m) || B <= 0 || m->n_nodes <= 0) return 0;
+  const size_t cap = 3 * (size_t)B * (m->n_neighbors + 1), W = (m->n_nodes + 63) / 64;
+  return align16(W * 64) + align16(cap * 8) + 16;
+}
+
 extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, void* ws, size_t ws_bytes,
                               void* stream) {
   if (!attn_dims_ok(m) || !g || !io || io->B <= 0) return TG_EINVAL;
@@ -660,7 +668,8 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
   StepWs w{};
   if (!carve_step(m, B, cv, w)) return TG_EWORKSPACE;
   prof_mark(pf, ST_QUERIES, st);
-  hipError_t e = hipMemsetAsync(w.flags, 0, w.zero_bytes, st);
+  hipError_t e = hipSuccess;
+  if (!io->ws_is_clean || io->embed_only) e = hipMemsetAsync(w.flags, 0, w.zero_bytes, st);
   if (e != hipSuccess) {
     set_hip_error(e, "tg_stream_step memset");
     return TG_EHIP;
@@ -713,7 +722,8 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
     return check_launch("tg_stream_step(embed_only)");
   }
   // ---- dedup of positive nodes (select_latest_nids on float32 ts, tiger.py:232,419; memory.py:98)
-  hipLaunchKernelGGL(k_pos_max, dim3(flat_grid(2 * B, 256)), dim3(256), 0, st, B, src, dst, w.ts3f, w.bm, w.rank, w.best);
+  hipLaunchKernelGGL(k_pos_max, dim3(flat_grid(2 * B, 256)), dim3(256), 0, st, B, src, dst, w.ts3f, w.bm, w.rank, w.best,
+                     w.counts + 2);
   hipLaunchKernelGGL(k_pos_winners, dim3(flat_grid(2 * B, 256)), dim3(256), 0, st, B, src, dst, w.ts3f, w.bm, w.rank,
                      w.best, w.upos, w.index, w.counts + 2);
   // ---- STEP 4-6 (tiger.py:229-255) in two launches; STEP 5 shares a launch with whichever of
@@ -723,6 +733,8 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
   wa.n_upos = w.counts + 2; wa.reprs = w.reprs; wa.bm = w.bm; wa.rank = w.rank; wa.h = io->h; wa.err = io->err;
   wa.counts_src = io->counts ? w.counts : nullptr; wa.counts_dst = io->counts;
   wa.offset_dev = (io->offset_dev && io->advance) ? io->offset_dev : nullptr;
+  wa.clean_flags = w.flags; wa.flag_bytes = (int64_t)((m->n_nodes + 63) / 64) * 64; wa.clean_best = w.best;
+  wa.clean_counts = w.counts;
   prof_mark(pf, ST_WRITE_RIGHT, st);
   if ((rc = writeback_launch(m, wa, 0, st)) != TG_OK) return rc;
   prof_mark(pf, ST_STORE_EVENTS, st);
@@ -826,7 +838,8 @@ extern "C" int tg_stream_writeback(const tg_model* m, const tg_writeback_io* io,
     return rc;
   const int64_t* src = w.pos;
   const int64_t* dst = w.pos + Bg;
-  hipLaunchKernelGGL(k_pos_max, dim3(flat_grid(2 * Bg, 256)), dim3(256), 0, st, Bg, src, dst, w.ts2f, w.bm, w.rank, w.best);
+  hipLaunchKernelGGL(k_pos_max, dim3(flat_grid(2 * Bg, 256)), dim3(256), 0, st, Bg, src, dst, w.ts2f, w.bm, w.rank, w.best,
+                     w.counts + 2);
   hipLaunchKernelGGL(k_pos_winners, dim3(flat_grid(2 * Bg, 256)), dim3(256), 0, st, Bg, src, dst, w.ts2f, w.bm, w.rank,
                      w.best, w.upos, w.index, w.counts + 2);
   WritebackArgs wa{};

@@ -285,12 +285,12 @@ class TIGE(nn.Module):
             nbytes = int(lib.tg_stream_step_workspace_bytes(C.byref(m), B))
             if nbytes == 0:
                 raise RuntimeError('tg_stream_step: unsupported model dimensions')
-            self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)  # zero-filled: the step keeps it clean
             self.io = TgStepIo(B, ptr(self.src), ptr(self.dst), ptr(self.neg), ptr(self.ts), ptr(self.eids),
                                ptr(self.h), ptr(self.l1_nids), ptr(self.l1_eids), ptr(self.l1_ts), ptr(self.involved),
                                ptr(self.counts), ptr(self.h_prev_left), ptr(self.h_prev_right), ptr(self.err),
                                ptr(self.offset), 1 if resident is not None else 0, 1 if embed_only else 0, None,
-                               ptr(self.h_new))
+                               ptr(self.h_new), 0 if embed_only else 1, 0)
 
         def attach_profiler(self, prof):
             self.io.profiler = prof
