@@ -286,6 +286,13 @@ def bench_main(args, cfg, make_stream, build_models, rank, local_rank, world):
     """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: weak scaling,
     global batch = N * B events per step; value = events of all ranks / max-over-ranks time."""
     assert world == args.gpus, f'launch with torchrun: WORLD_SIZE={world} but --gpus {args.gpus}'
+    # RCCL prints a version banner on fd 1 when the communicator is created; the contract is ONE JSON
+    # line on stdout, so fd 1 is pointed at stderr until the result is ready
+    import os
+    import sys
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     tdist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
@@ -304,7 +311,6 @@ def bench_main(args, cfg, make_stream, build_models, rank, local_rank, world):
         p = ShardPlan(stream['dst'][sl], owner, world, B, balance=True)
         spilled += float((p.rank_of != owner[stream['dst'][sl]]).mean())
     spilled /= min(n_steps, 50)
-    import os
     debug = bool(os.environ.get('TG_DIST_DEBUG'))
     n_eager = min(2, args.warmup)
     for _ in range(n_eager):
@@ -340,5 +346,8 @@ def bench_main(args, cfg, make_stream, build_models, rank, local_rank, world):
                                spilled_event_fraction=round(spilled, 4),
                                launch='2 hipGraphs + 1 all-gather per step' if use_graphs else 'eager launches + 1 all-gather per step'),
                    roofline=None, cpu_baseline=None)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     tdist.destroy_process_group()
