@@ -395,3 +395,53 @@ def test_sampler_properties_at_scale():
                 s, dd = src_of[int(e10[i, k])]
                 assert {int(q[i]), int(n10[i, k])} == {s, dd}
                 assert d10[i, k] == (1 if int(q[i]) == dd else 0)
+
+
+def test_ragged_and_degenerate_batches_match_oracle():
+    """Batch sizes 1, 7 and a ragged tail; a batch whose events all share one timestamp (every
+    dedup decision is a tie); the same node as src of many events (collisions)."""
+    import bench
+    from oracle import tiger_oracle as O
+    rs = np.random.RandomState(5)
+    st = bench.make_stream(40, 12, 700, 90.0, seed=5, d_e=16)
+    st['ts'][300:364] = st['ts'][300]            # 64 simultaneous events
+    st['ts'] = np.sort(st['ts'])
+    st['src'][400:440] = st['src'][400]          # one hot source node
+    model, orc = bench.build_models(st, 16, 5, 'right', 'left', with_oracle=True)
+    edges = [0, 1, 8, 72, 300, 364, 400, 440, 571, 700]   # sizes 1, 7, 64, 228, 64, 36, 40, 131, 129
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        a = [st[k][lo:hi] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        buf = model.stream_step(*a)
+        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], 5, 'static')
+        ref = orc.stream_step(*a, cg).numpy()
+        n = hi - lo
+        np.testing.assert_array_equal(buf.l1_nids.cpu().numpy()[:3 * n], cg['l1_nids'])
+        assert rel_err(buf.h[:2 * n].cpu().numpy(), ref) < TOL, (lo, hi)
+    has = np.array(sorted(model.msg_store.nodes_with_messages), dtype=np.int64)
+    np.testing.assert_array_equal(has, np.nonzero(orc.has_msg)[0])
+    assert rel_err(model.left_memory.vals.cpu().numpy(), orc.left_vals.numpy()) < TOL
+    assert rel_err(model.right_memory.vals.cpu().numpy(), orc.right_vals.numpy()) < TOL
+    np.testing.assert_array_equal(model.right_memory.update_ts.cpu().numpy(), orc.right_ts.numpy())
+    assert rel_err(model.msg_store.node_msg_vals.cpu().numpy()[has], orc.msg_vals.numpy()[has]) < TOL
+
+
+def test_reset_and_memory_snapshots():
+    """reset(), save_memory_state / load_memory_state (tiger.py:457-484) rewind the stream exactly."""
+    z = load('static_ll_d16')
+    cfg = parse_cfg(z)
+    model, _, coll = build_hip_model(z, cfg)
+    B = cfg['B']
+    def run(b):
+        sl = slice(b * B, (b + 1) * B)
+        return model.stream_step(*(z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids'))).h.clone()
+    run(0); run(1)
+    snap = model.save_memory_state()
+    h2 = run(2)
+    run(3)
+    model.load_memory_state(snap)
+    h2b = run(2)
+    assert torch.equal(h2, h2b)
+    model.reset()
+    assert float(model.left_memory.vals.abs().sum()) == 0 and not model.msg_store.nodes_with_messages
+    h0 = run(0)
+    assert rel_err(h0[:2 * B].cpu().numpy(), z['b0_h_left']) < TOL
