@@ -271,8 +271,8 @@ class OracleTIGER:
                 raise ValueError('You are not allowed to modify past memory.')
             if len(ids) != len(torch.unique(ids)):
                 raise ValueError('Duplicate node ids are not allowed.')
-        tss[ids] = new_ts
-        vals[ids] = new_vals
+        tss[ids] = new_ts.detach() if isinstance(new_ts, torch.Tensor) else new_ts
+        vals[ids] = new_vals.detach()
 
     # ---- features (feature_getter.py:80-106) ----------------------------------
     def node_feat(self, ids):
@@ -368,7 +368,7 @@ class OracleTIGER:
         dm = torch.cat([dv, sv, ev, self.te(ts - dpt)], 1)
         ts2 = ts.repeat(2)
         ids, idx = select_latest_nids(pos, ts2.numpy())
-        self.msg_vals[_t(ids)] = torch.cat([sm, dm], 0)[_t(idx)]
+        self.msg_vals[_t(ids)] = torch.cat([sm, dm], 0)[_t(idx)].detach()  # tiger.py:422 @torch.no_grad
         self.msg_ts[_t(ids)] = ts2[_t(idx)]
         self.has_msg[ids] = True
 
@@ -419,6 +419,55 @@ class OracleTIGER:
         loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, labels)
         return dict(loss=loss, h_left=h_left, pos_scores=ps, neg_scores=ns,
                     h_prev_left=h_prev_left, h_prev_right=h_prev_right)
+
+    # ---- training tail (tiger.py:547-592, train_self_supervised.py:143-171) ----
+    def train_losses(self, src, dst, neg, ts, eids, cg, contrast_only=False):
+        """contrast_and_mutual_learning with the parameters as autograd leaves.
+        Returns (contrast_loss, mutual_loss) as differentiable torch scalars."""
+        for v in self.p.values():
+            v.requires_grad_(True)
+            v.grad = None
+        with torch.enable_grad():
+            r = self.contrast_learning(src, dst, neg, ts, eids, cg)
+            c_loss = r['loss']
+            if contrast_only:  # tiger.py:570-572
+                return c_loss, torch.zeros(())
+            index = _t(cg['rd_index'])
+            pos = np.concatenate([np.asarray(src, dtype=np.int64), np.asarray(dst, dtype=np.int64)])
+            u_nids = pos[cg['rd_index']]
+            u_ts = _t(np.asarray(ts)).float().repeat(2)[index]
+            sl, sr, _ = self.restarter_forward(u_nids, u_ts.numpy(), cg)
+            targets = torch.cat([r['h_prev_left'][index], r['h_prev_right'][index]], 0).detach()
+            preds = torch.cat([sl, sr], 0)
+            valid = torch.where(~(targets == 0).all(1))[0]
+            m_loss = torch.nn.functional.mse_loss(preds[valid], targets[valid]) if len(valid) else torch.zeros(())
+        return c_loss, m_loss
+
+    def train_step(self, src, dst, neg, ts, eids, cg, *, lr, mutual_coef=1.0, contrast_only=False,
+                   betas=(0.9, 0.999), eps=1e-8):
+        """One optimisation step: losses, backward, torch.optim.Adam update (defaults, no weight
+        decay).  Returns (contrast_loss, mutual_loss, grads)."""
+        c_loss, m_loss = self.train_losses(src, dst, neg, ts, eids, cg, contrast_only)
+        (c_loss + mutual_coef * m_loss).backward()
+        grads = {k: (torch.zeros_like(v) if v.grad is None else v.grad.clone()) for k, v in self.p.items()}
+        if not hasattr(self, 'adam'):
+            self.adam = {k: [torch.zeros_like(v), torch.zeros_like(v), 0] for k, v in self.p.items()}
+        with torch.no_grad():
+            for k, v in self.p.items():
+                if v.grad is None:  # Adam skips parameters without a gradient (their step count too)
+                    continue
+                g = v.grad
+                self.adam[k][2] += 1
+                m1, m2, t = self.adam[k]
+                m1.mul_(betas[0]).add_(g, alpha=1 - betas[0])
+                m2.mul_(betas[1]).addcmul_(g, g, value=1 - betas[1])
+                bc1, bc2 = 1 - betas[0] ** t, 1 - betas[1] ** t
+                denom = (m2.sqrt() / np.sqrt(bc2)).add_(eps)
+                v.addcdiv_(m1, denom, value=-lr / bc1)
+        for v in self.p.values():
+            v.requires_grad_(False)
+            v.grad = None
+        return float(c_loss.detach()), float(m_loss.detach()), grads
 
     # ---- streaming step: STEP 1-6 only, the benchmarked path -----------------
     def stream_step(self, src, dst, neg, ts, eids, cg):

@@ -138,7 +138,7 @@ def gen_sampler():
 
 
 # --------------------------------------------------------------------------- model
-def build_reference_model(cfg, nfeats, efeats, graph, n_edges):
+def build_reference_model(cfg, nfeats, efeats, graph, n_edges, dropout=0.1):
     d = cfg['d']
     fg = NumericalFeature(None if nfeats is None else torch.from_numpy(nfeats).float(),
                           None if efeats is None else torch.from_numpy(efeats).float(),
@@ -146,11 +146,11 @@ def build_reference_model(cfg, nfeats, efeats, graph, n_edges):
     fg.n_nodes = graph.num_node
     fg.n_edges = n_edges
     if cfg['restarter'] == 'seq':
-        rst = SeqRestarter(raw_feat_getter=fg, graph=graph, hist_len=cfg['H'], n_head=2, dropout=0.1)
+        rst = SeqRestarter(raw_feat_getter=fg, graph=graph, hist_len=cfg['H'], n_head=2, dropout=dropout)
     else:
         rst = StaticRestarter(raw_feat_getter=fg, graph=graph)
     model = TIGER(raw_feat_getter=fg, graph=graph, restarter=rst, n_neighbors=cfg['K'],
-                  hit_type=cfg.get('hit', 'bin'), n_layers=1, n_head=2, dropout=0.1,
+                  hit_type=cfg.get('hit', 'bin'), n_layers=1, n_head=2, dropout=dropout,
                   msg_src=cfg['msg_src'], upd_src=cfg['upd_src'],
                   msg_tsfm_type=cfg.get('tsfm', 'id'), mem_update_type=cfg.get('upd_fn', 'gru'),
                   tgn_mode=True, msg_last_only=True)
@@ -287,6 +287,84 @@ def gen_model(name, cfg):
     print(f'{name}.npz', sum(v.nbytes for v in out.values()) // 1024, 'KiB raw')
 
 
+def gen_train(name, cfg):
+    """The training loop of train_self_supervised.py:143-171 (dropout 0, Adam) for a few batches:
+    per-batch losses, the gradients of every parameter at selected batches, final parameters
+    and memories."""
+    d = cfg['d']
+    src, dst, ts, eids = make_stream(cfg['seed'], cfg['n_u'], cfg['n_i'], cfg['E'], cfg['T'],
+                                     integer_ts=cfg.get('integer_ts', True))
+    E = len(src)
+    n_nodes = int(max(src.max(), dst.max())) + 1
+    rs = np.random.RandomState(cfg['seed'] + 100)
+    nfeats = rs.standard_normal((n_nodes, d)).astype(np.float32) * 0.5
+    nfeats[0] = 0
+    efeats = rs.standard_normal((E + 1, cfg.get('d_e', d))).astype(np.float32)
+    efeats[0] = 0
+    labels = np.zeros(E, dtype=np.int64)
+    neg = rs.randint(cfg['n_u'] + 1, n_nodes, E).astype(np.int64)
+    data = InteractionData(src, dst, ts, eids, labels, seed=0, eval=True, neg_dst=neg)
+    graph = Graph.from_data(data, strategy='recent_edges', seed=0)
+    model, pnames, pshapes = build_reference_model(cfg, nfeats, efeats, graph, E, dropout=0.0)
+    collator = GraphCollator(graph, cfg['K'], 1, restarter=cfg['restarter'], hist_len=cfg.get('H'))
+    out = {'versions': VERSIONS, 'src': src, 'dst': dst, 'ts': ts, 'eids': eids, 'neg': neg,
+           'n_nodes': np.int64(n_nodes), 'param_names': np.array(pnames),
+           'param_shapes': np.array([','.join(map(str, s)) for s in pshapes]),
+           'cfg': np.array([f'{k}={v}' for k, v in sorted(cfg.items())]),
+           'nfeats': nfeats, 'efeats': efeats}
+    B, n_batches = cfg['B'], cfg['n_batches']
+    contrast_only = bool(cfg.get('contrast_only', 0))
+    coef = float(cfg['mutual_coef'])
+    optimizer = torch.optim.Adam(model.parameters(), lr=cfg['lr'])
+    model.train()
+    model.reset()
+    restarting, uptodate = False, set()
+    for b in range(n_batches):
+        lo, hi = b * B, min((b + 1) * B, E)
+        s, dd, ng, t, ee, _, cg = collator([data[i] for i in range(lo, hi)])
+        s, dd, ng, ee, t = s.long(), dd.long(), ng.long(), ee.long(), t.float()
+        optimizer.zero_grad()
+        if b == cfg.get('restart_at', -1):
+            restarting, uptodate = True, set()
+            model.msg_store.clear()
+        if restarting:
+            involved = cg.np_computation_graph_nodes
+            r_nodes = np.array(sorted(set(involved.tolist()) - uptodate), dtype=np.int64)
+            r_nids = torch.from_numpy(r_nodes).long()
+            model.restart(r_nids, torch.full((len(r_nids),), t.min().item()))
+            uptodate.update(r_nodes.tolist())
+        c_loss, m_loss = model.contrast_and_mutual_learning(s, dd, ng, t, ee, cg, contrast_only=contrast_only)
+        loss = c_loss + coef * m_loss
+        loss.backward()
+        out[f'b{b}_contrast_loss'] = np.float32(c_loss.item())
+        out[f'b{b}_mutual_loss'] = np.float32(m_loss.item())
+        if b in cfg['grad_batches']:
+            for nm, p_ in model.named_parameters():
+                out[f'b{b}_grad.{nm}'] = (torch.zeros_like(p_) if p_.grad is None else p_.grad).numpy().copy()
+        optimizer.step()
+    for nm, p_ in model.named_parameters():
+        out[f'final.{nm}'] = p_.detach().numpy().copy()
+    with torch.no_grad():
+        snapshot(model, out, 'final')
+    np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
+    print(f'{name}.npz', sum(v.nbytes for v in out.values()) // 1024, 'KiB raw')
+
+
+TRAIN_SCENARIOS = {
+    # CLI defaults: seq restarter, msg=left upd=right, 'bin' hits, mutual learning with a lazy restart
+    'train_seq_lr_d8': dict(d=8, n_u=40, n_i=15, E=480, T=300.0, B=40, n_batches=10, K=5, H=8, seed=21, wseed=21,
+                            restarter='seq', msg_src='left', upd_src='right', hit='bin', restart_at=6,
+                            lr=1e-2, mutual_coef=1.0, grad_batches=(0, 1, 4, 7)),
+    # C2-shaped: msg=left upd=left, static restarter, 'vec' hits, wider edge features
+    'train_static_ll_d16': dict(d=16, d_e=12, n_u=60, n_i=25, E=640, T=500.0, B=64, n_batches=8, K=10, seed=22,
+                                wseed=22, restarter='static', msg_src='left', upd_src='left', hit='vec',
+                                restart_at=5, lr=1e-2, mutual_coef=0.5, grad_batches=(1, 3, 6)),
+    # restart_prob == 0: contrast loss only (tiger.py:570-572), TGN-style right/right
+    'train_contrast_rr_d8': dict(d=8, n_u=30, n_i=30, E=400, T=500.0, B=50, n_batches=6, K=10, H=6, seed=23,
+                                 wseed=23, integer_ts=False, restarter='seq', msg_src='right', upd_src='right',
+                                 hit='none', contrast_only=1, lr=1e-2, mutual_coef=1.0, grad_batches=(1, 4)),
+}
+
 SCENARIOS = {
     # C1-like plumbing case: seq restarter, msg=left upd=right (CLI defaults)
     'seq_lr_d8': dict(d=8, n_u=40, n_i=15, E=600, T=300.0, B=40, n_batches=12, K=5, H=8, seed=1, wseed=1,
@@ -319,3 +397,6 @@ if __name__ == '__main__':
     for nm, cfg in SCENARIOS.items():
         if not only or nm in only:
             gen_model(nm, cfg)
+    for nm, cfg in TRAIN_SCENARIOS.items():
+        if not only or nm in only:
+            gen_train(nm, cfg)

@@ -140,3 +140,48 @@ def test_stream_matches_reference(name):
             check_state(m, z, tag)
     m.flush_msg()
     check_state(m, z, 'flushed')
+
+
+# --------------------------------------------------------------------------- training tail
+TRAIN_FIXTURES = ['train_seq_lr_d8', 'train_static_ll_d16', 'train_contrast_rr_d8']
+
+
+def grad_err(a, b):
+    """max |a-b| relative to the largest entry of the reference gradient (floor 1e-3)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(1e-3, np.abs(b).max()))
+
+
+def oracle_train_batch(m, z, cfg, b, state):
+    """One iteration of train_self_supervised.py:143-171 on the oracle."""
+    B = cfg['B']
+    lo, hi = b * B, min((b + 1) * B, len(z['src']))
+    a = [z[k][lo:hi] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+    cg = O.collate(m.graph, a[0], a[1], a[2], a[3], cfg['K'], cfg['restarter'], hist_len=cfg.get('H'))
+    if b == cfg.get('restart_at', -1):
+        state['restarting'], state['uptodate'] = True, set()
+        m.clear_msgs()
+    if state.get('restarting'):
+        r_nodes = np.array(sorted(set(cg['involved'].tolist()) - state['uptodate']), dtype=np.int64)
+        m.restart(r_nodes, np.full(len(r_nodes), np.float32(a[3]).min(), dtype=np.float32))
+        state['uptodate'].update(r_nodes.tolist())
+    return m.train_step(*a, cg, lr=cfg['lr'], mutual_coef=cfg['mutual_coef'],
+                        contrast_only=bool(cfg.get('contrast_only', 0)))
+
+
+@pytest.mark.parametrize('name', TRAIN_FIXTURES)
+def test_training_matches_reference(name):
+    z = load(name)
+    cfg = parse_cfg(z)
+    m = build_oracle(z, cfg)
+    state = {}
+    for b in range(cfg['n_batches']):
+        c, ml, grads = oracle_train_batch(m, z, cfg, b, state)
+        assert abs(c - float(z[f'b{b}_contrast_loss'])) < 2e-5 * max(1.0, abs(c)), b
+        assert abs(ml - float(z[f'b{b}_mutual_loss'])) < 2e-5 * max(1.0, abs(ml)), b
+        if b in cfg['grad_batches']:
+            for k, g in grads.items():
+                assert grad_err(g.numpy(), z[f'b{b}_grad.{k}']) < 1e-4, (b, k)
+    for k, v in m.p.items():
+        assert rel_err(v.detach().numpy(), z[f"final.{k}"]) < 1e-3, k  # Adam amplifies ulp-level gradient noise
+    check_state(m, z, 'final')
