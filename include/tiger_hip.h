@@ -359,6 +359,71 @@ int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, vo
                    void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* Training tail: STEP 7, backward pass, Adam            */
+/* tiger.py:257-288 (scores + BCE), tiger.py:547-592 (mutual loss),            */
+/* train_self_supervised.py:165-171 (loss.backward(); optimizer.step())        */
+/* ------------------------------------------------------------------------- */
+#define TG_HIT_NONE 0
+#define TG_HIT_VEC 1
+#define TG_HIT_BIN 2
+#define TG_HIT_COUNT 3
+
+/* score head of TIGE (tiger.py:135-149): optional hit embedding + MergeLayer(W, W, d, 1),
+ * W = d (+ n_neighbors for 'vec') */
+typedef struct tg_score_params {
+  int32_t hit_type;   /* TG_HIT_* */
+  int32_t n_hit_rows; /* rows of hit_emb: 2 ('bin'), n_neighbors + 1 ('count'), else 0 */
+  const float* hit_emb; /* [n_hit_rows, d] or NULL */
+  tg_linear fc1;      /* [d, 2W] */
+  tg_linear fc2;      /* [1, d]  */
+} tg_score_params;
+
+/* One training iteration's device work: the fused step (as tg_stream_step) with STEP 7 and the
+ * backward pass of the contrastive loss inserted between STEP 3 and the write-back.
+ * Gradients are ACCUMULATED (+=) into buffers laid out like the parameters: `grads` is a
+ * tg_model whose parameter pointers (te_*, gru_*, attn_*) point at gradient buffers (other
+ * fields ignored), `score_grads` likewise for the score head.  Supported: message transform
+ * 'id', updater 'gru', one attention layer, dropout 0.
+ * flags (device int32[4]) says which parameter groups received a gradient this step (torch leaves
+ * the .grad of the others None and Adam skips them): [0] = 1 always (embedding, score head, time
+ * encoder), [1] = the GRU ran (some involved node had a pending message), [2] = the mutual loss
+ * had at least one valid target row (restarter parameters), [3] reserved. */
+typedef struct tg_train_io {
+  tg_step_io step;
+  const tg_score_params* score;
+  const tg_model* grads;
+  const tg_score_params* score_grads;
+  float* losses;     /* [2] device: contrast loss (mean BCE over 2B logits), mutual loss */
+  float* pos_scores; /* [B] logits or NULL */
+  float* neg_scores; /* [B] or NULL */
+  int32_t* flags;    /* [4] device, see above (NULL allowed) */
+  int32_t reserved[2];
+} tg_train_io;
+
+size_t tg_train_step_workspace_bytes(const tg_model* m, const tg_score_params* sp, int64_t B);
+int tg_train_step(const tg_model* m, const tg_tcsr* g, const tg_train_io* io, void* ws, size_t ws_bytes,
+                  void* stream);
+
+/* torch.optim.Adam (defaults: no weight decay, no amsgrad) over a device-resident table of
+ * parameter segments.  Segment i belongs to group `group`; a group whose enabled flag
+ * (device int32, NULL = always on) is 0 is skipped entirely, including its step count
+ * (steps[group], device int32, incremented here), exactly as Adam skips parameters whose
+ * .grad is None.  g is read scaled by `grad_scale`. */
+typedef struct tg_adam_seg {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+  int32_t group;
+  int32_t reserved;
+} tg_adam_seg;
+
+int tg_adam_step(const tg_adam_seg* segs_dev, int32_t n_segs, int32_t n_groups, const int32_t* enabled_dev,
+                 int32_t* steps_dev, float lr, float beta1, float beta2, float eps, float grad_scale,
+                 void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Multi-GPU: replicated write-back of a GLOBAL batch from all-gathered rows  */
 /* (www2023tiger_amd/dist.py; STEP 4-6 of tiger.py:229-255 for every event of */
 /* the global batch, the embeddings having been computed on other ranks)      */

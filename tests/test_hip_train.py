@@ -1,0 +1,92 @@
+"""GPU parity of the training tail (tg_train_step, tg_adam_step) against the oracle's autograd
+gradients on the reference-generated training fixtures (tests/golden/train_*.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from _util import load, parse_cfg, rel_err
+from test_hip_parity import build_hip_model, dev
+from test_oracle_golden import build_oracle, grad_err, TRAIN_FIXTURES
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def batch(z, cfg, b):
+    B = cfg['B']
+    lo, hi = b * B, min((b + 1) * B, len(z['src']))
+    return [z[k][lo:hi] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+
+
+def sync_params(model, orc):
+    own = dict(model.named_parameters())
+    with torch.no_grad():
+        for k, v in orc.p.items():
+            own[k].copy_(v.detach())
+
+
+def lazy_restart(model, orc, cfg, b, a, cg, state):
+    """train_self_supervised.py:152-163 on both sides"""
+    if b == cfg.get('restart_at', -1):
+        state['restarting'], state['uptodate'] = True, set()
+        orc.clear_msgs()
+        model.msg_store.clear()
+    if state.get('restarting'):
+        r_nodes = np.array(sorted(set(cg['involved'].tolist()) - state['uptodate']), dtype=np.int64)
+        r_ts = np.full(len(r_nodes), np.float32(a[3]).min(), dtype=np.float32)
+        orc.restart(r_nodes, r_ts)
+        model.restart(torch.from_numpy(r_nodes), torch.from_numpy(r_ts))
+        state['uptodate'].update(r_nodes.tolist())
+
+
+@pytest.mark.parametrize('name', TRAIN_FIXTURES)
+def test_contrast_gradients_match_oracle(name):
+    from oracle import tiger_oracle as O
+    from www2023tiger_amd.model.training import TrainBuffers
+    z = load(name)
+    cfg = parse_cfg(z)
+    model, _, _ = build_hip_model(z, cfg, dropout=0.0)
+    orc = build_oracle(z, cfg)
+    model.train()
+    bufs = {}
+    state = {}
+    for b in range(cfg['n_batches']):
+        a = batch(z, cfg, b)
+        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], cfg['K'], cfg['restarter'], hist_len=cfg.get('H'))
+        lazy_restart(model, orc, cfg, b, a, cg, state)
+        sync_params(model, orc)
+        c, _, grads = orc.train_step(*a, cg, lr=cfg['lr'], contrast_only=True)
+        n = len(a[0])
+        tb = bufs.get(n) or TrainBuffers(model, n)
+        bufs[n] = tb
+        to = lambda x, dt: torch.as_tensor(x).to(dev(), dt)
+        tb.sb.load(to(a[0], torch.int64), to(a[1], torch.int64), to(a[2], torch.int64), to(a[3], torch.float64),
+                   to(a[4], torch.int64))
+        tb.launch()
+        assert int(tb.sb.err.item()) == 0
+        assert abs(float(tb.losses[0]) - c) < TOL * max(1.0, abs(c)), b
+        for k, g in tb.grads.items():
+            assert grad_err(g.cpu().numpy(), grads[k].numpy()) < 2e-4, (b, k)
+        gru_ran = float(grads['right_mem_updater.cell.bias_ih'].abs().max()) > 0
+        assert int(tb.flags[0]) == 1 and int(tb.flags[1]) == int(gru_ran), b
+    assert rel_err(model.left_memory.vals.cpu().numpy(), orc.left_vals.numpy()) < TOL
+    assert rel_err(model.right_memory.vals.cpu().numpy(), orc.right_vals.numpy()) < TOL
+
+
+def test_fused_trainer_follows_reference_trajectory():
+    """tg_train_step + tg_adam_step, no parameter sync: the contrast-only trajectory of the
+    reference (losses per batch, final parameters, final memories)."""
+    from www2023tiger_amd.model.training import FusedTrainer
+    z = load('train_contrast_rr_d8')
+    cfg = parse_cfg(z)
+    model, _, _ = build_hip_model(z, cfg, dropout=0.0)
+    model.train()
+    tr = FusedTrainer(model, cfg['B'], lr=cfg['lr'])
+    for b in range(cfg['n_batches']):
+        losses = tr.step(*batch(z, cfg, b))
+        assert abs(float(losses[0]) - float(z[f'b{b}_contrast_loss'])) < 1e-3, b
+    for k, p in model.named_parameters():
+        if k.startswith('restarter_fn.'):
+            continue
+        assert rel_err(p.detach().cpu().numpy(), z[f'final.{k}']) < 2e-3, k
+    assert rel_err(model.left_memory.vals.cpu().numpy(), z['final_left_vals']) < 1e-3

@@ -79,6 +79,21 @@ class TgWritebackIo(C.Structure):
     ]
 
 
+class TgScoreParams(C.Structure):
+    _fields_ = [('hit_type', i32), ('n_hit_rows', i32), ('hit_emb', vp), ('fc1', TgLinear), ('fc2', TgLinear)]
+
+
+class TgTrainIo(C.Structure):
+    _fields_ = [
+        ('step', TgStepIo), ('score', vp), ('grads', vp), ('score_grads', vp), ('losses', vp),
+        ('pos_scores', vp), ('neg_scores', vp), ('flags', vp), ('reserved', i32 * 2),
+    ]
+
+
+class TgAdamSeg(C.Structure):
+    _fields_ = [('p', vp), ('g', vp), ('m', vp), ('v', vp), ('n', i64), ('group', i32), ('reserved', i32)]
+
+
 P = C.POINTER
 # name -> (restype, argtypes); every symbol include/tiger_hip.h declares
 SIGNATURES = {
@@ -123,6 +138,9 @@ SIGNATURES = {
     'tg_stream_step_workspace_bytes': (sz, [P(TgModel), i64]),
     'tg_stream_step_zero_bytes': (sz, [P(TgModel), i64]),
     'tg_stream_step': (C.c_int, [P(TgModel), P(TgTcsr), P(TgStepIo), vp, sz, vp]),
+    'tg_train_step_workspace_bytes': (sz, [P(TgModel), P(TgScoreParams), i64]),
+    'tg_train_step': (C.c_int, [P(TgModel), P(TgTcsr), P(TgTrainIo), vp, sz, vp]),
+    'tg_adam_step': (C.c_int, [vp, i32, i32, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
     'tg_stream_writeback_workspace_bytes': (sz, [P(TgModel), i64]),
     'tg_stream_writeback': (C.c_int, [P(TgModel), P(TgWritebackIo), vp, sz, vp]),
 }

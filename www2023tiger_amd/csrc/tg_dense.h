@@ -33,6 +33,11 @@ struct GemmArgs {
   int relu;
   int nbatch;                // batched over blockIdx: per-batch element offsets below
   int64_t a0_bs, w_bs, bias_bs, c_bs;
+  // backward-pass epilogues: C = v * (relu_mask[m, n] > 0) (mask shares ldc-style indexing with
+  // its own stride), and C += v instead of C = v
+  const float* relu_mask;
+  int64_t ld_mask;
+  int accumulate;
 };
 
 int gemm_launch(const GemmArgs& g, hipStream_t st);
@@ -47,10 +52,36 @@ struct GruArgs {
   float* out;
   int64_t ldo;
   const int32_t* out_rows;  // nullable
+  float* gates;             // nullable [cap, 4, d]: r, z, n, h_n (+bias) per live row, for the backward pass
   int dbg;                  // diagnostic bits, 0 in production
   int64_t rows_hint;        // upper bound of live rows known on the host (0 = unknown), picks the tile height
 };
 
 int gru_launch(const GruArgs& g, hipStream_t st);
+
+// Weight-gradient GEMM: out[n, k] (+)= alpha * sum_m Y[m, n] * X[m, k], X = [x0 | x1] with optional
+// row gathers, m < *m_dev (<= m_cap).  The M extent is split over blocks; partial tiles go to
+// `part` ([splits, nbatch, N, K] floats, plain stores) and a second launch reduces them in a
+// fixed order (deterministic, no float atomics).
+struct TnArgs {
+  int64_t m_cap;
+  const int32_t* m_dev;
+  int n, k;
+  const float* y;
+  int64_t ldy;
+  ASeg x0, x1;
+  float* out;
+  int64_t ldo;
+  float alpha;
+  int accumulate;
+  int nbatch;
+  int64_t y_bs, x0_bs, out_bs;
+  float* part;
+  size_t part_floats;  // capacity of `part`
+};
+int gemm_tn_launch(const TnArgs& a, hipStream_t st);
+// out[n] (+)= alpha * sum_m Y[m, n]
+int colsum_launch(int64_t m_cap, const int32_t* m_dev, int n, const float* y, int64_t ldy, float alpha, float* out,
+                  int accumulate, float* part, size_t part_floats, hipStream_t st);
 
 }  // namespace tg

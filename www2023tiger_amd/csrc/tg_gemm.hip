@@ -163,7 +163,9 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
     float v = g.alpha * (acc[r] + bias);
     if (g.relu) v = fmaxf(v, 0.f);
     if (g.row_valid && !g.row_valid[m]) v = 0.f;
+    if (g.relu_mask && !(g.relu_mask[m * g.ld_mask + n] > 0.f)) v = 0.f;
     const int64_t cr = g.c_rows ? (int64_t)g.c_rows[m] : m;
+    if (g.accumulate) v += cp[cr * g.ldc + n];
     cp[cr * g.ldc + n] = v;
   }
 }
@@ -385,8 +387,15 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
     const float hold = hold_v[r];
     const float rg = fast_sigmoid(acc_r[r] + br);
     const float zg = fast_sigmoid(acc_z[r] + bz);
-    const float ng = fast_tanh(acc_in[r] + bin + rg * (acc_hn[r] + bhn));
-    if (jok && m < M) g.out[orow_v[r] * g.ldo + j] = (1.f - zg) * ng + zg * hold;
+    const float hn = acc_hn[r] + bhn;
+    const float ng = fast_tanh(acc_in[r] + bin + rg * hn);
+    if (jok && m < M) {
+      g.out[orow_v[r] * g.ldo + j] = (1.f - zg) * ng + zg * hold;
+      if (g.gates) {
+        float* gp = g.gates + m * 4 * (int64_t)d + j;
+        gp[0] = rg; gp[d] = zg; gp[2 * d] = ng; gp[3 * d] = hn;
+      }
+    }
   }
   if ((dbg & 16) && tid == 0 && blockIdx.x < 2048) {
     g_gru_trace[blockIdx.x * 4 + 0] = t_entry;
@@ -418,6 +427,161 @@ int gru_launch(const GruArgs& g, hipStream_t st) {
   else
     hipLaunchKernelGGL((k_gru<4, 1>), dim3((unsigned)grid), dim3(256), 0, st, a);
   return check_launch("gru");
+}
+
+// ---------------------------------------------------------------------------------
+// Weight gradients: out[n, k] = sum_m Y[m, n] X[m, k].  Both MFMA operands are read along m,
+// so tiles are staged [m][col] exactly as they lie in memory (no transposition): lane l feeds
+// A[n = l&31][m = l>>5] = Ys[m][n], B[m = l>>5][k = l&31] = Xs[m][k].
+// ---------------------------------------------------------------------------------
+constexpr int TN_T = 64;        // output tile (n and k extent)
+constexpr int TN_MC = 32;       // m rows per staged chunk
+constexpr int TN_LD = TN_T + 32;  // row stride: the two half-waves (rows m, m+1) hit disjoint banks
+
+__global__ void __launch_bounds__(256) k_gemm_tn(TnArgs a, int splits) {
+  __shared__ float Ys[2][TN_MC][TN_LD];
+  __shared__ float Xs[2][TN_MC][TN_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NT = (a.n + TN_T - 1) / TN_T, KT = (a.k + TN_T - 1) / TN_T;
+  int b = blockIdx.x;
+  const int kt = b % KT; b /= KT;
+  const int nt = b % NT; b /= NT;
+  const int bz = b % a.nbatch;
+  const int sp = b / a.nbatch;
+  int64_t M = a.m_cap;
+  if (a.m_dev) M = min(M, (int64_t)*a.m_dev);
+  const int64_t mc = ((M + splits - 1) / splits + TN_MC - 1) / TN_MC * TN_MC;  // rows per split
+  const int64_t m_lo = (int64_t)sp * mc, m_hi = min(M, m_lo + mc);
+  const int n0 = nt * TN_T, k0 = kt * TN_T;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int fr = lane & 31, fk = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  // staging coordinates: 16 threads per 64-float row, 16 rows per pass, 2 passes per operand
+  const int sr = tid >> 4, sc = (tid & 15) * 4;
+  const float* yb = a.y + (int64_t)bz * a.y_bs;
+  const float* x0b = a.x0.p + (int64_t)bz * a.x0_bs;
+  const int ycol = min(n0 + sc, a.n - 4);           // clamped: columns past N are zeroed at the LDS store
+  const bool yin = n0 + sc < a.n;
+  const int kcol = k0 + sc;
+  const bool xin = kcol < a.k;
+  const int kc = xin ? kcol : 0;
+  const bool seg1 = kc >= a.x0.w;
+  float4 ry[2], rx[2];
+  auto load_chunk = [&](int64_t mb) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t m = min(mb + sr + i * 16, M - 1);
+      ry[i] = ldg4(yb + m * a.ldy + ycol);
+      const float* xr = seg1 ? a.x1.p + (a.x1.idx ? a.x1.idx[m] : m) * a.x1.ld + (kc - a.x0.w)
+                             : x0b + (a.x0.idx ? a.x0.idx[m] : m) * a.x0.ld + kc;
+      rx[i] = ldg4(xr);
+    }
+  };
+  auto store_chunk = [&](int buf, int64_t mb) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool live = mb + sr + i * 16 < m_hi;
+      *reinterpret_cast<float4*>(&Ys[buf][sr + i * 16][sc]) = (live && yin) ? ry[i] : zero4();
+      *reinterpret_cast<float4*>(&Xs[buf][sr + i * 16][sc]) = (live && xin) ? rx[i] : zero4();
+    }
+  };
+  if (m_lo < m_hi) {
+    load_chunk(m_lo);
+    store_chunk(0, m_lo);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t mb = m_lo; mb < m_hi; mb += TN_MC) {
+      const bool more = mb + TN_MC < m_hi;
+      if (more) load_chunk(mb + TN_MC);
+      const float* yp = &Ys[buf][fk][wn * 32 + fr];
+      const float* xp = &Xs[buf][fk][wk * 32 + fr];
+#pragma unroll
+      for (int s2 = 0; s2 < TN_MC / 2; ++s2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yp[s2 * 2 * TN_LD], xp[s2 * 2 * TN_LD], acc, 0, 0, 0);
+      if (more) store_chunk(buf ^ 1, mb + TN_MC);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  // partial tile -> part[sp][bz][n][k] (zeros when this split is empty)
+  float* pp = a.part + ((int64_t)sp * a.nbatch + bz) * a.n * a.k;
+  const int kk = k0 + wk * 32 + fr;
+  if (kk < a.k) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+      if (n < a.n) pp[(int64_t)n * a.k + kk] = acc[r];
+    }
+  }
+}
+
+__global__ void k_tn_reduce(TnArgs a, int splits) {
+  const int64_t per = (int64_t)a.n * a.k, total = per * a.nbatch;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int bz = (int)(t / per);
+    const int64_t e = t - (int64_t)bz * per;
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += a.part[((int64_t)sp * a.nbatch + bz) * per + e];
+    float* o = a.out + (int64_t)bz * a.out_bs + (e / a.k) * a.ldo + (e % a.k);
+    *o = a.alpha * s + (a.accumulate ? *o : 0.f);
+  }
+}
+
+int gemm_tn_launch(const TnArgs& a, hipStream_t st) {
+  if (a.m_cap <= 0) return TG_OK;
+  if (a.n <= 0 || a.k <= 0 || (a.n % 4) || (a.k % 4) || (a.x0.w % 4) || (a.ldy % 4) || a.nbatch <= 0) return TG_EINVAL;
+  if (a.x0.w + (a.x1.p ? a.x1.w : 0) != a.k) return TG_EINVAL;
+  const int NT = (int)cdiv(a.n, TN_T), KT = (int)cdiv(a.k, TN_T);
+  const int64_t tiles = (int64_t)NT * KT * a.nbatch;
+  int64_t splits = std::max<int64_t>(1, std::min<int64_t>(cdiv(1024, tiles), cdiv(a.m_cap, 2 * TN_MC)));
+  const int64_t fit = (int64_t)(a.part_floats / ((size_t)a.nbatch * a.n * a.k));
+  if (fit < 1) return TG_EWORKSPACE;
+  splits = std::min(splits, fit);
+  hipLaunchKernelGGL(k_gemm_tn, dim3((unsigned)(tiles * splits)), dim3(256), 0, st, a, (int)splits);
+  hipLaunchKernelGGL(k_tn_reduce, dim3(flat_grid((int64_t)a.n * a.k * a.nbatch, 256)), dim3(256), 0, st, a, (int)splits);
+  return check_launch("gemm_tn");
+}
+
+// column sums: one block per (64 columns, split of m); partials then a fixed-order reduce
+__global__ void __launch_bounds__(256) k_colsum(int64_t m_cap, const int32_t* __restrict__ m_dev, int n,
+                                                const float* __restrict__ y, int64_t ldy, float* __restrict__ part,
+                                                int splits) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x % ((n + 63) / 64) * 64 + (threadIdx.x & 63);
+  const int sp = blockIdx.x / ((n + 63) / 64);
+  int64_t M = m_cap;
+  if (m_dev) M = min(M, (int64_t)*m_dev);
+  const int64_t mc = (M + splits - 1) / splits;
+  const int64_t lo = sp * mc, hi = min(M, lo + mc);
+  float s = 0.f;
+  if (c < n)
+    for (int64_t m = lo + (threadIdx.x >> 6); m < hi; m += 4) s += y[m * ldy + c];
+  red[threadIdx.x >> 6][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (threadIdx.x < 64 && c < n) part[(int64_t)sp * n + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void k_colsum_reduce(int n, const float* __restrict__ part, int splits, float alpha, float* __restrict__ out,
+                                int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float s = 0.f;
+  for (int sp = 0; sp < splits; ++sp) s += part[(int64_t)sp * n + c];
+  out[c] = alpha * s + (accumulate ? out[c] : 0.f);
+}
+
+int colsum_launch(int64_t m_cap, const int32_t* m_dev, int n, const float* y, int64_t ldy, float alpha, float* out,
+                  int accumulate, float* part, size_t part_floats, hipStream_t st) {
+  if (m_cap <= 0 || n <= 0) return TG_OK;
+  const int ct = (n + 63) / 64;
+  int64_t splits = std::max<int64_t>(1, std::min<int64_t>(cdiv(512, ct), cdiv(m_cap, 64)));
+  splits = std::min<int64_t>(splits, (int64_t)(part_floats / (size_t)n));
+  if (splits < 1) return TG_EWORKSPACE;
+  hipLaunchKernelGGL(k_colsum, dim3((unsigned)(ct * splits)), dim3(256), 0, st, m_cap, m_dev, n, y, ldy, part, (int)splits);
+  hipLaunchKernelGGL(k_colsum_reduce, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, n, part, (int)splits, alpha, out,
+                     accumulate);
+  return check_launch("colsum");
 }
 
 }  // namespace tg

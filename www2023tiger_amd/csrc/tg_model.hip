@@ -9,30 +9,9 @@
 // once.  q.bk is constant over keys and cancels in the softmax; sum(a)=1 carries bv.
 // Mathematically identical, ~5x fewer flops, and the K*3d key rows are touched once by
 // a gather kernel instead of being materialised for a GEMM.
-#include "tg_dense.h"
+#include "tg_step.h"
 
 namespace tg {
-
-static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
-
-struct Carver {
-  char* p;
-  size_t left;
-  bool ok = true;
-  Carver(void* ws, size_t bytes) : p((char*)ws), left(bytes) {}
-  template <typename T>
-  T* take(size_t count) {
-    const size_t b = align16(count * sizeof(T));
-    if (b > left || !p) {
-      ok = false;
-      return nullptr;
-    }
-    T* r = (T*)p;
-    p += b;
-    left -= b;
-    return r;
-  }
-};
 
 // ---- invariants of compute_messages (message_modules.py:158-159, tiger.py:325-327) ----
 __global__ void k_check_messages(tg_model m, const int64_t* __restrict__ outdated, const int32_t* __restrict__ n_dev,
@@ -236,17 +215,12 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
   }
 }
 
-static int attn_dims_ok(const tg_model* m) {
+int attn_dims_ok(const tg_model* m) {
   if (!m || m->d <= 0 || (m->d % 4) || m->d_e <= 0 || (m->d_e % 4) || m->n_neighbors <= 0) return 0;
   if (m->n_neighbors > TG_WAVE) return 0;  // one key per lane in k_attn_core
   if (m->n_head <= 0 || (2 * m->d) % m->n_head || ((2 * m->d / m->n_head) % 4)) return 0;
   return 1;
 }
-
-struct AttnWs {
-  float *cc, *qp, *g, *s, *o, *hh, *t, *qconst;
-  uint8_t* valid;
-};
 
 static bool carve_attn(const tg_model* m, int64_t Q, Carver& cv, AttnWs& w) {
   const int d = m->d, kvw = 2 * m->d + m->d_e, nh = m->n_head;
@@ -269,7 +243,6 @@ static size_t attn_ws_bytes(const tg_model* m, int64_t Q) {
 }
 
 }  // namespace tg
-struct tg_profiler;
 static inline void prof_mark(tg_profiler* p, int i, hipStream_t st);
 namespace tg {
 constexpr int ST_ATTN_FIRST = 5;  // == ST_ATTN_PREP (checked by a static_assert below)
@@ -366,7 +339,7 @@ static size_t apply_ws_bytes(const tg_model* m, int64_t cap) {
 
 int apply_messages(const tg_model* m, const int64_t* outdated, const int32_t* out_pos, const int32_t* n_dev,
                    int64_t cap, float* reprs, uint32_t* err, void* ws, size_t ws_bytes, hipStream_t st,
-                   bool checked_already = false) {
+                   bool checked_already = false, float* gates = nullptr) {
   const int d = m->d, mw = 3 * m->d + m->d_e;
   Carver cv(ws, ws_bytes);
   ApplyWs w{};
@@ -400,7 +373,7 @@ int apply_messages(const tg_model* m, const int64_t* outdated, const int32_t* ou
     GruArgs a{};
     a.cap = cap; a.n_dev = n_dev; a.d = d; a.xw = mw; a.x = x; a.h = h;
     a.w_ih = m->gru_w_ih; a.w_hh = m->gru_w_hh; a.b_ih = m->gru_b_ih; a.b_hh = m->gru_b_hh;
-    a.out = reprs; a.ldo = d; a.out_rows = out_pos;
+    a.out = reprs; a.ldo = d; a.out_rows = out_pos; a.gates = gates;
     a.rows_hint = std::min<int64_t>(cap, m->n_nodes);
     return gru_launch(a, st);
   }
@@ -589,26 +562,8 @@ extern "C" int tg_profiler_read(tg_profiler* p, float* ms_out) {
   return TG_OK;
 }
 
-struct StepWs {
-  uint8_t* flags;            // involved byte flags        (zeroed every step)
-  unsigned long long* best;  // per involved rank          (zeroed every step)
-  int32_t* counts;           // [4]                        (zeroed every step)
-  size_t zero_bytes;         // size of the contiguous zeroed region starting at flags
-  uint64_t* bm;              // involved bitmap, packed from the flags
-  uint32_t *rank, *rank_out;
-  int64_t *nids3, *eids, *involved, *outdated, *upos, *index;
-  double* ts3;
-  float *ts3f, *l1_ts, *reprs;
-  int64_t *l1_nids, *l1_eids;
-  int32_t* out_pos;
-  void* scan_ws;
-  size_t scan_bytes;
-  AttnWs attn;
-  void* apply_ws;
-  size_t apply_bytes;
-};
-
-static bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w) {
+namespace tg {
+bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w) {
   const int64_t Q = 3 * B, K = m->n_neighbors, cap = Q * (K + 1);
   const int64_t W = (m->n_nodes + 63) / 64;
   char* z0 = cv.p;
@@ -639,6 +594,7 @@ static bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w) {
   w.apply_ws = cv.take<char>(w.apply_bytes);
   return cv.ok;
 }
+}  // namespace tg
 
 extern "C" size_t tg_stream_step_workspace_bytes(const tg_model* m, int64_t B) {
   if (!attn_dims_ok(m) || B <= 0 || m->n_nodes <= 0) return 0;
@@ -656,17 +612,10 @@ extern "C" size_t tg_stream_step_zero_bytes(const tg_model* m, int64_t B) {
   return align16(W * 64) + align16(cap * 8) + 16;
 }
 
-extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, void* ws, size_t ws_bytes,
-                              void* stream) {
-  if (!attn_dims_ok(m) || !g || !io || io->B <= 0) return TG_EINVAL;
-  if (!io->src || !io->dst || !io->neg || !io->ts || !io->eids || !io->h || !io->err) return TG_EINVAL;
-  if (g->num_node != m->n_nodes) return TG_EINVAL;
-  hipStream_t st = as_stream(stream);
-  tg_profiler* pf = (tg_profiler*)io->profiler;
+namespace tg {
+int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, StepWs& w, float* gates, hipStream_t st,
+                 tg_profiler* pf) {
   const int64_t B = io->B, Q = 3 * B, K = m->n_neighbors, cap = Q * (K + 1);
-  Carver cv(ws, ws_bytes);
-  StepWs w{};
-  if (!carve_step(m, B, cv, w)) return TG_EWORKSPACE;
   prof_mark(pf, ST_QUERIES, st);
   hipError_t e = hipSuccess;
   if (!io->ws_is_clean || io->embed_only) e = hipMemsetAsync(w.flags, 0, w.zero_bytes, st);
@@ -677,31 +626,30 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
   int rc;
   // ---- collate (data_loader.py:77-131): queries + temporal neighbours + involved flags, one launch
   prof_mark(pf, ST_SAMPLE, st);
-  int64_t* l1n = io->l1_nids ? io->l1_nids : w.l1_nids;
-  int64_t* l1e = io->l1_eids ? io->l1_eids : w.l1_eids;
-  float* l1t = io->l1_ts ? io->l1_ts : w.l1_ts;
+  w.l1n = io->l1_nids ? io->l1_nids : w.l1_nids;
+  w.l1e = io->l1_eids ? io->l1_eids : w.l1_eids;
+  w.l1t = io->l1_ts ? io->l1_ts : w.l1_ts;
   if ((rc = sample_batch_launch(g, B, io->src, io->dst, io->neg, io->ts, io->eids, io->offset_dev, (int32_t)K, w.nids3,
-                                w.ts3f, w.eids, l1n, l1e, l1t, w.flags, st)) != TG_OK)
+                                w.ts3f, w.eids, w.l1n, w.l1e, w.l1t, w.flags, st)) != TG_OK)
     return rc;
-  const int64_t* src = w.nids3;
-  const int64_t* dst = w.nids3 + B;
   prof_mark(pf, ST_COMPACT, st);
-  int64_t* involved = io->involved ? io->involved : w.involved;
+  w.inv = io->involved ? io->involved : w.involved;
   // involved = sorted(set(...)); outdated = involved & has-message (memory.py:108-126)
-  if ((rc = unique_compact_launch(w.flags, w.bm, m->n_nodes, w.rank, involved, w.counts + 0, cap, m->has_msg, w.rank_out,
+  if ((rc = unique_compact_launch(w.flags, w.bm, m->n_nodes, w.rank, w.inv, w.counts + 0, cap, m->has_msg, w.rank_out,
                                   w.outdated, w.out_pos, w.counts + 1, w.scan_ws, w.scan_bytes, st)) != TG_OK)
     return rc;
   prof_mark(pf, ST_GATHER, st);
   // ---- STEP 1-2: reprs = right_memory[involved] (+ invariants); outdated rows <- updater(...)
-  if ((rc = consume_gather_check_launch(m, involved, w.counts + 0, cap, w.reprs, w.outdated, w.counts + 1, io->err,
-                                        st)) != TG_OK)
+  if ((rc = consume_gather_check_launch(m, w.inv, w.counts + 0, cap, w.reprs, w.outdated, w.counts + 1, io->err, st)) !=
+      TG_OK)
     return rc;
   prof_mark(pf, ST_UPDATE, st);
   if ((rc = apply_messages(m, w.outdated, w.out_pos, w.counts + 1, cap, w.reprs, io->err, w.apply_ws, w.apply_bytes,
-                           st, true)) != TG_OK)
+                           st, true, gates)) != TG_OK)
     return rc;
   // ---- STEP 3: temporal embeddings of cat[src, dst, neg]
-  if ((rc = attn_forward(m, Q, w.nids3, w.ts3f, l1n, l1e, l1t, w.reprs, w.bm, w.rank, io->h, w.attn, st, pf)) != TG_OK)
+  if ((rc = attn_forward(m, Q, w.nids3, w.ts3f, w.l1n, w.l1e, w.l1t, w.reprs, w.bm, w.rank, io->h, w.attn, st, pf)) !=
+      TG_OK)
     return rc;
   prof_mark(pf, ST_DEDUP, st);
   if (io->h_new) {  // h(t'+) rows of cat[src, dst]: reprs[local(node)]
@@ -710,48 +658,87 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                        (float*)nullptr);
   }
-  if (io->embed_only) {
-    if (io->counts) {
-      e = hipMemcpyAsync(io->counts, w.counts, 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
-      if (e != hipSuccess) {
-        set_hip_error(e, "tg_stream_step counts copy");
-        return TG_EHIP;
-      }
-    }
-    if (io->offset_dev && io->advance) hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, io->offset_dev, B);
-    return check_launch("tg_stream_step(embed_only)");
-  }
-  // ---- dedup of positive nodes (select_latest_nids on float32 ts, tiger.py:232,419; memory.py:98)
-  hipLaunchKernelGGL(k_pos_max, dim3(flat_grid(2 * B, 256)), dim3(256), 0, st, B, src, dst, w.ts3f, w.bm, w.rank, w.best,
-                     w.counts + 2);
-  hipLaunchKernelGGL(k_pos_winners, dim3(flat_grid(2 * B, 256)), dim3(256), 0, st, B, src, dst, w.ts3f, w.bm, w.rank,
-                     w.best, w.upos, w.index, w.counts + 2);
-  // ---- STEP 4-6 (tiger.py:229-255) in two launches; STEP 5 shares a launch with whichever of
-  // STEP 4 / STEP 6 does not write the message memory (see tg_memory.hip)
+  return check_launch("tg_stream_step(forward)");
+}
+
+// ---- dedup of positive nodes (select_latest_nids on float32 ts, tiger.py:232,419; memory.py:98),
+// STEP 4-5 and the restarter targets.  STEP 4-6 (tiger.py:229-255) take two launches; STEP 5
+// shares a launch with whichever of STEP 4 / STEP 6 does not write the message memory
+// (see tg_memory.hip)
+static WritebackArgs writeback_args(const tg_model* m, const tg_step_io* io, StepWs& w) {
+  const int64_t B = io->B;
   WritebackArgs wa{};
-  wa.B = B; wa.src = src; wa.dst = dst; wa.eids = w.eids; wa.upos = w.upos; wa.index = w.index; wa.ts = w.ts3f;
+  wa.B = B; wa.src = w.nids3; wa.dst = w.nids3 + B; wa.eids = w.eids; wa.upos = w.upos; wa.index = w.index;
+  wa.ts = w.ts3f;
   wa.n_upos = w.counts + 2; wa.reprs = w.reprs; wa.bm = w.bm; wa.rank = w.rank; wa.h = io->h; wa.err = io->err;
   wa.counts_src = io->counts ? w.counts : nullptr; wa.counts_dst = io->counts;
   wa.offset_dev = (io->offset_dev && io->advance) ? io->offset_dev : nullptr;
   wa.clean_flags = w.flags; wa.flag_bytes = (int64_t)((m->n_nodes + 63) / 64) * 64; wa.clean_best = w.best;
   wa.clean_counts = w.counts;
+  return wa;
+}
+
+int step_writeback_a(const tg_model* m, const tg_step_io* io, StepWs& w, hipStream_t st, tg_profiler* pf) {
+  const int64_t B = io->B;
+  const int64_t* src = w.nids3;
+  const int64_t* dst = w.nids3 + B;
+  hipLaunchKernelGGL(k_pos_max, dim3(flat_grid(2 * B, 256)), dim3(256), 0, st, B, src, dst, w.ts3f, w.bm, w.rank, w.best,
+                     w.counts + 2);
+  hipLaunchKernelGGL(k_pos_winners, dim3(flat_grid(2 * B, 256)), dim3(256), 0, st, B, src, dst, w.ts3f, w.bm, w.rank,
+                     w.best, w.upos, w.index, w.counts + 2);
+  const WritebackArgs wa = writeback_args(m, io, w);
+  int rc;
   prof_mark(pf, ST_WRITE_RIGHT, st);
   if ((rc = writeback_launch(m, wa, 0, st)) != TG_OK) return rc;
   prof_mark(pf, ST_STORE_EVENTS, st);
   // ---- side outputs for the restarter (tiger.py:248-251): after STEP 4, before STEP 6
   if (io->h_prev_left) {
-    if ((rc = tg_gather_rows(2 * B, w.nids3, m->d, m->left_vals, io->h_prev_left, nullptr, nullptr, stream)) != TG_OK)
+    if ((rc = tg_gather_rows(2 * B, w.nids3, m->d, m->left_vals, io->h_prev_left, nullptr, nullptr, (void*)st)) != TG_OK)
       return rc;
   }
   if (io->h_prev_right) {
-    if ((rc = tg_gather_rows(2 * B, w.nids3, m->d, m->right_vals, io->h_prev_right, nullptr, nullptr, stream)) != TG_OK)
+    if ((rc = tg_gather_rows(2 * B, w.nids3, m->d, m->right_vals, io->h_prev_right, nullptr, nullptr, (void*)st)) != TG_OK)
       return rc;
   }
+  return TG_OK;
+}
+
+int step_writeback_b(const tg_model* m, const tg_step_io* io, StepWs& w, hipStream_t st, tg_profiler* pf) {
+  const WritebackArgs wa = writeback_args(m, io, w);
   prof_mark(pf, ST_WRITE_LEFT, st);
+  int rc;
   if ((rc = writeback_launch(m, wa, 1, st)) != TG_OK) return rc;
   prof_mark(pf, ST_COUNT, st);
   if (pf) pf->armed = true;
   return check_launch("tg_stream_step");
+}
+}  // namespace tg
+
+extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, void* ws, size_t ws_bytes,
+                              void* stream) {
+  if (!attn_dims_ok(m) || !g || !io || io->B <= 0) return TG_EINVAL;
+  if (!io->src || !io->dst || !io->neg || !io->ts || !io->eids || !io->h || !io->err) return TG_EINVAL;
+  if (g->num_node != m->n_nodes) return TG_EINVAL;
+  hipStream_t st = as_stream(stream);
+  tg_profiler* pf = (tg_profiler*)io->profiler;
+  Carver cv(ws, ws_bytes);
+  StepWs w{};
+  if (!carve_step(m, io->B, cv, w)) return TG_EWORKSPACE;
+  int rc;
+  if ((rc = step_forward(m, g, io, w, nullptr, st, pf)) != TG_OK) return rc;
+  if (io->embed_only) {
+    if (io->counts) {
+      hipError_t e = hipMemcpyAsync(io->counts, w.counts, 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) {
+        set_hip_error(e, "tg_stream_step counts copy");
+        return TG_EHIP;
+      }
+    }
+    if (io->offset_dev && io->advance) hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, io->offset_dev, io->B);
+    return check_launch("tg_stream_step(embed_only)");
+  }
+  if ((rc = step_writeback_a(m, io, w, st, pf)) != TG_OK) return rc;
+  return step_writeback_b(m, io, w, st, pf);
 }
 
 // ---------------------------------------------------------------------------------

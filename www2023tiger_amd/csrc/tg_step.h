@@ -1,0 +1,70 @@
+// Internal layout of the fused step's workspace and the pieces of tg_stream_step that the
+// training step (tg_train.hip) re-uses.  Not part of the C ABI.
+#pragma once
+#include "tg_dense.h"
+
+struct tg_profiler;
+
+namespace tg {
+
+static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+struct Carver {
+  char* p;
+  size_t left;
+  bool ok = true;
+  Carver(void* ws, size_t bytes) : p((char*)ws), left(bytes) {}
+  template <typename T>
+  T* take(size_t count) {
+    const size_t b = align16(count * sizeof(T));
+    if (b > left || !p) {
+      ok = false;
+      return nullptr;
+    }
+    T* r = (T*)p;
+    p += b;
+    left -= b;
+    return r;
+  }
+};
+
+// intermediates of the temporal attention; all of them survive until the end of the step,
+// which is what the backward pass reads
+struct AttnWs {
+  float *cc, *qp, *g, *s, *o, *hh, *t, *qconst;
+  uint8_t* valid;
+};
+
+struct StepWs {
+  uint8_t* flags;            // involved byte flags        (zeroed every step)
+  unsigned long long* best;  // per involved rank          (zeroed every step)
+  int32_t* counts;           // [4]                        (zeroed every step)
+  size_t zero_bytes;         // size of the contiguous zeroed region starting at flags
+  uint64_t* bm;              // involved bitmap, packed from the flags
+  uint32_t *rank, *rank_out;
+  int64_t *nids3, *eids, *involved, *outdated, *upos, *index;
+  double* ts3;
+  float *ts3f, *l1_ts, *reprs;
+  int64_t *l1_nids, *l1_eids;
+  int32_t* out_pos;
+  void* scan_ws;
+  size_t scan_bytes;
+  AttnWs attn;
+  void* apply_ws;
+  size_t apply_bytes;
+  // resolved per call (io overrides)
+  int64_t *l1n, *l1e, *inv;
+  float* l1t;
+};
+
+bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w);
+int attn_dims_ok(const tg_model* m);
+// collate + STEP 1-3 (+ io->h_new); `gates` (nullable) receives the GRU gate activations
+int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, StepWs& w, float* gates, hipStream_t st,
+                 tg_profiler* pf);
+// positive-node dedup + STEP 4/5 + restarter targets
+int step_writeback_a(const tg_model* m, const tg_step_io* io, StepWs& w, hipStream_t st, tg_profiler* pf);
+// STEP 6 + workspace clean-up + offset advance
+int step_writeback_b(const tg_model* m, const tg_step_io* io, StepWs& w, hipStream_t st, tg_profiler* pf);
+
+}  // namespace tg

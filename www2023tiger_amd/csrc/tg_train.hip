@@ -1,0 +1,783 @@
+// Training tail on device: STEP 7 of TIGE.contrast_learning
+// (tiger/model/tiger.py:257-288: hit features, score MergeLayer, BCE-with-logits), the
+// backward pass of that loss through the temporal attention (temporal_agg_modules.py:29-83,
+// 186-235), the GRU updater (update_modules.py:30-37) and the time encoder
+// (time_encoding.py:24-26), and torch.optim.Adam (train_self_supervised.py:114,170).
+//
+// The backward pass follows the restructured forward of tg_model.hip (query folded through
+// Wk, softmax-weighted raw key rows projected once through Wv): every dX product re-uses the
+// forward GEMM kernel on the weight read k-major (no transposed copies), every dW product is
+// k_gemm_tn (both operands read along the batch dimension, deterministic split reduction),
+// and one gather kernel recomputes the K scores per centre, back-propagates the softmax and
+// scatters the key-row gradients to the involved-node rows.
+#include <algorithm>
+
+#include "tg_step.h"
+
+namespace tg {
+
+// sin with the same three-term Cody-Waite reduction as cos_cw (tg_common.h)
+__device__ __forceinline__ float sin_cw(float x) {
+  const float n = rintf(__fmul_rn(x, 0.6366197723675814f));
+  float r = fmaf(-n, 1.5707963705062866f, x);
+  r = fmaf(-n, -4.371138828673793e-08f, r);
+  r = fmaf(-n, -1.7763568394002505e-15f, r);
+  const float z = __fmul_rn(r, r);
+  const float s = fmaf(__fmul_rn(r, z), fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+  const float c = fmaf(__fmul_rn(z, z), fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                       fmaf(z, -0.5f, 1.0f));
+  const int q = (int)n & 3;
+  const float v = (q & 1) ? c : s;
+  return (q >= 2) ? -v : v;
+}
+__device__ __forceinline__ float time_enc_sin(float dt, float w, float phi) {
+  const float x = __fadd_rn(__fmul_rn(dt, w), phi);
+  return fabsf(x) <= 3.0e6f ? sin_cw(x) : sinf(x);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, TG_WAVE));
+  return v;
+}
+
+__device__ __forceinline__ float dot4f(float4 a, float4 b, float acc) {
+  return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, fmaf(a.x, b.x, acc))));
+}
+__device__ __forceinline__ void axpy4f(float4& s, float b, float4 x) {
+  s.x = fmaf(b, x.x, s.x);
+  s.y = fmaf(b, x.y, s.y);
+  s.z = fmaf(b, x.z, s.z);
+  s.w = fmaf(b, x.w, s.w);
+}
+
+// ---------------------------------------------------------------------------------
+// STEP 7 forward pieces
+// ---------------------------------------------------------------------------------
+// Pair rows for the score MergeLayer (tiger.py:259-279).  Row r < B is the positive pair of
+// event r, row B + r the negative pair: P[r] = [x_pair | y_pair], each W = d (+K) wide.
+// Hit windows (data_loader.py:60-75) are the recent-edges neighbour lists the step already
+// sampled: nbrs(src) = l1[i], nbrs(dst) = l1[B+i], nbrs(neg) = l1[2B+i].
+__global__ void __launch_bounds__(256) k_build_pairs(int64_t B, int d, int K, int hit_type,
+                                                     const float* __restrict__ h, const int64_t* __restrict__ nids3,
+                                                     const int64_t* __restrict__ l1_nids,
+                                                     const float* __restrict__ hit_emb, float* __restrict__ P,
+                                                     int32_t* __restrict__ hit_idx) {
+  const int lane = lane_id();
+  const int W = d + (hit_type == TG_HIT_VEC ? K : 0);
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < 2 * B; r += (int64_t)gridDim.x * 4) {
+    const bool neg = r >= B;
+    const int64_t i = neg ? r - B : r;
+    const int64_t src = nids3[i];
+    const int64_t yrow = neg ? 2 * B + i : B + i;  // the other endpoint: dst or the negative dst
+    const int64_t other = nids3[yrow];
+    // x side: is src inside the window of the other endpoint; y side: is the other endpoint in src's window
+    const bool hx = lane < K && l1_nids[yrow * K + lane] == src;
+    const bool hy = lane < K && l1_nids[i * K + lane] == other;
+    const unsigned long long bx = __ballot(hx), by = __ballot(hy);
+    int ix = 0, iy = 0;
+    if (hit_type == TG_HIT_BIN) {
+      ix = bx != 0ull;
+      iy = by != 0ull;
+    } else if (hit_type == TG_HIT_COUNT) {
+      ix = __popcll(bx);
+      iy = __popcll(by);
+    }
+    if (lane == 0) {
+      hit_idx[2 * r] = ix;
+      hit_idx[2 * r + 1] = iy;
+    }
+    float* row = P + r * 2 * (int64_t)W;
+    const bool emb = hit_type == TG_HIT_BIN || hit_type == TG_HIT_COUNT;
+    for (int c = lane; c < d; c += TG_WAVE) {
+      float vx = h[i * d + c], vy = h[yrow * d + c];
+      if (emb) {
+        vx += hit_emb[(int64_t)ix * d + c];
+        vy += hit_emb[(int64_t)iy * d + c];
+      }
+      row[c] = vx;
+      row[W + c] = vy;
+    }
+    if (hit_type == TG_HIT_VEC && lane < K) {
+      row[d + lane] = hx ? 1.f : 0.f;
+      row[W + d + lane] = hy ? 1.f : 0.f;
+    }
+  }
+}
+
+// logits, BCE-with-logits (mean over 2B), d(loss)/d(logit), fc2 gradients, and dT1 in place:
+// T1[r] <- (T1[r] > 0) * dscore_r * w2.   NVS * 64 >= d.
+constexpr int NVS = 8;
+__global__ void __launch_bounds__(256) k_score_loss(int64_t B, int d, float* __restrict__ T1,
+                                                    const float* __restrict__ w2, const float* __restrict__ b2,
+                                                    float* __restrict__ pos_scores, float* __restrict__ neg_scores,
+                                                    float* __restrict__ loss_out, float* __restrict__ dw2,
+                                                    float* __restrict__ db2) {
+  __shared__ float red[4][NVS * 64 + 2];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  float acc[NVS];
+#pragma unroll
+  for (int v = 0; v < NVS; ++v) acc[v] = 0.f;
+  float loss = 0.f, dbs = 0.f;
+  const float inv = 1.f / (float)(2 * B);
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < 2 * B; r += (int64_t)gridDim.x * 4) {
+    float* t = T1 + r * d;
+    float tv[NVS], wv[NVS];
+    float p = 0.f;
+#pragma unroll
+    for (int v = 0; v < NVS; ++v) {
+      const int c = lane + v * 64;
+      tv[v] = c < d ? t[c] : 0.f;
+      wv[v] = c < d ? w2[c] : 0.f;
+      p = fmaf(tv[v], wv[v], p);
+    }
+    const float s = wave_sum(p) + b2[0];
+    const float y = r < B ? 1.f : 0.f;
+    if (lane == 0) {
+      if (r < B) {
+        if (pos_scores) pos_scores[r] = s;
+      } else if (neg_scores) {
+        neg_scores[r - B] = s;
+      }
+    }
+    loss += fmaxf(s, 0.f) - s * y + log1pf(expf(-fabsf(s)));
+    const float ds = (1.f / (1.f + expf(-s)) - y) * inv;
+    dbs += ds;
+#pragma unroll
+    for (int v = 0; v < NVS; ++v) {
+      const int c = lane + v * 64;
+      acc[v] = fmaf(ds, tv[v], acc[v]);
+      if (c < d) t[c] = tv[v] > 0.f ? ds * wv[v] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NVS; ++v) red[wave][v * 64 + lane] = acc[v];
+  if (lane == 0) {
+    red[wave][NVS * 64] = loss;
+    red[wave][NVS * 64 + 1] = dbs;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < NVS * 64 + 2; c += 256) {
+    const float s = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    if (c < d) atomicAdd(dw2 + c, s);
+    else if (c == NVS * 64) atomicAdd(loss_out, s * inv);
+    else if (c == NVS * 64 + 1) atomicAdd(db2, s);
+  }
+}
+
+// dP -> dh rows (x collects the positive and the negative pair) and hit-embedding gradients
+__global__ void __launch_bounds__(256) k_pairs_bwd(int64_t B, int d, int W, int hit_type, int n_hit_rows,
+                                                   const float* __restrict__ dP, const int32_t* __restrict__ hit_idx,
+                                                   float* __restrict__ dH, float* __restrict__ demb) {
+  extern __shared__ float lacc[];  // [n_hit_rows, d] when the embedding is used
+  const bool emb = (hit_type == TG_HIT_BIN || hit_type == TG_HIT_COUNT) && demb;
+  if (emb) {
+    for (int c = threadIdx.x; c < n_hit_rows * d; c += 256) lacc[c] = 0.f;
+    __syncthreads();
+  }
+  const int lane = lane_id();
+  for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < B; i += (int64_t)gridDim.x * 4) {
+    const float* pp = dP + i * 2 * (int64_t)W;
+    const float* pn = dP + (B + i) * 2 * (int64_t)W;
+    int ipx = 0, ipy = 0, inx = 0, iny = 0;
+    if (emb) {
+      ipx = hit_idx[2 * i];
+      ipy = hit_idx[2 * i + 1];
+      inx = hit_idx[2 * (B + i)];
+      iny = hit_idx[2 * (B + i) + 1];
+    }
+    for (int c = lane; c < d; c += TG_WAVE) {
+      const float xp = pp[c], yp = pp[W + c], xn = pn[c], yn = pn[W + c];
+      dH[i * d + c] = xp + xn;
+      dH[(B + i) * d + c] = yp;
+      dH[(2 * B + i) * d + c] = yn;
+      if (emb) {
+        atomicAdd(&lacc[ipx * d + c], xp);
+        atomicAdd(&lacc[ipy * d + c], yp);
+        atomicAdd(&lacc[inx * d + c], xn);
+        atomicAdd(&lacc[iny * d + c], yn);
+      }
+    }
+  }
+  if (emb) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < n_hit_rows * d; c += 256) atomicAdd(demb + c, lacc[c]);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// attention core, backward.  One wavefront per centre, two passes over its K key rows:
+//   pass 1  p_hj = g_h . x_j,  da_hj = dS_h . x_j            (lane j keeps the pair)
+//   softmax a_hj over the live keys;  ds_hj = a_hj (da_hj - sum_j a_hj da_hj)
+//   pass 2  dG_h = sum_j ds_hj x_j;  dx_j = sum_h a_hj dS_h + ds_hj g_h
+// dx_j's node part is added to the involved-node gradient row, its time part feeds the
+// TimeEncode gradients (d cos(dt w + phi) = -sin(.) (dt dw + dphi)); edge features have no
+// gradient.
+// ---------------------------------------------------------------------------------
+template <int NH, int NV>
+__global__ void __launch_bounds__(256) k_attn_core_bwd(tg_model m, int64_t Q, const float* __restrict__ ts,
+                                                       const int64_t* __restrict__ l1_nids,
+                                                       const int64_t* __restrict__ l1_eids,
+                                                       const float* __restrict__ l1_ts, const float4* __restrict__ reprs,
+                                                       const uint64_t* __restrict__ bm, const uint32_t* __restrict__ rank,
+                                                       const float4* __restrict__ G, const float4* __restrict__ dS,
+                                                       float4* __restrict__ dG, float* __restrict__ dreprs,
+                                                       float* __restrict__ dfreq, float* __restrict__ dphase) {
+  __shared__ float4 tred[4][2][NV][64];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int d = m.d, d4 = m.d / 4, e4 = m.d_e / 4, K = m.n_neighbors;
+  const int kv4 = 2 * d4 + e4;
+  const float4* nf = reinterpret_cast<const float4*>(m.nfeats);
+  const float4* ef = reinterpret_cast<const float4*>(m.efeats);
+  const float4* fq = reinterpret_cast<const float4*>(m.te_freq);
+  const float4* ph = reinterpret_cast<const float4*>(m.te_phase);
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 w4[NV], p4[NV], gw[NV], gp[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int c = lane + v * TG_WAVE;
+    w4[v] = c < d4 ? fq[c] : z4;
+    p4[v] = c < d4 ? ph[c] : z4;
+    gw[v] = gp[v] = z4;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < Q; i += (int64_t)gridDim.x * 4) {
+    int64_t nb_l = 0, eid_l = 0;
+    float dt_l = 0.f;
+    int u_l = 0;
+    if (lane < K) {
+      nb_l = l1_nids[i * K + lane];
+      eid_l = l1_eids[i * K + lane];
+      dt_l = ts[i] - l1_ts[i * K + lane];
+      if (nb_l != 0) u_l = (int)bm_rank(bm, rank, nb_l);
+    }
+    const unsigned long long live0 = __ballot(nb_l != 0);
+    float4 g[NH][3][NV], ds[NH][3][NV], dg[NH][3][NV];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const float4* gh = G + ((int64_t)i * NH + h) * kv4;
+      const float4* sh = dS + ((int64_t)i * NH + h) * kv4;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int c = lane + v * TG_WAVE;
+        g[h][0][v] = c < d4 ? gh[c] : z4;
+        g[h][1][v] = c < e4 ? gh[d4 + c] : z4;
+        g[h][2][v] = c < d4 ? gh[d4 + e4 + c] : z4;
+        ds[h][0][v] = c < d4 ? sh[c] : z4;
+        ds[h][1][v] = c < e4 ? sh[d4 + c] : z4;
+        ds[h][2][v] = c < d4 ? sh[d4 + e4 + c] : z4;
+        dg[h][0][v] = dg[h][1][v] = dg[h][2][v] = z4;
+      }
+    }
+    float4 ya[NV], yn[NV], yb[NV];
+    auto fetch = [&](int k) {
+      const int64_t u = __shfl(u_l, k, TG_WAVE);
+      const int64_t nb = __shfl(nb_l, k, TG_WAVE);
+      const int64_t eid = __shfl(eid_l, k, TG_WAVE);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int c = lane + v * TG_WAVE;
+        ya[v] = c < d4 ? reprs[u * d4 + c] : z4;
+        yn[v] = (nf && c < d4) ? nf[nb * d4 + c] : z4;
+        yb[v] = (ef && c < e4) ? ef[eid * e4 + c] : z4;
+      }
+    };
+    auto build = [&](float dt, float4 (&x)[3][NV]) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int c = lane + v * TG_WAVE;
+        float4 a = ya[v];
+        a.x += yn[v].x; a.y += yn[v].y; a.z += yn[v].z; a.w += yn[v].w;
+        x[0][v] = a;
+        x[1][v] = yb[v];
+        x[2][v] = c < d4 ? make_float4(time_enc(dt, w4[v].x, p4[v].x), time_enc(dt, w4[v].y, p4[v].y),
+                                       time_enc(dt, w4[v].z, p4[v].z), time_enc(dt, w4[v].w, p4[v].w))
+                         : z4;
+      }
+    };
+    // ---- pass 1: scores and dS . x per key, kept by lane k
+    float p_l[NH], da_l[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) p_l[h] = da_l[h] = 0.f;
+    unsigned long long live = live0;
+    int k = live ? (__ffsll(live) - 1) : -1;
+    if (k >= 0) fetch(k);
+    while (k >= 0) {
+      live &= live - 1;
+      const int kn = live ? (__ffsll(live) - 1) : -1;
+      float4 x[3][NV];
+      build(__shfl(dt_l, k, TG_WAVE), x);
+      if (kn >= 0) fetch(kn);
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        float p = 0.f, q = 0.f;
+#pragma unroll
+        for (int sgm = 0; sgm < 3; ++sgm)
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            p = dot4f(g[h][sgm][v], x[sgm][v], p);
+            q = dot4f(ds[h][sgm][v], x[sgm][v], q);
+          }
+        p = wave_sum(p);
+        q = wave_sum(q);
+        if (lane == k) {
+          p_l[h] = p;
+          da_l[h] = q;
+        }
+      }
+      k = kn;
+    }
+    // ---- softmax backward, one key per lane
+    const bool mine = (live0 >> lane) & 1ull;
+    float a_l[NH], s_l[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const float mx = wave_max(mine ? p_l[h] : -INFINITY);
+      const float e = mine ? expf(p_l[h] - mx) : 0.f;
+      const float l = wave_sum(e);
+      const float a = live0 ? e / l : 0.f;
+      const float dot = wave_sum(a * da_l[h]);
+      a_l[h] = a;
+      s_l[h] = a * (da_l[h] - dot);
+    }
+    // ---- pass 2: dG and the key-row gradients
+    live = live0;
+    k = live ? (__ffsll(live) - 1) : -1;
+    if (k >= 0) fetch(k);
+    while (k >= 0) {
+      live &= live - 1;
+      const int kn = live ? (__ffsll(live) - 1) : -1;
+      const float dt = __shfl(dt_l, k, TG_WAVE);
+      const int64_t u = __shfl(u_l, k, TG_WAVE);
+      float4 x[3][NV];
+      build(dt, x);
+      if (kn >= 0) fetch(kn);
+      float4 dxn[NV], dxt[NV];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) dxn[v] = dxt[v] = z4;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const float a = __shfl(a_l[h], k, TG_WAVE), sk = __shfl(s_l[h], k, TG_WAVE);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          axpy4f(dg[h][0][v], sk, x[0][v]);
+          axpy4f(dg[h][1][v], sk, x[1][v]);
+          axpy4f(dg[h][2][v], sk, x[2][v]);
+          axpy4f(dxn[v], a, ds[h][0][v]);
+          axpy4f(dxn[v], sk, g[h][0][v]);
+          axpy4f(dxt[v], a, ds[h][2][v]);
+          axpy4f(dxt[v], sk, g[h][2][v]);
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int c = lane + v * TG_WAVE;
+        if (c < d4) {
+          float* dr = dreprs + u * d + 4 * c;
+          atomicAdd(dr + 0, dxn[v].x);
+          atomicAdd(dr + 1, dxn[v].y);
+          atomicAdd(dr + 2, dxn[v].z);
+          atomicAdd(dr + 3, dxn[v].w);
+          const float sx = -time_enc_sin(dt, w4[v].x, p4[v].x) * dxt[v].x;
+          const float sy = -time_enc_sin(dt, w4[v].y, p4[v].y) * dxt[v].y;
+          const float sz = -time_enc_sin(dt, w4[v].z, p4[v].z) * dxt[v].z;
+          const float sw = -time_enc_sin(dt, w4[v].w, p4[v].w) * dxt[v].w;
+          gp[v].x += sx; gp[v].y += sy; gp[v].z += sz; gp[v].w += sw;
+          gw[v].x = fmaf(sx, dt, gw[v].x); gw[v].y = fmaf(sy, dt, gw[v].y);
+          gw[v].z = fmaf(sz, dt, gw[v].z); gw[v].w = fmaf(sw, dt, gw[v].w);
+        }
+      }
+      k = kn;
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      float4* oh = dG + ((int64_t)i * NH + h) * kv4;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int c = lane + v * TG_WAVE;
+        if (c < d4) {
+          oh[c] = dg[h][0][v];
+          oh[d4 + e4 + c] = dg[h][2][v];
+        }
+        if (c < e4) oh[d4 + c] = dg[h][1][v];
+      }
+    }
+  }
+  // TimeEncode gradients: block reduction, then one atomic per column and block
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    tred[wave][0][v][lane] = gw[v];
+    tred[wave][1][v][lane] = gp[v];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = lane + v * TG_WAVE;
+      if (c < d4) {
+        float4 s = tred[0][wave][v][lane];
+        const float4 b = tred[1][wave][v][lane], e = tred[2][wave][v][lane], f = tred[3][wave][v][lane];
+        s.x += b.x + e.x + f.x; s.y += b.y + e.y + f.y; s.z += b.z + e.z + f.z; s.w += b.w + e.w + f.w;
+        float* o = (wave == 0 ? dfreq : dphase) + 4 * c;
+        atomicAdd(o + 0, s.x); atomicAdd(o + 1, s.y); atomicAdd(o + 2, s.z); atomicAdd(o + 3, s.w);
+      }
+    }
+  }
+}
+
+// centre rows: dreprs[local(nid_i)] += dcc_i
+__global__ void k_centre_scatter(int64_t Q, int d, const int64_t* __restrict__ nids, const uint64_t* __restrict__ bm,
+                                 const uint32_t* __restrict__ rank, const float* __restrict__ dcc,
+                                 float* __restrict__ dreprs) {
+  const int64_t total = Q * d;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / d;
+    atomicAdd(dreprs + (int64_t)bm_rank(bm, rank, nids[i]) * d + (t - i * d), dcc[t]);
+  }
+}
+
+// constant half of the query projection: qconst[n] = bq[n] + sum_j Wq[n, d + j] cos(phi_j)
+//   dWq[n, d + j] += dqconst[n] cos(phi_j);  dphi_j -= sin(phi_j) sum_n dqconst[n] Wq[n, d + j]
+__global__ void __launch_bounds__(256) k_qconst_bwd(int d, const float* __restrict__ dqconst,
+                                                    const float* __restrict__ wq, const float* __restrict__ freq,
+                                                    const float* __restrict__ phase, float* __restrict__ dwq,
+                                                    float* __restrict__ dbq, float* __restrict__ dphase) {
+  const int E = 2 * d;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < E) dbq[j] += dqconst[j];
+  if (j >= d) return;
+  const float c = time_enc(0.f, freq[j], phase[j]), s = time_enc_sin(0.f, freq[j], phase[j]);
+  float acc = 0.f;
+  for (int n = 0; n < E; ++n) {
+    const float dq = dqconst[n];
+    dwq[(int64_t)n * E + d + j] += dq * c;
+    acc = fmaf(dq, wq[(int64_t)n * E + d + j], acc);
+  }
+  atomicAdd(dphase + j, -s * acc);
+}
+
+// ---------------------------------------------------------------------------------
+// GRU cell backward (torch.nn.GRUCell): gate activations were kept by the forward epilogue
+// ---------------------------------------------------------------------------------
+__global__ void k_gru_bwd(tg_model m, int64_t cap, const int32_t* __restrict__ n_dev,
+                          const int64_t* __restrict__ outdated, const int32_t* __restrict__ out_pos,
+                          const float* __restrict__ gates, const float* __restrict__ dreprs, float* __restrict__ dgi,
+                          float* __restrict__ dgh, int32_t* __restrict__ flags) {
+  const int d = m.d;
+  const int64_t n = min((int64_t)*n_dev, cap);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && flags) {
+    flags[0] = 1;
+    flags[1] = n > 0;
+  }
+  const float* hv = (m.upd_src == TG_SRC_LEFT) ? m.left_vals : m.right_vals;
+  const int64_t total = n * d;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / d;
+    const int j = (int)(t - i * d);
+    const float* gp = gates + i * 4 * (int64_t)d + j;
+    const float r = gp[0], z = gp[d], nn = gp[2 * d], hn = gp[3 * d];
+    const float dh = dreprs[(int64_t)out_pos[i] * d + j];
+    const float hold = hv[outdated[i] * d + j];
+    const float dn = dh * (1.f - z) * (1.f - nn * nn);
+    const float dz = dh * (hold - nn) * z * (1.f - z);
+    const float dr = dn * hn * r * (1.f - r);
+    float* gi = dgi + i * 3 * (int64_t)d + j;
+    float* gh = dgh + i * 3 * (int64_t)d + j;
+    gi[0] = dr; gi[d] = dz; gi[2 * d] = dn;
+    gh[0] = dr; gh[d] = dz; gh[2 * d] = dn * r;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Adam
+// ---------------------------------------------------------------------------------
+__global__ void k_adam_tick(int n_groups, const int32_t* __restrict__ enabled, int32_t* __restrict__ steps) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < n_groups && (!enabled || enabled[g])) steps[g] += 1;
+}
+
+__global__ void __launch_bounds__(256) k_adam(const tg_adam_seg* __restrict__ segs, const int32_t* __restrict__ enabled,
+                                              const int32_t* __restrict__ steps, float lr, float b1, float b2, float eps,
+                                              float gscale) {
+  const tg_adam_seg sg = segs[blockIdx.y];
+  if (enabled && !enabled[sg.group]) return;
+  // bias corrections in double, as the Python scalars of torch.optim.Adam
+  const double t = (double)steps[sg.group];
+  const double bc1 = 1.0 - pow((double)b1, t), bc2 = 1.0 - pow((double)b2, t);
+  const float step_size = (float)((double)lr / bc1), bc2s = (float)sqrt(bc2);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < sg.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float g = sg.g[i] * gscale;
+    const float mm = sg.m[i] + (g - sg.m[i]) * (1.f - b1);  // exp_avg.lerp_(grad, 1 - beta1)
+    const float vv = sg.v[i] * b2 + (1.f - b2) * g * g;
+    sg.m[i] = mm;
+    sg.v[i] = vv;
+    sg.p[i] -= step_size * (mm / (sqrtf(vv) / bc2s + eps));
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// workspace of the training tail
+// ---------------------------------------------------------------------------------
+struct TrainWs {
+  float *gates, *P, *T1, *dP, *dH, *dT, *dhh, *dcc, *dO, *dS, *dG, *dqp, *dreprs, *dgi, *dgh, *dqconst, *part;
+  size_t part_floats;
+  int32_t* hit_idx;
+  int64_t rows_cap;
+};
+
+static int score_width(const tg_model* m, const tg_score_params* sp) {
+  return m->d + (sp->hit_type == TG_HIT_VEC ? m->n_neighbors : 0);
+}
+
+static size_t part_floats_for(const tg_model* m, const tg_score_params* sp) {
+  // largest [N, K] weight-gradient times the maximum split count the launcher may pick (1024 blocks
+  // of 64x64 tiles => at most 1024 * 4096 floats plus tile padding)
+  (void)m; (void)sp;
+  return (size_t)1280 * 4096;
+}
+
+static bool carve_train(const tg_model* m, const tg_score_params* sp, int64_t B, Carver& cv, TrainWs& w) {
+  const int64_t Q = 3 * B, K = m->n_neighbors;
+  const int d = m->d, E = 2 * d, kvw = 2 * d + m->d_e, nh = m->n_head, W = score_width(m, sp);
+  w.rows_cap = std::min<int64_t>(Q * (K + 1), m->n_nodes);
+  w.gates = cv.take<float>((size_t)w.rows_cap * 4 * d);
+  w.P = cv.take<float>((size_t)2 * B * 2 * W);
+  w.T1 = cv.take<float>((size_t)2 * B * d);
+  w.dP = cv.take<float>((size_t)2 * B * 2 * W);
+  w.dH = cv.take<float>((size_t)Q * d);
+  w.dT = cv.take<float>((size_t)Q * d);
+  w.dhh = cv.take<float>((size_t)Q * E);
+  w.dcc = cv.take<float>((size_t)Q * d);
+  w.dO = cv.take<float>((size_t)Q * E);
+  w.dS = cv.take<float>((size_t)Q * nh * kvw);
+  w.dG = cv.take<float>((size_t)Q * nh * kvw);
+  w.dqp = cv.take<float>((size_t)Q * E);
+  w.dreprs = cv.take<float>((size_t)w.rows_cap * d);
+  w.dgi = cv.take<float>((size_t)w.rows_cap * 3 * d);
+  w.dgh = cv.take<float>((size_t)w.rows_cap * 3 * d);
+  w.dqconst = cv.take<float>((size_t)E);
+  w.part_floats = part_floats_for(m, sp);
+  w.part = cv.take<float>(w.part_floats);
+  w.hit_idx = cv.take<int32_t>((size_t)4 * B);
+  return cv.ok;
+}
+
+static size_t train_ws_bytes(const tg_model* m, const tg_score_params* sp, int64_t B) {
+  const size_t Q = 3 * (size_t)B, K = m->n_neighbors;
+  const size_t d = m->d, E = 2 * d, kvw = 2 * d + m->d_e, nh = m->n_head, W = score_width(m, sp);
+  const size_t rows = std::min<size_t>(Q * (K + 1), (size_t)m->n_nodes);
+  return align16(rows * 4 * d * 4) + align16(2 * B * 2 * W * 4) * 2 + align16(2 * B * d * 4) + align16(Q * d * 4) * 3 +
+         align16(Q * E * 4) * 3 + align16(Q * nh * kvw * 4) * 2 + align16(rows * d * 4) + align16(rows * 3 * d * 4) * 2 +
+         align16(E * 4) + align16(part_floats_for(m, sp) * 4) + align16(4 * B * 4) + 256;
+}
+
+static int train_supported(const tg_model* m, const tg_score_params* sp) {
+  if (!attn_dims_ok(m) || !sp) return 0;
+  if (m->tsfm != TG_TSFM_ID || m->upd_fn != TG_UPD_GRU) return 0;
+  if (m->d > NVS * 64) return 0;
+  if ((2 * score_width(m, sp)) % 4) return 0;
+  if (sp->hit_type < TG_HIT_NONE || sp->hit_type > TG_HIT_COUNT) return 0;
+  if ((sp->hit_type == TG_HIT_BIN || sp->hit_type == TG_HIT_COUNT) && (!sp->hit_emb || sp->n_hit_rows <= 0)) return 0;
+  if (sp->hit_type == TG_HIT_COUNT && sp->n_hit_rows < m->n_neighbors + 1) return 0;
+  if (sp->hit_type == TG_HIT_BIN && sp->n_hit_rows < 2) return 0;
+  return 1;
+}
+
+// backward of the contrastive loss; everything it reads is still in the step workspace
+static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w, TrainWs& t, hipStream_t st) {
+  const tg_score_params* sp = io->score;
+  const tg_model* gm = io->grads;
+  const tg_score_params* gs = io->score_grads;
+  const int64_t B = io->step.B, Q = 3 * B;
+  const int d = m->d, d_e = m->d_e, E = 2 * d, kvw = 2 * d + d_e, nh = m->n_head, dh = E / nh, K = m->n_neighbors;
+  const int W = score_width(m, sp), W2 = 2 * W;
+  const int mw = 3 * d + d_e;
+  const float alpha = 1.0f / sqrtf((float)dh);
+  int rc;
+  hipError_t e = hipMemsetAsync(t.dreprs, 0, (size_t)t.rows_cap * d * sizeof(float), st);
+  if (e == hipSuccess) e = hipMemsetAsync(io->losses, 0, 2 * sizeof(float), st);
+  if (e != hipSuccess) {
+    set_hip_error(e, "tg_train_step memset");
+    return TG_EHIP;
+  }
+  auto F = [](const float* p) { return const_cast<float*>(p); };
+  // ---- STEP 7 forward
+  hipLaunchKernelGGL(k_build_pairs, dim3(flat_grid(2 * B, 4)), dim3(256), 0, st, B, d, K, sp->hit_type, io->step.h,
+                     w.nids3, w.l1n, sp->hit_emb, t.P, t.hit_idx);
+  GemmArgs g{};
+  g.m_cap = 2 * B; g.n = d; g.k = W2; g.a0 = ASeg{t.P, W2, W2, nullptr};
+  g.w = sp->fc1.w; g.ldw = W2; g.bias = sp->fc1.b; g.c = t.T1; g.ldc = d; g.relu = 1; g.alpha = 1.f; g.nbatch = 1;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  // fc1 input gradient needs relu(T1) as the mask, and k_score_loss overwrites T1 with dT1: since
+  // dT1 is zero exactly where T1 <= 0, the masked gradient IS dT1 and no copy of T1 is needed
+  hipLaunchKernelGGL(k_score_loss, dim3(std::min<unsigned>(flat_grid(2 * B, 4), 256)), dim3(256), 0, st, B, d, t.T1,
+                     sp->fc2.w, sp->fc2.b, io->pos_scores, io->neg_scores, io->losses, F(gs->fc2.w), F(gs->fc2.b));
+  // ---- STEP 7 backward: score MergeLayer
+  TnArgs tn{};
+  tn.m_cap = 2 * B; tn.n = d; tn.k = W2; tn.y = t.T1; tn.ldy = d; tn.x0 = ASeg{t.P, W2, W2, nullptr};
+  tn.out = F(gs->fc1.w); tn.ldo = W2; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = 1; tn.part = t.part;
+  tn.part_floats = t.part_floats;
+  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  if ((rc = colsum_launch(2 * B, nullptr, d, t.T1, d, 1.f, F(gs->fc1.b), 1, t.part, t.part_floats, st)) != TG_OK) return rc;
+  g = GemmArgs{};
+  g.m_cap = 2 * B; g.n = W2; g.k = d; g.a0 = ASeg{t.T1, d, d, nullptr};
+  g.w = sp->fc1.w; g.ldw = W2; g.w_kmajor = 1; g.c = t.dP; g.ldc = W2; g.alpha = 1.f; g.nbatch = 1;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  const bool emb = sp->hit_type == TG_HIT_BIN || sp->hit_type == TG_HIT_COUNT;
+  const size_t lbytes = emb ? (size_t)sp->n_hit_rows * d * sizeof(float) : 0;
+  if (lbytes > 60 * 1024) return TG_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_pairs_bwd, dim3(std::min<unsigned>(flat_grid(B, 4), 256)), dim3(256), lbytes, st, B, d, W,
+                     sp->hit_type, sp->n_hit_rows, t.dP, t.hit_idx, t.dH, emb ? F(gs->hit_emb) : (float*)nullptr);
+  // ---- embedding merger (basic_modules.py:16-19): z = fc2(relu(fc1([hh | cc])))
+  const AttnWs& a = w.attn;
+  tn = TnArgs{};
+  tn.m_cap = Q; tn.n = d; tn.k = d; tn.y = t.dH; tn.ldy = d; tn.x0 = ASeg{a.t, d, d, nullptr};
+  tn.out = F(gm->attn_fc2.w); tn.ldo = d; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = 1; tn.part = t.part;
+  tn.part_floats = t.part_floats;
+  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  if ((rc = colsum_launch(Q, nullptr, d, t.dH, d, 1.f, F(gm->attn_fc2.b), 1, t.part, t.part_floats, st)) != TG_OK) return rc;
+  g = GemmArgs{};
+  g.m_cap = Q; g.n = d; g.k = d; g.a0 = ASeg{t.dH, d, d, nullptr};
+  g.w = m->attn_fc2.w; g.ldw = d; g.w_kmajor = 1; g.c = t.dT; g.ldc = d; g.alpha = 1.f; g.nbatch = 1;
+  g.relu_mask = a.t; g.ld_mask = d;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  tn = TnArgs{};
+  tn.m_cap = Q; tn.n = d; tn.k = E + d; tn.y = t.dT; tn.ldy = d;
+  tn.x0 = ASeg{a.hh, E, E, nullptr}; tn.x1 = ASeg{a.cc, d, d, nullptr};
+  tn.out = F(gm->attn_fc1.w); tn.ldo = E + d; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = 1; tn.part = t.part;
+  tn.part_floats = t.part_floats;
+  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  if ((rc = colsum_launch(Q, nullptr, d, t.dT, d, 1.f, F(gm->attn_fc1.b), 1, t.part, t.part_floats, st)) != TG_OK) return rc;
+  // d hh (zero for centres without neighbours: their hh was masked) and the direct part of d cc
+  g = GemmArgs{};
+  g.m_cap = Q; g.n = E; g.k = d; g.a0 = ASeg{t.dT, d, d, nullptr};
+  g.w = m->attn_fc1.w; g.ldw = E + d; g.w_kmajor = 1; g.c = t.dhh; g.ldc = E; g.alpha = 1.f; g.nbatch = 1;
+  g.row_valid = a.valid;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  g = GemmArgs{};
+  g.m_cap = Q; g.n = d; g.k = d; g.a0 = ASeg{t.dT, d, d, nullptr};
+  g.w = m->attn_fc1.w + E; g.ldw = E + d; g.w_kmajor = 1; g.c = t.dcc; g.ldc = d; g.alpha = 1.f; g.nbatch = 1;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  // ---- out projection
+  tn = TnArgs{};
+  tn.m_cap = Q; tn.n = E; tn.k = E; tn.y = t.dhh; tn.ldy = E; tn.x0 = ASeg{a.o, E, E, nullptr};
+  tn.out = F(gm->attn_out.w); tn.ldo = E; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = 1; tn.part = t.part;
+  tn.part_floats = t.part_floats;
+  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  if ((rc = colsum_launch(Q, nullptr, E, t.dhh, E, 1.f, F(gm->attn_out.b), 1, t.part, t.part_floats, st)) != TG_OK) return rc;
+  g = GemmArgs{};
+  g.m_cap = Q; g.n = E; g.k = E; g.a0 = ASeg{t.dhh, E, E, nullptr};
+  g.w = m->attn_out.w; g.ldw = E; g.w_kmajor = 1; g.c = t.dO; g.ldc = E; g.alpha = 1.f; g.nbatch = 1;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  // ---- value projection: o_h = Wv_h s_h + bv_h
+  tn = TnArgs{};
+  tn.m_cap = Q; tn.n = dh; tn.k = kvw; tn.y = t.dO; tn.ldy = E; tn.y_bs = dh;
+  tn.x0 = ASeg{a.s, (int64_t)nh * kvw, kvw, nullptr}; tn.x0_bs = kvw;
+  tn.out = F(gm->attn_wv); tn.ldo = kvw; tn.out_bs = (int64_t)dh * kvw; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = nh;
+  tn.part = t.part; tn.part_floats = t.part_floats;
+  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  if ((rc = colsum_launch(Q, nullptr, E, t.dO, E, 1.f, F(gm->attn_b_in) + 2 * E, 1, t.part, t.part_floats, st)) != TG_OK)
+    return rc;
+  g = GemmArgs{};
+  g.m_cap = Q; g.n = kvw; g.k = dh; g.a0 = ASeg{t.dO, E, dh, nullptr}; g.a0_bs = dh;
+  g.w = m->attn_wv; g.ldw = kvw; g.w_kmajor = 1; g.w_bs = (int64_t)dh * kvw;
+  g.c = t.dS; g.ldc = (int64_t)nh * kvw; g.c_bs = kvw; g.alpha = 1.f; g.nbatch = nh;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  // ---- softmax / gather core
+  const int nv = (int)cdiv(std::max(d, d_e) / 4, TG_WAVE);
+  const unsigned cgrid = std::min<unsigned>(flat_grid(Q, 4), 1024);
+#define TG_CORE_BWD(NH_, NV_)                                                                                       \
+  hipLaunchKernelGGL((k_attn_core_bwd<NH_, NV_>), dim3(cgrid), dim3(256), 0, st, *m, Q, w.ts3f, w.l1n, w.l1e, w.l1t, \
+                     (const float4*)w.reprs, w.bm, w.rank, (const float4*)a.g, (const float4*)t.dS, (float4*)t.dG,    \
+                     t.dreprs, F(gm->te_freq), F(gm->te_phase))
+  if (nh == 2 && nv == 1) TG_CORE_BWD(2, 1);
+  else if (nh == 2 && nv == 2) TG_CORE_BWD(2, 2);
+  else if (nh == 1 && nv == 1) TG_CORE_BWD(1, 1);
+  else if (nh == 4 && nv == 1) TG_CORE_BWD(4, 1);
+  else return TG_EUNSUPPORTED;
+#undef TG_CORE_BWD
+  // ---- key projection folded into the query: g_h = Wk_h^T q_h
+  tn = TnArgs{};
+  tn.m_cap = Q; tn.n = dh; tn.k = kvw; tn.y = a.qp; tn.ldy = E; tn.y_bs = dh;
+  tn.x0 = ASeg{t.dG, (int64_t)nh * kvw, kvw, nullptr}; tn.x0_bs = kvw;
+  tn.out = F(gm->attn_wk); tn.ldo = kvw; tn.out_bs = (int64_t)dh * kvw; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = nh;
+  tn.part = t.part; tn.part_floats = t.part_floats;
+  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  g = GemmArgs{};
+  g.m_cap = Q; g.n = dh; g.k = kvw; g.a0 = ASeg{t.dG, (int64_t)nh * kvw, kvw, nullptr}; g.a0_bs = kvw;
+  g.w = m->attn_wk; g.ldw = kvw; g.w_bs = (int64_t)dh * kvw;
+  g.c = t.dqp; g.ldc = E; g.c_bs = dh; g.alpha = 1.f; g.nbatch = nh;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  // ---- query projection: qp = alpha (Wq[:, :d] cc + qconst)
+  tn = TnArgs{};
+  tn.m_cap = Q; tn.n = E; tn.k = d; tn.y = t.dqp; tn.ldy = E; tn.x0 = ASeg{a.cc, d, d, nullptr};
+  tn.out = F(gm->attn_wq); tn.ldo = E; tn.alpha = alpha; tn.accumulate = 1; tn.nbatch = 1; tn.part = t.part;
+  tn.part_floats = t.part_floats;
+  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  if ((rc = colsum_launch(Q, nullptr, E, t.dqp, E, alpha, t.dqconst, 0, t.part, t.part_floats, st)) != TG_OK) return rc;
+  hipLaunchKernelGGL(k_qconst_bwd, dim3((unsigned)cdiv(E, 256)), dim3(256), 0, st, d, t.dqconst, m->attn_wq, m->te_freq,
+                     m->te_phase, F(gm->attn_wq), F(gm->attn_b_in), F(gm->te_phase));
+  g = GemmArgs{};
+  g.m_cap = Q; g.n = d; g.k = E; g.a0 = ASeg{t.dqp, E, E, nullptr};
+  g.w = m->attn_wq; g.ldw = E; g.w_kmajor = 1; g.c = t.dcc; g.ldc = d; g.alpha = alpha; g.nbatch = 1; g.accumulate = 1;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  hipLaunchKernelGGL(k_centre_scatter, dim3(flat_grid(Q * d, 256)), dim3(256), 0, st, Q, d, w.nids3, w.bm, w.rank, t.dcc,
+                     t.dreprs);
+  // ---- GRU
+  hipLaunchKernelGGL(k_gru_bwd, dim3(flat_grid(t.rows_cap * d, 256)), dim3(256), 0, st, *m, t.rows_cap, w.counts + 1,
+                     w.outdated, w.out_pos, t.gates, t.dreprs, t.dgi, t.dgh, io->flags);
+  const float* upd_vals = (m->upd_src == TG_SRC_LEFT) ? m->left_vals : m->right_vals;
+  tn = TnArgs{};
+  tn.m_cap = t.rows_cap; tn.m_dev = w.counts + 1; tn.n = 3 * d; tn.k = mw; tn.y = t.dgi; tn.ldy = 3 * d;
+  tn.x0 = ASeg{m->msg_vals, mw, mw, w.outdated};
+  tn.out = F(gm->gru_w_ih); tn.ldo = mw; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = 1; tn.part = t.part;
+  tn.part_floats = t.part_floats;
+  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  tn.k = d; tn.y = t.dgh; tn.x0 = ASeg{upd_vals, d, d, w.outdated}; tn.out = F(gm->gru_w_hh); tn.ldo = d;
+  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  if ((rc = colsum_launch(t.rows_cap, w.counts + 1, 3 * d, t.dgi, 3 * d, 1.f, F(gm->gru_b_ih), 1, t.part, t.part_floats,
+                          st)) != TG_OK)
+    return rc;
+  if ((rc = colsum_launch(t.rows_cap, w.counts + 1, 3 * d, t.dgh, 3 * d, 1.f, F(gm->gru_b_hh), 1, t.part, t.part_floats,
+                          st)) != TG_OK)
+    return rc;
+  return check_launch("tg_train_step(backward)");
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+extern "C" size_t tg_train_step_workspace_bytes(const tg_model* m, const tg_score_params* sp, int64_t B) {
+  if (!m || !train_supported(m, sp) || B <= 0 || m->n_nodes <= 0) return 0;
+  return tg_stream_step_workspace_bytes(m, B) + train_ws_bytes(m, sp, B);
+}
+
+extern "C" int tg_train_step(const tg_model* m, const tg_tcsr* g, const tg_train_io* io, void* ws, size_t ws_bytes,
+                             void* stream) {
+  if (!m || !g || !io || !io->score || !io->grads || !io->score_grads || !io->losses) return TG_EINVAL;
+  if (!train_supported(m, io->score)) return TG_EUNSUPPORTED;
+  const tg_step_io* sio = &io->step;
+  if (sio->B <= 0 || !sio->src || !sio->dst || !sio->neg || !sio->ts || !sio->eids || !sio->h || !sio->err) return TG_EINVAL;
+  if (sio->embed_only || g->num_node != m->n_nodes) return TG_EINVAL;
+  hipStream_t st = as_stream(stream);
+  Carver cv(ws, ws_bytes);
+  StepWs w{};
+  TrainWs t{};
+  if (!carve_step(m, sio->B, cv, w) || !carve_train(m, io->score, sio->B, cv, t)) return TG_EWORKSPACE;
+  int rc;
+  if ((rc = step_forward(m, g, sio, w, t.gates, st, nullptr)) != TG_OK) return rc;
+  if ((rc = contrast_backward(m, io, w, t, st)) != TG_OK) return rc;
+  if ((rc = step_writeback_a(m, sio, w, st, nullptr)) != TG_OK) return rc;
+  return step_writeback_b(m, sio, w, st, nullptr);
+}
+
+extern "C" int tg_adam_step(const tg_adam_seg* segs_dev, int32_t n_segs, int32_t n_groups, const int32_t* enabled_dev,
+                            int32_t* steps_dev, float lr, float beta1, float beta2, float eps, float grad_scale,
+                            void* stream) {
+  if (!segs_dev || n_segs <= 0 || n_groups <= 0 || !steps_dev) return TG_EINVAL;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(k_adam_tick, dim3((unsigned)cdiv(n_groups, 64)), dim3(64), 0, st, n_groups, enabled_dev, steps_dev);
+  hipLaunchKernelGGL(k_adam, dim3(32, (unsigned)n_segs), dim3(256), 0, st, segs_dev, enabled_dev, steps_dev, lr, beta1, beta2,
+                     eps, grad_scale);
+  return check_launch("tg_adam_step");
+}

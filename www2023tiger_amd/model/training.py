@@ -1,0 +1,209 @@
+"""Training tail on device: one call per iteration of the reference's training loop
+(train_self_supervised.py:143-171) - collate, STEP 1-7, backward, write-back
+(`tg_train_step`) and `torch.optim.Adam` (`tg_adam_step`).
+
+Two ways in:
+
+* `TIGE.contrast_learning` / `TIGER.contrast_and_mutual_learning` in training mode return loss
+  tensors that carry an autograd node: `loss.backward()` hands the gradients computed by the
+  HIP backward pass to the parameters' `.grad`, so the reference's loop and any torch optimiser
+  run unchanged.
+* `FusedTrainer.step` keeps gradients and Adam state in flat device buffers and enqueues the
+  whole iteration without touching the host (graph-capturable; the bench's training leg).
+"""
+import ctypes as C
+from typing import List, Tuple
+
+import torch
+from torch import Tensor
+
+from .._lib import (TgAdamSeg, TgLinear, TgModel, TgScoreParams, TgStepIo, TgTrainIo, check, lib, ptr)
+from ..hip_ops import stream_ptr
+
+_HIT = {'none': 0, 'vec': 1, 'bin': 2, 'count': 3}
+
+
+def contrast_parameters(model) -> List[Tuple[str, Tensor, int]]:
+    """(state_dict name, parameter, Adam group) of everything the contrastive loss trains.
+    Groups follow tg_train_io.flags: 0 always has a gradient, 1 only when the GRU ran."""
+    att = model.temporal_embedding_fn.fns[0]
+    mha = att.mha_fn
+    cell = model.right_mem_updater.cell
+    pre = 'temporal_embedding_fn.fns.0.'
+    out = [
+        ('time_encoder.basis_freq', model.time_encoder.basis_freq, 0),
+        ('time_encoder.phase', model.time_encoder.phase, 0),
+        ('right_mem_updater.cell.weight_ih', cell.weight_ih, 1),
+        ('right_mem_updater.cell.weight_hh', cell.weight_hh, 1),
+        ('right_mem_updater.cell.bias_ih', cell.bias_ih, 1),
+        ('right_mem_updater.cell.bias_hh', cell.bias_hh, 1),
+        (pre + 'mha_fn.q_proj_weight', mha.q_proj_weight, 0),
+        (pre + 'mha_fn.k_proj_weight', mha.k_proj_weight, 0),
+        (pre + 'mha_fn.v_proj_weight', mha.v_proj_weight, 0),
+        (pre + 'mha_fn.in_proj_bias', mha.in_proj_bias, 0),
+        (pre + 'mha_fn.out_proj.weight', mha.out_proj.weight, 0),
+        (pre + 'mha_fn.out_proj.bias', mha.out_proj.bias, 0),
+        (pre + 'merger.fc1.weight', att.merger.fc1.weight, 0),
+        (pre + 'merger.fc1.bias', att.merger.fc1.bias, 0),
+        (pre + 'merger.fc2.weight', att.merger.fc2.weight, 0),
+        (pre + 'merger.fc2.bias', att.merger.fc2.bias, 0),
+        ('score_fn.fc1.weight', model.score_fn.fc1.weight, 0),
+        ('score_fn.fc1.bias', model.score_fn.fc1.bias, 0),
+        ('score_fn.fc2.weight', model.score_fn.fc2.weight, 0),
+        ('score_fn.fc2.bias', model.score_fn.fc2.bias, 0),
+    ]
+    if model.hit_type in ('bin', 'count'):
+        out.append(('hit_embedding.weight', model.hit_embedding.weight, 0))
+    return out
+
+
+def score_struct(model, tensors=None) -> TgScoreParams:
+    """tg_score_params over the model's score head, or over same-named gradient views."""
+    t = tensors or {n: p for n, p, _ in contrast_parameters(model)}
+    emb = t.get('hit_embedding.weight')
+    return TgScoreParams(_HIT[model.hit_type], 0 if emb is None else emb.shape[0], ptr(emb),
+                         TgLinear(ptr(t['score_fn.fc1.weight']), ptr(t['score_fn.fc1.bias'])),
+                         TgLinear(ptr(t['score_fn.fc2.weight']), ptr(t['score_fn.fc2.bias'])))
+
+
+def grads_struct(model, g) -> TgModel:
+    """A tg_model whose parameter pointers address gradient buffers (sizes copied, state NULL)."""
+    m = model.model_struct()
+    pre = 'temporal_embedding_fn.fns.0.'
+    nul = TgLinear(None, None)
+    return TgModel(m.n_nodes, m.d, m.d_e, m.n_neighbors, m.n_head, m.msg_src, m.upd_src, m.tsfm, m.upd_fn,
+                   None, None, None, None, None, None, None, None, None, None, None,
+                   ptr(g['time_encoder.basis_freq']), ptr(g['time_encoder.phase']), nul, nul,
+                   ptr(g['right_mem_updater.cell.weight_ih']), ptr(g['right_mem_updater.cell.weight_hh']),
+                   ptr(g['right_mem_updater.cell.bias_ih']), ptr(g['right_mem_updater.cell.bias_hh']), nul, nul,
+                   ptr(g[pre + 'mha_fn.q_proj_weight']), ptr(g[pre + 'mha_fn.k_proj_weight']),
+                   ptr(g[pre + 'mha_fn.v_proj_weight']), ptr(g[pre + 'mha_fn.in_proj_bias']),
+                   TgLinear(ptr(g[pre + 'mha_fn.out_proj.weight']), ptr(g[pre + 'mha_fn.out_proj.bias'])),
+                   TgLinear(ptr(g[pre + 'merger.fc1.weight']), ptr(g[pre + 'merger.fc1.bias'])),
+                   TgLinear(ptr(g[pre + 'merger.fc2.weight']), ptr(g[pre + 'merger.fc2.bias'])))
+
+
+def check_trainable(model):
+    if model.msg_tsfm_type != 'id' or model.mem_update_type != 'gru':
+        raise NotImplementedError("training on device supports msg_tsfm_type='id' with mem_update_type='gru'")
+    if model.n_layers != 1:
+        raise NotImplementedError('training on device supports n_layers == 1')
+    drops = [model.score_fn.dropout.p, model.temporal_embedding_fn.fns[0].merger.dropout.p,
+             model.temporal_embedding_fn.fns[0].mha_fn.dropout]
+    if any(p > 0 for p in drops):
+        raise NotImplementedError('training on device runs without dropout: build the model with dropout=0')
+
+
+class TrainBuffers:
+    """Static buffers of one batch size for tg_train_step: the step's inputs/outputs
+    (a TIGE.StepBuffers), flat gradient storage with one view per parameter, losses, scores."""
+
+    def __init__(self, model, B: int, resident=None):
+        check_trainable(model)
+        dev = model.device
+        self.model, self.B = model, B
+        self.sb = model.StepBuffers(model, B, want_prev=True, resident=resident)
+        self.params = contrast_parameters(model)
+        n = sum(p.numel() for _, p, _ in self.params)
+        self.gflat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grads, o = {}, 0
+        for name, p, _ in self.params:
+            self.grads[name] = self.gflat[o:o + p.numel()].view_as(p)
+            o += p.numel()
+        self.losses = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.pos_scores = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.neg_scores = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.flags = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.refresh()
+
+    def refresh(self):
+        """(Re)build the C structs; call again when parameters or state tensors were re-homed."""
+        model, B = self.model, self.B
+        self._score = score_struct(model)
+        self._gmodel = grads_struct(model, self.grads)
+        self._gscore = score_struct(model, self.grads)
+        m = model.model_struct()
+        nbytes = int(lib.tg_train_step_workspace_bytes(C.byref(m), C.byref(self._score), B))
+        if nbytes == 0:
+            raise RuntimeError('tg_train_step: unsupported model configuration')
+        if getattr(self, 'ws', None) is None or self.ws.numel() < nbytes:
+            self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=model.device)
+        io = TgTrainIo()
+        C.memmove(C.addressof(io.step), C.addressof(self.sb.io), C.sizeof(TgStepIo))
+        io.score = C.addressof(self._score)
+        io.grads = C.addressof(self._gmodel)
+        io.score_grads = C.addressof(self._gscore)
+        io.losses, io.pos_scores, io.neg_scores = ptr(self.losses), ptr(self.pos_scores), ptr(self.neg_scores)
+        io.flags = ptr(self.flags)
+        self.io = io
+
+    def launch(self, zero_grads: bool = True):
+        """Enqueue forward + STEP 7 + backward + write-back for the batch in `sb` (no host sync)."""
+        model = self.model
+        if zero_grads:
+            self.gflat.zero_()
+        m = model.model_struct()
+        g = model.graph.tcsr
+        check(lib.tg_train_step(C.byref(m), C.byref(g), C.byref(self.io), ptr(self.ws), self.ws.numel(),
+                                stream_ptr(model.device)), 'tg_train_step')
+
+
+class _HandOver(torch.autograd.Function):
+    """Connects the losses computed by tg_train_step to autograd: backward returns the gradients
+    the HIP backward pass already produced, scaled by the incoming loss gradient."""
+
+    @staticmethod
+    def forward(ctx, losses, grads, *params):
+        ctx.grads = grads
+        return losses.clone()
+
+    @staticmethod
+    def backward(ctx, g_losses):
+        # grads is a list of (gradient view, index of the loss it belongs to)
+        out = tuple(g * g_losses[k] for g, k in ctx.grads)
+        return (None, None) + out
+
+
+def hand_over(losses: Tensor, grads: List[Tuple[Tensor, int]], params: List[Tensor]) -> Tensor:
+    return _HandOver.apply(losses, grads, *params)
+
+
+class FusedTrainer:
+    """The training loop's device work with no host round trip per iteration: tg_train_step then
+    tg_adam_step over flat parameter-gradient / moment buffers."""
+
+    def __init__(self, model, B: int, *, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, resident=None):
+        self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
+        self.buf = TrainBuffers(model, B, resident=resident)
+        dev = model.device
+        n = self.buf.gflat.numel()
+        self.m1 = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m2 = torch.zeros(n, dtype=torch.float32, device=dev)
+        segs = (TgAdamSeg * len(self.buf.params))()
+        o = 0
+        for i, (name, p, group) in enumerate(self.buf.params):
+            k = p.numel()
+            segs[i] = TgAdamSeg(ptr(p), ptr(self.buf.grads[name]), self.m1[o:o + k].data_ptr(),
+                                self.m2[o:o + k].data_ptr(), k, group, 0)
+            o += k
+        raw = bytes(segs)
+        self.segs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.n_segs = len(self.buf.params)
+        self.steps = torch.zeros(4, dtype=torch.int32, device=dev)
+
+    def load(self, src, dst, neg, ts, eids):
+        dev = self.model.device
+        to = lambda x, dt: torch.as_tensor(x).to(dev, dt)
+        self.buf.sb.load(to(src, torch.int64), to(dst, torch.int64), to(neg, torch.int64), to(ts, torch.float64),
+                         to(eids, torch.int64))
+
+    def launch(self):
+        self.buf.launch()
+        check(lib.tg_adam_step(ptr(self.segs), self.n_segs, 4, ptr(self.buf.flags), ptr(self.steps), self.lr,
+                               self.betas[0], self.betas[1], self.eps, 1.0, stream_ptr(self.model.device)),
+              'tg_adam_step')
+
+    def step(self, src, dst, neg, ts, eids):
+        self.load(src, dst, neg, ts, eids)
+        self.launch()
+        return self.buf.losses
