@@ -72,7 +72,7 @@ def make_stream(n_u, n_i, E, T, seed=0, d_e=172, integer_ts=True, with_efeats=Tr
 
 
 def build_models(stream, d, K, msg_src, upd_src, restarter='static', hist_len=40, with_oracle=False, device='cuda:0',
-                 zero_nfeats=True, seed=0):
+                 zero_nfeats=True, seed=0, dropout=0.1):
     """HIP model (reference initialisers under torch.manual_seed) and, optionally, the CPU
     oracle carrying the very same weights."""
     from www2023tiger_amd.data.graph import Graph
@@ -91,11 +91,11 @@ def build_models(stream, d, K, msg_src, upd_src, restarter='static', hist_len=40
                               None if efeats is None else torch.from_numpy(efeats).to(dev), dim=d, device=dev)
         fg.n_nodes, fg.n_edges = n_nodes, len(stream['src'])
         if restarter == 'seq':
-            rst = SeqRestarter(raw_feat_getter=fg, graph=g, hist_len=hist_len, n_head=2, dropout=0.1)
+            rst = SeqRestarter(raw_feat_getter=fg, graph=g, hist_len=hist_len, n_head=2, dropout=dropout)
         else:
             rst = StaticRestarter(raw_feat_getter=fg, graph=g)
         model = TIGER(raw_feat_getter=fg, graph=g, restarter=rst, n_neighbors=K, hit_type='bin', n_layers=1, n_head=2,
-                      dropout=0.1, msg_src=msg_src, upd_src=upd_src)
+                      dropout=dropout, msg_src=msg_src, upd_src=upd_src)
         with torch.no_grad():  # non-trivial time-encoder phase so the cos path is exercised
             model.time_encoder.phase.uniform_(-0.5, 0.5)
     model = model.to(dev).eval()
@@ -160,6 +160,56 @@ def profile_stages(model, buf, steps):
     return names, acc / steps, counts / steps
 
 
+def train_main(args, cfg):
+    """--train: the training iteration of train_self_supervised.py:143-171 (contrast loss only,
+    restart_prob == 0) as tg_train_step + tg_adam_step on the resident stream.  Not the headline
+    metric; reported next to it in DESIGN.md."""
+    from www2023tiger_amd.model.training import FusedTrainer
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    B, K, d = cfg['B'], cfg['K'], cfg['d']
+    E = max(cfg['E'], (args.warmup + args.steps + 4) * B)
+    no_feats = bool(cfg.get('no_feats'))
+    stream = make_stream(cfg['n_u'], cfg['n_i'], E, cfg['T'] * E / cfg['E'], seed=0, d_e=d,
+                         integer_ts=cfg.get('integer_ts', True), with_efeats=not no_feats)
+    model, _ = build_models(stream, d, K, cfg['msg_src'], cfg['upd_src'], restarter='static', device='cuda:0',
+                            zero_nfeats=not no_feats, dropout=0.0)
+    model.train()
+    resident = tuple(torch.from_numpy(stream[k]).to(dev) for k in ('src', 'dst', 'neg', 'ts', 'eids'))
+    tr = FusedTrainer(model, B, lr=1e-4, resident=resident)
+    for _ in range(args.warmup):
+        tr.launch()
+    torch.cuda.synchronize()
+    assert int(tr.buf.sb.err.item()) == 0
+    graph = None
+    if not args.no_graph:
+        side = torch.cuda.Stream()
+        off0 = tr.buf.sb.offset.clone()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            tr.launch()
+        tr.buf.sb.offset.copy_(off0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if graph is not None:
+            graph.replay()
+        else:
+            tr.launch()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert int(tr.buf.sb.err.item()) == 0
+    assert int(tr.buf.sb.offset.item()) == (args.warmup + args.steps) * B
+    loss = float(tr.buf.losses[0])
+    assert np.isfinite(loss)
+    print(json.dumps(dict(metric='training interaction-events/sec (collate + STEP 1-7 + backward + Adam, contrast loss)',
+                          value=args.steps * B / dt, unit='events/s', n_gpus=1, steps=args.steps, warmup=args.warmup,
+                          ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='weak', vs_baseline=None,
+                          dtype='f32', data='synthetic',
+                          config=dict(workload=cfg['name'], batch=B, dim=d, n_neighbors=K, mode='train (contrast only)',
+                                      launch='hipGraph replay' if graph is not None else 'eager', last_loss=loss))))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -171,8 +221,11 @@ def main():
     ap.add_argument('--force-dist', action='store_true', help='run the multi-GPU code path even with one rank')
     ap.add_argument('--dist-graphs', action='store_true',
                     help='multi-GPU: replay captured hipGraphs around the all-gather (experimental; default eager)')
+    ap.add_argument('--train', action='store_true', help='measure the training iteration instead (not the headline metric)')
     args = ap.parse_args()
     cfg = dict(WORKLOADS[args.workload])
+    if args.train:
+        return train_main(args, cfg)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

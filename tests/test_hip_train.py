@@ -90,3 +90,32 @@ def test_fused_trainer_follows_reference_trajectory():
             continue
         assert rel_err(p.detach().cpu().numpy(), z[f'final.{k}']) < 2e-3, k
     assert rel_err(model.left_memory.vals.cpu().numpy(), z['final_left_vals']) < 1e-3
+
+
+def test_c2_shape_gradients_match_oracle():
+    """d=172, B=1024, K=10 (BASELINE configs[1] shapes) after a few streaming batches: every
+    gradient against the oracle's autograd."""
+    import bench
+    from oracle import tiger_oracle as O
+    from www2023tiger_amd.model.training import TrainBuffers
+    B = 1024
+    st = bench.make_stream(2000, 300, 6 * B, 6.0e4, seed=3, d_e=172)
+    model, orc = bench.build_models(st, 172, 10, 'left', 'left', with_oracle=True, dropout=0.0)
+    model.train()
+    tb = TrainBuffers(model, B)
+    to = lambda x, dt: torch.as_tensor(x).to(dev(), dt)
+    for b in range(5):
+        a = [st[k][b * B:(b + 1) * B] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], 10, 'static')
+        if b < 4:  # stream forward on both sides
+            orc.stream_step(*a, cg)
+            model.stream_step(*a)
+            continue
+        c, _, grads = orc.train_step(*a, cg, lr=1e-3, contrast_only=True)
+        tb.sb.load(to(a[0], torch.int64), to(a[1], torch.int64), to(a[2], torch.int64), to(a[3], torch.float64),
+                   to(a[4], torch.int64))
+        tb.launch()
+        assert int(tb.sb.err.item()) == 0
+        assert abs(float(tb.losses[0]) - c) < TOL * max(1.0, abs(c))
+        worst = max((grad_err(g.cpu().numpy(), grads[k].numpy()), k) for k, g in tb.grads.items())
+        assert worst[0] < 3e-4, worst
