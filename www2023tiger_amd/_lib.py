@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libtiger_hip.so')
+LIB_PATH = os.environ.get('TIGER_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libtiger_hip.so')  # override: experiments only
 
 TG_OK, TG_EINVAL, TG_EUNSUPPORTED, TG_EWORKSPACE, TG_EHIP = 0, -1, -2, -3, -4
 ERR_PAST_MEMORY, ERR_DUPLICATE_IDS, ERR_UNUSED_MESSAGE = 1, 2, 4

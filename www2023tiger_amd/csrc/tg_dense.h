@@ -78,6 +78,10 @@ struct TnArgs {
   int64_t y_bs, x0_bs, out_bs;
   float* part;
   size_t part_floats;  // capacity of `part`
+  // optional column sums of Y from the same pass: bias_out[bz * bias_bs + n] (+)= alpha * sum_m Y[m, n]
+  float* bias_out;
+  int bias_accumulate;
+  int64_t bias_bs;
 };
 int gemm_tn_launch(const TnArgs& a, hipStream_t st);
 // out[n] (+)= alpha * sum_m Y[m, n]

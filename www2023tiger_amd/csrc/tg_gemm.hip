@@ -487,6 +487,8 @@ __global__ void __launch_bounds__(256) k_gemm_tn(TnArgs a, int splits) {
       *reinterpret_cast<float4*>(&Xs[buf][sr + i * 16][sc]) = (live && xin) ? rx[i] : zero4();
     }
   };
+  const bool do_bias = a.bias_out && kt == 0 && tid < TN_T;  // column sums of Y ride on the k-tile-0 blocks
+  float bsum = 0.f;
   if (m_lo < m_hi) {
     load_chunk(m_lo);
     store_chunk(0, m_lo);
@@ -500,6 +502,10 @@ __global__ void __launch_bounds__(256) k_gemm_tn(TnArgs a, int splits) {
 #pragma unroll
       for (int s2 = 0; s2 < TN_MC / 2; ++s2)
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yp[s2 * 2 * TN_LD], xp[s2 * 2 * TN_LD], acc, 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int r = 0; r < TN_MC; ++r) bsum += Ys[buf][r][tid];
+      }
       if (more) store_chunk(buf ^ 1, mb + TN_MC);
       __syncthreads();
       buf ^= 1;
@@ -515,6 +521,10 @@ __global__ void __launch_bounds__(256) k_gemm_tn(TnArgs a, int splits) {
       if (n < a.n) pp[(int64_t)n * a.k + kk] = acc[r];
     }
   }
+  if (do_bias && n0 + tid < a.n) {
+    float* bp = a.part + (int64_t)splits * a.nbatch * a.n * a.k;  // bias partials follow the weight partials
+    bp[((int64_t)sp * a.nbatch + bz) * a.n + n0 + tid] = bsum;
+  }
 }
 
 __global__ void k_tn_reduce(TnArgs a, int splits) {
@@ -527,6 +537,18 @@ __global__ void k_tn_reduce(TnArgs a, int splits) {
     float* o = a.out + (int64_t)bz * a.out_bs + (e / a.k) * a.ldo + (e % a.k);
     *o = a.alpha * s + (a.accumulate ? *o : 0.f);
   }
+  if (a.bias_out) {
+    const float* bp = a.part + (int64_t)splits * a.nbatch * per;
+    const int64_t tb = (int64_t)a.n * a.nbatch;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < tb; t += (int64_t)gridDim.x * blockDim.x) {
+      const int bz = (int)(t / a.n);
+      const int n = (int)(t - (int64_t)bz * a.n);
+      float s = 0.f;
+      for (int sp = 0; sp < splits; ++sp) s += bp[((int64_t)sp * a.nbatch + bz) * a.n + n];
+      float* o = a.bias_out + (int64_t)bz * a.bias_bs + n;
+      *o = a.alpha * s + (a.bias_accumulate ? *o : 0.f);
+    }
+  }
 }
 
 int gemm_tn_launch(const TnArgs& a, hipStream_t st) {
@@ -535,8 +557,9 @@ int gemm_tn_launch(const TnArgs& a, hipStream_t st) {
   if (a.x0.w + (a.x1.p ? a.x1.w : 0) != a.k) return TG_EINVAL;
   const int NT = (int)cdiv(a.n, TN_T), KT = (int)cdiv(a.k, TN_T);
   const int64_t tiles = (int64_t)NT * KT * a.nbatch;
-  int64_t splits = std::max<int64_t>(1, std::min<int64_t>(cdiv(1024, tiles), cdiv(a.m_cap, 2 * TN_MC)));
-  const int64_t fit = (int64_t)(a.part_floats / ((size_t)a.nbatch * a.n * a.k));
+  // enough blocks to fill the chip, but a short fixed-order reduction (k_tn_reduce walks the splits serially)
+  int64_t splits = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(cdiv(768, tiles), 16), cdiv(a.m_cap, 2 * TN_MC)));
+  const int64_t fit = (int64_t)(a.part_floats / ((size_t)a.nbatch * a.n * (a.k + 1)));
   if (fit < 1) return TG_EWORKSPACE;
   splits = std::min(splits, fit);
   hipLaunchKernelGGL(k_gemm_tn, dim3((unsigned)(tiles * splits)), dim3(256), 0, st, a, (int)splits);
@@ -575,7 +598,7 @@ int colsum_launch(int64_t m_cap, const int32_t* m_dev, int n, const float* y, in
                   int accumulate, float* part, size_t part_floats, hipStream_t st) {
   if (m_cap <= 0 || n <= 0) return TG_OK;
   const int ct = (n + 63) / 64;
-  int64_t splits = std::max<int64_t>(1, std::min<int64_t>(cdiv(512, ct), cdiv(m_cap, 64)));
+  int64_t splits = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(cdiv(512, ct), 16), cdiv(m_cap, 64)));
   splits = std::min<int64_t>(splits, (int64_t)(part_floats / (size_t)n));
   if (splits < 1) return TG_EWORKSPACE;
   hipLaunchKernelGGL(k_colsum, dim3((unsigned)(ct * splits)), dim3(256), 0, st, m_cap, m_dev, n, y, ldy, part, (int)splits);

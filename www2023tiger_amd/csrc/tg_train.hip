@@ -441,18 +441,27 @@ __global__ void __launch_bounds__(256) k_qconst_bwd(int d, const float* __restri
                                                     const float* __restrict__ wq, const float* __restrict__ freq,
                                                     const float* __restrict__ phase, float* __restrict__ dwq,
                                                     float* __restrict__ dbq, float* __restrict__ dphase) {
+  // grid = (column blocks of 64, row slices): thread (c, rg) walks rows n = slice start + rg, +4, ...
+  __shared__ float red[4][64];
   const int E = 2 * d;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < E) dbq[j] += dqconst[j];
-  if (j >= d) return;
-  const float c = time_enc(0.f, freq[j], phase[j]), s = time_enc_sin(0.f, freq[j], phase[j]);
-  float acc = 0.f;
-  for (int n = 0; n < E; ++n) {
-    const float dq = dqconst[n];
-    dwq[(int64_t)n * E + d + j] += dq * c;
-    acc = fmaf(dq, wq[(int64_t)n * E + d + j], acc);
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  const int per = (E + gridDim.y - 1) / gridDim.y;
+  const int n_lo = blockIdx.y * per, n_hi = min(E, n_lo + per);
+  if (blockIdx.x == 0)
+    for (int n = n_lo + threadIdx.x; n < n_hi; n += 256) dbq[n] += dqconst[n];
+  float acc = 0.f, c = 0.f, s = 0.f;
+  if (j < d) {
+    c = time_enc(0.f, freq[j], phase[j]);
+    s = time_enc_sin(0.f, freq[j], phase[j]);
+    for (int n = n_lo + rg; n < n_hi; n += 4) {
+      const float dq = dqconst[n];
+      dwq[(int64_t)n * E + d + j] += dq * c;
+      acc = fmaf(dq, wq[(int64_t)n * E + d + j], acc);
+    }
   }
-  atomicAdd(dphase + j, -s * acc);
+  red[rg][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rg == 0 && j < d) atomicAdd(dphase + j, -s * (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
 // ---------------------------------------------------------------------------------
@@ -500,10 +509,16 @@ __global__ void __launch_bounds__(256) k_adam(const tg_adam_seg* __restrict__ se
                                               float gscale) {
   const tg_adam_seg sg = segs[blockIdx.y];
   if (enabled && !enabled[sg.group]) return;
-  // bias corrections in double, as the Python scalars of torch.optim.Adam
-  const double t = (double)steps[sg.group];
-  const double bc1 = 1.0 - pow((double)b1, t), bc2 = 1.0 - pow((double)b2, t);
-  const float step_size = (float)((double)lr / bc1), bc2s = (float)sqrt(bc2);
+  if ((int64_t)blockIdx.x * blockDim.x >= sg.n) return;
+  __shared__ float sh[2];
+  if (threadIdx.x == 0) {  // bias corrections in double, as the Python scalars of torch.optim.Adam
+    const double t = (double)steps[sg.group];
+    const double bc1 = 1.0 - pow((double)b1, t), bc2 = 1.0 - pow((double)b2, t);
+    sh[0] = (float)((double)lr / bc1);
+    sh[1] = (float)sqrt(bc2);
+  }
+  __syncthreads();
+  const float step_size = sh[0], bc2s = sh[1];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < sg.n; i += (int64_t)gridDim.x * blockDim.x) {
     const float g = sg.g[i] * gscale;
     const float mm = sg.m[i] + (g - sg.m[i]) * (1.f - b1);  // exp_avg.lerp_(grad, 1 - beta1)
@@ -615,9 +630,8 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
   TnArgs tn{};
   tn.m_cap = 2 * B; tn.n = d; tn.k = W2; tn.y = t.T1; tn.ldy = d; tn.x0 = ASeg{t.P, W2, W2, nullptr};
   tn.out = F(gs->fc1.w); tn.ldo = W2; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = 1; tn.part = t.part;
-  tn.part_floats = t.part_floats;
+  tn.part_floats = t.part_floats; tn.bias_out = F(gs->fc1.b); tn.bias_accumulate = 1;
   if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
-  if ((rc = colsum_launch(2 * B, nullptr, d, t.T1, d, 1.f, F(gs->fc1.b), 1, t.part, t.part_floats, st)) != TG_OK) return rc;
   g = GemmArgs{};
   g.m_cap = 2 * B; g.n = W2; g.k = d; g.a0 = ASeg{t.T1, d, d, nullptr};
   g.w = sp->fc1.w; g.ldw = W2; g.w_kmajor = 1; g.c = t.dP; g.ldc = W2; g.alpha = 1.f; g.nbatch = 1;
@@ -632,9 +646,8 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
   tn = TnArgs{};
   tn.m_cap = Q; tn.n = d; tn.k = d; tn.y = t.dH; tn.ldy = d; tn.x0 = ASeg{a.t, d, d, nullptr};
   tn.out = F(gm->attn_fc2.w); tn.ldo = d; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = 1; tn.part = t.part;
-  tn.part_floats = t.part_floats;
+  tn.part_floats = t.part_floats; tn.bias_out = F(gm->attn_fc2.b); tn.bias_accumulate = 1;
   if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
-  if ((rc = colsum_launch(Q, nullptr, d, t.dH, d, 1.f, F(gm->attn_fc2.b), 1, t.part, t.part_floats, st)) != TG_OK) return rc;
   g = GemmArgs{};
   g.m_cap = Q; g.n = d; g.k = d; g.a0 = ASeg{t.dH, d, d, nullptr};
   g.w = m->attn_fc2.w; g.ldw = d; g.w_kmajor = 1; g.c = t.dT; g.ldc = d; g.alpha = 1.f; g.nbatch = 1;
@@ -644,9 +657,8 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
   tn.m_cap = Q; tn.n = d; tn.k = E + d; tn.y = t.dT; tn.ldy = d;
   tn.x0 = ASeg{a.hh, E, E, nullptr}; tn.x1 = ASeg{a.cc, d, d, nullptr};
   tn.out = F(gm->attn_fc1.w); tn.ldo = E + d; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = 1; tn.part = t.part;
-  tn.part_floats = t.part_floats;
+  tn.part_floats = t.part_floats; tn.bias_out = F(gm->attn_fc1.b); tn.bias_accumulate = 1;
   if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
-  if ((rc = colsum_launch(Q, nullptr, d, t.dT, d, 1.f, F(gm->attn_fc1.b), 1, t.part, t.part_floats, st)) != TG_OK) return rc;
   // d hh (zero for centres without neighbours: their hh was masked) and the direct part of d cc
   g = GemmArgs{};
   g.m_cap = Q; g.n = E; g.k = d; g.a0 = ASeg{t.dT, d, d, nullptr};
@@ -661,9 +673,8 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
   tn = TnArgs{};
   tn.m_cap = Q; tn.n = E; tn.k = E; tn.y = t.dhh; tn.ldy = E; tn.x0 = ASeg{a.o, E, E, nullptr};
   tn.out = F(gm->attn_out.w); tn.ldo = E; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = 1; tn.part = t.part;
-  tn.part_floats = t.part_floats;
+  tn.part_floats = t.part_floats; tn.bias_out = F(gm->attn_out.b); tn.bias_accumulate = 1;
   if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
-  if ((rc = colsum_launch(Q, nullptr, E, t.dhh, E, 1.f, F(gm->attn_out.b), 1, t.part, t.part_floats, st)) != TG_OK) return rc;
   g = GemmArgs{};
   g.m_cap = Q; g.n = E; g.k = E; g.a0 = ASeg{t.dhh, E, E, nullptr};
   g.w = m->attn_out.w; g.ldw = E; g.w_kmajor = 1; g.c = t.dO; g.ldc = E; g.alpha = 1.f; g.nbatch = 1;
@@ -674,9 +685,8 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
   tn.x0 = ASeg{a.s, (int64_t)nh * kvw, kvw, nullptr}; tn.x0_bs = kvw;
   tn.out = F(gm->attn_wv); tn.ldo = kvw; tn.out_bs = (int64_t)dh * kvw; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = nh;
   tn.part = t.part; tn.part_floats = t.part_floats;
+  tn.bias_out = F(gm->attn_b_in) + 2 * E; tn.bias_accumulate = 1; tn.bias_bs = dh;
   if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
-  if ((rc = colsum_launch(Q, nullptr, E, t.dO, E, 1.f, F(gm->attn_b_in) + 2 * E, 1, t.part, t.part_floats, st)) != TG_OK)
-    return rc;
   g = GemmArgs{};
   g.m_cap = Q; g.n = kvw; g.k = dh; g.a0 = ASeg{t.dO, E, dh, nullptr}; g.a0_bs = dh;
   g.w = m->attn_wv; g.ldw = kvw; g.w_kmajor = 1; g.w_bs = (int64_t)dh * kvw;
@@ -711,10 +721,9 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
   tn = TnArgs{};
   tn.m_cap = Q; tn.n = E; tn.k = d; tn.y = t.dqp; tn.ldy = E; tn.x0 = ASeg{a.cc, d, d, nullptr};
   tn.out = F(gm->attn_wq); tn.ldo = E; tn.alpha = alpha; tn.accumulate = 1; tn.nbatch = 1; tn.part = t.part;
-  tn.part_floats = t.part_floats;
+  tn.part_floats = t.part_floats; tn.bias_out = t.dqconst; tn.bias_accumulate = 0;
   if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
-  if ((rc = colsum_launch(Q, nullptr, E, t.dqp, E, alpha, t.dqconst, 0, t.part, t.part_floats, st)) != TG_OK) return rc;
-  hipLaunchKernelGGL(k_qconst_bwd, dim3((unsigned)cdiv(E, 256)), dim3(256), 0, st, d, t.dqconst, m->attn_wq, m->te_freq,
+  hipLaunchKernelGGL(k_qconst_bwd, dim3((unsigned)cdiv(d, 64), 16), dim3(256), 0, st, d, t.dqconst, m->attn_wq, m->te_freq,
                      m->te_phase, F(gm->attn_wq), F(gm->attn_b_in), F(gm->te_phase));
   g = GemmArgs{};
   g.m_cap = Q; g.n = d; g.k = E; g.a0 = ASeg{t.dqp, E, E, nullptr};
@@ -730,16 +739,11 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
   tn.m_cap = t.rows_cap; tn.m_dev = w.counts + 1; tn.n = 3 * d; tn.k = mw; tn.y = t.dgi; tn.ldy = 3 * d;
   tn.x0 = ASeg{m->msg_vals, mw, mw, w.outdated};
   tn.out = F(gm->gru_w_ih); tn.ldo = mw; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = 1; tn.part = t.part;
-  tn.part_floats = t.part_floats;
+  tn.part_floats = t.part_floats; tn.bias_out = F(gm->gru_b_ih); tn.bias_accumulate = 1;
   if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
   tn.k = d; tn.y = t.dgh; tn.x0 = ASeg{upd_vals, d, d, w.outdated}; tn.out = F(gm->gru_w_hh); tn.ldo = d;
+  tn.bias_out = F(gm->gru_b_hh);
   if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
-  if ((rc = colsum_launch(t.rows_cap, w.counts + 1, 3 * d, t.dgi, 3 * d, 1.f, F(gm->gru_b_ih), 1, t.part, t.part_floats,
-                          st)) != TG_OK)
-    return rc;
-  if ((rc = colsum_launch(t.rows_cap, w.counts + 1, 3 * d, t.dgh, 3 * d, 1.f, F(gm->gru_b_hh), 1, t.part, t.part_floats,
-                          st)) != TG_OK)
-    return rc;
   return check_launch("tg_train_step(backward)");
 }
 
@@ -777,7 +781,7 @@ extern "C" int tg_adam_step(const tg_adam_seg* segs_dev, int32_t n_segs, int32_t
   if (!segs_dev || n_segs <= 0 || n_groups <= 0 || !steps_dev) return TG_EINVAL;
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(k_adam_tick, dim3((unsigned)cdiv(n_groups, 64)), dim3(64), 0, st, n_groups, enabled_dev, steps_dev);
-  hipLaunchKernelGGL(k_adam, dim3(32, (unsigned)n_segs), dim3(256), 0, st, segs_dev, enabled_dev, steps_dev, lr, beta1, beta2,
+  hipLaunchKernelGGL(k_adam, dim3(128, (unsigned)n_segs), dim3(256), 0, st, segs_dev, enabled_dev, steps_dev, lr, beta1, beta2,
                      eps, grad_scale);
   return check_launch("tg_adam_step");
 }
