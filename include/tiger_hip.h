@@ -397,10 +397,27 @@ typedef struct tg_train_io {
   float* pos_scores; /* [B] logits or NULL */
   float* neg_scores; /* [B] or NULL */
   int32_t* flags;    /* [4] device, see above (NULL allowed) */
-  int32_t reserved[2];
+  /* mutual learning (tiger.py:574-590): the restarter predicts the targets h_prev_left/right
+   * (step.h_prev_* must be given) of the latest occurrence of every positive node; MSE over the
+   * rows whose target is not all zero.  Restart data (data_loader.py:133-165) is collated on
+   * device.  restarter = TG_RESTARTER_NONE is contrast_only (tiger.py:570-572). */
+  int32_t restarter; /* TG_RESTARTER_* */
+  int32_t reserved;
+  const tg_seq_restarter* seq;        /* TG_RESTARTER_SEQ: parameters ... */
+  const tg_seq_restarter* seq_grads;  /* ... and gradient buffers in the same layout (+=) */
+  const float* static_left;           /* TG_RESTARTER_STATIC: left_emb / right_emb tables [n_nodes, d] */
+  const float* static_right;
+  float* static_left_grad;            /* dense gradients [n_nodes, d] (+=) */
+  float* static_right_grad;
 } tg_train_io;
 
-size_t tg_train_step_workspace_bytes(const tg_model* m, const tg_score_params* sp, int64_t B);
+#define TG_RESTARTER_NONE 0
+#define TG_RESTARTER_SEQ 1
+#define TG_RESTARTER_STATIC 2
+
+/* seq: the SeqRestarter when restarter == TG_RESTARTER_SEQ (sizes only), else NULL */
+size_t tg_train_step_workspace_bytes(const tg_model* m, const tg_score_params* sp, int32_t restarter,
+                                     const tg_seq_restarter* seq, int64_t B);
 int tg_train_step(const tg_model* m, const tg_tcsr* g, const tg_train_io* io, void* ws, size_t ws_bytes,
                   void* stream);
 
@@ -416,7 +433,7 @@ typedef struct tg_adam_seg {
   float* v;
   int64_t n;
   int32_t group;
-  int32_t reserved;
+  float grad_scale; /* per-segment factor on g (e.g. the mutual-loss coefficient); 0 means 1 */
 } tg_adam_seg;
 
 int tg_adam_step(const tg_adam_seg* segs_dev, int32_t n_segs, int32_t n_groups, const int32_t* enabled_dev,

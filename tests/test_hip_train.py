@@ -53,8 +53,8 @@ def test_contrast_gradients_match_oracle(name):
     for b in range(cfg['n_batches']):
         a = batch(z, cfg, b)
         cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], cfg['K'], cfg['restarter'], hist_len=cfg.get('H'))
-        lazy_restart(model, orc, cfg, b, a, cg, state)
         sync_params(model, orc)
+        lazy_restart(model, orc, cfg, b, a, cg, state)
         c, _, grads = orc.train_step(*a, cg, lr=cfg['lr'], contrast_only=True)
         n = len(a[0])
         tb = bufs.get(n) or TrainBuffers(model, n)
@@ -119,3 +119,65 @@ def test_c2_shape_gradients_match_oracle():
         assert abs(float(tb.losses[0]) - c) < TOL * max(1.0, abs(c))
         worst = max((grad_err(g.cpu().numpy(), grads[k].numpy()), k) for k, g in tb.grads.items())
         assert worst[0] < 3e-4, worst
+
+
+@pytest.mark.parametrize('name', ['train_seq_lr_d8', 'train_static_ll_d16'])
+def test_mutual_gradients_match_oracle(name):
+    """contrast + mutual loss (tiger.py:547-592): restarter gradients and both losses."""
+    from oracle import tiger_oracle as O
+    from www2023tiger_amd.model.training import TrainBuffers
+    z = load(name)
+    cfg = parse_cfg(z)
+    model, _, _ = build_hip_model(z, cfg, dropout=0.0)
+    orc = build_oracle(z, cfg)
+    model.train()
+    bufs, state = {}, {}
+    for b in range(cfg['n_batches']):
+        a = batch(z, cfg, b)
+        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], cfg['K'], cfg['restarter'], hist_len=cfg.get('H'))
+        sync_params(model, orc)
+        lazy_restart(model, orc, cfg, b, a, cg, state)
+        rkey = next(k for k in orc.p if k.startswith('restarter_fn.') and 'time_encoder' not in k)
+        before = orc.adam[rkey][2] if hasattr(orc, 'adam') else 0
+        c, ml, grads = orc.train_step(*a, cg, lr=cfg['lr'], mutual_coef=1.0)
+        had_grad = orc.adam[rkey][2] - before  # Adam counts a step only for parameters whose .grad is not None
+        n = len(a[0])
+        tb = bufs.get(n) or TrainBuffers(model, n, mutual=True)
+        bufs[n] = tb
+        to = lambda x, dt: torch.as_tensor(x).to(dev(), dt)
+        tb.sb.load(to(a[0], torch.int64), to(a[1], torch.int64), to(a[2], torch.int64), to(a[3], torch.float64),
+                   to(a[4], torch.int64))
+        tb.launch()
+        assert int(tb.sb.err.item()) == 0
+        assert abs(float(tb.losses[0]) - c) < TOL * max(1.0, abs(c)), b
+        assert abs(float(tb.losses[1]) - ml) < TOL * max(1.0, abs(ml)), (b, float(tb.losses[1]), ml)
+        for k, g in tb.grads.items():
+            assert grad_err(g.cpu().numpy(), grads[k].numpy()) < 2e-4, (b, k)
+        assert int(tb.flags[2]) == had_grad, b
+
+
+def test_fused_trainer_mutual_trajectory():
+    """Full reference recipe (seq restarter, mutual learning, lazy restart at batch 6) with no
+    parameter sync: per-batch losses and final parameters of the reference run."""
+    from www2023tiger_amd.model.training import FusedTrainer
+    z = load('train_seq_lr_d8')
+    cfg = parse_cfg(z)
+    model, _, coll = build_hip_model(z, cfg, dropout=0.0)
+    model.train()
+    tr = FusedTrainer(model, cfg['B'], lr=cfg['lr'], mutual=True, mutual_coef=cfg['mutual_coef'])
+    restarting, uptodate = False, set()
+    for b in range(cfg['n_batches']):
+        a = batch(z, cfg, b)
+        if b == cfg['restart_at']:
+            restarting, uptodate = True, set()
+            model.msg_store.clear()
+        if restarting:
+            cg = coll.collate_arrays(*a)[-1]
+            r_nodes = np.array(sorted(set(cg.np_computation_graph_nodes.tolist()) - uptodate), dtype=np.int64)
+            model.restart(torch.from_numpy(r_nodes), torch.full((len(r_nodes),), float(np.float32(a[3]).min())))
+            uptodate.update(r_nodes.tolist())
+        losses = tr.step(*a)
+        assert abs(float(losses[0]) - float(z[f'b{b}_contrast_loss'])) < 1e-3, b
+        assert abs(float(losses[1]) - float(z[f'b{b}_mutual_loss'])) < 1e-3, b
+    for k, p in model.named_parameters():
+        assert rel_err(p.detach().cpu().numpy(), z[f'final.{k}']) < 2e-3, k

@@ -86,12 +86,14 @@ class TgScoreParams(C.Structure):
 class TgTrainIo(C.Structure):
     _fields_ = [
         ('step', TgStepIo), ('score', vp), ('grads', vp), ('score_grads', vp), ('losses', vp),
-        ('pos_scores', vp), ('neg_scores', vp), ('flags', vp), ('reserved', i32 * 2),
+        ('pos_scores', vp), ('neg_scores', vp), ('flags', vp), ('restarter', i32), ('reserved', i32),
+        ('seq', vp), ('seq_grads', vp), ('static_left', vp), ('static_right', vp),
+        ('static_left_grad', vp), ('static_right_grad', vp),
     ]
 
 
 class TgAdamSeg(C.Structure):
-    _fields_ = [('p', vp), ('g', vp), ('m', vp), ('v', vp), ('n', i64), ('group', i32), ('reserved', i32)]
+    _fields_ = [('p', vp), ('g', vp), ('m', vp), ('v', vp), ('n', i64), ('group', i32), ('grad_scale', C.c_float)]
 
 
 P = C.POINTER
@@ -138,7 +140,7 @@ SIGNATURES = {
     'tg_stream_step_workspace_bytes': (sz, [P(TgModel), i64]),
     'tg_stream_step_zero_bytes': (sz, [P(TgModel), i64]),
     'tg_stream_step': (C.c_int, [P(TgModel), P(TgTcsr), P(TgStepIo), vp, sz, vp]),
-    'tg_train_step_workspace_bytes': (sz, [P(TgModel), P(TgScoreParams), i64]),
+    'tg_train_step_workspace_bytes': (sz, [P(TgModel), P(TgScoreParams), i32, vp, i64]),
     'tg_train_step': (C.c_int, [P(TgModel), P(TgTcsr), P(TgTrainIo), vp, sz, vp]),
     'tg_adam_step': (C.c_int, [vp, i32, i32, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
     'tg_stream_writeback_workspace_bytes': (sz, [P(TgModel), i64]),

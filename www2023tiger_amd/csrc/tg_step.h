@@ -67,4 +67,11 @@ int step_writeback_a(const tg_model* m, const tg_step_io* io, StepWs& w, hipStre
 // STEP 6 + workspace clean-up + offset advance
 int step_writeback_b(const tg_model* m, const tg_step_io* io, StepWs& w, hipStream_t st, tg_profiler* pf);
 
+// mutual-learning half of the training step (tg_restart.hip)
+size_t mutual_ws_bytes(const tg_model* m, const tg_seq_restarter* r, int64_t B);
+int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, const StepWs& sw,
+                const tg_seq_restarter* r, const tg_seq_restarter* gr, const float* st_left, const float* st_right,
+                float* g_left, float* g_right, float* loss_out, int32_t* flag_out, float* part, size_t part_floats,
+                void* ws, size_t ws_bytes, hipStream_t st);
+
 }  // namespace tg

@@ -519,8 +519,9 @@ __global__ void __launch_bounds__(256) k_adam(const tg_adam_seg* __restrict__ se
   }
   __syncthreads();
   const float step_size = sh[0], bc2s = sh[1];
+  const float gs = gscale * (sg.grad_scale != 0.f ? sg.grad_scale : 1.f);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < sg.n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float g = sg.g[i] * gscale;
+    const float g = sg.g[i] * gs;
     const float mm = sg.m[i] + (g - sg.m[i]) * (1.f - b1);  // exp_avg.lerp_(grad, 1 - beta1)
     const float vv = sg.v[i] * b2 + (1.f - b2) * g * g;
     sg.m[i] = mm;
@@ -751,9 +752,13 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
 
 using namespace tg;
 
-extern "C" size_t tg_train_step_workspace_bytes(const tg_model* m, const tg_score_params* sp, int64_t B) {
+extern "C" size_t tg_train_step_workspace_bytes(const tg_model* m, const tg_score_params* sp, int32_t restarter,
+                                                const tg_seq_restarter* seq, int64_t B) {
   if (!m || !train_supported(m, sp) || B <= 0 || m->n_nodes <= 0) return 0;
-  return tg_stream_step_workspace_bytes(m, B) + train_ws_bytes(m, sp, B);
+  if (restarter < TG_RESTARTER_NONE || restarter > TG_RESTARTER_STATIC || (restarter == TG_RESTARTER_SEQ && !seq)) return 0;
+  size_t b = tg_stream_step_workspace_bytes(m, B) + train_ws_bytes(m, sp, B);
+  if (restarter != TG_RESTARTER_NONE) b += mutual_ws_bytes(m, restarter == TG_RESTARTER_SEQ ? seq : nullptr, B);
+  return b;
 }
 
 extern "C" int tg_train_step(const tg_model* m, const tg_tcsr* g, const tg_train_io* io, void* ws, size_t ws_bytes,
@@ -763,6 +768,7 @@ extern "C" int tg_train_step(const tg_model* m, const tg_tcsr* g, const tg_train
   const tg_step_io* sio = &io->step;
   if (sio->B <= 0 || !sio->src || !sio->dst || !sio->neg || !sio->ts || !sio->eids || !sio->h || !sio->err) return TG_EINVAL;
   if (sio->embed_only || g->num_node != m->n_nodes) return TG_EINVAL;
+  if (io->restarter < TG_RESTARTER_NONE || io->restarter > TG_RESTARTER_STATIC) return TG_EINVAL;
   hipStream_t st = as_stream(stream);
   Carver cv(ws, ws_bytes);
   StepWs w{};
@@ -772,6 +778,16 @@ extern "C" int tg_train_step(const tg_model* m, const tg_tcsr* g, const tg_train
   if ((rc = step_forward(m, g, sio, w, t.gates, st, nullptr)) != TG_OK) return rc;
   if ((rc = contrast_backward(m, io, w, t, st)) != TG_OK) return rc;
   if ((rc = step_writeback_a(m, sio, w, st, nullptr)) != TG_OK) return rc;
+  if (io->restarter != TG_RESTARTER_NONE) {  // needs the targets of STEP 4/5 and the step's bitmap-free inputs
+    const bool seq = io->restarter == TG_RESTARTER_SEQ;
+    if (seq && (!io->seq || !io->seq_grads)) return TG_EINVAL;
+    if ((rc = mutual_step(m, g, sio, w, seq ? io->seq : nullptr, seq ? io->seq_grads : nullptr, io->static_left,
+                          io->static_right, io->static_left_grad, io->static_right_grad, io->losses + 1,
+                          io->flags ? io->flags + 2 : nullptr, t.part, t.part_floats, cv.p, cv.left, st)) != TG_OK)
+      return rc;
+  } else if (io->flags) {
+    hipMemsetAsync(io->flags + 2, 0, sizeof(int32_t), st);
+  }
   return step_writeback_b(m, sio, w, st, nullptr);
 }
 

@@ -17,7 +17,8 @@ from typing import List, Tuple
 import torch
 from torch import Tensor
 
-from .._lib import (TgAdamSeg, TgLinear, TgModel, TgScoreParams, TgStepIo, TgTrainIo, check, lib, ptr)
+from .._lib import (TgAdamSeg, TgLinear, TgModel, TgScoreParams, TgSeqRestarter, TgStepIo, TgTrainIo, check, lib,
+                    ptr)
 from ..hip_ops import stream_ptr
 
 _HIT = {'none': 0, 'vec': 1, 'bin': 2, 'count': 3}
@@ -57,6 +58,37 @@ def contrast_parameters(model) -> List[Tuple[str, Tensor, int]]:
     return out
 
 
+def restarter_parameters(model) -> List[Tuple[str, Tensor, int]]:
+    """Parameters the mutual loss trains (Adam group 2: they have a gradient only when some
+    target row is non-zero, tiger.py:584-590)."""
+    from .restarters import SeqRestarter
+    r = model.restarter_fn
+    if isinstance(r, SeqRestarter):
+        named = [('time_encoder.basis_freq', r.time_encoder.basis_freq), ('time_encoder.phase', r.time_encoder.phase),
+                 ('anony_emb.weight', r.anony_emb.weight), ('mha_fn.in_proj_weight', r.mha_fn.in_proj_weight),
+                 ('mha_fn.in_proj_bias', r.mha_fn.in_proj_bias), ('mha_fn.out_proj.weight', r.mha_fn.out_proj.weight),
+                 ('mha_fn.out_proj.bias', r.mha_fn.out_proj.bias), ('out_fn.weight', r.out_fn.weight),
+                 ('out_fn.bias', r.out_fn.bias), ('merger.fc1.weight', r.merger.fc1.weight),
+                 ('merger.fc1.bias', r.merger.fc1.bias), ('merger.fc2.weight', r.merger.fc2.weight),
+                 ('merger.fc2.bias', r.merger.fc2.bias)]
+    else:
+        named = [('left_emb.weight', r.left_emb.weight), ('right_emb.weight', r.right_emb.weight)]
+    return [('restarter_fn.' + n, p, 2) for n, p in named]
+
+
+def seq_struct(r, g=None) -> TgSeqRestarter:
+    """tg_seq_restarter over the SeqRestarter's parameters, or over same-named gradient views."""
+    if g is None:
+        return r._struct()
+    t = lambda n: ptr(g['restarter_fn.' + n])
+    return TgSeqRestarter(r.hist_len, r.n_head, t('time_encoder.basis_freq'), t('time_encoder.phase'),
+                          t('anony_emb.weight'), t('mha_fn.in_proj_weight'), t('mha_fn.in_proj_bias'),
+                          TgLinear(t('mha_fn.out_proj.weight'), t('mha_fn.out_proj.bias')),
+                          TgLinear(t('out_fn.weight'), t('out_fn.bias')),
+                          TgLinear(t('merger.fc1.weight'), t('merger.fc1.bias')),
+                          TgLinear(t('merger.fc2.weight'), t('merger.fc2.bias')))
+
+
 def score_struct(model, tensors=None) -> TgScoreParams:
     """tg_score_params over the model's score head, or over same-named gradient views."""
     t = tensors or {n: p for n, p, _ in contrast_parameters(model)}
@@ -90,6 +122,9 @@ def check_trainable(model):
         raise NotImplementedError('training on device supports n_layers == 1')
     drops = [model.score_fn.dropout.p, model.temporal_embedding_fn.fns[0].merger.dropout.p,
              model.temporal_embedding_fn.fns[0].mha_fn.dropout]
+    r = getattr(model, 'restarter_fn', None)
+    if r is not None and hasattr(r, 'mha_fn'):
+        drops += [r.mha_fn.dropout, r.merger.dropout.p]
     if any(p > 0 for p in drops):
         raise NotImplementedError('training on device runs without dropout: build the model with dropout=0')
 
@@ -98,12 +133,14 @@ class TrainBuffers:
     """Static buffers of one batch size for tg_train_step: the step's inputs/outputs
     (a TIGE.StepBuffers), flat gradient storage with one view per parameter, losses, scores."""
 
-    def __init__(self, model, B: int, resident=None):
+    def __init__(self, model, B: int, resident=None, mutual: bool = False):
+        """mutual=True adds the restarter's mutual-learning loss (tiger.py:574-590) and its
+        gradients; False is the reference's contrast_only (restart_prob == 0)."""
         check_trainable(model)
         dev = model.device
-        self.model, self.B = model, B
+        self.model, self.B, self.mutual = model, B, mutual
         self.sb = model.StepBuffers(model, B, want_prev=True, resident=resident)
-        self.params = contrast_parameters(model)
+        self.params = contrast_parameters(model) + (restarter_parameters(model) if mutual else [])
         n = sum(p.numel() for _, p, _ in self.params)
         self.gflat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grads, o = {}, 0
@@ -123,7 +160,16 @@ class TrainBuffers:
         self._gmodel = grads_struct(model, self.grads)
         self._gscore = score_struct(model, self.grads)
         m = model.model_struct()
-        nbytes = int(lib.tg_train_step_workspace_bytes(C.byref(m), C.byref(self._score), B))
+        from .restarters import SeqRestarter
+        kind, self._seq, self._gseq = 0, None, None
+        if self.mutual:
+            r = model.restarter_fn
+            if isinstance(r, SeqRestarter):
+                kind, self._seq, self._gseq = 1, seq_struct(r), seq_struct(r, self.grads)
+            else:
+                kind = 2
+        nbytes = int(lib.tg_train_step_workspace_bytes(C.byref(m), C.byref(self._score), kind,
+                                                       C.addressof(self._seq) if self._seq is not None else None, B))
         if nbytes == 0:
             raise RuntimeError('tg_train_step: unsupported model configuration')
         if getattr(self, 'ws', None) is None or self.ws.numel() < nbytes:
@@ -135,6 +181,14 @@ class TrainBuffers:
         io.score_grads = C.addressof(self._gscore)
         io.losses, io.pos_scores, io.neg_scores = ptr(self.losses), ptr(self.pos_scores), ptr(self.neg_scores)
         io.flags = ptr(self.flags)
+        io.restarter = kind
+        if kind == 1:
+            io.seq, io.seq_grads = C.addressof(self._seq), C.addressof(self._gseq)
+        elif kind == 2:
+            r = model.restarter_fn
+            io.static_left, io.static_right = ptr(r.left_emb.weight), ptr(r.right_emb.weight)
+            io.static_left_grad = ptr(self.grads['restarter_fn.left_emb.weight'])
+            io.static_right_grad = ptr(self.grads['restarter_fn.right_emb.weight'])
         self.io = io
 
     def launch(self, zero_grads: bool = True):
@@ -172,9 +226,11 @@ class FusedTrainer:
     """The training loop's device work with no host round trip per iteration: tg_train_step then
     tg_adam_step over flat parameter-gradient / moment buffers."""
 
-    def __init__(self, model, B: int, *, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, resident=None):
+    def __init__(self, model, B: int, *, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, resident=None,
+                 mutual: bool = False, mutual_coef: float = 1.0):
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
-        self.buf = TrainBuffers(model, B, resident=resident)
+        self.mutual_coef = mutual_coef
+        self.buf = TrainBuffers(model, B, resident=resident, mutual=mutual)
         dev = model.device
         n = self.buf.gflat.numel()
         self.m1 = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -184,7 +240,7 @@ class FusedTrainer:
         for i, (name, p, group) in enumerate(self.buf.params):
             k = p.numel()
             segs[i] = TgAdamSeg(ptr(p), ptr(self.buf.grads[name]), self.m1[o:o + k].data_ptr(),
-                                self.m2[o:o + k].data_ptr(), k, group, 0)
+                                self.m2[o:o + k].data_ptr(), k, group, mutual_coef if group == 2 else 1.0)
             o += k
         raw = bytes(segs)
         self.segs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
