@@ -76,3 +76,29 @@ def test_tcsr_build_rejects_bad_ids():
     from www2023tiger_amd.data.graph import Graph
     with pytest.raises(_lib.TigerHipError):
         Graph.from_arrays(np.array([1, 2]), np.array([3, 4]), np.array([0.0, 1.0]), np.array([1, 2 ** 31]))
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof / offsetof of every struct, as gcc lays out include/tiger_hip.h, against the ctypes mirrors."""
+    import subprocess
+    from www2023tiger_amd import _lib
+    root = ROOT
+    pairs = {'tg_tcsr': _lib.TgTcsr, 'tg_linear': _lib.TgLinear, 'tg_model': _lib.TgModel,
+             'tg_seq_restarter': _lib.TgSeqRestarter, 'tg_step_io': _lib.TgStepIo,
+             'tg_writeback_io': _lib.TgWritebackIo, 'tg_score_params': _lib.TgScoreParams,
+             'tg_train_io': _lib.TgTrainIo, 'tg_adam_seg': _lib.TgAdamSeg}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "tiger_hip.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-I', os.path.join(root, 'include'), str(src), '-o', str(exe)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs.items():
+        assert int(out[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(out[f'{cname}.{fname}']) == getattr(cls, fname).offset, f'{cname}.{fname}'

@@ -181,3 +181,51 @@ def test_fused_trainer_mutual_trajectory():
         assert abs(float(losses[1]) - float(z[f'b{b}_mutual_loss'])) < 1e-3, b
     for k, p in model.named_parameters():
         assert rel_err(p.detach().cpu().numpy(), z[f'final.{k}']) < 2e-3, k
+
+
+def test_reference_training_loop_with_torch_adam():
+    """The loop of train_self_supervised.py:143-171 written against the mirrored API only
+    (collator -> contrast_and_mutual_learning -> loss.backward() -> torch.optim.Adam.step()):
+    losses and final parameters of the reference run."""
+    z = load('train_seq_lr_d8')
+    cfg = parse_cfg(z)
+    model, _, coll = build_hip_model(z, cfg, dropout=0.0)
+    optimizer = torch.optim.Adam(model.parameters(), lr=cfg['lr'])
+    model.train()
+    model.reset()
+    restarting, uptodate = False, set()
+    device = dev()
+    for b in range(cfg['n_batches']):
+        src_ids, dst_ids, neg_dst_ids, ts, eids, _, comp_graph = coll.collate_arrays(*batch(z, cfg, b))
+        src_ids, dst_ids, neg_dst_ids = (x.long().to(device) for x in (src_ids, dst_ids, neg_dst_ids))
+        ts, eids = ts.float().to(device), eids.long().to(device)
+        comp_graph.to(device)
+        optimizer.zero_grad()
+        if b == cfg['restart_at']:
+            restarting, uptodate = True, set()
+            model.msg_store.clear()
+        if restarting:
+            restart_nodes = set(comp_graph.np_computation_graph_nodes) - set(uptodate)
+            r_nids = torch.tensor(sorted(restart_nodes)).long().to(device)
+            model.restart(r_nids, torch.full((len(r_nids),), ts.min().item()).to(device))
+            uptodate.update(restart_nodes)
+        contrast_loss, mutual_loss = model.contrast_and_mutual_learning(
+            src_ids, dst_ids, neg_dst_ids, ts, eids, comp_graph, contrast_only=False)
+        loss = contrast_loss + cfg['mutual_coef'] * mutual_loss
+        loss.backward()
+        optimizer.step()
+        assert abs(contrast_loss.item() - float(z[f'b{b}_contrast_loss'])) < 1e-3, b
+        assert abs(mutual_loss.item() - float(z[f'b{b}_mutual_loss'])) < 1e-3, b
+        if b in cfg['grad_batches'] and b < 2:  # identical parameters so far: gradients comparable directly
+            for k, p in model.named_parameters():
+                ref = z[f'b{b}_grad.{k}']
+                got = np.zeros_like(ref) if p.grad is None else p.grad.cpu().numpy()
+                assert grad_err(got, ref) < 2e-4, (b, k)
+    for k, p in model.named_parameters():
+        assert rel_err(p.detach().cpu().numpy(), z[f'final.{k}']) < 2e-3, k
+    # evaluation mode still takes the inference path
+    model.eval()
+    model.reset()
+    with torch.no_grad():
+        out = model.contrast_and_mutual_learning(src_ids, dst_ids, neg_dst_ids, ts, eids, comp_graph)
+    assert out[0].grad_fn is None

@@ -195,10 +195,44 @@ class TIGE(nn.Module):
         return outdated, self.msg_transform_fn(raw.detach()), ts
 
     # ---- the batch ----------------------------------------------------------------------
-    @torch.no_grad()
+    def _train_forward(self, src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph, mutual: bool):
+        """Training mode with autograd enabled: the whole iteration (collate, STEP 1-7, backward,
+        write-back) runs as one tg_train_step; the returned losses carry an autograd node that
+        hands the finished gradients to the parameters when `.backward()` is called."""
+        from .training import TrainBuffers, hand_over
+        dev = self.device
+        B = len(src_ids)
+        key = ('train', B, mutual)
+        tb = self._step_ws.get(key)
+        if tb is None:
+            tb = TrainBuffers(self, B, mutual=mutual)
+            self._step_ws[key] = tb
+        ts64 = getattr(computation_graph, 'ts64', None)  # the collator keeps the float64 event times
+        if ts64 is None:
+            ts64 = ts.to(dev).double()
+        to = lambda x: x.to(dev).long()
+        tb.sb.load(to(src_ids), to(dst_ids), to(neg_dst_ids), ts64, to(eids))
+        tb.launch()
+        word = int(tb.sb.err.item())
+        if word:
+            tb.sb.err.zero_()
+            from .._lib import raise_invariants
+            raise_invariants(word & 0xFFFFFFFF)
+        grads = [(tb.grads[name], 1 if group == 2 else 0, group) for name, _, group in tb.params]
+        losses = hand_over(tb.losses, grads, tb.flags.clone(), [p for _, p, _ in tb.params])
+        return (losses, tb.sb.h[:2 * B].clone(), tb.pos_scores.clone(), tb.neg_scores.clone(),
+                tb.sb.h_prev_left.clone(), tb.sb.h_prev_right.clone())
+
     def contrast_learning(self, src_ids: Tensor, dst_ids: Tensor, neg_dst_ids: Tensor, ts: Tensor, eids: Tensor,
                           computation_graph) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
         """tiger.py:174-290 -> (contrast_loss, h_left, pos_scores, neg_scores, h_prev_left, h_prev_right)"""
+        if self.training and torch.is_grad_enabled():
+            losses, *rest = self._train_forward(src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph, False)
+            return (losses[0], *rest)
+        with torch.no_grad():
+            return self._contrast_learning_eval(src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph)
+
+    def _contrast_learning_eval(self, src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph):
         cg = computation_graph
         dev = self.device
         m = self.model_struct()
@@ -393,10 +427,21 @@ class TIGER(TIGE):
     def forward(self, *args, **kwargs):
         return self.contrast_and_mutual_learning(*args, **kwargs)
 
-    @torch.no_grad()
     def contrast_and_mutual_learning(self, src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph,
                                      contrast_only: bool = False):
         """tiger.py:547-592"""
+        if self.training and torch.is_grad_enabled():
+            losses, *_ = self._train_forward(src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph,
+                                             mutual=not contrast_only)
+            if contrast_only:
+                return losses[0], torch.tensor(0, device=losses.device)
+            return losses[0], losses[1]
+        with torch.no_grad():
+            return self._contrast_and_mutual_eval(src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph,
+                                                  contrast_only)
+
+    def _contrast_and_mutual_eval(self, src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph,
+                                  contrast_only: bool = False):
         contrast_loss, *_, h_prev_left, h_prev_right = self.contrast_learning(
             src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph)
         if contrast_only:

@@ -207,19 +207,22 @@ class _HandOver(torch.autograd.Function):
     the HIP backward pass already produced, scaled by the incoming loss gradient."""
 
     @staticmethod
-    def forward(ctx, losses, grads, *params):
-        ctx.grads = grads
+    def forward(ctx, losses, grads, flags, *params):
+        ctx.grads, ctx.flags = grads, flags
         return losses.clone()
 
     @staticmethod
     def backward(ctx, g_losses):
-        # grads is a list of (gradient view, index of the loss it belongs to)
-        out = tuple(g * g_losses[k] for g, k in ctx.grads)
-        return (None, None) + out
+        # grads: (gradient view, index of the loss it belongs to, parameter group).  A group whose flag
+        # is 0 took no part in the graph this step: torch would leave .grad None (and Adam would skip
+        # the parameter, step count included), so None is returned for it.
+        live = ctx.flags.tolist()
+        out = tuple((g * g_losses[k]) if live[grp] else None for g, k, grp in ctx.grads)
+        return (None, None, None) + out
 
 
-def hand_over(losses: Tensor, grads: List[Tuple[Tensor, int]], params: List[Tensor]) -> Tensor:
-    return _HandOver.apply(losses, grads, *params)
+def hand_over(losses: Tensor, grads: List[Tuple[Tensor, int, int]], flags: Tensor, params: List[Tensor]) -> Tensor:
+    return _HandOver.apply(losses, grads, flags, *params)
 
 
 class FusedTrainer:
