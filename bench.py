@@ -172,11 +172,12 @@ def train_main(args, cfg):
     no_feats = bool(cfg.get('no_feats'))
     stream = make_stream(cfg['n_u'], cfg['n_i'], E, cfg['T'] * E / cfg['E'], seed=0, d_e=d,
                          integer_ts=cfg.get('integer_ts', True), with_efeats=not no_feats)
-    model, _ = build_models(stream, d, K, cfg['msg_src'], cfg['upd_src'], restarter='static', device='cuda:0',
-                            zero_nfeats=not no_feats, dropout=0.0)
+    rkind = args.train_restarter
+    model, _ = build_models(stream, d, K, cfg['msg_src'], cfg['upd_src'], restarter='seq' if rkind == 'seq' else 'static',
+                            hist_len=args.hist_len, device='cuda:0', zero_nfeats=not no_feats, dropout=0.0)
     model.train()
     resident = tuple(torch.from_numpy(stream[k]).to(dev) for k in ('src', 'dst', 'neg', 'ts', 'eids'))
-    tr = FusedTrainer(model, B, lr=1e-4, resident=resident)
+    tr = FusedTrainer(model, B, lr=1e-4, resident=resident, mutual=rkind != 'none', mutual_coef=1.0)
     for _ in range(args.warmup):
         tr.launch()
     torch.cuda.synchronize()
@@ -202,11 +203,14 @@ def train_main(args, cfg):
     assert int(tr.buf.sb.offset.item()) == (args.warmup + args.steps) * B
     loss = float(tr.buf.losses[0])
     assert np.isfinite(loss)
-    print(json.dumps(dict(metric='training interaction-events/sec (collate + STEP 1-7 + backward + Adam, contrast loss)',
+    print(json.dumps(dict(metric='training interaction-events/sec (collate + STEP 1-7 + backward + Adam)',
                           value=args.steps * B / dt, unit='events/s', n_gpus=1, steps=args.steps, warmup=args.warmup,
                           ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='weak', vs_baseline=None,
                           dtype='f32', data='synthetic',
-                          config=dict(workload=cfg['name'], batch=B, dim=d, n_neighbors=K, mode='train (contrast only)',
+                          config=dict(workload=cfg['name'], batch=B, dim=d, n_neighbors=K,
+                                      mode='train (contrast only)' if rkind == 'none' else
+                                      f'train (contrast + mutual, {rkind} restarter, hist_len {args.hist_len})',
+                                      last_mutual_loss=float(tr.buf.losses[1]),
                                       launch='hipGraph replay' if graph is not None else 'eager', last_loss=loss))))
 
 
@@ -222,6 +226,9 @@ def main():
     ap.add_argument('--dist-graphs', action='store_true',
                     help='multi-GPU: replay captured hipGraphs around the all-gather (experimental; default eager)')
     ap.add_argument('--train', action='store_true', help='measure the training iteration instead (not the headline metric)')
+    ap.add_argument('--train-restarter', default='none', choices=['none', 'seq', 'static'],
+                    help='--train: add the mutual-learning loss of this restarter (none = contrast_only)')
+    ap.add_argument('--hist-len', type=int, default=20)
     args = ap.parse_args()
     cfg = dict(WORKLOADS[args.workload])
     if args.train:
