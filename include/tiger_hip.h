@@ -441,6 +441,17 @@ int tg_adam_step(const tg_adam_seg* segs_dev, int32_t n_segs, int32_t n_groups, 
                  void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* Evaluation metrics (tiger/eval_utils.py:49-67)           */
+/* ------------------------------------------------------------------------- */
+/* For consecutive windows of `chunk` events (the last may be shorter): sklearn's
+ * average_precision_score and roc_auc_score of the predictions [pos | neg] with labels [1 | 0],
+ * ties handled as sklearn does.  pos_pred / neg_pred: [n] probabilities (sigmoid of the logits);
+ * ap / auc: double[ceil(n / chunk)] on device.  Non-finite predictions are dropped from their
+ * window and counted in *n_nonfinite (nullable, device int32, not reset here). */
+int tg_ap_auc(int64_t n, int32_t chunk, const float* pos_pred, const float* neg_pred, double* ap, double* auc,
+              int32_t* n_nonfinite, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Multi-GPU: replicated write-back of a GLOBAL batch from all-gathered rows  */
 /* (www2023tiger_amd/dist.py; STEP 4-6 of tiger.py:229-255 for every event of */
 /* the global batch, the embeddings having been computed on other ranks)      */

@@ -350,6 +350,61 @@ def gen_train(name, cfg):
     print(f'{name}.npz', sum(v.nbytes for v in out.values()) // 1024, 'KiB raw')
 
 
+def gen_eval(name, cfg):
+    """tiger/eval_utils.py: warmup + eval_edge_prediction over DataLoaders (AP / AUC per
+    `mean_over_n_samples` events), in restart mode and in plain streaming mode."""
+    from torch.utils.data import DataLoader
+    from tiger.eval_utils import eval_edge_prediction, warmup
+    d = cfg['d']
+    src, dst, ts, eids = make_stream(cfg['seed'], cfg['n_u'], cfg['n_i'], cfg['E'], cfg['T'])
+    E = len(src)
+    n_nodes = int(max(src.max(), dst.max())) + 1
+    rs = np.random.RandomState(cfg['seed'] + 100)
+    nfeats = rs.standard_normal((n_nodes, d)).astype(np.float32) * 0.5
+    nfeats[0] = 0
+    efeats = rs.standard_normal((E + 1, d)).astype(np.float32)
+    efeats[0] = 0
+    labels = np.zeros(E, dtype=np.int64)
+    data = InteractionData(src, dst, ts, eids, labels, seed=0, eval=True)  # pre-sampled negatives (bs=200)
+    graph = Graph.from_data(data, strategy='recent_edges', seed=0)
+    model, pnames, pshapes = build_reference_model(cfg, nfeats, efeats, graph, E, dropout=0.0)
+    collator = GraphCollator(graph, cfg['K'], 1, restarter=cfg['restarter'], hist_len=cfg.get('H'))
+    out = {'versions': VERSIONS, 'src': src, 'dst': dst, 'ts': ts, 'eids': eids, 'neg': data.neg_dst,
+           'n_nodes': np.int64(n_nodes), 'param_names': np.array(pnames),
+           'param_shapes': np.array([','.join(map(str, s)) for s in pshapes]),
+           'cfg': np.array([f'{k}={v}' for k, v in sorted(cfg.items())]), 'nfeats': nfeats, 'efeats': efeats}
+    B = cfg['B']
+    dev = torch.device('cpu')
+    mk = lambda lo, hi: DataLoader(data.get_subset(lo, hi), batch_size=B, shuffle=False, collate_fn=collator)
+    n_warm, n_val = cfg['n_warm'], cfg['n_val']
+    # plain streaming evaluation from an empty state
+    model.reset()
+    ap, auc = eval_edge_prediction(model, mk(0, n_val), dev, restart_mode=False, mean_over_n_samples=cfg['chunk'])
+    out['stream_ap'], out['stream_auc'] = np.float64(ap), np.float64(auc)
+    # restart mode: warm-up on the first block, evaluate the next one (train_self_supervised.py:179-202)
+    model.reset()
+    up = warmup(model, mk(0, n_warm), dev)
+    out['warm_uptodate'] = np.array(sorted(int(x) for x in up), dtype=np.int64)
+    state = model.save_memory_state()
+    ap, auc = eval_edge_prediction(model, mk(n_warm, n_warm + n_val), dev, restart_mode=True,
+                                   uptodate_nodes=set(up), mean_over_n_samples=cfg['chunk'])
+    out['restart_ap'], out['restart_auc'] = np.float64(ap), np.float64(auc)
+    model.load_memory_state(state)  # rewind and evaluate with the default 200-event windows
+    ap, auc = eval_edge_prediction(model, mk(n_warm, n_warm + n_val), dev, restart_mode=True, uptodate_nodes=set(up))
+    out['restart200_ap'], out['restart200_auc'] = np.float64(ap), np.float64(auc)
+    with torch.no_grad():
+        snapshot(model, out, 'final')
+    np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
+    print(f'{name}.npz', sum(v.nbytes for v in out.values()) // 1024, 'KiB raw')
+
+
+EVAL_SCENARIOS = {
+    'eval_seq_lr_d8': dict(d=8, n_u=40, n_i=15, E=900, T=450.0, B=50, K=5, H=8, seed=31, wseed=31, restarter='seq',
+                           msg_src='left', upd_src='right', hit='bin', n_warm=300, n_val=500, chunk=64),
+    'eval_static_ll_d16': dict(d=16, n_u=60, n_i=25, E=900, T=500.0, B=64, K=10, seed=32, wseed=32, restarter='static',
+                               msg_src='left', upd_src='left', hit='vec', n_warm=256, n_val=600, chunk=100),
+}
+
 TRAIN_SCENARIOS = {
     # CLI defaults: seq restarter, msg=left upd=right, 'bin' hits, mutual learning with a lazy restart
     'train_seq_lr_d8': dict(d=8, n_u=40, n_i=15, E=480, T=300.0, B=40, n_batches=10, K=5, H=8, seed=21, wseed=21,
@@ -400,3 +455,6 @@ if __name__ == '__main__':
     for nm, cfg in TRAIN_SCENARIOS.items():
         if not only or nm in only:
             gen_train(nm, cfg)
+    for nm, cfg in EVAL_SCENARIOS.items():
+        if not only or nm in only:
+            gen_eval(nm, cfg)

@@ -1,0 +1,67 @@
+"""Evaluation harness (www2023tiger_amd/eval_utils.py) against the AP / AUC the reference's own
+tiger/eval_utils.py produced on the same streams (tests/golden/eval_*.npz), and tg_ap_auc
+against sklearn."""
+import numpy as np
+import pytest
+import torch
+
+from _util import load, parse_cfg, rel_err
+from test_hip_parity import build_hip_model, dev
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ap_auc_matches_sklearn():
+    from sklearn.metrics import average_precision_score, roc_auc_score
+    from www2023tiger_amd.eval_utils import ap_auc_windows
+    rs = np.random.RandomState(0)
+    n, w = 1000, 200
+    pos = rs.uniform(0, 1, n).astype(np.float32)
+    neg = rs.uniform(0, 1, n).astype(np.float32)
+    pos[::7] = np.float32(1.0)          # saturated sigmoids: ties between and within the classes
+    neg[::11] = np.float32(1.0)
+    neg[5:40] = pos[5:40]
+    neg[300:310] = np.nan                # dropped from their window
+    ap, auc, bad = ap_auc_windows(torch.from_numpy(pos).to(dev()), torch.from_numpy(neg).to(dev()), w)
+    assert int(bad.item()) == 10
+    for i in range(n // w):
+        sc = np.concatenate([pos[i * w:(i + 1) * w], neg[i * w:(i + 1) * w]])
+        lab = np.concatenate([np.ones(w), np.zeros(w)])
+        ok = np.isfinite(sc)
+        assert abs(float(ap[i]) - average_precision_score(lab[ok], sc[ok])) < 1e-12, i
+        assert abs(float(auc[i]) - roc_auc_score(lab[ok], sc[ok])) < 1e-12, i
+    # ragged tail window
+    ap2, auc2, _ = ap_auc_windows(torch.from_numpy(pos[:250]).to(dev()), torch.from_numpy(neg[:250]).to(dev()), w)
+    sc = np.concatenate([pos[200:250], neg[200:250]])
+    assert abs(float(ap2[1]) - average_precision_score(np.r_[np.ones(50), np.zeros(50)], sc)) < 1e-12
+
+
+@pytest.mark.parametrize('name', ['eval_seq_lr_d8', 'eval_static_ll_d16'])
+def test_eval_harness_matches_reference(name):
+    from torch.utils.data import DataLoader
+    from www2023tiger_amd.data.data_loader import InteractionData
+    from www2023tiger_amd.eval_utils import eval_edge_prediction, warmup
+    z = load(name)
+    cfg = parse_cfg(z)
+    model, _, coll = build_hip_model(z, cfg, dropout=0.0)
+    data = InteractionData(z['src'], z['dst'], z['ts'], z['eids'], np.zeros(len(z['src']), dtype=np.int64), seed=0,
+                           eval=True)
+    np.testing.assert_array_equal(data.neg_dst, z['neg'])  # RandEdgeSampler.pre_sample_neg_dsts stream
+    mk = lambda lo, hi: DataLoader(data.get_subset(lo, hi), batch_size=cfg['B'], shuffle=False, collate_fn=coll)
+    n_warm, n_val = cfg['n_warm'], cfg['n_val']
+    tol = 2e-4  # scores are float32 to 1e-4; a window's AP/AUC moves only when a near-tie flips
+    model.reset()
+    ap, auc = eval_edge_prediction(model, mk(0, n_val), dev(), restart_mode=False, mean_over_n_samples=cfg['chunk'])
+    assert abs(ap - float(z['stream_ap'])) < tol and abs(auc - float(z['stream_auc'])) < tol
+    model.reset()
+    up = warmup(model, mk(0, n_warm), dev())
+    np.testing.assert_array_equal(np.array(sorted(up), dtype=np.int64), z['warm_uptodate'])
+    state = model.save_memory_state()
+    ap, auc = eval_edge_prediction(model, mk(n_warm, n_warm + n_val), dev(), restart_mode=True,
+                                   uptodate_nodes=set(up), mean_over_n_samples=cfg['chunk'])
+    assert abs(ap - float(z['restart_ap'])) < tol and abs(auc - float(z['restart_auc'])) < tol
+    model.load_memory_state(state)
+    ap, auc = eval_edge_prediction(model, mk(n_warm, n_warm + n_val), dev(), restart_mode=True, uptodate_nodes=set(up))
+    assert abs(ap - float(z['restart200_ap'])) < tol and abs(auc - float(z['restart200_auc'])) < tol
+    assert rel_err(model.left_memory.vals.cpu().numpy(), z['final_left_vals']) < 1e-4
+    assert rel_err(model.right_memory.vals.cpu().numpy(), z['final_right_vals']) < 1e-4

@@ -143,6 +143,7 @@ SIGNATURES = {
     'tg_train_step_workspace_bytes': (sz, [P(TgModel), P(TgScoreParams), i32, vp, i64]),
     'tg_train_step': (C.c_int, [P(TgModel), P(TgTcsr), P(TgTrainIo), vp, sz, vp]),
     'tg_adam_step': (C.c_int, [vp, i32, i32, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
+    'tg_ap_auc': (C.c_int, [i64, i32, vp, vp, vp, vp, vp, vp]),
     'tg_stream_writeback_workspace_bytes': (sz, [P(TgModel), i64]),
     'tg_stream_writeback': (C.c_int, [P(TgModel), P(TgWritebackIo), vp, sz, vp]),
 }

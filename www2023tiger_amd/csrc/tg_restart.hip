@@ -650,7 +650,7 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
     return check_launch("mutual_step(static)");
   }
   // ---- SeqRestarter backward
-  const int dm = 4 * d + m->d_e, nh = r->n_head, dh = dm / nh;
+  const int dm = 4 * d + m->d_e, nh = r->n_head;
   const int32_t* n_dev = w.counts2;
   const int32_t* nH_dev = w.counts2 + 1;
   const SeqWs& q = w.seq;

@@ -786,7 +786,7 @@ extern "C" int tg_train_step(const tg_model* m, const tg_tcsr* g, const tg_train
                           io->flags ? io->flags + 2 : nullptr, t.part, t.part_floats, cv.p, cv.left, st)) != TG_OK)
       return rc;
   } else if (io->flags) {
-    hipMemsetAsync(io->flags + 2, 0, sizeof(int32_t), st);
+    (void)hipMemsetAsync(io->flags + 2, 0, sizeof(int32_t), st);
   }
   return step_writeback_b(m, sio, w, st, nullptr);
 }
