@@ -398,6 +398,58 @@ def gen_eval(name, cfg):
     print(f'{name}.npz', sum(v.nbytes for v in out.values()) // 1024, 'KiB raw')
 
 
+def write_jodie_files(root, name, src, dst, ts, labels, efeats, nfeats):
+    """The preprocessed JODIE layout the reference reads: data/ml_<name>.csv (+ .npy, _node.npy)."""
+    import pandas as pd
+    os.makedirs(os.path.join(root, 'data'), exist_ok=True)
+    df = pd.DataFrame({'u': src, 'i': dst, 'ts': ts, 'label': labels, 'idx': np.arange(1, len(src) + 1)})
+    df.to_csv(os.path.join(root, 'data', f'ml_{name}.csv'))
+    if efeats is not None:
+        np.save(os.path.join(root, 'data', f'ml_{name}.npy'), efeats)
+    if nfeats is not None:
+        np.save(os.path.join(root, 'data', f'ml_{name}_node.npy'), nfeats)
+
+
+def gen_input_side():
+    """load_jodie_data splits (data_loader.py:316-404) on a toy dataset and ChunkSampler ranges."""
+    import tempfile
+    from tiger.data.data_loader import ChunkSampler, load_jodie_data
+    out = {'versions': VERSIONS}
+    src, dst, ts, _ = make_stream(41, 120, 40, 3000, 5000.0, integer_ts=False)
+    rs = np.random.RandomState(41)
+    labels = (rs.uniform(size=len(src)) < 0.02).astype(np.int64)
+    efeats = rs.standard_normal((len(src) + 1, 6)).astype(np.float32)
+    nfeats = np.zeros((int(max(src.max(), dst.max())) + 1, 6), dtype=np.float32)
+    out.update(src=src, dst=dst, ts=ts, labels=labels, efeats=efeats, nfeats=nfeats)
+    with tempfile.TemporaryDirectory() as root:
+        write_jodie_files(root, 'toy', src, dst, ts, labels, efeats, nfeats)
+        for seed in (0, 7):
+            res = load_jodie_data('toy', train_seed=seed, root=root)
+            names = ('full', 'train', 'val', 'test', 'ind_val', 'ind_test')
+            for nm, dset in zip(names, res[2:]):
+                out[f's{seed}_{nm}_eids'] = np.asarray(dset.eids)
+                if dset.neg_dst is not None:
+                    out[f's{seed}_{nm}_neg'] = np.asarray(dset.neg_dst)
+            # the training split draws negatives on the fly from its own sampler
+            tr = res[3]
+            out[f's{seed}_train_draws'] = np.array([tr[i][2] for i in range(50)])
+        write_jodie_files(root, 'bare', src, dst, ts, labels, None, None)  # no feature files
+        res = load_jodie_data('bare', train_seed=1, root=root, val_p=0.6, test_p=0.8)
+        assert res[0] is None and res[1] is None
+        out['bare_train_eids'] = np.asarray(res[3].eids)
+        out['bare_ind_test_eids'] = np.asarray(res[7].eids)
+    rows = []
+    for (n, rank, ws, bs, seed, epoch) in [(1000, 0, 2, 64, 0, 0), (1000, 1, 2, 64, 0, 0), (1000, 1, 2, 64, 0, 3),
+                                           (12345, 2, 4, 200, 5, 1), (512, 0, 1, 64, 9, 2), (130, 1, 2, 64, 1, 4)]:
+        cs = ChunkSampler(n, rank, ws, bs, seed)
+        cs.set_epoch(epoch)
+        idx = list(iter(cs))
+        rows.append([n, rank, ws, bs, seed, epoch, len(cs), idx[0] if idx else -1, idx[-1] if idx else -1])
+    out['chunk_sampler'] = np.array(rows, dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, 'input_side.npz'), **out)
+    print('input_side.npz', sum(v.nbytes for v in out.values()) // 1024, 'KiB raw')
+
+
 EVAL_SCENARIOS = {
     'eval_seq_lr_d8': dict(d=8, n_u=40, n_i=15, E=900, T=450.0, B=50, K=5, H=8, seed=31, wseed=31, restarter='seq',
                            msg_src='left', upd_src='right', hit='bin', n_warm=300, n_val=500, chunk=64),
@@ -455,6 +507,8 @@ if __name__ == '__main__':
     for nm, cfg in TRAIN_SCENARIOS.items():
         if not only or nm in only:
             gen_train(nm, cfg)
+    if not only or 'input_side' in only:
+        gen_input_side()
     for nm, cfg in EVAL_SCENARIOS.items():
         if not only or nm in only:
             gen_eval(nm, cfg)

@@ -65,3 +65,30 @@ def test_eval_harness_matches_reference(name):
     assert abs(ap - float(z['restart200_ap'])) < tol and abs(auc - float(z['restart200_auc'])) < tol
     assert rel_err(model.left_memory.vals.cpu().numpy(), z['final_left_vals']) < 1e-4
     assert rel_err(model.right_memory.vals.cpu().numpy(), z['final_right_vals']) < 1e-4
+
+
+def test_end_to_end_recipe_on_toy_jodie_files(tmp_path):
+    """init_data -> init_model -> train (torch Adam, lazy restarts, mutual learning) -> validate with
+    snapshots -> checkpoint round trip -> test: the reference's script flow on this package's API."""
+    import os
+    import sys
+    from test_input_side import write_files
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'examples'))
+    import link_prediction as lp
+    z = load('input_side')
+    write_files(str(tmp_path), 'toy', z, with_feats=False)  # LastFM-style: no feature files, width from --dim
+    ckpt = str(tmp_path / 'model.pt')
+    out, model = lp.run('toy', str(tmp_path), seed=0, n_epochs=2, bs=100, lr=1e-3, dim=8, n_neighbors=4, hist_len=6,
+                        restarter_type='seq', restart_prob=0.2, warmup_steps=100, ckpt_path=ckpt)
+    e0, e1 = out['epochs']
+    assert all(np.isfinite(list(e.values())).all() for e in out['epochs'])
+    assert e1['contrast'] < e0['contrast']           # it learns
+    assert 0.0 <= out['test_ap'] <= 1.0 and 0.0 <= out['ind_test_auc'] <= 1.0
+    # the checkpoint carries parameters and both memories (with the alias keys); the mailbox buffers are
+    # non-persistent in the reference (memory.py:62-67) and here
+    sd = torch.load(ckpt)
+    for k in ('left_memory.vals', 'right_memory.update_ts', 'msg_memory.vals', 'upd_memory.vals',
+              'score_fn.fc1.weight', 'restarter_fn.mha_fn.in_proj_weight'):
+        assert k in sd, k
+    assert not any(k.startswith('msg_store.') for k in sd)

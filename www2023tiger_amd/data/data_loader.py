@@ -141,3 +141,89 @@ class InteractionData(torch.utils.data.Dataset):
 
     def __len__(self):
         return len(self.ts)
+
+
+class ChunkSampler(torch.utils.data.Sampler):
+    """data_loader.py:17-40: the time-chunk sampler of the reference's DDP recipe.  Rank r reads
+    the contiguous index range [shift + r*len, shift + (r+1)*len), len = n // (world*bs) * bs;
+    `shift` is drawn per epoch from the leftover events so that chunk boundaries move."""
+
+    def __init__(self, n: int, rank: int, world_size: int, bs: int, seed: int = 0):
+        self.n, self.rank, self.world_size, self.bs, self.seed = n, rank, world_size, bs, seed
+        self.epoch = 0
+
+    def __len__(self):
+        return self.n // (self.world_size * self.bs) * self.bs
+
+    def set_epoch(self, epoch: int):
+        self.epoch = epoch
+
+    def __iter__(self):
+        gen = torch.Generator()
+        gen.manual_seed(self.seed + self.epoch)
+        leftover = self.n % (self.world_size * self.bs)
+        shift = int(torch.randint(0, leftover + 1, size=(), generator=gen))
+        start = shift + len(self) * self.rank
+        return iter(range(start, start + len(self)))
+
+
+def _read_jodie_tables(root, name):
+    import pathlib
+
+    import pandas as pd
+    base = pathlib.Path(root) / 'data'
+    frame = pd.read_csv(base / f'ml_{name}.csv')
+    feats = []
+    for suffix in ('', '_node'):  # edge features, then node features; either file may be absent
+        f = base / f'ml_{name}{suffix}.npy'
+        feats.append(np.load(f) if f.exists() else None)
+    return frame, feats[0], feats[1]
+
+
+def load_jodie_data(name: str, train_seed: int, *, root='.', data_seed=2020, val_p=0.7, test_p=0.85):
+    """data_loader.py:316-404: preprocessed JODIE files -> (nfeats, efeats, full, train, val, test,
+    inductive_val, inductive_test).  Chronological split at the val_p / test_p time quantiles; 10 %
+    of all nodes, drawn (python `random`, seed 2020 as TGAT/TGN) among the nodes seen after the
+    validation time, are removed from training so that they are new at inference time; the
+    inductive splits keep the events touching any node never seen in training."""
+    import random
+    frame, efeats, nfeats = _read_jodie_tables(root, name)
+    src, dst, ts = frame.u.values, frame.i.values, frame.ts.values
+    eids, labels = frame.idx.values, frame.label.values
+    cols = (src, dst, ts, eids, labels)
+    t_val, t_test = (float(q) for q in np.quantile(frame.ts, [val_p, test_p]))
+
+    def subset(mask, seed, eval_mode):
+        return InteractionData(*(c[mask] for c in cols), seed=seed, eval=eval_mode)
+
+    all_nodes = set(src) | set(dst)
+    late = ts > t_val
+    # the draw depends on the iteration order of this set: build it exactly as a union of two sets
+    seen_late = set(src[late]).union(set(dst[late]))
+    hidden = set(random.Random(data_seed).sample(tuple(seen_late), int(0.1 * len(all_nodes))))
+    touches_hidden = frame.u.isin(hidden).values | frame.i.isin(hidden).values
+    train = subset((ts <= t_val) & ~touches_hidden, train_seed, False)
+    trained_nodes = set(train.src) | set(train.dst)
+    if trained_nodes & hidden:
+        raise AssertionError('a held-out node leaked into the training split')
+    unseen = list(all_nodes - trained_nodes)
+    in_val, in_test = (ts > t_val) & (ts <= t_test), ts > t_test
+    touches_unseen = np.isin(src, unseen) | np.isin(dst, unseen)
+    return (nfeats, efeats, InteractionData(*cols),
+            train, subset(in_val, 0, True), subset(in_test, 2, True),
+            subset(in_val & touches_unseen, 1, True), subset(in_test & touches_unseen, 3, True))
+
+
+def compute_delta_std(srcs: np.ndarray, dsts: np.ndarray, ts: np.ndarray) -> float:
+    """data_loader.py:464-478: std of the time since each endpoint's previous event (first event: since 0)."""
+    last = {}
+    deltas = np.empty(2 * len(ts), dtype=np.float64)
+    for k, (s, d, t) in enumerate(zip(srcs, dsts, ts)):
+        deltas[2 * k], deltas[2 * k + 1] = t - last.get(s, 0), t - last.get(d, 0)
+        last[s] = last[d] = t
+    return float(np.std(deltas))
+
+
+def is_sorted(x) -> bool:
+    x = np.asarray(x)
+    return bool(np.all(x[:-1] <= x[1:]))
