@@ -256,3 +256,63 @@ def test_resident_sharded_stream_graph_replay_equals_single_gpu(tmp_path):
         assert rel_err(got['left'], model.left_memory.vals.cpu().numpy()) < 1e-6
         assert rel_err(got['right'], model.right_memory.vals.cpu().numpy()) < 1e-6
         assert rel_err(got['msg'][has], model.msg_store.node_msg_vals.cpu().numpy()[has]) < 1e-6
+
+
+# ------------------------------------------------------------------------------ the reference's DDP recipe
+def _ddp_worker(rank, world, port, root, n_steps, out_dir):
+    """train_self_supervised_ddp.py:107-211 on this package's API: ChunkSampler time chunks,
+    always-on lazy restarts, torch DDP (find_unused_parameters) around the model, Adam with lr*sqrt(world)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    tdist.init_process_group('gloo', rank=rank, world_size=world)
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from www2023tiger_amd.init_utils import init_data, init_model
+    device = torch.device('cuda', 0)
+    torch.manual_seed(0)
+    basic, (train_graph, full_graph), dls = init_data(
+        'toy', root, 0, rank=rank, world_size=world, num_workers=0, bs=64, warmup_steps=0, subset=1.0,
+        strategy='recent_edges', n_layers=1, n_neighbors=4, restarter_type='seq', hist_len=6, device=device)
+    model = init_model(basic[0], basic[1], train_graph, full_graph, basic[2], device, dim=8, n_layers=1, n_heads=2,
+                       n_neighbors=4, hit_type='bin', dropout=0.0, restarter_type='seq', hist_len=6, msg_src='left',
+                       upd_src='right', msg_tsfm_type='id', mem_update_type='gru')
+    ddp_model = DDP(model, broadcast_buffers=False, find_unused_parameters=True)
+    optimizer = torch.optim.Adam(ddp_model.parameters(), lr=1e-3 * np.sqrt(world))
+    ddp_model.train()
+    model.reset()
+    uptodate, losses = set(), []
+    first_index = None
+    for i_batch, (src, dst, neg, ts, eids, _, cg) in enumerate(dls[0]):
+        if i_batch == n_steps:
+            break
+        if first_index is None:
+            first_index = int(eids[0])
+        src, dst, neg, eids = (x.long().to(device) for x in (src, dst, neg, eids))
+        ts = ts.float().to(device)
+        optimizer.zero_grad()
+        todo = set(cg.np_computation_graph_nodes.tolist()) - uptodate  # DDP mode: always restarting
+        nids = torch.tensor(sorted(todo), dtype=torch.long, device=device)
+        model.restart(nids, torch.full((len(nids),), ts.min().item(), device=device))
+        uptodate |= todo
+        c_loss, m_loss = ddp_model(src, dst, neg, ts, eids, cg, contrast_only=False)
+        loss = c_loss + m_loss
+        loss.backward()
+        optimizer.step()
+        losses.append(loss.item())
+    flat = torch.cat([p.detach().flatten() for p in model.parameters()]).cpu().numpy()
+    np.savez(os.path.join(out_dir, f'ddp{rank}.npz'), params=flat, losses=np.array(losses), first=first_index)
+    tdist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_reference_ddp_recipe_two_ranks(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from test_input_side import write_files
+    z = load('input_side')
+    write_files(str(tmp_path), 'toy', z, with_feats=False)
+    world, n_steps = 2, 4
+    mp.spawn(_ddp_worker, args=(world, free_port(), str(tmp_path), n_steps, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (np.load(os.path.join(str(tmp_path), f'ddp{r}.npz')) for r in range(world))
+    assert np.isfinite(r0['losses']).all() and np.isfinite(r1['losses']).all()
+    assert int(r0['first']) != int(r1['first'])                    # different time chunks
+    assert not np.allclose(r0['losses'], r1['losses'])               # ... hence different losses
+    np.testing.assert_array_equal(r0['params'], r1['params'])        # gradients were all-reduced: replicas agree
