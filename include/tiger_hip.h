@@ -295,6 +295,15 @@ int tg_restart_seq_fwd(const tg_model* m, const tg_seq_restarter* r, int64_t n, 
                        const float* hist_ts, const int64_t* hist_dirs, float* h_left, float* h_right,
                        float* prev_ts, void* ws, size_t ws_bytes, void* stream);
 
+/* The same forward in training mode (the reference calls TIGER.restart inside the training loop with
+ * the module in train() mode, so the restarter's attention / merger dropout is active): masks as
+ * described at tg_train_io; rng[1] is incremented.  dropout_p == 0 equals tg_restart_seq_fwd. */
+int tg_restart_seq_fwd_train(const tg_model* m, const tg_seq_restarter* r, int64_t n, const int64_t* nids,
+                             const int64_t* hist_nids, const int64_t* anon_ids, const int64_t* hist_eids,
+                             const float* hist_ts, const int64_t* hist_dirs, float* h_left, float* h_right,
+                             float* prev_ts, float dropout_p, uint64_t* rng, void* ws, size_t ws_bytes,
+                             void* stream);
+
 /* TIGER.restart's state update (tiger.py:603,608-609): clear has-message bits of
  * nids, then left/right memory rows and timestamps <- (h_left, h_right, prev_ts)
  * with skip_check semantics. */
@@ -383,7 +392,7 @@ typedef struct tg_score_params {
  * Gradients are ACCUMULATED (+=) into buffers laid out like the parameters: `grads` is a
  * tg_model whose parameter pointers (te_*, gru_*, attn_*) point at gradient buffers (other
  * fields ignored), `score_grads` likewise for the score head.  Supported: message transform
- * 'id', updater 'gru', one attention layer, dropout 0.
+ * 'id', updater 'gru', one attention layer.
  * flags (device int32[4]) says which parameter groups received a gradient this step (torch leaves
  * the .grad of the others None and Adam skips them): [0] = 1 always (embedding, score head, time
  * encoder), [1] = the GRU ran (some involved node had a pending message), [2] = the mutual loss
@@ -409,6 +418,13 @@ typedef struct tg_train_io {
   const float* static_right;
   float* static_left_grad;            /* dense gradients [n_nodes, d] (+=) */
   float* static_right_grad;
+  /* dropout (the reference's --dropout: attention probabilities of the embedding and of the
+   * SeqRestarter, hidden layer of the score head and of the SeqRestarter's merger).  Masks are a
+   * counter-based hash of (rng[0] = seed, rng[1] = step counter, stream, element); the step ends by
+   * incrementing rng[1].  The masks are NOT torch's: results match the reference in distribution. */
+  float dropout_p;                    /* 0 <= p < 1; 0 = off */
+  int32_t reserved2;
+  uint64_t* rng;                      /* device uint64[2]; required when dropout_p > 0 */
 } tg_train_io;
 
 #define TG_RESTARTER_NONE 0

@@ -187,10 +187,32 @@ def linear(x, w, b=None):
     return y if b is None else y + b
 
 
-def merge_layer(x1, x2, p, prefix):
-    """basic_modules.py:16-19 (dropout inactive in eval)."""
+def merge_layer(x1, x2, p, prefix, hmask=None):
+    """basic_modules.py:16-19.  hmask: dropout mask (keep / (1-p)) on the hidden layer, None in eval."""
     h = torch.relu(linear(torch.cat([x1, x2], -1), p[prefix + 'fc1.weight'], p[prefix + 'fc1.bias']))
+    if hmask is not None:
+        h = h * hmask
     return linear(h, p[prefix + 'fc2.weight'], p[prefix + 'fc2.bias'])
+
+
+def _mix32(x):
+    x = x ^ (x >> np.uint64(16))
+    x = (x * np.uint64(0x7feb352d)) & np.uint64(0xffffffff)
+    x = x ^ (x >> np.uint64(15))
+    x = (x * np.uint64(0x846ca68b)) & np.uint64(0xffffffff)
+    return x ^ (x >> np.uint64(16))
+
+
+def dropout_keep(seed: int, counter: int, stream: int, n: int, p: float, offset: int = 0) -> np.ndarray:
+    """The library's counter-based dropout mask (csrc/tg_common.h: drop_keep): element `offset + j`
+    of mask stream `stream` at step `counter` of seed `seed` is kept iff hash >= p * 2^32."""
+    key = (seed + counter * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
+    idx = np.arange(offset, offset + n, dtype=np.uint64)
+    m32 = np.uint64(0xffffffff)
+    h = _mix32((idx & m32) ^ np.uint64(key & 0xffffffff))
+    h = _mix32((h + (idx >> np.uint64(32)) * np.uint64(0x9e3779b9) + np.uint64(key >> 32)
+                + np.uint64((stream * 0x85ebca6b) & 0xffffffff)) & m32)
+    return h >= np.uint64(min(int(p * 4294967296.0), 0xffffffff))
 
 
 def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh):
@@ -204,7 +226,7 @@ def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh):
     return (1 - z) * n + z * h
 
 
-def mha(query, key, value, wq, wk, wv, b_in, wo, bo, n_head, key_padding_mask):
+def mha(query, key, value, wq, wk, wv, b_in, wo, bo, n_head, key_padding_mask, drop=None):
     """torch.nn.MultiheadAttention forward (eval, batch_first=False, math path):
     query [L,n,E], key/value [S,n,*]; returns [L,n,E].  Used at
     temporal_agg_modules.py:204-227 and restarters.py:46,105."""
@@ -221,6 +243,8 @@ def mha(query, key, value, wq, wk, wv, b_in, wo, bo, n_head, key_padding_mask):
     mask = key_padding_mask.view(n, 1, 1, S).expand(n, n_head, L, S).reshape(n * n_head, L, S)
     att = att.masked_fill(mask, float('-inf'))
     att = torch.softmax(att, dim=-1)
+    if drop is not None:  # nn.MultiheadAttention dropout acts on the attention probabilities
+        att = att * drop(att.numel()).reshape(att.shape)
     o = (att @ v).transpose(0, 1).reshape(L, n, E)
     return linear(o, wo, bo)
 
@@ -248,6 +272,7 @@ class OracleTIGER:
         self.msg_src, self.upd_src = msg_src, upd_src
         self.restarter, self.tsfm, self.upd_fn, self.hit_type = restarter, tsfm, upd_fn, hit_type
         self.raw_msg_dim = 2 * dim + self.d_e + dim  # tiger.py:62
+        self.dropout = None  # training only: (p, seed, step counter) of the library's mask generator
         self.reset()
 
     # ---- state (memory.py:12-52, 55-75) -------------------------------------
@@ -273,6 +298,13 @@ class OracleTIGER:
                 raise ValueError('Duplicate node ids are not allowed.')
         tss[ids] = new_ts.detach() if isinstance(new_ts, torch.Tensor) else new_ts
         vals[ids] = new_vals.detach()
+
+    def _drop(self, stream: int, offset: int = 0):
+        """mask factory for one dropout site: n -> float tensor keep / (1 - p), or None when off"""
+        if self.dropout is None or not torch.is_grad_enabled():
+            return None
+        p, seed, counter = self.dropout
+        return lambda n: _t(dropout_keep(seed, counter, stream, n, p, offset).astype(F32) / np.float32(1.0 - p))
 
     # ---- features (feature_getter.py:80-106) ----------------------------------
     def node_feat(self, ids):
@@ -346,7 +378,7 @@ class OracleTIGER:
         h = mha(query, kv, kv, self.p[pre + 'mha_fn.q_proj_weight'], self.p[pre + 'mha_fn.k_proj_weight'],
                 self.p[pre + 'mha_fn.v_proj_weight'], self.p[pre + 'mha_fn.in_proj_bias'],
                 self.p[pre + 'mha_fn.out_proj.weight'], self.p[pre + 'mha_fn.out_proj.bias'],
-                self.n_head, mask).squeeze(0)
+                self.n_head, mask, drop=self._drop(1)).squeeze(0)
         h = h.masked_fill(invalid, 0.0)
         return merge_layer(h, c, self.p, pre + 'merger.')
 
@@ -412,8 +444,9 @@ class OracleTIGER:
             xp, yp, xn, yn = (a + emb[red(b)] for a, b in zip((x, y, x, ny), hits))
         else:
             xp, yp, xn, yn = x, y, x, ny
-        ps = merge_layer(xp, yp, self.p, 'score_fn.').squeeze(1)
-        ns = merge_layer(xn, yn, self.p, 'score_fn.').squeeze(1)
+        dp, dn = self._drop(2), self._drop(2, B * self.d)
+        ps = merge_layer(xp, yp, self.p, 'score_fn.', None if dp is None else dp(B * self.d).reshape(B, self.d)).squeeze(1)
+        ns = merge_layer(xn, yn, self.p, 'score_fn.', None if dn is None else dn(B * self.d).reshape(B, self.d)).squeeze(1)
         logits = torch.cat([ps, ns])
         labels = torch.cat([torch.ones_like(ps), torch.zeros_like(ns)])
         loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, labels)
@@ -467,6 +500,8 @@ class OracleTIGER:
         for v in self.p.values():
             v.requires_grad_(False)
             v.grad = None
+        if self.dropout is not None:  # the library advances its mask counter once per training step
+            self.dropout = (self.dropout[0], self.dropout[1], self.dropout[2] + 1)
         return float(c_loss.detach()), float(m_loss.detach()), grads
 
     # ---- streaming step: STEP 1-6 only, the benchmarked path -----------------
@@ -515,9 +550,11 @@ class OracleTIGER:
         w_in = self.p['restarter_fn.mha_fn.in_proj_weight']
         out = mha(qkv, qkv, qkv, w_in[:dm], w_in[dm:2 * dm], w_in[2 * dm:], self.p['restarter_fn.mha_fn.in_proj_bias'],
                   self.p['restarter_fn.mha_fn.out_proj.weight'], self.p['restarter_fn.mha_fn.out_proj.bias'],
-                  self.n_head, mask)
+                  self.n_head, mask, drop=self._drop(3))
         h_left = linear(torch.relu(out.mean(0)), self.p['restarter_fn.out_fn.weight'], self.p['restarter_fn.out_fn.bias'])
-        h_right = merge_layer(h_left, last, self.p, 'restarter_fn.merger.')
+        dm_ = self._drop(4)
+        h_right = merge_layer(h_left, last, self.p, 'restarter_fn.merger.',
+                              None if dm_ is None else dm_(h_left.numel()).reshape(h_left.shape))
         return h_left.masked_fill(invalid, 0.0), h_right.masked_fill(invalid, 0.0), ht[:, -1]
 
     def restart(self, nids: np.ndarray, ts: np.ndarray):  # tiger.py:594-609 (mix == 0)
@@ -526,6 +563,9 @@ class OracleTIGER:
             return
         self.has_msg[nids] = False
         hl, hr, pt = self.restarter_forward(nids, ts)
+        if self.dropout is not None and self.restarter == 'seq' and torch.is_grad_enabled():
+            # train() mode restart: the seq restarter's dropout was active; the library ticks its counter
+            self.dropout = (self.dropout[0], self.dropout[1], self.dropout[2] + 1)
         self._mem_set(self.left_vals, self.left_ts, _t(nids), hl, pt, skip_check=True)
         self._mem_set(self.right_vals, self.right_ts, _t(nids), hr, pt, skip_check=True)
 

@@ -89,6 +89,7 @@ class TgTrainIo(C.Structure):
         ('pos_scores', vp), ('neg_scores', vp), ('flags', vp), ('restarter', i32), ('reserved', i32),
         ('seq', vp), ('seq_grads', vp), ('static_left', vp), ('static_right', vp),
         ('static_left_grad', vp), ('static_right_grad', vp),
+        ('dropout_p', C.c_float), ('reserved2', i32), ('rng', vp),
     ]
 
 
@@ -131,6 +132,8 @@ SIGNATURES = {
     'tg_store_events': (C.c_int, [P(TgModel), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'tg_restart_seq_workspace_bytes': (sz, [P(TgModel), P(TgSeqRestarter), i64]),
     'tg_restart_seq_fwd': (C.c_int, [P(TgModel), P(TgSeqRestarter), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'tg_restart_seq_fwd_train': (C.c_int, [P(TgModel), P(TgSeqRestarter), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                           C.c_float, vp, vp, sz, vp]),
     'tg_restart_apply': (C.c_int, [P(TgModel), i64, vp, vp, vp, vp, vp]),
     'tg_profiler_create': (vp, []),
     'tg_profiler_destroy': (None, [vp]),

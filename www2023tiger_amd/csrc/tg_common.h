@@ -100,6 +100,43 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return copysignf(t, x);
 }
 
+// ---- dropout (training only).  Counter-based: element `idx` of mask stream `stream` at step
+// `rng[1]` of seed `rng[0]` is kept iff hash >= p * 2^32; kept values are scaled by 1/(1-p).  No
+// state is carried between kernels, so forward and backward regenerate identical masks, and the
+// host can reproduce them (tests/_util.py::dropout_keep).
+struct DropCfg {
+  float p;              // 0: dropout off
+  float scale;          // 1 / (1 - p)
+  uint32_t thresh;      // p * 2^32
+  const uint64_t* rng;  // device: {seed, step counter}
+};
+enum { DROP_ATTN = 1, DROP_SCORE = 2, DROP_SEQ_ATTN = 3, DROP_SEQ_MERGER = 4 };
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint64_t drop_key(const DropCfg& c) {
+  return c.rng ? c.rng[0] + c.rng[1] * 0x9E3779B97F4A7C15ull : 0ull;
+}
+__device__ __forceinline__ bool drop_keep(uint64_t key, uint32_t stream, uint64_t idx, uint32_t thresh) {
+  uint32_t h = mix32((uint32_t)idx ^ (uint32_t)key);
+  h = mix32(h + (uint32_t)(idx >> 32) * 0x9e3779b9u + (uint32_t)(key >> 32) + stream * 0x85ebca6bu);
+  return h >= thresh;
+}
+inline DropCfg make_drop(float p, const uint64_t* rng) {
+  DropCfg c{};
+  if (p > 0.f && rng) {
+    c.p = p;
+    c.scale = 1.0f / (1.0f - p);
+    const double t = (double)p * 4294967296.0;
+    c.thresh = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+    c.rng = rng;
+  }
+  return c;
+}
+
 // order-preserving maps float -> unsigned (for atomicMax on timestamps)
 __device__ __forceinline__ uint64_t orderable(double x) {
   uint64_t u = (uint64_t)__double_as_longlong(x);

@@ -38,6 +38,10 @@ struct GemmArgs {
   const float* relu_mask;
   int64_t ld_mask;
   int accumulate;
+  // bias[n] * bias_rs[m * ld_brs + batch] instead of bias[n] (attention with dropout: the value
+  // bias is weighted by the sum of the kept, rescaled probabilities)
+  const float* bias_rs;
+  int64_t ld_brs;
 };
 
 int gemm_launch(const GemmArgs& g, hipStream_t st);
@@ -82,6 +86,9 @@ struct TnArgs {
   float* bias_out;
   int bias_accumulate;
   int64_t bias_bs;
+  const float* bias_rs;  // nullable: row weights, bias_out[n] = sum_m bias_rs[m * ld_brs + brs_col] * Y[m, n]
+  int64_t ld_brs;
+  int brs_col;           // column of bias_rs used by batch 0 (batch b uses brs_col + b)
 };
 int gemm_tn_launch(const TnArgs& a, hipStream_t st);
 // out[n] (+)= alpha * sum_m Y[m, n]

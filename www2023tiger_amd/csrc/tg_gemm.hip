@@ -160,7 +160,8 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
   for (int r = 0; r < 16; ++r) {
     const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
     if (m >= M) continue;
-    float v = g.alpha * (acc[r] + bias);
+    const float be = g.bias_rs ? bias * g.bias_rs[m * g.ld_brs + bz] : bias;
+    float v = g.alpha * (acc[r] + be);
     if (g.relu) v = fmaxf(v, 0.f);
     if (g.row_valid && !g.row_valid[m]) v = 0.f;
     if (g.relu_mask && !(g.relu_mask[m * g.ld_mask + n] > 0.f)) v = 0.f;
@@ -503,8 +504,15 @@ __global__ void __launch_bounds__(256) k_gemm_tn(TnArgs a, int splits) {
       for (int s2 = 0; s2 < TN_MC / 2; ++s2)
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yp[s2 * 2 * TN_LD], xp[s2 * 2 * TN_LD], acc, 0, 0, 0);
       if (do_bias) {
+        if (a.bias_rs) {
+          for (int r = 0; r < TN_MC; ++r) {
+            const int64_t m = min(mb + r, M - 1);  // rows past m_hi are zero in Ys
+            bsum = fmaf(Ys[buf][r][tid], a.bias_rs[m * a.ld_brs + a.brs_col + bz], bsum);
+          }
+        } else {
 #pragma unroll
-        for (int r = 0; r < TN_MC; ++r) bsum += Ys[buf][r][tid];
+          for (int r = 0; r < TN_MC; ++r) bsum += Ys[buf][r][tid];
+        }
       }
       if (more) store_chunk(buf ^ 1, mb + TN_MC);
       __syncthreads();

@@ -88,8 +88,10 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
                                                    const int64_t* __restrict__ l1_eids, const float* __restrict__ l1_ts,
                                                    const float4* __restrict__ reprs, const uint64_t* __restrict__ bm,
                                                    const uint32_t* __restrict__ rank, const float4* __restrict__ G,
-                                                   float4* __restrict__ S, uint8_t* __restrict__ valid) {
+                                                   float4* __restrict__ S, uint8_t* __restrict__ valid, DropCfg dc,
+                                                   float* __restrict__ rsum) {
   const int lane = lane_id();
+  const uint64_t dkey = drop_key(dc);
   const int d4 = m.d / 4, e4 = m.d_e / 4, K = m.n_neighbors;
   const int kv4 = 2 * d4 + e4;
   const float4* nf = reinterpret_cast<const float4*>(m.nfeats);
@@ -118,11 +120,12 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
     unsigned long long live = __ballot(nb_l != 0);  // padding keys are masked (temporal_agg_modules.py:80)
     const bool any = live != 0ull;
     float4 g[NH][3][NV], acc[NH][3][NV];
-    float mx[NH], l[NH];
+    float mx[NH], l[NH], lk[NH];  // lk: sum of the kept exponentials (dropout), same rescaling as l
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       mx[h] = -INFINITY;
       l[h] = 0.f;
+      lk[h] = 0.f;
       const float4* gh = G + ((int64_t)i * NH + h) * kv4;
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
@@ -177,6 +180,7 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
         if (p > mx[h]) {  // new running maximum: rescale what has been accumulated (uniform branch)
           const float a = expf(mx[h] - p);
           l[h] *= a;
+          lk[h] *= a;
 #pragma unroll
           for (int sgm = 0; sgm < 3; ++sgm)
 #pragma unroll
@@ -186,6 +190,10 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
           b = expf(p - mx[h]);
         }
         l[h] += b;
+        if (dc.p > 0.f) {  // attention dropout (nn.MultiheadAttention): the softmax normaliser keeps every key
+          b = drop_keep(dkey, DROP_ATTN, ((uint64_t)i * NH + h) * (uint64_t)K + (uint64_t)k, dc.thresh) ? b * dc.scale : 0.f;
+          lk[h] += b;
+        }
 #pragma unroll
         for (int sgm = 0; sgm < 3; ++sgm)
 #pragma unroll
@@ -211,7 +219,13 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
         if (c < e4) sh[d4 + c] = b;
       }
     }
-    if (lane == 0) valid[i] = any ? 1 : 0;
+    if (lane == 0) {
+      valid[i] = any ? 1 : 0;
+      if (rsum) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) rsum[i * NH + h] = dc.p > 0.f ? (any ? lk[h] / l[h] : 0.f) : 1.f;
+      }
+    }
   }
 }
 
@@ -232,6 +246,7 @@ static bool carve_attn(const tg_model* m, int64_t Q, Carver& cv, AttnWs& w) {
   w.hh = cv.take<float>((size_t)Q * 2 * d);
   w.t = cv.take<float>((size_t)Q * d);
   w.qconst = cv.take<float>((size_t)2 * d);
+  w.rsum = cv.take<float>((size_t)Q * nh);
   w.valid = cv.take<uint8_t>((size_t)Q);
   return cv.ok;
 }
@@ -239,7 +254,7 @@ static bool carve_attn(const tg_model* m, int64_t Q, Carver& cv, AttnWs& w) {
 static size_t attn_ws_bytes(const tg_model* m, int64_t Q) {
   const size_t d = m->d, kvw = 2 * m->d + m->d_e, nh = m->n_head;
   return align16(Q * d * 4) * 2 + align16(Q * 2 * d * 4) * 3 + align16(Q * nh * kvw * 4) * 2 + align16(2 * d * 4) +
-         align16(Q);
+         align16(Q * nh * 4) + align16(Q);
 }
 
 }  // namespace tg
@@ -249,7 +264,9 @@ constexpr int ST_ATTN_FIRST = 5;  // == ST_ATTN_PREP (checked by a static_assert
 
 int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float* ts, const int64_t* l1_nids,
                  const int64_t* l1_eids, const float* l1_ts, const float* reprs, const uint64_t* bm,
-                 const uint32_t* rank, float* out, const AttnWs& w, hipStream_t st, tg_profiler* pf = nullptr) {
+                 const uint32_t* rank, float* out, const AttnWs& w, hipStream_t st, tg_profiler* pf = nullptr,
+                 const DropCfg* drop = nullptr) {
+  const DropCfg dc = drop ? *drop : DropCfg{};
   int stage = ST_ATTN_FIRST;
   prof_mark(pf, stage++, st);
   const int d = m->d, d_e = m->d_e, kvw = 2 * d + d_e, nh = m->n_head, dh = 2 * d / nh, E = 2 * d;
@@ -281,7 +298,8 @@ int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float*
   const unsigned cgrid = flat_grid(Q, 4);
 #define TG_CORE(NH_, NV_)                                                                                          \
   hipLaunchKernelGGL((k_attn_core<NH_, NV_>), dim3(cgrid), dim3(256), 0, st, *m, Q, ts, l1_nids, l1_eids, l1_ts,   \
-                     (const float4*)reprs, bm, rank, (const float4*)w.g, (float4*)w.s, w.valid)
+                     (const float4*)reprs, bm, rank, (const float4*)w.g, (float4*)w.s, w.valid, dc,                 \
+                     dc.p > 0.f ? w.rsum : (float*)nullptr)
   if (nh == 2 && nv == 1) TG_CORE(2, 1);
   else if (nh == 2 && nv == 2) TG_CORE(2, 2);
   else if (nh == 1 && nv == 1) TG_CORE(1, 1);
@@ -295,6 +313,7 @@ int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float*
   g.a0 = ASeg{w.s, (int64_t)nh * kvw, kvw, nullptr}; g.a0_bs = kvw;
   g.w = m->attn_wv; g.ldw = kvw; g.w_bs = (int64_t)dh * kvw;
   g.bias = m->attn_b_in + 2 * E; g.bias_bs = dh;
+  if (dc.p > 0.f) { g.bias_rs = w.rsum; g.ld_brs = nh; }
   g.c = w.o; g.ldc = E; g.c_bs = dh; g.alpha = 1.f; g.nbatch = nh;
   if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
   // h = Wo o + bo, zeroed for centres without neighbours (temporal_agg_modules.py:224-231)
@@ -614,7 +633,7 @@ extern "C" size_t tg_stream_step_zero_bytes(const tg_model* m, int64_t B) {
 
 namespace tg {
 int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, StepWs& w, float* gates, hipStream_t st,
-                 tg_profiler* pf) {
+                 tg_profiler* pf, const DropCfg* drop) {
   const int64_t B = io->B, Q = 3 * B, K = m->n_neighbors, cap = Q * (K + 1);
   prof_mark(pf, ST_QUERIES, st);
   hipError_t e = hipSuccess;
@@ -648,8 +667,8 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
                            st, true, gates)) != TG_OK)
     return rc;
   // ---- STEP 3: temporal embeddings of cat[src, dst, neg]
-  if ((rc = attn_forward(m, Q, w.nids3, w.ts3f, w.l1n, w.l1e, w.l1t, w.reprs, w.bm, w.rank, io->h, w.attn, st, pf)) !=
-      TG_OK)
+  if ((rc = attn_forward(m, Q, w.nids3, w.ts3f, w.l1n, w.l1e, w.l1t, w.reprs, w.bm, w.rank, io->h, w.attn, st, pf,
+                         drop)) != TG_OK)
     return rc;
   prof_mark(pf, ST_DEDUP, st);
   if (io->h_new) {  // h(t'+) rows of cat[src, dst]: reprs[local(node)]

@@ -66,12 +66,15 @@ __global__ void k_seq_build(tg_model m, tg_seq_restarter r, int64_t n, const int
 template <int HMAX>
 __global__ void __launch_bounds__(256) k_seq_scores(int64_t n, int H, int dm, int nh, const float* __restrict__ qk,
                                                     const int64_t* __restrict__ h_n, float* __restrict__ abar,
-                                                    const int32_t* __restrict__ n_dev) {
+                                                    const int32_t* __restrict__ n_dev, DropCfg dc,
+                                                    float* __restrict__ rbar) {
   if (n_dev && (int64_t)(blockIdx.x / nh) >= (int64_t)*n_dev) return;
+  const uint64_t dkey = drop_key(dc);
   constexpr int CH = 32;                   // dh chunk staged per iteration
   constexpr int PPT = (HMAX * HMAX + 255) / 256;  // (t,s) pairs per thread
   __shared__ float sq[HMAX][CH + 1], sk[HMAX][CH + 1];
   __shared__ float sc[HMAX][HMAX + 1];
+  __shared__ float colm[HMAX];
   const int64_t i = blockIdx.x / nh;
   const int h = blockIdx.x % nh;
   const int dh = dm / nh;
@@ -122,13 +125,26 @@ __global__ void __launch_bounds__(256) k_seq_scores(int64_t n, int H, int dm, in
       sum += e;
     }
     const float inv = 1.f / sum;
-    for (int s = 0; s < H; ++s) sc[tid][s] *= inv;
+    for (int s = 0; s < H; ++s) {
+      float ms = 1.f;  // attention dropout (nn.MultiheadAttention) on the normalised probabilities
+      if (dc.p > 0.f)
+        ms = drop_keep(dkey, DROP_SEQ_ATTN, (((uint64_t)i * nh + h) * H + tid) * H + s, dc.thresh) ? dc.scale : 0.f;
+      sc[tid][s] *= inv * ms;
+    }
   }
   __syncthreads();
   if (tid < H) {  // column mean
     float a = 0.f;
     for (int t = 0; t < H; ++t) a += sc[t][tid];
-    abar[((int64_t)i * nh + h) * H + tid] = a / (float)H;
+    a /= (float)H;
+    abar[((int64_t)i * nh + h) * H + tid] = a;
+    colm[tid] = a;
+  }
+  __syncthreads();
+  if (tid == 0 && rbar) {  // sum of the column means: weight of the value bias (1 without dropout)
+    float r = 0.f;
+    for (int s = 0; s < H; ++s) r += colm[s];
+    rbar[(int64_t)i * nh + h] = dc.p > 0.f ? r : 1.f;
   }
 }
 
@@ -157,7 +173,9 @@ __global__ void k_seq_mix(int64_t n, int H, int row4, int nh, const float* __res
 // dabar[i, h, s] = dxbar[i, h, :] . X[(i, s), :]   (one wavefront per (i, h, s))
 __global__ void __launch_bounds__(256) k_seq_mix_bwd(int64_t n, const int32_t* __restrict__ n_dev, int H, int row4,
                                                      int nh, const float4* __restrict__ dxbar,
-                                                     const float4* __restrict__ X, float* __restrict__ dabar) {
+                                                     const float4* __restrict__ X, float* __restrict__ dabar,
+                                                     const float* __restrict__ dO, const float* __restrict__ bv) {
+  // dO / bv non-null (dropout): abar also weights the value bias, d rbar = dO_h . bv_h is added
   if (n_dev) n = min(n, (int64_t)*n_dev);
   const int lane = lane_id();
   const int64_t total = n * nh * H;
@@ -172,6 +190,10 @@ __global__ void __launch_bounds__(256) k_seq_mix_bwd(int64_t n, const int32_t* _
       const float4 u = a[c], v = b[c];
       acc = fmaf(u.x, v.x, fmaf(u.y, v.y, fmaf(u.z, v.z, fmaf(u.w, v.w, acc))));
     }
+    if (dO) {
+      const int dm = row4 * 4, dh = dm / nh, h = (int)(ih % nh);
+      for (int c = lane; c < dh; c += TG_WAVE) acc = fmaf(dO[i * dm + h * dh + c], bv[h * dh + c], acc);
+    }
     acc = wave_sum(acc);
     if (lane == 0) dabar[t] = acc;
   }
@@ -184,8 +206,10 @@ template <int HMAX>
 __global__ void __launch_bounds__(256) k_seq_scores_bwd(int64_t n, const int32_t* __restrict__ n_dev, int H, int dm,
                                                         int nh, const float* __restrict__ qk,
                                                         const int64_t* __restrict__ h_n,
-                                                        const float* __restrict__ dabar, float* __restrict__ dqk) {
+                                                        const float* __restrict__ dabar, float* __restrict__ dqk,
+                                                        DropCfg dc) {
   if (n_dev && (int64_t)(blockIdx.x / nh) >= (int64_t)*n_dev) return;
+  const uint64_t dkey = drop_key(dc);
   constexpr int CH = 32;
   constexpr int PPT = (HMAX * HMAX + 255) / 256;
   constexpr int OPT = (HMAX * CH + 255) / 256;  // (row, column) outputs per thread and chunk
@@ -242,13 +266,19 @@ __global__ void __launch_bounds__(256) k_seq_scores_bwd(int64_t n, const int32_t
     }
     const float inv = 1.f / sum, invH = 1.f / (float)H;
     const float* da = dabar + ((int64_t)i * nh + h) * H;
+    auto dA = [&](int s) {  // d A[t, s]: through the dropout mask of this entry
+      float g = da[s] * invH;
+      if (dc.p > 0.f)
+        g = drop_keep(dkey, DROP_SEQ_ATTN, (((uint64_t)i * nh + h) * H + tid) * H + s, dc.thresh) ? g * dc.scale : 0.f;
+      return g;
+    };
     float dot = 0.f;
     for (int s = 0; s < H; ++s) {
       const float a = sc[tid][s] * inv;
       sc[tid][s] = a;
-      dot = fmaf(a, da[s] * invH, dot);
+      dot = fmaf(a, dA(s), dot);
     }
-    for (int s = 0; s < H; ++s) sc[tid][s] = sc[tid][s] * (da[s] * invH - dot) * scale;
+    for (int s = 0; s < H; ++s) sc[tid][s] = sc[tid][s] * (dA(s) - dot) * scale;
   }
   __syncthreads();
   float* ob = dqk + (int64_t)i * H * 2 * dm + (int64_t)h * dh;
@@ -392,6 +422,16 @@ __global__ void __launch_bounds__(256) k_mutual_b(int64_t cap, const int32_t* __
   }
 }
 
+// MergeLayer dropout on the hidden activations, in place (basic_modules.py:18)
+__global__ void k_dropout_rows(int64_t n, const int32_t* __restrict__ n_dev, int d, float* __restrict__ x, DropCfg dc,
+                               uint32_t stream) {
+  if (n_dev) n = min(n, (int64_t)*n_dev);
+  const uint64_t dkey = drop_key(dc);
+  const int64_t total = n * d;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
+    x[e] = drop_keep(dkey, stream, (uint64_t)e, dc.thresh) ? x[e] * dc.scale : 0.f;
+}
+
 // dOm[h] = dO with the columns outside head h's slice zeroed
 __global__ void k_head_mask(int64_t n, const int32_t* __restrict__ n_dev, int dm, int nh, const float* __restrict__ dO,
                             float* __restrict__ dOm) {
@@ -457,7 +497,7 @@ __global__ void k_restart_pad(int64_t cap, const int32_t* __restrict__ n_dev, in
 }
 
 struct SeqWs {
-  float *x, *qk, *abar, *xbar, *o, *om, *t2;
+  float *x, *qk, *abar, *xbar, *o, *om, *t2, *rbar;
 };
 
 static bool carve_seq(const tg_model* m, const tg_seq_restarter* r, int64_t n, Carver& cv, SeqWs& w, bool keep_t2) {
@@ -469,6 +509,7 @@ static bool carve_seq(const tg_model* m, const tg_seq_restarter* r, int64_t n, C
   w.o = cv.take<float>(n * dm);
   w.om = cv.take<float>(n * dm);
   w.t2 = keep_t2 ? cv.take<float>(n * (size_t)m->d) : w.om;
+  w.rbar = keep_t2 ? cv.take<float>(n * nh) : nullptr;
   return cv.ok;
 }
 
@@ -484,7 +525,7 @@ static int seq_ok(const tg_model* m, const tg_seq_restarter* r) {
 static int seq_forward(const tg_model* m, const tg_seq_restarter* r, int64_t n, const int32_t* counts2,
                        const int64_t* nids, const int64_t* h_n, const int64_t* anon, const int64_t* h_e,
                        const float* h_t, const int64_t* h_d, float* h_left, float* h_right, float* prev_ts,
-                       const SeqWs& w, hipStream_t st) {
+                       const SeqWs& w, hipStream_t st, const DropCfg& dc = DropCfg{}) {
   const int d = m->d, dm = 4 * m->d + m->d_e, H = r->hist_len, nh = r->n_head, dh = dm / nh;
   const int32_t* n_dev = counts2;
   const int32_t* nH_dev = counts2 ? counts2 + 1 : nullptr;
@@ -498,10 +539,10 @@ static int seq_forward(const tg_model* m, const tg_seq_restarter* r, int64_t n, 
   if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
   if (H <= 40)
     hipLaunchKernelGGL((k_seq_scores<40>), dim3((unsigned)(n * nh)), dim3(256), 0, st, n, H, dm, nh, w.qk, h_n, w.abar,
-                       n_dev);
+                       n_dev, dc, w.rbar);
   else
     hipLaunchKernelGGL((k_seq_scores<64>), dim3((unsigned)(n * nh)), dim3(256), 0, st, n, H, dm, nh, w.qk, h_n, w.abar,
-                       n_dev);
+                       n_dev, dc, w.rbar);
   hipLaunchKernelGGL(k_seq_mix, dim3(flat_grid(n * nh * (dm / 4), 256)), dim3(256), 0, st, n, H, dm / 4, nh, w.abar,
                      (const float4*)w.x, (float4*)w.xbar, n_dev);
   // o[:, h] = Wv_h xbar_h + bv_h
@@ -509,6 +550,7 @@ static int seq_forward(const tg_model* m, const tg_seq_restarter* r, int64_t n, 
   g.m_cap = n; g.m_dev = n_dev; g.n = dh; g.k = dm; g.a0 = ASeg{w.xbar, (int64_t)nh * dm, dm, nullptr}; g.a0_bs = dm;
   g.w = r->in_proj_w + (int64_t)2 * dm * dm; g.ldw = dm; g.w_bs = (int64_t)dh * dm;
   g.bias = r->in_proj_b + 2 * dm; g.bias_bs = dh; g.c = w.o; g.ldc = dm; g.c_bs = dh; g.alpha = 1.f; g.nbatch = nh;
+  if (dc.p > 0.f && w.rbar) { g.bias_rs = w.rbar; g.ld_brs = nh; }
   if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
   // relu(mean_t out_t) = relu(Wo o + bo)
   g = GemmArgs{};
@@ -527,6 +569,9 @@ static int seq_forward(const tg_model* m, const tg_seq_restarter* r, int64_t n, 
   g.m_cap = n; g.m_dev = n_dev; g.n = d; g.k = d; g.a0 = ASeg{h_left, d, d, nullptr};
   g.w = r->fc1.w; g.ldw = dm; g.bias = r->fc1.b; g.c = w.t2; g.ldc = d; g.relu = 1; g.alpha = 1.f; g.nbatch = 1;
   if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  if (dc.p > 0.f)
+    hipLaunchKernelGGL(k_dropout_rows, dim3(flat_grid(n * d, 256)), dim3(256), 0, st, n, n_dev, d, w.t2, dc,
+                       (uint32_t)DROP_SEQ_MERGER);
   g = GemmArgs{};
   g.m_cap = n; g.m_dev = n_dev; g.n = d; g.k = d; g.a0 = ASeg{w.t2, d, d, nullptr};
   g.w = r->fc2.w; g.ldw = d; g.bias = r->fc2.b; g.c = h_right; g.ldc = d; g.alpha = 1.f; g.nbatch = 1;
@@ -595,7 +640,7 @@ size_t mutual_ws_bytes(const tg_model* m, const tg_seq_restarter* r, int64_t B) 
     b += align16(n * H * 8) * 4 + align16(n * H * 4) + align16(n * 4) + align16(n * d * 4) + align16(n * dm * 4) * 2 +
          align16(n * nh * dm * 4) * 2 + align16(n * nh * H * 4) + align16(n * H * 2 * dm * 4) + align16(n * H * 2 * d * 4);
     b += align16(n * H * dm * 4) + align16(n * H * 2 * dm * 4) + align16(n * nh * H * 4) + align16(n * nh * dm * 4) +
-         2 * align16(n * dm * 4) + align16(n * d * 4);
+         2 * align16(n * dm * 4) + align16(n * d * 4) + align16(n * nh * 4);
   }
   return b + 256;
 }
@@ -605,7 +650,7 @@ size_t mutual_ws_bytes(const tg_model* m, const tg_seq_restarter* r, int64_t B) 
 int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, const StepWs& sw,
                 const tg_seq_restarter* r, const tg_seq_restarter* gr, const float* st_left, const float* st_right,
                 float* g_left, float* g_right, float* loss_out, int32_t* flag_out, float* part, size_t part_floats,
-                void* ws, size_t ws_bytes, hipStream_t st) {
+                void* ws, size_t ws_bytes, const DropCfg& dc, hipStream_t st) {
   if (!sio->h_prev_left || !sio->h_prev_right) return TG_EINVAL;
   if (r && (!seq_ok(m, r) || r->hist_len > 64 || !gr)) return TG_EUNSUPPORTED;
   if (!r && (!st_left || !st_right || !g_left || !g_right)) return TG_EINVAL;
@@ -637,7 +682,7 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
       return rc;
     if ((rc = tg_anonymized_reindex(n, H, w.h_n, w.anon, (void*)st)) != TG_OK) return rc;
     if ((rc = seq_forward(m, r, n, w.counts2, w.uniq, w.h_n, w.anon, w.h_e, w.h_t, w.h_d, w.sl, w.sr, w.prev_ts, w.seq,
-                          st)) != TG_OK)
+                          st, dc)) != TG_OK)
       return rc;
   }
   hipLaunchKernelGGL(k_mutual_a, dim3(std::min<unsigned>(flat_grid(2 * n, 4), 512)), dim3(256), 0, st, n, w.counts2, d,
@@ -669,7 +714,8 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
   if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
   ga = GemmArgs{};
   ga.m_cap = n; ga.m_dev = n_dev; ga.n = d; ga.k = d; ga.a0 = ASeg{w.dsr, d, d, nullptr};
-  ga.w = r->fc2.w; ga.ldw = d; ga.w_kmajor = 1; ga.c = w.dt2; ga.ldc = d; ga.alpha = 1.f; ga.nbatch = 1;
+  ga.w = r->fc2.w; ga.ldw = d; ga.w_kmajor = 1; ga.c = w.dt2; ga.ldc = d; ga.nbatch = 1;
+  ga.alpha = dc.p > 0.f ? dc.scale : 1.f;  // q.t2 is the dropped activation: > 0 iff kept and positive
   ga.relu_mask = q.t2; ga.ld_mask = d;
   if ((rc = gemm_launch(ga, st)) != TG_OK) return rc;
   tn = tn_base(n, n_dev);
@@ -708,6 +754,7 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
     tn = tn_base(n, n_dev);
     tn.n = dm; tn.k = dm; tn.y = dOh; tn.ldy = dm; tn.x0 = ASeg{q.xbar + (int64_t)h * dm, (int64_t)nh * dm, dm, nullptr};
     tn.out = F(gr->in_proj_w) + (int64_t)2 * dm * dm; tn.ldo = dm; tn.bias_out = F(gr->in_proj_b) + 2 * dm;
+    if (dc.p > 0.f) { tn.bias_rs = q.rbar; tn.ld_brs = nh; tn.brs_col = h; }
     if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
     ga = GemmArgs{};
     ga.m_cap = n; ga.m_dev = n_dev; ga.n = dm; ga.k = dm; ga.a0 = ASeg{dOh, dm, dm, nullptr};
@@ -717,13 +764,14 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
   }
   // value mix and attention scores
   hipLaunchKernelGGL(k_seq_mix_bwd, dim3(flat_grid(n * nh * H, 4)), dim3(256), 0, st, n, n_dev, H, dm / 4, nh,
-                     (const float4*)w.dxbar, (const float4*)q.x, w.dabar);
+                     (const float4*)w.dxbar, (const float4*)q.x, w.dabar, dc.p > 0.f ? w.dO : (const float*)nullptr,
+                     r->in_proj_b + 2 * dm);
   if (H <= 40)
     hipLaunchKernelGGL((k_seq_scores_bwd<40>), dim3((unsigned)(n * nh)), dim3(256), 0, st, n, n_dev, H, dm, nh, q.qk,
-                       w.h_n, w.dabar, w.dqk);
+                       w.h_n, w.dabar, w.dqk, dc);
   else
     hipLaunchKernelGGL((k_seq_scores_bwd<64>), dim3((unsigned)(n * nh)), dim3(256), 0, st, n, n_dev, H, dm, nh, q.qk,
-                       w.h_n, w.dabar, w.dqk);
+                       w.h_n, w.dabar, w.dqk, dc);
   // q/k projection
   tn = tn_base(n * H, nH_dev);
   tn.n = 2 * dm; tn.k = dm; tn.y = w.dqk; tn.ldy = 2 * dm; tn.x0 = ASeg{q.x, dm, dm, nullptr};
@@ -752,7 +800,7 @@ extern "C" size_t tg_restart_seq_workspace_bytes(const tg_model* m, const tg_seq
   if (!seq_ok(m, r) || n < 0) return 0;
   const size_t dm = 4 * (size_t)m->d + m->d_e, H = r->hist_len, nh = r->n_head;
   return align16(n * H * dm * 4) + align16(n * H * 2 * dm * 4) + align16(n * nh * H * 4) + align16(n * nh * dm * 4) +
-         2 * align16(n * dm * 4) + 64;
+         2 * align16(n * dm * 4) + align16(n * (size_t)m->d * 4) + align16(n * nh * 4) + 64;
 }
 
 extern "C" int tg_restart_seq_fwd(const tg_model* m, const tg_seq_restarter* r, int64_t n, const int64_t* nids,
@@ -767,4 +815,28 @@ extern "C" int tg_restart_seq_fwd(const tg_model* m, const tg_seq_restarter* r, 
   SeqWs w{};
   if (!ws || !carve_seq(m, r, n, cv, w, false)) return TG_EWORKSPACE;
   return seq_forward(m, r, n, nullptr, nids, h_n, anon, h_e, h_t, h_d, h_left, h_right, prev_ts, w, as_stream(stream));
+}
+
+namespace tg {
+__global__ void k_rng_tick_r(uint64_t* rng) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += 1;
+}
+}  // namespace tg
+
+extern "C" int tg_restart_seq_fwd_train(const tg_model* m, const tg_seq_restarter* r, int64_t n, const int64_t* nids,
+                                        const int64_t* h_n, const int64_t* anon, const int64_t* h_e, const float* h_t,
+                                        const int64_t* h_d, float* h_left, float* h_right, float* prev_ts,
+                                        float dropout_p, uint64_t* rng, void* ws, size_t ws_bytes, void* stream) {
+  if (!seq_ok(m, r) || n < 0 || dropout_p < 0.f || dropout_p >= 1.f || (dropout_p > 0.f && !rng)) return TG_EINVAL;
+  if (r->hist_len > 64) return TG_EUNSUPPORTED;
+  if (n == 0) return TG_OK;
+  if (!nids || !h_n || !anon || !h_e || !h_t || !h_d || !h_left || !h_right || !prev_ts) return TG_EINVAL;
+  Carver cv(ws, ws_bytes);
+  SeqWs w{};
+  if (!ws || !carve_seq(m, r, n, cv, w, true)) return TG_EWORKSPACE;
+  const DropCfg dc = make_drop(dropout_p, rng);
+  hipStream_t st = as_stream(stream);
+  const int rc = seq_forward(m, r, n, nullptr, nids, h_n, anon, h_e, h_t, h_d, h_left, h_right, prev_ts, w, st, dc);
+  if (rc == TG_OK && dc.p > 0.f) hipLaunchKernelGGL(k_rng_tick_r, dim3(1), dim3(64), 0, st, rng);
+  return rc;
 }

@@ -32,6 +32,7 @@ struct Carver {
 // which is what the backward pass reads
 struct AttnWs {
   float *cc, *qp, *g, *s, *o, *hh, *t, *qconst;
+  float* rsum;  // [Q, n_head] sum of the kept, rescaled attention probabilities (training with dropout)
   uint8_t* valid;
 };
 
@@ -61,7 +62,7 @@ bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w);
 int attn_dims_ok(const tg_model* m);
 // collate + STEP 1-3 (+ io->h_new); `gates` (nullable) receives the GRU gate activations
 int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, StepWs& w, float* gates, hipStream_t st,
-                 tg_profiler* pf);
+                 tg_profiler* pf, const DropCfg* drop = nullptr);
 // positive-node dedup + STEP 4/5 + restarter targets
 int step_writeback_a(const tg_model* m, const tg_step_io* io, StepWs& w, hipStream_t st, tg_profiler* pf);
 // STEP 6 + workspace clean-up + offset advance
@@ -72,6 +73,6 @@ size_t mutual_ws_bytes(const tg_model* m, const tg_seq_restarter* r, int64_t B);
 int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, const StepWs& sw,
                 const tg_seq_restarter* r, const tg_seq_restarter* gr, const float* st_left, const float* st_right,
                 float* g_left, float* g_right, float* loss_out, int32_t* flag_out, float* part, size_t part_floats,
-                void* ws, size_t ws_bytes, hipStream_t st);
+                void* ws, size_t ws_bytes, const DropCfg& dc, hipStream_t st);
 
 }  // namespace tg

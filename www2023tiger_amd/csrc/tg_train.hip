@@ -112,9 +112,10 @@ __global__ void __launch_bounds__(256) k_score_loss(int64_t B, int d, float* __r
                                                     const float* __restrict__ w2, const float* __restrict__ b2,
                                                     float* __restrict__ pos_scores, float* __restrict__ neg_scores,
                                                     float* __restrict__ loss_out, float* __restrict__ dw2,
-                                                    float* __restrict__ db2) {
+                                                    float* __restrict__ db2, DropCfg dc) {
   __shared__ float red[4][NVS * 64 + 2];
   const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const uint64_t dkey = drop_key(dc);
   float acc[NVS];
 #pragma unroll
   for (int v = 0; v < NVS; ++v) acc[v] = 0.f;
@@ -129,7 +130,12 @@ __global__ void __launch_bounds__(256) k_score_loss(int64_t B, int d, float* __r
       const int c = lane + v * 64;
       tv[v] = c < d ? t[c] : 0.f;
       wv[v] = c < d ? w2[c] : 0.f;
-      p = fmaf(tv[v], wv[v], p);
+      if (dc.p > 0.f && c < d) {  // MergeLayer dropout on relu(fc1) (basic_modules.py:18); folded into w2 for the backward
+        const float ms = drop_keep(dkey, DROP_SCORE, (uint64_t)r * d + c, dc.thresh) ? dc.scale : 0.f;
+        tv[v] *= ms;
+        wv[v] *= ms;
+      }
+      p = fmaf(tv[v], c < d ? w2[c] : 0.f, p);
     }
     const float s = wave_sum(p) + b2[0];
     const float y = r < B ? 1.f : 0.f;
@@ -222,9 +228,12 @@ __global__ void __launch_bounds__(256) k_attn_core_bwd(tg_model m, int64_t Q, co
                                                        const uint64_t* __restrict__ bm, const uint32_t* __restrict__ rank,
                                                        const float4* __restrict__ G, const float4* __restrict__ dS,
                                                        float4* __restrict__ dG, float* __restrict__ dreprs,
-                                                       float* __restrict__ dfreq, float* __restrict__ dphase) {
+                                                       float* __restrict__ dfreq, float* __restrict__ dphase,
+                                                       DropCfg dc, const float* __restrict__ dO,
+                                                       const float* __restrict__ bv) {
   __shared__ float4 tred[4][2][NV][64];
   const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const uint64_t dkey = drop_key(dc);
   const int d = m.d, d4 = m.d / 4, e4 = m.d_e / 4, K = m.n_neighbors;
   const int kv4 = 2 * d4 + e4;
   const float4* nf = reinterpret_cast<const float4*>(m.nfeats);
@@ -326,7 +335,9 @@ __global__ void __launch_bounds__(256) k_attn_core_bwd(tg_model m, int64_t Q, co
       }
       k = kn;
     }
-    // ---- softmax backward, one key per lane
+    // ---- softmax backward, one key per lane.  With attention dropout the weights that multiply
+    // the values are a' = a * keep / (1 - p); the value bias enters as bv * sum_j a'_j, so
+    // d a'_j also receives dr = dO_h . bv_h.
     const bool mine = (live0 >> lane) & 1ull;
     float a_l[NH], s_l[NH];
 #pragma unroll
@@ -335,9 +346,19 @@ __global__ void __launch_bounds__(256) k_attn_core_bwd(tg_model m, int64_t Q, co
       const float e = mine ? expf(p_l[h] - mx) : 0.f;
       const float l = wave_sum(e);
       const float a = live0 ? e / l : 0.f;
-      const float dot = wave_sum(a * da_l[h]);
-      a_l[h] = a;
-      s_l[h] = a * (da_l[h] - dot);
+      float da = da_l[h], ms = 1.f;
+      if (dc.p > 0.f) {
+        const int dh = 2 * d / NH;
+        float dr = 0.f;
+        for (int c = lane; c < dh; c += TG_WAVE) dr = fmaf(dO[i * 2 * d + h * dh + c], bv[h * dh + c], dr);
+        dr = wave_sum(dr);
+        ms = (mine && drop_keep(dkey, DROP_ATTN, ((uint64_t)i * NH + h) * (uint64_t)K + (uint64_t)lane, dc.thresh))
+                 ? dc.scale : 0.f;
+        da = (da + dr) * ms;
+      }
+      const float dot = wave_sum(a * da);
+      a_l[h] = a * ms;  // a' (what the values were weighted with)
+      s_l[h] = a * (da - dot);
     }
     // ---- pass 2: dG and the key-row gradients
     live = live0;
@@ -530,6 +551,10 @@ __global__ void __launch_bounds__(256) k_adam(const tg_adam_seg* __restrict__ se
   }
 }
 
+__global__ void k_rng_tick(uint64_t* rng) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += 1;
+}
+
 // ---------------------------------------------------------------------------------
 // workspace of the training tail
 // ---------------------------------------------------------------------------------
@@ -599,7 +624,8 @@ static int train_supported(const tg_model* m, const tg_score_params* sp) {
 }
 
 // backward of the contrastive loss; everything it reads is still in the step workspace
-static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w, TrainWs& t, hipStream_t st) {
+static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w, TrainWs& t, const DropCfg& dc,
+                             hipStream_t st) {
   const tg_score_params* sp = io->score;
   const tg_model* gm = io->grads;
   const tg_score_params* gs = io->score_grads;
@@ -626,7 +652,7 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
   // fc1 input gradient needs relu(T1) as the mask, and k_score_loss overwrites T1 with dT1: since
   // dT1 is zero exactly where T1 <= 0, the masked gradient IS dT1 and no copy of T1 is needed
   hipLaunchKernelGGL(k_score_loss, dim3(std::min<unsigned>(flat_grid(2 * B, 4), 256)), dim3(256), 0, st, B, d, t.T1,
-                     sp->fc2.w, sp->fc2.b, io->pos_scores, io->neg_scores, io->losses, F(gs->fc2.w), F(gs->fc2.b));
+                     sp->fc2.w, sp->fc2.b, io->pos_scores, io->neg_scores, io->losses, F(gs->fc2.w), F(gs->fc2.b), dc);
   // ---- STEP 7 backward: score MergeLayer
   TnArgs tn{};
   tn.m_cap = 2 * B; tn.n = d; tn.k = W2; tn.y = t.T1; tn.ldy = d; tn.x0 = ASeg{t.P, W2, W2, nullptr};
@@ -687,6 +713,7 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
   tn.out = F(gm->attn_wv); tn.ldo = kvw; tn.out_bs = (int64_t)dh * kvw; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = nh;
   tn.part = t.part; tn.part_floats = t.part_floats;
   tn.bias_out = F(gm->attn_b_in) + 2 * E; tn.bias_accumulate = 1; tn.bias_bs = dh;
+  if (dc.p > 0.f) { tn.bias_rs = a.rsum; tn.ld_brs = nh; tn.brs_col = 0; }  // d bv_h = sum_i r_ih dO_ih
   if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
   g = GemmArgs{};
   g.m_cap = Q; g.n = kvw; g.k = dh; g.a0 = ASeg{t.dO, E, dh, nullptr}; g.a0_bs = dh;
@@ -699,7 +726,7 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
 #define TG_CORE_BWD(NH_, NV_)                                                                                       \
   hipLaunchKernelGGL((k_attn_core_bwd<NH_, NV_>), dim3(cgrid), dim3(256), 0, st, *m, Q, w.ts3f, w.l1n, w.l1e, w.l1t, \
                      (const float4*)w.reprs, w.bm, w.rank, (const float4*)a.g, (const float4*)t.dS, (float4*)t.dG,    \
-                     t.dreprs, F(gm->te_freq), F(gm->te_phase))
+                     t.dreprs, F(gm->te_freq), F(gm->te_phase), dc, t.dO, m->attn_b_in + 2 * E)
   if (nh == 2 && nv == 1) TG_CORE_BWD(2, 1);
   else if (nh == 2 && nv == 2) TG_CORE_BWD(2, 2);
   else if (nh == 1 && nv == 1) TG_CORE_BWD(1, 1);
@@ -775,19 +802,22 @@ extern "C" int tg_train_step(const tg_model* m, const tg_tcsr* g, const tg_train
   TrainWs t{};
   if (!carve_step(m, sio->B, cv, w) || !carve_train(m, io->score, sio->B, cv, t)) return TG_EWORKSPACE;
   int rc;
-  if ((rc = step_forward(m, g, sio, w, t.gates, st, nullptr)) != TG_OK) return rc;
-  if ((rc = contrast_backward(m, io, w, t, st)) != TG_OK) return rc;
+  if (io->dropout_p < 0.f || io->dropout_p >= 1.f || (io->dropout_p > 0.f && !io->rng)) return TG_EINVAL;
+  const DropCfg dc = make_drop(io->dropout_p, io->rng);
+  if ((rc = step_forward(m, g, sio, w, t.gates, st, nullptr, &dc)) != TG_OK) return rc;
+  if ((rc = contrast_backward(m, io, w, t, dc, st)) != TG_OK) return rc;
   if ((rc = step_writeback_a(m, sio, w, st, nullptr)) != TG_OK) return rc;
   if (io->restarter != TG_RESTARTER_NONE) {  // needs the targets of STEP 4/5 and the step's bitmap-free inputs
     const bool seq = io->restarter == TG_RESTARTER_SEQ;
     if (seq && (!io->seq || !io->seq_grads)) return TG_EINVAL;
     if ((rc = mutual_step(m, g, sio, w, seq ? io->seq : nullptr, seq ? io->seq_grads : nullptr, io->static_left,
                           io->static_right, io->static_left_grad, io->static_right_grad, io->losses + 1,
-                          io->flags ? io->flags + 2 : nullptr, t.part, t.part_floats, cv.p, cv.left, st)) != TG_OK)
+                          io->flags ? io->flags + 2 : nullptr, t.part, t.part_floats, cv.p, cv.left, dc, st)) != TG_OK)
       return rc;
   } else if (io->flags) {
     (void)hipMemsetAsync(io->flags + 2, 0, sizeof(int32_t), st);
   }
+  if (dc.p > 0.f) hipLaunchKernelGGL(k_rng_tick, dim3(1), dim3(64), 0, st, io->rng);
   return step_writeback_b(m, sio, w, st, nullptr);
 }
 

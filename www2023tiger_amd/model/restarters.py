@@ -24,6 +24,7 @@ class Restarter(nn.Module):
         self.time_encoder = TimeEncode(dim=self.nfeat_dim)
         self.tfeat_dim = self.time_encoder.dim
         self.model_struct_fn = None  # set by TIGER: () -> TgModel of the owning model
+        self.rng_fn = None           # set by TIGER: () -> device int64[2] dropout generator state
 
     def forward(self, nids: Tensor, ts: Tensor, computation_graph=None) -> Tuple[Tensor, Tensor, Tensor]:
         raise NotImplementedError
@@ -71,6 +72,16 @@ class SeqRestarter(Restarter):
         nbytes = int(lib.tg_restart_seq_workspace_bytes(C.byref(m), C.byref(r), n))
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
         nids = nids.long().contiguous()
+        p = float(self.mha_fn.dropout)
+        if self.training and p > 0 and self.rng_fn is not None:
+            # train() mode: attention / merger dropout is active, also inside TIGER.restart (as in the reference)
+            if float(self.merger.dropout.p) != p:
+                raise NotImplementedError('one dropout probability for the restarter')
+            check(lib.tg_restart_seq_fwd_train(C.byref(m), C.byref(r), n, ptr(nids), ptr(h_n), ptr(anon), ptr(h_e),
+                                               ptr(h_t), ptr(h_d), ptr(h_left), ptr(h_right), ptr(prev_ts), p,
+                                               ptr(self.rng_fn()), ptr(ws), nbytes, stream_ptr(dev)),
+                  'tg_restart_seq_fwd_train')
+            return h_left, h_right, prev_ts
         check(lib.tg_restart_seq_fwd(C.byref(m), C.byref(r), n, ptr(nids), ptr(h_n), ptr(anon), ptr(h_e), ptr(h_t),
                                      ptr(h_d), ptr(h_left), ptr(h_right), ptr(prev_ts), ptr(ws), nbytes,
                                      stream_ptr(dev)), 'tg_restart_seq_fwd')

@@ -120,6 +120,14 @@ class TIGE(nn.Module):
         self._step_ws = {}
         return super()._apply(fn, *a, **kw)
 
+    def dropout_rng(self) -> Tensor:
+        """device int64[2] = {seed, step counter} of the dropout mask generator (training only)"""
+        t = self._step_ws.get('rng')
+        if t is None or t.device != self.device:
+            t = torch.tensor([torch.initial_seed() & (2 ** 63 - 1), 0], dtype=torch.int64, device=self.device)
+            self._step_ws['rng'] = t
+        return t
+
     def invalidate_struct(self):
         self._struct_cache = None
 
@@ -422,6 +430,7 @@ class TIGER(TIGE):
                          msg_last_only=msg_last_only, hit_type=hit_type)
         self.restarter_fn = restarter
         self.restarter_fn.model_struct_fn = self.model_struct
+        self.restarter_fn.rng_fn = self.dropout_rng
         self.mutual_loss_fn = nn.MSELoss()
 
     def forward(self, *args, **kwargs):

@@ -120,13 +120,21 @@ def check_trainable(model):
         raise NotImplementedError("training on device supports msg_tsfm_type='id' with mem_update_type='gru'")
     if model.n_layers != 1:
         raise NotImplementedError('training on device supports n_layers == 1')
-    drops = [model.score_fn.dropout.p, model.temporal_embedding_fn.fns[0].merger.dropout.p,
-             model.temporal_embedding_fn.fns[0].mha_fn.dropout]
+    if model.temporal_embedding_fn.fns[0].merger.dropout.p > 0:
+        raise NotImplementedError('dropout inside the embedding merger is not built (the reference never sets it)')
+    dropout_p(model)
+
+
+def dropout_p(model) -> float:
+    """The single dropout probability of the model (the reference passes one --dropout to the score
+    head, the embedding attention, and the SeqRestarter's attention and merger)."""
+    ps = {float(model.score_fn.dropout.p), float(model.temporal_embedding_fn.fns[0].mha_fn.dropout)}
     r = getattr(model, 'restarter_fn', None)
     if r is not None and hasattr(r, 'mha_fn'):
-        drops += [r.mha_fn.dropout, r.merger.dropout.p]
-    if any(p > 0 for p in drops):
-        raise NotImplementedError('training on device runs without dropout: build the model with dropout=0')
+        ps |= {float(r.mha_fn.dropout), float(r.merger.dropout.p)}
+    if len(ps) != 1:
+        raise NotImplementedError(f'one dropout probability for all sites is supported, got {sorted(ps)}')
+    return ps.pop()
 
 
 class TrainBuffers:
@@ -151,6 +159,7 @@ class TrainBuffers:
         self.pos_scores = torch.zeros(B, dtype=torch.float32, device=dev)
         self.neg_scores = torch.zeros(B, dtype=torch.float32, device=dev)
         self.flags = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.rng = model.dropout_rng()  # dropout mask generator state {seed, step counter}, shared with restart()
         self.refresh()
 
     def refresh(self):
@@ -181,6 +190,8 @@ class TrainBuffers:
         io.score_grads = C.addressof(self._gscore)
         io.losses, io.pos_scores, io.neg_scores = ptr(self.losses), ptr(self.pos_scores), ptr(self.neg_scores)
         io.flags = ptr(self.flags)
+        io.dropout_p = dropout_p(model)
+        io.rng = ptr(self.rng)
         io.restarter = kind
         if kind == 1:
             io.seq, io.seq_grads = C.addressof(self._seq), C.addressof(self._gseq)
