@@ -59,7 +59,7 @@ def evaluate_pair(model, dl, ind_dl, device, restart_mode, uptodate):
 
 def run(data, root, *, seed=0, n_epochs=1, bs=200, lr=1e-4, dim=None, n_neighbors=10, n_heads=2, hit_type='bin',
         restarter_type='seq', hist_len=40, msg_src='left', upd_src='right', restart_prob=0.01, mutual_coef=1.0,
-        warmup_steps=0, strategy='recent_edges', ckpt_path=None, device='cuda:0'):
+        warmup_steps=0, strategy='recent_edges', dropout=0.1, ckpt_path=None, device='cuda:0'):
     device = torch.device(device)
     torch.manual_seed(seed)
     rng = np.random.RandomState(seed)
@@ -69,7 +69,7 @@ def run(data, root, *, seed=0, n_epochs=1, bs=200, lr=1e-4, dim=None, n_neighbor
     nfeats, efeats, full_data = basic[:3]
     train_dl, _, val_dl, ind_val_dl, test_dl, ind_test_dl, val_warm_dl, test_warm_dl = dls
     model = init_model(nfeats, efeats, train_graph, full_graph, full_data, device, dim=dim, n_layers=1,
-                       n_heads=n_heads, n_neighbors=n_neighbors, hit_type=hit_type, dropout=0.0,
+                       n_heads=n_heads, n_neighbors=n_neighbors, hit_type=hit_type, dropout=dropout,
                        restarter_type=restarter_type, hist_len=hist_len, msg_src=msg_src, upd_src=upd_src,
                        msg_tsfm_type='id', mem_update_type='gru')
     optimizer = torch.optim.Adam(model.parameters(), lr=lr)
@@ -116,7 +116,8 @@ if __name__ == '__main__':
     ap.add_argument('--lr', type=float, default=1e-4)
     ap.add_argument('--restarter_type', default='seq', choices=['seq', 'static'])
     ap.add_argument('--restart_prob', type=float, default=0.01)
+    ap.add_argument('--dropout', type=float, default=0.1)
     a = ap.parse_args()
     out, _ = run(a.data, a.root, n_epochs=a.n_epochs, bs=a.bs, lr=a.lr, restarter_type=a.restarter_type,
-                 restart_prob=a.restart_prob)
+                 restart_prob=a.restart_prob, dropout=a.dropout)
     print(out)
