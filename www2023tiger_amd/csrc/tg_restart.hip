@@ -347,8 +347,7 @@ __global__ void __launch_bounds__(256) k_seq_build_bwd(tg_model m, tg_seq_restar
       else atomicAdd(danon + a * d + c, ga);
     }
     const float dt = h_t[i * H + H - 1] - h_t[row];
-    const float x = __fadd_rn(__fmul_rn(dt, r.te_freq[c]), r.te_phase[c]);
-    const float sn = -sinf(x) * gt;
+    const float sn = -time_enc_sin(dt, r.te_freq[c], r.te_phase[c]) * gt;
     atomicAdd(&lte[c], sn * dt);
     atomicAdd(&lte[d + c], sn);
   }

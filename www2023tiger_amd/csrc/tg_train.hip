@@ -16,25 +16,6 @@
 
 namespace tg {
 
-// sin with the same three-term Cody-Waite reduction as cos_cw (tg_common.h)
-__device__ __forceinline__ float sin_cw(float x) {
-  const float n = rintf(__fmul_rn(x, 0.6366197723675814f));
-  float r = fmaf(-n, 1.5707963705062866f, x);
-  r = fmaf(-n, -4.371138828673793e-08f, r);
-  r = fmaf(-n, -1.7763568394002505e-15f, r);
-  const float z = __fmul_rn(r, r);
-  const float s = fmaf(__fmul_rn(r, z), fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
-  const float c = fmaf(__fmul_rn(z, z), fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
-                       fmaf(z, -0.5f, 1.0f));
-  const int q = (int)n & 3;
-  const float v = (q & 1) ? c : s;
-  return (q >= 2) ? -v : v;
-}
-__device__ __forceinline__ float time_enc_sin(float dt, float w, float phi) {
-  const float x = __fadd_rn(__fmul_rn(dt, w), phi);
-  return fabsf(x) <= 3.0e6f ? sin_cw(x) : sinf(x);
-}
-
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, TG_WAVE));
@@ -228,10 +209,11 @@ __global__ void __launch_bounds__(256) k_attn_core_bwd(tg_model m, int64_t Q, co
                                                        const uint64_t* __restrict__ bm, const uint32_t* __restrict__ rank,
                                                        const float4* __restrict__ G, const float4* __restrict__ dS,
                                                        float4* __restrict__ dG, float* __restrict__ dreprs,
-                                                       float* __restrict__ dfreq, float* __restrict__ dphase,
+                                                       float* __restrict__ tepart,
                                                        DropCfg dc, const float* __restrict__ dO,
                                                        const float* __restrict__ bv) {
   __shared__ float4 tred[4][2][NV][64];
+  __shared__ float xp[4][NV * 256];
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   const uint64_t dkey = drop_key(dc);
   const int d = m.d, d4 = m.d / 4, e4 = m.d_e / 4, K = m.n_neighbors;
@@ -389,15 +371,22 @@ __global__ void __launch_bounds__(256) k_attn_core_bwd(tg_model m, int64_t Q, co
           axpy4f(dxt[v], sk, g[h][2][v]);
         }
       }
+      // node part -> involved-node gradient row.  The row is transposed through LDS so that every
+      // atomic instruction covers 64 CONSECUTIVE floats (two 128-byte lines) instead of 64 dwords
+      // strided by 16 bytes (eight lines): the L2 atomic units work per cache line.
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int c = lane + v * TG_WAVE;
+        if (c < d4) *reinterpret_cast<float4*>(&xp[wave][4 * c]) = dxn[v];
+      }
+      {
+        float* dr = dreprs + u * d;
+        for (int c = lane; c < d; c += TG_WAVE) atomicAdd(dr + c, xp[wave][c]);
+      }
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const int c = lane + v * TG_WAVE;
         if (c < d4) {
-          float* dr = dreprs + u * d + 4 * c;
-          atomicAdd(dr + 0, dxn[v].x);
-          atomicAdd(dr + 1, dxn[v].y);
-          atomicAdd(dr + 2, dxn[v].z);
-          atomicAdd(dr + 3, dxn[v].w);
           const float sx = -time_enc_sin(dt, w4[v].x, p4[v].x) * dxt[v].x;
           const float sy = -time_enc_sin(dt, w4[v].y, p4[v].y) * dxt[v].y;
           const float sz = -time_enc_sin(dt, w4[v].z, p4[v].z) * dxt[v].z;
@@ -438,10 +427,30 @@ __global__ void __launch_bounds__(256) k_attn_core_bwd(tg_model m, int64_t Q, co
         float4 s = tred[0][wave][v][lane];
         const float4 b = tred[1][wave][v][lane], e = tred[2][wave][v][lane], f = tred[3][wave][v][lane];
         s.x += b.x + e.x + f.x; s.y += b.y + e.y + f.y; s.z += b.z + e.z + f.z; s.w += b.w + e.w + f.w;
-        float* o = (wave == 0 ? dfreq : dphase) + 4 * c;
-        atomicAdd(o + 0, s.x); atomicAdd(o + 1, s.y); atomicAdd(o + 2, s.z); atomicAdd(o + 3, s.w);
+        // per-block partial row (plain store): [block][freq | phase][d]; k_te_reduce sums the blocks.
+        // (768 blocks x 344 atomics on 344 addresses cost ~60 us here.)
+        *reinterpret_cast<float4*>(tepart + ((int64_t)blockIdx.x * 2 + wave) * d + 4 * c) = s;
       }
     }
+  }
+}
+
+// dfreq[c] += sum_b tepart[b][0][c], dphase[c] += sum_b tepart[b][1][c]
+__global__ void __launch_bounds__(256) k_te_reduce(int nblocks, int d, const float* __restrict__ tepart,
+                                                   float* __restrict__ dfreq, float* __restrict__ dphase) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;  // column of [freq | phase]
+  // gridDim.y slices of the partial rows; one atomic per column and slice (16 per address)
+  const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+  const int b_lo = blockIdx.y * per, b_hi = min(nblocks, b_lo + per);
+  float s = 0.f;
+  if (c < 2 * d)
+    for (int b = b_lo + rg; b < b_hi; b += 4) s += tepart[(int64_t)b * 2 * d + c];
+  red[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0 && c < 2 * d) {
+    const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    atomicAdd(c < d ? dfreq + c : dphase + (c - d), t);
   }
 }
 
@@ -559,7 +568,7 @@ __global__ void k_rng_tick(uint64_t* rng) {
 // workspace of the training tail
 // ---------------------------------------------------------------------------------
 struct TrainWs {
-  float *gates, *P, *T1, *dP, *dH, *dT, *dhh, *dcc, *dO, *dS, *dG, *dqp, *dreprs, *dgi, *dgh, *dqconst, *part;
+  float *gates, *P, *T1, *dP, *dH, *dT, *dhh, *dcc, *dO, *dS, *dG, *dqp, *dreprs, *dgi, *dgh, *dqconst, *part, *tepart;
   size_t part_floats;
   int32_t* hit_idx;
   int64_t rows_cap;
@@ -596,6 +605,7 @@ static bool carve_train(const tg_model* m, const tg_score_params* sp, int64_t B,
   w.dgi = cv.take<float>((size_t)w.rows_cap * 3 * d);
   w.dgh = cv.take<float>((size_t)w.rows_cap * 3 * d);
   w.dqconst = cv.take<float>((size_t)E);
+  w.tepart = cv.take<float>((size_t)1024 * 2 * d);
   w.part_floats = part_floats_for(m, sp);
   w.part = cv.take<float>(w.part_floats);
   w.hit_idx = cv.take<int32_t>((size_t)4 * B);
@@ -608,7 +618,7 @@ static size_t train_ws_bytes(const tg_model* m, const tg_score_params* sp, int64
   const size_t rows = std::min<size_t>(Q * (K + 1), (size_t)m->n_nodes);
   return align16(rows * 4 * d * 4) + align16(2 * B * 2 * W * 4) * 2 + align16(2 * B * d * 4) + align16(Q * d * 4) * 3 +
          align16(Q * E * 4) * 3 + align16(Q * nh * kvw * 4) * 2 + align16(rows * d * 4) + align16(rows * 3 * d * 4) * 2 +
-         align16(E * 4) + align16(part_floats_for(m, sp) * 4) + align16(4 * B * 4) + 256;
+         align16(E * 4) + align16(1024 * 2 * d * 4) + align16(part_floats_for(m, sp) * 4) + align16(4 * B * 4) + 256;
 }
 
 static int train_supported(const tg_model* m, const tg_score_params* sp) {
@@ -726,13 +736,15 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
 #define TG_CORE_BWD(NH_, NV_)                                                                                       \
   hipLaunchKernelGGL((k_attn_core_bwd<NH_, NV_>), dim3(cgrid), dim3(256), 0, st, *m, Q, w.ts3f, w.l1n, w.l1e, w.l1t, \
                      (const float4*)w.reprs, w.bm, w.rank, (const float4*)a.g, (const float4*)t.dS, (float4*)t.dG,    \
-                     t.dreprs, F(gm->te_freq), F(gm->te_phase), dc, t.dO, m->attn_b_in + 2 * E)
+                     t.dreprs, t.tepart, dc, t.dO, m->attn_b_in + 2 * E)
   if (nh == 2 && nv == 1) TG_CORE_BWD(2, 1);
   else if (nh == 2 && nv == 2) TG_CORE_BWD(2, 2);
   else if (nh == 1 && nv == 1) TG_CORE_BWD(1, 1);
   else if (nh == 4 && nv == 1) TG_CORE_BWD(4, 1);
   else return TG_EUNSUPPORTED;
 #undef TG_CORE_BWD
+  hipLaunchKernelGGL(k_te_reduce, dim3((unsigned)cdiv(2 * d, 64), 16), dim3(256), 0, st, (int)cgrid, d, t.tepart,
+                     F(gm->te_freq), F(gm->te_phase));
   // ---- key projection folded into the query: g_h = Wk_h^T q_h
   tn = TnArgs{};
   tn.m_cap = Q; tn.n = dh; tn.k = kvw; tn.y = a.qp; tn.ldy = E; tn.y_bs = dh;
