@@ -42,6 +42,7 @@ struct GemmArgs {
   // bias is weighted by the sum of the kept, rescaled probabilities)
   const float* bias_rs;
   int64_t ld_brs;
+  int dbg;  // diagnostic bits, 0 in production
 };
 
 int gemm_launch(const GemmArgs& g, hipStream_t st);

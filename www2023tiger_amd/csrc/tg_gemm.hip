@@ -31,12 +31,28 @@ __device__ __forceinline__ void sts4(float* row, int k, float4 v) {
   row[k + 3] = v.w;
 }
 
-template <int WM, int WN>
-__global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
+// diagnostic only (TG_GEMM_DBG=16): per-block s_memtime stamps {entry, loop start, loop end, exit}
+__device__ unsigned long long g_gemm_trace[4096 * 4];
+
+template <int WM, int WN, int KS, int D>
+__global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
+  const unsigned long long t_entry = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
+  // KS = 2: a second group of four wavefronts takes the other half of every tile's k-steps into its
+  // own accumulators (summed through LDS at the end).  For the under-filled launches of the C2 shapes
+  // (a few hundred 64x64 tiles on 1024 SIMDs) this doubles the wavefronts in flight and halves each
+  // one's serial MFMA / load chain; large launches keep KS = 1.
+  constexpr int THREADS = 256 * KS;
   constexpr int BM = 32 * WM, BN = 32 * WN;
+  constexpr int RP = THREADS / 8;       // tile rows staged per pass (8 threads per 32-float row)
+  constexpr int NA = BM / RP;           // A float4 per thread per tile
+  constexpr int NB = BN / RP;           // W float4 per thread per tile (row-major and k-major alike)
+  constexpr int NOPS = NA + NB;
+  constexpr int PP = 8 / KS;            // k-step pairs per wave per tile
+  static_assert(BM % RP == 0 && BN % RP == 0 && NOPS <= PP / 2, "one memory op per k-step pair in each half");
   __shared__ float As[2][BM][LDK];
   __shared__ float Bs[2][BN][LDK];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float red[KS == 2 ? 4 : 1][KS == 2 ? 16 : 1][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, ks = tid >> 8;
   const int NT = (g.n + BN - 1) / BN;
   const int per = NT * g.nbatch;
   const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
@@ -56,50 +72,53 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
   // Branch-free staging: every load is issued unconditionally from a clamped (valid) address,
   // so the compiler can keep two tiles in flight behind counted vmcnt waits.  Rows past M and
   // weight rows past N only feed outputs that are never stored; only k >= K needs zeros.
-  const float* arow0[WM];
-  const float* arow1[WM];
+  const float* arow0[NA];
+  const float* arow1[NA];
 #pragma unroll
-  for (int i = 0; i < WM; ++i) {
-    const int64_t m = min(m0 + ar + i * 32, M - 1);
+  for (int i = 0; i < NA; ++i) {
+    const int64_t m = min(m0 + ar + i * RP, M - 1);
     arow0[i] = a0p + (g.a0.idx ? g.a0.idx[m] : m) * g.a0.ld;
     arow1[i] = g.a1.p ? g.a1.p + (g.a1.idx ? g.a1.idx[m] : m) * g.a1.ld - kw0 : arow0[i];
   }
-  const float* wrow[WN];
+  const float* wrow[NB];
 #pragma unroll
-  for (int i = 0; i < WN; ++i) {
+  for (int i = 0; i < NB; ++i) {
     if (!g.w_kmajor) {
-      wrow[i] = wp + (int64_t)min(n0 + ar + i * 32, N - 1) * g.ldw;
+      wrow[i] = wp + (int64_t)min(n0 + ar + i * RP, N - 1) * g.ldw;
     } else {
-      const int f = tid + i * 256;
+      const int f = tid + i * THREADS;
       wrow[i] = wp + min(n0 + (f % (BN / 4)) * 4, N - 4);  // column offset; the k row is added per tile
     }
   }
-  float4 ra0[WM], rb0[WN], ra1[WM], rb1[WN];  // two tiles in flight (global -> registers)
+  // D tiles in flight (global -> registers): with the short K of the attention shapes (6-17 tiles) the
+  // kernel is a chain of dependent tile loads, so the prefetch distance sets its duration
+  static_assert(D >= 2 && D % 2 == 0, "even prefetch depth");
+  float4 ra[D][NA], rb[D][NB];
   const int nkt = (K + BK - 1) / BK;
-  // i-th staged float4 of tile kt (i < WM: A, else W): raw load from a clamped address; columns
+  // i-th staged float4 of tile kt (i < NA: A, else W): raw load from a clamped address; columns
   // past K are zeroed when the tile is written to LDS, so nothing waits on the load here
   auto load_one = [&](int kt, int i, float4* ra, float4* rb) {
     const int k = kt * BK + ac4;
     const int kc = k < K ? k : 0;
-    if (i < WM) {
+    if (i < NA) {
       ra[i] = ldg4((kc < kw0 ? arow0[i] : arow1[i]) + kc);
     } else if (!g.w_kmajor) {
-      rb[i - WM] = ldg4(wrow[i - WM] + kc);
+      rb[i - NA] = ldg4(wrow[i - NA] + kc);
     } else {
-      const int kk = kt * BK + (tid + (i - WM) * 256) / (BN / 4);
-      rb[i - WM] = ldg4(wrow[i - WM] + (int64_t)min(kk, K - 1) * g.ldw);
+      const int kk = kt * BK + (tid + (i - NA) * THREADS) / (BN / 4);
+      rb[i - NA] = ldg4(wrow[i - NA] + (int64_t)min(kk, K - 1) * g.ldw);
     }
   };
   auto store_one = [&](int buf, int kt, int i, const float4* ra, const float4* rb) {
     const bool kin = kt * BK + ac4 < K;
-    if (i < WM) {
-      sts4(As[buf][ar + i * 32], ac4, kin ? ra[i] : zero4());
+    if (i < NA) {
+      sts4(As[buf][ar + i * RP], ac4, kin ? ra[i] : zero4());
     } else if (!g.w_kmajor) {
-      sts4(Bs[buf][ar + (i - WM) * 32], ac4, kin ? rb[i - WM] : zero4());
+      sts4(Bs[buf][ar + (i - NA) * RP], ac4, kin ? rb[i - NA] : zero4());
     } else {
-      const int f = tid + (i - WM) * 256;
+      const int f = tid + (i - NA) * THREADS;
       const int kk = f / (BN / 4), nn = (f % (BN / 4)) * 4;
-      const float4 v = (kt * BK + kk < K) ? rb[i - WM] : zero4();
+      const float4 v = (kt * BK + kk < K) ? rb[i - NA] : zero4();
       Bs[buf][nn][kk] = v.x;
       Bs[buf][nn + 1][kk] = v.y;
       Bs[buf][nn + 2][kk] = v.z;
@@ -108,6 +127,10 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
   };
   const int wm = wave / WN, wn = wave % WN;
   const int fr = lane & 31, fk = lane >> 5;
+  // the bias is requested before the main loop: in the epilogue its load latency (~1 us) would be
+  // fully exposed, a third of the block's lifetime at K = 172
+  const int n_out = min(n0 + wn * 32 + fr, N - 1);
+  const float bias = g.bias ? g.bias[(int64_t)bz * g.bias_bs + n_out] : 0.f;
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -115,26 +138,24 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
   // in-order wave make bursts of loads / ds_writes stall the matrix pipe, so tile t+2's
   // global loads and tile t+1's LDS writes are threaded between the MFMAs of tile t, with
   // the operand fragments read one k-step pair ahead.  One barrier per tile.
-  constexpr int NOPS = WM + WN;
-  static_assert(NOPS <= 4, "one memory op per k-step pair in each half");
   auto tile = [&](int buf, int kt, float4* la, float4* lb, const float4* sa, const float4* sb) {
-    const int tl = min(kt + 2, nkt - 1);
-    const float* ap = &As[buf][wm * 32 + fr][fk];
-    const float* bp = &Bs[buf][wn * 32 + fr][fk];
+    const int tl = min(kt + D, nkt - 1);
+    const float* ap = &As[buf][wm * 32 + fr][fk + 4 * PP * ks];  // this wave group's share of the k-steps
+    const float* bp = &Bs[buf][wn * 32 + fr][fk + 4 * PP * ks];
     float a0 = ap[0], a1 = ap[2], b0 = bp[0], b1 = bp[2];
 #pragma unroll
-    for (int pr = 0; pr < 8; ++pr) {
+    for (int pr = 0; pr < PP; ++pr) {
       float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
-      if (pr < 7) {
+      if (pr < PP - 1) {
         na0 = ap[4 * pr + 4]; na1 = ap[4 * pr + 6];
         nb0 = bp[4 * pr + 4]; nb1 = bp[4 * pr + 6];
       }
       __builtin_amdgcn_sched_barrier(0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
-      if ((pr & 3) < NOPS) {
-        if (pr < 4) load_one(tl, pr & 3, la, lb);
-        else store_one(buf ^ 1, kt + 1, pr & 3, sa, sb);
+      if ((pr % (PP / 2)) < NOPS) {
+        if (pr < PP / 2) load_one(tl, pr % (PP / 2), la, lb);
+        else store_one(buf ^ 1, kt + 1, pr % (PP / 2), sa, sb);
       }
       __builtin_amdgcn_sched_barrier(0);
       a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
@@ -142,19 +163,33 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
     __syncthreads();
   };
 #pragma unroll
-  for (int i = 0; i < NOPS; ++i) load_one(0, i, ra0, rb0);
+  for (int j = 0; j < D; ++j)
 #pragma unroll
-  for (int i = 0; i < NOPS; ++i) load_one(min(1, nkt - 1), i, ra1, rb1);
+    for (int i = 0; i < NOPS; ++i) load_one(min(j, nkt - 1), i, ra[j], rb[j]);
 #pragma unroll
-  for (int i = 0; i < NOPS; ++i) store_one(0, 0, i, ra0, rb0);
+  for (int i = 0; i < NOPS; ++i) store_one(0, 0, i, ra[0], rb[0]);
   __syncthreads();
-  for (int kt = 0; kt < nkt; kt += 2) {
-    tile(0, kt, ra0, rb0, ra1, rb1);
-    if (kt + 1 < nkt) tile(1, kt + 1, ra1, rb1, ra0, rb0);
+  const unsigned long long t_loop0 = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
+  // tile t multiplies LDS[t & 1]; meanwhile tile t + D is loaded into the register slot tile t just
+  // left (t % D) and tile t + 1 moves from its slot to the other LDS buffer
+  for (int kt = 0; kt < nkt; kt += D) {
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+      if (kt + j < nkt) tile(j & 1, kt + j, ra[j], rb[j], ra[(j + 1) % D], rb[(j + 1) % D]);
+  }
+  const unsigned long long t_loop1 = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
+  if (KS == 2) {  // fold the second k-group's partial sums into the first
+    if (ks == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (ks == 1) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += red[wave][r][lane];
   }
   const int n = n0 + wn * 32 + fr;
   if (n >= N) return;
-  const float bias = g.bias ? g.bias[(int64_t)bz * g.bias_bs + n] : 0.f;
   float* cp = g.c + (int64_t)bz * g.c_bs;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -169,6 +204,16 @@ __global__ void __launch_bounds__(256) k_gemm(GemmArgs g) {
     if (g.accumulate) v += cp[cr * g.ldc + n];
     cp[cr * g.ldc + n] = v;
   }
+  if ((g.dbg & 16) && tid == 0 && blockIdx.x < 4096) {
+    g_gemm_trace[blockIdx.x * 4 + 0] = t_entry;
+    g_gemm_trace[blockIdx.x * 4 + 1] = t_loop0;
+    g_gemm_trace[blockIdx.x * 4 + 2] = t_loop1;
+    g_gemm_trace[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
+  }
+}
+
+extern "C" int tg_debug_gemm_trace(unsigned long long* out_host, int n_blocks) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_gemm_trace), sizeof(unsigned long long) * 4 * n_blocks) == hipSuccess ? 0 : -4;
 }
 
 int gemm_launch(const GemmArgs& g, hipStream_t st) {
@@ -180,7 +225,18 @@ int gemm_launch(const GemmArgs& g, hipStream_t st) {
   const int64_t MT = cdiv(g.m_cap, BM);
   const int NT = (int)cdiv(g.n, BN);
   const int64_t grid = 8 * cdiv(MT, 8) * NT * g.nbatch;
-  hipLaunchKernelGGL((k_gemm<2, 2>), dim3((unsigned)grid), dim3(256), 0, st, g);
+  static const int ks_knob = getenv("TG_GEMM_KS") ? atoi(getenv("TG_GEMM_KS")) : 0;  // tuning knob: 1 / 2, 0 = auto
+  const bool split = ks_knob == 2;  // measured: no gain at the C2 shapes (the tile-load chain, not the MFMA chain, is the limit)
+  static const int gdbg = getenv("TG_GEMM_DBG") ? atoi(getenv("TG_GEMM_DBG")) : 0;
+  GemmArgs gd = g;
+  gd.dbg = gdbg;
+  static const int depth_knob = getenv("TG_GEMM_DEPTH") ? atoi(getenv("TG_GEMM_DEPTH")) : 2;  // tuning knob: 2 / 4
+  if (split)
+    hipLaunchKernelGGL((k_gemm<2, 2, 2, 2>), dim3((unsigned)grid), dim3(512), 0, st, gd);
+  else if (depth_knob == 2)
+    hipLaunchKernelGGL((k_gemm<2, 2, 1, 2>), dim3((unsigned)grid), dim3(256), 0, st, gd);
+  else
+    hipLaunchKernelGGL((k_gemm<2, 2, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, gd);
   return check_launch("gemm");
 }
 
@@ -210,6 +266,11 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
   __shared__ float As[2][BM][LDK];
   __shared__ float Bs[2][3][32][LDK];
   __shared__ float red[KS == 2 ? 4 : 1][KS == 2 ? NW : 1][16][64];
+  // epilogue operands staged while the loop runs (no global load is left for the epilogue, where its
+  // latency would be exposed): the old-memory tile h[m, j0..j0+32) is one of the A tiles the loop
+  // streams anyway, the output rows are fetched at block start
+  __shared__ float Hs[BM][LDK];
+  __shared__ int orow_s[BM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rw = wave % NW, ks = wave / NW;
   const int d = g.d, xw = g.xw;
@@ -222,6 +283,15 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
   const int64_t m0 = mt * BM;
   if (m0 >= M) return;
   const int j0 = nt * 32;
+  if (tid < BM) {
+    const int64_t m = min(m0 + tid, M - 1);
+    orow_s[tid] = g.out_rows ? g.out_rows[m] : (int)m;
+  }
+  // gate biases, requested before the loop
+  const int jb = min(j0 + (lane & 31), d - 1);
+  const float br = g.b_ih[jb] + g.b_hh[jb];
+  const float bz = g.b_ih[d + jb] + g.b_hh[d + jb];
+  const float bin = g.b_ih[2 * d + jb], bhn = g.b_hh[2 * d + jb];
   const int ar = tid >> 3, ac4 = (tid & 7) * 4;
   // branch-free staging (see k_gemm): clamped addresses, zeros only for k past the segment
   const float* xrow[NA];
@@ -322,6 +392,9 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
       TG_SB();
       cur = nxt;
     }
+    if (HP && t == nkx + nt) {  // this A tile is h[m0.., j0..j0+32): keep it for the epilogue
+      for (int f = tid; f < BM * 32; f += THREADS) Hs[f >> 5][f & 31] = As[buf][f >> 5][f & 31];
+    }
     __syncthreads();
   };
 #undef TG_SB
@@ -368,30 +441,18 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
   }
   const int j = min(j0 + fr, d - 1);
   const bool jok = j0 + fr < d;
-  const float br = g.b_ih[j] + g.b_hh[j];
-  const float bz = g.b_ih[d + j] + g.b_hh[d + j];
-  const float bin = g.b_ih[2 * d + j], bhn = g.b_hh[2 * d + j];
-  // branch-free epilogue: all 16 old-memory values are requested up front (rows clamped),
-  // only the final store is predicated
-  float hold_v[16];
-  int64_t orow_v[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int64_t m = min(m0 + rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk, M - 1);
-    const int64_t hr = g.h.idx ? g.h.idx[m] : m;
-    hold_v[r] = g.h.p[hr * g.h.ld + j];
-    orow_v[r] = g.out_rows ? (int64_t)g.out_rows[m] : m;
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int64_t m = m0 + rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-    const float hold = hold_v[r];
+    const int lr = rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+    const int64_t m = m0 + lr;
+    const float hold = Hs[lr][fr];
+    const int64_t orow = orow_s[lr];
     const float rg = fast_sigmoid(acc_r[r] + br);
     const float zg = fast_sigmoid(acc_z[r] + bz);
     const float hn = acc_hn[r] + bhn;
     const float ng = fast_tanh(acc_in[r] + bin + rg * hn);
     if (jok && m < M) {
-      g.out[orow_v[r] * g.ldo + j] = (1.f - zg) * ng + zg * hold;
+      g.out[orow * g.ldo + j] = (1.f - zg) * ng + zg * hold;
       if (g.gates) {
         float* gp = g.gates + m * 4 * (int64_t)d + j;
         gp[0] = rg; gp[d] = zg; gp[2 * d] = ng; gp[3 * d] = hn;
