@@ -210,10 +210,44 @@ int sample_batch_launch(const tg_tcsr* g, int64_t B, const int64_t* src, const i
                         const double* ts, const int64_t* eids, const int64_t* off, int32_t K, int64_t* nids3,
                         float* ts3f, int64_t* eids_b, int64_t* o_nbr, int64_t* o_eid, float* o_ts, uint8_t* mark,
                         hipStream_t st);
+// positive-node dedup of the fused step (select_latest_nids on float32 ts): best[rank(node)] =
+// max over positions of (ts_key << 32 | ~pos), then the winners.  The two passes ride on other
+// launches of the step (they are ~2B threads of work each, not worth a launch of their own).
+struct PosArgs {
+  int64_t B;
+  const int64_t* nids3;  // cat[src, dst, ...]
+  const float* ts;       // [>= B]
+  const uint64_t* bm;
+  const uint32_t* rank;
+  unsigned long long* best;
+  int32_t* count;
+  int64_t *upos, *index;
+};
+__device__ __forceinline__ void pos_max_pass(const PosArgs& a, int64_t tid, int64_t nth) {
+  if (tid == 0) *a.count = 0;  // the winners pass (a later launch) counts into it
+  for (int64_t i = tid; i < 2 * a.B; i += nth) {
+    const int64_t e = i < a.B ? i : i - a.B;
+    const unsigned long long key = (orderable(a.ts[e]) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)i);
+    atomicMax(a.best + bm_rank(a.bm, a.rank, a.nids3[i]), key);
+  }
+}
+__device__ __forceinline__ void pos_winners_pass(const PosArgs& a, int64_t tid, int64_t nth) {
+  for (int64_t i = tid; i < 2 * a.B; i += nth) {
+    const int64_t e = i < a.B ? i : i - a.B;
+    const int64_t node = a.nids3[i];
+    const unsigned long long key = (orderable(a.ts[e]) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)i);
+    if (a.best[bm_rank(a.bm, a.rank, node)] == key) {
+      const int slot = atomicAdd(a.count, 1);
+      a.upos[slot] = node;
+      a.index[slot] = i;
+    }
+  }
+}
 // reprs <- right memory rows of the involved nodes, plus the message/memory time invariants
+// (+ the first dedup pass when pos != nullptr)
 int consume_gather_check_launch(const tg_model* m, const int64_t* involved, const int32_t* n_involved, int64_t cap,
                                 float* reprs, const int64_t* outdated, const int32_t* n_outdated, uint32_t* err,
-                                hipStream_t st);
+                                hipStream_t st, const PosArgs* pos = nullptr);
 // STEP 4-6 in two launches (phase 0 then 1); the tail work (counts copy, stream offset advance)
 // rides on phase 1
 struct WritebackArgs {

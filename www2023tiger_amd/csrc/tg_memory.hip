@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) k_store_events(tg_model m, int64_t B, con
 __global__ void k_consume_gather_check(tg_model m, const int64_t* __restrict__ involved,
                                        const int32_t* __restrict__ n_involved, int64_t cap, float4* __restrict__ reprs,
                                        const int64_t* __restrict__ outdated, const int32_t* __restrict__ n_outdated,
-                                       uint32_t* __restrict__ err) {
+                                       uint32_t* __restrict__ err, PosArgs pos) {
   const int w4 = m.d / 4;
   const int64_t n = min((int64_t)*n_involved, cap);
   const int64_t total = n * w4;
@@ -166,6 +166,7 @@ __global__ void k_consume_gather_check(tg_model m, const int64_t* __restrict__ i
     if (last > mts) atomicOr(err, TG_ERR_MSG_BEFORE_MEM);
     if (m.msg_src == TG_SRC_LEFT && !(mts == last)) atomicOr(err, TG_ERR_MSG_TS_MISMATCH);
   }
+  if (pos.best) pos_max_pass(pos, tid, nth);
 }
 
 // ---- fused write-back (tiger.py:229-255).  Hazards: STEP 5 reads the message memory
@@ -298,9 +299,9 @@ __global__ void __launch_bounds__(256) k_writeback(tg_model m, WritebackArgs a) 
 
 int consume_gather_check_launch(const tg_model* m, const int64_t* involved, const int32_t* n_involved, int64_t cap,
                                 float* reprs, const int64_t* outdated, const int32_t* n_outdated, uint32_t* err,
-                                hipStream_t st) {
+                                hipStream_t st, const PosArgs* pos) {
   hipLaunchKernelGGL(k_consume_gather_check, dim3(flat_grid(cap * (m->d / 4), 256)), dim3(256), 0, st, *m, involved,
-                     n_involved, cap, (float4*)reprs, outdated, n_outdated, err);
+                     n_involved, cap, (float4*)reprs, outdated, n_outdated, err, pos ? *pos : PosArgs{});
   return check_launch("consume_gather_check");
 }
 

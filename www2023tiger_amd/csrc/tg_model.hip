@@ -34,8 +34,11 @@ __global__ void __launch_bounds__(256) k_attn_centres(int64_t Q, int d4, const i
                                                       const uint32_t* __restrict__ rank, const float4* __restrict__ nf,
                                                       float4* __restrict__ out, int qblocks, const float* __restrict__ wq,
                                                       const float* __restrict__ bq, const float* __restrict__ freq,
-                                                      const float* __restrict__ phase, float* __restrict__ qconst) {
+                                                      const float* __restrict__ phase, float* __restrict__ qconst,
+                                                      PosArgs pos) {
   const int cblocks = (int)gridDim.x - qblocks;
+  if (pos.best && (int)blockIdx.x < cblocks)  // second dedup pass rides on the centre blocks
+    pos_winners_pass(pos, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)cblocks * blockDim.x);
   if ((int)blockIdx.x >= cblocks) {
     const int d = d4 * 4, lane = lane_id();
     const int n = ((int)blockIdx.x - cblocks) * 4 + (threadIdx.x >> 6);
@@ -265,7 +268,7 @@ constexpr int ST_ATTN_FIRST = 5;  // == ST_ATTN_PREP (checked by a static_assert
 int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float* ts, const int64_t* l1_nids,
                  const int64_t* l1_eids, const float* l1_ts, const float* reprs, const uint64_t* bm,
                  const uint32_t* rank, float* out, const AttnWs& w, hipStream_t st, tg_profiler* pf = nullptr,
-                 const DropCfg* drop = nullptr) {
+                 const DropCfg* drop = nullptr, const PosArgs* pos = nullptr) {
   const DropCfg dc = drop ? *drop : DropCfg{};
   int stage = ST_ATTN_FIRST;
   prof_mark(pf, stage++, st);
@@ -273,7 +276,7 @@ int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float*
   const int qblocks = (int)cdiv(2 * d, 4);
   hipLaunchKernelGGL(k_attn_centres, dim3(flat_grid(Q * (d / 4), 256) + qblocks), dim3(256), 0, st, Q, d / 4, nids,
                      (const float4*)reprs, bm, rank, (const float4*)m->nfeats, (float4*)w.cc, qblocks, m->attn_wq,
-                     m->attn_b_in, m->te_freq, m->te_phase, w.qconst);
+                     m->attn_b_in, m->te_freq, m->te_phase, w.qconst, pos ? *pos : PosArgs{});
   int rc;
   GemmArgs g{};
   // q = (Wq [c | TE(0)] + bq) / sqrt(dh)          (F.multi_head_attention_forward scaling)
@@ -658,9 +661,13 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
                                   w.outdated, w.out_pos, w.counts + 1, w.scan_ws, w.scan_bytes, st)) != TG_OK)
     return rc;
   prof_mark(pf, ST_GATHER, st);
+  // the positive-node dedup (needed by the write-back) rides on two launches of the forward pass
+  PosArgs pos{B, w.nids3, w.ts3f, w.bm, w.rank, w.best, w.counts + 2, w.upos, w.index};
+  const PosArgs* pp = io->embed_only ? nullptr : &pos;
+  w.dedup_done = pp != nullptr;
   // ---- STEP 1-2: reprs = right_memory[involved] (+ invariants); outdated rows <- updater(...)
-  if ((rc = consume_gather_check_launch(m, w.inv, w.counts + 0, cap, w.reprs, w.outdated, w.counts + 1, io->err, st)) !=
-      TG_OK)
+  if ((rc = consume_gather_check_launch(m, w.inv, w.counts + 0, cap, w.reprs, w.outdated, w.counts + 1, io->err, st,
+                                        pp)) != TG_OK)
     return rc;
   prof_mark(pf, ST_UPDATE, st);
   if ((rc = apply_messages(m, w.outdated, w.out_pos, w.counts + 1, cap, w.reprs, io->err, w.apply_ws, w.apply_bytes,
@@ -668,14 +675,14 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
     return rc;
   // ---- STEP 3: temporal embeddings of cat[src, dst, neg]
   if ((rc = attn_forward(m, Q, w.nids3, w.ts3f, w.l1n, w.l1e, w.l1t, w.reprs, w.bm, w.rank, io->h, w.attn, st, pf,
-                         drop)) != TG_OK)
+                         drop, pp)) != TG_OK)
     return rc;
   prof_mark(pf, ST_DEDUP, st);
   if (io->h_new) {  // h(t'+) rows of cat[src, dst]: reprs[local(node)]
     hipLaunchKernelGGL(k_attn_centres, dim3(flat_grid(2 * B * (m->d / 4), 256)), dim3(256), 0, st, 2 * B, m->d / 4,
                        w.nids3, (const float4*)w.reprs, w.bm, w.rank, (const float4*)nullptr, (float4*)io->h_new, 0,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       (float*)nullptr);
+                       (float*)nullptr, PosArgs{});
   }
   return check_launch("tg_stream_step(forward)");
 }
@@ -701,10 +708,12 @@ int step_writeback_a(const tg_model* m, const tg_step_io* io, StepWs& w, hipStre
   const int64_t B = io->B;
   const int64_t* src = w.nids3;
   const int64_t* dst = w.nids3 + B;
-  hipLaunchKernelGGL(k_pos_max, dim3(flat_grid(2 * B, 256)), dim3(256), 0, st, B, src, dst, w.ts3f, w.bm, w.rank, w.best,
-                     w.counts + 2);
-  hipLaunchKernelGGL(k_pos_winners, dim3(flat_grid(2 * B, 256)), dim3(256), 0, st, B, src, dst, w.ts3f, w.bm, w.rank,
-                     w.best, w.upos, w.index, w.counts + 2);
+  if (!w.dedup_done) {
+    hipLaunchKernelGGL(k_pos_max, dim3(flat_grid(2 * B, 256)), dim3(256), 0, st, B, src, dst, w.ts3f, w.bm, w.rank,
+                       w.best, w.counts + 2);
+    hipLaunchKernelGGL(k_pos_winners, dim3(flat_grid(2 * B, 256)), dim3(256), 0, st, B, src, dst, w.ts3f, w.bm, w.rank,
+                       w.best, w.upos, w.index, w.counts + 2);
+  }
   const WritebackArgs wa = writeback_args(m, io, w);
   int rc;
   prof_mark(pf, ST_WRITE_RIGHT, st);

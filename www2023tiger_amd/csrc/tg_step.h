@@ -56,6 +56,7 @@ struct StepWs {
   // resolved per call (io overrides)
   int64_t *l1n, *l1e, *inv;
   float* l1t;
+  bool dedup_done;  // the positive-node dedup already ran inside the forward launches
 };
 
 bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w);
