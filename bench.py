@@ -225,6 +225,7 @@ def main():
     ap.add_argument('--force-dist', action='store_true', help='run the multi-GPU code path even with one rank')
     ap.add_argument('--dist-graphs', action='store_true',
                     help='multi-GPU: replay captured hipGraphs around the all-gather (experimental; default eager)')
+    ap.add_argument('--no-fuse', action='store_true', help='keep the six-product attention (no tg_attn_fuse)')
     ap.add_argument('--train', action='store_true', help='measure the training iteration instead (not the headline metric)')
     ap.add_argument('--train-restarter', default='none', choices=['none', 'seq', 'static'],
                     help='--train: add the mutual-learning loss of this restarter (none = contrast_only)')
@@ -251,6 +252,8 @@ def main():
     model, _ = build_models(stream, d, K, cfg['msg_src'], cfg['upd_src'], restarter='static', device='cuda:0',
                             zero_nfeats=not no_feats)
     resident = tuple(torch.from_numpy(stream[k]).to(dev) for k in ('src', 'dst', 'neg', 'ts', 'eids'))
+    if not args.no_fuse:  # streaming inference, parameters fixed: pre-multiplied attention weights (tg_attn_fuse)
+        model.fuse_attention()
     buf = model.StepBuffers(model, B, False, resident=resident)
 
     # ---- warm-up (untimed, eager): also brings memory / mailbox to steady state
@@ -330,6 +333,7 @@ def main():
                config=dict(workload=cfg['name'], batch=B, dim=d, n_neighbors=K, msg_src=cfg['msg_src'],
                            upd_src=cfg['upd_src'], n_nodes=stream['n_nodes'], events=E, mode='stream (no_grad) STEP 1-6',
                            launch='hipGraph replay' if graph is not None else 'eager',
+                           attention_weights='pre-multiplied (tg_attn_fuse)' if not args.no_fuse else 'as stored',
                            involved_per_batch=float(U), outdated_per_batch=float(O_), unique_pos_per_batch=float(P)),
                roofline=roof,
                stages_ms={n: round(float(v), 5) for n, v in zip(names, stage_ms)})

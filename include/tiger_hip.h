@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 1
+#define TG_ABI_VERSION 2
 
 /* status codes */
 #define TG_OK 0
@@ -193,7 +193,20 @@ typedef struct tg_model {
   const float* attn_b_in;                   /* [6d] */
   tg_linear attn_out;                       /* [2d,2d] */
   tg_linear attn_fc1, attn_fc2;             /* merger: [d,3d], [d,d] */
+  /* Optional (NULL = off): weights pre-multiplied by tg_attn_fuse for inference with FIXED parameters.
+   * The forward pass then runs three products instead of six (see tg_attn_fuse). */
+  const float* attn_fused;
 } tg_model;
+
+/* Inference-time algebra on the attention weights (parameters only, no data):
+ *   g_h   = alpha Wk_h^T (Wq[:, :d] c + qconst_h)            ->  G = c Wqk^T + gconst      (q and g products merged)
+ *   fc1([Wo concat_h(Wv_h s_h + bv_h) + bo | c])             ->  [S | c] W1f^T + b1 + valid * c1
+ * `fused` receives tg_attn_fused_floats(m) floats: Wqk [n_head*kvw, d], gconst [n_head*kvw],
+ * W1f [d, n_head*kvw + d], b1 [d], c1 [d]  (kvw = 2d + d_e).  Must be recomputed whenever an attention
+ * parameter or the time encoder changes; training (tg_train_step) ignores it. */
+size_t tg_attn_fused_floats(const tg_model* m);
+size_t tg_attn_fuse_workspace_bytes(const tg_model* m);
+int tg_attn_fuse(const tg_model* m, float* fused, void* ws, size_t ws_bytes, void* stream);
 
 /* TimeEncode.forward (time_encoding.py:24-26): out[i,:] = cos(fl32(ts[i]*w) + phi) */
 int tg_time_encode(int64_t n, const float* ts, int32_t d, const float* freq, const float* phase,

@@ -50,7 +50,7 @@ class TgModel(C.Structure):
         ('gru_w_ih', vp), ('gru_w_hh', vp), ('gru_b_ih', vp), ('gru_b_hh', vp),
         ('upd_fc1', TgLinear), ('upd_fc2', TgLinear),
         ('attn_wq', vp), ('attn_wk', vp), ('attn_wv', vp), ('attn_b_in', vp),
-        ('attn_out', TgLinear), ('attn_fc1', TgLinear), ('attn_fc2', TgLinear),
+        ('attn_out', TgLinear), ('attn_fc1', TgLinear), ('attn_fc2', TgLinear), ('attn_fused', vp),
     ]
 
 
@@ -146,6 +146,9 @@ SIGNATURES = {
     'tg_train_step_workspace_bytes': (sz, [P(TgModel), P(TgScoreParams), i32, vp, i64]),
     'tg_train_step': (C.c_int, [P(TgModel), P(TgTcsr), P(TgTrainIo), vp, sz, vp]),
     'tg_adam_step': (C.c_int, [vp, i32, i32, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
+    'tg_attn_fused_floats': (sz, [P(TgModel)]),
+    'tg_attn_fuse_workspace_bytes': (sz, [P(TgModel)]),
+    'tg_attn_fuse': (C.c_int, [P(TgModel), vp, vp, sz, vp]),
     'tg_ap_auc': (C.c_int, [i64, i32, vp, vp, vp, vp, vp, vp]),
     'tg_stream_writeback_workspace_bytes': (sz, [P(TgModel), i64]),
     'tg_stream_writeback': (C.c_int, [P(TgModel), P(TgWritebackIo), vp, sz, vp]),
@@ -166,7 +169,7 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the library does not export the symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.tg_abi_version() != 1:
+    if lib.tg_abi_version() != 2:
         raise TigerHipError('libtiger_hip.so ABI version mismatch')
     return lib
 

@@ -42,6 +42,10 @@ struct GemmArgs {
   // bias is weighted by the sum of the kept, rescaled probabilities)
   const float* bias_rs;
   int64_t ld_brs;
+  // second bias added only on rows with bias2_valid[m] != 0 (fused attention: the constant that the
+  // reference zeroes together with the attention output of neighbour-less centres)
+  const float* bias2;
+  const uint8_t* bias2_valid;
   int dbg;  // diagnostic bits, 0 in production
 };
 

@@ -1,0 +1,115 @@
+// tg_attn_fuse: products of attention PARAMETERS for inference with fixed weights (see
+// include/tiger_hip.h).  Reference maths: temporal_agg_modules.py:204-235 (MultiheadAttention
+// + MergeLayer); re-associated so that the forward pass multiplies activations three times
+// instead of six.  Runs once per parameter version, so nothing here is tuned.
+#include "tg_step.h"
+
+namespace tg {
+
+// qconst[n] = bq[n] + sum_j Wq[n, d + j] cos(phi_j)                    (TE(0) = cos(phi))
+// c0[n]     = bo[n] + sum_k Wo[n, k] bv[k]
+__global__ void k_fuse_vec1(int d, const float* __restrict__ wq, const float* __restrict__ b_in,
+                            const float* __restrict__ freq, const float* __restrict__ phase,
+                            const float* __restrict__ wo, const float* __restrict__ bo, float* __restrict__ qconst,
+                            float* __restrict__ c0) {
+  const int E = 2 * d, lane = lane_id();
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= 2 * E) return;
+  const int n = row % E;
+  float acc = 0.f;
+  if (row < E) {
+    for (int j = lane; j < d; j += TG_WAVE) acc += wq[(int64_t)n * E + d + j] * time_enc(0.f, freq[j], phase[j]);
+    acc = wave_sum(acc);
+    if (lane == 0) qconst[n] = acc + b_in[n];
+  } else {
+    for (int k = lane; k < E; k += TG_WAVE) acc += wo[(int64_t)n * E + k] * b_in[2 * E + k];
+    acc = wave_sum(acc);
+    if (lane == 0) c0[n] = acc + bo[n];
+  }
+}
+// gconst[h kvw + c] = alpha sum_k Wk_h[k, c] qconst[h dh + k];  c1[n] = sum_e W1[n, e] c0[e];  b1 copy;
+// W1f[n, nk + j] = W1[n, E + j]
+__global__ void k_fuse_vec2(int d, int kvw, int nh, float alpha, const float* __restrict__ wk,
+                            const float* __restrict__ qconst, const float* __restrict__ w1, const float* __restrict__ b1,
+                            const float* __restrict__ c0, float* __restrict__ gconst, float* __restrict__ w1f,
+                            float* __restrict__ b1o, float* __restrict__ c1) {
+  const int E = 2 * d, dh = E / nh, nk = nh * kvw;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < nk) {
+    const int h = t / kvw, c = t % kvw;
+    float acc = 0.f;
+    for (int k = 0; k < dh; ++k) acc += wk[((int64_t)h * dh + k) * kvw + c] * qconst[h * dh + k];
+    gconst[t] = alpha * acc;
+  }
+  if (t < d) {
+    float acc = 0.f;
+    for (int e = 0; e < E; ++e) acc += w1[(int64_t)t * (E + d) + e] * c0[e];
+    c1[t] = acc;
+    b1o[t] = b1[t];
+  }
+  for (int e = t; e < d * d; e += gridDim.x * blockDim.x) {
+    const int n = e / d, j = e % d;
+    w1f[(int64_t)n * (nk + d) + nk + j] = w1[(int64_t)n * (E + d) + E + j];
+  }
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+extern "C" size_t tg_attn_fused_floats(const tg_model* m) {
+  if (!attn_dims_ok(m)) return 0;
+  const size_t d = m->d, nk = (size_t)m->n_head * (2 * d + m->d_e);
+  return nk * d + nk + d * (nk + d) + 2 * d;
+}
+
+extern "C" size_t tg_attn_fuse_workspace_bytes(const tg_model* m) {
+  if (!attn_dims_ok(m)) return 0;
+  const size_t d = m->d, E = 2 * d, nk = (size_t)m->n_head * (2 * d + m->d_e);
+  // qconst [E], c0 [E], Wov [E, nk], partials of the weight-gradient-style product
+  return align16(E * 4) * 2 + align16(E * nk * 4) + align16((size_t)16 * nk * (d + 1) * 4) + 256;
+}
+
+extern "C" int tg_attn_fuse(const tg_model* m, float* fused, void* ws, size_t ws_bytes, void* stream) {
+  if (!attn_dims_ok(m) || !fused) return TG_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const int d = m->d, E = 2 * d, kvw = 2 * d + m->d_e, nh = m->n_head, dh = E / nh, nk = nh * kvw;
+  const float alpha = 1.0f / sqrtf((float)dh);
+  Carver cv(ws, ws_bytes);
+  float* qconst = cv.take<float>(E);
+  float* c0 = cv.take<float>(E);
+  float* wov = cv.take<float>((size_t)E * nk);
+  const size_t part_floats = (size_t)16 * nk * (d + 1);
+  float* part = cv.take<float>(part_floats);
+  if (!cv.ok) return TG_EWORKSPACE;
+  float* wqk = fused;
+  float* gconst = wqk + (size_t)nk * d;
+  float* w1f = gconst + nk;
+  float* b1 = w1f + (size_t)d * (nk + d);
+  float* c1 = b1 + d;
+  hipLaunchKernelGGL(k_fuse_vec1, dim3((unsigned)cdiv(2 * E, 4)), dim3(256), 0, st, d, m->attn_wq, m->attn_b_in, m->te_freq,
+                     m->te_phase, m->attn_out.w, m->attn_out.b, qconst, c0);
+  int rc;
+  // Wqk_h[c, j] = alpha sum_k Wk_h[k, c] Wq[h dh + k, j]: both operands are read along k, i.e. the
+  // weight-gradient product shape
+  TnArgs tn{};
+  tn.m_cap = dh; tn.n = kvw; tn.k = d; tn.y = m->attn_wk; tn.ldy = kvw; tn.y_bs = (int64_t)dh * kvw;
+  tn.x0 = ASeg{m->attn_wq, E, d, nullptr}; tn.x0_bs = (int64_t)dh * E;
+  tn.out = wqk; tn.ldo = d; tn.out_bs = (int64_t)kvw * d; tn.alpha = alpha; tn.accumulate = 0; tn.nbatch = nh;
+  tn.part = part; tn.part_floats = part_floats;
+  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  // Wov[n, h kvw + c] = sum_k Wo[n, h dh + k] Wv_h[k, c]
+  GemmArgs g{};
+  g.m_cap = E; g.n = kvw; g.k = dh; g.a0 = ASeg{m->attn_out.w, E, dh, nullptr}; g.a0_bs = dh;
+  g.w = m->attn_wv; g.ldw = kvw; g.w_kmajor = 1; g.w_bs = (int64_t)dh * kvw;
+  g.c = wov; g.ldc = nk; g.c_bs = kvw; g.alpha = 1.f; g.nbatch = nh;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  // W1f[:, :nk] = W1[:, :E] Wov
+  g = GemmArgs{};
+  g.m_cap = d; g.n = nk; g.k = E; g.a0 = ASeg{m->attn_fc1.w, E + d, E, nullptr};
+  g.w = wov; g.ldw = nk; g.w_kmajor = 1; g.c = w1f; g.ldc = nk + d; g.alpha = 1.f; g.nbatch = 1;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  hipLaunchKernelGGL(k_fuse_vec2, dim3((unsigned)cdiv(std::max(nk, d * d / 8), 256)), dim3(256), 0, st, d, kvw, nh, alpha,
+                     m->attn_wk, qconst, m->attn_fc1.w, m->attn_fc1.b, c0, gconst, w1f, b1, c1);
+  return check_launch("tg_attn_fuse");
+}

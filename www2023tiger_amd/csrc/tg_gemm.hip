@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
   // fully exposed, a third of the block's lifetime at K = 172
   const int n_out = min(n0 + wn * 32 + fr, N - 1);
   const float bias = g.bias ? g.bias[(int64_t)bz * g.bias_bs + n_out] : 0.f;
+  const float bias2 = g.bias2 ? g.bias2[n_out] : 0.f;
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -195,7 +196,8 @@ __global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
   for (int r = 0; r < 16; ++r) {
     const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
     if (m >= M) continue;
-    const float be = g.bias_rs ? bias * g.bias_rs[m * g.ld_brs + bz] : bias;
+    float be = g.bias_rs ? bias * g.bias_rs[m * g.ld_brs + bz] : bias;
+    if (g.bias2 && g.bias2_valid[m]) be += bias2;
     float v = g.alpha * (acc[r] + be);
     if (g.relu) v = fmaxf(v, 0.f);
     if (g.row_valid && !g.row_valid[m]) v = 0.f;

@@ -265,6 +265,85 @@ static inline void prof_mark(tg_profiler* p, int i, hipStream_t st);
 namespace tg {
 constexpr int ST_ATTN_FIRST = 5;  // == ST_ATTN_PREP (checked by a static_assert below)
 
+// ---- inference with pre-multiplied weights (tg_attn_fuse) --------------------------------
+struct FusedView {
+  const float *wqk, *gconst, *w1f, *b1, *c1;
+  int nk;  // n_head * kvw
+};
+static FusedView fused_view(const tg_model* m, const float* f) {
+  FusedView v{};
+  const int d = m->d;
+  v.nk = m->n_head * (2 * d + m->d_e);
+  v.wqk = f;
+  v.gconst = v.wqk + (size_t)v.nk * d;
+  v.w1f = v.gconst + v.nk;
+  v.b1 = v.w1f + (size_t)d * (v.nk + d);
+  v.c1 = v.b1 + d;
+  return v;
+}
+
+void launch_attn_core(const tg_model* m, int64_t Q, const float* ts, const int64_t* l1_nids, const int64_t* l1_eids,
+                      const float* l1_ts, const float* reprs, const uint64_t* bm, const uint32_t* rank, const AttnWs& w,
+                      const DropCfg& dc, hipStream_t st, int* rc_out) {
+  const int d = m->d, d_e = m->d_e, nh = m->n_head;
+  *rc_out = TG_OK;
+  const int nv = (int)cdiv(std::max(d, d_e) / 4, TG_WAVE);
+  const unsigned cgrid = flat_grid(Q, 4);
+#define TG_CORE(NH_, NV_)                                                                                          \
+  hipLaunchKernelGGL((k_attn_core<NH_, NV_>), dim3(cgrid), dim3(256), 0, st, *m, Q, ts, l1_nids, l1_eids, l1_ts,   \
+                     (const float4*)reprs, bm, rank, (const float4*)w.g, (float4*)w.s, w.valid, dc,                 \
+                     dc.p > 0.f ? w.rsum : (float*)nullptr)
+  if (nh == 2 && nv == 1) TG_CORE(2, 1);
+  else if (nh == 2 && nv == 2) TG_CORE(2, 2);
+  else if (nh == 1 && nv == 1) TG_CORE(1, 1);
+  else if (nh == 4 && nv == 1) TG_CORE(4, 1);
+  else *rc_out = TG_EUNSUPPORTED;
+#undef TG_CORE
+}
+
+static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids, const float* ts,
+                              const int64_t* l1_nids, const int64_t* l1_eids, const float* l1_ts, const float* reprs,
+                              const uint64_t* bm, const uint32_t* rank, float* out, const AttnWs& w, hipStream_t st,
+                              tg_profiler* pf, const PosArgs* pos) {
+  // stage numbering of the profiler is kept: q -> "merged q+g", g -> skipped, v/out -> skipped, fc1 -> fused
+  int stage = ST_ATTN_FIRST + 1;
+  const int d = m->d;
+  const FusedView f = fused_view(m, m->attn_fused);
+  hipLaunchKernelGGL(k_attn_centres, dim3(flat_grid(Q * (d / 4), 256)), dim3(256), 0, st, Q, d / 4, nids,
+                     (const float4*)reprs, bm, rank, (const float4*)m->nfeats, (float4*)w.cc, 0, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr,
+                     pos ? *pos : PosArgs{});
+  int rc;
+  GemmArgs g{};
+  // G = c Wqk^T + gconst   (scaled query folded through the key projection, all heads at once)
+  prof_mark(pf, stage++, st);
+  g.m_cap = Q; g.n = f.nk; g.k = d; g.a0 = ASeg{w.cc, d, d, nullptr};
+  g.w = f.wqk; g.ldw = d; g.bias = f.gconst; g.c = w.g; g.ldc = f.nk; g.alpha = 1.f; g.nbatch = 1;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  prof_mark(pf, stage++, st);
+  prof_mark(pf, stage++, st);
+  launch_attn_core(m, Q, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, w, DropCfg{}, st, &rc);
+  if (rc != TG_OK) return rc;
+  prof_mark(pf, stage++, st);
+  prof_mark(pf, stage++, st);
+  // t = relu([S | c] W1f^T + b1 + valid * c1)   (value projection, out projection and fc1 merged)
+  prof_mark(pf, stage++, st);
+  g = GemmArgs{};
+  g.m_cap = Q; g.n = d; g.k = f.nk + d;
+  g.a0 = ASeg{w.s, f.nk, f.nk, nullptr}; g.a1 = ASeg{w.cc, d, d, nullptr};
+  g.w = f.w1f; g.ldw = f.nk + d; g.bias = f.b1; g.bias2 = f.c1; g.bias2_valid = w.valid;
+  g.c = w.t; g.ldc = d; g.relu = 1; g.alpha = 1.f; g.nbatch = 1;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  prof_mark(pf, stage++, st);
+  g = GemmArgs{};
+  g.m_cap = Q; g.n = d; g.k = d;
+  g.a0 = ASeg{w.t, d, d, nullptr};
+  g.w = m->attn_fc2.w; g.ldw = d; g.bias = m->attn_fc2.b;
+  g.c = out; g.ldc = d; g.alpha = 1.f; g.nbatch = 1;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  return check_launch("tg_temporal_attn_fwd(fused)");
+}
+
 int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float* ts, const int64_t* l1_nids,
                  const int64_t* l1_eids, const float* l1_ts, const float* reprs, const uint64_t* bm,
                  const uint32_t* rank, float* out, const AttnWs& w, hipStream_t st, tg_profiler* pf = nullptr,
@@ -273,6 +352,8 @@ int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float*
   int stage = ST_ATTN_FIRST;
   prof_mark(pf, stage++, st);
   const int d = m->d, d_e = m->d_e, kvw = 2 * d + d_e, nh = m->n_head, dh = 2 * d / nh, E = 2 * d;
+  if (m->attn_fused && dc.p == 0.f)
+    return attn_forward_fused(m, Q, nids, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, out, w, st, pf, pos);
   const int qblocks = (int)cdiv(2 * d, 4);
   hipLaunchKernelGGL(k_attn_centres, dim3(flat_grid(Q * (d / 4), 256) + qblocks), dim3(256), 0, st, Q, d / 4, nids,
                      (const float4*)reprs, bm, rank, (const float4*)m->nfeats, (float4*)w.cc, qblocks, m->attn_wq,
@@ -297,18 +378,8 @@ int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float*
   if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
   // gather + scores + softmax + weighted raw sum
   prof_mark(pf, stage++, st);
-  const int nv = (int)cdiv(std::max(d, d_e) / 4, TG_WAVE);
-  const unsigned cgrid = flat_grid(Q, 4);
-#define TG_CORE(NH_, NV_)                                                                                          \
-  hipLaunchKernelGGL((k_attn_core<NH_, NV_>), dim3(cgrid), dim3(256), 0, st, *m, Q, ts, l1_nids, l1_eids, l1_ts,   \
-                     (const float4*)reprs, bm, rank, (const float4*)w.g, (float4*)w.s, w.valid, dc,                 \
-                     dc.p > 0.f ? w.rsum : (float*)nullptr)
-  if (nh == 2 && nv == 1) TG_CORE(2, 1);
-  else if (nh == 2 && nv == 2) TG_CORE(2, 2);
-  else if (nh == 1 && nv == 1) TG_CORE(1, 1);
-  else if (nh == 4 && nv == 1) TG_CORE(4, 1);
-  else return TG_EUNSUPPORTED;
-#undef TG_CORE
+  launch_attn_core(m, Q, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, w, dc, st, &rc);
+  if (rc != TG_OK) return rc;
   // o_h = Wv_h s_h + bv_h
   prof_mark(pf, stage++, st);
   g = GemmArgs{};

@@ -800,8 +800,12 @@ extern "C" size_t tg_train_step_workspace_bytes(const tg_model* m, const tg_scor
   return b;
 }
 
-extern "C" int tg_train_step(const tg_model* m, const tg_tcsr* g, const tg_train_io* io, void* ws, size_t ws_bytes,
-                             void* stream) {
+extern "C" int tg_train_step(const tg_model* m_in, const tg_tcsr* g, const tg_train_io* io, void* ws,
+                             size_t ws_bytes, void* stream) {
+  if (!m_in) return TG_EINVAL;
+  tg_model m_local = *m_in;
+  m_local.attn_fused = nullptr;  // the backward pass is built on the unfused forward's intermediates
+  const tg_model* m = &m_local;
   if (!m || !g || !io || !io->score || !io->grads || !io->score_grads || !io->losses) return TG_EINVAL;
   if (!train_supported(m, io->score)) return TG_EUNSUPPORTED;
   const tg_step_io* sio = &io->step;

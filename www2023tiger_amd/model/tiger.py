@@ -94,6 +94,7 @@ class TIGE(nn.Module):
         self.score_fn = MergeLayer(merge_dim, merge_dim, self.nfeat_dim, 1, dropout=dropout)
         self.contrast_loss_fn = nn.BCEWithLogitsLoss()
         self._struct_cache = None
+        self._fused = None
         self._step_ws = {}
 
     def _sanity_check(self):
@@ -117,6 +118,7 @@ class TIGE(nn.Module):
 
     def _apply(self, fn, *a, **kw):  # .to() / .cuda() move every tensor: pointers change
         self._struct_cache = None
+        self._fused = None
         self._step_ws = {}
         return super()._apply(fn, *a, **kw)
 
@@ -163,9 +165,30 @@ class TIGE(nn.Module):
                     ptr(fg.nfeats), ptr(fg.efeats), ptr(self.time_encoder.basis_freq), ptr(self.time_encoder.phase),
                     tsfm1, tsfm2, gru[0], gru[1], gru[2], gru[3], fc1, fc2,
                     ptr(mha.q_proj_weight), ptr(mha.k_proj_weight), ptr(mha.v_proj_weight), ptr(mha.in_proj_bias),
-                    lin(mha.out_proj), lin(att.merger.fc1), lin(att.merger.fc2))
+                    lin(mha.out_proj), lin(att.merger.fc1), lin(att.merger.fc2),
+                    ptr(self._fused) if self._fused is not None else None)
         self._struct_cache = m
         return m
+
+    def fuse_attention(self, enable: bool = True):
+        """Inference with FIXED parameters: pre-multiply the attention weights (tg_attn_fuse) so that the
+        embedding runs three products instead of six.  Call again after any parameter update; training
+        ignores the fused weights."""
+        self._fused = None
+        self._struct_cache = None
+        if not enable:
+            return self
+        m = self.model_struct()
+        n = int(lib.tg_attn_fused_floats(C.byref(m)))
+        if n == 0:
+            raise RuntimeError('tg_attn_fuse: unsupported model dimensions')
+        fused = torch.empty(n, dtype=torch.float32, device=self.device)
+        nbytes = int(lib.tg_attn_fuse_workspace_bytes(C.byref(m)))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        check(lib.tg_attn_fuse(C.byref(m), ptr(fused), ptr(ws), nbytes, stream_ptr(self.device)), 'tg_attn_fuse')
+        self._fused = fused
+        self._struct_cache = None
+        return self
 
     def _ws(self, key, nbytes) -> Tensor:
         t = self._step_ws.get(key)

@@ -112,7 +112,7 @@ def grads_struct(model, g) -> TgModel:
                    ptr(g[pre + 'mha_fn.v_proj_weight']), ptr(g[pre + 'mha_fn.in_proj_bias']),
                    TgLinear(ptr(g[pre + 'mha_fn.out_proj.weight']), ptr(g[pre + 'mha_fn.out_proj.bias'])),
                    TgLinear(ptr(g[pre + 'merger.fc1.weight']), ptr(g[pre + 'merger.fc1.bias'])),
-                   TgLinear(ptr(g[pre + 'merger.fc2.weight']), ptr(g[pre + 'merger.fc2.bias'])))
+                   TgLinear(ptr(g[pre + 'merger.fc2.weight']), ptr(g[pre + 'merger.fc2.bias'])), None)
 
 
 def check_trainable(model):
