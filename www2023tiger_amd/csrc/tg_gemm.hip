@@ -228,7 +228,9 @@ int gemm_launch(const GemmArgs& g, hipStream_t st) {
   const int NT = (int)cdiv(g.n, BN);
   const int64_t grid = 8 * cdiv(MT, 8) * NT * g.nbatch;
   static const int ks_knob = getenv("TG_GEMM_KS") ? atoi(getenv("TG_GEMM_KS")) : 0;  // tuning knob: 1 / 2, 0 = auto
-  const bool split = ks_knob == 2;  // measured: no gain at the C2 shapes (the tile-load chain, not the MFMA chain, is the limit)
+  // measured at C2: a second k-group helps only launches that leave CUs idle AND have a long K (the merged
+  // value/out/fc1 product: 144 tiles x 38 k-steps, 37 -> 35 us); elsewhere it is neutral or slightly worse
+  const bool split = ks_knob ? ks_knob == 2 : (grid <= 256 && g.k >= 512);
   static const int gdbg = getenv("TG_GEMM_DBG") ? atoi(getenv("TG_GEMM_DBG")) : 0;
   GemmArgs gd = g;
   gd.dbg = gdbg;

@@ -302,6 +302,8 @@ def bench_main(args, cfg, make_stream, build_models, rank, local_rank, world):
     E = max(cfg['E'], (n_steps + 2) * Bg)
     stream = make_stream(cfg['n_u'], cfg['n_i'], E, cfg['T'] * E / cfg['E'], seed=0, d_e=d)  # identical on every rank
     model, _ = build_models(stream, d, K, cfg['msg_src'], cfg['upd_src'], restarter='static', device=str(dev))
+    if not getattr(args, 'no_fuse', False):
+        model.fuse_attention()  # fixed parameters: pre-multiplied attention weights, as in the 1-GPU bench
     owner = balanced_owner_table(stream['n_nodes'], stream['dst'], world)
     use_graphs = bool(getattr(args, 'dist_graphs', False)) and not args.no_graph
     rs = ResidentShardedStream(model, stream, owner, rank, world, B, n_steps, use_graphs=use_graphs)
