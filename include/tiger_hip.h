@@ -406,6 +406,8 @@ typedef struct tg_score_params {
  * tg_model whose parameter pointers (te_*, gru_*, attn_*) point at gradient buffers (other
  * fields ignored), `score_grads` likewise for the score head.  Supported: message transform
  * 'id', updater 'gru', one attention layer.
+ * grads == NULL selects EVALUATION: forward, STEP 7 scores and BCE loss, write-back - no gradients,
+ * no mutual loss, no dropout (the path of tiger/eval_utils.py:29-48); attn_fused is honoured.
  * flags (device int32[4]) says which parameter groups received a gradient this step (torch leaves
  * the .grad of the others None and Adam skips them): [0] = 1 always (embedding, score head, time
  * encoder), [1] = the GRU ran (some involved node had a pending message), [2] = the mutual loss

@@ -229,10 +229,12 @@ def check_state(model, z, tag):
     np.testing.assert_array_equal(S.node_msg_ts.cpu().numpy()[has], z[f'{tag}_msg_ts'])
 
 
-def run_stream(name, fused):
+def run_stream(name, fused, op_path=False):
     z = load(name)
     cfg = parse_cfg(z)
     model, g, coll = build_hip_model(z, cfg)
+    if op_path:  # operator-by-operator evaluation (one C call per reference method) instead of the one-call step
+        model._fused_eval_ok = lambda: False
     B = cfg['B']
     restarting, uptodate = False, set()
     for b in range(n_batches(z)):
@@ -291,8 +293,15 @@ def run_stream(name, fused):
 
 @pytest.mark.parametrize('name', MODEL_FIXTURES)
 def test_stream_reference_api(name):
-    """GraphCollator -> TIGER.contrast_learning / restart / flush_msg, the reference's call sequence."""
+    """GraphCollator -> TIGER.contrast_learning / restart / flush_msg, the reference's call sequence
+    (evaluation takes the one-call step where the configuration allows it)."""
     run_stream(name, fused=False)
+
+
+@pytest.mark.parametrize('name', MODEL_FIXTURES)
+def test_stream_reference_api_operator_path(name):
+    """the same sequence with every reference method bound to its own C entry point"""
+    run_stream(name, fused=False, op_path=True)
 
 
 @pytest.mark.parametrize('name', MODEL_FIXTURES)

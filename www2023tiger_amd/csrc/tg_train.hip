@@ -130,11 +130,13 @@ __global__ void __launch_bounds__(256) k_score_loss(int64_t B, int d, float* __r
     loss += fmaxf(s, 0.f) - s * y + log1pf(expf(-fabsf(s)));
     const float ds = (1.f / (1.f + expf(-s)) - y) * inv;
     dbs += ds;
+    if (dw2) {
 #pragma unroll
-    for (int v = 0; v < NVS; ++v) {
-      const int c = lane + v * 64;
-      acc[v] = fmaf(ds, tv[v], acc[v]);
-      if (c < d) t[c] = tv[v] > 0.f ? ds * wv[v] : 0.f;
+      for (int v = 0; v < NVS; ++v) {
+        const int c = lane + v * 64;
+        acc[v] = fmaf(ds, tv[v], acc[v]);
+        if (c < d) t[c] = tv[v] > 0.f ? ds * wv[v] : 0.f;
+      }
     }
   }
 #pragma unroll
@@ -146,9 +148,13 @@ __global__ void __launch_bounds__(256) k_score_loss(int64_t B, int d, float* __r
   __syncthreads();
   for (int c = threadIdx.x; c < NVS * 64 + 2; c += 256) {
     const float s = red[0][c] + red[1][c] + red[2][c] + red[3][c];
-    if (c < d) atomicAdd(dw2 + c, s);
-    else if (c == NVS * 64) atomicAdd(loss_out, s * inv);
-    else if (c == NVS * 64 + 1) atomicAdd(db2, s);
+    if (c < d) {
+      if (dw2) atomicAdd(dw2 + c, s);
+    } else if (c == NVS * 64) {
+      atomicAdd(loss_out, s * inv);
+    } else if (c == NVS * 64 + 1 && db2) {
+      atomicAdd(db2, s);
+    }
   }
 }
 
@@ -633,6 +639,30 @@ static int train_supported(const tg_model* m, const tg_score_params* sp) {
   return 1;
 }
 
+// STEP 7 forward only (evaluation): scores and the BCE loss, no gradients
+static int score_forward(const tg_model* m, const tg_train_io* io, StepWs& w, TrainWs& t, hipStream_t st) {
+  const tg_score_params* sp = io->score;
+  const int64_t B = io->step.B;
+  const int d = m->d, K = m->n_neighbors;
+  const int W2 = 2 * score_width(m, sp);
+  hipError_t e = hipMemsetAsync(io->losses, 0, 2 * sizeof(float), st);
+  if (e != hipSuccess) {
+    set_hip_error(e, "tg_train_step memset");
+    return TG_EHIP;
+  }
+  hipLaunchKernelGGL(k_build_pairs, dim3(flat_grid(2 * B, 4)), dim3(256), 0, st, B, d, K, sp->hit_type, io->step.h,
+                     w.nids3, w.l1n, sp->hit_emb, t.P, t.hit_idx);
+  GemmArgs g{};
+  g.m_cap = 2 * B; g.n = d; g.k = W2; g.a0 = ASeg{t.P, W2, W2, nullptr};
+  g.w = sp->fc1.w; g.ldw = W2; g.bias = sp->fc1.b; g.c = t.T1; g.ldc = d; g.relu = 1; g.alpha = 1.f; g.nbatch = 1;
+  int rc;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  hipLaunchKernelGGL(k_score_loss, dim3(std::min<unsigned>(flat_grid(2 * B, 4), 256)), dim3(256), 0, st, B, d, t.T1,
+                     sp->fc2.w, sp->fc2.b, io->pos_scores, io->neg_scores, io->losses, (float*)nullptr, (float*)nullptr,
+                     DropCfg{});
+  return check_launch("tg_train_step(scores)");
+}
+
 // backward of the contrastive loss; everything it reads is still in the step workspace
 static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w, TrainWs& t, const DropCfg& dc,
                              hipStream_t st) {
@@ -802,11 +832,12 @@ extern "C" size_t tg_train_step_workspace_bytes(const tg_model* m, const tg_scor
 
 extern "C" int tg_train_step(const tg_model* m_in, const tg_tcsr* g, const tg_train_io* io, void* ws,
                              size_t ws_bytes, void* stream) {
-  if (!m_in) return TG_EINVAL;
+  if (!m_in || !io) return TG_EINVAL;
+  const bool eval_only = !io->grads;  // evaluation: forward + STEP 7 scores + write-back, nothing else
   tg_model m_local = *m_in;
-  m_local.attn_fused = nullptr;  // the backward pass is built on the unfused forward's intermediates
+  if (!eval_only) m_local.attn_fused = nullptr;  // the backward pass is built on the unfused forward's intermediates
   const tg_model* m = &m_local;
-  if (!m || !g || !io || !io->score || !io->grads || !io->score_grads || !io->losses) return TG_EINVAL;
+  if (!g || !io->score || (!eval_only && !io->score_grads) || !io->losses) return TG_EINVAL;
   if (!train_supported(m, io->score)) return TG_EUNSUPPORTED;
   const tg_step_io* sio = &io->step;
   if (sio->B <= 0 || !sio->src || !sio->dst || !sio->neg || !sio->ts || !sio->eids || !sio->h || !sio->err) return TG_EINVAL;
@@ -818,6 +849,12 @@ extern "C" int tg_train_step(const tg_model* m_in, const tg_tcsr* g, const tg_tr
   TrainWs t{};
   if (!carve_step(m, sio->B, cv, w) || !carve_train(m, io->score, sio->B, cv, t)) return TG_EWORKSPACE;
   int rc;
+  if (eval_only) {
+    if ((rc = step_forward(m, g, sio, w, nullptr, st, nullptr, nullptr)) != TG_OK) return rc;
+    if ((rc = score_forward(m, io, w, t, st)) != TG_OK) return rc;
+    if ((rc = step_writeback_a(m, sio, w, st, nullptr)) != TG_OK) return rc;
+    return step_writeback_b(m, sio, w, st, nullptr);
+  }
   if (io->dropout_p < 0.f || io->dropout_p >= 1.f || (io->dropout_p > 0.f && !io->rng)) return TG_EINVAL;
   const DropCfg dc = make_drop(io->dropout_p, io->rng);
   if ((rc = step_forward(m, g, sio, w, t.gates, st, nullptr, &dc)) != TG_OK) return rc;

@@ -261,7 +261,38 @@ class TIGE(nn.Module):
             losses, *rest = self._train_forward(src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph, False)
             return (losses[0], *rest)
         with torch.no_grad():
+            if getattr(computation_graph, 'ts64', None) is not None and self._fused_eval_ok():
+                return self._contrast_learning_fused_eval(src_ids, dst_ids, neg_dst_ids, eids, computation_graph)
             return self._contrast_learning_eval(src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph)
+
+    def _fused_eval_ok(self) -> bool:
+        """the one-call evaluation step covers the default model family; other configurations take the
+        operator-by-operator path below"""
+        return (self.msg_tsfm_type == 'id' and self.mem_update_type == 'gru'
+                and getattr(self.graph, 'strategy', 'recent_edges') == 'recent_edges')
+
+    def _contrast_learning_fused_eval(self, src_ids, dst_ids, neg_dst_ids, eids, computation_graph):
+        """no_grad / eval(): collate, STEP 1-7 and the write-back as ONE device call (tg_train_step without
+        gradient buffers).  The computation graph only contributes the float64 event times: the step
+        samples the same neighbourhoods itself."""
+        from .training import TrainBuffers
+        dev = self.device
+        B = len(src_ids)
+        key = ('eval', B)
+        tb = self._step_ws.get(key)
+        if tb is None:
+            tb = TrainBuffers(self, B, eval_only=True)
+            self._step_ws[key] = tb
+        to = lambda x: x.to(dev).long()
+        tb.sb.load(to(src_ids), to(dst_ids), to(neg_dst_ids), computation_graph.ts64, to(eids))
+        tb.launch()
+        word = int(tb.sb.err.item())
+        if word:
+            tb.sb.err.zero_()
+            from .._lib import raise_invariants
+            raise_invariants(word & 0xFFFFFFFF)
+        return (tb.losses[0].clone(), tb.sb.h[:2 * B].clone(), tb.pos_scores.clone(), tb.neg_scores.clone(),
+                tb.sb.h_prev_left.clone(), tb.sb.h_prev_right.clone())
 
     def _contrast_learning_eval(self, src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph):
         cg = computation_graph

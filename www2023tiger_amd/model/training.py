@@ -141,14 +141,16 @@ class TrainBuffers:
     """Static buffers of one batch size for tg_train_step: the step's inputs/outputs
     (a TIGE.StepBuffers), flat gradient storage with one view per parameter, losses, scores."""
 
-    def __init__(self, model, B: int, resident=None, mutual: bool = False):
+    def __init__(self, model, B: int, resident=None, mutual: bool = False, eval_only: bool = False):
         """mutual=True adds the restarter's mutual-learning loss (tiger.py:574-590) and its
-        gradients; False is the reference's contrast_only (restart_prob == 0)."""
+        gradients; False is the reference's contrast_only (restart_prob == 0).
+        eval_only=True: no gradient storage; the step computes embeddings, scores, loss and the
+        write-back (the forward of tiger/eval_utils.py:29-48)."""
         check_trainable(model)
         dev = model.device
-        self.model, self.B, self.mutual = model, B, mutual
+        self.model, self.B, self.mutual, self.eval_only = model, B, mutual and not eval_only, eval_only
         self.sb = model.StepBuffers(model, B, want_prev=True, resident=resident)
-        self.params = contrast_parameters(model) + (restarter_parameters(model) if mutual else [])
+        self.params = [] if eval_only else (contrast_parameters(model) + (restarter_parameters(model) if mutual else []))
         n = sum(p.numel() for _, p, _ in self.params)
         self.gflat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grads, o = {}, 0
@@ -166,8 +168,8 @@ class TrainBuffers:
         """(Re)build the C structs; call again when parameters or state tensors were re-homed."""
         model, B = self.model, self.B
         self._score = score_struct(model)
-        self._gmodel = grads_struct(model, self.grads)
-        self._gscore = score_struct(model, self.grads)
+        self._gmodel = None if self.eval_only else grads_struct(model, self.grads)
+        self._gscore = None if self.eval_only else score_struct(model, self.grads)
         m = model.model_struct()
         from .restarters import SeqRestarter
         kind, self._seq, self._gseq = 0, None, None
@@ -186,11 +188,12 @@ class TrainBuffers:
         io = TgTrainIo()
         C.memmove(C.addressof(io.step), C.addressof(self.sb.io), C.sizeof(TgStepIo))
         io.score = C.addressof(self._score)
-        io.grads = C.addressof(self._gmodel)
-        io.score_grads = C.addressof(self._gscore)
+        if not self.eval_only:
+            io.grads = C.addressof(self._gmodel)
+            io.score_grads = C.addressof(self._gscore)
         io.losses, io.pos_scores, io.neg_scores = ptr(self.losses), ptr(self.pos_scores), ptr(self.neg_scores)
         io.flags = ptr(self.flags)
-        io.dropout_p = dropout_p(model)
+        io.dropout_p = 0.0 if self.eval_only else dropout_p(model)
         io.rng = ptr(self.rng)
         io.restarter = kind
         if kind == 1:
@@ -205,7 +208,7 @@ class TrainBuffers:
     def launch(self, zero_grads: bool = True):
         """Enqueue forward + STEP 7 + backward + write-back for the batch in `sb` (no host sync)."""
         model = self.model
-        if zero_grads:
+        if zero_grads and not self.eval_only:
             self.gflat.zero_()
         m = model.model_struct()
         g = model.graph.tcsr
