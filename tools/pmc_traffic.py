@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""HBM/fabric traffic per kernel launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE).
+
+  # on the GPU box (separate passes, counters only - never combined with trace domains):
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -o f -- python bench.py --steps 10 --warmup 25 --no-cpu-baseline --no-graph
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -o w -- python bench.py --steps 10 --warmup 25 --no-cpu-baseline --no-graph
+  # anywhere:
+  tools/pmc_traffic.py gpurun_out/pmc_f/f_counter_collection.csv gpurun_out/pmc_w/w_counter_collection.csv out.json
+
+bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024  (gfx950: FETCH_SIZE counts half of a wide coalesced
+read, MI355X_MICROARCH.md HBM section); averages over the LAST `n` launches of each kernel."""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def per_kernel(path, last=10):
+    rows = collections.defaultdict(list)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            name = re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '')
+            rows[name].append(float(r['Counter_Value']))
+    return {k: sum(v[-last:]) / len(v[-last:]) for k, v in rows.items()}
+
+
+def main():
+    fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
+    out = {'method': __doc__.split('\n\n')[2].strip().replace('\n', ' '), 'kernels': {}}
+    for k in sorted(set(fetch) | set(write)):
+        if not k.startswith('tg::'):
+            continue
+        f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+        out['kernels'][k] = {'FETCH_SIZE_KB': round(f, 1), 'WRITE_SIZE_KB': round(w, 1),
+                             'bytes_per_launch': int(2 * f * 1024 + w * 1024)}
+    json.dump(out, open(sys.argv[3], 'w'), indent=1)
+    for k, v in out['kernels'].items():
+        print('%-50s %12d B/launch' % (k, v['bytes_per_launch']))
+
+
+if __name__ == '__main__':
+    main()
