@@ -96,6 +96,16 @@ struct TnArgs {
   int brs_col;           // column of bias_rs used by batch 0 (batch b uses brs_col + b)
 };
 int gemm_tn_launch(const TnArgs& a, hipStream_t st);
+// up to TN_GROUP_MAX independent products in one launch + one reduction launch; `part` is carved per problem
+constexpr int TN_GROUP_MAX = 12;
+struct TnGroup {
+  int n;
+  int first_block[TN_GROUP_MAX + 1];
+  int first_rblock[TN_GROUP_MAX + 1];
+  int splits[TN_GROUP_MAX];
+  TnArgs a[TN_GROUP_MAX];
+};
+int gemm_tn_group_launch(const TnArgs* list, int n, float* part, size_t part_floats, hipStream_t st);
 // out[n] (+)= alpha * sum_m Y[m, n]
 int colsum_launch(int64_t m_cap, const int32_t* m_dev, int n, const float* y, int64_t ldy, float alpha, float* out,
                   int accumulate, float* part, size_t part_floats, hipStream_t st);

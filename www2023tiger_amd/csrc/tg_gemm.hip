@@ -504,12 +504,11 @@ constexpr int TN_T = 64;        // output tile (n and k extent)
 constexpr int TN_MC = 32;       // m rows per staged chunk
 constexpr int TN_LD = TN_T + 32;  // row stride: the two half-waves (rows m, m+1) hit disjoint banks
 
-__global__ void __launch_bounds__(256) k_gemm_tn(TnArgs a, int splits) {
+__device__ __forceinline__ void tn_block(const TnArgs& a, int splits, int b) {
   __shared__ float Ys[2][TN_MC][TN_LD];
   __shared__ float Xs[2][TN_MC][TN_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NT = (a.n + TN_T - 1) / TN_T, KT = (a.k + TN_T - 1) / TN_T;
-  int b = blockIdx.x;
   const int kt = b % KT; b /= KT;
   const int nt = b % NT; b /= NT;
   const int bz = b % a.nbatch;
@@ -600,9 +599,12 @@ __global__ void __launch_bounds__(256) k_gemm_tn(TnArgs a, int splits) {
   }
 }
 
-__global__ void k_tn_reduce(TnArgs a, int splits) {
+__global__ void __launch_bounds__(256) k_gemm_tn(TnArgs a, int splits) { tn_block(a, splits, (int)blockIdx.x); }
+
+// fixed-order reduction of the split partials of one problem; threads [start, start + stride, ...)
+__device__ __forceinline__ void tn_reduce_part(const TnArgs& a, int splits, int64_t start, int64_t stride) {
   const int64_t per = (int64_t)a.n * a.k, total = per * a.nbatch;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t t = start; t < total; t += stride) {
     const int bz = (int)(t / per);
     const int64_t e = t - (int64_t)bz * per;
     float s = 0.f;
@@ -613,7 +615,7 @@ __global__ void k_tn_reduce(TnArgs a, int splits) {
   if (a.bias_out) {
     const float* bp = a.part + (int64_t)splits * a.nbatch * per;
     const int64_t tb = (int64_t)a.n * a.nbatch;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < tb; t += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t t = start; t < tb; t += stride) {
       const int bz = (int)(t / a.n);
       const int n = (int)(t - (int64_t)bz * a.n);
       float s = 0.f;
@@ -622,6 +624,24 @@ __global__ void k_tn_reduce(TnArgs a, int splits) {
       *o = a.alpha * s + (a.bias_accumulate ? *o : 0.f);
     }
   }
+}
+__global__ void k_tn_reduce(TnArgs a, int splits) {
+  tn_reduce_part(a, splits, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+}
+
+// several weight-gradient products in ONE launch (and one reduction launch): the nine products of
+// the contrastive backward pass are each too small to fill the chip and independent of one another
+__global__ void __launch_bounds__(256) k_gemm_tn_group(TnGroup g) {
+  int p = 0;
+  while (p + 1 < g.n && (int)blockIdx.x >= g.first_block[p + 1]) ++p;
+  tn_block(g.a[p], g.splits[p], (int)blockIdx.x - g.first_block[p]);
+}
+__global__ void k_tn_reduce_group(TnGroup g) {
+  int p = 0;
+  while (p + 1 < g.n && (int)blockIdx.x >= g.first_rblock[p + 1]) ++p;
+  const int nb = g.first_rblock[p + 1] - g.first_rblock[p];
+  tn_reduce_part(g.a[p], g.splits[p], (int64_t)((int)blockIdx.x - g.first_rblock[p]) * blockDim.x + threadIdx.x,
+                 (int64_t)nb * blockDim.x);
 }
 
 int gemm_tn_launch(const TnArgs& a, hipStream_t st) {
@@ -638,6 +658,41 @@ int gemm_tn_launch(const TnArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_gemm_tn, dim3((unsigned)(tiles * splits)), dim3(256), 0, st, a, (int)splits);
   hipLaunchKernelGGL(k_tn_reduce, dim3(flat_grid((int64_t)a.n * a.k * a.nbatch, 256)), dim3(256), 0, st, a, (int)splits);
   return check_launch("gemm_tn");
+}
+
+int gemm_tn_group_launch(const TnArgs* list, int n, float* part, size_t part_floats, hipStream_t st) {
+  if (n <= 0) return TG_OK;
+  if (n > TN_GROUP_MAX) return TG_EINVAL;
+  TnGroup g{};
+  g.n = n;
+  int64_t tiles_total = 0;
+  for (int p = 0; p < n; ++p) {
+    const TnArgs& a = list[p];
+    if (a.m_cap <= 0 || a.n <= 0 || a.k <= 0 || (a.n % 4) || (a.k % 4) || (a.x0.w % 4) || (a.ldy % 4) || a.nbatch <= 0)
+      return TG_EINVAL;
+    if (a.x0.w + (a.x1.p ? a.x1.w : 0) != a.k) return TG_EINVAL;
+    tiles_total += cdiv(a.n, TN_T) * cdiv(a.k, TN_T) * a.nbatch;
+  }
+  // splits: aim at ~1500 blocks in total, at least two staged chunks per block
+  const int64_t want = std::max<int64_t>(1, std::min<int64_t>(16, cdiv(1536, tiles_total)));
+  size_t off = 0;
+  for (int p = 0; p < n; ++p) {
+    g.a[p] = list[p];
+    TnArgs& a = g.a[p];
+    const int64_t tiles = cdiv(a.n, TN_T) * cdiv(a.k, TN_T) * a.nbatch;
+    const int64_t sp = std::max<int64_t>(1, std::min<int64_t>(want, cdiv(a.m_cap, 2 * TN_MC)));
+    const size_t need = (size_t)sp * a.nbatch * a.n * (a.k + 1);
+    if (off + need > part_floats) return TG_EWORKSPACE;
+    a.part = part + off;
+    a.part_floats = need;
+    off += (need + 3) & ~(size_t)3;
+    g.splits[p] = (int)sp;
+    g.first_block[p + 1] = g.first_block[p] + (int)(tiles * sp);
+    g.first_rblock[p + 1] = g.first_rblock[p] + (int)std::min<int64_t>(cdiv((int64_t)a.n * a.k * a.nbatch, 256), 256);
+  }
+  hipLaunchKernelGGL(k_gemm_tn_group, dim3((unsigned)g.first_block[n]), dim3(256), 0, st, g);
+  hipLaunchKernelGGL(k_tn_reduce_group, dim3((unsigned)g.first_rblock[n]), dim3(256), 0, st, g);
+  return check_launch("gemm_tn_group");
 }
 
 // column sums: one block per (64 columns, split of m); partials then a fixed-order reduce

@@ -11,6 +11,7 @@
 // and one gather kernel recomputes the K scores per centre, back-propagates the softmax and
 // scatters the key-row gradients to the involved-node rows.
 #include <algorithm>
+#include <vector>
 
 #include "tg_step.h"
 
@@ -580,15 +581,18 @@ struct TrainWs {
   int64_t rows_cap;
 };
 
+
 static int score_width(const tg_model* m, const tg_score_params* sp) {
   return m->d + (sp->hit_type == TG_HIT_VEC ? m->n_neighbors : 0);
 }
 
 static size_t part_floats_for(const tg_model* m, const tg_score_params* sp) {
-  // largest [N, K] weight-gradient times the maximum split count the launcher may pick (1024 blocks
-  // of 64x64 tiles => at most 1024 * 4096 floats plus tile padding)
-  (void)m; (void)sp;
-  return (size_t)1280 * 4096;
+  // split partials of the grouped weight-gradient launch: at most 16 splits of every [N, K + 1] product
+  // of the contrastive backward pass (also ample for the single launches of the restarter's backward)
+  const size_t d = m->d, E = 2 * d, kvw = 2 * d + m->d_e, mw = 3 * d + m->d_e, W2 = 2 * (size_t)score_width(m, sp);
+  const size_t total = d * (W2 + 1) + d * (d + 1) + d * (E + d + 1) + E * (E + 1) + 2 * E * (kvw + 1) + E * (d + 1) +
+                       3 * d * (mw + 1) + 3 * d * (d + 1);
+  return std::max<size_t>(16 * total + 64, (size_t)1280 * 4096);
 }
 
 static bool carve_train(const tg_model* m, const tg_score_params* sp, int64_t B, Carver& cv, TrainWs& w) {
@@ -675,6 +679,7 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
   const int mw = 3 * d + d_e;
   const float alpha = 1.0f / sqrtf((float)dh);
   int rc;
+  std::vector<TnArgs> tns;  // weight-gradient products, launched together at the end
   hipError_t e = hipMemsetAsync(t.dreprs, 0, (size_t)t.rows_cap * d * sizeof(float), st);
   if (e == hipSuccess) e = hipMemsetAsync(io->losses, 0, 2 * sizeof(float), st);
   if (e != hipSuccess) {
@@ -698,7 +703,7 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
   tn.m_cap = 2 * B; tn.n = d; tn.k = W2; tn.y = t.T1; tn.ldy = d; tn.x0 = ASeg{t.P, W2, W2, nullptr};
   tn.out = F(gs->fc1.w); tn.ldo = W2; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = 1; tn.part = t.part;
   tn.part_floats = t.part_floats; tn.bias_out = F(gs->fc1.b); tn.bias_accumulate = 1;
-  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  tns.push_back(tn);
   g = GemmArgs{};
   g.m_cap = 2 * B; g.n = W2; g.k = d; g.a0 = ASeg{t.T1, d, d, nullptr};
   g.w = sp->fc1.w; g.ldw = W2; g.w_kmajor = 1; g.c = t.dP; g.ldc = W2; g.alpha = 1.f; g.nbatch = 1;
@@ -714,7 +719,7 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
   tn.m_cap = Q; tn.n = d; tn.k = d; tn.y = t.dH; tn.ldy = d; tn.x0 = ASeg{a.t, d, d, nullptr};
   tn.out = F(gm->attn_fc2.w); tn.ldo = d; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = 1; tn.part = t.part;
   tn.part_floats = t.part_floats; tn.bias_out = F(gm->attn_fc2.b); tn.bias_accumulate = 1;
-  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  tns.push_back(tn);
   g = GemmArgs{};
   g.m_cap = Q; g.n = d; g.k = d; g.a0 = ASeg{t.dH, d, d, nullptr};
   g.w = m->attn_fc2.w; g.ldw = d; g.w_kmajor = 1; g.c = t.dT; g.ldc = d; g.alpha = 1.f; g.nbatch = 1;
@@ -725,7 +730,7 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
   tn.x0 = ASeg{a.hh, E, E, nullptr}; tn.x1 = ASeg{a.cc, d, d, nullptr};
   tn.out = F(gm->attn_fc1.w); tn.ldo = E + d; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = 1; tn.part = t.part;
   tn.part_floats = t.part_floats; tn.bias_out = F(gm->attn_fc1.b); tn.bias_accumulate = 1;
-  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  tns.push_back(tn);
   // d hh (zero for centres without neighbours: their hh was masked) and the direct part of d cc
   g = GemmArgs{};
   g.m_cap = Q; g.n = E; g.k = d; g.a0 = ASeg{t.dT, d, d, nullptr};
@@ -741,7 +746,7 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
   tn.m_cap = Q; tn.n = E; tn.k = E; tn.y = t.dhh; tn.ldy = E; tn.x0 = ASeg{a.o, E, E, nullptr};
   tn.out = F(gm->attn_out.w); tn.ldo = E; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = 1; tn.part = t.part;
   tn.part_floats = t.part_floats; tn.bias_out = F(gm->attn_out.b); tn.bias_accumulate = 1;
-  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  tns.push_back(tn);
   g = GemmArgs{};
   g.m_cap = Q; g.n = E; g.k = E; g.a0 = ASeg{t.dhh, E, E, nullptr};
   g.w = m->attn_out.w; g.ldw = E; g.w_kmajor = 1; g.c = t.dO; g.ldc = E; g.alpha = 1.f; g.nbatch = 1;
@@ -754,7 +759,7 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
   tn.part = t.part; tn.part_floats = t.part_floats;
   tn.bias_out = F(gm->attn_b_in) + 2 * E; tn.bias_accumulate = 1; tn.bias_bs = dh;
   if (dc.p > 0.f) { tn.bias_rs = a.rsum; tn.ld_brs = nh; tn.brs_col = 0; }  // d bv_h = sum_i r_ih dO_ih
-  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  tns.push_back(tn);
   g = GemmArgs{};
   g.m_cap = Q; g.n = kvw; g.k = dh; g.a0 = ASeg{t.dO, E, dh, nullptr}; g.a0_bs = dh;
   g.w = m->attn_wv; g.ldw = kvw; g.w_kmajor = 1; g.w_bs = (int64_t)dh * kvw;
@@ -781,7 +786,7 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
   tn.x0 = ASeg{t.dG, (int64_t)nh * kvw, kvw, nullptr}; tn.x0_bs = kvw;
   tn.out = F(gm->attn_wk); tn.ldo = kvw; tn.out_bs = (int64_t)dh * kvw; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = nh;
   tn.part = t.part; tn.part_floats = t.part_floats;
-  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  tns.push_back(tn);
   g = GemmArgs{};
   g.m_cap = Q; g.n = dh; g.k = kvw; g.a0 = ASeg{t.dG, (int64_t)nh * kvw, kvw, nullptr}; g.a0_bs = kvw;
   g.w = m->attn_wk; g.ldw = kvw; g.w_bs = (int64_t)dh * kvw;
@@ -792,9 +797,7 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
   tn.m_cap = Q; tn.n = E; tn.k = d; tn.y = t.dqp; tn.ldy = E; tn.x0 = ASeg{a.cc, d, d, nullptr};
   tn.out = F(gm->attn_wq); tn.ldo = E; tn.alpha = alpha; tn.accumulate = 1; tn.nbatch = 1; tn.part = t.part;
   tn.part_floats = t.part_floats; tn.bias_out = t.dqconst; tn.bias_accumulate = 0;
-  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
-  hipLaunchKernelGGL(k_qconst_bwd, dim3((unsigned)cdiv(d, 64), 16), dim3(256), 0, st, d, t.dqconst, m->attn_wq, m->te_freq,
-                     m->te_phase, F(gm->attn_wq), F(gm->attn_b_in), F(gm->te_phase));
+  tns.push_back(tn);
   g = GemmArgs{};
   g.m_cap = Q; g.n = d; g.k = E; g.a0 = ASeg{t.dqp, E, E, nullptr};
   g.w = m->attn_wq; g.ldw = E; g.w_kmajor = 1; g.c = t.dcc; g.ldc = d; g.alpha = alpha; g.nbatch = 1; g.accumulate = 1;
@@ -810,10 +813,13 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
   tn.x0 = ASeg{m->msg_vals, mw, mw, w.outdated};
   tn.out = F(gm->gru_w_ih); tn.ldo = mw; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = 1; tn.part = t.part;
   tn.part_floats = t.part_floats; tn.bias_out = F(gm->gru_b_ih); tn.bias_accumulate = 1;
-  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  tns.push_back(tn);
   tn.k = d; tn.y = t.dgh; tn.x0 = ASeg{upd_vals, d, d, w.outdated}; tn.out = F(gm->gru_w_hh); tn.ldo = d;
   tn.bias_out = F(gm->gru_b_hh);
-  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  tns.push_back(tn);
+  if ((rc = gemm_tn_group_launch(tns.data(), (int)tns.size(), t.part, t.part_floats, st)) != TG_OK) return rc;
+  hipLaunchKernelGGL(k_qconst_bwd, dim3((unsigned)cdiv(d, 64), 16), dim3(256), 0, st, d, t.dqconst, m->attn_wq, m->te_freq,
+                     m->te_phase, F(gm->attn_wq), F(gm->attn_b_in), F(gm->te_phase));
   return check_launch("tg_train_step(backward)");
 }
 
