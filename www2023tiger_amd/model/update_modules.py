@@ -1,35 +1,31 @@
-"""Mirror of tiger/model/update_modules.py.  The modules are parameter containers with
-the reference's names/initialisers; inside the engine they run as tg_apply_messages
-(fused f32-MFMA GRU, csrc/tg_gemm.hip).  `forward` is the standalone dense form."""
-import torch
+"""Memory updaters (reference: tiger/model/update_modules.py).  Parameter containers only: the
+attribute names (`cell`, `fn`) are what the reference's state_dict uses; inside the engine
+the update runs as tg_apply_messages (fused float32-MFMA GRU, csrc/tg_gemm.hip).  Calling a
+module directly runs the same kernels on dense rows."""
 from torch import Tensor, nn
 
+from . import dense
 from .basic_modules import MergeLayer
 
 
-class UpdateModule(nn.Module):
-    def __init__(self, msg_dim, memory_dim):
+class GRUUpdater(nn.Module):
+    """h(t'+) = GRUCell(message, memory)   (update_modules.py:30-37)"""
+
+    def __init__(self, msg_dim: int, memory_dim: int):
         super().__init__()
-        self.msg_dim = msg_dim
-        self.memory_dim = memory_dim
-
-    def forward(self, mem: Tensor, msg: Tensor, delta_ts: Tensor) -> Tensor:
-        raise NotImplementedError
-
-
-class GRUUpdater(UpdateModule):
-    def __init__(self, msg_dim, memory_dim):
-        super().__init__(msg_dim, memory_dim)
-        self.cell = nn.GRUCell(input_size=self.msg_dim, hidden_size=self.memory_dim)
+        self.msg_dim, self.memory_dim = msg_dim, memory_dim
+        self.cell = nn.GRUCell(msg_dim, memory_dim)
 
     def forward(self, mem: Tensor, msg: Tensor, delta_ts: Tensor = None) -> Tensor:
-        from .dense import gru_forward
-        return gru_forward(self.cell, msg, mem)
+        return dense.gru_forward(self.cell, msg, mem)
 
 
-class MergeUpdater(UpdateModule):
-    def __init__(self, msg_dim, memory_dim):
-        super().__init__(msg_dim, memory_dim)
+class MergeUpdater(nn.Module):
+    """h(t'+) = MergeLayer(message, memory)   (update_modules.py:40-47)"""
+
+    def __init__(self, msg_dim: int, memory_dim: int):
+        super().__init__()
+        self.msg_dim, self.memory_dim = msg_dim, memory_dim
         self.fn = MergeLayer(msg_dim, memory_dim, memory_dim, memory_dim)
 
     def forward(self, mem: Tensor, msg: Tensor, delta_ts: Tensor = None) -> Tensor:
