@@ -316,3 +316,69 @@ def test_reference_ddp_recipe_two_ranks(tmp_path):
     assert int(r0['first']) != int(r1['first'])                    # different time chunks
     assert not np.allclose(r0['losses'], r1['losses'])               # ... hence different losses
     np.testing.assert_array_equal(r0['params'], r1['params'])        # gradients were all-reduced: replicas agree
+
+
+def _fused_ddp_worker(rank, world, port, n_steps, out_dir):
+    """FusedTrainer with one all-reduce of the flat gradient buffer per iteration: every rank trains its own
+    time chunk (ChunkSampler ranges), replicas stay identical; rank 0 also dumps its per-step gradients."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    tdist.init_process_group('gloo', rank=rank, world_size=world)
+    from test_hip_parity import build_hip_model
+    from www2023tiger_amd.model.training import FusedTrainer
+    z = load('train_seq_lr_d8')
+    cfg = parse_cfg(z)
+    model, _, _ = build_hip_model(z, cfg, dropout=0.0)
+    model.train()
+    tr = FusedTrainer(model, cfg['B'], lr=cfg['lr'], mutual=True, world_size=world)
+    B = cfg['B']
+    per = (len(z['src']) // (world * B)) * B
+    lo = rank * per  # this rank's time chunk
+    for s in range(n_steps):
+        sl = slice(lo + s * B, lo + (s + 1) * B)
+        tr.step(*(z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')))
+    flat = torch.cat([p.detach().flatten() for p in model.parameters()]).cpu().numpy()
+    np.savez(os.path.join(out_dir, f'fddp{rank}.npz'), params=flat, losses=tr.buf.losses.cpu().numpy())
+    tdist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_fused_trainer_data_parallel_two_ranks(tmp_path):
+    world, n_steps = 2, 4
+    mp.spawn(_fused_ddp_worker, args=(world, free_port(), n_steps, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (np.load(os.path.join(str(tmp_path), f'fddp{r}.npz')) for r in range(world))
+    np.testing.assert_array_equal(r0['params'], r1['params'])  # same averaged gradients, same Adam state
+    assert not np.allclose(r0['losses'], r1['losses'])           # different chunks
+    # against a single process that averages the two chunks' gradients itself
+    from test_hip_parity import build_hip_model
+    from www2023tiger_amd.model.training import FusedTrainer, TrainBuffers
+    z = load('train_seq_lr_d8')
+    cfg = parse_cfg(z)
+    B = cfg['B']
+    per = (len(z['src']) // (world * B)) * B
+    ma, _, _ = build_hip_model(z, cfg, dropout=0.0)
+    mb, _, _ = build_hip_model(z, cfg, dropout=0.0)
+    ma.train(); mb.train()
+    ta = FusedTrainer(ma, B, lr=cfg['lr'], mutual=True)
+    tb = TrainBuffers(mb, B, mutual=True)
+    to = lambda x, dt: torch.as_tensor(x).to('cuda:0', dt)
+    for s in range(n_steps):
+        with torch.no_grad():  # model b follows model a's parameters; only its memories are its own
+            for pa, pb in zip(ma.parameters(), mb.parameters()):
+                pb.copy_(pa)
+        a = [z[k][s * B:(s + 1) * B] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        b = [z[k][per + s * B:per + (s + 1) * B] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        tb.sb.load(to(b[0], torch.int64), to(b[1], torch.int64), to(b[2], torch.int64), to(b[3], torch.float64),
+                   to(b[4], torch.int64))
+        tb.launch()
+        ta.load(*a)
+        ta.buf.launch()
+        ta.buf.gflat.add_(tb.gflat).mul_(0.5)
+        ta.buf.flags.copy_(torch.maximum(ta.buf.flags, tb.flags))
+        from www2023tiger_amd._lib import check, lib, ptr
+        from www2023tiger_amd.hip_ops import stream_ptr
+        check(lib.tg_adam_step(ptr(ta.segs), ta.n_segs, 4, ptr(ta.buf.flags), ptr(ta.steps), ta.lr, 0.9, 0.999, 1e-8,
+                               1.0, stream_ptr(ma.device)), 'adam')
+    ref = torch.cat([p.detach().flatten() for p in ma.parameters()]).cpu().numpy()
+    assert rel_err(r0['params'], ref) < 1e-5

@@ -244,9 +244,14 @@ class FusedTrainer:
     tg_adam_step over flat parameter-gradient / moment buffers."""
 
     def __init__(self, model, B: int, *, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, resident=None,
-                 mutual: bool = False, mutual_coef: float = 1.0):
+                 mutual: bool = False, mutual_coef: float = 1.0, process_group=None, world_size: int = 1):
+        """process_group / world_size > 1: the reference's data-parallel recipe
+        (train_self_supervised_ddp.py:145-146: every rank trains its own time chunk, gradients are
+        averaged, lr is scaled by the caller).  All gradients live in ONE flat buffer, so the
+        synchronisation is a single all-reduce over RCCL between the backward pass and Adam."""
         self.model, self.lr, self.betas, self.eps = model, lr, betas, eps
         self.mutual_coef = mutual_coef
+        self.process_group, self.world_size = process_group, world_size
         self.buf = TrainBuffers(model, B, resident=resident, mutual=mutual)
         dev = model.device
         n = self.buf.gflat.numel()
@@ -272,8 +277,16 @@ class FusedTrainer:
 
     def launch(self):
         self.buf.launch()
+        gscale = 1.0
+        if self.world_size > 1:
+            import torch.distributed as dist
+            # a group is "live" if it produced a gradient on ANY rank (DDP semantics: an all-reduced
+            # gradient is never None), so the flags are max-reduced together with the gradient sum
+            dist.all_reduce(self.buf.gflat, group=self.process_group)
+            dist.all_reduce(self.buf.flags, op=dist.ReduceOp.MAX, group=self.process_group)
+            gscale = 1.0 / self.world_size
         check(lib.tg_adam_step(ptr(self.segs), self.n_segs, 4, ptr(self.buf.flags), ptr(self.steps), self.lr,
-                               self.betas[0], self.betas[1], self.eps, 1.0, stream_ptr(self.model.device)),
+                               self.betas[0], self.betas[1], self.eps, gscale, stream_ptr(self.model.device)),
               'tg_adam_step')
 
     def step(self, src, dst, neg, ts, eids):
