@@ -77,6 +77,14 @@ int tg_tcsr_build_host(int64_t num_events, const int64_t* src_host, const int64_
                        int64_t* indptr_host, double* ts_out_host, int32_t* nbr_out_host,
                        int32_t* eid_out_host);
 
+/* The same build on device for a TIME-ORDERED stream (ts non-decreasing - the caller checks; every
+ * JODIE file is): a stable radix sort of the 2E (owner, entry) pairs on the owner id.  All pointers
+ * are DEVICE pointers; ids must lie in [0, num_node), eids in [0, 2^31), 2E < 2^32. */
+size_t tg_tcsr_build_device_workspace_bytes(int64_t num_events, int64_t num_node);
+int tg_tcsr_build_device(int64_t num_events, const int64_t* src, const int64_t* dst, const double* ts,
+                         const int64_t* eid, int64_t num_node, int64_t* indptr, double* ts_out,
+                         int32_t* nbr_out, int32_t* eid_out, void* ws, size_t ws_bytes, void* stream);
+
 /* Graph.sample_temporal_neighbor(strategy='recent_edges') and Graph.get_history
  * (graph.py:67-127,150-155): per query the last K entries with ts < t (strict),
  * left padded with zeros.  out_dir may be NULL.  If mark_flags != NULL every query

@@ -74,8 +74,15 @@ def test_tcsr_host_build_matches_oracle():
 def test_tcsr_build_rejects_bad_ids():
     from www2023tiger_amd import _lib
     from www2023tiger_amd.data.graph import Graph
-    with pytest.raises(_lib.TigerHipError):
+    with pytest.raises(ValueError):  # checked before either builder runs
         Graph.from_arrays(np.array([1, 2]), np.array([3, 4]), np.array([0.0, 1.0]), np.array([1, 2 ** 31]))
+    with pytest.raises(ValueError):
+        Graph.from_arrays(np.array([1, 9]), np.array([3, 4]), np.array([0.0, 1.0]), np.array([1, 2]), max_node_id=5)
+    # the C entry point itself refuses them too
+    bad = [np.array([1, 2]), np.array([3, 4]), np.array([0.0, 1.0]), np.array([1, 2 ** 31])]
+    out = [np.empty(6, dtype=np.int64), np.empty(4), np.empty(4, dtype=np.int32), np.empty(4, dtype=np.int32)]
+    rc = _lib.lib.tg_tcsr_build_host(2, *(_lib.ptr(a) for a in bad), 5, *(_lib.ptr(a) for a in out))
+    assert rc == _lib.TG_EINVAL
 
 
 def test_struct_layouts_match_the_header(tmp_path):

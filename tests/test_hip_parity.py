@@ -498,3 +498,37 @@ def test_fused_attention_weights_match_reference(name):
     assert rel_err(model.right_memory.vals.cpu().numpy(), plain.right_memory.vals.cpu().numpy()) < 2e-5
     model.fuse_attention(False)
     assert not model.model_struct().attn_fused
+
+
+@pytest.mark.parametrize('case', ['sampler_fixture', 'zipf_300k', 'tiny', 'one_node_heavy'])
+def test_device_tcsr_build_equals_host_build(case):
+    """tg_tcsr_build_device (stable radix sort on the owner id) against tg_tcsr_build_host: identical
+    indptr / ts / nbr / eid+flag arrays, including self loops, id gaps and a node owning most entries."""
+    from www2023tiger_amd.data.graph import Graph
+    rs = np.random.RandomState(7)
+    if case == 'sampler_fixture':
+        z = load('sampler')
+        src, dst, ts, eids = z['src'], z['dst'], z['ts'], z['eids']
+    elif case == 'zipf_300k':
+        import bench
+        st = bench.make_stream(200000, 5000, 300000, 1.0e6, seed=2, d_e=4, with_efeats=False)
+        src, dst, ts, eids = st['src'], st['dst'], st['ts'], st['eids']
+    elif case == 'tiny':
+        src, dst = np.array([3, 3, 1]), np.array([3, 2, 3])
+        ts, eids = np.array([1.0, 1.0, 2.0]), np.array([1, 2, 3])
+    else:
+        E = 50000
+        src = np.where(rs.uniform(size=E) < 0.9, 7, rs.randint(1, 4000, E))
+        dst = rs.randint(1, 70000, E)
+        ts, eids = np.sort(rs.uniform(0, 1e5, E)), np.arange(1, E + 1)
+    g = Graph.from_arrays(src, dst, ts, eids, strategy='recent_edges', seed=0, device=dev())
+    assert g._time_ordered
+    got = [t.cpu().numpy() for t in g._tensors()]          # built on the GPU
+    want = g._host_tcsr()                                   # built by the host routine
+    for a, b, nm in zip(got, want, ('indptr', 'ts', 'nbr', 'eid')):
+        np.testing.assert_array_equal(a, b, err_msg=nm)
+    # an unsorted stream falls back to the host builder (per-node stable sort by time)
+    perm = rs.permutation(len(src))
+    g2 = Graph.from_arrays(src[perm], dst[perm], ts[perm], eids[perm], strategy='recent_edges', seed=0, device=dev())
+    assert not g2._time_ordered or len(src) < 2
+    g2._tensors()

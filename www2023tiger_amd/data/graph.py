@@ -41,11 +41,9 @@ class Graph:
         if len(eid) and (eid.min() < 0 or eid.max() > 0x7FFFFFFF):
             raise ValueError('edge ids must fit in 31 bits')
         self._init_common(len(adj_list), strategy, seed, alpha, device)
-        self._h_indptr = np.concatenate([[0], np.cumsum(np.bincount(owner, minlength=self.num_node))]).astype(np.int64)
-        self._h_ts = ts[order]
-        self._h_nbr = np.asarray(nbr, dtype=np.int64)[order].astype(np.int32)
         packed = eid[order].astype(np.uint32) | (np.asarray(flag, dtype=np.uint32)[order] << np.uint32(31))
-        self._h_eid = packed.view(np.int32)
+        self._host = (np.concatenate([[0], np.cumsum(np.bincount(owner, minlength=self.num_node))]).astype(np.int64),
+                      ts[order], np.asarray(nbr, dtype=np.int64)[order].astype(np.int32), packed.view(np.int32))
 
     def _init_common(self, num_node, strategy, seed, alpha, device):
         self.num_node = int(num_node)
@@ -54,8 +52,11 @@ class Graph:
         self.alpha = alpha
         self.rng = np.random.RandomState(seed)  # graph.py:22; its state seeds the device MT19937
         self._device = torch.device(device) if device is not None else None
-        self._dev = None  # device tensors, uploaded lazily
+        self._dev = None  # device tensors, built / uploaded lazily
         self._mt = None
+        self._events = None  # (src, dst, ts, eids) of from_arrays, the input of either builder
+        self._host = None    # host T-CSR arrays (indptr, ts, nbr, eid), built on demand
+        self._time_ordered = False
 
     @classmethod
     def from_arrays(cls, src, dst, ts, eids, strategy='recent_nodes', seed=None, max_node_id=None, device=None):
@@ -68,13 +69,44 @@ class Graph:
         self = cls.__new__(cls)
         self._init_common(max_node_id + 1, strategy, seed, 0.0, device)
         E = len(src)
-        self._h_indptr = np.empty(self.num_node + 1, dtype=np.int64)
-        self._h_ts = np.empty(2 * E, dtype=np.float64)
-        self._h_nbr = np.empty(2 * E, dtype=np.int32)
-        self._h_eid = np.empty(2 * E, dtype=np.int32)
-        check(lib.tg_tcsr_build_host(E, ptr(src), ptr(dst), ptr(ts), ptr(eids), self.num_node, ptr(self._h_indptr),
-                                     ptr(self._h_ts), ptr(self._h_nbr), ptr(self._h_eid)), 'tg_tcsr_build_host')
+        if E and (min(src.min(), dst.min()) < 0 or max(src.max(), dst.max()) >= self.num_node):
+            raise ValueError('node ids must lie in [0, num_node)')
+        if E and (eids.min() < 0 or eids.max() > 0x7FFFFFFF):
+            raise ValueError('edge ids must fit in 31 bits')
+        self._events = (src, dst, ts, eids)
+        # a time-ordered stream (every JODIE file) is built on the GPU; others take the host builder,
+        # which also performs the reference's stable per-node sort by time (graph.py:32)
+        self._time_ordered = bool(E < 2 or np.all(ts[1:] >= ts[:-1])) and 2 * E < 2 ** 32
         return self
+
+    def _host_tcsr(self):
+        if self._host is None:
+            src, dst, ts, eids = self._events
+            E = len(src)
+            h = (np.empty(self.num_node + 1, dtype=np.int64), np.empty(2 * E, dtype=np.float64),
+                 np.empty(2 * E, dtype=np.int32), np.empty(2 * E, dtype=np.int32))
+            check(lib.tg_tcsr_build_host(E, ptr(src), ptr(dst), ptr(ts), ptr(eids), self.num_node, *(ptr(a) for a in h)),
+                  'tg_tcsr_build_host')
+            self._host = h
+        return self._host
+
+    _h_indptr = property(lambda self: self._host_tcsr()[0])
+    _h_ts = property(lambda self: self._host_tcsr()[1])
+    _h_nbr = property(lambda self: self._host_tcsr()[2])
+    _h_eid = property(lambda self: self._host_tcsr()[3])
+
+    def _build_on_device(self, dev):
+        src, dst, ts, eids = (torch.from_numpy(a).to(dev) for a in self._events)
+        E = src.numel()
+        out = (torch.empty(self.num_node + 1, dtype=torch.int64, device=dev),
+               torch.empty(2 * E, dtype=torch.float64, device=dev), torch.empty(2 * E, dtype=torch.int32, device=dev),
+               torch.empty(2 * E, dtype=torch.int32, device=dev))
+        nbytes = int(lib.tg_tcsr_build_device_workspace_bytes(E, self.num_node))
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        check(lib.tg_tcsr_build_device(E, ptr(src), ptr(dst), ptr(ts), ptr(eids), self.num_node, *(ptr(t) for t in out),
+                                       ptr(ws), nbytes, stream_ptr(dev)), 'tg_tcsr_build_device')
+        torch.cuda.current_stream(dev).synchronize()  # the inputs and the workspace die with this scope
+        return out
 
     @classmethod
     def from_data(cls, data, strategy='recent_nodes', seed=None, max_node_id=None, device=None):
@@ -98,8 +130,11 @@ class Graph:
     def _tensors(self):
         if self._dev is None:
             dev = self.device
-            self._dev = tuple(torch.from_numpy(a).to(dev) for a in (self._h_indptr, self._h_ts, self._h_nbr, self._h_eid))
-            self._struct = TgTcsr(self.num_node, len(self._h_ts), *[t.data_ptr() for t in self._dev])
+            if self._time_ordered and self._events is not None and self._host is None:
+                self._dev = self._build_on_device(dev)  # tg_tcsr_build_device: stable radix sort on the owner id
+            else:
+                self._dev = tuple(torch.from_numpy(a).to(dev) for a in self._host_tcsr())
+            self._struct = TgTcsr(self.num_node, self._dev[1].numel(), *[t.data_ptr() for t in self._dev])
         return self._dev
 
     @property
