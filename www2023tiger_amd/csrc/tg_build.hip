@@ -67,12 +67,12 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_count(uint32_t P, const uint3
                                                          uint32_t* __restrict__ hist, uint32_t nblocks) {
   __shared__ uint32_t cnt[16][RS_THREADS + 1];
   __shared__ uint32_t totals[16];
-  const uint32_t base = blockIdx.x * RS_TILE + threadIdx.x * RS_ITEMS;
+  const uint64_t base = (uint64_t)blockIdx.x * RS_TILE + threadIdx.x * RS_ITEMS;  // 64-bit: P may be close to 2^32
   uint32_t keys[RS_ITEMS];
   int n = 0;
   for (int i = 0; i < RS_ITEMS; ++i) {
-    const uint32_t p = base + i;
-    if (p < P) keys[n++] = FIRST ? owner_of(src, dst, p) : keys_in[p];
+    const uint64_t p = base + i;
+    if (p < P) keys[n++] = FIRST ? owner_of(src, dst, (uint32_t)p) : keys_in[p];
   }
   tile_prefix(cnt, keys, n, shift, totals);
   if (threadIdx.x < 16) hist[(uint64_t)threadIdx.x * nblocks + blockIdx.x] = totals[threadIdx.x];
@@ -89,14 +89,14 @@ __global__ void __launch_bounds__(RS_THREADS) k_rs_scatter(uint32_t P, const uin
   __shared__ uint32_t cnt[16][RS_THREADS + 1];
   __shared__ uint32_t totals[16];
   __shared__ uint32_t gbase[16];
-  const uint32_t base = blockIdx.x * RS_TILE + threadIdx.x * RS_ITEMS;
+  const uint64_t base = (uint64_t)blockIdx.x * RS_TILE + threadIdx.x * RS_ITEMS;
   uint32_t keys[RS_ITEMS], vals[RS_ITEMS];
   int n = 0;
   for (int i = 0; i < RS_ITEMS; ++i) {
-    const uint32_t p = base + i;
+    const uint64_t p = base + i;
     if (p < P) {
-      keys[n] = FIRST ? owner_of(src, dst, p) : keys_in[p];
-      vals[n] = FIRST ? p : vals_in[p];
+      keys[n] = FIRST ? owner_of(src, dst, (uint32_t)p) : keys_in[p];
+      vals[n] = FIRST ? (uint32_t)p : vals_in[p];
       ++n;
     }
   }
@@ -174,7 +174,7 @@ __global__ void k_tcsr_fill(uint32_t P, const uint32_t* __restrict__ order, cons
                             const int64_t* __restrict__ dst, const double* __restrict__ ts,
                             const int64_t* __restrict__ eid, double* __restrict__ ts_out, int32_t* __restrict__ nbr_out,
                             int32_t* __restrict__ eid_out) {
-  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < P; s += gridDim.x * blockDim.x) {
+  for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < P; s += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t p = order[s], e = p >> 1;
     ts_out[s] = ts[e];
     nbr_out[s] = (int32_t)((p & 1u) ? src[e] : dst[e]);
