@@ -337,10 +337,12 @@ def test_state_dict_keys_match_reference():
 
 
 # ------------------------------------------------------------------------------ larger shapes vs the oracle
-def _oracle_vs_fused(stream, d, K, B, n_batches, msg_src, upd_src, zero_nfeats=True):
+def _oracle_vs_fused(stream, d, K, B, n_batches, msg_src, upd_src, zero_nfeats=True, fuse=False):
     import bench
     from oracle import tiger_oracle as O
     model, orc = bench.build_models(stream, d, K, msg_src, upd_src, with_oracle=True, zero_nfeats=zero_nfeats)
+    if fuse:
+        model.fuse_attention()
     worst = 0.0
     for b in range(n_batches):
         sl = slice(b * B, (b + 1) * B)
@@ -368,6 +370,15 @@ def test_c2_full_size_batches_match_oracle():
     c = bench.C2
     stream = bench.make_stream(c['n_u'], c['n_i'], 20000, c['T'] * 20000 / c['E'], seed=1, d_e=c['d'])
     _oracle_vs_fused(stream, c['d'], c['K'], c['B'], 5, c['msg_src'], c['upd_src'])
+
+
+def test_c2_bench_configuration_soak_matches_oracle():
+    """The benchmarked configuration exactly (C2 shapes, pre-multiplied attention weights, device-built
+    graph) over 16 consecutive batches: errors must not accumulate through the memories."""
+    import bench
+    c = bench.C2
+    stream = bench.make_stream(c['n_u'], c['n_i'], 40000, c['T'] * 40000 / c['E'], seed=4, d_e=c['d'])
+    _oracle_vs_fused(stream, c['d'], c['K'], c['B'], 16, c['msg_src'], c['upd_src'], fuse=True)
 
 
 def test_large_sparse_graph_multiblock_compaction_matches_oracle():
