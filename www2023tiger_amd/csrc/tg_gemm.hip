@@ -192,19 +192,67 @@ __global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
   const int n = n0 + wn * 32 + fr;
   if (n >= N) return;
   float* cp = g.c + (int64_t)bz * g.c_bs;
+  const bool plain = !g.bias_rs && !g.bias2 && !g.row_valid && !g.relu_mask && !g.c_rows && !g.accumulate;
+  if (plain) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-    if (m >= M) continue;
-    float be = g.bias_rs ? bias * g.bias_rs[m * g.ld_brs + bz] : bias;
-    if (g.bias2 && g.bias2_valid[m]) be += bias2;
-    float v = g.alpha * (acc[r] + be);
-    if (g.relu) v = fmaxf(v, 0.f);
-    if (g.row_valid && !g.row_valid[m]) v = 0.f;
-    if (g.relu_mask && !(g.relu_mask[m * g.ld_mask + n] > 0.f)) v = 0.f;
-    const int64_t cr = g.c_rows ? (int64_t)g.c_rows[m] : m;
-    if (g.accumulate) v += cp[cr * g.ldc + n];
-    cp[cr * g.ldc + n] = v;
+    for (int r = 0; r < 16; ++r) {
+      const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+      if (m >= M) continue;
+      float v = g.alpha * (acc[r] + bias);
+      if (g.relu) v = fmaxf(v, 0.f);
+      cp[m * g.ldc + n] = v;
+    }
+  } else {
+    // Optional per-row / per-element operands (row scale of the bias, validity bytes, ReLU mask, output
+    // row, old value for C +=).  Phase 1 issues EVERY load of the 16 outputs unconditionally - an absent
+    // operand reads a harmless valid address (the output tile) and is ignored in phase 2 - so the wave
+    // waits for memory once.  With a branch per operand and output the compiler waits after each load:
+    // up to 16 x 5 serialised memory latencies per wave (this was a third of the merged fc1 product).
+    const float* rsp = g.bias_rs ? g.bias_rs : cp;
+    const uint8_t* v2p = g.bias2 ? g.bias2_valid : reinterpret_cast<const uint8_t*>(cp);
+    const uint8_t* rvp = g.row_valid ? g.row_valid : reinterpret_cast<const uint8_t*>(cp);
+    const float* rmp = g.relu_mask ? g.relu_mask : cp;
+    const int* crp = g.c_rows ? g.c_rows : reinterpret_cast<const int*>(cp);
+    const int64_t rs_ld = g.bias_rs ? g.ld_brs : 0, rs_o = g.bias_rs ? bz : 0;
+    const int64_t rm_ld = g.relu_mask ? g.ld_mask : 0, rm_o = g.relu_mask ? n : 0;
+    // four outputs at a time: one exposed latency per group, 24 live registers instead of 96
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float rs[4], rm[4], old[4];
+      int crow[4];
+      uint8_t v2[4], rv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = q * 4 + j;
+        const int64_t m = min(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk, M - 1);
+        rs[j] = rsp[m * rs_ld + rs_o];
+        v2[j] = v2p[m];
+        rv[j] = rvp[m];
+        rm[j] = rmp[m * rm_ld + rm_o];
+        crow[j] = crp[m];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = q * 4 + j;
+        const int64_t m = min(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk, M - 1);
+        if (!g.c_rows) crow[j] = (int)m;
+        old[j] = cp[(int64_t)crow[j] * g.ldc + n];  // read even without C +=: a valid address either way
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = q * 4 + j;
+        const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+        if (m >= M) continue;
+        float be = g.bias_rs ? bias * rs[j] : bias;
+        if (g.bias2 && v2[j]) be += bias2;
+        float v = g.alpha * (acc[r] + be);
+        if (g.relu) v = fmaxf(v, 0.f);
+        if (g.row_valid && !rv[j]) v = 0.f;
+        if (g.relu_mask && !(rm[j] > 0.f)) v = 0.f;
+        if (g.accumulate) v += old[j];
+        cp[(int64_t)crow[j] * g.ldc + n] = v;
+      }
+    }
   }
   if ((g.dbg & 16) && tid == 0 && blockIdx.x < 4096) {
     g_gemm_trace[blockIdx.x * 4 + 0] = t_entry;
