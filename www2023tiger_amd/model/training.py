@@ -120,6 +120,9 @@ def check_trainable(model):
         raise NotImplementedError("training on device supports msg_tsfm_type='id' with mem_update_type='gru'")
     if model.n_layers != 1:
         raise NotImplementedError('training on device supports n_layers == 1')
+    if getattr(model.graph, 'strategy', 'recent_edges') != 'recent_edges':
+        # tg_train_step collates by itself with the recent-edges sampler (the CLI default, init_utils.py:41)
+        raise NotImplementedError("training on device samples with strategy='recent_edges'")
     if model.temporal_embedding_fn.fns[0].merger.dropout.p > 0:
         raise NotImplementedError('dropout inside the embedding merger is not built (the reference never sets it)')
     dropout_p(model)
