@@ -467,6 +467,13 @@ TRAIN_SCENARIOS = {
                                 wseed=22, restarter='static', msg_src='left', upd_src='left', hit='vec',
                                 restart_at=5, lr=1e-2, mutual_coef=0.5, grad_batches=(1, 3, 6)),
     # restart_prob == 0: contrast loss only (tiger.py:570-572), TGN-style right/right
+    # non-default message transforms / updater (--tsfm_fn, --upd_fn)
+    'train_mlp_merge_d8': dict(d=8, n_u=30, n_i=12, E=300, T=200.0, B=30, n_batches=8, K=6, H=6, seed=24, wseed=24,
+                               restarter='seq', msg_src='left', upd_src='right', tsfm='mlp', upd_fn='merge', hit='bin',
+                               restart_at=5, lr=1e-2, mutual_coef=1.0, grad_batches=(1, 3, 6)),
+    'train_linear_gru_d8': dict(d=8, n_u=30, n_i=12, E=300, T=200.0, B=30, n_batches=8, K=6, seed=25, wseed=25,
+                                restarter='static', msg_src='right', upd_src='left', tsfm='linear', hit='count',
+                                lr=1e-2, mutual_coef=1.0, grad_batches=(1, 4)),
     'train_contrast_rr_d8': dict(d=8, n_u=30, n_i=30, E=400, T=500.0, B=50, n_batches=6, K=10, H=6, seed=23,
                                  wseed=23, integer_ts=False, restarter='seq', msg_src='right', upd_src='right',
                                  hit='none', contrast_only=1, lr=1e-2, mutual_coef=1.0, grad_batches=(1, 4)),

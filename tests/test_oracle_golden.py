@@ -143,7 +143,8 @@ def test_stream_matches_reference(name):
 
 
 # --------------------------------------------------------------------------- training tail
-TRAIN_FIXTURES = ['train_seq_lr_d8', 'train_static_ll_d16', 'train_contrast_rr_d8']
+TRAIN_FIXTURES = ['train_seq_lr_d8', 'train_static_ll_d16', 'train_contrast_rr_d8', 'train_mlp_merge_d8',
+                  'train_linear_gru_d8']
 
 
 def grad_err(a, b):

@@ -533,6 +533,21 @@ __global__ void k_gru_bwd(tg_model m, int64_t cap, const int32_t* __restrict__ n
   }
 }
 
+// dh_new[i, :] = dreprs[out_pos[i], :] for the live outdated rows (MergeUpdater backward input)
+__global__ void k_gather_dh(int64_t cap, const int32_t* __restrict__ n_dev, int d, const int32_t* __restrict__ out_pos,
+                            const float* __restrict__ dreprs, float* __restrict__ dh, int32_t* __restrict__ flags) {
+  const int64_t n = min((int64_t)*n_dev, cap);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && flags) {
+    flags[0] = 1;
+    flags[1] = n > 0;
+  }
+  const int64_t total = n * d;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / d;
+    dh[t] = dreprs[(int64_t)out_pos[i] * d + (t - i * d)];
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // Adam
 // ---------------------------------------------------------------------------------
@@ -576,6 +591,7 @@ __global__ void k_rng_tick(uint64_t* rng) {
 // ---------------------------------------------------------------------------------
 struct TrainWs {
   float *gates, *P, *T1, *dP, *dH, *dT, *dhh, *dcc, *dO, *dS, *dG, *dqp, *dreprs, *dgi, *dgh, *dqconst, *part, *tepart;
+  float *dX, *dHn, *dt2, *dt0;  // non-default message transform / updater only
   size_t part_floats;
   int32_t* hit_idx;
   int64_t rows_cap;
@@ -591,7 +607,7 @@ static size_t part_floats_for(const tg_model* m, const tg_score_params* sp) {
   // of the contrastive backward pass (also ample for the single launches of the restarter's backward)
   const size_t d = m->d, E = 2 * d, kvw = 2 * d + m->d_e, mw = 3 * d + m->d_e, W2 = 2 * (size_t)score_width(m, sp);
   const size_t total = d * (W2 + 1) + d * (d + 1) + d * (E + d + 1) + E * (E + 1) + 2 * E * (kvw + 1) + E * (d + 1) +
-                       3 * d * (mw + 1) + 3 * d * (d + 1);
+                       3 * d * (mw + 1) + 3 * d * (d + 1) + 2 * mw * (mw + 1) + d * (mw + d + 1) + d * (d + 1);
   return std::max<size_t>(16 * total + 64, (size_t)1280 * 4096);
 }
 
@@ -614,6 +630,13 @@ static bool carve_train(const tg_model* m, const tg_score_params* sp, int64_t B,
   w.dreprs = cv.take<float>((size_t)w.rows_cap * d);
   w.dgi = cv.take<float>((size_t)w.rows_cap * 3 * d);
   w.dgh = cv.take<float>((size_t)w.rows_cap * 3 * d);
+  const size_t mw = 3 * (size_t)d + m->d_e;
+  if (m->tsfm != TG_TSFM_ID) w.dX = cv.take<float>((size_t)w.rows_cap * mw);
+  if (m->tsfm == TG_TSFM_MLP) w.dt0 = cv.take<float>((size_t)w.rows_cap * (mw / 2));
+  if (m->upd_fn == TG_UPD_MERGE) {
+    w.dHn = cv.take<float>((size_t)w.rows_cap * d);
+    w.dt2 = cv.take<float>((size_t)w.rows_cap * d);
+  }
   w.dqconst = cv.take<float>((size_t)E);
   w.tepart = cv.take<float>((size_t)1024 * 2 * d);
   w.part_floats = part_floats_for(m, sp);
@@ -628,12 +651,15 @@ static size_t train_ws_bytes(const tg_model* m, const tg_score_params* sp, int64
   const size_t rows = std::min<size_t>(Q * (K + 1), (size_t)m->n_nodes);
   return align16(rows * 4 * d * 4) + align16(2 * B * 2 * W * 4) * 2 + align16(2 * B * d * 4) + align16(Q * d * 4) * 3 +
          align16(Q * E * 4) * 3 + align16(Q * nh * kvw * 4) * 2 + align16(rows * d * 4) + align16(rows * 3 * d * 4) * 2 +
-         align16(E * 4) + align16(1024 * 2 * d * 4) + align16(part_floats_for(m, sp) * 4) + align16(4 * B * 4) + 256;
+         align16(E * 4) + align16(1024 * 2 * d * 4) + align16(part_floats_for(m, sp) * 4) + align16(4 * B * 4) + 256 +
+         (m->tsfm != TG_TSFM_ID ? align16(rows * (3 * d + m->d_e) * 4) : 0) +
+         (m->tsfm == TG_TSFM_MLP ? align16(rows * ((3 * d + m->d_e) / 2) * 4) : 0) +
+         (m->upd_fn == TG_UPD_MERGE ? 2 * align16(rows * d * 4) : 0);
 }
 
 static int train_supported(const tg_model* m, const tg_score_params* sp) {
   if (!attn_dims_ok(m) || !sp) return 0;
-  if (m->tsfm != TG_TSFM_ID || m->upd_fn != TG_UPD_GRU) return 0;
+  if (m->tsfm == TG_TSFM_MLP && (((3 * m->d + m->d_e) / 2) % 4)) return 0;
   if (m->d > NVS * 64) return 0;
   if ((2 * score_width(m, sp)) % 4) return 0;
   if (sp->hit_type < TG_HIT_NONE || sp->hit_type > TG_HIT_COUNT) return 0;
@@ -804,19 +830,82 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
   if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
   hipLaunchKernelGGL(k_centre_scatter, dim3(flat_grid(Q * d, 256)), dim3(256), 0, st, Q, d, w.nids3, w.bm, w.rank, t.dcc,
                      t.dreprs);
-  // ---- GRU
-  hipLaunchKernelGGL(k_gru_bwd, dim3(flat_grid(t.rows_cap * d, 256)), dim3(256), 0, st, *m, t.rows_cap, w.counts + 1,
-                     w.outdated, w.out_pos, t.gates, t.dreprs, t.dgi, t.dgh, io->flags);
+  // ---- updater (update_modules.py:30-47) and message transform (message_modules.py:20-55)
   const float* upd_vals = (m->upd_src == TG_SRC_LEFT) ? m->left_vals : m->right_vals;
-  tn = TnArgs{};
-  tn.m_cap = t.rows_cap; tn.m_dev = w.counts + 1; tn.n = 3 * d; tn.k = mw; tn.y = t.dgi; tn.ldy = 3 * d;
-  tn.x0 = ASeg{m->msg_vals, mw, mw, w.outdated};
-  tn.out = F(gm->gru_w_ih); tn.ldo = mw; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = 1; tn.part = t.part;
-  tn.part_floats = t.part_floats; tn.bias_out = F(gm->gru_b_ih); tn.bias_accumulate = 1;
-  tns.push_back(tn);
-  tn.k = d; tn.y = t.dgh; tn.x0 = ASeg{upd_vals, d, d, w.outdated}; tn.out = F(gm->gru_w_hh); tn.ldo = d;
-  tn.bias_out = F(gm->gru_b_hh);
-  tns.push_back(tn);
+  const int32_t* n_out = w.counts + 1;
+  // the forward pass left the transformed messages / hidden layers in its own scratch (apply_messages)
+  Carver av(w.apply_ws, w.apply_bytes);
+  const float* t0 = m->tsfm == TG_TSFM_MLP ? av.take<float>((size_t)(Q * (K + 1)) * (mw / 2)) : nullptr;
+  const float* t1 = m->tsfm != TG_TSFM_ID ? av.take<float>((size_t)(Q * (K + 1)) * mw) : nullptr;
+  const float* t2 = m->upd_fn == TG_UPD_MERGE ? av.take<float>((size_t)(Q * (K + 1)) * d) : nullptr;
+  const ASeg xmsg = m->tsfm == TG_TSFM_ID ? ASeg{m->msg_vals, mw, mw, w.outdated} : ASeg{t1, mw, mw, nullptr};
+  const ASeg xraw = ASeg{m->msg_vals, mw, mw, w.outdated};
+  const ASeg xmem = ASeg{upd_vals, d, d, w.outdated};
+  auto tn_rows = [&]() {
+    TnArgs a{};
+    a.m_cap = t.rows_cap; a.m_dev = n_out; a.alpha = 1.f; a.accumulate = 1; a.nbatch = 1; a.bias_accumulate = 1;
+    return a;
+  };
+  const bool need_dx = m->tsfm != TG_TSFM_ID;
+  if (m->upd_fn == TG_UPD_GRU) {
+    hipLaunchKernelGGL(k_gru_bwd, dim3(flat_grid(t.rows_cap * d, 256)), dim3(256), 0, st, *m, t.rows_cap, n_out,
+                       w.outdated, w.out_pos, t.gates, t.dreprs, t.dgi, t.dgh, io->flags);
+    tn = tn_rows();
+    tn.n = 3 * d; tn.k = mw; tn.y = t.dgi; tn.ldy = 3 * d; tn.x0 = xmsg;
+    tn.out = F(gm->gru_w_ih); tn.ldo = mw; tn.bias_out = F(gm->gru_b_ih);
+    tns.push_back(tn);
+    tn.k = d; tn.y = t.dgh; tn.x0 = xmem; tn.out = F(gm->gru_w_hh); tn.ldo = d; tn.bias_out = F(gm->gru_b_hh);
+    tns.push_back(tn);
+    if (need_dx) {  // d msg = d gi W_ih
+      g = GemmArgs{};
+      g.m_cap = t.rows_cap; g.m_dev = n_out; g.n = mw; g.k = 3 * d; g.a0 = ASeg{t.dgi, 3 * d, 3 * d, nullptr};
+      g.w = m->gru_w_ih; g.ldw = mw; g.w_kmajor = 1; g.c = t.dX; g.ldc = mw; g.alpha = 1.f; g.nbatch = 1;
+      if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+    }
+  } else {  // MergeUpdater: h = fc2(relu(fc1([msg | mem])))
+    hipLaunchKernelGGL(k_gather_dh, dim3(flat_grid(t.rows_cap * d, 256)), dim3(256), 0, st, t.rows_cap, n_out, d,
+                       w.out_pos, t.dreprs, t.dHn, io->flags);
+    tn = tn_rows();
+    tn.n = d; tn.k = d; tn.y = t.dHn; tn.ldy = d; tn.x0 = ASeg{t2, d, d, nullptr};
+    tn.out = F(gm->upd_fc2.w); tn.ldo = d; tn.bias_out = F(gm->upd_fc2.b);
+    tns.push_back(tn);
+    g = GemmArgs{};
+    g.m_cap = t.rows_cap; g.m_dev = n_out; g.n = d; g.k = d; g.a0 = ASeg{t.dHn, d, d, nullptr};
+    g.w = m->upd_fc2.w; g.ldw = d; g.w_kmajor = 1; g.c = t.dt2; g.ldc = d; g.alpha = 1.f; g.nbatch = 1;
+    g.relu_mask = t2; g.ld_mask = d;
+    if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+    tn = tn_rows();
+    tn.n = d; tn.k = mw + d; tn.y = t.dt2; tn.ldy = d; tn.x0 = xmsg; tn.x1 = xmem;
+    tn.out = F(gm->upd_fc1.w); tn.ldo = mw + d; tn.bias_out = F(gm->upd_fc1.b);
+    tns.push_back(tn);
+    if (need_dx) {  // d msg = d t2 fc1[:, :mw]
+      g = GemmArgs{};
+      g.m_cap = t.rows_cap; g.m_dev = n_out; g.n = mw; g.k = d; g.a0 = ASeg{t.dt2, d, d, nullptr};
+      g.w = m->upd_fc1.w; g.ldw = mw + d; g.w_kmajor = 1; g.c = t.dX; g.ldc = mw; g.alpha = 1.f; g.nbatch = 1;
+      if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+    }
+  }
+  if (m->tsfm == TG_TSFM_LINEAR) {  // msg = W raw + b  (raw messages carry no gradient: tgn_mode, tiger.py:329-333)
+    tn = tn_rows();
+    tn.n = mw; tn.k = mw; tn.y = t.dX; tn.ldy = mw; tn.x0 = xraw;
+    tn.out = F(gm->tsfm1.w); tn.ldo = mw; tn.bias_out = F(gm->tsfm1.b);
+    tns.push_back(tn);
+  } else if (m->tsfm == TG_TSFM_MLP) {  // msg = W2 relu(W1 raw + b1) + b2
+    const int hw = mw / 2;
+    tn = tn_rows();
+    tn.n = mw; tn.k = hw; tn.y = t.dX; tn.ldy = mw; tn.x0 = ASeg{t0, hw, hw, nullptr};
+    tn.out = F(gm->tsfm2.w); tn.ldo = hw; tn.bias_out = F(gm->tsfm2.b);
+    tns.push_back(tn);
+    g = GemmArgs{};
+    g.m_cap = t.rows_cap; g.m_dev = n_out; g.n = hw; g.k = mw; g.a0 = ASeg{t.dX, mw, mw, nullptr};
+    g.w = m->tsfm2.w; g.ldw = hw; g.w_kmajor = 1; g.c = t.dt0; g.ldc = hw; g.alpha = 1.f; g.nbatch = 1;
+    g.relu_mask = t0; g.ld_mask = hw;
+    if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+    tn = tn_rows();
+    tn.n = hw; tn.k = mw; tn.y = t.dt0; tn.ldy = hw; tn.x0 = xraw;
+    tn.out = F(gm->tsfm1.w); tn.ldo = mw; tn.bias_out = F(gm->tsfm1.b);
+    tns.push_back(tn);
+  }
   if ((rc = gemm_tn_group_launch(tns.data(), (int)tns.size(), t.part, t.part_floats, st)) != TG_OK) return rc;
   hipLaunchKernelGGL(k_qconst_bwd, dim3((unsigned)cdiv(d, 64), 16), dim3(256), 0, st, d, t.dqconst, m->attn_wq, m->te_freq,
                      m->te_phase, F(gm->attn_wq), F(gm->attn_b_in), F(gm->te_phase));

@@ -29,15 +29,23 @@ def contrast_parameters(model) -> List[Tuple[str, Tensor, int]]:
     Groups follow tg_train_io.flags: 0 always has a gradient, 1 only when the GRU ran."""
     att = model.temporal_embedding_fn.fns[0]
     mha = att.mha_fn
-    cell = model.right_mem_updater.cell
     pre = 'temporal_embedding_fn.fns.0.'
     out = [
         ('time_encoder.basis_freq', model.time_encoder.basis_freq, 0),
         ('time_encoder.phase', model.time_encoder.phase, 0),
-        ('right_mem_updater.cell.weight_ih', cell.weight_ih, 1),
-        ('right_mem_updater.cell.weight_hh', cell.weight_hh, 1),
-        ('right_mem_updater.cell.bias_ih', cell.bias_ih, 1),
-        ('right_mem_updater.cell.bias_hh', cell.bias_hh, 1),
+    ]
+    upd = model.right_mem_updater
+    if model.mem_update_type == 'gru':
+        out += [('right_mem_updater.cell.' + n, getattr(upd.cell, n), 1)
+                for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+    else:
+        out += [(f'right_mem_updater.fn.{l}.{n}', getattr(getattr(upd.fn, l), n), 1)
+                for l in ('fc1', 'fc2') for n in ('weight', 'bias')]
+    if model.msg_tsfm_type != 'id':  # nn.Sequential indices of the Linear layers (message_modules.py:33-39,52)
+        for idx in ((1,) if model.msg_tsfm_type == 'linear' else (1, 4)):
+            lin = model.msg_transform_fn.fn[idx]
+            out += [(f'msg_transform_fn.fn.{idx}.weight', lin.weight, 1), (f'msg_transform_fn.fn.{idx}.bias', lin.bias, 1)]
+    out += [
         (pre + 'mha_fn.q_proj_weight', mha.q_proj_weight, 0),
         (pre + 'mha_fn.k_proj_weight', mha.k_proj_weight, 0),
         (pre + 'mha_fn.v_proj_weight', mha.v_proj_weight, 0),
@@ -103,11 +111,15 @@ def grads_struct(model, g) -> TgModel:
     m = model.model_struct()
     pre = 'temporal_embedding_fn.fns.0.'
     nul = TgLinear(None, None)
+    lin = lambda stem: TgLinear(ptr(g[stem + '.weight']), ptr(g[stem + '.bias'])) if stem + '.weight' in g else nul
+    gp = lambda name: ptr(g.get(name))
     return TgModel(m.n_nodes, m.d, m.d_e, m.n_neighbors, m.n_head, m.msg_src, m.upd_src, m.tsfm, m.upd_fn,
                    None, None, None, None, None, None, None, None, None, None, None,
-                   ptr(g['time_encoder.basis_freq']), ptr(g['time_encoder.phase']), nul, nul,
-                   ptr(g['right_mem_updater.cell.weight_ih']), ptr(g['right_mem_updater.cell.weight_hh']),
-                   ptr(g['right_mem_updater.cell.bias_ih']), ptr(g['right_mem_updater.cell.bias_hh']), nul, nul,
+                   ptr(g['time_encoder.basis_freq']), ptr(g['time_encoder.phase']),
+                   lin('msg_transform_fn.fn.1'), lin('msg_transform_fn.fn.4'),
+                   gp('right_mem_updater.cell.weight_ih'), gp('right_mem_updater.cell.weight_hh'),
+                   gp('right_mem_updater.cell.bias_ih'), gp('right_mem_updater.cell.bias_hh'),
+                   lin('right_mem_updater.fn.fc1'), lin('right_mem_updater.fn.fc2'),
                    ptr(g[pre + 'mha_fn.q_proj_weight']), ptr(g[pre + 'mha_fn.k_proj_weight']),
                    ptr(g[pre + 'mha_fn.v_proj_weight']), ptr(g[pre + 'mha_fn.in_proj_bias']),
                    TgLinear(ptr(g[pre + 'mha_fn.out_proj.weight']), ptr(g[pre + 'mha_fn.out_proj.bias'])),
@@ -116,8 +128,8 @@ def grads_struct(model, g) -> TgModel:
 
 
 def check_trainable(model):
-    if model.msg_tsfm_type != 'id' or model.mem_update_type != 'gru':
-        raise NotImplementedError("training on device supports msg_tsfm_type='id' with mem_update_type='gru'")
+    if model.msg_tsfm_type != 'id' and any(isinstance(l, torch.nn.Dropout) and l.p > 0 for l in model.msg_transform_fn.fn):
+        raise NotImplementedError('dropout inside the message transform is not built (the reference never sets it)')
     if model.n_layers != 1:
         raise NotImplementedError('training on device supports n_layers == 1')
     if getattr(model.graph, 'strategy', 'recent_edges') != 'recent_edges':
