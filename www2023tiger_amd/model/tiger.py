@@ -266,10 +266,9 @@ class TIGE(nn.Module):
             return self._contrast_learning_eval(src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph)
 
     def _fused_eval_ok(self) -> bool:
-        """the one-call evaluation step covers the default model family; other configurations take the
-        operator-by-operator path below"""
-        return (self.msg_tsfm_type == 'id' and self.mem_update_type == 'gru'
-                and getattr(self.graph, 'strategy', 'recent_edges') == 'recent_edges')
+        """the one-call evaluation step samples with the default recent-edges strategy; graphs built with
+        another strategy take the operator-by-operator path below"""
+        return getattr(self.graph, 'strategy', 'recent_edges') == 'recent_edges'
 
     def _contrast_learning_fused_eval(self, src_ids, dst_ids, neg_dst_ids, eids, computation_graph):
         """no_grad / eval(): collate, STEP 1-7 and the write-back as ONE device call (tg_train_step without
