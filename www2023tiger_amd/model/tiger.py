@@ -268,6 +268,8 @@ class TIGE(nn.Module):
     def _fused_eval_ok(self) -> bool:
         """the one-call evaluation step samples with the default recent-edges strategy; graphs built with
         another strategy take the operator-by-operator path below"""
+        if self.hit_type == 'vec' and (2 * (self.nfeat_dim + self.n_neighbors)) % 4:
+            return False  # the score head's pair rows must be float4-aligned
         return getattr(self.graph, 'strategy', 'recent_edges') == 'recent_edges'
 
     def _contrast_learning_fused_eval(self, src_ids, dst_ids, neg_dst_ids, eids, computation_graph):
