@@ -2,14 +2,18 @@
 method names, buffer/parameter names (state_dict compatible, alias keys included),
 executed by libtiger_hip.so.
 
-Two ways to run a batch:
+Ways to run a batch:
   * `contrast_learning(src, dst, neg, ts, eids, computation_graph)` - the reference
-    signature; the collator's ComputationGraph supplies neighbours and the involved
-    set, STEP 1-6 run as HIP entry points, STEP 7 (score head + BCE) in torch.
+    signature.  In train() mode with autograd on, the whole iteration (collate, STEP 1-7,
+    backward, write-back; `contrast_and_mutual_learning` adds the mutual loss) is one
+    tg_train_step and the returned losses carry an autograd node that hands the finished
+    gradients to the parameters.  In eval() / no_grad mode the batch is one tg_train_step
+    without gradient buffers; where that call does not apply (non-default sampling strategy,
+    a foreign ComputationGraph) STEP 1-6 run as one HIP entry point per reference method
+    and STEP 7 in torch.
   * `stream_step(src, dst, neg, ts64, eids)` - collation and STEP 1-6 fused behind one
     C call (tg_stream_step) with no host synchronisation; the benchmarked path.
-Forward only: gradients are not propagated through the HIP kernels (the training
-tail is the next scope row, SURVEY.md s8 f 1).
+  * `fuse_attention()` - inference with fixed parameters: pre-multiplied attention weights.
 """
 import ctypes as C
 from typing import Optional, Tuple, Union
