@@ -309,7 +309,8 @@ def main():
     # collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command); null if not recorded
     traffic = None
     try:
-        tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic_v5.json')))
+        tfile = {'c2': 'r01_hbm_traffic_v5.json', 'c5s': 'r01_hbm_traffic_c5s_v6.json'}.get(args.workload)
+        tj = json.load(open(os.path.join(ROOT, 'profiles', tfile))) if tfile else {'kernels': {}}
         traffic = tj['kernels'].get(kernel_of_stage.get(name, ''), {}).get('bytes_per_launch')
     except (OSError, ValueError):
         pass
