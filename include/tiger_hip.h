@@ -448,6 +448,10 @@ typedef struct tg_train_io {
   float dropout_p;                    /* 0 <= p < 1; 0 = off */
   int32_t reserved2;
   uint64_t* rng;                      /* device uint64[2]; required when dropout_p > 0 */
+  /* graph the restarter reads its histories from (restarter_fn.graph in the reference); NULL = the
+   * graph passed to tg_train_step, which is always the one the neighbourhoods are sampled from
+   * (the collator's graph) */
+  const tg_tcsr* hist_graph;
 } tg_train_io;
 
 #define TG_RESTARTER_NONE 0

@@ -92,3 +92,32 @@ def test_end_to_end_recipe_on_toy_jodie_files(tmp_path):
               'score_fn.fc1.weight', 'restarter_fn.mha_fn.in_proj_weight'):
         assert k in sd, k
     assert not any(k.startswith('msg_store.') for k in sd)
+
+
+def test_fused_eval_samples_from_the_collators_graph():
+    """Warm-up batches are collated on the TRAINING graph while model.graph is the full graph
+    (train_self_supervised.py:175-183): the one-call evaluation must embed with the collator's
+    neighbourhoods, exactly as the operator path (which consumes the collated layers) does."""
+    from www2023tiger_amd.data.data_loader import GraphCollator
+    from www2023tiger_amd.data.graph import Graph
+    z = load('eval_seq_lr_d8')
+    cfg = parse_cfg(z)
+    model, full_graph, _ = build_hip_model(z, cfg, dropout=0.0)
+    keep = np.ones(len(z['src']), dtype=bool)
+    keep[::3] = False  # a "training" graph that misses a third of the events
+    train_graph = Graph.from_arrays(z['src'][keep], z['dst'][keep], z['ts'][keep], z['eids'][keep],
+                                    strategy='recent_edges', seed=0, max_node_id=int(z['n_nodes']) - 1, device=dev())
+    coll = GraphCollator(train_graph, cfg['K'], 1, restarter=cfg['restarter'], hist_len=cfg.get('H'))
+    ref, _, _ = build_hip_model(z, cfg, dropout=0.0)
+    ref._fused_eval_ok = lambda: False  # operator path: uses the collated layers as they are
+    model.eval(); ref.eval()
+    assert model.graph is not train_graph
+    B = cfg['B']
+    for b in range(6, 10):
+        sl = slice(b * B, (b + 1) * B)
+        a = [z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        s, d_, n_, t, e, _, cg = coll.collate_arrays(*a)
+        out = model.contrast_learning(s, d_, n_, t, e, cg)
+        out_ref = ref.contrast_learning(s, d_, n_, t, e, cg)
+        for x, y in zip(out[1:4], out_ref[1:4]):
+            assert rel_err(x.cpu().numpy(), y.cpu().numpy()) < 1e-5, b

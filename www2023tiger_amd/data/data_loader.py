@@ -80,6 +80,7 @@ class GraphCollator:
         hit = self.collate_hit_data(s_d, d_d, n_d, t_dev, layers[1][0])
         cg = ComputationGraph(layers, bitmap, comp['rank'], comp['ids'], comp['count'], restart, hit, self.n_nodes)
         cg.ts64 = t_dev  # float64 event times for the fused training step (which collates on device itself)
+        cg.graph = self.graph if self.graph.strategy == 'recent_edges' else None  # None: one-call steps do not apply
         e = torch.from_numpy(np.ascontiguousarray(eids, dtype=np.int64))
         lab = torch.from_numpy(np.ascontiguousarray(labels, dtype=np.int64)) if labels is not None else None
         return s, d_, n_, torch.from_numpy(ts64).float(), e, lab, cg

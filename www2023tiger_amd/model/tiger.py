@@ -247,7 +247,10 @@ class TIGE(nn.Module):
             ts64 = ts.to(dev).double()
         to = lambda x: x.to(dev).long()
         tb.sb.load(to(src_ids), to(dst_ids), to(neg_dst_ids), ts64, to(eids))
-        tb.launch()
+        cg_graph = getattr(computation_graph, 'graph', None)
+        if cg_graph is None and hasattr(computation_graph, 'ts64'):
+            raise NotImplementedError("training on device samples with strategy='recent_edges'")
+        tb.launch(graph=cg_graph)  # sample where the collator sampled
         word = int(tb.sb.err.item())
         if word:
             tb.sb.err.zero_()
@@ -265,7 +268,8 @@ class TIGE(nn.Module):
             losses, *rest = self._train_forward(src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph, False)
             return (losses[0], *rest)
         with torch.no_grad():
-            if getattr(computation_graph, 'ts64', None) is not None and self._fused_eval_ok():
+            if (getattr(computation_graph, 'ts64', None) is not None
+                    and getattr(computation_graph, 'graph', None) is not None and self._fused_eval_ok()):
                 return self._contrast_learning_fused_eval(src_ids, dst_ids, neg_dst_ids, eids, computation_graph)
             return self._contrast_learning_eval(src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph)
 
@@ -274,7 +278,7 @@ class TIGE(nn.Module):
         another strategy take the operator-by-operator path below"""
         if self.hit_type == 'vec' and (2 * (self.nfeat_dim + self.n_neighbors)) % 4:
             return False  # the score head's pair rows must be float4-aligned
-        return getattr(self.graph, 'strategy', 'recent_edges') == 'recent_edges'
+        return True
 
     def _contrast_learning_fused_eval(self, src_ids, dst_ids, neg_dst_ids, eids, computation_graph):
         """no_grad / eval(): collate, STEP 1-7 and the write-back as ONE device call (tg_train_step without
@@ -290,7 +294,9 @@ class TIGE(nn.Module):
             self._step_ws[key] = tb
         to = lambda x: x.to(dev).long()
         tb.sb.load(to(src_ids), to(dst_ids), to(neg_dst_ids), computation_graph.ts64, to(eids))
-        tb.launch()
+        # the collator's graph, not model.graph: the reference embeds with the neighbourhoods the collator
+        # sampled (e.g. warm-up batches are collated on the training graph while model.graph is the full one)
+        tb.launch(graph=getattr(computation_graph, 'graph', None))
         word = int(tb.sb.err.item())
         if word:
             tb.sb.err.zero_()
