@@ -432,7 +432,8 @@ typedef struct tg_train_io {
   /* mutual learning (tiger.py:574-590): the restarter predicts the targets h_prev_left/right
    * (step.h_prev_* must be given) of the latest occurrence of every positive node; MSE over the
    * rows whose target is not all zero.  Restart data (data_loader.py:133-165) is collated on
-   * device.  restarter = TG_RESTARTER_NONE is contrast_only (tiger.py:570-572). */
+   * device from the graph passed to tg_train_step - the collator's graph, as in the reference,
+   * where the histories of the mutual loss come from the collated batch (tiger.py:579-581).  restarter = TG_RESTARTER_NONE is contrast_only (tiger.py:570-572). */
   int32_t restarter; /* TG_RESTARTER_* */
   int32_t reserved;
   const tg_seq_restarter* seq;        /* TG_RESTARTER_SEQ: parameters ... */
@@ -448,10 +449,6 @@ typedef struct tg_train_io {
   float dropout_p;                    /* 0 <= p < 1; 0 = off */
   int32_t reserved2;
   uint64_t* rng;                      /* device uint64[2]; required when dropout_p > 0 */
-  /* graph the restarter reads its histories from (restarter_fn.graph in the reference); NULL = the
-   * graph passed to tg_train_step, which is always the one the neighbourhoods are sampled from
-   * (the collator's graph) */
-  const tg_tcsr* hist_graph;
 } tg_train_io;
 
 #define TG_RESTARTER_NONE 0

@@ -89,7 +89,7 @@ class TgTrainIo(C.Structure):
         ('pos_scores', vp), ('neg_scores', vp), ('flags', vp), ('restarter', i32), ('reserved', i32),
         ('seq', vp), ('seq_grads', vp), ('static_left', vp), ('static_right', vp),
         ('static_left_grad', vp), ('static_right_grad', vp),
-        ('dropout_p', C.c_float), ('reserved2', i32), ('rng', vp), ('hist_graph', vp),
+        ('dropout_p', C.c_float), ('reserved2', i32), ('rng', vp),
     ]
 
 

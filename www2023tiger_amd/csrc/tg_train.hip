@@ -958,7 +958,7 @@ extern "C" int tg_train_step(const tg_model* m_in, const tg_tcsr* g, const tg_tr
   if (io->restarter != TG_RESTARTER_NONE) {  // needs the targets of STEP 4/5 and the step's bitmap-free inputs
     const bool seq = io->restarter == TG_RESTARTER_SEQ;
     if (seq && (!io->seq || !io->seq_grads)) return TG_EINVAL;
-    if ((rc = mutual_step(m, io->hist_graph ? io->hist_graph : g, sio, w, seq ? io->seq : nullptr, seq ? io->seq_grads : nullptr, io->static_left,
+    if ((rc = mutual_step(m, g, sio, w, seq ? io->seq : nullptr, seq ? io->seq_grads : nullptr, io->static_left,
                           io->static_right, io->static_left_grad, io->static_right_grad, io->losses + 1,
                           io->flags ? io->flags + 2 : nullptr, t.part, t.part_floats, cv.p, cv.left, dc, st)) != TG_OK)
       return rc;

@@ -222,16 +222,15 @@ class TrainBuffers:
 
     def launch(self, zero_grads: bool = True, graph=None):
         """Enqueue forward + STEP 7 + backward + write-back for the batch in `sb` (no host sync).
-        `graph`: the graph the neighbourhoods are sampled from (the collator's; default model.graph);
-        the restarter's histories always come from model.graph, as in the reference."""
+        `graph`: the graph the neighbourhoods AND the mutual loss's histories are sampled from - the
+        collator's graph, as in the reference (tiger.py:579-581 reads the collated restart data);
+        default model.graph."""
         model = self.model
         if zero_grads and not self.eval_only:
             self.gflat.zero_()
         m = model.model_struct()
         graph = model.graph if graph is None else graph
         g = graph.tcsr
-        self._hist = model.graph.tcsr if (graph is not model.graph and self.mutual) else None
-        self.io.hist_graph = C.addressof(self._hist) if self._hist is not None else None
         check(lib.tg_train_step(C.byref(m), C.byref(g), C.byref(self.io), ptr(self.ws), self.ws.numel(),
                                 stream_ptr(model.device)), 'tg_train_step')
 
