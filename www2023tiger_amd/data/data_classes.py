@@ -59,21 +59,63 @@ class HitData(_Bundle):
 
 class ComputationGraph:
     """layers[0] = (cat[src,dst,neg], None, None); layers[1] = (nids, eids, ts) [3B, K].
-    The involved-node set is the bitmap; `involved`/`rank`/`n_involved` decode it."""
+    The involved-node set is the bitmap; `involved`/`rank`/`n_involved` decode it.
+
+    Built eagerly from collated pieces, or LAZILY from a collator and the batch arrays
+    (`ComputationGraph.lazy`): the one-call training / evaluation steps collate on device
+    themselves and only need `ts64` / `graph`, so the neighbourhood sample, the involved set,
+    the restart data and the hit matrices are produced on first access only (the lazy-restart
+    bookkeeping of the loops asks for `np_computation_graph_nodes`, nothing else)."""
 
     def __init__(self, layers: List[Tuple], bitmap: Tensor, rank: Tensor, involved: Tensor, n_involved: Tensor,
                  restart_data: Optional[RestartData], hit_data: Optional[HitData], n_nodes: int):
         self.n_nodes = n_nodes
-        self.layers = layers
-        self.bitmap, self.rank = bitmap, rank
-        self.involved, self.n_involved = involved, n_involved
-        self.restart_data = restart_data
-        self.hit_data = hit_data
+        self._memory = (layers, bitmap, rank, involved, n_involved)
+        self._restart = restart_data
+        self._hit = hit_data
+        self._pending = None
         self._count = None
+
+    @classmethod
+    def lazy(cls, collator, src_d: Tensor, dst_d: Tensor, neg_d: Tensor, ts64_d: Tensor):
+        self = cls.__new__(cls)
+        self.n_nodes = collator.n_nodes
+        self._memory = self._restart = self._hit = None
+        self._pending = (collator, src_d, dst_d, neg_d, ts64_d)
+        self._count = None
+        return self
+
+    # ---- pieces, collated on first use ---------------------------------------------------
+    def _mem(self):
+        if self._memory is None:
+            coll, s, d, n, t = self._pending
+            layers, bitmap, comp = coll.collate_memory_nodes(torch.cat([s, d, n]), t.repeat(3))
+            self._memory = (layers, bitmap, comp['rank'], comp['ids'], comp['count'])
+        return self._memory
+
+    layers = property(lambda self: self._mem()[0])
+    bitmap = property(lambda self: self._mem()[1])
+    rank = property(lambda self: self._mem()[2])
+    involved = property(lambda self: self._mem()[3])
+    n_involved = property(lambda self: self._mem()[4])
+
+    @property
+    def restart_data(self):
+        if self._restart is None and self._pending is not None:
+            coll, s, d, n, t = self._pending
+            self._restart = coll.collate_restart_data(torch.cat([s, d]), t.repeat(2))
+        return self._restart
+
+    @property
+    def hit_data(self):
+        if self._hit is None and self._pending is not None:
+            coll, s, d, n, t = self._pending
+            self._hit = coll.collate_hit_data(s, d, n, t, self.layers[1][0])
+        return self._hit
 
     @property
     def device(self):
-        return self.bitmap.device
+        return self._pending[1].device if self._pending is not None else self.bitmap.device
 
     @property
     def num_involved(self) -> int:

@@ -74,12 +74,8 @@ class GraphCollator:
         s, d_, n_ = (torch.from_numpy(np.ascontiguousarray(x, dtype=np.int64)) for x in (src, dst, neg))
         t_dev = torch.from_numpy(ts64).to(dev)
         s_d, d_d, n_d = s.to(dev), d_.to(dev), n_.to(dev)
-        nids3 = torch.cat([s_d, d_d, n_d])
-        layers, bitmap, comp = self.collate_memory_nodes(nids3, t_dev.repeat(3))
-        restart = self.collate_restart_data(nids3[:2 * len(s)], t_dev.repeat(2))
-        hit = self.collate_hit_data(s_d, d_d, n_d, t_dev, layers[1][0])
-        cg = ComputationGraph(layers, bitmap, comp['rank'], comp['ids'], comp['count'], restart, hit, self.n_nodes)
-        cg.ts64 = t_dev  # float64 event times for the fused training step (which collates on device itself)
+        cg = ComputationGraph.lazy(self, s_d, d_d, n_d, t_dev)  # pieces are collated on first access
+        cg.ts64 = t_dev  # float64 event times for the one-call steps (which collate on device themselves)
         cg.graph = self.graph if self.graph.strategy == 'recent_edges' else None  # None: one-call steps do not apply
         e = torch.from_numpy(np.ascontiguousarray(eids, dtype=np.int64))
         lab = torch.from_numpy(np.ascontiguousarray(labels, dtype=np.int64)) if labels is not None else None
