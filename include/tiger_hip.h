@@ -77,6 +77,12 @@ int tg_tcsr_build_host(int64_t num_events, const int64_t* src_host, const int64_
                        int64_t* indptr_host, double* ts_out_host, int32_t* nbr_out_host,
                        int32_t* eid_out_host);
 
+/* RandEdgeSampler.sample(1) called `count` times (data_loader.py:291-294): per event one
+ * randint(0, n_src) then one randint(0, n_dst) on a numpy legacy RandomState.  mt_state: HOST
+ * uint32[625] = MT19937 key + position (numpy get_state()[1:3]), advanced in place. */
+int tg_rand_edge_pairs_host(uint32_t* mt_state, int64_t n_src, int64_t n_dst, int64_t count,
+                            int64_t* src_idx_host, int64_t* dst_idx_host);
+
 /* The same build on device for a TIME-ORDERED stream (ts non-decreasing - the caller checks; every
  * JODIE file is): a stable radix sort of the 2E (owner, entry) pairs on the owner id.  All pointers
  * are DEVICE pointers; ids must lie in [0, num_node), eids in [0, 2^31), 2E < 2^32. */

@@ -121,3 +121,28 @@ def test_fused_eval_samples_from_the_collators_graph():
         out_ref = ref.contrast_learning(s, d_, n_, t, e, cg)
         for x, y in zip(out[1:4], out_ref[1:4]):
             assert rel_err(x.cpu().numpy(), y.cpu().numpy()) < 1e-5, b
+
+
+def test_batch_loader_equals_dataloader():
+    """BatchLoader (arrays + one native negative-sampling call per batch) against torch's DataLoader over the same
+    dataset and collator: identical batches, training-mode negatives included."""
+    from torch.utils.data import DataLoader
+    from www2023tiger_amd.data.data_loader import BatchLoader, ChunkSampler, InteractionData
+    z = load('eval_seq_lr_d8')
+    cfg = parse_cfg(z)
+    _, _, coll = build_hip_model(z, cfg, dropout=0.0)
+    lab = np.zeros(len(z['src']), dtype=np.int64)
+    mk = lambda: InteractionData(z['src'], z['dst'], z['ts'], z['eids'], lab, seed=9, eval=False)
+    ref = DataLoader(mk(), batch_size=64, shuffle=False, collate_fn=coll)
+    got = BatchLoader(mk(), 64, coll)
+    assert len(ref) == len(got)
+    for a, b in zip(ref, got):
+        for x, y in zip(a[:5], b[:5]):
+            assert torch.equal(x, y)
+        np.testing.assert_array_equal(a[6].np_computation_graph_nodes, b[6].np_computation_graph_nodes)
+    cs = ChunkSampler(len(lab), rank=1, world_size=2, bs=64, seed=3)
+    ref = DataLoader(mk(), batch_size=64, sampler=cs, collate_fn=coll)
+    got = BatchLoader(mk(), 64, coll, sampler=cs)
+    assert len(ref) == len(got)
+    for a, b in zip(ref, got):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[4], b[4])

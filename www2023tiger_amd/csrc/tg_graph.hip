@@ -474,3 +474,63 @@ extern "C" int tg_anonymized_reindex(int64_t n, int32_t H, const int64_t* in, in
   hipLaunchKernelGGL(k_anon_reindex, dim3(flat_grid(n, 4)), dim3(256), 0, as_stream(stream), n, H, in, out);
   return check_launch("tg_anonymized_reindex");
 }
+
+// ---------------------------------------------------------------------------------
+// Negative sampling stream of RandEdgeSampler (data_loader.py:283-313) for a whole batch.
+// The reference draws, per event, `rng.randint(0, n_src, 1)` then `rng.randint(0, n_dst, 1)` on a
+// numpy legacy RandomState: MT19937 32-bit outputs under the smallest covering bit mask, redrawn
+// while above the range (rk_random_uint64, range < 2^32).  Same state in, same state out as `count`
+// calls of RandEdgeSampler.sample(1).  Host routine: the stream is sequential by construction.
+// ---------------------------------------------------------------------------------
+namespace tg {
+struct HostMt {
+  uint32_t* key;
+  uint32_t pos;
+  uint32_t next() {
+    constexpr uint32_t UP = 0x80000000u, LO = 0x7fffffffu, MA = 0x9908b0dfu;
+    if (pos >= 624) {
+      int kk = 0;
+      for (; kk < 227; ++kk) {
+        const uint32_t y = (key[kk] & UP) | (key[kk + 1] & LO);
+        key[kk] = key[kk + 397] ^ (y >> 1) ^ ((y & 1u) ? MA : 0u);
+      }
+      for (; kk < 623; ++kk) {
+        const uint32_t y = (key[kk] & UP) | (key[kk + 1] & LO);
+        key[kk] = key[kk - 227] ^ (y >> 1) ^ ((y & 1u) ? MA : 0u);
+      }
+      const uint32_t y = (key[623] & UP) | (key[0] & LO);
+      key[623] = key[396] ^ (y >> 1) ^ ((y & 1u) ? MA : 0u);
+      pos = 0;
+    }
+    uint32_t y = key[pos++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+  }
+  int64_t below(int64_t n) {  // randint(0, n): n >= 1
+    const uint32_t rng = (uint32_t)(n - 1);
+    if (rng == 0) return 0;
+    uint32_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    uint32_t v;
+    while ((v = next() & mask) > rng) {
+    }
+    return (int64_t)v;
+  }
+};
+}  // namespace tg
+
+extern "C" int tg_rand_edge_pairs_host(uint32_t* mt_state, int64_t n_src, int64_t n_dst, int64_t count,
+                                       int64_t* src_idx, int64_t* dst_idx) {
+  if (!mt_state || n_src <= 0 || n_dst <= 0 || n_src > 0xffffffffLL || n_dst > 0xffffffffLL || count < 0) return TG_EINVAL;
+  if (count && (!src_idx || !dst_idx)) return TG_EINVAL;
+  tg::HostMt mt{mt_state, mt_state[624]};
+  for (int64_t i = 0; i < count; ++i) {
+    src_idx[i] = mt.below(n_src);
+    dst_idx[i] = mt.below(n_dst);
+  }
+  mt_state[624] = mt.pos;
+  return TG_OK;
+}

@@ -96,6 +96,19 @@ class RandEdgeSampler:
         di = self.rng.randint(0, len(self.dst_list), size)
         return self.src_list[si], self.dst_list[di]
 
+    def sample_pairs(self, count: int):
+        """`count` consecutive `sample(1)` calls in one native call (same RandomState stream, same
+        final state): the per-event draws of a training batch without a Python loop."""
+        from .._lib import check, lib, ptr
+        name, key, pos, has_gauss, cached = self.rng.get_state()
+        st = np.concatenate([key.astype(np.uint32), np.array([pos], dtype=np.uint32)])
+        si = np.empty(count, dtype=np.int64)
+        di = np.empty(count, dtype=np.int64)
+        check(lib.tg_rand_edge_pairs_host(ptr(st), len(self.src_list), len(self.dst_list), count, ptr(si), ptr(di)),
+              'tg_rand_edge_pairs_host')
+        self.rng.set_state((name, st[:624].copy(), int(st[624]), has_gauss, cached))
+        return self.src_list[si], self.dst_list[di]
+
     def reset_random_state(self):
         self.rng = np.random.RandomState(self.seed)
 
@@ -136,8 +149,42 @@ class InteractionData(torch.utils.data.Dataset):
     def __getitem__(self, i):
         return (self.src[i], self.dst[i], self.get_neg_dst_item(i), self.ts[i], self.eids[i], self.labels[i])
 
+    def get_batch(self, lo: int, hi: int):
+        """events [lo, hi) as arrays, negatives drawn exactly as `hi - lo` consecutive __getitem__ calls would"""
+        sl = slice(lo, hi)
+        neg = self.neg_dst[sl] if self.eval else self.neg_dst_sampler.sample_pairs(hi - lo)[1]
+        return self.src[sl], self.dst[sl], neg, self.ts[sl], self.eids[sl], self.labels[sl]
+
     def __len__(self):
         return len(self.ts)
+
+
+class BatchLoader:
+    """What the reference's loops need from `DataLoader(data, batch_size=bs, collate_fn=collator[, sampler=...])`
+    - iteration over collated batches in order, `len()` - without one Python `__getitem__` per event:
+    a batch is sliced as arrays, its negatives come from one native call that consumes the sampler's
+    RandomState stream exactly as the per-event draws would.  `sampler` may be a ChunkSampler (a contiguous
+    index range per epoch)."""
+
+    def __init__(self, dataset: 'InteractionData', batch_size: int, collate_fn: GraphCollator, sampler=None):
+        self.dataset, self.batch_size, self.collate_fn, self.sampler = dataset, batch_size, collate_fn, sampler
+
+    def _range(self):
+        if self.sampler is None:
+            return 0, len(self.dataset)
+        idx = list(iter(self.sampler))
+        if idx and idx != list(range(idx[0], idx[0] + len(idx))):
+            raise ValueError('BatchLoader needs a contiguous index range')
+        return (idx[0], idx[0] + len(idx)) if idx else (0, 0)
+
+    def __len__(self):
+        lo, hi = self._range() if self.sampler is None else (0, len(self.sampler))
+        return (hi - lo + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        lo, hi = self._range()
+        for a in range(lo, hi, self.batch_size):
+            yield self.collate_fn.collate_arrays(*self.dataset.get_batch(a, min(a + self.batch_size, hi)))
 
 
 class ChunkSampler(torch.utils.data.Sampler):

@@ -5,7 +5,7 @@ import math
 import torch
 from torch.utils.data import DataLoader
 
-from .data.data_loader import ChunkSampler, GraphCollator, load_jodie_data
+from .data.data_loader import BatchLoader, ChunkSampler, GraphCollator, load_jodie_data
 from .data.graph import Graph
 from .model.feature_getter import NumericalFeature
 from .model.restarters import SeqRestarter, StaticRestarter
@@ -31,7 +31,8 @@ def init_data(data, root, seed, rank=None, world_size=None, *, num_workers=0, bs
     full_graph = Graph.from_data(full_data, strategy=strategy, seed=seed, device=device)
     mk_coll = lambda g: GraphCollator(g, n_neighbors, n_layers, restarter=restarter_type, hist_len=hist_len)
     train_coll, eval_coll = mk_coll(train_graph), mk_coll(full_graph)
-    loader = lambda ds, coll, **kw: DataLoader(ds, batch_size=bs, collate_fn=coll, **kw)
+    # same iteration protocol as the reference's DataLoaders, batches sliced natively (no per-event Python)
+    loader = lambda ds, coll, **kw: BatchLoader(ds, bs, coll, **kw)
     if world_size is not None:  # the reference's DDP recipe: one time chunk per rank
         sampler = ChunkSampler(len(train_data), rank=rank, world_size=world_size, bs=bs, seed=seed)
         train_dl, offline_dl = loader(train_data, train_coll, sampler=sampler), None
