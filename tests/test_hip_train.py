@@ -184,14 +184,17 @@ def test_fused_trainer_mutual_trajectory():
         assert rel_err(p.detach().cpu().numpy(), z[f'final.{k}']) < 2e-3, k
 
 
-def test_reference_training_loop_with_torch_adam():
+@pytest.mark.parametrize('which', ['torch', 'device-flags'])
+def test_reference_training_loop_with_torch_adam(which):
     """The loop of train_self_supervised.py:143-171 written against the mirrored API only
-    (collator -> contrast_and_mutual_learning -> loss.backward() -> torch.optim.Adam.step()):
-    losses and final parameters of the reference run."""
+    (collator -> contrast_and_mutual_learning -> loss.backward() -> Adam.step()): losses and final
+    parameters of the reference run, with torch.optim.Adam (idle groups handed over as None, one host
+    read-back per backward) and with www2023tiger_amd.optim.Adam (live flags stay on the device)."""
+    from www2023tiger_amd import optim as tg_optim
     z = load('train_seq_lr_d8')
     cfg = parse_cfg(z)
     model, _, coll = build_hip_model(z, cfg, dropout=0.0)
-    optimizer = torch.optim.Adam(model.parameters(), lr=cfg['lr'])
+    optimizer = (torch.optim.Adam if which == 'torch' else tg_optim.Adam)(model.parameters(), lr=cfg['lr'])
     model.train()
     model.reset()
     restarting, uptodate = False, set()
@@ -224,6 +227,10 @@ def test_reference_training_loop_with_torch_adam():
                 assert grad_err(got, ref) < 2e-4, (b, k)
     for k, p in model.named_parameters():
         assert rel_err(p.detach().cpu().numpy(), z[f'final.{k}']) < 2e-3, k
+    if which != 'torch':  # the deferred path really ran: gradients are views of the step's flat buffer
+        tb = model._step_ws[('train', len(src_ids), True)]
+        assert all(p.grad is tb.grads[k] for k, p in model.named_parameters() if k in tb.grads)
+        model.flush_msg()  # polls the deferred invariant word
     # evaluation mode still takes the inference path
     model.eval()
     model.reset()

@@ -173,11 +173,17 @@ __global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
   const unsigned long long t_loop0 = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
   // tile t multiplies LDS[t & 1]; meanwhile tile t + D is loaded into the register slot tile t just
   // left (t % D) and tile t + 1 moves from its slot to the other LDS buffer
-  for (int kt = 0; kt < nkt; kt += D) {
+  // The loop body is straight-line (whole groups of D tiles; the remainder follows it): with a conditional
+  // tile inside the loop the compiler's wait-count bookkeeping loses track of which loads are pending at the
+  // joins and waits for ALL of them (vmcnt(0)) at the top of every tile, which throws the prefetch away.
+  int kt = 0;
+  for (; kt + D <= nkt; kt += D) {
 #pragma unroll
-    for (int j = 0; j < D; ++j)
-      if (kt + j < nkt) tile(j & 1, kt + j, ra[j], rb[j], ra[(j + 1) % D], rb[(j + 1) % D]);
+    for (int j = 0; j < D; ++j) tile(j & 1, kt + j, ra[j], rb[j], ra[(j + 1) % D], rb[(j + 1) % D]);
   }
+#pragma unroll
+  for (int j = 0; j < D - 1; ++j)
+    if (kt + j < nkt) tile(j & 1, kt + j, ra[j], rb[j], ra[(j + 1) % D], rb[(j + 1) % D]);
   const unsigned long long t_loop1 = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
   if (KS == 2) {  // fold the second k-group's partial sums into the first
     if (ks == 1) {
@@ -461,14 +467,29 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
   for (int i = 0; i < NOPS; ++i) store_one(0, 0, i, ra0, rb0);
   __syncthreads();
   const unsigned long long t_loop0 = (dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
-  for (int t = 0; t < nkt; t += 2) {
-    // even tile: multiply LDS[0]; load tile t+2 -> R0; store tile t+1 (R1) -> LDS[1]
-    if (t < nkx) tile(HP0{}, 0, t, ra0, rb0, ra1, rb1);
-    else tile(HP1{}, 0, t, ra0, rb0, ra1, rb1);
-    if (t + 1 < nkt) {
-      if (t + 1 < nkx) tile(HP0{}, 1, t + 1, ra1, rb1, ra0, rb0);
-      else tile(HP1{}, 1, t + 1, ra1, rb1, ra0, rb0);
+  // Message tiles (i_n plane) first, then memory tiles (h_n plane), each as its own straight-line loop
+  // over tile pairs, with the memory loops written out for both LDS-buffer parities.  A single loop with a
+  // per-tile phase test moved the accumulators between registers on every path (64 v_mov_b64 per pair)
+  // and its joins made the compiler wait for prefetched tiles half a tile early.
+  // even tile: multiply LDS[0]; load tile t+2 -> R0; store tile t+1 (R1) -> LDS[1]; odd tile: mirrored
+  int t = 0;
+  for (; t + 2 <= nkx; t += 2) {
+    tile(HP0{}, 0, t, ra0, rb0, ra1, rb1);
+    tile(HP0{}, 1, t + 1, ra1, rb1, ra0, rb0);
+  }
+  if (t < nkx) {  // odd number of message tiles: the memory tiles start in LDS[1]
+    tile(HP0{}, 0, t, ra0, rb0, ra1, rb1);
+    for (++t; t + 2 <= nkt; t += 2) {
+      tile(HP1{}, 1, t, ra1, rb1, ra0, rb0);
+      tile(HP1{}, 0, t + 1, ra0, rb0, ra1, rb1);
     }
+    if (t < nkt) tile(HP1{}, 1, t, ra1, rb1, ra0, rb0);
+  } else {
+    for (; t + 2 <= nkt; t += 2) {
+      tile(HP1{}, 0, t, ra0, rb0, ra1, rb1);
+      tile(HP1{}, 1, t + 1, ra1, rb1, ra0, rb0);
+    }
+    if (t < nkt) tile(HP1{}, 0, t, ra0, rb0, ra1, rb1);
   }
   const unsigned long long t_loop1 = (dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
   if (KS == 2) {  // fold the second k-group's partial sums into the first

@@ -250,16 +250,40 @@ class TIGE(nn.Module):
         cg_graph = getattr(computation_graph, 'graph', None)
         if cg_graph is None and hasattr(computation_graph, 'ts64'):
             raise NotImplementedError("training on device samples with strategy='recent_edges'")
+        # every parameter owned by www2023tiger_amd.optim.Adam: nothing is read back in this iteration (the
+        # invariant word of this batch is checked at the next one / flush_msg(), the live flags stay on the device)
+        deferred = tb.err_host is not None and all(getattr(p, '_tg_deferred', False) for _, p, _ in tb.params)
+        self._poll_train_errors()
         tb.launch(graph=cg_graph)  # sample where the collator sampled
-        word = int(tb.sb.err.item())
-        if word:
-            tb.sb.err.zero_()
-            from .._lib import raise_invariants
-            raise_invariants(word & 0xFFFFFFFF)
+        if deferred:
+            tb.err_host.copy_(tb.sb.err, non_blocking=True)
+            tb.err_event = torch.cuda.Event()
+            tb.err_event.record()
+        else:
+            word = int(tb.sb.err.item())
+            if word:
+                tb.sb.err.zero_()
+                from .._lib import raise_invariants
+                raise_invariants(word & 0xFFFFFFFF)
         grads = [(tb.grads[name], 1 if group == 2 else 0, group) for name, _, group in tb.params]
-        losses = hand_over(tb.losses, grads, tb.flags.clone(), [p for _, p, _ in tb.params])
+        losses = hand_over(tb.losses, grads, tb.flags if deferred else tb.flags.clone(),
+                           [p for _, p, _ in tb.params], tb if deferred else None)
         return (losses, tb.sb.h[:2 * B].clone(), tb.pos_scores.clone(), tb.neg_scores.clone(),
                 tb.sb.h_prev_left.clone(), tb.sb.h_prev_right.clone())
+
+    def _poll_train_errors(self):
+        """Deferred invariant check of the train steps launched without a read-back."""
+        for key, tb in self._step_ws.items():
+            ev = getattr(tb, 'err_event', None)
+            if ev is None:
+                continue
+            ev.synchronize()
+            tb.err_event = None
+            word = int(tb.err_host.item())
+            if word:
+                tb.sb.err.zero_()
+                from .._lib import raise_invariants
+                raise_invariants(word & 0xFFFFFFFF)
 
     def contrast_learning(self, src_ids: Tensor, dst_ids: Tensor, neg_dst_ids: Tensor, ts: Tensor, eids: Tensor,
                           computation_graph) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
@@ -456,6 +480,7 @@ class TIGE(nn.Module):
     @torch.no_grad()
     def flush_msg(self):
         """tiger.py:444-455: consume every pending message into the right memory."""
+        self._poll_train_errors()
         dev = self.device
         m = self.model_struct()
         err = hip_ops.new_err(dev)
@@ -508,7 +533,7 @@ class TIGER(TIGE):
             losses, *_ = self._train_forward(src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph,
                                              mutual=not contrast_only)
             if contrast_only:
-                return losses[0], torch.tensor(0, device=losses.device)
+                return losses[0], torch.zeros((), dtype=torch.int64, device=losses.device)  # no host copy
             return losses[0], losses[1]
         with torch.no_grad():
             return self._contrast_and_mutual_eval(src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph,
@@ -519,7 +544,7 @@ class TIGER(TIGE):
         contrast_loss, *_, h_prev_left, h_prev_right = self.contrast_learning(
             src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph)
         if contrast_only:
-            return contrast_loss, torch.tensor(0, device=contrast_loss.device)
+            return contrast_loss, torch.zeros((), dtype=torch.int64, device=contrast_loss.device)
         dev = self.device
         index = computation_graph.restart_data.index
         unique_nids = torch.cat([src_ids, dst_ids]).to(dev)[index]
@@ -531,7 +556,7 @@ class TIGER(TIGE):
         if len(valid_rows):
             mutual_loss = self.mutual_loss_fn(preds[valid_rows], targets[valid_rows])
         else:
-            mutual_loss = torch.tensor(0, device=dev)
+            mutual_loss = torch.zeros((), dtype=torch.int64, device=dev)
         return contrast_loss, mutual_loss
 
     @torch.no_grad()

@@ -169,13 +169,23 @@ class TrainBuffers:
         n = sum(p.numel() for _, p, _ in self.params)
         self.gflat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grads, o = {}, 0
-        for name, p, _ in self.params:
+        self.n_contrast = 0  # gflat = [gradients of the contrast loss | gradients of the mutual loss]
+        for name, p, group in self.params:
             self.grads[name] = self.gflat[o:o + p.numel()].view_as(p)
+            self.grads[name]._tg_group = (None, group)  # completed below: (live flags, parameter group)
             o += p.numel()
+            if group != 2:
+                assert self.n_contrast == o - p.numel(), 'contrast parameters first'
+                self.n_contrast = o
         self.losses = torch.zeros(2, dtype=torch.float32, device=dev)
         self.pos_scores = torch.zeros(B, dtype=torch.float32, device=dev)
         self.neg_scores = torch.zeros(B, dtype=torch.float32, device=dev)
         self.flags = torch.zeros(4, dtype=torch.int32, device=dev)
+        for g in self.grads.values():
+            g._tg_group = (self.flags, g._tg_group[1])  # read by www2023tiger_amd.optim.Adam
+        # invariant word read back without stalling the loop (deferred mode): async copy + event
+        self.err_host = torch.zeros(1, dtype=torch.int32).pin_memory() if dev.type == 'cuda' else None
+        self.err_event = None
         self.rng = model.dropout_rng()  # dropout mask generator state {seed, step counter}, shared with restart()
         self.refresh()
 
@@ -237,25 +247,39 @@ class TrainBuffers:
 
 class _HandOver(torch.autograd.Function):
     """Connects the losses computed by tg_train_step to autograd: backward returns the gradients
-    the HIP backward pass already produced, scaled by the incoming loss gradient."""
+    the HIP backward pass already produced, scaled by the incoming loss gradient.
+
+    Deferred mode (every parameter is owned by www2023tiger_amd.optim.Adam): no host read-back.  The flat
+    gradient buffer is scaled in place and each parameter's `.grad` becomes its view of that buffer
+    (stable addresses: the optimizer's launch plan is built once); idle groups keep zero gradients
+    and are skipped by the optimizer on the device."""
 
     @staticmethod
-    def forward(ctx, losses, grads, flags, *params):
-        ctx.grads, ctx.flags = grads, flags
+    def forward(ctx, losses, grads, flags, buf, *params):
+        ctx.grads, ctx.flags, ctx.buf, ctx.params = grads, flags, buf, params
         return losses.clone()
 
     @staticmethod
     def backward(ctx, g_losses):
+        if ctx.buf is not None:
+            tb = ctx.buf
+            tb.gflat[:tb.n_contrast].mul_(g_losses[0])
+            if tb.n_contrast < tb.gflat.numel():
+                tb.gflat[tb.n_contrast:].mul_(g_losses[1])
+            for p, (g, _, _) in zip(ctx.params, ctx.grads):
+                p.grad = g
+            return (None,) * (4 + len(ctx.params))
         # grads: (gradient view, index of the loss it belongs to, parameter group).  A group whose flag
         # is 0 took no part in the graph this step: torch would leave .grad None (and Adam would skip
         # the parameter, step count included), so None is returned for it.
         live = ctx.flags.tolist()
         out = tuple((g * g_losses[k]) if live[grp] else None for g, k, grp in ctx.grads)
-        return (None, None, None) + out
+        return (None, None, None, None) + out
 
 
-def hand_over(losses: Tensor, grads: List[Tuple[Tensor, int, int]], flags: Tensor, params: List[Tensor]) -> Tensor:
-    return _HandOver.apply(losses, grads, flags, *params)
+def hand_over(losses: Tensor, grads: List[Tuple[Tensor, int, int]], flags: Tensor, params: List[Tensor],
+              deferred_buf=None) -> Tensor:
+    return _HandOver.apply(losses, grads, flags, deferred_buf, *params)
 
 
 class FusedTrainer:
