@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--restarter', default='static')
 ap.add_argument('--contrast-only', action='store_true')
 ap.add_argument('--steps', type=int, default=60)
+ap.add_argument('--eval', type=int, default=0, help='time eval_edge_prediction with this batch size instead')
 ap.add_argument('--adam', default='torch', choices=['torch', 'device-flags'])
 ap.add_argument('--item', action='store_true', help='read the loss back every iteration, as the reference loop does')
 args = ap.parse_args()
@@ -33,6 +34,22 @@ coll = GraphCollator(model.graph, c['K'], 1, restarter=args.restarter, hist_len=
 dl = BatchLoader(data, B, coll)
 from www2023tiger_amd import optim as tg_optim  # noqa: E402
 opt = (torch.optim.Adam if args.adam == 'torch' else tg_optim.Adam)(model.parameters(), lr=1e-4)
+if args.eval:
+    from www2023tiger_amd.eval_utils import eval_edge_prediction
+    n = args.steps * args.eval
+    rs = np.random.RandomState(1)
+    ev = InteractionData(st['src'][:n], st['dst'][:n], st['ts'][:n], st['eids'][:n], np.zeros(n, dtype=np.int64), seed=0,
+                         eval=True, neg_dst=rs.randint(c['n_u'] + 1, c['n_u'] + c['n_i'] + 1, n))
+    edl = BatchLoader(ev, args.eval, coll)
+    model.eval()
+    for rep in range(2):
+        model.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ap_, auc_ = eval_edge_prediction(model, edl, dev, restart_mode=False)
+        dt = time.perf_counter() - t0
+    print(f'eval_edge_prediction bs={args.eval}: {dt / args.steps * 1e3:.3f} ms/batch, {n / dt / 1e6:.3f} M events/s, AP {ap_:.4f}')
+    sys.exit(0)
 model.train()
 t0 = None
 for i, (src, dst, neg, ts, eids, _, cg) in enumerate(dl):

@@ -57,6 +57,7 @@ def eval_edge_prediction(model, dl, device: torch.device, restart_mode: bool, up
                                                                        comp_graph)
             pos_all.append(pos_scores.sigmoid())
             neg_all.append(neg_scores.sigmoid())
+    model._poll_train_errors()  # the last batch's invariant word (the one-call step reads it back asynchronously)
     if not pos_all:
         return float('nan'), float('nan')
     ap, auc, bad = ap_auc_windows(torch.cat(pos_all), torch.cat(neg_all), mean_over_n_samples)
@@ -76,4 +77,5 @@ def warmup(model, dl, device: torch.device, uptodate_nodes: Optional[set] = None
             comp_graph.to(device)
             _lazy_restart(model, comp_graph, ts, uptodate_nodes, device)
             model.contrast_learning(src_ids, dst_ids, neg_dst_ids, ts, eids, comp_graph)
+    model._poll_train_errors()
     return uptodate_nodes

@@ -320,12 +320,18 @@ class TIGE(nn.Module):
         tb.sb.load(to(src_ids), to(dst_ids), to(neg_dst_ids), computation_graph.ts64, to(eids))
         # the collator's graph, not model.graph: the reference embeds with the neighbourhoods the collator
         # sampled (e.g. warm-up batches are collated on the training graph while model.graph is the full one)
+        self._poll_train_errors()  # invariant word of the previous batch (read back asynchronously, no stall)
         tb.launch(graph=getattr(computation_graph, 'graph', None))
-        word = int(tb.sb.err.item())
-        if word:
-            tb.sb.err.zero_()
-            from .._lib import raise_invariants
-            raise_invariants(word & 0xFFFFFFFF)
+        if tb.err_host is not None:
+            tb.err_host.copy_(tb.sb.err, non_blocking=True)
+            tb.err_event = torch.cuda.Event()
+            tb.err_event.record()
+        else:
+            word = int(tb.sb.err.item())
+            if word:
+                tb.sb.err.zero_()
+                from .._lib import raise_invariants
+                raise_invariants(word & 0xFFFFFFFF)
         return (tb.losses[0].clone(), tb.sb.h[:2 * B].clone(), tb.pos_scores.clone(), tb.neg_scores.clone(),
                 tb.sb.h_prev_left.clone(), tb.sb.h_prev_right.clone())
 
