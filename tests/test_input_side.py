@@ -94,3 +94,29 @@ def test_interaction_data_get_batch_equals_getitem():
         got = b.get_batch(40, 140)
         for col in range(6):
             np.testing.assert_array_equal(np.array([it[col] for it in items]), got[col])
+
+
+def test_optim_adam_plain_path_equals_torch_adam():
+    """www2023tiger_amd.optim.Adam on gradients from ordinary autograd (no fused train step): the
+    torch-op fallback follows torch.optim.Adam step for step, and parameters without a gradient are
+    skipped (no state, no step count), as torch does."""
+    import torch
+    from www2023tiger_amd.optim import Adam
+    torch.manual_seed(0)
+    a = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2))]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    oa, ob = Adam(a, lr=3e-3, betas=(0.8, 0.95), eps=1e-6), torch.optim.Adam(b, lr=3e-3, betas=(0.8, 0.95), eps=1e-6)
+    assert all(getattr(p, '_tg_deferred', False) for p in a)
+    for it in range(6):
+        for ps, opt in ((a, oa), (b, ob)):
+            opt.zero_grad()
+            x = torch.arange(15, dtype=torch.float32).reshape(5, 3) * 0.1 + it
+            loss = ((ps[0] * x).sum() - 1.0) ** 2 + (ps[1] ** 3).sum() * (it % 2)  # ps[1] idle on even iterations
+            loss.backward()
+            if it % 2 == 0:
+                ps[1].grad = None
+            opt.step()
+    for p, q in zip(a, b):
+        assert torch.allclose(p, q, rtol=1e-6, atol=1e-7)
+    assert a[2].grad is None and 'exp_avg' not in oa.state[a[2]]
+    assert oa.state[a[1]]['step'] == 3 and oa.state[a[0]]['step'] == 6

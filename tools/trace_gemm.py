@@ -27,12 +27,11 @@ nb = min(4096, 8 * ((M + 63) // 64 + 7) // 8 * ((N + 63) // 64))
 buf = np.zeros(4 * nb, dtype=np.uint64)
 raw.tg_debug_gemm_trace(buf.ctypes.data_as(C.c_void_p), nb)
 t = buf.reshape(nb, 4).astype(np.int64)
-t = t[t[:, 3] > 0]
+t = t[(t[:, 3] > 0) & (t[:, 0] > 0)]
 t0 = t[:, 0].min()
 pro, loop, epi = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
-print(f'blocks {len(t)}  (s_memtime ticks = 100 MHz: x24 for 2.4 GHz core cycles)')
+print(f'blocks {len(t)}  (s_memtime ticks; compare with the kernel duration to get the tick rate)')
 print('prologue  mean %.0f  loop mean %.0f (%.0f per k-tile)  epilogue mean %.0f' % (pro.mean(), loop.mean(), loop.mean() / ((K + 31) // 32), epi.mean()))
-print('first entry -> last exit: %d ticks = %.2f us' % (t[:, 3].max() - t0, (t[:, 3].max() - t0) / 100.0))
-print('entry spread: %.2f us' % ((t[:, 0].max() - t0) / 100.0))
+print('first entry -> last exit: %d ticks; entry spread %d ticks; block lifetime mean %d' % (t[:, 3].max() - t0, t[:, 0].max() - t0, (t[:, 3] - t[:, 0]).mean()))
 ref = x @ w.t() + b
 print('max err', float((out - ref).abs().max()))

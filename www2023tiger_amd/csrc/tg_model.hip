@@ -139,38 +139,38 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
         acc[h][0][v] = acc[h][1][v] = acc[h][2][v] = z4;
       }
     }
-    float4 ya[NV], yn[NV], yb[NV];  // raw rows of the NEXT key (in flight)
-    auto fetch = [&](int k) {
+    // Raw rows of the next keys travel in a ring of PD register slots while the current key is reduced:
+    // a wave's keys are a chain of dependent gathers (row address <- key metadata), and with ~3 waves per
+    // SIMD at C2 nothing else covers their latency.  Keys are reduced in list order whatever PD is, so the
+    // result does not depend on it.
+    constexpr int PD = NV == 1 ? 3 : 2;
+    float4 ya[PD][NV], yn[PD][NV], yb[PD][NV];
+    auto fetch = [&](int slot, int k) {
       const int64_t u = __shfl(u_l, k, TG_WAVE);
       const int64_t nb = __shfl(nb_l, k, TG_WAVE);
       const int64_t eid = __shfl(eid_l, k, TG_WAVE);
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const int c = lane + v * TG_WAVE;
-        ya[v] = c < d4 ? reprs[u * d4 + c] : z4;
-        yn[v] = (nf && c < d4) ? nf[nb * d4 + c] : z4;
-        yb[v] = (ef && c < e4) ? ef[eid * e4 + c] : z4;
+        ya[slot][v] = c < d4 ? reprs[u * d4 + c] : z4;
+        yn[slot][v] = (nf && c < d4) ? nf[nb * d4 + c] : z4;
+        yb[slot][v] = (ef && c < e4) ? ef[eid * e4 + c] : z4;
       }
     };
-    int k = live ? (__ffsll(live) - 1) : -1;
-    if (k >= 0) fetch(k);
-    while (k >= 0) {
-      live &= live - 1;
-      const int kn = live ? (__ffsll(live) - 1) : -1;
+    auto reduce = [&](int slot, int k) {
       const float dt = __shfl(dt_l, k, TG_WAVE);
       float4 x[3][NV];
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const int c = lane + v * TG_WAVE;
-        float4 a = ya[v];
-        a.x += yn[v].x; a.y += yn[v].y; a.z += yn[v].z; a.w += yn[v].w;
+        float4 a = ya[slot][v];
+        a.x += yn[slot][v].x; a.y += yn[slot][v].y; a.z += yn[slot][v].z; a.w += yn[slot][v].w;
         x[0][v] = a;
-        x[1][v] = yb[v];
+        x[1][v] = yb[slot][v];
         x[2][v] = c < d4 ? make_float4(time_enc(dt, w4[v].x, p4[v].x), time_enc(dt, w4[v].y, p4[v].y),
                                        time_enc(dt, w4[v].z, p4[v].z), time_enc(dt, w4[v].w, p4[v].w))
                          : z4;
       }
-      if (kn >= 0) fetch(kn);  // next key's rows travel while this key is reduced
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         float p = 0.f;
@@ -202,7 +202,31 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
 #pragma unroll
           for (int v = 0; v < NV; ++v) axpy4(acc[h][sgm][v], b, x[sgm][v]);
       }
-      k = kn;
+    };
+    unsigned long long todo = live;  // fetch cursor over the live keys, in list order
+    auto next_key = [&]() {
+      const int k = todo ? (__ffsll(todo) - 1) : -1;
+      todo &= todo - 1;
+      return k;
+    };
+    int ks[PD];
+#pragma unroll
+    for (int sl = 0; sl < PD; ++sl) {
+      ks[sl] = next_key();
+      if (ks[sl] >= 0) fetch(sl, ks[sl]);
+    }
+    while (ks[0] >= 0) {
+      bool more = true;
+#pragma unroll
+      for (int sl = 0; sl < PD; ++sl) {
+        if (more && ks[sl] >= 0) {
+          reduce(sl, ks[sl]);
+          ks[sl] = next_key();  // the slot is free: the key PD places further on starts travelling
+          if (ks[sl] >= 0) fetch(sl, ks[sl]);
+        } else {
+          more = false;  // the cursor ran dry before this slot was refilled: nothing is left anywhere
+        }
+      }
     }
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
