@@ -80,34 +80,75 @@ __device__ __forceinline__ void scale4(float4& s, float a) {
 
 // One wavefront per centre.  Streams its K neighbour rows once: node part
 // reprs[local]+nfeat, edge part efeat, time part cos(dt*w+phi); per head an online
-// softmax over the keys accumulates the weighted raw row.  Rows are float4 per lane
-// (NV float4 per segment per lane, i.e. widths up to 256*NV).
+// softmax over the keys accumulates the weighted raw row.  A lane owns W consecutive columns
+// of every segment (NV such groups, i.e. widths up to 64*W*NV); W is picked per model so that
+// the 64 lanes are as full as possible: the kernel is VALU-bound (time encoding + 2*NH fmas per
+// column and key), and d = 172 fills 43 lanes as float4 but 58 lanes as three floats.
 // Latency structure: lane k first resolves key k's metadata (neighbour id -> local row via
 // the rank popcount, edge id, dt) for all K keys at once, the per-key loop then only
-// broadcasts it, and the raw rows of key k+1 are requested before key k is reduced.
-template <int NH, int NV>
+// broadcasts it, and the raw rows of the next keys are requested before key k is reduced.
+template <int W>
+struct RowVec {
+  float a[W];
+};
+struct __attribute__((packed, aligned(4))) F3 {
+  float x, y, z;
+};
+// columns [col, col+W) of a row of `width` floats (row 16-byte aligned, width % 4 == 0); zeros past the end
+template <int W>
+__device__ __forceinline__ RowVec<W> row_load(const float* __restrict__ row, int col, int width) {
+  RowVec<W> r;
+  if (W == 4) {
+    const float4 v = col < width ? *reinterpret_cast<const float4*>(row + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    r.a[0] = v.x; r.a[1] = v.y; r.a[2] = v.z; r.a[W - 1] = v.w;
+  } else if (W == 3) {
+    if (col + 3 <= width) {
+      const F3 v = *reinterpret_cast<const F3*>(row + col);
+      r.a[0] = v.x; r.a[1] = v.y; r.a[W - 1] = v.z;
+    } else {  // the lane that straddles the row end (one per wave) and the idle lanes
+#pragma unroll
+      for (int j = 0; j < W; ++j) r.a[j] = col + j < width ? row[col + j] : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < W; ++j) r.a[j] = col + j < width ? row[col + j] : 0.f;
+  }
+  return r;
+}
+template <int W>
+__device__ __forceinline__ void row_store(float* __restrict__ row, int col, int width, const RowVec<W>& r) {
+  if (W == 4) {
+    if (col < width) *reinterpret_cast<float4*>(row + col) = make_float4(r.a[0], r.a[1], r.a[2], r.a[W - 1]);
+  } else if (W == 3 && col + 3 <= width) {
+    F3 v;
+    v.x = r.a[0]; v.y = r.a[1]; v.z = r.a[W - 1];
+    *reinterpret_cast<F3*>(row + col) = v;
+  } else {
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+      if (col + j < width) row[col + j] = r.a[j];
+  }
+}
+
+template <int NH, int NV, int W>
 __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const float* __restrict__ ts,
                                                    const int64_t* __restrict__ l1_nids,
                                                    const int64_t* __restrict__ l1_eids, const float* __restrict__ l1_ts,
-                                                   const float4* __restrict__ reprs, const uint64_t* __restrict__ bm,
-                                                   const uint32_t* __restrict__ rank, const float4* __restrict__ G,
-                                                   float4* __restrict__ S, uint8_t* __restrict__ valid, DropCfg dc,
+                                                   const float* __restrict__ reprs, const uint64_t* __restrict__ bm,
+                                                   const uint32_t* __restrict__ rank, const float* __restrict__ G,
+                                                   float* __restrict__ S, uint8_t* __restrict__ valid, DropCfg dc,
                                                    float* __restrict__ rsum) {
+  using V = RowVec<W>;
   const int lane = lane_id();
   const uint64_t dkey = drop_key(dc);
-  const int d4 = m.d / 4, e4 = m.d_e / 4, K = m.n_neighbors;
-  const int kv4 = 2 * d4 + e4;
-  const float4* nf = reinterpret_cast<const float4*>(m.nfeats);
-  const float4* ef = reinterpret_cast<const float4*>(m.efeats);
-  const float4* fq = reinterpret_cast<const float4*>(m.te_freq);
-  const float4* ph = reinterpret_cast<const float4*>(m.te_phase);
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 w4[NV], p4[NV];
+  const int d = m.d, de = m.d_e, K = m.n_neighbors;
+  const int kvw = 2 * d + de;
+  V w4[NV], p4[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    const int c = lane + v * TG_WAVE;
-    w4[v] = c < d4 ? fq[c] : z4;
-    p4[v] = c < d4 ? ph[c] : z4;
+    const int c = (lane + v * TG_WAVE) * W;
+    w4[v] = row_load<W>(m.te_freq, c, d);
+    p4[v] = row_load<W>(m.te_phase, c, d);
   }
   for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < Q; i += (int64_t)gridDim.x * 4) {
     // ---- per-key metadata, one key per lane
@@ -122,21 +163,22 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
     }
     unsigned long long live = __ballot(nb_l != 0);  // padding keys are masked (temporal_agg_modules.py:80)
     const bool any = live != 0ull;
-    float4 g[NH][3][NV], acc[NH][3][NV];
+    V g[NH][3][NV], acc[NH][3][NV];
     float mx[NH], l[NH], lk[NH];  // lk: sum of the kept exponentials (dropout), same rescaling as l
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       mx[h] = -INFINITY;
       l[h] = 0.f;
       lk[h] = 0.f;
-      const float4* gh = G + ((int64_t)i * NH + h) * kv4;
+      const float* gh = G + ((int64_t)i * NH + h) * kvw;
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
-        const int c = lane + v * TG_WAVE;
-        g[h][0][v] = c < d4 ? gh[c] : z4;
-        g[h][1][v] = c < e4 ? gh[d4 + c] : z4;
-        g[h][2][v] = c < d4 ? gh[d4 + e4 + c] : z4;
-        acc[h][0][v] = acc[h][1][v] = acc[h][2][v] = z4;
+        const int c = (lane + v * TG_WAVE) * W;
+        g[h][0][v] = row_load<W>(gh, c, d);
+        g[h][1][v] = row_load<W>(gh + d, c, de);
+        g[h][2][v] = row_load<W>(gh + d + de, c, d);
+#pragma unroll
+        for (int j = 0; j < W; ++j) acc[h][0][v].a[j] = acc[h][1][v].a[j] = acc[h][2][v].a[j] = 0.f;
       }
     }
     // Raw rows of the next keys travel in a ring of PD register slots while the current key is reduced:
@@ -144,32 +186,31 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
     // SIMD at C2 nothing else covers their latency.  Keys are reduced in list order whatever PD is, so the
     // result does not depend on it.
     constexpr int PD = NV == 1 ? 3 : 2;
-    float4 ya[PD][NV], yn[PD][NV], yb[PD][NV];
+    V ya[PD][NV], yn[PD][NV], yb[PD][NV];
     auto fetch = [&](int slot, int k) {
       const int64_t u = __shfl(u_l, k, TG_WAVE);
       const int64_t nb = __shfl(nb_l, k, TG_WAVE);
       const int64_t eid = __shfl(eid_l, k, TG_WAVE);
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
-        const int c = lane + v * TG_WAVE;
-        ya[slot][v] = c < d4 ? reprs[u * d4 + c] : z4;
-        yn[slot][v] = (nf && c < d4) ? nf[nb * d4 + c] : z4;
-        yb[slot][v] = (ef && c < e4) ? ef[eid * e4 + c] : z4;
+        const int c = (lane + v * TG_WAVE) * W;
+        ya[slot][v] = row_load<W>(reprs + u * d, c, d);
+        yn[slot][v] = row_load<W>(m.nfeats ? m.nfeats + nb * d : reprs, c, m.nfeats ? d : 0);
+        yb[slot][v] = row_load<W>(m.efeats ? m.efeats + eid * de : reprs, c, m.efeats ? de : 0);
       }
     };
     auto reduce = [&](int slot, int k) {
       const float dt = __shfl(dt_l, k, TG_WAVE);
-      float4 x[3][NV];
+      V x[3][NV];
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
-        const int c = lane + v * TG_WAVE;
-        float4 a = ya[slot][v];
-        a.x += yn[slot][v].x; a.y += yn[slot][v].y; a.z += yn[slot][v].z; a.w += yn[slot][v].w;
-        x[0][v] = a;
-        x[1][v] = yb[slot][v];
-        x[2][v] = c < d4 ? make_float4(time_enc(dt, w4[v].x, p4[v].x), time_enc(dt, w4[v].y, p4[v].y),
-                                       time_enc(dt, w4[v].z, p4[v].z), time_enc(dt, w4[v].w, p4[v].w))
-                         : z4;
+        const int c = (lane + v * TG_WAVE) * W;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          x[0][v].a[j] = ya[slot][v].a[j] + yn[slot][v].a[j];
+          x[1][v].a[j] = yb[slot][v].a[j];
+          x[2][v].a[j] = c + j < d ? time_enc(dt, w4[v].a[j], p4[v].a[j]) : 0.f;
+        }
       }
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
@@ -177,7 +218,9 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
 #pragma unroll
         for (int sgm = 0; sgm < 3; ++sgm)
 #pragma unroll
-          for (int v = 0; v < NV; ++v) p = dot4(g[h][sgm][v], x[sgm][v], p);
+          for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int j = 0; j < W; ++j) p = fmaf(g[h][sgm][v].a[j], x[sgm][v].a[j], p);
         p = wave_sum(p);  // wave-uniform
         float b = 1.f;
         if (p > mx[h]) {  // new running maximum: rescale what has been accumulated (uniform branch)
@@ -187,7 +230,9 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
 #pragma unroll
           for (int sgm = 0; sgm < 3; ++sgm)
 #pragma unroll
-            for (int v = 0; v < NV; ++v) scale4(acc[h][sgm][v], a);
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+              for (int j = 0; j < W; ++j) acc[h][sgm][v].a[j] *= a;
           mx[h] = p;
         } else {
           b = expf(p - mx[h]);
@@ -200,7 +245,9 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
 #pragma unroll
         for (int sgm = 0; sgm < 3; ++sgm)
 #pragma unroll
-          for (int v = 0; v < NV; ++v) axpy4(acc[h][sgm][v], b, x[sgm][v]);
+          for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int j = 0; j < W; ++j) acc[h][sgm][v].a[j] = fmaf(b, x[sgm][v].a[j], acc[h][sgm][v].a[j]);
       }
     };
     unsigned long long todo = live;  // fetch cursor over the live keys, in list order
@@ -231,19 +278,17 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const float inv = any ? 1.f / l[h] : 0.f;
-      float4* sh = S + ((int64_t)i * NH + h) * kv4;
+      float* sh = S + ((int64_t)i * NH + h) * kvw;
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
-        const int c = lane + v * TG_WAVE;
-        float4 a = acc[h][0][v], b = acc[h][1][v], t = acc[h][2][v];
-        a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv;
-        b.x *= inv; b.y *= inv; b.z *= inv; b.w *= inv;
-        t.x *= inv; t.y *= inv; t.z *= inv; t.w *= inv;
-        if (c < d4) {
-          sh[c] = a;
-          sh[d4 + e4 + c] = t;
-        }
-        if (c < e4) sh[d4 + c] = b;
+        const int c = (lane + v * TG_WAVE) * W;
+#pragma unroll
+        for (int sgm = 0; sgm < 3; ++sgm)
+#pragma unroll
+          for (int j = 0; j < W; ++j) acc[h][sgm][v].a[j] *= inv;
+        row_store<W>(sh, c, d, acc[h][0][v]);
+        row_store<W>(sh + d, c, de, acc[h][1][v]);
+        row_store<W>(sh + d + de, c, d, acc[h][2][v]);
       }
     }
     if (lane == 0) {
@@ -311,16 +356,28 @@ void launch_attn_core(const tg_model* m, int64_t Q, const float* ts, const int64
                       const DropCfg& dc, hipStream_t st, int* rc_out) {
   const int d = m->d, d_e = m->d_e, nh = m->n_head;
   *rc_out = TG_OK;
-  const int nv = (int)cdiv(std::max(d, d_e) / 4, TG_WAVE);
+  // Columns per lane: float4.  Three columns per lane fill 58 of 64 lanes at d = 172 instead of 43 and cut
+  // the VALU work per key by a quarter, but measured SLOWER (29.7 vs 24.3 us at C2): the 12-byte accesses
+  // straddle 16-byte sectors and the gather, not the arithmetic, sets the pace.  Kept as a knob.
+  const int wmax = std::max(d, d_e);
+  int W = 4, nv = (int)cdiv(cdiv(wmax, 4), TG_WAVE);
+  {
+    const int nv3 = (int)cdiv(cdiv(wmax, 3), TG_WAVE);
+    static const int w_knob = getenv("TG_ATTN_W") ? atoi(getenv("TG_ATTN_W")) : 0;  // tuning knob: 3, default 4
+    if (nv3 == 1 && w_knob == 3) { W = 3; nv = 1; }
+  }
   const unsigned cgrid = flat_grid(Q, 4);
-#define TG_CORE(NH_, NV_)                                                                                          \
-  hipLaunchKernelGGL((k_attn_core<NH_, NV_>), dim3(cgrid), dim3(256), 0, st, *m, Q, ts, l1_nids, l1_eids, l1_ts,   \
-                     (const float4*)reprs, bm, rank, (const float4*)w.g, (float4*)w.s, w.valid, dc,                 \
+#define TG_CORE(NH_, NV_, W_)                                                                                      \
+  hipLaunchKernelGGL((k_attn_core<NH_, NV_, W_>), dim3(cgrid), dim3(256), 0, st, *m, Q, ts, l1_nids, l1_eids,      \
+                     l1_ts, reprs, bm, rank, (const float*)w.g, w.s, w.valid, dc,                                  \
                      dc.p > 0.f ? w.rsum : (float*)nullptr)
-  if (nh == 2 && nv == 1) TG_CORE(2, 1);
-  else if (nh == 2 && nv == 2) TG_CORE(2, 2);
-  else if (nh == 1 && nv == 1) TG_CORE(1, 1);
-  else if (nh == 4 && nv == 1) TG_CORE(4, 1);
+  if (nh == 2 && nv == 1 && W == 3) TG_CORE(2, 1, 3);
+  else if (nh == 1 && nv == 1 && W == 3) TG_CORE(1, 1, 3);
+  else if (nh == 4 && nv == 1 && W == 3) TG_CORE(4, 1, 3);
+  else if (nh == 2 && nv == 1) TG_CORE(2, 1, 4);
+  else if (nh == 2 && nv == 2) TG_CORE(2, 2, 4);
+  else if (nh == 1 && nv == 1) TG_CORE(1, 1, 4);
+  else if (nh == 4 && nv == 1) TG_CORE(4, 1, 4);
   else *rc_out = TG_EUNSUPPORTED;
 #undef TG_CORE
 }
