@@ -301,15 +301,15 @@ def main():
         'store_events': P * (4 * (3 * d + d_e) + 4) + 2 * B * 4 * d + B * 4 * d_e,
     }
     flops_by_stage = {'apply_messages(gru)': 2.0 * O_ * 3 * d * ((3 * d + d_e) + d)}
-    kernel_of_stage = {'apply_messages(gru)': 'tg::k_gru<4, 2>', 'attn_core(gather+softmax)': 'tg::k_attn_core<2, 1>',
+    kernel_of_stage = {'apply_messages(gru)': 'tg::k_gru<4, 2>', 'attn_core(gather+softmax)': 'tg::k_attn_core<2, 1, 4>',
                        'gather_right_memory': 'tg::k_consume_gather_check', 'sample_recent_edges': 'tg::k_sample_batch<16>'}
     name = names[dom]
     t_s = stage_ms[dom] * 1e-3
-    # fabric/HBM bytes per launch of that kernel from the committed PMC passes (profiles/r01_hbm_traffic_v5.json,
+    # fabric/HBM bytes per launch of that kernel from the committed PMC passes (profiles/r01_hbm_traffic_v8.json,
     # collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command); null if not recorded
     traffic = None
     try:
-        tfile = {'c2': 'r01_hbm_traffic_v5.json', 'c5s': 'r01_hbm_traffic_c5s_v6.json'}.get(args.workload)
+        tfile = {'c2': 'r01_hbm_traffic_v8.json', 'c5s': 'r01_hbm_traffic_c5s_v6.json'}.get(args.workload)
         tj = json.load(open(os.path.join(ROOT, 'profiles', tfile))) if tfile else {'kernels': {}}
         traffic = tj['kernels'].get(kernel_of_stage.get(name, ''), {}).get('bytes_per_launch')
     except (OSError, ValueError):
