@@ -47,7 +47,25 @@ struct GemmArgs {
   const float* bias2;
   const uint8_t* bias2_valid;
   int dbg;  // diagnostic bits, 0 in production
+  // A operand assembled from the stream-K pieces of the producing product (gemm_sk_partials) instead of a0 / a1:
+  // A[m, k] = act(ask_alpha * (sum of pieces + ask_bias[k] + ask_valid[m] * ask_bias2[k]))
+  const float* ask_part;
+  int ask_U, ask_nkt, ask_NT;
+  const float *ask_bias, *ask_bias2;
+  const uint8_t* ask_valid;
+  int ask_relu;
+  float ask_alpha;
 };
+constexpr int TG_SK_WORKERS = 256;
+constexpr size_t TG_SK_WS_FLOATS = (size_t)TG_SK_WORKERS * 2 * 4096;
+// stream-K plan of a product that cannot fill the chip (see tg_gemm.hip)
+struct SkPlan {
+  int U, nkt, tiles, NT;  // units per worker, k-tiles per tile, tiles, column tiles
+  float* part;            // [workers][2][64 * 64]
+};
+// Launches the piece kernel for `g` (bias / activation of g are NOT applied: the consumer applies them) and
+// returns true, or returns false (nothing launched) when the shape does not call for it.
+bool gemm_sk_partials(const GemmArgs& g, float* ws, size_t ws_floats, hipStream_t st, SkPlan* plan);
 
 int gemm_launch(const GemmArgs& g, hipStream_t st);
 

@@ -34,8 +34,16 @@ __device__ __forceinline__ void sts4(float* row, int k, float4 v) {
 // diagnostic only (TG_GEMM_DBG=16): per-block s_memtime stamps {entry, loop start, loop end, exit}
 __device__ unsigned long long g_gemm_trace[4096 * 4];
 
-template <int WM, int WN, int KS, int D>
-__global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16& acc, float bias, float bias2,
+                                              int64_t m0, int64_t M, int n0, int wm, int wn, int fr, int fk, int bz);
+
+// One output tile over the k-tiles [kt_begin, kt_end).  raw == nullptr: the normal epilogue; otherwise the
+// accumulators are stored unmodified as a row-major [BM][BN] piece for a later fixed-order sum (stream-K
+// partials, below).  ASK: the A operand is not read from a0 / a1 but assembled from such pieces while it
+// is staged: A[m, k] = act(alpha * (sum of the pieces of element (m, k) + bias[k] + valid[m] * bias2[k])).
+template <int WM, int WN, int KS, int D, bool ASK = false>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, int64_t mt, int nt, int bz, int kt_begin, int kt_end,
+                                          float* __restrict__ raw, int trace_slot) {
   const unsigned long long t_entry = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
   // KS = 2: a second group of four wavefronts takes the other half of every tile's k-steps into its
   // own accumulators (summed through LDS at the end).  For the under-filled launches of the C2 shapes
@@ -53,12 +61,6 @@ __global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
   __shared__ float Bs[2][BN][LDK];
   __shared__ float red[KS == 2 ? 4 : 1][KS == 2 ? 16 : 1][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, ks = tid >> 8;
-  const int NT = (g.n + BN - 1) / BN;
-  const int per = NT * g.nbatch;
-  const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
-  const int64_t mt = (int64_t)(s / per) * 8 + xcd;
-  const int rem = s % per;
-  const int nt = rem % NT, bz = rem / NT;
   int64_t M = g.m_cap;
   if (g.m_dev) M = min(M, (int64_t)*g.m_dev);
   const int64_t m0 = mt * BM;
@@ -80,6 +82,14 @@ __global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
     arow0[i] = a0p + (g.a0.idx ? g.a0.idx[m] : m) * g.a0.ld;
     arow1[i] = g.a1.p ? g.a1.p + (g.a1.idx ? g.a1.idx[m] : m) * g.a1.ld - kw0 : arow0[i];
   }
+  int amloc[NA];       // ASK: row inside the producer's 64-row tile, validity byte of the row
+  uint8_t avalid[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int64_t m = min(m0 + ar + i * RP, M - 1);
+    amloc[i] = (int)(m & 63);
+    avalid[i] = (ASK && g.ask_valid) ? g.ask_valid[m] : 0;
+  }
   const float* wrow[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
@@ -94,13 +104,37 @@ __global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
   // kernel is a chain of dependent tile loads, so the prefetch distance sets its duration
   static_assert(D >= 2 && D % 2 == 0, "even prefetch depth");
   float4 ra[D][NA], rb[D][NB];
-  const int nkt = (K + BK - 1) / BK;
+  float4 rx[D][ASK ? NA : 1][4];  // ASK: second / third piece, bias, second bias of every staged A float4
+  const int nkt = kt_end;  // tiles past the end are clamped to the last one of the range
+  // ASK: the pieces of element column k of this block's row tile (producer tile T = mt * NT_p + k / 64)
+  auto ask_pieces = [&](int kc, int64_t* wsel, int* psel, bool* have) {
+    const int64_t ua = ((int64_t)mt * g.ask_NT + (kc >> 6)) * g.ask_nkt, ub = ua + g.ask_nkt;
+    const int64_t w0 = ua / g.ask_U;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int64_t w = w0 + j;
+      have[j] = w * g.ask_U < ub;
+      wsel[j] = have[j] ? w : w0;
+      psel[j] = wsel[j] * g.ask_U < ua ? 1 : 0;  // a worker that started in the previous tile holds this one second
+    }
+  };
   // i-th staged float4 of tile kt (i < NA: A, else W): raw load from a clamped address; columns
   // past K are zeroed when the tile is written to LDS, so nothing waits on the load here
-  auto load_one = [&](int kt, int i, float4* ra, float4* rb) {
+  auto load_one = [&](int kt, int i, float4* ra, float4* rb, float4 (*rx)[4]) {
     const int k = kt * BK + ac4;
     const int kc = k < K ? k : 0;
-    if (i < NA) {
+    if (ASK && i < NA) {
+      int64_t wsel[3];
+      int psel[3];
+      bool have[3];
+      ask_pieces(kc, wsel, psel, have);
+      const size_t off = (size_t)amloc[i] * 64 + (kc & 63);
+      ra[i] = ldg4(g.ask_part + ((size_t)wsel[0] * 2 + psel[0]) * 4096 + off);
+      rx[i][0] = ldg4(g.ask_part + ((size_t)wsel[1] * 2 + psel[1]) * 4096 + off);
+      rx[i][1] = ldg4(g.ask_part + ((size_t)wsel[2] * 2 + psel[2]) * 4096 + off);
+      rx[i][2] = ldg4(g.ask_bias + kc);
+      rx[i][3] = ldg4((g.ask_bias2 ? g.ask_bias2 : g.ask_bias) + kc);
+    } else if (i < NA) {
       ra[i] = ldg4((kc < kw0 ? arow0[i] : arow1[i]) + kc);
     } else if (!g.w_kmajor) {
       rb[i - NA] = ldg4(wrow[i - NA] + kc);
@@ -109,9 +143,28 @@ __global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
       rb[i - NA] = ldg4(wrow[i - NA] + (int64_t)min(kk, K - 1) * g.ldw);
     }
   };
-  auto store_one = [&](int buf, int kt, int i, const float4* ra, const float4* rb) {
+  auto store_one = [&](int buf, int kt, int i, const float4* ra, const float4* rb, const float4 (*rx)[4]) {
     const bool kin = kt * BK + ac4 < K;
-    if (i < NA) {
+    if (ASK && i < NA) {
+      int64_t wsel[3];
+      int psel[3];
+      bool have[3];
+      ask_pieces(kin ? kt * BK + ac4 : 0, wsel, psel, have);
+      const bool b2 = g.ask_bias2 && avalid[i];
+      auto fin = [&](float p0, float p1, float p2, float b, float c) {
+        float v = p0;
+        if (have[1]) v += p1;
+        if (have[2]) v += p2;
+        v = g.ask_alpha * (v + (b2 ? b + c : b));
+        if (g.ask_relu) v = fmaxf(v, 0.f);
+        return kin ? v : 0.f;
+      };
+      sts4(As[buf][ar + i * RP], ac4,
+           make_float4(fin(ra[i].x, rx[i][0].x, rx[i][1].x, rx[i][2].x, rx[i][3].x),
+                       fin(ra[i].y, rx[i][0].y, rx[i][1].y, rx[i][2].y, rx[i][3].y),
+                       fin(ra[i].z, rx[i][0].z, rx[i][1].z, rx[i][2].z, rx[i][3].z),
+                       fin(ra[i].w, rx[i][0].w, rx[i][1].w, rx[i][2].w, rx[i][3].w)));
+    } else if (i < NA) {
       sts4(As[buf][ar + i * RP], ac4, kin ? ra[i] : zero4());
     } else if (!g.w_kmajor) {
       sts4(Bs[buf][ar + (i - NA) * RP], ac4, kin ? rb[i - NA] : zero4());
@@ -139,7 +192,8 @@ __global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
   // in-order wave make bursts of loads / ds_writes stall the matrix pipe, so tile t+2's
   // global loads and tile t+1's LDS writes are threaded between the MFMAs of tile t, with
   // the operand fragments read one k-step pair ahead.  One barrier per tile.
-  auto tile = [&](int buf, int kt, float4* la, float4* lb, const float4* sa, const float4* sb) {
+  auto tile = [&](int buf, int kt, float4* la, float4* lb, float4 (*lx)[4], const float4* sa, const float4* sb,
+                  const float4 (*sx)[4]) {
     const int tl = min(kt + D, nkt - 1);
     const float* ap = &As[buf][wm * 32 + fr][fk + 4 * PP * ks];  // this wave group's share of the k-steps
     const float* bp = &Bs[buf][wn * 32 + fr][fk + 4 * PP * ks];
@@ -155,8 +209,8 @@ __global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
       __builtin_amdgcn_sched_barrier(0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
       if ((pr % (PP / 2)) < NOPS) {
-        if (pr < PP / 2) load_one(tl, pr % (PP / 2), la, lb);
-        else store_one(buf ^ 1, kt + 1, pr % (PP / 2), sa, sb);
+        if (pr < PP / 2) load_one(tl, pr % (PP / 2), la, lb, lx);
+        else store_one(buf ^ 1, kt + 1, pr % (PP / 2), sa, sb, sx);
       }
       __builtin_amdgcn_sched_barrier(0);
       a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
@@ -166,9 +220,9 @@ __global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
 #pragma unroll
   for (int j = 0; j < D; ++j)
 #pragma unroll
-    for (int i = 0; i < NOPS; ++i) load_one(min(j, nkt - 1), i, ra[j], rb[j]);
+    for (int i = 0; i < NOPS; ++i) load_one(min(kt_begin + j, nkt - 1), i, ra[j], rb[j], rx[j]);
 #pragma unroll
-  for (int i = 0; i < NOPS; ++i) store_one(0, 0, i, ra[0], rb[0]);
+  for (int i = 0; i < NOPS; ++i) store_one(0, kt_begin, i, ra[0], rb[0], rx[0]);
   __syncthreads();
   const unsigned long long t_loop0 = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
   // tile t multiplies LDS[t & 1]; meanwhile tile t + D is loaded into the register slot tile t just
@@ -176,14 +230,15 @@ __global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
   // The loop body is straight-line (whole groups of D tiles; the remainder follows it): with a conditional
   // tile inside the loop the compiler's wait-count bookkeeping loses track of which loads are pending at the
   // joins and waits for ALL of them (vmcnt(0)) at the top of every tile, which throws the prefetch away.
-  int kt = 0;
+  int kt = kt_begin;
   for (; kt + D <= nkt; kt += D) {
 #pragma unroll
-    for (int j = 0; j < D; ++j) tile(j & 1, kt + j, ra[j], rb[j], ra[(j + 1) % D], rb[(j + 1) % D]);
+    for (int j = 0; j < D; ++j)
+      tile(j & 1, kt + j, ra[j], rb[j], rx[j], ra[(j + 1) % D], rb[(j + 1) % D], rx[(j + 1) % D]);
   }
 #pragma unroll
   for (int j = 0; j < D - 1; ++j)
-    if (kt + j < nkt) tile(j & 1, kt + j, ra[j], rb[j], ra[(j + 1) % D], rb[(j + 1) % D]);
+    if (kt + j < nkt) tile(j & 1, kt + j, ra[j], rb[j], rx[j], ra[(j + 1) % D], rb[(j + 1) % D], rx[(j + 1) % D]);
   const unsigned long long t_loop1 = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
   if (KS == 2) {  // fold the second k-group's partial sums into the first
     if (ks == 1) {
@@ -195,6 +250,25 @@ __global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += red[wave][r][lane];
   }
+  if (raw) {  // partial sums of a split tile, row-major [BM][BN]: a wave store covers two full 128-byte rows
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      raw[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk) * BN + wn * 32 + fr] = acc[r];
+    return;
+  }
+  gemm_epilogue(g, acc, bias, bias2, m0, M, n0, wm, wn, fr, fk, bz);
+  if ((g.dbg & 16) && tid == 0 && trace_slot >= 0 && trace_slot < 4096) {
+    g_gemm_trace[trace_slot * 4 + 0] = t_entry;
+    g_gemm_trace[trace_slot * 4 + 1] = t_loop0;
+    g_gemm_trace[trace_slot * 4 + 2] = t_loop1;
+    g_gemm_trace[trace_slot * 4 + 3] = __builtin_amdgcn_s_memtime();
+  }
+}
+
+// the epilogue of one wave's 32x32 tile: bias / scale / activation / optional per-row operands / store
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16& acc, float bias, float bias2,
+                                                   int64_t m0, int64_t M, int n0, int wm, int wn, int fr, int fk, int bz) {
+  const int N = g.n;
   const int n = n0 + wn * 32 + fr;
   if (n >= N) return;
   float* cp = g.c + (int64_t)bz * g.c_bs;
@@ -260,16 +334,67 @@ __global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
       }
     }
   }
-  if ((g.dbg & 16) && tid == 0 && blockIdx.x < 4096) {
-    g_gemm_trace[blockIdx.x * 4 + 0] = t_entry;
-    g_gemm_trace[blockIdx.x * 4 + 1] = t_loop0;
-    g_gemm_trace[blockIdx.x * 4 + 2] = t_loop1;
-    g_gemm_trace[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
-  }
 }
 
 extern "C" int tg_debug_gemm_trace(unsigned long long* out_host, int n_blocks) {
   return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_gemm_trace), sizeof(unsigned long long) * 4 * n_blocks) == hipSuccess ? 0 : -4;
+}
+
+template <int WM, int WN, int KS, int D, bool ASK = false>
+__global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
+  constexpr int BN = 32 * WN;
+  const int NT = (g.n + BN - 1) / BN;
+  const int per = NT * g.nbatch;
+  const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
+  const int64_t mt = (int64_t)(s / per) * 8 + xcd;
+  const int rem = s % per;
+  gemm_tile<WM, WN, KS, D, ASK>(g, mt, rem % NT, rem / NT, 0, (g.k + BK - 1) / BK, nullptr, (int)blockIdx.x);
+}
+
+// ---- stream-K for launches that cannot fill the chip --------------------------------------------------
+// A product with fewer 64x64 tiles than CUs and a long K (the merged value/out/fc1 product of the fused
+// attention: 144 tiles x 38 k-tiles on 256 CUs) leaves CUs idle for its whole duration.  Here the
+// (tile, k-tile) units are dealt evenly: worker w owns units [w U, (w+1) U) of the tile-major sequence, i.e.
+// the tail of one tile and/or the head of the next, and stores each piece's accumulators in its own slot.
+// Nobody waits for anybody: the pieces of a tile are summed, in worker order (a fixed order: deterministic),
+// by the CONSUMER of the product while it stages its A operand (gemm_tile<..., ASK>), together with the
+// producer's bias / activation.  nkt / 2 <= U < nkt is required (every tile is split into two or three pieces).
+template <int KS, int D>
+__global__ void __launch_bounds__(256 * KS) k_gemm_sk(GemmArgs g, SkPlan sk) {
+  const int64_t total = (int64_t)sk.tiles * sk.nkt;
+  int64_t u = (int64_t)blockIdx.x * sk.U;
+  const int64_t u1 = min(u + sk.U, total);
+  int piece = 0;
+  while (u < u1) {  // at most two pieces (U < nkt)
+    const int T = (int)(u / sk.nkt), kt0 = (int)(u % sk.nkt);
+    const int kt1 = (int)min((int64_t)sk.nkt, kt0 + (u1 - u));
+    gemm_tile<2, 2, KS, D>(g, T / sk.NT, T % sk.NT, 0, kt0, kt1, sk.part + ((size_t)blockIdx.x * 2 + piece) * 4096, -1);
+    __syncthreads();  // the LDS tiles are re-used by the next piece
+    u += kt1 - kt0;
+    ++piece;
+  }
+}
+
+bool gemm_sk_partials(const GemmArgs& g, float* ws, size_t ws_floats, hipStream_t st, SkPlan* plan) {
+  static const int sk_knob = getenv("TG_GEMM_SK") ? atoi(getenv("TG_GEMM_SK")) : 1;  // tuning knob: 0 = off
+  if (!sk_knob || !ws || g.m_cap <= 0 || g.nbatch != 1 || g.m_dev || (g.k % 4) || (g.a0.w % 4) || (g.ldw % 4) ||
+      g.a0.w + (g.a1.p ? g.a1.w : 0) != g.k)
+    return false;
+  SkPlan p{};
+  p.NT = (int)cdiv(g.n, 64);
+  p.tiles = (int)(cdiv(g.m_cap, 64) * p.NT);
+  p.nkt = (int)cdiv(g.k, BK);
+  if (p.tiles >= TG_SK_WORKERS || p.nkt < 16) return false;
+  p.U = (int)cdiv((int64_t)p.tiles * p.nkt, (int64_t)TG_SK_WORKERS);
+  const int workers = (int)cdiv((int64_t)p.tiles * p.nkt, (int64_t)p.U);
+  if (p.U >= p.nkt || 2 * p.U < p.nkt || p.U < 4 || ws_floats < (size_t)workers * 2 * 4096) return false;
+  p.part = ws;
+  static const int gdbg = getenv("TG_GEMM_DBG") ? atoi(getenv("TG_GEMM_DBG")) : 0;
+  GemmArgs gd = g;
+  gd.dbg = gdbg & ~16;
+  hipLaunchKernelGGL((k_gemm_sk<2, 2>), dim3(workers), dim3(512), 0, st, gd, p);
+  *plan = p;
+  return true;
 }
 
 int gemm_launch(const GemmArgs& g, hipStream_t st) {
@@ -289,7 +414,10 @@ int gemm_launch(const GemmArgs& g, hipStream_t st) {
   GemmArgs gd = g;
   gd.dbg = gdbg;
   static const int depth_knob = getenv("TG_GEMM_DEPTH") ? atoi(getenv("TG_GEMM_DEPTH")) : 2;  // tuning knob: 2 / 4
-  if (split)
+  if (g.ask_part) {  // A assembled from stream-K pieces of a 64-row-tiled producer with g.k output columns
+    if (g.nbatch != 1 || g.w_kmajor || g.k != g.a0.w || !g.ask_bias || g.ask_NT != (int)cdiv(g.k, 64)) return TG_EINVAL;
+    hipLaunchKernelGGL((k_gemm<2, 2, 1, 2, true>), dim3((unsigned)grid), dim3(256), 0, st, gd);
+  } else if (split)
     hipLaunchKernelGGL((k_gemm<2, 2, 2, 2>), dim3((unsigned)grid), dim3(512), 0, st, gd);
   else if (depth_knob == 2)
     hipLaunchKernelGGL((k_gemm<2, 2, 1, 2>), dim3((unsigned)grid), dim3(256), 0, st, gd);

@@ -320,13 +320,14 @@ static bool carve_attn(const tg_model* m, int64_t Q, Carver& cv, AttnWs& w) {
   w.qconst = cv.take<float>((size_t)2 * d);
   w.rsum = cv.take<float>((size_t)Q * nh);
   w.valid = cv.take<uint8_t>((size_t)Q);
+  w.sk = cv.take<float>(TG_SK_WS_FLOATS);
   return cv.ok;
 }
 
 static size_t attn_ws_bytes(const tg_model* m, int64_t Q) {
   const size_t d = m->d, kvw = 2 * m->d + m->d_e, nh = m->n_head;
   return align16(Q * d * 4) * 2 + align16(Q * 2 * d * 4) * 3 + align16(Q * nh * kvw * 4) * 2 + align16(2 * d * 4) +
-         align16(Q * nh * 4) + align16(Q);
+         align16(Q * nh * 4) + align16(Q) + align16(TG_SK_WS_FLOATS * 4);
 }
 
 }  // namespace tg
@@ -414,11 +415,19 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
   g.a0 = ASeg{w.s, f.nk, f.nk, nullptr}; g.a1 = ASeg{w.cc, d, d, nullptr};
   g.w = f.w1f; g.ldw = f.nk + d; g.bias = f.b1; g.bias2 = f.c1; g.bias2_valid = w.valid;
   g.c = w.t; g.ldc = d; g.relu = 1; g.alpha = 1.f; g.nbatch = 1;
-  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  // C2-sized batches leave this product with fewer tiles than CUs: dealt as stream-K pieces, which fc2 sums
+  // (+ b1 + valid * c1, ReLU) while it stages its A operand; otherwise the plain product writes t
+  SkPlan sk{};
+  const bool pieces = gemm_sk_partials(g, w.sk, TG_SK_WS_FLOATS, st, &sk);
+  if (!pieces && (rc = gemm_launch(g, st)) != TG_OK) return rc;
   prof_mark(pf, stage++, st);
   g = GemmArgs{};
   g.m_cap = Q; g.n = d; g.k = d;
   g.a0 = ASeg{w.t, d, d, nullptr};
+  if (pieces) {
+    g.ask_part = sk.part; g.ask_U = sk.U; g.ask_nkt = sk.nkt; g.ask_NT = sk.NT;
+    g.ask_bias = f.b1; g.ask_bias2 = f.c1; g.ask_valid = w.valid; g.ask_relu = 1; g.ask_alpha = 1.f;
+  }
   g.w = m->attn_fc2.w; g.ldw = d; g.bias = m->attn_fc2.b;
   g.c = out; g.ldc = d; g.alpha = 1.f; g.nbatch = 1;
   if ((rc = gemm_launch(g, st)) != TG_OK) return rc;

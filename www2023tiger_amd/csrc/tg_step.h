@@ -34,6 +34,7 @@ struct AttnWs {
   float *cc, *qp, *g, *s, *o, *hh, *t, *qconst;
   float* rsum;  // [Q, n_head] sum of the kept, rescaled attention probabilities (training with dropout)
   uint8_t* valid;
+  float* sk;  // stream-K partial tiles of the merged fc1 product (TG_SK_WS_FLOATS)
 };
 
 struct StepWs {
