@@ -51,6 +51,7 @@ struct GemmArgs {
   // A[m, k] = act(ask_alpha * (sum of pieces + ask_bias[k] + ask_valid[m] * ask_bias2[k]))
   const float* ask_part;
   int ask_U, ask_nkt, ask_NT;
+  float ask_rcpU;  // set by gemm_launch
   const float *ask_bias, *ask_bias2;
   const uint8_t* ask_valid;
   int ask_relu;
@@ -60,7 +61,7 @@ constexpr int TG_SK_WORKERS = 256;
 constexpr size_t TG_SK_WS_FLOATS = (size_t)TG_SK_WORKERS * 2 * 4096;
 // stream-K plan of a product that cannot fill the chip (see tg_gemm.hip)
 struct SkPlan {
-  int U, nkt, tiles, NT;  // units per worker, k-tiles per tile, tiles, column tiles
+  int U, nkt, tiles, NT, MT;  // units per worker, k-tiles per tile, tiles, column tiles, row tiles
   float* part;            // [workers][2][64 * 64]
 };
 // Launches the piece kernel for `g` (bias / activation of g are NOT applied: the consumer applies them) and

@@ -107,15 +107,20 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int64_t mt, int nt,
   float4 rx[D][ASK ? NA : 1][4];  // ASK: second / third piece, bias, second bias of every staged A float4
   const int nkt = kt_end;  // tiles past the end are clamped to the last one of the range
   // ASK: the pieces of element column k of this block's row tile (producer tile T = mt * NT_p + k / 64)
-  auto ask_pieces = [&](int kc, int64_t* wsel, int* psel, bool* have) {
-    const int64_t ua = ((int64_t)mt * g.ask_NT + (kc >> 6)) * g.ask_nkt, ub = ua + g.ask_nkt;
-    const int64_t w0 = ua / g.ask_U;
+  auto ask_pieces = [&](int kc, int* wsel, int* psel, bool* have) {
+    // (units are dealt per XCD: row tile mt belongs to XCD mt % 8, whose workers are blockIdx = 8 j + mt % 8)
+    const int U = g.ask_U;
+    const int ua = (((int)mt >> 3) * g.ask_NT + (kc >> 6)) * g.ask_nkt, ub = ua + g.ask_nkt;
+    int j0 = (int)((float)ua * g.ask_rcpU);  // ua / U without the integer-division sequence (ua < 2^20: exact after the fix-up)
+    j0 += ((j0 + 1) * U <= ua) ? 1 : 0;
+    j0 -= (j0 * U > ua) ? 1 : 0;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int64_t w = w0 + j;
-      have[j] = w * g.ask_U < ub;
-      wsel[j] = have[j] ? w : w0;
-      psel[j] = wsel[j] * g.ask_U < ua ? 1 : 0;  // a worker that started in the previous tile holds this one second
+    for (int jj = 0; jj < 3; ++jj) {
+      const int j = j0 + jj;
+      have[jj] = j * U < ub;
+      const int jc = have[jj] ? j : j0;
+      wsel[jj] = jc * 8 + ((int)mt & 7);
+      psel[jj] = jc * U < ua ? 1 : 0;  // a worker that started in the previous tile holds this one second
     }
   };
   // i-th staged float4 of tile kt (i < NA: A, else W): raw load from a clamped address; columns
@@ -124,8 +129,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int64_t mt, int nt,
     const int k = kt * BK + ac4;
     const int kc = k < K ? k : 0;
     if (ASK && i < NA) {
-      int64_t wsel[3];
-      int psel[3];
+      int wsel[3], psel[3];
       bool have[3];
       ask_pieces(kc, wsel, psel, have);
       const size_t off = (size_t)amloc[i] * 64 + (kc & 63);
@@ -146,8 +150,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int64_t mt, int nt,
   auto store_one = [&](int buf, int kt, int i, const float4* ra, const float4* rb, const float4 (*rx)[4]) {
     const bool kin = kt * BK + ac4 < K;
     if (ASK && i < NA) {
-      int64_t wsel[3];
-      int psel[3];
+      int wsel[3], psel[3];
       bool have[3];
       ask_pieces(kin ? kt * BK + ac4 : 0, wsel, psel, have);
       const bool b2 = g.ask_bias2 && avalid[i];
@@ -361,14 +364,19 @@ __global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
 // producer's bias / activation.  nkt / 2 <= U < nkt is required (every tile is split into two or three pieces).
 template <int KS, int D>
 __global__ void __launch_bounds__(256 * KS) k_gemm_sk(GemmArgs g, SkPlan sk) {
-  const int64_t total = (int64_t)sk.tiles * sk.nkt;
-  int64_t u = (int64_t)blockIdx.x * sk.U;
+  // Units are dealt per XCD (blockIdx % 8, as the hardware deals blocks): the row tiles mt = x (mod 8) belong to
+  // XCD x, as in k_gemm's map, and so do the consumer's blocks of these rows - every piece is written and read
+  // inside one XCD's L2 (32 workers x 2 slots x 16 KB = 1 MB of its 4 MB).
+  const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int64_t total = (int64_t)((sk.MT - x + 7) / 8) * sk.NT * sk.nkt;
+  int64_t u = (int64_t)j * sk.U;
   const int64_t u1 = min(u + sk.U, total);
   int piece = 0;
   while (u < u1) {  // at most two pieces (U < nkt)
-    const int T = (int)(u / sk.nkt), kt0 = (int)(u % sk.nkt);
+    const int lt = (int)(u / sk.nkt), kt0 = (int)(u % sk.nkt);
     const int kt1 = (int)min((int64_t)sk.nkt, kt0 + (u1 - u));
-    gemm_tile<2, 2, KS, D>(g, T / sk.NT, T % sk.NT, 0, kt0, kt1, sk.part + ((size_t)blockIdx.x * 2 + piece) * 4096, -1);
+    gemm_tile<2, 2, KS, D>(g, (int64_t)(lt / sk.NT) * 8 + x, lt % sk.NT, 0, kt0, kt1,
+                           sk.part + ((size_t)blockIdx.x * 2 + piece) * 4096, -1);
     __syncthreads();  // the LDS tiles are re-used by the next piece
     u += kt1 - kt0;
     ++piece;
@@ -382,11 +390,13 @@ bool gemm_sk_partials(const GemmArgs& g, float* ws, size_t ws_floats, hipStream_
     return false;
   SkPlan p{};
   p.NT = (int)cdiv(g.n, 64);
-  p.tiles = (int)(cdiv(g.m_cap, 64) * p.NT);
+  p.MT = (int)cdiv(g.m_cap, 64);
+  p.tiles = p.MT * p.NT;
   p.nkt = (int)cdiv(g.k, BK);
   if (p.tiles >= TG_SK_WORKERS || p.nkt < 16) return false;
-  p.U = (int)cdiv((int64_t)p.tiles * p.nkt, (int64_t)TG_SK_WORKERS);
-  const int workers = (int)cdiv((int64_t)p.tiles * p.nkt, (int64_t)p.U);
+  const int64_t units_xcd = cdiv((int64_t)p.MT, 8) * p.NT * p.nkt;  // of the fullest XCD
+  p.U = (int)cdiv(units_xcd, (int64_t)(TG_SK_WORKERS / 8));
+  const int workers = TG_SK_WORKERS;
   if (p.U >= p.nkt || 2 * p.U < p.nkt || p.U < 4 || ws_floats < (size_t)workers * 2 * 4096) return false;
   p.part = ws;
   static const int gdbg = getenv("TG_GEMM_DBG") ? atoi(getenv("TG_GEMM_DBG")) : 0;
@@ -416,7 +426,10 @@ int gemm_launch(const GemmArgs& g, hipStream_t st) {
   static const int depth_knob = getenv("TG_GEMM_DEPTH") ? atoi(getenv("TG_GEMM_DEPTH")) : 2;  // tuning knob: 2 / 4
   if (g.ask_part) {  // A assembled from stream-K pieces of a 64-row-tiled producer with g.k output columns
     if (g.nbatch != 1 || g.w_kmajor || g.k != g.a0.w || !g.ask_bias || g.ask_NT != (int)cdiv(g.k, 64)) return TG_EINVAL;
-    hipLaunchKernelGGL((k_gemm<2, 2, 1, 2, true>), dim3((unsigned)grid), dim3(256), 0, st, gd);
+    static const int ask_depth = getenv("TG_GEMM_ASK_DEPTH") ? atoi(getenv("TG_GEMM_ASK_DEPTH")) : 2;  // tuning knob: 2 / 4
+    gd.ask_rcpU = 1.0f / (float)g.ask_U;
+    if (ask_depth == 4) hipLaunchKernelGGL((k_gemm<2, 2, 1, 4, true>), dim3((unsigned)grid), dim3(256), 0, st, gd);
+    else hipLaunchKernelGGL((k_gemm<2, 2, 1, 2, true>), dim3((unsigned)grid), dim3(256), 0, st, gd);
   } else if (split)
     hipLaunchKernelGGL((k_gemm<2, 2, 2, 2>), dim3((unsigned)grid), dim3(512), 0, st, gd);
   else if (depth_knob == 2)
