@@ -191,8 +191,9 @@ class ResidentShardedStream:
     """Production form for a stream that is resident in HBM: balanced plans are prepared for
     every step up front, each rank's shard of the stream and the global stream sit on the
     device, and a step is  [hipGraph: embed shard] -> all-gather -> [hipGraph: write-back].
-    Send buffer per rank: 5B rows = [h(t-) src | h(t-) dst | h(neg) | h(t'+) src | h(t'+) dst]
-    (the step writes its outputs straight into it)."""
+    The step writes its outputs straight into one buffer of 5B rows,
+    [h(t'+) src | h(t'+) dst | h(t-) src | h(t-) dst | h(neg)]; the first 4B rows are what the other ranks'
+    write-back needs and what travels (the negatives' embeddings are outputs of the owner only)."""
 
     def __init__(self, model, stream: dict, owner: np.ndarray, rank: int, world: int, B: int, n_steps: int,
                  group=None, use_graphs: bool = True):
@@ -203,7 +204,7 @@ class ResidentShardedStream:
         dev, d = model.device, model.memory_dim
         Bg = B * world
         self.Bg, self.n_steps = Bg, n_steps
-        layout = (5 * B, 0, 3 * B, B)
+        layout = (4 * B, 2 * B, 0, B)  # rows per rank, base of h(t-), base of h(t'+), stride between src and dst rows
         keys = ('src', 'dst', 'neg', 'ts', 'eids')
         local = {k: [] for k in keys}
         left_rows, new_rows = [], []
@@ -222,9 +223,9 @@ class ResidentShardedStream:
                           for k in ('src', 'dst', 'ts', 'eids'))
         self.left_row, self.new_row = tod(left_rows, torch.int64), tod(new_rows, torch.int64)
         self.send = torch.zeros(5 * B, d, dtype=torch.float32, device=dev)
-        self.gathered = torch.zeros(world, 5 * B, d, dtype=torch.float32, device=dev)
-        self.buf = model.StepBuffers(model, B, False, resident=self.local, embed_only=True, h_out=self.send[:3 * B],
-                                     h_new_out=self.send[3 * B:])
+        self.gathered = torch.zeros(world, 4 * B, d, dtype=torch.float32, device=dev)
+        self.buf = model.StepBuffers(model, B, False, resident=self.local, embed_only=True, h_out=self.send[2 * B:],
+                                     h_new_out=self.send[:2 * B])
         self.err = hip_ops.new_err(dev)
         ms = model.model_struct()
         nbytes = int(lib.tg_stream_writeback_workspace_bytes(C.byref(ms), Bg))
@@ -267,7 +268,7 @@ class ResidentShardedStream:
         else:
             self.model.launch_step(self.buf)
         mark('embed')
-        all_gather_rows(self.send, self.world, self.group, out=self.gathered)
+        all_gather_rows(self.send[:4 * self.B], self.world, self.group, out=self.gathered)
         mark('all_gather')
         if self.g_wb is not None:
             self.g_wb.replay()
@@ -344,7 +345,7 @@ def bench_main(args, cfg, make_stream, build_models, rank, local_rank, world):
                                msg_src=cfg['msg_src'], upd_src=cfg['upd_src'], n_nodes=stream['n_nodes'], events=E,
                                mode='stream (no_grad) STEP 1-6',
                                parallelism=f'dst-owner event shards x{world} (capacity-balanced), replicated state, '
-                                           f'1 RCCL all-gather of {5 * B}x{d} f32 rows per rank per batch',
+                                           f'1 RCCL all-gather of {4 * B}x{d} f32 rows per rank per batch',
                                spilled_event_fraction=round(spilled, 4),
                                launch='2 hipGraphs + 1 all-gather per step' if use_graphs else 'eager launches + 1 all-gather per step'),
                    roofline=None, cpu_baseline=None)
