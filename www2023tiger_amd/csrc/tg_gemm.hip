@@ -428,7 +428,9 @@ int gemm_launch(const GemmArgs& g, hipStream_t st) {
     if (g.nbatch != 1 || g.w_kmajor || g.k != g.a0.w || !g.ask_bias || g.ask_NT != (int)cdiv(g.k, 64)) return TG_EINVAL;
     static const int ask_depth = getenv("TG_GEMM_ASK_DEPTH") ? atoi(getenv("TG_GEMM_ASK_DEPTH")) : 2;  // tuning knob: 2 / 4
     gd.ask_rcpU = 1.0f / (float)g.ask_U;
-    if (ask_depth == 4) hipLaunchKernelGGL((k_gemm<2, 2, 1, 4, true>), dim3((unsigned)grid), dim3(256), 0, st, gd);
+    static const int ask_ks = getenv("TG_GEMM_ASK_KS") ? atoi(getenv("TG_GEMM_ASK_KS")) : 2;  // tuning knob: 1 / 2 (measured 12.6 / 11.1 us)
+    if (ask_ks == 2) hipLaunchKernelGGL((k_gemm<2, 2, 2, 2, true>), dim3((unsigned)grid), dim3(512), 0, st, gd);
+    else if (ask_depth == 4) hipLaunchKernelGGL((k_gemm<2, 2, 1, 4, true>), dim3((unsigned)grid), dim3(256), 0, st, gd);
     else hipLaunchKernelGGL((k_gemm<2, 2, 1, 2, true>), dim3((unsigned)grid), dim3(256), 0, st, gd);
   } else if (split)
     hipLaunchKernelGGL((k_gemm<2, 2, 2, 2>), dim3((unsigned)grid), dim3(512), 0, st, gd);
