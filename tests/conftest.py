@@ -13,6 +13,21 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def pytest_sessionstart(session):
+    """The shared library is a build product (git-ignored): make sure it exists and is not older than its
+    sources before anything imports the package (hipcc cross-compiles gfx950 without a GPU)."""
+    import glob
+    import subprocess
+    csrc = os.path.join(ROOT, 'www2023tiger_amd', 'csrc')
+    lib = os.path.join(csrc, 'libtiger_hip.so')
+    srcs = glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.h')) + \
+        [os.path.join(ROOT, 'include', 'tiger_hip.h')]
+    if os.path.exists(lib) and os.path.getmtime(lib) >= max(os.path.getmtime(f) for f in srcs):
+        return
+    if os.path.exists('/opt/rocm/bin/hipcc'):
+        subprocess.run(['make', '-j4', '-C', csrc], check=True, stdout=subprocess.DEVNULL)
+
+
 def pytest_collection_modifyitems(config, items):
     """GPU tests are skipped (not failed) when no device is visible, so that
     `pytest tests/` without a marker expression works in the CPU container."""
