@@ -237,6 +237,10 @@ class ResidentShardedStream:
         self.g_embed = self.g_wb = None
         self.use_graphs = use_graphs
         self.steps_done = 0
+        # graph replays and the collective are ordered through an explicit stream: on the legacy null stream the
+        # order between a hipGraph launch and the event the process group records for its own stream is not
+        # reliable (a replay around the all-gather faulted when nothing else synchronised the phases)
+        self.stream = torch.cuda.Stream(device=dev) if (use_graphs and dev.type == 'cuda') else None
 
     def _launch_wb(self):
         ms = self.model.model_struct()
@@ -249,12 +253,18 @@ class ResidentShardedStream:
         side = torch.cuda.Stream(device=self.model.device)
         off_e, off_w = self.buf.offset.clone(), self.wb_off.clone()
         self.g_embed, self.g_wb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_embed, stream=side):
+        # thread_local: with the default (global) capture mode ANY thread's unsafe runtime call invalidates a
+        # capture in progress, and the RCCL process group runs a watchdog thread that polls the events of
+        # recent collectives (hipEventQuery) - an intermittently broken capture whose replay then faults
+        torch.cuda.synchronize()
+        with torch.cuda.graph(self.g_embed, stream=side, capture_error_mode='thread_local'):
             self.model.launch_step(self.buf)
-        with torch.cuda.graph(self.g_wb, stream=side):
+        with torch.cuda.graph(self.g_wb, stream=side, capture_error_mode='thread_local'):
             self._launch_wb()
         self.buf.offset.copy_(off_e)  # capture does not execute, but be explicit
         self.wb_off.copy_(off_w)
+        if self.stream is not None:
+            torch.cuda.synchronize()  # the eager steps ran on the current stream; replays continue on self.stream
 
     def step(self, debug: bool = False):
         assert self.steps_done < self.n_steps, 'resident stream exhausted'
@@ -263,18 +273,21 @@ class ResidentShardedStream:
             if debug:
                 torch.cuda.synchronize()
                 print(f'[dist debug] step {self.steps_done} {what} ok', flush=True)
-        if self.g_embed is not None:
-            self.g_embed.replay()
-        else:
-            self.model.launch_step(self.buf)
-        mark('embed')
-        all_gather_rows(self.send[:4 * self.B], self.world, self.group, out=self.gathered)
-        mark('all_gather')
-        if self.g_wb is not None:
-            self.g_wb.replay()
-        else:
-            self._launch_wb()
-        mark('writeback')
+        import contextlib
+        ctx = torch.cuda.stream(self.stream) if (self.stream is not None and self.g_embed is not None) else contextlib.nullcontext()
+        with ctx:
+            if self.g_embed is not None:
+                self.g_embed.replay()
+            else:
+                self.model.launch_step(self.buf)
+            mark('embed')
+            all_gather_rows(self.send[:4 * self.B], self.world, self.group, out=self.gathered)
+            mark('all_gather')
+            if self.g_wb is not None:
+                self.g_wb.replay()
+            else:
+                self._launch_wb()
+            mark('writeback')
         self.steps_done += 1
 
     def check_invariants(self):
