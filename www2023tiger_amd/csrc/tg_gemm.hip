@@ -745,55 +745,83 @@ __device__ __forceinline__ void tn_block(const TnArgs& a, int splits, int b) {
   const bool xin = kcol < a.k;
   const int kc = xin ? kcol : 0;
   const bool seg1 = kc >= a.x0.w;
-  float4 ry[2], rx[2];
-  auto load_chunk = [&](int64_t mb) {
+  // Two chunks travel in registers (sets A / B) while a third is multiplied from LDS, and the row indices of
+  // gathered X rows (mailbox / memory rows of the outdated nodes) are fetched one chunk further ahead, so that
+  // a chunk's row loads never wait for their index.  All loads are unconditional (rows clamped to M - 1, zeroed
+  // at the LDS store when past the split): the loop body is straight-line code with exact wait counts.
+  struct Regs {
+    float4 y[2], x[2];
+    int64_t row[2];
+  };
+  const int64_t* xidx = seg1 ? a.x1.idx : a.x0.idx;
+  auto load_index = [&](int64_t mb, Regs& r) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int64_t m = min(mb + sr + i * 16, M - 1);
-      ry[i] = ldg4(yb + m * a.ldy + ycol);
-      const float* xr = seg1 ? a.x1.p + (a.x1.idx ? a.x1.idx[m] : m) * a.x1.ld + (kc - a.x0.w)
-                             : x0b + (a.x0.idx ? a.x0.idx[m] : m) * a.x0.ld + kc;
-      rx[i] = ldg4(xr);
+      r.row[i] = xidx ? xidx[m] : m;
     }
   };
-  auto store_chunk = [&](int buf, int64_t mb) {
+  auto load_chunk = [&](int64_t mb, Regs& r) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t m = min(mb + sr + i * 16, M - 1);
+      r.y[i] = ldg4(yb + m * a.ldy + ycol);
+      const float* xr = seg1 ? a.x1.p + r.row[i] * a.x1.ld + (kc - a.x0.w) : x0b + r.row[i] * a.x0.ld + kc;
+      r.x[i] = ldg4(xr);
+    }
+  };
+  auto store_chunk = [&](int buf, int64_t mb, const Regs& r) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const bool live = mb + sr + i * 16 < m_hi;
-      *reinterpret_cast<float4*>(&Ys[buf][sr + i * 16][sc]) = (live && yin) ? ry[i] : zero4();
-      *reinterpret_cast<float4*>(&Xs[buf][sr + i * 16][sc]) = (live && xin) ? rx[i] : zero4();
+      *reinterpret_cast<float4*>(&Ys[buf][sr + i * 16][sc]) = (live && yin) ? r.y[i] : zero4();
+      *reinterpret_cast<float4*>(&Xs[buf][sr + i * 16][sc]) = (live && xin) ? r.x[i] : zero4();
     }
   };
   const bool do_bias = a.bias_out && kt == 0 && tid < TN_T;  // column sums of Y ride on the k-tile-0 blocks
   float bsum = 0.f;
-  if (m_lo < m_hi) {
-    load_chunk(m_lo);
-    store_chunk(0, m_lo);
-    __syncthreads();
-    int buf = 0;
-    for (int64_t mb = m_lo; mb < m_hi; mb += TN_MC) {
-      const bool more = mb + TN_MC < m_hi;
-      if (more) load_chunk(mb + TN_MC);
-      const float* yp = &Ys[buf][fk][wn * 32 + fr];
-      const float* xp = &Xs[buf][fk][wk * 32 + fr];
+  // chunk `mb` is in LDS[buf]: request chunk mb + 2 into `ld` (its indices are there already) and the indices of
+  // chunk mb + 3 into `nx`'s slot... (see the call sites), multiply, then move chunk mb + 1 from `stv` to LDS
+  auto step = [&](int buf, int64_t mb, Regs& ld, const Regs& stv) {
+    load_chunk(mb + 2 * TN_MC, ld);
+    const float* yp = &Ys[buf][fk][wn * 32 + fr];
+    const float* xp = &Xs[buf][fk][wk * 32 + fr];
 #pragma unroll
-      for (int s2 = 0; s2 < TN_MC / 2; ++s2)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yp[s2 * 2 * TN_LD], xp[s2 * 2 * TN_LD], acc, 0, 0, 0);
-      if (do_bias) {
-        if (a.bias_rs) {
-          for (int r = 0; r < TN_MC; ++r) {
-            const int64_t m = min(mb + r, M - 1);  // rows past m_hi are zero in Ys
-            bsum = fmaf(Ys[buf][r][tid], a.bias_rs[m * a.ld_brs + a.brs_col + bz], bsum);
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < TN_MC; ++r) bsum += Ys[buf][r][tid];
+    for (int s2 = 0; s2 < TN_MC / 2; ++s2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yp[s2 * 2 * TN_LD], xp[s2 * 2 * TN_LD], acc, 0, 0, 0);
+    if (do_bias) {
+      if (a.bias_rs) {
+        for (int r = 0; r < TN_MC; ++r) {
+          const int64_t m = min(mb + r, M - 1);  // rows past m_hi are zero in Ys
+          bsum = fmaf(Ys[buf][r][tid], a.bias_rs[m * a.ld_brs + a.brs_col + bz], bsum);
         }
+      } else {
+#pragma unroll
+        for (int r = 0; r < TN_MC; ++r) bsum += Ys[buf][r][tid];
       }
-      if (more) store_chunk(buf ^ 1, mb + TN_MC);
-      __syncthreads();
-      buf ^= 1;
     }
+    store_chunk(buf ^ 1, mb + TN_MC, stv);
+    __syncthreads();
+  };
+  if (m_lo < m_hi) {
+    Regs ra, rb;
+    load_index(m_lo, ra);
+    load_index(m_lo + TN_MC, rb);
+    load_chunk(m_lo, ra);
+    load_chunk(m_lo + TN_MC, rb);
+    store_chunk(0, m_lo, ra);
+    load_index(m_lo + 2 * TN_MC, ra);
+    __syncthreads();
+    int64_t mb = m_lo;
+    const int64_t m_pairs = m_lo + (m_hi - m_lo + TN_MC - 1) / TN_MC / 2 * (2 * TN_MC);  // end of the whole chunk pairs
+    for (; mb < m_pairs; mb += 2 * TN_MC) {
+      // even chunk from LDS[0]: chunk mb+2 -> ra, chunk mb+1 (rb) -> LDS[1]; then rb's indices for chunk mb+3
+      step(0, mb, ra, rb);
+      load_index(mb + 3 * TN_MC, rb);
+      step(1, mb + TN_MC, rb, ra);
+      load_index(mb + 4 * TN_MC, ra);
+    }
+    if (mb < m_hi) step(0, mb, ra, rb);
   }
   // partial tile -> part[sp][bz][n][k] (zeros when this split is empty)
   float* pp = a.part + ((int64_t)sp * a.nbatch + bz) * a.n * a.k;
