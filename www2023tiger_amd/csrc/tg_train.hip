@@ -266,27 +266,29 @@ __global__ void __launch_bounds__(256) k_attn_core_bwd(tg_model m, int64_t Q, co
         dg[h][0][v] = dg[h][1][v] = dg[h][2][v] = z4;
       }
     }
-    float4 ya[NV], yn[NV], yb[NV];
-    auto fetch = [&](int k) {
+    // raw rows of the next keys travel in a ring of PD register slots (see k_attn_core)
+    constexpr int PD = NV == 1 ? 3 : 2;
+    float4 ya[PD][NV], yn[PD][NV], yb[PD][NV];
+    auto fetch = [&](int slot, int k) {
       const int64_t u = __shfl(u_l, k, TG_WAVE);
       const int64_t nb = __shfl(nb_l, k, TG_WAVE);
       const int64_t eid = __shfl(eid_l, k, TG_WAVE);
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const int c = lane + v * TG_WAVE;
-        ya[v] = c < d4 ? reprs[u * d4 + c] : z4;
-        yn[v] = (nf && c < d4) ? nf[nb * d4 + c] : z4;
-        yb[v] = (ef && c < e4) ? ef[eid * e4 + c] : z4;
+        ya[slot][v] = c < d4 ? reprs[u * d4 + c] : z4;
+        yn[slot][v] = (nf && c < d4) ? nf[nb * d4 + c] : z4;
+        yb[slot][v] = (ef && c < e4) ? ef[eid * e4 + c] : z4;
       }
     };
-    auto build = [&](float dt, float4 (&x)[3][NV]) {
+    auto build = [&](int slot, float dt, float4 (&x)[3][NV]) {
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const int c = lane + v * TG_WAVE;
-        float4 a = ya[v];
-        a.x += yn[v].x; a.y += yn[v].y; a.z += yn[v].z; a.w += yn[v].w;
+        float4 a = ya[slot][v];
+        a.x += yn[slot][v].x; a.y += yn[slot][v].y; a.z += yn[slot][v].z; a.w += yn[slot][v].w;
         x[0][v] = a;
-        x[1][v] = yb[v];
+        x[1][v] = yb[slot][v];
         x[2][v] = c < d4 ? make_float4(time_enc(dt, w4[v].x, p4[v].x), time_enc(dt, w4[v].y, p4[v].y),
                                        time_enc(dt, w4[v].z, p4[v].z), time_enc(dt, w4[v].w, p4[v].w))
                          : z4;
@@ -296,15 +298,24 @@ __global__ void __launch_bounds__(256) k_attn_core_bwd(tg_model m, int64_t Q, co
     float p_l[NH], da_l[NH];
 #pragma unroll
     for (int h = 0; h < NH; ++h) p_l[h] = da_l[h] = 0.f;
-    unsigned long long live = live0;
-    int k = live ? (__ffsll(live) - 1) : -1;
-    if (k >= 0) fetch(k);
-    while (k >= 0) {
-      live &= live - 1;
-      const int kn = live ? (__ffsll(live) - 1) : -1;
+    unsigned long long todo = live0;  // fetch cursor over the live keys, in list order
+    auto next_key = [&]() {
+      const int kk = todo ? (__ffsll(todo) - 1) : -1;
+      todo &= todo - 1;
+      return kk;
+    };
+    int ks[PD];
+    auto prime = [&]() {
+      todo = live0;
+#pragma unroll
+      for (int sl = 0; sl < PD; ++sl) {
+        ks[sl] = next_key();
+        if (ks[sl] >= 0) fetch(sl, ks[sl]);
+      }
+    };
+    auto pass1 = [&](int slot, int k) {
       float4 x[3][NV];
-      build(__shfl(dt_l, k, TG_WAVE), x);
-      if (kn >= 0) fetch(kn);
+      build(slot, __shfl(dt_l, k, TG_WAVE), x);
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         float p = 0.f, q = 0.f;
@@ -322,7 +333,20 @@ __global__ void __launch_bounds__(256) k_attn_core_bwd(tg_model m, int64_t Q, co
           da_l[h] = q;
         }
       }
-      k = kn;
+    };
+    prime();
+    while (ks[0] >= 0) {
+      bool more = true;
+#pragma unroll
+      for (int sl = 0; sl < PD; ++sl) {
+        if (more && ks[sl] >= 0) {
+          pass1(sl, ks[sl]);
+          ks[sl] = next_key();
+          if (ks[sl] >= 0) fetch(sl, ks[sl]);
+        } else {
+          more = false;
+        }
+      }
     }
     // ---- softmax backward, one key per lane.  With attention dropout the weights that multiply
     // the values are a' = a * keep / (1 - p); the value bias enters as bv * sum_j a'_j, so
@@ -350,17 +374,11 @@ __global__ void __launch_bounds__(256) k_attn_core_bwd(tg_model m, int64_t Q, co
       s_l[h] = a * (da - dot);
     }
     // ---- pass 2: dG and the key-row gradients
-    live = live0;
-    k = live ? (__ffsll(live) - 1) : -1;
-    if (k >= 0) fetch(k);
-    while (k >= 0) {
-      live &= live - 1;
-      const int kn = live ? (__ffsll(live) - 1) : -1;
+    auto pass2 = [&](int slot, int k) {
       const float dt = __shfl(dt_l, k, TG_WAVE);
       const int64_t u = __shfl(u_l, k, TG_WAVE);
       float4 x[3][NV];
-      build(dt, x);
-      if (kn >= 0) fetch(kn);
+      build(slot, dt, x);
       float4 dxn[NV], dxt[NV];
 #pragma unroll
       for (int v = 0; v < NV; ++v) dxn[v] = dxt[v] = z4;
@@ -403,7 +421,20 @@ __global__ void __launch_bounds__(256) k_attn_core_bwd(tg_model m, int64_t Q, co
           gw[v].z = fmaf(sz, dt, gw[v].z); gw[v].w = fmaf(sw, dt, gw[v].w);
         }
       }
-      k = kn;
+    };
+    prime();
+    while (ks[0] >= 0) {
+      bool more = true;
+#pragma unroll
+      for (int sl = 0; sl < PD; ++sl) {
+        if (more && ks[sl] >= 0) {
+          pass2(sl, ks[sl]);
+          ks[sl] = next_key();
+          if (ks[sl] >= 0) fetch(sl, ks[sl]);
+        } else {
+          more = false;
+        }
+      }
     }
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
