@@ -5,7 +5,6 @@ import os
 import sys
 
 import numpy as np
-import pytest
 
 from _util import load
 

@@ -16,7 +16,6 @@ import numpy as np
 import torch
 from torch import Tensor
 
-from .. import _lib
 from .._lib import TgTcsr, check, lib, ptr
 from ..hip_ops import stream_ptr
 

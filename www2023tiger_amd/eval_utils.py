@@ -8,7 +8,6 @@ import math
 import warnings
 from typing import Optional
 
-import numpy as np
 import torch
 
 from ._lib import check, lib, ptr

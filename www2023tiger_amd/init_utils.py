@@ -3,7 +3,6 @@ training scripts build, on this package's classes.  The argument parser / CLI is
 import math
 
 import torch
-from torch.utils.data import DataLoader
 
 from .data.data_loader import BatchLoader, ChunkSampler, GraphCollator, load_jodie_data
 from .data.graph import Graph

@@ -1,7 +1,7 @@
 """Mirror of tiger/model/restarters.py: SeqRestarter and StaticRestarter
 (WalkRestarter cannot be constructed through init_model, init_utils.py:144-157)."""
 import ctypes as C
-from typing import Optional, Tuple
+from typing import Tuple
 
 import torch
 from torch import Tensor, nn

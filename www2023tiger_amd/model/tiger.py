@@ -16,7 +16,7 @@ Ways to run a batch:
   * `fuse_attention()` - inference with fixed parameters: pre-multiplied attention weights.
 """
 import ctypes as C
-from typing import Optional, Tuple, Union
+from typing import Tuple, Union
 
 import numpy as np
 import torch

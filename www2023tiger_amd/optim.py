@@ -12,7 +12,6 @@ square root; amsgrad / weight decay are not used by the reference and not offere
 
 Parameters whose gradient came from ordinary autograd (anything outside the fused train step) are
 updated with the same formula through torch ops."""
-import ctypes as C
 from typing import Dict, Tuple
 
 import torch
