@@ -274,7 +274,10 @@ class ResidentShardedStream:
                 torch.cuda.synchronize()
                 print(f'[dist debug] step {self.steps_done} {what} ok', flush=True)
         import contextlib
-        ctx = torch.cuda.stream(self.stream) if (self.stream is not None and self.g_embed is not None) else contextlib.nullcontext()
+        own = self.stream is not None and self.g_embed is not None
+        ctx = torch.cuda.stream(self.stream) if own else contextlib.nullcontext()
+        if own:  # whatever the caller queued on its stream happens before this step ...
+            self.stream.wait_stream(torch.cuda.current_stream())
         with ctx:
             if self.g_embed is not None:
                 self.g_embed.replay()
@@ -288,6 +291,8 @@ class ResidentShardedStream:
             else:
                 self._launch_wb()
             mark('writeback')
+        if own:  # ... and whatever it queues next (reading the memories back, say) after it
+            torch.cuda.current_stream().wait_stream(self.stream)
         self.steps_done += 1
 
     def check_invariants(self):
