@@ -83,6 +83,7 @@ struct GruArgs {
   float* gates;             // nullable [cap, 4, d]: r, z, n, h_n (+bias) per live row, for the backward pass
   int dbg;                  // diagnostic bits, 0 in production
   int64_t rows_hint;        // upper bound of live rows known on the host (0 = unknown), picks the tile height
+  int tail_blocks;          // set by gru_launch: leading blocks that run the 16-column tail (k_gru<3, 4> only)
 };
 
 int gru_launch(const GruArgs& g, hipStream_t st);

@@ -446,6 +446,189 @@ int gemm_launch(const GemmArgs& g, hipStream_t st) {
 // columns and accumulates four planes per column: r and z over K = [x | h], i_n over x
 // only, h_n over h only (no wasted MFMAs on the zero blocks of a packed [4d, 5d] weight).
 // ---------------------------------------------------------------------------------
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+
+// The last hidden columns of the GRU when d is not a multiple of 32: a 16-column tile on
+// v_mfma_f32_16x16x4_f32 instead of a 32-column tile that is mostly padding (d = 172: 12 columns of 32).
+// One block owns 144 rows x 16 columns x 3 planes - three quarters of the MFMA work of a 96 x 32 block of
+// k_gru<3, 4>, whose launch it shares, but the same 24 KB of operands staged per tile, which is what sets the
+// pace (12 wavefronts: 3 row groups of 48 rows x 4 k-groups).
+// Lane l feeds A[i = l % 16][k = l / 16] and B[k = l / 16][j = l % 16] and receives D[4 (l / 16) + r][l % 16].
+// Tiles are [row][k] with a 34-float stride: (34 r + k) mod 32 is injective over the 16 rows x 2 k of a
+// 32-lane read group.  Plain pipeline (next tile in registers while this one is multiplied).
+constexpr int T16_RT = 3;                       // 16-row MFMA tiles per row group
+constexpr int T16_RG = 16 * T16_RT;             // rows per row group (three groups)
+constexpr int T16_ROWS = 3 * T16_RG, T16_LD = 34;
+constexpr int T16_A = 2 * T16_ROWS * T16_LD, T16_B = 2 * 48 * T16_LD;  // floats
+__device__ __forceinline__ void gru_tail16(const GruArgs& g, int tb, int j0, float* __restrict__ arena,
+                                           float* __restrict__ hs, int* __restrict__ orow_s) {
+  constexpr int THREADS = 768;
+  float (*As)[T16_ROWS][T16_LD] = reinterpret_cast<float (*)[T16_ROWS][T16_LD]>(arena);
+  float (*Bs)[48][T16_LD] = reinterpret_cast<float (*)[48][T16_LD]>(arena + T16_A);
+  float (*red)[4][3][16][64] = reinterpret_cast<float (*)[4][3][16][64]>(arena);
+  float (*Hs)[17] = reinterpret_cast<float (*)[17]>(hs);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rg = wave % 3, ks = wave / 3;
+  const int d = g.d, xw = g.xw;
+  int64_t M = g.cap;
+  if (g.n_dev) M = min(M, (int64_t)*g.n_dev);
+  const int64_t m0 = (int64_t)tb * T16_ROWS;
+  if (m0 >= M) return;
+  if (tid < T16_ROWS) {
+    const int64_t m = min(m0 + tid, M - 1);
+    orow_s[tid] = g.out_rows ? g.out_rows[m] : (int)m;
+  }
+  const int li = lane & 15, lk = lane >> 4;
+  const int jb = min(j0 + li, d - 1);
+  const float br = g.b_ih[jb] + g.b_hh[jb];
+  const float bz = g.b_ih[d + jb] + g.b_hh[d + jb];
+  const float bin = g.b_ih[2 * d + jb], bhn = g.b_hh[2 * d + jb];
+  // staging: two activation float4 per thread (rows ar, ar + 96), one weight float4 for the first 384 threads
+  const int ar = tid >> 3, ac4 = (tid & 7) * 4;
+  const float* xrow[2];
+  const float* hrow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int64_t m = min(m0 + min(ar + 96 * i, T16_ROWS - 1), M - 1);
+    xrow[i] = g.x.p + (g.x.idx ? g.x.idx[m] : m) * g.x.ld;
+    hrow[i] = g.h.p + (g.h.idx ? g.h.idx[m] : m) * g.h.ld;
+  }
+  const int wl = min(ar, 47);  // weight-tile row: plane wl / 16, column wl % 16
+  const int wj = min(j0 + (wl & 15), d - 1);
+  const float* wx = g.w_ih + ((int64_t)(wl >> 4) * d + wj) * xw;
+  const float* wh = g.w_hh + ((int64_t)(wl >> 4) * d + wj) * d;
+  const int nkx = (xw + BK - 1) / BK, nkh = (d + BK - 1) / BK;
+  const int nkt = nkx + nkh;
+  struct Stage {
+    float4 a0, a1, b;
+  };
+  auto load_tile = [&](int t, Stage& r) {  // raw loads from clamped addresses (tiles past the end: the last one again)
+    t = min(t, nkt - 1);
+    const bool hp = t >= nkx;
+    const int k = (hp ? t - nkx : t) * BK + ac4;
+    const int kc = k < (hp ? d : xw) ? k : 0;
+    r.a0 = ldg4((hp ? hrow[0] : xrow[0]) + kc);
+    r.a1 = ldg4((hp ? hrow[1] : xrow[1]) + kc);
+    r.b = ldg4((hp ? wh : wx) + kc);
+  };
+  auto store_tile = [&](int buf, int t, const Stage& r) {
+    const bool hp = t >= nkx;
+    const bool kin = (hp ? t - nkx : t) * BK + ac4 < (hp ? d : xw);
+    sts4(As[buf][ar], ac4, kin ? r.a0 : zero4());
+    if (ar + 96 < T16_ROWS) sts4(As[buf][ar + 96], ac4, kin ? r.a1 : zero4());
+    if (ar < 48) sts4(Bs[buf][ar], ac4, kin ? r.b : zero4());
+  };
+  f32x4m acc_r[T16_RT], acc_z[T16_RT], acc_in[T16_RT], acc_hn[T16_RT];
+#pragma unroll
+  for (int i = 0; i < T16_RT; ++i) acc_r[i] = acc_z[i] = acc_in[i] = acc_hn[i] = f32x4m{0.f, 0.f, 0.f, 0.f};
+  const int ht = nkx + (j0 >> 5), hc = j0 & 31;  // the memory tile / column offset that holds h[., j0 .. j0 + 16)
+  // tile t in LDS[buf]: tile t + 2 is requested into `ld`, the k-steps run, tile t + 1 (`stv`, requested a tile
+  // ago) moves to LDS[buf ^ 1]; straight-line body, all loads unconditional
+  auto step = [&](auto hp_tag, int buf, int t, Stage& ld, const Stage& stv) {
+    constexpr bool HP = decltype(hp_tag)::value;
+    load_tile(t + 2, ld);
+    float a[2][T16_RT], b[2][3];
+    auto read = [&](int st, float* av, float* bv) {  // this k-group's k-step st: columns ks * 8 + 4 st + lk
+      const int k = ks * 8 + st * 4 + lk;
+#pragma unroll
+      for (int rt = 0; rt < T16_RT; ++rt) av[rt] = As[buf][rg * T16_RG + rt * 16 + li][k];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) bv[pl] = Bs[buf][pl * 16 + li][k];
+    };
+    read(0, a[0], b[0]);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+      for (int rt = 0; rt < T16_RT; ++rt) {
+        acc_r[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st][rt], b[st][0], acc_r[rt], 0, 0, 0);
+        if (st == 0 && rt == 0) read(1, a[1], b[1]);
+        acc_z[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st][rt], b[st][1], acc_z[rt], 0, 0, 0);
+        if (HP) acc_hn[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st][rt], b[st][2], acc_hn[rt], 0, 0, 0);
+        else acc_in[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st][rt], b[st][2], acc_in[rt], 0, 0, 0);
+      }
+    }
+    if (HP && t == ht) {
+      for (int f = tid; f < T16_ROWS * 16; f += THREADS) Hs[f >> 4][f & 15] = As[buf][f >> 4][hc + (f & 15)];
+    }
+    store_tile(buf ^ 1, t + 1, stv);
+    __syncthreads();
+  };
+  using HP0 = std::integral_constant<bool, false>;
+  using HP1 = std::integral_constant<bool, true>;
+  Stage sa, sb;
+  load_tile(0, sa);
+  load_tile(1, sb);
+  store_tile(0, 0, sa);
+  __syncthreads();
+  int t = 0;
+  for (; t + 2 <= nkx; t += 2) {
+    step(HP0{}, 0, t, sa, sb);
+    step(HP0{}, 1, t + 1, sb, sa);
+  }
+  if (t < nkx) {  // odd number of message tiles: the memory tiles start in LDS[1]
+    step(HP0{}, 0, t, sa, sb);
+    for (++t; t + 2 <= nkt; t += 2) {
+      step(HP1{}, 1, t, sb, sa);
+      step(HP1{}, 0, t + 1, sa, sb);
+    }
+    if (t < nkt) step(HP1{}, 1, t, sb, sa);
+  } else {
+    for (; t + 2 <= nkt; t += 2) {
+      step(HP1{}, 0, t, sa, sb);
+      step(HP1{}, 1, t + 1, sb, sa);
+    }
+    if (t < nkt) step(HP1{}, 0, t, sa, sb);
+  }
+  // fold the four k-groups (as in k_gru): groups [half, 2 half) write, groups [0, half) add
+#pragma unroll
+  for (int half = 2; half >= 1; half /= 2) {
+    if (ks >= half && ks < 2 * half) {
+#pragma unroll
+      for (int rt = 0; rt < T16_RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          red[ks - half][0][rg][rt * 4 + r][lane] = acc_r[rt][r];
+          red[ks - half][1][rg][rt * 4 + r][lane] = acc_z[rt][r];
+          red[ks - half][2][rg][rt * 4 + r][lane] = acc_in[rt][r];
+          red[ks - half][3][rg][rt * 4 + r][lane] = acc_hn[rt][r];
+        }
+    }
+    __syncthreads();
+    if (ks < half) {
+#pragma unroll
+      for (int rt = 0; rt < T16_RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc_r[rt][r] += red[ks][0][rg][rt * 4 + r][lane];
+          acc_z[rt][r] += red[ks][1][rg][rt * 4 + r][lane];
+          acc_in[rt][r] += red[ks][2][rg][rt * 4 + r][lane];
+          acc_hn[rt][r] += red[ks][3][rg][rt * 4 + r][lane];
+        }
+    }
+    if (half > 1) __syncthreads();
+  }
+  if (ks != 0) return;
+  const int j = j0 + li;
+  if (j >= d) return;
+#pragma unroll
+  for (int rt = 0; rt < T16_RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int lr = rg * T16_RG + rt * 16 + 4 * lk + r;
+      const int64_t m = m0 + lr;
+      if (m >= M) continue;
+      const float rgate = fast_sigmoid(acc_r[rt][r] + br);
+      const float zgate = fast_sigmoid(acc_z[rt][r] + bz);
+      const float hn = acc_hn[rt][r] + bhn;
+      const float ng = fast_tanh(acc_in[rt][r] + bin + rgate * hn);
+      g.out[(int64_t)orow_s[lr] * g.ldo + j] = (1.f - zgate) * ng + zgate * Hs[lr][li];
+      if (g.gates) {
+        float* gp = g.gates + m * 4 * (int64_t)d + j;
+        gp[0] = rgate; gp[d] = zgate; gp[2 * d] = ng; gp[3 * d] = hn;
+      }
+    }
+}
+
 // diagnostic only (TG_GRU_DBG & 16): per-block s_memtime stamps {entry, loop start, loop end, exit}
 __device__ unsigned long long g_gru_trace[2048 * 4];
 
@@ -464,23 +647,51 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
   constexpr int PP = 8 / KS;                   // k-step pairs per wave per tile
   static_assert(BM % RP == 0 && NOPS <= (PP / 2) * 3, "three memory-op slots per k-step pair");
   const unsigned long long t_entry = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
-  __shared__ float As[2][BM][LDK];
-  __shared__ float Bs[2][3][32][LDK];
-  __shared__ float red[KS == 2 ? 4 : 1][KS == 2 ? NW : 1][16][64];
+  // One LDS arena: the operand tiles while the loop runs, the k-group fold afterwards (the tiles are dead then).
+  constexpr int A_FLOATS = 2 * BM * LDK, B_FLOATS = 2 * 3 * 32 * LDK;
+  constexpr int RED_FLOATS = KS == 1 ? 0 : (KS / 2) * 4 * NW * 16 * 64;  // the upper half of the k-groups writes at once
+  constexpr int ARENA0 = (A_FLOATS + B_FLOATS) > RED_FLOATS ? (A_FLOATS + B_FLOATS) : RED_FLOATS;
+  constexpr bool TAIL = NW == 3 && KS == 4;  // this instance also serves the 16-column tail blocks (gru_tail16)
+  constexpr int ARENA = TAIL && (T16_A + T16_B) > ARENA0 ? (T16_A + T16_B) : ARENA0;
+  __shared__ float arena[ARENA];
+  float (*As)[BM][LDK] = reinterpret_cast<float (*)[BM][LDK]>(arena);
+  float (*Bs)[3][32][LDK] = reinterpret_cast<float (*)[3][32][LDK]>(arena + A_FLOATS);
+  float (*red)[4][NW][16][64] = reinterpret_cast<float (*)[4][NW][16][64]>(arena);  // [k-group slot][plane][row wave]
   // epilogue operands staged while the loop runs (no global load is left for the epilogue, where its
   // latency would be exposed): the old-memory tile h[m, j0..j0+32) is one of the A tiles the loop
   // streams anyway, the output rows are fetched at block start
-  __shared__ float Hs[BM][LDK];
-  __shared__ int orow_s[BM];
+  constexpr int HS_FLOATS = TAIL && T16_ROWS * 17 > BM * LDK ? T16_ROWS * 17 : BM * LDK;
+  __shared__ float hs_raw[HS_FLOATS];
+  __shared__ int orow_s[TAIL ? T16_ROWS : BM];
+  float (*Hs)[LDK] = reinterpret_cast<float (*)[LDK]>(hs_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rw = wave % NW, ks = wave / NW;
   const int d = g.d, xw = g.xw;
-  const int NT = (d + 31) / 32;
-  const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
-  const int64_t mt = (int64_t)(s / NT) * 8 + xcd;
-  const int nt = s % NT;
+  // column tiles of 32 handled here; with a tail (tail_blocks > 0) the last, partial one belongs to gru_tail16,
+  // whose blocks come FIRST in the grid so that they start with everybody else
+  const int NT = (d + 31) / 32 - (g.tail_blocks > 0 ? 1 : 0);
   int64_t M = g.cap;
   if (g.n_dev) M = min(M, (int64_t)*g.n_dev);
+  const int xcd = blockIdx.x & 7;
+  int s = blockIdx.x >> 3;
+  if (TAIL && g.tail_blocks > 0) {
+    // With the tail the launch is sized to fit the chip in ONE round (every CU at most one block), so the live
+    // blocks must also be dealt evenly over the eight XCDs (blockIdx % 8): XCD x works through the row tiles
+    // mt = x (mod 8), all their column tiles, then its share of the tail blocks - the XCDs that own one row
+    // tile less take NT tail blocks each first, the rest is dealt round robin.  All from the live row count.
+    const int MT = (int)((M + BM - 1) / BM), TT = (int)((M + T16_ROWS - 1) / T16_ROWS);
+    const int r = MT & 7, n_main = (MT / 8 + (xcd < r ? 1 : 0)) * NT;
+    if (s >= n_main) {
+      const int ti = s - n_main, light = r ? 8 - r : 0, first = light * NT;
+      int tb;
+      if (r && xcd >= r) tb = ti < NT ? (xcd - r) * NT + ti : first + xcd + 8 * (ti - NT);
+      else tb = first + xcd + 8 * ti;
+      if (tb < TT) gru_tail16(g, tb, NT * 32, arena, hs_raw, orow_s);
+      return;
+    }
+  }
+  const int64_t mt = (int64_t)(s / NT) * 8 + xcd;
+  const int nt = s % NT;
   const int64_t m0 = mt * BM;
   if (m0 >= M) return;
   const int j0 = nt * 32;
@@ -635,26 +846,32 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
     if (t < nkt) tile(HP1{}, 0, t, ra0, rb0, ra1, rb1);
   }
   const unsigned long long t_loop1 = (dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
-  if (KS == 2) {  // fold the second k-group's partial sums into the first
-    if (ks == 1) {
+  // fold the k-groups' partial sums into group 0, halving the number of live groups per round: groups
+  // [half, 2 half) write, groups [0, half) add (the last tile's barrier has retired every read of the tiles)
+#pragma unroll
+  for (int half = KS / 2; half >= 1; half /= 2) {
+    if (ks >= half && ks < 2 * half) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        red[0][rw][r][lane] = acc_r[r];
-        red[1][rw][r][lane] = acc_z[r];
-        red[2][rw][r][lane] = acc_in[r];
-        red[3][rw][r][lane] = acc_hn[r];
+        red[ks - half][0][rw][r][lane] = acc_r[r];
+        red[ks - half][1][rw][r][lane] = acc_z[r];
+        red[ks - half][2][rw][r][lane] = acc_in[r];
+        red[ks - half][3][rw][r][lane] = acc_hn[r];
       }
     }
     __syncthreads();
-    if (ks == 1) return;
+    if (ks < half) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      acc_r[r] += red[0][rw][r][lane];
-      acc_z[r] += red[1][rw][r][lane];
-      acc_in[r] += red[2][rw][r][lane];
-      acc_hn[r] += red[3][rw][r][lane];
+      for (int r = 0; r < 16; ++r) {
+        acc_r[r] += red[ks][0][rw][r][lane];
+        acc_z[r] += red[ks][1][rw][r][lane];
+        acc_in[r] += red[ks][2][rw][r][lane];
+        acc_hn[r] += red[ks][3][rw][r][lane];
+      }
     }
+    if (half > 1) __syncthreads();  // the next round overwrites the slots
   }
+  if (ks != 0) return;
   const int j = min(j0 + fr, d - 1);
   const bool jok = j0 + fr < d;
 #pragma unroll
@@ -697,8 +914,31 @@ int gru_launch(const GruArgs& g, hipStream_t st) {
   const int NT = (g.d + 31) / 32;
   // small problems (at most ~64k live rows): 64-row blocks double the block count so that two
   // blocks share a CU and cover each other's stalls; large ones keep 128 rows (half the weight traffic)
-  (void)force_nw;
   static const int ks_knob = getenv("TG_GRU_KS") ? atoi(getenv("TG_GRU_KS")) : 2;  // tuning knob
+  // 96-row blocks (four k-groups of three row waves: 12 wavefronts, three per SIMD) with the partial column tile
+  // as 16-column blocks: a quarter less work per block and no padded columns, which pays exactly when the whole
+  // launch fits the chip in ONE round - every CU runs at most one block, so the duration is one block's duration
+  // (C2 shapes, 4174 rows: 61.9 -> 51.8 us).  One block more than CUs and it costs a second round (4400 rows:
+  // 83 us), so the choice needs a guaranteed bound on the live rows: rows_hint (the caller's bound, e.g. the node
+  // count), not the capacity.  At C2's steady state (4350-4550 involved nodes of 9228) it does not apply.
+  bool small = false;
+  {
+    const int tail = g.d % 32;
+    const bool use_tail = tail > 0 && tail <= 16;
+    const int64_t rows = g.rows_hint > 0 ? std::min<int64_t>(g.rows_hint, g.cap) : g.cap;
+    const int64_t blocks96 = cdiv(rows, 96) * (NT - (use_tail ? 1 : 0)) + (use_tail ? cdiv(rows, T16_ROWS) : 0);
+    small = blocks96 + 8 <= 256;  // (+8: the per-XCD dealing can leave one XCD a block short of full)
+  }
+  if (force_nw == 3 || (force_nw == 0 && small)) {
+    const int tail = g.d % 32;
+    const bool use_tail = tail > 0 && tail <= 16;  // the partial column tile as 16-column blocks of T16_ROWS rows
+    a.tail_blocks = use_tail ? (int)cdiv(g.cap, T16_ROWS) : 0;
+    const int ntm = NT - (use_tail ? 1 : 0);
+    // per XCD: its row tiles x column tiles, then at most NT + ceil(tails / 8) + 1 tail slots (see the kernel's map)
+    const int64_t per_xcd = cdiv(cdiv(g.cap, 96), 8) * ntm + (use_tail ? ntm + cdiv(a.tail_blocks, 8) + 1 : 0);
+    hipLaunchKernelGGL((k_gru<3, 4>), dim3((unsigned)(8 * per_xcd)), dim3(768), 0, st, a);
+    return check_launch("gru(96)");
+  }
   const int64_t grid = 8 * cdiv(cdiv(g.cap, 128), 8) * NT;
   if (ks_knob == 2)
     hipLaunchKernelGGL((k_gru<4, 2>), dim3((unsigned)grid), dim3(512), 0, st, a);
