@@ -338,6 +338,21 @@ def main():
                            involved_per_batch=float(U), outdated_per_batch=float(O_), unique_pos_per_batch=float(P)),
                roofline=roof,
                stages_ms={n: round(float(v), 5) for n, v in zip(names, stage_ms)})
+    # the HBM-bound memory-gather kernel (right-memory rows of the involved nodes), next to the dominant kernel:
+    # the north star prices THIS kernel against the HBM roofline on the C5-scaled run (at C2 the state is cache resident)
+    gname = 'gather_right_memory'
+    if gname in names and name != gname:
+        gi = names.index(gname)
+        gt = stage_ms[gi] * 1e-3
+        gtraffic = None
+        try:
+            gtraffic = tj['kernels'].get(kernel_of_stage[gname], {}).get('bytes_per_launch')
+        except (NameError, KeyError):
+            pass
+        out['roofline_memory_gather'] = dict(bound='hbm', kernel=gname, achieved=bytes_by_stage[gname] / gt / 1e9,
+                                             peak=HBM_PEAK_GBS, unit='GB/s', frac=bytes_by_stage[gname] / gt / 1e9 / HBM_PEAK_GBS,
+                                             traffic=gtraffic, avg_ms=float(stage_ms[gi]),
+                                             algorithmic_bytes=float(bytes_by_stage[gname]))
     if not args.no_cpu_baseline and args.workload == 'c2':
         out['cpu_baseline'] = cpu_baseline(stream, cfg, model)
     print(json.dumps(out))
