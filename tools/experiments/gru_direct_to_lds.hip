@@ -6,8 +6,9 @@
 //   k_gru_dl, ds_read2_b32 fragments         64.8 us      (4-way bank conflicts: 32-bank addressing)
 //   k_gru_dl, ds_read_b64 fragments          61.0 us      without its loads 52.7 us
 //   k_gru_dl, ds_read_b128 quads (this file) 60.7 us      without its loads 50.3 us; 4 LDS buffers: 60.9 us
-// i.e. the transfers cost ~10 us however they are issued - the LDS write port takes ~30 KB per tile and CU either
-// way - so the direct path only saves registers here.  Kept for the next round (larger tiles per staged byte).
+// i.e. the transfers cost ~10 us however they are issued (see also gru_activations_in_registers.hip: halving the
+// LDS writes changes nothing either), so the direct path only saves registers here.  Kept for the next round
+// (larger tiles per staged byte).
 // ---------------------------------------------------------------------------------
 // GRU cell, direct-to-LDS staging (global_load_lds_dwordx4): the operand tiles travel from global memory
 // into LDS without passing through registers - no staging VGPRs, no ds_write, no tail selects in the loop
