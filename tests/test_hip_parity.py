@@ -161,7 +161,13 @@ def test_linear_fwd_vs_torch(n, in_f, out_f):
     assert rel_err(out, ref) < 1e-5
 
 
-@pytest.mark.parametrize('n,d,xw', [(1, 8, 32), (200, 172, 688), (131, 100, 400), (513, 16, 60)])
+@pytest.mark.parametrize('n,d,xw', [
+    (1, 8, 32), (200, 172, 688), (131, 100, 400), (513, 16, 60),
+    # block configurations of the fused cell: 96-row blocks (+ 16-column tail blocks) when everything fits one
+    # round, 128-row blocks otherwise; hidden widths with no partial tile (32, 160), a tail of 4 / 12 / 16 columns
+    # (100, 44, 172, 176) and one above 16 (180: padded 32-column tile); row counts at tile and XCD-dealing edges
+    (97, 32, 64), (96, 44, 128), (1000, 160, 640), (1153, 176, 256), (600, 180, 360), (4174, 172, 688),
+    (4400, 172, 688), (2305, 100, 400), (145, 12, 48)])
 def test_gru_fwd_vs_torch(n, d, xw):
     from www2023tiger_amd.model.dense import gru_forward
     torch.manual_seed(d)
