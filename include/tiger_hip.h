@@ -374,7 +374,12 @@ typedef struct tg_step_io {
    * the workspace are zero (freshly zero-filled, or left by a previous completed full step, which
    * always cleans up after itself); the step then skips its initial memset launch. */
   int32_t ws_is_clean;
-  int32_t reserved;
+  /* rows_hint > 0: the caller's bound on the number of nodes with a pending message among the involved nodes of
+   * this batch (e.g. 1.2 x the largest count seen so far).  Performance only: it lets the updater pick blocks
+   * sized for a launch that fits the chip in one round; a batch that exceeds the bound is still correct.
+   * 0 = unknown (the capacity and the node count are used).  (This field was `reserved` before: 0 is the old
+   * behaviour, the layout is unchanged.) */
+  int32_t rows_hint;
 } tg_step_io;
 
 /* Per-stage timer of tg_stream_step (HIP events on the step's stream).  Stage names:

@@ -522,7 +522,7 @@ static size_t apply_ws_bytes(const tg_model* m, int64_t cap) {
 
 int apply_messages(const tg_model* m, const int64_t* outdated, const int32_t* out_pos, const int32_t* n_dev,
                    int64_t cap, float* reprs, uint32_t* err, void* ws, size_t ws_bytes, hipStream_t st,
-                   bool checked_already = false, float* gates = nullptr) {
+                   bool checked_already = false, float* gates = nullptr, int64_t rows_bound = 0) {
   const int d = m->d, mw = 3 * m->d + m->d_e;
   Carver cv(ws, ws_bytes);
   ApplyWs w{};
@@ -558,6 +558,7 @@ int apply_messages(const tg_model* m, const int64_t* outdated, const int32_t* ou
     a.w_ih = m->gru_w_ih; a.w_hh = m->gru_w_hh; a.b_ih = m->gru_b_ih; a.b_hh = m->gru_b_hh;
     a.out = reprs; a.ldo = d; a.out_rows = out_pos; a.gates = gates;
     a.rows_hint = std::min<int64_t>(cap, m->n_nodes);
+    if (rows_bound > 0) a.rows_hint = std::min<int64_t>(a.rows_hint, rows_bound);  // the caller's bound on the live rows
     return gru_launch(a, st);
   }
   GemmArgs g{};  // MergeUpdater: fc2(relu(fc1([msg | mem])))
@@ -832,7 +833,7 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
     return rc;
   prof_mark(pf, ST_UPDATE, st);
   if ((rc = apply_messages(m, w.outdated, w.out_pos, w.counts + 1, cap, w.reprs, io->err, w.apply_ws, w.apply_bytes,
-                           st, true, gates)) != TG_OK)
+                           st, true, gates, io->rows_hint)) != TG_OK)
     return rc;
   // ---- STEP 3: temporal embeddings of cat[src, dst, neg]
   if ((rc = attn_forward(m, Q, w.nids3, w.ts3f, w.l1n, w.l1e, w.l1t, w.reprs, w.bm, w.rank, io->h, w.attn, st, pf,

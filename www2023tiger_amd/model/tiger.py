@@ -256,11 +256,13 @@ class TIGE(nn.Module):
         self._poll_train_errors()
         tb.launch(graph=cg_graph)  # sample where the collator sampled
         if deferred:
-            tb.err_host.copy_(tb.sb.err, non_blocking=True)
+            tb.err_host[:1].copy_(tb.sb.err, non_blocking=True)
+            tb.err_host[1:].copy_(tb.sb.counts[1:2], non_blocking=True)
             tb.err_event = torch.cuda.Event()
             tb.err_event.record()
         else:
             word = int(tb.sb.err.item())
+            self.note_rows(int(tb.sb.counts[1].item()))
             if word:
                 tb.sb.err.zero_()
                 from .._lib import raise_invariants
@@ -279,7 +281,8 @@ class TIGE(nn.Module):
                 continue
             ev.synchronize()
             tb.err_event = None
-            word = int(tb.err_host.item())
+            word = int(tb.err_host[0].item())
+            self.note_rows(int(tb.err_host[1].item()))
             if word:
                 tb.sb.err.zero_()
                 from .._lib import raise_invariants
@@ -323,7 +326,8 @@ class TIGE(nn.Module):
         self._poll_train_errors()  # invariant word of the previous batch (read back asynchronously, no stall)
         tb.launch(graph=getattr(computation_graph, 'graph', None))
         if tb.err_host is not None:
-            tb.err_host.copy_(tb.sb.err, non_blocking=True)
+            tb.err_host[:1].copy_(tb.sb.err, non_blocking=True)
+            tb.err_host[1:].copy_(tb.sb.counts[1:2], non_blocking=True)
             tb.err_event = torch.cuda.Event()
             tb.err_event.record()
         else:
@@ -447,8 +451,18 @@ class TIGE(nn.Module):
             self._step_ws[key] = buf
         return buf
 
+    def rows_bound(self) -> int:
+        """Bound on the nodes with a pending message per batch handed to the library (tg_step_io.rows_hint):
+        1.2 x the largest count read back so far, 0 while nothing has been read back.  Performance only."""
+        seen = getattr(self, '_rows_seen', 0)
+        return int(1.2 * seen) + 32 if seen else 0
+
+    def note_rows(self, n_outdated: int):
+        self._rows_seen = max(getattr(self, '_rows_seen', 0), int(n_outdated))
+
     def launch_step(self, buf: 'TIGE.StepBuffers'):
         """Enqueue collate + STEP 1-6 for the batch already in `buf` (no host sync)."""
+        buf.io.rows_hint = self.rows_bound()
         m = self.model_struct()
         g = self.graph.tcsr
         check(lib.tg_stream_step(C.byref(m), C.byref(g), C.byref(buf.io), ptr(buf.ws), buf.ws.numel(),
@@ -467,6 +481,7 @@ class TIGE(nn.Module):
         self.launch_step(buf)
         if check_invariants:
             word = int(buf.err.item())
+            self.note_rows(int(buf.counts[1].item()))
             if word:
                 buf.err.zero_()
                 from .._lib import raise_invariants
