@@ -375,7 +375,7 @@ typedef struct tg_step_io {
    * always cleans up after itself); the step then skips its initial memset launch. */
   int32_t ws_is_clean;
   /* rows_hint > 0: the caller's bound on the number of nodes with a pending message among the involved nodes of
-   * this batch (e.g. 1.2 x the largest count seen so far).  Performance only: it lets the updater pick blocks
+   * this batch (e.g. 1.5 x the largest count seen so far).  Performance only: it lets the updater pick blocks
    * sized for a launch that fits the chip in one round; a batch that exceeds the bound is still correct.
    * 0 = unknown (the capacity and the node count are used).  (This field was `reserved` before: 0 is the old
    * behaviour, the layout is unchanged.) */

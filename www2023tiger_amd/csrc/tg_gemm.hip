@@ -921,13 +921,22 @@ int gru_launch(const GruArgs& g, hipStream_t st) {
   // (C2 shapes, 4174 rows: 61.9 -> 51.8 us).  One block more than CUs and it costs a second round (4400 rows:
   // 83 us), so the choice needs a guaranteed bound on the live rows: rows_hint (the caller's bound, e.g. the node
   // count), not the capacity.  At C2's steady state (4350-4550 involved nodes of 9228) it does not apply.
-  bool small = false;
+  // Smaller still when it fits: 64-row blocks (k_gru<2, 4>, 8 wavefronts; 1588 rows at d = 172: 36 us against
+  // 47 us with 96 rows and 58 us with 128).  Its blocks follow the plain XCD map, so every XCD must hold its
+  // share: ceil(row tiles / 8) x column tiles <= 32 CUs.
+  bool small = false, tiny = false;
   {
     const int tail = g.d % 32;
     const bool use_tail = tail > 0 && tail <= 16;
     const int64_t rows = g.rows_hint > 0 ? std::min<int64_t>(g.rows_hint, g.cap) : g.cap;
     const int64_t blocks96 = cdiv(rows, 96) * (NT - (use_tail ? 1 : 0)) + (use_tail ? cdiv(rows, T16_ROWS) : 0);
     small = blocks96 + 8 <= 256;  // (+8: the per-XCD dealing can leave one XCD a block short of full)
+    tiny = cdiv(cdiv(rows, 64), 8) * NT <= 32;
+  }
+  if (force_nw == 2 || (force_nw == 0 && tiny)) {
+    a.tail_blocks = 0;
+    hipLaunchKernelGGL((k_gru<2, 4>), dim3((unsigned)(8 * cdiv(cdiv(g.cap, 64), 8) * NT)), dim3(512), 0, st, a);
+    return check_launch("gru(64)");
   }
   if (force_nw == 3 || (force_nw == 0 && small)) {
     const int tail = g.d % 32;
