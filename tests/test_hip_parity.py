@@ -387,11 +387,12 @@ def test_c2_bench_configuration_soak_matches_oracle():
     _oracle_vs_fused(stream, c['d'], c['K'], c['B'], 16, c['msg_src'], c['upd_src'], fuse=True)
 
 
-@pytest.mark.parametrize('B', [1200, 683])
+@pytest.mark.parametrize('B', [1200, 683, 200])
 def test_stream_k_piece_sums_with_uneven_row_tiles(B):
     """The merged fc1 product runs as stream-K pieces whenever it has 128..255 tiles (C2: 144).  B = 1200 gives
     57 row tiles (not a multiple of the 8 XCDs the units are dealt over, last tile partly empty), B = 683 gives
-    33 row tiles x 3 = 99 tiles -> the plain product; both against the oracle with pre-multiplied weights."""
+    33 row tiles x 3 = 99 tiles and B = 200 (the reference's default batch) 10 x 3 = 30 tiles, each cut into more
+    pieces (up to eight per tile); all against the oracle with pre-multiplied weights."""
     import bench
     c = bench.C2
     stream = bench.make_stream(c['n_u'], c['n_i'], 4 * B, c['T'] * 4 * B / c['E'], seed=6, d_e=c['d'])

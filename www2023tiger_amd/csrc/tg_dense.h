@@ -50,7 +50,7 @@ struct GemmArgs {
   // A operand assembled from the stream-K pieces of the producing product (gemm_sk_partials) instead of a0 / a1:
   // A[m, k] = act(ask_alpha * (sum of pieces + ask_bias[k] + ask_valid[m] * ask_bias2[k]))
   const float* ask_part;
-  int ask_U, ask_nkt, ask_NT;
+  int ask_U, ask_nkt, ask_NT, ask_pieces;
   float ask_rcpU;  // set by gemm_launch
   const float *ask_bias, *ask_bias2;
   const uint8_t* ask_valid;
@@ -61,7 +61,7 @@ constexpr int TG_SK_WORKERS = 256;
 constexpr size_t TG_SK_WS_FLOATS = (size_t)TG_SK_WORKERS * 2 * 4096;
 // stream-K plan of a product that cannot fill the chip (see tg_gemm.hip)
 struct SkPlan {
-  int U, nkt, tiles, NT, MT;  // units per worker, k-tiles per tile, tiles, column tiles, row tiles
+  int U, nkt, tiles, NT, MT, pieces;  // units per worker, k-tiles per tile, tiles, column tiles, row tiles, max pieces per tile
   float* part;            // [workers][2][64 * 64]
 };
 // Launches the piece kernel for `g` (bias / activation of g are NOT applied: the consumer applies them) and

@@ -41,7 +41,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16& a
 // accumulators are stored unmodified as a row-major [BM][BN] piece for a later fixed-order sum (stream-K
 // partials, below).  ASK: the A operand is not read from a0 / a1 but assembled from such pieces while it
 // is staged: A[m, k] = act(alpha * (sum of the pieces of element (m, k) + bias[k] + valid[m] * bias2[k])).
-template <int WM, int WN, int KS, int D, bool ASK = false>
+template <int WM, int WN, int KS, int D, bool ASK = false, int AP = 3>  // AP: most pieces one element is summed from
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int64_t mt, int nt, int bz, int kt_begin, int kt_end,
                                           float* __restrict__ raw, int trace_slot) {
   const unsigned long long t_entry = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -104,7 +104,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int64_t mt, int nt,
   // kernel is a chain of dependent tile loads, so the prefetch distance sets its duration
   static_assert(D >= 2 && D % 2 == 0, "even prefetch depth");
   float4 ra[D][NA], rb[D][NB];
-  float4 rx[D][ASK ? NA : 1][4];  // ASK: second / third piece, bias, second bias of every staged A float4
+  float4 rx[D][ASK ? NA : 1][AP + 1];  // ASK: pieces 1 .. AP-1, bias, second bias of every staged A float4
   const int nkt = kt_end;  // tiles past the end are clamped to the last one of the range
   // ASK: the pieces of element column k of this block's row tile (producer tile T = mt * NT_p + k / 64)
   auto ask_pieces = [&](int kc, int* wsel, int* psel, bool* have) {
@@ -115,7 +115,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int64_t mt, int nt,
     j0 += ((j0 + 1) * U <= ua) ? 1 : 0;
     j0 -= (j0 * U > ua) ? 1 : 0;
 #pragma unroll
-    for (int jj = 0; jj < 3; ++jj) {
+    for (int jj = 0; jj < AP; ++jj) {
       const int j = j0 + jj;
       have[jj] = j * U < ub;
       const int jc = have[jj] ? j : j0;
@@ -125,19 +125,19 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int64_t mt, int nt,
   };
   // i-th staged float4 of tile kt (i < NA: A, else W): raw load from a clamped address; columns
   // past K are zeroed when the tile is written to LDS, so nothing waits on the load here
-  auto load_one = [&](int kt, int i, float4* ra, float4* rb, float4 (*rx)[4]) {
+  auto load_one = [&](int kt, int i, float4* ra, float4* rb, float4 (*rx)[AP + 1]) {
     const int k = kt * BK + ac4;
     const int kc = k < K ? k : 0;
     if (ASK && i < NA) {
-      int wsel[3], psel[3];
-      bool have[3];
+      int wsel[AP], psel[AP];
+      bool have[AP];
       ask_pieces(kc, wsel, psel, have);
       const size_t off = (size_t)amloc[i] * 64 + (kc & 63);
       ra[i] = ldg4(g.ask_part + ((size_t)wsel[0] * 2 + psel[0]) * 4096 + off);
-      rx[i][0] = ldg4(g.ask_part + ((size_t)wsel[1] * 2 + psel[1]) * 4096 + off);
-      rx[i][1] = ldg4(g.ask_part + ((size_t)wsel[2] * 2 + psel[2]) * 4096 + off);
-      rx[i][2] = ldg4(g.ask_bias + kc);
-      rx[i][3] = ldg4((g.ask_bias2 ? g.ask_bias2 : g.ask_bias) + kc);
+#pragma unroll
+      for (int pc = 1; pc < AP; ++pc) rx[i][pc - 1] = ldg4(g.ask_part + ((size_t)wsel[pc] * 2 + psel[pc]) * 4096 + off);
+      rx[i][AP - 1] = ldg4(g.ask_bias + kc);
+      rx[i][AP] = ldg4((g.ask_bias2 ? g.ask_bias2 : g.ask_bias) + kc);
     } else if (i < NA) {
       ra[i] = ldg4((kc < kw0 ? arow0[i] : arow1[i]) + kc);
     } else if (!g.w_kmajor) {
@@ -147,26 +147,28 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int64_t mt, int nt,
       rb[i - NA] = ldg4(wrow[i - NA] + (int64_t)min(kk, K - 1) * g.ldw);
     }
   };
-  auto store_one = [&](int buf, int kt, int i, const float4* ra, const float4* rb, const float4 (*rx)[4]) {
+  auto store_one = [&](int buf, int kt, int i, const float4* ra, const float4* rb, const float4 (*rx)[AP + 1]) {
     const bool kin = kt * BK + ac4 < K;
     if (ASK && i < NA) {
-      int wsel[3], psel[3];
-      bool have[3];
+      int wsel[AP], psel[AP];
+      bool have[AP];
       ask_pieces(kin ? kt * BK + ac4 : 0, wsel, psel, have);
       const bool b2 = g.ask_bias2 && avalid[i];
-      auto fin = [&](float p0, float p1, float p2, float b, float c) {
-        float v = p0;
-        if (have[1]) v += p1;
-        if (have[2]) v += p2;
-        v = g.ask_alpha * (v + (b2 ? b + c : b));
-        if (g.ask_relu) v = fmaxf(v, 0.f);
-        return kin ? v : 0.f;
+      float4 v = ra[i];
+#pragma unroll
+      for (int pc = 1; pc < AP; ++pc) {  // in worker (= k) order: a fixed order
+        if (have[pc]) {
+          v.x += rx[i][pc - 1].x; v.y += rx[i][pc - 1].y; v.z += rx[i][pc - 1].z; v.w += rx[i][pc - 1].w;
+        }
+      }
+      auto fin = [&](float p, float b, float c) {
+        float o = g.ask_alpha * (p + (b2 ? b + c : b));
+        if (g.ask_relu) o = fmaxf(o, 0.f);
+        return kin ? o : 0.f;
       };
       sts4(As[buf][ar + i * RP], ac4,
-           make_float4(fin(ra[i].x, rx[i][0].x, rx[i][1].x, rx[i][2].x, rx[i][3].x),
-                       fin(ra[i].y, rx[i][0].y, rx[i][1].y, rx[i][2].y, rx[i][3].y),
-                       fin(ra[i].z, rx[i][0].z, rx[i][1].z, rx[i][2].z, rx[i][3].z),
-                       fin(ra[i].w, rx[i][0].w, rx[i][1].w, rx[i][2].w, rx[i][3].w)));
+           make_float4(fin(v.x, rx[i][AP - 1].x, rx[i][AP].x), fin(v.y, rx[i][AP - 1].y, rx[i][AP].y),
+                       fin(v.z, rx[i][AP - 1].z, rx[i][AP].z), fin(v.w, rx[i][AP - 1].w, rx[i][AP].w)));
     } else if (i < NA) {
       sts4(As[buf][ar + i * RP], ac4, kin ? ra[i] : zero4());
     } else if (!g.w_kmajor) {
@@ -195,8 +197,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int64_t mt, int nt,
   // in-order wave make bursts of loads / ds_writes stall the matrix pipe, so tile t+2's
   // global loads and tile t+1's LDS writes are threaded between the MFMAs of tile t, with
   // the operand fragments read one k-step pair ahead.  One barrier per tile.
-  auto tile = [&](int buf, int kt, float4* la, float4* lb, float4 (*lx)[4], const float4* sa, const float4* sb,
-                  const float4 (*sx)[4]) {
+  auto tile = [&](int buf, int kt, float4* la, float4* lb, float4 (*lx)[AP + 1], const float4* sa, const float4* sb,
+                  const float4 (*sx)[AP + 1]) {
     const int tl = min(kt + D, nkt - 1);
     const float* ap = &As[buf][wm * 32 + fr][fk + 4 * PP * ks];  // this wave group's share of the k-steps
     const float* bp = &Bs[buf][wn * 32 + fr][fk + 4 * PP * ks];
@@ -343,7 +345,7 @@ extern "C" int tg_debug_gemm_trace(unsigned long long* out_host, int n_blocks) {
   return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_gemm_trace), sizeof(unsigned long long) * 4 * n_blocks) == hipSuccess ? 0 : -4;
 }
 
-template <int WM, int WN, int KS, int D, bool ASK = false>
+template <int WM, int WN, int KS, int D, bool ASK = false, int AP = 3>
 __global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
   constexpr int BN = 32 * WN;
   const int NT = (g.n + BN - 1) / BN;
@@ -351,7 +353,7 @@ __global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
   const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
   const int64_t mt = (int64_t)(s / per) * 8 + xcd;
   const int rem = s % per;
-  gemm_tile<WM, WN, KS, D, ASK>(g, mt, rem % NT, rem / NT, 0, (g.k + BK - 1) / BK, nullptr, (int)blockIdx.x);
+  gemm_tile<WM, WN, KS, D, ASK, AP>(g, mt, rem % NT, rem / NT, 0, (g.k + BK - 1) / BK, nullptr, (int)blockIdx.x);
 }
 
 // ---- stream-K for launches that cannot fill the chip --------------------------------------------------
@@ -361,7 +363,8 @@ __global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
 // the tail of one tile and/or the head of the next, and stores each piece's accumulators in its own slot.
 // Nobody waits for anybody: the pieces of a tile are summed, in worker order (a fixed order: deterministic),
 // by the CONSUMER of the product while it stages its A operand (gemm_tile<..., ASK>), together with the
-// producer's bias / activation.  nkt / 2 <= U < nkt is required (every tile is split into two or three pieces).
+// producer's bias / activation.  U < nkt is required (every tile is split); with few tiles a tile is cut into up to
+// eight pieces (consumer instance AP = 8), with 128 .. 255 tiles into two or three (AP = 3).
 template <int KS, int D>
 __global__ void __launch_bounds__(256 * KS) k_gemm_sk(GemmArgs g, SkPlan sk) {
   // Units are dealt per XCD (blockIdx % 8, as the hardware deals blocks): the row tiles mt = x (mod 8) belong to
@@ -393,11 +396,12 @@ bool gemm_sk_partials(const GemmArgs& g, float* ws, size_t ws_floats, hipStream_
   p.MT = (int)cdiv(g.m_cap, 64);
   p.tiles = p.MT * p.NT;
   p.nkt = (int)cdiv(g.k, BK);
-  if (p.tiles >= TG_SK_WORKERS || p.nkt < 16) return false;
+  if (p.tiles >= TG_SK_WORKERS || p.nkt < 16) return false;  // (also covers few tiles: then a tile is cut into more pieces)
   const int64_t units_xcd = cdiv((int64_t)p.MT, 8) * p.NT * p.nkt;  // of the fullest XCD
   p.U = (int)cdiv(units_xcd, (int64_t)(TG_SK_WORKERS / 8));
   const int workers = TG_SK_WORKERS;
-  if (p.U >= p.nkt || 2 * p.U < p.nkt || p.U < 4 || ws_floats < (size_t)workers * 2 * 4096) return false;
+  p.pieces = (int)cdiv(p.nkt, p.U) + 1;  // most pieces a tile can be cut into (its range may start mid-worker)
+  if (p.U >= p.nkt || p.pieces > 8 || p.U < 3 || ws_floats < (size_t)workers * 2 * 4096) return false;
   p.part = ws;
   static const int gdbg = getenv("TG_GEMM_DBG") ? atoi(getenv("TG_GEMM_DBG")) : 0;
   GemmArgs gd = g;
@@ -429,7 +433,8 @@ int gemm_launch(const GemmArgs& g, hipStream_t st) {
     static const int ask_depth = getenv("TG_GEMM_ASK_DEPTH") ? atoi(getenv("TG_GEMM_ASK_DEPTH")) : 2;  // tuning knob: 2 / 4
     gd.ask_rcpU = 1.0f / (float)g.ask_U;
     static const int ask_ks = getenv("TG_GEMM_ASK_KS") ? atoi(getenv("TG_GEMM_ASK_KS")) : 2;  // tuning knob: 1 / 2 (measured 12.6 / 11.1 us)
-    if (ask_ks == 2) hipLaunchKernelGGL((k_gemm<2, 2, 2, 2, true>), dim3((unsigned)grid), dim3(512), 0, st, gd);
+    if (g.ask_pieces > 3) hipLaunchKernelGGL((k_gemm<2, 2, 2, 2, true, 8>), dim3((unsigned)grid), dim3(512), 0, st, gd);
+    else if (ask_ks == 2) hipLaunchKernelGGL((k_gemm<2, 2, 2, 2, true>), dim3((unsigned)grid), dim3(512), 0, st, gd);
     else if (ask_depth == 4) hipLaunchKernelGGL((k_gemm<2, 2, 1, 4, true>), dim3((unsigned)grid), dim3(256), 0, st, gd);
     else hipLaunchKernelGGL((k_gemm<2, 2, 1, 2, true>), dim3((unsigned)grid), dim3(256), 0, st, gd);
   } else if (split)

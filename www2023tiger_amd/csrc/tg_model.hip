@@ -425,7 +425,7 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
   g.m_cap = Q; g.n = d; g.k = d;
   g.a0 = ASeg{w.t, d, d, nullptr};
   if (pieces) {
-    g.ask_part = sk.part; g.ask_U = sk.U; g.ask_nkt = sk.nkt; g.ask_NT = sk.NT;
+    g.ask_part = sk.part; g.ask_U = sk.U; g.ask_nkt = sk.nkt; g.ask_NT = sk.NT; g.ask_pieces = sk.pieces;
     g.ask_bias = f.b1; g.ask_bias2 = f.c1; g.ask_valid = w.valid; g.ask_relu = 1; g.ask_alpha = 1.f;
   }
   g.w = m->attn_fc2.w; g.ldw = d; g.bias = m->attn_fc2.b;
