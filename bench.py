@@ -312,11 +312,11 @@ def main():
                        'gather_right_memory': 'tg::k_consume_gather_check', 'sample_recent_edges': 'tg::k_sample_batch<16>'}
     name = names[dom]
     t_s = stage_ms[dom] * 1e-3
-    # fabric/HBM bytes per launch of that kernel from the committed PMC passes (profiles/r01_hbm_traffic_v12.json,
+    # fabric/HBM bytes per launch of that kernel from the committed PMC passes (profiles/r01_hbm_traffic_v13.json,
     # collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command); null if not recorded
     traffic = None
     try:
-        tfile = {'c2': 'r01_hbm_traffic_v12.json', 'c5s': 'r01_hbm_traffic_c5s_v6.json'}.get(args.workload)
+        tfile = {'c2': 'r01_hbm_traffic_v13.json', 'c5s': 'r01_hbm_traffic_c5s_v6.json'}.get(args.workload)
         tj = json.load(open(os.path.join(ROOT, 'profiles', tfile))) if tfile else {'kernels': {}}
         traffic = tj['kernels'].get(kernel_of_stage.get(name, ''), {}).get('bytes_per_launch')
     except (OSError, ValueError):
