@@ -64,6 +64,30 @@ def test_owner_table_and_plan():
     assert ((bal.left_row % (5 * 32)) < 2 * 32).all() and ((bal.new_row % (5 * 32)) >= 3 * 32).all()
 
 
+def test_plan_row_maps_of_the_bench_layout_at_eight_ranks():
+    """The layout ResidentShardedStream gathers (4B rows per rank: [h(t'+) src | h(t'+) dst | h(t-) src | h(t-) dst])
+    at the size the driver runs: 8 ranks x B = 1024, Zipf destinations, every shard exactly full."""
+    from www2023tiger_amd.dist import ShardPlan, balanced_owner_table
+    rs = np.random.RandomState(3)
+    world, B, n_items = 8, 1024, 1000
+    p = 1.0 / np.arange(1, n_items + 1)
+    dst_all = rs.choice(n_items, 40000, p=p / p.sum()) + 8228
+    owner = balanced_owner_table(9228, dst_all, world)
+    for b in range(4):
+        dst = dst_all[b * world * B:(b + 1) * world * B]
+        plan = ShardPlan(dst, owner, world, B, balance=True, layout=(4 * B, 2 * B, 0, B))
+        assert plan.counts.tolist() == [B] * world
+        assert sorted(np.concatenate(plan.local_idx).tolist()) == list(range(world * B))
+        rows = np.concatenate([plan.left_row, plan.new_row])
+        assert len(set(rows.tolist())) == 4 * world * B and rows.min() >= 0 and rows.max() < world * 4 * B
+        assert ((plan.left_row % (4 * B)) >= 2 * B).all() and ((plan.new_row % (4 * B)) < 2 * B).all()
+        # position i of cat[src, dst] of the global batch: rank of its event, role block (src / dst), slot in the shard
+        ev = np.tile(np.arange(world * B), 2)
+        role = np.repeat([0, 1], world * B)
+        assert (plan.left_row // (4 * B) == plan.rank_of[ev]).all()
+        assert (((plan.left_row % (4 * B)) - 2 * B) // B == role).all() and ((plan.new_row % (4 * B)) // B == role).all()
+
+
 # ------------------------------------------------------------------------------ oracle backend (CPU)
 class OracleBackend:
     """Splits OracleTIGER.contrast_learning (tiger.py:196-255) into the two halves the
