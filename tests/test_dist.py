@@ -258,11 +258,13 @@ def _gpu_resident_worker(rank, world, port, name, B, n_steps, out_dir):
 
 
 @pytest.mark.gpu
-def test_resident_sharded_stream_graph_replay_equals_single_gpu(tmp_path):
+@pytest.mark.parametrize('world,B', [(2, 48), (4, 24)])
+def test_resident_sharded_stream_graph_replay_equals_single_gpu(tmp_path, world, B):
     """The production multi-GPU loop (balanced shards, resident stream, two hipGraphs + one
-    all-gather per step) against the single-GPU fused step on the same global batches."""
+    all-gather per step) against the single-GPU fused step on the same global batches; two and four
+    ranks (processes sharing the one GPU of the test box, gloo for the exchange)."""
     from test_hip_parity import build_hip_model
-    name, B, n_steps, world = 'static_ll_d16', 48, 6, 2
+    name, n_steps = 'static_ll_d16', 6
     mp.spawn(_gpu_resident_worker, args=(world, free_port(), name, B, n_steps, str(tmp_path)), nprocs=world, join=True)
     z = load(name)
     cfg = parse_cfg(z)
