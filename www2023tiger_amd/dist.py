@@ -312,9 +312,15 @@ def bench_main(args, cfg, make_stream, build_models, rank, local_rank, world):
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    tdist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    # rehearsal on a box with fewer GPUs than ranks (TG_BENCH_REHEARSAL=1): every rank uses GPU 0 and the exchange
+    # goes through gloo - the timings mean nothing, the flow (plans, shapes, collectives, the JSON line) is the same
+    rehearsal = bool(os.environ.get('TG_BENCH_REHEARSAL'))
+    dev = torch.device('cuda', 0 if rehearsal else local_rank)
+    torch.cuda.set_device(dev)
+    if rehearsal:
+        tdist.init_process_group('gloo', rank=rank, world_size=world)
+    else:
+        tdist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     B, K, d = cfg['B'], cfg['K'], cfg['d']
     Bg = B * world
     n_steps = args.warmup + args.steps
