@@ -22,6 +22,10 @@ import numpy as np
 import torch
 
 F32 = np.float32
+# inputs at least this long take the vectorised forms of the sampler / dedup loops (identical results,
+# checked in tests/test_oracle_golden.py); the full-size parity cases would otherwise spend minutes in Python
+VECTORISE_FROM = 4096
+EMBED_CHUNK = 16384
 
 
 # =============================================================================
@@ -71,6 +75,8 @@ class OracleGraph:
         strategy = self.strategy if strategy is None else strategy
         bs, K = len(nids), n_neighbors
         assert len(nids) == len(ts)
+        if strategy == 'recent_edges' and bs >= VECTORISE_FROM:
+            return self._sample_recent_edges_vectorised(np.asarray(nids), np.asarray(ts), K)
         o_n = np.zeros((bs, K), dtype=np.int64)
         o_e = np.zeros((bs, K), dtype=np.int64)
         o_t = np.zeros((bs, K), dtype=np.float32)
@@ -99,6 +105,28 @@ class OracleGraph:
             o_d[i, K - n:] = self.dir[sel]
         return o_n, o_e, o_t, o_d
 
+    def _sample_recent_edges_vectorised(self, nids, ts, K):
+        """The 'recent_edges' branch of the loop above for all queries at once (same arithmetic: a
+        'left' binary search on the float64 run of each node, then the K-entry tail, left padded).
+        Only a speed-up for the full-size parity cases; tests/test_oracle_golden.py checks it equal to
+        the per-query loop and against the reference's sampler vectors."""
+        lo0 = self.indptr[nids]
+        lo, hi = lo0.copy(), self.indptr[nids + 1].copy()
+        last = max(len(self.ts) - 1, 0)
+        while True:
+            act = lo < hi
+            if not act.any():
+                break
+            mid = (lo + hi) >> 1
+            go = act & (self.ts[np.minimum(mid, last)] < ts)  # entries with ts < t lie left of the cut
+            lo = np.where(go, mid + 1, lo)
+            hi = np.where(act & ~go, mid, hi)
+        idx = lo[:, None] - K + np.arange(K)[None, :]
+        ok = idx >= lo0[:, None]
+        idx = np.where(ok, idx, 0)
+        pick = lambda arr, dt: np.where(ok, arr[idx], 0).astype(dt) if len(arr) else np.zeros(idx.shape, dtype=dt)
+        return pick(self.nbr, np.int64), pick(self.eid, np.int64), pick(self.ts, np.float32), pick(self.dir, np.int64)
+
     def get_history(self, nids, ts, hist_len):  # graph.py:150-155
         return self.sample_temporal_neighbor(nids, ts, hist_len, strategy='recent_edges')
 
@@ -112,6 +140,10 @@ def select_latest_nids(nids: np.ndarray, ts: np.ndarray) -> Tuple[np.ndarray, np
     nids = np.asarray(nids)
     ts = np.asarray(ts)
     uniq, inv = np.unique(nids, return_inverse=True)
+    if len(nids) >= VECTORISE_FROM:  # same rule without the Python loop: per id the largest ts, first position among ties
+        order = np.lexsort((np.arange(len(nids)), -ts, inv))
+        first = np.concatenate([[True], inv[order][1:] != inv[order][:-1]])
+        return uniq.astype(np.int64), order[first].astype(np.int64)
     best = np.full(len(uniq), -1, dtype=np.int64)
     for i in range(len(nids)):
         j = inv[i]
@@ -361,6 +393,13 @@ class OracleTIGER:
 
     # ---- STEP 3 (temporal_agg_modules.py:29-83, 210-235) ---------------------
     def embed(self, reprs, local_index, nids3, ts3, l1_nids, l1_eids, l1_ts):
+        if len(nids3) > EMBED_CHUNK and self._drop(1) is None:
+            # every centre is embedded independently of the others: large batches go through in slices so that
+            # the [Q, K, 3d] key tensors of a 65 536-event batch do not have to exist at once
+            parts = [self.embed(reprs, local_index, nids3[a:a + EMBED_CHUNK], ts3[a:a + EMBED_CHUNK],
+                                l1_nids[a:a + EMBED_CHUNK], l1_eids[a:a + EMBED_CHUNK], l1_ts[a:a + EMBED_CHUNK])
+                     for a in range(0, len(nids3), EMBED_CHUNK)]
+            return torch.cat(parts, 0)
         pre = 'temporal_embedding_fn.fns.0.'
         c = reprs[_t(local_index[nids3])] + self.node_feat(_t(nids3))
         ln = _t(l1_nids)

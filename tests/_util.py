@@ -56,3 +56,38 @@ def rel_err(a, b):
     if a.size == 0 and b.size == 0:
         return 0.0
     return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+
+
+def row_rel_err(a, b, floor=1e-3):
+    """Truly relative measure: max over rows of ||a_i - b_i||_2 / ||b_i||_2, taken over the rows whose
+    reference norm exceeds `floor`; rows below the floor (padding / never-written rows) must agree to
+    `floor` * 1e-4 absolutely, reported on the same scale."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.size == 0 and b.size == 0:
+        return 0.0
+    a = a.reshape(-1, a.shape[-1]) if a.ndim > 1 else a.reshape(1, -1)
+    b = b.reshape(a.shape)
+    nb = np.sqrt((b * b).sum(1))
+    nd = np.sqrt(((a - b) ** 2).sum(1))
+    big = nb > floor
+    worst = float((nd[big] / nb[big]).max()) if big.any() else 0.0
+    if (~big).any():
+        worst = max(worst, float(nd[~big].max() / floor))
+    return worst
+
+
+WORST = {}  # test id -> {what: (max-abs-relative, row-relative)}; printed by conftest.pytest_terminal_summary
+
+
+def assert_close(a, b, what, tol=1e-4, row_tol=None):
+    """Both parity measures for float32 results: max|a-b| / max(1, max|b|) < tol AND the per-row relative
+    L2 error < row_tol (default tol).  The worst values of every test are collected for the session report."""
+    row_tol = tol if row_tol is None else row_tol
+    e1, e2 = rel_err(a, b), row_rel_err(a, b)
+    test = os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0].split('::', 1)[-1]
+    cur = WORST.setdefault(test, {}).get(what, (0.0, 0.0))
+    WORST[test][what] = (max(cur[0], e1), max(cur[1], e2))
+    assert e1 < tol, (what, 'max-abs-relative', e1)
+    assert e2 < row_tol, (what, 'row-relative', e2)
+    return e1, e2

@@ -42,3 +42,19 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Worst parity errors per test (max|a-b|/max(1,max|ref|) and per-row ||a-b||/||ref||)."""
+    try:
+        from _util import WORST
+    except Exception:
+        return
+    if not WORST:
+        return
+    terminalreporter.write_line('parity, worst error per test  [max-abs-relative | row-relative]')
+    for test, d in WORST.items():
+        e1 = max(v[0] for v in d.values())
+        e2 = max(v[1] for v in d.values())
+        which = max(d, key=lambda k: d[k][1])
+        terminalreporter.write_line(f'  {test}: {e1:.2e} | {e2:.2e} ({which})')

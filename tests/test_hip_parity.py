@@ -2,13 +2,16 @@
 and with the CPU oracle.  Needs a real MI355X: every test is marked gpu.
 
 Bars: integer / index outputs bit-exact; float32 embeddings and memory state within
-1e-4 relative (max |a-b| / max(1, max|ref|)) - the tolerance BASELINE.json's north_star
-states ("within 1e-4 relative fp32 and bit-exact neighbor indices")."""
+1e-4 relative - the tolerance BASELINE.json's north_star states ("within 1e-4 relative fp32
+and bit-exact neighbor indices") - under BOTH measures of _util.assert_close:
+max |a-b| / max(1, max|ref|) over the tensor and the per-row ||a_i-b_i|| / ||ref_i|| (rows with
+||ref_i|| > 1e-3).  The worst values per test are printed in the session summary."""
 import numpy as np
 import pytest
 import torch
 
-from _util import MODEL_FIXTURES, fixture_params, fixture_tables, load, n_batches, parse_cfg, rel_err
+from _util import (MODEL_FIXTURES, assert_close, fixture_params, fixture_tables, load, n_batches, parse_cfg, rel_err,
+                   row_rel_err)
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -225,13 +228,13 @@ def test_collator_bit_exact(name):
 # ------------------------------------------------------------------------------ full stream
 def check_state(model, z, tag):
     L, R, S = model.left_memory, model.right_memory, model.msg_store
-    assert rel_err(L.vals.cpu().numpy(), z[f'{tag}_left_vals']) < TOL, tag
-    assert rel_err(R.vals.cpu().numpy(), z[f'{tag}_right_vals']) < TOL, tag
+    assert_close(L.vals.cpu().numpy(), z[f'{tag}_left_vals'], 'left memory', TOL)
+    assert_close(R.vals.cpu().numpy(), z[f'{tag}_right_vals'], 'right memory', TOL)
     np.testing.assert_array_equal(L.update_ts.cpu().numpy(), z[f'{tag}_left_ts'])
     np.testing.assert_array_equal(R.update_ts.cpu().numpy(), z[f'{tag}_right_ts'])
     has = np.array(sorted(S.nodes_with_messages), dtype=np.int64)
     np.testing.assert_array_equal(has, z[f'{tag}_has_msg'])
-    assert rel_err(S.node_msg_vals.cpu().numpy()[has], z[f'{tag}_msg_vals']) < TOL, tag
+    assert_close(S.node_msg_vals.cpu().numpy()[has], z[f'{tag}_msg_vals'], 'mailbox', TOL)
     np.testing.assert_array_equal(S.node_msg_ts.cpu().numpy()[has], z[f'{tag}_msg_ts'])
 
 
@@ -258,8 +261,8 @@ def run_stream(name, fused, op_path=False):
             r_ts = torch.full((len(r),), float(np.float32(ts.min())), device=dev())
             if len(r):
                 hl, hr, pt = model.restarter_fn(r_nids, r_ts)
-                assert rel_err(hl.cpu().numpy(), z[f'{tag}_restart_h_left']) < TOL
-                assert rel_err(hr.cpu().numpy(), z[f'{tag}_restart_h_right']) < TOL
+                assert_close(hl.cpu().numpy(), z[f'{tag}_restart_h_left'], 'restart h_left', TOL)
+                assert_close(hr.cpu().numpy(), z[f'{tag}_restart_h_right'], 'restart h_right', TOL)
                 np.testing.assert_array_equal(pt.cpu().numpy(), z[f'{tag}_restart_prev_ts'])
             model.restart(r_nids, r_ts)
             uptodate.update(r.tolist())
@@ -273,13 +276,14 @@ def run_stream(name, fused, op_path=False):
             np.testing.assert_array_equal(buf.l1_ts.cpu().numpy(), z[f'{tag}_l1_ts'])
             np.testing.assert_array_equal(buf.involved.cpu().numpy()[:counts[0]], z[f'{tag}_involved'])
             assert counts[2] == len(z[f'{tag}_rd_nids'])
-            assert rel_err(buf.h[:2 * nb].cpu().numpy(), z[f'{tag}_h_left']) < TOL, (b, 'h_left')
-            assert rel_err(buf.h_prev_left.cpu().numpy(), z[f'{tag}_h_prev_left']) < TOL
-            assert rel_err(buf.h_prev_right.cpu().numpy(), z[f'{tag}_h_prev_right']) < TOL
+            assert_close(buf.h[:2 * nb].cpu().numpy(), z[f'{tag}_h_left'], 'h_left', TOL)
+            assert_close(buf.h_prev_left.cpu().numpy(), z[f'{tag}_h_prev_left'], 'h_prev_left', TOL)
+            assert_close(buf.h_prev_right.cpu().numpy(), z[f'{tag}_h_prev_right'], 'h_prev_right', TOL)
         else:
             loss, h_left, ps, ns, hpl, hpr = model.contrast_learning(s_t, d_t, n_t, t_t, e_t, cg)
-            for k, v in (('h_left', h_left), ('pos_scores', ps), ('neg_scores', ns), ('h_prev_left', hpl),
-                         ('h_prev_right', hpr)):
+            for k, v in (('h_left', h_left), ('h_prev_left', hpl), ('h_prev_right', hpr)):
+                assert_close(v.cpu().numpy(), z[f'{tag}_{k}'], k, TOL)
+            for k, v in (('pos_scores', ps), ('neg_scores', ns)):   # one logit per event: the tensor measure
                 assert rel_err(v.cpu().numpy(), z[f'{tag}_{k}']) < TOL, (b, k)
             assert abs(float(loss) - float(z[f'{tag}_loss'])) < 1e-4
             # mutual-learning surrogate on the collated restart data (tiger.py:576-590)
@@ -287,8 +291,8 @@ def run_stream(name, fused, op_path=False):
             u_n = torch.cat([s_t, d_t]).to(dev())[idx]
             u_t = t_t.to(dev()).repeat(2)[idx]
             sl_, sr_, spt = model.restarter_fn(u_n, u_t, cg)
-            assert rel_err(sl_.cpu().numpy(), z[f'{tag}_sur_left']) < TOL
-            assert rel_err(sr_.cpu().numpy(), z[f'{tag}_sur_right']) < TOL
+            assert_close(sl_.cpu().numpy(), z[f'{tag}_sur_left'], 'surrogate left', TOL)
+            assert_close(sr_.cpu().numpy(), z[f'{tag}_sur_right'], 'surrogate right', TOL)
             np.testing.assert_array_equal(spt.cpu().numpy().reshape(z[f'{tag}_sur_prev_ts'].shape),
                                           z[f'{tag}_sur_prev_ts'])
         if f'{tag}_left_vals' in z.files:
@@ -343,6 +347,20 @@ def test_state_dict_keys_match_reference():
 
 
 # ------------------------------------------------------------------------------ larger shapes vs the oracle
+def compare_state_with_oracle(model, orc):
+    """memories, mailbox rows, has-message set and timestamps of the HIP model against the oracle's"""
+    has = model.msg_store.has_msg_mask().cpu().numpy()
+    np.testing.assert_array_equal(np.nonzero(has)[0], np.nonzero(orc.has_msg)[0])
+    has = np.nonzero(has)[0]
+    assert_close(model.left_memory.vals.cpu().numpy(), orc.left_vals.numpy(), 'left memory', TOL)
+    assert_close(model.right_memory.vals.cpu().numpy(), orc.right_vals.numpy(), 'right memory', TOL)
+    assert_close(model.msg_store.node_msg_vals[torch.from_numpy(has).to(dev())].cpu().numpy(),
+                 orc.msg_vals.numpy()[has], 'mailbox', TOL)
+    np.testing.assert_array_equal(model.left_memory.update_ts.cpu().numpy(), orc.left_ts.numpy())
+    np.testing.assert_array_equal(model.right_memory.update_ts.cpu().numpy(), orc.right_ts.numpy())
+    np.testing.assert_array_equal(model.msg_store.node_msg_ts.cpu().numpy()[has], orc.msg_ts.numpy()[has])
+
+
 def _oracle_vs_fused(stream, d, K, B, n_batches, msg_src, upd_src, zero_nfeats=True, fuse=False):
     import bench
     from oracle import tiger_oracle as O
@@ -360,13 +378,8 @@ def _oracle_vs_fused(stream, d, K, B, n_batches, msg_src, upd_src, zero_nfeats=T
         np.testing.assert_array_equal(buf.l1_eids.cpu().numpy(), cg['l1_eids'])
         counts = buf.counts.cpu().numpy()
         np.testing.assert_array_equal(buf.involved.cpu().numpy()[:counts[0]], cg['involved'])
-        worst = max(worst, rel_err(buf.h[:2 * B].cpu().numpy(), ref))
-    has = np.array(sorted(model.msg_store.nodes_with_messages), dtype=np.int64)
-    np.testing.assert_array_equal(has, np.nonzero(orc.has_msg)[0])
-    assert rel_err(model.left_memory.vals.cpu().numpy(), orc.left_vals.numpy()) < TOL
-    assert rel_err(model.right_memory.vals.cpu().numpy(), orc.right_vals.numpy()) < TOL
-    assert rel_err(model.msg_store.node_msg_vals.cpu().numpy()[has], orc.msg_vals.numpy()[has]) < TOL
-    np.testing.assert_array_equal(model.left_memory.update_ts.cpu().numpy(), orc.left_ts.numpy())
+        worst = max(worst, assert_close(buf.h[:2 * B].cpu().numpy(), ref, 'h_left', TOL)[0])
+    compare_state_with_oracle(model, orc)
     assert worst < TOL, worst
 
 
@@ -454,13 +467,8 @@ def test_ragged_and_degenerate_batches_match_oracle():
         ref = orc.stream_step(*a, cg).numpy()
         n = hi - lo
         np.testing.assert_array_equal(buf.l1_nids.cpu().numpy()[:3 * n], cg['l1_nids'])
-        assert rel_err(buf.h[:2 * n].cpu().numpy(), ref) < TOL, (lo, hi)
-    has = np.array(sorted(model.msg_store.nodes_with_messages), dtype=np.int64)
-    np.testing.assert_array_equal(has, np.nonzero(orc.has_msg)[0])
-    assert rel_err(model.left_memory.vals.cpu().numpy(), orc.left_vals.numpy()) < TOL
-    assert rel_err(model.right_memory.vals.cpu().numpy(), orc.right_vals.numpy()) < TOL
-    np.testing.assert_array_equal(model.right_memory.update_ts.cpu().numpy(), orc.right_ts.numpy())
-    assert rel_err(model.msg_store.node_msg_vals.cpu().numpy()[has], orc.msg_vals.numpy()[has]) < TOL
+        assert_close(buf.h[:2 * n].cpu().numpy(), ref, 'h_left', TOL)
+    compare_state_with_oracle(model, orc)
 
 
 def test_reset_and_memory_snapshots():

@@ -186,3 +186,40 @@ def test_training_matches_reference(name):
     for k, v in m.p.items():
         assert rel_err(v.detach().numpy(), z[f"final.{k}"]) < 1e-3, k  # Adam amplifies ulp-level gradient noise
     check_state(m, z, 'final')
+
+
+# ------------------------------------------------------------------------------ vectorised forms of the oracle loops
+def test_vectorised_sampler_and_dedup_equal_the_loops(samp, monkeypatch):
+    """The full-size parity cases use numpy-vectorised forms of the per-query sampler loop and of the
+    select_latest loop; they must agree with the loops bit for bit (and with the reference's vectors)."""
+    g = _graph(samp, 'recent_edges')
+    rs = np.random.RandomState(11)
+    q = np.concatenate([samp['q_nids'], rs.randint(0, g.num_node, 5000)])
+    t = np.concatenate([samp['q_ts'], rs.choice(np.concatenate([samp['ts'], samp['ts'] + 0.5, [-1.0, 1e12]]), 5000)])
+    for K in (1, 10, 40):
+        for tq in (t, t.astype(np.float32)):
+            monkeypatch.setattr(O, 'VECTORISE_FROM', 10 ** 9)
+            loop = g.sample_temporal_neighbor(q, tq, K)
+            monkeypatch.setattr(O, 'VECTORISE_FROM', 0)
+            vec = g.sample_temporal_neighbor(q, tq, K)
+            for a, b in zip(loop, vec):
+                assert a.dtype == b.dtype
+                np.testing.assert_array_equal(a, b)
+    res = g.sample_temporal_neighbor(samp['q_nids'], samp['q_ts'], 10)   # still VECTORISE_FROM == 0
+    for nm, a in zip(('nbr', 'eid', 'ts', 'dir'), res):
+        np.testing.assert_array_equal(a, samp[f'recent_edges_K10_{nm}'])
+    ids = rs.randint(0, 300, 20000)
+    for ts in (np.floor(rs.uniform(0, 40, 20000)), np.floor(rs.uniform(0, 40, 20000)).astype(np.float32)):
+        monkeypatch.setattr(O, 'VECTORISE_FROM', 10 ** 9)
+        u0, i0 = O.select_latest_nids(ids, ts)
+        monkeypatch.setattr(O, 'VECTORISE_FROM', 0)
+        u1, i1 = O.select_latest_nids(ids, ts)
+        np.testing.assert_array_equal(u0, u1)
+        np.testing.assert_array_equal(i0, i1)
+    for i in range(3):
+        u, idx = O.select_latest_nids(samp[f'sel{i}_ids'], samp[f'sel{i}_ts'])
+        np.testing.assert_array_equal(u, samp[f'sel{i}_unique'])
+        np.testing.assert_array_equal(idx, samp[f'sel{i}_index'])
+    empty = O.OracleGraph(np.array([1]), np.array([2]), np.array([5.0]), np.array([1]), max_node_id=9)
+    out = empty.sample_temporal_neighbor(np.array([0, 1, 9]), np.array([1.0, 9.0, 9.0]), 3)
+    assert out[0].tolist() == [[0, 0, 0], [0, 0, 2], [0, 0, 0]]

@@ -129,5 +129,9 @@ class MessageStoreNoGradLastOnly(nn.Module):
         hip_ops.memory_scatter(self.node_msg_vals, self.node_msg_ts, None, ids, full, ts2, src_index=index)
         hip_ops.bitmap_mark(ids, self.has_msg_bits, self.n)
 
+    def has_msg_mask(self) -> Tensor:
+        """bool[n] on the device: node holds an unconsumed message (the bitmap, one flag per node)"""
+        return self._bits_of(torch.arange(self.n, device=self.device)).bool()
+
     def _bits_of(self, ids: Tensor) -> Tensor:
         return (self.has_msg_bits[ids >> 6] >> (ids & 63)) & 1

@@ -592,8 +592,9 @@ class TIGER(TIGE):
         nids = nids.to(dev).long().contiguous()
         h_left, h_right, prev_ts = self.restarter_fn(nids, ts.to(dev))
         if mix > 0:
-            h_left = mix * h_left + (1 - mix) * self.left_memory.vals[nids]
-            h_right = mix * h_right + (1 - mix) * self.right_memory.vals[nids]
+            # the library's gather, not torch indexing: tables beyond 2^31 elements (10 M nodes x 256)
+            h_left = mix * h_left + (1 - mix) * hip_ops.gather_rows(self.left_memory.vals, nids)
+            h_right = mix * h_right + (1 - mix) * hip_ops.gather_rows(self.right_memory.vals, nids)
         m = self.model_struct()
         check(lib.tg_restart_apply(C.byref(m), nids.numel(), ptr(nids), ptr(h_left.contiguous()),
                                    ptr(h_right.contiguous()), ptr(prev_ts.contiguous()), stream_ptr(dev)),
