@@ -228,6 +228,7 @@ def main():
     ap.add_argument('--dist-graphs', action='store_true',
                     help='multi-GPU: replay captured hipGraphs around the all-gather (experimental; default eager)')
     ap.add_argument('--no-fuse', action='store_true', help='keep the six-product attention (no tg_attn_fuse)')
+    ap.add_argument('--no-eager', action='store_true', help='updater on the fly for every involved node (no eager_updates)')
     ap.add_argument('--train', action='store_true', help='measure the training iteration instead (not the headline metric)')
     ap.add_argument('--train-restarter', default='none', choices=['none', 'seq', 'static'],
                     help='--train: add the mutual-learning loss of this restarter (none = contrast_only)')
@@ -256,6 +257,8 @@ def main():
     resident = tuple(torch.from_numpy(stream[k]).to(dev) for k in ('src', 'dst', 'neg', 'ts', 'eids'))
     if not args.no_fuse:  # streaming inference, parameters fixed: pre-multiplied attention weights (tg_attn_fuse)
         model.fuse_attention()
+    if not args.no_eager:  # ... and the updater run once per stored message (TIGE.eager_updates)
+        model.eager_updates()
     buf = model.StepBuffers(model, B, False, resident=resident)
     _ = model.graph.tcsr, model.model_struct()  # lazy device-side builds happen here, not inside a capture (--warmup 0)
 

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 2
+#define TG_ABI_VERSION 3
 
 /* status codes */
 #define TG_OK 0
@@ -210,6 +210,20 @@ typedef struct tg_model {
   /* Optional (NULL = off): weights pre-multiplied by tg_attn_fuse for inference with FIXED parameters.
    * The forward pass then runs three products instead of six (see tg_attn_fuse). */
   const float* attn_fused;
+  /* Optional (NULL = off): EAGER updates for streaming with FIXED parameters.  pending_vals [n_nodes, d] holds,
+   * for every node with a pending message (has_msg bit set), the row the updater would produce when the
+   * message is consumed: pending[v] = updater(upd_memory[v], tsfm(mailbox[v]))  (tiger.py:216,352-355).
+   * Between the batch that stores a node's message and the batch that consumes it, neither the mailbox row nor
+   * the node's memory rows change (both are written only when the node is a positive node of a batch, and that
+   * batch consumes the message first), so the reference's on-the-fly h(t'+) of a neighbour is the same row
+   * every time it is recomputed.  With this table tg_stream_step computes it ONCE, at the end of the step
+   * that stores the message (one updater launch over the unique positive nodes), and STEP 1-2 become a pure
+   * gather  reprs[u] = has_msg[v] ? pending[v] : right[v].  Results are those of the lazy form; the updater
+   * runs on P <= 2B rows per batch instead of on every involved node with a pending message.
+   * Contract (the caller's): whenever state or parameters change by any other route (restart, flush, reset,
+   * a training step, loading a snapshot) the table is rebuilt with tg_apply_messages over the has_msg set
+   * before the next eager step.  tg_train_step ignores the table. */
+  float* pending_vals;
 } tg_model;
 
 /* Inference-time algebra on the attention weights (parameters only, no data):
@@ -341,6 +355,7 @@ int tg_restart_apply(const tg_model* m, int64_t n, const int64_t* nids, const fl
 /* Fused streaming step: collate + STEP 1-6 of TIGE.contrast_learning         */
 /* (data_loader.py:77-131 + tiger.py:196-255) with no host round trip.         */
 /* ------------------------------------------------------------------------- */
+struct tg_lazy_restart; /* below */
 typedef struct tg_step_io {
   int64_t B;
   const int64_t* src;   /* [B] */
@@ -354,7 +369,7 @@ typedef struct tg_step_io {
   int64_t* l1_eids;     /* [3B, K] */
   float* l1_ts;         /* [3B, K] */
   int64_t* involved;    /* [3B*(K+1)] capacity */
-  int32_t* counts;      /* [4]: n_involved, n_outdated, n_unique_pos, reserved */
+  int32_t* counts;      /* [4]: n_involved, n_outdated, n_unique_pos, n_restarted (lazy restart, else 0) */
   float* h_prev_left;   /* [2B, d] restarter targets (tiger.py:248-251) or NULL */
   float* h_prev_right;  /* [2B, d] or NULL */
   uint32_t* err;        /* invariant word */
@@ -380,7 +395,33 @@ typedef struct tg_step_io {
    * 0 = unknown (the capacity and the node count are used).  (This field was `reserved` before: 0 is the old
    * behaviour, the layout is unchanged.) */
   int32_t rows_hint;
+  /* Lazy restart of train_self_supervised.py:152-163 with the StaticRestarter, on device (NULL = off);
+   * see tg_lazy_restart below. */
+  const struct tg_lazy_restart* lazy;
 } tg_step_io;
+
+/* The reference loop draws `np.random.rand() < restart_prob` before every batch but the first; a hit sets
+ * `restarting`, forgets which nodes are up to date and drops every pending message (msg_store.clear()).  While
+ * restarting, every batch re-initialises its involved nodes that are not yet up to date with
+ * TIGER.restart(nodes, full(min(ts))) (tiger.py:594-609).  With the StaticRestarter (restarters.py:254-277) the
+ * surrogate state is two table rows and the time of the node's last event before min(ts), so the whole
+ * loop body runs inside tg_stream_step, between the sampler and STEP 1, without a host round trip:
+ *   trigger[*batch_dev]  != 0: uptodate bitmap and has-message bitmap cleared, *restarting_dev = 1;
+ *   *restarting_dev != 0: for every involved node v without its uptodate bit:
+ *       left/right memory rows <- static_left[v] / static_right[v], both update_ts <- t'(v) = time of v's last
+ *       event strictly before float32(min(ts of the batch)) (0 when there is none), has-message bit cleared,
+ *       uptodate bit set.
+ * The step ends by incrementing *batch_dev.  The draws are the caller's (pre-drawn per batch, so a run is
+ * reproducible and can be replayed as a hipGraph). */
+typedef struct tg_lazy_restart {
+  const float* static_left;   /* StaticRestarter.left_emb.weight  [n_nodes, d] */
+  const float* static_right;  /* StaticRestarter.right_emb.weight [n_nodes, d] */
+  const uint8_t* trigger;     /* [n_trigger]; batches at or beyond n_trigger do not trigger */
+  int64_t n_trigger;
+  int64_t* batch_dev;         /* device batch counter (index into trigger); NULL = index 0, not advanced */
+  int32_t* restarting_dev;    /* device flag, persists between steps */
+  uint64_t* uptodate;         /* device bitmap over n_nodes (tg_bitmap_words), persists between steps */
+} tg_lazy_restart;
 
 /* Per-stage timer of tg_stream_step (HIP events on the step's stream).  Stage names:
  * tg_profiler_stage_name(i), i < tg_profiler_num_stages().  tg_profiler_read waits for

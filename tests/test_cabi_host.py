@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, n), f'{n} declared in tiger_hip.h but not exported'
         assert n in _lib.SIGNATURES, f'{n} has no ctypes signature'
     assert set(_lib.SIGNATURES) == set(names)
-    assert _lib.lib.tg_abi_version() == 2
+    assert _lib.lib.tg_abi_version() == 3
 
 
 def test_struct_layouts_match_header():
@@ -33,8 +33,8 @@ def test_struct_layouts_match_header():
     from www2023tiger_amd import _lib
     assert ctypes.sizeof(_lib.TgTcsr) == 6 * 8
     assert ctypes.sizeof(_lib.TgLinear) == 16
-    assert ctypes.sizeof(_lib.TgModel) == 8 + 8 * 4 + 8 * 13 + 2 * 16 + 4 * 8 + 2 * 16 + 4 * 8 + 3 * 16 + 8
-    assert ctypes.sizeof(_lib.TgStepIo) == 20 * 8
+    assert ctypes.sizeof(_lib.TgModel) == 8 + 8 * 4 + 8 * 13 + 2 * 16 + 4 * 8 + 2 * 16 + 4 * 8 + 3 * 16 + 8 + 8
+    assert ctypes.sizeof(_lib.TgStepIo) == 21 * 8
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
@@ -93,7 +93,7 @@ def test_struct_layouts_match_the_header(tmp_path):
     pairs = {'tg_tcsr': _lib.TgTcsr, 'tg_linear': _lib.TgLinear, 'tg_model': _lib.TgModel,
              'tg_seq_restarter': _lib.TgSeqRestarter, 'tg_step_io': _lib.TgStepIo,
              'tg_writeback_io': _lib.TgWritebackIo, 'tg_score_params': _lib.TgScoreParams,
-             'tg_train_io': _lib.TgTrainIo, 'tg_adam_seg': _lib.TgAdamSeg}
+             'tg_train_io': _lib.TgTrainIo, 'tg_adam_seg': _lib.TgAdamSeg, 'tg_lazy_restart': _lib.TgLazyRestart}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "tiger_hip.h"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')

@@ -45,7 +45,8 @@ def _compare_indices(buf, cg, node_map=None):
     return counts
 
 
-def test_c3_reddit_shape_b4096_static_lazy_restart():
+@pytest.mark.parametrize('eager', [False, True], ids=['lazy', 'eager'])
+def test_c3_reddit_shape_b4096_static_lazy_restart(eager):
     import bench
     from oracle import tiger_oracle as O
     from test_hip_parity import compare_state_with_oracle
@@ -55,6 +56,16 @@ def test_c3_reddit_shape_b4096_static_lazy_restart():
     E = (nb + 1) * B
     stream = bench.make_stream(c['n_u'], c['n_i'], E, c['T'] * E / c['E'], seed=3, d_e=d)
     model, orc = bench.build_models(stream, d, K, c['msg_src'], c['upd_src'], restarter='static', with_oracle=True)
+    # the reference initialises the static restarter's tables with zeros (restarters.py:259-260); trained values
+    # are what a restart is for, so the tables get non-trivial rows here (the same in the oracle)
+    torch.manual_seed(11)
+    with torch.no_grad():
+        for nm in ('left_emb', 'right_emb'):
+            tbl = getattr(model.restarter_fn, nm).weight
+            tbl.normal_(0.0, 0.5)
+            orc.p[f'restarter_fn.{nm}.weight'] = tbl.detach().cpu().clone()
+    if eager:
+        model.eager_updates()
     coll = GraphCollator(model.graph, K, 1, restarter='static')
     restarting, uptodate, n_restarted = False, set(), 0
     for b in range(nb):
@@ -98,6 +109,7 @@ def test_c4_lastfm_shape_b8192_no_feature_tables_large_timestamps():
     assert (ts.astype(np.float32).astype(np.float64) != ts).mean() > 0.5   # float32 cannot hold these times
     model, orc = bench.build_models(stream, d, K, c['msg_src'], c['upd_src'], with_oracle=True, zero_nfeats=False)
     assert model.raw_feat_getter.nfeats is None and model.raw_feat_getter.efeats is None
+    model.eager_updates()
     for b in range(nb):
         a = _batch(stream, b, B)
         cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], K, 'static')
@@ -126,6 +138,7 @@ def test_c5_d256_b65536_ten_million_node_tables():
     assert N == 10_000_001
     model, _ = bench.build_models(stream, d, K, c['msg_src'], c['upd_src'], zero_nfeats=False)
     model.fuse_attention()
+    model.eager_updates()   # the benchmarked form: updater rows precomputed per stored message
     # the oracle on the compacted id space (order preserving, padding id 0 kept)
     used = np.unique(np.concatenate([[0], stream['src'], stream['dst'], stream['neg']]))
     to_c = lambda x: np.searchsorted(used, x)

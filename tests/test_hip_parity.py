@@ -238,10 +238,12 @@ def check_state(model, z, tag):
     np.testing.assert_array_equal(S.node_msg_ts.cpu().numpy()[has], z[f'{tag}_msg_ts'])
 
 
-def run_stream(name, fused, op_path=False):
+def run_stream(name, fused, op_path=False, eager=False):
     z = load(name)
     cfg = parse_cfg(z)
     model, g, coll = build_hip_model(z, cfg)
+    if eager:  # updater rows precomputed when a message is stored; restart / flush below force rebuilds of the table
+        model.eager_updates()
     if op_path:  # operator-by-operator evaluation (one C call per reference method) instead of the one-call step
         model._fused_eval_ok = lambda: False
     B = cfg['B']
@@ -314,10 +316,12 @@ def test_stream_reference_api_operator_path(name):
     run_stream(name, fused=False, op_path=True)
 
 
+@pytest.mark.parametrize('eager', [False, True], ids=['lazy', 'eager'])
 @pytest.mark.parametrize('name', MODEL_FIXTURES)
-def test_stream_fused_step(name):
-    """tg_stream_step (collate + STEP 1-6 behind one C call), the benchmarked path."""
-    run_stream(name, fused=True)
+def test_stream_fused_step(name, eager):
+    """tg_stream_step (collate + STEP 1-6 behind one C call), the benchmarked path; `eager`: with the updater
+    run once per stored message (TIGE.eager_updates) instead of on the fly for every involved node."""
+    run_stream(name, fused=True, eager=eager)
 
 
 def test_invariant_errors_surface_as_value_errors():
@@ -361,12 +365,14 @@ def compare_state_with_oracle(model, orc):
     np.testing.assert_array_equal(model.msg_store.node_msg_ts.cpu().numpy()[has], orc.msg_ts.numpy()[has])
 
 
-def _oracle_vs_fused(stream, d, K, B, n_batches, msg_src, upd_src, zero_nfeats=True, fuse=False):
+def _oracle_vs_fused(stream, d, K, B, n_batches, msg_src, upd_src, zero_nfeats=True, fuse=False, eager=False):
     import bench
     from oracle import tiger_oracle as O
     model, orc = bench.build_models(stream, d, K, msg_src, upd_src, with_oracle=True, zero_nfeats=zero_nfeats)
     if fuse:
         model.fuse_attention()
+    if eager:
+        model.eager_updates()
     worst = 0.0
     for b in range(n_batches):
         sl = slice(b * B, (b + 1) * B)
@@ -397,7 +403,30 @@ def test_c2_bench_configuration_soak_matches_oracle():
     import bench
     c = bench.C2
     stream = bench.make_stream(c['n_u'], c['n_i'], 40000, c['T'] * 40000 / c['E'], seed=4, d_e=c['d'])
-    _oracle_vs_fused(stream, c['d'], c['K'], c['B'], 16, c['msg_src'], c['upd_src'], fuse=True)
+    _oracle_vs_fused(stream, c['d'], c['K'], c['B'], 16, c['msg_src'], c['upd_src'], fuse=True, eager=True)
+
+
+def test_c2_lazy_and_eager_updates_agree():
+    """the same stream through the lazy form (updater on every involved node with a pending message, every
+    batch) and the eager form (once per stored message): embeddings and state agree to float32 rounding of
+    differently tiled products, far inside the parity bar"""
+    import bench
+    c = bench.C2
+    stream = bench.make_stream(c['n_u'], c['n_i'], 12 * c['B'], c['T'] * 12 * c['B'] / c['E'], seed=8, d_e=c['d'])
+    lazy, _ = bench.build_models(stream, c['d'], c['K'], c['msg_src'], c['upd_src'])
+    eager, _ = bench.build_models(stream, c['d'], c['K'], c['msg_src'], c['upd_src'])
+    eager.eager_updates()
+    for b in range(10):
+        sl = slice(b * c['B'], (b + 1) * c['B'])
+        a = [stream[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        h0, h1 = lazy.stream_step(*a), eager.stream_step(*a)
+        np.testing.assert_array_equal(h0.counts.cpu().numpy()[:3], h1.counts.cpu().numpy()[:3])
+        assert_close(h1.h.cpu().numpy(), h0.h.cpu().numpy(), 'h (eager vs lazy)', 1e-5)
+        if b == 5:   # a flush in the middle: the eager table must be rebuilt (here: emptied) behind it
+            lazy.flush_msg(); eager.flush_msg()
+    assert_close(eager.left_memory.vals.cpu().numpy(), lazy.left_memory.vals.cpu().numpy(), 'left memory', 1e-5)
+    assert_close(eager.right_memory.vals.cpu().numpy(), lazy.right_memory.vals.cpu().numpy(), 'right memory', 1e-5)
+    assert torch.equal(eager.msg_store.has_msg_bits, lazy.msg_store.has_msg_bits)
 
 
 @pytest.mark.parametrize('B', [1200, 683, 200])

@@ -51,6 +51,7 @@ class TgModel(C.Structure):
         ('upd_fc1', TgLinear), ('upd_fc2', TgLinear),
         ('attn_wq', vp), ('attn_wk', vp), ('attn_wv', vp), ('attn_b_in', vp),
         ('attn_out', TgLinear), ('attn_fc1', TgLinear), ('attn_fc2', TgLinear), ('attn_fused', vp),
+        ('pending_vals', vp),
     ]
 
 
@@ -68,8 +69,13 @@ class TgStepIo(C.Structure):
         ('h', vp), ('l1_nids', vp), ('l1_eids', vp), ('l1_ts', vp), ('involved', vp), ('counts', vp),
         ('h_prev_left', vp), ('h_prev_right', vp), ('err', vp),
         ('offset_dev', vp), ('advance', i32), ('embed_only', i32), ('profiler', vp), ('h_new', vp),
-        ('ws_is_clean', i32), ('rows_hint', i32),
+        ('ws_is_clean', i32), ('rows_hint', i32), ('lazy', vp),
     ]
+
+
+class TgLazyRestart(C.Structure):
+    _fields_ = [('static_left', vp), ('static_right', vp), ('trigger', vp), ('n_trigger', i64), ('batch_dev', vp),
+                ('restarting_dev', vp), ('uptodate', vp)]
 
 
 class TgWritebackIo(C.Structure):
@@ -172,7 +178,7 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the library does not export the symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.tg_abi_version() != 2:
+    if lib.tg_abi_version() != 3:
         raise TigerHipError('libtiger_hip.so ABI version mismatch')
     return lib
 

@@ -222,6 +222,7 @@ struct PosArgs {
   unsigned long long* best;
   int32_t* count;
   int64_t *upos, *index;
+  int32_t* upos32;  // nullable: the winners' node ids once more as int32 (output rows of the eager updater launch)
 };
 __device__ __forceinline__ void pos_max_pass(const PosArgs& a, int64_t tid, int64_t nth) {
   if (tid == 0) *a.count = 0;  // the winners pass (a later launch) counts into it
@@ -240,14 +241,17 @@ __device__ __forceinline__ void pos_winners_pass(const PosArgs& a, int64_t tid, 
       const int slot = atomicAdd(a.count, 1);
       a.upos[slot] = node;
       a.index[slot] = i;
+      if (a.upos32) a.upos32[slot] = (int32_t)node;
     }
   }
 }
 // reprs <- right memory rows of the involved nodes, plus the message/memory time invariants
 // (+ the first dedup pass when pos != nullptr)
+// eager: rows of nodes with a pending message come from m->pending_vals (see tiger_hip.h) instead of being left
+// for the updater launch to fill
 int consume_gather_check_launch(const tg_model* m, const int64_t* involved, const int32_t* n_involved, int64_t cap,
                                 float* reprs, const int64_t* outdated, const int32_t* n_outdated, uint32_t* err,
-                                hipStream_t st, const PosArgs* pos = nullptr);
+                                hipStream_t st, const PosArgs* pos = nullptr, bool eager = false);
 // STEP 4-6 in two launches (phase 0 then 1); the tail work (counts copy, stream offset advance)
 // rides on phase 1
 struct WritebackArgs {

@@ -143,8 +143,13 @@ __global__ void __launch_bounds__(256) k_store_events(tg_model m, int64_t B, con
   }
 }
 
-// reprs[u] = right_memory[involved[u]] fused with the invariants of compute_messages
-// (message_modules.py:158-159, tiger.py:325-327) over the outdated list.
+// reprs[u] = right_memory[involved[u]] (tiger.py:214) fused with the invariants of compute_messages
+// (message_modules.py:158-159, tiger.py:325-327) over the outdated list.  Rows of nodes with a pending
+// message: lazy form (EAGER = false) - NOT copied, the updater launch that follows writes h(t'+) to exactly
+// those rows of reprs (tiger.py:219-221), copying them would be dead stores (in steady state most of the
+// involved set); eager form - gathered from the table of precomputed updater rows (tg_model.pending_vals), which
+// makes STEP 1-2 this one gather.
+template <bool EAGER>
 __global__ void k_consume_gather_check(tg_model m, const int64_t* __restrict__ involved,
                                        const int32_t* __restrict__ n_involved, int64_t cap, float4* __restrict__ reprs,
                                        const int64_t* __restrict__ outdated, const int32_t* __restrict__ n_outdated,
@@ -153,10 +158,18 @@ __global__ void k_consume_gather_check(tg_model m, const int64_t* __restrict__ i
   const int64_t n = min((int64_t)*n_involved, cap);
   const int64_t total = n * w4;
   const float4* right = reinterpret_cast<const float4*>(m.right_vals);
+  const float4* pend = reinterpret_cast<const float4*>(m.pending_vals);
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
   for (int64_t t = tid; t < total; t += nth) {
     const int64_t i = t / w4;
-    reprs[t] = right[involved[i] * w4 + (t - i * w4)];
+    const int64_t id = involved[i];
+    const bool pending = bm_test(m.has_msg, id);
+    if (EAGER) {
+      reprs[t] = (pending ? pend : right)[id * w4 + (t - i * w4)];
+    } else {
+      if (pending) continue;
+      reprs[t] = right[id * w4 + (t - i * w4)];
+    }
   }
   const int64_t no = min((int64_t)*n_outdated, cap);
   const float* mem_ts = (m.msg_src == TG_SRC_LEFT) ? m.left_ts : m.right_ts;
@@ -299,9 +312,14 @@ __global__ void __launch_bounds__(256) k_writeback(tg_model m, WritebackArgs a) 
 
 int consume_gather_check_launch(const tg_model* m, const int64_t* involved, const int32_t* n_involved, int64_t cap,
                                 float* reprs, const int64_t* outdated, const int32_t* n_outdated, uint32_t* err,
-                                hipStream_t st, const PosArgs* pos) {
-  hipLaunchKernelGGL(k_consume_gather_check, dim3(flat_grid(cap * (m->d / 4), 256)), dim3(256), 0, st, *m, involved,
-                     n_involved, cap, (float4*)reprs, outdated, n_outdated, err, pos ? *pos : PosArgs{});
+                                hipStream_t st, const PosArgs* pos, bool eager) {
+  if (eager && !m->pending_vals) return TG_EINVAL;
+  if (eager)
+    hipLaunchKernelGGL(k_consume_gather_check<true>, dim3(flat_grid(cap * (m->d / 4), 256)), dim3(256), 0, st, *m,
+                       involved, n_involved, cap, (float4*)reprs, outdated, n_outdated, err, pos ? *pos : PosArgs{});
+  else
+    hipLaunchKernelGGL(k_consume_gather_check<false>, dim3(flat_grid(cap * (m->d / 4), 256)), dim3(256), 0, st, *m,
+                       involved, n_involved, cap, (float4*)reprs, outdated, n_outdated, err, pos ? *pos : PosArgs{});
   return check_launch("consume_gather_check");
 }
 

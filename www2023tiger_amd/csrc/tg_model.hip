@@ -694,12 +694,14 @@ extern "C" int tg_apply_messages(const tg_model* m, const int64_t* outdated, con
 namespace tg {
 enum Stage : int {
   ST_QUERIES = 0, ST_SAMPLE, ST_COMPACT, ST_GATHER, ST_UPDATE, ST_ATTN_PREP, ST_ATTN_Q, ST_ATTN_G, ST_ATTN_CORE,
-  ST_ATTN_V, ST_ATTN_O, ST_ATTN_FC1, ST_ATTN_FC2, ST_DEDUP, ST_WRITE_RIGHT, ST_STORE_EVENTS, ST_WRITE_LEFT, ST_COUNT
+  ST_ATTN_V, ST_ATTN_O, ST_ATTN_FC1, ST_ATTN_FC2, ST_DEDUP, ST_WRITE_RIGHT, ST_STORE_EVENTS, ST_WRITE_LEFT, ST_EAGER,
+  ST_COUNT
 };
 static const char* const kStageNames[ST_COUNT] = {
     "zero_flags", "sample_recent_edges", "unique_compact", "gather_right_memory", "apply_messages(gru)",
     "attn_centres+qconst", "attn_gemm_q", "attn_gemm_g", "attn_core(gather+softmax)", "attn_gemm_v", "attn_gemm_out",
-    "attn_gemm_fc1", "attn_gemm_fc2", "dedup_positive", "writeback_phase0", "restarter_targets", "writeback_phase1"};
+    "attn_gemm_fc1", "attn_gemm_fc2", "dedup_positive", "writeback_phase0", "restarter_targets", "writeback_phase1",
+    "eager_updater(gru)"};
 static_assert(ST_ATTN_PREP == ST_ATTN_FIRST, "attention stage numbering");
 }  // namespace tg
 
@@ -753,11 +755,12 @@ bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w) {
   char* z0 = cv.p;
   w.flags = cv.take<uint8_t>((size_t)W * 64);
   w.best = cv.take<unsigned long long>((size_t)cap);
-  w.counts = cv.take<int32_t>(4);
+  w.counts = cv.take<int32_t>(8);
   w.zero_bytes = cv.ok ? (size_t)(cv.p - z0) : 0;
   w.bm = cv.take<uint64_t>((size_t)W);
   w.rank = cv.take<uint32_t>((size_t)W + 1);
   w.rank_out = cv.take<uint32_t>((size_t)W + 1);
+  w.upos32 = cv.take<int32_t>((size_t)2 * B);
   w.nids3 = cv.take<int64_t>((size_t)Q);
   w.eids = cv.take<int64_t>((size_t)B);
   w.ts3 = cv.take<double>((size_t)Q);
@@ -783,7 +786,8 @@ bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w) {
 extern "C" size_t tg_stream_step_workspace_bytes(const tg_model* m, int64_t B) {
   if (!attn_dims_ok(m) || B <= 0 || m->n_nodes <= 0) return 0;
   const size_t Q = 3 * (size_t)B, K = m->n_neighbors, cap = Q * (K + 1), W = (m->n_nodes + 63) / 64;
-  size_t b = align16(W * 64) + align16(W * 8) + align16(cap * 8) + 16 + 2 * align16((W + 1) * 4) + align16(Q * 8) * 2 + align16(B * 8) +
+  size_t b = align16(W * 64) + align16(W * 8) + align16(cap * 8) + 32 + 2 * align16((W + 1) * 4) + align16(2 * B * 4) +
+             align16(Q * 8) * 2 + align16(B * 8) +
              align16(Q * 4) + align16(Q * K * 8) * 2 + align16(Q * K * 4) + align16(cap * 8) * 2 + align16(cap * 4) +
              align16(2 * B * 8) * 2 + align16(cap * m->d * 4) + align16(tg_unique_compact_workspace_bytes(m->n_nodes)) +
              attn_ws_bytes(m, Q) + align16(apply_ws_bytes(m, cap));
@@ -793,12 +797,13 @@ extern "C" size_t tg_stream_step_workspace_bytes(const tg_model* m, int64_t B) {
 extern "C" size_t tg_stream_step_zero_bytes(const tg_model* m, int64_t B) {
   if (!attn_dims_ok(m) || B <= 0 || m->n_nodes <= 0) return 0;
   const size_t cap = 3 * (size_t)B * (m->n_neighbors + 1), W = (m->n_nodes + 63) / 64;
-  return align16(W * 64) + align16(cap * 8) + 16;
+  return align16(W * 64) + align16(cap * 8) + 32;
 }
 
 namespace tg {
 int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, StepWs& w, float* gates, hipStream_t st,
-                 tg_profiler* pf, const DropCfg* drop) {
+                 tg_profiler* pf, const DropCfg* drop, bool eager) {
+  w.eager = eager;
   const int64_t B = io->B, Q = 3 * B, K = m->n_neighbors, cap = Q * (K + 1);
   prof_mark(pf, ST_QUERIES, st);
   hipError_t e = hipSuccess;
@@ -824,15 +829,16 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
     return rc;
   prof_mark(pf, ST_GATHER, st);
   // the positive-node dedup (needed by the write-back) rides on two launches of the forward pass
-  PosArgs pos{B, w.nids3, w.ts3f, w.bm, w.rank, w.best, w.counts + 2, w.upos, w.index};
+  PosArgs pos{B, w.nids3, w.ts3f, w.bm, w.rank, w.best, w.counts + 2, w.upos, w.index, w.upos32};
   const PosArgs* pp = io->embed_only ? nullptr : &pos;
   w.dedup_done = pp != nullptr;
   // ---- STEP 1-2: reprs = right_memory[involved] (+ invariants); outdated rows <- updater(...)
   if ((rc = consume_gather_check_launch(m, w.inv, w.counts + 0, cap, w.reprs, w.outdated, w.counts + 1, io->err, st,
-                                        pp)) != TG_OK)
+                                        pp, eager)) != TG_OK)
     return rc;
   prof_mark(pf, ST_UPDATE, st);
-  if ((rc = apply_messages(m, w.outdated, w.out_pos, w.counts + 1, cap, w.reprs, io->err, w.apply_ws, w.apply_bytes,
+  if (!eager &&  // eager: the rows were gathered from the table of precomputed updater rows just now
+      (rc = apply_messages(m, w.outdated, w.out_pos, w.counts + 1, cap, w.reprs, io->err, w.apply_ws, w.apply_bytes,
                            st, true, gates, io->rows_hint)) != TG_OK)
     return rc;
   // ---- STEP 3: temporal embeddings of cat[src, dst, neg]
@@ -898,6 +904,16 @@ int step_writeback_b(const tg_model* m, const tg_step_io* io, StepWs& w, hipStre
   prof_mark(pf, ST_WRITE_LEFT, st);
   int rc;
   if ((rc = writeback_launch(m, wa, 1, st)) != TG_OK) return rc;
+  prof_mark(pf, ST_EAGER, st);
+  if (w.eager) {
+    // every unique positive node has just received a message (STEP 5) and its memories are final for this batch
+    // (STEP 4 / STEP 6): the row a later batch would compute on the fly when the node turns up as a neighbour,
+    // pending[v] = updater(upd_memory[v], tsfm(mailbox[v])), is computed here, once
+    const int64_t P = 2 * io->B;
+    if ((rc = apply_messages(m, w.upos, w.upos32, w.counts + 2, P, m->pending_vals, io->err, w.apply_ws, w.apply_bytes, st,
+                             true, nullptr, P)) != TG_OK)
+      return rc;
+  }
   prof_mark(pf, ST_COUNT, st);
   if (pf) pf->armed = true;
   return check_launch("tg_stream_step");
@@ -915,7 +931,9 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
   StepWs w{};
   if (!carve_step(m, io->B, cv, w)) return TG_EWORKSPACE;
   int rc;
-  if ((rc = step_forward(m, g, io, w, nullptr, st, pf)) != TG_OK) return rc;
+  // eager updates need the full step (the updater launch at its end keeps the table current)
+  const bool eager = m->pending_vals != nullptr && !io->embed_only;
+  if ((rc = step_forward(m, g, io, w, nullptr, st, pf, nullptr, eager)) != TG_OK) return rc;
   if (io->embed_only) {
     if (io->counts) {
       hipError_t e = hipMemcpyAsync(io->counts, w.counts, 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, st);

@@ -40,7 +40,8 @@ struct AttnWs {
 struct StepWs {
   uint8_t* flags;            // involved byte flags        (zeroed every step)
   unsigned long long* best;  // per involved rank          (zeroed every step)
-  int32_t* counts;           // [4]                        (zeroed every step)
+  int32_t* counts;           // [8]: involved, outdated, unique positives, restarted | batch-min-time key, 3 spare
+                             //                            (zeroed every step)
   size_t zero_bytes;         // size of the contiguous zeroed region starting at flags
   uint64_t* bm;              // involved bitmap, packed from the flags
   uint32_t *rank, *rank_out;
@@ -49,6 +50,7 @@ struct StepWs {
   float *ts3f, *l1_ts, *reprs;
   int64_t *l1_nids, *l1_eids;
   int32_t* out_pos;
+  int32_t* upos32;
   void* scan_ws;
   size_t scan_bytes;
   AttnWs attn;
@@ -58,13 +60,15 @@ struct StepWs {
   int64_t *l1n, *l1e, *inv;
   float* l1t;
   bool dedup_done;  // the positive-node dedup already ran inside the forward launches
+  bool eager;       // STEP 1-2 gathered precomputed updater rows; the updater runs at the end of the step instead
 };
 
 bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w);
 int attn_dims_ok(const tg_model* m);
 // collate + STEP 1-3 (+ io->h_new); `gates` (nullable) receives the GRU gate activations
+// eager: take the outdated nodes' rows from m->pending_vals instead of running the updater (tg_stream_step only)
 int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, StepWs& w, float* gates, hipStream_t st,
-                 tg_profiler* pf, const DropCfg* drop = nullptr);
+                 tg_profiler* pf, const DropCfg* drop = nullptr, bool eager = false);
 // positive-node dedup + STEP 4/5 + restarter targets
 int step_writeback_a(const tg_model* m, const tg_step_io* io, StepWs& w, hipStream_t st, tg_profiler* pf);
 // STEP 6 + workspace clean-up + offset advance

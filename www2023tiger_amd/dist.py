@@ -169,6 +169,7 @@ class HipBackend:
 
     def writeback(self, src, dst, ts, eids, rows, left_row, new_row):
         m, lib, ptr = self.model, self.lib, self.ptr
+        m._touch()  # state changes outside the model's own step
         Bg = len(src)
         ms = m.model_struct()
         keep = [self._dev(src, torch.int64), self._dev(dst, torch.int64), self._dev(ts, torch.float64),
@@ -243,6 +244,7 @@ class ResidentShardedStream:
         self.stream = torch.cuda.Stream(device=dev) if (use_graphs and dev.type == 'cuda') else None
 
     def _launch_wb(self):
+        self.model._touch()  # state changes outside the model's own step
         ms = self.model.model_struct()
         self.check(self.lib.tg_stream_writeback(C.byref(ms), C.byref(self.wb_io), self.ptr(self.wb_ws),
                                                 self.wb_ws.numel(), self.hip_ops.stream_ptr(self.model.device)),

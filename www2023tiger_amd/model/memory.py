@@ -24,6 +24,7 @@ class Memory(nn.Module):
         self.register_buffer('vals', torch.zeros(n, dim), persistent=True)
         self.register_buffer('update_ts', torch.zeros(n), persistent=True)
         self.register_buffer('active_mask', torch.zeros(n).bool(), persistent=True)
+        self._version_ = 0  # bumped by every mutating method (the model's eager-update table watches it)
 
     def clone(self):
         """memory.py:21-25 - like the reference, active_mask is not carried over."""
@@ -37,6 +38,7 @@ class Memory(nn.Module):
         return self.vals.device
 
     def clear(self):
+        self._version_ += 1
         self.vals.zero_()
         self.update_ts.zero_()
         self.active_mask.zero_()
@@ -47,6 +49,7 @@ class Memory(nn.Module):
     def set(self, ids: Tensor, vals: Tensor, ts: Tensor, skip_check=False):
         if len(ids) == 0:
             return
+        self._version_ += 1
         err = None
         if not skip_check:
             if len(ids) != len(torch.unique(ids)):
@@ -68,6 +71,7 @@ class MessageStoreNoGradLastOnly(nn.Module):
         self.register_buffer('node_msg_vals', torch.zeros((n, dim)).float(), persistent=False)
         self.register_buffer('node_msg_ts', torch.zeros(n).float(), persistent=False)
         self.register_buffer('has_msg_bits', torch.zeros(hip_ops.bitmap_words(n), dtype=torch.int64), persistent=False)
+        self._version_ = 0  # bumped by every mutating method
 
     @property
     def node_messages(self):
@@ -102,6 +106,7 @@ class MessageStoreNoGradLastOnly(nn.Module):
     def clear(self, nids: Optional[Tensor] = None):
         """memory.py:128-138 (the reference's zero-fill of rows is a no-op on an indexed copy;
         only membership changes)."""
+        self._version_ += 1
         if nids is None:
             self.has_msg_bits.zero_()
             return
@@ -116,6 +121,7 @@ class MessageStoreNoGradLastOnly(nn.Module):
                      time_encoder):
         """memory.py:77-106, composed from the standalone ops.  TIGE.store_events uses the
         fused tg_store_events kernel instead; this form exists for API compatibility."""
+        self._version_ += 1
         pos = torch.cat([src_ids, dst_ids])
         if bool((self._bits_of(pos)).any()):
             raise ValueError('Node has unused messages.')

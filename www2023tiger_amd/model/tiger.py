@@ -99,6 +99,9 @@ class TIGE(nn.Module):
         self.contrast_loss_fn = nn.BCEWithLogitsLoss()
         self._struct_cache = None
         self._fused = None
+        self._pending = None        # eager updates: table of precomputed updater rows (see eager_updates)
+        self._pending_stamp = None  # state stamp the table is current for
+        self._state_version = 0     # bumped by every method that changes state outside the eager streaming step
         self._step_ws = {}
 
     def _sanity_check(self):
@@ -123,6 +126,8 @@ class TIGE(nn.Module):
     def _apply(self, fn, *a, **kw):  # .to() / .cuda() move every tensor: pointers change
         self._struct_cache = None
         self._fused = None
+        self._pending = None
+        self._pending_stamp = None
         self._step_ws = {}
         return super()._apply(fn, *a, **kw)
 
@@ -170,9 +175,61 @@ class TIGE(nn.Module):
                     tsfm1, tsfm2, gru[0], gru[1], gru[2], gru[3], fc1, fc2,
                     ptr(mha.q_proj_weight), ptr(mha.k_proj_weight), ptr(mha.v_proj_weight), ptr(mha.in_proj_bias),
                     lin(mha.out_proj), lin(att.merger.fc1), lin(att.merger.fc2),
-                    ptr(self._fused) if self._fused is not None else None)
+                    ptr(self._fused) if self._fused is not None else None,
+                    ptr(self._pending) if self._pending is not None else None)
         self._struct_cache = m
         return m
+
+    # ---- eager updates (streaming with fixed parameters) ----------------------------------
+    def eager_updates(self, enable: bool = True):
+        """Streaming inference with FIXED parameters: h(t'+) of a node with a pending message is the same row
+        every time the reference recomputes it (neither its mailbox row nor its memories change before the
+        message is consumed), so `stream_step` / `launch_step` compute it ONCE, at the end of the batch that
+        stores the message, into a [n_nodes, d] table; STEP 1-2 of later batches are then a gather of that
+        table and the updater runs on the unique positive nodes of a batch instead of on every involved node
+        with a pending message (C2: ~1 050 rows instead of ~4 200).  Same results as the lazy form.
+        Every other method that touches state (restart, flush_msg, reset, contrast_learning, snapshots ...)
+        is noticed and the table is rebuilt before the next eager step; after a parameter update or after
+        writing to state tensors directly, call `invalidate_pending()`."""
+        self._pending = None
+        self._pending_stamp = None
+        self._struct_cache = None
+        if enable:
+            self._pending = torch.zeros(self.n_nodes, self.memory_dim, dtype=torch.float32, device=self.device)
+        return self
+
+    def invalidate_pending(self):
+        self._pending_stamp = None
+
+    def _touch(self):
+        self._state_version += 1
+
+    def _state_stamp(self):
+        L, R, S = self.left_memory, self.right_memory, self.msg_store
+        return (self._state_version, id(L), L._version_, id(R), R._version_, id(S), S._version_)
+
+    def _sync_pending(self):
+        """Rebuild the table of precomputed updater rows if state changed outside the eager step:
+        pending[v] = updater(upd_memory[v], tsfm(mailbox[v])) for every node with a pending message."""
+        stamp = self._state_stamp()
+        if stamp == self._pending_stamp:
+            return
+        if self.device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('eager updates: run one step eagerly before capturing it into a graph')
+        dev = self.device
+        m = self.model_struct()
+        comp = hip_ops.unique_compact(self.msg_store.has_msg_bits, self.n_nodes, self.n_nodes)
+        n = int(comp['count'].item())
+        if n:
+            ids = comp['ids'][:n].contiguous()
+            ids32 = ids.to(torch.int32)
+            err = hip_ops.new_err(dev)
+            nbytes = int(lib.tg_apply_messages_workspace_bytes(C.byref(m), n))
+            ws = self._ws('apply', nbytes)
+            check(lib.tg_apply_messages(C.byref(m), ptr(ids), ptr(ids32), ptr(comp['count']), n, ptr(self._pending),
+                                        ptr(err), ptr(ws), ws.numel(), stream_ptr(dev)), 'tg_apply_messages(pending)')
+            hip_ops.raise_if_err(err)
+        self._pending_stamp = stamp
 
     def fuse_attention(self, enable: bool = True):
         """Inference with FIXED parameters: pre-multiply the attention weights (tg_attn_fuse) so that the
@@ -235,6 +292,7 @@ class TIGE(nn.Module):
         write-back) runs as one tg_train_step; the returned losses carry an autograd node that
         hands the finished gradients to the parameters when `.backward()` is called."""
         from .training import TrainBuffers, hand_over
+        self._touch()
         dev = self.device
         B = len(src_ids)
         key = ('train', B, mutual)
@@ -312,6 +370,7 @@ class TIGE(nn.Module):
         gradient buffers).  The computation graph only contributes the float64 event times: the step
         samples the same neighbourhoods itself."""
         from .training import TrainBuffers
+        self._touch()
         dev = self.device
         B = len(src_ids)
         key = ('eval', B)
@@ -341,6 +400,7 @@ class TIGE(nn.Module):
 
     def _contrast_learning_eval(self, src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph):
         cg = computation_graph
+        self._touch()
         dev = self.device
         m = self.model_struct()
         s = stream_ptr(dev)
@@ -401,6 +461,7 @@ class TIGE(nn.Module):
             step then reads batch [offset, offset+B) and advances `offset` on device."""
             dev, d, K = model.device, model.memory_dim, model.n_neighbors
             self.B = B
+            self.embed_only = embed_only
             i64 = dict(dtype=torch.int64, device=dev)
             self.offset = None
             if resident is None:
@@ -466,6 +527,8 @@ class TIGE(nn.Module):
     def launch_step(self, buf: 'TIGE.StepBuffers'):
         """Enqueue collate + STEP 1-6 for the batch already in `buf` (no host sync)."""
         buf.io.rows_hint = self.rows_bound()
+        if self._pending is not None and not buf.embed_only:
+            self._sync_pending()
         m = self.model_struct()
         g = self.graph.tcsr
         check(lib.tg_stream_step(C.byref(m), C.byref(g), C.byref(buf.io), ptr(buf.ws), buf.ws.numel(),
@@ -505,6 +568,7 @@ class TIGE(nn.Module):
     def flush_msg(self):
         """tiger.py:444-455: consume every pending message into the right memory."""
         self._poll_train_errors()
+        self._touch()
         dev = self.device
         m = self.model_struct()
         err = hip_ops.new_err(dev)
@@ -518,7 +582,17 @@ class TIGE(nn.Module):
             self.msg_store.clear(ids)
         hip_ops.raise_if_err(err)
 
+    def load_state_dict(self, *args, **kwargs):
+        """parameters (and memories) change under the derived tables: the pre-multiplied attention weights are
+        recomputed and the eager-update table is rebuilt before its next use"""
+        out = super().load_state_dict(*args, **kwargs)
+        self._touch()
+        if self._fused is not None:
+            self.fuse_attention()
+        return out
+
     def reset(self):
+        self._touch()
         self.left_memory.clear()
         self.right_memory.clear()
         self.msg_store.clear()
@@ -527,6 +601,7 @@ class TIGE(nn.Module):
         return (self.left_memory.clone(), self.right_memory.clone(), self.msg_store.clone())
 
     def load_memory_state(self, data):
+        self._touch()
         self.left_memory, self.right_memory, self.msg_store = data
         self.msg_memory = self.left_memory if self.msg_src == 'left' else self.right_memory
         self.upd_memory = self.left_memory if self.upd_src == 'left' else self.right_memory
@@ -588,6 +663,7 @@ class TIGER(TIGE):
         """tiger.py:594-609: fill both memories with the surrogate state."""
         if len(nids) == 0:
             return
+        self._touch()
         dev = self.device
         nids = nids.to(dev).long().contiguous()
         h_left, h_right, prev_ts = self.restarter_fn(nids, ts.to(dev))
