@@ -24,7 +24,7 @@ import torch
 F32 = np.float32
 # inputs at least this long take the vectorised forms of the sampler / dedup loops (identical results,
 # checked in tests/test_oracle_golden.py); the full-size parity cases would otherwise spend minutes in Python
-VECTORISE_FROM = 4096
+VECTORISE_FROM = 256
 EMBED_CHUNK = 16384
 
 

@@ -94,6 +94,58 @@ def test_c3_reddit_shape_b4096_static_lazy_restart(eager):
     compare_state_with_oracle(model, orc)
 
 
+@pytest.mark.parametrize('eager', [False, True], ids=['lazy', 'eager'])
+def test_c3_in_step_lazy_restart_equals_the_reference_loop(eager):
+    """BASELINE configs[2] as written: the restart draws of train_self_supervised.py:152-163 are made up front
+    and the loop body (forget / clear mailbox on a hit, re-initialise the involved nodes that are not up to date
+    with the static restarter) runs inside tg_stream_step; the oracle runs the reference's loop on the host."""
+    import bench
+    from oracle import tiger_oracle as O
+    from test_hip_parity import compare_state_with_oracle
+    c = bench.WORKLOADS['c3']
+    B, K, d, nb = c['B'], c['K'], c['d'], 9
+    E = (nb + 1) * B
+    stream = bench.make_stream(c['n_u'], c['n_i'], E, c['T'] * E / c['E'], seed=13, d_e=d)
+    model, orc = bench.build_models(stream, d, K, c['msg_src'], c['upd_src'], restarter='static', with_oracle=True)
+    torch.manual_seed(12)
+    with torch.no_grad():
+        for nm in ('left_emb', 'right_emb'):
+            tbl = getattr(model.restarter_fn, nm).weight
+            tbl.normal_(0.0, 0.5)
+            orc.p[f'restarter_fn.{nm}.weight'] = tbl.detach().cpu().clone()
+    if eager:
+        model.eager_updates()
+    trigger = np.zeros(nb, dtype=np.uint8)
+    trigger[[2, 6]] = 1          # two hits: the second one forgets the nodes restarted after the first
+    buf = model.step_buffers(B).enable_lazy_restart(model, trigger)
+    restarting, uptodate = False, set()
+    for b in range(nb):
+        a = _batch(stream, b, B)
+        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], K, 'static')
+        n_r = 0
+        if trigger[b] and b:
+            restarting, uptodate = True, set()
+            orc.clear_msgs()
+        if restarting:
+            r = np.array(sorted(set(cg['involved'].tolist()) - uptodate), dtype=np.int64)
+            orc.restart(r, np.full(len(r), np.float32(a[3].min()), dtype=np.float32))
+            uptodate.update(r.tolist())
+            n_r = len(r)
+        got = model.stream_step(*a)
+        assert got is buf
+        ref = orc.stream_step(*a, cg).numpy()
+        counts = _compare_indices(buf, cg)
+        assert counts[3] == n_r, (b, counts, n_r)
+        assert_close(buf.h[:2 * B].cpu().numpy(), ref, 'h_left', TOL)
+        if b in (2, 3, 6):
+            compare_state_with_oracle(model, orc)
+    assert int(buf.lazy_batch) == nb and int(buf.lazy_restarting) == 1
+    up = buf.lazy_uptodate.cpu().numpy().view(np.uint64)
+    bits = np.unpackbits(up.view(np.uint8), bitorder='little')[:model.n_nodes]
+    np.testing.assert_array_equal(np.nonzero(bits)[0], np.array(sorted(uptodate)))
+    compare_state_with_oracle(model, orc)
+
+
 def test_c4_lastfm_shape_b8192_no_feature_tables_large_timestamps():
     import bench
     from oracle import tiger_oracle as O

@@ -209,7 +209,11 @@ __device__ __forceinline__ uint64_t orderable(float x) {
 int sample_batch_launch(const tg_tcsr* g, int64_t B, const int64_t* src, const int64_t* dst, const int64_t* neg,
                         const double* ts, const int64_t* eids, const int64_t* off, int32_t K, int64_t* nids3,
                         float* ts3f, int64_t* eids_b, int64_t* o_nbr, int64_t* o_eid, float* o_ts, uint8_t* mark,
-                        hipStream_t st);
+                        hipStream_t st, uint32_t* tmin_key = nullptr);
+// the lazy-restart loop body of train_self_supervised.py:152-163 with the static restarter (tiger_hip.h: tg_lazy_restart);
+// runs between the sampler (flags, *tmin_key) and the compaction
+int lazy_restart_launch(const tg_tcsr* g, const tg_model* m, const tg_lazy_restart* lz, const uint8_t* flags,
+                        const uint32_t* tmin_key, int32_t* n_restarted, hipStream_t st);
 // positive-node dedup of the fused step (select_latest_nids on float32 ts): best[rank(node)] =
 // max over positions of (ts_key << 32 | ~pos), then the winners.  The two passes ride on other
 // launches of the step (they are ~2B threads of work each, not worth a launch of their own).
@@ -279,6 +283,7 @@ struct WritebackArgs {
   int64_t flag_bytes;
   unsigned long long* clean_best;
   int32_t* clean_counts;
+  int64_t* lazy_batch;  // nullable: the lazy restart's batch counter, += 1 by the last kernel of the step
 };
 int writeback_launch(const tg_model* m, const WritebackArgs& a, int phase, hipStream_t st);
 

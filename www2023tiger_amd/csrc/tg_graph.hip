@@ -179,16 +179,18 @@ __global__ void __launch_bounds__(256) k_sample_batch(tg_tcsr g, int64_t B, cons
                                                       int64_t* __restrict__ nids3, float* __restrict__ ts3f,
                                                       int64_t* __restrict__ eids_b, int64_t* __restrict__ o_nbr,
                                                       int64_t* __restrict__ o_eid, float* __restrict__ o_ts,
-                                                      uint8_t* __restrict__ mark) {
+                                                      uint8_t* __restrict__ mark, uint32_t* __restrict__ tmin_key) {
   constexpr int GPB = 256 / G;
   const int sub = threadIdx.x % G;
   const int64_t o = off ? *off : 0;
   const int64_t Q = 3 * B;
+  float tmin = INFINITY;  // earliest event time of the batch in float32 (`ts.min()` of train_self_supervised.py:162)
   for (int64_t q = (int64_t)blockIdx.x * GPB + threadIdx.x / G; q < Q; q += (int64_t)gridDim.x * GPB) {
     const int64_t e = q % B;
     const int r = (int)(q / B);
     const int64_t nid = r == 0 ? src[o + e] : (r == 1 ? dst[o + e] : neg[o + e]);
     const double t = ts[o + e];
+    if (r == 0) tmin = fminf(tmin, (float)t);
     if (sub == 0) {
       nids3[q] = nid;
       ts3f[q] = (float)t;
@@ -213,19 +215,96 @@ __global__ void __launch_bounds__(256) k_sample_batch(tg_tcsr g, int64_t B, cons
     }
     if (sub == 0 && nid >= 0 && nid < g.num_node) mark[nid] = 1;
   }
+  if (tmin_key) {  // lazy restart only: one atomic per block on the complemented order-preserving key (slot starts at 0)
+    __shared__ float s_tmin[4];
+    for (int sh = 32; sh > 0; sh >>= 1) tmin = fminf(tmin, __shfl_xor(tmin, sh, TG_WAVE));
+    if (lane_id() == 0) s_tmin[threadIdx.x >> 6] = tmin;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float v = fminf(fminf(s_tmin[0], s_tmin[1]), fminf(s_tmin[2], s_tmin[3]));
+      if (v < INFINITY) atomicMax(tmin_key, ~(uint32_t)orderable(v));
+    }
+  }
+}
+
+// ---- lazy restart with the static restarter (train_self_supervised.py:152-163, tiger.py:594-609,
+// restarters.py:262-277); contract in tiger_hip.h (tg_lazy_restart).  One wavefront per bitmap word: lane l
+// decides for node 64 w + l (involved this batch and not yet up to date), needing lanes search the time of
+// their node's last event before the batch's earliest time (float32 query, as the reference's history call),
+// then the wavefront copies the surrogate rows of each needing node.  The word's has-message and uptodate
+// bits have a single writer (this wavefront): plain stores.
+__global__ void __launch_bounds__(256) k_lazy_restart(tg_tcsr g, tg_model m, tg_lazy_restart lz,
+                                                      const uint8_t* __restrict__ flags,
+                                                      const uint32_t* __restrict__ tmin_key,
+                                                      int32_t* __restrict__ n_restarted) {
+  const int lane = lane_id();
+  const int64_t W = (m.n_nodes + 63) / 64;
+  const int64_t b = lz.batch_dev ? *lz.batch_dev : 0;
+  const bool trig = b >= 0 && b < lz.n_trigger && lz.trigger[b] != 0;
+  if (!trig && *lz.restarting_dev == 0) return;
+  uint32_t key = ~*tmin_key;  // inverse of orderable(float)
+  key = (key & 0x80000000u) ? (key ^ 0x80000000u) : ~key;
+  const double t = (double)__uint_as_float(key);
+  const int w4 = m.d / 4;
+  const float4* sl = reinterpret_cast<const float4*>(lz.static_left);
+  const float4* sr = reinterpret_cast<const float4*>(lz.static_right);
+  float4* left = reinterpret_cast<float4*>(m.left_vals);
+  float4* right = reinterpret_cast<float4*>(m.right_vals);
+  for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < W; w += (int64_t)gridDim.x * 4) {
+    const uint64_t upd = trig ? 0ull : lz.uptodate[w];  // a trigger forgets who is up to date ...
+    const uint64_t msg = trig ? 0ull : m.has_msg[w];    // ... and drops every pending message (msg_store.clear())
+    const int64_t node = w * 64 + lane;
+    const bool need_l = node < m.n_nodes && flags[node] != 0 && !((upd >> lane) & 1ull);
+    const unsigned long long need = __ballot(need_l);
+    float pt_l = 0.f;
+    if (need_l) {
+      int64_t start;
+      const int64_t end = prefix_end(g, node, t, &start);
+      if (end > start) pt_l = (float)g.ts[end - 1];
+    }
+    for (unsigned long long todo = need; todo; todo &= todo - 1) {
+      const int k = __ffsll(todo) - 1;
+      const int64_t v = w * 64 + k;
+      const float pt = __shfl(pt_l, k, TG_WAVE);
+      for (int c = lane; c < w4; c += TG_WAVE) {
+        left[v * w4 + c] = sl[v * w4 + c];
+        right[v * w4 + c] = sr[v * w4 + c];
+      }
+      if (lane == 0) {
+        m.left_ts[v] = pt;
+        m.right_ts[v] = pt;
+        if (m.left_active) m.left_active[v] = 1;
+        if (m.right_active) m.right_active[v] = 1;
+      }
+    }
+    if (lane == 0 && (trig || need)) {
+      lz.uptodate[w] = upd | need;
+      m.has_msg[w] = msg & ~need;
+      if (need) atomicAdd(n_restarted, __popcll(need));
+    }
+  }
+  if (trig && blockIdx.x == 0 && threadIdx.x == 0) *lz.restarting_dev = 1;
+}
+
+int lazy_restart_launch(const tg_tcsr* g, const tg_model* m, const tg_lazy_restart* lz, const uint8_t* flags,
+                        const uint32_t* tmin_key, int32_t* n_restarted, hipStream_t st) {
+  if (!lz->static_left || !lz->static_right || !lz->trigger || !lz->restarting_dev || !lz->uptodate) return TG_EINVAL;
+  const int64_t W = (m->n_nodes + 63) / 64;
+  hipLaunchKernelGGL(k_lazy_restart, dim3(flat_grid(W, 4)), dim3(256), 0, st, *g, *m, *lz, flags, tmin_key, n_restarted);
+  return check_launch("lazy_restart");
 }
 
 int sample_batch_launch(const tg_tcsr* g, int64_t B, const int64_t* src, const int64_t* dst, const int64_t* neg,
                         const double* ts, const int64_t* eids, const int64_t* off, int32_t K, int64_t* nids3,
                         float* ts3f, int64_t* eids_b, int64_t* o_nbr, int64_t* o_eid, float* o_ts, uint8_t* mark,
-                        hipStream_t st) {
+                        hipStream_t st, uint32_t* tmin_key) {
   const int64_t Q = 3 * B;
   if (K <= 16)
     hipLaunchKernelGGL(k_sample_batch<16>, dim3(flat_grid(Q, 16)), dim3(256), 0, st, *g, B, src, dst, neg, ts, eids,
-                       off, K, nids3, ts3f, eids_b, o_nbr, o_eid, o_ts, mark);
+                       off, K, nids3, ts3f, eids_b, o_nbr, o_eid, o_ts, mark, tmin_key);
   else
     hipLaunchKernelGGL(k_sample_batch<64>, dim3(flat_grid(Q, 4)), dim3(256), 0, st, *g, B, src, dst, neg, ts, eids,
-                       off, K, nids3, ts3f, eids_b, o_nbr, o_eid, o_ts, mark);
+                       off, K, nids3, ts3f, eids_b, o_nbr, o_eid, o_ts, mark, tmin_key);
   return check_launch("sample_batch");
 }
 

@@ -305,7 +305,9 @@ __global__ void __launch_bounds__(256) k_writeback(tg_model m, WritebackArgs a) 
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       if (a.counts_dst)
         for (int i = 0; i < 4; ++i) a.counts_dst[i] = a.counts_src[i];
+      if (a.clean_counts) a.clean_counts[3] = a.clean_counts[4] = 0;  // restarted-node count, batch-min-time key
       if (a.offset_dev) *a.offset_dev += B;
+      if (a.lazy_batch) *a.lazy_batch += 1;
     }
   }
 }

@@ -818,8 +818,14 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   w.l1n = io->l1_nids ? io->l1_nids : w.l1_nids;
   w.l1e = io->l1_eids ? io->l1_eids : w.l1_eids;
   w.l1t = io->l1_ts ? io->l1_ts : w.l1_ts;
+  const tg_lazy_restart* lz = (io->lazy && !io->embed_only) ? io->lazy : nullptr;
   if ((rc = sample_batch_launch(g, B, io->src, io->dst, io->neg, io->ts, io->eids, io->offset_dev, (int32_t)K, w.nids3,
-                                w.ts3f, w.eids, w.l1n, w.l1e, w.l1t, w.flags, st)) != TG_OK)
+                                w.ts3f, w.eids, w.l1n, w.l1e, w.l1t, w.flags, st,
+                                lz ? reinterpret_cast<uint32_t*>(w.counts + 4) : nullptr)) != TG_OK)
+    return rc;
+  // lazy restart (train_self_supervised.py:152-163): before STEP 1, because a restarted node loses its pending message
+  if (lz && (rc = lazy_restart_launch(g, m, lz, w.flags, reinterpret_cast<const uint32_t*>(w.counts + 4), w.counts + 3,
+                                      st)) != TG_OK)
     return rc;
   prof_mark(pf, ST_COMPACT, st);
   w.inv = io->involved ? io->involved : w.involved;
@@ -869,6 +875,7 @@ static WritebackArgs writeback_args(const tg_model* m, const tg_step_io* io, Ste
   wa.offset_dev = (io->offset_dev && io->advance) ? io->offset_dev : nullptr;
   wa.clean_flags = w.flags; wa.flag_bytes = (int64_t)((m->n_nodes + 63) / 64) * 64; wa.clean_best = w.best;
   wa.clean_counts = w.counts;
+  wa.lazy_batch = (io->lazy && io->lazy->batch_dev) ? io->lazy->batch_dev : nullptr;
   return wa;
 }
 

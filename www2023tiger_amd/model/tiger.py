@@ -23,7 +23,7 @@ import torch
 from torch import Tensor, nn
 
 from .. import hip_ops
-from .._lib import TgLinear, TgModel, TgStepIo, check, lib, ptr
+from .._lib import TgLazyRestart, TgLinear, TgModel, TgStepIo, check, lib, ptr
 from ..hip_ops import stream_ptr
 from .basic_modules import MergeLayer
 from .memory import Memory, MessageStoreNoGradLastOnly
@@ -496,6 +496,28 @@ class TIGE(nn.Module):
 
         def attach_profiler(self, prof):
             self.io.profiler = prof
+
+        def enable_lazy_restart(self, model: 'TIGER', trigger):
+            """The lazy-restart loop of train_self_supervised.py:152-163 inside the step (static restarter only;
+            tiger_hip.h: tg_lazy_restart).  trigger[b] != 0 means the reference's `np.random.rand() < restart_prob`
+            fired before batch b (the loop never fires before batch 0); the draws are the caller's, made up front,
+            so a run is reproducible and the step stays free of host round trips.  counts[3] of every step is the
+            number of nodes re-initialised by it."""
+            from .restarters import StaticRestarter
+            r = getattr(model, 'restarter_fn', None)
+            if not isinstance(r, StaticRestarter):
+                raise NotImplementedError('the in-step lazy restart is built for the static restarter; '
+                                          'use TIGER.restart() from the loop for the sequence restarter')
+            dev = model.device
+            self.lazy_trigger = torch.as_tensor(trigger).to(dev, torch.uint8).contiguous()
+            self.lazy_batch = torch.zeros(1, dtype=torch.int64, device=dev)
+            self.lazy_restarting = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.lazy_uptodate = torch.zeros(hip_ops.bitmap_words(model.n_nodes), dtype=torch.int64, device=dev)
+            self._lazy = TgLazyRestart(ptr(r.left_emb.weight), ptr(r.right_emb.weight), ptr(self.lazy_trigger),
+                                       self.lazy_trigger.numel(), ptr(self.lazy_batch), ptr(self.lazy_restarting),
+                                       ptr(self.lazy_uptodate))
+            self.io.lazy = C.addressof(self._lazy)
+            return self
 
         def load(self, src, dst, neg, ts, eids):
             self.src.copy_(src, non_blocking=True)
