@@ -7,18 +7,28 @@ msg_src=left upd_src=left, on 1 (or N) MI355X.
   python bench.py --gpus N --steps K --warmup W
 
 A step = one batch of B events through tg_stream_step.  The whole synthetic stream is
-resident in HBM before the timed region; the timed region replays a captured hipGraph of
-one step K times (the step reads its batch at a device-side offset and advances it).
+resident in HBM before the timed region.  Order of a run: PREROLL untimed batches bring the
+memories / mailbox to steady state (independent of --warmup: the number of involved nodes per
+batch keeps growing for ~100 batches), W untimed warm-up steps, then the timed region replays
+a captured hipGraph of one step K times (the step reads its batch at a device-side offset and
+advances it).  Per-stage HIP-event times are then taken on the NEXT unseen batches of the
+stream (the state keeps moving forward: no batch is replayed).
 Rank 0 prints ONE JSON line (see the task contract) including
-  roofline     - the dominant kernel of the step, timed live with HIP events, against the
-                 HBM roofline with algorithmic bytes from SURVEY.md s8(d);
-  cpu_baseline - the CPU oracle (oracle/tiger_oracle.py, "port") on a bounded sample of the
-                 same workload on this host's cores.
+  roofline               - the dominant kernel of the step, timed live with HIP events, priced with the
+                           algorithmic flops / bytes of SURVEY.md s8(d) and the measured U / O / P of the run;
+  roofline_memory_gather - the memory-gather kernel (STEP 1-2 as one gather, reprs[u] = pending-or-right row)
+                           against the HBM roofline, plus SURVEY's full bytes_gather over gather + updater;
+  c5s_leg                - (default C2 run only) a short run of the HBM-roofline configuration (10 M nodes,
+                           d=256, B=65536): at C2 every table is cache resident, so the HBM claim is made there;
+  cpu_baseline           - the CPU oracle (oracle/tiger_oracle.py, "port") on a bounded sample of the same
+                           workload on this host's cores (thread count chosen by a quick sweep).
+With --gpus N > 1 and no torchrun environment the script starts its own N ranks.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -38,8 +48,9 @@ C2 = dict(name='C2 JODIE-Wikipedia-shaped synthetic', n_u=8227, n_i=1000, E=1574
 WORKLOADS = {
     'c1': dict(C2, name='C1 JODIE-Wikipedia-shaped synthetic, the reference default batch', B=200, upd_src='right'),
     'c2': C2,
-    'c3': dict(name='C3 JODIE-Reddit-shaped synthetic', n_u=10000, n_i=984, E=672447, T=2.68e6, d=172, K=10, B=4096,
-               msg_src='left', upd_src='right'),
+    'c3': dict(name='C3 JODIE-Reddit-shaped synthetic, static restarter, restart_prob=0.01 (lazy restarts in the step)',
+               n_u=10000, n_i=984, E=672447, T=2.68e6, d=172, K=10, B=4096, msg_src='left', upd_src='right',
+               restart_prob=0.01),
     'c4': dict(name='C4 JODIE-LastFM-shaped synthetic (no feature tables)', n_u=980, n_i=1000, E=1293103, T=1.37e8, d=100,
                K=10, B=8192, msg_src='left', upd_src='right', no_feats=True),
     # C5 scaled to one GPU-box host: 10 M nodes as in BASELINE, 4 M events (the state tables are full size:
@@ -110,9 +121,17 @@ def build_models(stream, d, K, msg_src, upd_src, restarter='static', hist_len=40
     return model, oracle
 
 
-def cpu_baseline(stream, cfg, model, budget_s=20.0, max_batches=40, warm=3):
-    """Oracle (CPU restatement, parity-pinned to the reference) on the first batches of the same
-    stream: collate + STEP 1-6 per batch, all host cores via torch's intra-op threads."""
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32 MFMA (MI355X_MICROARCH.md)
+PREROLL = 150                 # untimed batches before --warmup (state reaches steady U / O / P after ~100 at C2)
+REFERENCE_MEASURED = ('5730 events/s @ 8 cores: the reference\'s own CPU stream (collate + contrast_learning, no_grad), '
+                      'd=172 B=1024, measured by importing it in the survey container (BASELINE.md s2)')
+
+
+def cpu_baseline(stream, cfg, model, budget_s=45.0, batches=100, warm=10):
+    """Oracle (CPU restatement, parity-pinned to the reference) on the first batches of the same stream:
+    collate + STEP 1-6 per batch.  The intra-op thread count is chosen by a quick sweep (the box may expose
+    more hardware threads than its share of cores: more threads than that is slower)."""
     from oracle import tiger_oracle as O
     og = O.OracleGraph(stream['src'], stream['dst'], stream['ts'], stream['eids'], max_node_id=stream['n_nodes'] - 1)
     params = {k: v.detach().cpu().numpy() for k, v in model.named_parameters()}
@@ -120,27 +139,42 @@ def cpu_baseline(stream, cfg, model, budget_s=20.0, max_batches=40, warm=3):
     orc = O.OracleTIGER(params, og, n_nodes=stream['n_nodes'], dim=cfg['d'], nfeats=nfeats, efeats=stream['efeats'],
                         n_neighbors=cfg['K'], msg_src=cfg['msg_src'], upd_src=cfg['upd_src'], restarter='static')
     B = cfg['B']
-    done, t0, elapsed = 0, None, 0.0
-    with torch.no_grad():
-        for b in range(warm + max_batches):
-            if b == warm:
-                t0 = time.perf_counter()
-            sl = slice(b * B, (b + 1) * B)
-            a = [stream[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
-            cg = O.collate(og, a[0], a[1], a[2], a[3], cfg['K'], 'static')
-            orc.stream_step(*a, cg)
-            if b >= warm:
-                done += 1
-                elapsed = time.perf_counter() - t0
-                if elapsed > budget_s:
-                    break
-    return dict(value=done * B / elapsed, unit='events/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'oracle/tiger_oracle.py, first {done} batches of B={B} after {warm} warm-up '
-                       f'(collate + STEP 1-6), {elapsed:.1f} s')
+    pos = [0]
+
+    def run(n):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for _ in range(n):
+                sl = slice(pos[0] * B, (pos[0] + 1) * B)
+                pos[0] += 1
+                a = [stream[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+                orc.stream_step(*a, O.collate(og, a[0], a[1], a[2], a[3], cfg['K'], 'static'))
+        return time.perf_counter() - t0
+
+    run(2)
+    ncpu = os.cpu_count() or 1
+    cands = sorted({t for t in (4, 8, 16, 32, 64, ncpu) if t <= ncpu})
+    sweep = {}
+    for t in cands:  # 2 batches per candidate
+        torch.set_num_threads(t)
+        sweep[t] = 2 * B / run(2)
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    run(max(0, warm - 2 - 2 * len(cands)))
+    done, elapsed = 0, 0.0
+    while done < batches and elapsed < budget_s and (pos[0] + 1) * B <= len(stream['src']):
+        elapsed += run(1)
+        done += 1
+    return dict(value=done * B / elapsed, unit='events/s', cores=best, kind='port',
+                sample=f'oracle/tiger_oracle.py, {done} timed batches of B={B} after {pos[0] - done} warm-up batches '
+                       f'(collate + STEP 1-6), {elapsed:.1f} s; thread sweep (events/s on 2 batches): '
+                       + ', '.join(f'{t}: {v:.0f}' for t, v in sweep.items()),
+                host_threads_visible=ncpu, reference_measured=REFERENCE_MEASURED)
 
 
 def profile_stages(model, buf, steps):
-    """Eager steps with the library's per-stage HIP-event timer attached (same stream)."""
+    """Eager steps on the next batches of the stream with the library's per-stage HIP-event timer attached
+    (events are recorded on the stream the kernels are launched on)."""
     from www2023tiger_amd._lib import lib
     n = lib.tg_profiler_num_stages()
     names = [lib.tg_profiler_stage_name(i).decode() for i in range(n)]
@@ -159,6 +193,205 @@ def profile_stages(model, buf, steps):
     buf.attach_profiler(None)
     lib.tg_profiler_destroy(prof)
     return names, acc / steps, counts / steps
+
+
+def stage_work(cfg, U, O_, P, eager, fused, n_nodes, E):
+    """Algorithmic work per launch of every stage (SURVEY.md s8 d, with the measured U = involved, O = with a
+    pending message, P = unique positive nodes of the run): name -> (flops or None, HBM bytes, kernel name)."""
+    B, K, d = cfg['B'], cfg['K'], cfg['d']
+    Q, d_e = 3 * B, d
+    fe = 0 if cfg.get('no_feats') else 1
+    mw = 3 * d + d_e               # mailbox row width
+    kvw, nh = 2 * d + d_e, 2
+    nk = nh * kvw
+    deg = max(2.0, 2.0 * E / n_nodes)
+    upd_rows = P if eager else O_  # rows the updater runs on
+    gru = (2.0 * upd_rows * 3 * d * (mw + d), upd_rows * (4 * mw + 4) + upd_rows * (4 * d + 4) + upd_rows * 4 * d)
+    w = {
+        'sample_recent_edges': (None, Q * (8 * np.ceil(np.log2(deg + 1)) + K * 28) + 5 * 8 * B, 'tg::k_sample_batch<16>'),
+        'unique_compact': (None, n_nodes + 8 * U + 12 * O_, 'tg::k_bm_small' if n_nodes <= 65536 else 'tg::k_bm_emit'),
+        # eager: every involved row is a live copy (pending-or-right row -> reprs); lazy: only rows without a pending message
+        'gather_right_memory': (None, 2.0 * 4 * d * (U if eager else max(U - O_, 0)) + 12 * O_, 'tg::k_consume_gather_check'),
+        'apply_messages(gru)': gru + ('tg::k_gru',),
+        'eager_updater(gru)': gru + ('tg::k_gru',),
+        'attn_centres+qconst': (None, Q * 4 * d * (2 + fe), 'tg::k_attn_centres'),
+        'attn_core(gather+softmax)': (None, U * 4 * d * (1 + fe) + Q * K * 4 * d_e * fe + 2.0 * Q * nk * 4 + Q * K * 20,
+                                      'tg::k_attn_core'),
+        'attn_gemm_fc2': (2.0 * Q * d * d, Q * d * 8 + d * d * 4, 'tg::k_gemm'),
+        'writeback_phase0': (None, P * (4 * mw + 4) + P * 4 * d * 2 + 2 * B * 4 * d + B * 4 * d_e * fe, 'tg::k_writeback<0>'),
+        'writeback_phase1': (None, 2 * P * (4 * d + 5) + n_nodes, 'tg::k_writeback<1>'),
+    }
+    if fused:
+        w['attn_gemm_q'] = (2.0 * Q * nk * d, Q * d * 4 + Q * nk * 4 + nk * d * 4, 'tg::k_gemm')           # G = c Wqk^T + gconst
+        w['attn_gemm_fc1'] = (2.0 * Q * d * (nk + d), Q * (nk + d) * 4 + Q * d * 4 + d * (nk + d) * 4, 'tg::k_gemm_sk / k_gemm')
+    else:
+        w['attn_gemm_q'] = (2.0 * Q * 2 * d * d, Q * d * 4 + Q * 2 * d * 4, 'tg::k_gemm')
+        w['attn_gemm_g'] = (2.0 * Q * kvw * 2 * d, Q * 2 * d * 4 + Q * nk * 4, 'tg::k_gemm')
+        w['attn_gemm_v'] = (2.0 * Q * kvw * 2 * d, Q * nk * 4 + Q * 2 * d * 4, 'tg::k_gemm')
+        w['attn_gemm_out'] = (2.0 * Q * 2 * d * 2 * d, Q * 2 * d * 8, 'tg::k_gemm')
+        w['attn_gemm_fc1'] = (2.0 * Q * d * 3 * d, Q * 3 * d * 4 + Q * d * 4, 'tg::k_gemm')
+    return w
+
+
+def load_traffic(tag):
+    """HBM / fabric bytes per launch from the committed PMC passes of this round (profiles/r02_hbm_traffic_<tag>.json,
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command, tools/pmc_traffic.py); {} if not recorded."""
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', f'r02_hbm_traffic_{tag}.json')))['kernels']
+    except (OSError, ValueError, KeyError):
+        return {}
+
+
+def kernel_traffic(traffic, kname):
+    for k, v in traffic.items():  # template arguments vary with the shape: match on the kernel's base name
+        if k.split('<')[0] == kname.split('<')[0].split(' ')[0]:
+            return v.get('bytes_per_launch')
+    return None
+
+
+def roofline_of(name, ms, work, traffic):
+    flops, nbytes, kname = work.get(name, (None, None, name))
+    t_s = ms * 1e-3
+    tr = kernel_traffic(traffic, kname)
+    if flops:
+        ach = flops / t_s / 1e12
+        return dict(bound='mfma', kernel=name, device_kernel=kname, achieved=ach, peak=MFMA_F32_PEAK_TFLOPS,
+                    unit='TFLOP/s', frac=ach / MFMA_F32_PEAK_TFLOPS, traffic=tr, avg_ms=float(ms),
+                    algorithmic_flops=float(flops), algorithmic_bytes=float(nbytes),
+                    hbm_gbs=nbytes / t_s / 1e9, hbm_frac=nbytes / t_s / 1e9 / HBM_PEAK_GBS)
+    if nbytes:
+        ach = nbytes / t_s / 1e9
+        return dict(bound='hbm', kernel=name, device_kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s',
+                    frac=ach / HBM_PEAK_GBS, traffic=tr, avg_ms=float(ms), algorithmic_bytes=float(nbytes))
+    return dict(bound='hbm', kernel=name, achieved=None, peak=HBM_PEAK_GBS, unit='GB/s', frac=None, traffic=tr,
+                avg_ms=float(ms))
+
+
+def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_cpu=False):
+    """One single-GPU measurement of the streaming step on workload `cfg`; returns the pieces of the JSON line."""
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    B, K, d = cfg['B'], cfg['K'], cfg['d']
+    n_batches = preroll + warmup + steps + n_prof + 2
+    E = max(cfg['E'], n_batches * B)
+    no_feats = bool(cfg.get('no_feats'))
+    stream = make_stream(cfg['n_u'], cfg['n_i'], E, cfg['T'] * E / cfg['E'], seed=0, d_e=d,
+                         integer_ts=cfg.get('integer_ts', True), with_efeats=not no_feats)
+    model, _ = build_models(stream, d, K, cfg['msg_src'], cfg['upd_src'], restarter='static', device='cuda:0',
+                            zero_nfeats=not no_feats)
+    resident = tuple(torch.from_numpy(stream[k]).to(dev) for k in ('src', 'dst', 'neg', 'ts', 'eids'))
+    fused, eager = not args.no_fuse, not args.no_eager
+    if fused:   # streaming inference, parameters fixed: pre-multiplied attention weights (tg_attn_fuse)
+        model.fuse_attention()
+    if eager:   # ... and the updater run once per stored message (TIGE.eager_updates)
+        model.eager_updates()
+    buf = model.StepBuffers(model, B, False, resident=resident)
+    restart_prob = float(cfg.get('restart_prob', 0.0))
+    n_trig = 0
+    if restart_prob > 0:  # train_self_supervised.py:153: one uniform draw per batch, never before batch 0
+        trig = (np.random.RandomState(1).rand(n_batches) < restart_prob).astype(np.uint8)
+        trig[0] = 0
+        with torch.no_grad():  # trained surrogate rows (the reference initialises the tables with zeros)
+            torch.manual_seed(1)
+            model.restarter_fn.left_emb.weight.normal_(0.0, 0.5)
+            model.restarter_fn.right_emb.weight.normal_(0.0, 0.5)
+        buf.enable_lazy_restart(model, trig)
+        n_trig = int(trig[preroll + warmup:preroll + warmup + steps].sum())
+    _ = model.graph.tcsr, model.model_struct()  # lazy device-side builds happen here, not inside a capture
+
+    # ---- untimed: state pre-roll, then the contract's warm-up steps (all eager launches)
+    for _ in range(preroll + warmup):
+        model.launch_step(buf)
+    torch.cuda.synchronize()
+    assert int(buf.err.item()) == 0, f'invariant word {int(buf.err.item())}'
+    if not eager:
+        model.note_rows(int(buf.counts[1].item()))  # bound on the pending-message rows (steady state reached)
+
+    # ---- timed region: K steps, hipGraph replay of one captured step
+    graph = None
+    if not args.no_graph:
+        side = torch.cuda.Stream()
+        snap = [t.clone() for t in (buf.offset,) + ((buf.lazy_batch,) if restart_prob > 0 else ())]
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            model.launch_step(buf)
+        buf.offset.copy_(snap[0])  # capture does not execute: offset unchanged; make sure
+        if restart_prob > 0:
+            buf.lazy_batch.copy_(snap[1])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        if graph is not None:
+            graph.replay()
+        else:
+            model.launch_step(buf)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert int(buf.err.item()) == 0, f'invariant word {int(buf.err.item())}'
+    assert int(buf.offset.item()) == (preroll + warmup + steps) * B
+
+    # ---- per-stage timing on the next unseen batches, live (HIP events on the launch stream)
+    names, stage_ms, counts = profile_stages(model, buf, n_prof)
+    assert int(buf.err.item()) == 0, f'invariant word {int(buf.err.item())} after the profiling pass'
+    U, O_, P = counts[0], counts[1], counts[2]
+    work = stage_work(cfg, U, O_, P, eager, fused, stream['n_nodes'], E)
+    traffic = load_traffic(traffic_tag)
+    empty = {'zero_flags', 'dedup_positive', 'restarter_targets', 'apply_messages(gru)' if eager else 'eager_updater(gru)'}
+    if fused:
+        empty |= {'attn_gemm_g', 'attn_gemm_v', 'attn_gemm_out'}
+    overhead = float(np.median([v for n, v in zip(names, stage_ms) if n in empty]))  # cost of an empty event pair
+    stages = {n: float(v) for n, v in zip(names, stage_ms) if n not in empty}
+    dom = max(stages, key=stages.get)
+    out = dict(value=steps * B / dt, ms_per_step=dt / steps * 1e3,
+               config=dict(workload=cfg['name'], batch=B, dim=d, n_neighbors=K, msg_src=cfg['msg_src'],
+                           upd_src=cfg['upd_src'], n_nodes=stream['n_nodes'], events=E, mode='stream (no_grad) STEP 1-6',
+                           launch='hipGraph replay' if graph is not None else 'eager',
+                           attention_weights='pre-multiplied (tg_attn_fuse)' if fused else 'as stored',
+                           updater='eager: once per stored message (TIGE.eager_updates)' if eager else
+                                   'lazy: on the fly for every involved node with a pending message',
+                           state_preroll_batches=preroll, involved_per_batch=float(U), outdated_per_batch=float(O_),
+                           unique_pos_per_batch=float(P)),
+               roofline=roofline_of(dom, stages[dom], work, traffic),
+               stages_ms={n: round(v, 5) for n, v in stages.items()}, stage_event_overhead_ms=round(overhead, 5))
+    if restart_prob > 0:
+        out['config'].update(restart_prob=restart_prob, restart_triggers_in_timed_region=n_trig,
+                             restarter='static, re-initialisation inside the step (tg_lazy_restart)')
+    # the memory-gather kernel: STEP 1-2's gather of the involved nodes' rows (tiger.py:214-221), HBM-bound;
+    # next to it SURVEY s8(d)'s full bytes_gather (mailbox + updater-source rows included) over the kernels that
+    # move those bytes (the gather and the updater launch), and the updater launch on both rooflines
+    g_name, u_name = 'gather_right_memory', 'eager_updater(gru)' if eager else 'apply_messages(gru)'
+    mg = roofline_of(g_name, stages[g_name], work, traffic)
+    mw = 4 * d
+    not_right = 0 if cfg['upd_src'] == 'right' else 1
+    survey_bytes = U * 4 * d + O_ * (4 * mw + 4) + O_ * (4 * d + 4) * not_right + U * 4 * d
+    t_both = (stages[g_name] + stages[u_name]) * 1e-3
+    mg['survey_bytes_gather'] = dict(
+        formula='U*4d + O*(16d+4) + O*(4d+4)*[upd_src != right] + U*4d  (SURVEY.md s8 d)', bytes=float(survey_bytes),
+        kernels=[g_name, u_name], ms=float(stages[g_name] + stages[u_name]),
+        gbs=survey_bytes / t_both / 1e9, frac=survey_bytes / t_both / 1e9 / HBM_PEAK_GBS,
+        note='the mailbox / updater-source rows are gathered inside the updater launch, which is MFMA-bound'
+             + (' and, with eager updates, runs on the P nodes that received a message instead of the O nodes that hold one' if eager else ''))
+    out['roofline_memory_gather'] = mg
+    out['roofline_updater'] = roofline_of(u_name, stages[u_name], work, traffic)
+    out['roofline_neighbour_gather'] = roofline_of('attn_core(gather+softmax)', stages['attn_core(gather+softmax)'], work, traffic)
+    if want_cpu:
+        out['cpu_baseline'] = cpu_baseline(stream, cfg, model)
+    del buf, graph, model, resident
+    torch.cuda.empty_cache()
+    return out
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks ourselves (this process has made no GPU
+    call), relay rank 0's JSON line (the children inherit stdout) and exit with the launcher's code."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def train_main(args, cfg):
@@ -223,10 +456,17 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS), help='c2 is the benchmarked configuration')
+    ap.add_argument('--preroll', type=int, default=None,
+                    help=f'untimed state pre-roll batches before --warmup (default {PREROLL}; 20 for c5s)')
+    ap.add_argument('--no-c5s-leg', action='store_true', help='default C2 run: skip the short HBM-roofline leg')
     ap.add_argument('--no-graph', action='store_true', help='launch steps eagerly instead of replaying a hipGraph')
     ap.add_argument('--force-dist', action='store_true', help='run the multi-GPU code path even with one rank')
     ap.add_argument('--dist-graphs', action='store_true',
-                    help='multi-GPU: replay captured hipGraphs around the all-gather (experimental; default eager)')
+                    help='multi-GPU: replay captured hipGraphs around the exchange (experimental; default eager)')
+    ap.add_argument('--dist-mode', default='partitioned', choices=['partitioned', 'replicated'],
+                    help='multi-GPU state layout (www2023tiger_amd/dist.py)')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='multi-GPU: weak = B events per rank per step, strong = the global batch stays B')
     ap.add_argument('--no-fuse', action='store_true', help='keep the six-product attention (no tg_attn_fuse)')
     ap.add_argument('--no-eager', action='store_true', help='updater on the fly for every involved node (no eager_updates)')
     ap.add_argument('--train', action='store_true', help='measure the training iteration instead (not the headline metric)')
@@ -240,133 +480,29 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))
     if args.gpus > 1 or world > 1 or args.force_dist:
         from www2023tiger_amd import dist as tdist
         return tdist.bench_main(args, cfg, make_stream, build_models, rank, local_rank, world)
 
-    torch.cuda.set_device(0)
-    dev = torch.device('cuda', 0)
-    B, K, d = cfg['B'], cfg['K'], cfg['d']
-    n_batches = args.warmup + args.steps + 4
-    E = max(cfg['E'], n_batches * B)
-    no_feats = bool(cfg.get('no_feats'))
-    stream = make_stream(cfg['n_u'], cfg['n_i'], E, cfg['T'] * E / cfg['E'], seed=0, d_e=d,
-                         integer_ts=cfg.get('integer_ts', True), with_efeats=not no_feats)
-    model, _ = build_models(stream, d, K, cfg['msg_src'], cfg['upd_src'], restarter='static', device='cuda:0',
-                            zero_nfeats=not no_feats)
-    resident = tuple(torch.from_numpy(stream[k]).to(dev) for k in ('src', 'dst', 'neg', 'ts', 'eids'))
-    if not args.no_fuse:  # streaming inference, parameters fixed: pre-multiplied attention weights (tg_attn_fuse)
-        model.fuse_attention()
-    if not args.no_eager:  # ... and the updater run once per stored message (TIGE.eager_updates)
-        model.eager_updates()
-    buf = model.StepBuffers(model, B, False, resident=resident)
-    _ = model.graph.tcsr, model.model_struct()  # lazy device-side builds happen here, not inside a capture (--warmup 0)
-
-    # ---- warm-up (untimed, eager): also brings memory / mailbox to steady state
-    for _ in range(args.warmup):
-        model.launch_step(buf)
-    torch.cuda.synchronize()
-    assert int(buf.err.item()) == 0, f'invariant word {int(buf.err.item())}'
-    # what the loops of the package do with the counts they read back: a bound on the pending-message rows lets
-    # the updater pick blocks sized for a one-round launch.  Not for the headline workload: the choice is frozen
-    # into the captured graph, C2's row count keeps growing for a hundred batches, and a bound learnt from a short
-    # warm-up would size the launch for rows it soon exceeds (the library default - capacity / node count - is used)
-    if args.workload != 'c2':
-        model.note_rows(int(buf.counts[1].item()))
-
-    # ---- timed region: K steps, hipGraph replay of one captured step
-    graph = None
-    if not args.no_graph:
-        side = torch.cuda.Stream()
-        off0 = buf.offset.clone()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
-            model.launch_step(buf)
-        # capture does not execute: offset unchanged; make sure
-        buf.offset.copy_(off0)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        if graph is not None:
-            graph.replay()
-        else:
-            model.launch_step(buf)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    assert int(buf.err.item()) == 0, f'invariant word {int(buf.err.item())}'
-    assert int(buf.offset.item()) == (args.warmup + args.steps) * B
-    events_per_s = args.steps * B / dt
-
-    # ---- per-stage timing of the same step, live (HIP events on the launch stream)
-    buf.offset.fill_((args.warmup) * B)  # re-run a slice of the stream: costs are state-independent enough
-    names, stage_ms, counts = profile_stages(model, buf, min(args.steps, 50))
-    U, O_, P = counts[0], counts[1], counts[2]
-    dom = int(np.argmax(stage_ms))
-    # algorithmic HBM bytes per launch (SURVEY.md s8 d), with the measured U/O/P of this run
-    Q = 3 * B
-    d_e = d
-    fe = 0 if no_feats else 1  # feature tables present?
-    bytes_by_stage = {
-        'gather_right_memory': U * 4 * d * 2,                                   # read rows + compact write
-        'apply_messages(gru)': O_ * (4 * (3 * d + d_e) + 4) + O_ * (4 * d + 4) + O_ * 4 * d,  # mailbox + upd rows + write
-        'attn_core(gather+softmax)': Q * K * 4 * (fe * d_e + fe * d + d) + Q * 2 * (2 * d + d_e) * 4 * 2,  # efeat+nfeat+reprs rows, G in, S out
-        'store_events': P * (4 * (3 * d + d_e) + 4) + 2 * B * 4 * d + B * 4 * d_e,
-    }
-    flops_by_stage = {'apply_messages(gru)': 2.0 * O_ * 3 * d * ((3 * d + d_e) + d)}
-    kernel_of_stage = {'apply_messages(gru)': 'tg::k_gru<4, 2>', 'attn_core(gather+softmax)': 'tg::k_attn_core<2, 1, 4>',
-                       'gather_right_memory': 'tg::k_consume_gather_check', 'sample_recent_edges': 'tg::k_sample_batch<16>'}
-    name = names[dom]
-    t_s = stage_ms[dom] * 1e-3
-    # fabric/HBM bytes per launch of that kernel from the committed PMC passes (profiles/r01_hbm_traffic_v13.json,
-    # collected with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command); null if not recorded
-    traffic = None
-    try:
-        tfile = {'c2': 'r01_hbm_traffic_v13.json', 'c5s': 'r01_hbm_traffic_c5s_v6.json'}.get(args.workload)
-        tj = json.load(open(os.path.join(ROOT, 'profiles', tfile))) if tfile else {'kernels': {}}
-        traffic = tj['kernels'].get(kernel_of_stage.get(name, ''), {}).get('bytes_per_launch')
-    except (OSError, ValueError):
-        pass
-    if name in flops_by_stage:  # the GRU kernel is MFMA-bound at C2 (3.7 GFLOP vs 17 MB): price it against f32 MFMA
-        ach = flops_by_stage[name] / t_s / 1e12
-        roof = dict(bound='mfma', kernel=name, achieved=ach, peak=157.3, unit='TFLOP/s', frac=ach / 157.3,
-                    traffic=traffic, avg_ms=float(stage_ms[dom]), algorithmic_flops=float(flops_by_stage[name]),
-                    algorithmic_bytes=float(bytes_by_stage[name]),
-                    hbm_gbs=bytes_by_stage[name] / t_s / 1e9)
-    elif name in bytes_by_stage:
-        ach = bytes_by_stage[name] / t_s / 1e9
-        roof = dict(bound='hbm', kernel=name, achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS,
-                    traffic=traffic, avg_ms=float(stage_ms[dom]), algorithmic_bytes=float(bytes_by_stage[name]))
-    else:
-        roof = dict(bound='hbm', kernel=name, achieved=None, peak=HBM_PEAK_GBS, unit='GB/s', frac=None, traffic=traffic,
-                    avg_ms=float(stage_ms[dom]))
+    preroll = args.preroll if args.preroll is not None else (20 if args.workload == 'c5s' else PREROLL)
+    n_prof = max(4, min(args.steps, 30 if cfg['B'] <= 8192 else 6))
+    leg = run_stream_leg(cfg, args, preroll, args.warmup, args.steps, n_prof, traffic_tag=args.workload,
+                         want_cpu=not args.no_cpu_baseline and args.workload == 'c2')
     out = dict(metric='processed interaction-events/sec (memory+aggregate+embed), Wikipedia d=172',
-               value=events_per_s, unit='events/s', n_gpus=1, steps=args.steps, warmup=args.warmup,
-               ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='weak', vs_baseline=None,
-               dtype='f32', data='synthetic',
-               config=dict(workload=cfg['name'], batch=B, dim=d, n_neighbors=K, msg_src=cfg['msg_src'],
-                           upd_src=cfg['upd_src'], n_nodes=stream['n_nodes'], events=E, mode='stream (no_grad) STEP 1-6',
-                           launch='hipGraph replay' if graph is not None else 'eager',
-                           attention_weights='pre-multiplied (tg_attn_fuse)' if not args.no_fuse else 'as stored',
-                           involved_per_batch=float(U), outdated_per_batch=float(O_), unique_pos_per_batch=float(P)),
-               roofline=roof,
-               stages_ms={n: round(float(v), 5) for n, v in zip(names, stage_ms)})
-    # the HBM-bound memory-gather kernel (right-memory rows of the involved nodes), next to the dominant kernel:
-    # the north star prices THIS kernel against the HBM roofline on the C5-scaled run (at C2 the state is cache resident)
-    gname = 'gather_right_memory'
-    if gname in names and name != gname:
-        gi = names.index(gname)
-        gt = stage_ms[gi] * 1e-3
-        gtraffic = None
-        try:
-            gtraffic = tj['kernels'].get(kernel_of_stage[gname], {}).get('bytes_per_launch')
-        except (NameError, KeyError):
-            pass
-        out['roofline_memory_gather'] = dict(bound='hbm', kernel=gname, achieved=bytes_by_stage[gname] / gt / 1e9,
-                                             peak=HBM_PEAK_GBS, unit='GB/s', frac=bytes_by_stage[gname] / gt / 1e9 / HBM_PEAK_GBS,
-                                             traffic=gtraffic, avg_ms=float(stage_ms[gi]),
-                                             algorithmic_bytes=float(bytes_by_stage[gname]))
-    if not args.no_cpu_baseline and args.workload == 'c2':
-        out['cpu_baseline'] = cpu_baseline(stream, cfg, model)
+               value=leg.pop('value'), unit='events/s', n_gpus=1, steps=args.steps, warmup=args.warmup,
+               ms_per_step=leg.pop('ms_per_step'), higher_is_better=True, scaling='weak', vs_baseline=None,
+               dtype='f32', data='synthetic')
+    out.update(leg)
+    if args.workload == 'c2' and not args.no_c5s_leg:
+        # at C2 every table is cache resident (150 MB): the HBM-roofline claim for the memory-gather kernel is made
+        # on the C5-shaped tables (10 M nodes, d=256, B=65536: 70 GB of state), 20 warm + 10 timed steps
+        c5 = run_stream_leg(dict(WORKLOADS['c5s']), args, 20, 4, 10, 4, traffic_tag='c5s')
+        out['c5s_leg'] = dict(value=c5['value'], unit='events/s', ms_per_step=c5['ms_per_step'], steps=10, warmup=24,
+                              config=c5['config'], roofline_memory_gather=c5['roofline_memory_gather'],
+                              roofline_updater=c5['roofline_updater'],
+                              roofline_neighbour_gather=c5['roofline_neighbour_gather'], stages_ms=c5['stages_ms'])
     print(json.dumps(out))
 
 
