@@ -305,6 +305,12 @@ int tg_consume_update_right(const tg_model* m, const int64_t* upos, const int32_
 /* same, reading node upos[p]'s new row at rows[row_index[p]] instead of reprs[local(upos[p])] */
 int tg_consume_update_right_rows(const tg_model* m, const int64_t* upos, const int32_t* n_upos, int64_t cap,
                                  const float* rows, const int64_t* row_index, uint32_t* err, void* stream);
+/* Effective right-memory rows: out[i] = has_msg[v] ? pending_vals[v] : right_vals[v], ts_out[i] = has_msg[v] ?
+ * msg_ts[v] : right_ts[v] for v = ids[i] - the row and time STEP 4 would leave in the right memory if v's pending
+ * message were consumed now (tiger.py:214-221,236-241).  Needs tg_model.pending_vals (eager updates).  This is
+ * what the owner of a node serves to a rank that embeds an event involving it (partitioned multi-GPU path). */
+int tg_gather_eff_rows(const tg_model* m, int64_t n, const int64_t* ids, float* out, float* ts_out, void* stream);
+
 /* STEP 5: build the two raw messages of the winning event of each unique positive
  * node and write mailbox row, mailbox ts and has-message bit.  `index` is the
  * select_latest position into cat[src,dst]. */
@@ -398,6 +404,11 @@ typedef struct tg_step_io {
   /* Lazy restart of train_self_supervised.py:152-163 with the StaticRestarter, on device (NULL = off);
    * see tg_lazy_restart below. */
   const struct tg_lazy_restart* lazy;
+  /* collate_only != 0: stop after the collation (sampler + involved-set compaction): l1_* / involved / counts are
+   * the outputs, no state is read or written, h may be NULL.  The partitioned multi-GPU path uses it to learn
+   * which rows a rank must pull from their owners before it embeds (www2023tiger_amd/dist.py). */
+  int32_t collate_only;
+  int32_t reserved2;
 } tg_step_io;
 
 /* The reference loop draws `np.random.rand() < restart_prob` before every batch but the first; a hit sets
@@ -561,6 +572,13 @@ typedef struct tg_writeback_io {
   const int64_t* left_row;  /* [.., 2Bg] row of h(t-) for position i of cat[src,dst], at element 2*offset + i */
   const int64_t* new_row;   /* [.., 2Bg] row of h(t'+) likewise */
   uint32_t* err;
+  /* Partitioned state (owner != NULL): only nodes with owner[node] == my_rank are written (STEP 4-6 and the
+   * event-before-memory check); the other positive nodes of the global batch belong to other ranks.  With
+   * new_from_pending != 0 STEP 4 takes h(t'+) from tg_model.pending_vals (the owner's own table of precomputed
+   * updater rows) instead of rows[new_row[..]], and new_row may be NULL. */
+  const int32_t* owner;     /* [n_nodes] or NULL */
+  int32_t my_rank;
+  int32_t new_from_pending;
 } tg_writeback_io;
 
 size_t tg_stream_writeback_workspace_bytes(const tg_model* m, int64_t Bg);

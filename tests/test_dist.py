@@ -284,6 +284,238 @@ def test_resident_sharded_stream_graph_replay_equals_single_gpu(tmp_path, world,
         assert rel_err(got['msg'][has], model.msg_store.node_msg_vals.cpu().numpy()[has]) < 1e-6
 
 
+# ------------------------------------------------------------------------------ partitioned node state
+class OraclePartitionEngine:
+    """The local compute of www2023tiger_amd.dist.PartitionedRunner on the CPU oracle (test-only): a rank's
+    OracleTIGER holds full-height tables of which only the rows of its own nodes are authoritative."""
+
+    def __init__(self, orc, K):
+        from oracle import tiger_oracle as O
+        self.O, self.orc, self.K = O, orc, K
+        self.device, self.d = torch.device('cpu'), orc.d
+
+    def select_latest(self, pos, ts32):
+        u, i = self.O.select_latest_nids(pos.numpy(), ts32.numpy())
+        return torch.from_numpy(u), torch.from_numpy(i)
+
+    def collate(self, src, dst, neg, ts):
+        cg = self.O.collate(self.orc.graph, src.numpy(), dst.numpy(), neg.numpy(), ts.numpy(), self.K, 'static')
+        return torch.from_numpy(cg['involved'])
+
+    def _eff(self, ids):
+        """right memory as STEP 4 would leave it: updater row / message time for nodes with a pending message"""
+        m, ids_np = self.orc, ids.numpy()
+        rows, ts = m.right_vals[ids].clone(), m.right_ts[ids].clone()
+        has = m.has_msg[ids_np]
+        if has.any():
+            outd, h_new, mts = m.consume(ids_np[has])
+            where = torch.from_numpy(np.searchsorted(outd, ids_np[has]))
+            sel = torch.from_numpy(np.nonzero(has)[0])
+            rows[sel], ts[sel] = h_new[where], mts[where]
+        return rows, ts
+
+    def serve(self, ids, is_msg):
+        m = self.orc
+        out = torch.empty(len(ids), self.d + 1)
+        r, t = self._eff(ids[~is_msg])
+        out[~is_msg] = torch.cat([r, t[:, None]], 1)
+        mi = ids[is_msg]
+        r2, t2 = (m.left_vals[mi], m.left_ts[mi]) if m.msg_src == 'left' else self._eff(mi)
+        out[is_msg] = torch.cat([r2, t2[:, None]], 1)
+        return out
+
+    def adopt(self, eff_ids, eff_rows, msg_ids, msg_rows):
+        m, d = self.orc, self.d
+        assert not m.has_msg[eff_ids.numpy()].any()  # a rank never holds a message of a node it does not own
+        m.right_vals[eff_ids], m.right_ts[eff_ids] = eff_rows[:, :d], eff_rows[:, d]
+        vals, tss = m._mem(m.msg_src)
+        vals[msg_ids], tss[msg_ids] = msg_rows[:, :d], msg_rows[:, d]
+
+    def embed(self, src, dst, neg, ts, eids):
+        O, m = self.O, self.orc
+        src, dst, neg = src.numpy(), dst.numpy(), neg.numpy()
+        cg = O.collate(m.graph, src, dst, neg, ts.numpy(), self.K, 'static')
+        involved = cg['involved']
+        outdated, h_new, _ = m.consume(involved)
+        reprs = m.right_vals[torch.from_numpy(involved)].clone()
+        if len(outdated):
+            reprs[torch.from_numpy(cg['local_index'][outdated])] = h_new
+        nids3 = np.concatenate([src, dst, neg])
+        return m.embed(reprs, cg['local_index'], nids3, ts.float().repeat(3), cg['l1_nids'], cg['l1_eids'], cg['l1_ts'])
+
+    def writeback(self, src, dst, ts, eids, rows, left_row, owner, rank):
+        O, m = self.O, self.orc
+        Bg = len(src)
+        t32 = ts.float()
+        ts2 = t32.repeat(2)
+        ids, idx = O.select_latest_nids(torch.cat([src, dst]).numpy(), ts2.numpy())
+        keep = owner.numpy()[ids] == rank
+        ids, idx = ids[keep], idx[keep]
+        had = m.has_msg[ids]
+        if had.any():  # STEP 4 (tiger.py:230-241)
+            sel = ids[had]
+            outd, h_new, mts = m.consume(sel)
+            np.testing.assert_array_equal(outd, sel)
+            m.has_msg[sel] = False
+            m._mem_set(m.right_vals, m.right_ts, torch.from_numpy(sel), h_new, mts)
+        own, e = torch.from_numpy(ids), torch.from_numpy(idx % Bg)  # STEP 5 (tiger.py:422-442) for this rank's nodes
+        other = torch.where(torch.from_numpy(idx) < Bg, dst[e], src[e])
+        mv, mt = m._mem(m.msg_src)
+        te, opt_ = t32[e], mt[own]
+        if (opt_ > te).any():
+            raise ValueError('Events occur before the udpated memory.')
+        msg = torch.cat([mv[own] + m.node_feat(own), mv[other] + m.node_feat(other), m.edge_feat(eids[e]),
+                         m.te(te - opt_)], 1)
+        m.msg_vals[own], m.msg_ts[own] = msg, te
+        m.has_msg[ids] = True
+        m._mem_set(m.left_vals, m.left_ts, own, rows[left_row[torch.from_numpy(idx)]], ts2[torch.from_numpy(idx)])  # STEP 6
+
+    def refresh(self, ids):
+        pass  # the oracle computes updater rows on demand
+
+
+def _save_owned(path, owner, rank, left, right, left_ts, right_ts, msg, msg_ts, has):
+    np.savez(path, owner=owner, rank=rank, left=left, right=right, left_ts=left_ts, right_ts=right_ts, msg=msg,
+             msg_ts=msg_ts, has=has)
+
+
+def _assemble_owned(out_dir, world):
+    """the authoritative rows of every rank put back into full tables"""
+    parts = [np.load(os.path.join(out_dir, f'rank{r}.npz')) for r in range(world)]
+    owner = parts[0]['owner']
+    full = {}
+    for k in ('left', 'right', 'left_ts', 'right_ts', 'msg', 'msg_ts', 'has'):
+        a = np.zeros_like(parts[0][k])
+        for r, p in enumerate(parts):
+            np.testing.assert_array_equal(p['owner'], owner)
+            a[owner == r] = p[k][owner == r]
+        full[k] = a
+    return full, owner
+
+
+def _partitioned_cpu_worker(rank, world, port, name, Bg, n_batches, balance, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    tdist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from www2023tiger_amd.dist import PartitionedRunner, ShardPlan, balanced_owner_table
+    z = load(name)
+    cfg = parse_cfg(z)
+    orc = _make_oracle(z, cfg)
+    owner = balanced_owner_table(int(z['n_nodes']), z['dst'], world)
+    runner = PartitionedRunner(OraclePartitionEngine(orc, cfg['K']), owner, rank, world)
+    pulled = pushed = 0
+    for b in range(n_batches):
+        sl = slice(b * Bg, (b + 1) * Bg)
+        rank_of = ShardPlan(z['dst'][sl], owner, world, Bg // world, balance=True).rank_of if balance else None
+        plan = runner.plan(*(z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')), rank_of=rank_of)
+        runner.run(plan)
+        pulled += plan.stats['pulled_rows']
+        pushed += plan.stats['pushed_rows']
+    assert pulled > 0 and pushed > 0   # the exchange really carried rows
+    _save_owned(os.path.join(out_dir, f'rank{rank}.npz'), owner, rank, orc.left_vals.numpy(), orc.right_vals.numpy(),
+                orc.left_ts.numpy(), orc.right_ts.numpy(), orc.msg_vals.numpy(), orc.msg_ts.numpy(), orc.has_msg)
+    tdist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,balance', [(2, False), (2, True), (4, True)])
+def test_partitioned_state_equals_single_process_cpu_gloo(tmp_path, world, balance):
+    """Node state partitioned by owner(node), one all_to_all of rows each way per global batch (pull, push):
+    the owners' rows after 6 global batches are those of the single-process oracle on the same batches, bit for
+    bit; with owner placement of the events and with capacity-balanced placement (an event may then run on a rank
+    that owns neither endpoint)."""
+    name, Bg, n_batches = 'static_ll_d16', 96, 6
+    mp.spawn(_partitioned_cpu_worker, args=(world, free_port(), name, Bg, n_batches, balance, str(tmp_path)),
+             nprocs=world, join=True)
+    from oracle import tiger_oracle as O
+    z = load(name)
+    cfg = parse_cfg(z)
+    ref = _make_oracle(z, cfg)
+    torch.set_num_threads(1)
+    for b in range(n_batches):
+        sl = slice(b * Bg, (b + 1) * Bg)
+        a = [z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        ref.contrast_learning(*a, O.collate(ref.graph, a[0], a[1], a[2], a[3], cfg['K'], 'static'))
+    got, owner = _assemble_owned(str(tmp_path), world)
+    assert len(set(owner.tolist())) == world
+    np.testing.assert_array_equal(got['has'], ref.has_msg)
+    np.testing.assert_array_equal(got['left_ts'], ref.left_ts.numpy())
+    np.testing.assert_array_equal(got['right_ts'], ref.right_ts.numpy())
+    np.testing.assert_array_equal(got['msg_ts'][ref.has_msg], ref.msg_ts.numpy()[ref.has_msg])
+    # two ranks: bit for bit.  Four ranks embed 24 events each: the CPU BLAS rounds a product of 72 rows differently
+    # from the same rows inside a product of 288 (4e-8 absolute), which is all that separates the float tables
+    same = np.testing.assert_array_equal if world == 2 else (lambda a, b, err_msg='': np.testing.assert_allclose(
+        a, b, rtol=0, atol=2e-7, err_msg=err_msg))
+    same(got['left'], ref.left_vals.numpy(), err_msg='left')
+    same(got['right'], ref.right_vals.numpy(), err_msg='right')
+    same(got['msg'][ref.has_msg], ref.msg_vals.numpy()[ref.has_msg], err_msg='mailbox')
+
+
+def _partitioned_gpu_worker(rank, world, port, name, B, n_steps, resident, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    tdist.init_process_group('gloo', rank=rank, world_size=world)
+    from test_hip_parity import build_hip_model
+    from www2023tiger_amd.dist import (HipPartitionEngine, PartitionedRunner, ResidentPartitionedStream,
+                                       balanced_owner_table)
+    z = load(name)
+    cfg = parse_cfg(z)
+    model, _, _ = build_hip_model(z, cfg)
+    model.fuse_attention()
+    Bg = B * world
+    owner = balanced_owner_table(int(z['n_nodes']), z['dst'], world)
+    keys = ('src', 'dst', 'neg', 'ts', 'eids')
+    if resident:  # all plans up front, balanced shards (the benchmarked form)
+        rs = ResidentPartitionedStream(model, {k: z[k] for k in keys}, owner, rank, world, B, n_steps)
+        for _ in range(n_steps):
+            rs.step()
+        rs.check_invariants()
+    else:         # plan + run per batch, events on the owner of their destination
+        eng = HipPartitionEngine(model, cap=Bg)
+        runner = PartitionedRunner(eng, owner, rank, world)
+        for b in range(n_steps):
+            runner.step(*(z[k][b * Bg:(b + 1) * Bg] for k in keys))
+        eng.check_invariants()
+    has = model.msg_store.has_msg_mask().cpu().numpy()
+    _save_owned(os.path.join(out_dir, f'rank{rank}.npz'), owner, rank, model.left_memory.vals.cpu().numpy(),
+                model.right_memory.vals.cpu().numpy(), model.left_memory.update_ts.cpu().numpy(),
+                model.right_memory.update_ts.cpu().numpy(), model.msg_store.node_msg_vals.cpu().numpy(),
+                model.msg_store.node_msg_ts.cpu().numpy(), has)
+    tdist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,world,B,resident', [('static_ll_d16', 2, 48, False), ('static_ll_d16', 4, 24, True),
+                                                   ('seq_rr_d8_nofeat', 2, 50, True)])
+def test_partitioned_state_equals_single_gpu(tmp_path, name, world, B, resident):
+    """The partitioned mode on the HIP engine (ranks are processes sharing the one GPU of the test box, gloo for
+    the exchange) against the single-GPU fused step on the same global batches: the owners' rows."""
+    from test_hip_parity import build_hip_model
+    n_steps = 6
+    mp.spawn(_partitioned_gpu_worker, args=(world, free_port(), name, B, n_steps, resident, str(tmp_path)),
+             nprocs=world, join=True)
+    z = load(name)
+    cfg = parse_cfg(z)
+    model, _, _ = build_hip_model(z, cfg)
+    model.fuse_attention()
+    model.eager_updates()
+    Bg = B * world
+    for b in range(n_steps):
+        sl = slice(b * Bg, (b + 1) * Bg)
+        model.stream_step(*(z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')))
+    got, _ = _assemble_owned(str(tmp_path), world)
+    has = model.msg_store.has_msg_mask().cpu().numpy()
+    np.testing.assert_array_equal(got['has'], has)
+    np.testing.assert_array_equal(got['left_ts'], model.left_memory.update_ts.cpu().numpy())
+    np.testing.assert_array_equal(got['right_ts'], model.right_memory.update_ts.cpu().numpy())
+    np.testing.assert_array_equal(got['msg_ts'][has], model.msg_store.node_msg_ts.cpu().numpy()[has])
+    assert rel_err(got['left'], model.left_memory.vals.cpu().numpy()) < 1e-6
+    assert rel_err(got['right'], model.right_memory.vals.cpu().numpy()) < 1e-6
+    assert rel_err(got['msg'][has], model.msg_store.node_msg_vals.cpu().numpy()[has]) < 1e-6
+
+
 # ------------------------------------------------------------------------------ the reference's DDP recipe
 def _ddp_worker(rank, world, port, root, n_steps, out_dir):
     """train_self_supervised_ddp.py:107-211 on this package's API: ChunkSampler time chunks,

@@ -94,6 +94,42 @@ def test_end_to_end_recipe_on_toy_jodie_files(tmp_path):
     assert not any(k.startswith('msg_store.') for k in sd)
 
 
+def test_recipe_when_the_training_split_lacks_the_highest_node_id(tmp_path):
+    """Real JODIE splits: items first seen after the validation time (and the hidden 10 % of the nodes) are missing
+    from the training split, so Graph.from_data(train_data) alone would cover fewer ids than the model's tables.
+    init_data builds both graphs over the id space of the full data; the loop must run end to end."""
+    import os
+    import sys
+    from test_input_side import write_files
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'examples'))
+    import link_prediction as lp
+    from www2023tiger_amd.data.graph import Graph
+    from www2023tiger_amd.init_utils import init_data
+    z0 = load('input_side')
+    z = {k: z0[k] for k in ('src', 'dst', 'ts', 'labels')}
+    for _ in range(3):  # three late events on brand-new items: the highest ids occur in the test period only
+        z['src'] = np.append(z['src'], z['src'][-1])
+        z['dst'] = np.append(z['dst'], z['dst'].max() + 1)
+        z['ts'] = np.append(z['ts'], z['ts'][-1] + 1.0)
+        z['labels'] = np.append(z['labels'], 0)
+    write_files(str(tmp_path), 'late', z, with_feats=False)
+    basic, (train_graph, full_graph), _ = init_data('late', str(tmp_path), 0, bs=100, warmup_steps=0, subset=1.0,
+                                                    strategy='recent_edges', n_layers=1, n_neighbors=4,
+                                                    restarter_type='static', hist_len=6, device=dev())
+    train_data, full_data = basic[3], basic[2]
+    assert max(train_data.src.max(), train_data.dst.max()) < max(full_data.src.max(), full_data.dst.max())
+    assert train_graph.num_node == full_graph.num_node == int(max(full_data.src.max(), full_data.dst.max())) + 1
+    out, model = lp.run('late', str(tmp_path), seed=0, n_epochs=1, bs=100, lr=1e-3, dim=8, n_neighbors=4, hist_len=6,
+                        restarter_type='static', restart_prob=0.1, warmup_steps=50, ckpt_path=str(tmp_path / 'm.pt'))
+    assert np.isfinite(list(out['epochs'][0].values())).all() and 0.0 <= out['test_ap'] <= 1.0
+    # a graph over fewer ids than the model is refused with a pointer to the fix, not with an opaque status code
+    small = Graph.from_data(train_data, strategy='recent_edges', seed=0, device=dev())
+    assert small.num_node < model.n_nodes
+    with pytest.raises(ValueError, match='max_node_id'):
+        model.check_graph(small)
+
+
 def test_fused_eval_samples_from_the_collators_graph():
     """Warm-up batches are collated on the TRAINING graph while model.graph is the full graph
     (train_self_supervised.py:175-183): the one-call evaluation must embed with the collator's

@@ -69,7 +69,7 @@ class TgStepIo(C.Structure):
         ('h', vp), ('l1_nids', vp), ('l1_eids', vp), ('l1_ts', vp), ('involved', vp), ('counts', vp),
         ('h_prev_left', vp), ('h_prev_right', vp), ('err', vp),
         ('offset_dev', vp), ('advance', i32), ('embed_only', i32), ('profiler', vp), ('h_new', vp),
-        ('ws_is_clean', i32), ('rows_hint', i32), ('lazy', vp),
+        ('ws_is_clean', i32), ('rows_hint', i32), ('lazy', vp), ('collate_only', i32), ('reserved2', i32),
     ]
 
 
@@ -82,6 +82,7 @@ class TgWritebackIo(C.Structure):
     _fields_ = [
         ('Bg', i64), ('src', vp), ('dst', vp), ('ts', vp), ('eids', vp), ('offset_dev', vp), ('advance', i32),
         ('reserved', i32), ('rows', vp), ('left_row', vp), ('new_row', vp), ('err', vp),
+        ('owner', vp), ('my_rank', i32), ('new_from_pending', i32),
     ]
 
 
@@ -138,6 +139,7 @@ SIGNATURES = {
     'tg_temporal_attn_workspace_bytes': (sz, [P(TgModel), i64]),
     'tg_temporal_attn_fwd': (C.c_int, [P(TgModel), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     'tg_consume_update_right': (C.c_int, [P(TgModel), vp, vp, i64, vp, vp, vp, vp, vp]),
+    'tg_gather_eff_rows': (C.c_int, [P(TgModel), i64, vp, vp, vp, vp]),
     'tg_store_events': (C.c_int, [P(TgModel), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'tg_restart_seq_workspace_bytes': (sz, [P(TgModel), P(TgSeqRestarter), i64]),
     'tg_restart_seq_fwd': (C.c_int, [P(TgModel), P(TgSeqRestarter), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),

@@ -284,6 +284,11 @@ struct WritebackArgs {
   unsigned long long* clean_best;
   int32_t* clean_counts;
   int64_t* lazy_batch;  // nullable: the lazy restart's batch counter, += 1 by the last kernel of the step
+  // partitioned state: only nodes with owner[node] == my_rank are written / checked; STEP 4 may read the
+  // owner's table of precomputed updater rows
+  const int32_t* owner;
+  int32_t my_rank;
+  int32_t new_from_pending;
 };
 int writeback_launch(const tg_model* m, const WritebackArgs& a, int phase, hipStream_t st);
 

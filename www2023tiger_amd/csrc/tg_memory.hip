@@ -273,14 +273,18 @@ __global__ void __launch_bounds__(256) k_writeback(tg_model m, WritebackArgs a) 
     for (int64_t i = wave0 * TG_WAVE + lane; i < 2 * B; i += nwave * TG_WAVE) {
       const int64_t e = i < B ? i : i - B;
       const int64_t node = i < B ? a.src[e] : a.dst[e];
+      if (a.owner && a.owner[node] != a.my_rank) continue;  // another rank's node: its time is not kept here
       if (mem_ts[node] > a.ts[e]) atomicOr(a.err, TG_ERR_EVENT_BEFORE_MEM);
     }
   }
   const int64_t po = a.plan_off ? 2 * *a.plan_off : 0;
   for (int64_t p = wave0; p < n; p += nwave) {
     const int64_t id = a.upos[p], idx = a.index[p];
+    if (a.owner && a.owner[id] != a.my_rank) continue;  // partitioned state: the owner writes (wave-uniform)
     if (PHASE == 0) {
-      if (a.rows)
+      if (a.new_from_pending)
+        wb_step4(m, id, id, reinterpret_cast<const float4*>(m.pending_vals), a.err, lane);
+      else if (a.rows)
         wb_step4(m, id, a.new_row[po + idx], reinterpret_cast<const float4*>(a.rows), a.err, lane);
       else
         wb_step4(m, id, (int64_t)bm_rank(a.bm, a.rank, id), reinterpret_cast<const float4*>(a.reprs), a.err, lane);
@@ -441,6 +445,34 @@ extern "C" int tg_consume_update_right_rows(const tg_model* m, const int64_t* up
   hipLaunchKernelGGL(k_consume_update_right, dim3(flat_grid(cap, 4)), dim3(256), 0, as_stream(stream), *m, upos, n_upos,
                      cap, (const float4*)rows, (const uint64_t*)nullptr, (const uint32_t*)nullptr, row_index, err);
   return check_launch("tg_consume_update_right_rows");
+}
+
+namespace tg {
+__global__ void k_gather_eff_rows(tg_model m, int64_t n, const int64_t* __restrict__ ids, float4* __restrict__ out,
+                                  float* __restrict__ ts_out) {
+  const int w4 = m.d / 4;
+  const float4* right = reinterpret_cast<const float4*>(m.right_vals);
+  const float4* pend = reinterpret_cast<const float4*>(m.pending_vals);
+  const int64_t total = n * w4;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / w4;
+    const int c = (int)(t - i * w4);
+    const int64_t id = ids[i];
+    const bool pending = bm_test(m.has_msg, id);
+    out[t] = (pending ? pend : right)[id * w4 + c];
+    if (c == 0 && ts_out) ts_out[i] = pending ? m.msg_ts[id] : m.right_ts[id];
+  }
+}
+}  // namespace tg
+
+extern "C" int tg_gather_eff_rows(const tg_model* m, int64_t n, const int64_t* ids, float* out, float* ts_out,
+                                  void* stream) {
+  if (!model_ok(m) || n < 0 || !m->pending_vals) return TG_EINVAL;
+  if (n == 0) return TG_OK;
+  if (!ids || !out) return TG_EINVAL;
+  hipLaunchKernelGGL(k_gather_eff_rows, dim3(flat_grid(n * (m->d / 4), 256)), dim3(256), 0, as_stream(stream), *m, n, ids,
+                     (float4*)out, ts_out);
+  return check_launch("tg_gather_eff_rows");
 }
 
 extern "C" int tg_store_events(const tg_model* m, int64_t B, const int64_t* src, const int64_t* dst, const float* ts,

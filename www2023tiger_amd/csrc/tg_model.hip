@@ -807,7 +807,7 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   const int64_t B = io->B, Q = 3 * B, K = m->n_neighbors, cap = Q * (K + 1);
   prof_mark(pf, ST_QUERIES, st);
   hipError_t e = hipSuccess;
-  if (!io->ws_is_clean || io->embed_only) e = hipMemsetAsync(w.flags, 0, w.zero_bytes, st);
+  if (!io->ws_is_clean || io->embed_only || io->collate_only) e = hipMemsetAsync(w.flags, 0, w.zero_bytes, st);
   if (e != hipSuccess) {
     set_hip_error(e, "tg_stream_step memset");
     return TG_EHIP;
@@ -833,6 +833,7 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   if ((rc = unique_compact_launch(w.flags, w.bm, m->n_nodes, w.rank, w.inv, w.counts + 0, cap, m->has_msg, w.rank_out,
                                   w.outdated, w.out_pos, w.counts + 1, w.scan_ws, w.scan_bytes, st)) != TG_OK)
     return rc;
+  if (io->collate_only) return check_launch("tg_stream_step(collate_only)");
   prof_mark(pf, ST_GATHER, st);
   // the positive-node dedup (needed by the write-back) rides on two launches of the forward pass
   PosArgs pos{B, w.nids3, w.ts3f, w.bm, w.rank, w.best, w.counts + 2, w.upos, w.index, w.upos32};
@@ -912,7 +913,7 @@ int step_writeback_b(const tg_model* m, const tg_step_io* io, StepWs& w, hipStre
   int rc;
   if ((rc = writeback_launch(m, wa, 1, st)) != TG_OK) return rc;
   prof_mark(pf, ST_EAGER, st);
-  if (w.eager) {
+  if (w.eager && !io->embed_only) {
     // every unique positive node has just received a message (STEP 5) and its memories are final for this batch
     // (STEP 4 / STEP 6): the row a later batch would compute on the fly when the node turns up as a neighbour,
     // pending[v] = updater(upd_memory[v], tsfm(mailbox[v])), is computed here, once
@@ -930,7 +931,8 @@ int step_writeback_b(const tg_model* m, const tg_step_io* io, StepWs& w, hipStre
 extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, void* ws, size_t ws_bytes,
                               void* stream) {
   if (!attn_dims_ok(m) || !g || !io || io->B <= 0) return TG_EINVAL;
-  if (!io->src || !io->dst || !io->neg || !io->ts || !io->eids || !io->h || !io->err) return TG_EINVAL;
+  if (!io->src || !io->dst || !io->neg || !io->ts || !io->eids || (!io->h && !io->collate_only) || !io->err)
+    return TG_EINVAL;
   if (g->num_node != m->n_nodes) return TG_EINVAL;
   hipStream_t st = as_stream(stream);
   tg_profiler* pf = (tg_profiler*)io->profiler;
@@ -939,9 +941,11 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
   if (!carve_step(m, io->B, cv, w)) return TG_EWORKSPACE;
   int rc;
   // eager updates need the full step (the updater launch at its end keeps the table current)
-  const bool eager = m->pending_vals != nullptr && !io->embed_only;
+  // embed_only still GATHERS the precomputed rows when the table is there (the partitioned multi-GPU path keeps it
+  // current through tg_apply_messages after its own write-back); only a full step runs the updater at its end
+  const bool eager = m->pending_vals != nullptr;
   if ((rc = step_forward(m, g, io, w, nullptr, st, pf, nullptr, eager)) != TG_OK) return rc;
-  if (io->embed_only) {
+  if (io->embed_only || io->collate_only) {
     if (io->counts) {
       hipError_t e = hipMemcpyAsync(io->counts, w.counts, 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
       if (e != hipSuccess) {
@@ -1020,8 +1024,8 @@ extern "C" size_t tg_stream_writeback_workspace_bytes(const tg_model* m, int64_t
 extern "C" int tg_stream_writeback(const tg_model* m, const tg_writeback_io* io, void* ws, size_t ws_bytes,
                                    void* stream) {
   if (!attn_dims_ok(m) || !io || io->Bg <= 0) return TG_EINVAL;
-  if (!io->src || !io->dst || !io->ts || !io->eids || !io->rows || !io->left_row || !io->new_row || !io->err)
-    return TG_EINVAL;
+  if (!io->src || !io->dst || !io->ts || !io->eids || !io->rows || !io->left_row || !io->err) return TG_EINVAL;
+  if (io->new_from_pending ? !m->pending_vals : !io->new_row) return TG_EINVAL;
   hipStream_t st = as_stream(stream);
   const int64_t Bg = io->Bg;
   Carver cv(ws, ws_bytes);
@@ -1048,6 +1052,7 @@ extern "C" int tg_stream_writeback(const tg_model* m, const tg_writeback_io* io,
   wa.B = Bg; wa.src = src; wa.dst = dst; wa.eids = w.eids; wa.upos = w.upos; wa.index = w.index; wa.ts = w.ts2f;
   wa.n_upos = w.counts + 2; wa.err = io->err;
   wa.rows = io->rows; wa.new_row = io->new_row; wa.left_row = io->left_row; wa.plan_off = io->offset_dev;
+  wa.owner = io->owner; wa.my_rank = io->my_rank; wa.new_from_pending = io->new_from_pending;
   if ((rc = writeback_launch(m, wa, 0, st)) != TG_OK) return rc;
   if ((rc = writeback_launch(m, wa, 1, st)) != TG_OK) return rc;
   // phase 1 itself reads the offset (plan_off), so it is advanced by a separate launch

@@ -1,19 +1,32 @@
-"""Multi-GPU streaming: one process per GPU, events of a batch sharded by the owner of
-their destination node, node state replicated and kept coherent by ONE collective per
-batch (an all-gather of the positive nodes' new rows over RCCL/xGMI).
+"""Multi-GPU streaming (SURVEY.md s8 e): one process per GPU, events of a global batch sharded by the
+owner of their destination node.  Two layouts of the node state:
 
-Why this shape (SURVEY.md s8 e): every rank embeds only its shard of the global batch
-(sampling, GRU, attention - the expensive part), reading a replica of the memories that
-is exact because the exchange period is 1.  The write-back (STEP 4-6) is cheap, needs
-only the 2 rows per event that the all-gather delivers, and is applied redundantly on
-every rank, so no second collective and no remote reads are needed.  An all-gather
-drives all 7 xGMI links of a GPU at once (a ring all-reduce would be bound by one link).
-Results are bit-identical to the single-GPU engine run on the same global batch.
-All state fits replicated for every BASELINE config (C5: 67 GB of 288 GB per GPU);
-partitioning the tables themselves (all-to-all of remote rows) is future work.
+PARTITIONED (PartitionedRunner; the north star's layout; needs the model's eager updates).  A node's rows -
+both memories, mailbox, has-message bit, the precomputed updater row - are authoritative on owner(node) only.
+Per global batch, on every rank:
+  1. PULL  one all_to_all_single of rows, owner -> user: the effective right-memory rows
+           (has_msg ? pending : right, tg_gather_eff_rows) of the involved nodes of the rank's events that it does
+           not own, and the message-source memory rows of the remote "other" endpoints of the winning events of
+           its own nodes (STEP 5 reads them, tiger.py:422-442).  Received rows are written over the rank's stale
+           copies of those rows, so every kernel of the single-GPU engine runs unchanged on global node ids;
+  2. local collate + STEP 1-3 for the rank's events (tg_stream_step, embed_only);
+  3. PUSH  one all_to_all_single the other way, event rank -> owner: h(t-) of the winning positions of nodes
+           owned elsewhere (STEP 6's rows);
+  4. STEP 4-6 for the rank's OWN positive nodes only (tg_stream_writeback with the owner filter; STEP 4 reads
+           the owner's table of precomputed updater rows), then the eager updater for the nodes that received a
+           message (tg_apply_messages).
+Which rows travel is a function of the graph and the batch only (sampling does not depend on state), so the
+exchange is PLANNED first (`plan`, which also tells every owner what it will be asked for) and then RUN; for a
+stream resident in HBM all plans are made up front and a step is the two collectives above plus local kernels.
+Exchange period 1: results equal the single-GPU engine on the global batch.  (Row addressing stays global: a rank
+allocates full-height tables and touches only its own rows plus the pulled rows of the current batch.)
 
-The reference's own multi-GPU mode (time-chunk DDP, train_self_supervised_ddp.py) is a
-different algorithm and is not what this file implements.
+REPLICATED (ShardedRunner / ResidentShardedStream).  Every rank keeps all rows; each embeds its shard, ONE
+all-gather delivers the positive nodes' new rows and every rank applies the whole global write-back.  No remote
+reads, but P-fold redundant write-back and 4 B rows per rank received from every peer.
+
+The reference's own multi-GPU mode (time-chunk DDP, train_self_supervised_ddp.py) is a different algorithm and
+is not what this file implements (it runs on the drop-in API, tests/test_dist.py).
 """
 import ctypes as C
 import json
@@ -26,21 +39,28 @@ import torch.distributed as tdist
 
 
 # --------------------------------------------------------------------------- host logic
-def balanced_owner_table(n_nodes: int, dst: np.ndarray, world: int) -> np.ndarray:
-    """owner[node] in [0, world).  dst-hash sharding with the hash chosen as a static
-    lookup table that balances load: destination nodes are dealt to ranks in order of
-    decreasing popularity (longest-processing-time first), so that a few very hot items
-    (JODIE item popularity is Zipf-like) do not pile up on one rank.  Nodes that never
-    occur as a destination fall back to node % world."""
+def balanced_owner_table(n_nodes: int, dst: np.ndarray, world: int, exact: int = 4096) -> np.ndarray:
+    """owner[node] in [0, world): the "dst hash" as a static lookup table that balances load.  The `exact` most
+    popular destination nodes are placed one by one on the least loaded rank (longest-processing-time first: a few
+    very hot items of a Zipf-like popularity must not pile up on one rank); the long tail, whose nodes carry little
+    load each, is dealt boustrophedon (0..P-1, P-1..0, ...) in order of decreasing popularity - vectorised, so the
+    table of a 10 M-node graph takes well under a second.  Nodes that never occur as a destination fall back to
+    node % world."""
     deg = np.bincount(dst, minlength=n_nodes).astype(np.int64)
     owner = (np.arange(n_nodes) % world).astype(np.int64)
+    hot = np.argsort(-deg, kind='stable')
+    hot = hot[:int((deg > 0).sum())]
     load = np.zeros(world, dtype=np.int64)
-    for node in np.argsort(-deg, kind='stable'):
-        if deg[node] == 0:
-            break
+    for node in hot[:exact]:
         r = int(np.argmin(load))
         owner[node] = r
         load[r] += deg[node]
+    tail = hot[exact:]
+    if len(tail):
+        start = np.argsort(load, kind='stable')  # the lightest rank takes the first (largest) node of every lap
+        k = np.arange(len(tail))
+        lap, pos = k // world, k % world
+        owner[tail] = start[np.where(lap % 2 == 0, pos, world - 1 - pos)]
     return owner
 
 
@@ -67,20 +87,17 @@ class ShardPlan:
             per = Bg // world
             if per > cap:
                 raise ValueError(f'shard of {per} events exceeds capacity {cap}')
-            rank_of = np.empty(Bg, dtype=np.int64)
-            room = np.full(world, per, dtype=np.int64)
-            spill = []
-            for e in range(Bg):  # stream order
-                r = pref[e]
-                if room[r] > 0:
-                    rank_of[e] = r
-                    room[r] -= 1
-                else:
-                    spill.append(e)
-            for e in spill:
-                r = int(np.argmax(room))  # most room first (ties -> lowest rank)
-                rank_of[e] = r
-                room[r] -= 1
+            # an event stays on the owner of its dst while that shard has room (the first `per` events of every
+            # owner, in stream order); the overflow, in stream order, fills the free slots rank by rank
+            order = np.argsort(pref, kind='stable')
+            cnt = np.bincount(pref, minlength=world)
+            first = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+            nth = np.empty(Bg, dtype=np.int64)
+            nth[order] = np.arange(Bg) - np.repeat(first, cnt)  # how many earlier events prefer the same rank
+            stays = nth < per
+            rank_of = np.where(stays, pref, -1)
+            room = per - np.minimum(cnt, per)
+            rank_of[~stays] = np.repeat(np.arange(world), room)
         else:
             rank_of = pref
         self.rank_of = rank_of
@@ -302,10 +319,295 @@ class ResidentShardedStream:
         self.hip_ops.raise_if_err(self.buf.err)
 
 
+# --------------------------------------------------------------------------- partitioned state
+def all_to_all_rows(send: torch.Tensor, in_splits, out_splits, group=None) -> torch.Tensor:
+    """all_to_all_single over the leading dimension with per-peer row counts.  RCCL: on device.  gloo (CPU tests,
+    or several ranks sharing one GPU): staged through host memory."""
+    out = torch.empty((int(sum(out_splits)),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+    if tdist.get_backend(group) == 'nccl':
+        tdist.all_to_all_single(out, send.contiguous(), list(out_splits), list(in_splits), group=group)
+        return out
+    host = torch.empty(out.shape, dtype=send.dtype)
+    tdist.all_to_all_single(host, send.detach().cpu().contiguous(), list(out_splits), list(in_splits), group=group)
+    out.copy_(host)
+    return out
+
+
+def exchange_counts(counts: torch.Tensor, group=None) -> torch.Tensor:
+    """counts [world, k] on the host (row q: what I send to peer q) -> [world, k] (row q: what peer q sends to me)"""
+    c = counts.reshape(counts.shape[0], -1).to(torch.int64).contiguous()
+    if tdist.get_backend(group) == 'nccl':
+        c = c.cuda()
+    out = torch.empty_like(c)
+    tdist.all_to_all_single(out, c, group=group)
+    return out.cpu()
+
+
+class StepPlan:
+    """Everything about one global batch that does not depend on node state (see PartitionedRunner.plan)."""
+    __slots__ = ('n', 'Bg', 'local', 'glob', 'serve_ids', 'serve_is_msg', 'serve_in', 'serve_out', 'req_eff',
+                 'req_msg', 'reply_is_msg', 'push_rows', 'push_in', 'push_out', 'left_row', 'mine', 'stats')
+
+
+class PartitionedRunner:
+    """Drives global batches over partitioned node state (module docstring).  `engine` supplies the local compute
+    (HipPartitionEngine in production; the CPU tests plug in an oracle-backed engine to exercise this host logic
+    under gloo).  Index arithmetic runs on `engine.device` with torch ops; rows never touch the host on RCCL."""
+
+    def __init__(self, engine, owner: np.ndarray, rank: int, world: int, group=None):
+        self.engine, self.rank, self.world, self.group = engine, rank, world, group
+        self.dev = engine.device
+        self.owner = torch.as_tensor(np.asarray(owner), dtype=torch.int64, device=self.dev)
+
+    def _by_peer(self, ids: torch.Tensor):
+        """ids grouped by owning rank (stable) and the per-rank counts"""
+        dest = self.owner[ids]
+        order = torch.argsort(dest, stable=True)
+        return ids[order], torch.bincount(dest, minlength=self.world)
+
+    def plan(self, src, dst, neg, ts, eids, rank_of=None) -> StepPlan:
+        """Collective.  src..eids: the GLOBAL batch (host arrays, identical on every rank); rank_of[e]: the rank that
+        embeds event e (default: owner of its dst)."""
+        E, dev, rank, world, own = self.engine, self.dev, self.rank, self.world, self.owner
+        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(dev)
+        g_src, g_dst, g_neg, g_eids = (t(a, torch.int64) for a in (src, dst, neg, eids))
+        g_ts = t(ts, torch.float64)
+        Bg = len(g_src)
+        rank_of = own[g_dst] if rank_of is None else t(rank_of, torch.int64)
+        p = StepPlan()
+        p.Bg = Bg
+        p.glob = (g_src, g_dst, g_ts, g_eids)
+        li = torch.nonzero(rank_of == rank).flatten()
+        n = p.n = int(li.numel())
+        p.local = tuple(a[li] for a in (g_src, g_dst, g_neg, g_ts, g_eids))
+        # ---- what this rank must pull
+        involved = E.collate(*p.local[:4]) if n else torch.zeros(0, dtype=torch.int64, device=dev)
+        eff = involved[(own[involved] != rank) & (involved != 0)]  # node 0 is the padding row: zero everywhere, never written
+        pos = torch.cat([g_src, g_dst])
+        upos, index = E.select_latest(pos, g_ts.float().repeat(2))  # the winners of the global batch (same on every rank)
+        mine_mask = own[upos] == rank
+        p.mine = upos[mine_mask]
+        idx_mine = index[mine_mask]
+        other = torch.where(idx_mine < Bg, g_dst[idx_mine % Bg], g_src[idx_mine % Bg])
+        msg = torch.unique(other[own[other] != rank])               # STEP 5 reads the other endpoint's message memory
+        eff_s, eff_c = self._by_peer(eff)
+        msg_s, msg_c = self._by_peer(msg)
+        p.req_eff, p.req_msg = eff_s, msg_s
+        # requests travel once, in the plan: peer q receives [eff ids | msg ids] of every requester
+        cnt = torch.stack([eff_c, msg_c], 1).cpu()                    # [world, 2] what I ask of each peer
+        got = exchange_counts(cnt, self.group)                        # [world, 2] what each peer asks of me
+        eo = torch.cumsum(torch.cat([torch.zeros(1, dtype=torch.int64), eff_c.cpu()]), 0).tolist()
+        mo = torch.cumsum(torch.cat([torch.zeros(1, dtype=torch.int64), msg_c.cpu()]), 0).tolist()
+        send_ids = torch.cat([torch.cat([eff_s[eo[q]:eo[q + 1]], msg_s[mo[q]:mo[q + 1]]]) for q in range(world)])
+        p.serve_out = cnt.sum(1).tolist()   # rows I receive from each peer when the pull runs
+        p.serve_in = got.sum(1).tolist()    # rows I serve to each peer
+        p.serve_ids = all_to_all_rows(send_ids, p.serve_out, p.serve_in, self.group)
+        kinds = lambda c: torch.cat([torch.cat([torch.zeros(int(a), dtype=torch.bool), torch.ones(int(b), dtype=torch.bool)])
+                                     for a, b in c.tolist()]).to(dev)
+        p.serve_is_msg = kinds(got)   # per requester: [eff ids | msg ids]
+        p.reply_is_msg = kinds(cnt)   # the reply of peer q to me has the same shape as my request to q
+        # ---- what this rank must push: h(t-) of winning positions of its events whose node lives elsewhere
+        slot = torch.full((Bg,), -1, dtype=torch.int64, device=dev)
+        slot[li] = torch.arange(n, device=dev)
+        ev, role = index % Bg, index // Bg
+        here = rank_of[ev] == rank
+        away = here & ~mine_mask
+        push_pos = index[away]
+        dest = own[upos[away]]
+        order = torch.argsort(dest, stable=True)
+        push_pos = push_pos[order]
+        push_c = torch.bincount(dest, minlength=world).cpu()
+        p.push_rows = (push_pos // Bg) * n + slot[push_pos % Bg]       # rows of this rank's h = [src | dst | neg] blocks
+        got_c = exchange_counts(push_c.reshape(world, 1), self.group).flatten()
+        p.push_in, p.push_out = push_c.tolist(), got_c.tolist()
+        recv_pos = all_to_all_rows(push_pos, p.push_in, p.push_out, self.group)  # global positions of the rows I will receive
+        # ---- row of h(t-) for every position of cat[src, dst] that this rank writes: local rows first, received after
+        left_row = torch.zeros(2 * Bg, dtype=torch.int64, device=dev)
+        loc = mine_mask & here
+        left_row[index[loc]] = role[loc] * n + slot[ev[loc]]
+        left_row[recv_pos] = 2 * n + torch.arange(recv_pos.numel(), device=dev)
+        p.left_row = left_row
+        p.stats = dict(local_events=n, pulled_rows=int(sum(p.serve_out)), served_rows=int(sum(p.serve_in)),
+                       pushed_rows=int(sum(p.push_in)), received_rows=int(sum(p.push_out)), own_winners=int(p.mine.numel()))
+        return p
+
+    def run(self, p: StepPlan) -> torch.Tensor:
+        """Collective.  The state-dependent part of a global batch: pull, embed, push, owner write-back, eager updater.
+        Returns this rank's embeddings [3 n, d] (rows [0, 2n) are h(t-) of cat[src, dst] of its events)."""
+        E = self.engine
+        served = E.serve(p.serve_ids, p.serve_is_msg)                                        # [*, d + 1]: row | time
+        got = all_to_all_rows(served, p.serve_in, p.serve_out, self.group)                   # PULL
+        is_msg = p.reply_is_msg
+        E.adopt(p.req_eff, got[~is_msg], p.req_msg, got[is_msg])
+        h = E.embed(*p.local) if p.n else torch.zeros(0, E.d, dtype=torch.float32, device=self.dev)
+        recv = all_to_all_rows(h[p.push_rows], p.push_in, p.push_out, self.group)            # PUSH
+        rows = torch.cat([h[:2 * p.n], recv]) if recv.numel() or p.n else torch.zeros(1, E.d, device=self.dev)
+        E.writeback(*p.glob, rows, p.left_row, self.owner, self.rank)
+        E.refresh(p.mine)
+        return h
+
+    def step(self, src, dst, neg, ts, eids, rank_of=None) -> torch.Tensor:
+        return self.run(self.plan(src, dst, neg, ts, eids, rank_of))
+
+
+class HipPartitionEngine:
+    """The local compute of the partitioned mode on the HIP engine (every method is C-ABI calls on the model's
+    tables): collation, serving rows to peers, adopting pulled rows, embedding, owner write-back, eager updater."""
+
+    def __init__(self, model, cap: int):
+        from . import hip_ops
+        from ._lib import TgWritebackIo, check, lib, ptr
+        if model._pending is None:
+            model.eager_updates()  # owners serve precomputed updater rows: the partitioned layout builds on them
+        model._sync_pending()
+        self.model, self.cap, self.device, self.d = model, cap, model.device, model.memory_dim
+        self.hip_ops, self.check, self.lib, self.ptr, self.WbIo = hip_ops, check, lib, ptr, TgWritebackIo
+        self.buf = model.StepBuffers(model, cap, False, embed_only=True)
+        self.err = hip_ops.new_err(model.device)
+        self._wb_ws = None
+        self._owner32 = None
+
+    def _load(self, src, dst, neg, ts, eids=None):
+        n, buf = int(src.numel()), self.buf
+        assert n <= self.cap, f'{n} events exceed the engine capacity {self.cap}'
+        buf.src[:n], buf.dst[:n], buf.neg[:n], buf.ts[:n] = src, dst, neg, ts
+        if eids is not None:
+            buf.eids[:n] = eids
+        buf.io.B = n
+        return n
+
+    def select_latest(self, pos, ts32):
+        return self.hip_ops.select_latest_nids(pos, ts32, self.model.n_nodes)
+
+    def collate(self, src, dst, neg, ts):
+        """sorted involved node ids of these events (sampler + compaction only: no state is read)"""
+        self._load(src, dst, neg, ts)
+        self.buf.io.collate_only = 1
+        try:
+            self.model.launch_step(self.buf)
+        finally:
+            self.buf.io.collate_only = 0
+        return self.buf.involved[:int(self.buf.counts[0].item())].clone()
+
+    def serve(self, ids, is_msg):
+        m, lib, ptr = self.model, self.lib, self.ptr
+        out = torch.empty(ids.numel(), self.d + 1, dtype=torch.float32, device=self.device)
+        if ids.numel() == 0:
+            return out
+        ms = m.model_struct()
+        e_ids, m_ids = ids[~is_msg].contiguous(), ids[is_msg].contiguous()
+        rows = torch.empty(e_ids.numel(), self.d, dtype=torch.float32, device=self.device)
+        ts = torch.empty(e_ids.numel(), dtype=torch.float32, device=self.device)
+        self.check(lib.tg_gather_eff_rows(C.byref(ms), e_ids.numel(), ptr(e_ids), ptr(rows), ptr(ts),
+                                          self.hip_ops.stream_ptr(self.device)), 'tg_gather_eff_rows')
+        out[~is_msg] = torch.cat([rows, ts[:, None]], 1)
+        if m_ids.numel():
+            if m.msg_src == 'left':
+                r2, t2 = self.hip_ops.gather_rows(m.left_memory.vals, m_ids, m.left_memory.update_ts)
+            else:  # the right memory as STEP 4 leaves it
+                r2 = torch.empty(m_ids.numel(), self.d, dtype=torch.float32, device=self.device)
+                t2 = torch.empty(m_ids.numel(), dtype=torch.float32, device=self.device)
+                self.check(lib.tg_gather_eff_rows(C.byref(ms), m_ids.numel(), ptr(m_ids), ptr(r2), ptr(t2),
+                                                  self.hip_ops.stream_ptr(self.device)), 'tg_gather_eff_rows')
+            out[is_msg] = torch.cat([r2, t2[:, None]], 1)
+        return out
+
+    def adopt(self, eff_ids, eff_rows, msg_ids, msg_rows):
+        """pulled rows overwrite this rank's stale copies (rows of nodes it does not own: never authoritative here)"""
+        m, ops = self.model, self.hip_ops
+        R, L = m.right_memory, m.left_memory
+        if eff_ids.numel():
+            ops.memory_scatter(R.vals, R.update_ts, None, eff_ids, eff_rows[:, :self.d].contiguous(),
+                               eff_rows[:, self.d].contiguous())
+        if msg_ids.numel():
+            T = L if m.msg_src == 'left' else R
+            ops.memory_scatter(T.vals, T.update_ts, None, msg_ids, msg_rows[:, :self.d].contiguous(),
+                               msg_rows[:, self.d].contiguous())
+
+    def embed(self, src, dst, neg, ts, eids):
+        n = self._load(src, dst, neg, ts, eids)
+        self.model.launch_step(self.buf)
+        return self.buf.h[:3 * n]
+
+    def writeback(self, src, dst, ts, eids, rows, left_row, owner, rank):
+        m, lib, ptr = self.model, self.lib, self.ptr
+        m._touch()
+        Bg = int(src.numel())
+        ms = m.model_struct()
+        if self._owner32 is None:
+            self._owner32 = owner.to(torch.int32).contiguous()
+        keep = [src.contiguous(), dst.contiguous(), ts.contiguous(), eids.contiguous(), rows.contiguous(),
+                left_row.contiguous()]
+        nbytes = int(lib.tg_stream_writeback_workspace_bytes(C.byref(ms), Bg))
+        if self._wb_ws is None or self._wb_ws.numel() < nbytes:
+            self._wb_ws = torch.empty(nbytes, dtype=torch.uint8, device=m.device)
+        io = self.WbIo(Bg, ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), None, 0, 0, ptr(keep[4]),
+                       ptr(keep[5]), None, ptr(self.err), ptr(self._owner32), rank, 1)
+        self.check(lib.tg_stream_writeback(C.byref(ms), C.byref(io), ptr(self._wb_ws), self._wb_ws.numel(),
+                                           self.hip_ops.stream_ptr(m.device)), 'tg_stream_writeback')
+        self._keep = keep
+
+    def refresh(self, ids):
+        """eager updater: pending[v] = updater(upd_memory[v], tsfm(mailbox[v])) for the owned nodes that just
+        received a message"""
+        m, lib, ptr = self.model, self.lib, self.ptr
+        n = int(ids.numel())
+        if n:
+            ms = m.model_struct()
+            ids = ids.contiguous()
+            ids32 = ids.to(torch.int32)
+            cnt = torch.tensor([n], dtype=torch.int32, device=self.device)
+            nbytes = int(lib.tg_apply_messages_workspace_bytes(C.byref(ms), n))
+            ws = m._ws('apply', nbytes)
+            self.check(lib.tg_apply_messages(C.byref(ms), ptr(ids), ptr(ids32), ptr(cnt), n, ptr(m._pending), ptr(self.err),
+                                             ptr(ws), ws.numel(), self.hip_ops.stream_ptr(self.device)),
+                       'tg_apply_messages(pending)')
+        m._pending_stamp = m._state_stamp()  # the table is current again
+
+    def check_invariants(self):
+        self.hip_ops.raise_if_err(self.err)
+        self.hip_ops.raise_if_err(self.buf.err)
+
+
+class ResidentPartitionedStream:
+    """The partitioned mode for a stream that is resident in HBM: every step is planned up front (plans are
+    functions of the graph and the stream only; the planning pass also tells every owner what it will be asked
+    for), so a timed step is pull -> embed -> push -> owner write-back -> eager updater: two all_to_all_single
+    of rows and local kernels, no host decision in between."""
+
+    def __init__(self, model, stream: dict, owner: np.ndarray, rank: int, world: int, B: int, n_steps: int,
+                 group=None, balance: bool = True):
+        Bg = B * world
+        self.engine = HipPartitionEngine(model, cap=B if balance else Bg)
+        self.runner = PartitionedRunner(self.engine, owner, rank, world, group)
+        self.plans = []
+        keys = ('src', 'dst', 'neg', 'ts', 'eids')
+        for b in range(n_steps):
+            sl = slice(b * Bg, (b + 1) * Bg)
+            rank_of = ShardPlan(stream['dst'][sl], owner, world, B, balance=True).rank_of if balance else None
+            self.plans.append(self.runner.plan(*(stream[k][sl] for k in keys), rank_of=rank_of))
+        self.steps_done = 0
+
+    def step(self):
+        h = self.runner.run(self.plans[self.steps_done])
+        self.steps_done += 1
+        return h
+
+    def traffic(self):
+        keys = ('pulled_rows', 'served_rows', 'pushed_rows', 'received_rows', 'own_winners', 'local_events')
+        return {k: float(np.mean([p.stats[k] for p in self.plans])) for k in keys}
+
+    def check_invariants(self):
+        self.engine.check_invariants()
+
+
 # --------------------------------------------------------------------------- benchmark leg
 def bench_main(args, cfg, make_stream, build_models, rank, local_rank, world):
-    """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: weak scaling,
-    global batch = N * B events per step; value = events of all ranks / max-over-ranks time."""
+    """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (or `python bench.py --gpus N`,
+    which starts the ranks itself).  --scaling weak: B events per rank per step (global batch N * B);
+    strong: the global batch stays B.  value = events of all ranks / max-over-ranks time.
+    Period-1 exchange: a global batch is one batch of the single-GPU engine (its events read the state left by
+    the previous global batch), so with weak scaling the batch whose events do not see each other grows with N."""
     assert world == args.gpus, f'launch with torchrun: WORLD_SIZE={world} but --gpus {args.gpus}'
     # RCCL prints a version banner on fd 1 when the communicator is created; the contract is ONE JSON
     # line on stdout, so fd 1 is pointed at stderr until the result is ready
@@ -323,32 +625,43 @@ def bench_main(args, cfg, make_stream, build_models, rank, local_rank, world):
         tdist.init_process_group('gloo', rank=rank, world_size=world)
     else:
         tdist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-    B, K, d = cfg['B'], cfg['K'], cfg['d']
+    K, d = cfg['K'], cfg['d']
+    strong = getattr(args, 'scaling', 'weak') == 'strong'
+    if strong and cfg['B'] % world:
+        raise ValueError('strong scaling needs the batch to divide by the number of ranks')
+    B = cfg['B'] // world if strong else cfg['B']   # events per rank per step
     Bg = B * world
-    n_steps = args.warmup + args.steps
+    mode = getattr(args, 'dist_mode', 'partitioned')
+    preroll = args.preroll if getattr(args, 'preroll', None) is not None else (20 if cfg['B'] > 8192 else 150)
+    n_steps = preroll + args.warmup + args.steps
     E = max(cfg['E'], (n_steps + 2) * Bg)
-    stream = make_stream(cfg['n_u'], cfg['n_i'], E, cfg['T'] * E / cfg['E'], seed=0, d_e=d)  # identical on every rank
-    model, _ = build_models(stream, d, K, cfg['msg_src'], cfg['upd_src'], restarter='static', device=str(dev))
+    no_feats = bool(cfg.get('no_feats'))
+    stream = make_stream(cfg['n_u'], cfg['n_i'], E, cfg['T'] * E / cfg['E'], seed=0, d_e=d,
+                         integer_ts=cfg.get('integer_ts', True), with_efeats=not no_feats)  # identical on every rank
+    model, _ = build_models(stream, d, K, cfg['msg_src'], cfg['upd_src'], restarter='static', device=str(dev),
+                            zero_nfeats=not no_feats)
     if not getattr(args, 'no_fuse', False):
         model.fuse_attention()  # fixed parameters: pre-multiplied attention weights, as in the 1-GPU bench
     owner = balanced_owner_table(stream['n_nodes'], stream['dst'], world)
-    use_graphs = bool(getattr(args, 'dist_graphs', False)) and not args.no_graph
-    rs = ResidentShardedStream(model, stream, owner, rank, world, B, n_steps, use_graphs=use_graphs)
+    use_graphs = bool(getattr(args, 'dist_graphs', False)) and not args.no_graph and mode == 'replicated'
+    if mode == 'partitioned':
+        rs = ResidentPartitionedStream(model, stream, owner, rank, world, B, n_steps)  # enables eager updates
+    else:
+        rs = ResidentShardedStream(model, stream, owner, rank, world, B, n_steps, use_graphs=use_graphs)
     spilled = 0.0
     for b in range(min(n_steps, 50)):  # how often the owner's shard was full (reported, not timed)
         sl = slice(b * Bg, (b + 1) * Bg)
         p = ShardPlan(stream['dst'][sl], owner, world, B, balance=True)
         spilled += float((p.rank_of != owner[stream['dst'][sl]]).mean())
     spilled /= min(n_steps, 50)
-    debug = bool(os.environ.get('TG_DIST_DEBUG'))
-    n_eager = min(2, args.warmup)
+    n_eager = min(2, n_steps - args.steps)
     for _ in range(n_eager):
-        rs.step(debug)
+        rs.step()
     torch.cuda.synchronize()
     if use_graphs:
         rs.capture()
-    for _ in range(args.warmup - n_eager):
-        rs.step(debug)
+    for _ in range(preroll + args.warmup - n_eager):
+        rs.step()
     torch.cuda.synchronize()
     tdist.barrier()
     torch.cuda.synchronize()
@@ -363,17 +676,29 @@ def bench_main(args, cfg, make_stream, build_models, rank, local_rank, world):
     rs.check_invariants()
     dt = float(dt.item())
     if rank == 0:
+        if mode == 'partitioned':
+            tr = rs.traffic()
+            row_b = 4 * (d + 1)
+            par = (f'dst-owner event shards x{world} (capacity-balanced), node state partitioned by owner(node): per batch one '
+                   f'all_to_all_single owner->user (pull, {tr["pulled_rows"]:.0f} rows of {row_b} B into rank 0) and one '
+                   f'user->owner (push, {tr["pushed_rows"]:.0f} rows of {4 * d} B from rank 0); owner-only write-back + eager updater')
+            launch = 'eager launches + 2 all_to_all_single per step (plans made before the timed region)'
+        else:
+            tr = None
+            par = (f'dst-owner event shards x{world} (capacity-balanced), replicated state, '
+                   f'1 RCCL all-gather of {4 * B}x{d} f32 rows per rank per batch')
+            launch = '2 hipGraphs + 1 all-gather per step' if use_graphs else 'eager launches + 1 all-gather per step'
         out = dict(metric='processed interaction-events/sec (memory+aggregate+embed), Wikipedia d=172',
                    value=args.steps * Bg / dt, unit='events/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='weak', vs_baseline=None,
-                   dtype='f32', data='synthetic',
+                   ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='strong' if strong else 'weak',
+                   vs_baseline=None, dtype='f32', data='synthetic',
                    config=dict(workload=cfg['name'], batch_per_gpu=B, global_batch=Bg, dim=d, n_neighbors=K,
                                msg_src=cfg['msg_src'], upd_src=cfg['upd_src'], n_nodes=stream['n_nodes'], events=E,
-                               mode='stream (no_grad) STEP 1-6',
-                               parallelism=f'dst-owner event shards x{world} (capacity-balanced), replicated state, '
-                                           f'1 RCCL all-gather of {4 * B}x{d} f32 rows per rank per batch',
-                               spilled_event_fraction=round(spilled, 4),
-                               launch='2 hipGraphs + 1 all-gather per step' if use_graphs else 'eager launches + 1 all-gather per step'),
+                               mode='stream (no_grad) STEP 1-6', state_preroll_batches=preroll,
+                               state_layout=mode, parallelism=par, exchange_rows_per_step_rank0=tr,
+                               spilled_event_fraction=round(spilled, 4), launch=launch,
+                               semantics='one global batch = one batch of the single-GPU engine (exchange period 1): '
+                                         f'events of a batch do not see each other, and that batch has {Bg} events here'),
                    roofline=None, cpu_baseline=None)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)

@@ -26,8 +26,13 @@ def init_data(data, root, seed, rank=None, world_size=None, *, num_workers=0, bs
         cut = math.ceil(len(train_data) * subset)
         offline_data = train_data.get_subset(cut, len(train_data))
         train_data = train_data.get_subset(0, cut)
-    train_graph = Graph.from_data(train_data, strategy=strategy, seed=seed, device=device)
-    full_graph = Graph.from_data(full_data, strategy=strategy, seed=seed, device=device)
+    # both graphs over the id space of the FULL data: the model's tables (n_nodes = full_graph.num_node,
+    # init_utils.py:141) and the collator's bitmaps are sized by it, while the training split usually lacks the
+    # highest ids (items first seen after the validation time, the hidden 10 % of the nodes).  Rows of nodes without
+    # training events are empty, so sampling on the training graph is what the reference's smaller graph gives
+    max_id = int(max(full_data.src.max(), full_data.dst.max()))
+    train_graph = Graph.from_data(train_data, strategy=strategy, seed=seed, max_node_id=max_id, device=device)
+    full_graph = Graph.from_data(full_data, strategy=strategy, seed=seed, max_node_id=max_id, device=device)
     mk_coll = lambda g: GraphCollator(g, n_neighbors, n_layers, restarter=restarter_type, hist_len=hist_len)
     train_coll, eval_coll = mk_coll(train_graph), mk_coll(full_graph)
     # same iteration protocol as the reference's DataLoaders, batches sliced natively (no per-event Python)

@@ -534,6 +534,14 @@ class TIGE(nn.Module):
             self._step_ws[key] = buf
         return buf
 
+    def check_graph(self, graph):
+        """the tables of the model and the bitmaps of a step are indexed by node id: a graph over fewer ids (e.g.
+        Graph.from_data(train_data) when the training split lacks the highest ids) must be built with
+        max_node_id = the largest id of the full data"""
+        if graph.num_node != self.n_nodes:
+            raise ValueError(f'graph covers {graph.num_node} node ids, the model {self.n_nodes}: build every graph with '
+                             'max_node_id = the largest node id of the full data (init_utils.init_data does)')
+
     def rows_bound(self) -> int:
         """Bound on the nodes with a pending message per batch handed to the library (tg_step_io.rows_hint):
         1.5 x the largest count read back so far, 0 while nothing has been read back.  Performance only - but a
@@ -552,6 +560,7 @@ class TIGE(nn.Module):
         if self._pending is not None and not buf.embed_only:
             self._sync_pending()
         m = self.model_struct()
+        self.check_graph(self.graph)
         g = self.graph.tcsr
         check(lib.tg_stream_step(C.byref(m), C.byref(g), C.byref(buf.io), ptr(buf.ws), buf.ws.numel(),
                                  stream_ptr(self.device)), 'tg_stream_step')

@@ -236,11 +236,14 @@ class TrainBuffers:
         collator's graph, as in the reference (tiger.py:579-581 reads the collated restart data);
         default model.graph."""
         model = self.model
+        self._grads_taken = False
         if zero_grads and not self.eval_only:
             self.gflat.zero_()
         m = model.model_struct()
         self.io.step.rows_hint = model.rows_bound()
         graph = model.graph if graph is None else graph
+        model.check_graph(graph)
+        model._touch()  # state changes outside the eager streaming step
         g = graph.tcsr
         check(lib.tg_train_step(C.byref(m), C.byref(g), C.byref(self.io), ptr(self.ws), self.ws.numel(),
                                 stream_ptr(model.device)), 'tg_train_step')
@@ -264,6 +267,18 @@ class _HandOver(torch.autograd.Function):
     def backward(ctx, g_losses):
         if ctx.buf is not None:
             tb = ctx.buf
+            # the gradients of this step live in ONE buffer that backward() scales in place and hands over as the
+            # .grad views: that REPLACES .grad (the reference's loop zero_grad()s every iteration, so nothing is
+            # lost there); accumulating over several batches or a second backward() of the same step would silently
+            # give wrong gradients, so both are refused - accumulate with torch.optim.Adam (non-deferred hand-over)
+            if getattr(tb, '_grads_taken', False):
+                raise RuntimeError('backward() was already run for this training step: its gradient buffer is '
+                                   'handed over in place and cannot be back-propagated twice')
+            for p, (g, _, _) in zip(ctx.params, ctx.grads):
+                if p.grad is not None and p.grad.data_ptr() != g.data_ptr():
+                    raise RuntimeError('gradient accumulation is not supported with www2023tiger_amd.optim.Adam '
+                                       '(call zero_grad() every iteration, or use torch.optim.Adam)')
+            tb._grads_taken = True
             tb.gflat[:tb.n_contrast].mul_(g_losses[0])
             if tb.n_contrast < tb.gflat.numel():
                 tb.gflat[tb.n_contrast:].mul_(g_losses[1])
