@@ -83,6 +83,13 @@ int tg_tcsr_build_host(int64_t num_events, const int64_t* src_host, const int64_
 int tg_rand_edge_pairs_host(uint32_t* mt_state, int64_t n_src, int64_t n_dst, int64_t count,
                             int64_t* src_idx_host, int64_t* dst_idx_host);
 
+/* The same draws on DEVICE (one wavefront, the accept / reject decisions of a state block taken 64 words at a time):
+ * mt_state is device uint32[625], advanced in place exactly as the host routine advances it, so host and device
+ * draws can continue each other's stream.  src_list / dst_list (device int64, nullable) map the drawn indices to
+ * node ids as RandEdgeSampler.sample does (data_loader.py:293-294); out_* are device int64[count]. */
+int tg_rand_edge_pairs(uint32_t* mt_state, int64_t n_src, int64_t n_dst, int64_t count, const int64_t* src_list,
+                       const int64_t* dst_list, int64_t* out_src, int64_t* out_dst, void* stream);
+
 /* The same build on device for a TIME-ORDERED stream (ts non-decreasing - the caller checks; every
  * JODIE file is): a stable radix sort of the 2E (owner, entry) pairs on the owner id.  All pointers
  * are DEVICE pointers; ids must lie in [0, num_node), eids in [0, 2^31), 2E < 2^32. */

@@ -350,6 +350,57 @@ def gen_train(name, cfg):
     print(f'{name}.npz', sum(v.nbytes for v in out.values()) // 1024, 'KiB raw')
 
 
+def gen_checkpoint(name, cfg):
+    """train_self_supervised.py:208-209,110-114: `model.flush_msg(); torch.save(model.state_dict(), ...)` and,
+    in a later process, `model.load_state_dict(torch.load(...))`.  Stream `ckpt_at` batches, flush, take the
+    reference's state_dict (every key and tensor, alias keys included), load it into a FRESH reference model built
+    with other weights, and continue the stream: the outputs of the following batches are what a build that loads
+    this checkpoint must reproduce."""
+    d = cfg['d']
+    src, dst, ts, eids = make_stream(cfg['seed'], cfg['n_u'], cfg['n_i'], cfg['E'], cfg['T'])
+    E = len(src)
+    n_nodes = int(max(src.max(), dst.max())) + 1
+    rs = np.random.RandomState(cfg['seed'] + 100)
+    nfeats = rs.standard_normal((n_nodes, d)).astype(np.float32) * 0.5
+    nfeats[0] = 0
+    efeats = rs.standard_normal((E + 1, d)).astype(np.float32)
+    efeats[0] = 0
+    labels = np.zeros(E, dtype=np.int64)
+    neg = rs.randint(cfg['n_u'] + 1, n_nodes, E).astype(np.int64)
+    data = InteractionData(src, dst, ts, eids, labels, seed=0, eval=True, neg_dst=neg)
+    graph = Graph.from_data(data, strategy='recent_edges', seed=0)
+    model, pnames, pshapes = build_reference_model(cfg, nfeats, efeats, graph, E)
+    collator = GraphCollator(graph, cfg['K'], 1, restarter=cfg['restarter'], hist_len=cfg.get('H'))
+    out = {'versions': VERSIONS, 'src': src, 'dst': dst, 'ts': ts, 'eids': eids, 'neg': neg,
+           'n_nodes': np.int64(n_nodes), 'nfeats': nfeats, 'efeats': efeats,
+           'cfg': np.array([f'{k}={v}' for k, v in sorted(cfg.items())])}
+    B, at = cfg['B'], cfg['ckpt_at']
+    batch = lambda b: collator([data[i] for i in range(b * B, (b + 1) * B)])
+    with torch.no_grad():
+        for b in range(at):
+            s, dd, ng, t, ee, _, cg = batch(b)
+            model.contrast_learning(s, dd, ng, t, ee, cg)
+        model.flush_msg()
+        sd = model.state_dict()
+        out['sd_keys'] = np.array(list(sd.keys()))
+        for k, v in sd.items():
+            out['sd.' + k] = v.numpy().copy()
+        other = dict(cfg, wseed=cfg['wseed'] + 1000)
+        fresh, _, _ = build_reference_model(other, nfeats, efeats, graph, E)
+        res = fresh.load_state_dict(sd)  # strict
+        assert not res.missing_keys and not res.unexpected_keys
+        for b in range(at, at + cfg['n_after']):
+            s, dd, ng, t, ee, _, cg = batch(b)
+            loss, h_left, pos, negs, _, _ = fresh.contrast_learning(s, dd, ng, t, ee, cg)
+            out[f'b{b}_loss'] = np.float32(loss.item())
+            out[f'b{b}_h_left'] = h_left.numpy().copy()
+            out[f'b{b}_pos_scores'] = pos.numpy().copy()
+            out[f'b{b}_neg_scores'] = negs.numpy().copy()
+        snapshot(fresh, out, 'final')
+    np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)
+    print(f'{name}.npz', sum(v.nbytes for v in out.values()) // 1024, 'KiB raw', len(sd), 'state_dict keys')
+
+
 def gen_eval(name, cfg):
     """tiger/eval_utils.py: warmup + eval_edge_prediction over DataLoaders (AP / AUC per
     `mean_over_n_samples` events), in restart mode and in plain streaming mode."""
@@ -479,6 +530,13 @@ TRAIN_SCENARIOS = {
                                  hit='none', contrast_only=1, lr=1e-2, mutual_coef=1.0, grad_batches=(1, 4)),
 }
 
+CKPT_SCENARIOS = {
+    'ckpt_seq_lr_d8': dict(d=8, n_u=40, n_i=15, E=400, T=300.0, B=40, K=5, H=8, seed=51, wseed=51, restarter='seq',
+                           msg_src='left', upd_src='right', hit='bin', ckpt_at=4, n_after=3),
+    'ckpt_static_ll_d16': dict(d=16, n_u=60, n_i=25, E=500, T=500.0, B=64, K=10, seed=52, wseed=52, restarter='static',
+                               msg_src='left', upd_src='left', hit='vec', ckpt_at=3, n_after=3),
+}
+
 SCENARIOS = {
     # C1-like plumbing case: seq restarter, msg=left upd=right (CLI defaults)
     'seq_lr_d8': dict(d=8, n_u=40, n_i=15, E=600, T=300.0, B=40, n_batches=12, K=5, H=8, seed=1, wseed=1,
@@ -519,3 +577,6 @@ if __name__ == '__main__':
     for nm, cfg in EVAL_SCENARIOS.items():
         if not only or nm in only:
             gen_eval(nm, cfg)
+    for nm, cfg in CKPT_SCENARIOS.items():
+        if not only or nm in only:
+            gen_checkpoint(nm, cfg)

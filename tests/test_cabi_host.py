@@ -109,3 +109,27 @@ def test_struct_layouts_match_the_header(tmp_path):
         assert int(out[cname]) == ctypes.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert int(out[f'{cname}.{fname}']) == getattr(cls, fname).offset, f'{cname}.{fname}'
+
+
+@pytest.mark.parametrize('name', ['ckpt_seq_lr_d8', 'ckpt_static_ll_d16'])
+def test_state_dict_key_set_is_the_references(name):
+    """The FULL key set (and order, shapes, dtypes) of a state_dict written by the reference - alias keys
+    msg_memory.* / upd_memory.* and the duplicated time encoders included, mailbox and feature tables absent
+    (non-persistent) - against this package's model on CPU tensors; strict loading succeeds."""
+    import numpy as np
+    import torch
+    from _util import load, parse_cfg
+    from test_hip_parity import _model_for_checkpoint
+    z = load(name)
+    cfg = parse_cfg(z)
+    model, _, _ = _model_for_checkpoint(z, cfg, torch.device('cpu'))
+    own = model.state_dict()
+    keys = [str(k) for k in z['sd_keys']]
+    assert list(own.keys()) == keys
+    for k in keys:
+        assert tuple(own[k].shape) == z['sd.' + k].shape, k
+        assert own[k].numpy().dtype == z['sd.' + k].dtype, k
+    res = model.load_state_dict({k: torch.from_numpy(z['sd.' + k]) for k in keys}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    np.testing.assert_array_equal(model.left_memory.vals.numpy(), z['sd.left_memory.vals'])
+    assert model.msg_memory is (model.left_memory if cfg['msg_src'] == 'left' else model.right_memory)

@@ -314,15 +314,11 @@ class OraclePartitionEngine:
             rows[sel], ts[sel] = h_new[where], mts[where]
         return rows, ts
 
-    def serve(self, ids, is_msg):
+    def serve(self, e_ids, m_ids):
         m = self.orc
-        out = torch.empty(len(ids), self.d + 1)
-        r, t = self._eff(ids[~is_msg])
-        out[~is_msg] = torch.cat([r, t[:, None]], 1)
-        mi = ids[is_msg]
-        r2, t2 = (m.left_vals[mi], m.left_ts[mi]) if m.msg_src == 'left' else self._eff(mi)
-        out[is_msg] = torch.cat([r2, t2[:, None]], 1)
-        return out
+        r, t = self._eff(e_ids)
+        r2, t2 = (m.left_vals[m_ids], m.left_ts[m_ids]) if m.msg_src == 'left' else self._eff(m_ids)
+        return torch.cat([r, t[:, None]], 1), torch.cat([r2, t2[:, None]], 1)
 
     def adopt(self, eff_ids, eff_rows, msg_ids, msg_rows):
         m, d = self.orc, self.d
@@ -493,7 +489,7 @@ def test_partitioned_state_equals_single_gpu(tmp_path, name, world, B, resident)
     """The partitioned mode on the HIP engine (ranks are processes sharing the one GPU of the test box, gloo for
     the exchange) against the single-GPU fused step on the same global batches: the owners' rows."""
     from test_hip_parity import build_hip_model
-    n_steps = 6
+    n_steps = min(6, len(load(name)['src']) // (B * world))
     mp.spawn(_partitioned_gpu_worker, args=(world, free_port(), name, B, n_steps, resident, str(tmp_path)),
              nprocs=world, join=True)
     z = load(name)

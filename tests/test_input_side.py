@@ -5,6 +5,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 
 from _util import load
 
@@ -119,3 +120,63 @@ def test_optim_adam_plain_path_equals_torch_adam():
         assert torch.allclose(p, q, rtol=1e-6, atol=1e-7)
     assert a[2].grad is None and 'exp_avg' not in oa.state[a[2]]
     assert oa.state[a[1]]['step'] == 3 and oa.state[a[0]]['step'] == 6
+
+
+@pytest.mark.gpu
+def test_device_negative_stream_continues_the_datasets_random_state():
+    """tg_rand_edge_pairs: the per-event two-draw RandomState stream of RandEdgeSampler.sample(1) on the GPU
+    (data_loader.py:246-251,291-294), bit for bit - against the reference's own draws (input_side.npz), against
+    the host routine on awkward table sizes (powers of two, size 1, sizes whose mask rejects half the words),
+    across state-block boundaries, and interleaved with host draws of the same sampler."""
+    import torch
+    from www2023tiger_amd.data.data_loader import InteractionData, RandEdgeSampler
+    dev = torch.device('cuda', 0)
+    z = load('input_side')
+    for seed in (0, 7):   # the reference's training split draws negatives from ITS OWN node lists, seed = train_seed
+        eids = z[f's{seed}_train_eids'] - 1
+        tr = InteractionData(z['src'][eids], z['dst'][eids], z['ts'][eids], z[f's{seed}_train_eids'], z['labels'][eids],
+                             seed=seed, eval=False)
+        got = tr.neg_dst_sampler.sample_pairs_device(50, dev)[1].cpu().numpy()
+        np.testing.assert_array_equal(got, z[f's{seed}_train_draws'])
+    rs = np.random.RandomState(5)
+    for n_src, n_dst in ((1, 1), (1, 37), (64, 1), (64, 64), (33, 65), (1000, 3), (5, 100000), (129, 2 ** 20 + 1)):
+        a = RandEdgeSampler(np.arange(n_src) * 3 + 1, np.arange(n_dst) * 2 + 5, seed=11)
+        b = RandEdgeSampler(np.arange(n_src) * 3 + 1, np.arange(n_dst) * 2 + 5, seed=11)
+        for count in (1, 7, 300, 2048, 1):                        # 2048 pairs cross several 624-word state blocks
+            hs, hd = a.sample_pairs(count)
+            ds, dd = b.sample_pairs_device(count, dev)
+            np.testing.assert_array_equal(ds.cpu().numpy(), hs, err_msg=f'{n_src}x{n_dst} src')
+            np.testing.assert_array_equal(dd.cpu().numpy(), hd, err_msg=f'{n_src}x{n_dst} dst')
+        # host draws continue the device stream and the other way round
+        np.testing.assert_array_equal(b.sample(5)[1], a.sample(5)[1])
+        np.testing.assert_array_equal(b.sample_pairs_device(9, dev)[1].cpu().numpy(), a.sample_pairs(9)[1])
+        assert a.rng.get_state()[2] == b.rng.get_state()[2] and (a.rng.get_state()[1] == b.rng.get_state()[1]).all()
+
+
+@pytest.mark.gpu
+def test_device_resident_batches_equal_the_host_loader(tmp_path):
+    """BatchLoader over a dataset kept on the GPU (InteractionData.to_device): ids, times, labels and the
+    on-the-fly negatives of every batch equal those of the host loader; nothing but launches happens per batch."""
+    import torch
+    from www2023tiger_amd.data.data_loader import BatchLoader, GraphCollator, load_jodie_data
+    from www2023tiger_amd.data.graph import Graph
+    dev = torch.device('cuda', 0)
+    z = load('input_side')
+    write_files(str(tmp_path), 'toy', z)
+    outs = []
+    for on_device in (False, True):
+        res = load_jodie_data('toy', train_seed=3, root=str(tmp_path))
+        full, train = res[2], res[3]
+        g = Graph.from_data(train, strategy='recent_edges', seed=0, max_node_id=int(max(full.src.max(), full.dst.max())),
+                            device=dev)
+        coll = GraphCollator(g, 4, 1, restarter='static')
+        if on_device:
+            train.to_device(dev)
+        rows = []
+        for s, d, n, t, e, lab, cg in BatchLoader(train, 64, coll):
+            rows.append([x.cpu().numpy() for x in (s, d, n, t, e, lab, cg.ts64, cg.layers[1][0])])
+        outs.append(rows)
+    assert len(outs[0]) == len(outs[1]) > 3
+    for a, b in zip(*outs):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)

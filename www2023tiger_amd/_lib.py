@@ -111,6 +111,7 @@ SIGNATURES = {
     'tg_last_hip_error': (C.c_char_p, []),
     'tg_tcsr_build_host': (C.c_int, [i64, vp, vp, vp, vp, i64, vp, vp, vp, vp]),
     'tg_rand_edge_pairs_host': (C.c_int, [vp, i64, i64, i64, vp, vp]),
+    'tg_rand_edge_pairs': (C.c_int, [vp, i64, i64, i64, vp, vp, vp, vp, vp]),
     'tg_tcsr_build_device_workspace_bytes': (sz, [i64, i64]),
     'tg_tcsr_build_device': (C.c_int, [i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, sz, vp]),
     'tg_sample_recent_edges': (C.c_int, [P(TgTcsr), i64, vp, vp, i32, vp, vp, vp, vp, vp, vp]),

@@ -490,6 +490,100 @@ __global__ void __launch_bounds__(64) k_sample_uniform(tg_tcsr g, int64_t Q, con
   if (lane == 0) mt_state[624] = (uint32_t)s_pos;
 }
 
+// ---- RandEdgeSampler.sample(1) x count on device (data_loader.py:291-294): per event one
+// randint(0, n_src) then one randint(0, n_dst) of numpy's legacy RandomState - masked rejection on 32-bit
+// draws, so how many words a draw consumes depends on the words.  One wavefront; the 624 tempered words of
+// a state block are judged 64 at a time: word i would be accepted as a source draw (a_i) or as a destination
+// draw (b_i), and whether it is asked for a source or a destination is the state of a two-state automaton
+// (accepted source -> expect destination, accepted destination -> expect source, rejection -> stay).  The
+// state in front of every word is an exclusive scan over the transition maps (composition of 2-bit maps,
+// six shuffle steps), the event a word belongs to is a prefix popcount of the accept ballots.
+__device__ __forceinline__ uint32_t bitmask_of(uint32_t rng) {
+  uint32_t m = rng;
+  m |= m >> 1; m |= m >> 2; m |= m >> 4; m |= m >> 8; m |= m >> 16;
+  return m;
+}
+__device__ __forceinline__ uint32_t map_compose(uint32_t later, uint32_t earlier) {  // x -> later(earlier(x))
+  return ((later >> (earlier & 1u)) & 1u) | (((later >> ((earlier >> 1) & 1u)) & 1u) << 1);
+}
+__global__ void __launch_bounds__(64) k_rand_edge_pairs(uint32_t* mt_state, uint32_t rng_s, uint32_t rng_d, int64_t count,
+                                                        const int64_t* __restrict__ src_list,
+                                                        const int64_t* __restrict__ dst_list,
+                                                        int64_t* __restrict__ out_src, int64_t* __restrict__ out_dst) {
+  __shared__ uint32_t key[624];
+  const int lane = lane_id();
+  for (int i = lane; i < 624; i += TG_WAVE) key[i] = mt_state[i];
+  int pos = (int)mt_state[624];
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t mask_s = bitmask_of(rng_s), mask_d = bitmask_of(rng_d);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  auto emit = [&](int64_t* out, const int64_t* list, int64_t e, uint32_t v) { out[e] = list ? list[v] : (int64_t)v; };
+  if (rng_s == 0) {  // a range of one value draws nothing (numpy returns the offset without touching the state)
+    for (int64_t e = lane; e < count; e += TG_WAVE) emit(out_src, src_list, e, 0u);
+  }
+  if (rng_d == 0) {
+    for (int64_t e = lane; e < count; e += TG_WAVE) emit(out_dst, dst_list, e, 0u);
+  }
+  const bool both = rng_s != 0 && rng_d != 0;
+  int64_t done_s = 0, done_d = 0;  // accepted source / destination draws so far (wave-uniform)
+  uint32_t state = 0;              // both ranges draw: 0 = the next accepted word is a source, 1 = a destination
+  const int64_t want = (rng_s == 0 && rng_d == 0) ? 0 : count;
+  while ((rng_d != 0 ? done_d : done_s) < want) {
+    if (pos >= 624) {
+      mt_regen(key, lane);
+      pos = 0;
+    }
+    const int i = pos + lane;
+    const bool live = i < 624;
+    const uint32_t w = live ? mt_temper(key[i]) : 0u;
+    const uint32_t vs = w & mask_s, vd = w & mask_d;
+    const bool a = live && rng_s != 0 && vs <= rng_s;
+    const bool b = live && rng_d != 0 && vd <= rng_d;
+    bool is_s, is_d;
+    if (both) {
+      uint32_t m = live ? ((a ? 1u : 0u) | ((b ? 0u : 1u) << 1)) : 2u;  // bit x = next state from state x; 2 = identity
+      for (int sh = 1; sh < TG_WAVE; sh <<= 1) {  // inclusive scan of the maps
+        const uint32_t prev = __shfl_up(m, sh, TG_WAVE);
+        if (lane >= sh) m = map_compose(m, prev);
+      }
+      const uint32_t upto = __shfl_up(m, 1, TG_WAVE);
+      const uint32_t st = lane == 0 ? state : ((upto >> state) & 1u);  // the state in front of this lane's word
+      is_s = a && st == 0;
+      is_d = b && st == 1;
+      state = (__shfl(m, TG_WAVE - 1, TG_WAVE) >> state) & 1u;
+    } else {
+      is_s = a;
+      is_d = b;
+    }
+    const unsigned long long ms = __ballot(is_s), md = __ballot(is_d);
+    // the chunk ends the job at the word that completes the last event: the count-th accepted draw of the
+    // kind that closes an event (destination when it draws, else source); later words stay unconsumed
+    const unsigned long long mc = rng_d != 0 ? md : ms;
+    const int64_t had = rng_d != 0 ? done_d : done_s;
+    int used = min(TG_WAVE, 624 - pos);
+    if (had + __popcll(mc) >= want) {  // find the lane of the (want - had)-th set bit of mc
+      unsigned long long t = mc;
+      for (int64_t k = 1; k < want - had; ++k) t &= t - 1;
+      used = __ffsll(t);  // 1-based lane index = number of words consumed in this chunk
+    }
+    const unsigned long long keep = used >= 64 ? ~0ull : ((1ull << used) - 1ull);
+    if (is_s && ((keep >> lane) & 1ull)) {
+      const int64_t e = done_s + __popcll(ms & below);
+      if (e < count) emit(out_src, src_list, e, vs);
+    }
+    if (is_d && ((keep >> lane) & 1ull)) {
+      const int64_t e = done_d + __popcll(md & below);
+      if (e < count) emit(out_dst, dst_list, e, vd);
+    }
+    done_s += __popcll(ms & keep);
+    done_d += __popcll(md & keep);
+    pos += used;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < 624; i += TG_WAVE) mt_state[i] = key[i];
+  if (lane == 0) mt_state[624] = (uint32_t)pos;
+}
+
 __global__ void k_hits(int64_t n, int K, const int64_t* __restrict__ center, const int64_t* __restrict__ nbr,
                        float* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -565,6 +659,17 @@ extern "C" int tg_sample_uniform(const tg_tcsr* g, int64_t Q, const int64_t* nid
   hipLaunchKernelGGL(k_sample_uniform, dim3(1), dim3(64), 0, as_stream(stream), *g, Q, nids, ts, K, mt_state, o_nbr,
                      o_eid, o_ts, o_dir);
   return check_launch("tg_sample_uniform");
+}
+
+extern "C" int tg_rand_edge_pairs(uint32_t* mt_state, int64_t n_src, int64_t n_dst, int64_t count, const int64_t* src_list,
+                                  const int64_t* dst_list, int64_t* out_src, int64_t* out_dst, void* stream) {
+  if (!mt_state || n_src <= 0 || n_dst <= 0 || count < 0) return TG_EINVAL;
+  if (n_src > 0xFFFFFFFFll || n_dst > 0xFFFFFFFFll) return TG_EUNSUPPORTED;  // 64-bit draws: no node table is that long
+  if (count == 0) return TG_OK;
+  if (!out_src || !out_dst) return TG_EINVAL;
+  hipLaunchKernelGGL(k_rand_edge_pairs, dim3(1), dim3(64), 0, as_stream(stream), mt_state, (uint32_t)(n_src - 1),
+                     (uint32_t)(n_dst - 1), count, src_list, dst_list, out_src, out_dst);
+  return check_launch("tg_rand_edge_pairs");
 }
 
 extern "C" int tg_hits(int64_t B, int32_t K, const int64_t* center, const int64_t* nbr, float* out, void* stream) {

@@ -68,6 +68,13 @@ class GraphCollator:
         src, dst, neg, ts, eids, labels = (np.array(x) for x in zip(*batch))
         return self.collate_arrays(src, dst, neg, ts, eids, labels)
 
+    def collate_tensors(self, src, dst, neg, ts64, eids, labels=None):
+        """collate_arrays for a batch that already lives on the collator's device (int64 ids, float64 times)"""
+        cg = ComputationGraph.lazy(self, src, dst, neg, ts64)
+        cg.ts64 = ts64
+        cg.graph = self.graph if self.graph.strategy == 'recent_edges' else None
+        return src, dst, neg, ts64.float(), eids, labels, cg
+
     def collate_arrays(self, src, dst, neg, ts, eids, labels=None):
         """The batch as the reference's collate_fn returns it.  With the graph on a GPU the five id / time
         columns travel as ONE pinned, asynchronous transfer and are returned as device tensors (the loop's
@@ -101,9 +108,48 @@ class RandEdgeSampler:
 
     def __init__(self, src_list: np.ndarray, dst_list: np.ndarray, seed: Optional[int] = None):
         self.seed = seed
-        self.rng = np.random.RandomState(self.seed)
+        self._rng = np.random.RandomState(self.seed)
         self.src_list = np.unique(src_list)
         self.dst_list = np.unique(dst_list)
+        self._dev = None        # device twin: (mt state uint32[625], src_list, dst_list) once sample_pairs_device ran
+        self._dev_ahead = False  # the device copy of the generator state is ahead of the host RandomState
+
+    @property
+    def rng(self) -> np.random.RandomState:
+        """the host generator; draws made on the device are folded back into it first (one stream, two homes)"""
+        if self._dev_ahead:
+            st = self._dev[0].cpu().numpy().view(np.uint32)
+            name, _, _, has_gauss, cached = self._rng.get_state()
+            self._rng.set_state((name, st[:624].copy(), int(st[624]), has_gauss, cached))
+            self._dev_ahead = False
+        return self._rng
+
+    @rng.setter
+    def rng(self, value):
+        self._rng, self._dev_ahead = value, False
+        if self._dev is not None:
+            self._dev = (None,) + self._dev[1:]  # re-uploaded from the host state on the next device draw
+
+    def sample_pairs_device(self, count: int, device):
+        """`count` consecutive `sample(1)` calls ON THE DEVICE (tg_rand_edge_pairs): the same RandomState stream -
+        host draws and device draws continue each other - returned as device tensors (src ids, dst ids), with no
+        host work per batch beyond the launch."""
+        from .._lib import check, lib, ptr
+        device = torch.device(device)
+        if self._dev is None or self._dev[1].device != device:
+            self._dev = (None, torch.from_numpy(self.src_list.astype(np.int64)).to(device),
+                         torch.from_numpy(self.dst_list.astype(np.int64)).to(device))
+        if self._dev[0] is None or not self._dev_ahead:  # the host generator moved (or first use): upload its state
+            _, key, pos, _, _ = self._rng.get_state()
+            st = np.concatenate([key.astype(np.uint32), np.array([pos], dtype=np.uint32)])
+            self._dev = (torch.from_numpy(st.view(np.int32).copy()).to(device),) + self._dev[1:]
+        st, sl, dl = self._dev
+        out_s = torch.empty(count, dtype=torch.int64, device=device)
+        out_d = torch.empty(count, dtype=torch.int64, device=device)
+        check(lib.tg_rand_edge_pairs(ptr(st), len(self.src_list), len(self.dst_list), count, ptr(sl), ptr(dl),
+                                     ptr(out_s), ptr(out_d), hip_ops.stream_ptr(device)), 'tg_rand_edge_pairs')
+        self._dev_ahead = True
+        return out_s, out_d
 
     def sample(self, size: int):
         si = self.rng.randint(0, len(self.src_list), size)
@@ -145,6 +191,7 @@ class InteractionData(torch.utils.data.Dataset):
             raise AssertionError('all interaction arrays must have the same length')
         self.src, self.dst, self.ts, self.eids, self.labels = src, dst, ts, eids, labels
         self.eval, self.seed = eval, seed
+        self._dev = None
         self.neg_dst = None
         self.neg_dst_sampler = RandEdgeSampler(src, dst, seed)
         if self.eval:
@@ -168,6 +215,25 @@ class InteractionData(torch.utils.data.Dataset):
         sl = slice(lo, hi)
         neg = self.neg_dst[sl] if self.eval else self.neg_dst_sampler.sample_pairs(hi - lo)[1]
         return self.src[sl], self.dst[sl], neg, self.ts[sl], self.eids[sl], self.labels[sl]
+
+    def to_device(self, device):
+        """Keep the event columns resident on `device`: batches are then sliced there and the training negatives
+        are drawn there (RandEdgeSampler.sample_pairs_device), so a training loop makes no per-batch host call
+        on the input side (data_loader.py:246-251,291-294 without the per-event Python)."""
+        device = torch.device(device)
+        i64 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(device)
+        self._dev = dict(device=device, src=i64(self.src), dst=i64(self.dst), eids=i64(self.eids), labels=i64(self.labels),
+                         ts=torch.from_numpy(np.ascontiguousarray(self.ts, dtype=np.float64)).to(device),
+                         neg=i64(self.neg_dst) if self.neg_dst is not None else None)
+        return self
+
+    def get_batch_device(self, lo: int, hi: int):
+        """events [lo, hi) as device tensors (src, dst, neg, ts float64, eids, labels); negatives exactly those of
+        `hi - lo` consecutive __getitem__ calls"""
+        c = self._dev
+        sl = slice(lo, hi)
+        neg = c['neg'][sl] if self.eval else self.neg_dst_sampler.sample_pairs_device(hi - lo, c['device'])[1]
+        return c['src'][sl], c['dst'][sl], neg, c['ts'][sl], c['eids'][sl], c['labels'][sl]
 
     def __len__(self):
         return len(self.ts)
@@ -197,8 +263,13 @@ class BatchLoader:
 
     def __iter__(self):
         lo, hi = self._range()
+        on_device = getattr(self.dataset, '_dev', None) is not None
         for a in range(lo, hi, self.batch_size):
-            yield self.collate_fn.collate_arrays(*self.dataset.get_batch(a, min(a + self.batch_size, hi)))
+            b = min(a + self.batch_size, hi)
+            if on_device:  # columns resident on the GPU, negatives drawn there: nothing crosses the bus
+                yield self.collate_fn.collate_tensors(*self.dataset.get_batch_device(a, b))
+            else:
+                yield self.collate_fn.collate_arrays(*self.dataset.get_batch(a, b))
 
 
 class ChunkSampler(torch.utils.data.Sampler):

@@ -345,8 +345,9 @@ def exchange_counts(counts: torch.Tensor, group=None) -> torch.Tensor:
 
 class StepPlan:
     """Everything about one global batch that does not depend on node state (see PartitionedRunner.plan)."""
-    __slots__ = ('n', 'Bg', 'local', 'glob', 'serve_ids', 'serve_is_msg', 'serve_in', 'serve_out', 'req_eff',
-                 'req_msg', 'reply_is_msg', 'push_rows', 'push_in', 'push_out', 'left_row', 'mine', 'stats')
+    __slots__ = ('n', 'Bg', 'local', 'glob', 'serve_eff', 'serve_msg', 'serve_eff_pos', 'serve_msg_pos', 'serve_in',
+                 'serve_out', 'req_eff', 'req_msg', 'reply_eff_pos', 'reply_msg_pos', 'push_rows', 'push_in', 'push_out',
+                 'left_row', 'mine', 'stats')
 
 
 class PartitionedRunner:
@@ -401,11 +402,15 @@ class PartitionedRunner:
         send_ids = torch.cat([torch.cat([eff_s[eo[q]:eo[q + 1]], msg_s[mo[q]:mo[q + 1]]]) for q in range(world)])
         p.serve_out = cnt.sum(1).tolist()   # rows I receive from each peer when the pull runs
         p.serve_in = got.sum(1).tolist()    # rows I serve to each peer
-        p.serve_ids = all_to_all_rows(send_ids, p.serve_out, p.serve_in, self.group)
-        kinds = lambda c: torch.cat([torch.cat([torch.zeros(int(a), dtype=torch.bool), torch.ones(int(b), dtype=torch.bool)])
-                                     for a, b in c.tolist()]).to(dev)
-        p.serve_is_msg = kinds(got)   # per requester: [eff ids | msg ids]
-        p.reply_is_msg = kinds(cnt)   # the reply of peer q to me has the same shape as my request to q
+        serve_ids = all_to_all_rows(send_ids, p.serve_out, p.serve_in, self.group)
+
+        def kinds(c):  # positions of the eff / msg entries in a buffer laid out per peer as [eff | msg]
+            m = torch.cat([torch.cat([torch.zeros(int(a), dtype=torch.bool), torch.ones(int(b), dtype=torch.bool)])
+                           for a, b in c.tolist()])
+            return torch.nonzero(~m).flatten().to(dev), torch.nonzero(m).flatten().to(dev)
+        p.serve_eff_pos, p.serve_msg_pos = kinds(got)   # what I serve: per requester [eff ids | msg ids]
+        p.serve_eff, p.serve_msg = serve_ids[p.serve_eff_pos].contiguous(), serve_ids[p.serve_msg_pos].contiguous()
+        p.reply_eff_pos, p.reply_msg_pos = kinds(cnt)   # the reply of peer q to me has the shape of my request to q
         # ---- what this rank must push: h(t-) of winning positions of its events whose node lives elsewhere
         slot = torch.full((Bg,), -1, dtype=torch.int64, device=dev)
         slot[li] = torch.arange(n, device=dev)
@@ -435,10 +440,11 @@ class PartitionedRunner:
         """Collective.  The state-dependent part of a global batch: pull, embed, push, owner write-back, eager updater.
         Returns this rank's embeddings [3 n, d] (rows [0, 2n) are h(t-) of cat[src, dst] of its events)."""
         E = self.engine
-        served = E.serve(p.serve_ids, p.serve_is_msg)                                        # [*, d + 1]: row | time
+        eff_rows, msg_rows = E.serve(p.serve_eff, p.serve_msg)                               # [*, d + 1]: row | time
+        served = torch.empty(p.serve_eff.numel() + p.serve_msg.numel(), E.d + 1, dtype=torch.float32, device=self.dev)
+        served[p.serve_eff_pos], served[p.serve_msg_pos] = eff_rows, msg_rows
         got = all_to_all_rows(served, p.serve_in, p.serve_out, self.group)                   # PULL
-        is_msg = p.reply_is_msg
-        E.adopt(p.req_eff, got[~is_msg], p.req_msg, got[is_msg])
+        E.adopt(p.req_eff, got[p.reply_eff_pos], p.req_msg, got[p.reply_msg_pos])
         h = E.embed(*p.local) if p.n else torch.zeros(0, E.d, dtype=torch.float32, device=self.dev)
         recv = all_to_all_rows(h[p.push_rows], p.push_in, p.push_out, self.group)            # PUSH
         rows = torch.cat([h[:2 * p.n], recv]) if recv.numel() or p.n else torch.zeros(1, E.d, device=self.dev)
@@ -489,28 +495,26 @@ class HipPartitionEngine:
             self.buf.io.collate_only = 0
         return self.buf.involved[:int(self.buf.counts[0].item())].clone()
 
-    def serve(self, ids, is_msg):
-        m, lib, ptr = self.model, self.lib, self.ptr
-        out = torch.empty(ids.numel(), self.d + 1, dtype=torch.float32, device=self.device)
-        if ids.numel() == 0:
-            return out
+    def serve(self, e_ids, m_ids):
+        """(effective right-memory rows of e_ids, message-source memory rows of m_ids), each [*, d + 1]: row | time"""
+        m, lib, ptr, d = self.model, self.lib, self.ptr, self.d
         ms = m.model_struct()
-        e_ids, m_ids = ids[~is_msg].contiguous(), ids[is_msg].contiguous()
-        rows = torch.empty(e_ids.numel(), self.d, dtype=torch.float32, device=self.device)
-        ts = torch.empty(e_ids.numel(), dtype=torch.float32, device=self.device)
-        self.check(lib.tg_gather_eff_rows(C.byref(ms), e_ids.numel(), ptr(e_ids), ptr(rows), ptr(ts),
-                                          self.hip_ops.stream_ptr(self.device)), 'tg_gather_eff_rows')
-        out[~is_msg] = torch.cat([rows, ts[:, None]], 1)
-        if m_ids.numel():
-            if m.msg_src == 'left':
-                r2, t2 = self.hip_ops.gather_rows(m.left_memory.vals, m_ids, m.left_memory.update_ts)
-            else:  # the right memory as STEP 4 leaves it
-                r2 = torch.empty(m_ids.numel(), self.d, dtype=torch.float32, device=self.device)
-                t2 = torch.empty(m_ids.numel(), dtype=torch.float32, device=self.device)
-                self.check(lib.tg_gather_eff_rows(C.byref(ms), m_ids.numel(), ptr(m_ids), ptr(r2), ptr(t2),
+
+        def eff(ids):
+            out = torch.empty(ids.numel(), d + 1, dtype=torch.float32, device=self.device)
+            if ids.numel():
+                rows = torch.empty(ids.numel(), d, dtype=torch.float32, device=self.device)
+                ts = torch.empty(ids.numel(), dtype=torch.float32, device=self.device)
+                self.check(lib.tg_gather_eff_rows(C.byref(ms), ids.numel(), ptr(ids), ptr(rows), ptr(ts),
                                                   self.hip_ops.stream_ptr(self.device)), 'tg_gather_eff_rows')
-            out[is_msg] = torch.cat([r2, t2[:, None]], 1)
-        return out
+                out[:, :d], out[:, d] = rows, ts
+            return out
+        if m.msg_src == 'left' and m_ids.numel():
+            r2, t2 = self.hip_ops.gather_rows(m.left_memory.vals, m_ids, m.left_memory.update_ts)
+            msg = torch.cat([r2, t2[:, None]], 1)
+        else:  # msg_src == right: the right memory as STEP 4 leaves it
+            msg = eff(m_ids)
+        return eff(e_ids), msg
 
     def adopt(self, eff_ids, eff_rows, msg_ids, msg_rows):
         """pulled rows overwrite this rank's stale copies (rows of nodes it does not own: never authoritative here)"""
