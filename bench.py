@@ -337,6 +337,9 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     work = stage_work(cfg, U, O_, P, eager, fused, stream['n_nodes'], E)
     traffic = load_traffic(traffic_tag)
     empty = {'zero_flags', 'dedup_positive', 'restarter_targets', 'apply_messages(gru)' if eager else 'eager_updater(gru)'}
+    direct = eager and os.environ.get('TG_EAGER_DIRECT', '1') != '0'  # no compact copy of the involved rows
+    if direct:
+        empty.add('gather_right_memory')
     if fused:
         empty |= {'attn_gemm_g', 'attn_gemm_v', 'attn_gemm_out'}
     overhead = float(np.median([v for n, v in zip(names, stage_ms) if n in empty]))  # cost of an empty event pair
@@ -347,7 +350,7 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
                            upd_src=cfg['upd_src'], n_nodes=stream['n_nodes'], events=E, mode='stream (no_grad) STEP 1-6',
                            launch='hipGraph replay' if graph is not None else 'eager',
                            attention_weights='pre-multiplied (tg_attn_fuse)' if fused else 'as stored',
-                           updater='eager: once per stored message (TIGE.eager_updates)' if eager else
+                           updater=('eager: once per stored message (TIGE.eager_updates)' + (', rows read from the tables directly' if eager and os.environ.get('TG_EAGER_DIRECT', '1') != '0' else ', compact reprs copy')) if eager else
                                    'lazy: on the fly for every involved node with a pending message',
                            state_preroll_batches=preroll, involved_per_batch=float(U), outdated_per_batch=float(O_),
                            unique_pos_per_batch=float(P)),
@@ -356,11 +359,18 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     if restart_prob > 0:
         out['config'].update(restart_prob=restart_prob, restart_triggers_in_timed_region=n_trig,
                              restarter='static, re-initialisation inside the step (tg_lazy_restart)')
-    # the memory-gather kernel: STEP 1-2's gather of the involved nodes' rows (tiger.py:214-221), HBM-bound;
-    # next to it SURVEY s8(d)'s full bytes_gather (mailbox + updater-source rows included) over the kernels that
-    # move those bytes (the gather and the updater launch), and the updater launch on both rooflines
-    g_name, u_name = 'gather_right_memory', 'eager_updater(gru)' if eager else 'apply_messages(gru)'
+    # the memory-gather kernel: the launch that gathers the involved nodes' memory rows (STEP 1-2, tiger.py:214-221),
+    # HBM-bound.  Eager updates, direct form: there is no separate copy - the attention core gathers the rows from
+    # pending / right itself (U unique rows compulsory, + its G in / S out streams).  Otherwise: the gather into reprs.
+    # Next to it SURVEY s8(d)'s full bytes_gather (mailbox + updater-source rows included) over the launches that move
+    # those bytes (the gather and the updater launch), and the updater launch on both rooflines
+    g_name, u_name = 'attn_core(gather+softmax)' if direct else 'gather_right_memory', \
+        'eager_updater(gru)' if eager else 'apply_messages(gru)'
     mg = roofline_of(g_name, stages[g_name], work, traffic)
+    if direct:
+        mg['note'] = ('eager updates, direct form: STEP 1-2 leave no gather launch; the involved rows are gathered once, by the '
+                      'attention core, from pending / right by node id (algorithmic bytes = U unique rows + the per-centre '
+                      'G / S streams + feature rows)')
     mw = 4 * d
     not_right = 0 if cfg['upd_src'] == 'right' else 1
     survey_bytes = U * 4 * d + O_ * (4 * mw + 4) + O_ * (4 * d + 4) * not_right + U * 4 * d

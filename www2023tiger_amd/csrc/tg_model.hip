@@ -63,6 +63,49 @@ __global__ void __launch_bounds__(256) k_attn_centres(int64_t Q, int d4, const i
   }
 }
 
+// Eager updates, direct form: the centre row is read from the state tables themselves,
+//   c_i = (has_msg[v] ? pending[v] : right[v]) + nfeat[v],   v = nid_i
+// (what reprs[local(v)] holds after STEP 1-2, tiger.py:214-221), so no compact copy of the involved rows is made.
+// The launch also carries what rode on the gather launch: the time invariants of compute_messages over the outdated
+// list (message_modules.py:158-159, tiger.py:325-327) and the first dedup pass.
+struct DirectArgs {
+  const int64_t* outdated;
+  const int32_t* n_outdated;
+  int64_t cap;
+  uint32_t* err;
+};
+__global__ void __launch_bounds__(256) k_attn_centres_direct(tg_model m, int64_t Q, const int64_t* __restrict__ nids,
+                                                             const float4* __restrict__ nf, float4* __restrict__ out,
+                                                             DirectArgs da, PosArgs pos) {
+  const int d4 = m.d / 4;
+  const float4* right = reinterpret_cast<const float4*>(m.right_vals);
+  const float4* pend = reinterpret_cast<const float4*>(m.pending_vals);
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+  const int64_t total = Q * d4;
+  for (int64_t t = tid; t < total; t += nth) {
+    const int64_t i = t / d4;
+    const int c = (int)(t - i * d4);
+    const int64_t id = nids[i];
+    float4 v = (bm_test(m.has_msg, id) ? pend : right)[id * d4 + c];
+    if (nf) {
+      const float4 f = nf[id * d4 + c];
+      v.x += f.x; v.y += f.y; v.z += f.z; v.w += f.w;
+    }
+    out[t] = v;
+  }
+  if (da.outdated) {
+    const int64_t no = min((int64_t)*da.n_outdated, da.cap);
+    const float* mem_ts = (m.msg_src == TG_SRC_LEFT) ? m.left_ts : m.right_ts;
+    for (int64_t i = tid; i < no; i += nth) {
+      const int64_t id = da.outdated[i];
+      const float mts = m.msg_ts[id], last = mem_ts[id];
+      if (last > mts) atomicOr(da.err, TG_ERR_MSG_BEFORE_MEM);
+      if (m.msg_src == TG_SRC_LEFT && !(mts == last)) atomicOr(da.err, TG_ERR_MSG_TS_MISMATCH);
+    }
+  }
+  if (pos.best) pos_max_pass(pos, tid, nth);
+}
+
 // explicit fma: the library is built with -ffp-contract=off (only the time encoding needs the
 // unfused product), so contractions are spelled out where they are wanted
 __device__ __forceinline__ float dot4(float4 a, float4 b, float acc) {
@@ -137,9 +180,12 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
                                                    const float* __restrict__ reprs, const uint64_t* __restrict__ bm,
                                                    const uint32_t* __restrict__ rank, const float* __restrict__ G,
                                                    float* __restrict__ S, uint8_t* __restrict__ valid, DropCfg dc,
-                                                   float* __restrict__ rsum) {
+                                                   float* __restrict__ rsum, int direct, PosArgs pos) {
   using V = RowVec<W>;
   const int lane = lane_id();
+  // direct (eager updates): neighbour rows come from the state tables, row(v) = has_msg[v] ? pending[v] : right[v];
+  // the second dedup pass of the step rides here (a few thousand threads of work)
+  if (pos.best) pos_winners_pass(pos, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
   const uint64_t dkey = drop_key(dc);
   const int d = m.d, de = m.d_e, K = m.n_neighbors;
   const int kvw = 2 * d + de;
@@ -159,7 +205,7 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
       nb_l = l1_nids[i * K + lane];
       eid_l = l1_eids[i * K + lane];
       dt_l = ts[i] - l1_ts[i * K + lane];
-      if (nb_l != 0) u_l = (int)bm_rank(bm, rank, nb_l);
+      if (nb_l != 0) u_l = direct ? (int)(2 * nb_l + (bm_test(m.has_msg, nb_l) ? 1 : 0)) : (int)bm_rank(bm, rank, nb_l);
     }
     unsigned long long live = __ballot(nb_l != 0);  // padding keys are masked (temporal_agg_modules.py:80)
     const bool any = live != 0ull;
@@ -191,10 +237,11 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
       const int64_t u = __shfl(u_l, k, TG_WAVE);
       const int64_t nb = __shfl(nb_l, k, TG_WAVE);
       const int64_t eid = __shfl(eid_l, k, TG_WAVE);
+      const float* nrow = direct ? ((u & 1) ? m.pending_vals : m.right_vals) + (u >> 1) * d : reprs + u * d;
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const int c = (lane + v * TG_WAVE) * W;
-        ya[slot][v] = row_load<W>(reprs + u * d, c, d);
+        ya[slot][v] = row_load<W>(nrow, c, d);
         yn[slot][v] = row_load<W>(m.nfeats ? m.nfeats + nb * d : reprs, c, m.nfeats ? d : 0);
         yb[slot][v] = row_load<W>(m.efeats ? m.efeats + eid * de : reprs, c, m.efeats ? de : 0);
       }
@@ -354,7 +401,7 @@ static FusedView fused_view(const tg_model* m, const float* f) {
 
 void launch_attn_core(const tg_model* m, int64_t Q, const float* ts, const int64_t* l1_nids, const int64_t* l1_eids,
                       const float* l1_ts, const float* reprs, const uint64_t* bm, const uint32_t* rank, const AttnWs& w,
-                      const DropCfg& dc, hipStream_t st, int* rc_out) {
+                      const DropCfg& dc, hipStream_t st, int* rc_out, int direct = 0, const PosArgs* pos = nullptr) {
   const int d = m->d, d_e = m->d_e, nh = m->n_head;
   *rc_out = TG_OK;
   // Columns per lane: float4.  Three columns per lane fill 58 of 64 lanes at d = 172 instead of 43 and cut
@@ -371,7 +418,7 @@ void launch_attn_core(const tg_model* m, int64_t Q, const float* ts, const int64
 #define TG_CORE(NH_, NV_, W_)                                                                                      \
   hipLaunchKernelGGL((k_attn_core<NH_, NV_, W_>), dim3(cgrid), dim3(256), 0, st, *m, Q, ts, l1_nids, l1_eids,      \
                      l1_ts, reprs, bm, rank, (const float*)w.g, w.s, w.valid, dc,                                  \
-                     dc.p > 0.f ? w.rsum : (float*)nullptr)
+                     dc.p > 0.f ? w.rsum : (float*)nullptr, direct, pos ? *pos : PosArgs{})
   if (nh == 2 && nv == 1 && W == 3) TG_CORE(2, 1, 3);
   else if (nh == 1 && nv == 1 && W == 3) TG_CORE(1, 1, 3);
   else if (nh == 4 && nv == 1 && W == 3) TG_CORE(4, 1, 3);
@@ -383,18 +430,28 @@ void launch_attn_core(const tg_model* m, int64_t Q, const float* ts, const int64
 #undef TG_CORE
 }
 
+static void launch_centres(const tg_model* m, int64_t Q, const int64_t* nids, const float* reprs, const uint64_t* bm,
+                           const uint32_t* rank, const AttnWs& w, const PosArgs* pos, const DirectArgs* da, hipStream_t st) {
+  const int d = m->d;
+  if (da)  // rows from the state tables; checks + first dedup pass ride along (the second one rides on the core)
+    hipLaunchKernelGGL(k_attn_centres_direct, dim3(flat_grid(Q * (d / 4), 256)), dim3(256), 0, st, *m, Q, nids,
+                       (const float4*)m->nfeats, (float4*)w.cc, *da, pos ? *pos : PosArgs{});
+  else
+    hipLaunchKernelGGL(k_attn_centres, dim3(flat_grid(Q * (d / 4), 256)), dim3(256), 0, st, Q, d / 4, nids,
+                       (const float4*)reprs, bm, rank, (const float4*)m->nfeats, (float4*)w.cc, 0, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr,
+                       pos ? *pos : PosArgs{});
+}
+
 static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids, const float* ts,
                               const int64_t* l1_nids, const int64_t* l1_eids, const float* l1_ts, const float* reprs,
                               const uint64_t* bm, const uint32_t* rank, float* out, const AttnWs& w, hipStream_t st,
-                              tg_profiler* pf, const PosArgs* pos) {
+                              tg_profiler* pf, const PosArgs* pos, const DirectArgs* da) {
   // stage numbering of the profiler is kept: q -> "merged q+g", g -> skipped, v/out -> skipped, fc1 -> fused
   int stage = ST_ATTN_FIRST + 1;
   const int d = m->d;
   const FusedView f = fused_view(m, m->attn_fused);
-  hipLaunchKernelGGL(k_attn_centres, dim3(flat_grid(Q * (d / 4), 256)), dim3(256), 0, st, Q, d / 4, nids,
-                     (const float4*)reprs, bm, rank, (const float4*)m->nfeats, (float4*)w.cc, 0, (const float*)nullptr,
-                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr,
-                     pos ? *pos : PosArgs{});
+  launch_centres(m, Q, nids, reprs, bm, rank, w, pos, da, st);
   int rc;
   GemmArgs g{};
   // G = c Wqk^T + gconst   (scaled query folded through the key projection, all heads at once)
@@ -404,7 +461,7 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
   if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
   prof_mark(pf, stage++, st);
   prof_mark(pf, stage++, st);
-  launch_attn_core(m, Q, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, w, DropCfg{}, st, &rc);
+  launch_attn_core(m, Q, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, w, DropCfg{}, st, &rc, da ? 1 : 0, da ? pos : nullptr);
   if (rc != TG_OK) return rc;
   prof_mark(pf, stage++, st);
   prof_mark(pf, stage++, st);
@@ -437,17 +494,24 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
 int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float* ts, const int64_t* l1_nids,
                  const int64_t* l1_eids, const float* l1_ts, const float* reprs, const uint64_t* bm,
                  const uint32_t* rank, float* out, const AttnWs& w, hipStream_t st, tg_profiler* pf = nullptr,
-                 const DropCfg* drop = nullptr, const PosArgs* pos = nullptr) {
+                 const DropCfg* drop = nullptr, const PosArgs* pos = nullptr, const DirectArgs* da = nullptr) {
   const DropCfg dc = drop ? *drop : DropCfg{};
   int stage = ST_ATTN_FIRST;
   prof_mark(pf, stage++, st);
   const int d = m->d, d_e = m->d_e, kvw = 2 * d + d_e, nh = m->n_head, dh = 2 * d / nh, E = 2 * d;
   if (m->attn_fused && dc.p == 0.f)
-    return attn_forward_fused(m, Q, nids, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, out, w, st, pf, pos);
+    return attn_forward_fused(m, Q, nids, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, out, w, st, pf, pos, da);
   const int qblocks = (int)cdiv(2 * d, 4);
-  hipLaunchKernelGGL(k_attn_centres, dim3(flat_grid(Q * (d / 4), 256) + qblocks), dim3(256), 0, st, Q, d / 4, nids,
-                     (const float4*)reprs, bm, rank, (const float4*)m->nfeats, (float4*)w.cc, qblocks, m->attn_wq,
-                     m->attn_b_in, m->te_freq, m->te_phase, w.qconst, pos ? *pos : PosArgs{});
+  if (da) {  // the constant half of the query projection from the rank-form kernel (no centre rows), then the direct centres
+    hipLaunchKernelGGL(k_attn_centres, dim3(1 + qblocks), dim3(256), 0, st, (int64_t)0, d / 4, nids, (const float4*)reprs, bm,
+                       rank, (const float4*)m->nfeats, (float4*)w.cc, qblocks, m->attn_wq, m->attn_b_in, m->te_freq,
+                       m->te_phase, w.qconst, PosArgs{});
+    launch_centres(m, Q, nids, reprs, bm, rank, w, pos, da, st);
+  } else {
+    hipLaunchKernelGGL(k_attn_centres, dim3(flat_grid(Q * (d / 4), 256) + qblocks), dim3(256), 0, st, Q, d / 4, nids,
+                       (const float4*)reprs, bm, rank, (const float4*)m->nfeats, (float4*)w.cc, qblocks, m->attn_wq,
+                       m->attn_b_in, m->te_freq, m->te_phase, w.qconst, pos ? *pos : PosArgs{});
+  }
   int rc;
   GemmArgs g{};
   // q = (Wq [c | TE(0)] + bq) / sqrt(dh)          (F.multi_head_attention_forward scaling)
@@ -468,7 +532,7 @@ int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float*
   if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
   // gather + scores + softmax + weighted raw sum
   prof_mark(pf, stage++, st);
-  launch_attn_core(m, Q, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, w, dc, st, &rc);
+  launch_attn_core(m, Q, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, w, dc, st, &rc, da ? 1 : 0, da ? pos : nullptr);
   if (rc != TG_OK) return rc;
   // o_h = Wv_h s_h + bv_h
   prof_mark(pf, stage++, st);
@@ -840,8 +904,14 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   const PosArgs* pp = io->embed_only ? nullptr : &pos;
   w.dedup_done = pp != nullptr;
   // ---- STEP 1-2: reprs = right_memory[involved] (+ invariants); outdated rows <- updater(...)
-  if ((rc = consume_gather_check_launch(m, w.inv, w.counts + 0, cap, w.reprs, w.outdated, w.counts + 1, io->err, st,
-                                        pp, eager)) != TG_OK)
+  // eager updates, direct form (default; TG_EAGER_DIRECT=0 keeps the compact copy): centres and neighbour rows are read
+  // from pending / right themselves, so there is no gather launch and no reprs buffer
+  static const int direct_knob = getenv("TG_EAGER_DIRECT") ? atoi(getenv("TG_EAGER_DIRECT")) : 1;
+  w.direct = eager && direct_knob != 0;
+  const DirectArgs da{w.outdated, w.counts + 1, cap, io->err};
+  if (!w.direct &&
+      (rc = consume_gather_check_launch(m, w.inv, w.counts + 0, cap, w.reprs, w.outdated, w.counts + 1, io->err, st, pp,
+                                        eager)) != TG_OK)
     return rc;
   prof_mark(pf, ST_UPDATE, st);
   if (!eager &&  // eager: the rows were gathered from the table of precomputed updater rows just now
@@ -850,14 +920,18 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
     return rc;
   // ---- STEP 3: temporal embeddings of cat[src, dst, neg]
   if ((rc = attn_forward(m, Q, w.nids3, w.ts3f, w.l1n, w.l1e, w.l1t, w.reprs, w.bm, w.rank, io->h, w.attn, st, pf,
-                         drop, pp)) != TG_OK)
+                         drop, pp, w.direct ? &da : nullptr)) != TG_OK)
     return rc;
   prof_mark(pf, ST_DEDUP, st);
-  if (io->h_new) {  // h(t'+) rows of cat[src, dst]: reprs[local(node)]
-    hipLaunchKernelGGL(k_attn_centres, dim3(flat_grid(2 * B * (m->d / 4), 256)), dim3(256), 0, st, 2 * B, m->d / 4,
-                       w.nids3, (const float4*)w.reprs, w.bm, w.rank, (const float4*)nullptr, (float4*)io->h_new, 0,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       (float*)nullptr, PosArgs{});
+  if (io->h_new) {  // h(t'+) rows of cat[src, dst]: reprs[local(node)], or the table rows themselves
+    if (w.direct)
+      hipLaunchKernelGGL(k_attn_centres_direct, dim3(flat_grid(2 * B * (m->d / 4), 256)), dim3(256), 0, st, *m, 2 * B,
+                         w.nids3, (const float4*)nullptr, (float4*)io->h_new, DirectArgs{}, PosArgs{});
+    else
+      hipLaunchKernelGGL(k_attn_centres, dim3(flat_grid(2 * B * (m->d / 4), 256)), dim3(256), 0, st, 2 * B, m->d / 4,
+                         w.nids3, (const float4*)w.reprs, w.bm, w.rank, (const float4*)nullptr, (float4*)io->h_new, 0,
+                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                         (float*)nullptr, PosArgs{});
   }
   return check_launch("tg_stream_step(forward)");
 }
@@ -877,6 +951,7 @@ static WritebackArgs writeback_args(const tg_model* m, const tg_step_io* io, Ste
   wa.clean_flags = w.flags; wa.flag_bytes = (int64_t)((m->n_nodes + 63) / 64) * 64; wa.clean_best = w.best;
   wa.clean_counts = w.counts;
   wa.lazy_batch = (io->lazy && io->lazy->batch_dev) ? io->lazy->batch_dev : nullptr;
+  wa.new_from_pending = w.direct ? 1 : 0;  // no reprs copy was made: STEP 4 reads the owner table of updater rows
   return wa;
 }
 

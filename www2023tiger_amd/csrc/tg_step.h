@@ -61,6 +61,7 @@ struct StepWs {
   float* l1t;
   bool dedup_done;  // the positive-node dedup already ran inside the forward launches
   bool eager;       // STEP 1-2 gathered precomputed updater rows; the updater runs at the end of the step instead
+  bool direct;      // ... and no compact copy of the involved rows was made (centres / neighbours read the tables)
 };
 
 bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w);
