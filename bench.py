@@ -338,8 +338,10 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     traffic = load_traffic(traffic_tag)
     empty = {'zero_flags', 'dedup_positive', 'restarter_targets', 'apply_messages(gru)' if eager else 'eager_updater(gru)'}
     direct = eager and os.environ.get('TG_EAGER_DIRECT', '1') != '0'  # no compact copy of the involved rows
-    if direct:
-        empty.add('gather_right_memory')
+    if direct:  # ... and STEP 4-6 are one launch (reported under writeback_phase1)
+        empty |= {'gather_right_memory', 'writeback_phase0'}
+        w0, w1 = work['writeback_phase0'], work['writeback_phase1']
+        work['writeback_phase1'] = (None, w0[1] + w1[1], 'tg::k_writeback_fused')
     if fused:
         empty |= {'attn_gemm_g', 'attn_gemm_v', 'attn_gemm_out'}
     overhead = float(np.median([v for n, v in zip(names, stage_ms) if n in empty]))  # cost of an empty event pair

@@ -289,7 +289,12 @@ struct WritebackArgs {
   const int32_t* owner;
   int32_t my_rank;
   int32_t new_from_pending;
+  // one-launch write-back (phase 2): STEP 5 reads these pre-batch copies instead of the tables STEP 6 overwrites:
+  // snap[i] = message-source memory row (+ node features) of position i of cat[src, dst], snap_ts[i] its time
+  const float* snap;
+  const float* snap_ts;
 };
+// phase 0 / 1: the two launches of tg_memory.hip's hazard analysis; phase 2: STEP 4-6 in one launch (needs a.snap)
 int writeback_launch(const tg_model* m, const WritebackArgs& a, int phase, hipStream_t st);
 
 }  // namespace tg

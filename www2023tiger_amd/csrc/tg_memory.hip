@@ -316,6 +316,72 @@ __global__ void __launch_bounds__(256) k_writeback(tg_model m, WritebackArgs a) 
   }
 }
 
+// ---- STEP 4-6 in ONE launch (eager updates, direct form).  The hazard that forces two launches above is STEP 5 reading
+// message-memory rows that STEP 4 / STEP 6 of other wavefronts write.  Every row STEP 5 reads belongs to a positive node
+// of the batch, so the launch that reads the centres takes a copy of exactly those 2B rows (a.snap: row + node
+// features, a.snap_ts) before anything is written, and STEP 5 builds the message from the copy:
+//   mailbox[own] = [snap[own pos] | snap[other pos] | efeat | TE(t - snap_ts[own pos])]
+// (msg_src = right: the copy is the right memory as STEP 4 leaves it, pending-or-right, as the reference reads it).
+__global__ void __launch_bounds__(256) k_writeback_fused(tg_model m, WritebackArgs a) {
+  const int lane = lane_id();
+  const int64_t B = a.B;
+  const int64_t n = min((int64_t)*a.n_upos, 2 * B);
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (int64_t)gridDim.x * 4;
+  for (int64_t i = wave0 * TG_WAVE + lane; i < 2 * B; i += nwave * TG_WAVE) {  // tiger.py:437-438 over all 2B positions
+    const int64_t e = i < B ? i : i - B;
+    if (a.snap_ts[i] > a.ts[e]) atomicOr(a.err, TG_ERR_EVENT_BEFORE_MEM);
+  }
+  const int d4 = m.d / 4, e4 = m.d_e / 4;
+  const int row4 = 3 * d4 + e4;
+  const float4* snap = reinterpret_cast<const float4*>(a.snap);
+  const float4* ef = reinterpret_cast<const float4*>(m.efeats);
+  const float4* fq = reinterpret_cast<const float4*>(m.te_freq);
+  const float4* ph = reinterpret_cast<const float4*>(m.te_phase);
+  float4* box = reinterpret_cast<float4*>(m.msg_vals);
+  for (int64_t p = wave0; p < n; p += nwave) {
+    const int64_t id = a.upos[p], idx = a.index[p];
+    wb_step4(m, id, id, reinterpret_cast<const float4*>(m.pending_vals), a.err, lane);  // STEP 4: right <- pending
+    const int64_t e = idx < B ? idx : idx - B;
+    const int64_t other_pos = idx < B ? B + e : e;
+    const float t = a.ts[e];
+    const float dt = t - a.snap_ts[idx];
+    const int64_t eid = a.eids[e];
+    for (int c = lane; c < row4; c += TG_WAVE) {  // STEP 5
+      float4 v;
+      if (c < d4) v = snap[idx * d4 + c];
+      else if (c < 2 * d4) v = snap[other_pos * d4 + (c - d4)];
+      else if (c < 2 * d4 + e4) v = ef ? ef[eid * e4 + (c - 2 * d4)] : make_float4(0.f, 0.f, 0.f, 0.f);
+      else {
+        const int cc = c - 2 * d4 - e4;
+        const float4 w = fq[cc], q = ph[cc];
+        v = make_float4(time_enc(dt, w.x, q.x), time_enc(dt, w.y, q.y), time_enc(dt, w.z, q.z), time_enc(dt, w.w, q.w));
+      }
+      box[id * row4 + c] = v;
+    }
+    if (lane == 0) {
+      const uint64_t bit = 1ull << (id & 63);
+      const unsigned long long old = atomicOr((unsigned long long*)(m.has_msg + (id >> 6)), bit);
+      if (old & bit) atomicOr(a.err, TG_ERR_UNUSED_MESSAGE);
+      m.msg_ts[id] = t;
+    }
+    wb_step6(m, id, idx, idx, reinterpret_cast<const float4*>(a.h), a.ts, a.err, lane);  // STEP 6: left <- h(t-)
+  }
+  if (a.clean_flags) {  // leave the step workspace zeroed for the next step
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+    uint4* f = reinterpret_cast<uint4*>(a.clean_flags);
+    for (int64_t i = tid; i < a.flag_bytes / 16; i += nth) f[i] = make_uint4(0u, 0u, 0u, 0u);
+    const int64_t nb = a.clean_counts[0];
+    for (int64_t i = tid; i < nb; i += nth) a.clean_best[i] = 0ull;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (a.counts_dst)
+      for (int i = 0; i < 4; ++i) a.counts_dst[i] = a.counts_src[i];
+    if (a.clean_counts) a.clean_counts[3] = a.clean_counts[4] = 0;
+    if (a.offset_dev) *a.offset_dev += B;
+    if (a.lazy_batch) *a.lazy_batch += 1;
+  }
+}
+
 int consume_gather_check_launch(const tg_model* m, const int64_t* involved, const int32_t* n_involved, int64_t cap,
                                 float* reprs, const int64_t* outdated, const int32_t* n_outdated, uint32_t* err,
                                 hipStream_t st, const PosArgs* pos, bool eager) {
@@ -331,10 +397,13 @@ int consume_gather_check_launch(const tg_model* m, const int64_t* involved, cons
 
 int writeback_launch(const tg_model* m, const WritebackArgs& a, int phase, hipStream_t st) {
   const unsigned grid = flat_grid(2 * a.B, 4);
+  if (phase == 2 && (!a.snap || !a.snap_ts || !m->pending_vals || a.rows || a.owner)) return TG_EINVAL;
   if (phase == 0)
     hipLaunchKernelGGL(k_writeback<0>, dim3(grid), dim3(256), 0, st, *m, a);
-  else
+  else if (phase == 1)
     hipLaunchKernelGGL(k_writeback<1>, dim3(grid), dim3(256), 0, st, *m, a);
+  else
+    hipLaunchKernelGGL(k_writeback_fused, dim3(grid), dim3(256), 0, st, *m, a);
   return check_launch("writeback");
 }
 

@@ -73,6 +73,13 @@ struct DirectArgs {
   const int32_t* n_outdated;
   int64_t cap;
   uint32_t* err;
+  // snapshot for the one-launch write-back (nullable): for position i < n_snap of cat[src, dst] the message-source
+  // memory row of its node as STEP 5 will want it (tiger.py:422-442: + node features; msg_src = right: the right memory
+  // as STEP 4 leaves it, i.e. the centre row itself) and that memory's time.  Taken here, before anything is written,
+  // it lets STEP 5 share a launch with STEP 6, which overwrites those very rows of the left memory.
+  float4* snap;
+  float* snap_ts;
+  int64_t n_snap;
 };
 __global__ void __launch_bounds__(256) k_attn_centres_direct(tg_model m, int64_t Q, const int64_t* __restrict__ nids,
                                                              const float4* __restrict__ nf, float4* __restrict__ out,
@@ -86,12 +93,23 @@ __global__ void __launch_bounds__(256) k_attn_centres_direct(tg_model m, int64_t
     const int64_t i = t / d4;
     const int c = (int)(t - i * d4);
     const int64_t id = nids[i];
-    float4 v = (bm_test(m.has_msg, id) ? pend : right)[id * d4 + c];
-    if (nf) {
-      const float4 f = nf[id * d4 + c];
-      v.x += f.x; v.y += f.y; v.z += f.z; v.w += f.w;
-    }
+    const bool pending = bm_test(m.has_msg, id);
+    float4 v = (pending ? pend : right)[id * d4 + c];
+    float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nf) f = nf[id * d4 + c];
+    v.x += f.x; v.y += f.y; v.z += f.z; v.w += f.w;
     out[t] = v;
+    if (da.snap && i < da.n_snap) {
+      if (m.msg_src == TG_SRC_LEFT) {
+        float4 l = reinterpret_cast<const float4*>(m.left_vals)[id * d4 + c];
+        l.x += f.x; l.y += f.y; l.z += f.z; l.w += f.w;
+        da.snap[t] = l;
+        if (c == 0) da.snap_ts[i] = m.left_ts[id];
+      } else {
+        da.snap[t] = v;
+        if (c == 0) da.snap_ts[i] = pending ? m.msg_ts[id] : m.right_ts[id];
+      }
+    }
   }
   if (da.outdated) {
     const int64_t no = min((int64_t)*da.n_outdated, da.cap);
@@ -825,6 +843,8 @@ bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w) {
   w.rank = cv.take<uint32_t>((size_t)W + 1);
   w.rank_out = cv.take<uint32_t>((size_t)W + 1);
   w.upos32 = cv.take<int32_t>((size_t)2 * B);
+  w.snap = cv.take<float>((size_t)2 * B * m->d);
+  w.snap_ts = cv.take<float>((size_t)2 * B);
   w.nids3 = cv.take<int64_t>((size_t)Q);
   w.eids = cv.take<int64_t>((size_t)B);
   w.ts3 = cv.take<double>((size_t)Q);
@@ -851,7 +871,7 @@ extern "C" size_t tg_stream_step_workspace_bytes(const tg_model* m, int64_t B) {
   if (!attn_dims_ok(m) || B <= 0 || m->n_nodes <= 0) return 0;
   const size_t Q = 3 * (size_t)B, K = m->n_neighbors, cap = Q * (K + 1), W = (m->n_nodes + 63) / 64;
   size_t b = align16(W * 64) + align16(W * 8) + align16(cap * 8) + 32 + 2 * align16((W + 1) * 4) + align16(2 * B * 4) +
-             align16(Q * 8) * 2 + align16(B * 8) +
+             align16(2 * B * m->d * 4) + align16(2 * B * 4) + align16(Q * 8) * 2 + align16(B * 8) +
              align16(Q * 4) + align16(Q * K * 8) * 2 + align16(Q * K * 4) + align16(cap * 8) * 2 + align16(cap * 4) +
              align16(2 * B * 8) * 2 + align16(cap * m->d * 4) + align16(tg_unique_compact_workspace_bytes(m->n_nodes)) +
              attn_ws_bytes(m, Q) + align16(apply_ws_bytes(m, cap));
@@ -908,7 +928,10 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   // from pending / right themselves, so there is no gather launch and no reprs buffer
   static const int direct_knob = getenv("TG_EAGER_DIRECT") ? atoi(getenv("TG_EAGER_DIRECT")) : 1;
   w.direct = eager && direct_knob != 0;
-  const DirectArgs da{w.outdated, w.counts + 1, cap, io->err};
+  // the one-launch write-back needs the snapshot; the restarter targets (h_prev_*) are read between STEP 4 and STEP 6,
+  // so a step that outputs them keeps the two-phase write-back
+  w.fused_wb = w.direct && !io->embed_only && !io->h_prev_left && !io->h_prev_right;
+  const DirectArgs da{w.outdated, w.counts + 1, cap, io->err, w.fused_wb ? (float4*)w.snap : nullptr, w.snap_ts, 2 * B};
   if (!w.direct &&
       (rc = consume_gather_check_launch(m, w.inv, w.counts + 0, cap, w.reprs, w.outdated, w.counts + 1, io->err, st, pp,
                                         eager)) != TG_OK)
@@ -957,6 +980,11 @@ static WritebackArgs writeback_args(const tg_model* m, const tg_step_io* io, Ste
 
 int step_writeback_a(const tg_model* m, const tg_step_io* io, StepWs& w, hipStream_t st, tg_profiler* pf) {
   const int64_t B = io->B;
+  if (w.fused_wb) {  // STEP 4-6 run as ONE launch from step_writeback_b
+    prof_mark(pf, ST_WRITE_RIGHT, st);
+    prof_mark(pf, ST_STORE_EVENTS, st);
+    return TG_OK;
+  }
   const int64_t* src = w.nids3;
   const int64_t* dst = w.nids3 + B;
   if (!w.dedup_done) {
@@ -983,10 +1011,14 @@ int step_writeback_a(const tg_model* m, const tg_step_io* io, StepWs& w, hipStre
 }
 
 int step_writeback_b(const tg_model* m, const tg_step_io* io, StepWs& w, hipStream_t st, tg_profiler* pf) {
-  const WritebackArgs wa = writeback_args(m, io, w);
+  WritebackArgs wa = writeback_args(m, io, w);
   prof_mark(pf, ST_WRITE_LEFT, st);
   int rc;
-  if ((rc = writeback_launch(m, wa, 1, st)) != TG_OK) return rc;
+  if (w.fused_wb) {
+    wa.snap = w.snap;
+    wa.snap_ts = w.snap_ts;
+  }
+  if ((rc = writeback_launch(m, wa, w.fused_wb ? 2 : 1, st)) != TG_OK) return rc;
   prof_mark(pf, ST_EAGER, st);
   if (w.eager && !io->embed_only) {
     // every unique positive node has just received a message (STEP 5) and its memories are final for this batch

@@ -51,6 +51,7 @@ struct StepWs {
   int64_t *l1_nids, *l1_eids;
   int32_t* out_pos;
   int32_t* upos32;
+  float *snap, *snap_ts;  // one-launch write-back: message-source rows (+ node features) / times of cat[src, dst], pre-batch
   void* scan_ws;
   size_t scan_bytes;
   AttnWs attn;
@@ -61,6 +62,7 @@ struct StepWs {
   float* l1t;
   bool dedup_done;  // the positive-node dedup already ran inside the forward launches
   bool eager;       // STEP 1-2 gathered precomputed updater rows; the updater runs at the end of the step instead
+  bool fused_wb;    // STEP 4-6 run as one launch (needs the snapshot taken by the direct centres launch)
   bool direct;      // ... and no compact copy of the involved rows was made (centres / neighbours read the tables)
 };
 
