@@ -586,7 +586,27 @@ typedef struct tg_writeback_io {
   const int32_t* owner;     /* [n_nodes] or NULL */
   int32_t my_rank;
   int32_t new_from_pending;
+  /* Planned winners (upos != NULL): the latest-event-per-node dedup of the batch (select_latest_nids on float32 times,
+   * tiger.py:232,419; memory.py:98) was made ahead - it depends on the batch only, not on node state - and only the
+   * nodes this rank writes are listed: upos[p] the node, index[p] its winning position in cat[src, dst], *n_upos_dev the
+   * count (device).  src / dst / eids are then the batch itself (offset_dev unused) and ts32 its float32 event times
+   * tiled twice ([2 Bg]); the call is two launches (STEP 4+5 | STEP 6, or 4 | 5+6) with no dedup work. */
+  const int64_t* upos;
+  const int64_t* index;
+  const int32_t* n_upos_dev;
+  const float* ts32;
 } tg_writeback_io;
+
+/* What an owner serves and what a user adopts in the partitioned multi-GPU mode, one launch each.
+ * tg_serve_rows: out[eff_pos[i], :] = effective right-memory row of eff_ids[i] and its time in column d
+ * (tg_gather_eff_rows); out[msg_pos[j], :] = message-source memory row of msg_ids[j] (left memory for msg_src = left,
+ * the effective right row otherwise) and its time.  out is [*, d + 1] float32.
+ * tg_adopt_rows: the inverse on the receiving side - rows[eff_pos[i]] overwrites right_vals / right_ts of eff_ids[i],
+ * rows[msg_pos[j]] the message-source memory row / time of msg_ids[j] (rows of nodes the rank does not own). */
+int tg_serve_rows(const tg_model* m, int64_t n_eff, const int64_t* eff_ids, const int64_t* eff_pos, int64_t n_msg,
+                  const int64_t* msg_ids, const int64_t* msg_pos, float* out, void* stream);
+int tg_adopt_rows(const tg_model* m, int64_t n_eff, const int64_t* eff_ids, const int64_t* eff_pos, int64_t n_msg,
+                  const int64_t* msg_ids, const int64_t* msg_pos, const float* rows, void* stream);
 
 size_t tg_stream_writeback_workspace_bytes(const tg_model* m, int64_t Bg);
 int tg_stream_writeback(const tg_model* m, const tg_writeback_io* io, void* ws, size_t ws_bytes, void* stream);

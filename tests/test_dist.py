@@ -314,39 +314,50 @@ class OraclePartitionEngine:
             rows[sel], ts[sel] = h_new[where], mts[where]
         return rows, ts
 
-    def serve(self, e_ids, m_ids):
+    def serve(self, p):
         m = self.orc
-        r, t = self._eff(e_ids)
-        r2, t2 = (m.left_vals[m_ids], m.left_ts[m_ids]) if m.msg_src == 'left' else self._eff(m_ids)
-        return torch.cat([r, t[:, None]], 1), torch.cat([r2, t2[:, None]], 1)
+        out = torch.empty(len(p.serve_eff) + len(p.serve_msg), self.d + 1)
+        r, t = self._eff(p.serve_eff)
+        r2, t2 = (m.left_vals[p.serve_msg], m.left_ts[p.serve_msg]) if m.msg_src == 'left' else self._eff(p.serve_msg)
+        out[p.serve_eff_pos], out[p.serve_msg_pos] = torch.cat([r, t[:, None]], 1), torch.cat([r2, t2[:, None]], 1)
+        return out
 
-    def adopt(self, eff_ids, eff_rows, msg_ids, msg_rows):
+    def adopt(self, p, got):
         m, d = self.orc, self.d
-        assert not m.has_msg[eff_ids.numpy()].any()  # a rank never holds a message of a node it does not own
-        m.right_vals[eff_ids], m.right_ts[eff_ids] = eff_rows[:, :d], eff_rows[:, d]
+        eff_rows, msg_rows = got[p.reply_eff_pos], got[p.reply_msg_pos]
+        assert not m.has_msg[p.req_eff.numpy()].any()  # a rank never holds a message of a node it does not own
+        m.right_vals[p.req_eff], m.right_ts[p.req_eff] = eff_rows[:, :d], eff_rows[:, d]
         vals, tss = m._mem(m.msg_src)
-        vals[msg_ids], tss[msg_ids] = msg_rows[:, :d], msg_rows[:, d]
+        vals[p.req_msg], tss[p.req_msg] = msg_rows[:, :d], msg_rows[:, d]
 
-    def embed(self, src, dst, neg, ts, eids):
+    def embed(self, p):
         O, m = self.O, self.orc
-        src, dst, neg = src.numpy(), dst.numpy(), neg.numpy()
-        cg = O.collate(m.graph, src, dst, neg, ts.numpy(), self.K, 'static')
+        rows = torch.zeros(3 * p.n + p.n_recv, self.d)
+        if p.n == 0:
+            return rows
+        src, dst, neg, ts, _ = (x.numpy() for x in p.local)
+        cg = O.collate(m.graph, src, dst, neg, ts, self.K, 'static')
         involved = cg['involved']
         outdated, h_new, _ = m.consume(involved)
         reprs = m.right_vals[torch.from_numpy(involved)].clone()
         if len(outdated):
             reprs[torch.from_numpy(cg['local_index'][outdated])] = h_new
         nids3 = np.concatenate([src, dst, neg])
-        return m.embed(reprs, cg['local_index'], nids3, ts.float().repeat(3), cg['l1_nids'], cg['l1_eids'], cg['l1_ts'])
+        rows[:3 * p.n] = m.embed(reprs, cg['local_index'], nids3, p.local[3].float().repeat(3), cg['l1_nids'], cg['l1_eids'],
+                                 cg['l1_ts'])
+        return rows
 
-    def writeback(self, src, dst, ts, eids, rows, left_row, owner, rank):
+    def writeback(self, p, rows, owner, rank):
         O, m = self.O, self.orc
+        src, dst, ts, eids = p.glob
         Bg = len(src)
         t32 = ts.float()
         ts2 = t32.repeat(2)
         ids, idx = O.select_latest_nids(torch.cat([src, dst]).numpy(), ts2.numpy())
         keep = owner.numpy()[ids] == rank
         ids, idx = ids[keep], idx[keep]
+        np.testing.assert_array_equal(ids, p.mine.numpy())          # the plan's winners are the write-back's
+        np.testing.assert_array_equal(idx, p.mine_index.numpy())
         had = m.has_msg[ids]
         if had.any():  # STEP 4 (tiger.py:230-241)
             sel = ids[had]
@@ -364,9 +375,9 @@ class OraclePartitionEngine:
                          m.te(te - opt_)], 1)
         m.msg_vals[own], m.msg_ts[own] = msg, te
         m.has_msg[ids] = True
-        m._mem_set(m.left_vals, m.left_ts, own, rows[left_row[torch.from_numpy(idx)]], ts2[torch.from_numpy(idx)])  # STEP 6
+        m._mem_set(m.left_vals, m.left_ts, own, rows[p.left_row[torch.from_numpy(idx)]], ts2[torch.from_numpy(idx)])  # STEP 6
 
-    def refresh(self, ids):
+    def refresh(self, p):
         pass  # the oracle computes updater rows on demand
 
 

@@ -83,6 +83,7 @@ class TgWritebackIo(C.Structure):
         ('Bg', i64), ('src', vp), ('dst', vp), ('ts', vp), ('eids', vp), ('offset_dev', vp), ('advance', i32),
         ('reserved', i32), ('rows', vp), ('left_row', vp), ('new_row', vp), ('err', vp),
         ('owner', vp), ('my_rank', i32), ('new_from_pending', i32),
+        ('upos', vp), ('index', vp), ('n_upos_dev', vp), ('ts32', vp),
     ]
 
 
@@ -141,6 +142,8 @@ SIGNATURES = {
     'tg_temporal_attn_fwd': (C.c_int, [P(TgModel), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     'tg_consume_update_right': (C.c_int, [P(TgModel), vp, vp, i64, vp, vp, vp, vp, vp]),
     'tg_gather_eff_rows': (C.c_int, [P(TgModel), i64, vp, vp, vp, vp]),
+    'tg_serve_rows': (C.c_int, [P(TgModel), i64, vp, vp, i64, vp, vp, vp, vp]),
+    'tg_adopt_rows': (C.c_int, [P(TgModel), i64, vp, vp, i64, vp, vp, vp, vp]),
     'tg_store_events': (C.c_int, [P(TgModel), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'tg_restart_seq_workspace_bytes': (sz, [P(TgModel), P(TgSeqRestarter), i64]),
     'tg_restart_seq_fwd': (C.c_int, [P(TgModel), P(TgSeqRestarter), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),

@@ -534,6 +534,80 @@ __global__ void k_gather_eff_rows(tg_model m, int64_t n, const int64_t* __restri
 }
 }  // namespace tg
 
+namespace tg {
+// out[pos[i], 0..d) = row, out[pos[i], d] = time; kind 0: effective right memory, kind 1: left memory
+__global__ void k_serve_rows(tg_model m, int64_t n_eff, const int64_t* __restrict__ eff_ids,
+                             const int64_t* __restrict__ eff_pos, int64_t n_msg, const int64_t* __restrict__ msg_ids,
+                             const int64_t* __restrict__ msg_pos, float* __restrict__ out) {
+  const int d = m.d, w4 = d / 4, ld = d + 1;
+  const float4* right = reinterpret_cast<const float4*>(m.right_vals);
+  const float4* pend = reinterpret_cast<const float4*>(m.pending_vals);
+  const float4* left = reinterpret_cast<const float4*>(m.left_vals);
+  const bool msg_left = m.msg_src == TG_SRC_LEFT;
+  const int64_t total = (n_eff + n_msg) * w4;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / w4;
+    const int c = (int)(t - i * w4);
+    const bool is_msg = i >= n_eff;
+    const int64_t id = is_msg ? msg_ids[i - n_eff] : eff_ids[i];
+    const int64_t row = is_msg ? msg_pos[i - n_eff] : eff_pos[i];
+    float4 v;
+    float ts;
+    if (is_msg && msg_left) {
+      v = left[id * w4 + c];
+      ts = m.left_ts[id];
+    } else {
+      const bool pending = bm_test(m.has_msg, id);
+      v = (pending ? pend : right)[id * w4 + c];
+      ts = pending ? m.msg_ts[id] : m.right_ts[id];
+    }
+    float* o = out + row * ld + 4 * c;  // rows of d + 1 floats are not 16-byte aligned
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    if (c == 0) out[row * ld + d] = ts;
+  }
+}
+__global__ void k_adopt_rows(tg_model m, int64_t n_eff, const int64_t* __restrict__ eff_ids,
+                             const int64_t* __restrict__ eff_pos, int64_t n_msg, const int64_t* __restrict__ msg_ids,
+                             const int64_t* __restrict__ msg_pos, const float* __restrict__ rows) {
+  const int d = m.d, w4 = d / 4, ld = d + 1;
+  const bool msg_left = m.msg_src == TG_SRC_LEFT;
+  const int64_t total = (n_eff + n_msg) * w4;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / w4;
+    const int c = (int)(t - i * w4);
+    const bool is_msg = i >= n_eff;
+    const int64_t id = is_msg ? msg_ids[i - n_eff] : eff_ids[i];
+    const int64_t row = is_msg ? msg_pos[i - n_eff] : eff_pos[i];
+    const float* r = rows + row * ld + 4 * c;
+    const float4 v = make_float4(r[0], r[1], r[2], r[3]);
+    const bool to_left = is_msg && msg_left;
+    reinterpret_cast<float4*>(to_left ? m.left_vals : m.right_vals)[id * w4 + c] = v;
+    if (c == 0) (to_left ? m.left_ts : m.right_ts)[id] = rows[row * ld + d];
+  }
+}
+}  // namespace tg
+
+extern "C" int tg_serve_rows(const tg_model* m, int64_t n_eff, const int64_t* eff_ids, const int64_t* eff_pos,
+                             int64_t n_msg, const int64_t* msg_ids, const int64_t* msg_pos, float* out, void* stream) {
+  if (!model_ok(m) || n_eff < 0 || n_msg < 0 || !m->pending_vals) return TG_EINVAL;
+  if (n_eff + n_msg == 0) return TG_OK;
+  if (!out || (n_eff && (!eff_ids || !eff_pos)) || (n_msg && (!msg_ids || !msg_pos))) return TG_EINVAL;
+  hipLaunchKernelGGL(k_serve_rows, dim3(flat_grid((n_eff + n_msg) * (m->d / 4), 256)), dim3(256), 0, as_stream(stream), *m,
+                     n_eff, eff_ids, eff_pos, n_msg, msg_ids, msg_pos, out);
+  return check_launch("tg_serve_rows");
+}
+
+extern "C" int tg_adopt_rows(const tg_model* m, int64_t n_eff, const int64_t* eff_ids, const int64_t* eff_pos,
+                             int64_t n_msg, const int64_t* msg_ids, const int64_t* msg_pos, const float* rows,
+                             void* stream) {
+  if (!model_ok(m) || n_eff < 0 || n_msg < 0) return TG_EINVAL;
+  if (n_eff + n_msg == 0) return TG_OK;
+  if (!rows || (n_eff && (!eff_ids || !eff_pos)) || (n_msg && (!msg_ids || !msg_pos))) return TG_EINVAL;
+  hipLaunchKernelGGL(k_adopt_rows, dim3(flat_grid((n_eff + n_msg) * (m->d / 4), 256)), dim3(256), 0, as_stream(stream), *m,
+                     n_eff, eff_ids, eff_pos, n_msg, msg_ids, msg_pos, rows);
+  return check_launch("tg_adopt_rows");
+}
+
 extern "C" int tg_gather_eff_rows(const tg_model* m, int64_t n, const int64_t* ids, float* out, float* ts_out,
                                   void* stream) {
   if (!model_ok(m) || n < 0 || !m->pending_vals) return TG_EINVAL;

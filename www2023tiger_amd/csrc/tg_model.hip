@@ -1135,6 +1135,18 @@ extern "C" int tg_stream_writeback(const tg_model* m, const tg_writeback_io* io,
   if (io->new_from_pending ? !m->pending_vals : !io->new_row) return TG_EINVAL;
   hipStream_t st = as_stream(stream);
   const int64_t Bg = io->Bg;
+  if (io->upos) {  // planned winners: no dedup work, two launches
+    if (!io->index || !io->n_upos_dev || !io->ts32) return TG_EINVAL;
+    WritebackArgs wa{};
+    wa.B = Bg; wa.src = io->src; wa.dst = io->dst; wa.eids = io->eids; wa.upos = io->upos; wa.index = io->index;
+    wa.ts = io->ts32; wa.n_upos = io->n_upos_dev; wa.err = io->err;
+    wa.rows = io->rows; wa.new_row = io->new_row; wa.left_row = io->left_row;
+    wa.owner = io->owner; wa.my_rank = io->my_rank; wa.new_from_pending = io->new_from_pending;
+    int rc;
+    if ((rc = writeback_launch(m, wa, 0, st)) != TG_OK) return rc;
+    if ((rc = writeback_launch(m, wa, 1, st)) != TG_OK) return rc;
+    return check_launch("tg_stream_writeback(planned)");
+  }
   Carver cv(ws, ws_bytes);
   WbWs w{};
   if (!carve_wb(m, Bg, cv, w)) return TG_EWORKSPACE;

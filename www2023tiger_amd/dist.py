@@ -320,10 +320,11 @@ class ResidentShardedStream:
 
 
 # --------------------------------------------------------------------------- partitioned state
-def all_to_all_rows(send: torch.Tensor, in_splits, out_splits, group=None) -> torch.Tensor:
+def all_to_all_rows(send: torch.Tensor, in_splits, out_splits, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """all_to_all_single over the leading dimension with per-peer row counts.  RCCL: on device.  gloo (CPU tests,
-    or several ranks sharing one GPU): staged through host memory."""
-    out = torch.empty((int(sum(out_splits)),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+    or several ranks sharing one GPU): staged through host memory.  `out`: receive in place (contiguous rows)."""
+    if out is None:
+        out = torch.empty((int(sum(out_splits)),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
     if tdist.get_backend(group) == 'nccl':
         tdist.all_to_all_single(out, send.contiguous(), list(out_splits), list(in_splits), group=group)
         return out
@@ -345,9 +346,9 @@ def exchange_counts(counts: torch.Tensor, group=None) -> torch.Tensor:
 
 class StepPlan:
     """Everything about one global batch that does not depend on node state (see PartitionedRunner.plan)."""
-    __slots__ = ('n', 'Bg', 'local', 'glob', 'serve_eff', 'serve_msg', 'serve_eff_pos', 'serve_msg_pos', 'serve_in',
-                 'serve_out', 'req_eff', 'req_msg', 'reply_eff_pos', 'reply_msg_pos', 'push_rows', 'push_in', 'push_out',
-                 'left_row', 'mine', 'stats')
+    __slots__ = ('n', 'Bg', 'local', 'glob', 'ts32', 'serve_eff', 'serve_msg', 'serve_eff_pos', 'serve_msg_pos',
+                 'serve_in', 'serve_out', 'req_eff', 'req_msg', 'reply_eff_pos', 'reply_msg_pos', 'push_rows', 'push_in',
+                 'push_out', 'n_recv', 'left_row', 'mine', 'mine_index', 'mine32', 'n_mine', 'stats')
 
 
 class PartitionedRunner:
@@ -387,8 +388,11 @@ class PartitionedRunner:
         pos = torch.cat([g_src, g_dst])
         upos, index = E.select_latest(pos, g_ts.float().repeat(2))  # the winners of the global batch (same on every rank)
         mine_mask = own[upos] == rank
-        p.mine = upos[mine_mask]
-        idx_mine = index[mine_mask]
+        p.mine = upos[mine_mask].contiguous()
+        idx_mine = p.mine_index = index[mine_mask].contiguous()
+        p.mine32 = p.mine.to(torch.int32)
+        p.n_mine = torch.tensor([p.mine.numel()], dtype=torch.int32, device=dev)
+        p.ts32 = g_ts.float().repeat(2).contiguous()
         other = torch.where(idx_mine < Bg, g_dst[idx_mine % Bg], g_src[idx_mine % Bg])
         msg = torch.unique(other[own[other] != rank])               # STEP 5 reads the other endpoint's message memory
         eff_s, eff_c = self._by_peer(eff)
@@ -430,8 +434,9 @@ class PartitionedRunner:
         left_row = torch.zeros(2 * Bg, dtype=torch.int64, device=dev)
         loc = mine_mask & here
         left_row[index[loc]] = role[loc] * n + slot[ev[loc]]
-        left_row[recv_pos] = 2 * n + torch.arange(recv_pos.numel(), device=dev)
+        left_row[recv_pos] = 3 * n + torch.arange(recv_pos.numel(), device=dev)  # received rows sit behind the rank's own 3n
         p.left_row = left_row
+        p.n_recv = int(recv_pos.numel())
         p.stats = dict(local_events=n, pulled_rows=int(sum(p.serve_out)), served_rows=int(sum(p.serve_in)),
                        pushed_rows=int(sum(p.push_in)), received_rows=int(sum(p.push_out)), own_winners=int(p.mine.numel()))
         return p
@@ -440,17 +445,14 @@ class PartitionedRunner:
         """Collective.  The state-dependent part of a global batch: pull, embed, push, owner write-back, eager updater.
         Returns this rank's embeddings [3 n, d] (rows [0, 2n) are h(t-) of cat[src, dst] of its events)."""
         E = self.engine
-        eff_rows, msg_rows = E.serve(p.serve_eff, p.serve_msg)                               # [*, d + 1]: row | time
-        served = torch.empty(p.serve_eff.numel() + p.serve_msg.numel(), E.d + 1, dtype=torch.float32, device=self.dev)
-        served[p.serve_eff_pos], served[p.serve_msg_pos] = eff_rows, msg_rows
-        got = all_to_all_rows(served, p.serve_in, p.serve_out, self.group)                   # PULL
-        E.adopt(p.req_eff, got[p.reply_eff_pos], p.req_msg, got[p.reply_msg_pos])
-        h = E.embed(*p.local) if p.n else torch.zeros(0, E.d, dtype=torch.float32, device=self.dev)
-        recv = all_to_all_rows(h[p.push_rows], p.push_in, p.push_out, self.group)            # PUSH
-        rows = torch.cat([h[:2 * p.n], recv]) if recv.numel() or p.n else torch.zeros(1, E.d, device=self.dev)
-        E.writeback(*p.glob, rows, p.left_row, self.owner, self.rank)
-        E.refresh(p.mine)
-        return h
+        served = E.serve(p)                                                       # [*, d + 1]: row | time, peer-major
+        got = all_to_all_rows(served, p.serve_in, p.serve_out, self.group)        # PULL
+        E.adopt(p, got)
+        rows = E.embed(p)                                                         # [3 n + n_recv, d]: h, then room for the push
+        all_to_all_rows(rows[p.push_rows], p.push_in, p.push_out, self.group, out=rows[3 * p.n:])   # PUSH
+        E.writeback(p, rows, self.owner, self.rank)
+        E.refresh(p)
+        return rows[:3 * p.n]
 
     def step(self, src, dst, neg, ts, eids, rank_of=None) -> torch.Tensor:
         return self.run(self.plan(src, dst, neg, ts, eids, rank_of))
@@ -458,9 +460,11 @@ class PartitionedRunner:
 
 class HipPartitionEngine:
     """The local compute of the partitioned mode on the HIP engine (every method is C-ABI calls on the model's
-    tables): collation, serving rows to peers, adopting pulled rows, embedding, owner write-back, eager updater."""
+    tables): collation, serving rows to peers, adopting pulled rows, embedding, owner write-back, eager updater.
+    resident = (src, dst, neg, ts64, eids) device tensors of this rank's events of ALL steps, B per step: the
+    embed then reads its batch at a device-side offset (no per-step copies)."""
 
-    def __init__(self, model, cap: int):
+    def __init__(self, model, cap: int, resident=None):
         from . import hip_ops
         from ._lib import TgWritebackIo, check, lib, ptr
         if model._pending is None:
@@ -468,13 +472,17 @@ class HipPartitionEngine:
         model._sync_pending()
         self.model, self.cap, self.device, self.d = model, cap, model.device, model.memory_dim
         self.hip_ops, self.check, self.lib, self.ptr, self.WbIo = hip_ops, check, lib, ptr, TgWritebackIo
-        self.buf = model.StepBuffers(model, cap, False, embed_only=True)
+        self.max_recv = 2 * cap if resident is not None else 0  # resident: fixed output buffer with room for pushed rows
+        self.hbuf = torch.zeros(3 * cap + max(self.max_recv, 1), self.d, dtype=torch.float32, device=self.device)
+        self.cbuf = model.StepBuffers(model, cap, False, embed_only=True, h_out=self.hbuf, want_h_new=False)  # collation
+        self.buf = self.cbuf if resident is None else model.StepBuffers(
+            model, cap, False, resident=resident, embed_only=True, h_out=self.hbuf, want_h_new=False)
+        self.resident = resident is not None
         self.err = hip_ops.new_err(model.device)
-        self._wb_ws = None
         self._owner32 = None
 
     def _load(self, src, dst, neg, ts, eids=None):
-        n, buf = int(src.numel()), self.buf
+        n, buf = int(src.numel()), self.cbuf
         assert n <= self.cap, f'{n} events exceed the engine capacity {self.cap}'
         buf.src[:n], buf.dst[:n], buf.neg[:n], buf.ts[:n] = src, dst, neg, ts
         if eids is not None:
@@ -488,89 +496,83 @@ class HipPartitionEngine:
     def collate(self, src, dst, neg, ts):
         """sorted involved node ids of these events (sampler + compaction only: no state is read)"""
         self._load(src, dst, neg, ts)
-        self.buf.io.collate_only = 1
+        self.cbuf.io.collate_only = 1
         try:
-            self.model.launch_step(self.buf)
+            self.model.launch_step(self.cbuf)
         finally:
-            self.buf.io.collate_only = 0
-        return self.buf.involved[:int(self.buf.counts[0].item())].clone()
+            self.cbuf.io.collate_only = 0
+        return self.cbuf.involved[:int(self.cbuf.counts[0].item())].clone()
 
-    def serve(self, e_ids, m_ids):
-        """(effective right-memory rows of e_ids, message-source memory rows of m_ids), each [*, d + 1]: row | time"""
-        m, lib, ptr, d = self.model, self.lib, self.ptr, self.d
+    def serve(self, p):
+        """one launch: effective right-memory rows of p.serve_eff and message-source memory rows of p.serve_msg, each
+        with its time in column d, at their places in the peer-major send buffer"""
+        m, lib, ptr = self.model, self.lib, self.ptr
+        ne, nm = p.serve_eff.numel(), p.serve_msg.numel()
+        out = torch.empty(ne + nm, self.d + 1, dtype=torch.float32, device=self.device)
         ms = m.model_struct()
+        self.check(lib.tg_serve_rows(C.byref(ms), ne, ptr(p.serve_eff), ptr(p.serve_eff_pos), nm, ptr(p.serve_msg),
+                                     ptr(p.serve_msg_pos), ptr(out), self.hip_ops.stream_ptr(self.device)), 'tg_serve_rows')
+        return out
 
-        def eff(ids):
-            out = torch.empty(ids.numel(), d + 1, dtype=torch.float32, device=self.device)
-            if ids.numel():
-                rows = torch.empty(ids.numel(), d, dtype=torch.float32, device=self.device)
-                ts = torch.empty(ids.numel(), dtype=torch.float32, device=self.device)
-                self.check(lib.tg_gather_eff_rows(C.byref(ms), ids.numel(), ptr(ids), ptr(rows), ptr(ts),
-                                                  self.hip_ops.stream_ptr(self.device)), 'tg_gather_eff_rows')
-                out[:, :d], out[:, d] = rows, ts
-            return out
-        if m.msg_src == 'left' and m_ids.numel():
-            r2, t2 = self.hip_ops.gather_rows(m.left_memory.vals, m_ids, m.left_memory.update_ts)
-            msg = torch.cat([r2, t2[:, None]], 1)
-        else:  # msg_src == right: the right memory as STEP 4 leaves it
-            msg = eff(m_ids)
-        return eff(e_ids), msg
+    def adopt(self, p, got):
+        """one launch: pulled rows overwrite this rank's stale copies (rows of nodes it does not own: never
+        authoritative here)"""
+        m, lib, ptr = self.model, self.lib, self.ptr
+        ms = m.model_struct()
+        self.check(lib.tg_adopt_rows(C.byref(ms), p.req_eff.numel(), ptr(p.req_eff), ptr(p.reply_eff_pos), p.req_msg.numel(),
+                                     ptr(p.req_msg), ptr(p.reply_msg_pos), ptr(got), self.hip_ops.stream_ptr(self.device)),
+                   'tg_adopt_rows')
 
-    def adopt(self, eff_ids, eff_rows, msg_ids, msg_rows):
-        """pulled rows overwrite this rank's stale copies (rows of nodes it does not own: never authoritative here)"""
-        m, ops = self.model, self.hip_ops
-        R, L = m.right_memory, m.left_memory
-        if eff_ids.numel():
-            ops.memory_scatter(R.vals, R.update_ts, None, eff_ids, eff_rows[:, :self.d].contiguous(),
-                               eff_rows[:, self.d].contiguous())
-        if msg_ids.numel():
-            T = L if m.msg_src == 'left' else R
-            ops.memory_scatter(T.vals, T.update_ts, None, msg_ids, msg_rows[:, :self.d].contiguous(),
-                               msg_rows[:, self.d].contiguous())
+    def embed(self, p):
+        """collate + STEP 1-3 of this rank's events -> [3 n + n_recv, d]: the embeddings, then room for pushed rows"""
+        n = p.n
+        if self.resident:
+            assert n == self.cap and p.n_recv <= self.max_recv
+            self.model.launch_step(self.buf)   # reads its batch at the device-side offset and advances it
+            return self.hbuf[:3 * n + p.n_recv]
+        if n:
+            self._load(*p.local)
+            self.model.launch_step(self.cbuf)
+        if 3 * n + p.n_recv <= self.hbuf.shape[0] and n == self.cap:
+            return self.hbuf[:3 * n + p.n_recv]
+        rows = torch.empty(3 * n + p.n_recv, self.d, dtype=torch.float32, device=self.device)  # ragged shard: rows are
+        if n:                                                                                   # [src | dst | neg] blocks of n
+            rows[:3 * n] = self.hbuf[:3 * n]
+        return rows
 
-    def embed(self, src, dst, neg, ts, eids):
-        n = self._load(src, dst, neg, ts, eids)
-        self.model.launch_step(self.buf)
-        return self.buf.h[:3 * n]
-
-    def writeback(self, src, dst, ts, eids, rows, left_row, owner, rank):
+    def writeback(self, p, rows, owner, rank):
+        """STEP 4-6 for this rank's own winners (planned: the dedup of the global batch was made by `plan`), two launches"""
         m, lib, ptr = self.model, self.lib, self.ptr
         m._touch()
-        Bg = int(src.numel())
         ms = m.model_struct()
         if self._owner32 is None:
             self._owner32 = owner.to(torch.int32).contiguous()
-        keep = [src.contiguous(), dst.contiguous(), ts.contiguous(), eids.contiguous(), rows.contiguous(),
-                left_row.contiguous()]
-        nbytes = int(lib.tg_stream_writeback_workspace_bytes(C.byref(ms), Bg))
-        if self._wb_ws is None or self._wb_ws.numel() < nbytes:
-            self._wb_ws = torch.empty(nbytes, dtype=torch.uint8, device=m.device)
-        io = self.WbIo(Bg, ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), None, 0, 0, ptr(keep[4]),
-                       ptr(keep[5]), None, ptr(self.err), ptr(self._owner32), rank, 1)
-        self.check(lib.tg_stream_writeback(C.byref(ms), C.byref(io), ptr(self._wb_ws), self._wb_ws.numel(),
-                                           self.hip_ops.stream_ptr(m.device)), 'tg_stream_writeback')
-        self._keep = keep
+        g_src, g_dst, g_ts, g_eids = p.glob
+        if rows.numel() == 0:
+            rows = torch.zeros(1, self.d, dtype=torch.float32, device=self.device)
+        io = self.WbIo(p.Bg, ptr(g_src), ptr(g_dst), ptr(g_ts), ptr(g_eids), None, 0, 0, ptr(rows), ptr(p.left_row), None,
+                       ptr(self.err), ptr(self._owner32), rank, 1, ptr(p.mine), ptr(p.mine_index), ptr(p.n_mine), ptr(p.ts32))
+        self.check(lib.tg_stream_writeback(C.byref(ms), C.byref(io), None, 0, self.hip_ops.stream_ptr(m.device)),
+                   'tg_stream_writeback')
 
-    def refresh(self, ids):
+    def refresh(self, p):
         """eager updater: pending[v] = updater(upd_memory[v], tsfm(mailbox[v])) for the owned nodes that just
         received a message"""
         m, lib, ptr = self.model, self.lib, self.ptr
-        n = int(ids.numel())
+        n = int(p.mine.numel())
         if n:
             ms = m.model_struct()
-            ids = ids.contiguous()
-            ids32 = ids.to(torch.int32)
-            cnt = torch.tensor([n], dtype=torch.int32, device=self.device)
             nbytes = int(lib.tg_apply_messages_workspace_bytes(C.byref(ms), n))
             ws = m._ws('apply', nbytes)
-            self.check(lib.tg_apply_messages(C.byref(ms), ptr(ids), ptr(ids32), ptr(cnt), n, ptr(m._pending), ptr(self.err),
-                                             ptr(ws), ws.numel(), self.hip_ops.stream_ptr(self.device)),
+            self.check(lib.tg_apply_messages(C.byref(ms), ptr(p.mine), ptr(p.mine32), ptr(p.n_mine), n, ptr(m._pending),
+                                             ptr(self.err), ptr(ws), ws.numel(), self.hip_ops.stream_ptr(self.device)),
                        'tg_apply_messages(pending)')
         m._pending_stamp = m._state_stamp()  # the table is current again
 
     def check_invariants(self):
         self.hip_ops.raise_if_err(self.err)
         self.hip_ops.raise_if_err(self.buf.err)
+        self.hip_ops.raise_if_err(self.cbuf.err)
 
 
 class ResidentPartitionedStream:
@@ -580,16 +582,24 @@ class ResidentPartitionedStream:
     of rows and local kernels, no host decision in between."""
 
     def __init__(self, model, stream: dict, owner: np.ndarray, rank: int, world: int, B: int, n_steps: int,
-                 group=None, balance: bool = True):
+                 group=None):
         Bg = B * world
-        self.engine = HipPartitionEngine(model, cap=B if balance else Bg)
-        self.runner = PartitionedRunner(self.engine, owner, rank, world, group)
-        self.plans = []
         keys = ('src', 'dst', 'neg', 'ts', 'eids')
-        for b in range(n_steps):
+        rank_ofs, local = [], {k: [] for k in keys}
+        for b in range(n_steps):  # capacity-balanced shards: every rank embeds exactly B events of every global batch
             sl = slice(b * Bg, (b + 1) * Bg)
-            rank_of = ShardPlan(stream['dst'][sl], owner, world, B, balance=True).rank_of if balance else None
-            self.plans.append(self.runner.plan(*(stream[k][sl] for k in keys), rank_of=rank_of))
+            rank_of = ShardPlan(stream['dst'][sl], owner, world, B, balance=True).rank_of
+            rank_ofs.append(rank_of)
+            li = np.nonzero(rank_of == rank)[0]
+            for k in keys:
+                local[k].append(stream[k][sl][li])
+        dev = model.device
+        tod = lambda a, dt: torch.from_numpy(np.ascontiguousarray(np.concatenate(a))).to(dev, dt)
+        resident = tuple(tod(local[k], torch.float64 if k == 'ts' else torch.int64) for k in keys)
+        self.engine = HipPartitionEngine(model, cap=B, resident=resident)
+        self.runner = PartitionedRunner(self.engine, owner, rank, world, group)
+        self.plans = [self.runner.plan(*(stream[k][b * Bg:(b + 1) * Bg] for k in keys), rank_of=rank_ofs[b])
+                      for b in range(n_steps)]
         self.steps_done = 0
 
     def step(self):
@@ -623,6 +633,11 @@ def bench_main(args, cfg, make_stream, build_models, rank, local_rank, world):
     # rehearsal on a box with fewer GPUs than ranks (TG_BENCH_REHEARSAL=1): every rank uses GPU 0 and the exchange
     # goes through gloo - the timings mean nothing, the flow (plans, shapes, collectives, the JSON line) is the same
     rehearsal = bool(os.environ.get('TG_BENCH_REHEARSAL'))
+    if 'MASTER_ADDR' not in os.environ:  # a single rank started by hand (--force-dist)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(sk.getsockname()[1]))
     dev = torch.device('cuda', 0 if rehearsal else local_rank)
     torch.cuda.set_device(dev)
     if rehearsal:

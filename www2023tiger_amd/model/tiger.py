@@ -456,7 +456,7 @@ class TIGE(nn.Module):
         tg_stream_step; reused every step so the call sequence can be graph-captured."""
 
         def __init__(self, model: 'TIGE', B: int, want_prev: bool, resident=None, embed_only: bool = False,
-                     h_out=None, h_new_out=None):
+                     h_out=None, h_new_out=None, want_h_new: bool = True):
             """resident = (src, dst, neg, ts64, eids) device tensors of the WHOLE stream: the
             step then reads batch [offset, offset+B) and advances `offset` on device."""
             dev, d, K = model.device, model.memory_dim, model.n_neighbors
@@ -482,7 +482,7 @@ class TIGE(nn.Module):
             self.h_prev_left = torch.zeros(2 * B, d, dtype=torch.float32, device=dev) if want_prev else None
             self.h_prev_right = torch.zeros(2 * B, d, dtype=torch.float32, device=dev) if want_prev else None
             self.h_new = h_new_out if h_new_out is not None else (
-                torch.zeros(2 * B, d, dtype=torch.float32, device=dev) if embed_only else None)
+                torch.zeros(2 * B, d, dtype=torch.float32, device=dev) if (embed_only and want_h_new) else None)
             m = model.model_struct()
             nbytes = int(lib.tg_stream_step_workspace_bytes(C.byref(m), B))
             if nbytes == 0:
