@@ -304,8 +304,8 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
         model.launch_step(buf)
     torch.cuda.synchronize()
     assert int(buf.err.item()) == 0, f'invariant word {int(buf.err.item())}'
-    if not eager:
-        model.note_rows(int(buf.counts[1].item()))  # bound on the pending-message rows (steady state reached)
+    cnt = buf.counts.tolist()
+    model.note_rows(cnt[1], cnt[2])  # bounds on the updater's rows (steady state reached): pending messages / unique positives
 
     # ---- timed region: K steps, hipGraph replay of one captured step
     graph = None

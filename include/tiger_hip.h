@@ -405,8 +405,9 @@ typedef struct tg_step_io {
   /* rows_hint > 0: the caller's bound on the number of nodes with a pending message among the involved nodes of
    * this batch (e.g. 1.5 x the largest count seen so far).  Performance only: it lets the updater pick blocks
    * sized for a launch that fits the chip in one round; a batch that exceeds the bound is still correct.
-   * 0 = unknown (the capacity and the node count are used).  (This field was `reserved` before: 0 is the old
-   * behaviour, the layout is unchanged.) */
+   * 0 = unknown (the capacity and the node count are used).  With eager updates (tg_model.pending_vals) the updater
+   * runs on the unique positive nodes of the batch and the bound is on THEIR number (counts[2]).  (This field was
+   * `reserved` before: 0 is the old behaviour, the layout is unchanged.) */
   int32_t rows_hint;
   /* Lazy restart of train_self_supervised.py:152-163 with the StaticRestarter, on device (NULL = off);
    * see tg_lazy_restart below. */

@@ -650,7 +650,8 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
   constexpr int NBL = (96 + RP - 1) / RP;      // weight float4 per thread per tile (3 planes x 32 rows)
   constexpr int NOPS = NA + NBL;
   constexpr int PP = 8 / KS;                   // k-step pairs per wave per tile
-  static_assert(BM % RP == 0 && NOPS <= (PP / 2) * 3, "three memory-op slots per k-step pair");
+  constexpr int SL = (NOPS + PP / 2 - 1) / (PP / 2);  // memory-op slots per k-step pair: 3 in the wide blocks, 4 in the 32-row one
+  static_assert(BM % RP == 0 && SL <= 4, "at most four memory-op slots between the six MFMAs of a k-step pair");
   const unsigned long long t_entry = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
   // One LDS arena: the operand tiles while the loop runs, the k-group fold afterwards (the tiles are dead then).
   constexpr int A_FLOATS = 2 * BM * LDK, B_FLOATS = 2 * 3 * 32 * LDK;
@@ -782,7 +783,7 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
     read_pair(buf, p0, cur);
 #pragma unroll
     for (int q = 0; q < PP; ++q) {
-      const int op0 = (q % (PP / 2)) * 3;  // up to three memory-op slots per pair; NOPS of them are used
+      const int op0 = (q % (PP / 2)) * SL;  // SL memory-op slots per pair; NOPS of them are used
       auto memop = [&](int i) {
         if (i < NOPS) {
           if (q < PP / 2) load_one(tl, i, la, lb);
@@ -797,6 +798,7 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
       TG_SB();
       if (HP) acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a0, cur.b20, acc_hn, 0, 0, 0);
       else acc_in = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a0, cur.b20, acc_in, 0, 0, 0);
+      if (SL > 3) memop(op0 + 3);
       TG_SB();
       acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a1, cur.b01, acc_r, 0, 0, 0);
       memop(op0 + 1);
@@ -929,7 +931,7 @@ int gru_launch(const GruArgs& g, hipStream_t st) {
   // Smaller still when it fits: 64-row blocks (k_gru<2, 4>, 8 wavefronts; 1588 rows at d = 172: 36 us against
   // 47 us with 96 rows and 58 us with 128).  Its blocks follow the plain XCD map, so every XCD must hold its
   // share: ceil(row tiles / 8) x column tiles <= 32 CUs.
-  bool small = false, tiny = false;
+  bool small = false, tiny = false, micro = false;
   {
     const int tail = g.d % 32;
     const bool use_tail = tail > 0 && tail <= 16;
@@ -937,6 +939,16 @@ int gru_launch(const GruArgs& g, hipStream_t st) {
     const int64_t blocks96 = cdiv(rows, 96) * (NT - (use_tail ? 1 : 0)) + (use_tail ? cdiv(rows, T16_ROWS) : 0);
     small = blocks96 + 8 <= 256;  // (+8: the per-XCD dealing can leave one XCD a block short of full)
     tiny = cdiv(cdiv(rows, 64), 8) * NT <= 32;
+    // fewer rows still: 32-row blocks (k_gru<1, 4>, four wavefronts) double the block count once more - the updater of the
+    // eager step runs on ~1000 rows at C2: 17 x 6 = 102 blocks of 64 rows leave 154 CUs idle, 34 x 6 = 204 do not.  An XCD
+    // that ends up with a few more blocks than its 32 CUs co-hosts two of these small blocks on a CU (no second round)
+    micro = cdiv(cdiv(rows, 32), 8) * NT <= 40;
+  }
+  static const int micro_knob = getenv("TG_GRU_MICRO") ? atoi(getenv("TG_GRU_MICRO")) : 1;  // tuning knob: 0 = off
+  if (force_nw == 1 || (force_nw == 0 && micro && micro_knob)) {
+    a.tail_blocks = 0;
+    hipLaunchKernelGGL((k_gru<1, 4>), dim3((unsigned)(8 * cdiv(cdiv(g.cap, 32), 8) * NT)), dim3(256), 0, st, a);
+    return check_launch("gru(32)");
   }
   if (force_nw == 2 || (force_nw == 0 && tiny)) {
     a.tail_blocks = 0;

@@ -1025,8 +1025,10 @@ int step_writeback_b(const tg_model* m, const tg_step_io* io, StepWs& w, hipStre
     // (STEP 4 / STEP 6): the row a later batch would compute on the fly when the node turns up as a neighbour,
     // pending[v] = updater(upd_memory[v], tsfm(mailbox[v])), is computed here, once
     const int64_t P = 2 * io->B;
+    // rows_hint (eager steps): the caller's bound on the unique positive nodes of a batch; performance only
+    const int64_t bound = io->rows_hint > 0 ? std::min<int64_t>(P, io->rows_hint) : P;
     if ((rc = apply_messages(m, w.upos, w.upos32, w.counts + 2, P, m->pending_vals, io->err, w.apply_ws, w.apply_bytes, st,
-                             true, nullptr, P)) != TG_OK)
+                             true, nullptr, bound)) != TG_OK)
       return rc;
   }
   prof_mark(pf, ST_COUNT, st);

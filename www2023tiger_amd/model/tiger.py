@@ -548,11 +548,15 @@ class TIGE(nn.Module):
         launch sized for one round that needs a second one costs more than the smaller blocks win, and the count
         grows while the graph behind the stream fills up (C2: 3200 at batch 20, 4550 at batch 120), hence the
         generous margin; the bound follows the counts as they are read back."""
+        if self._pending is not None:  # eager updates: the updater runs on the unique positive nodes of a batch
+            seen = getattr(self, '_pos_seen', 0)
+            return int(1.25 * seen) + 32 if seen else 0
         seen = getattr(self, '_rows_seen', 0)
         return int(1.5 * seen) + 64 if seen else 0
 
-    def note_rows(self, n_outdated: int):
+    def note_rows(self, n_outdated: int, n_unique_pos: int = 0):
         self._rows_seen = max(getattr(self, '_rows_seen', 0), int(n_outdated))
+        self._pos_seen = max(getattr(self, '_pos_seen', 0), int(n_unique_pos))
 
     def launch_step(self, buf: 'TIGE.StepBuffers'):
         """Enqueue collate + STEP 1-6 for the batch already in `buf` (no host sync)."""
@@ -578,7 +582,8 @@ class TIGE(nn.Module):
         self.launch_step(buf)
         if check_invariants:
             word = int(buf.err.item())
-            self.note_rows(int(buf.counts[1].item()))
+            cnt = buf.counts.tolist()
+            self.note_rows(cnt[1], cnt[2])
             if word:
                 buf.err.zero_()
                 from .._lib import raise_invariants
