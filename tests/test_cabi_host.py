@@ -133,3 +133,13 @@ def test_state_dict_key_set_is_the_references(name):
     assert not res.missing_keys and not res.unexpected_keys
     np.testing.assert_array_equal(model.left_memory.vals.numpy(), z['sd.left_memory.vals'])
     assert model.msg_memory is (model.left_memory if cfg['msg_src'] == 'left' else model.right_memory)
+
+
+def test_graft_entry_module_imports_and_builds():
+    """the driver's entry points: the module must import (a syntax slip there would fail the round's build check) and
+    build() must leave a library with the current ABI"""
+    import importlib
+    import __graft_entry__ as g
+    importlib.reload(g)
+    g.build()
+    assert callable(g.smoke)
