@@ -338,33 +338,58 @@ __global__ void __launch_bounds__(256) k_writeback_fused(tg_model m, WritebackAr
   const float4* fq = reinterpret_cast<const float4*>(m.te_freq);
   const float4* ph = reinterpret_cast<const float4*>(m.te_phase);
   float4* box = reinterpret_cast<float4*>(m.msg_vals);
+  const float4* pend = reinterpret_cast<const float4*>(m.pending_vals);
+  const float4* hrow = reinterpret_cast<const float4*>(a.h);
+  float4* right = reinterpret_cast<float4*>(m.right_vals);
+  float4* left = reinterpret_cast<float4*>(m.left_vals);
   for (int64_t p = wave0; p < n; p += nwave) {
+    // every load of the three steps is independent of every store: request them together (one wavefront has nothing
+    // else to hide a dependent chain of five row fetches behind), then write
     const int64_t id = a.upos[p], idx = a.index[p];
-    wb_step4(m, id, id, reinterpret_cast<const float4*>(m.pending_vals), a.err, lane);  // STEP 4: right <- pending
     const int64_t e = idx < B ? idx : idx - B;
     const int64_t other_pos = idx < B ? B + e : e;
+    const bool consume = bm_test(m.has_msg, id);  // STEP 4 applies (wave-uniform)
     const float t = a.ts[e];
-    const float dt = t - a.snap_ts[idx];
+    const float own_ts = a.snap_ts[idx];
     const int64_t eid = a.eids[e];
-    for (int c = lane; c < row4; c += TG_WAVE) {  // STEP 5
-      float4 v;
-      if (c < d4) v = snap[idx * d4 + c];
-      else if (c < 2 * d4) v = snap[other_pos * d4 + (c - d4)];
-      else if (c < 2 * d4 + e4) v = ef ? ef[eid * e4 + (c - 2 * d4)] : make_float4(0.f, 0.f, 0.f, 0.f);
-      else {
+    const float mts = m.msg_ts[id], rts = m.right_ts[id], lts = m.left_ts[id];
+    for (int c0 = 0; c0 < row4; c0 += TG_WAVE) {
+      const int c = c0 + lane;
+      float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), hv = pv, v = pv;
+      if (c < d4) {
+        if (consume) pv = pend[id * d4 + c];
+        hv = hrow[idx * d4 + c];
+        v = snap[idx * d4 + c];
+      } else if (c < 2 * d4) {
+        v = snap[other_pos * d4 + (c - d4)];
+      } else if (c < 2 * d4 + e4) {
+        if (ef) v = ef[eid * e4 + (c - 2 * d4)];
+      } else if (c < row4) {
         const int cc = c - 2 * d4 - e4;
         const float4 w = fq[cc], q = ph[cc];
+        const float dt = t - own_ts;
         v = make_float4(time_enc(dt, w.x, q.x), time_enc(dt, w.y, q.y), time_enc(dt, w.z, q.z), time_enc(dt, w.w, q.w));
       }
-      box[id * row4 + c] = v;
+      if (c < d4) {
+        if (consume) right[id * d4 + c] = pv;  // STEP 4: right <- pending (tiger.py:236-241)
+        left[id * d4 + c] = hv;                // STEP 6: left <- h(t-)  (tiger.py:253-255)
+      }
+      if (c < row4) box[id * row4 + c] = v;    // STEP 5: [own | other | edge | time] (memory.py:89-106)
     }
     if (lane == 0) {
-      const uint64_t bit = 1ull << (id & 63);
-      const unsigned long long old = atomicOr((unsigned long long*)(m.has_msg + (id >> 6)), bit);
-      if (old & bit) atomicOr(a.err, TG_ERR_UNUSED_MESSAGE);
+      if (consume) {
+        if (rts > mts) atomicOr(a.err, TG_ERR_PAST_MEMORY);
+        m.right_ts[id] = mts;
+        if (m.right_active) m.right_active[id] = 1;
+      }
+      const uint64_t bit = 1ull << (id & 63);  // consumed (if it was set) and set again by the new message: stays / becomes set
+      if (!consume) atomicOr((unsigned long long*)(m.has_msg + (id >> 6)), bit);
       m.msg_ts[id] = t;
+      const float nt = a.ts[idx];
+      if (lts > nt) atomicOr(a.err, TG_ERR_PAST_MEMORY);
+      m.left_ts[id] = nt;
+      if (m.left_active) m.left_active[id] = 1;
     }
-    wb_step6(m, id, idx, idx, reinterpret_cast<const float4*>(a.h), a.ts, a.err, lane);  // STEP 6: left <- h(t-)
   }
   if (a.clean_flags) {  // leave the step workspace zeroed for the next step
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
