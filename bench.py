@@ -202,11 +202,14 @@ def stage_work(cfg, U, O_, P, eager, fused, n_nodes, E):
     Q, d_e = 3 * B, d
     fe = 0 if cfg.get('no_feats') else 1
     mw = 3 * d + d_e               # mailbox row width
-    kvw, nh = 2 * d + d_e, 2
+    # without an edge table the edge segment of mailbox rows and key rows is zeros: the pre-multiplied attention weights
+    # drop its columns and the updater skips the k-tiles that lie inside it (no flops are counted for skipped zeros)
+    kvw, nh = 2 * d + (d_e if (fe or not fused) else 0), 2
     nk = nh * kvw
     deg = max(2.0, 2.0 * E / n_nodes)
     upd_rows = P if eager else O_  # rows the updater runs on
-    gru = (2.0 * upd_rows * 3 * d * (mw + d), upd_rows * (4 * mw + 4) + upd_rows * (4 * d + 4) + upd_rows * 4 * d)
+    mw_mul = mw if fe else mw - 32 * max(0, (2 * d + d_e) // 32 - (2 * d + 31) // 32)
+    gru = (2.0 * upd_rows * 3 * d * (mw_mul + d), upd_rows * (4 * mw_mul + 4) + upd_rows * (4 * d + 4) + upd_rows * 4 * d)
     w = {
         'sample_recent_edges': (None, Q * (8 * np.ceil(np.log2(deg + 1)) + K * 28) + 5 * 8 * B, 'tg::k_sample_batch<16>'),
         'unique_compact': (None, n_nodes + 8 * U + 12 * O_, 'tg::k_bm_small' if n_nodes <= 65536 else 'tg::k_bm_emit'),

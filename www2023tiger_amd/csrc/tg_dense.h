@@ -84,6 +84,9 @@ struct GruArgs {
   int dbg;                  // diagnostic bits, 0 in production
   int64_t rows_hint;        // upper bound of live rows known on the host (0 = unknown), picks the tile height
   int tail_blocks;          // set by gru_launch: leading blocks that run the 16-column tail (k_gru<3, 4> only)
+  // k-tiles [x_skip_at, x_skip_at + x_skip_n) of the message operand are known to be all zero (the edge-feature segment
+  // of a raw mailbox row when there is no edge table, feature_getter.py:95-99): they are not loaded and not multiplied
+  int x_skip_at, x_skip_n;
 };
 
 int gru_launch(const GruArgs& g, hipStream_t st);

@@ -53,21 +53,52 @@ __global__ void k_fuse_vec2(int d, int kvw, int nh, float alpha, const float* __
   }
 }
 
+// Without an edge table the edge segment of every key row is zeros (feature_getter.py:95-99), so the columns of Wqk /
+// gconst and of W1f that meet it multiply zeros: the compact form drops them (kvw -> 2d per head) and the attention
+// block runs a third fewer flops.  full: [Wqk [nk, d] | gconst [nk] | W1f [d, nk + d] | b1 | c1], nk = nh kvw;
+// out: the same with nkc = nh (kvw - de).
+__global__ void k_fuse_compact(int d, int de, int nh, const float* __restrict__ full, float* __restrict__ out) {
+  const int kvw = 2 * d + de, kc = 2 * d, nk = nh * kvw, nkc = nh * kc;
+  auto src_col = [&](int cc) {  // compact key column -> full key column
+    const int h = cc / kc, c = cc % kc;
+    return h * kvw + (c < d ? c : c + de);
+  };
+  const float* wqk = full;
+  const float* gconst = wqk + (size_t)nk * d;
+  const float* w1f = gconst + nk;
+  const float* tailv = w1f + (size_t)d * (nk + d);  // b1 | c1
+  float* o_wqk = out;
+  float* o_gconst = o_wqk + (size_t)nkc * d;
+  float* o_w1f = o_gconst + nkc;
+  float* o_tail = o_w1f + (size_t)d * (nkc + d);
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = t0; t < (int64_t)nkc * d; t += nth) o_wqk[t] = wqk[(size_t)src_col((int)(t / d)) * d + t % d];
+  for (int64_t t = t0; t < nkc; t += nth) o_gconst[t] = gconst[src_col((int)t)];
+  for (int64_t t = t0; t < (int64_t)d * (nkc + d); t += nth) {
+    const int n = (int)(t / (nkc + d)), c = (int)(t % (nkc + d));
+    o_w1f[t] = w1f[(size_t)n * (nk + d) + (c < nkc ? src_col(c) : nk + (c - nkc))];
+  }
+  for (int64_t t = t0; t < 2 * d; t += nth) o_tail[t] = tailv[t];
+}
+
+size_t attn_fused_floats_of(size_t d, size_t nk) { return nk * d + nk + d * (nk + d) + 2 * d; }
+
 }  // namespace tg
 
 using namespace tg;
 
 extern "C" size_t tg_attn_fused_floats(const tg_model* m) {
   if (!attn_dims_ok(m)) return 0;
-  const size_t d = m->d, nk = (size_t)m->n_head * (2 * d + m->d_e);
-  return nk * d + nk + d * (nk + d) + 2 * d;
+  const size_t d = m->d, nk = (size_t)m->n_head * (2 * d + (m->efeats ? m->d_e : 0));  // compact without an edge table
+  return attn_fused_floats_of(d, nk);
 }
 
 extern "C" size_t tg_attn_fuse_workspace_bytes(const tg_model* m) {
   if (!attn_dims_ok(m)) return 0;
   const size_t d = m->d, E = 2 * d, nk = (size_t)m->n_head * (2 * d + m->d_e);
-  // qconst [E], c0 [E], Wov [E, nk], partials of the weight-gradient-style product
-  return align16(E * 4) * 2 + align16(E * nk * 4) + align16((size_t)16 * nk * (d + 1) * 4) + 256;
+  // qconst [E], c0 [E], Wov [E, nk], partials of the weight-gradient-style product, the full form before compaction
+  return align16(E * 4) * 2 + align16(E * nk * 4) + align16((size_t)16 * nk * (d + 1) * 4) +
+         align16(attn_fused_floats_of(d, nk) * 4) + 256;
 }
 
 extern "C" int tg_attn_fuse(const tg_model* m, float* fused, void* ws, size_t ws_bytes, void* stream) {
@@ -81,8 +112,10 @@ extern "C" int tg_attn_fuse(const tg_model* m, float* fused, void* ws, size_t ws
   float* wov = cv.take<float>((size_t)E * nk);
   const size_t part_floats = (size_t)16 * nk * (d + 1);
   float* part = cv.take<float>(part_floats);
+  const bool compact = m->efeats == nullptr;  // built in full into scratch, then the edge columns are dropped
+  float* full = compact ? cv.take<float>(attn_fused_floats_of(d, nk)) : fused;
   if (!cv.ok) return TG_EWORKSPACE;
-  float* wqk = fused;
+  float* wqk = full;
   float* gconst = wqk + (size_t)nk * d;
   float* w1f = gconst + nk;
   float* b1 = w1f + (size_t)d * (nk + d);
@@ -111,5 +144,7 @@ extern "C" int tg_attn_fuse(const tg_model* m, float* fused, void* ws, size_t ws
   if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
   hipLaunchKernelGGL(k_fuse_vec2, dim3((unsigned)cdiv(std::max(nk, d * d / 8), 256)), dim3(256), 0, st, d, kvw, nh, alpha,
                      m->attn_wk, qconst, m->attn_fc1.w, m->attn_fc1.b, c0, gconst, w1f, b1, c1);
+  if (compact)
+    hipLaunchKernelGGL(k_fuse_compact, dim3(256), dim3(256), 0, st, d, (int)m->d_e, nh, (const float*)full, fused);
   return check_launch("tg_attn_fuse");
 }

@@ -502,8 +502,11 @@ __device__ __forceinline__ void gru_tail16(const GruArgs& g, int tb, int j0, flo
   const int wj = min(j0 + (wl & 15), d - 1);
   const float* wx = g.w_ih + ((int64_t)(wl >> 4) * d + wj) * xw;
   const float* wh = g.w_hh + ((int64_t)(wl >> 4) * d + wj) * d;
-  const int nkx = (xw + BK - 1) / BK, nkh = (d + BK - 1) / BK;
+  const int nkx = (xw + BK - 1) / BK - g.x_skip_n, nkh = (d + BK - 1) / BK;  // message tiles that are processed
   const int nkt = nkx + nkh;
+  // processed message tile t holds k-tile t, or t + x_skip_n past the skipped run: a column shift on the ADDRESSES of
+  // those tiles (xs_sh), the k arithmetic itself runs on the compacted width xwe
+  const int xs_at = g.x_skip_at, xs_sh = g.x_skip_n * BK, xwe = xw - xs_sh;
   struct Stage {
     float4 a0, a1, b;
   };
@@ -511,14 +514,14 @@ __device__ __forceinline__ void gru_tail16(const GruArgs& g, int tb, int j0, flo
     t = min(t, nkt - 1);
     const bool hp = t >= nkx;
     const int k = (hp ? t - nkx : t) * BK + ac4;
-    const int kc = k < (hp ? d : xw) ? k : 0;
+    const int kc = (k < (hp ? d : xwe) ? k : 0) + ((!hp && t >= xs_at) ? xs_sh : 0);
     r.a0 = ldg4((hp ? hrow[0] : xrow[0]) + kc);
     r.a1 = ldg4((hp ? hrow[1] : xrow[1]) + kc);
     r.b = ldg4((hp ? wh : wx) + kc);
   };
   auto store_tile = [&](int buf, int t, const Stage& r) {
     const bool hp = t >= nkx;
-    const bool kin = (hp ? t - nkx : t) * BK + ac4 < (hp ? d : xw);
+    const bool kin = (hp ? t - nkx : t) * BK + ac4 < (hp ? d : xwe);
     sts4(As[buf][ar], ac4, kin ? r.a0 : zero4());
     if (ar + 96 < T16_ROWS) sts4(As[buf][ar + 96], ac4, kin ? r.a1 : zero4());
     if (ar < 48) sts4(Bs[buf][ar], ac4, kin ? r.b : zero4());
@@ -720,8 +723,11 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
     xrow[i] = g.x.p + (g.x.idx ? g.x.idx[m] : m) * g.x.ld;
     hrow[i] = g.h.p + (g.h.idx ? g.h.idx[m] : m) * g.h.ld;
   }
-  const int nkx = (xw + BK - 1) / BK, nkh = (d + BK - 1) / BK;
+  const int nkx = (xw + BK - 1) / BK - g.x_skip_n, nkh = (d + BK - 1) / BK;  // message tiles that are processed
   const int nkt = nkx + nkh;
+  // processed message tile t holds k-tile t, or t + x_skip_n past the skipped run: a column shift on the ADDRESSES of
+  // those tiles (xs_sh), the k arithmetic itself runs on the compacted width xwe
+  const int xs_at = g.x_skip_at, xs_sh = g.x_skip_n * BK, xwe = xw - xs_sh;
   float4 ra0[NA], rb0[NBL], ra1[NA], rb1[NBL];
   const int fr = lane & 31, fk = lane >> 5;
   f32x16 acc_r, acc_z, acc_in, acc_hn;
@@ -752,8 +758,8 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
   auto load_one = [&](int t, int i, float4* ra, float4* rb) {  // i-th staged float4 of tile t
     const bool hp = t >= nkx;
     const int k = (hp ? t - nkx : t) * BK + ac4;
-    const int width = hp ? d : xw;
-    const int kc = k < width ? k : 0;
+    const int width = hp ? d : xw;  // row stride of the weight operand
+    const int kc = (k < (hp ? d : xwe) ? k : 0) + ((!hp && t >= xs_at) ? xs_sh : 0);
     // raw load from a clamped address; columns past the segment are zeroed when the tile is
     // written to LDS (store_one), so nothing consumes the load result here
     if (i < NA) {
@@ -766,7 +772,7 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
   };
   auto store_one = [&](int buf, int t, int i, const float4* ra, const float4* rb) {  // tile t's i-th float4
     const bool hp = t >= nkx;
-    const bool kin = (hp ? t - nkx : t) * BK + ac4 < (hp ? d : xw);
+    const bool kin = (hp ? t - nkx : t) * BK + ac4 < (hp ? d : xwe);
     if (i < NA) {
       sts4(As[buf][ar + i * RP], ac4, kin ? ra[i] : zero4());
     } else {

@@ -408,7 +408,7 @@ struct FusedView {
 static FusedView fused_view(const tg_model* m, const float* f) {
   FusedView v{};
   const int d = m->d;
-  v.nk = m->n_head * (2 * d + m->d_e);
+  v.nk = m->n_head * (2 * d + (m->efeats ? m->d_e : 0));  // compact form without an edge table (tg_fuse.hip)
   v.wqk = f;
   v.gconst = v.wqk + (size_t)v.nk * d;
   v.w1f = v.gconst + v.nk;
@@ -479,7 +479,9 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
   if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
   prof_mark(pf, stage++, st);
   prof_mark(pf, stage++, st);
-  launch_attn_core(m, Q, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, w, DropCfg{}, st, &rc, da ? 1 : 0, da ? pos : nullptr);
+  tg_model mc = *m;  // without an edge table the fused weights are compact: the key rows have no edge segment
+  if (!m->efeats) mc.d_e = 0;
+  launch_attn_core(&mc, Q, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, w, DropCfg{}, st, &rc, da ? 1 : 0, da ? pos : nullptr);
   if (rc != TG_OK) return rc;
   prof_mark(pf, stage++, st);
   prof_mark(pf, stage++, st);
@@ -639,6 +641,12 @@ int apply_messages(const tg_model* m, const int64_t* outdated, const int32_t* ou
     a.cap = cap; a.n_dev = n_dev; a.d = d; a.xw = mw; a.x = x; a.h = h;
     a.w_ih = m->gru_w_ih; a.w_hh = m->gru_w_hh; a.b_ih = m->gru_b_ih; a.b_hh = m->gru_b_hh;
     a.out = reprs; a.ldo = d; a.out_rows = out_pos; a.gates = gates;
+    if (!m->efeats && m->tsfm == TG_TSFM_ID) {
+      // raw mailbox rows [own | other | edge | time] without an edge table: the edge segment [2d, 2d + d_e) is zeros
+      // (memory.py:91 over feature_getter.py:95-99); the k-tiles that lie entirely inside it are skipped
+      const int first = (2 * d + 31) / 32, last = (2 * d + m->d_e) / 32;  // tiles [first, last) are inside
+      if (last > first) { a.x_skip_at = first; a.x_skip_n = last - first; }
+    }
     a.rows_hint = std::min<int64_t>(cap, m->n_nodes);
     if (rows_bound > 0) a.rows_hint = std::min<int64_t>(a.rows_hint, rows_bound);  // the caller's bound on the live rows
     return gru_launch(a, st);
