@@ -162,6 +162,9 @@ __device__ __forceinline__ RowVec<W> row_load(const float* __restrict__ row, int
   if (W == 4) {
     const float4 v = col < width ? *reinterpret_cast<const float4*>(row + col) : make_float4(0.f, 0.f, 0.f, 0.f);
     r.a[0] = v.x; r.a[1] = v.y; r.a[2] = v.z; r.a[W - 1] = v.w;
+  } else if (W == 2) {  // rows are 16-byte aligned and widths multiples of 4: an 8-byte access never straddles the row end
+    const float2 v = col < width ? *reinterpret_cast<const float2*>(row + col) : make_float2(0.f, 0.f);
+    r.a[0] = v.x; r.a[W - 1] = v.y;
   } else if (W == 3) {
     if (col + 3 <= width) {
       const F3 v = *reinterpret_cast<const F3*>(row + col);
@@ -180,6 +183,8 @@ template <int W>
 __device__ __forceinline__ void row_store(float* __restrict__ row, int col, int width, const RowVec<W>& r) {
   if (W == 4) {
     if (col < width) *reinterpret_cast<float4*>(row + col) = make_float4(r.a[0], r.a[1], r.a[2], r.a[W - 1]);
+  } else if (W == 2) {
+    if (col < width) *reinterpret_cast<float2*>(row + col) = make_float2(r.a[0], r.a[W - 1]);
   } else if (W == 3 && col + 3 <= width) {
     F3 v;
     v.x = r.a[0]; v.y = r.a[1]; v.z = r.a[W - 1];
@@ -431,13 +436,19 @@ void launch_attn_core(const tg_model* m, int64_t Q, const float* ts, const int64
     const int nv3 = (int)cdiv(cdiv(wmax, 3), TG_WAVE);
     static const int w_knob = getenv("TG_ATTN_W") ? atoi(getenv("TG_ATTN_W")) : 0;  // tuning knob: 3, default 4
     if (nv3 == 1 && w_knob == 3) { W = 3; nv = 1; }
+    // narrow rows (d <= 128, e.g. LastFM's --dim 100): two columns per lane instead of four fill 50 lanes instead of 25;
+    // the kernel is bound by per-key VALU work and latency there, not by bytes (8-byte accesses stay sector aligned)
+    if (wmax <= 128 && w_knob != 4 && w_knob != 3) { W = 2; nv = 1; }
   }
   const unsigned cgrid = flat_grid(Q, 4);
 #define TG_CORE(NH_, NV_, W_)                                                                                      \
   hipLaunchKernelGGL((k_attn_core<NH_, NV_, W_>), dim3(cgrid), dim3(256), 0, st, *m, Q, ts, l1_nids, l1_eids,      \
                      l1_ts, reprs, bm, rank, (const float*)w.g, w.s, w.valid, dc,                                  \
                      dc.p > 0.f ? w.rsum : (float*)nullptr, direct, pos ? *pos : PosArgs{})
-  if (nh == 2 && nv == 1 && W == 3) TG_CORE(2, 1, 3);
+  if (nh == 2 && nv == 1 && W == 2) TG_CORE(2, 1, 2);
+  else if (nh == 1 && nv == 1 && W == 2) TG_CORE(1, 1, 2);
+  else if (nh == 4 && nv == 1 && W == 2) TG_CORE(4, 1, 2);
+  else if (nh == 2 && nv == 1 && W == 3) TG_CORE(2, 1, 3);
   else if (nh == 1 && nv == 1 && W == 3) TG_CORE(1, 1, 3);
   else if (nh == 4 && nv == 1 && W == 3) TG_CORE(4, 1, 3);
   else if (nh == 2 && nv == 1) TG_CORE(2, 1, 4);
