@@ -275,7 +275,7 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     torch.cuda.set_device(0)
     dev = torch.device('cuda', 0)
     B, K, d = cfg['B'], cfg['K'], cfg['d']
-    n_batches = preroll + warmup + steps + n_prof + 2
+    n_batches = preroll + warmup + steps + n_prof + 6  # + 4 batches for the copy-form gather timing, + 2 spare
     E = max(cfg['E'], n_batches * B)
     no_feats = bool(cfg.get('no_feats'))
     stream = make_stream(cfg['n_u'], cfg['n_i'], E, cfg['T'] * E / cfg['E'], seed=0, d_e=d,
@@ -289,6 +289,8 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     if eager:   # ... and the updater run once per stored message (TIGE.eager_updates)
         model.eager_updates()
     buf = model.StepBuffers(model, B, False, resident=resident)
+    if args.eager_copy:
+        buf.io.eager_copy = 1
     restart_prob = float(cfg.get('restart_prob', 0.0))
     n_trig = 0
     if restart_prob > 0:  # train_self_supervised.py:153: one uniform draw per batch, never before batch 0
@@ -340,7 +342,7 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     work = stage_work(cfg, U, O_, P, eager, fused, stream['n_nodes'], E)
     traffic = load_traffic(traffic_tag)
     empty = {'zero_flags', 'dedup_positive', 'restarter_targets', 'apply_messages(gru)' if eager else 'eager_updater(gru)'}
-    direct = eager and os.environ.get('TG_EAGER_DIRECT', '1') != '0'  # no compact copy of the involved rows
+    direct = eager and os.environ.get('TG_EAGER_DIRECT', '1') != '0' and not args.eager_copy  # no compact copy
     if direct:  # ... and STEP 4-6 are one launch (reported under writeback_phase1)
         empty |= {'gather_right_memory', 'writeback_phase0'}
         w0, w1 = work['writeback_phase0'], work['writeback_phase1']
@@ -355,7 +357,7 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
                            upd_src=cfg['upd_src'], n_nodes=stream['n_nodes'], events=E, mode='stream (no_grad) STEP 1-6',
                            launch='hipGraph replay' if graph is not None else 'eager',
                            attention_weights='pre-multiplied (tg_attn_fuse)' if fused else 'as stored',
-                           updater=('eager: once per stored message (TIGE.eager_updates)' + (', rows read from the tables directly' if eager and os.environ.get('TG_EAGER_DIRECT', '1') != '0' else ', compact reprs copy')) if eager else
+                           updater=('eager: once per stored message (TIGE.eager_updates)' + (', rows read from the tables directly' if direct else ', compact reprs copy')) if eager else
                                    'lazy: on the fly for every involved node with a pending message',
                            state_preroll_batches=preroll, involved_per_batch=float(U), outdated_per_batch=float(O_),
                            unique_pos_per_batch=float(P)),
@@ -373,16 +375,32 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
         'eager_updater(gru)' if eager else 'apply_messages(gru)'
     mg = roofline_of(g_name, stages[g_name], work, traffic)
     if direct:
-        mg['note'] = ('eager updates, direct form: STEP 1-2 leave no gather launch; the involved rows are gathered once, by the '
-                      'attention core, from pending / right by node id (algorithmic bytes = U unique rows + the per-centre '
-                      'G / S streams + feature rows)')
+        # the direct form fuses the gather into the attention core.  The stand-alone memory-gather launch (the copy form of
+        # the same step: tg_step_io.eager_copy, reprs[u] = pending-or-right row) is timed on a few more batches of the
+        # stream so that the HBM-roofline figure of THAT kernel sits next to the fused one
+        buf.io.eager_copy = 1
+        n2, st2, c2 = profile_stages(model, buf, 4)
+        buf.io.eager_copy = 0
+        assert int(buf.err.item()) == 0
+        U2, O2 = c2[0], c2[1]
+        t2 = float(st2[n2.index('gather_right_memory')])
+        b2 = 2.0 * 4 * d * U2 + 12 * O2
+        mg = dict(bound='hbm', kernel='gather_right_memory', device_kernel='tg::k_consume_gather_check<true>',
+                  achieved=b2 / (t2 * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s', frac=b2 / (t2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  traffic=kernel_traffic(load_traffic(traffic_tag + '_copy'), 'tg::k_consume_gather_check'), avg_ms=t2,
+                  algorithmic_bytes=float(b2),
+                  note='stand-alone gather launch of the copy form of the eager step (tg_step_io.eager_copy = 1), timed on 4 '
+                       'further batches; the benchmarked step is the direct form, in which the attention core gathers these rows '
+                       'itself (no reprs copy): fused_into = that launch on the same roofline',
+                  fused_into=roofline_of(g_name, stages[g_name], work, traffic))
     mw = 4 * d
     not_right = 0 if cfg['upd_src'] == 'right' else 1
     survey_bytes = U * 4 * d + O_ * (4 * mw + 4) + O_ * (4 * d + 4) * not_right + U * 4 * d
-    t_both = (stages[g_name] + stages[u_name]) * 1e-3
+    t_gather = mg['avg_ms'] if direct else stages[g_name]
+    t_both = (t_gather + stages[u_name]) * 1e-3
     mg['survey_bytes_gather'] = dict(
         formula='U*4d + O*(16d+4) + O*(4d+4)*[upd_src != right] + U*4d  (SURVEY.md s8 d)', bytes=float(survey_bytes),
-        kernels=[g_name, u_name], ms=float(stages[g_name] + stages[u_name]),
+        kernels=['gather_right_memory', u_name], ms=float(t_gather + stages[u_name]),
         gbs=survey_bytes / t_both / 1e9, frac=survey_bytes / t_both / 1e9 / HBM_PEAK_GBS,
         note='the mailbox / updater-source rows are gathered inside the updater launch, which is MFMA-bound'
              + (' and, with eager updates, runs on the P nodes that received a message instead of the O nodes that hold one' if eager else ''))
@@ -484,6 +502,8 @@ def main():
                     help='multi-GPU: weak = B events per rank per step, strong = the global batch stays B')
     ap.add_argument('--no-fuse', action='store_true', help='keep the six-product attention (no tg_attn_fuse)')
     ap.add_argument('--no-eager', action='store_true', help='updater on the fly for every involved node (no eager_updates)')
+    ap.add_argument('--eager-copy', action='store_true',
+                    help='eager updates with the compact copy of the involved rows (stand-alone gather launch) instead of the direct form')
     ap.add_argument('--train', action='store_true', help='measure the training iteration instead (not the headline metric)')
     ap.add_argument('--train-restarter', default='none', choices=['none', 'seq', 'static'],
                     help='--train: add the mutual-learning loss of this restarter (none = contrast_only)')

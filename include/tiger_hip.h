@@ -416,7 +416,10 @@ typedef struct tg_step_io {
    * the outputs, no state is read or written, h may be NULL.  The partitioned multi-GPU path uses it to learn
    * which rows a rank must pull from their owners before it embeds (www2023tiger_amd/dist.py). */
   int32_t collate_only;
-  int32_t reserved2;
+  /* eager_copy != 0 (only meaningful with tg_model.pending_vals): keep the compact copy of the involved rows - STEP 1-2
+   * as ONE stand-alone gather launch into reprs - instead of letting the attention launches read pending / right by
+   * node id (the default "direct" form, one launch and one row copy fewer).  Same results. */
+  int32_t eager_copy;
 } tg_step_io;
 
 /* The reference loop draws `np.random.rand() < restart_prob` before every batch but the first; a hit sets

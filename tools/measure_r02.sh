@@ -28,6 +28,11 @@ for W in c2 c5s; do
   python $R/tools/pmc_traffic.py $F $Wf $O/r02_hbm_traffic_${W}.json | grep -i "gru\|attn_core\|gather" || true
   cp $F $O/r02_pmc_FETCH_SIZE_${W}_$TAG.csv; cp $Wf $O/r02_pmc_WRITE_SIZE_${W}_$TAG.csv
 done
+# the copy form of the eager step (stand-alone memory-gather launch) at C5 shape: traffic of that kernel
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f_copy -o f -- python $R/bench.py --workload c5s --steps 4 --warmup 4 --preroll 16 --no-cpu-baseline --no-graph --eager-copy > $O/pmc_f_copy.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w_copy -o w -- python $R/bench.py --workload c5s --steps 4 --warmup 4 --preroll 16 --no-cpu-baseline --no-graph --eager-copy > $O/pmc_w_copy.log 2>&1
+python $R/tools/pmc_traffic.py $(find $O/pmc_f_copy -name '*counter_collection.csv' | head -1) $(find $O/pmc_w_copy -name '*counter_collection.csv' | head -1) $O/r02_hbm_traffic_c5s_copy.json | grep -i "gather" || true
+rm -rf $O/pmc_f_copy $O/pmc_w_copy
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_m -o m -- python $R/bench.py --steps 10 --warmup 25 --preroll 100 --no-cpu-baseline --no-graph --no-c5s-leg > $O/pmc_m.log 2>&1 || true
 cp $(find $O/pmc_m -name '*counter_collection.csv' | head -1) $O/r02_pmc_mfma_c2_$TAG.csv 2>/dev/null || true
 rm -rf $O/prof_c2 $O/prof_c5s $O/pmc_f_* $O/pmc_w_* $O/pmc_m; echo done

@@ -946,7 +946,7 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   // eager updates, direct form (default; TG_EAGER_DIRECT=0 keeps the compact copy): centres and neighbour rows are read
   // from pending / right themselves, so there is no gather launch and no reprs buffer
   static const int direct_knob = getenv("TG_EAGER_DIRECT") ? atoi(getenv("TG_EAGER_DIRECT")) : 1;
-  w.direct = eager && direct_knob != 0;
+  w.direct = eager && direct_knob != 0 && !io->eager_copy;
   // the one-launch write-back needs the snapshot; the restarter targets (h_prev_*) are read between STEP 4 and STEP 6,
   // so a step that outputs them keeps the two-phase write-back
   w.fused_wb = w.direct && !io->embed_only && !io->h_prev_left && !io->h_prev_right;
