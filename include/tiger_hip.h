@@ -301,6 +301,16 @@ int tg_temporal_attn_fwd(const tg_model* m, int64_t Q, const int64_t* nids, cons
                          const float* reprs, const uint64_t* bitmap, const uint32_t* rank, float* out,
                          void* ws, size_t ws_bytes, void* stream);
 
+/* The FIRST attention layer of --n_layers 2 (temporal_agg_modules.py:29-83 at depth == n_layers; weights fns[0]):
+ * the node part of key k of centre i is key_rows[i*K + k, :] - the embedding of that neighbour computed by the layer
+ * below (tg_temporal_attn_fwd on the Q*K neighbours as centres with the weights of fns[1], hop-2 neighbours sampled at
+ * the neighbours' timestamps, data_loader.py:131, query time = the root's, :63) - instead of its memory row + node
+ * features; edge features, time encoding and the padding mask (l1_nids == 0) are as in tg_temporal_attn_fwd. */
+int tg_temporal_attn_fwd_keys(const tg_model* m, int64_t Q, const int64_t* nids, const float* ts,
+                              const int64_t* l1_nids, const int64_t* l1_eids, const float* l1_ts,
+                              const float* reprs, const uint64_t* bitmap, const uint32_t* rank,
+                              const float* key_rows, float* out, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------- */
 /* STEP 4-6: write-back (tiger.py:229-255,396-442; memory.py:77-106)          */
 /* ------------------------------------------------------------------------- */

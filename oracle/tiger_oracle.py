@@ -168,17 +168,25 @@ def anonymized_reindex(hist_nids: np.ndarray) -> np.ndarray:
 # Collation (tiger/data/data_loader.py:43-168, data_classes.py:150-165)
 # =============================================================================
 def collate(graph: OracleGraph, src, dst, neg, ts, n_neighbors: int, restarter: str,
-            hist_len: Optional[int] = None) -> Dict[str, np.ndarray]:
-    """One batch of GraphCollator.__call__ for n_layers == 1 (data_loader.py:77-93)."""
+            hist_len: Optional[int] = None, n_layers: int = 1) -> Dict[str, np.ndarray]:
+    """One batch of GraphCollator.__call__ (data_loader.py:77-93) for n_layers 1 or 2."""
     src, dst, neg = (np.asarray(x, dtype=np.int64) for x in (src, dst, neg))
     ts = np.asarray(ts, dtype=np.float64)
     nids3 = np.concatenate([src, dst, neg])
     ts3 = np.tile(ts, 3)
     l1_n, l1_e, l1_t, _ = graph.sample_temporal_neighbor(nids3, ts3, n_neighbors)  # :128
-    involved = np.unique(np.concatenate([nids3, l1_n.ravel()]))  # :109-121 (sorted set)
+    seen = [nids3, l1_n.ravel()]
+    out = {}
+    if n_layers == 2:  # :131 the next hop is sampled at the NEIGHBOURS' (float32) timestamps
+        h2_n, h2_e, h2_t, _ = graph.sample_temporal_neighbor(l1_n.ravel(), l1_t.ravel(), n_neighbors)
+        seen.append(h2_n.ravel())
+        out.update(hop2_nids=h2_n, hop2_eids=h2_e, hop2_ts=h2_t)
+    elif n_layers != 1:
+        raise NotImplementedError('n_layers in (1, 2)')
+    involved = np.unique(np.concatenate(seen))  # :109-121 (sorted set)
     local_index = np.zeros(graph.num_node, dtype=np.int64)  # data_classes.py:163-165
     local_index[involved] = np.arange(len(involved))
-    out = dict(l1_nids=l1_n, l1_eids=l1_e, l1_ts=l1_t, involved=involved, local_index=local_index)
+    out.update(l1_nids=l1_n, l1_eids=l1_e, l1_ts=l1_t, involved=involved, local_index=local_index)
     # restart data (:133-168) on cat[src,dst], tile(ts,2) with float64 timestamps
     pos = np.concatenate([src, dst])
     ts2 = np.tile(ts, 2)
@@ -392,20 +400,37 @@ class OracleTIGER:
         return outdated, self.updater(old, msgs), mts
 
     # ---- STEP 3 (temporal_agg_modules.py:29-83, 210-235) ---------------------
-    def embed(self, reprs, local_index, nids3, ts3, l1_nids, l1_eids, l1_ts):
+    def embed(self, reprs, local_index, nids3, ts3, l1_nids, l1_eids, l1_ts, hop2=None):
+        """temporal_agg_modules.py:29-83.  hop2 = (nids, eids, ts) [Q*K, K] for n_layers == 2: the neighbours are then
+        embedded first (with the LAST attention layer, fns[n_layers - depth], at the ROOT's query time, :63) and their
+        embeddings take the place of reprs + node features in the keys of the first layer."""
         if len(nids3) > EMBED_CHUNK and self._drop(1) is None:
             # every centre is embedded independently of the others: large batches go through in slices so that
             # the [Q, K, 3d] key tensors of a 65 536-event batch do not have to exist at once
+            K = l1_nids.shape[1]
             parts = [self.embed(reprs, local_index, nids3[a:a + EMBED_CHUNK], ts3[a:a + EMBED_CHUNK],
-                                l1_nids[a:a + EMBED_CHUNK], l1_eids[a:a + EMBED_CHUNK], l1_ts[a:a + EMBED_CHUNK])
+                                l1_nids[a:a + EMBED_CHUNK], l1_eids[a:a + EMBED_CHUNK], l1_ts[a:a + EMBED_CHUNK],
+                                None if hop2 is None else tuple(x[a * K:(a + EMBED_CHUNK) * K] for x in hop2))
                      for a in range(0, len(nids3), EMBED_CHUNK)]
             return torch.cat(parts, 0)
-        pre = 'temporal_embedding_fn.fns.0.'
-        c = reprs[_t(local_index[nids3])] + self.node_feat(_t(nids3))
-        ln = _t(l1_nids)
-        nb = reprs[_t(local_index[l1_nids])] + self.node_feat(ln)
-        ef = self.edge_feat(_t(l1_eids))
-        delta = ts3[:, None] - _t(l1_ts)
+        rows = lambda ids: reprs[_t(local_index[ids])] + self.node_feat(_t(ids))
+        c = rows(nids3)
+        if hop2 is None:
+            nb = rows(l1_nids)
+        else:
+            K = l1_nids.shape[1]
+            h2_n, h2_e, h2_t = hop2
+            inner = self._attend('temporal_embedding_fn.fns.1.', rows(l1_nids.ravel()), ts3.repeat_interleave(K),
+                                 rows(h2_n), h2_n, h2_e, h2_t)
+            nb = inner.reshape(len(nids3), K, self.d)
+        return self._attend('temporal_embedding_fn.fns.0.', c, ts3, nb, l1_nids, l1_eids, l1_ts)
+
+    def _attend(self, pre, c, ts, nb, l_nids, l_eids, l_ts):
+        """one TemporalAttention layer (temporal_agg_modules.py:52-81,210-235): centre rows c [n, d] at times ts,
+        key node rows nb [n, K, d], edge ids / times of the keys, padding mask from l_nids == 0"""
+        ln = _t(l_nids)
+        ef = self.edge_feat(_t(l_eids))
+        delta = ts[:, None] - _t(l_ts)
         kt = self.te(delta)
         qt = self.te(torch.zeros_like(delta[:, 0]))
         mask = (ln == 0)
@@ -455,7 +480,8 @@ class OracleTIGER:
         reprs = self.right_vals[_t(involved)].clone()  # STEP 2 (always the right memory)
         if len(outdated):
             reprs[_t(cg['local_index'][outdated])] = h_new
-        h = self.embed(reprs, cg['local_index'], nids3, ts.repeat(3), cg['l1_nids'], cg['l1_eids'], cg['l1_ts'])
+        hop2 = (cg['hop2_nids'], cg['hop2_eids'], cg['hop2_ts']) if 'hop2_nids' in cg else None
+        h = self.embed(reprs, cg['local_index'], nids3, ts.repeat(3), cg['l1_nids'], cg['l1_eids'], cg['l1_ts'], hop2)
         if len(outdated):  # STEP 4
             upos, _ = select_latest_nids(pos, ts.repeat(2).numpy())
             where = np.searchsorted(outdated, upos)

@@ -9,6 +9,7 @@ from golden._weights import golden_param
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 MODEL_FIXTURES = ['seq_lr_d8', 'static_ll_d16', 'seq_rr_d8_nofeat', 'static_ll_d172', 'seq_lr_d172',
                   'mlp_merge_d8', 'linear_gru_d8']
+TWO_LAYER_FIXTURES = ['static_lr_d8_L2', 'seq_ll_d16_L2']  # --n_layers 2 (hop-2 sampled at the neighbours' timestamps)
 
 
 def load(name):

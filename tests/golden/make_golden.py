@@ -150,7 +150,7 @@ def build_reference_model(cfg, nfeats, efeats, graph, n_edges, dropout=0.1):
     else:
         rst = StaticRestarter(raw_feat_getter=fg, graph=graph)
     model = TIGER(raw_feat_getter=fg, graph=graph, restarter=rst, n_neighbors=cfg['K'],
-                  hit_type=cfg.get('hit', 'bin'), n_layers=1, n_head=2, dropout=dropout,
+                  hit_type=cfg.get('hit', 'bin'), n_layers=cfg.get('L', 1), n_head=2, dropout=dropout,
                   msg_src=cfg['msg_src'], upd_src=cfg['upd_src'],
                   msg_tsfm_type=cfg.get('tsfm', 'id'), mem_update_type=cfg.get('upd_fn', 'gru'),
                   tgn_mode=True, msg_last_only=True)
@@ -196,7 +196,8 @@ def gen_model(name, cfg):
     data = InteractionData(src, dst, ts, eids, labels, seed=0, eval=True, neg_dst=neg)
     graph = Graph.from_data(data, strategy='recent_edges', seed=0)
     model, pnames, pshapes = build_reference_model(cfg, nfeats, efeats, graph, E)
-    collator = GraphCollator(graph, cfg['K'], 1, restarter=cfg['restarter'], hist_len=cfg.get('H'))
+    L = cfg.get('L', 1)  # embedding layers: layers[L] are the neighbours of the batch nodes, layers[1] the deepest hop
+    collator = GraphCollator(graph, cfg['K'], L, restarter=cfg['restarter'], hist_len=cfg.get('H'))
 
     out = {'versions': VERSIONS, 'src': src, 'dst': dst, 'ts': ts, 'eids': eids, 'neg': neg,
            'n_nodes': np.int64(n_nodes), 'param_names': np.array(pnames),
@@ -219,9 +220,13 @@ def gen_model(name, cfg):
             s, dd, ng, t, ee, _, cg = collator(batch)
             tag = f'b{b}'
             # ---- collator outputs
-            out[f'{tag}_l1_nids'] = cg.layers[1][0].numpy().copy()
-            out[f'{tag}_l1_eids'] = cg.layers[1][1].numpy().copy()
-            out[f'{tag}_l1_ts'] = cg.layers[1][2].numpy().copy()
+            out[f'{tag}_l1_nids'] = cg.layers[L][0].numpy().copy()
+            out[f'{tag}_l1_eids'] = cg.layers[L][1].numpy().copy()
+            out[f'{tag}_l1_ts'] = cg.layers[L][2].numpy().copy()
+            for depth in range(1, L):  # deeper hops, sampled at the neighbours' timestamps (data_loader.py:131)
+                out[f'{tag}_hop{L - depth + 1}_nids'] = cg.layers[depth][0].numpy().copy()
+                out[f'{tag}_hop{L - depth + 1}_eids'] = cg.layers[depth][1].numpy().copy()
+                out[f'{tag}_hop{L - depth + 1}_ts'] = cg.layers[depth][2].numpy().copy()
             out[f'{tag}_involved'] = cg.np_computation_graph_nodes.copy()
             rd = cg.restart_data
             out[f'{tag}_rd_index'] = rd.index.numpy().copy()
@@ -560,6 +565,11 @@ SCENARIOS = {
                          restarter='seq', msg_src='left', upd_src='right', tsfm='mlp', upd_fn='merge'),
     'linear_gru_d8': dict(d=8, n_u=30, n_i=12, E=300, T=200.0, B=30, n_batches=6, K=5, seed=7, wseed=7,
                           restarter='static', msg_src='right', upd_src='left', tsfm='linear', hit='vec'),
+    # --n_layers 2: hop-2 sampled at the neighbours' timestamps, two attention layers
+    'static_lr_d8_L2': dict(d=8, n_u=30, n_i=12, E=360, T=240.0, B=30, n_batches=8, K=4, L=2, seed=8, wseed=8,
+                            restarter='static', msg_src='left', upd_src='right', restart_at=5),
+    'seq_ll_d16_L2': dict(d=16, n_u=40, n_i=15, E=300, T=200.0, B=40, n_batches=5, K=5, H=6, L=2, seed=9, wseed=9,
+                          nfeat='zero', restarter='seq', msg_src='left', upd_src='left'),
 }
 
 if __name__ == '__main__':

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import (MODEL_FIXTURES, assert_close, fixture_params, fixture_tables, load, n_batches, parse_cfg, rel_err,
+from _util import (MODEL_FIXTURES, TWO_LAYER_FIXTURES, assert_close, fixture_params, fixture_tables, load, n_batches, parse_cfg, rel_err,
                    row_rel_err)
 
 pytestmark = pytest.mark.gpu
@@ -38,7 +38,7 @@ def build_hip_model(z, cfg, strategy='recent_edges', dropout=0.1):
     else:
         rst = StaticRestarter(raw_feat_getter=fg, graph=g)
     model = TIGER(raw_feat_getter=fg, graph=g, restarter=rst, n_neighbors=cfg['K'], hit_type=cfg.get('hit', 'bin'),
-                  n_layers=1, n_head=2, dropout=dropout, msg_src=cfg['msg_src'], upd_src=cfg['upd_src'],
+                  n_layers=cfg.get('L', 1), n_head=2, dropout=dropout, msg_src=cfg['msg_src'], upd_src=cfg['upd_src'],
                   msg_tsfm_type=cfg.get('tsfm', 'id'), mem_update_type=cfg.get('upd_fn', 'gru'))
     params = fixture_params(z, cfg)
     own = dict(model.named_parameters())
@@ -47,7 +47,7 @@ def build_hip_model(z, cfg, strategy='recent_edges', dropout=0.1):
         for k, v in params.items():
             own[k].copy_(torch.from_numpy(v))
     model = model.to(dev()).eval()
-    coll = GraphCollator(g, cfg['K'], 1, restarter=cfg['restarter'], hist_len=cfg.get('H'))
+    coll = GraphCollator(g, cfg['K'], cfg.get('L', 1), restarter=cfg['restarter'], hist_len=cfg.get('H'))
     return model, g, coll
 
 
@@ -194,20 +194,24 @@ def test_time_encode_rounding():
 
 
 # ------------------------------------------------------------------------------ collation
-@pytest.mark.parametrize('name', MODEL_FIXTURES)
+@pytest.mark.parametrize('name', MODEL_FIXTURES + TWO_LAYER_FIXTURES)
 def test_collator_bit_exact(name):
     z = load(name)
     cfg = parse_cfg(z)
     _, g, coll = build_hip_model(z, cfg)
-    B = cfg['B']
+    B, L = cfg['B'], cfg.get('L', 1)
     for b in range(n_batches(z)):
         sl = slice(b * B, min((b + 1) * B, len(z['src'])))
         out = coll.collate_arrays(*(z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')))
         cg = out[-1]
         tag = f'b{b}'
-        np.testing.assert_array_equal(cg.layers[1][0].cpu().numpy(), z[f'{tag}_l1_nids'])
-        np.testing.assert_array_equal(cg.layers[1][1].cpu().numpy(), z[f'{tag}_l1_eids'])
-        np.testing.assert_array_equal(cg.layers[1][2].cpu().numpy(), z[f'{tag}_l1_ts'])
+        assert len(cg.layers) == L + 1
+        np.testing.assert_array_equal(cg.layers[L][0].cpu().numpy(), z[f'{tag}_l1_nids'])
+        np.testing.assert_array_equal(cg.layers[L][1].cpu().numpy(), z[f'{tag}_l1_eids'])
+        np.testing.assert_array_equal(cg.layers[L][2].cpu().numpy(), z[f'{tag}_l1_ts'])
+        if L == 2:  # the deepest hop, sampled at the neighbours' float32 timestamps (data_loader.py:131)
+            for j, nm in enumerate(('nids', 'eids', 'ts')):
+                np.testing.assert_array_equal(cg.layers[1][j].cpu().numpy(), z[f'{tag}_hop2_{nm}'], err_msg=nm)
         np.testing.assert_array_equal(cg.np_computation_graph_nodes, z[f'{tag}_involved'])
         li = cg.local_index.cpu().numpy()
         np.testing.assert_array_equal(li[z[f'{tag}_involved']], np.arange(len(z[f'{tag}_involved'])))
@@ -303,14 +307,14 @@ def run_stream(name, fused, op_path=False, eager=False):
     check_state(model, z, 'flushed')
 
 
-@pytest.mark.parametrize('name', MODEL_FIXTURES)
+@pytest.mark.parametrize('name', MODEL_FIXTURES + TWO_LAYER_FIXTURES)
 def test_stream_reference_api(name):
     """GraphCollator -> TIGER.contrast_learning / restart / flush_msg, the reference's call sequence
     (evaluation takes the one-call step where the configuration allows it)."""
     run_stream(name, fused=False)
 
 
-@pytest.mark.parametrize('name', MODEL_FIXTURES)
+@pytest.mark.parametrize('name', MODEL_FIXTURES + TWO_LAYER_FIXTURES)
 def test_stream_reference_api_operator_path(name):
     """the same sequence with every reference method bound to its own C entry point"""
     run_stream(name, fused=False, op_path=True)
@@ -322,6 +326,23 @@ def test_stream_fused_step(name, eager):
     """tg_stream_step (collate + STEP 1-6 behind one C call), the benchmarked path; `eager`: with the updater
     run once per stored message (TIGE.eager_updates) instead of on the fly for every involved node."""
     run_stream(name, fused=True, eager=eager)
+
+
+def test_two_layer_model_refuses_the_one_layer_fast_paths():
+    """--n_layers 2 runs on the operator path; the fused step, the pre-multiplied weights and the device training step
+    are built for one layer and say so instead of computing something else"""
+    z = load('static_lr_d8_L2')
+    cfg = parse_cfg(z)
+    model, _, coll = build_hip_model(z, cfg)
+    a = [z[k][:cfg['B']] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+    with pytest.raises(NotImplementedError):
+        model.stream_step(*a)
+    with pytest.raises(NotImplementedError):
+        model.fuse_attention()
+    model.train()
+    s_t, d_t, n_t, t_t, e_t, _, cg = coll.collate_arrays(*a)
+    with pytest.raises(NotImplementedError):
+        model.contrast_learning(s_t, d_t, n_t, t_t, e_t, cg)
 
 
 def test_invariant_errors_surface_as_value_errors():

@@ -6,7 +6,7 @@ per step (same torch build produced both, only operation order differs)."""
 import numpy as np
 import pytest
 
-from _util import MODEL_FIXTURES, fixture_params, fixture_tables, load, n_batches, parse_cfg, rel_err
+from _util import MODEL_FIXTURES, TWO_LAYER_FIXTURES, fixture_params, fixture_tables, load, n_batches, parse_cfg, rel_err
 from oracle import tiger_oracle as O
 
 TOL = 2e-5
@@ -87,7 +87,7 @@ def check_state(m, z, tag):
     np.testing.assert_array_equal(m.msg_ts.numpy()[has], z[f'{tag}_msg_ts'])
 
 
-@pytest.mark.parametrize('name', MODEL_FIXTURES)
+@pytest.mark.parametrize('name', MODEL_FIXTURES + TWO_LAYER_FIXTURES)
 def test_stream_matches_reference(name):
     z = load(name)
     cfg = parse_cfg(z)
@@ -97,11 +97,12 @@ def test_stream_matches_reference(name):
     for b in range(n_batches(z)):
         sl = slice(b * B, min((b + 1) * B, len(z['src'])))
         src, dst, neg, ts, eids = (z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids'))
-        cg = O.collate(m.graph, src, dst, neg, ts, cfg['K'], cfg['restarter'], cfg.get('H'))
+        cg = O.collate(m.graph, src, dst, neg, ts, cfg['K'], cfg['restarter'], cfg.get('H'), n_layers=cfg.get('L', 1))
         tag = f'b{b}'
         # collation is integer work: bit-exact
         for k in ('l1_nids', 'l1_eids', 'l1_ts', 'involved', 'rd_index', 'rd_nids', 'rd_ts',
-                  'src_hits', 'dst_hits', 'neg_src_hits', 'neg_dst_hits'):
+                  'src_hits', 'dst_hits', 'neg_src_hits', 'neg_dst_hits') + (
+                      ('hop2_nids', 'hop2_eids', 'hop2_ts') if cfg.get('L', 1) == 2 else ()):
             np.testing.assert_array_equal(cg[k], z[f'{tag}_{k}'], err_msg=k)
         if cfg['restarter'] == 'seq':
             for k in ('rd_hist_nids', 'rd_anon', 'rd_hist_eids', 'rd_hist_ts', 'rd_hist_dirs'):

@@ -140,6 +140,7 @@ SIGNATURES = {
     'tg_apply_messages': (C.c_int, [P(TgModel), vp, vp, vp, i64, vp, vp, vp, sz, vp]),
     'tg_temporal_attn_workspace_bytes': (sz, [P(TgModel), i64]),
     'tg_temporal_attn_fwd': (C.c_int, [P(TgModel), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'tg_temporal_attn_fwd_keys': (C.c_int, [P(TgModel), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     'tg_consume_update_right': (C.c_int, [P(TgModel), vp, vp, i64, vp, vp, vp, vp, vp]),
     'tg_gather_eff_rows': (C.c_int, [P(TgModel), i64, vp, vp, vp, vp]),
     'tg_serve_rows': (C.c_int, [P(TgModel), i64, vp, vp, i64, vp, vp, vp, vp]),

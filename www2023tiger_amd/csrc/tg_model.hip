@@ -203,7 +203,8 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
                                                    const float* __restrict__ reprs, const uint64_t* __restrict__ bm,
                                                    const uint32_t* __restrict__ rank, const float* __restrict__ G,
                                                    float* __restrict__ S, uint8_t* __restrict__ valid, DropCfg dc,
-                                                   float* __restrict__ rsum, int direct, PosArgs pos) {
+                                                   float* __restrict__ rsum, int direct, PosArgs pos,
+                                                   const float* __restrict__ key_rows) {
   using V = RowVec<W>;
   const int lane = lane_id();
   // direct (eager updates): neighbour rows come from the state tables, row(v) = has_msg[v] ? pending[v] : right[v];
@@ -260,12 +261,16 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
       const int64_t u = __shfl(u_l, k, TG_WAVE);
       const int64_t nb = __shfl(nb_l, k, TG_WAVE);
       const int64_t eid = __shfl(eid_l, k, TG_WAVE);
-      const float* nrow = direct ? ((u & 1) ? m.pending_vals : m.right_vals) + (u >> 1) * d : reprs + u * d;
+      // key_rows (second attention layer of --n_layers 2): the node part of key k of centre i is row i*K + k of a dense
+      // tensor - the neighbour's own embedding (temporal_agg_modules.py:57-66) - instead of its memory row + features
+      const float* nrow = key_rows ? key_rows + (i * K + k) * d
+                                   : (direct ? ((u & 1) ? m.pending_vals : m.right_vals) + (u >> 1) * d : reprs + u * d);
+      const bool feat = m.nfeats && !key_rows;
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const int c = (lane + v * TG_WAVE) * W;
         ya[slot][v] = row_load<W>(nrow, c, d);
-        yn[slot][v] = row_load<W>(m.nfeats ? m.nfeats + nb * d : reprs, c, m.nfeats ? d : 0);
+        yn[slot][v] = row_load<W>(feat ? m.nfeats + nb * d : nrow, c, feat ? d : 0);
         yb[slot][v] = row_load<W>(m.efeats ? m.efeats + eid * de : reprs, c, m.efeats ? de : 0);
       }
     };
@@ -424,7 +429,8 @@ static FusedView fused_view(const tg_model* m, const float* f) {
 
 void launch_attn_core(const tg_model* m, int64_t Q, const float* ts, const int64_t* l1_nids, const int64_t* l1_eids,
                       const float* l1_ts, const float* reprs, const uint64_t* bm, const uint32_t* rank, const AttnWs& w,
-                      const DropCfg& dc, hipStream_t st, int* rc_out, int direct = 0, const PosArgs* pos = nullptr) {
+                      const DropCfg& dc, hipStream_t st, int* rc_out, int direct = 0, const PosArgs* pos = nullptr,
+                      const float* key_rows = nullptr) {
   const int d = m->d, d_e = m->d_e, nh = m->n_head;
   *rc_out = TG_OK;
   // Columns per lane: float4.  Three columns per lane fill 58 of 64 lanes at d = 172 instead of 43 and cut
@@ -444,7 +450,7 @@ void launch_attn_core(const tg_model* m, int64_t Q, const float* ts, const int64
 #define TG_CORE(NH_, NV_, W_)                                                                                      \
   hipLaunchKernelGGL((k_attn_core<NH_, NV_, W_>), dim3(cgrid), dim3(256), 0, st, *m, Q, ts, l1_nids, l1_eids,      \
                      l1_ts, reprs, bm, rank, (const float*)w.g, w.s, w.valid, dc,                                  \
-                     dc.p > 0.f ? w.rsum : (float*)nullptr, direct, pos ? *pos : PosArgs{})
+                     dc.p > 0.f ? w.rsum : (float*)nullptr, direct, pos ? *pos : PosArgs{}, key_rows)
   if (nh == 2 && nv == 1 && W == 2) TG_CORE(2, 1, 2);
   else if (nh == 1 && nv == 1 && W == 2) TG_CORE(1, 1, 2);
   else if (nh == 4 && nv == 1 && W == 2) TG_CORE(4, 1, 2);
@@ -525,12 +531,13 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
 int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float* ts, const int64_t* l1_nids,
                  const int64_t* l1_eids, const float* l1_ts, const float* reprs, const uint64_t* bm,
                  const uint32_t* rank, float* out, const AttnWs& w, hipStream_t st, tg_profiler* pf = nullptr,
-                 const DropCfg* drop = nullptr, const PosArgs* pos = nullptr, const DirectArgs* da = nullptr) {
+                 const DropCfg* drop = nullptr, const PosArgs* pos = nullptr, const DirectArgs* da = nullptr,
+                 const float* key_rows = nullptr) {
   const DropCfg dc = drop ? *drop : DropCfg{};
   int stage = ST_ATTN_FIRST;
   prof_mark(pf, stage++, st);
   const int d = m->d, d_e = m->d_e, kvw = 2 * d + d_e, nh = m->n_head, dh = 2 * d / nh, E = 2 * d;
-  if (m->attn_fused && dc.p == 0.f)
+  if (m->attn_fused && dc.p == 0.f && !key_rows)
     return attn_forward_fused(m, Q, nids, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, out, w, st, pf, pos, da);
   const int qblocks = (int)cdiv(2 * d, 4);
   if (da) {  // the constant half of the query projection from the rank-form kernel (no centre rows), then the direct centres
@@ -563,7 +570,7 @@ int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float*
   if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
   // gather + scores + softmax + weighted raw sum
   prof_mark(pf, stage++, st);
-  launch_attn_core(m, Q, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, w, dc, st, &rc, da ? 1 : 0, da ? pos : nullptr);
+  launch_attn_core(m, Q, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, w, dc, st, &rc, da ? 1 : 0, da ? pos : nullptr, key_rows);
   if (rc != TG_OK) return rc;
   // o_h = Wv_h s_h + bv_h
   prof_mark(pf, stage++, st);
@@ -751,6 +758,20 @@ extern "C" int tg_temporal_attn_fwd(const tg_model* m, int64_t Q, const int64_t*
   AttnWs w{};
   if (!carve_attn(m, Q, cv, w)) return TG_EWORKSPACE;
   return attn_forward(m, Q, nids, ts, l1_nids, l1_eids, l1_ts, reprs, bitmap, rank, out, w, as_stream(stream));
+}
+
+extern "C" int tg_temporal_attn_fwd_keys(const tg_model* m, int64_t Q, const int64_t* nids, const float* ts,
+                                         const int64_t* l1_nids, const int64_t* l1_eids, const float* l1_ts,
+                                         const float* reprs, const uint64_t* bitmap, const uint32_t* rank,
+                                         const float* key_rows, float* out, void* ws, size_t ws_bytes, void* stream) {
+  if (!attn_dims_ok(m) || Q < 0) return TG_EINVAL;
+  if (Q == 0) return TG_OK;
+  if (!nids || !ts || !l1_nids || !l1_eids || !l1_ts || !reprs || !bitmap || !rank || !out || !key_rows) return TG_EINVAL;
+  Carver cv(ws, ws_bytes);
+  AttnWs w{};
+  if (!carve_attn(m, Q, cv, w)) return TG_EWORKSPACE;
+  return attn_forward(m, Q, nids, ts, l1_nids, l1_eids, l1_ts, reprs, bitmap, rank, out, w, as_stream(stream), nullptr,
+                      nullptr, nullptr, nullptr, key_rows);
 }
 
 extern "C" int tg_linear_fwd(int64_t n, const float* x, int32_t in_f, const tg_linear* lin, int32_t out_f, int32_t relu,

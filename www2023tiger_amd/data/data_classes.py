@@ -110,7 +110,7 @@ class ComputationGraph:
     def hit_data(self):
         if self._hit is None and self._pending is not None:
             coll, s, d, n, t = self._pending
-            self._hit = coll.collate_hit_data(s, d, n, t, self.layers[1][0])
+            self._hit = coll.collate_hit_data(s, d, n, t, self.layers[-1][0])  # the batch nodes' own neighbours
         return self._hit
 
     @property

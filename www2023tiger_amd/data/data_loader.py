@@ -21,8 +21,8 @@ from .graph import Graph
 class GraphCollator:
     def __init__(self, graph: Graph, n_neighbors: int, n_layers: int, *, restarter: str = 'seq',
                  hist_len: Optional[int] = None, n_walks=None, walk_length=None, alpha: float = 0.0):
-        if n_layers != 1:
-            raise NotImplementedError('the HIP engine implements n_layers == 1')
+        if n_layers not in (1, 2):
+            raise NotImplementedError('the HIP engine implements n_layers 1 and 2')
         if restarter not in ('seq', 'static'):
             raise NotImplementedError(restarter)  # 'walk' is unreachable from the CLI (init_utils.py:56-57)
         self.graph = graph
@@ -39,8 +39,15 @@ class GraphCollator:
         flags = hip_ops.new_flags(self.n_nodes, dev)
         l_n, l_e, l_t, _ = g.sample_device(nids3, ts3, K, mark_flags=flags, want_dirs=False)
         cap = nids3.numel() * (K + 1)
-        comp = hip_ops.unique_compact(None, self.n_nodes, cap, flags=flags)
         layers = [(nids3, None, None), (l_n, l_e, l_t)]
+        if self.n_layers == 2:
+            # data_loader.py:131: the next hop is sampled for every neighbour slot (padding slots included) at the
+            # neighbour's own - float32 - timestamp; layers[2] are the batch nodes' neighbours, layers[1] the deepest hop
+            h_n, h_e, h_t, _ = g.sample_device(l_n.reshape(-1).contiguous(), l_t.reshape(-1).double().contiguous(), K,
+                                               mark_flags=flags, want_dirs=False)
+            layers = [(nids3, None, None), (h_n, h_e, h_t), (l_n, l_e, l_t)]
+            cap = nids3.numel() * (1 + K + K * K)
+        comp = hip_ops.unique_compact(None, self.n_nodes, cap, flags=flags)
         return layers, comp['bitmap'], comp
 
     def collate_restart_data(self, pos: torch.Tensor, ts2: torch.Tensor):

@@ -28,9 +28,9 @@ class TemporalAttention(nn.Module):
 class GraphAttnEmbedding(nn.Module):
     def __init__(self, raw_feat_getter, time_encoder, graph, n_neighbors=20, n_layers=2, n_head=2, dropout=0.1):
         super().__init__()
-        if n_layers != 1:
-            # every BASELINE config and the CLI default use one layer (init_utils.py:36)
-            raise NotImplementedError('the HIP engine implements n_layers == 1')
+        if n_layers not in (1, 2):
+            # every BASELINE config and the CLI default use one layer (init_utils.py:36); two run on the operator path
+            raise NotImplementedError('the HIP engine implements n_layers 1 and 2')
         self.raw_feat_getter = raw_feat_getter
         self.time_encoder = time_encoder
         self.graph = graph
@@ -48,15 +48,36 @@ class GraphAttnEmbedding(nn.Module):
 
     def compute_embedding_with_computation_graph(self, involved_node_reprs: Tensor, center_nids: Tensor, ts: Tensor,
                                                  computation_graph, model_struct, rank: Tensor) -> Tensor:
-        """temporal_agg_modules.py:29-83 for depth == n_layers == 1.  `involved_node_reprs`
-        is indexed by the local index that (computation_graph.bitmap, rank) encode."""
-        l1_n, l1_e, l1_t = computation_graph.layers[1]
-        Q = center_nids.numel()
+        """temporal_agg_modules.py:29-83.  `involved_node_reprs` is indexed by the local index that
+        (computation_graph.bitmap, rank) encode.  `model_struct`: the tg_model of the owning TIGE, or a callable
+        layer -> tg_model (n_layers == 2: each attention layer has its own weights, fns[n_layers - depth]).
+        Two layers: the K neighbours of every centre are embedded first - as Q*K centres over the hop-2 neighbours,
+        with fns[1], at the ROOT's query time (:63) - and their embeddings are the node part of the keys of fns[0]."""
+        cg = computation_graph
+        struct = model_struct if callable(model_struct) else (lambda layer: model_struct)
+        top_n, top_e, top_t = cg.layers[self.n_layers]
+        Q, K = center_nids.numel(), self.n_neighbors
         d = involved_node_reprs.shape[1]
-        out = torch.empty(Q, d, dtype=torch.float32, device=involved_node_reprs.device)
-        nbytes = int(lib.tg_temporal_attn_workspace_bytes(C.byref(model_struct), Q))
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=out.device)
-        check(lib.tg_temporal_attn_fwd(C.byref(model_struct), Q, ptr(center_nids), ptr(ts), ptr(l1_n), ptr(l1_e),
-                                       ptr(l1_t), ptr(involved_node_reprs), ptr(computation_graph.bitmap), ptr(rank),
-                                       ptr(out), ptr(ws), nbytes, stream_ptr(out.device)), 'tg_temporal_attn_fwd')
-        return out
+        dev = involved_node_reprs.device
+        s = stream_ptr(dev)
+
+        def attend(m, q, nids, qts, l_n, l_e, l_t, key_rows=None):
+            out = torch.empty(q, d, dtype=torch.float32, device=dev)
+            nbytes = int(lib.tg_temporal_attn_workspace_bytes(C.byref(m), q))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            if key_rows is None:
+                check(lib.tg_temporal_attn_fwd(C.byref(m), q, ptr(nids), ptr(qts), ptr(l_n), ptr(l_e), ptr(l_t),
+                                               ptr(involved_node_reprs), ptr(cg.bitmap), ptr(rank), ptr(out), ptr(ws),
+                                               nbytes, s), 'tg_temporal_attn_fwd')
+            else:
+                check(lib.tg_temporal_attn_fwd_keys(C.byref(m), q, ptr(nids), ptr(qts), ptr(l_n), ptr(l_e), ptr(l_t),
+                                                    ptr(involved_node_reprs), ptr(cg.bitmap), ptr(rank), ptr(key_rows),
+                                                    ptr(out), ptr(ws), nbytes, s), 'tg_temporal_attn_fwd_keys')
+            return out
+
+        if self.n_layers == 1:
+            return attend(struct(0), Q, center_nids, ts, top_n, top_e, top_t)
+        hop_n, hop_e, hop_t = cg.layers[1]
+        inner = attend(struct(1), Q * K, top_n.reshape(-1).contiguous(), ts.repeat_interleave(K).contiguous(),
+                       hop_n, hop_e, hop_t)
+        return attend(struct(0), Q, center_nids, ts, top_n, top_e, top_t, key_rows=inner)

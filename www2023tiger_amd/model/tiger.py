@@ -142,8 +142,19 @@ class TIGE(nn.Module):
     def invalidate_struct(self):
         self._struct_cache = None
 
-    def model_struct(self) -> TgModel:
-        """tg_model view of this module's tensors (cached until tensors are re-homed)."""
+    def model_struct(self, layer: int = 0) -> TgModel:
+        """tg_model view of this module's tensors (cached until tensors are re-homed).  layer: which attention layer's
+        weights the struct carries (temporal_embedding_fn.fns[layer]; only the two-layer operator path asks for 1)."""
+        if layer:
+            m = TgModel.from_buffer_copy(self.model_struct())  # ctypes structs with pointers do not copy.copy
+            att = self.temporal_embedding_fn.fns[layer]
+            lin = lambda l: TgLinear(ptr(l.weight), ptr(l.bias))
+            mha = att.mha_fn
+            m.attn_wq, m.attn_wk, m.attn_wv, m.attn_b_in = (ptr(mha.q_proj_weight), ptr(mha.k_proj_weight),
+                                                           ptr(mha.v_proj_weight), ptr(mha.in_proj_bias))
+            m.attn_out, m.attn_fc1, m.attn_fc2 = lin(mha.out_proj), lin(att.merger.fc1), lin(att.merger.fc2)
+            m.attn_fused = None
+            return m
         if self._struct_cache is not None:
             return self._struct_cache
         lin = lambda l: TgLinear(ptr(l.weight), ptr(l.bias))
@@ -239,6 +250,8 @@ class TIGE(nn.Module):
         self._struct_cache = None
         if not enable:
             return self
+        if self.n_layers != 1:
+            raise NotImplementedError('pre-multiplied attention weights are built for n_layers == 1')
         m = self.model_struct()
         n = int(lib.tg_attn_fused_floats(C.byref(m)))
         if n == 0:
@@ -292,6 +305,9 @@ class TIGE(nn.Module):
         write-back) runs as one tg_train_step; the returned losses carry an autograd node that
         hands the finished gradients to the parameters when `.backward()` is called."""
         from .training import TrainBuffers, hand_over
+        if self.n_layers != 1:
+            raise NotImplementedError('training on device is built for n_layers == 1 (--n_layers 2 evaluates / streams '
+                                      'through the operator path)')
         self._touch()
         dev = self.device
         B = len(src_ids)
@@ -363,7 +379,7 @@ class TIGE(nn.Module):
         another strategy take the operator-by-operator path below"""
         if self.hit_type == 'vec' and (2 * (self.nfeat_dim + self.n_neighbors)) % 4:
             return False  # the score head's pair rows must be float4-aligned
-        return True
+        return self.n_layers == 1  # two embedding layers run on the operator path
 
     def _contrast_learning_fused_eval(self, src_ids, dst_ids, neg_dst_ids, eids, computation_graph):
         """no_grad / eval(): collate, STEP 1-7 and the write-back as ONE device call (tg_train_step without
@@ -412,10 +428,11 @@ class TIGE(nn.Module):
         batch_ids = torch.cat([pos, neg_dst_ids])
         ts2, ts3 = ts.repeat(2), ts.repeat(3)
         err = hip_ops.new_err(dev)
-        cap = 3 * bs * (self.n_neighbors + 1)
+        K = self.n_neighbors
+        cap = 3 * bs * (1 + K + (K * K if self.n_layers == 2 else 0))
         comp, reprs = self._consume(cg.bitmap, cap, err)  # STEP 1-2
         h_all = self.temporal_embedding_fn.compute_embedding_with_computation_graph(  # STEP 3
-            reprs, batch_ids, ts3, cg, m, comp['rank'])
+            reprs, batch_ids, ts3, cg, m if self.n_layers == 1 else self.model_struct, comp['rank'])
         upos, index = hip_ops.select_latest_nids(pos, ts2, self.n_nodes)  # dedup (tiger.py:232,419; memory.py:98)
         n_upos = torch.tensor([len(upos)], dtype=torch.int32, device=dev)
         check(lib.tg_consume_update_right(C.byref(m), ptr(upos), ptr(n_upos), len(upos), ptr(reprs), ptr(cg.bitmap),
@@ -560,6 +577,8 @@ class TIGE(nn.Module):
 
     def launch_step(self, buf: 'TIGE.StepBuffers'):
         """Enqueue collate + STEP 1-6 for the batch already in `buf` (no host sync)."""
+        if self.n_layers != 1:
+            raise NotImplementedError('the fused step is built for n_layers == 1; use contrast_learning (operator path)')
         buf.io.rows_hint = self.rows_bound()
         if self._pending is not None and not buf.embed_only:
             self._sync_pending()
