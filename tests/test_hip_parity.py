@@ -345,6 +345,38 @@ def test_two_layer_model_refuses_the_one_layer_fast_paths():
         model.contrast_learning(s_t, d_t, n_t, t_t, e_t, cg)
 
 
+def test_no_feat_buffer_reads_pinned_host_tables():
+    """--no_feat_buffer (feature_getter.py:41-47,86-87): NumericalFeature(register_buffer=False) keeps the feature tables
+    in pinned host memory; the kernels read them in place, the stream reproduces the reference like the resident form"""
+    from www2023tiger_amd.data.graph import Graph
+    from www2023tiger_amd.model.feature_getter import NumericalFeature
+    from www2023tiger_amd.model.restarters import StaticRestarter
+    from www2023tiger_amd.model.tiger import TIGER
+    z = load('static_ll_d16')
+    cfg = parse_cfg(z)
+    n_nodes, nfeats, efeats = fixture_tables(z, cfg)
+    g = Graph.from_arrays(z['src'], z['dst'], z['ts'], z['eids'], strategy='recent_edges', seed=0, device=dev())
+    fg = NumericalFeature(torch.from_numpy(nfeats), torch.from_numpy(efeats), dim=cfg['d'], register_buffer=False, device=dev())
+    fg.n_nodes, fg.n_edges = n_nodes, len(z['src'])
+    model = TIGER(raw_feat_getter=fg, graph=g, restarter=StaticRestarter(raw_feat_getter=fg, graph=g), n_neighbors=cfg['K'],
+                  hit_type='bin', n_layers=1, n_head=2, dropout=0.1, msg_src=cfg['msg_src'], upd_src=cfg['upd_src'])
+    params = fixture_params(z, cfg)
+    with torch.no_grad():
+        for k, v in model.named_parameters():
+            v.copy_(torch.from_numpy(params[k]))
+    model = model.to(dev()).eval()
+    assert fg.nfeats.device.type == 'cpu' and fg.nfeats.is_pinned() and fg.efeats.is_pinned()   # .to() left them on the host
+    assert 'nfeats' not in dict(fg.named_buffers())
+    B = cfg['B']
+    for b in range(4):
+        sl = slice(b * B, (b + 1) * B)
+        buf = model.stream_step(*(z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')))
+        assert_close(buf.h[:2 * B].cpu().numpy(), z[f'b{b}_h_left'], 'h_left', TOL)
+    check_state(model, z, 'b3')
+    ids = torch.tensor([1, 5, 7], device=dev())
+    np.testing.assert_array_equal(fg.get_node_embeddings(ids).cpu().numpy(), nfeats[[1, 5, 7]])
+
+
 def test_invariant_errors_surface_as_value_errors():
     """memory.py:45-46: writing a memory row back in time must raise, as in the reference."""
     from www2023tiger_amd.model.memory import Memory

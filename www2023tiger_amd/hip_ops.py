@@ -134,10 +134,11 @@ def time_encode(ts: Tensor, freq: Tensor, phase: Tensor) -> Tensor:
 def gather_rows(table: Tensor, ids: Tensor, ts_table: Optional[Tensor] = None):
     ids_f = _i64(ids).reshape(-1)
     width = table.shape[1]
-    out = torch.empty(ids_f.numel(), width, dtype=torch.float32, device=table.device)
-    ts_out = torch.empty(ids_f.numel(), dtype=torch.float32, device=table.device) if ts_table is not None else None
+    dev = ids_f.device if table.device.type == 'cpu' else table.device  # a pinned host table is read from the ids' GPU
+    out = torch.empty(ids_f.numel(), width, dtype=torch.float32, device=dev)
+    ts_out = torch.empty(ids_f.numel(), dtype=torch.float32, device=dev) if ts_table is not None else None
     check(lib.tg_gather_rows(ids_f.numel(), ptr(ids_f), width, ptr(table), ptr(out), ptr(ts_table), ptr(ts_out),
-                             stream_ptr(table.device)), 'tg_gather_rows')
+                             stream_ptr(dev)), 'tg_gather_rows')
     out = out.reshape(*ids.shape, width)
     if ts_table is None:
         return out

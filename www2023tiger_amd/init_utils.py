@@ -58,14 +58,13 @@ def init_data(data, root, seed, rank=None, world_size=None, *, num_workers=0, bs
 def init_model(nfeats, efeats, train_graph, full_graph, full_data, device, *, feature_as_buffer=True, dim, n_layers,
                n_heads, n_neighbors, hit_type, dropout, restarter_type, hist_len, msg_src, upd_src, msg_tsfm_type,
                mem_update_type):
-    if not feature_as_buffer:
-        raise NotImplementedError('feature tables live in HBM (--no_feat_buffer is not supported)')
     to_t = lambda a: None if a is None else torch.from_numpy(a).float()
     nfeats, efeats = to_t(nfeats), to_t(efeats)
     for t in (nfeats, efeats):  # the first table present fixes the width when --dim is not given
         if t is not None and dim is None:
             dim = t.shape[1]
-    getter = NumericalFeature(nfeats, efeats, dim=dim, device=device)
+    # --no_feat_buffer: the tables stay in pinned host memory and the kernels read them in place
+    getter = NumericalFeature(nfeats, efeats, dim=dim, register_buffer=feature_as_buffer, device=device)
     getter.n_nodes, getter.n_edges = full_graph.num_node, len(full_data)
     if restarter_type == 'seq':
         restarter = SeqRestarter(raw_feat_getter=getter, graph=train_graph, hist_len=hist_len, n_head=n_heads,

@@ -27,18 +27,24 @@ class NumericalFeature(nn.Module):
             self.n_nodes, nd = nfeats.shape
         if efeats is not None:
             self.n_edges, ed = efeats.shape
-        # buffers are non-persistent like the reference (not part of the state_dict)
-        self.register_buffer('nfeats', None if nfeats is None else nfeats.float().contiguous(), persistent=False)
-        self.register_buffer('efeats', None if efeats is None else efeats.float().contiguous(), persistent=False)
+        prep = lambda t: None if t is None else t.float().contiguous()
+        if register_buffer:
+            # buffers are non-persistent like the reference (not part of the state_dict); they move with .to(device)
+            self.register_buffer('nfeats', prep(nfeats), persistent=False)
+            self.register_buffer('efeats', prep(efeats), persistent=False)
+        else:
+            # --no_feat_buffer (feature_getter.py:41-47,86-87: tables stay on the CPU, rows are copied per lookup): here the
+            # tables stay in PINNED host memory, which the GPU addresses directly - the kernels read the rows they need over
+            # the host link, nothing is staged and `.to(device)` does not move them (plain attributes, as in the reference)
+            pin = lambda t: None if t is None else (t.pin_memory() if torch.cuda.is_available() else t)
+            self.nfeats, self.efeats = pin(prep(nfeats)), pin(prep(efeats))
         self.nfeat_dim = nd if nd else dim
         self.efeat_dim = ed if ed else dim
 
     def _lookup(self, table, ids, width):
         if table is None:
             return torch.zeros(*ids.shape, width, device=ids.device)
-        if table.device != ids.device:
-            table = table.to(ids.device)
-        return hip_ops.gather_rows(table, ids)
+        return hip_ops.gather_rows(table, ids)  # a pinned host table is read in place by the kernel
 
     def get_node_embeddings(self, nids: Tensor) -> Tensor:
         return self._lookup(self.nfeats, nids, self.out_dim)

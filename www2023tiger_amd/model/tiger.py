@@ -161,8 +161,9 @@ class TIGE(nn.Module):
         nul = TgLinear(None, None)
         fg, att = self.raw_feat_getter, self.temporal_embedding_fn.fns[0]
         for t in (fg.nfeats, fg.efeats):
-            if t is not None and t.device != self.device:
-                raise RuntimeError('feature tables must live on the model device (--no_feat_buffer is not supported)')
+            if t is not None and t.device != self.device and not (t.device.type == 'cpu' and t.is_pinned()):
+                raise RuntimeError('feature tables must live on the model device or in pinned host memory '
+                                   '(NumericalFeature(register_buffer=False) pins them)')
         tsfm1 = tsfm2 = nul
         if self.msg_tsfm_type == 'linear':
             tsfm1 = lin(self.msg_transform_fn.fn[1])
