@@ -275,7 +275,7 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     torch.cuda.set_device(0)
     dev = torch.device('cuda', 0)
     B, K, d = cfg['B'], cfg['K'], cfg['d']
-    n_batches = preroll + warmup + steps + n_prof + 6  # + 4 batches for the copy-form gather timing, + 2 spare
+    n_batches = preroll + warmup + steps + n_prof + 8  # + 4 batches for the copy-form gather timing, + 2 for the set sizes of a lean run, + 2 spare
     E = max(cfg['E'], n_batches * B)
     no_feats = bool(cfg.get('no_feats'))
     stream = make_stream(cfg['n_u'], cfg['n_i'], E, cfg['T'] * E / cfg['E'], seed=0, d_e=d,
@@ -303,6 +303,11 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
         buf.enable_lazy_restart(model, trig)
         n_trig = int(trig[preroll + warmup:preroll + warmup + steps].sum())
     _ = model.graph.tcsr, model.model_struct()  # lazy device-side builds happen here, not inside a capture
+    # lean step (tg_step_io.lean): the benchmark reads neither the involved set nor its size, so a direct-form eager step
+    # on a graph of at most 3B(K+1) node ids does not form it (the library ignores the flag everywhere else)
+    direct = eager and os.environ.get('TG_EAGER_DIRECT', '1') != '0' and not args.eager_copy  # no compact copy (DESIGN.md s4)
+    lean = direct and not args.no_lean and restart_prob == 0 and stream['n_nodes'] <= 3 * B * (K + 1)
+    buf.io.lean = 1 if lean else 0
 
     # ---- untimed: state pre-roll, then the contract's warm-up steps (all eager launches)
     for _ in range(preroll + warmup):
@@ -311,6 +316,7 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     assert int(buf.err.item()) == 0, f'invariant word {int(buf.err.item())}'
     cnt = buf.counts.tolist()
     model.note_rows(cnt[1], cnt[2])  # bounds on the updater's rows (steady state reached): pending messages / unique positives
+    assert (cnt[0] == -1) == lean, (cnt, lean)  # the lean form was taken exactly where expected
 
     # ---- timed region: K steps, hipGraph replay of one captured step
     graph = None
@@ -339,10 +345,16 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     names, stage_ms, counts = profile_stages(model, buf, n_prof)
     assert int(buf.err.item()) == 0, f'invariant word {int(buf.err.item())} after the profiling pass'
     U, O_, P = counts[0], counts[1], counts[2]
+    if lean:  # the sets were not formed in the timed form: their sizes (for the algorithmic byte counts) from two full steps
+        buf.io.lean = 0
+        _, _, cf = profile_stages(model, buf, 2)
+        buf.io.lean = 1
+        U, O_ = cf[0], cf[1]
     work = stage_work(cfg, U, O_, P, eager, fused, stream['n_nodes'], E)
     traffic = load_traffic(traffic_tag)
     empty = {'zero_flags', 'dedup_positive', 'restarter_targets', 'apply_messages(gru)' if eager else 'eager_updater(gru)'}
-    direct = eager and os.environ.get('TG_EAGER_DIRECT', '1') != '0' and not args.eager_copy  # no compact copy (DESIGN.md s4)
+    if lean:
+        empty |= {'unique_compact'}
     if direct:  # ... and STEP 4-6 are one launch (reported under writeback_phase1)
         empty |= {'gather_right_memory', 'writeback_phase0'}
         w0, w1 = work['writeback_phase0'], work['writeback_phase1']
@@ -359,6 +371,7 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
                            attention_weights='pre-multiplied (tg_attn_fuse)' if fused else 'as stored',
                            updater=('eager: once per stored message (TIGE.eager_updates)' + (', rows read from the tables directly' if direct else ', compact reprs copy')) if eager else
                                    'lazy: on the fly for every involved node with a pending message',
+                           involved_set=('not formed (tg_step_io.lean: nothing in a direct-form eager step reads it)' if lean else 'formed (sorted unique ids + ranks)'),
                            state_preroll_batches=preroll, involved_per_batch=float(U), outdated_per_batch=float(O_),
                            unique_pos_per_batch=float(P)),
                roofline=roofline_of(dom, stages[dom], work, traffic),
@@ -492,6 +505,8 @@ def main():
     ap.add_argument('--preroll', type=int, default=None,
                     help=f'untimed state pre-roll batches before --warmup (default {PREROLL}; 20 for c5s)')
     ap.add_argument('--no-c5s-leg', action='store_true', help='default C2 run: skip the short HBM-roofline leg')
+    ap.add_argument('--no-lean', action='store_true',
+                    help='form the involved / outdated sets in every step even where nothing reads them')
     ap.add_argument('--no-graph', action='store_true', help='launch steps eagerly instead of replaying a hipGraph')
     ap.add_argument('--force-dist', action='store_true', help='run the multi-GPU code path even with one rank')
     ap.add_argument('--dist-graphs', action='store_true',

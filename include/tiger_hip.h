@@ -430,6 +430,13 @@ typedef struct tg_step_io {
    * as ONE stand-alone gather launch into reprs - instead of letting the attention launches read pending / right by
    * node id (the default "direct" form, one launch and one row copy fewer).  Same results. */
   int32_t eager_copy;
+  /* lean != 0: the caller does not need the involved / outdated SETS of the batch (io->involved is ignored, counts[0] and
+   * counts[1] come back as -1).  With eager updates in the direct form nothing else in the step needs them either - rows
+   * are addressed by node id, the dedup slots can be indexed by node id, the time invariants can be checked per centre /
+   * per neighbour - so the sampler marks no flags and the compaction launch is skipped.  Honoured only there (and only
+   * when n_nodes <= 3B(K+1), no lazy restart, no h_prev_* outputs); ignored otherwise.  Same results. */
+  int32_t lean;
+  int32_t reserved3;
 } tg_step_io;
 
 /* The reference loop draws `np.random.rand() < restart_prob` before every batch but the first; a hit sets

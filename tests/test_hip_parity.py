@@ -460,7 +460,10 @@ def compare_state_with_oracle(model, orc):
     np.testing.assert_array_equal(model.msg_store.node_msg_ts.cpu().numpy()[has], orc.msg_ts.numpy()[has])
 
 
-def _oracle_vs_fused(stream, d, K, B, n_batches, msg_src, upd_src, zero_nfeats=True, fuse=False, eager=False):
+def _oracle_vs_fused(stream, d, K, B, n_batches, msg_src, upd_src, zero_nfeats=True, fuse=False, eager=False,
+                     lean=None):
+    """lean: None = never; 'all' = every step lean; 'mixed' = the SAME step buffers (one workspace) switch between the
+    lean and the full form every third batch, which also checks that either form leaves the workspace clean"""
     import bench
     from oracle import tiger_oracle as O
     model, orc = bench.build_models(stream, d, K, msg_src, upd_src, with_oracle=True, zero_nfeats=zero_nfeats)
@@ -472,13 +475,20 @@ def _oracle_vs_fused(stream, d, K, B, n_batches, msg_src, upd_src, zero_nfeats=T
     for b in range(n_batches):
         sl = slice(b * B, (b + 1) * B)
         a = [stream[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
-        buf = model.stream_step(*a)
+        is_lean = lean == 'all' or (lean == 'mixed' and b % 3 != 1)
+        if lean == 'mixed':
+            model.step_buffers(B).io.lean = 1 if is_lean else 0
+        buf = model.stream_step(*a, lean=(lean == 'all'))
         cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], K, 'static')
         ref = orc.stream_step(*a, cg).numpy()
         np.testing.assert_array_equal(buf.l1_nids.cpu().numpy(), cg['l1_nids'])
         np.testing.assert_array_equal(buf.l1_eids.cpu().numpy(), cg['l1_eids'])
         counts = buf.counts.cpu().numpy()
-        np.testing.assert_array_equal(buf.involved.cpu().numpy()[:counts[0]], cg['involved'])
+        if is_lean:  # the sets were not formed; the number of unique positive nodes still is reported
+            assert counts[0] == -1 and counts[1] == -1
+            assert counts[2] == len(np.unique(np.concatenate([a[0], a[1]])))
+        else:
+            np.testing.assert_array_equal(buf.involved.cpu().numpy()[:counts[0]], cg['involved'])
         worst = max(worst, assert_close(buf.h[:2 * B].cpu().numpy(), ref, 'h_left', TOL)[0])
     compare_state_with_oracle(model, orc)
     assert worst < TOL, worst
@@ -499,6 +509,45 @@ def test_c2_bench_configuration_soak_matches_oracle():
     c = bench.C2
     stream = bench.make_stream(c['n_u'], c['n_i'], 40000, c['T'] * 40000 / c['E'], seed=4, d_e=c['d'])
     _oracle_vs_fused(stream, c['d'], c['K'], c['B'], 16, c['msg_src'], c['upd_src'], fuse=True, eager=True)
+
+
+@pytest.mark.parametrize('lean', ['all', 'mixed'])
+def test_c2_lean_steps_match_oracle(lean):
+    """tg_step_io.lean (no involved / outdated sets formed: the compaction launch is skipped, dedup slots are indexed by
+    node id, the time invariants are checked per centre and per neighbour) against the oracle, C2 shapes, 12 batches"""
+    import bench
+    c = bench.C2
+    stream = bench.make_stream(c['n_u'], c['n_i'], 40000, c['T'] * 40000 / c['E'], seed=5, d_e=c['d'])
+    _oracle_vs_fused(stream, c['d'], c['K'], c['B'], 12, c['msg_src'], c['upd_src'], fuse=True, eager=True, lean=lean)
+
+
+def test_lean_step_checks_the_time_invariants():
+    """a message older than its node's memory (message_modules.py:158-159) must raise from a lean step as from a full
+    one: the check moved from the outdated list to the centres / neighbours of the batch"""
+    import bench
+    c = bench.C2
+    stream = bench.make_stream(c['n_u'], c['n_i'], 8000, c['T'] * 8000 / c['E'], seed=6, d_e=c['d'])
+    B = c['B']
+    for where in ('centre', 'neighbour'):
+        model, _ = bench.build_models(stream, c['d'], c['K'], c['msg_src'], c['upd_src'])
+        model.fuse_attention()
+        model.eager_updates()
+        for b in range(3):
+            a = [stream[k][b * B:(b + 1) * B] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+            model.stream_step(*a, lean=True)
+        a = [stream[k][3 * B:4 * B] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        has = model.msg_store.has_msg_mask().cpu().numpy()
+        if where == 'centre':
+            v = next(int(x) for x in a[0] if has[x])
+        else:  # a node that is only a sampled neighbour in this batch
+            g = model.graph
+            nb = g.sample_temporal_neighbor(np.asarray(a[0]), np.asarray(a[3]), c['K'])[0]
+            centres = set(np.concatenate([a[0], a[1], a[2]]).tolist())
+            v = next(int(x) for x in nb.reshape(-1) if x != 0 and has[x] and int(x) not in centres)
+        mem = model.left_memory if c['msg_src'] == 'left' else model.right_memory
+        mem.update_ts[v] += 1.0e6   # state written behind the model's back: the memory is now ahead of the stored message
+        with pytest.raises(ValueError):
+            model.stream_step(*a, lean=True)
 
 
 def test_c2_lazy_and_eager_updates_agree():

@@ -227,13 +227,18 @@ struct PosArgs {
   int32_t* count;
   int64_t *upos, *index;
   int32_t* upos32;  // nullable: the winners' node ids once more as int32 (output rows of the eager updater launch)
+  uint32_t* chk_err;  // lean steps: the core launch checks the time invariants of every neighbour with a pending message
 };
+// dedup slot of a node: its rank in the involved set, or (lean steps: no involved set) the node id itself
+__device__ __forceinline__ int64_t pos_slot(const PosArgs& a, int64_t node) {
+  return a.bm ? (int64_t)bm_rank(a.bm, a.rank, node) : node;
+}
 __device__ __forceinline__ void pos_max_pass(const PosArgs& a, int64_t tid, int64_t nth) {
   if (tid == 0) *a.count = 0;  // the winners pass (a later launch) counts into it
   for (int64_t i = tid; i < 2 * a.B; i += nth) {
     const int64_t e = i < a.B ? i : i - a.B;
     const unsigned long long key = (orderable(a.ts[e]) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)i);
-    atomicMax(a.best + bm_rank(a.bm, a.rank, a.nids3[i]), key);
+    atomicMax(a.best + pos_slot(a, a.nids3[i]), key);
   }
 }
 __device__ __forceinline__ void pos_winners_pass(const PosArgs& a, int64_t tid, int64_t nth) {
@@ -241,7 +246,7 @@ __device__ __forceinline__ void pos_winners_pass(const PosArgs& a, int64_t tid, 
     const int64_t e = i < a.B ? i : i - a.B;
     const int64_t node = a.nids3[i];
     const unsigned long long key = (orderable(a.ts[e]) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)i);
-    if (a.best[bm_rank(a.bm, a.rank, node)] == key) {
+    if (a.best[pos_slot(a, node)] == key) {
       const int slot = atomicAdd(a.count, 1);
       a.upos[slot] = node;
       a.index[slot] = i;
@@ -293,6 +298,9 @@ struct WritebackArgs {
   // snap[i] = message-source memory row (+ node features) of position i of cat[src, dst], snap_ts[i] its time
   const float* snap;
   const float* snap_ts;
+  // lean step (no involved set): the dedup slots are indexed by node id - clean_best_n (= n_nodes) of them are zeroed -
+  // and counts[0], counts[1] are reported as -1
+  int64_t clean_best_n;
 };
 // phase 0 / 1: the two launches of tg_memory.hip's hazard analysis; phase 2: STEP 4-6 in one launch (needs a.snap)
 int writeback_launch(const tg_model* m, const WritebackArgs& a, int phase, hipStream_t st);

@@ -211,9 +211,9 @@ __global__ void __launch_bounds__(256) k_sample_batch(tg_tcsr g, int64_t B, cons
       o_nbr[w] = nb;
       o_eid[w] = ed;
       o_ts[w] = tt;
-      mark[nb] = 1;
+      if (mark) mark[nb] = 1;
     }
-    if (sub == 0 && nid >= 0 && nid < g.num_node) mark[nid] = 1;
+    if (mark && sub == 0 && nid >= 0 && nid < g.num_node) mark[nid] = 1;
   }
   if (tmin_key) {  // lazy restart only: one atomic per block on the complemented order-preserving key (slot starts at 0)
     __shared__ float s_tmin[4];

@@ -80,7 +80,15 @@ struct DirectArgs {
   float4* snap;
   float* snap_ts;
   int64_t n_snap;
+  // lean step (no outdated list): the invariants are checked per centre here and per neighbour in the core launch -
+  // the same node set, involved & has-message, some nodes more than once
+  int per_row_checks;
 };
+__device__ __forceinline__ void check_msg_times(const tg_model& m, int64_t id, uint32_t* err) {
+  const float mts = m.msg_ts[id], last = (m.msg_src == TG_SRC_LEFT ? m.left_ts : m.right_ts)[id];
+  if (last > mts) atomicOr(err, TG_ERR_MSG_BEFORE_MEM);
+  if (m.msg_src == TG_SRC_LEFT && !(mts == last)) atomicOr(err, TG_ERR_MSG_TS_MISMATCH);
+}
 __global__ void __launch_bounds__(256) k_attn_centres_direct(tg_model m, int64_t Q, const int64_t* __restrict__ nids,
                                                              const float4* __restrict__ nf, float4* __restrict__ out,
                                                              DirectArgs da, PosArgs pos) {
@@ -99,6 +107,7 @@ __global__ void __launch_bounds__(256) k_attn_centres_direct(tg_model m, int64_t
     if (nf) f = nf[id * d4 + c];
     v.x += f.x; v.y += f.y; v.z += f.z; v.w += f.w;
     out[t] = v;
+    if (da.per_row_checks && c == 0 && pending) check_msg_times(m, id, da.err);
     if (da.snap && i < da.n_snap) {
       if (m.msg_src == TG_SRC_LEFT) {
         float4 l = reinterpret_cast<const float4*>(m.left_vals)[id * d4 + c];
@@ -113,13 +122,7 @@ __global__ void __launch_bounds__(256) k_attn_centres_direct(tg_model m, int64_t
   }
   if (da.outdated) {
     const int64_t no = min((int64_t)*da.n_outdated, da.cap);
-    const float* mem_ts = (m.msg_src == TG_SRC_LEFT) ? m.left_ts : m.right_ts;
-    for (int64_t i = tid; i < no; i += nth) {
-      const int64_t id = da.outdated[i];
-      const float mts = m.msg_ts[id], last = mem_ts[id];
-      if (last > mts) atomicOr(da.err, TG_ERR_MSG_BEFORE_MEM);
-      if (m.msg_src == TG_SRC_LEFT && !(mts == last)) atomicOr(da.err, TG_ERR_MSG_TS_MISMATCH);
-    }
+    for (int64_t i = tid; i < no; i += nth) check_msg_times(m, da.outdated[i], da.err);
   }
   if (pos.best) pos_max_pass(pos, tid, nth);
 }
@@ -230,6 +233,7 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
       eid_l = l1_eids[i * K + lane];
       dt_l = ts[i] - l1_ts[i * K + lane];
       if (nb_l != 0) u_l = direct ? (int)(2 * nb_l + (bm_test(m.has_msg, nb_l) ? 1 : 0)) : (int)bm_rank(bm, rank, nb_l);
+      if (direct && pos.chk_err && (u_l & 1)) check_msg_times(m, nb_l, pos.chk_err);
     }
     unsigned long long live = __ballot(nb_l != 0);  // padding keys are masked (temporal_agg_modules.py:80)
     const bool any = live != 0ull;
@@ -943,8 +947,17 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   w.l1e = io->l1_eids ? io->l1_eids : w.l1_eids;
   w.l1t = io->l1_ts ? io->l1_ts : w.l1_ts;
   const tg_lazy_restart* lz = (io->lazy && !io->embed_only) ? io->lazy : nullptr;
+  // eager updates, direct form (default; TG_EAGER_DIRECT=0 keeps the compact copy): centres and neighbour rows are read
+  // from pending / right themselves, so there is no gather launch and no reprs buffer
+  static const int direct_knob = getenv("TG_EAGER_DIRECT") ? atoi(getenv("TG_EAGER_DIRECT")) : 1;
+  w.direct = eager && direct_knob != 0 && !io->eager_copy && !io->collate_only;
+  // the one-launch write-back needs the snapshot; the restarter targets (h_prev_*) are read between STEP 4 and STEP 6,
+  // so a step that outputs them keeps the two-phase write-back
+  w.fused_wb = w.direct && !io->embed_only && !io->h_prev_left && !io->h_prev_right;
+  // lean: nothing in such a step needs the involved / outdated sets, so they are not formed (tiger_hip.h, tg_step_io.lean)
+  w.lean = io->lean && w.fused_wb && !lz && m->n_nodes <= cap;
   if ((rc = sample_batch_launch(g, B, io->src, io->dst, io->neg, io->ts, io->eids, io->offset_dev, (int32_t)K, w.nids3,
-                                w.ts3f, w.eids, w.l1n, w.l1e, w.l1t, w.flags, st,
+                                w.ts3f, w.eids, w.l1n, w.l1e, w.l1t, w.lean ? nullptr : w.flags, st,
                                 lz ? reinterpret_cast<uint32_t*>(w.counts + 4) : nullptr)) != TG_OK)
     return rc;
   // lazy restart (train_self_supervised.py:152-163): before STEP 1, because a restarted node loses its pending message
@@ -954,24 +967,20 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   prof_mark(pf, ST_COMPACT, st);
   w.inv = io->involved ? io->involved : w.involved;
   // involved = sorted(set(...)); outdated = involved & has-message (memory.py:108-126)
-  if ((rc = unique_compact_launch(w.flags, w.bm, m->n_nodes, w.rank, w.inv, w.counts + 0, cap, m->has_msg, w.rank_out,
+  if (!w.lean &&
+      (rc = unique_compact_launch(w.flags, w.bm, m->n_nodes, w.rank, w.inv, w.counts + 0, cap, m->has_msg, w.rank_out,
                                   w.outdated, w.out_pos, w.counts + 1, w.scan_ws, w.scan_bytes, st)) != TG_OK)
     return rc;
   if (io->collate_only) return check_launch("tg_stream_step(collate_only)");
   prof_mark(pf, ST_GATHER, st);
   // the positive-node dedup (needed by the write-back) rides on two launches of the forward pass
-  PosArgs pos{B, w.nids3, w.ts3f, w.bm, w.rank, w.best, w.counts + 2, w.upos, w.index, w.upos32};
+  PosArgs pos{B, w.nids3, w.ts3f, w.bm, w.rank, w.best, w.counts + 2, w.upos, w.index, w.upos32, nullptr};
+  if (w.lean) { pos.bm = nullptr; pos.rank = nullptr; pos.chk_err = io->err; }
   const PosArgs* pp = io->embed_only ? nullptr : &pos;
   w.dedup_done = pp != nullptr;
   // ---- STEP 1-2: reprs = right_memory[involved] (+ invariants); outdated rows <- updater(...)
-  // eager updates, direct form (default; TG_EAGER_DIRECT=0 keeps the compact copy): centres and neighbour rows are read
-  // from pending / right themselves, so there is no gather launch and no reprs buffer
-  static const int direct_knob = getenv("TG_EAGER_DIRECT") ? atoi(getenv("TG_EAGER_DIRECT")) : 1;
-  w.direct = eager && direct_knob != 0 && !io->eager_copy;
-  // the one-launch write-back needs the snapshot; the restarter targets (h_prev_*) are read between STEP 4 and STEP 6,
-  // so a step that outputs them keeps the two-phase write-back
-  w.fused_wb = w.direct && !io->embed_only && !io->h_prev_left && !io->h_prev_right;
-  const DirectArgs da{w.outdated, w.counts + 1, cap, io->err, w.fused_wb ? (float4*)w.snap : nullptr, w.snap_ts, 2 * B};
+  const DirectArgs da{w.lean ? nullptr : w.outdated, w.counts + 1, cap, io->err, w.fused_wb ? (float4*)w.snap : nullptr,
+                      w.snap_ts, 2 * B, w.lean ? 1 : 0};
   if (!w.direct &&
       (rc = consume_gather_check_launch(m, w.inv, w.counts + 0, cap, w.reprs, w.outdated, w.counts + 1, io->err, st, pp,
                                         eager)) != TG_OK)
@@ -1011,7 +1020,8 @@ static WritebackArgs writeback_args(const tg_model* m, const tg_step_io* io, Ste
   wa.n_upos = w.counts + 2; wa.reprs = w.reprs; wa.bm = w.bm; wa.rank = w.rank; wa.h = io->h; wa.err = io->err;
   wa.counts_src = io->counts ? w.counts : nullptr; wa.counts_dst = io->counts;
   wa.offset_dev = (io->offset_dev && io->advance) ? io->offset_dev : nullptr;
-  wa.clean_flags = w.flags; wa.flag_bytes = (int64_t)((m->n_nodes + 63) / 64) * 64; wa.clean_best = w.best;
+  wa.clean_flags = w.lean ? nullptr : w.flags; wa.flag_bytes = (int64_t)((m->n_nodes + 63) / 64) * 64;
+  wa.clean_best = w.best; wa.clean_best_n = w.lean ? m->n_nodes : 0;
   wa.clean_counts = w.counts;
   wa.lazy_batch = (io->lazy && io->lazy->batch_dev) ? io->lazy->batch_dev : nullptr;
   wa.new_from_pending = w.direct ? 1 : 0;  // no reprs copy was made: STEP 4 reads the owner table of updater rows

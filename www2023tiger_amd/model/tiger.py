@@ -474,9 +474,11 @@ class TIGE(nn.Module):
         tg_stream_step; reused every step so the call sequence can be graph-captured."""
 
         def __init__(self, model: 'TIGE', B: int, want_prev: bool, resident=None, embed_only: bool = False,
-                     h_out=None, h_new_out=None, want_h_new: bool = True):
+                     h_out=None, h_new_out=None, want_h_new: bool = True, lean: bool = False):
             """resident = (src, dst, neg, ts64, eids) device tensors of the WHOLE stream: the
-            step then reads batch [offset, offset+B) and advances `offset` on device."""
+            step then reads batch [offset, offset+B) and advances `offset` on device.
+            lean: the caller does not read `involved` nor counts[0:2] (tiger_hip.h: tg_step_io.lean) - an eager
+            step on a graph of at most 3B(K+1) nodes then skips forming those sets; same results otherwise."""
             dev, d, K = model.device, model.memory_dim, model.n_neighbors
             self.B = B
             self.embed_only = embed_only
@@ -511,6 +513,7 @@ class TIGE(nn.Module):
                                ptr(self.counts), ptr(self.h_prev_left), ptr(self.h_prev_right), ptr(self.err),
                                ptr(self.offset), 1 if resident is not None else 0, 1 if embed_only else 0, None,
                                ptr(self.h_new), 0 if embed_only else 1, 0)
+            self.io.lean = 1 if lean else 0
 
         def attach_profiler(self, prof):
             self.io.profiler = prof
@@ -544,11 +547,11 @@ class TIGE(nn.Module):
             self.ts.copy_(ts, non_blocking=True)
             self.eids.copy_(eids, non_blocking=True)
 
-    def step_buffers(self, B: int, want_prev: bool = False) -> 'TIGE.StepBuffers':
-        key = ('step', B, want_prev)
+    def step_buffers(self, B: int, want_prev: bool = False, lean: bool = False) -> 'TIGE.StepBuffers':
+        key = ('step', B, want_prev, lean)
         buf = self._step_ws.get(key)
         if buf is None:
-            buf = TIGE.StepBuffers(self, B, want_prev)
+            buf = TIGE.StepBuffers(self, B, want_prev, lean=lean)
             self._step_ws[key] = buf
         return buf
 
@@ -590,13 +593,14 @@ class TIGE(nn.Module):
                                  stream_ptr(self.device)), 'tg_stream_step')
 
     @torch.no_grad()
-    def stream_step(self, src, dst, neg, ts, eids, want_prev: bool = False, check_invariants: bool = True):
+    def stream_step(self, src, dst, neg, ts, eids, want_prev: bool = False, check_invariants: bool = True,
+                    lean: bool = False):
         """Fused collate + STEP 1-6 (data_loader.py:77-131 + tiger.py:196-255).
         ts are the float64 event times.  Returns the StepBuffers (h = embeddings of
-        cat[src,dst,neg]; rows [0,2B) are h_left)."""
+        cat[src,dst,neg]; rows [0,2B) are h_left).  lean: see StepBuffers."""
         dev = self.device
         to = lambda x, dt: torch.as_tensor(x).to(dev, dt)
-        buf = self.step_buffers(len(src), want_prev)
+        buf = self.step_buffers(len(src), want_prev, lean)
         buf.load(to(src, torch.int64), to(dst, torch.int64), to(neg, torch.int64), to(ts, torch.float64),
                  to(eids, torch.int64))
         self.launch_step(buf)
