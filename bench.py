@@ -353,8 +353,8 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     work = stage_work(cfg, U, O_, P, eager, fused, stream['n_nodes'], E)
     traffic = load_traffic(traffic_tag)
     empty = {'zero_flags', 'dedup_positive', 'restarter_targets', 'apply_messages(gru)' if eager else 'eager_updater(gru)'}
-    if lean:
-        empty |= {'unique_compact'}
+    if lean:  # no compaction launch, and the centres ride on the sampler's launch
+        empty |= {'unique_compact'} | ({'attn_centres+qconst'} if fused else set())
     if direct:  # ... and STEP 4-6 are one launch (reported under writeback_phase1)
         empty |= {'gather_right_memory', 'writeback_phase0'}
         w0, w1 = work['writeback_phase0'], work['writeback_phase1']

@@ -206,10 +206,11 @@ __device__ __forceinline__ uint64_t orderable(float x) {
 
 // ---- internal launchers shared between translation units (not part of the C ABI) ----
 // sampler with the batch -> query expansion fused in (data_loader.py:79-81,92,128)
+struct CentresRider;
 int sample_batch_launch(const tg_tcsr* g, int64_t B, const int64_t* src, const int64_t* dst, const int64_t* neg,
                         const double* ts, const int64_t* eids, const int64_t* off, int32_t K, int64_t* nids3,
                         float* ts3f, int64_t* eids_b, int64_t* o_nbr, int64_t* o_eid, float* o_ts, uint8_t* mark,
-                        hipStream_t st, uint32_t* tmin_key = nullptr);
+                        hipStream_t st, uint32_t* tmin_key = nullptr, const CentresRider* rider = nullptr);
 // the lazy-restart loop body of train_self_supervised.py:152-163 with the static restarter (tiger_hip.h: tg_lazy_restart);
 // runs between the sampler (flags, *tmin_key) and the compaction
 int lazy_restart_launch(const tg_tcsr* g, const tg_model* m, const tg_lazy_restart* lz, const uint8_t* flags,
@@ -233,13 +234,36 @@ struct PosArgs {
 __device__ __forceinline__ int64_t pos_slot(const PosArgs& a, int64_t node) {
   return a.bm ? (int64_t)bm_rank(a.bm, a.rank, node) : node;
 }
-__device__ __forceinline__ void pos_max_pass(const PosArgs& a, int64_t tid, int64_t nth) {
+// where the ids / times of cat[src, dst, neg] come from: the step's own copy (nids3, float32 times), or - for work that
+// shares a launch with the sampler, which is still writing that copy - the batch arrays themselves
+struct ArrayIds {
+  const int64_t* nids3;
+  const float* ts3f;
+  __device__ __forceinline__ int64_t id(int64_t i) const { return nids3[i]; }
+  __device__ __forceinline__ float tf(int64_t e) const { return ts3f[e]; }
+};
+struct RawIds {
+  const int64_t *src, *dst, *neg;
+  const double* ts;
+  int64_t off, B;
+  __device__ __forceinline__ int64_t id(int64_t i) const {
+    const int64_t e = i % B;
+    const int r = (int)(i / B);
+    return r == 0 ? src[off + e] : (r == 1 ? dst[off + e] : neg[off + e]);
+  }
+  __device__ __forceinline__ float tf(int64_t e) const { return (float)ts[off + e]; }
+};
+template <class Ids>
+__device__ __forceinline__ void pos_max_pass(const PosArgs& a, const Ids& b, int64_t tid, int64_t nth) {
   if (tid == 0) *a.count = 0;  // the winners pass (a later launch) counts into it
   for (int64_t i = tid; i < 2 * a.B; i += nth) {
     const int64_t e = i < a.B ? i : i - a.B;
-    const unsigned long long key = (orderable(a.ts[e]) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)i);
-    atomicMax(a.best + pos_slot(a, a.nids3[i]), key);
+    const unsigned long long key = (orderable(b.tf(e)) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)i);
+    atomicMax(a.best + pos_slot(a, b.id(i)), key);
   }
+}
+__device__ __forceinline__ void pos_max_pass(const PosArgs& a, int64_t tid, int64_t nth) {
+  pos_max_pass(a, ArrayIds{a.nids3, a.ts}, tid, nth);
 }
 __device__ __forceinline__ void pos_winners_pass(const PosArgs& a, int64_t tid, int64_t nth) {
   for (int64_t i = tid; i < 2 * a.B; i += nth) {
@@ -254,6 +278,80 @@ __device__ __forceinline__ void pos_winners_pass(const PosArgs& a, int64_t tid, 
     }
   }
 }
+// Eager updates, direct form: the centre row is read from the state tables themselves,
+//   c_i = (has_msg[v] ? pending[v] : right[v]) + nfeat[v],   v = nid_i
+// (what reprs[local(v)] holds after STEP 1-2, tiger.py:214-221), so no compact copy of the involved rows is made.
+// The launch also carries what rode on the gather launch: the time invariants of compute_messages over the outdated
+// list (message_modules.py:158-159, tiger.py:325-327) and the first dedup pass.
+struct DirectArgs {
+  const int64_t* outdated;
+  const int32_t* n_outdated;
+  int64_t cap;
+  uint32_t* err;
+  // snapshot for the one-launch write-back (nullable): for position i < n_snap of cat[src, dst] the message-source
+  // memory row of its node as STEP 5 will want it (tiger.py:422-442: + node features; msg_src = right: the right memory
+  // as STEP 4 leaves it, i.e. the centre row itself) and that memory's time.  Taken here, before anything is written,
+  // it lets STEP 5 share a launch with STEP 6, which overwrites those very rows of the left memory.
+  float4* snap;
+  float* snap_ts;
+  int64_t n_snap;
+  // lean step (no outdated list): the invariants are checked per centre here and per neighbour in the core launch -
+  // the same node set, involved & has-message, some nodes more than once
+  int per_row_checks;
+};
+__device__ __forceinline__ void check_msg_times(const tg_model& m, int64_t id, uint32_t* err) {
+  const float mts = m.msg_ts[id], last = (m.msg_src == TG_SRC_LEFT ? m.left_ts : m.right_ts)[id];
+  if (last > mts) atomicOr(err, TG_ERR_MSG_BEFORE_MEM);
+  if (m.msg_src == TG_SRC_LEFT && !(mts == last)) atomicOr(err, TG_ERR_MSG_TS_MISMATCH);
+}
+// thread tid of nth: Q centre rows (float4 granularity), the checks and the first dedup pass
+template <class Ids>
+__device__ __forceinline__ void centres_direct_body(const tg_model& m, int64_t Q, const Ids& ids,
+                                                    const float4* __restrict__ nf, float4* __restrict__ out,
+                                                    const DirectArgs& da, const PosArgs& pos, int64_t tid, int64_t nth) {
+  const int d4 = m.d / 4;
+  const float4* right = reinterpret_cast<const float4*>(m.right_vals);
+  const float4* pend = reinterpret_cast<const float4*>(m.pending_vals);
+  const int64_t total = Q * d4;
+  for (int64_t t = tid; t < total; t += nth) {
+    const int64_t i = t / d4;
+    const int c = (int)(t - i * d4);
+    const int64_t id = ids.id(i);
+    const bool pending = bm_test(m.has_msg, id);
+    float4 v = (pending ? pend : right)[id * d4 + c];
+    float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nf) f = nf[id * d4 + c];
+    v.x += f.x; v.y += f.y; v.z += f.z; v.w += f.w;
+    out[t] = v;
+    if (da.per_row_checks && c == 0 && pending) check_msg_times(m, id, da.err);
+    if (da.snap && i < da.n_snap) {
+      if (m.msg_src == TG_SRC_LEFT) {
+        float4 l = reinterpret_cast<const float4*>(m.left_vals)[id * d4 + c];
+        l.x += f.x; l.y += f.y; l.z += f.z; l.w += f.w;
+        da.snap[t] = l;
+        if (c == 0) da.snap_ts[i] = m.left_ts[id];
+      } else {
+        da.snap[t] = v;
+        if (c == 0) da.snap_ts[i] = pending ? m.msg_ts[id] : m.right_ts[id];
+      }
+    }
+  }
+  if (da.outdated) {
+    const int64_t no = min((int64_t)*da.n_outdated, da.cap);
+    for (int64_t i = tid; i < no; i += nth) check_msg_times(m, da.outdated[i], da.err);
+  }
+  if (pos.best) pos_max_pass(pos, ids, tid, nth);
+}
+// The centres of a lean step depend on nothing the sampler produces (ids and times come from the batch arrays, the dedup
+// slots are node ids), so they ride on the sampler's launch as `blocks` extra workgroups at the end of its grid.
+struct CentresRider {
+  tg_model m;
+  const float4* nf;
+  float4* out;
+  DirectArgs da;
+  PosArgs pos;
+  unsigned blocks;
+};
 // reprs <- right memory rows of the involved nodes, plus the message/memory time invariants
 // (+ the first dedup pass when pos != nullptr)
 // eager: rows of nodes with a pending message come from m->pending_vals (see tiger_hip.h) instead of being left

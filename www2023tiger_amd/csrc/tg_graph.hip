@@ -179,13 +179,20 @@ __global__ void __launch_bounds__(256) k_sample_batch(tg_tcsr g, int64_t B, cons
                                                       int64_t* __restrict__ nids3, float* __restrict__ ts3f,
                                                       int64_t* __restrict__ eids_b, int64_t* __restrict__ o_nbr,
                                                       int64_t* __restrict__ o_eid, float* __restrict__ o_ts,
-                                                      uint8_t* __restrict__ mark, uint32_t* __restrict__ tmin_key) {
+                                                      uint8_t* __restrict__ mark, uint32_t* __restrict__ tmin_key,
+                                                      CentresRider cr) {
   constexpr int GPB = 256 / G;
   const int sub = threadIdx.x % G;
   const int64_t o = off ? *off : 0;
   const int64_t Q = 3 * B;
+  const unsigned sblocks = gridDim.x - cr.blocks;  // the sampler's share of the grid
+  if (blockIdx.x >= sblocks) {  // rider: the attention centres of a lean step (tg_common.h)
+    centres_direct_body(cr.m, Q, RawIds{src, dst, neg, ts, o, B}, cr.nf, cr.out, cr.da, cr.pos,
+                        (int64_t)(blockIdx.x - sblocks) * blockDim.x + threadIdx.x, (int64_t)cr.blocks * blockDim.x);
+    return;
+  }
   float tmin = INFINITY;  // earliest event time of the batch in float32 (`ts.min()` of train_self_supervised.py:162)
-  for (int64_t q = (int64_t)blockIdx.x * GPB + threadIdx.x / G; q < Q; q += (int64_t)gridDim.x * GPB) {
+  for (int64_t q = (int64_t)blockIdx.x * GPB + threadIdx.x / G; q < Q; q += (int64_t)sblocks * GPB) {
     const int64_t e = q % B;
     const int r = (int)(q / B);
     const int64_t nid = r == 0 ? src[o + e] : (r == 1 ? dst[o + e] : neg[o + e]);
@@ -297,14 +304,15 @@ int lazy_restart_launch(const tg_tcsr* g, const tg_model* m, const tg_lazy_resta
 int sample_batch_launch(const tg_tcsr* g, int64_t B, const int64_t* src, const int64_t* dst, const int64_t* neg,
                         const double* ts, const int64_t* eids, const int64_t* off, int32_t K, int64_t* nids3,
                         float* ts3f, int64_t* eids_b, int64_t* o_nbr, int64_t* o_eid, float* o_ts, uint8_t* mark,
-                        hipStream_t st, uint32_t* tmin_key) {
+                        hipStream_t st, uint32_t* tmin_key, const CentresRider* rider) {
   const int64_t Q = 3 * B;
+  const CentresRider cr = rider ? *rider : CentresRider{};
   if (K <= 16)
-    hipLaunchKernelGGL(k_sample_batch<16>, dim3(flat_grid(Q, 16)), dim3(256), 0, st, *g, B, src, dst, neg, ts, eids,
-                       off, K, nids3, ts3f, eids_b, o_nbr, o_eid, o_ts, mark, tmin_key);
+    hipLaunchKernelGGL(k_sample_batch<16>, dim3(flat_grid(Q, 16) + cr.blocks), dim3(256), 0, st, *g, B, src, dst, neg, ts,
+                       eids, off, K, nids3, ts3f, eids_b, o_nbr, o_eid, o_ts, mark, tmin_key, cr);
   else
-    hipLaunchKernelGGL(k_sample_batch<64>, dim3(flat_grid(Q, 4)), dim3(256), 0, st, *g, B, src, dst, neg, ts, eids,
-                       off, K, nids3, ts3f, eids_b, o_nbr, o_eid, o_ts, mark, tmin_key);
+    hipLaunchKernelGGL(k_sample_batch<64>, dim3(flat_grid(Q, 4) + cr.blocks), dim3(256), 0, st, *g, B, src, dst, neg, ts,
+                       eids, off, K, nids3, ts3f, eids_b, o_nbr, o_eid, o_ts, mark, tmin_key, cr);
   return check_launch("sample_batch");
 }
 

@@ -63,68 +63,11 @@ __global__ void __launch_bounds__(256) k_attn_centres(int64_t Q, int d4, const i
   }
 }
 
-// Eager updates, direct form: the centre row is read from the state tables themselves,
-//   c_i = (has_msg[v] ? pending[v] : right[v]) + nfeat[v],   v = nid_i
-// (what reprs[local(v)] holds after STEP 1-2, tiger.py:214-221), so no compact copy of the involved rows is made.
-// The launch also carries what rode on the gather launch: the time invariants of compute_messages over the outdated
-// list (message_modules.py:158-159, tiger.py:325-327) and the first dedup pass.
-struct DirectArgs {
-  const int64_t* outdated;
-  const int32_t* n_outdated;
-  int64_t cap;
-  uint32_t* err;
-  // snapshot for the one-launch write-back (nullable): for position i < n_snap of cat[src, dst] the message-source
-  // memory row of its node as STEP 5 will want it (tiger.py:422-442: + node features; msg_src = right: the right memory
-  // as STEP 4 leaves it, i.e. the centre row itself) and that memory's time.  Taken here, before anything is written,
-  // it lets STEP 5 share a launch with STEP 6, which overwrites those very rows of the left memory.
-  float4* snap;
-  float* snap_ts;
-  int64_t n_snap;
-  // lean step (no outdated list): the invariants are checked per centre here and per neighbour in the core launch -
-  // the same node set, involved & has-message, some nodes more than once
-  int per_row_checks;
-};
-__device__ __forceinline__ void check_msg_times(const tg_model& m, int64_t id, uint32_t* err) {
-  const float mts = m.msg_ts[id], last = (m.msg_src == TG_SRC_LEFT ? m.left_ts : m.right_ts)[id];
-  if (last > mts) atomicOr(err, TG_ERR_MSG_BEFORE_MEM);
-  if (m.msg_src == TG_SRC_LEFT && !(mts == last)) atomicOr(err, TG_ERR_MSG_TS_MISMATCH);
-}
 __global__ void __launch_bounds__(256) k_attn_centres_direct(tg_model m, int64_t Q, const int64_t* __restrict__ nids,
                                                              const float4* __restrict__ nf, float4* __restrict__ out,
                                                              DirectArgs da, PosArgs pos) {
-  const int d4 = m.d / 4;
-  const float4* right = reinterpret_cast<const float4*>(m.right_vals);
-  const float4* pend = reinterpret_cast<const float4*>(m.pending_vals);
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
-  const int64_t total = Q * d4;
-  for (int64_t t = tid; t < total; t += nth) {
-    const int64_t i = t / d4;
-    const int c = (int)(t - i * d4);
-    const int64_t id = nids[i];
-    const bool pending = bm_test(m.has_msg, id);
-    float4 v = (pending ? pend : right)[id * d4 + c];
-    float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (nf) f = nf[id * d4 + c];
-    v.x += f.x; v.y += f.y; v.z += f.z; v.w += f.w;
-    out[t] = v;
-    if (da.per_row_checks && c == 0 && pending) check_msg_times(m, id, da.err);
-    if (da.snap && i < da.n_snap) {
-      if (m.msg_src == TG_SRC_LEFT) {
-        float4 l = reinterpret_cast<const float4*>(m.left_vals)[id * d4 + c];
-        l.x += f.x; l.y += f.y; l.z += f.z; l.w += f.w;
-        da.snap[t] = l;
-        if (c == 0) da.snap_ts[i] = m.left_ts[id];
-      } else {
-        da.snap[t] = v;
-        if (c == 0) da.snap_ts[i] = pending ? m.msg_ts[id] : m.right_ts[id];
-      }
-    }
-  }
-  if (da.outdated) {
-    const int64_t no = min((int64_t)*da.n_outdated, da.cap);
-    for (int64_t i = tid; i < no; i += nth) check_msg_times(m, da.outdated[i], da.err);
-  }
-  if (pos.best) pos_max_pass(pos, tid, nth);
+  centres_direct_body(m, Q, ArrayIds{nids, pos.ts}, nf, out, da, pos,
+                      (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
 // explicit fma: the library is built with -ffp-contract=off (only the time encoding needs the
@@ -485,12 +428,12 @@ static void launch_centres(const tg_model* m, int64_t Q, const int64_t* nids, co
 static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids, const float* ts,
                               const int64_t* l1_nids, const int64_t* l1_eids, const float* l1_ts, const float* reprs,
                               const uint64_t* bm, const uint32_t* rank, float* out, const AttnWs& w, hipStream_t st,
-                              tg_profiler* pf, const PosArgs* pos, const DirectArgs* da) {
+                              tg_profiler* pf, const PosArgs* pos, const DirectArgs* da, bool centres_done) {
   // stage numbering of the profiler is kept: q -> "merged q+g", g -> skipped, v/out -> skipped, fc1 -> fused
   int stage = ST_ATTN_FIRST + 1;
   const int d = m->d;
   const FusedView f = fused_view(m, m->attn_fused);
-  launch_centres(m, Q, nids, reprs, bm, rank, w, pos, da, st);
+  if (!centres_done) launch_centres(m, Q, nids, reprs, bm, rank, w, pos, da, st);  // else: rode on the sampler's launch
   int rc;
   GemmArgs g{};
   // G = c Wqk^T + gconst   (scaled query folded through the key projection, all heads at once)
@@ -536,19 +479,19 @@ int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float*
                  const int64_t* l1_eids, const float* l1_ts, const float* reprs, const uint64_t* bm,
                  const uint32_t* rank, float* out, const AttnWs& w, hipStream_t st, tg_profiler* pf = nullptr,
                  const DropCfg* drop = nullptr, const PosArgs* pos = nullptr, const DirectArgs* da = nullptr,
-                 const float* key_rows = nullptr) {
+                 const float* key_rows = nullptr, bool centres_done = false) {
   const DropCfg dc = drop ? *drop : DropCfg{};
   int stage = ST_ATTN_FIRST;
   prof_mark(pf, stage++, st);
   const int d = m->d, d_e = m->d_e, kvw = 2 * d + d_e, nh = m->n_head, dh = 2 * d / nh, E = 2 * d;
   if (m->attn_fused && dc.p == 0.f && !key_rows)
-    return attn_forward_fused(m, Q, nids, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, out, w, st, pf, pos, da);
+    return attn_forward_fused(m, Q, nids, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, out, w, st, pf, pos, da, centres_done);
   const int qblocks = (int)cdiv(2 * d, 4);
   if (da) {  // the constant half of the query projection from the rank-form kernel (no centre rows), then the direct centres
     hipLaunchKernelGGL(k_attn_centres, dim3(1 + qblocks), dim3(256), 0, st, (int64_t)0, d / 4, nids, (const float4*)reprs, bm,
                        rank, (const float4*)m->nfeats, (float4*)w.cc, qblocks, m->attn_wq, m->attn_b_in, m->te_freq,
                        m->te_phase, w.qconst, PosArgs{});
-    launch_centres(m, Q, nids, reprs, bm, rank, w, pos, da, st);
+    if (!centres_done) launch_centres(m, Q, nids, reprs, bm, rank, w, pos, da, st);
   } else {
     hipLaunchKernelGGL(k_attn_centres, dim3(flat_grid(Q * (d / 4), 256) + qblocks), dim3(256), 0, st, Q, d / 4, nids,
                        (const float4*)reprs, bm, rank, (const float4*)m->nfeats, (float4*)w.cc, qblocks, m->attn_wq,
@@ -956,9 +899,17 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   w.fused_wb = w.direct && !io->embed_only && !io->h_prev_left && !io->h_prev_right;
   // lean: nothing in such a step needs the involved / outdated sets, so they are not formed (tiger_hip.h, tg_step_io.lean)
   w.lean = io->lean && w.fused_wb && !lz && m->n_nodes <= cap;
+  // the positive-node dedup (needed by the write-back) rides on two launches of the forward pass
+  PosArgs pos{B, w.nids3, w.ts3f, w.bm, w.rank, w.best, w.counts + 2, w.upos, w.index, w.upos32, nullptr};
+  if (w.lean) { pos.bm = nullptr; pos.rank = nullptr; pos.chk_err = io->err; }
+  const PosArgs* pp = io->embed_only ? nullptr : &pos;
+  const DirectArgs da{w.lean ? nullptr : w.outdated, w.counts + 1, cap, io->err, w.fused_wb ? (float4*)w.snap : nullptr,
+                      w.snap_ts, 2 * B, w.lean ? 1 : 0};
+  // lean: the centres need nothing the sampler produces and share its launch
+  const CentresRider rider{*m, (const float4*)m->nfeats, (float4*)w.attn.cc, da, pos, flat_grid(Q * (m->d / 4), 256)};
   if ((rc = sample_batch_launch(g, B, io->src, io->dst, io->neg, io->ts, io->eids, io->offset_dev, (int32_t)K, w.nids3,
                                 w.ts3f, w.eids, w.l1n, w.l1e, w.l1t, w.lean ? nullptr : w.flags, st,
-                                lz ? reinterpret_cast<uint32_t*>(w.counts + 4) : nullptr)) != TG_OK)
+                                lz ? reinterpret_cast<uint32_t*>(w.counts + 4) : nullptr, w.lean ? &rider : nullptr)) != TG_OK)
     return rc;
   // lazy restart (train_self_supervised.py:152-163): before STEP 1, because a restarted node loses its pending message
   if (lz && (rc = lazy_restart_launch(g, m, lz, w.flags, reinterpret_cast<const uint32_t*>(w.counts + 4), w.counts + 3,
@@ -973,14 +924,8 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
     return rc;
   if (io->collate_only) return check_launch("tg_stream_step(collate_only)");
   prof_mark(pf, ST_GATHER, st);
-  // the positive-node dedup (needed by the write-back) rides on two launches of the forward pass
-  PosArgs pos{B, w.nids3, w.ts3f, w.bm, w.rank, w.best, w.counts + 2, w.upos, w.index, w.upos32, nullptr};
-  if (w.lean) { pos.bm = nullptr; pos.rank = nullptr; pos.chk_err = io->err; }
-  const PosArgs* pp = io->embed_only ? nullptr : &pos;
   w.dedup_done = pp != nullptr;
   // ---- STEP 1-2: reprs = right_memory[involved] (+ invariants); outdated rows <- updater(...)
-  const DirectArgs da{w.lean ? nullptr : w.outdated, w.counts + 1, cap, io->err, w.fused_wb ? (float4*)w.snap : nullptr,
-                      w.snap_ts, 2 * B, w.lean ? 1 : 0};
   if (!w.direct &&
       (rc = consume_gather_check_launch(m, w.inv, w.counts + 0, cap, w.reprs, w.outdated, w.counts + 1, io->err, st, pp,
                                         eager)) != TG_OK)
@@ -992,7 +937,7 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
     return rc;
   // ---- STEP 3: temporal embeddings of cat[src, dst, neg]
   if ((rc = attn_forward(m, Q, w.nids3, w.ts3f, w.l1n, w.l1e, w.l1t, w.reprs, w.bm, w.rank, io->h, w.attn, st, pf,
-                         drop, pp, w.direct ? &da : nullptr)) != TG_OK)
+                         drop, pp, w.direct ? &da : nullptr, nullptr, w.lean)) != TG_OK)
     return rc;
   prof_mark(pf, ST_DEDUP, st);
   if (io->h_new) {  // h(t'+) rows of cat[src, dst]: reprs[local(node)], or the table rows themselves
