@@ -658,7 +658,11 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
   const unsigned long long t_entry = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
   // One LDS arena: the operand tiles while the loop runs, the k-group fold afterwards (the tiles are dead then).
   constexpr int A_FLOATS = 2 * BM * LDK, B_FLOATS = 2 * 3 * 32 * LDK;
-  constexpr int RED_FLOATS = KS == 1 ? 0 : (KS / 2) * 4 * NW * 16 * 64;  // the upper half of the k-groups writes at once
+  // k-group fold: either halving rounds (the upper half of the live groups writes at once), or - where the LDS allows -
+  // one reduce-scatter round after which EVERY k-group finishes the rows it owns (see the epilogue)
+  constexpr bool SCAT = KS > 1 && NW != 3;
+  constexpr int OWN = 16 / KS;  // accumulator registers (row quads) a k-group owns in the scattered epilogue
+  constexpr int RED_FLOATS = KS == 1 ? 0 : SCAT ? NW * KS * (KS - 1) * 4 * OWN * 64 : (KS / 2) * 4 * NW * 16 * 64;
   constexpr int ARENA0 = (A_FLOATS + B_FLOATS) > RED_FLOATS ? (A_FLOATS + B_FLOATS) : RED_FLOATS;
   constexpr bool TAIL = NW == 3 && KS == 4;  // this instance also serves the 16-column tail blocks (gru_tail16)
   constexpr int ARENA = TAIL && (T16_A + T16_B) > ARENA0 ? (T16_A + T16_B) : ARENA0;
@@ -859,6 +863,68 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
     if (t < nkt) tile(HP1{}, 0, t, ra0, rb0, ra1, rb1);
   }
   const unsigned long long t_loop1 = (dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
+  const int j = min(j0 + fr, d - 1);
+  const bool jok = j0 + fr < d;
+  auto finish = [&](int r, float ar_, float az_, float ain_, float ahn_) {  // gates + blend of accumulator row r
+    const int lr = rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+    const int64_t m = m0 + lr;
+    const float hold = Hs[lr][fr];
+    const int64_t orow = orow_s[lr];
+    const float rg = fast_sigmoid(ar_ + br);
+    const float zg = fast_sigmoid(az_ + bz);
+    const float hn = ahn_ + bhn;
+    const float ng = fast_tanh(ain_ + bin + rg * hn);
+    if (jok && m < M) {
+      g.out[orow * g.ldo + j] = (1.f - zg) * ng + zg * hold;
+      if (g.gates) {
+        float* gp = g.gates + m * 4 * (int64_t)d + j;
+        gp[0] = rg; gp[d] = zg; gp[2 * d] = ng; gp[3 * d] = hn;
+      }
+    }
+  };
+  if constexpr (SCAT) {
+    // Reduce-scatter over the k-groups of a row wave: group v owns accumulator registers [v OWN, (v+1) OWN) (a quarter
+    // of the tile's rows with four groups).  Every group parks the registers the others own in LDS - one round, one
+    // barrier - then sums its own share and runs the gate arithmetic and the stores for it, so the epilogue's
+    // transcendental work is spread over all the block's wavefronts instead of the first k-group's.
+    float (*sc)[KS][KS - 1][4][OWN][64] = reinterpret_cast<float (*)[KS][KS - 1][4][OWN][64]>(arena);
+#pragma unroll
+    for (int v = 0; v < KS; ++v) {
+      if (v != ks) {  // wave-uniform
+        const int slot = (ks - v - 1 + KS) % KS;
+#pragma unroll
+        for (int q = 0; q < OWN; ++q) {
+          sc[rw][v][slot][0][q][lane] = acc_r[v * OWN + q];
+          sc[rw][v][slot][1][q][lane] = acc_z[v * OWN + q];
+          sc[rw][v][slot][2][q][lane] = acc_in[v * OWN + q];
+          sc[rw][v][slot][3][q][lane] = acc_hn[v * OWN + q];
+        }
+      }
+    }
+    __syncthreads();
+    float o_r[OWN], o_z[OWN], o_in[OWN], o_hn[OWN];
+#pragma unroll
+    for (int v = 0; v < KS; ++v) {
+      if (v == ks) {
+#pragma unroll
+        for (int q = 0; q < OWN; ++q) {
+          o_r[q] = acc_r[v * OWN + q]; o_z[q] = acc_z[v * OWN + q];
+          o_in[q] = acc_in[v * OWN + q]; o_hn[q] = acc_hn[v * OWN + q];
+        }
+      }
+    }
+#pragma unroll
+    for (int sl = 0; sl < KS - 1; ++sl)
+#pragma unroll
+      for (int q = 0; q < OWN; ++q) {
+        o_r[q] += sc[rw][ks][sl][0][q][lane];
+        o_z[q] += sc[rw][ks][sl][1][q][lane];
+        o_in[q] += sc[rw][ks][sl][2][q][lane];
+        o_hn[q] += sc[rw][ks][sl][3][q][lane];
+      }
+#pragma unroll
+    for (int q = 0; q < OWN; ++q) finish(ks * OWN + q, o_r[q], o_z[q], o_in[q], o_hn[q]);
+  } else {
   // fold the k-groups' partial sums into group 0, halving the number of live groups per round: groups
   // [half, 2 half) write, groups [0, half) add (the last tile's barrier has retired every read of the tiles)
 #pragma unroll
@@ -884,26 +950,10 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
     }
     if (half > 1) __syncthreads();  // the next round overwrites the slots
   }
-  if (ks != 0) return;
-  const int j = min(j0 + fr, d - 1);
-  const bool jok = j0 + fr < d;
+  if (ks == 0) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int lr = rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-    const int64_t m = m0 + lr;
-    const float hold = Hs[lr][fr];
-    const int64_t orow = orow_s[lr];
-    const float rg = fast_sigmoid(acc_r[r] + br);
-    const float zg = fast_sigmoid(acc_z[r] + bz);
-    const float hn = acc_hn[r] + bhn;
-    const float ng = fast_tanh(acc_in[r] + bin + rg * hn);
-    if (jok && m < M) {
-      g.out[orow * g.ldo + j] = (1.f - zg) * ng + zg * hold;
-      if (g.gates) {
-        float* gp = g.gates + m * 4 * (int64_t)d + j;
-        gp[0] = rg; gp[d] = zg; gp[2 * d] = ng; gp[3 * d] = hn;
-      }
-    }
+    for (int r = 0; r < 16; ++r) finish(r, acc_r[r], acc_z[r], acc_in[r], acc_hn[r]);
+  }
   }
   if ((dbg & 16) && tid == 0 && blockIdx.x < 2048) {
     g_gru_trace[blockIdx.x * 4 + 0] = t_entry;
