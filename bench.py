@@ -304,9 +304,9 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
         n_trig = int(trig[preroll + warmup:preroll + warmup + steps].sum())
     _ = model.graph.tcsr, model.model_struct()  # lazy device-side builds happen here, not inside a capture
     # lean step (tg_step_io.lean): the benchmark reads neither the involved set nor its size, so a direct-form eager step
-    # on a graph of at most 3B(K+1) node ids does not form it (the library ignores the flag everywhere else)
+    # does not form it (the library ignores the flag everywhere else, e.g. with the in-step lazy restart of C3)
     direct = eager and os.environ.get('TG_EAGER_DIRECT', '1') != '0' and not args.eager_copy  # no compact copy
-    lean = direct and not args.no_lean and restart_prob == 0 and stream['n_nodes'] <= 3 * B * (K + 1)
+    lean = direct and not args.no_lean and restart_prob == 0
     buf.io.lean = 1 if lean else 0
 
     # ---- untimed: state pre-roll, then the contract's warm-up steps (all eager launches)

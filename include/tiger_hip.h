@@ -434,7 +434,7 @@ typedef struct tg_step_io {
    * counts[1] come back as -1).  With eager updates in the direct form nothing else in the step needs them either - rows
    * are addressed by node id, the dedup slots can be indexed by node id, the time invariants can be checked per centre /
    * per neighbour - so the sampler marks no flags and the compaction launch is skipped.  Honoured only there (and only
-   * when n_nodes <= 3B(K+1), no lazy restart, no h_prev_* outputs); ignored otherwise.  Same results. */
+   * without the lazy-restart loop and the h_prev_* outputs); ignored otherwise.  Same results. */
   int32_t lean;
   int32_t reserved3;
 } tg_step_io;

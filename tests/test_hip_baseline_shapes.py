@@ -39,8 +39,11 @@ def _compare_indices(buf, cg, node_map=None):
     np.testing.assert_array_equal(buf.l1_eids.cpu().numpy(), cg['l1_eids'])
     np.testing.assert_array_equal(buf.l1_ts.cpu().numpy(), cg['l1_ts'])
     counts = buf.counts.cpu().numpy()
-    assert counts[0] == len(cg['involved'])
-    np.testing.assert_array_equal(buf.involved.cpu().numpy()[:counts[0]], f(cg['involved']))
+    if counts[0] == -1:  # lean step (tg_step_io.lean): the involved / outdated sets were not formed
+        assert counts[1] == -1
+    else:
+        assert counts[0] == len(cg['involved'])
+        np.testing.assert_array_equal(buf.involved.cpu().numpy()[:counts[0]], f(cg['involved']))
     assert counts[2] == len(cg['rd_nids'])
     return counts
 
@@ -174,8 +177,10 @@ def test_c4_lastfm_shape_b8192_no_feature_tables_large_timestamps():
     model.fuse_attention()
     a = _batch(stream, nb, B)
     cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], K, 'static')
-    buf = model.stream_step(*a)
+    buf = model.stream_step(*a, lean=True)   # and as a lean step (no involved set; 2 982 node ids < 3B(K+1) slots)
+    assert int(buf.counts[0]) == -1
     assert_close(buf.h[:2 * B].cpu().numpy(), orc.stream_step(*a, cg).numpy(), 'h_left (fused weights)', TOL)
+    compare_state_with_oracle(model, orc)
 
 
 def test_c5_d256_b65536_ten_million_node_tables():
@@ -208,10 +213,12 @@ def test_c5_d256_b65536_ten_million_node_tables():
     for b in range(nb):
         a, ac = _batch(stream, b, B), _batch(cs, b, B)
         cg = O.collate(og, ac[0], ac[1], ac[2], ac[3], K, 'static')
-        buf = model.stream_step(*a)
+        lean = b == nb - 1  # the last batch as a lean step: 10 M dedup slots indexed by node id, cleaned by position
+        buf = model.stream_step(*a, lean=lean)
         ref = orc.stream_step(*ac, cg).numpy()
         counts = _compare_indices(buf, cg, node_map=used)
-        assert counts[1] == (0 if b == 0 else counts[1]) and (b == 0 or counts[1] > 1000)   # pending messages consumed
+        assert (counts[0] == -1) == lean
+        assert lean or (counts[1] == (0 if b == 0 else counts[1]) and (b == 0 or counts[1] > 1000))   # pending messages consumed
         assert_close(buf.h[:2 * B].cpu().numpy(), ref, 'h_left', TOL)
     # state: touched rows against the oracle, every other row of the 10 M-row tables still exactly zero
     has = model.msg_store.has_msg_mask()

@@ -521,6 +521,15 @@ def test_c2_lean_steps_match_oracle(lean):
     _oracle_vs_fused(stream, c['d'], c['K'], c['B'], 12, c['msg_src'], c['upd_src'], fuse=True, eager=True, lean=lean)
 
 
+def test_lean_steps_with_more_node_ids_than_batch_slots():
+    """B = 200 on the 9 228-node graph: 3B(K+1) = 6 600 < n_nodes, so the id-indexed dedup slots of a lean step are a table
+    of their own (one per node id) and the write-back cleans the positions of the batch's positive nodes, not a prefix"""
+    import bench
+    c = bench.C2
+    stream = bench.make_stream(c['n_u'], c['n_i'], 8000, c['T'] * 8000 / c['E'], seed=7, d_e=c['d'])
+    _oracle_vs_fused(stream, c['d'], c['K'], 200, 24, c['msg_src'], c['upd_src'], fuse=True, eager=True, lean='mixed')
+
+
 def test_lean_step_checks_the_time_invariants():
     """a message older than its node's memory (message_modules.py:158-159) must raise from a lean step as from a full
     one: the check moved from the outdated list to the centres / neighbours of the batch"""

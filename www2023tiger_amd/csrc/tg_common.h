@@ -396,9 +396,9 @@ struct WritebackArgs {
   // snap[i] = message-source memory row (+ node features) of position i of cat[src, dst], snap_ts[i] its time
   const float* snap;
   const float* snap_ts;
-  // lean step (no involved set): the dedup slots are indexed by node id - clean_best_n (= n_nodes) of them are zeroed -
-  // and counts[0], counts[1] are reported as -1
-  int64_t clean_best_n;
+  // lean step (no involved set): the dedup slots are indexed by node id - the slots of the batch's positive nodes are
+  // zeroed, not a prefix - and counts[0], counts[1] are reported as -1
+  int clean_best_by_pos;
 };
 // phase 0 / 1: the two launches of tg_memory.hip's hazard analysis; phase 2: STEP 4-6 in one launch (needs a.snap)
 int writeback_launch(const tg_model* m, const WritebackArgs& a, int phase, hipStream_t st);

@@ -397,14 +397,17 @@ __global__ void __launch_bounds__(256) k_writeback_fused(tg_model m, WritebackAr
       uint4* f = reinterpret_cast<uint4*>(a.clean_flags);
       for (int64_t i = tid; i < a.flag_bytes / 16; i += nth) f[i] = make_uint4(0u, 0u, 0u, 0u);
     }
-    const int64_t nb = a.clean_best_n > 0 ? a.clean_best_n : (int64_t)a.clean_counts[0];
-    if (a.clean_best)
+    if (a.clean_best && a.clean_best_by_pos) {
+      for (int64_t i = tid; i < 2 * B; i += nth) a.clean_best[i < B ? a.src[i] : a.dst[i - B]] = 0ull;
+    } else if (a.clean_best) {
+      const int64_t nb = a.clean_counts[0];
       for (int64_t i = tid; i < nb; i += nth) a.clean_best[i] = 0ull;
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (a.counts_dst) {
       for (int i = 0; i < 4; ++i) a.counts_dst[i] = a.counts_src[i];
-      if (a.clean_best_n > 0) a.counts_dst[0] = a.counts_dst[1] = -1;  // lean step: the sets were not formed
+      if (a.clean_best_by_pos) a.counts_dst[0] = a.counts_dst[1] = -1;  // lean step: the sets were not formed
     }
     if (a.clean_counts) a.clean_counts[3] = a.clean_counts[4] = 0;
     if (a.offset_dev) *a.offset_dev += B;

@@ -850,6 +850,7 @@ bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w) {
   if (!carve_attn(m, Q, cv, w.attn)) return false;
   w.apply_bytes = apply_ws_bytes(m, cap);
   w.apply_ws = cv.take<char>(w.apply_bytes);
+  w.best_id = cv.take<unsigned long long>((size_t)m->n_nodes);  // lean steps: dedup slots indexed by node id (kept zero)
   return cv.ok;
 }
 }  // namespace tg
@@ -861,7 +862,7 @@ extern "C" size_t tg_stream_step_workspace_bytes(const tg_model* m, int64_t B) {
              align16(2 * B * m->d * 4) + align16(2 * B * 4) + align16(Q * 8) * 2 + align16(B * 8) +
              align16(Q * 4) + align16(Q * K * 8) * 2 + align16(Q * K * 4) + align16(cap * 8) * 2 + align16(cap * 4) +
              align16(2 * B * 8) * 2 + align16(cap * m->d * 4) + align16(tg_unique_compact_workspace_bytes(m->n_nodes)) +
-             attn_ws_bytes(m, Q) + align16(apply_ws_bytes(m, cap));
+             attn_ws_bytes(m, Q) + align16(apply_ws_bytes(m, cap)) + align16((size_t)m->n_nodes * 8);
   return b + 256;
 }
 
@@ -898,10 +899,11 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   // so a step that outputs them keeps the two-phase write-back
   w.fused_wb = w.direct && !io->embed_only && !io->h_prev_left && !io->h_prev_right;
   // lean: nothing in such a step needs the involved / outdated sets, so they are not formed (tiger_hip.h, tg_step_io.lean)
-  w.lean = io->lean && w.fused_wb && !lz && m->n_nodes <= cap;
+  w.lean = io->lean && w.fused_wb && !lz;
+  if (w.lean && !io->ws_is_clean && hipMemsetAsync(w.best_id, 0, (size_t)m->n_nodes * 8, st) != hipSuccess) return TG_EHIP;
   // the positive-node dedup (needed by the write-back) rides on two launches of the forward pass
   PosArgs pos{B, w.nids3, w.ts3f, w.bm, w.rank, w.best, w.counts + 2, w.upos, w.index, w.upos32, nullptr};
-  if (w.lean) { pos.bm = nullptr; pos.rank = nullptr; pos.chk_err = io->err; }
+  if (w.lean) { pos.bm = nullptr; pos.rank = nullptr; pos.best = w.best_id; pos.chk_err = io->err; }
   const PosArgs* pp = io->embed_only ? nullptr : &pos;
   const DirectArgs da{w.lean ? nullptr : w.outdated, w.counts + 1, cap, io->err, w.fused_wb ? (float4*)w.snap : nullptr,
                       w.snap_ts, 2 * B, w.lean ? 1 : 0};
@@ -966,7 +968,7 @@ static WritebackArgs writeback_args(const tg_model* m, const tg_step_io* io, Ste
   wa.counts_src = io->counts ? w.counts : nullptr; wa.counts_dst = io->counts;
   wa.offset_dev = (io->offset_dev && io->advance) ? io->offset_dev : nullptr;
   wa.clean_flags = w.lean ? nullptr : w.flags; wa.flag_bytes = (int64_t)((m->n_nodes + 63) / 64) * 64;
-  wa.clean_best = w.best; wa.clean_best_n = w.lean ? m->n_nodes : 0;
+  wa.clean_best = w.lean ? w.best_id : w.best; wa.clean_best_by_pos = w.lean ? 1 : 0;
   wa.clean_counts = w.counts;
   wa.lazy_batch = (io->lazy && io->lazy->batch_dev) ? io->lazy->batch_dev : nullptr;
   wa.new_from_pending = w.direct ? 1 : 0;  // no reprs copy was made: STEP 4 reads the owner table of updater rows

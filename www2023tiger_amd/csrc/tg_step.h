@@ -62,6 +62,7 @@ struct StepWs {
   float* l1t;
   bool dedup_done;  // the positive-node dedup already ran inside the forward launches
   bool eager;       // STEP 1-2 gathered precomputed updater rows; the updater runs at the end of the step instead
+  unsigned long long* best_id;  // [n_nodes] dedup slots of a lean step (indexed by node id; zero between steps)
   bool lean;        // no involved / outdated sets are formed (tg_step_io.lean)
   bool fused_wb;    // STEP 4-6 run as one launch (needs the snapshot taken by the direct centres launch)
   bool direct;      // ... and no compact copy of the involved rows was made (centres / neighbours read the tables)

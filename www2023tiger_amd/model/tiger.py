@@ -478,7 +478,7 @@ class TIGE(nn.Module):
             """resident = (src, dst, neg, ts64, eids) device tensors of the WHOLE stream: the
             step then reads batch [offset, offset+B) and advances `offset` on device.
             lean: the caller does not read `involved` nor counts[0:2] (tiger_hip.h: tg_step_io.lean) - an eager
-            step on a graph of at most 3B(K+1) nodes then skips forming those sets; same results otherwise."""
+            step then skips forming those sets; same results otherwise."""
             dev, d, K = model.device, model.memory_dim, model.n_neighbors
             self.B = B
             self.embed_only = embed_only
