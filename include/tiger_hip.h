@@ -434,7 +434,8 @@ typedef struct tg_step_io {
    * counts[1] come back as -1).  With eager updates in the direct form nothing else in the step needs them either - rows
    * are addressed by node id, the dedup slots can be indexed by node id, the time invariants can be checked per centre /
    * per neighbour - so the sampler marks no flags and the compaction launch is skipped.  Honoured only there (and only
-   * without the lazy-restart loop and the h_prev_* outputs); ignored otherwise.  Same results. */
+   * without the lazy-restart loop and the h_prev_* outputs); ignored otherwise.  Same results.  An embed_only step
+   * honours it too (then `counts` is not written at all and the stream offset is advanced by the core launch). */
   int32_t lean;
   int32_t reserved3;
 } tg_step_io;

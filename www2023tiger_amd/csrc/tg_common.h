@@ -229,6 +229,7 @@ struct PosArgs {
   int64_t *upos, *index;
   int32_t* upos32;  // nullable: the winners' node ids once more as int32 (output rows of the eager updater launch)
   uint32_t* chk_err;  // lean steps: the core launch checks the time invariants of every neighbour with a pending message
+  int64_t* advance_off;  // lean embed-only steps: the core launch advances the stream offset by B when it is done with it
 };
 // dedup slot of a node: its rank in the involved set, or (lean steps: no involved set) the node id itself
 __device__ __forceinline__ int64_t pos_slot(const PosArgs& a, int64_t node) {

@@ -156,6 +156,7 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
   // direct (eager updates): neighbour rows come from the state tables, row(v) = has_msg[v] ? pending[v] : right[v];
   // the second dedup pass of the step rides here (a few thousand threads of work)
   if (pos.best) pos_winners_pass(pos, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+  if (pos.advance_off && blockIdx.x == 0 && threadIdx.x == 0) *pos.advance_off += pos.B;  // (the sampler has read it)
   const uint64_t dkey = drop_key(dc);
   const int d = m.d, de = m.d_e, K = m.n_neighbors;
   const int kvw = 2 * d + de;
@@ -879,11 +880,6 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   const int64_t B = io->B, Q = 3 * B, K = m->n_neighbors, cap = Q * (K + 1);
   prof_mark(pf, ST_QUERIES, st);
   hipError_t e = hipSuccess;
-  if (!io->ws_is_clean || io->embed_only || io->collate_only) e = hipMemsetAsync(w.flags, 0, w.zero_bytes, st);
-  if (e != hipSuccess) {
-    set_hip_error(e, "tg_stream_step memset");
-    return TG_EHIP;
-  }
   int rc;
   // ---- collate (data_loader.py:77-131): queries + temporal neighbours + involved flags, one launch
   prof_mark(pf, ST_SAMPLE, st);
@@ -899,16 +895,29 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   // so a step that outputs them keeps the two-phase write-back
   w.fused_wb = w.direct && !io->embed_only && !io->h_prev_left && !io->h_prev_right;
   // lean: nothing in such a step needs the involved / outdated sets, so they are not formed (tiger_hip.h, tg_step_io.lean)
-  w.lean = io->lean && w.fused_wb && !lz;
-  if (w.lean && !io->ws_is_clean && hipMemsetAsync(w.best_id, 0, (size_t)m->n_nodes * 8, st) != hipSuccess) return TG_EHIP;
+  // (an embed-only step has no write-back to clean up after: lean, it touches none of the self-cleaning state at all)
+  w.lean = io->lean && w.direct && !lz && (w.fused_wb || io->embed_only);
+  const bool untouched = w.lean && io->embed_only;  // no flags, no dedup slots, no counts
+  if ((!io->ws_is_clean || io->embed_only || io->collate_only) && !untouched) e = hipMemsetAsync(w.flags, 0, w.zero_bytes, st);
+  if (e == hipSuccess && w.lean && !io->embed_only && !io->ws_is_clean)
+    e = hipMemsetAsync(w.best_id, 0, (size_t)m->n_nodes * 8, st);
+  if (e != hipSuccess) {
+    set_hip_error(e, "tg_stream_step memset");
+    return TG_EHIP;
+  }
   // the positive-node dedup (needed by the write-back) rides on two launches of the forward pass
-  PosArgs pos{B, w.nids3, w.ts3f, w.bm, w.rank, w.best, w.counts + 2, w.upos, w.index, w.upos32, nullptr};
+  PosArgs pos{B, w.nids3, w.ts3f, w.bm, w.rank, w.best, w.counts + 2, w.upos, w.index, w.upos32, nullptr, nullptr};
   if (w.lean) { pos.bm = nullptr; pos.rank = nullptr; pos.best = w.best_id; pos.chk_err = io->err; }
-  const PosArgs* pp = io->embed_only ? nullptr : &pos;
+  if (untouched) {  // no dedup (there is no write-back), but the core still checks its neighbours and moves the offset on
+    pos.best = nullptr;
+    pos.advance_off = (io->offset_dev && io->advance) ? io->offset_dev : nullptr;
+  }
+  const PosArgs* pp = (io->embed_only && !untouched) ? nullptr : &pos;
   const DirectArgs da{w.lean ? nullptr : w.outdated, w.counts + 1, cap, io->err, w.fused_wb ? (float4*)w.snap : nullptr,
                       w.snap_ts, 2 * B, w.lean ? 1 : 0};
   // lean: the centres need nothing the sampler produces and share its launch
-  const CentresRider rider{*m, (const float4*)m->nfeats, (float4*)w.attn.cc, da, pos, flat_grid(Q * (m->d / 4), 256)};
+  const CentresRider rider{*m, (const float4*)m->nfeats, (float4*)w.attn.cc, da, pp ? pos : PosArgs{},
+                           flat_grid(Q * (m->d / 4), 256)};
   if ((rc = sample_batch_launch(g, B, io->src, io->dst, io->neg, io->ts, io->eids, io->offset_dev, (int32_t)K, w.nids3,
                                 w.ts3f, w.eids, w.l1n, w.l1e, w.l1t, w.lean ? nullptr : w.flags, st,
                                 lz ? reinterpret_cast<uint32_t*>(w.counts + 4) : nullptr, w.lean ? &rider : nullptr)) != TG_OK)
@@ -926,7 +935,7 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
     return rc;
   if (io->collate_only) return check_launch("tg_stream_step(collate_only)");
   prof_mark(pf, ST_GATHER, st);
-  w.dedup_done = pp != nullptr;
+  w.dedup_done = pp != nullptr && pp->best != nullptr;
   // ---- STEP 1-2: reprs = right_memory[involved] (+ invariants); outdated rows <- updater(...)
   if (!w.direct &&
       (rc = consume_gather_check_launch(m, w.inv, w.counts + 0, cap, w.reprs, w.outdated, w.counts + 1, io->err, st, pp,
@@ -1051,6 +1060,7 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
   // current through tg_apply_messages after its own write-back); only a full step runs the updater at its end
   const bool eager = m->pending_vals != nullptr;
   if ((rc = step_forward(m, g, io, w, nullptr, st, pf, nullptr, eager)) != TG_OK) return rc;
+  if (io->embed_only && w.lean) return check_launch("tg_stream_step(embed_only, lean)");  // counts are not written
   if (io->embed_only || io->collate_only) {
     if (io->counts) {
       hipError_t e = hipMemcpyAsync(io->counts, w.counts, 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, st);

@@ -445,6 +445,8 @@ class PartitionedRunner:
         """Collective.  The state-dependent part of a global batch: pull, embed, push, owner write-back, eager updater.
         Returns this rank's embeddings [3 n, d] (rows [0, 2n) are h(t-) of cat[src, dst] of its events)."""
         E = self.engine
+        if hasattr(E, 'begin_step'):
+            E.begin_step()
         served = E.serve(p)                                                       # [*, d + 1]: row | time, peer-major
         got = all_to_all_rows(served, p.serve_in, p.serve_out, self.group)        # PULL
         E.adopt(p, got)
@@ -452,6 +454,8 @@ class PartitionedRunner:
         all_to_all_rows(rows[p.push_rows], p.push_in, p.push_out, self.group, out=rows[3 * p.n:])   # PUSH
         E.writeback(p, rows, self.owner, self.rank)
         E.refresh(p)
+        if hasattr(E, 'end_step'):
+            E.end_step()
         return rows[:3 * p.n]
 
     def step(self, src, dst, neg, ts, eids, rank_of=None) -> torch.Tensor:
@@ -474,12 +478,25 @@ class HipPartitionEngine:
         self.hip_ops, self.check, self.lib, self.ptr, self.WbIo = hip_ops, check, lib, ptr, TgWritebackIo
         self.max_recv = 2 * cap if resident is not None else 0  # resident: fixed output buffer with room for pushed rows
         self.hbuf = torch.zeros(3 * cap + max(self.max_recv, 1), self.d, dtype=torch.float32, device=self.device)
-        self.cbuf = model.StepBuffers(model, cap, False, embed_only=True, h_out=self.hbuf, want_h_new=False)  # collation
+        # lean: the embedding step forms no involved set (the exchange lists come from `plan`'s collation, a collate_only
+        # call on cbuf, which ignores the flag); sampler + centres, G, core, fc1, fc2 and nothing else
+        self.cbuf = model.StepBuffers(model, cap, False, embed_only=True, h_out=self.hbuf, want_h_new=False, lean=True)
         self.buf = self.cbuf if resident is None else model.StepBuffers(
-            model, cap, False, resident=resident, embed_only=True, h_out=self.hbuf, want_h_new=False)
+            model, cap, False, resident=resident, embed_only=True, h_out=self.hbuf, want_h_new=False, lean=True)
         self.resident = resident is not None
         self.err = hip_ops.new_err(model.device)
         self._owner32 = None
+        self._st = None
+
+    def begin_step(self):
+        """the launch stream is looked up once per step (torch.cuda.current_stream costs ~5 us a call)"""
+        self._st = self.hip_ops.stream_ptr(self.device)
+
+    def _stream(self):
+        return self._st if self._st is not None else self.hip_ops.stream_ptr(self.device)
+
+    def end_step(self):
+        self._st = None
 
     def _load(self, src, dst, neg, ts, eids=None):
         n, buf = int(src.numel()), self.cbuf
@@ -511,7 +528,7 @@ class HipPartitionEngine:
         out = torch.empty(ne + nm, self.d + 1, dtype=torch.float32, device=self.device)
         ms = m.model_struct()
         self.check(lib.tg_serve_rows(C.byref(ms), ne, ptr(p.serve_eff), ptr(p.serve_eff_pos), nm, ptr(p.serve_msg),
-                                     ptr(p.serve_msg_pos), ptr(out), self.hip_ops.stream_ptr(self.device)), 'tg_serve_rows')
+                                     ptr(p.serve_msg_pos), ptr(out), self._stream()), 'tg_serve_rows')
         return out
 
     def adopt(self, p, got):
@@ -520,7 +537,7 @@ class HipPartitionEngine:
         m, lib, ptr = self.model, self.lib, self.ptr
         ms = m.model_struct()
         self.check(lib.tg_adopt_rows(C.byref(ms), p.req_eff.numel(), ptr(p.req_eff), ptr(p.reply_eff_pos), p.req_msg.numel(),
-                                     ptr(p.req_msg), ptr(p.reply_msg_pos), ptr(got), self.hip_ops.stream_ptr(self.device)),
+                                     ptr(p.req_msg), ptr(p.reply_msg_pos), ptr(got), self._stream()),
                    'tg_adopt_rows')
 
     def embed(self, p):
@@ -552,7 +569,7 @@ class HipPartitionEngine:
             rows = torch.zeros(1, self.d, dtype=torch.float32, device=self.device)
         io = self.WbIo(p.Bg, ptr(g_src), ptr(g_dst), ptr(g_ts), ptr(g_eids), None, 0, 0, ptr(rows), ptr(p.left_row), None,
                        ptr(self.err), ptr(self._owner32), rank, 1, ptr(p.mine), ptr(p.mine_index), ptr(p.n_mine), ptr(p.ts32))
-        self.check(lib.tg_stream_writeback(C.byref(ms), C.byref(io), None, 0, self.hip_ops.stream_ptr(m.device)),
+        self.check(lib.tg_stream_writeback(C.byref(ms), C.byref(io), None, 0, self._stream()),
                    'tg_stream_writeback')
 
     def refresh(self, p):
@@ -565,7 +582,7 @@ class HipPartitionEngine:
             nbytes = int(lib.tg_apply_messages_workspace_bytes(C.byref(ms), n))
             ws = m._ws('apply', nbytes)
             self.check(lib.tg_apply_messages(C.byref(ms), ptr(p.mine), ptr(p.mine32), ptr(p.n_mine), n, ptr(m._pending),
-                                             ptr(self.err), ptr(ws), ws.numel(), self.hip_ops.stream_ptr(self.device)),
+                                             ptr(self.err), ptr(ws), ws.numel(), self._stream()),
                        'tg_apply_messages(pending)')
         m._pending_stamp = m._state_stamp()  # the table is current again
 
@@ -687,6 +704,7 @@ def bench_main(args, cfg, make_stream, build_models, rank, local_rank, world):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         rs.step()
+    t_host = time.perf_counter() - t0  # the host has enqueued everything; the GPU may still be working
     torch.cuda.synchronize()
     tdist.barrier()
     torch.cuda.synchronize()
@@ -709,7 +727,8 @@ def bench_main(args, cfg, make_stream, build_models, rank, local_rank, world):
             launch = '2 hipGraphs + 1 all-gather per step' if use_graphs else 'eager launches + 1 all-gather per step'
         out = dict(metric='processed interaction-events/sec (memory+aggregate+embed), Wikipedia d=172',
                    value=args.steps * Bg / dt, unit='events/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='strong' if strong else 'weak',
+                   ms_per_step=dt / args.steps * 1e3, host_enqueue_ms_per_step_rank0=t_host / args.steps * 1e3,
+                   higher_is_better=True, scaling='strong' if strong else 'weak',
                    vs_baseline=None, dtype='f32', data='synthetic',
                    config=dict(workload=cfg['name'], batch_per_gpu=B, global_batch=Bg, dim=d, n_neighbors=K,
                                msg_src=cfg['msg_src'], upd_src=cfg['upd_src'], n_nodes=stream['n_nodes'], events=E,
