@@ -125,6 +125,23 @@ __device__ __forceinline__ float time_enc(float dt, float w, float phi) {
   return fabsf(x) <= 3.0e6f ? cos_cw(x) : cos_big(x);
 }
 
+// The attention core evaluates K*d of these per centre and is VALU-bound on them: there the cosine of the SAME float32
+// argument comes from the hardware unit (v_cos_f32, input in revolutions) behind a three-term Cody-Waite reduction
+// modulo 2*pi - 3.5e-7 max abs error against float64 cos on |x| <= 3e6 (tools/micro/vcos_err.hip; the polynomial
+// path: 9.2e-8), about ten issue slots instead of twenty-five.  Everything that is compared element-wise with the
+// reference's encoding (tg_time_encode, the raw messages of STEP 5, training) keeps the polynomial path.
+__device__ __forceinline__ float cos_hw(float x) {
+  const float n = rintf(__fmul_rn(x, 0.15915494309189535f));
+  float r = fmaf(-n, 6.2831854820251465f, x);
+  r = fmaf(-n, -1.7484555314695172e-07f, r);
+  r = fmaf(-n, -7.1054273576010019e-15f, r);
+  return __builtin_amdgcn_cosf(__fmul_rn(r, 0.15915494309189535f));
+}
+__device__ __forceinline__ float time_enc_fast(float dt, float w, float phi) {
+  const float x = __fadd_rn(__fmul_rn(dt, w), phi);
+  return fabsf(x) <= 3.0e6f ? cos_hw(x) : cos_big(x);
+}
+
 // sin with the same three-term Cody-Waite reduction as cos_cw above
 __device__ __forceinline__ float sin_cw(float x) {
   const float n = rintf(__fmul_rn(x, 0.6366197723675814f));

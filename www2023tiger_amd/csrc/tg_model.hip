@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
         for (int j = 0; j < W; ++j) {
           x[0][v].a[j] = ya[slot][v].a[j] + yn[slot][v].a[j];
           x[1][v].a[j] = yb[slot][v].a[j];
-          x[2][v].a[j] = c + j < d ? time_enc(dt, w4[v].a[j], p4[v].a[j]) : 0.f;
+          x[2][v].a[j] = c + j < d ? time_enc_fast(dt, w4[v].a[j], p4[v].a[j]) : 0.f;
         }
       }
 #pragma unroll
