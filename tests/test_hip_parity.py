@@ -630,9 +630,11 @@ def test_sampler_properties_at_scale():
                 assert d10[i, k] == (1 if int(q[i]) == dd else 0)
 
 
-def test_ragged_and_degenerate_batches_match_oracle():
+@pytest.mark.parametrize('form', ['lazy', 'eager', 'eager-lean'])
+def test_ragged_and_degenerate_batches_match_oracle(form):
     """Batch sizes 1, 7 and a ragged tail; a batch whose events all share one timestamp (every
-    dedup decision is a tie); the same node as src of many events (collisions)."""
+    dedup decision is a tie); the same node as src of many events (collisions).  In the lazy form, with eager
+    updates, and as lean eager steps (dedup slots indexed by node id, no involved set)."""
     import bench
     from oracle import tiger_oracle as O
     rs = np.random.RandomState(5)
@@ -641,10 +643,13 @@ def test_ragged_and_degenerate_batches_match_oracle():
     st['ts'] = np.sort(st['ts'])
     st['src'][400:440] = st['src'][400]          # one hot source node
     model, orc = bench.build_models(st, 16, 5, 'right', 'left', with_oracle=True)
+    if form != 'lazy':
+        model.eager_updates()
     edges = [0, 1, 8, 72, 300, 364, 400, 440, 571, 700]   # sizes 1, 7, 64, 228, 64, 36, 40, 131, 129
     for lo, hi in zip(edges[:-1], edges[1:]):
         a = [st[k][lo:hi] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
-        buf = model.stream_step(*a)
+        buf = model.stream_step(*a, lean=(form == 'eager-lean'))
+        assert (int(buf.counts[0]) == -1) == (form == 'eager-lean')
         cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], 5, 'static')
         ref = orc.stream_step(*a, cg).numpy()
         n = hi - lo
