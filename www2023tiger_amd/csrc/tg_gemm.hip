@@ -963,6 +963,219 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
   }
 }
 
+// ---------------------------------------------------------------------------------
+// The GRU cell for FEW rows (the eager updater of a C2-sized batch: ~1 000 rows): 32 rows x 32 hidden columns
+// per block, four wavefronts, and NO LDS in the k-loop.
+// In a 32-row block the four wavefronts share nothing: with one row wave, LDS staging only re-shapes global
+// rows into MFMA fragments, and that costs more than the MFMAs (s_memtime ablations of k_gru<1, 4>: 44.9 k
+// cycles per block loop, 27.2 k without the LDS stores, 25.1 k for the MFMAs alone - the store path moves
+// 64-79 B/clk per CU and every ds_write holds the issuing wave).  The sum over k does not care which k values
+// share an MFMA step, so a lane can feed the matrix unit straight from what it loads: lane (row r, half kh)
+// reads the 64 contiguous bytes A[r][k0 + 16 kh .. + 15] of its row as four float4, the same slice of its weight
+// row in each of the three planes, and MFMA step (q, j) multiplies element j of float4 q - k = k0 + 16 kh + 4 q + j
+// on both operands.  The k-tiles are dealt to the wavefronts (wave w takes tiles w, w + 4, ...), each into its own
+// accumulators: no barrier and no LDS until the fold, a tile is 16 loads and 48 MFMAs of one wavefront, the next
+// tile's loads are in flight meanwhile.  Fold and epilogue as k_gru's scattered form: every wavefront finishes
+// a quarter of the rows; the old-memory values and output rows of those are requested at kernel start.
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gru_direct(GruArgs g) {
+  constexpr int KS = 4, OWN = 4;
+  __shared__ float sc_raw[KS * (KS - 1) * 4 * OWN * 64];
+  float (*sc)[KS - 1][4][OWN][64] = reinterpret_cast<float (*)[KS - 1][4][OWN][64]>(sc_raw);
+  const unsigned long long t_entry = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
+  const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
+  const int fr = lane & 31, fk = lane >> 5;
+  const int d = g.d, xw = g.xw;
+  const int NT = (d + 31) / 32;
+  int64_t M = g.cap;
+  if (g.n_dev) M = min(M, (int64_t)*g.n_dev);
+  const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
+  const int64_t mt = (int64_t)(s / NT) * 8 + xcd;
+  const int nt = s % NT;
+  const int64_t m0 = mt * 32;
+  if (m0 >= M) return;
+  const int j0 = nt * 32;
+  const int jc = min(j0 + fr, d - 1);
+  const bool jok = j0 + fr < d;
+  // this lane's operand rows: activation row m0 + fr, weight row jc of every plane
+  const int64_t mrow = min(m0 + fr, M - 1);
+  const float* xrow = g.x.p + (g.x.idx ? g.x.idx[mrow] : mrow) * g.x.ld;
+  const float* hrow = g.h.p + (g.h.idx ? g.h.idx[mrow] : mrow) * g.h.ld;
+  const float* wi = g.w_ih + (int64_t)jc * xw;
+  const float* wh = g.w_hh + (int64_t)jc * d;
+  const int64_t wi_ps = (int64_t)d * xw, wh_ps = (int64_t)d * d;  // plane strides
+  // epilogue operands of the rows this wavefront finishes (accumulator registers [4 ks, 4 ks + 4))
+  float hold[OWN];
+  int64_t orow[OWN];
+#pragma unroll
+  for (int q = 0; q < OWN; ++q) {
+    const int64_t mm = min(m0 + 8 * ks + q + 4 * fk, M - 1);
+    hold[q] = g.h.p[(g.h.idx ? g.h.idx[mm] : mm) * g.h.ld + jc];
+    orow[q] = g.out_rows ? (int64_t)g.out_rows[mm] : mm;
+  }
+  const float br = g.b_ih[jc] + g.b_hh[jc];
+  const float bz = g.b_ih[d + jc] + g.b_hh[d + jc];
+  const float bin = g.b_ih[2 * d + jc], bhn = g.b_hh[2 * d + jc];
+  const int nkx = (xw + BK - 1) / BK - g.x_skip_n, nkh = (d + BK - 1) / BK;
+  const int nkt = nkx + nkh;
+  const int xs_at = g.x_skip_at, xs_sh = g.x_skip_n * BK, xwe = xw - xs_sh;  // zero k-tiles skipped (see k_gru)
+  // this wavefront's tiles: message tiles ks, ks + 4, ... < nkx, then memory tiles th0, th0 + 4, ... < nkt
+  const int nx = ks < nkx ? (nkx - ks + 3) / 4 : 0;
+  const int th0 = nkx + ((ks - nkx) % 4 + 4) % 4;
+  const int nh = th0 < nkt ? (nkt - th0 + 3) / 4 : 0;
+  const int n_my = nx + nh;
+  auto tile_of = [&](int i) { return i < nx ? ks + 4 * i : th0 + 4 * (i - nx); };
+  struct Tile {
+    float4 a[4], w0[4], w1[4], w2[4];
+  };
+  // raw loads from clamped addresses; `live` bit q: float4 q of the activation slice lies inside the operand (the
+  // others are taken as zero when they are used - the weight slice then multiplies zeros, whatever it holds)
+  auto load_tile = [&](int i, Tile& T, unsigned& live) {
+    // past the end: a redundant reload keeps the code branch-free; a wavefront without tiles (fewer than four k-tiles
+    // in all) reads tile th0 >= nkt, whose every k is out of range: clamped addresses, nothing live
+    const int t = tile_of(max(0, min(i, n_my - 1)));
+    const bool hp = t >= nkx;
+    const int kb = (hp ? t - nkx : t) * BK + 16 * fk;
+    const int sh = (!hp && t >= xs_at) ? xs_sh : 0;
+    const int wid = hp ? d : xwe;
+    const float* ar = hp ? hrow : xrow;
+    const float* wr = hp ? wh : wi;
+    const int64_t ps = hp ? wh_ps : wi_ps;
+    live = 0u;
+    int kc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = kb + 4 * q;
+      if (k < wid) live |= 1u << q;
+      kc[q] = (k < wid ? k : 0) + sh;
+    }
+    // the four float4 of one row slice are requested back to back (one cache line each row)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) T.a[q] = ldg4(ar + kc[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) T.w0[q] = ldg4(wr + kc[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) T.w1[q] = ldg4(wr + ps + kc[q]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) T.w2[q] = ldg4(wr + 2 * ps + kc[q]);
+  };
+  f32x16 acc_r, acc_z, acc_in, acc_hn;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc_r[i] = acc_z[i] = acc_in[i] = acc_hn[i] = 0.f;
+  auto mma_tile = [&](auto hp_tag, const Tile& T, unsigned live) {
+    constexpr bool HP = decltype(hp_tag)::value;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 a = ((live >> q) & 1u) ? T.a[q] : zero4();
+      const float av[4] = {a.x, a.y, a.z, a.w};
+      const float b0[4] = {T.w0[q].x, T.w0[q].y, T.w0[q].z, T.w0[q].w};
+      const float b1[4] = {T.w1[q].x, T.w1[q].y, T.w1[q].z, T.w1[q].w};
+      const float b2[4] = {T.w2[q].x, T.w2[q].y, T.w2[q].z, T.w2[q].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b0[j], acc_r, 0, 0, 0);
+        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b1[j], acc_z, 0, 0, 0);
+        if (HP) acc_hn = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b2[j], acc_hn, 0, 0, 0);
+        else acc_in = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b2[j], acc_in, 0, 0, 0);
+      }
+    }
+  };
+  using HP0 = std::integral_constant<bool, false>;
+  using HP1 = std::integral_constant<bool, true>;
+  Tile T0, T1;
+  unsigned l0 = 0u, l1 = 0u;
+  load_tile(0, T0, l0);
+  const unsigned long long t_loop0 = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
+  // One step: request tile i + 1 into the idle register set, THEN multiply tile i (the order is pinned: left to
+  // itself the scheduler sinks the loads to the end of the MFMA stream, where the next tile waits for them in full).
+  // Message tiles (i_n plane) first, then memory tiles (h_n plane), each as straight-line pairs, written out for both
+  // register parities of the phase change.
+#define TG_STEP(HPT, CUR, LCUR, NXT, LNXT, INEXT)     \
+  do {                                                \
+    load_tile(INEXT, NXT, LNXT);                      \
+    __builtin_amdgcn_sched_barrier(0);                \
+    mma_tile(HPT{}, CUR, LCUR);                       \
+    __builtin_amdgcn_sched_barrier(0);                \
+  } while (0)
+  int i = 0;
+  for (; i + 2 <= nx; i += 2) {
+    TG_STEP(HP0, T0, l0, T1, l1, i + 1);
+    TG_STEP(HP0, T1, l1, T0, l0, i + 2);
+  }
+  if (i < nx) {  // odd number of message tiles: the memory tiles start in the other register set
+    TG_STEP(HP0, T0, l0, T1, l1, i + 1);
+    for (++i; i + 2 <= n_my; i += 2) {
+      TG_STEP(HP1, T1, l1, T0, l0, i + 1);
+      TG_STEP(HP1, T0, l0, T1, l1, i + 2);
+    }
+    if (i < n_my) mma_tile(HP1{}, T1, l1);
+  } else {
+    for (; i + 2 <= n_my; i += 2) {
+      TG_STEP(HP1, T0, l0, T1, l1, i + 1);
+      TG_STEP(HP1, T1, l1, T0, l0, i + 2);
+    }
+    if (i < n_my) mma_tile(HP1{}, T0, l0);
+  }
+#undef TG_STEP
+  const unsigned long long t_loop1 = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
+  // reduce-scatter over the four wavefronts (as k_gru's scattered epilogue): park what the others own, sum one's own
+#pragma unroll
+  for (int v = 0; v < KS; ++v) {
+    if (v != ks) {
+      const int slot = (ks - v - 1 + KS) % KS;
+#pragma unroll
+      for (int q = 0; q < OWN; ++q) {
+        sc[v][slot][0][q][lane] = acc_r[v * OWN + q];
+        sc[v][slot][1][q][lane] = acc_z[v * OWN + q];
+        sc[v][slot][2][q][lane] = acc_in[v * OWN + q];
+        sc[v][slot][3][q][lane] = acc_hn[v * OWN + q];
+      }
+    }
+  }
+  __syncthreads();
+  float o_r[OWN], o_z[OWN], o_in[OWN], o_hn[OWN];
+#pragma unroll
+  for (int v = 0; v < KS; ++v) {
+    if (v == ks) {
+#pragma unroll
+      for (int q = 0; q < OWN; ++q) {
+        o_r[q] = acc_r[v * OWN + q]; o_z[q] = acc_z[v * OWN + q];
+        o_in[q] = acc_in[v * OWN + q]; o_hn[q] = acc_hn[v * OWN + q];
+      }
+    }
+  }
+#pragma unroll
+  for (int sl = 0; sl < KS - 1; ++sl)
+#pragma unroll
+    for (int q = 0; q < OWN; ++q) {
+      o_r[q] += sc[ks][sl][0][q][lane];
+      o_z[q] += sc[ks][sl][1][q][lane];
+      o_in[q] += sc[ks][sl][2][q][lane];
+      o_hn[q] += sc[ks][sl][3][q][lane];
+    }
+#pragma unroll
+  for (int q = 0; q < OWN; ++q) {
+    const int64_t m = m0 + 8 * ks + q + 4 * fk;
+    const float rg = fast_sigmoid(o_r[q] + br);
+    const float zg = fast_sigmoid(o_z[q] + bz);
+    const float hn = o_hn[q] + bhn;
+    const float ng = fast_tanh(o_in[q] + bin + rg * hn);
+    if (jok && m < M) {
+      g.out[orow[q] * g.ldo + j0 + fr] = (1.f - zg) * ng + zg * hold[q];
+      if (g.gates) {
+        float* gp = g.gates + m * 4 * (int64_t)d + j0 + fr;
+        gp[0] = rg; gp[d] = zg; gp[2 * d] = ng; gp[3 * d] = hn;
+      }
+    }
+  }
+  if ((g.dbg & 16) && tid == 0 && blockIdx.x < 2048) {
+    g_gru_trace[blockIdx.x * 4 + 0] = t_entry;
+    g_gru_trace[blockIdx.x * 4 + 1] = t_loop0;
+    g_gru_trace[blockIdx.x * 4 + 2] = t_loop1;
+    g_gru_trace[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
+  }
+}
+
 extern "C" int tg_debug_gru_trace(unsigned long long* out_host, int n_blocks) {
   return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_gru_trace), sizeof(unsigned long long) * 4 * n_blocks) == hipSuccess ? 0 : -4;
 }
@@ -1003,7 +1216,10 @@ int gru_launch(const GruArgs& g, hipStream_t st) {
   static const int micro_knob = getenv("TG_GRU_MICRO") ? atoi(getenv("TG_GRU_MICRO")) : 1;  // tuning knob: 0 = off
   if (force_nw == 1 || (force_nw == 0 && micro && micro_knob)) {
     a.tail_blocks = 0;
-    hipLaunchKernelGGL((k_gru<1, 4>), dim3((unsigned)(8 * cdiv(cdiv(g.cap, 32), 8) * NT)), dim3(256), 0, st, a);
+    static const int direct_knob = getenv("TG_GRU_DIRECT") ? atoi(getenv("TG_GRU_DIRECT")) : 1;  // tuning knob: 0 = LDS-staged
+    const dim3 grid32((unsigned)(8 * cdiv(cdiv(g.cap, 32), 8) * NT));
+    if (direct_knob) hipLaunchKernelGGL(k_gru_direct, grid32, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_gru<1, 4>), grid32, dim3(256), 0, st, a);
     return check_launch("gru(32)");
   }
   if (force_nw == 2 || (force_nw == 0 && tiny)) {
