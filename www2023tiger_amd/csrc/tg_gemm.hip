@@ -356,6 +356,143 @@ __global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
   gemm_tile<WM, WN, KS, D, ASK, AP>(g, mt, rem % NT, rem / NT, 0, (g.k + BK - 1) / BK, nullptr, (int)blockIdx.x);
 }
 
+// ---- register-blocked tiles for plain products ----------------------------------------------------------------------
+// At C2 sizes the 64 x 64 blocks above are bound by what a CU can pull through its vector-memory path, not by the
+// matrix pipe: the G product moves 306 KB per CU for 19.6 k cycles of MFMA work and takes 46 k cycles, and an LDS-free
+// form with the SAME bytes per MFMA takes as long (tools/experiments/gemm_direct_no_lds.patch).  Here a wavefront owns
+// RM x RN accumulator tiles of 32 x 32, the block (64 RM) x (64 RN): every staged float feeds 2 RN (A) or 2 RM (B) MFMA
+// rows instead of two, i.e. 128 x 128 blocks stage half the bytes per MFMA, and a fragment read from LDS feeds RN (RM)
+// MFMAs instead of one.  Same pipeline as gemm_tile (two register sets, two LDS buffers, one barrier per k-tile, the
+// loads of tile t + 2 and the LDS writes of tile t + 1 threaded between the MFMAs of tile t); plain epilogue only.
+template <int RM, int RN>
+__global__ void __launch_bounds__(256) k_gemm_rb(GemmArgs g) {
+  constexpr int BM = 64 * RM, BN = 64 * RN;
+  constexpr int RP = 32;                 // tile rows staged per pass (8 threads per 32-float row)
+  constexpr int NA = BM / RP, NB = BN / RP, NOPS = NA + NB;
+  static_assert(NOPS <= 8, "one memory op per k-step in each half of the tile");
+  __shared__ float As[2][BM][LDK];
+  __shared__ float Bs[2][BN][LDK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 31, fk = lane >> 5;
+  const int K = g.k, N = g.n;
+  int64_t M = g.m_cap;
+  if (g.m_dev) M = min(M, (int64_t)*g.m_dev);
+  const int NT = (N + BN - 1) / BN;
+  const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
+  const int64_t mt = (int64_t)(s / NT) * 8 + xcd;
+  const int nt = s % NT;
+  const int64_t m0 = mt * BM;
+  if (m0 >= M) return;
+  const int n0 = nt * BN;
+  const int ar = tid >> 3, ac4 = (tid & 7) * 4;
+  const int kw0 = g.a0.w;  // A = [a0 | a1]: columns [0, kw0) from a0, the rest from a1
+  const float* arow[NA];
+  const float* arow1[NA];
+  const float* wrow[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int64_t m = min(m0 + ar + i * RP, M - 1);
+    arow[i] = g.a0.p + (g.a0.idx ? g.a0.idx[m] : m) * g.a0.ld;
+    arow1[i] = g.a1.p ? g.a1.p + (g.a1.idx ? g.a1.idx[m] : m) * g.a1.ld - kw0 : arow[i];
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) wrow[i] = g.w + (int64_t)min(n0 + ar + i * RP, N - 1) * g.ldw;
+  float bias[RN], bias2[RN];
+#pragma unroll
+  for (int v = 0; v < RN; ++v) {
+    const int nb = min(n0 + (wn * RN + v) * 32 + fr, N - 1);
+    bias[v] = g.bias ? g.bias[nb] : 0.f;
+    bias2[v] = g.bias2 ? g.bias2[nb] : 0.f;
+  }
+  const int nkt = (K + BK - 1) / BK;
+  float4 ra[2][NA], rb[2][NB];
+  auto load_one = [&](int kt, int i, float4* qa, float4* qb) {
+    const int k = min(kt, nkt - 1) * BK + ac4;
+    const int kc = k < K ? k : 0;
+    if (i < NA) qa[i] = ldg4((kc < kw0 ? arow[i] : arow1[i]) + kc);
+    else qb[i - NA] = ldg4(wrow[i - NA] + kc);
+  };
+  auto store_one = [&](int buf, int kt, int i, const float4* qa, const float4* qb) {
+    const bool kin = kt * BK + ac4 < K;
+    if (i < NA) sts4(As[buf][ar + i * RP], ac4, kin ? qa[i] : zero4());
+    else sts4(Bs[buf][ar + (i - NA) * RP], ac4, kin ? qb[i - NA] : zero4());
+  };
+  f32x16 acc[RM][RN];
+#pragma unroll
+  for (int u = 0; u < RM; ++u)
+#pragma unroll
+    for (int v = 0; v < RN; ++v)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[u][v][i] = 0.f;
+  auto tile = [&](int buf, int kt, float4* la, float4* lb, const float4* sa, const float4* sb) {
+    float a[RM], b[RN], na[RM], nb[RN];
+#pragma unroll
+    for (int u = 0; u < RM; ++u) a[u] = As[buf][(wm * RM + u) * 32 + fr][fk];
+#pragma unroll
+    for (int v = 0; v < RN; ++v) b[v] = Bs[buf][(wn * RN + v) * 32 + fr][fk];
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {  // k-steps of two
+      if (st < 15) {
+#pragma unroll
+        for (int u = 0; u < RM; ++u) na[u] = As[buf][(wm * RM + u) * 32 + fr][fk + 2 * st + 2];
+#pragma unroll
+        for (int v = 0; v < RN; ++v) nb[v] = Bs[buf][(wn * RN + v) * 32 + fr][fk + 2 * st + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < RM; ++u)
+#pragma unroll
+        for (int v = 0; v < RN; ++v) {
+          acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[v], acc[u][v], 0, 0, 0);
+          if (u == 0 && v == 0) {  // this k-step's memory op rides behind its first MFMA
+            if (st < 8) { if (st < NOPS) load_one(kt + 2, st, la, lb); }
+            else if (st - 8 < NOPS) store_one(buf ^ 1, kt + 1, st - 8, sa, sb);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+      for (int u = 0; u < RM; ++u) a[u] = na[u];
+#pragma unroll
+      for (int v = 0; v < RN; ++v) b[v] = nb[v];
+    }
+    __syncthreads();
+  };
+#pragma unroll
+  for (int i = 0; i < NOPS; ++i) load_one(0, i, ra[0], rb[0]);
+#pragma unroll
+  for (int i = 0; i < NOPS; ++i) load_one(1, i, ra[1], rb[1]);
+#pragma unroll
+  for (int i = 0; i < NOPS; ++i) store_one(0, 0, i, ra[0], rb[0]);
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 2 <= nkt; kt += 2) {  // even tile: LDS[0], loads tile t + 2 -> set 0, stores tile t + 1 (set 1) -> LDS[1]
+    tile(0, kt, ra[0], rb[0], ra[1], rb[1]);
+    tile(1, kt + 1, ra[1], rb[1], ra[0], rb[0]);
+  }
+  if (kt < nkt) tile(0, kt, ra[0], rb[0], ra[1], rb[1]);
+#pragma unroll
+  for (int u = 0; u < RM; ++u)
+#pragma unroll
+    for (int v = 0; v < RN; ++v) {
+      const int n = n0 + (wn * RN + v) * 32 + fr;
+      if (n >= N) continue;
+      uint8_t v2[16];  // the second bias is added on rows whose validity byte is set; all 16 bytes requested together
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = min(m0 + (wm * RM + u) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk, M - 1);
+        v2[r] = g.bias2 ? g.bias2_valid[m] : 0;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + (wm * RM + u) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+        if (m >= M) continue;
+        float x = g.alpha * (acc[u][v][r] + bias[v] + (v2[r] ? bias2[v] : 0.f));
+        if (g.relu) x = fmaxf(x, 0.f);
+        g.c[m * g.ldc + n] = x;
+      }
+    }
+}
+
 // ---- stream-K for launches that cannot fill the chip --------------------------------------------------
 // A product with fewer 64x64 tiles than CUs and a long K (the merged value/out/fc1 product of the fused
 // attention: 144 tiles x 38 k-tiles on 256 CUs) leaves CUs idle for its whole duration.  Here the
@@ -428,6 +565,20 @@ int gemm_launch(const GemmArgs& g, hipStream_t st) {
   GemmArgs gd = g;
   gd.dbg = gdbg;
   static const int depth_knob = getenv("TG_GEMM_DEPTH") ? atoi(getenv("TG_GEMM_DEPTH")) : 2;  // tuning knob: 2 / 4
+  // plain row-major products with MANY rows: register-blocked 128 x 64 blocks (three quarters of the staged bytes per
+  // MFMA, half the fragment reads).  Measured: C5 shape (24 576 / 6 144 / 6 144 blocks) G 1.00 -> 0.96 ms, fc1 1.19 ->
+  // 1.08 ms, fc2 0.261 -> 0.253 ms; at C3 / C4 sizes (288 .. 2 500 blocks) 3 .. 17 % SLOWER than the 64 x 64 blocks (whose
+  // several co-resident blocks per CU cover each other's prologue and epilogue); 128 x 128 blocks are slower still there
+  static const int rb_knob = getenv("TG_GEMM_RB") ? atoi(getenv("TG_GEMM_RB")) : 1;  // tuning knob: 0 = off, 2 = 128 x 128
+  if (rb_knob && !g.ask_part && g.nbatch == 1 && !g.w_kmajor && !g.bias_rs && !g.row_valid && !g.relu_mask && !g.c_rows &&
+      !g.accumulate && cdiv(g.m_cap, 128) * NT >= 4096) {
+    if (rb_knob == 2 && g.n >= 512) {
+      hipLaunchKernelGGL((k_gemm_rb<2, 2>), dim3((unsigned)(8 * cdiv(cdiv(g.m_cap, 128), 8) * cdiv(g.n, 128))), dim3(256), 0, st, gd);
+    } else {
+      hipLaunchKernelGGL((k_gemm_rb<2, 1>), dim3((unsigned)(8 * cdiv(cdiv(g.m_cap, 128), 8) * NT)), dim3(256), 0, st, gd);
+    }
+    return check_launch("gemm(rb)");
+  }
   if (g.ask_part) {  // A assembled from stream-K pieces of a 64-row-tiled producer with g.k output columns
     if (g.nbatch != 1 || g.w_kmajor || g.k != g.a0.w || !g.ask_bias || g.ask_NT != (int)cdiv(g.k, 64)) return TG_EINVAL;
     static const int ask_depth = getenv("TG_GEMM_ASK_DEPTH") ? atoi(getenv("TG_GEMM_ASK_DEPTH")) : 2;  // tuning knob: 2 / 4
