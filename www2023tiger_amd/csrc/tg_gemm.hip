@@ -493,6 +493,111 @@ __global__ void __launch_bounds__(256) k_gemm_rb(GemmArgs g) {
     }
 }
 
+// ---- activation-stationary blocks for short-K, wide-N products ------------------------------------------------------
+// The G product of the fused attention (K = d, N = n_head (2d + d_e)) has NKT = 4 .. 8 k-tiles per output tile and many
+// column tiles per row tile.  As separate 64 x 64 blocks every column tile re-stages the same 64 x K activation panel
+// and pays its own prologue (first loads exposed) and epilogue; at C2 that is 816 blocks of 18 k cycles, a third of it
+// outside the k-loop.  Here a block stages its activation panel ONCE (64 x K, odd row stride: conflict-free fragment
+// reads) and walks `cpb` column tiles, streaming only weight tiles through the two-buffer pipeline: the stream never
+// drains between column tiles (the next tile's first weight tile is already in LDS when a tile's outputs are stored),
+// and per k-tile half as much is staged.  NKT is a template parameter so that the tile walk is straight-line.
+template <int NKT>
+__global__ void __launch_bounds__(256) k_gemm_astat(GemmArgs g, int cpb) {
+  static_assert(NKT % 2 == 0, "the LDS buffer of a weight tile follows from its k-tile index");
+  constexpr int SA = NKT * BK + 1;  // panel row stride (odd)
+  __shared__ float As[64][SA];
+  __shared__ float Bs[2][64][LDK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 31, fk = lane >> 5;
+  const int K = g.k, N = g.n;
+  int64_t M = g.m_cap;
+  if (g.m_dev) M = min(M, (int64_t)*g.m_dev);
+  const int NT = (N + 63) / 64, NG = (NT + cpb - 1) / cpb;  // column tiles, column groups
+  const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
+  const int64_t mt = (int64_t)(s / NG) * 8 + xcd;
+  const int c0 = (s % NG) * cpb, c1 = min(c0 + cpb, NT);
+  const int64_t m0 = mt * 64;
+  if (m0 >= M) return;
+  const int ar = tid >> 3, ac4 = (tid & 7) * 4;
+  // ---- the activation panel, once
+  {
+    float4 pa[2][NKT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t m = min(m0 + ar + 32 * i, M - 1);
+      const float* row = g.a0.p + (g.a0.idx ? g.a0.idx[m] : m) * g.a0.ld;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        const int k = kt * BK + ac4;
+        pa[i][kt] = ldg4(row + (k < K ? k : 0));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) sts4(As[ar + 32 * i], kt * BK + ac4, kt * BK + ac4 < K ? pa[i][kt] : zero4());
+  }
+  // ---- weight tiles: (column tile c, k-tile j), two register sets / two LDS buffers by the parity of j
+  float4 rb[2][2];
+  auto load_w = [&](int c, int j, int i, float4* q) {  // i-th staged float4 (rows ar, ar + 32 of the tile)
+    const int cc = min(c, c1 - 1);  // past the last column tile: a redundant reload keeps the walk branch-free
+    const int k = j * BK + ac4;
+    q[i] = ldg4(g.w + (int64_t)min(cc * 64 + ar + 32 * i, N - 1) * g.ldw + (k < K ? k : 0));
+  };
+  auto store_w = [&](int buf, int j, int i, const float4* q) {
+    sts4(Bs[buf][ar + 32 * i], ac4, j * BK + ac4 < K ? q[i] : zero4());
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  load_w(c0, 0, 0, rb[0]); load_w(c0, 0, 1, rb[0]);
+  load_w(c0, 1, 0, rb[1]); load_w(c0, 1, 1, rb[1]);
+  store_w(0, 0, 0, rb[0]); store_w(0, 0, 1, rb[0]);
+  __syncthreads();
+  for (int c = c0; c < c1; ++c) {
+    const int n_out = min(c * 64 + wn * 32 + fr, N - 1);
+    const float bias = g.bias ? g.bias[n_out] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {  // straight-line walk over the k-tiles of column tile c
+      constexpr int PP = 8;
+      const int buf = j & 1;
+      // tile (c, j) multiplies; tile (c, j + 2) - or (c + 1, j + 2 - NKT) - is requested into the set tile (c, j) came
+      // from; tile (c, j + 1) - or (c + 1, 0) - moves from its set to the other LDS buffer
+      const int lc = j + 2 < NKT ? c : c + 1, lj = (j + 2) % NKT, sj = (j + 1) % NKT;
+      const float* ap = &As[wm * 32 + fr][j * BK + fk];
+      const float* bp = &Bs[buf][wn * 32 + fr][fk];
+      float a0 = ap[0], a1 = ap[2], b0 = bp[0], b1 = bp[2];
+#pragma unroll
+      for (int pr = 0; pr < PP; ++pr) {
+        float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+        if (pr < PP - 1) {
+          na0 = ap[4 * pr + 4]; na1 = ap[4 * pr + 6];
+          nb0 = bp[4 * pr + 4]; nb1 = bp[4 * pr + 6];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
+        if (pr < 2) load_w(lc, lj, pr, rb[j & 1]);
+        else if (pr >= 4 && pr < 6) store_w(buf ^ 1, sj, pr - 4, rb[(j + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+      }
+      __syncthreads();
+    }
+    // outputs of column tile c (plain epilogue); the next tile's first weight tile is already staged
+    const int n = c * 64 + wn * 32 + fr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+      float x = g.alpha * (acc[r] + bias);
+      if (g.relu) x = fmaxf(x, 0.f);
+      if (n < N && m < M) g.c[m * g.ldc + n] = x;
+      acc[r] = 0.f;
+    }
+  }
+}
+
 // ---- stream-K for launches that cannot fill the chip --------------------------------------------------
 // A product with fewer 64x64 tiles than CUs and a long K (the merged value/out/fc1 product of the fused
 // attention: 144 tiles x 38 k-tiles on 256 CUs) leaves CUs idle for its whole duration.  Here the
@@ -578,6 +683,24 @@ int gemm_launch(const GemmArgs& g, hipStream_t st) {
       hipLaunchKernelGGL((k_gemm_rb<2, 1>), dim3((unsigned)(8 * cdiv(cdiv(g.m_cap, 128), 8) * NT)), dim3(256), 0, st, gd);
     }
     return check_launch("gemm(rb)");
+  }
+  // short K, many column tiles, a launch of a few blocks per CU: activation-stationary blocks (see k_gemm_astat)
+  static const int as_knob = getenv("TG_GEMM_ASTAT") ? atoi(getenv("TG_GEMM_ASTAT")) : 1;  // tuning knob: 0 = off, n = column tiles per block
+  {
+    const int nkt = (int)cdiv(g.k, BK);
+    const bool plain_as = !g.ask_part && g.nbatch == 1 && !g.a1.p && !g.w_kmajor && !g.bias_rs && !g.bias2 && !g.row_valid &&
+                          !g.relu_mask && !g.c_rows && !g.accumulate && g.a0.w == g.k;
+    if (as_knob && plain_as && NT >= 8 && (nkt == 4 || nkt == 6 || nkt == 8) && MT * NT <= 1024) {  // (C3's 3 264 tiles: no gain)
+      // two column tiles per block (measured at C2, 48 x 17 tiles: 21.6 us; three: 28.1, four: 24.6, six: 29.8, nine:
+      // 40.8; separate 64 x 64 blocks: 24.4): two such blocks share a CU and cover each other's barriers, which matters
+      // more than the shared panel
+      const int cpb = as_knob > 1 ? std::min(as_knob, NT) : 2;
+      const dim3 grid_as((unsigned)(8 * cdiv(MT, 8) * cdiv(NT, cpb)));
+      if (nkt == 4) hipLaunchKernelGGL((k_gemm_astat<4>), grid_as, dim3(256), 0, st, gd, cpb);
+      else if (nkt == 6) hipLaunchKernelGGL((k_gemm_astat<6>), grid_as, dim3(256), 0, st, gd, cpb);
+      else hipLaunchKernelGGL((k_gemm_astat<8>), grid_as, dim3(256), 0, st, gd, cpb);
+      return check_launch("gemm(astat)");
+    }
   }
   if (g.ask_part) {  // A assembled from stream-K pieces of a 64-row-tiled producer with g.k output columns
     if (g.nbatch != 1 || g.w_kmajor || g.k != g.a0.w || !g.ask_bias || g.ask_NT != (int)cdiv(g.k, 64)) return TG_EINVAL;
