@@ -154,7 +154,9 @@ def test_empty_inputs():
 
 # ------------------------------------------------------------------------------ dense kernels
 @pytest.mark.parametrize('n,in_f,out_f', [(1, 8, 4), (37, 172, 344), (300, 516, 172), (129, 860, 516), (64, 64, 64),
-                                          (140001, 44, 300)])   # 1 094 x 5 blocks of 128 x 64: the register-blocked form, ragged edges
+                                          (140001, 44, 300),    # 1 094 x 5 blocks of 128 x 64: the register-blocked form, ragged edges
+                                          # activation-stationary blocks (short K of 4 / 6 / 8 k-tiles, >= 8 column tiles), ragged edges
+                                          (500, 172, 1032), (70, 100, 600), (129, 256, 520)])
 def test_linear_fwd_vs_torch(n, in_f, out_f):
     from www2023tiger_amd.model.dense import linear_forward
     torch.manual_seed(n)
