@@ -203,7 +203,9 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
     // a wave's keys are a chain of dependent gathers (row address <- key metadata), and with ~3 waves per
     // SIMD at C2 nothing else covers their latency.  Keys are reduced in list order whatever PD is, so the
     // result does not depend on it.
-    constexpr int PD = NV == 1 ? 3 : 2;
+    // (measured: narrow rows, W = 2, gain from a fourth slot - C4 core 84 -> 78 us - and nothing from a fifth or sixth,
+    // eight are slower; W = 4 is the same with three and four)
+    constexpr int PD = NV == 1 ? (W == 2 ? 4 : 3) : 2;
     V ya[PD][NV], yn[PD][NV], yb[PD][NV];
     auto fetch = [&](int slot, int k) {
       const int64_t u = __shfl(u_l, k, TG_WAVE);
