@@ -1,0 +1,33 @@
+"""Long-horizon agreement of the two most different forms of the step on one stream (both on the GPU): the round-1 form
+(lazy updater, attention weights as stored, involved set formed) against the benchmarked form (eager updates in the
+direct form, pre-multiplied weights, lean).  python tools/long_soak.py [n_batches]"""
+import os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))
+import numpy as np, torch
+import bench
+from _util import row_rel_err
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+c = bench.C2
+B = c['B']
+E = n * B
+stream = bench.make_stream(c['n_u'], c['n_i'], E, c['T'] * E / c['E'], seed=11, d_e=c['d'])
+a, _ = bench.build_models(stream, c['d'], c['K'], c['msg_src'], c['upd_src'])
+b, _ = bench.build_models(stream, c['d'], c['K'], c['msg_src'], c['upd_src'])
+b.fuse_attention(); b.eager_updates()
+worst = 0.0
+for i in range(n):
+    s = [stream[k][i * B:(i + 1) * B] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+    ha = a.stream_step(*s, check_invariants=(i % 50 == 0))
+    hb = b.stream_step(*s, check_invariants=(i % 50 == 0), lean=True)
+    if i % 100 == 0 or i == n - 1:
+        x, y = hb.h[:2 * B].cpu().numpy(), ha.h[:2 * B].cpu().numpy()
+        e = float(np.abs(x - y).max() / max(1.0, np.abs(y).max())); r = row_rel_err(x, y)
+        worst = max(worst, e, r)
+        print(i, 'h: max-abs-rel %.2e row-rel %.2e' % (e, r), flush=True)
+for nm in ('left_memory', 'right_memory'):
+    x, y = getattr(b, nm).vals.cpu().numpy(), getattr(a, nm).vals.cpu().numpy()
+    e = float(np.abs(x - y).max() / max(1.0, np.abs(y).max()))
+    worst = max(worst, e)
+    print(nm, '%.2e' % e, 'ts equal', bool(torch.equal(getattr(b, nm).update_ts, getattr(a, nm).update_ts)))
+print('has_msg equal', bool(torch.equal(a.msg_store.has_msg_bits, b.msg_store.has_msg_bits)), 'worst %.2e' % worst)
+assert worst < 1e-4
