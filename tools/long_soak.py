@@ -1,18 +1,20 @@
 """Long-horizon agreement of the two most different forms of the step on one stream (both on the GPU): the round-1 form
 (lazy updater, attention weights as stored, involved set formed) against the benchmarked form (eager updates in the
-direct form, pre-multiplied weights, lean).  python tools/long_soak.py [n_batches]"""
+direct form, pre-multiplied weights, lean).  python tools/long_soak.py [n_batches [workload]]"""
 import os, sys
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))
 import numpy as np, torch
 import bench
 from _util import row_rel_err
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
-c = bench.C2
+c = bench.WORKLOADS[sys.argv[2]] if len(sys.argv) > 2 else bench.C2
 B = c['B']
 E = n * B
-stream = bench.make_stream(c['n_u'], c['n_i'], E, c['T'] * E / c['E'], seed=11, d_e=c['d'])
-a, _ = bench.build_models(stream, c['d'], c['K'], c['msg_src'], c['upd_src'])
-b, _ = bench.build_models(stream, c['d'], c['K'], c['msg_src'], c['upd_src'])
+nf = bool(c.get('no_feats'))
+stream = bench.make_stream(c['n_u'], c['n_i'], E, c['T'] * E / c['E'], seed=11, d_e=c['d'],
+                           integer_ts=c.get('integer_ts', True), with_efeats=not nf)
+a, _ = bench.build_models(stream, c['d'], c['K'], c['msg_src'], c['upd_src'], zero_nfeats=not nf)
+b, _ = bench.build_models(stream, c['d'], c['K'], c['msg_src'], c['upd_src'], zero_nfeats=not nf)
 b.fuse_attention(); b.eager_updates()
 worst = 0.0
 for i in range(n):
