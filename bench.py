@@ -195,7 +195,7 @@ def profile_stages(model, buf, steps):
     return names, acc / steps, counts / steps
 
 
-def stage_work(cfg, U, O_, P, eager, fused, n_nodes, E):
+def stage_work(cfg, U, O_, P, eager, fused, n_nodes, E, tile=False):
     """Algorithmic work per launch of every stage (SURVEY.md s8 d, with the measured U = involved, O = with a
     pending message, P = unique positive nodes of the run): name -> (flops or None, HBM bytes, kernel name)."""
     B, K, d = cfg['B'], cfg['K'], cfg['d']
@@ -224,7 +224,15 @@ def stage_work(cfg, U, O_, P, eager, fused, n_nodes, E):
         'writeback_phase0': (None, P * (4 * mw + 4) + P * 4 * d * 2 + 2 * B * 4 * d + B * 4 * d_e * fe, 'tg::k_writeback<0>'),
         'writeback_phase1': (None, 2 * P * (4 * d + 5) + n_nodes, 'tg::k_writeback<1>'),
     }
-    if fused:
+    if fused and tile:
+        # the whole attention block is ONE launch (k_attn_tile): G and S stay in LDS.  flops: the three products;
+        # compulsory bytes: the unique neighbour rows (+ their node features), the edge-feature rows, the neighbour
+        # lists, centre rows in, embeddings out, every weight once
+        wts = (nk * d + nk + d * (nk + d) + 2 * d + d * d + d) * 4
+        w['attn_core(gather+softmax)'] = (2.0 * Q * (nk * d + d * (nk + d) + d * d),
+                                          U * 4 * d * (1 + fe) + Q * K * 4 * d_e * fe + Q * K * 20 + 2.0 * Q * d * 4 + wts,
+                                          'tg::k_attn_tile')
+    elif fused:
         w['attn_gemm_q'] = (2.0 * Q * nk * d, Q * d * 4 + Q * nk * 4 + nk * d * 4, 'tg::k_gemm')           # G = c Wqk^T + gconst
         w['attn_gemm_fc1'] = (2.0 * Q * d * (nk + d), Q * (nk + d) * 4 + Q * d * 4 + d * (nk + d) * 4, 'tg::k_gemm_sk / k_gemm')
     else:
@@ -340,6 +348,10 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     dt = time.perf_counter() - t0
     assert int(buf.err.item()) == 0, f'invariant word {int(buf.err.item())}'
     assert int(buf.offset.item()) == (preroll + warmup + steps) * B
+    self_check = None
+    if graph is not None and not args.no_self_check and stream['n_nodes'] <= 2_000_000:
+        self_check = replay_self_check(cfg, args, stream, resident, model, buf, preroll, warmup, steps, cnt,
+                                       trig if restart_prob > 0 else None, lean)
 
     # ---- per-stage timing on the next unseen batches, live (HIP events on the launch stream)
     names, stage_ms, counts = profile_stages(model, buf, n_prof)
@@ -350,7 +362,9 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
         _, _, cf = profile_stages(model, buf, 2)
         buf.io.lean = 1
         U, O_ = cf[0], cf[1]
-    work = stage_work(cfg, U, O_, P, eager, fused, stream['n_nodes'], E)
+    from www2023tiger_amd._lib import lib as _tg
+    tile = bool(fused and _tg.tg_attn_tile_applies(C.byref(model.model_struct())))
+    work = stage_work(cfg, U, O_, P, eager, fused, stream['n_nodes'], E, tile)
     traffic = load_traffic(traffic_tag)
     empty = {'zero_flags', 'dedup_positive', 'restarter_targets', 'apply_messages(gru)' if eager else 'eager_updater(gru)'}
     if lean:  # no compaction launch, and the centres ride on the sampler's launch
@@ -361,6 +375,8 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
         work['writeback_phase1'] = (None, w0[1] + w1[1], 'tg::k_writeback_fused')
     if fused:
         empty |= {'attn_gemm_g', 'attn_gemm_v', 'attn_gemm_out'}
+    if tile:
+        empty |= {'attn_gemm_q', 'attn_gemm_fc1', 'attn_gemm_fc2'}
     overhead = float(np.median([v for n, v in zip(names, stage_ms) if n in empty]))  # cost of an empty event pair
     stages = {n: float(v) for n, v in zip(names, stage_ms) if n not in empty}
     dom = max(stages, key=stages.get)
@@ -368,7 +384,7 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
                config=dict(workload=cfg['name'], batch=B, dim=d, n_neighbors=K, msg_src=cfg['msg_src'],
                            upd_src=cfg['upd_src'], n_nodes=stream['n_nodes'], events=E, mode='stream (no_grad) STEP 1-6',
                            launch='hipGraph replay' if graph is not None else 'eager',
-                           attention_weights='pre-multiplied (tg_attn_fuse)' if fused else 'as stored',
+                           attention_weights=('pre-multiplied (tg_attn_fuse)' + (', whole block in one launch with G / S in LDS (k_attn_tile)' if tile else '')) if fused else 'as stored',
                            updater=('eager: once per stored message (TIGE.eager_updates)' + (', rows read from the tables directly' if direct else ', compact reprs copy')) if eager else
                                    'lazy: on the fly for every involved node with a pending message',
                            involved_set=('not formed (tg_step_io.lean: nothing in a direct-form eager step reads it)' if lean else 'formed (sorted unique ids + ranks)'),
@@ -376,6 +392,8 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
                            unique_pos_per_batch=float(P)),
                roofline=roofline_of(dom, stages[dom], work, traffic),
                stages_ms={n: round(v, 5) for n, v in stages.items()}, stage_event_overhead_ms=round(overhead, 5))
+    if self_check is not None:
+        out['replay_self_check'] = self_check
     if restart_prob > 0:
         out['config'].update(restart_prob=restart_prob, restart_triggers_in_timed_region=n_trig,
                              restarter='static, re-initialisation inside the step (tg_lazy_restart)')
@@ -425,6 +443,54 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     del buf, graph, model, resident
     torch.cuda.empty_cache()
     return out
+
+
+def replay_self_check(cfg, args, stream, resident, model, buf, preroll, warmup, steps, cnt, trig, lean):
+    """Untimed: the batches the timed region has just replayed from ONE captured graph go through a SECOND model (same
+    seed, same weights, same switches) as plain eager launches, in the same order; memories, mailbox, has-message set
+    and the last batch's embeddings of the two must be equal.  The graph replay (device-side offset, baked launch
+    parameters) is thereby checked against the launch form the parity tests compare with the oracle."""
+    model2, _ = build_models(stream, cfg['d'], cfg['K'], cfg['msg_src'], cfg['upd_src'], restarter='static', device='cuda:0',
+                             zero_nfeats=not cfg.get('no_feats'))
+    if not args.no_fuse:
+        model2.fuse_attention()
+    if not args.no_eager:
+        model2.eager_updates()
+    buf2 = model2.StepBuffers(model2, cfg['B'], False, resident=resident)
+    buf2.io.eager_copy = buf.io.eager_copy
+    buf2.io.lean = 1 if lean else 0
+    if trig is not None:
+        with torch.no_grad():
+            model2.restarter_fn.left_emb.weight.copy_(model.restarter_fn.left_emb.weight)
+            model2.restarter_fn.right_emb.weight.copy_(model.restarter_fn.right_emb.weight)
+        buf2.enable_lazy_restart(model2, trig)
+    for _ in range(preroll + warmup):
+        model2.launch_step(buf2)
+    torch.cuda.synchronize()
+    model2.note_rows(cnt[1], cnt[2])  # the same row bounds as the timed model had: the same updater blocks
+    for _ in range(steps):
+        model2.launch_step(buf2)
+    torch.cuda.synchronize()
+    assert int(buf2.err.item()) == 0 and int(buf2.offset.item()) == int(buf.offset.item())
+    worst = 0.0
+    pairs = [('left_memory.vals', model.left_memory.vals, model2.left_memory.vals),
+             ('right_memory.vals', model.right_memory.vals, model2.right_memory.vals),
+             ('left_memory.update_ts', model.left_memory.update_ts, model2.left_memory.update_ts),
+             ('right_memory.update_ts', model.right_memory.update_ts, model2.right_memory.update_ts),
+             ('h (last batch)', buf.h, buf2.h)]
+    has, has2 = model.msg_store.has_msg_mask(), model2.msg_store.has_msg_mask()
+    assert torch.equal(has, has2), 'self-check: has-message sets differ between graph replay and eager launches'
+    idx = torch.nonzero(has).flatten()
+    pairs.append(('mailbox rows', model.msg_store.node_msg_vals[idx], model2.msg_store.node_msg_vals[idx]))
+    pairs.append(('mailbox ts', model.msg_store.node_msg_ts[idx], model2.msg_store.node_msg_ts[idx]))
+    for name, a, b in pairs:
+        diff = float((a - b).abs().max()) if a.numel() else 0.0
+        assert diff <= 1e-5, f'self-check: {name} differs between graph replay and eager launches by {diff}'
+        worst = max(worst, diff)
+    del buf2, model2
+    return dict(compared='memories, update times, mailbox rows / times, has-message set, last embeddings: hipGraph replay '
+                         'of the timed region vs a second model driven by eager launches over the same batches',
+                batches=preroll + warmup + steps, max_abs_diff=worst)
 
 
 def spawn_ranks(args):
@@ -508,6 +574,8 @@ def main():
     ap.add_argument('--no-lean', action='store_true',
                     help='form the involved / outdated sets in every step even where nothing reads them')
     ap.add_argument('--no-graph', action='store_true', help='launch steps eagerly instead of replaying a hipGraph')
+    ap.add_argument('--no-self-check', action='store_true',
+                    help='skip the untimed comparison of the replayed region with a second, eagerly launched model')
     ap.add_argument('--force-dist', action='store_true', help='run the multi-GPU code path even with one rank')
     ap.add_argument('--dist-graphs', action='store_true',
                     help='multi-GPU: replay captured hipGraphs around the exchange (experimental; default eager)')
@@ -522,7 +590,7 @@ def main():
     ap.add_argument('--train', action='store_true', help='measure the training iteration instead (not the headline metric)')
     ap.add_argument('--train-restarter', default='none', choices=['none', 'seq', 'static'],
                     help='--train: add the mutual-learning loss of this restarter (none = contrast_only)')
-    ap.add_argument('--hist-len', type=int, default=20)
+    ap.add_argument('--hist-len', type=int, default=40, help='--train-restarter seq: history length (reference default 40, init_utils.py:58)')
     args = ap.parse_args()
     cfg = dict(WORKLOADS[args.workload])
     if args.train:

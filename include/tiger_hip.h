@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 3
+#define TG_ABI_VERSION 4
 
 /* status codes */
 #define TG_OK 0
@@ -238,10 +238,16 @@ typedef struct tg_model {
  *   fc1([Wo concat_h(Wv_h s_h + bv_h) + bo | c])             ->  [S | c] W1f^T + b1 + valid * c1
  * `fused` receives tg_attn_fused_floats(m) floats: Wqk [n_head*kvw, d], gconst [n_head*kvw],
  * W1f [d, n_head*kvw + d], b1 [d], c1 [d]  (kvw = 2d + d_e).  Must be recomputed whenever an attention
- * parameter or the time encoder changes; training (tg_train_step) ignores it. */
+ * parameter or the time encoder changes; training (tg_train_step) ignores it.
+ * Where the attention block fits one workgroup (d, d_e <= 256, the tiles of 16 centres inside one CU's 160 KB of LDS)
+ * the same weights and fc2 follow once more in FRAGMENT-MAJOR order (csrc/tg_tile.h) and the forward pass of a model
+ * carrying `attn_fused` runs the whole block - G product, neighbour gather / softmax, merged value-out-fc1 product,
+ * fc2 (temporal_agg_modules.py:48-81,210-235; basic_modules.py:16-19) - as ONE launch per batch with G and S in LDS
+ * only (k_attn_tile).  tg_attn_tile_applies: 1 when that form will be taken for `m` (TG_ATTN_TILE=0 switches it off). */
 size_t tg_attn_fused_floats(const tg_model* m);
 size_t tg_attn_fuse_workspace_bytes(const tg_model* m);
 int tg_attn_fuse(const tg_model* m, float* fused, void* ws, size_t ws_bytes, void* stream);
+int tg_attn_tile_applies(const tg_model* m);
 
 /* TimeEncode.forward (time_encoding.py:24-26): out[i,:] = cos(fl32(ts[i]*w) + phi) */
 int tg_time_encode(int64_t n, const float* ts, int32_t d, const float* freq, const float* phase,

@@ -1,0 +1,140 @@
+"""Parity of the exact launch form bench.py times: the event stream resident in HBM, the
+step reading its batch at a device-side offset and advancing it, ONE captured hipGraph replayed per batch, lean
+direct-form eager step with pre-multiplied attention weights and the row bound that selects the small updater
+blocks - against the oracle after every replay, and the final state.  C3: the lazy-restart triggers fire INSIDE
+the replayed graph (train_self_supervised.py:152-163 with the static restarter, restarters.py:254-277)."""
+import numpy as np
+import pytest
+import torch
+
+from _util import assert_close
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def dev():
+    return torch.device('cuda', 0)
+
+
+def _resident(stream):
+    return tuple(torch.from_numpy(stream[k]).to(dev()) for k in ('src', 'dst', 'neg', 'ts', 'eids'))
+
+
+def _capture(model, buf, extra=()):
+    """bench.py::run_stream_leg's capture: side stream, offset (and lazy batch counter) restored afterwards"""
+    side = torch.cuda.Stream()
+    snap = [t.clone() for t in (buf.offset,) + tuple(extra)]
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        model.launch_step(buf)
+    for t, s in zip((buf.offset,) + tuple(extra), snap):
+        t.copy_(s)
+    torch.cuda.synchronize()
+    return graph
+
+
+@pytest.mark.parametrize('n_eager', [3, 0], ids=['after_eager_steps', 'first_step_replayed'])
+def test_c2_graph_replay_of_the_resident_lean_step_matches_oracle(n_eager):
+    """BASELINE configs[1] in bench.py's timed form: n_eager eager steps (state pre-roll; they also give the model the
+    row bound that selects k_gru_direct), then the captured step replayed 12 times - embeddings compared after every
+    replay, memories / mailbox / has-message set at the end."""
+    import bench
+    from oracle import tiger_oracle as O
+    from test_hip_parity import compare_state_with_oracle
+    c = bench.C2
+    B, K, d = c['B'], c['K'], c['d']
+    nb = n_eager + 12
+    E = (nb + 2) * B
+    stream = bench.make_stream(c['n_u'], c['n_i'], E, c['T'] * E / c['E'], seed=21, d_e=d)
+    model, orc = bench.build_models(stream, d, K, c['msg_src'], c['upd_src'], with_oracle=True)
+    model.fuse_attention()
+    model.eager_updates()
+    buf = model.StepBuffers(model, B, False, resident=_resident(stream))
+    buf.io.lean = 1
+    _ = model.graph.tcsr, model.model_struct()
+
+    def check(b):
+        torch.cuda.synchronize()
+        assert int(buf.err.item()) == 0
+        assert int(buf.offset.item()) == (b + 1) * B
+        a = [stream[k][b * B:(b + 1) * B] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], K, 'static')
+        ref = orc.stream_step(*a, cg).numpy()
+        np.testing.assert_array_equal(buf.l1_nids.cpu().numpy(), cg['l1_nids'])
+        cnt = buf.counts.tolist()
+        assert cnt[0] == -1 and cnt[2] == len(cg['rd_nids'])  # lean form taken; unique positives still counted
+        assert_close(buf.h[:2 * B].cpu().numpy(), ref, f'h_left, batch {b}', TOL)
+        return cnt
+
+    for b in range(n_eager):
+        model.launch_step(buf)
+        cnt = check(b)
+        model.note_rows(cnt[1], cnt[2])
+    if n_eager == 0:  # the eager-update table must be current before a capture (TIGE._sync_pending refuses inside one)
+        model._sync_pending()
+    graph = _capture(model, buf)
+    for b in range(n_eager, nb):
+        graph.replay()
+        check(b)
+    compare_state_with_oracle(model, orc)
+
+
+def test_c3_graph_replay_with_lazy_restart_triggers_inside_matches_reference_loop():
+    """BASELINE configs[2] as bench.py --workload c3 times it: static restarter, the restart draws made up front, the
+    forget / re-initialise loop inside the step and the step inside a replayed graph; two triggers fall into the
+    replayed region.  Oracle: the reference's loop on the host."""
+    import bench
+    from oracle import tiger_oracle as O
+    from test_hip_parity import compare_state_with_oracle
+    c = bench.WORKLOADS['c3']
+    B, K, d = c['B'], c['K'], c['d']
+    n_eager, nb = 2, 9
+    E = (nb + 1) * B
+    stream = bench.make_stream(c['n_u'], c['n_i'], E, c['T'] * E / c['E'], seed=23, d_e=d)
+    model, orc = bench.build_models(stream, d, K, c['msg_src'], c['upd_src'], restarter='static', with_oracle=True)
+    torch.manual_seed(12)
+    with torch.no_grad():
+        for nm in ('left_emb', 'right_emb'):
+            tbl = getattr(model.restarter_fn, nm).weight
+            tbl.normal_(0.0, 0.5)
+            orc.p[f'restarter_fn.{nm}.weight'] = tbl.detach().cpu().clone()
+    model.fuse_attention()
+    model.eager_updates()
+    trigger = np.zeros(nb, dtype=np.uint8)
+    trigger[[3, 6]] = 1
+    buf = model.StepBuffers(model, B, False, resident=_resident(stream))
+    buf.enable_lazy_restart(model, trigger)
+    _ = model.graph.tcsr, model.model_struct()
+    restarting, uptodate, total = False, set(), 0
+    graph = None
+    for b in range(nb):
+        a = [stream[k][b * B:(b + 1) * B] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], K, 'static')
+        n_r = 0
+        if trigger[b] and b:
+            restarting, uptodate = True, set()
+            orc.clear_msgs()
+        if restarting:
+            r = np.array(sorted(set(cg['involved'].tolist()) - uptodate), dtype=np.int64)
+            orc.restart(r, np.full(len(r), np.float32(a[3].min()), dtype=np.float32))
+            uptodate.update(r.tolist())
+            n_r = len(r)
+        if b == n_eager:
+            graph = _capture(model, buf, extra=(buf.lazy_batch,))
+        if graph is not None:
+            graph.replay()
+        else:
+            model.launch_step(buf)
+        torch.cuda.synchronize()
+        assert int(buf.err.item()) == 0
+        ref = orc.stream_step(*a, cg).numpy()
+        cnt = buf.counts.tolist()
+        assert cnt[0] == len(cg['involved']) and cnt[3] == n_r, (b, cnt, n_r)
+        np.testing.assert_array_equal(buf.l1_nids.cpu().numpy(), cg['l1_nids'])
+        assert_close(buf.h[:2 * B].cpu().numpy(), ref, f'h_left, batch {b}', TOL)
+        if graph is None:
+            model.note_rows(cnt[1], cnt[2])
+        total += n_r
+    assert total > 5000
+    compare_state_with_oracle(model, orc)

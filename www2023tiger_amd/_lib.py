@@ -165,6 +165,7 @@ SIGNATURES = {
     'tg_attn_fused_floats': (sz, [P(TgModel)]),
     'tg_attn_fuse_workspace_bytes': (sz, [P(TgModel)]),
     'tg_attn_fuse': (C.c_int, [P(TgModel), vp, vp, sz, vp]),
+    'tg_attn_tile_applies': (C.c_int, [P(TgModel)]),
     'tg_ap_auc': (C.c_int, [i64, i32, vp, vp, vp, vp, vp, vp]),
     'tg_stream_writeback_workspace_bytes': (sz, [P(TgModel), i64]),
     'tg_stream_writeback': (C.c_int, [P(TgModel), P(TgWritebackIo), vp, sz, vp]),
@@ -185,7 +186,7 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the library does not export the symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.tg_abi_version() != 3:
+    if lib.tg_abi_version() != 4:
         raise TigerHipError('libtiger_hip.so ABI version mismatch')
     return lib
 

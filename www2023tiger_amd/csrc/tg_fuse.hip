@@ -3,6 +3,7 @@
 // + MergeLayer); re-associated so that the forward pass multiplies activations three times
 // instead of six.  Runs once per parameter version, so nothing here is tuned.
 #include "tg_step.h"
+#include "tg_tile.h"
 
 namespace tg {
 
@@ -83,6 +84,24 @@ __global__ void k_fuse_compact(int d, int de, int nh, const float* __restrict__ 
 
 size_t attn_fused_floats_of(size_t d, size_t nk) { return nk * d + nk + d * (nk + d) + 2 * d; }
 
+// fragment-major copy of K columns [k_src0, k_src0 + K) of W[N][ldw] into k-chunks [kc_off, kc_off + ceil(K / 16)) of a
+// packed weight with KC chunks per column tile (tg_tile.h); zeros where n >= N or k >= K
+__global__ void k_pack_frag(const float* __restrict__ w, int N, int K, int64_t ldw, int k_src0, float* __restrict__ out,
+                            int NT, int KC, int kc_off) {
+  const int kcs = (K + 15) / 16;
+  const int64_t total = (int64_t)NT * kcs * 256;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(e & 3), l = (int)((e >> 2) & 63);
+    const int64_t blk = e >> 8;
+    const int kc = (int)(blk % kcs), nt = (int)(blk / kcs);
+    const int n = nt * 16 + (l & 15), k = kc * 16 + 4 * (l >> 4) + j;
+    out[((int64_t)nt * KC + kc_off + kc) * 256 + l * 4 + j] = (n < N && k < K) ? w[(int64_t)n * ldw + k_src0 + k] : 0.f;
+  }
+}
+__global__ void k_pad_vec(const float* __restrict__ v, int n, float* __restrict__ out, int np) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) out[i] = i < n ? v[i] : 0.f;
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -90,8 +109,11 @@ using namespace tg;
 extern "C" size_t tg_attn_fused_floats(const tg_model* m) {
   if (!attn_dims_ok(m)) return 0;
   const size_t d = m->d, nk = (size_t)m->n_head * (2 * d + (m->efeats ? m->d_e : 0));  // compact without an edge table
-  return attn_fused_floats_of(d, nk);
+  // + the tile form of the same weights and of fc2 (tg_tile.h) where the one-launch attention applies
+  return attn_fused_floats_of(d, nk) + (tile_waves_for_shape(m) ? tile_dims(m).floats : 0);
 }
+
+extern "C" int tg_attn_tile_applies(const tg_model* m) { return (m && attn_dims_ok(m)) ? attn_tile_applies(m) : 0; }
 
 extern "C" size_t tg_attn_fuse_workspace_bytes(const tg_model* m) {
   if (!attn_dims_ok(m)) return 0;
@@ -146,5 +168,29 @@ extern "C" int tg_attn_fuse(const tg_model* m, float* fused, void* ws, size_t ws
                      m->attn_wk, qconst, m->attn_fc1.w, m->attn_fc1.b, c0, gconst, w1f, b1, c1);
   if (compact)
     hipLaunchKernelGGL(k_fuse_compact, dim3(256), dim3(256), 0, st, d, (int)m->d_e, nh, (const float*)full, fused);
+  if (tile_waves_for_shape(m)) {  // the same weights (and fc2) fragment-major for k_attn_tile
+    const TileDims t = tile_dims(m);
+    const float* f_wqk = fused;
+    const float* f_gconst = f_wqk + (size_t)t.nk * d;
+    const float* f_w1f = f_gconst + t.nk;
+    const float* f_b1 = f_w1f + (size_t)d * (t.nk + d);
+    const float* f_c1 = f_b1 + d;
+    float* tile = fused + attn_fused_floats_of(d, t.nk);
+    auto pack = [&](const float* w, int N, int K, int64_t ldw, int k0, float* out, int NT, int KC, int kc_off) {
+      hipLaunchKernelGGL(k_pack_frag, dim3(256), dim3(256), 0, st, w, N, K, ldw, k0, out, NT, KC, kc_off);
+    };
+    auto pad = [&](const float* v, int n, float* out, int np) {
+      hipLaunchKernelGGL(k_pad_vec, dim3(4), dim3(256), 0, st, v, n, out, np);
+    };
+    pack(f_wqk, t.nk, d, d, 0, tile + t.o_wqk, t.NTg, t.KCd, 0);
+    pad(f_gconst, t.nk, tile + t.o_gconst, t.nk_p);
+    pack(f_w1f, d, t.nk, t.nk + d, 0, tile + t.o_w1f, t.NTd, t.KCnk + t.KCd, 0);      // the S part of [S | c]
+    pack(f_w1f, d, d, t.nk + d, t.nk, tile + t.o_w1f, t.NTd, t.KCnk + t.KCd, t.KCnk);  // the c part, from a fresh chunk
+    pad(f_b1, d, tile + t.o_b1, t.d_p);
+    pad(f_c1, d, tile + t.o_c1, t.d_p);
+    pack(m->attn_fc2.w, d, d, d, 0, tile + t.o_w2, t.NTd, t.KCd, 0);
+    pad(m->attn_fc2.b, d, tile + t.o_b2, t.d_p);
+    if ((rc = attn_tile_prepare()) != TG_OK) return rc;
+  }
   return check_launch("tg_attn_fuse");
 }

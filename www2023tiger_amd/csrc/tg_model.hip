@@ -10,6 +10,7 @@
 // Mathematically identical, ~5x fewer flops, and the K*3d key rows are touched once by
 // a gather kernel instead of being materialised for a GEMM.
 #include "tg_step.h"
+#include "tg_tile.h"
 
 namespace tg {
 
@@ -377,6 +378,10 @@ static FusedView fused_view(const tg_model* m, const float* f) {
   return v;
 }
 
+int attn_tile_launch(const tg_model* m, int64_t Q, const float* cc, const float* ts, const int64_t* l1_nids,
+                     const int64_t* l1_eids, const float* l1_ts, const float* reprs, const uint64_t* bm,
+                     const uint32_t* rank, float* out, int direct, const PosArgs* pos, hipStream_t st);
+
 void launch_attn_core(const tg_model* m, int64_t Q, const float* ts, const int64_t* l1_nids, const int64_t* l1_eids,
                       const float* l1_ts, const float* reprs, const uint64_t* bm, const uint32_t* rank, const AttnWs& w,
                       const DropCfg& dc, hipStream_t st, int* rc_out, int direct = 0, const PosArgs* pos = nullptr,
@@ -438,6 +443,16 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
   const FusedView f = fused_view(m, m->attn_fused);
   if (!centres_done) launch_centres(m, Q, nids, reprs, bm, rank, w, pos, da, st);  // else: rode on the sampler's launch
   int rc;
+  if (attn_tile_applies(m)) {  // the whole block in one launch, G and S in LDS only (tg_attn_tile.hip); timed as the core
+    prof_mark(pf, stage++, st);
+    prof_mark(pf, stage++, st);
+    prof_mark(pf, stage++, st);
+    if ((rc = attn_tile_launch(m, Q, w.cc, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, out, da ? 1 : 0,
+                               da ? pos : nullptr, st)) != TG_OK)
+      return rc;
+    for (int i = 0; i < 5; ++i) prof_mark(pf, stage++, st);
+    return check_launch("tg_temporal_attn_fwd(tile)");
+  }
   GemmArgs g{};
   // G = c Wqk^T + gconst   (scaled query folded through the key projection, all heads at once)
   prof_mark(pf, stage++, st);
@@ -1146,7 +1161,10 @@ extern "C" int tg_stream_writeback(const tg_model* m, const tg_writeback_io* io,
   if (io->new_from_pending ? !m->pending_vals : !io->new_row) return TG_EINVAL;
   hipStream_t st = as_stream(stream);
   const int64_t Bg = io->Bg;
-  if (io->upos) {  // planned winners: no dedup work, two launches
+  // planned winners (no dedup work, two launches): the caller hands over the count on the device.  A rank that owns no
+  // winner of the batch passes empty lists, whose pointers may be NULL: nothing to write
+  if (io->n_upos_dev && !io->upos) return TG_OK;
+  if (io->upos) {
     if (!io->index || !io->n_upos_dev || !io->ts32) return TG_EINVAL;
     WritebackArgs wa{};
     wa.B = Bg; wa.src = io->src; wa.dst = io->dst; wa.eids = io->eids; wa.upos = io->upos; wa.index = io->index;

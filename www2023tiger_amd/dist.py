@@ -561,6 +561,8 @@ class HipPartitionEngine:
         """STEP 4-6 for this rank's own winners (planned: the dedup of the global batch was made by `plan`), two launches"""
         m, lib, ptr = self.model, self.lib, self.ptr
         m._touch()
+        if p.mine.numel() == 0:  # this rank owns no winning positive node of the batch: STEP 4-6 have nothing to write
+            return               # (an empty tensor's data pointer is NULL - the library would take the unplanned branch)
         ms = m.model_struct()
         if self._owner32 is None:
             self._owner32 = owner.to(torch.int32).contiguous()
