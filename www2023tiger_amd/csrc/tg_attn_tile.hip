@@ -35,10 +35,15 @@ struct TileArgs {
   const uint32_t* rank;
   int direct;          // eager updates, direct form: neighbour rows are read from pending / right by node id
   const float* tile;   // tile section of the fused blob (tg_tile.h)
+  const float* zeros;  // zero_line()
   float* out;          // [Q, d]
   TileDims t;
   PosArgs pos;
+  int dbg;  // diagnostic (TG_TILE_DBG=1): s_memtime stamps of every wavefront at the phase boundaries, 0 in production
 };
+
+// diagnostic only: [workgroup < 512][wavefront < 16][8] stamps {entry, P0 done, P1 done, P2 own centre done, P2 barrier, P3 done, P4 done}
+__device__ unsigned long long g_tile_trace[512 * 16 * 8];
 
 __device__ __forceinline__ float4 ldg4t(const float* p) { return *reinterpret_cast<const float4*>(p); }
 // float offset of (row, col) inside a swizzled tile
@@ -48,14 +53,16 @@ template <int W>
 struct RV {
   float a[W];
 };
+// The load itself is UNCONDITIONAL and its result is used as it is: lanes past the end of the row read the zero line.
 template <int W>
-__device__ __forceinline__ RV<W> gld(const float* __restrict__ row, int col, int width) {  // zeros past the end
+__device__ __forceinline__ RV<W> gld(const float* __restrict__ row, int col, int width, const float* __restrict__ zl) {
   RV<W> r;
+  const float* p = col < width ? row + col : zl;
   if (W == 4) {
-    const float4 v = col < width ? *reinterpret_cast<const float4*>(row + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v = *reinterpret_cast<const float4*>(p);
     r.a[0] = v.x; r.a[1] = v.y; r.a[2] = v.z; r.a[W - 1] = v.w;
   } else {
-    const float2 v = col < width ? *reinterpret_cast<const float2*>(row + col) : make_float2(0.f, 0.f);
+    const float2 v = *reinterpret_cast<const float2*>(p);
     r.a[0] = v.x; r.a[W - 1] = v.y;
   }
   return r;
@@ -63,12 +70,14 @@ __device__ __forceinline__ RV<W> gld(const float* __restrict__ row, int col, int
 template <int W>
 __device__ __forceinline__ RV<W> lld(const float* S, int row, int ld, int col, bool in) {
   RV<W> r;
-  const float* p = S + swz(row, col, ld);
+  const float* p = S + swz(row, in ? col : 0, ld);
   if (W == 4) {
-    const float4 v = in ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v = *reinterpret_cast<const float4*>(p);
+    if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);
     r.a[0] = v.x; r.a[1] = v.y; r.a[2] = v.z; r.a[W - 1] = v.w;
   } else {
-    const float2 v = in ? *reinterpret_cast<const float2*>(p) : make_float2(0.f, 0.f);
+    float2 v = *reinterpret_cast<const float2*>(p);
+    if (!in) v = make_float2(0.f, 0.f);
     r.a[0] = v.x; r.a[W - 1] = v.y;
   }
   return r;
@@ -82,33 +91,58 @@ __device__ __forceinline__ void lst(float* S, int row, int ld, int col, bool in,
 }
 
 // ---- one run of MFMA steps: G column tiles nt[0..G) over k-chunks [kc0, kc1); a_of(kc) = this lane's A float4 ----
-template <int G, class AFn>
+// The weight blocks of a run are contiguous in memory (chunk-major inside a column tile) and come from L2, ~2.5 k cycles
+// away, while a chunk is 4 G MFMAs of work: the blocks travel PF chunks ahead in a ring of register slots (first version,
+// one chunk ahead: the fc1 phase ran at 45 % of the matrix rate, every chunk waiting for its block).  The loop body has
+// no guards (addresses are clamped to the last chunk instead), so the wait counts stay exact; the < PF chunks that are
+// left over are in the ring already.
+template <int G, int PF, class AFn>
 __device__ __forceinline__ void mm_run(const float* __restrict__ wf, int KC, const int (&nt)[G], int kc0, int kc1, AFn&& a_of,
                                        f32x4t (&acc)[G], int lane) {
   const float* wp[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) wp[g] = wf + (size_t)nt[g] * KC * 256 + lane * 4;
-  float4 b[G];
+  const int last = kc1 - 1;
+  float4 b[PF][G];
+#pragma unroll
+  for (int s = 0; s < PF; ++s) {
+    const int kk = min(kc0 + s, last);
+#pragma unroll
+    for (int g = 0; g < G; ++g) b[s][g] = ldg4t(wp[g] + (size_t)kk * 256);
+  }
   float4 a = a_of(kc0);
+  auto steps = [&](const float4& av, const float4 (&bv)[G]) {
 #pragma unroll
-  for (int g = 0; g < G; ++g) b[g] = ldg4t(wp[g] + (size_t)kc0 * 256);
-  for (int kc = kc0; kc < kc1; ++kc) {
-    const int kn = kc + 1 < kc1 ? kc + 1 : kc;  // the last chunk is requested twice: the loop body stays straight-line
-    float4 bn[G];
+    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv[g].x, acc[g], 0, 0, 0);
 #pragma unroll
-    for (int g = 0; g < G; ++g) bn[g] = ldg4t(wp[g] + (size_t)kn * 256);
-    const float4 an = a_of(kn);
+    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv[g].y, acc[g], 0, 0, 0);
 #pragma unroll
-    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[g].x, acc[g], 0, 0, 0);
+    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv[g].z, acc[g], 0, 0, 0);
 #pragma unroll
-    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[g].y, acc[g], 0, 0, 0);
+    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv[g].w, acc[g], 0, 0, 0);
+  };
+  int kc = kc0;
+  for (; kc + PF <= kc1; kc += PF) {
 #pragma unroll
-    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[g].z, acc[g], 0, 0, 0);
+    for (int s = 0; s < PF; ++s) {
+      const float4 an = a_of(min(kc + s + 1, last));
+      float4 cur[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[g].w, acc[g], 0, 0, 0);
-    a = an;
+      for (int g = 0; g < G; ++g) cur[g] = b[s][g];
+      const int kk = min(kc + s + PF, last);
 #pragma unroll
-    for (int g = 0; g < G; ++g) b[g] = bn[g];
+      for (int g = 0; g < G; ++g) b[s][g] = ldg4t(wp[g] + (size_t)kk * 256);
+      steps(a, cur);
+      a = an;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < PF - 1; ++s) {
+    if (kc + s < kc1) {
+      const float4 an = a_of(min(kc + s + 1, last));
+      steps(a, b[s]);
+      a = an;
+    }
   }
 }
 
@@ -122,7 +156,7 @@ __device__ __forceinline__ void mm_whole(const float* __restrict__ wf, int KC, i
     nt[g] = wave + NWV * (first + g);
     acc[g] = f32x4t{0.f, 0.f, 0.f, 0.f};
   }
-  mm_run<G>(wf, KC, nt, 0, KC, a_of, acc, lane);
+  mm_run<G, (G == 4 ? 3 : (G == 2 ? 4 : 8))>(wf, KC, nt, 0, KC, a_of, acc, lane);
 #pragma unroll
   for (int g = 0; g < G; ++g) epi(nt[g], acc[g]);
 }
@@ -150,7 +184,7 @@ __device__ __forceinline__ void mm_phase(const float* __restrict__ wf, int NT, i
       const int r = u / KC, kc0 = u - r * KC, kc1 = min(KC, kc0 + (u1 - u));
       const int nt[1] = {NTw + r};
       f32x4t acc[1] = {f32x4t{0.f, 0.f, 0.f, 0.f}};
-      mm_run<1>(wf, KC, nt, kc0, kc1, a_of, acc, lane);
+      mm_run<1, 8>(wf, KC, nt, kc0, kc1, a_of, acc, lane);
       float* p = red + (wave * 2 + slot) * 256 + lane;
       p[0] = acc[0][0]; p[64] = acc[0][1]; p[128] = acc[0][2]; p[192] = acc[0][3];
       ++slot;
@@ -182,15 +216,15 @@ __device__ __forceinline__ bool core_centre(const tg_model& m, const TileArgs& a
   const bool in_d = c < d, in_e = c < de;
   const unsigned long long live = __ballot(nb_l != 0);  // padding keys are masked (temporal_agg_modules.py:80)
   const bool any = live != 0ull;
-  V g[NH][3], acc[NH][3];
+  // The folded query g stays in LDS and is re-read for every key (6 conflict-free reads of this wavefront's own row):
+  // held in registers as in k_attn_core it pushed the kernel over the 168 VGPRs of three wavefronts per SIMD, and the
+  // spill reloads inside the key loop (scratch loads are counted with the row gathers) serialised the gathers.
+  V acc[NH][3];
   float mx[NH], l[NH];
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
     mx[h] = -INFINITY;
     l[h] = 0.f;
-    g[h][0] = lld<W>(GS, row, ld, h * kvw + c, in_d);
-    g[h][1] = lld<W>(GS, row, ld, h * kvw + d + c, in_e);
-    g[h][2] = lld<W>(GS, row, ld, h * kvw + d + de + c, in_d);
 #pragma unroll
     for (int j = 0; j < W; ++j) acc[h][0].a[j] = acc[h][1].a[j] = acc[h][2].a[j] = 0.f;
   }
@@ -201,9 +235,10 @@ __device__ __forceinline__ bool core_centre(const tg_model& m, const TileArgs& a
     const int64_t nb = __shfl(nb_l, k, TG_WAVE);
     const int64_t eid = __shfl(eid_l, k, TG_WAVE);
     const float* nrow = a.direct ? ((u & 1) ? m.pending_vals : m.right_vals) + (u >> 1) * d : a.reprs + u * d;
-    ya[slot] = gld<W>(nrow, c, d);
-    yn[slot] = gld<W>(m.nfeats ? m.nfeats + nb * d : nrow, c, m.nfeats ? d : 0);
-    yb[slot] = gld<W>(m.efeats ? m.efeats + eid * de : nrow, c, m.efeats ? de : 0);
+    const int wd = (a.dbg & 4) ? 0 : d, we = (a.dbg & 4) ? 0 : de;  // diagnostic: bit 4 = no gathers (every lane reads the zero line)
+    ya[slot] = gld<W>(nrow, c, wd, a.zeros);
+    yn[slot] = gld<W>(m.nfeats ? m.nfeats + nb * d : nrow, c, m.nfeats ? wd : 0, a.zeros);
+    yb[slot] = gld<W>(m.efeats ? m.efeats + eid * de : nrow, c, m.efeats ? we : 0, a.zeros);
   };
   auto reduce = [&](int slot, int k) {
     const float dt = __shfl(dt_l, k, TG_WAVE);
@@ -216,11 +251,15 @@ __device__ __forceinline__ bool core_centre(const tg_model& m, const TileArgs& a
     }
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
+      V g[3];
+      g[0] = lld<W>(GS, row, ld, h * kvw + c, in_d);
+      g[1] = lld<W>(GS, row, ld, h * kvw + d + c, in_e);
+      g[2] = lld<W>(GS, row, ld, h * kvw + d + de + c, in_d);
       float p = 0.f;
 #pragma unroll
       for (int sgm = 0; sgm < 3; ++sgm)
 #pragma unroll
-        for (int j = 0; j < W; ++j) p = fmaf(g[h][sgm].a[j], x[sgm].a[j], p);
+        for (int j = 0; j < W; ++j) p = fmaf(g[sgm].a[j], x[sgm].a[j], p);
       p = wave_sum(p);  // wave-uniform
       float b = 1.f;
       if (p > mx[h]) {  // new running maximum: rescale what has been accumulated (uniform branch)
@@ -241,29 +280,20 @@ __device__ __forceinline__ bool core_centre(const tg_model& m, const TileArgs& a
         for (int j = 0; j < W; ++j) acc[h][sgm].a[j] = fmaf(b, x[sgm].a[j], acc[h][sgm].a[j]);
     }
   };
-  unsigned long long todo = live;  // fetch cursor over the live keys, in list order
-  auto next_key = [&]() {
-    const int k = todo ? (__ffsll(todo) - 1) : -1;
-    todo &= todo - 1;
-    return k;
-  };
-  int ks[PD];
+  // Keys are walked in list order, padding included, PD at a time; key k travels in ring slot k % PD.  Every fetch is
+  // unconditional (a padding key reads node / edge row 0, which exists and is never used) and only the arithmetic is
+  // skipped for padding keys: a branch that holds vector-memory instructions makes the compiler's wait-count pass give
+  // up at the join and wait for EVERYTHING in flight before the next key - the ring then hides nothing (the cursor
+  // form of k_attn_core, with its guarded fetches, spends one full memory latency per key).
+  const int K = m.n_neighbors;
 #pragma unroll
-  for (int sl = 0; sl < PD; ++sl) {
-    ks[sl] = next_key();
-    if (ks[sl] >= 0) fetch(sl, ks[sl]);
-  }
-  while (ks[0] >= 0) {
-    bool more = true;
+  for (int sl = 0; sl < PD; ++sl) fetch(sl, min(sl, K - 1));
+  for (int k0 = 0; k0 < K; k0 += PD) {
 #pragma unroll
     for (int sl = 0; sl < PD; ++sl) {
-      if (more && ks[sl] >= 0) {
-        reduce(sl, ks[sl]);
-        ks[sl] = next_key();
-        if (ks[sl] >= 0) fetch(sl, ks[sl]);
-      } else {
-        more = false;
-      }
+      const int k = k0 + sl;
+      if (k < K && ((live >> k) & 1ull) && !(a.dbg & 2)) reduce(sl, k);  // diagnostic: bit 2 = no arithmetic
+      fetch(sl, min(k + PD, K - 1));
     }
   }
 #pragma unroll
@@ -296,10 +326,7 @@ __global__ void __launch_bounds__(64 * NWV) k_attn_tile(tg_model m, TileArgs a) 
   float* RED = TT + TILE_M * t.c_ld;
   int* valid_s = reinterpret_cast<int*>(RED + NWV * 2 * 256);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // what rode on the core launch: second dedup pass of the step, stream offset of a lean embed-only step
-  if (a.pos.best)
-    pos_winners_pass(a.pos, (int64_t)blockIdx.x * blockDim.x + tid, (int64_t)gridDim.x * blockDim.x);
-  if (a.pos.advance_off && blockIdx.x == 0 && tid == 0) *a.pos.advance_off += a.pos.B;
+  if (a.pos.advance_off && blockIdx.x == 0 && tid == 0) *a.pos.advance_off += a.pos.B;  // lean embed-only step
   const int d = t.d, K = m.n_neighbors;
   const float* wqk = a.tile + t.o_wqk;
   const float* gconst = a.tile + t.o_gconst;
@@ -309,8 +336,11 @@ __global__ void __launch_bounds__(64 * NWV) k_attn_tile(tg_model m, TileArgs a) 
   const float* w2 = a.tile + t.o_w2;
   const float* b2 = a.tile + t.o_b2;
   const int fr = lane & 15, fk = lane >> 4;  // MFMA fragment coordinates: A row / B column, k group
-  RV<W> w4 = gld<W>(m.te_freq, lane * W, d), p4 = gld<W>(m.te_phase, lane * W, d);
+  RV<W> w4 = gld<W>(m.te_freq, lane * W, d, a.zeros), p4 = gld<W>(m.te_phase, lane * W, d, a.zeros);
   const int64_t ntiles = (a.Q + MC - 1) / MC;
+  const bool trace = a.dbg && blockIdx.x < 512 && lane == 0;
+  unsigned long long* tr = g_tile_trace + ((size_t)blockIdx.x * 16 + wave) * 8;
+  if (trace) tr[0] = __builtin_amdgcn_s_memtime();
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t i0 = tile * MC;
     // ---- per-key metadata of this wavefront's centres, one key per lane: requested now, needed in P2
@@ -325,9 +355,6 @@ __global__ void __launch_bounds__(64 * NWV) k_attn_tile(tg_model m, TileArgs a) 
         nb_l[s] = a.l1_nids[i * K + lane];
         eid_l[s] = a.l1_eids[i * K + lane];
         dt_l[s] = a.ts[i] - a.l1_ts[i * K + lane];
-        if (nb_l[s] != 0)
-          u_l[s] = a.direct ? (int)(2 * nb_l[s] + (bm_test(m.has_msg, nb_l[s]) ? 1 : 0)) : (int)bm_rank(a.bm, a.rank, nb_l[s]);
-        if (a.direct && a.pos.chk_err && (u_l[s] & 1)) check_msg_times(m, nb_l[s], a.pos.chk_err);
       }
     }
     // ---- P0: centre rows -> LDS (zeros past d and past Q)
@@ -341,6 +368,16 @@ __global__ void __launch_bounds__(64 * NWV) k_attn_tile(tg_model m, TileArgs a) 
       }
     }
     __syncthreads();
+    // the loads that depend on the neighbour ids (has-message bit or rank; the time invariants of a lean step) are
+    // requested here: they are in flight while P1 runs
+#pragma unroll
+    for (int s = 0; s < CPW; ++s) {
+      if (nb_l[s] != 0) {
+        u_l[s] = a.direct ? (int)(2 * nb_l[s] + (bm_test(m.has_msg, nb_l[s]) ? 1 : 0)) : (int)bm_rank(a.bm, a.rank, nb_l[s]);
+        if (a.direct && a.pos.chk_err && (u_l[s] & 1)) check_msg_times(m, nb_l[s], a.pos.chk_err);
+      }
+    }
+    if (trace) tr[1] = __builtin_amdgcn_s_memtime();
     // ---- P1: G = c Wqk^T + gconst
     mm_phase<NWV>(
         wqk, t.NTg, t.KCd,
@@ -352,6 +389,7 @@ __global__ void __launch_bounds__(64 * NWV) k_attn_tile(tg_model m, TileArgs a) 
           for (int j = 0; j < 4; ++j) GS[swz(4 * fk + j, col, t.gs_ld)] = acc[j] + gc;
         },
         RED, wave, lane);
+    if (trace) tr[2] = __builtin_amdgcn_s_memtime();
     // ---- P2: gather + scores + softmax + weighted raw-row sum, S over G
 #pragma unroll
     for (int s = 0; s < CPW; ++s) {
@@ -362,7 +400,9 @@ __global__ void __launch_bounds__(64 * NWV) k_attn_tile(tg_model m, TileArgs a) 
       if (lane == 0) valid_s[row] = any ? 1 : 0;
     }
     if (MC < TILE_M && tid >= MC && tid < TILE_M) valid_s[tid] = 0;  // padding rows
+    if (trace) tr[3] = __builtin_amdgcn_s_memtime();
     __syncthreads();
+    if (trace) tr[4] = __builtin_amdgcn_s_memtime();
     // ---- P3: t = relu([S | c] W1f^T + b1 + valid c1)
     mm_phase<NWV>(
         w1f, t.NTd, t.KCnk + t.KCd,
@@ -382,6 +422,7 @@ __global__ void __launch_bounds__(64 * NWV) k_attn_tile(tg_model m, TileArgs a) 
           }
         },
         RED, wave, lane);
+    if (trace) tr[5] = __builtin_amdgcn_s_memtime();
     // ---- P4: h = t W2^T + b2 -> global
     mm_phase<NWV>(
         w2, t.NTd, t.KCd,
@@ -398,7 +439,12 @@ __global__ void __launch_bounds__(64 * NWV) k_attn_tile(tg_model m, TileArgs a) 
           }
         },
         RED, wave, lane);
+    if (trace) tr[6] = __builtin_amdgcn_s_memtime();
   }
+  // what rode on the core launch: the second dedup pass of the step (a chain of four dependent memory round trips for
+  // the few thousand positions of a batch).  Last of all and by one wavefront per workgroup only: nothing waits for it.
+  if (a.pos.best && wave == NWV - 1)
+    pos_winners_pass(a.pos, (int64_t)blockIdx.x * 64 + lane, (int64_t)gridDim.x * 64);
 }
 
 // dynamic LDS beyond the default limit has to be requested once per kernel
@@ -437,7 +483,11 @@ int attn_tile_prepare() {
 
 // 1 when attn_tile_launch would run for this model (the dimensions fit one workgroup's LDS and the knob is on)
 int attn_tile_applies(const tg_model* m) {
-  static const int knob = getenv("TG_ATTN_TILE") ? atoi(getenv("TG_ATTN_TILE")) : 1;
+  // OFF by default: measured on MI355X the one-launch form is slower than the four launches it replaces (C2: 97 us
+  // against 76; C5 shape 3.98 ms against 2.97) - a 16-centre tile needs 32 B/clk of weights per CU at full matrix rate
+  // and a CU pulls 13-16 B/clk of L2-resident lines here, while the 64-row tiles of the separate products need a quarter
+  // of that and their G / S round trip costs less than it saves (profiles/r03_attn_tile_phase_trace.txt)
+  static const int knob = getenv("TG_ATTN_TILE") ? atoi(getenv("TG_ATTN_TILE")) : 0;
   return (knob != 0 && tile_waves(m) != 0) ? 1 : 0;
 }
 
@@ -451,6 +501,10 @@ int attn_tile_launch(const tg_model* m, int64_t Q, const float* cc, const float*
   a.t = tile_dims(m);
   a.tile = m->attn_fused + attn_fused_floats_of((size_t)a.t.d, (size_t)a.t.nk);
   a.pos = pos ? *pos : PosArgs{};
+  a.zeros = zero_line();
+  if (!a.zeros) return TG_EHIP;
+  static const int dbg_knob = getenv("TG_TILE_DBG") ? atoi(getenv("TG_TILE_DBG")) : 0;
+  a.dbg = dbg_knob;
   // tiles of 12 centres (12 wavefronts) while they need no more rounds of 256 workgroups than tiles of 16 would: the
   // matrix work of a workgroup is that of a 16-row tile either way, so below that point more CUs share the centres
   static const int mc_knob = getenv("TG_ATTN_TILE_MC") ? atoi(getenv("TG_ATTN_TILE_MC")) : 0;
@@ -467,3 +521,7 @@ int attn_tile_launch(const tg_model* m, int64_t Q, const float* cc, const float*
 }
 
 }  // namespace tg
+
+extern "C" int tg_debug_tile_trace(unsigned long long* out_host, int n_blocks) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(tg::g_tile_trace), sizeof(unsigned long long) * 16 * 8 * n_blocks) == hipSuccess ? 0 : -4;
+}

@@ -34,6 +34,14 @@ inline unsigned flat_grid(int64_t work_items, int block) {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (TG_WAVE - 1); }
 
+// Sixteen bytes of zeros in device memory (zero_line(): its address, a plain global pointer handed to kernels as an
+// argument).  Where lanes past the end of a row must read zeros they LOAD them from there - the load stays unconditional
+// and its result needs no select.  (A load inside a divergent branch, or a select on a loaded value that the scheduler
+// places right behind the load, makes the compiler wait for every load in flight: a ring of gathers then hides nothing.
+// Taking the symbol's address in device code instead turns the selected pointer into a flat one: flat loads, which count
+// on both counters and are waited for one by one.)
+const float* zero_line();
+
 // Wave-wide sum, result broadcast to every lane.  DPP row shifts / row broadcasts (GFX9
 // encodings, valid on gfx950) instead of six ds_bpermute round trips through the LDS unit.
 template <int CTRL, int ROW_MASK>

@@ -18,6 +18,18 @@ void set_hip_error(hipError_t e, const char* what) {
 
 }  // namespace tg
 
+namespace tg {
+__device__ float4 g_zero16_store = {0.f, 0.f, 0.f, 0.f};
+const float* zero_line() {
+  static const float* p = nullptr;
+  if (!p) {
+    void* a = nullptr;
+    if (hipGetSymbolAddress(&a, HIP_SYMBOL(g_zero16_store)) == hipSuccess) p = (const float*)a;
+  }
+  return p;
+}
+}  // namespace tg
+
 extern "C" int tg_abi_version(void) { return TG_ABI_VERSION; }
 extern "C" const char* tg_last_hip_error(void) { return tg::g_hip_error.c_str(); }
 

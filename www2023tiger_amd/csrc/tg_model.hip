@@ -104,13 +104,17 @@ struct __attribute__((packed, aligned(4))) F3 {
 };
 // columns [col, col+W) of a row of `width` floats (row 16-byte aligned, width % 4 == 0); zeros past the end
 template <int W>
-__device__ __forceinline__ RowVec<W> row_load(const float* __restrict__ row, int col, int width) {
+__device__ __forceinline__ RowVec<W> row_load(const float* __restrict__ row, int col, int width, const float* __restrict__ zl) {
   RowVec<W> r;
+  // W = 4, 2: the load is UNCONDITIONAL and its result is used as it is - lanes past the end of the row read the zero line zl.
+  // (A load inside a divergent branch makes the compiler's wait-count pass wait for every load in flight at the join,
+  // and so does a select on the loaded value scheduled right behind the load: either way the gathers of the key ring
+  // were serialised, one full memory latency per key.)
   if (W == 4) {
-    const float4 v = col < width ? *reinterpret_cast<const float4*>(row + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v = *reinterpret_cast<const float4*>(col < width ? row + col : zl);
     r.a[0] = v.x; r.a[1] = v.y; r.a[2] = v.z; r.a[W - 1] = v.w;
   } else if (W == 2) {  // rows are 16-byte aligned and widths multiples of 4: an 8-byte access never straddles the row end
-    const float2 v = col < width ? *reinterpret_cast<const float2*>(row + col) : make_float2(0.f, 0.f);
+    const float2 v = *reinterpret_cast<const float2*>(col < width ? row + col : zl);
     r.a[0] = v.x; r.a[W - 1] = v.y;
   } else if (W == 3) {
     if (col + 3 <= width) {
@@ -151,7 +155,7 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
                                                    const uint32_t* __restrict__ rank, const float* __restrict__ G,
                                                    float* __restrict__ S, uint8_t* __restrict__ valid, DropCfg dc,
                                                    float* __restrict__ rsum, int direct, PosArgs pos,
-                                                   const float* __restrict__ key_rows) {
+                                                   const float* __restrict__ key_rows, const float* __restrict__ zl) {
   using V = RowVec<W>;
   const int lane = lane_id();
   // direct (eager updates): neighbour rows come from the state tables, row(v) = has_msg[v] ? pending[v] : right[v];
@@ -165,8 +169,8 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const int c = (lane + v * TG_WAVE) * W;
-    w4[v] = row_load<W>(m.te_freq, c, d);
-    p4[v] = row_load<W>(m.te_phase, c, d);
+    w4[v] = row_load<W>(m.te_freq, c, d, zl);
+    p4[v] = row_load<W>(m.te_phase, c, d, zl);
   }
   for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < Q; i += (int64_t)gridDim.x * 4) {
     // ---- per-key metadata, one key per lane
@@ -193,9 +197,9 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const int c = (lane + v * TG_WAVE) * W;
-        g[h][0][v] = row_load<W>(gh, c, d);
-        g[h][1][v] = row_load<W>(gh + d, c, de);
-        g[h][2][v] = row_load<W>(gh + d + de, c, d);
+        g[h][0][v] = row_load<W>(gh, c, d, zl);
+        g[h][1][v] = row_load<W>(gh + d, c, de, zl);
+        g[h][2][v] = row_load<W>(gh + d + de, c, d, zl);
 #pragma unroll
         for (int j = 0; j < W; ++j) acc[h][0][v].a[j] = acc[h][1][v].a[j] = acc[h][2][v].a[j] = 0.f;
       }
@@ -220,9 +224,9 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const int c = (lane + v * TG_WAVE) * W;
-        ya[slot][v] = row_load<W>(nrow, c, d);
-        yn[slot][v] = row_load<W>(feat ? m.nfeats + nb * d : nrow, c, feat ? d : 0);
-        yb[slot][v] = row_load<W>(m.efeats ? m.efeats + eid * de : reprs, c, m.efeats ? de : 0);
+        ya[slot][v] = row_load<W>(nrow, c, d, zl);
+        yn[slot][v] = row_load<W>(feat ? m.nfeats + nb * d : nrow, c, feat ? d : 0, zl);
+        yb[slot][v] = row_load<W>(m.efeats ? m.efeats + eid * de : reprs, c, m.efeats ? de : 0, zl);
       }
     };
     auto reduce = [&](int slot, int k) {
@@ -276,29 +280,19 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
             for (int j = 0; j < W; ++j) acc[h][sgm][v].a[j] = fmaf(b, x[sgm][v].a[j], acc[h][sgm][v].a[j]);
       }
     };
-    unsigned long long todo = live;  // fetch cursor over the live keys, in list order
-    auto next_key = [&]() {
-      const int k = todo ? (__ffsll(todo) - 1) : -1;
-      todo &= todo - 1;
-      return k;
-    };
-    int ks[PD];
+    // Keys are walked in list order, padding included, PD at a time; key k travels in ring slot k % PD.  Every fetch is
+    // unconditional (a padding key reads node / edge row 0, which exists and is never used) and only the arithmetic is
+    // skipped for padding keys: a branch that holds vector-memory instructions makes the compiler's wait-count pass
+    // wait for EVERYTHING in flight at the join (the cursor form this replaces, with guarded fetches, spent one full
+    // memory latency per key whatever PD was).  Keys are reduced in list order, so the result does not depend on PD.
 #pragma unroll
-    for (int sl = 0; sl < PD; ++sl) {
-      ks[sl] = next_key();
-      if (ks[sl] >= 0) fetch(sl, ks[sl]);
-    }
-    while (ks[0] >= 0) {
-      bool more = true;
+    for (int sl = 0; sl < PD; ++sl) fetch(sl, min(sl, K - 1));
+    for (int k0 = 0; k0 < K; k0 += PD) {
 #pragma unroll
       for (int sl = 0; sl < PD; ++sl) {
-        if (more && ks[sl] >= 0) {
-          reduce(sl, ks[sl]);
-          ks[sl] = next_key();  // the slot is free: the key PD places further on starts travelling
-          if (ks[sl] >= 0) fetch(sl, ks[sl]);
-        } else {
-          more = false;  // the cursor ran dry before this slot was refilled: nothing is left anywhere
-        }
+        const int k = k0 + sl;
+        if (k < K && ((live >> k) & 1ull)) reduce(sl, k);
+        fetch(sl, min(k + PD, K - 1));
       }
     }
 #pragma unroll
@@ -402,10 +396,12 @@ void launch_attn_core(const tg_model* m, int64_t Q, const float* ts, const int64
     if (wmax <= 128 && w_knob != 4 && w_knob != 3) { W = 2; nv = 1; }
   }
   const unsigned cgrid = flat_grid(Q, 4);
+  const float* zl = zero_line();
+  if (!zl) { *rc_out = TG_EHIP; return; }
 #define TG_CORE(NH_, NV_, W_)                                                                                      \
   hipLaunchKernelGGL((k_attn_core<NH_, NV_, W_>), dim3(cgrid), dim3(256), 0, st, *m, Q, ts, l1_nids, l1_eids,      \
                      l1_ts, reprs, bm, rank, (const float*)w.g, w.s, w.valid, dc,                                  \
-                     dc.p > 0.f ? w.rsum : (float*)nullptr, direct, pos ? *pos : PosArgs{}, key_rows)
+                     dc.p > 0.f ? w.rsum : (float*)nullptr, direct, pos ? *pos : PosArgs{}, key_rows, zl)
   if (nh == 2 && nv == 1 && W == 2) TG_CORE(2, 1, 2);
   else if (nh == 1 && nv == 1 && W == 2) TG_CORE(1, 1, 2);
   else if (nh == 4 && nv == 1 && W == 2) TG_CORE(4, 1, 2);
