@@ -136,8 +136,10 @@ __device__ __forceinline__ float time_enc(float dt, float w, float phi) {
 // The attention core evaluates K*d of these per centre and is VALU-bound on them: there the cosine of the SAME float32
 // argument comes from the hardware unit (v_cos_f32, input in revolutions) behind a three-term Cody-Waite reduction
 // modulo 2*pi - 3.5e-7 max abs error against float64 cos on |x| <= 3e6 (tools/micro/vcos_err.hip; the polynomial
-// path: 9.2e-8), about ten issue slots instead of twenty-five.  Everything that is compared element-wise with the
-// reference's encoding (tg_time_encode, the raw messages of STEP 5, training) keeps the polynomial path.
+// path: 9.2e-8), about ten issue slots instead of twenty-five.  k_attn_core is the forward of every path (streaming,
+// the operator path, evaluation and the training step), so all of them encode the KEYS with the hardware cosine; what is
+// compared element-wise with the reference's encoding (tg_time_encode, the raw messages of STEP 5) and the backward
+// pass's sin / cos keep the polynomial path.  The 3.5e-7 sit two orders below the 1e-4 parity bar.
 __device__ __forceinline__ float cos_hw(float x) {
   const float n = rintf(__fmul_rn(x, 0.15915494309189535f));
   float r = fmaf(-n, 6.2831854820251465f, x);

@@ -147,6 +147,38 @@ __device__ __forceinline__ void row_store(float* __restrict__ row, int col, int 
   }
 }
 
+// broadcast of lane k's pointer / float to the whole wavefront through SGPRs (k is wave-uniform): v_readlane instead of a
+// ds_bpermute round trip, and the row address becomes scalar base + per-lane column offset (no 64-bit vector arithmetic)
+__device__ __forceinline__ const float* bcast_ptr(const float* p, int k) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, k);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), k);
+  return reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ float bcast_f(float x, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), k)); }
+// W consecutive floats at p, no bounds: the caller clamps the column offset of lanes past the end of the row
+template <int W>
+__device__ __forceinline__ RowVec<W> row_load_raw(const float* __restrict__ p) {
+  RowVec<W> r;
+  if (W == 4) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    r.a[0] = v.x; r.a[1] = v.y; r.a[2] = v.z; r.a[W - 1] = v.w;
+  } else {
+    const float2 v = *reinterpret_cast<const float2*>(p);
+    r.a[0] = v.x; r.a[W - 1] = v.y;
+  }
+  return r;
+}
+
+// The kernel is bound by instruction issue, not by its gathers (ablated in the one-launch form, profiles/
+// r03_attn_tile_phase_trace.txt: without the gathers its time does not change), so the per-key path is kept short:
+//  * lane k resolves key k's three row addresses ONCE; per key they are broadcast through SGPRs (bcast_ptr) and every lane
+//    adds its constant column offset - lanes past the end of a row read its first columns, which meet g = 0;
+//  * node features are added as fma(fmask, yn, ya) with fmask = 0 when there is no table (yn then re-reads the node row),
+//    edge features are emask * yb likewise;
+//  * the range test of the time encoding (|x| <= 3e6: hardware cosine) is made once per key on a wave-uniform bound
+//    instead of per element;
+//  * the softmax exponentials are v_exp_f32 (arguments <= 0; ~2 ulp).
 template <int NH, int NV, int W>
 __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const float* __restrict__ ts,
                                                    const int64_t* __restrict__ l1_nids,
@@ -166,14 +198,31 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
   const int d = m.d, de = m.d_e, K = m.n_neighbors;
   const int kvw = 2 * d + de;
   V w4[NV], p4[NV];
+  int coff[NV], eoff[NV];  // column offsets of this lane in a node-width / edge-width row (0 past the end)
+  float wmax = 0.f, pmax = 0.f;
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const int c = (lane + v * TG_WAVE) * W;
+    coff[v] = c < d ? c : 0;
+    eoff[v] = c < de ? c : 0;
     w4[v] = row_load<W>(m.te_freq, c, d, zl);
     p4[v] = row_load<W>(m.te_phase, c, d, zl);
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      wmax = fmaxf(wmax, fabsf(w4[v].a[j]));
+      pmax = fmaxf(pmax, fabsf(p4[v].a[j]));
+    }
   }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    wmax = fmaxf(wmax, __shfl_xor(wmax, o, TG_WAVE));
+    pmax = fmaxf(pmax, __shfl_xor(pmax, o, TG_WAVE));
+  }
+  const bool feat = m.nfeats && !key_rows;
+  const float fmask = feat ? 1.f : 0.f;
+  const float emask = m.efeats ? 1.f : 0.f;  // no edge table: the edge segment of a key row is zeros (feature_getter.py:95-99)
   for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < Q; i += (int64_t)gridDim.x * 4) {
-    // ---- per-key metadata, one key per lane
+    // ---- per-key metadata and row addresses, one key per lane
     int64_t nb_l = 0, eid_l = 0;
     float dt_l = 0.f;
     int u_l = 0;
@@ -184,6 +233,15 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
       if (nb_l != 0) u_l = direct ? (int)(2 * nb_l + (bm_test(m.has_msg, nb_l) ? 1 : 0)) : (int)bm_rank(bm, rank, nb_l);
       if (direct && pos.chk_err && (u_l & 1)) check_msg_times(m, nb_l, pos.chk_err);
     }
+    // key_rows (second attention layer of --n_layers 2): the node part of key k of centre i is row i*K + k of a dense
+    // tensor - the neighbour's own embedding (temporal_agg_modules.py:57-66) - instead of its memory row + features.
+    // A padding key (id 0) addresses row 0 of every table, which exists; its rows are fetched and never used.
+    const int kk = lane < K ? lane : 0;
+    const float* pn_l = key_rows ? key_rows + (i * K + kk) * d
+                                 : (direct ? ((u_l & 1) ? m.pending_vals : m.right_vals) + (int64_t)(u_l >> 1) * d
+                                           : reprs + (int64_t)u_l * d);
+    const float* pf_l = feat ? m.nfeats + nb_l * d : pn_l;
+    const float* pe_l = m.efeats ? m.efeats + eid_l * de : pn_l;
     unsigned long long live = __ballot(nb_l != 0);  // padding keys are masked (temporal_agg_modules.py:80)
     const bool any = live != 0ull;
     V g[NH][3][NV], acc[NH][3][NV];
@@ -197,49 +255,49 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const int c = (lane + v * TG_WAVE) * W;
-        g[h][0][v] = row_load<W>(gh, c, d, zl);
+        g[h][0][v] = row_load<W>(gh, c, d, zl);  // zeros past the end of a segment: those lanes add nothing to a score
         g[h][1][v] = row_load<W>(gh + d, c, de, zl);
         g[h][2][v] = row_load<W>(gh + d + de, c, d, zl);
 #pragma unroll
         for (int j = 0; j < W; ++j) acc[h][0][v].a[j] = acc[h][1][v].a[j] = acc[h][2][v].a[j] = 0.f;
       }
     }
-    // Raw rows of the next keys travel in a ring of PD register slots while the current key is reduced:
-    // a wave's keys are a chain of dependent gathers (row address <- key metadata), and with ~3 waves per
-    // SIMD at C2 nothing else covers their latency.  Keys are reduced in list order whatever PD is, so the
-    // result does not depend on it.
+    // Raw rows of the next keys travel in a ring of PD register slots while the current key is reduced.  Keys are
+    // reduced in list order whatever PD is, so the result does not depend on it.
     // (measured: narrow rows, W = 2, gain from a fourth slot - C4 core 84 -> 78 us - and nothing from a fifth or sixth,
     // eight are slower; W = 4 is the same with three and four)
     constexpr int PD = NV == 1 ? (W == 2 ? 4 : 3) : 2;
     V ya[PD][NV], yn[PD][NV], yb[PD][NV];
     auto fetch = [&](int slot, int k) {
-      const int64_t u = __shfl(u_l, k, TG_WAVE);
-      const int64_t nb = __shfl(nb_l, k, TG_WAVE);
-      const int64_t eid = __shfl(eid_l, k, TG_WAVE);
-      // key_rows (second attention layer of --n_layers 2): the node part of key k of centre i is row i*K + k of a dense
-      // tensor - the neighbour's own embedding (temporal_agg_modules.py:57-66) - instead of its memory row + features
-      const float* nrow = key_rows ? key_rows + (i * K + k) * d
-                                   : (direct ? ((u & 1) ? m.pending_vals : m.right_vals) + (u >> 1) * d : reprs + u * d);
-      const bool feat = m.nfeats && !key_rows;
+      const float* pn = bcast_ptr(pn_l, k);
+      const float* pf = bcast_ptr(pf_l, k);
+      const float* pe = bcast_ptr(pe_l, k);
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
-        const int c = (lane + v * TG_WAVE) * W;
-        ya[slot][v] = row_load<W>(nrow, c, d, zl);
-        yn[slot][v] = row_load<W>(feat ? m.nfeats + nb * d : nrow, c, feat ? d : 0, zl);
-        yb[slot][v] = row_load<W>(m.efeats ? m.efeats + eid * de : reprs, c, m.efeats ? de : 0, zl);
+        ya[slot][v] = row_load_raw<W>(pn + coff[v]);
+        yn[slot][v] = row_load_raw<W>(pf + coff[v]);
+        yb[slot][v] = row_load_raw<W>(pe + eoff[v]);
       }
     };
     auto reduce = [&](int slot, int k) {
-      const float dt = __shfl(dt_l, k, TG_WAVE);
+      const float dt = bcast_f(dt_l, k);
+      // |dt w + phi| <= |dt| wmax + pmax: below the switch-over of time_enc_fast the hardware cosine serves every element
+      const bool small = fmaf(fabsf(dt), wmax, pmax) < 2.9e6f;
       V x[3][NV];
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const int c = (lane + v * TG_WAVE) * W;
 #pragma unroll
         for (int j = 0; j < W; ++j) {
-          x[0][v].a[j] = ya[slot][v].a[j] + yn[slot][v].a[j];
-          x[1][v].a[j] = yb[slot][v].a[j];
-          x[2][v].a[j] = c + j < d ? time_enc_fast(dt, w4[v].a[j], p4[v].a[j]) : 0.f;
+          x[0][v].a[j] = fmaf(fmask, yn[slot][v].a[j], ya[slot][v].a[j]);
+          x[1][v].a[j] = emask * yb[slot][v].a[j];
+        }
+        if (small) {
+#pragma unroll
+          for (int j = 0; j < W; ++j) x[2][v].a[j] = cos_hw(__fadd_rn(__fmul_rn(dt, w4[v].a[j]), p4[v].a[j]));
+        } else {
+#pragma unroll
+          for (int j = 0; j < W; ++j) x[2][v].a[j] = c + j < d ? time_enc_fast(dt, w4[v].a[j], p4[v].a[j]) : 0.f;
         }
       }
 #pragma unroll
@@ -254,7 +312,7 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
         p = wave_sum(p);  // wave-uniform
         float b = 1.f;
         if (p > mx[h]) {  // new running maximum: rescale what has been accumulated (uniform branch)
-          const float a = expf(mx[h] - p);
+          const float a = __expf(mx[h] - p);
           l[h] *= a;
           lk[h] *= a;
 #pragma unroll
@@ -265,7 +323,7 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
               for (int j = 0; j < W; ++j) acc[h][sgm][v].a[j] *= a;
           mx[h] = p;
         } else {
-          b = expf(p - mx[h]);
+          b = __expf(p - mx[h]);
         }
         l[h] += b;
         if (dc.p > 0.f) {  // attention dropout (nn.MultiheadAttention): the softmax normaliser keeps every key
@@ -281,10 +339,8 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
       }
     };
     // Keys are walked in list order, padding included, PD at a time; key k travels in ring slot k % PD.  Every fetch is
-    // unconditional (a padding key reads node / edge row 0, which exists and is never used) and only the arithmetic is
-    // skipped for padding keys: a branch that holds vector-memory instructions makes the compiler's wait-count pass
-    // wait for EVERYTHING in flight at the join (the cursor form this replaces, with guarded fetches, spent one full
-    // memory latency per key whatever PD was).  Keys are reduced in list order, so the result does not depend on PD.
+    // unconditional and only the arithmetic is skipped for padding keys: a branch that holds vector-memory instructions
+    // makes the compiler's wait-count pass wait for EVERYTHING in flight at the join.
 #pragma unroll
     for (int sl = 0; sl < PD; ++sl) fetch(sl, min(sl, K - 1));
     for (int k0 = 0; k0 < K; k0 += PD) {
@@ -382,18 +438,15 @@ void launch_attn_core(const tg_model* m, int64_t Q, const float* ts, const int64
                       const float* key_rows = nullptr) {
   const int d = m->d, d_e = m->d_e, nh = m->n_head;
   *rc_out = TG_OK;
-  // Columns per lane: float4.  Three columns per lane fill 58 of 64 lanes at d = 172 instead of 43 and cut
-  // the VALU work per key by a quarter, but measured SLOWER (29.7 vs 24.3 us at C2): the 12-byte accesses
-  // straddle 16-byte sectors and the gather, not the arithmetic, sets the pace.  Kept as a knob.
+  // Columns per lane: float4 (three columns per lane fill 58 of 64 lanes at d = 172 instead of 43 but measured SLOWER,
+  // 29.7 vs 24.3 us at C2: 12-byte accesses straddle 16-byte sectors; that variant is gone).
   const int wmax = std::max(d, d_e);
   int W = 4, nv = (int)cdiv(cdiv(wmax, 4), TG_WAVE);
   {
-    const int nv3 = (int)cdiv(cdiv(wmax, 3), TG_WAVE);
-    static const int w_knob = getenv("TG_ATTN_W") ? atoi(getenv("TG_ATTN_W")) : 0;  // tuning knob: 3, default 4
-    if (nv3 == 1 && w_knob == 3) { W = 3; nv = 1; }
+    static const int w_knob = getenv("TG_ATTN_W") ? atoi(getenv("TG_ATTN_W")) : 0;  // tuning knob: 4 forces float4 lanes
     // narrow rows (d <= 128, e.g. LastFM's --dim 100): two columns per lane instead of four fill 50 lanes instead of 25;
     // the kernel is bound by per-key VALU work and latency there, not by bytes (8-byte accesses stay sector aligned)
-    if (wmax <= 128 && w_knob != 4 && w_knob != 3) { W = 2; nv = 1; }
+    if (wmax <= 128 && w_knob != 4) { W = 2; nv = 1; }
   }
   const unsigned cgrid = flat_grid(Q, 4);
   const float* zl = zero_line();
@@ -405,9 +458,6 @@ void launch_attn_core(const tg_model* m, int64_t Q, const float* ts, const int64
   if (nh == 2 && nv == 1 && W == 2) TG_CORE(2, 1, 2);
   else if (nh == 1 && nv == 1 && W == 2) TG_CORE(1, 1, 2);
   else if (nh == 4 && nv == 1 && W == 2) TG_CORE(4, 1, 2);
-  else if (nh == 2 && nv == 1 && W == 3) TG_CORE(2, 1, 3);
-  else if (nh == 1 && nv == 1 && W == 3) TG_CORE(1, 1, 3);
-  else if (nh == 4 && nv == 1 && W == 3) TG_CORE(4, 1, 3);
   else if (nh == 2 && nv == 1) TG_CORE(2, 1, 4);
   else if (nh == 2 && nv == 2) TG_CORE(2, 2, 4);
   else if (nh == 1 && nv == 1) TG_CORE(1, 1, 4);
