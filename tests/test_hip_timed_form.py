@@ -138,3 +138,47 @@ def test_c3_graph_replay_with_lazy_restart_triggers_inside_matches_reference_loo
         total += n_r
     assert total > 5000
     compare_state_with_oracle(model, orc)
+
+
+def test_graph_replay_and_eager_launches_are_bit_identical():
+    """The same C2 batches through a captured graph (model A) and through eager launches (model B, same weights): every
+    state tensor and the embeddings must be EQUAL, not close.  The updater's rows arrive in the order of an atomic
+    compaction, which differs from run to run: no result may depend on a row's place in its tile (k-group partial sums
+    are folded in group order, stream-K pieces in worker order)."""
+    import bench
+    c = bench.C2
+    B, K, d = c['B'], c['K'], c['d']
+    n_eager, n_graph = 3, 9
+    E = (n_eager + n_graph + 2) * B
+    stream = bench.make_stream(c['n_u'], c['n_i'], E, c['T'] * E / c['E'], seed=29, d_e=d)
+    res = _resident(stream)
+    models, bufs = [], []
+    for _ in range(2):
+        m, _ = bench.build_models(stream, d, K, c['msg_src'], c['upd_src'])
+        m.fuse_attention()
+        m.eager_updates()
+        b = m.StepBuffers(m, B, False, resident=res)
+        b.io.lean = 1
+        models.append(m)
+        bufs.append(b)
+    for _ in range(n_eager):
+        for m, b in zip(models, bufs):
+            m.launch_step(b)
+    torch.cuda.synchronize()
+    for m, b in zip(models, bufs):
+        cnt = b.counts.tolist()
+        m.note_rows(cnt[1], cnt[2])
+    graph = _capture(models[0], bufs[0])
+    for step in range(n_graph):
+        graph.replay()
+        models[1].launch_step(bufs[1])
+        torch.cuda.synchronize()
+        assert torch.equal(bufs[0].h, bufs[1].h), f'embeddings differ at replay {step}'
+    a, b = models
+    for name, x, y in [('left', a.left_memory.vals, b.left_memory.vals), ('right', a.right_memory.vals, b.right_memory.vals),
+                       ('left ts', a.left_memory.update_ts, b.left_memory.update_ts),
+                       ('right ts', a.right_memory.update_ts, b.right_memory.update_ts),
+                       ('pending', a._pending, b._pending), ('mailbox', a.msg_store.node_msg_vals, b.msg_store.node_msg_vals),
+                       ('mailbox ts', a.msg_store.node_msg_ts, b.msg_store.node_msg_ts),
+                       ('has_msg', a.msg_store.has_msg_bits, b.msg_store.has_msg_bits)]:
+        assert torch.equal(x, y), f'{name} differs between graph replay and eager launches'

@@ -1176,26 +1176,39 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
       }
     }
     __syncthreads();
+    // The partial sums of a row are added in k-group order 0, 1, .., KS - 1 WHICHEVER group owns the row: a row's result
+    // must not depend on its place in the tile (the eager updater's row order comes from an atomic compaction and
+    // differs from run to run; summed owner-first the step was reproducible only to the last bit or two).
     float o_r[OWN], o_z[OWN], o_in[OWN], o_hn[OWN];
 #pragma unroll
-    for (int v = 0; v < KS; ++v) {
-      if (v == ks) {
+    for (int gsrc = 0; gsrc < KS; ++gsrc) {
+      float t_r[OWN], t_z[OWN], t_in[OWN], t_hn[OWN];
+      if (gsrc == ks) {  // wave-uniform
+#pragma unroll
+        for (int v = 0; v < KS; ++v)
+          if (v == ks) {
+#pragma unroll
+            for (int q = 0; q < OWN; ++q) {
+              t_r[q] = acc_r[v * OWN + q]; t_z[q] = acc_z[v * OWN + q];
+              t_in[q] = acc_in[v * OWN + q]; t_hn[q] = acc_hn[v * OWN + q];
+            }
+          }
+      } else {
+        const int sl = (gsrc - ks - 1 + KS) % KS;
 #pragma unroll
         for (int q = 0; q < OWN; ++q) {
-          o_r[q] = acc_r[v * OWN + q]; o_z[q] = acc_z[v * OWN + q];
-          o_in[q] = acc_in[v * OWN + q]; o_hn[q] = acc_hn[v * OWN + q];
+          t_r[q] = sc[rw][ks][sl][0][q][lane]; t_z[q] = sc[rw][ks][sl][1][q][lane];
+          t_in[q] = sc[rw][ks][sl][2][q][lane]; t_hn[q] = sc[rw][ks][sl][3][q][lane];
         }
       }
-    }
-#pragma unroll
-    for (int sl = 0; sl < KS - 1; ++sl)
 #pragma unroll
       for (int q = 0; q < OWN; ++q) {
-        o_r[q] += sc[rw][ks][sl][0][q][lane];
-        o_z[q] += sc[rw][ks][sl][1][q][lane];
-        o_in[q] += sc[rw][ks][sl][2][q][lane];
-        o_hn[q] += sc[rw][ks][sl][3][q][lane];
+        o_r[q] = gsrc == 0 ? t_r[q] : o_r[q] + t_r[q];
+        o_z[q] = gsrc == 0 ? t_z[q] : o_z[q] + t_z[q];
+        o_in[q] = gsrc == 0 ? t_in[q] : o_in[q] + t_in[q];
+        o_hn[q] = gsrc == 0 ? t_hn[q] : o_hn[q] + t_hn[q];
       }
+    }
 #pragma unroll
     for (int q = 0; q < OWN; ++q) finish(ks * OWN + q, o_r[q], o_z[q], o_in[q], o_hn[q]);
   } else {
@@ -1407,26 +1420,37 @@ __global__ void __launch_bounds__(256) k_gru_direct(GruArgs g) {
     }
   }
   __syncthreads();
+  // in wavefront order 0..3 whichever wavefront owns the row (see k_gru: the result must not depend on the row's place)
   float o_r[OWN], o_z[OWN], o_in[OWN], o_hn[OWN];
 #pragma unroll
-  for (int v = 0; v < KS; ++v) {
-    if (v == ks) {
+  for (int gsrc = 0; gsrc < KS; ++gsrc) {
+    float t_r[OWN], t_z[OWN], t_in[OWN], t_hn[OWN];
+    if (gsrc == ks) {  // wave-uniform
+#pragma unroll
+      for (int v = 0; v < KS; ++v)
+        if (v == ks) {
+#pragma unroll
+          for (int q = 0; q < OWN; ++q) {
+            t_r[q] = acc_r[v * OWN + q]; t_z[q] = acc_z[v * OWN + q];
+            t_in[q] = acc_in[v * OWN + q]; t_hn[q] = acc_hn[v * OWN + q];
+          }
+        }
+    } else {
+      const int sl = (gsrc - ks - 1 + KS) % KS;
 #pragma unroll
       for (int q = 0; q < OWN; ++q) {
-        o_r[q] = acc_r[v * OWN + q]; o_z[q] = acc_z[v * OWN + q];
-        o_in[q] = acc_in[v * OWN + q]; o_hn[q] = acc_hn[v * OWN + q];
+        t_r[q] = sc[ks][sl][0][q][lane]; t_z[q] = sc[ks][sl][1][q][lane];
+        t_in[q] = sc[ks][sl][2][q][lane]; t_hn[q] = sc[ks][sl][3][q][lane];
       }
     }
-  }
-#pragma unroll
-  for (int sl = 0; sl < KS - 1; ++sl)
 #pragma unroll
     for (int q = 0; q < OWN; ++q) {
-      o_r[q] += sc[ks][sl][0][q][lane];
-      o_z[q] += sc[ks][sl][1][q][lane];
-      o_in[q] += sc[ks][sl][2][q][lane];
-      o_hn[q] += sc[ks][sl][3][q][lane];
+      o_r[q] = gsrc == 0 ? t_r[q] : o_r[q] + t_r[q];
+      o_z[q] = gsrc == 0 ? t_z[q] : o_z[q] + t_z[q];
+      o_in[q] = gsrc == 0 ? t_in[q] : o_in[q] + t_in[q];
+      o_hn[q] = gsrc == 0 ? t_hn[q] : o_hn[q] + t_hn[q];
     }
+  }
 #pragma unroll
   for (int q = 0; q < OWN; ++q) {
     const int64_t m = m0 + 8 * ks + q + 4 * fk;
