@@ -58,13 +58,55 @@ WORKLOADS = {
     'c5s': dict(name='C5 synthetic 10M nodes d=256 B=65536 (stream shortened to 4M events)', n_u=9000000, n_i=1000000,
                 E=4000000, T=4.0e6, d=256, K=10, B=65536, msg_src='left', upd_src='right', no_feats=True,
                 integer_ts=False),
+    # BASELINE configs[4] as written (SURVEY.md s8 d): 10^8 events over 10 M nodes, the stream from the counter-based
+    # generator - a run generates the prefix it processes (every rank the same slice, by construction), at the event
+    # rate of the full stream (T / E = 1); the first 10 % of the stream is warm-up (19 global batches at 8 x 65536)
+    'c5': dict(name='C5 synthetic 10^8 events / 10M nodes d=256 B=65536 (counter-based stream; the processed prefix is generated)',
+               n_u=9000000, n_i=1000000, E=100000000, T=1.0e8, d=256, K=10, B=65536, msg_src='left', upd_src='right',
+               no_feats=True, integer_ts=False, counter_stream=True),
 }
 
 
-def make_stream(n_u, n_i, E, T, seed=0, d_e=172, integer_ts=True, with_efeats=True):
+def _mix64(x):
+    """splitmix64 finaliser on uint64 arrays: the counter-based generator's hash"""
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def counter_uniform(seed, lane, lo, hi):
+    """uniform [0, 1) doubles for stream positions [lo, hi): a pure function of (seed, lane, position)"""
+    with np.errstate(over='ignore'):
+        idx = np.arange(lo, hi, dtype=np.uint64)
+        key = np.uint64((seed * 0x9E3779B97F4A7C15 + lane * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF)
+        bits = _mix64(_mix64(idx + key) ^ np.uint64(0xA0761D6478BD642F))
+    return (bits >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def make_stream_counter(n_u, n_i, E_total, T_total, lo, hi, seed=0):
+    """Events [lo, hi) of the SURVEY.md s8(d) C5 stream from a counter-based generator: every quantity is a pure
+    function of (seed, position), so any rank (or shard) generates exactly the slice it needs - identical wherever it
+    is generated, no RandomState walked over the whole 10^8-event stream.  Same marginals as make_stream: Zipf(0.8)
+    users / Zipf(1.0) items by inverse CDF, timestamps increasing with the position (one uniform draw inside each of
+    the E_total equal slots of [0, T_total)), uniform negatives."""
+    cu = np.cumsum(1.0 / np.arange(1, n_u + 1) ** 0.8)
+    ci = np.cumsum(1.0 / np.arange(1, n_i + 1) ** 1.0)
+    src = np.minimum(np.searchsorted(cu, counter_uniform(seed, 1, lo, hi) * cu[-1], side='right'), n_u - 1).astype(np.int64) + 1
+    dst = np.minimum(np.searchsorted(ci, counter_uniform(seed, 2, lo, hi) * ci[-1], side='right'), n_i - 1).astype(np.int64) + 1 + n_u
+    ts = (np.arange(lo, hi, dtype=np.float64) + counter_uniform(seed, 3, lo, hi)) * (T_total / E_total)
+    neg = (counter_uniform(seed, 4, lo, hi) * n_i).astype(np.int64) + 1 + n_u
+    return dict(src=src, dst=dst, ts=ts, eids=np.arange(lo + 1, hi + 1, dtype=np.int64), neg=neg,
+                n_nodes=n_u + n_i + 1, efeats=None)
+
+
+def make_stream(n_u, n_i, E, T, seed=0, d_e=172, integer_ts=True, with_efeats=True, counter=False):
     """SURVEY.md s8(d) generator: bipartite ids (0 = padding, users 1..n_u, items after),
     Zipf(0.8) users, Zipf(1.0) items, sorted uniform timestamps (floored: duplicates occur),
-    eid = 1..E, N(0,1) edge features with row 0 = 0, one pre-drawn negative per event."""
+    eid = 1..E, N(0,1) edge features with row 0 = 0, one pre-drawn negative per event.
+    counter: the first E events of the counter-based stream (make_stream_counter; no edge features)."""
+    if counter:
+        assert not with_efeats and not integer_ts
+        return make_stream_counter(n_u, n_i, E, T, 0, E, seed)
     rs = np.random.RandomState(seed)
     pu = 1.0 / np.arange(1, n_u + 1) ** 0.8
     pi = 1.0 / np.arange(1, n_i + 1) ** 1.0
@@ -244,13 +286,22 @@ def stage_work(cfg, U, O_, P, eager, fused, n_nodes, E, tile=False):
     return w
 
 
+TRAFFIC_SOURCE = {}
+
+
 def load_traffic(tag):
-    """HBM / fabric bytes per launch from the committed PMC passes of this round (profiles/r02_hbm_traffic_<tag>.json,
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command, tools/pmc_traffic.py); {} if not recorded."""
-    try:
-        return json.load(open(os.path.join(ROOT, 'profiles', f'r02_hbm_traffic_{tag}.json')))['kernels']
-    except (OSError, ValueError, KeyError):
-        return {}
+    """HBM / fabric bytes per launch from the committed PMC passes (profiles/r03_hbm_traffic_<tag>.json, else the
+    r02 file: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command, tools/pmc_traffic.py); {} if not recorded.
+    A stored, builder-run measurement - the profiler cannot wrap the driver's run - and named as such in the line."""
+    for rnd in ('r03', 'r02'):
+        path = os.path.join('profiles', f'{rnd}_hbm_traffic_{tag}.json')
+        try:
+            k = json.load(open(os.path.join(ROOT, path)))['kernels']
+            TRAFFIC_SOURCE[tag] = path + ' (builder-run PMC passes of the same command, not measured in this run)'
+            return k
+        except (OSError, ValueError, KeyError):
+            continue
+    return {}
 
 
 def kernel_traffic(traffic, kname):
@@ -284,10 +335,11 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     dev = torch.device('cuda', 0)
     B, K, d = cfg['B'], cfg['K'], cfg['d']
     n_batches = preroll + warmup + steps + n_prof + 8  # + 4 batches for the copy-form gather timing, + 2 for the set sizes of a lean run, + 2 spare
-    E = max(cfg['E'], n_batches * B)
+    E = max(cfg['E'], n_batches * B) if not cfg.get('counter_stream') else n_batches * B
     no_feats = bool(cfg.get('no_feats'))
     stream = make_stream(cfg['n_u'], cfg['n_i'], E, cfg['T'] * E / cfg['E'], seed=0, d_e=d,
-                         integer_ts=cfg.get('integer_ts', True), with_efeats=not no_feats)
+                         integer_ts=cfg.get('integer_ts', True), with_efeats=not no_feats,
+                         counter=bool(cfg.get('counter_stream')))
     model, _ = build_models(stream, d, K, cfg['msg_src'], cfg['upd_src'], restarter='static', device='cuda:0',
                             zero_nfeats=not no_feats)
     resident = tuple(torch.from_numpy(stream[k]).to(dev) for k in ('src', 'dst', 'neg', 'ts', 'eids'))
@@ -436,6 +488,8 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
         note='the mailbox / updater-source rows are gathered inside the updater launch, which is MFMA-bound'
              + (' and, with eager updates, runs on the P nodes that received a message instead of the O nodes that hold one' if eager else ''))
     out['roofline_memory_gather'] = mg
+    for r in (out['roofline'], mg):
+        r['traffic_source'] = TRAFFIC_SOURCE.get(traffic_tag) if r.get('traffic') is not None else None
     out['roofline_updater'] = roofline_of(u_name, stages[u_name], work, traffic)
     out['roofline_neighbour_gather'] = roofline_of('attn_core(gather+softmax)', stages['attn_core(gather+softmax)'], work, traffic)
     if want_cpu:
@@ -571,6 +625,8 @@ def main():
     ap.add_argument('--preroll', type=int, default=None,
                     help=f'untimed state pre-roll batches before --warmup (default {PREROLL}; 20 for c5s)')
     ap.add_argument('--no-c5s-leg', action='store_true', help='default C2 run: skip the short HBM-roofline leg')
+    ap.add_argument('--no-dist-leg', action='store_true',
+                    help='default C2 run: skip the one-rank leg of the multi-GPU code path (partitioned_form_1rank)')
     ap.add_argument('--no-lean', action='store_true',
                     help='form the involved / outdated sets in every step even where nothing reads them')
     ap.add_argument('--no-graph', action='store_true', help='launch steps eagerly instead of replaying a hipGraph')
@@ -616,11 +672,34 @@ def main():
     if args.workload == 'c2' and not args.no_c5s_leg:
         # at C2 every table is cache resident (150 MB): the HBM-roofline claim for the memory-gather kernel is made
         # on the C5-shaped tables (10 M nodes, d=256, B=65536: 70 GB of state), 20 warm + 10 timed steps
-        c5 = run_stream_leg(dict(WORKLOADS['c5s']), args, 20, 4, 10, 4, traffic_tag='c5s')
-        out['c5s_leg'] = dict(value=c5['value'], unit='events/s', ms_per_step=c5['ms_per_step'], steps=10, warmup=24,
+        c5 = run_stream_leg(dict(WORKLOADS['c5s']), args, 20, 4, 30, 4, traffic_tag='c5s')
+        out['c5s_leg'] = dict(value=c5['value'], unit='events/s', ms_per_step=c5['ms_per_step'], steps=30, warmup=24,
                               config=c5['config'], roofline_memory_gather=c5['roofline_memory_gather'],
                               roofline_updater=c5['roofline_updater'],
                               roofline_neighbour_gather=c5['roofline_neighbour_gather'], stages_ms=c5['stages_ms'])
+    if args.workload == 'c2' and not args.no_dist_leg:
+        # the N = 1 point of the multi-GPU code path (partitioned state, hipGraph segments around two RCCL
+        # all_to_all_single with one rank) next to the single-GPU graph line, so that a scaling curve whose N > 1 points
+        # come from that path has an N = 1 of the same form on record
+        try:
+            from www2023tiger_amd import dist as tdist
+            import copy
+            a2 = copy.copy(args)
+            a2.steps, a2.warmup, a2.preroll = min(args.steps, 100), min(args.warmup, 20), PREROLL
+            fd1 = os.dup(1)
+            os.dup2(2, 1)  # RCCL prints a banner on fd 1
+            try:
+                leg = tdist.run_dist_leg(a2, dict(cfg), make_stream, build_models, 0, 0, 1, want_cpu=False)
+            finally:
+                sys.stdout.flush()
+                os.dup2(fd1, 1)
+                os.close(fd1)
+            out['partitioned_form_1rank'] = dict(value=leg['value'], unit='events/s', ms_per_step=leg['ms_per_step'],
+                                                 host_enqueue_ms_per_step=leg['host_enqueue_ms_per_step_rank0'],
+                                                 steps=leg['steps'], launch=leg['config']['launch'],
+                                                 stages_ms=leg['stages_ms_rank0'])
+        except Exception as e:  # the headline line must not depend on RCCL coming up on a one-GPU box
+            out['partitioned_form_1rank'] = dict(error=repr(e))
     print(json.dumps(out))
 
 

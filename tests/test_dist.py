@@ -459,7 +459,7 @@ def test_partitioned_state_equals_single_process_cpu_gloo(tmp_path, world, balan
     same(got['msg'][ref.has_msg], ref.msg_vals.numpy()[ref.has_msg], err_msg='mailbox')
 
 
-def _partitioned_gpu_worker(rank, world, port, name, B, n_steps, resident, out_dir):
+def _partitioned_gpu_worker(rank, world, port, name, B, n_steps, resident, out_dir, lopsided=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
@@ -473,6 +473,8 @@ def _partitioned_gpu_worker(rank, world, port, name, B, n_steps, resident, out_d
     model.fuse_attention()
     Bg = B * world
     owner = balanced_owner_table(int(z['n_nodes']), z['dst'], world)
+    if lopsided:  # rank 0 owns every node: the other ranks embed their share of the events and own no winner, ever
+        owner = np.zeros_like(owner)
     keys = ('src', 'dst', 'neg', 'ts', 'eids')
     if resident:  # all plans up front, balanced shards (the benchmarked form)
         rs = ResidentPartitionedStream(model, {k: z[k] for k in keys}, owner, rank, world, B, n_steps)
@@ -521,6 +523,34 @@ def test_partitioned_state_equals_single_gpu(tmp_path, name, world, B, resident)
     assert rel_err(got['left'], model.left_memory.vals.cpu().numpy()) < 1e-6
     assert rel_err(got['right'], model.right_memory.vals.cpu().numpy()) < 1e-6
     assert rel_err(got['msg'][has], model.msg_store.node_msg_vals.cpu().numpy()[has]) < 1e-6
+
+
+@pytest.mark.gpu
+def test_partitioned_rank_that_owns_no_node(tmp_path):
+    """A rank whose write-back is empty in every batch (it owns no node; its events' rows are all pushed away) must
+    neither fail nor stall its peers inside the step's collectives (an empty winner list has a NULL data
+    pointer, which the write-back took for the unplanned form)."""
+    from test_hip_parity import build_hip_model
+    name, world, B = 'static_ll_d16', 2, 48
+    n_steps = min(5, len(load(name)['src']) // (B * world))
+    mp.spawn(_partitioned_gpu_worker, args=(world, free_port(), name, B, n_steps, True, str(tmp_path), True),
+             nprocs=world, join=True)
+    z = load(name)
+    cfg = parse_cfg(z)
+    model, _, _ = build_hip_model(z, cfg)
+    model.fuse_attention()
+    model.eager_updates()
+    Bg = B * world
+    for b in range(n_steps):
+        sl = slice(b * Bg, (b + 1) * Bg)
+        model.stream_step(*(z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')))
+    r0 = np.load(os.path.join(str(tmp_path), 'rank0.npz'))  # rank 0 is authoritative for everything
+    has = model.msg_store.has_msg_mask().cpu().numpy()
+    np.testing.assert_array_equal(r0['has'], has)
+    np.testing.assert_array_equal(r0['left_ts'], model.left_memory.update_ts.cpu().numpy())
+    assert rel_err(r0['left'], model.left_memory.vals.cpu().numpy()) < 1e-6
+    assert rel_err(r0['right'], model.right_memory.vals.cpu().numpy()) < 1e-6
+    assert rel_err(r0['msg'][has], model.msg_store.node_msg_vals.cpu().numpy()[has]) < 1e-6
 
 
 # ------------------------------------------------------------------------------ the reference's DDP recipe

@@ -1123,6 +1123,10 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
   // current through tg_apply_messages after its own write-back); only a full step runs the updater at its end
   const bool eager = m->pending_vals != nullptr;
   if ((rc = step_forward(m, g, io, w, nullptr, st, pf, nullptr, eager)) != TG_OK) return rc;
+  if (pf && (io->embed_only || io->collate_only)) {  // no write-back stages: close the timer's remaining intervals
+    for (int i = ST_WRITE_RIGHT; i <= ST_COUNT; ++i) prof_mark(pf, i, st);
+    pf->armed = true;
+  }
   if (io->embed_only && w.lean) return check_launch("tg_stream_step(embed_only, lean)");  // counts are not written
   if (io->embed_only || io->collate_only) {
     if (io->counts) {

@@ -348,7 +348,7 @@ class StepPlan:
     """Everything about one global batch that does not depend on node state (see PartitionedRunner.plan)."""
     __slots__ = ('n', 'Bg', 'local', 'glob', 'ts32', 'serve_eff', 'serve_msg', 'serve_eff_pos', 'serve_msg_pos',
                  'serve_in', 'serve_out', 'req_eff', 'req_msg', 'reply_eff_pos', 'reply_msg_pos', 'push_rows', 'push_in',
-                 'push_out', 'n_recv', 'left_row', 'mine', 'mine_index', 'mine32', 'n_mine', 'stats')
+                 'push_out', 'n_recv', 'left_row', 'mine', 'mine_index', 'mine32', 'n_mine', 'stats', 'push_idx')
 
 
 class PartitionedRunner:
@@ -437,7 +437,7 @@ class PartitionedRunner:
         left_row[recv_pos] = 3 * n + torch.arange(recv_pos.numel(), device=dev)  # received rows sit behind the rank's own 3n
         p.left_row = left_row
         p.n_recv = int(recv_pos.numel())
-        p.stats = dict(local_events=n, pulled_rows=int(sum(p.serve_out)), served_rows=int(sum(p.serve_in)),
+        p.stats = dict(local_events=n, involved=int(involved.numel()), pulled_rows=int(sum(p.serve_out)), served_rows=int(sum(p.serve_in)),
                        pushed_rows=int(sum(p.push_in)), received_rows=int(sum(p.push_out)), own_winners=int(p.mine.numel()))
         return p
 
@@ -468,7 +468,7 @@ class HipPartitionEngine:
     resident = (src, dst, neg, ts64, eids) device tensors of this rank's events of ALL steps, B per step: the
     embed then reads its batch at a device-side offset (no per-step copies)."""
 
-    def __init__(self, model, cap: int, resident=None):
+    def __init__(self, model, cap: int, resident=None, max_recv: Optional[int] = None):
         from . import hip_ops
         from ._lib import TgWritebackIo, check, lib, ptr
         if model._pending is None:
@@ -476,7 +476,8 @@ class HipPartitionEngine:
         model._sync_pending()
         self.model, self.cap, self.device, self.d = model, cap, model.device, model.memory_dim
         self.hip_ops, self.check, self.lib, self.ptr, self.WbIo = hip_ops, check, lib, ptr, TgWritebackIo
-        self.max_recv = 2 * cap if resident is not None else 0  # resident: fixed output buffer with room for pushed rows
+        # resident: fixed output buffer with room for pushed rows (max_recv: the planner's bound over all steps and ranks)
+        self.max_recv = (max_recv if max_recv is not None else 2 * cap) if resident is not None else 0
         self.hbuf = torch.zeros(3 * cap + max(self.max_recv, 1), self.d, dtype=torch.float32, device=self.device)
         # lean: the embedding step forms no involved set (the exchange lists come from `plan`'s collation, a collate_only
         # call on cbuf, which ignores the flag); sampler + centres, G, core, fc1, fc2 and nothing else
@@ -487,6 +488,15 @@ class HipPartitionEngine:
         self.err = hip_ops.new_err(model.device)
         self._owner32 = None
         self._st = None
+
+    def resize_recv(self, max_recv: int):
+        """room for `max_recv` pushed rows behind the rank's own 3 * cap embeddings (the planner's bound)"""
+        from ._lib import ptr
+        self.max_recv = int(max_recv)
+        self.hbuf = torch.zeros(3 * self.cap + max(self.max_recv, 1), self.d, dtype=torch.float32, device=self.device)
+        for b in {id(self.cbuf): self.cbuf, id(self.buf): self.buf}.values():
+            b.h = self.hbuf
+            b.io.h = ptr(self.hbuf)
 
     def begin_step(self):
         """the launch stream is looked up once per step (torch.cuda.current_stream costs ~5 us a call)"""
@@ -520,12 +530,13 @@ class HipPartitionEngine:
             self.cbuf.io.collate_only = 0
         return self.cbuf.involved[:int(self.cbuf.counts[0].item())].clone()
 
-    def serve(self, p):
+    def serve(self, p, out=None):
         """one launch: effective right-memory rows of p.serve_eff and message-source memory rows of p.serve_msg, each
-        with its time in column d, at their places in the peer-major send buffer"""
+        with its time in column d, at their places in the peer-major send buffer (`out`: a preallocated one)"""
         m, lib, ptr = self.model, self.lib, self.ptr
         ne, nm = p.serve_eff.numel(), p.serve_msg.numel()
-        out = torch.empty(ne + nm, self.d + 1, dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty(ne + nm, self.d + 1, dtype=torch.float32, device=self.device)
         ms = m.model_struct()
         self.check(lib.tg_serve_rows(C.byref(ms), ne, ptr(p.serve_eff), ptr(p.serve_eff_pos), nm, ptr(p.serve_msg),
                                      ptr(p.serve_msg_pos), ptr(out), self._stream()), 'tg_serve_rows')
@@ -544,7 +555,9 @@ class HipPartitionEngine:
         """collate + STEP 1-3 of this rank's events -> [3 n + n_recv, d]: the embeddings, then room for pushed rows"""
         n = p.n
         if self.resident:
-            assert n == self.cap and p.n_recv <= self.max_recv
+            if n != self.cap or p.n_recv > self.max_recv:  # (the static stream sizes max_recv from all plans, collectively)
+                raise RuntimeError(f'resident partitioned embed: {n} events / {p.n_recv} pushed rows exceed the buffers '
+                                   f'({self.cap} / {self.max_recv})')
             self.model.launch_step(self.buf)   # reads its batch at the device-side offset and advances it
             return self.hbuf[:3 * n + p.n_recv]
         if n:
@@ -598,10 +611,19 @@ class ResidentPartitionedStream:
     """The partitioned mode for a stream that is resident in HBM: every step is planned up front (plans are
     functions of the graph and the stream only; the planning pass also tells every owner what it will be asked
     for), so a timed step is pull -> embed -> push -> owner write-back -> eager updater: two all_to_all_single
-    of rows and local kernels, no host decision in between."""
+    of rows and local kernels, no host decision in between.
+
+    STATIC SHAPES.  The rows a rank exchanges with a peer vary from batch to batch; here every peer block of the
+    two exchanges is padded to the largest count any rank sees in any step (one MAX all-reduce when the plans are
+    made), so both collectives are equal-split all_to_all_single calls on preallocated buffers - no split lists, no
+    per-step allocation, no .item() - and a rank's positions inside the padded buffers are plain index arithmetic
+    on its plans.  With use_graphs the local kernels of step s are three captured hipGraphs (serve | adopt + embed +
+    push gather | write-back + eager updater) replayed around the two collectives.  (capture_collectives would put the
+    collectives inside one graph per step; on ROCm 7.2 / torch 2.10 such a capture never finished with one rank, so
+    nothing switches it on.)"""
 
     def __init__(self, model, stream: dict, owner: np.ndarray, rank: int, world: int, B: int, n_steps: int,
-                 group=None):
+                 group=None, use_graphs: bool = False, capture_collectives: bool = False):
         Bg = B * world
         keys = ('src', 'dst', 'neg', 'ts', 'eids')
         rank_ofs, local = [], {k: [] for k in keys}
@@ -615,54 +637,199 @@ class ResidentPartitionedStream:
         dev = model.device
         tod = lambda a, dt: torch.from_numpy(np.ascontiguousarray(np.concatenate(a))).to(dev, dt)
         resident = tuple(tod(local[k], torch.float64 if k == 'ts' else torch.int64) for k in keys)
-        self.engine = HipPartitionEngine(model, cap=B, resident=resident)
+        self.model, self.rank, self.world, self.B, self.group, self.n_steps = model, rank, world, B, group, n_steps
+        self.engine = HipPartitionEngine(model, cap=B, resident=resident, max_recv=0)  # receive room: sized below
         self.runner = PartitionedRunner(self.engine, owner, rank, world, group)
         self.plans = [self.runner.plan(*(stream[k][b * Bg:(b + 1) * Bg] for k in keys), rank_of=rank_ofs[b])
                       for b in range(n_steps)]
+        # ---- static shapes: the largest peer block of either exchange over all steps and ranks
+        mx = torch.tensor([max([1] + [max(max(p.serve_in), max(p.serve_out)) for p in self.plans]),
+                           max([1] + [max(max(p.push_in), max(p.push_out)) for p in self.plans])], dtype=torch.int64)
+        if tdist.is_initialized() and world > 1:
+            mxd = mx.to(dev) if tdist.get_backend(group) == 'nccl' else mx
+            tdist.all_reduce(mxd, op=tdist.ReduceOp.MAX, group=group)
+            mx = mxd.cpu()
+        self.pull_max, self.push_max = int(mx[0]), int(mx[1])
+        d = model.memory_dim
+        self.engine.resize_recv(world * self.push_max)
+        self.served = torch.zeros(world * self.pull_max, d + 1, dtype=torch.float32, device=dev)
+        self.got = torch.zeros(world * self.pull_max, d + 1, dtype=torch.float32, device=dev)
+        self.pushbuf = torch.zeros(world * self.push_max, d, dtype=torch.float32, device=dev)
+        self.recv = self.engine.hbuf[3 * B:3 * B + world * self.push_max]
+        for p in self.plans:
+            self._pad(p)
         self.steps_done = 0
+        self.use_graphs = bool(use_graphs) and dev.type == 'cuda'
+        self.capture_collectives = bool(capture_collectives) and self.use_graphs
+        self.graphs = {}
+        self.stream = torch.cuda.Stream(device=dev) if self.use_graphs else None
+
+    def _pad(self, p):
+        """positions of plan p inside the padded, peer-major exchange buffers"""
+        dev, world = self.model.device, self.world
+
+        def remap(pos, counts, width):  # compact peer-major position -> padded position
+            cum = torch.cumsum(torch.tensor([0] + list(counts)), 0).to(dev)
+            blk = torch.searchsorted(cum, pos, right=True) - 1
+            return (blk * width + (pos - cum[blk])).contiguous()
+        p.serve_eff_pos = remap(p.serve_eff_pos, p.serve_in, self.pull_max)
+        p.serve_msg_pos = remap(p.serve_msg_pos, p.serve_in, self.pull_max)
+        p.reply_eff_pos = remap(p.reply_eff_pos, p.serve_out, self.pull_max)
+        p.reply_msg_pos = remap(p.reply_msg_pos, p.serve_out, self.pull_max)
+        # push: row j of peer block q of the send buffer = h row push_rows[cum_in[q] + j]; padding re-sends row 0
+        idx = torch.zeros(world * self.push_max, dtype=torch.int64, device=dev)
+        n_push = int(sum(p.push_in))
+        if n_push:
+            idx[remap(torch.arange(n_push, device=dev), p.push_in, self.push_max)] = p.push_rows
+        p.push_idx = idx
+        # received rows sit behind the rank's own 3 n embeddings, peer block q at 3 n + q * push_max
+        n = p.n
+        n_recv = int(sum(p.push_out))
+        if n_recv:
+            was = p.left_row >= 3 * n
+            p.left_row = torch.where(was, 3 * n + remap((p.left_row - 3 * n).clamp(min=0), p.push_out, self.push_max),
+                                     p.left_row).contiguous()
+        p.n_recv = world * self.push_max
+
+    # ---- the three local segments of a step (every tensor preallocated; no host read-back)
+    def _seg_serve(self, p):
+        self.engine.serve(p, out=self.served)
+
+    def _seg_embed(self, p):
+        self.engine.adopt(p, self.got)
+        self.engine.embed(p)
+        torch.index_select(self.engine.hbuf, 0, p.push_idx, out=self.pushbuf)
+
+    def _seg_write(self, p):
+        self.engine.writeback(p, self.engine.hbuf, self.runner.owner, self.rank)
+        self.engine.refresh(p)
+
+    def _pull(self):
+        all_to_all_rows(self.served, [self.pull_max] * self.world, [self.pull_max] * self.world, self.group, out=self.got)
+
+    def _push(self):
+        all_to_all_rows(self.pushbuf, [self.push_max] * self.world, [self.push_max] * self.world, self.group, out=self.recv)
+
+    def capture(self, first: Optional[int] = None, last: Optional[int] = None):
+        """Capture the local segments of steps [first, last) (default: every step not yet run).  Call after at least one
+        eager step (workspaces exist, the eager-update table is current)."""
+        assert self.use_graphs
+        first = self.steps_done if first is None else first
+        last = self.n_steps if last is None else last
+        side = torch.cuda.Stream(device=self.model.device)
+        off = self.engine.buf.offset.clone()
+        torch.cuda.synchronize()
+        eng = self.engine
+        for s in range(first, last):
+            p = self.plans[s]
+            if self.capture_collectives:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
+                    eng.begin_step()
+                    self._seg_serve(p); self._pull(); self._seg_embed(p); self._push(); self._seg_write(p)
+                    eng.end_step()
+                self.graphs[s] = (g,)
+            else:
+                gs = []
+                for seg in (self._seg_serve, self._seg_embed, self._seg_write):
+                    g = torch.cuda.CUDAGraph()
+                    # thread_local: the RCCL watchdog thread polls events of recent collectives, which would invalidate
+                    # a capture in the default (global) mode
+                    with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
+                        eng.begin_step()
+                        seg(p)
+                        eng.end_step()
+                    gs.append(g)
+                self.graphs[s] = tuple(gs)
+        self.engine.buf.offset.copy_(off)  # capture does not execute, but be explicit
+        torch.cuda.synchronize()
 
     def step(self):
-        h = self.runner.run(self.plans[self.steps_done])
+        s = self.steps_done
+        assert s < self.n_steps, 'resident stream exhausted'
+        p = self.plans[s]
+        gs = self.graphs.get(s)
+        if gs is None:  # eager launches on the current stream
+            self.engine.begin_step()
+            self._seg_serve(p); self._pull(); self._seg_embed(p); self._push(); self._seg_write(p)
+            self.engine.end_step()
+        else:
+            # replays and collectives are ordered through one explicit stream (see ResidentShardedStream)
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                if len(gs) == 1:
+                    gs[0].replay()
+                else:
+                    gs[0].replay(); self._pull(); gs[1].replay(); self._push(); gs[2].replay()
+            torch.cuda.current_stream().wait_stream(self.stream)
+            m = self.model  # what the captured write-back / refresh did on the host side when they were recorded
+            m._touch()
+            m._pending_stamp = m._state_stamp()
         self.steps_done += 1
-        return h
+        return self.engine.hbuf[:3 * self.B]
+
+    def step_profiled(self, prof=None):
+        """One eager step with device timers around its segments (torch events on the launch stream; `prof`: the
+        library's per-stage timer attached to the embedding step).  Returns {segment: ms} after a synchronisation."""
+        s = self.steps_done
+        p = self.plans[s]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
+        eng = self.engine
+        eng.begin_step()
+        ev[0].record(); self._seg_serve(p)
+        ev[1].record(); self._pull()
+        ev[2].record(); eng.adopt(p, self.got)
+        ev[3].record()
+        if prof is not None:
+            eng.buf.attach_profiler(prof)
+        eng.embed(p)
+        eng.buf.attach_profiler(None)
+        ev[4].record()
+        torch.index_select(eng.hbuf, 0, p.push_idx, out=self.pushbuf); self._push()
+        ev[5].record(); eng.writeback(p, eng.hbuf, self.runner.owner, self.rank)
+        ev[6].record(); eng.refresh(p)
+        ev[7].record()
+        eng.end_step()
+        torch.cuda.synchronize()
+        self.steps_done += 1
+        names = ('serve_rows', 'pull_all_to_all', 'adopt_rows', 'embed', 'push_gather+all_to_all', 'writeback(owner)',
+                 'eager_updater(gru)')
+        return {n: ev[i].elapsed_time(ev[i + 1]) for i, n in enumerate(names)}
 
     def traffic(self):
-        keys = ('pulled_rows', 'served_rows', 'pushed_rows', 'received_rows', 'own_winners', 'local_events')
-        return {k: float(np.mean([p.stats[k] for p in self.plans])) for k in keys}
+        keys = ('pulled_rows', 'served_rows', 'pushed_rows', 'received_rows', 'own_winners', 'local_events', 'involved')
+        out = {k: float(np.mean([p.stats[k] for p in self.plans])) for k in keys}
+        out.update(padded_pull_rows_per_peer=self.pull_max, padded_push_rows_per_peer=self.push_max)
+        return out
 
     def check_invariants(self):
         self.engine.check_invariants()
 
 
 # --------------------------------------------------------------------------- benchmark leg
-def bench_main(args, cfg, make_stream, build_models, rank, local_rank, world):
-    """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (or `python bench.py --gpus N`,
-    which starts the ranks itself).  --scaling weak: B events per rank per step (global batch N * B);
-    strong: the global batch stays B.  value = events of all ranks / max-over-ranks time.
+def run_dist_leg(args, cfg, make_stream, build_models, rank, local_rank, world, own_process_group=True,
+                 want_cpu=True):
+    """One multi-rank measurement (also with ONE rank: the N = 1 point of this code path).  Returns the JSON line's
+    dict on rank 0, None elsewhere.  --scaling weak: B events per rank per step (global batch N * B); strong: the
+    global batch stays B.  value = events of all ranks / max-over-ranks time.
     Period-1 exchange: a global batch is one batch of the single-GPU engine (its events read the state left by
     the previous global batch), so with weak scaling the batch whose events do not see each other grows with N."""
-    assert world == args.gpus, f'launch with torchrun: WORLD_SIZE={world} but --gpus {args.gpus}'
-    # RCCL prints a version banner on fd 1 when the communicator is created; the contract is ONE JSON
-    # line on stdout, so fd 1 is pointed at stderr until the result is ready
     import os
-    import sys
-    sys.stdout.flush()
-    saved_stdout = os.dup(1)
-    os.dup2(2, 1)
     # rehearsal on a box with fewer GPUs than ranks (TG_BENCH_REHEARSAL=1): every rank uses GPU 0 and the exchange
     # goes through gloo - the timings mean nothing, the flow (plans, shapes, collectives, the JSON line) is the same
     rehearsal = bool(os.environ.get('TG_BENCH_REHEARSAL'))
-    if 'MASTER_ADDR' not in os.environ:  # a single rank started by hand (--force-dist)
+    if 'MASTER_ADDR' not in os.environ:  # a single rank started by hand (--force-dist) or the in-process N = 1 leg
         import socket
         with socket.socket() as sk:
             sk.bind(('127.0.0.1', 0))
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(sk.getsockname()[1]))
     dev = torch.device('cuda', 0 if rehearsal else local_rank)
     torch.cuda.set_device(dev)
-    if rehearsal:
-        tdist.init_process_group('gloo', rank=rank, world_size=world)
-    else:
-        tdist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    if own_process_group:
+        if rehearsal:
+            tdist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            tdist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
     K, d = cfg['K'], cfg['d']
     strong = getattr(args, 'scaling', 'weak') == 'strong'
     if strong and cfg['B'] % world:
@@ -671,20 +838,29 @@ def bench_main(args, cfg, make_stream, build_models, rank, local_rank, world):
     Bg = B * world
     mode = getattr(args, 'dist_mode', 'partitioned')
     preroll = args.preroll if getattr(args, 'preroll', None) is not None else (20 if cfg['B'] > 8192 else 150)
-    n_steps = preroll + args.warmup + args.steps
-    E = max(cfg['E'], (n_steps + 2) * Bg)
+    n_prof = 4 if mode == 'partitioned' else 0
+    n_steps = preroll + args.warmup + args.steps + n_prof
+    E = max(cfg['E'], (n_steps + 2) * Bg) if not cfg.get('counter_stream') else (n_steps + 2) * Bg
     no_feats = bool(cfg.get('no_feats'))
     stream = make_stream(cfg['n_u'], cfg['n_i'], E, cfg['T'] * E / cfg['E'], seed=0, d_e=d,
-                         integer_ts=cfg.get('integer_ts', True), with_efeats=not no_feats)  # identical on every rank
+                         integer_ts=cfg.get('integer_ts', True), with_efeats=not no_feats,
+                         **({'counter': True} if cfg.get('counter_stream') else {}))  # identical on every rank
     model, _ = build_models(stream, d, K, cfg['msg_src'], cfg['upd_src'], restarter='static', device=str(dev),
                             zero_nfeats=not no_feats)
-    if not getattr(args, 'no_fuse', False):
+    fused = not getattr(args, 'no_fuse', False)
+    if fused:
         model.fuse_attention()  # fixed parameters: pre-multiplied attention weights, as in the 1-GPU bench
     owner = balanced_owner_table(stream['n_nodes'], stream['dst'], world)
-    use_graphs = bool(getattr(args, 'dist_graphs', False)) and not args.no_graph and mode == 'replicated'
+    nccl = tdist.get_backend() == 'nccl'
     if mode == 'partitioned':
-        rs = ResidentPartitionedStream(model, stream, owner, rank, world, B, n_steps)  # enables eager updates
+        # eager launches by default: measured with one rank on RCCL (C2), three hipGraph segments around the two
+        # collectives are SLOWER than the ten eager launches they replace (0.207 vs 0.156 ms per step; a graph replay
+        # costs 10-16 us of host time, as much as the launches it stands for), and a capture that includes the
+        # collectives never finished.  --dist-graphs selects the segments.
+        use_graphs = nccl and bool(getattr(args, 'dist_graphs', False)) and not args.no_graph
+        rs = ResidentPartitionedStream(model, stream, owner, rank, world, B, n_steps, use_graphs=use_graphs)
     else:
+        use_graphs = bool(getattr(args, 'dist_graphs', False)) and not args.no_graph
         rs = ResidentShardedStream(model, stream, owner, rank, world, B, n_steps, use_graphs=use_graphs)
     spilled = 0.0
     for b in range(min(n_steps, 50)):  # how often the owner's shard was full (reported, not timed)
@@ -692,12 +868,15 @@ def bench_main(args, cfg, make_stream, build_models, rank, local_rank, world):
         p = ShardPlan(stream['dst'][sl], owner, world, B, balance=True)
         spilled += float((p.rank_of != owner[stream['dst'][sl]]).mean())
     spilled /= min(n_steps, 50)
-    n_eager = min(2, n_steps - args.steps)
+    n_eager = min(2, n_steps - args.steps - n_prof)
     for _ in range(n_eager):
         rs.step()
     torch.cuda.synchronize()
     if use_graphs:
-        rs.capture()
+        if mode == 'partitioned':
+            rs.capture(n_eager, n_steps - n_prof)  # (the profiled steps at the end stay eager)
+        else:
+            rs.capture()
     for _ in range(preroll + args.warmup - n_eager):
         rs.step()
     torch.cuda.synchronize()
@@ -714,19 +893,69 @@ def bench_main(args, cfg, make_stream, build_models, rank, local_rank, world):
     tdist.all_reduce(dt, op=tdist.ReduceOp.MAX)
     rs.check_invariants()
     dt = float(dt.item())
+    # ---- rank 0's stage times on the next steps of the stream (every rank runs them: they hold collectives)
+    seg_ms, stage_ms, stage_names = {}, None, None
+    if mode == 'partitioned':
+        from ._lib import lib as _lib
+        prof = _lib.tg_profiler_create() if rank == 0 else None
+        ns = _lib.tg_profiler_num_stages()
+        acc = np.zeros(ns)
+        ms_buf = (C.c_float * ns)()
+        for _ in range(n_prof):
+            one = rs.step_profiled(prof)
+            for k, v in one.items():
+                seg_ms[k] = seg_ms.get(k, 0.0) + v / n_prof
+            if prof is not None:
+                assert _lib.tg_profiler_read(prof, ms_buf) == 0
+                acc += np.array(ms_buf[:]) / n_prof
+        if prof is not None:
+            stage_names = [_lib.tg_profiler_stage_name(i).decode() for i in range(ns)]
+            stage_ms = acc
+            _lib.tg_profiler_destroy(prof)
+        rs.check_invariants()
+    out = None
     if rank == 0:
+        roofline = None
+        stages = {k: round(v, 5) for k, v in seg_ms.items()}
         if mode == 'partitioned':
             tr = rs.traffic()
             row_b = 4 * (d + 1)
             par = (f'dst-owner event shards x{world} (capacity-balanced), node state partitioned by owner(node): per batch one '
                    f'all_to_all_single owner->user (pull, {tr["pulled_rows"]:.0f} rows of {row_b} B into rank 0) and one '
-                   f'user->owner (push, {tr["pushed_rows"]:.0f} rows of {4 * d} B from rank 0); owner-only write-back + eager updater')
-            launch = 'eager launches + 2 all_to_all_single per step (plans made before the timed region)'
+                   f'user->owner (push, {tr["pushed_rows"]:.0f} rows of {4 * d} B from rank 0), both equal-split on buffers padded '
+                   f'to {rs.pull_max} / {rs.push_max} rows per peer; owner-only write-back + eager updater')
+            launch = ('one hipGraph per step incl. both collectives' if rs.capture_collectives else
+                      '3 hipGraph segments + 2 all_to_all_single per step') if use_graphs else \
+                'eager launches + 2 all_to_all_single per step'
+            launch += ' (plans made before the timed region)'
+            try:  # rank 0's dominant embedding kernel against its roofline, as in the 1-GPU line
+                import bench as _b
+                empty = {'zero_flags', 'dedup_positive', 'restarter_targets', 'apply_messages(gru)', 'unique_compact',
+                         'gather_right_memory', 'writeback_phase0', 'writeback_phase1', 'eager_updater(gru)',
+                         'attn_gemm_g', 'attn_gemm_v', 'attn_gemm_out', 'attn_centres+qconst'}
+                emb = {n: float(v) for n, v in zip(stage_names, stage_ms) if n not in empty}
+                emb['eager_updater(gru)'] = seg_ms['eager_updater(gru)']
+                tile = bool(fused and _lib.tg_attn_tile_applies(C.byref(model.model_struct())))
+                work = _b.stage_work(dict(cfg, B=B), tr['involved'], 0.0, tr['own_winners'], True, fused, stream['n_nodes'], E, tile)
+                dom = max(emb, key=emb.get)
+                roofline = _b.roofline_of(dom, emb[dom], work, {})
+                roofline['traffic_source'] = None
+                roofline['note'] = 'rank 0, HIP events over 4 eager steps after the timed region'
+                stages.update({'embed:' + k: round(v, 5) for k, v in emb.items() if k != 'eager_updater(gru)'})
+            except Exception as e:  # the measurement must not depend on the pricing
+                roofline = dict(error=repr(e))
         else:
             tr = None
             par = (f'dst-owner event shards x{world} (capacity-balanced), replicated state, '
                    f'1 RCCL all-gather of {4 * B}x{d} f32 rows per rank per batch')
             launch = '2 hipGraphs + 1 all-gather per step' if use_graphs else 'eager launches + 1 all-gather per step'
+        cpu = None
+        if want_cpu:
+            try:
+                import bench as _b
+                cpu = _b.cpu_baseline(stream, dict(cfg, B=cfg['B']), model)
+            except Exception as e:
+                cpu = dict(error=repr(e))
         out = dict(metric='processed interaction-events/sec (memory+aggregate+embed), Wikipedia d=172',
                    value=args.steps * Bg / dt, unit='events/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=dt / args.steps * 1e3, host_enqueue_ms_per_step_rank0=t_host / args.steps * 1e3,
@@ -739,9 +968,29 @@ def bench_main(args, cfg, make_stream, build_models, rank, local_rank, world):
                                spilled_event_fraction=round(spilled, 4), launch=launch,
                                semantics='one global batch = one batch of the single-GPU engine (exchange period 1): '
                                          f'events of a batch do not see each other, and that batch has {Bg} events here'),
-                   roofline=None, cpu_baseline=None)
+                   roofline=roofline, stages_ms_rank0=stages, cpu_baseline=cpu)
+    if want_cpu and world > 1:
+        tdist.barrier()  # the other ranks wait for rank 0's CPU leg inside the group, not at its teardown
+    if own_process_group:
+        tdist.destroy_process_group()
+    return out
+
+
+def bench_main(args, cfg, make_stream, build_models, rank, local_rank, world):
+    """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (or `python bench.py --gpus N`,
+    which starts the ranks itself): rank 0 prints the ONE JSON line."""
+    assert world == args.gpus, f'launch with torchrun: WORLD_SIZE={world} but --gpus {args.gpus}'
+    # RCCL prints a version banner on fd 1 when the communicator is created; the contract is ONE JSON
+    # line on stdout, so fd 1 is pointed at stderr until the result is ready
+    import os
+    import sys
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    out = run_dist_leg(args, cfg, make_stream, build_models, rank, local_rank, world,
+                       want_cpu=not getattr(args, 'no_cpu_baseline', False))
+    if rank == 0:
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
-    tdist.destroy_process_group()
