@@ -369,9 +369,19 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     lean = direct and not args.no_lean and restart_prob == 0
     buf.io.lean = 1 if lean else 0
 
-    # ---- untimed: state pre-roll, then the contract's warm-up steps (all eager launches)
-    for _ in range(preroll + warmup):
+    # ---- untimed: state pre-roll, then the contract's warm-up steps.  All eager launches but the last two warm-up
+    # steps, which are replays of the graph the timed region replays (the first replay of a fresh graph pays its upload)
+    n_untimed = preroll + warmup
+    n_replay_warm = 0 if (args.no_graph or n_untimed < 6) else min(2, warmup)
+    u_trace = []
+    for b in range(n_untimed - n_replay_warm):
+        full_form = lean and b in (n_untimed // 2, n_untimed - n_replay_warm - 2)  # two full steps: the involved set's size
+        if full_form:
+            buf.io.lean = 0
         model.launch_step(buf)
+        if full_form:
+            buf.io.lean = 1
+            u_trace.append((b, int(buf.counts[0].item())))
     torch.cuda.synchronize()
     assert int(buf.err.item()) == 0, f'invariant word {int(buf.err.item())}'
     cnt = buf.counts.tolist()
@@ -389,6 +399,8 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
         buf.offset.copy_(snap[0])  # capture does not execute: offset unchanged; make sure
         if restart_prob > 0:
             buf.lazy_batch.copy_(snap[1])
+        for _ in range(n_replay_warm):
+            graph.replay()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -402,8 +414,8 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     assert int(buf.offset.item()) == (preroll + warmup + steps) * B
     self_check = None
     if graph is not None and not args.no_self_check and stream['n_nodes'] <= 2_000_000:
-        self_check = replay_self_check(cfg, args, stream, resident, model, buf, preroll, warmup, steps, cnt,
-                                       trig if restart_prob > 0 else None, lean)
+        self_check = replay_self_check(cfg, args, stream, resident, model, buf, n_untimed - n_replay_warm,
+                                       steps + n_replay_warm, cnt, trig if restart_prob > 0 else None, lean)
 
     # ---- per-stage timing on the next unseen batches, live (HIP events on the launch stream)
     names, stage_ms, counts = profile_stages(model, buf, n_prof)
@@ -440,7 +452,9 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
                            updater=('eager: once per stored message (TIGE.eager_updates)' + (', rows read from the tables directly' if direct else ', compact reprs copy')) if eager else
                                    'lazy: on the fly for every involved node with a pending message',
                            involved_set=('not formed (tg_step_io.lean: nothing in a direct-form eager step reads it)' if lean else 'formed (sorted unique ids + ranks)'),
-                           state_preroll_batches=preroll, involved_per_batch=float(U), outdated_per_batch=float(O_),
+                           state_preroll_batches=preroll, involved_per_batch=float(U),
+                           involved_before_timed_region=[dict(batch=b, involved=u) for b, u in u_trace],
+                           outdated_per_batch=float(O_),
                            unique_pos_per_batch=float(P)),
                roofline=roofline_of(dom, stages[dom], work, traffic),
                stages_ms={n: round(v, 5) for n, v in stages.items()}, stage_event_overhead_ms=round(overhead, 5))
@@ -499,7 +513,7 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     return out
 
 
-def replay_self_check(cfg, args, stream, resident, model, buf, preroll, warmup, steps, cnt, trig, lean):
+def replay_self_check(cfg, args, stream, resident, model, buf, n_before, n_replayed, cnt, trig, lean):
     """Untimed: the batches the timed region has just replayed from ONE captured graph go through a SECOND model (same
     seed, same weights, same switches) as plain eager launches, in the same order; memories, mailbox, has-message set
     and the last batch's embeddings of the two must be equal.  The graph replay (device-side offset, baked launch
@@ -518,11 +532,11 @@ def replay_self_check(cfg, args, stream, resident, model, buf, preroll, warmup, 
             model2.restarter_fn.left_emb.weight.copy_(model.restarter_fn.left_emb.weight)
             model2.restarter_fn.right_emb.weight.copy_(model.restarter_fn.right_emb.weight)
         buf2.enable_lazy_restart(model2, trig)
-    for _ in range(preroll + warmup):
+    for _ in range(n_before):  # what the timed model launched eagerly before its graph was captured
         model2.launch_step(buf2)
     torch.cuda.synchronize()
-    model2.note_rows(cnt[1], cnt[2])  # the same row bounds as the timed model had: the same updater blocks
-    for _ in range(steps):
+    model2.note_rows(cnt[1], cnt[2])  # the same row bounds as the captured graph has baked in: the same updater blocks
+    for _ in range(n_replayed):  # the replays: the last warm-up steps and the timed region
         model2.launch_step(buf2)
     torch.cuda.synchronize()
     assert int(buf2.err.item()) == 0 and int(buf2.offset.item()) == int(buf.offset.item())
@@ -544,7 +558,7 @@ def replay_self_check(cfg, args, stream, resident, model, buf, preroll, warmup, 
     del buf2, model2
     return dict(compared='memories, update times, mailbox rows / times, has-message set, last embeddings: hipGraph replay '
                          'of the timed region vs a second model driven by eager launches over the same batches',
-                batches=preroll + warmup + steps, max_abs_diff=worst)
+                batches=n_before + n_replayed, replayed=n_replayed, max_abs_diff=worst)
 
 
 def spawn_ranks(args):
@@ -623,7 +637,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS), help='c2 is the benchmarked configuration')
     ap.add_argument('--preroll', type=int, default=None,
-                    help=f'untimed state pre-roll batches before --warmup (default {PREROLL}; 20 for c5s)')
+                    help=f'untimed state pre-roll batches before --warmup (default {PREROLL}; 96 for c5s / c5)')
     ap.add_argument('--no-c5s-leg', action='store_true', help='default C2 run: skip the short HBM-roofline leg')
     ap.add_argument('--no-dist-leg', action='store_true',
                     help='default C2 run: skip the one-rank leg of the multi-GPU code path (partitioned_form_1rank)')
@@ -660,7 +674,7 @@ def main():
         from www2023tiger_amd import dist as tdist
         return tdist.bench_main(args, cfg, make_stream, build_models, rank, local_rank, world)
 
-    preroll = args.preroll if args.preroll is not None else (20 if args.workload == 'c5s' else PREROLL)
+    preroll = args.preroll if args.preroll is not None else (96 if args.workload in ('c5s', 'c5') else PREROLL)
     n_prof = max(4, min(args.steps, 30 if cfg['B'] <= 8192 else 6))
     leg = run_stream_leg(cfg, args, preroll, args.warmup, args.steps, n_prof, traffic_tag=args.workload,
                          want_cpu=not args.no_cpu_baseline and args.workload == 'c2')
@@ -671,9 +685,10 @@ def main():
     out.update(leg)
     if args.workload == 'c2' and not args.no_c5s_leg:
         # at C2 every table is cache resident (150 MB): the HBM-roofline claim for the memory-gather kernel is made
-        # on the C5-shaped tables (10 M nodes, d=256, B=65536: 70 GB of state), 20 warm + 10 timed steps
-        c5 = run_stream_leg(dict(WORKLOADS['c5s']), args, 20, 4, 30, 4, traffic_tag='c5s')
-        out['c5s_leg'] = dict(value=c5['value'], unit='events/s', ms_per_step=c5['ms_per_step'], steps=30, warmup=24,
+        # on the C5-shaped tables (10 M nodes, d=256, B=65536: 70 GB of state), 100 untimed batches (6.5 M events) and 30 timed steps; the involved set still grows slowly
+        # there (its sizes before and after the timed region are in the line)
+        c5 = run_stream_leg(dict(WORKLOADS['c5s']), args, 96, 4, 30, 4, traffic_tag='c5s')
+        out['c5s_leg'] = dict(value=c5['value'], unit='events/s', ms_per_step=c5['ms_per_step'], steps=30, warmup=100,
                               config=c5['config'], roofline_memory_gather=c5['roofline_memory_gather'],
                               roofline_updater=c5['roofline_updater'],
                               roofline_neighbour_gather=c5['roofline_neighbour_gather'], stages_ms=c5['stages_ms'])
