@@ -467,6 +467,14 @@ typedef struct tg_lazy_restart {
   int64_t* batch_dev;         /* device batch counter (index into trigger); NULL = index 0, not advanced */
   int32_t* restarting_dev;    /* device flag, persists between steps */
   uint64_t* uptodate;         /* device bitmap over n_nodes (tg_bitmap_words), persists between steps */
+  /* LIST form (static_left == static_right == NULL; any restarter, e.g. the SeqRestarter of the reference's default
+   * recipe, restarters.py:36-114): the loop's bookkeeping runs on the device - trigger, bitmaps, has-message bits as
+   * above - but instead of writing surrogate rows the step stores the ids of the nodes to re-initialise in
+   * list[0 .. counts[3]) (order unspecified) and float32(min(ts of the batch)) in *tmin.  Used with
+   * tg_step_io.collate_only: the caller reads counts[3] (4 bytes), runs its restarter on the list
+   * (tg_restart_seq_fwd + tg_restart_apply) and then the step itself. */
+  int64_t* list;              /* [>= min(3B(K+1), n_nodes)] */
+  float* tmin;                /* [1] */
 } tg_lazy_restart;
 
 /* Per-stage timer of tg_stream_step (HIP events on the step's stream).  Stage names:

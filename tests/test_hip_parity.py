@@ -331,6 +331,43 @@ def test_stream_fused_step(name, eager):
     run_stream(name, fused=True, eager=eager)
 
 
+@pytest.mark.parametrize('eager', [False, True], ids=['lazy', 'eager'])
+@pytest.mark.parametrize('name', [n for n in MODEL_FIXTURES if 'restart_at' in parse_cfg(load(n))])
+def test_stream_fused_step_with_the_lazy_restart_loop_on_the_device(name, eager):
+    """train_self_supervised.py:152-163 without the host's sets: StepBuffers.enable_lazy_restart with the fixture's
+    restart batch as the one trigger.  Static restarter: the loop body runs inside tg_stream_step.  Sequence restarter
+    (the reference's default recipe, init_utils.py:55-58): the bookkeeping runs on the device (list form), one count is
+    read back, SeqRestarter + tg_restart_apply run on the device-resident list.  Against the reference's own loop
+    (fixtures): restarted node sets by size, embeddings and state after every batch."""
+    z = load(name)
+    cfg = parse_cfg(z)
+    model, g, coll = build_hip_model(z, cfg)
+    if eager:
+        model.eager_updates()
+    B, nb = cfg['B'], n_batches(z)
+    trigger = np.zeros(nb, dtype=np.uint8)
+    trigger[cfg['restart_at']] = 1
+    buf = model.step_buffers(B, True).enable_lazy_restart(model, trigger)
+    seq = cfg['restarter'] == 'seq'
+    restarting = False
+    for b in range(nb):
+        sl = slice(b * B, min((b + 1) * B, len(z['src'])))
+        a = [z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        if len(a[0]) != B:
+            break  # (the loop's buffers are of one batch size)
+        tag = f'b{b}'
+        restarting = restarting or b == cfg['restart_at']
+        got = model.stream_step(*a, want_prev=True)
+        assert got is buf
+        n_ref = len(z[f'{tag}_restart_nids']) if restarting else 0
+        n_got = buf.lazy_restarted if seq else int(buf.counts[3].item())
+        assert n_got == n_ref, (b, n_got, n_ref)
+        assert_close(buf.h[:2 * B].cpu().numpy(), z[f'{tag}_h_left'], 'h_left', TOL)
+        assert_close(buf.h_prev_left.cpu().numpy(), z[f'{tag}_h_prev_left'], 'h_prev_left', TOL)
+        if f'{tag}_left_vals' in z.files:
+            check_state(model, z, tag)
+
+
 def test_two_layer_model_refuses_the_one_layer_fast_paths():
     """--n_layers 2 runs on the operator path; the fused step, the pre-multiplied weights and the device training step
     are built for one layer and say so instead of computing something else"""

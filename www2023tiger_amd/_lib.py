@@ -75,7 +75,7 @@ class TgStepIo(C.Structure):
 
 class TgLazyRestart(C.Structure):
     _fields_ = [('static_left', vp), ('static_right', vp), ('trigger', vp), ('n_trigger', i64), ('batch_dev', vp),
-                ('restarting_dev', vp), ('uptodate', vp)]
+                ('restarting_dev', vp), ('uptodate', vp), ('list', vp), ('tmin', vp)]
 
 
 class TgWritebackIo(C.Structure):

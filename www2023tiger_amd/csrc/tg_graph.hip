@@ -275,6 +275,17 @@ __global__ void __launch_bounds__(256) k_lazy_restart(tg_tcsr g, tg_model m, tg_
     const int64_t node = w * 64 + lane;
     const bool need_l = node < m.n_nodes && flags[node] != 0 && !((upd >> lane) & 1ull);
     const unsigned long long need = __ballot(need_l);
+    if (lz.list) {  // list form: the caller's restarter re-initialises these nodes; only the bookkeeping happens here
+      int base = 0;
+      if (lane == 0 && need) base = atomicAdd(n_restarted, __popcll(need));
+      base = __shfl(base, 0, TG_WAVE);
+      if (need_l) lz.list[base + __popcll(need & ((1ull << lane) - 1ull))] = node;
+      if (lane == 0 && (trig || need)) {
+        lz.uptodate[w] = upd | need;
+        m.has_msg[w] = msg & ~need;
+      }
+      continue;
+    }
     float pt_l = 0.f;
     if (need_l) {
       int64_t start;
@@ -303,11 +314,13 @@ __global__ void __launch_bounds__(256) k_lazy_restart(tg_tcsr g, tg_model m, tg_
     }
   }
   if (trig && blockIdx.x == 0 && threadIdx.x == 0) *lz.restarting_dev = 1;
+  if (lz.tmin && blockIdx.x == 0 && threadIdx.x == 0) *lz.tmin = (float)t;
 }
 
 int lazy_restart_launch(const tg_tcsr* g, const tg_model* m, const tg_lazy_restart* lz, const uint8_t* flags,
                         const uint32_t* tmin_key, int32_t* n_restarted, hipStream_t st) {
-  if (!lz->static_left || !lz->static_right || !lz->trigger || !lz->restarting_dev || !lz->uptodate) return TG_EINVAL;
+  if (!lz->trigger || !lz->restarting_dev || !lz->uptodate) return TG_EINVAL;
+  if (lz->list ? (lz->static_left || lz->static_right) : (!lz->static_left || !lz->static_right)) return TG_EINVAL;
   const int64_t W = (m->n_nodes + 63) / 64;
   hipLaunchKernelGGL(k_lazy_restart, dim3(flat_grid(W, 4)), dim3(256), 0, st, *g, *m, *lz, flags, tmin_key, n_restarted);
   return check_launch("lazy_restart");

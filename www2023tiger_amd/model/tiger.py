@@ -526,18 +526,39 @@ class TIGE(nn.Module):
             number of nodes re-initialised by it."""
             from .restarters import StaticRestarter
             r = getattr(model, 'restarter_fn', None)
-            if not isinstance(r, StaticRestarter):
-                raise NotImplementedError('the in-step lazy restart is built for the static restarter; '
-                                          'use TIGER.restart() from the loop for the sequence restarter')
+            if r is None:
+                raise NotImplementedError('the lazy-restart loop needs a model with a restarter (TIGER)')
             dev = model.device
             self.lazy_trigger = torch.as_tensor(trigger).to(dev, torch.uint8).contiguous()
             self.lazy_batch = torch.zeros(1, dtype=torch.int64, device=dev)
             self.lazy_restarting = torch.zeros(1, dtype=torch.int32, device=dev)
             self.lazy_uptodate = torch.zeros(hip_ops.bitmap_words(model.n_nodes), dtype=torch.int64, device=dev)
-            self._lazy = TgLazyRestart(ptr(r.left_emb.weight), ptr(r.right_emb.weight), ptr(self.lazy_trigger),
-                                       self.lazy_trigger.numel(), ptr(self.lazy_batch), ptr(self.lazy_restarting),
-                                       ptr(self.lazy_uptodate))
-            self.io.lazy = C.addressof(self._lazy)
+            if isinstance(r, StaticRestarter):  # the whole loop body runs inside the step
+                self._lazy = TgLazyRestart(ptr(r.left_emb.weight), ptr(r.right_emb.weight), ptr(self.lazy_trigger),
+                                           self.lazy_trigger.numel(), ptr(self.lazy_batch), ptr(self.lazy_restarting),
+                                           ptr(self.lazy_uptodate), None, None)
+                self.io.lazy = C.addressof(self._lazy)
+                return self
+            # Any other restarter (the SeqRestarter of the reference's default recipe, init_utils.py:55-58): the LIST form.
+            # The loop's bookkeeping - trigger, uptodate / has-message bitmaps, involved & ~uptodate - runs on the device in
+            # a collate-only pass; the host reads back ONE count, runs restarter + tg_restart_apply on the device-resident
+            # list and then launches the step (TIGE.launch_step).  No node list crosses the host link, no Python sets.
+            cap = min(3 * self.B * (model.n_neighbors + 1), model.n_nodes)
+            self.lazy_list = torch.zeros(max(cap, 1), dtype=torch.int64, device=dev)
+            self.lazy_tmin = torch.zeros(1, dtype=torch.float32, device=dev)
+            self.lazy_restarted = 0  # nodes re-initialised before the last step (the step's own counts[3] stays 0)
+            self._lazy = TgLazyRestart(None, None, ptr(self.lazy_trigger), self.lazy_trigger.numel(), ptr(self.lazy_batch),
+                                       ptr(self.lazy_restarting), ptr(self.lazy_uptodate), ptr(self.lazy_list),
+                                       ptr(self.lazy_tmin))
+            cb = TIGE.StepBuffers(model, self.B, False, resident=(self.src, self.dst, self.neg, self.ts, self.eids))
+            if self.offset is not None:  # the same batch as the step that follows: its device-side offset, not advanced
+                cb.offset = self.offset
+                cb.io.offset_dev = ptr(self.offset)
+            cb.io.advance = 0
+            cb.io.collate_only = 1
+            cb.io.lazy = C.addressof(self._lazy)
+            self._lazy_collate = cb
+            self._lazy_host = torch.zeros(2, dtype=torch.float32).pin_memory() if dev.type == 'cuda' else None
             return self
 
         def load(self, src, dst, neg, ts, eids):
@@ -584,11 +605,24 @@ class TIGE(nn.Module):
         if self.n_layers != 1:
             raise NotImplementedError('the fused step is built for n_layers == 1; use contrast_learning (operator path)')
         buf.io.rows_hint = self.rows_bound()
+        self.check_graph(self.graph)
+        g = self.graph.tcsr
+        cb = getattr(buf, '_lazy_collate', None)
+        if cb is not None:  # lazy-restart loop, list form (see StepBuffers.enable_lazy_restart)
+            if self.device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('the lazy-restart loop with a sequence restarter reads one count back per batch: '
+                                   'it cannot be captured into a graph (the static restarter runs inside the step)')
+            m = self.model_struct()
+            check(lib.tg_stream_step(C.byref(m), C.byref(g), C.byref(cb.io), ptr(cb.ws), cb.ws.numel(),
+                                     stream_ptr(self.device)), 'tg_stream_step(lazy restart list)')
+            n = int(cb.counts[3].item())  # the one read-back of the loop
+            buf.lazy_restarted = n
+            if n:
+                self.restart(buf.lazy_list[:n], buf.lazy_tmin.expand(n))
+            buf.lazy_batch += 1
         if self._pending is not None and not buf.embed_only:
             self._sync_pending()
         m = self.model_struct()
-        self.check_graph(self.graph)
-        g = self.graph.tcsr
         check(lib.tg_stream_step(C.byref(m), C.byref(g), C.byref(buf.io), ptr(buf.ws), buf.ws.numel(),
                                  stream_ptr(self.device)), 'tg_stream_step')
 
