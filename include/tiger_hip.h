@@ -444,6 +444,14 @@ typedef struct tg_step_io {
    * honours it too (then `counts` is not written at all and the stream offset is advanced by the core launch). */
   int32_t lean;
   int32_t reserved3;
+  /* --n_layers 2 (tiger.py:29; data_loader.py:105-131; temporal_agg_modules.py:29-83).  NULL: one attention layer.
+   * Otherwise a tg_model that differs from the step's model only in its attention block: the weights of the SECOND
+   * layer (temporal_embedding_fn.fns[1]; attn_fused optional, as for the first).  The step then samples the second hop
+   * for every neighbour slot at the neighbour's own float32 timestamp (data_loader.py:131), counts those nodes among
+   * the involved ones, embeds the Q*K neighbour slots with that layer at the ROOT's query time
+   * (temporal_agg_modules.py:57-66) and feeds their embeddings to the first layer as the node part of its keys.
+   * Workspace: tg_stream_step_workspace_bytes2(m, B, 2). */
+  const struct tg_model* inner;
 } tg_step_io;
 
 /* The reference loop draws `np.random.rand() < restart_prob` before every batch but the first; a hit sets
@@ -489,6 +497,7 @@ const char* tg_profiler_stage_name(int stage);
 int tg_profiler_read(tg_profiler* p, float* ms_out);
 
 size_t tg_stream_step_workspace_bytes(const tg_model* m, int64_t B);
+size_t tg_stream_step_workspace_bytes2(const tg_model* m, int64_t B, int32_t n_layers); /* n_layers 1 or 2 */
 /* size of the leading workspace region that must be zero when a step starts */
 size_t tg_stream_step_zero_bytes(const tg_model* m, int64_t B);
 int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, void* ws, size_t ws_bytes,

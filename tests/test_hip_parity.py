@@ -368,21 +368,61 @@ def test_stream_fused_step_with_the_lazy_restart_loop_on_the_device(name, eager)
             check_state(model, z, tag)
 
 
-def test_two_layer_model_refuses_the_one_layer_fast_paths():
-    """--n_layers 2 runs on the operator path; the fused step, the pre-multiplied weights and the device training step
-    are built for one layer and say so instead of computing something else"""
+def test_two_layer_model_trains_on_the_operator_path_only():
+    """--n_layers 2 streams through the fused step (and with pre-multiplied weights, one blob per layer); the device
+    training step is built for one layer and says so instead of computing something else"""
     z = load('static_lr_d8_L2')
     cfg = parse_cfg(z)
     model, _, coll = build_hip_model(z, cfg)
     a = [z[k][:cfg['B']] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
-    with pytest.raises(NotImplementedError):
-        model.stream_step(*a)
-    with pytest.raises(NotImplementedError):
-        model.fuse_attention()
     model.train()
     s_t, d_t, n_t, t_t, e_t, _, cg = coll.collate_arrays(*a)
     with pytest.raises(NotImplementedError):
         model.contrast_learning(s_t, d_t, n_t, t_t, e_t, cg)
+
+
+@pytest.mark.parametrize('form', ['lazy', 'eager', 'eager-fused', 'eager-fused-lean'])
+@pytest.mark.parametrize('name', TWO_LAYER_FIXTURES)
+def test_stream_fused_step_two_layers(name, form):
+    """--n_layers 2 inside tg_stream_step (tg_step_io.inner): the second hop sampled in the step at the neighbours'
+    float32 timestamps (data_loader.py:128-131), the Q*K neighbour slots embedded with fns[1] at the root's query time
+    and fed to fns[0] as the node part of its keys (temporal_agg_modules.py:57-66) - against the reference's own two-layer
+    streams, restart and flush included; with the lazy / eager updater, pre-multiplied weights for both layers, and the
+    lean form (no involved set formed)."""
+    z = load(name)
+    cfg = parse_cfg(z)
+    model, g, coll = build_hip_model(z, cfg)
+    if 'eager' in form:
+        model.eager_updates()
+    if 'fused' in form:
+        model.fuse_attention()
+        assert model.model_struct(0).attn_fused and model.model_struct(1).attn_fused
+    lean = 'lean' in form
+    B = cfg['B']
+    restarting, uptodate = False, set()
+    for b in range(n_batches(z)):
+        sl = slice(b * B, min((b + 1) * B, len(z['src'])))
+        a = [z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        tag = f'b{b}'
+        if b == cfg.get('restart_at', -1):
+            restarting, uptodate = True, set()
+            model.msg_store.clear()
+        if restarting:
+            r = np.array(sorted(set(z[f'{tag}_involved'].tolist()) - uptodate), dtype=np.int64)
+            np.testing.assert_array_equal(r, z[f'{tag}_restart_nids'])
+            model.restart(torch.from_numpy(r).to(dev()), torch.full((len(r),), float(np.float32(a[3].min())), device=dev()))
+            uptodate.update(r.tolist())
+        buf = model.stream_step(*a, lean=lean)
+        nb = len(a[0])
+        counts = buf.counts.cpu().numpy()
+        np.testing.assert_array_equal(buf.l1_nids.cpu().numpy(), z[f'{tag}_l1_nids'])
+        if not lean:
+            np.testing.assert_array_equal(buf.involved.cpu().numpy()[:counts[0]], z[f'{tag}_involved'])  # hop 2 included
+        assert_close(buf.h[:2 * nb].cpu().numpy(), z[f'{tag}_h_left'], 'h_left', TOL)
+        if f'{tag}_left_vals' in z.files:
+            check_state(model, z, tag)
+    model.flush_msg()
+    check_state(model, z, 'flushed')
 
 
 def test_no_feat_buffer_reads_pinned_host_tables():

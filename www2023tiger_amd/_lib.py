@@ -70,6 +70,7 @@ class TgStepIo(C.Structure):
         ('h_prev_left', vp), ('h_prev_right', vp), ('err', vp),
         ('offset_dev', vp), ('advance', i32), ('embed_only', i32), ('profiler', vp), ('h_new', vp),
         ('ws_is_clean', i32), ('rows_hint', i32), ('lazy', vp), ('collate_only', i32), ('eager_copy', i32), ('lean', i32), ('reserved3', i32),
+        ('inner', vp),
     ]
 
 
@@ -157,6 +158,7 @@ SIGNATURES = {
     'tg_profiler_stage_name': (C.c_char_p, [C.c_int]),
     'tg_profiler_read': (C.c_int, [vp, vp]),
     'tg_stream_step_workspace_bytes': (sz, [P(TgModel), i64]),
+    'tg_stream_step_workspace_bytes2': (sz, [P(TgModel), i64, i32]),
     'tg_stream_step_zero_bytes': (sz, [P(TgModel), i64]),
     'tg_stream_step': (C.c_int, [P(TgModel), P(TgTcsr), P(TgStepIo), vp, sz, vp]),
     'tg_train_step_workspace_bytes': (sz, [P(TgModel), P(TgScoreParams), i32, vp, i64]),

@@ -238,6 +238,10 @@ int sample_batch_launch(const tg_tcsr* g, int64_t B, const int64_t* src, const i
                         const double* ts, const int64_t* eids, const int64_t* off, int32_t K, int64_t* nids3,
                         float* ts3f, int64_t* eids_b, int64_t* o_nbr, int64_t* o_eid, float* o_ts, uint8_t* mark,
                         hipStream_t st, uint32_t* tmin_key = nullptr, const CentresRider* rider = nullptr);
+// recent-edges sampler over float32 query times (the second hop of --n_layers 2 is sampled at the neighbours' own
+// float32 timestamps, data_loader.py:131); marks the sampled ids in `mark` when given
+int sample_edges_f32_launch(const tg_tcsr* g, int64_t Q, const int64_t* nids, const float* ts, int32_t K, int64_t* o_nbr,
+                            int64_t* o_eid, float* o_ts, uint8_t* mark, hipStream_t st);
 // the lazy-restart loop body of train_self_supervised.py:152-163 with the static restarter (tiger_hip.h: tg_lazy_restart);
 // runs between the sampler (flags, *tmin_key) and the compaction
 int lazy_restart_launch(const tg_tcsr* g, const tg_model* m, const tg_lazy_restart* lz, const uint8_t* flags,

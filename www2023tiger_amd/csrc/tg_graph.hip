@@ -151,13 +151,14 @@ __global__ void __launch_bounds__(256) k_sample_recent_edges(tg_tcsr g, int64_t 
                                                              const double* __restrict__ qts, int K,
                                                              int64_t* __restrict__ o_nbr, int64_t* __restrict__ o_eid,
                                                              float* __restrict__ o_ts, int64_t* __restrict__ o_dir,
-                                                             uint8_t* __restrict__ mark) {
+                                                             uint8_t* __restrict__ mark,
+                                                             const float* __restrict__ qts32 = nullptr) {
   constexpr int GPB = 256 / G;
   const int sub = threadIdx.x % G;
   for (int64_t q = (int64_t)blockIdx.x * GPB + threadIdx.x / G; q < Q; q += (int64_t)gridDim.x * GPB) {
     const int64_t nid = nids[q];
     int64_t start;
-    const int64_t end = prefix_end_group<G>(g, nid, qts[q], &start, sub);
+    const int64_t end = prefix_end_group<G>(g, nid, qts ? qts[q] : (double)qts32[q], &start, sub);
     for (int j = sub; j < K; j += G) {
       const int64_t p = end - K + j;
       int64_t nb = 0, ed = 0, dr = 0;
@@ -669,6 +670,18 @@ extern "C" int tg_sample_recent_edges(const tg_tcsr* g, int64_t Q, const int64_t
                        o_nbr, o_eid, o_ts, o_dir, mark);
   }
   return check_launch("tg_sample_recent_edges");
+}
+
+int tg::sample_edges_f32_launch(const tg_tcsr* g, int64_t Q, const int64_t* nids, const float* ts, int32_t K, int64_t* o_nbr,
+                                int64_t* o_eid, float* o_ts, uint8_t* mark, hipStream_t st) {
+  if (Q <= 0) return TG_OK;
+  if (K <= 16)
+    hipLaunchKernelGGL(k_sample_recent_edges<16>, dim3(flat_grid(Q, 256 / 16)), dim3(256), 0, st, *g, Q, nids,
+                       (const double*)nullptr, K, o_nbr, o_eid, o_ts, (int64_t*)nullptr, mark, ts);
+  else
+    hipLaunchKernelGGL(k_sample_recent_edges<64>, dim3(flat_grid(Q, 256 / 64)), dim3(256), 0, st, *g, Q, nids,
+                       (const double*)nullptr, K, o_nbr, o_eid, o_ts, (int64_t*)nullptr, mark, ts);
+  return check_launch("sample_edges_f32");
 }
 
 extern "C" int tg_sample_recent_nodes(const tg_tcsr* g, int64_t Q, const int64_t* nids, const double* ts, int32_t K,

@@ -482,14 +482,15 @@ static void launch_centres(const tg_model* m, int64_t Q, const int64_t* nids, co
 static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids, const float* ts,
                               const int64_t* l1_nids, const int64_t* l1_eids, const float* l1_ts, const float* reprs,
                               const uint64_t* bm, const uint32_t* rank, float* out, const AttnWs& w, hipStream_t st,
-                              tg_profiler* pf, const PosArgs* pos, const DirectArgs* da, bool centres_done) {
+                              tg_profiler* pf, const PosArgs* pos, const DirectArgs* da, bool centres_done,
+                              const float* key_rows) {
   // stage numbering of the profiler is kept: q -> "merged q+g", g -> skipped, v/out -> skipped, fc1 -> fused
   int stage = ST_ATTN_FIRST + 1;
   const int d = m->d;
   const FusedView f = fused_view(m, m->attn_fused);
   if (!centres_done) launch_centres(m, Q, nids, reprs, bm, rank, w, pos, da, st);  // else: rode on the sampler's launch
   int rc;
-  if (attn_tile_applies(m)) {  // the whole block in one launch, G and S in LDS only (tg_attn_tile.hip); timed as the core
+  if (attn_tile_applies(m) && !key_rows) {  // the whole block in one launch, G and S in LDS only (tg_attn_tile.hip); timed as the core
     prof_mark(pf, stage++, st);
     prof_mark(pf, stage++, st);
     prof_mark(pf, stage++, st);
@@ -509,7 +510,8 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
   prof_mark(pf, stage++, st);
   tg_model mc = *m;  // without an edge table the fused weights are compact: the key rows have no edge segment
   if (!m->efeats) mc.d_e = 0;
-  launch_attn_core(&mc, Q, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, w, DropCfg{}, st, &rc, da ? 1 : 0, da ? pos : nullptr);
+  launch_attn_core(&mc, Q, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, w, DropCfg{}, st, &rc, da ? 1 : 0, da ? pos : nullptr,
+                   key_rows);
   if (rc != TG_OK) return rc;
   prof_mark(pf, stage++, st);
   prof_mark(pf, stage++, st);
@@ -548,8 +550,9 @@ int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float*
   int stage = ST_ATTN_FIRST;
   prof_mark(pf, stage++, st);
   const int d = m->d, d_e = m->d_e, kvw = 2 * d + d_e, nh = m->n_head, dh = 2 * d / nh, E = 2 * d;
-  if (m->attn_fused && dc.p == 0.f && !key_rows)
-    return attn_forward_fused(m, Q, nids, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, out, w, st, pf, pos, da, centres_done);
+  if (m->attn_fused && dc.p == 0.f)  // (the pre-multiplied weights do not care where the node part of a key row comes from)
+    return attn_forward_fused(m, Q, nids, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, out, w, st, pf, pos, da, centres_done,
+                              key_rows);
   const int qblocks = (int)cdiv(2 * d, 4);
   if (da) {  // the constant half of the query projection from the rank-form kernel (no centre rows), then the direct centres
     hipLaunchKernelGGL(k_attn_centres, dim3(1 + qblocks), dim3(256), 0, st, (int64_t)0, d / 4, nids, (const float4*)reprs, bm,
@@ -882,8 +885,15 @@ extern "C" int tg_profiler_read(tg_profiler* p, float* ms_out) {
 }
 
 namespace tg {
-bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w) {
-  const int64_t Q = 3 * B, K = m->n_neighbors, cap = Q * (K + 1);
+// capacity of the involved-node lists: every slot of the computation graph, or - two layers, where that is Q (1 + K + K^2)
+// slots - every node id if that is fewer
+static int64_t involved_cap(const tg_model* m, int64_t B, int n_layers) {
+  const int64_t Q = 3 * B, K = m->n_neighbors;
+  return n_layers == 2 ? std::min<int64_t>(Q * (1 + K + K * K), std::max<int64_t>(m->n_nodes, 1)) : Q * (K + 1);
+}
+
+bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w, int n_layers) {
+  const int64_t Q = 3 * B, K = m->n_neighbors, cap = involved_cap(m, B, n_layers);
   const int64_t W = (m->n_nodes + 63) / 64;
   char* z0 = cv.p;
   w.flags = cv.take<uint8_t>((size_t)W * 64);
@@ -915,18 +925,35 @@ bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w) {
   w.apply_bytes = apply_ws_bytes(m, cap);
   w.apply_ws = cv.take<char>(w.apply_bytes);
   w.best_id = cv.take<unsigned long long>((size_t)m->n_nodes);  // lean steps: dedup slots indexed by node id (kept zero)
+  if (n_layers == 2) {
+    const size_t Q2 = (size_t)Q * K;
+    w.h2n = cv.take<int64_t>(Q2 * K);
+    w.h2e = cv.take<int64_t>(Q2 * K);
+    w.h2t = cv.take<float>(Q2 * K);
+    w.ts2 = cv.take<float>(Q2);
+    w.emb2 = cv.take<float>(Q2 * m->d);
+    if (!carve_attn(m, (int64_t)Q2, cv, w.attn2)) return false;
+  }
   return cv.ok;
 }
 }  // namespace tg
 
+extern "C" size_t tg_stream_step_workspace_bytes2(const tg_model* m, int64_t B, int32_t n_layers);
 extern "C" size_t tg_stream_step_workspace_bytes(const tg_model* m, int64_t B) {
-  if (!attn_dims_ok(m) || B <= 0 || m->n_nodes <= 0) return 0;
-  const size_t Q = 3 * (size_t)B, K = m->n_neighbors, cap = Q * (K + 1), W = (m->n_nodes + 63) / 64;
+  return tg_stream_step_workspace_bytes2(m, B, 1);
+}
+extern "C" size_t tg_stream_step_workspace_bytes2(const tg_model* m, int64_t B, int32_t n_layers) {
+  if (!attn_dims_ok(m) || B <= 0 || m->n_nodes <= 0 || (n_layers != 1 && n_layers != 2)) return 0;
+  const size_t Q = 3 * (size_t)B, K = m->n_neighbors, cap = (size_t)involved_cap(m, B, n_layers), W = (m->n_nodes + 63) / 64;
   size_t b = align16(W * 64) + align16(W * 8) + align16(cap * 8) + 32 + 2 * align16((W + 1) * 4) + align16(2 * B * 4) +
              align16(2 * B * m->d * 4) + align16(2 * B * 4) + align16(Q * 8) * 2 + align16(B * 8) +
              align16(Q * 4) + align16(Q * K * 8) * 2 + align16(Q * K * 4) + align16(cap * 8) * 2 + align16(cap * 4) +
              align16(2 * B * 8) * 2 + align16(cap * m->d * 4) + align16(tg_unique_compact_workspace_bytes(m->n_nodes)) +
              attn_ws_bytes(m, Q) + align16(apply_ws_bytes(m, cap)) + align16((size_t)m->n_nodes * 8);
+  if (n_layers == 2) {
+    const size_t Q2 = Q * K;
+    b += align16(Q2 * K * 8) * 2 + align16(Q2 * K * 4) + align16(Q2 * 4) + align16(Q2 * m->d * 4) + attn_ws_bytes(m, Q2);
+  }
   return b + 256;
 }
 
@@ -937,10 +964,15 @@ extern "C" size_t tg_stream_step_zero_bytes(const tg_model* m, int64_t B) {
 }
 
 namespace tg {
+__global__ void k_slot_times(int64_t n, int K, const float* __restrict__ ts, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = ts[i / K];
+}
+
 int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, StepWs& w, float* gates, hipStream_t st,
                  tg_profiler* pf, const DropCfg* drop, bool eager) {
   w.eager = eager;
-  const int64_t B = io->B, Q = 3 * B, K = m->n_neighbors, cap = Q * (K + 1);
+  const tg_model* inner = w.h2n ? io->inner : nullptr;  // two attention layers (the workspace was carved for them)
+  const int64_t B = io->B, Q = 3 * B, K = m->n_neighbors, cap = involved_cap(m, B, inner ? 2 : 1);
   prof_mark(pf, ST_QUERIES, st);
   hipError_t e = hipSuccess;
   int rc;
@@ -985,6 +1017,10 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
                                 w.ts3f, w.eids, w.l1n, w.l1e, w.l1t, w.lean ? nullptr : w.flags, st,
                                 lz ? reinterpret_cast<uint32_t*>(w.counts + 4) : nullptr, w.lean ? &rider : nullptr)) != TG_OK)
     return rc;
+  // second hop (data_loader.py:128-131): every neighbour slot (padding included) queried at its own float32 timestamp
+  if (inner && (rc = sample_edges_f32_launch(g, Q * K, w.l1n, w.l1t, (int32_t)K, w.h2n, w.h2e, w.h2t,
+                                             w.lean ? nullptr : w.flags, st)) != TG_OK)
+    return rc;
   // lazy restart (train_self_supervised.py:152-163): before STEP 1, because a restarted node loses its pending message
   if (lz && (rc = lazy_restart_launch(g, m, lz, w.flags, reinterpret_cast<const uint32_t*>(w.counts + 4), w.counts + 3,
                                       st)) != TG_OK)
@@ -1010,8 +1046,22 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
                            st, true, gates, io->rows_hint)) != TG_OK)
     return rc;
   // ---- STEP 3: temporal embeddings of cat[src, dst, neg]
+  const float* key_rows = nullptr;
+  if (inner) {
+    // the Q*K neighbour slots embedded with the second layer over their own neighbours, at the ROOT's query time
+    // (temporal_agg_modules.py:57-66); padding slots (node 0) are embedded too and masked by the first layer
+    const int64_t Q2 = Q * K;
+    hipLaunchKernelGGL(k_slot_times, dim3(flat_grid(Q2, 256)), dim3(256), 0, st, Q2, (int)K, (const float*)w.ts3f, w.ts2);
+    const DirectArgs da2{nullptr, w.counts + 1, cap, io->err, nullptr, nullptr, 0, w.lean ? 1 : 0};
+    PosArgs pos2{};  // no dedup rides on the inner launches; lean: the neighbours' time invariants still do
+    pos2.chk_err = w.lean ? io->err : nullptr;
+    if ((rc = attn_forward(inner, Q2, w.l1n, w.ts2, w.h2n, w.h2e, w.h2t, w.reprs, w.bm, w.rank, w.emb2, w.attn2, st, nullptr,
+                           drop, w.direct ? &pos2 : nullptr, w.direct ? &da2 : nullptr, nullptr, false)) != TG_OK)
+      return rc;
+    key_rows = w.emb2;
+  }
   if ((rc = attn_forward(m, Q, w.nids3, w.ts3f, w.l1n, w.l1e, w.l1t, w.reprs, w.bm, w.rank, io->h, w.attn, st, pf,
-                         drop, pp, w.direct ? &da : nullptr, nullptr, w.lean)) != TG_OK)
+                         drop, pp, w.direct ? &da : nullptr, key_rows, w.lean)) != TG_OK)
     return rc;
   prof_mark(pf, ST_DEDUP, st);
   if (io->h_new) {  // h(t'+) rows of cat[src, dst]: reprs[local(node)], or the table rows themselves
@@ -1116,7 +1166,7 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
   tg_profiler* pf = (tg_profiler*)io->profiler;
   Carver cv(ws, ws_bytes);
   StepWs w{};
-  if (!carve_step(m, io->B, cv, w)) return TG_EWORKSPACE;
+  if (!carve_step(m, io->B, cv, w, io->inner ? 2 : 1)) return TG_EWORKSPACE;
   int rc;
   // eager updates need the full step (the updater launch at its end keeps the table current)
   // embed_only still GATHERS the precomputed rows when the table is there (the partitioned multi-GPU path keeps it

@@ -126,6 +126,7 @@ class TIGE(nn.Module):
     def _apply(self, fn, *a, **kw):  # .to() / .cuda() move every tensor: pointers change
         self._struct_cache = None
         self._fused = None
+        self._fused_l1 = None
         self._pending = None
         self._pending_stamp = None
         self._step_ws = {}
@@ -146,14 +147,20 @@ class TIGE(nn.Module):
         """tg_model view of this module's tensors (cached until tensors are re-homed).  layer: which attention layer's
         weights the struct carries (temporal_embedding_fn.fns[layer]; only the two-layer operator path asks for 1)."""
         if layer:
-            m = TgModel.from_buffer_copy(self.model_struct())  # ctypes structs with pointers do not copy.copy
+            base = self.model_struct()
+            hit = getattr(self, '_struct_cache_l1', None)
+            if hit is not None and hit[0] is base:
+                return hit[1]
+            m = TgModel.from_buffer_copy(base)  # ctypes structs with pointers do not copy.copy
             att = self.temporal_embedding_fn.fns[layer]
             lin = lambda l: TgLinear(ptr(l.weight), ptr(l.bias))
             mha = att.mha_fn
             m.attn_wq, m.attn_wk, m.attn_wv, m.attn_b_in = (ptr(mha.q_proj_weight), ptr(mha.k_proj_weight),
                                                            ptr(mha.v_proj_weight), ptr(mha.in_proj_bias))
             m.attn_out, m.attn_fc1, m.attn_fc2 = lin(mha.out_proj), lin(att.merger.fc1), lin(att.merger.fc2)
-            m.attn_fused = None
+            f1 = getattr(self, '_fused_l1', None)
+            m.attn_fused = ptr(f1) if f1 is not None else None
+            self._struct_cache_l1 = (base, m)
             return m
         if self._struct_cache is not None:
             return self._struct_cache
@@ -248,20 +255,23 @@ class TIGE(nn.Module):
         embedding runs three products instead of six.  Call again after any parameter update; training
         ignores the fused weights."""
         self._fused = None
+        self._fused_l1 = None
         self._struct_cache = None
         if not enable:
             return self
-        if self.n_layers != 1:
-            raise NotImplementedError('pre-multiplied attention weights are built for n_layers == 1')
-        m = self.model_struct()
-        n = int(lib.tg_attn_fused_floats(C.byref(m)))
-        if n == 0:
-            raise RuntimeError('tg_attn_fuse: unsupported model dimensions')
-        fused = torch.empty(n, dtype=torch.float32, device=self.device)
-        nbytes = int(lib.tg_attn_fuse_workspace_bytes(C.byref(m)))
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        check(lib.tg_attn_fuse(C.byref(m), ptr(fused), ptr(ws), nbytes, stream_ptr(self.device)), 'tg_attn_fuse')
-        self._fused = fused
+        blobs = []
+        for layer in range(self.n_layers):  # every attention layer has its own weights (fns[layer])
+            m = self.model_struct(layer)
+            n = int(lib.tg_attn_fused_floats(C.byref(m)))
+            if n == 0:
+                raise RuntimeError('tg_attn_fuse: unsupported model dimensions')
+            fused = torch.empty(n, dtype=torch.float32, device=self.device)
+            nbytes = int(lib.tg_attn_fuse_workspace_bytes(C.byref(m)))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            check(lib.tg_attn_fuse(C.byref(m), ptr(fused), ptr(ws), nbytes, stream_ptr(self.device)), 'tg_attn_fuse')
+            blobs.append(fused)
+        self._fused = blobs[0]
+        self._fused_l1 = blobs[1] if len(blobs) > 1 else None
         self._struct_cache = None
         return self
 
@@ -504,7 +514,7 @@ class TIGE(nn.Module):
             self.h_new = h_new_out if h_new_out is not None else (
                 torch.zeros(2 * B, d, dtype=torch.float32, device=dev) if (embed_only and want_h_new) else None)
             m = model.model_struct()
-            nbytes = int(lib.tg_stream_step_workspace_bytes(C.byref(m), B))
+            nbytes = int(lib.tg_stream_step_workspace_bytes2(C.byref(m), B, model.n_layers))
             if nbytes == 0:
                 raise RuntimeError('tg_stream_step: unsupported model dimensions')
             self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)  # zero-filled: the step keeps it clean
@@ -602,8 +612,9 @@ class TIGE(nn.Module):
 
     def launch_step(self, buf: 'TIGE.StepBuffers'):
         """Enqueue collate + STEP 1-6 for the batch already in `buf` (no host sync)."""
-        if self.n_layers != 1:
-            raise NotImplementedError('the fused step is built for n_layers == 1; use contrast_learning (operator path)')
+        if self.n_layers == 2:  # the second attention layer's weights travel in a tg_model of their own
+            buf._inner = self.model_struct(1)
+            buf.io.inner = C.addressof(buf._inner)
         buf.io.rows_hint = self.rows_bound()
         self.check_graph(self.graph)
         g = self.graph.tcsr
