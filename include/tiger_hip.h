@@ -443,7 +443,11 @@ typedef struct tg_step_io {
    * without the lazy-restart loop and the h_prev_* outputs); ignored otherwise.  Same results.  An embed_only step
    * honours it too (then `counts` is not written at all and the stream offset is advanced by the core launch). */
   int32_t lean;
-  int32_t reserved3;
+  /* Graph.sample_temporal_neighbor's strategy for the neighbours of the batch (graph.py:94-148; init_utils.py:40):
+   * 0 = recent_edges (the default recipe), 1 = recent_nodes (last occurrence of each distinct neighbour, graph.py:129-143).
+   * `uniform` consumes the graph's MT19937 stream query by query (graph.py:101-108) and is served by tg_sample_uniform on
+   * the operator path only.  recent_nodes: not together with `lazy` or `inner`. */
+  int32_t strategy;
   /* --n_layers 2 (tiger.py:29; data_loader.py:105-131; temporal_agg_modules.py:29-83).  NULL: one attention layer.
    * Otherwise a tg_model that differs from the step's model only in its attention block: the weights of the SECOND
    * layer (temporal_embedding_fn.fns[1]; attn_fused optional, as for the first).  The step then samples the second hop

@@ -662,6 +662,46 @@ def test_c2_lazy_and_eager_updates_agree():
     assert torch.equal(eager.msg_store.has_msg_bits, lazy.msg_store.has_msg_bits)
 
 
+@pytest.mark.parametrize('lean', [False, True], ids=['full', 'lean'])
+def test_fused_step_with_the_recent_nodes_strategy_matches_oracle(lean):
+    """--strategy recent_nodes (graph.py:129-143: the last occurrence of each distinct neighbour) inside tg_stream_step
+    (tg_step_io.strategy = 1): neighbour lists bit-exact, embeddings and state against the oracle collating with the same
+    strategy; `uniform` is refused by the step (it runs on the operator path)."""
+    import bench
+    from oracle import tiger_oracle as O
+    from www2023tiger_amd.data.graph import Graph
+    c = bench.C2
+    B, K, d, nb = 512, c['K'], 64, 8
+    stream = bench.make_stream(600, 80, (nb + 1) * B, 3.0e4, seed=31, d_e=d)   # few nodes: neighbours repeat a lot
+    model, orc = bench.build_models(stream, d, K, c['msg_src'], c['upd_src'], with_oracle=True)
+    model.graph = Graph.from_arrays(stream['src'], stream['dst'], stream['ts'], stream['eids'], strategy='recent_nodes',
+                                    seed=0, max_node_id=stream['n_nodes'] - 1, device=dev())
+    orc.graph = O.OracleGraph(stream['src'], stream['dst'], stream['ts'], stream['eids'], strategy='recent_nodes',
+                              max_node_id=stream['n_nodes'] - 1)
+    model.fuse_attention()
+    model.eager_updates()
+    differs = False
+    for b in range(nb):
+        a = [stream[k][b * B:(b + 1) * B] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], K, 'static')
+        ref = orc.stream_step(*a, cg).numpy()
+        buf = model.stream_step(*a, lean=lean)
+        np.testing.assert_array_equal(buf.l1_nids.cpu().numpy(), cg['l1_nids'])
+        np.testing.assert_array_equal(buf.l1_eids.cpu().numpy(), cg['l1_eids'])
+        np.testing.assert_array_equal(buf.l1_ts.cpu().numpy(), cg['l1_ts'])
+        if not lean:
+            cnt = buf.counts.cpu().numpy()
+            np.testing.assert_array_equal(buf.involved.cpu().numpy()[:cnt[0]], cg['involved'])
+        assert_close(buf.h[:2 * B].cpu().numpy(), ref, 'h_left', TOL)
+        edges = orc.graph.sample_temporal_neighbor(np.concatenate(a[:3]), np.tile(a[3], 3), K, strategy='recent_edges')[0]
+        differs = differs or not np.array_equal(edges, cg['l1_nids'])
+    assert differs  # the two strategies really sample different lists on this stream
+    compare_state_with_oracle(model, orc)
+    model.graph.strategy = 'uniform'
+    with pytest.raises(NotImplementedError):
+        model.stream_step(*a)
+
+
 @pytest.mark.parametrize('B', [1200, 683, 200])
 def test_stream_k_piece_sums_with_uneven_row_tiles(B):
     """The merged fc1 product runs as stream-K pieces whenever it has 128..255 tiles (C2: 144).  B = 1200 gives

@@ -69,7 +69,7 @@ class TgStepIo(C.Structure):
         ('h', vp), ('l1_nids', vp), ('l1_eids', vp), ('l1_ts', vp), ('involved', vp), ('counts', vp),
         ('h_prev_left', vp), ('h_prev_right', vp), ('err', vp),
         ('offset_dev', vp), ('advance', i32), ('embed_only', i32), ('profiler', vp), ('h_new', vp),
-        ('ws_is_clean', i32), ('rows_hint', i32), ('lazy', vp), ('collate_only', i32), ('eager_copy', i32), ('lean', i32), ('reserved3', i32),
+        ('ws_is_clean', i32), ('rows_hint', i32), ('lazy', vp), ('collate_only', i32), ('eager_copy', i32), ('lean', i32), ('strategy', i32),
         ('inner', vp),
     ]
 

@@ -242,6 +242,9 @@ int sample_batch_launch(const tg_tcsr* g, int64_t B, const int64_t* src, const i
 // float32 timestamps, data_loader.py:131); marks the sampled ids in `mark` when given
 int sample_edges_f32_launch(const tg_tcsr* g, int64_t Q, const int64_t* nids, const float* ts, int32_t K, int64_t* o_nbr,
                             int64_t* o_eid, float* o_ts, uint8_t* mark, hipStream_t st);
+// recent-nodes sampler (graph.py:129-143) over prepared query arrays; marks queries and neighbours in `mark` when given
+int sample_nodes_launch(const tg_tcsr* g, int64_t Q, const int64_t* nids, const double* ts, int32_t K, int64_t* o_nbr,
+                        int64_t* o_eid, float* o_ts, uint8_t* mark, hipStream_t st);
 // the lazy-restart loop body of train_self_supervised.py:152-163 with the static restarter (tiger_hip.h: tg_lazy_restart);
 // runs between the sampler (flags, *tmin_key) and the compaction
 int lazy_restart_launch(const tg_tcsr* g, const tg_model* m, const tg_lazy_restart* lz, const uint8_t* flags,

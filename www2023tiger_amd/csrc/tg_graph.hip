@@ -672,6 +672,25 @@ extern "C" int tg_sample_recent_edges(const tg_tcsr* g, int64_t Q, const int64_t
   return check_launch("tg_sample_recent_edges");
 }
 
+namespace tg {
+__global__ void k_mark_lists(int64_t Q, int K, const int64_t* __restrict__ nids, const int64_t* __restrict__ nbr,
+                             uint8_t* __restrict__ mark) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < Q * (K + 1); i += (int64_t)gridDim.x * blockDim.x)
+    mark[i < Q ? nids[i] : nbr[i - Q]] = 1;  // byte flags, plain stores (padding id 0 included, as the sampler does)
+}
+}  // namespace tg
+int tg::sample_nodes_launch(const tg_tcsr* g, int64_t Q, const int64_t* nids, const double* ts, int32_t K, int64_t* o_nbr,
+                            int64_t* o_eid, float* o_ts, uint8_t* mark, hipStream_t st) {
+  if (Q <= 0) return TG_OK;
+  if (K > TG_WAVE) return TG_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_sample_recent_nodes, dim3(flat_grid(Q, 4)), dim3(256), 0, st, *g, Q, nids, ts, K, o_nbr, o_eid, o_ts,
+                     (int64_t*)nullptr);
+  if (mark)
+    hipLaunchKernelGGL(k_mark_lists, dim3(flat_grid(Q * (K + 1), 256)), dim3(256), 0, st, Q, (int)K, nids,
+                       (const int64_t*)o_nbr, mark);
+  return check_launch("sample_nodes");
+}
+
 int tg::sample_edges_f32_launch(const tg_tcsr* g, int64_t Q, const int64_t* nids, const float* ts, int32_t K, int64_t* o_nbr,
                                 int64_t* o_eid, float* o_ts, uint8_t* mark, hipStream_t st) {
   if (Q <= 0) return TG_OK;

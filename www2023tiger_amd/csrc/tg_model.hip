@@ -1013,9 +1013,19 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   // lean: the centres need nothing the sampler produces and share its launch
   const CentresRider rider{*m, (const float4*)m->nfeats, (float4*)w.attn.cc, da, pp ? pos : PosArgs{},
                            flat_grid(Q * (m->d / 4), 256)};
-  if ((rc = sample_batch_launch(g, B, io->src, io->dst, io->neg, io->ts, io->eids, io->offset_dev, (int32_t)K, w.nids3,
-                                w.ts3f, w.eids, w.l1n, w.l1e, w.l1t, w.lean ? nullptr : w.flags, st,
-                                lz ? reinterpret_cast<uint32_t*>(w.counts + 4) : nullptr, w.lean ? &rider : nullptr)) != TG_OK)
+  const bool recent_nodes = io->strategy == 1;
+  if (io->strategy != 0 && !recent_nodes) return TG_EUNSUPPORTED;
+  if (recent_nodes) {  // query arrays first, then the wave-per-query sampler of graph.py:129-143 and the involved flags
+    if (lz || inner) return TG_EUNSUPPORTED;
+    hipLaunchKernelGGL(k_build_queries, dim3(flat_grid(Q, 256)), dim3(256), 0, st, B, io->src, io->dst, io->neg, io->ts,
+                       io->eids, (const int64_t*)io->offset_dev, w.nids3, w.ts3, w.ts3f, w.eids);
+    if ((rc = sample_nodes_launch(g, Q, w.nids3, w.ts3, (int32_t)K, w.l1n, w.l1e, w.l1t, w.lean ? nullptr : w.flags, st)) !=
+        TG_OK)
+      return rc;
+  } else if ((rc = sample_batch_launch(g, B, io->src, io->dst, io->neg, io->ts, io->eids, io->offset_dev, (int32_t)K,
+                                       w.nids3, w.ts3f, w.eids, w.l1n, w.l1e, w.l1t, w.lean ? nullptr : w.flags, st,
+                                       lz ? reinterpret_cast<uint32_t*>(w.counts + 4) : nullptr,
+                                       w.lean ? &rider : nullptr)) != TG_OK)
     return rc;
   // second hop (data_loader.py:128-131): every neighbour slot (padding included) queried at its own float32 timestamp
   if (inner && (rc = sample_edges_f32_launch(g, Q * K, w.l1n, w.l1t, (int32_t)K, w.h2n, w.h2e, w.h2t,
@@ -1061,7 +1071,7 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
     key_rows = w.emb2;
   }
   if ((rc = attn_forward(m, Q, w.nids3, w.ts3f, w.l1n, w.l1e, w.l1t, w.reprs, w.bm, w.rank, io->h, w.attn, st, pf,
-                         drop, pp, w.direct ? &da : nullptr, key_rows, w.lean)) != TG_OK)
+                         drop, pp, w.direct ? &da : nullptr, key_rows, w.lean && !recent_nodes)) != TG_OK)
     return rc;
   prof_mark(pf, ST_DEDUP, st);
   if (io->h_new) {  // h(t'+) rows of cat[src, dst]: reprs[local(node)], or the table rows themselves

@@ -612,6 +612,11 @@ class TIGE(nn.Module):
 
     def launch_step(self, buf: 'TIGE.StepBuffers'):
         """Enqueue collate + STEP 1-6 for the batch already in `buf` (no host sync)."""
+        strategy = getattr(self.graph, 'strategy', 'recent_edges')
+        if strategy not in ('recent_edges', 'recent_nodes'):
+            raise NotImplementedError(f"the fused step samples 'recent_edges' or 'recent_nodes'; strategy={strategy!r} (its "
+                                      'draws walk the graph\'s MT19937 stream query by query) runs on the operator path')
+        buf.io.strategy = 1 if strategy == 'recent_nodes' else 0
         if self.n_layers == 2:  # the second attention layer's weights travel in a tg_model of their own
             buf._inner = self.model_struct(1)
             buf.io.inner = C.addressof(buf._inner)
