@@ -702,6 +702,38 @@ def test_fused_step_with_the_recent_nodes_strategy_matches_oracle(lean):
         model.stream_step(*a)
 
 
+def test_derived_tables_follow_in_place_writes_to_state_and_parameters():
+    """The eager-update table and the pre-multiplied attention weights are functions of state / parameters.  In-place torch
+    writes to a memory tensor, to the mailbox, to an updater weight or to an attention weight between steps (no
+    Memory.set, no invalidate_pending(), no second fuse_attention()) are seen through the tensors' version counters and
+    the derived tables are rebuilt: the eager + fused model keeps agreeing with a lazy, unfused one given the same
+    writes."""
+    import bench
+    c = bench.C2
+    B = 256
+    stream = bench.make_stream(c['n_u'], c['n_i'], 12 * B, c['T'] * 12 * B / c['E'], seed=33, d_e=c['d'])
+    plain, _ = bench.build_models(stream, c['d'], c['K'], c['msg_src'], c['upd_src'])
+    fast, _ = bench.build_models(stream, c['d'], c['K'], c['msg_src'], c['upd_src'])
+    fast.eager_updates()
+    fast.fuse_attention()
+    for b in range(10):
+        a = [stream[k][b * B:(b + 1) * B] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        for m in (plain, fast):
+            if b == 3:   # state written behind the model's back, through plain torch indexing
+                v = torch.as_tensor(a[0][:7], device=dev())
+                m.left_memory.vals[v] *= 0.5
+                m.right_memory.vals[v] += 0.25
+            if b == 5:   # an "optimizer step" on the updater and on the attention block
+                with torch.no_grad():
+                    m.right_mem_updater.cell.weight_hh.mul_(1.05)
+                    m.temporal_embedding_fn.fns[0].merger.fc2.weight.add_(0.01)
+                    m.time_encoder.phase.add_(0.05)
+        h0, h1 = plain.stream_step(*a), fast.stream_step(*a)
+        assert_close(h1.h.cpu().numpy(), h0.h.cpu().numpy(), f'h, batch {b}', 2e-5)
+    assert_close(fast.left_memory.vals.cpu().numpy(), plain.left_memory.vals.cpu().numpy(), 'left memory', 2e-5)
+    assert_close(fast.right_memory.vals.cpu().numpy(), plain.right_memory.vals.cpu().numpy(), 'right memory', 2e-5)
+
+
 @pytest.mark.parametrize('B', [1200, 683, 200])
 def test_stream_k_piece_sums_with_uneven_row_tiles(B):
     """The merged fc1 product runs as stream-K pieces whenever it has 128..255 tiles (C2: 144).  B = 1200 gives

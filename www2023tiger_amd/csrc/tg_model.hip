@@ -179,7 +179,9 @@ __device__ __forceinline__ RowVec<W> row_load_raw(const float* __restrict__ p) {
 //  * the range test of the time encoding (|x| <= 3e6: hardware cosine) is made once per key on a wave-uniform bound
 //    instead of per element;
 //  * the softmax exponentials are v_exp_f32 (arguments <= 0; ~2 ulp).
-template <int NH, int NV, int W>
+//  * FT = false: the model has neither a node-feature nor an edge-feature table (C4, C5): one gather per key instead of
+//    three, and twice as many keys in flight.
+template <int NH, int NV, int W, bool FT>
 __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const float* __restrict__ ts,
                                                    const int64_t* __restrict__ l1_nids,
                                                    const int64_t* __restrict__ l1_eids, const float* __restrict__ l1_ts,
@@ -266,17 +268,21 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
     // reduced in list order whatever PD is, so the result does not depend on it.
     // (measured: narrow rows, W = 2, gain from a fourth slot - C4 core 84 -> 78 us - and nothing from a fifth or sixth,
     // eight are slower; W = 4 is the same with three and four)
-    constexpr int PD = NV == 1 ? (W == 2 ? 4 : 3) : 2;
-    V ya[PD][NV], yn[PD][NV], yb[PD][NV];
+    constexpr int PD = FT ? (NV == 1 ? (W == 2 ? 4 : 3) : 2) : (NV == 1 ? 6 : 3);
+    constexpr int PF = FT ? PD : 1;  // slots of the feature rows (none without tables)
+    V ya[PD][NV], yn[PF][NV], yb[PF][NV];
     auto fetch = [&](int slot, int k) {
       const float* pn = bcast_ptr(pn_l, k);
-      const float* pf = bcast_ptr(pf_l, k);
-      const float* pe = bcast_ptr(pe_l, k);
 #pragma unroll
-      for (int v = 0; v < NV; ++v) {
-        ya[slot][v] = row_load_raw<W>(pn + coff[v]);
-        yn[slot][v] = row_load_raw<W>(pf + coff[v]);
-        yb[slot][v] = row_load_raw<W>(pe + eoff[v]);
+      for (int v = 0; v < NV; ++v) ya[slot][v] = row_load_raw<W>(pn + coff[v]);
+      if (FT) {
+        const float* pf = bcast_ptr(pf_l, k);
+        const float* pe = bcast_ptr(pe_l, k);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          yn[slot][v] = row_load_raw<W>(pf + coff[v]);
+          yb[slot][v] = row_load_raw<W>(pe + eoff[v]);
+        }
       }
     };
     auto reduce = [&](int slot, int k) {
@@ -289,8 +295,8 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
         const int c = (lane + v * TG_WAVE) * W;
 #pragma unroll
         for (int j = 0; j < W; ++j) {
-          x[0][v].a[j] = fmaf(fmask, yn[slot][v].a[j], ya[slot][v].a[j]);
-          x[1][v].a[j] = emask * yb[slot][v].a[j];
+          x[0][v].a[j] = FT ? fmaf(fmask, yn[slot][v].a[j], ya[slot][v].a[j]) : ya[slot][v].a[j];
+          x[1][v].a[j] = FT ? emask * yb[slot][v].a[j] : 0.f;
         }
         if (small) {
 #pragma unroll
@@ -451,10 +457,18 @@ void launch_attn_core(const tg_model* m, int64_t Q, const float* ts, const int64
   const unsigned cgrid = flat_grid(Q, 4);
   const float* zl = zero_line();
   if (!zl) { *rc_out = TG_EHIP; return; }
-#define TG_CORE(NH_, NV_, W_)                                                                                      \
-  hipLaunchKernelGGL((k_attn_core<NH_, NV_, W_>), dim3(cgrid), dim3(256), 0, st, *m, Q, ts, l1_nids, l1_eids,      \
-                     l1_ts, reprs, bm, rank, (const float*)w.g, w.s, w.valid, dc,                                  \
-                     dc.p > 0.f ? w.rsum : (float*)nullptr, direct, pos ? *pos : PosArgs{}, key_rows, zl)
+  const bool ft = (m->nfeats && !key_rows) || m->efeats;
+#define TG_CORE(NH_, NV_, W_)                                                                                              \
+  do {                                                                                                                     \
+    if (ft)                                                                                                                \
+      hipLaunchKernelGGL((k_attn_core<NH_, NV_, W_, true>), dim3(cgrid), dim3(256), 0, st, *m, Q, ts, l1_nids, l1_eids,    \
+                         l1_ts, reprs, bm, rank, (const float*)w.g, w.s, w.valid, dc,                                      \
+                         dc.p > 0.f ? w.rsum : (float*)nullptr, direct, pos ? *pos : PosArgs{}, key_rows, zl);             \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((k_attn_core<NH_, NV_, W_, false>), dim3(cgrid), dim3(256), 0, st, *m, Q, ts, l1_nids, l1_eids,   \
+                         l1_ts, reprs, bm, rank, (const float*)w.g, w.s, w.valid, dc,                                      \
+                         dc.p > 0.f ? w.rsum : (float*)nullptr, direct, pos ? *pos : PosArgs{}, key_rows, zl);             \
+  } while (0)
   if (nh == 2 && nv == 1 && W == 2) TG_CORE(2, 1, 2);
   else if (nh == 1 && nv == 1 && W == 2) TG_CORE(1, 1, 2);
   else if (nh == 4 && nv == 1 && W == 2) TG_CORE(4, 1, 2);

@@ -157,6 +157,14 @@ class ShardedRunner:
         return h_left
 
 
+def _refuse_eager_table(model):
+    """The replicated layout writes back through tg_stream_writeback, which does not run the eager updater: a model with
+    the table of precomputed updater rows (TIGE.eager_updates) would embed from rows that are never refreshed."""
+    if getattr(model, '_pending', None) is not None:
+        raise RuntimeError('the replicated multi-GPU layout runs the lazy updater: build it on a model without '
+                           'eager_updates() (or use the partitioned layout, which keeps the table current)')
+
+
 class HipBackend:
     """The two halves on the HIP engine, driven with host arrays (ragged shards allowed):
     tg_stream_step(embed_only) and tg_stream_writeback."""
@@ -164,6 +172,7 @@ class HipBackend:
     def __init__(self, model, cap: int):
         from . import hip_ops
         from ._lib import TgWritebackIo, check, lib, ptr
+        _refuse_eager_table(model)
         self.model, self.cap = model, cap
         self.hip_ops, self.check, self.lib, self.ptr, self.WbIo = hip_ops, check, lib, ptr, TgWritebackIo
         self.buf = model.StepBuffers(model, cap, False, embed_only=True)
@@ -217,6 +226,7 @@ class ResidentShardedStream:
                  group=None, use_graphs: bool = True):
         from . import hip_ops
         from ._lib import TgWritebackIo, check, lib, ptr
+        _refuse_eager_table(model)
         self.model, self.rank, self.world, self.B, self.group = model, rank, world, B, group
         self.check, self.lib, self.ptr, self.hip_ops = check, lib, ptr, hip_ops
         dev, d = model.device, model.memory_dim

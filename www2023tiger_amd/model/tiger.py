@@ -124,13 +124,22 @@ class TIGE(nn.Module):
         return self.msg_memory.device
 
     def _apply(self, fn, *a, **kw):  # .to() / .cuda() move every tensor: pointers change
+        eager, fused = self._pending is not None, self._fused is not None
         self._struct_cache = None
         self._fused = None
         self._fused_l1 = None
         self._pending = None
         self._pending_stamp = None
         self._step_ws = {}
-        return super()._apply(fn, *a, **kw)
+        out = super()._apply(fn, *a, **kw)
+        # derived tables follow the tensors to their new home: a model that streamed with eager updates / pre-multiplied
+        # weights keeps doing so (silently falling back to the lazy forms would change nothing but the speed - and would
+        # break engines that rely on the table, e.g. the partitioned multi-GPU layout)
+        if eager:
+            self.eager_updates()
+        if fused and self.device.type == 'cuda':
+            self.fuse_attention()
+        return out
 
     def dropout_rng(self) -> Tensor:
         """device int64[2] = {seed, step counter} of the dropout mask generator (training only)"""
@@ -224,8 +233,21 @@ class TIGE(nn.Module):
         self._state_version += 1
 
     def _state_stamp(self):
+        """What the eager-update table is a function of, as far as the host can see it: the explicit version counters of
+        the model and its state modules, torch's own version counters of the state tensors (any in-place torch operation
+        on a memory / mailbox tensor bumps them - the library's kernels, which write through raw pointers, do not) and
+        those of the updater / message-transform parameters (an optimizer step is an in-place update).  Writes through
+        .data / raw pointers by third parties remain invisible: invalidate_pending() is theirs to call."""
         L, R, S = self.left_memory, self.right_memory, self.msg_store
-        return (self._state_version, id(L), L._version_, id(R), R._version_, id(S), S._version_)
+        tv = tuple(t._version for t in (L.vals, L.update_ts, R.vals, R.update_ts, S.node_msg_vals, S.node_msg_ts,
+                                        S.has_msg_bits))
+        pv = sum(p._version for mod in (self.right_mem_updater, self.msg_transform_fn) for p in mod.parameters())
+        return (self._state_version, id(L), L._version_, id(R), R._version_, id(S), S._version_, tv, pv)
+
+    def _attn_stamp(self):
+        """versions of everything the pre-multiplied attention weights are made of"""
+        mods = [self.temporal_embedding_fn, self.time_encoder]
+        return tuple((id(p), p._version) for mod in mods for p in mod.parameters())
 
     def _sync_pending(self):
         """Rebuild the table of precomputed updater rows if state changed outside the eager step:
@@ -272,6 +294,7 @@ class TIGE(nn.Module):
             blobs.append(fused)
         self._fused = blobs[0]
         self._fused_l1 = blobs[1] if len(blobs) > 1 else None
+        self._fused_stamp = self._attn_stamp()
         self._struct_cache = None
         return self
 
@@ -621,6 +644,12 @@ class TIGE(nn.Module):
             buf._inner = self.model_struct(1)
             buf.io.inner = C.addressof(buf._inner)
         buf.io.rows_hint = self.rows_bound()
+        if self._fused is not None and self._fused_stamp != self._attn_stamp():
+            # an attention parameter was updated in place since the weights were pre-multiplied (an optimizer step, a
+            # copy_): recompute them instead of embedding with stale products
+            if self.device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('attention parameters changed since fuse_attention(): call it again before capturing')
+            self.fuse_attention()
         self.check_graph(self.graph)
         g = self.graph.tcsr
         cb = getattr(buf, '_lazy_collate', None)
