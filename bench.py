@@ -651,6 +651,9 @@ def main():
                     help='multi-GPU: replay captured hipGraphs around the exchange (experimental; default eager)')
     ap.add_argument('--dist-mode', default='partitioned', choices=['partitioned', 'replicated'],
                     help='multi-GPU state layout (www2023tiger_amd/dist.py)')
+    ap.add_argument('--dist-full-tables', action='store_true',
+                    help='multi-GPU, partitioned layout: every rank allocates full-height state tables (global row addressing) '
+                         'instead of its own rows + an arena (tg_model.row_of)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='multi-GPU: weak = B events per rank per step, strong = the global batch stays B')
     ap.add_argument('--no-fuse', action='store_true', help='keep the six-product attention (no tg_attn_fuse)')

@@ -231,6 +231,15 @@ typedef struct tg_model {
    * a training step, loading a snapshot) the table is rebuilt with tg_apply_messages over the has_msg set
    * before the next eager step.  tg_train_step ignores the table. */
   float* pending_vals;
+  /* Optional (NULL = identity): PHYSICALLY PARTITIONED state (multi-GPU, www2023tiger_amd/dist.py).  row_of[v] is the row
+   * of node v in THIS process's state tables - memories, their times / active flags, mailbox rows and times, the
+   * has-message bitmap (bit index = row) and pending_vals - which then have fewer rows than n_nodes: row 0 is the padding
+   * node, rows 1..n_own the nodes this rank owns, the rows behind them an arena that holds, for the duration of one batch,
+   * the rows pulled from other owners (the caller points row_of at them before the step).  Node ids everywhere else - the
+   * T-CSR, the batch arrays, neighbour lists, feature tables, the owner table - stay global.  Honoured by the embedding
+   * step (tg_stream_step with embed_only + lean on a model with pending_vals) and by the planned, owner-filtered
+   * tg_stream_writeback; every other entry point addresses state by node id and refuses a model that carries it. */
+  const int32_t* row_of;
 } tg_model;
 
 /* Inference-time algebra on the attention weights (parameters only, no data):

@@ -459,7 +459,7 @@ def test_partitioned_state_equals_single_process_cpu_gloo(tmp_path, world, balan
     same(got['msg'][ref.has_msg], ref.msg_vals.numpy()[ref.has_msg], err_msg='mailbox')
 
 
-def _partitioned_gpu_worker(rank, world, port, name, B, n_steps, resident, out_dir, lopsided=False):
+def _partitioned_gpu_worker(rank, world, port, name, B, n_steps, resident, out_dir, lopsided=False, physical=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
@@ -477,33 +477,46 @@ def _partitioned_gpu_worker(rank, world, port, name, B, n_steps, resident, out_d
         owner = np.zeros_like(owner)
     keys = ('src', 'dst', 'neg', 'ts', 'eids')
     if resident:  # all plans up front, balanced shards (the benchmarked form)
-        rs = ResidentPartitionedStream(model, {k: z[k] for k in keys}, owner, rank, world, B, n_steps)
+        rs = ResidentPartitionedStream(model, {k: z[k] for k in keys}, owner, rank, world, B, n_steps, physical=physical)
+        eng = rs.engine
         for _ in range(n_steps):
             rs.step()
         rs.check_invariants()
     else:         # plan + run per batch, events on the owner of their destination
         eng = HipPartitionEngine(model, cap=Bg)
+        if physical:
+            eng.partition(owner, rank, arena_rows=int(z['n_nodes']))
         runner = PartitionedRunner(eng, owner, rank, world)
         for b in range(n_steps):
             runner.step(*(z[k][b * Bg:(b + 1) * Bg] for k in keys))
         eng.check_invariants()
-    has = model.msg_store.has_msg_mask().cpu().numpy()
-    _save_owned(os.path.join(out_dir, f'rank{rank}.npz'), owner, rank, model.left_memory.vals.cpu().numpy(),
-                model.right_memory.vals.cpu().numpy(), model.left_memory.update_ts.cpu().numpy(),
-                model.right_memory.update_ts.cpu().numpy(), model.msg_store.node_msg_vals.cpu().numpy(),
-                model.msg_store.node_msg_ts.cpu().numpy(), has)
+    if physical:  # this rank's tables hold its own rows (+ an arena): scattered back to node ids for the comparison
+        assert model.left_memory.vals.shape[0] == 1 + eng.n_own + max(eng.arena_rows, 1)  # row 0 | own rows | arena
+        assert eng.n_own < int(z['n_nodes']) - 1                                            # (the ranks really share the nodes)
+        f = eng.export_full()
+        _save_owned(os.path.join(out_dir, f'rank{rank}.npz'), owner, rank, f['left'], f['right'], f['left_ts'], f['right_ts'],
+                    f['msg'], f['msg_ts'], f['has'])
+    else:
+        has = model.msg_store.has_msg_mask().cpu().numpy()
+        _save_owned(os.path.join(out_dir, f'rank{rank}.npz'), owner, rank, model.left_memory.vals.cpu().numpy(),
+                    model.right_memory.vals.cpu().numpy(), model.left_memory.update_ts.cpu().numpy(),
+                    model.right_memory.update_ts.cpu().numpy(), model.msg_store.node_msg_vals.cpu().numpy(),
+                    model.msg_store.node_msg_ts.cpu().numpy(), has)
     tdist.destroy_process_group()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name,world,B,resident', [('static_ll_d16', 2, 48, False), ('static_ll_d16', 4, 24, True),
-                                                   ('seq_rr_d8_nofeat', 2, 50, True)])
-def test_partitioned_state_equals_single_gpu(tmp_path, name, world, B, resident):
+@pytest.mark.parametrize('name,world,B,resident,physical', [
+    ('static_ll_d16', 2, 48, False, False), ('static_ll_d16', 4, 24, True, False), ('seq_rr_d8_nofeat', 2, 50, True, False),
+    ('static_ll_d16', 2, 48, False, True), ('static_ll_d16', 4, 24, True, True), ('seq_rr_d8_nofeat', 2, 50, True, True)])
+def test_partitioned_state_equals_single_gpu(tmp_path, name, world, B, resident, physical):
     """The partitioned mode on the HIP engine (ranks are processes sharing the one GPU of the test box, gloo for
-    the exchange) against the single-GPU fused step on the same global batches: the owners' rows."""
+    the exchange) against the single-GPU fused step on the same global batches: the owners' rows.  physical: every
+    rank's state tables hold only row 0, its own nodes' rows and an arena for the rows pulled per batch
+    (tg_model.row_of) - fewer rows than nodes - and state is addressed by row."""
     from test_hip_parity import build_hip_model
     n_steps = min(6, len(load(name)['src']) // (B * world))
-    mp.spawn(_partitioned_gpu_worker, args=(world, free_port(), name, B, n_steps, resident, str(tmp_path)),
+    mp.spawn(_partitioned_gpu_worker, args=(world, free_port(), name, B, n_steps, resident, str(tmp_path), False, physical),
              nprocs=world, join=True)
     z = load(name)
     cfg = parse_cfg(z)

@@ -15,7 +15,7 @@ stream = bench.make_stream(c['n_u'], c['n_i'], E, c['T'] * E / c['E'], seed=0, d
 model, _ = bench.build_models(stream, c['d'], c['K'], c['msg_src'], c['upd_src'], restarter='static', device='cuda:0')
 model.fuse_attention()
 owner = D.balanced_owner_table(stream['n_nodes'], stream['dst'], 1)
-rs = D.ResidentPartitionedStream(model, stream, owner, 0, 1, B, n_steps)
+rs = D.ResidentPartitionedStream(model, stream, owner, 0, 1, B, n_steps, physical=True)
 for _ in range(150): rs.step()
 torch.cuda.synchronize()
 pr = cProfile.Profile(); pr.enable()

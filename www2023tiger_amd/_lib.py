@@ -51,7 +51,7 @@ class TgModel(C.Structure):
         ('upd_fc1', TgLinear), ('upd_fc2', TgLinear),
         ('attn_wq', vp), ('attn_wk', vp), ('attn_wv', vp), ('attn_b_in', vp),
         ('attn_out', TgLinear), ('attn_fc1', TgLinear), ('attn_fc2', TgLinear), ('attn_fused', vp),
-        ('pending_vals', vp),
+        ('pending_vals', vp), ('row_of', vp),
     ]
 
 

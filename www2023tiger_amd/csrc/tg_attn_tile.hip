@@ -488,7 +488,7 @@ int attn_tile_applies(const tg_model* m) {
   // and a CU pulls 13-16 B/clk of L2-resident lines here, while the 64-row tiles of the separate products need a quarter
   // of that and their G / S round trip costs less than it saves (profiles/r03_attn_tile_phase_trace.txt)
   static const int knob = getenv("TG_ATTN_TILE") ? atoi(getenv("TG_ATTN_TILE")) : 0;
-  return (knob != 0 && tile_waves(m) != 0) ? 1 : 0;
+  return (knob != 0 && tile_waves(m) != 0 && !m->row_of) ? 1 : 0;
 }
 
 int attn_tile_launch(const tg_model* m, int64_t Q, const float* cc, const float* ts, const int64_t* l1_nids,

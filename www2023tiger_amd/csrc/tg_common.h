@@ -71,6 +71,10 @@ __device__ __forceinline__ bool bm_test(const uint64_t* __restrict__ bm, int64_t
   return (bm[id >> 6] >> (id & 63)) & 1ull;
 }
 
+// row of node v in this process's state tables (tiger_hip.h: tg_model.row_of; identity unless the state is physically
+// partitioned)
+__device__ __forceinline__ int64_t state_row(const tg_model& m, int64_t v) { return m.row_of ? (int64_t)m.row_of[v] : v; }
+
 // TimeEncode (time_encoding.py:24-26): the product is rounded to float32 before the
 // phase is added (no FMA contraction; the library is also built with -ffp-contract=off),
 // and the cosine is accurate over the whole argument range (never __cosf).
@@ -334,6 +338,7 @@ struct DirectArgs {
   // the same node set, involved & has-message, some nodes more than once
   int per_row_checks;
 };
+// (`id`: the node's ROW in the state tables, state_row)
 __device__ __forceinline__ void check_msg_times(const tg_model& m, int64_t id, uint32_t* err) {
   const float mts = m.msg_ts[id], last = (m.msg_src == TG_SRC_LEFT ? m.left_ts : m.right_ts)[id];
   if (last > mts) atomicOr(err, TG_ERR_MSG_BEFORE_MEM);
@@ -352,22 +357,23 @@ __device__ __forceinline__ void centres_direct_body(const tg_model& m, int64_t Q
     const int64_t i = t / d4;
     const int c = (int)(t - i * d4);
     const int64_t id = ids.id(i);
-    const bool pending = bm_test(m.has_msg, id);
-    float4 v = (pending ? pend : right)[id * d4 + c];
+    const int64_t r = state_row(m, id);  // state by row, features by node id
+    const bool pending = bm_test(m.has_msg, r);
+    float4 v = (pending ? pend : right)[r * d4 + c];
     float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
     if (nf) f = nf[id * d4 + c];
     v.x += f.x; v.y += f.y; v.z += f.z; v.w += f.w;
     out[t] = v;
-    if (da.per_row_checks && c == 0 && pending) check_msg_times(m, id, da.err);
+    if (da.per_row_checks && c == 0 && pending) check_msg_times(m, r, da.err);
     if (da.snap && i < da.n_snap) {
       if (m.msg_src == TG_SRC_LEFT) {
-        float4 l = reinterpret_cast<const float4*>(m.left_vals)[id * d4 + c];
+        float4 l = reinterpret_cast<const float4*>(m.left_vals)[r * d4 + c];
         l.x += f.x; l.y += f.y; l.z += f.z; l.w += f.w;
         da.snap[t] = l;
-        if (c == 0) da.snap_ts[i] = m.left_ts[id];
+        if (c == 0) da.snap_ts[i] = m.left_ts[r];
       } else {
         da.snap[t] = v;
-        if (c == 0) da.snap_ts[i] = pending ? m.msg_ts[id] : m.right_ts[id];
+        if (c == 0) da.snap_ts[i] = pending ? m.msg_ts[r] : m.right_ts[r];
       }
     }
   }

@@ -186,6 +186,8 @@ __global__ void k_consume_gather_check(tg_model m, const int64_t* __restrict__ i
 // rows of BOTH endpoints, STEP 4 writes right-memory rows and STEP 6 left-memory rows of
 // other nodes in other waves, so a kernel boundary must separate STEP 5 from whichever
 // step writes the message memory:  msg_src=left  -> [4 + 5] | [6],  msg_src=right -> [4] | [5 + 6].
+// (`id`, `own`, `other` below: ROWS of the state tables - state_row(node) - where the tables are physically partitioned;
+// feature tables are addressed by node id)
 __device__ __forceinline__ void wb_step4(const tg_model& m, int64_t id, int64_t u, const float4* __restrict__ reprs,
                                          uint32_t* err, int lane) {
   if (!bm_test(m.has_msg, id)) return;  // wave-uniform
@@ -215,7 +217,8 @@ __device__ __forceinline__ void wb_step5(const tg_model& m, int64_t B, const int
   const float4* ph = reinterpret_cast<const float4*>(m.te_phase);
   float4* box = reinterpret_cast<float4*>(m.msg_vals);
   const int64_t e = idx < B ? idx : idx - B;
-  const int64_t other = idx < B ? dst[e] : src[e];
+  const int64_t own_id = idx < B ? src[e] : dst[e], other_id = idx < B ? dst[e] : src[e];  // node ids (features)
+  const int64_t other = state_row(m, other_id);
   const float t = ts[e];
   const float dt = t - mem_ts[own];
   const int64_t eid = eids[e];
@@ -226,7 +229,7 @@ __device__ __forceinline__ void wb_step5(const tg_model& m, int64_t B, const int
       const int cc = c < d4 ? c : c - d4;
       v = mem[node * d4 + cc];
       if (nf) {
-        const float4 f = nf[node * d4 + cc];
+        const float4 f = nf[(c < d4 ? own_id : other_id) * d4 + cc];
         v.x += f.x; v.y += f.y; v.z += f.z; v.w += f.w;
       }
     } else if (c < 2 * d4 + e4) {
@@ -274,20 +277,21 @@ __global__ void __launch_bounds__(256) k_writeback(tg_model m, WritebackArgs a) 
       const int64_t e = i < B ? i : i - B;
       const int64_t node = i < B ? a.src[e] : a.dst[e];
       if (a.owner && a.owner[node] != a.my_rank) continue;  // another rank's node: its time is not kept here
-      if (mem_ts[node] > a.ts[e]) atomicOr(a.err, TG_ERR_EVENT_BEFORE_MEM);
+      if (mem_ts[state_row(m, node)] > a.ts[e]) atomicOr(a.err, TG_ERR_EVENT_BEFORE_MEM);
     }
   }
   const int64_t po = a.plan_off ? 2 * *a.plan_off : 0;
   for (int64_t p = wave0; p < n; p += nwave) {
-    const int64_t id = a.upos[p], idx = a.index[p];
-    if (a.owner && a.owner[id] != a.my_rank) continue;  // partitioned state: the owner writes (wave-uniform)
+    const int64_t node_id = a.upos[p], idx = a.index[p];
+    if (a.owner && a.owner[node_id] != a.my_rank) continue;  // partitioned state: the owner writes (wave-uniform)
+    const int64_t id = state_row(m, node_id);
     if (PHASE == 0) {
       if (a.new_from_pending)
         wb_step4(m, id, id, reinterpret_cast<const float4*>(m.pending_vals), a.err, lane);
       else if (a.rows)
         wb_step4(m, id, a.new_row[po + idx], reinterpret_cast<const float4*>(a.rows), a.err, lane);
       else
-        wb_step4(m, id, (int64_t)bm_rank(a.bm, a.rank, id), reinterpret_cast<const float4*>(a.reprs), a.err, lane);
+        wb_step4(m, id, (int64_t)bm_rank(a.bm, a.rank, node_id), reinterpret_cast<const float4*>(a.reprs), a.err, lane);
     }
     if (do5) wb_step5(m, B, a.src, a.dst, a.ts, a.eids, id, idx, a.err, lane);
     if (PHASE == 1) {

@@ -232,8 +232,15 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
       nb_l = l1_nids[i * K + lane];
       eid_l = l1_eids[i * K + lane];
       dt_l = ts[i] - l1_ts[i * K + lane];
-      if (nb_l != 0) u_l = direct ? (int)(2 * nb_l + (bm_test(m.has_msg, nb_l) ? 1 : 0)) : (int)bm_rank(bm, rank, nb_l);
-      if (direct && pos.chk_err && (u_l & 1)) check_msg_times(m, nb_l, pos.chk_err);
+      if (nb_l != 0) {
+        if (direct) {
+          const int64_t r = state_row(m, nb_l);
+          u_l = (int)(2 * r + (bm_test(m.has_msg, r) ? 1 : 0));
+          if (pos.chk_err && (u_l & 1)) check_msg_times(m, r, pos.chk_err);
+        } else {
+          u_l = (int)bm_rank(bm, rank, nb_l);
+        }
+      }
     }
     // key_rows (second attention layer of --n_layers 2): the node part of key k of centre i is row i*K + k of a dense
     // tensor - the neighbour's own embedding (temporal_agg_modules.py:57-66) - instead of its memory row + features.
@@ -1053,8 +1060,9 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   w.inv = io->involved ? io->involved : w.involved;
   // involved = sorted(set(...)); outdated = involved & has-message (memory.py:108-126)
   if (!w.lean &&
-      (rc = unique_compact_launch(w.flags, w.bm, m->n_nodes, w.rank, w.inv, w.counts + 0, cap, m->has_msg, w.rank_out,
-                                  w.outdated, w.out_pos, w.counts + 1, w.scan_ws, w.scan_bytes, st)) != TG_OK)
+      (rc = unique_compact_launch(w.flags, w.bm, m->n_nodes, w.rank, w.inv, w.counts + 0, cap,
+                                  m->row_of ? nullptr : m->has_msg,  // (row-indexed bitmap: a collate-only pass has no use for it)
+                                  w.rank_out, w.outdated, w.out_pos, w.counts + 1, w.scan_ws, w.scan_bytes, st)) != TG_OK)
     return rc;
   if (io->collate_only) return check_launch("tg_stream_step(collate_only)");
   prof_mark(pf, ST_GATHER, st);
@@ -1186,6 +1194,8 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
   if (!io->src || !io->dst || !io->neg || !io->ts || !io->eids || (!io->h && !io->collate_only) || !io->err)
     return TG_EINVAL;
   if (g->num_node != m->n_nodes) return TG_EINVAL;
+  // physically partitioned state (tg_model.row_of): only the forms that address state by row
+  if (m->row_of && !io->collate_only && !(io->embed_only && io->lean && m->pending_vals && !io->inner)) return TG_EUNSUPPORTED;
   hipStream_t st = as_stream(stream);
   tg_profiler* pf = (tg_profiler*)io->profiler;
   Carver cv(ws, ws_bytes);
@@ -1285,6 +1295,7 @@ extern "C" int tg_stream_writeback(const tg_model* m, const tg_writeback_io* io,
   if (io->new_from_pending ? !m->pending_vals : !io->new_row) return TG_EINVAL;
   hipStream_t st = as_stream(stream);
   const int64_t Bg = io->Bg;
+  if (m->row_of && (!io->n_upos_dev || !io->owner)) return TG_EUNSUPPORTED;  // rows: the planned, owner-filtered form only
   // planned winners (no dedup work, two launches): the caller hands over the count on the device.  A rank that owns no
   // winner of the batch passes empty lists, whose pointers may be NULL: nothing to write
   if (io->n_upos_dev && !io->upos) return TG_OK;

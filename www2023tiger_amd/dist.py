@@ -358,7 +358,7 @@ class StepPlan:
     """Everything about one global batch that does not depend on node state (see PartitionedRunner.plan)."""
     __slots__ = ('n', 'Bg', 'local', 'glob', 'ts32', 'serve_eff', 'serve_msg', 'serve_eff_pos', 'serve_msg_pos',
                  'serve_in', 'serve_out', 'req_eff', 'req_msg', 'reply_eff_pos', 'reply_msg_pos', 'push_rows', 'push_in',
-                 'push_out', 'n_recv', 'left_row', 'mine', 'mine_index', 'mine32', 'n_mine', 'stats', 'push_idx')
+                 'push_out', 'n_recv', 'left_row', 'mine', 'mine_index', 'mine32', 'n_mine', 'stats', 'push_idx', 'phys')
 
 
 class PartitionedRunner:
@@ -498,6 +498,78 @@ class HipPartitionEngine:
         self.err = hip_ops.new_err(model.device)
         self._owner32 = None
         self._st = None
+        self.row_of = None  # set by partition(): the state tables hold this rank's rows only
+
+    # ---- physically partitioned state (tg_model.row_of) --------------------------------------------------------
+    def partition(self, owner, rank: int, arena_rows: int):
+        """Keep only this rank's rows: row 0 (padding), one row per owned node (ascending node id), then `arena_rows` rows
+        that hold, for the duration of one batch, the rows pulled from other owners (TIGE.partition_state)."""
+        own = torch.as_tensor(np.asarray(owner)).to(self.device) == rank
+        own[0] = False
+        ids = torch.nonzero(own).flatten()
+        row_of = torch.full((self.model.n_nodes,), -1, dtype=torch.int32, device=self.device)
+        row_of[0] = 0
+        row_of[ids] = torch.arange(1, ids.numel() + 1, dtype=torch.int32, device=self.device)
+        self.n_own, self.arena_rows = int(ids.numel()), int(arena_rows)
+        self.arena_base = 1 + self.n_own
+        n_rows = self.arena_base + max(self.arena_rows, 1)
+        if self.model.msg_store.n == self.model.n_nodes or getattr(self.model, '_row_of', None) is not None:
+            self.model.partition_state(row_of, n_rows)   # full-height (or already partitioned) tables: owned rows move over
+        else:                                              # a model BORN with this rank's rows only (TIGE.born_with_rows)
+            assert self.model.msg_store.n == n_rows, (self.model.msg_store.n, n_rows)
+            self.model._row_of = row_of
+            self.model._struct_cache = None
+        self.row_of = self.model._row_of  # the tensor the kernels read; arena entries are re-pointed per batch
+        self.owned_ids = ids
+        return self
+
+    def grow_arena(self, arena_rows: int):
+        """more arena rows (known once every step is planned); the owned rows are copied into the larger tables"""
+        if arena_rows <= self.arena_rows:
+            return
+        keep = self.row_of.clone()
+        keep[keep >= self.arena_base] = -1  # arena contents are per batch: nothing to carry over
+        self.arena_rows = int(arena_rows)
+        self.model.partition_state(keep, self.arena_base + self.arena_rows)
+        self.row_of = self.model._row_of
+
+    def _phys(self, p):
+        """plan p's id lists as ROWS of this rank's tables (cached on the plan): owned nodes have static rows, the nodes it
+        pulls get arena rows for this batch - one per node, whether it is pulled as an effective row, as a message-source
+        row, or both"""
+        ph = getattr(p, 'phys', None)
+        if ph is not None:
+            return ph
+        ro = self.row_of.long()
+        req = torch.cat([p.req_eff, p.req_msg])
+        nodes, inv = torch.unique(req, return_inverse=True)
+        if nodes.numel() > self.arena_rows:
+            raise RuntimeError(f'{nodes.numel()} pulled nodes exceed the arena of {self.arena_rows} rows')
+        arena = (self.arena_base + inv).contiguous()
+        ne = p.req_eff.numel()
+        ph = dict(serve_eff=ro[p.serve_eff].contiguous(), serve_msg=ro[p.serve_msg].contiguous(),
+                  req_nodes=nodes, req_rows=(self.arena_base + torch.arange(nodes.numel(), device=self.device)).to(torch.int32),
+                  adopt_eff=arena[:ne].contiguous(), adopt_msg=arena[ne:].contiguous(),
+                  mine=ro[p.mine].contiguous(), mine32=ro[p.mine].to(torch.int32).contiguous())
+        p.phys = ph
+        return ph
+
+    def export_full(self):
+        """this rank's authoritative rows scattered back into full-height host arrays indexed by node id (tests)"""
+        m, ids = self.model, self.owned_ids
+        rows = self.row_of[ids].long()
+        n = m.n_nodes
+        out = {}
+        for name, t in (('left', m.left_memory.vals), ('right', m.right_memory.vals), ('left_ts', m.left_memory.update_ts),
+                        ('right_ts', m.right_memory.update_ts), ('msg', m.msg_store.node_msg_vals),
+                        ('msg_ts', m.msg_store.node_msg_ts)):
+            full = torch.zeros((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
+            full[ids] = t[rows]
+            out[name] = full.cpu().numpy()
+        has = torch.zeros(n, dtype=torch.bool, device=self.device)
+        has[ids] = m.msg_store._bits_of(rows).bool()
+        out['has'] = has.cpu().numpy()
+        return out
 
     def resize_recv(self, max_recv: int):
         """room for `max_recv` pushed rows behind the rank's own 3 * cap embeddings (the planner's bound)"""
@@ -548,7 +620,8 @@ class HipPartitionEngine:
         if out is None:
             out = torch.empty(ne + nm, self.d + 1, dtype=torch.float32, device=self.device)
         ms = m.model_struct()
-        self.check(lib.tg_serve_rows(C.byref(ms), ne, ptr(p.serve_eff), ptr(p.serve_eff_pos), nm, ptr(p.serve_msg),
+        eff, msg = (p.serve_eff, p.serve_msg) if self.row_of is None else (self._phys(p)['serve_eff'], self._phys(p)['serve_msg'])
+        self.check(lib.tg_serve_rows(C.byref(ms), ne, ptr(eff), ptr(p.serve_eff_pos), nm, ptr(msg),
                                      ptr(p.serve_msg_pos), ptr(out), self._stream()), 'tg_serve_rows')
         return out
 
@@ -557,8 +630,14 @@ class HipPartitionEngine:
         authoritative here)"""
         m, lib, ptr = self.model, self.lib, self.ptr
         ms = m.model_struct()
-        self.check(lib.tg_adopt_rows(C.byref(ms), p.req_eff.numel(), ptr(p.req_eff), ptr(p.reply_eff_pos), p.req_msg.numel(),
-                                     ptr(p.req_msg), ptr(p.reply_msg_pos), ptr(got), self._stream()),
+        eff, msg = p.req_eff, p.req_msg
+        if self.row_of is not None:  # the pulled nodes live in arena rows for this batch: point the translation at them
+            ph = self._phys(p)
+            if ph['req_nodes'].numel():
+                self.row_of[ph['req_nodes']] = ph['req_rows']
+            eff, msg = ph['adopt_eff'], ph['adopt_msg']
+        self.check(lib.tg_adopt_rows(C.byref(ms), p.req_eff.numel(), ptr(eff), ptr(p.reply_eff_pos), p.req_msg.numel(),
+                                     ptr(msg), ptr(p.reply_msg_pos), ptr(got), self._stream()),
                    'tg_adopt_rows')
 
     def embed(self, p):
@@ -606,7 +685,8 @@ class HipPartitionEngine:
             ms = m.model_struct()
             nbytes = int(lib.tg_apply_messages_workspace_bytes(C.byref(ms), n))
             ws = m._ws('apply', nbytes)
-            self.check(lib.tg_apply_messages(C.byref(ms), ptr(p.mine), ptr(p.mine32), ptr(p.n_mine), n, ptr(m._pending),
+            mine, mine32 = (p.mine, p.mine32) if self.row_of is None else (self._phys(p)['mine'], self._phys(p)['mine32'])
+            self.check(lib.tg_apply_messages(C.byref(ms), ptr(mine), ptr(mine32), ptr(p.n_mine), n, ptr(m._pending),
                                              ptr(self.err), ptr(ws), ws.numel(), self._stream()),
                        'tg_apply_messages(pending)')
         m._pending_stamp = m._state_stamp()  # the table is current again
@@ -633,7 +713,7 @@ class ResidentPartitionedStream:
     nothing switches it on.)"""
 
     def __init__(self, model, stream: dict, owner: np.ndarray, rank: int, world: int, B: int, n_steps: int,
-                 group=None, use_graphs: bool = False, capture_collectives: bool = False):
+                 group=None, use_graphs: bool = False, capture_collectives: bool = False, physical: bool = False):
         Bg = B * world
         keys = ('src', 'dst', 'neg', 'ts', 'eids')
         rank_ofs, local = [], {k: [] for k in keys}
@@ -649,6 +729,13 @@ class ResidentPartitionedStream:
         resident = tuple(tod(local[k], torch.float64 if k == 'ts' else torch.int64) for k in keys)
         self.model, self.rank, self.world, self.B, self.group, self.n_steps = model, rank, world, B, group, n_steps
         self.engine = HipPartitionEngine(model, cap=B, resident=resident, max_recv=0)  # receive room: sized below
+        self.physical = bool(physical)
+        if self.physical:
+            # PHYSICAL partition (before anything is planned, so that a model born with this rank's rows only never needs
+            # full-height tables): the tables keep row 0, this rank's rows and an arena for the rows pulled per batch - one
+            # provisional row for now, the real size (the most distinct nodes any of this rank's plans pulls) below; from
+            # here on state is addressed by row (tg_model.row_of)
+            self.engine.partition(owner, rank, 1)
         self.runner = PartitionedRunner(self.engine, owner, rank, world, group)
         self.plans = [self.runner.plan(*(stream[k][b * Bg:(b + 1) * Bg] for k in keys), rank_of=rank_ofs[b])
                       for b in range(n_steps)]
@@ -662,6 +749,10 @@ class ResidentPartitionedStream:
         self.pull_max, self.push_max = int(mx[0]), int(mx[1])
         d = model.memory_dim
         self.engine.resize_recv(world * self.push_max)
+        if self.physical:
+            self.engine.grow_arena(max([1] + [int(torch.unique(torch.cat([p.req_eff, p.req_msg])).numel()) for p in self.plans]))
+            for p in self.plans:
+                self.engine._phys(p)  # every plan's id lists as rows, now: nothing is translated inside a step
         self.served = torch.zeros(world * self.pull_max, d + 1, dtype=torch.float32, device=dev)
         self.got = torch.zeros(world * self.pull_max, d + 1, dtype=torch.float32, device=dev)
         self.pushbuf = torch.zeros(world * self.push_max, d, dtype=torch.float32, device=dev)
@@ -855,12 +946,22 @@ def run_dist_leg(args, cfg, make_stream, build_models, rank, local_rank, world, 
     stream = make_stream(cfg['n_u'], cfg['n_i'], E, cfg['T'] * E / cfg['E'], seed=0, d_e=d,
                          integer_ts=cfg.get('integer_ts', True), with_efeats=not no_feats,
                          **({'counter': True} if cfg.get('counter_stream') else {}))  # identical on every rank
-    model, _ = build_models(stream, d, K, cfg['msg_src'], cfg['upd_src'], restarter='static', device=str(dev),
-                            zero_nfeats=not no_feats)
+    owner = balanced_owner_table(stream['n_nodes'], stream['dst'], world)
+    physical = mode == 'partitioned' and not getattr(args, 'dist_full_tables', False)
+    if physical:
+        # the model is BORN with this rank's rows only (row 0, its nodes, one provisional arena row): no rank ever
+        # allocates a full-height state table
+        from .model.tiger import TIGE
+        own_rows = 1 + int(((owner == rank) & (np.arange(len(owner)) != 0)).sum()) + 1
+        with TIGE.born_with_rows(own_rows):
+            model, _ = build_models(stream, d, K, cfg['msg_src'], cfg['upd_src'], restarter='static', device=str(dev),
+                                    zero_nfeats=not no_feats)
+    else:
+        model, _ = build_models(stream, d, K, cfg['msg_src'], cfg['upd_src'], restarter='static', device=str(dev),
+                                zero_nfeats=not no_feats)
     fused = not getattr(args, 'no_fuse', False)
     if fused:
         model.fuse_attention()  # fixed parameters: pre-multiplied attention weights, as in the 1-GPU bench
-    owner = balanced_owner_table(stream['n_nodes'], stream['dst'], world)
     nccl = tdist.get_backend() == 'nccl'
     if mode == 'partitioned':
         # eager launches by default: measured with one rank on RCCL (C2), three hipGraph segments around the two
@@ -868,7 +969,8 @@ def run_dist_leg(args, cfg, make_stream, build_models, rank, local_rank, world, 
         # costs 10-16 us of host time, as much as the launches it stands for), and a capture that includes the
         # collectives never finished.  --dist-graphs selects the segments.
         use_graphs = nccl and bool(getattr(args, 'dist_graphs', False)) and not args.no_graph
-        rs = ResidentPartitionedStream(model, stream, owner, rank, world, B, n_steps, use_graphs=use_graphs)
+        rs = ResidentPartitionedStream(model, stream, owner, rank, world, B, n_steps, use_graphs=use_graphs,
+                                       physical=physical)
     else:
         use_graphs = bool(getattr(args, 'dist_graphs', False)) and not args.no_graph
         rs = ResidentShardedStream(model, stream, owner, rank, world, B, n_steps, use_graphs=use_graphs)
@@ -974,7 +1076,9 @@ def run_dist_leg(args, cfg, make_stream, build_models, rank, local_rank, world, 
                    config=dict(workload=cfg['name'], batch_per_gpu=B, global_batch=Bg, dim=d, n_neighbors=K,
                                msg_src=cfg['msg_src'], upd_src=cfg['upd_src'], n_nodes=stream['n_nodes'], events=E,
                                mode='stream (no_grad) STEP 1-6', state_preroll_batches=preroll,
-                               state_layout=mode, parallelism=par, exchange_rows_per_step_rank0=tr,
+                               state_layout=mode + (f' (physical: {model.msg_store.n} of {stream["n_nodes"]} table rows on rank 0)'
+                                                    if physical else ''),
+                               parallelism=par, exchange_rows_per_step_rank0=tr,
                                spilled_event_fraction=round(spilled, 4), launch=launch,
                                semantics='one global batch = one batch of the single-GPU engine (exchange period 1): '
                                          f'events of a batch do not see each other, and that batch has {Bg} events here'),

@@ -39,6 +39,24 @@ _UPD = {'gru': 0, 'merge': 1}
 
 
 class TIGE(nn.Module):
+    _born_rows = None
+
+    @staticmethod
+    def born_with_rows(n_rows: int):
+        """Context: models constructed inside allocate `n_rows` rows per state table instead of one per node - a rank of the
+        physically partitioned multi-GPU layout, whose engine installs the node -> row map right after (dist.py:
+        HipPartitionEngine.partition).  Until then such a model must not run."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            prev, TIGE._born_rows = TIGE._born_rows, int(n_rows)
+            try:
+                yield
+            finally:
+                TIGE._born_rows = prev
+        return ctx()
+
     def __init__(self, *, raw_feat_getter, graph, n_neighbors: int = 20, n_layers: int = 2, n_head: int = 2,
                  dropout: float = 0.1, msg_src: str, upd_src: str, msg_tsfm_type: str = 'id',
                  mem_update_type: str = 'gru', tgn_mode: bool = True, msg_last_only: bool = True,
@@ -59,9 +77,10 @@ class TIGE(nn.Module):
         self.tgn_mode, self.msg_last_only = True, True
         self._sanity_check()
 
-        self.left_memory = Memory(self.n_nodes, self.memory_dim)
-        self.right_memory = Memory(self.n_nodes, self.memory_dim)
-        self.msg_store = MessageStoreNoGradLastOnly(self.n_nodes, dim=self.raw_msg_dim)
+        rows = TIGE._born_rows if TIGE._born_rows is not None else self.n_nodes  # (born_with_rows: a partitioned rank)
+        self.left_memory = Memory(rows, self.memory_dim)
+        self.right_memory = Memory(rows, self.memory_dim)
+        self.msg_store = MessageStoreNoGradLastOnly(rows, dim=self.raw_msg_dim)
         # module aliases: they appear as extra state_dict keys exactly as in the reference
         self.msg_memory = self.left_memory if msg_src == 'left' else self.right_memory
         self.upd_memory = self.left_memory if upd_src == 'left' else self.right_memory
@@ -125,6 +144,7 @@ class TIGE(nn.Module):
 
     def _apply(self, fn, *a, **kw):  # .to() / .cuda() move every tensor: pointers change
         eager, fused = self._pending is not None, self._fused is not None
+        self._plists = None
         self._struct_cache = None
         self._fused = None
         self._fused_l1 = None
@@ -204,7 +224,8 @@ class TIGE(nn.Module):
                     ptr(mha.q_proj_weight), ptr(mha.k_proj_weight), ptr(mha.v_proj_weight), ptr(mha.in_proj_bias),
                     lin(mha.out_proj), lin(att.merger.fc1), lin(att.merger.fc2),
                     ptr(self._fused) if self._fused is not None else None,
-                    ptr(self._pending) if self._pending is not None else None)
+                    ptr(self._pending) if self._pending is not None else None,
+                    ptr(self._row_of) if getattr(self, '_row_of', None) is not None else None)
         self._struct_cache = m
         return m
 
@@ -223,7 +244,49 @@ class TIGE(nn.Module):
         self._pending_stamp = None
         self._struct_cache = None
         if enable:
-            self._pending = torch.zeros(self.n_nodes, self.memory_dim, dtype=torch.float32, device=self.device)
+            self._pending = torch.zeros(self.msg_store.n, self.memory_dim, dtype=torch.float32, device=self.device)
+        return self
+
+    def partition_state(self, row_of: Tensor, n_rows: int):
+        """PHYSICALLY partitioned state (multi-GPU; tiger_hip.h: tg_model.row_of): this process keeps `n_rows` rows of every
+        state table - both memories, mailbox, has-message bitmap, eager-update table - instead of one per node.
+        row_of[v] >= 0: the row of node v (rows the owner keeps for good); the caller re-points entries at arena rows for
+        the nodes it pulls per batch.  Rows of nodes with row_of >= 0 are carried over from the current tables.  Node ids
+        everywhere else (graph, batches, feature tables) stay global.  Only the partitioned engine's entry points address
+        state by row: the model's own step / restart / flush methods must not be used on a partitioned model."""
+        dev = self.device
+        row_of = row_of.to(dev, torch.int32).contiguous()
+        assert row_of.numel() == self.n_nodes and int(row_of.max()) < n_rows
+        keep = torch.nonzero(row_of >= 0).flatten()
+        rows = row_of[keep].long()
+        prev = getattr(self, '_row_of', None)
+        if prev is not None:  # already partitioned: the current tables are addressed by the CURRENT map
+            src = prev.to(dev)[keep].long()
+            if bool((src < 0).any()):
+                raise ValueError('partition_state: a node gets a row that has none in the current partition')
+            keep = src
+        oldL, oldR, oldS, oldP = self.left_memory, self.right_memory, self.msg_store, self._pending
+        L, R = Memory(n_rows, self.memory_dim).to(dev), Memory(n_rows, self.memory_dim).to(dev)
+        S = MessageStoreNoGradLastOnly(n_rows, dim=self.raw_msg_dim).to(dev)
+        for new, old in ((L, oldL), (R, oldR)):
+            new.vals[rows] = old.vals[keep]
+            new.update_ts[rows] = old.update_ts[keep]
+            new.active_mask[rows] = old.active_mask[keep]
+        S.node_msg_vals[rows] = oldS.node_msg_vals[keep]
+        S.node_msg_ts[rows] = oldS.node_msg_ts[keep]
+        has = rows[oldS._bits_of(keep).bool()]
+        if has.numel():
+            hip_ops.bitmap_mark(has, S.has_msg_bits, n_rows)
+        self.left_memory, self.right_memory, self.msg_store = L, R, S
+        self.msg_memory = L if self.msg_src == 'left' else R
+        self.upd_memory = L if self.upd_src == 'left' else R
+        self._row_of = row_of
+        if oldP is not None:
+            self._pending = torch.zeros(n_rows, self.memory_dim, dtype=torch.float32, device=dev)
+            self._pending[rows] = oldP[keep]
+        self._struct_cache = None
+        self._pending_stamp = None
+        self._touch()
         return self
 
     def invalidate_pending(self):
@@ -239,15 +302,25 @@ class TIGE(nn.Module):
         those of the updater / message-transform parameters (an optimizer step is an in-place update).  Writes through
         .data / raw pointers by third parties remain invisible: invalidate_pending() is theirs to call."""
         L, R, S = self.left_memory, self.right_memory, self.msg_store
-        tv = tuple(t._version for t in (L.vals, L.update_ts, R.vals, R.update_ts, S.node_msg_vals, S.node_msg_ts,
-                                        S.has_msg_bits))
-        pv = sum(p._version for mod in (self.right_mem_updater, self.msg_transform_fn) for p in mod.parameters())
+        tv = (L.vals._version, L.update_ts._version, R.vals._version, R.update_ts._version, S.node_msg_vals._version,
+              S.node_msg_ts._version, S.has_msg_bits._version)
+        pl = self._param_lists()[0]
+        pv = sum([p._version for p in pl])
         return (self._state_version, id(L), L._version_, id(R), R._version_, id(S), S._version_, tv, pv)
+
+    def _param_lists(self):
+        """(updater + message-transform parameters, attention + time-encoder parameters) as plain lists - walking the
+        module tree on every step costs more host time than the step's launches; reset when the tensors are re-homed"""
+        pl = getattr(self, '_plists', None)
+        if pl is None:
+            upd = [p for mod in (self.right_mem_updater, self.msg_transform_fn) for p in mod.parameters()]
+            att = [p for mod in (self.temporal_embedding_fn, self.time_encoder) for p in mod.parameters()]
+            pl = self._plists = (upd, att)
+        return pl
 
     def _attn_stamp(self):
         """versions of everything the pre-multiplied attention weights are made of"""
-        mods = [self.temporal_embedding_fn, self.time_encoder]
-        return tuple((id(p), p._version) for mod in mods for p in mod.parameters())
+        return [p._version for p in self._param_lists()[1]]
 
     def _sync_pending(self):
         """Rebuild the table of precomputed updater rows if state changed outside the eager step:
@@ -259,7 +332,8 @@ class TIGE(nn.Module):
             raise RuntimeError('eager updates: run one step eagerly before capturing it into a graph')
         dev = self.device
         m = self.model_struct()
-        comp = hip_ops.unique_compact(self.msg_store.has_msg_bits, self.n_nodes, self.n_nodes)
+        n_rows = self.msg_store.n  # (= n_nodes unless the state is physically partitioned: the bitmap is over rows)
+        comp = hip_ops.unique_compact(self.msg_store.has_msg_bits, n_rows, n_rows)
         n = int(comp['count'].item())
         if n:
             ids = comp['ids'][:n].contiguous()
