@@ -702,6 +702,27 @@ def test_fused_step_with_the_recent_nodes_strategy_matches_oracle(lean):
         model.stream_step(*a)
 
 
+@pytest.mark.parametrize('mc', ['12', '16'])
+def test_one_launch_attention_tile_kernel_matches_oracle(mc):
+    """k_attn_tile (the whole attention block of a tile of centres in one workgroup, G / S in LDS only) is off by default -
+    measured slower than the four launches it replaces - and stays parity-tested: TG_ATTN_TILE=1 is read when the library
+    first launches an attention block, so the run is a child process.  Tiles of 12 centres (12 wavefronts) and of 16
+    (8 wavefronts, two centres each), C2 shapes, eager + lean steps against the oracle."""
+    import os
+    import subprocess
+    import sys
+    code = ('import sys; sys.path.insert(0, "tests"); import bench, test_hip_parity as t; '
+            'from www2023tiger_amd._lib import lib; import ctypes as C; c = bench.C2; '
+            'stream = bench.make_stream(c["n_u"], c["n_i"], 12000, c["T"] * 12000 / c["E"], seed=41, d_e=c["d"]); '
+            't._oracle_vs_fused(stream, c["d"], c["K"], c["B"], 6, c["msg_src"], c["upd_src"], fuse=True, eager=True, lean="mixed"); '
+            'm, _ = bench.build_models(stream, c["d"], c["K"], c["msg_src"], c["upd_src"]); m.fuse_attention(); '
+            'assert lib.tg_attn_tile_applies(C.byref(m.model_struct())) == 1; print("tile parity ok")')
+    env = dict(os.environ, TG_ATTN_TILE='1', TG_ATTN_TILE_MC=mc)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'tile parity ok' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_derived_tables_follow_in_place_writes_to_state_and_parameters():
     """The eager-update table and the pre-multiplied attention weights are functions of state / parameters.  In-place torch
     writes to a memory tensor, to the mailbox, to an updater weight or to an attention weight between steps (no
