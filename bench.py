@@ -237,7 +237,7 @@ def profile_stages(model, buf, steps):
     return names, acc / steps, counts / steps
 
 
-def stage_work(cfg, U, O_, P, eager, fused, n_nodes, E, tile=False):
+def stage_work(cfg, U, O_, P, eager, fused, n_nodes, E, tile=False, gtab=False):
     """Algorithmic work per launch of every stage (SURVEY.md s8 d, with the measured U = involved, O = with a
     pending message, P = unique positive nodes of the run): name -> (flops or None, HBM bytes, kernel name)."""
     B, K, d = cfg['B'], cfg['K'], cfg['d']
@@ -276,6 +276,8 @@ def stage_work(cfg, U, O_, P, eager, fused, n_nodes, E, tile=False):
                                           'tg::k_attn_tile')
     elif fused:
         w['attn_gemm_q'] = (2.0 * Q * nk * d, Q * d * 4 + Q * nk * 4 + nk * d * 4, 'tg::k_gemm')           # G = c Wqk^T + gconst
+        if gtab:  # eager query rows: the product runs on the P positive nodes at the end of the step instead of on Q centres
+            w['eager_query_rows(G)'] = (2.0 * P * nk * d, P * d * 4 * (2 + fe) + P * nk * 4 + nk * d * 4, 'tg::k_gemm')
         w['attn_gemm_fc1'] = (2.0 * Q * d * (nk + d), Q * (nk + d) * 4 + Q * d * 4 + d * (nk + d) * 4, 'tg::k_gemm_sk / k_gemm')
     else:
         w['attn_gemm_q'] = (2.0 * Q * 2 * d * d, Q * d * 4 + Q * 2 * d * 4, 'tg::k_gemm')
@@ -428,7 +430,8 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
         U, O_ = cf[0], cf[1]
     from www2023tiger_amd._lib import lib as _tg
     tile = bool(fused and _tg.tg_attn_tile_applies(C.byref(model.model_struct())))
-    work = stage_work(cfg, U, O_, P, eager, fused, stream['n_nodes'], E, tile)
+    gtab = getattr(model, '_gtab', None) is not None and restart_prob == 0  # eager query rows (tg_model.g_table) in use
+    work = stage_work(cfg, U, O_, P, eager, fused, stream['n_nodes'], E, tile, gtab)
     traffic = load_traffic(traffic_tag)
     empty = {'zero_flags', 'dedup_positive', 'restarter_targets', 'apply_messages(gru)' if eager else 'eager_updater(gru)'}
     if lean:  # no compaction launch, and the centres ride on the sampler's launch
@@ -441,6 +444,10 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
         empty |= {'attn_gemm_g', 'attn_gemm_v', 'attn_gemm_out'}
     if tile:
         empty |= {'attn_gemm_q', 'attn_gemm_fc1', 'attn_gemm_fc2'}
+    if gtab:
+        empty |= {'attn_gemm_q'}
+    else:
+        empty |= {'eager_query_rows(G)'}
     overhead = float(np.median([v for n, v in zip(names, stage_ms) if n in empty]))  # cost of an empty event pair
     stages = {n: float(v) for n, v in zip(names, stage_ms) if n not in empty}
     dom = max(stages, key=stages.get)
@@ -451,6 +458,8 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
                            attention_weights=('pre-multiplied (tg_attn_fuse)' + (', whole block in one launch with G / S in LDS (k_attn_tile)' if tile else '')) if fused else 'as stored',
                            updater=('eager: once per stored message (TIGE.eager_updates)' + (', rows read from the tables directly' if direct else ', compact reprs copy')) if eager else
                                    'lazy: on the fly for every involved node with a pending message',
+                           query_rows=('eager: per-node table of folded queries, refreshed for the batch\'s positive nodes at the end of '
+                                       'the step (tg_model.g_table)' if gtab else 'G product over the 3B centres of the batch'),
                            involved_set=('not formed (tg_step_io.lean: nothing in a direct-form eager step reads it)' if lean else 'formed (sorted unique ids + ranks)'),
                            state_preroll_batches=preroll, involved_per_batch=float(U),
                            involved_before_timed_region=[dict(batch=b, involved=u) for b, u in u_trace],

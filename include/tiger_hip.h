@@ -240,6 +240,16 @@ typedef struct tg_model {
    * step (tg_stream_step with embed_only + lean on a model with pending_vals) and by the planned, owner-filtered
    * tg_stream_writeback; every other entry point addresses state by node id and refuses a model that carries it. */
   const int32_t* row_of;
+  /* Optional (NULL = off; needs attn_fused and pending_vals): EAGER QUERY ROWS for streaming with FIXED parameters.
+   * g_table [n_nodes, n_head * kvw'] (kvw' as in attn_fused) holds, for every node v, the folded query of the first
+   * attention layer  G_v = (e(v) + nfeat(v)) Wqk^T + gconst  with e(v) the node's effective state row (has_msg ?
+   * pending : right).  That row - hence G_v - changes only when v is a positive node of a batch (it IS pending[v] from
+   * the moment the eager updater writes it, and STEP 4 later copies the same values into the right memory), so a full
+   * eager tg_stream_step refreshes the rows of the batch's unique positive nodes at its very end (tg_attn_gtab_rows)
+   * and the G product over all 3B centres of the next batches (temporal_agg_modules.py:210-227, the query side) becomes a
+   * row lookup by node id.  Same arithmetic per row, so the same bits.  Honoured only by such steps (not with `lazy`,
+   * `inner`, embed_only); contract as for pending_vals: rebuilt (all rows) when state or parameters change elsewhere. */
+  float* g_table;
 } tg_model;
 
 /* Inference-time algebra on the attention weights (parameters only, no data):
@@ -257,6 +267,10 @@ size_t tg_attn_fused_floats(const tg_model* m);
 size_t tg_attn_fuse_workspace_bytes(const tg_model* m);
 int tg_attn_fuse(const tg_model* m, float* fused, void* ws, size_t ws_bytes, void* stream);
 int tg_attn_tile_applies(const tg_model* m);
+/* G rows of the listed nodes into m->g_table (see tg_model.g_table): n (<= *n_dev when given) node ids, state rows read as
+ * the attention centres read them; ws: n * d floats. */
+int tg_attn_gtab_rows(const tg_model* m, int64_t n, const int64_t* nids, const int32_t* n_dev, void* ws, size_t ws_bytes,
+                      void* stream);
 
 /* TimeEncode.forward (time_encoding.py:24-26): out[i,:] = cos(fl32(ts[i]*w) + phi) */
 int tg_time_encode(int64_t n, const float* ts, int32_t d, const float* freq, const float* phase,

@@ -33,7 +33,7 @@ def test_struct_layouts_match_header():
     from www2023tiger_amd import _lib
     assert ctypes.sizeof(_lib.TgTcsr) == 6 * 8
     assert ctypes.sizeof(_lib.TgLinear) == 16
-    assert ctypes.sizeof(_lib.TgModel) == 8 + 8 * 4 + 8 * 13 + 2 * 16 + 4 * 8 + 2 * 16 + 4 * 8 + 3 * 16 + 8 + 8 + 8
+    assert ctypes.sizeof(_lib.TgModel) == 8 + 8 * 4 + 8 * 13 + 2 * 16 + 4 * 8 + 2 * 16 + 4 * 8 + 3 * 16 + 8 + 8 + 8 + 8
     assert ctypes.sizeof(_lib.TgStepIo) == 24 * 8
 
 

@@ -71,8 +71,9 @@ def test_c2_graph_replay_of_the_resident_lean_step_matches_oracle(n_eager):
         model.launch_step(buf)
         cnt = check(b)
         model.note_rows(cnt[1], cnt[2])
-    if n_eager == 0:  # the eager-update table must be current before a capture (TIGE._sync_pending refuses inside one)
+    if n_eager == 0:  # the derived tables must be current before a capture (their rebuilds refuse to run inside one)
         model._sync_pending()
+        model._sync_gtab()
     graph = _capture(model, buf)
     for b in range(n_eager, nb):
         graph.replay()

@@ -51,7 +51,7 @@ class TgModel(C.Structure):
         ('upd_fc1', TgLinear), ('upd_fc2', TgLinear),
         ('attn_wq', vp), ('attn_wk', vp), ('attn_wv', vp), ('attn_b_in', vp),
         ('attn_out', TgLinear), ('attn_fc1', TgLinear), ('attn_fc2', TgLinear), ('attn_fused', vp),
-        ('pending_vals', vp), ('row_of', vp),
+        ('pending_vals', vp), ('row_of', vp), ('g_table', vp),
     ]
 
 
@@ -168,6 +168,7 @@ SIGNATURES = {
     'tg_attn_fuse_workspace_bytes': (sz, [P(TgModel)]),
     'tg_attn_fuse': (C.c_int, [P(TgModel), vp, vp, sz, vp]),
     'tg_attn_tile_applies': (C.c_int, [P(TgModel)]),
+    'tg_attn_gtab_rows': (C.c_int, [P(TgModel), i64, vp, vp, vp, sz, vp]),
     'tg_ap_auc': (C.c_int, [i64, i32, vp, vp, vp, vp, vp, vp]),
     'tg_stream_writeback_workspace_bytes': (sz, [P(TgModel), i64]),
     'tg_stream_writeback': (C.c_int, [P(TgModel), P(TgWritebackIo), vp, sz, vp]),

@@ -477,10 +477,12 @@ __global__ void __launch_bounds__(256) k_gemm_rb(GemmArgs g) {
       const int n = n0 + (wn * RN + v) * 32 + fr;
       if (n >= N) continue;
       uint8_t v2[16];  // the second bias is added on rows whose validity byte is set; all 16 bytes requested together
+      int crow[16];    // ... and the output rows (c_rows: scattered)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t m = min(m0 + (wm * RM + u) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk, M - 1);
         v2[r] = g.bias2 ? g.bias2_valid[m] : 0;
+        crow[r] = g.c_rows ? g.c_rows[m] : (int)m;
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -488,7 +490,7 @@ __global__ void __launch_bounds__(256) k_gemm_rb(GemmArgs g) {
         if (m >= M) continue;
         float x = g.alpha * (acc[u][v][r] + bias[v] + (v2[r] ? bias2[v] : 0.f));
         if (g.relu) x = fmaxf(x, 0.f);
-        g.c[m * g.ldc + n] = x;
+        g.c[(int64_t)crow[r] * g.ldc + n] = x;
       }
     }
 }
@@ -520,6 +522,12 @@ __global__ void __launch_bounds__(256) k_gemm_astat(GemmArgs g, int cpb) {
   const int64_t m0 = mt * 64;
   if (m0 >= M) return;
   const int ar = tid >> 3, ac4 = (tid & 7) * 4;
+  int crow[16];  // output rows of this lane's 16 accumulator rows (c_rows: scattered; requested now, used after the loop)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t m = min(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk, M - 1);
+    crow[r] = g.c_rows ? g.c_rows[m] : (int)m;
+  }
   // ---- the activation panel, once
   {
     float4 pa[2][NKT];
@@ -592,7 +600,7 @@ __global__ void __launch_bounds__(256) k_gemm_astat(GemmArgs g, int cpb) {
       const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
       float x = g.alpha * (acc[r] + bias);
       if (g.relu) x = fmaxf(x, 0.f);
-      if (n < N && m < M) g.c[m * g.ldc + n] = x;
+      if (n < N && m < M) g.c[(int64_t)crow[r] * g.ldc + n] = x;
       acc[r] = 0.f;
     }
   }
@@ -675,7 +683,7 @@ int gemm_launch(const GemmArgs& g, hipStream_t st) {
   // 1.08 ms, fc2 0.261 -> 0.253 ms; at C3 / C4 sizes (288 .. 2 500 blocks) 3 .. 17 % SLOWER than the 64 x 64 blocks (whose
   // several co-resident blocks per CU cover each other's prologue and epilogue); 128 x 128 blocks are slower still there
   static const int rb_knob = getenv("TG_GEMM_RB") ? atoi(getenv("TG_GEMM_RB")) : 1;  // tuning knob: 0 = off, 2 = 128 x 128
-  if (rb_knob && !g.ask_part && g.nbatch == 1 && !g.w_kmajor && !g.bias_rs && !g.row_valid && !g.relu_mask && !g.c_rows &&
+  if (rb_knob && !g.ask_part && g.nbatch == 1 && !g.w_kmajor && !g.bias_rs && !g.row_valid && !g.relu_mask &&
       !g.accumulate && cdiv(g.m_cap, 128) * NT >= 4096) {
     if (rb_knob == 2 && g.n >= 512) {
       hipLaunchKernelGGL((k_gemm_rb<2, 2>), dim3((unsigned)(8 * cdiv(cdiv(g.m_cap, 128), 8) * cdiv(g.n, 128))), dim3(256), 0, st, gd);
@@ -689,7 +697,7 @@ int gemm_launch(const GemmArgs& g, hipStream_t st) {
   {
     const int nkt = (int)cdiv(g.k, BK);
     const bool plain_as = !g.ask_part && g.nbatch == 1 && !g.a1.p && !g.w_kmajor && !g.bias_rs && !g.bias2 && !g.row_valid &&
-                          !g.relu_mask && !g.c_rows && !g.accumulate && g.a0.w == g.k;
+                          !g.relu_mask && !g.accumulate && g.a0.w == g.k;
     if (as_knob && plain_as && NT >= 8 && (nkt == 4 || nkt == 6 || nkt == 8) && MT * NT <= 1024) {  // (C3's 3 264 tiles: no gain)
       // two column tiles per block (measured at C2, 48 x 17 tiles: 21.6 us; three: 28.1, four: 24.6, six: 29.8, nine:
       // 40.8; separate 64 x 64 blocks: 24.4): two such blocks share a CU and cover each other's barriers, which matters

@@ -189,7 +189,8 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
                                                    const uint32_t* __restrict__ rank, const float* __restrict__ G,
                                                    float* __restrict__ S, uint8_t* __restrict__ valid, DropCfg dc,
                                                    float* __restrict__ rsum, int direct, PosArgs pos,
-                                                   const float* __restrict__ key_rows, const float* __restrict__ zl) {
+                                                   const float* __restrict__ key_rows, const float* __restrict__ zl,
+                                                   const float* __restrict__ gtab, const int64_t* __restrict__ cnids) {
   using V = RowVec<W>;
   const int lane = lane_id();
   // direct (eager updates): neighbour rows come from the state tables, row(v) = has_msg[v] ? pending[v] : right[v];
@@ -260,7 +261,8 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
       mx[h] = -INFINITY;
       l[h] = 0.f;
       lk[h] = 0.f;
-      const float* gh = G + ((int64_t)i * NH + h) * kvw;
+      // eager query rows (tg_model.g_table): the centre NODE's row of the table instead of row i of this batch's product
+      const float* gh = gtab ? gtab + (state_row(m, cnids[i]) * NH + h) * (int64_t)kvw : G + ((int64_t)i * NH + h) * kvw;
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const int c = (lane + v * TG_WAVE) * W;
@@ -448,7 +450,7 @@ int attn_tile_launch(const tg_model* m, int64_t Q, const float* cc, const float*
 void launch_attn_core(const tg_model* m, int64_t Q, const float* ts, const int64_t* l1_nids, const int64_t* l1_eids,
                       const float* l1_ts, const float* reprs, const uint64_t* bm, const uint32_t* rank, const AttnWs& w,
                       const DropCfg& dc, hipStream_t st, int* rc_out, int direct = 0, const PosArgs* pos = nullptr,
-                      const float* key_rows = nullptr) {
+                      const float* key_rows = nullptr, const float* gtab = nullptr, const int64_t* cnids = nullptr) {
   const int d = m->d, d_e = m->d_e, nh = m->n_head;
   *rc_out = TG_OK;
   // Columns per lane: float4 (three columns per lane fill 58 of 64 lanes at d = 172 instead of 43 but measured SLOWER,
@@ -470,11 +472,11 @@ void launch_attn_core(const tg_model* m, int64_t Q, const float* ts, const int64
     if (ft)                                                                                                                \
       hipLaunchKernelGGL((k_attn_core<NH_, NV_, W_, true>), dim3(cgrid), dim3(256), 0, st, *m, Q, ts, l1_nids, l1_eids,    \
                          l1_ts, reprs, bm, rank, (const float*)w.g, w.s, w.valid, dc,                                      \
-                         dc.p > 0.f ? w.rsum : (float*)nullptr, direct, pos ? *pos : PosArgs{}, key_rows, zl);             \
+                         dc.p > 0.f ? w.rsum : (float*)nullptr, direct, pos ? *pos : PosArgs{}, key_rows, zl, gtab, cnids); \
     else                                                                                                                   \
       hipLaunchKernelGGL((k_attn_core<NH_, NV_, W_, false>), dim3(cgrid), dim3(256), 0, st, *m, Q, ts, l1_nids, l1_eids,   \
                          l1_ts, reprs, bm, rank, (const float*)w.g, w.s, w.valid, dc,                                      \
-                         dc.p > 0.f ? w.rsum : (float*)nullptr, direct, pos ? *pos : PosArgs{}, key_rows, zl);             \
+                         dc.p > 0.f ? w.rsum : (float*)nullptr, direct, pos ? *pos : PosArgs{}, key_rows, zl, gtab, cnids); \
   } while (0)
   if (nh == 2 && nv == 1 && W == 2) TG_CORE(2, 1, 2);
   else if (nh == 1 && nv == 1 && W == 2) TG_CORE(1, 1, 2);
@@ -504,14 +506,14 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
                               const int64_t* l1_nids, const int64_t* l1_eids, const float* l1_ts, const float* reprs,
                               const uint64_t* bm, const uint32_t* rank, float* out, const AttnWs& w, hipStream_t st,
                               tg_profiler* pf, const PosArgs* pos, const DirectArgs* da, bool centres_done,
-                              const float* key_rows) {
+                              const float* key_rows, bool use_gtab) {
   // stage numbering of the profiler is kept: q -> "merged q+g", g -> skipped, v/out -> skipped, fc1 -> fused
   int stage = ST_ATTN_FIRST + 1;
   const int d = m->d;
   const FusedView f = fused_view(m, m->attn_fused);
   if (!centres_done) launch_centres(m, Q, nids, reprs, bm, rank, w, pos, da, st);  // else: rode on the sampler's launch
   int rc;
-  if (attn_tile_applies(m) && !key_rows) {  // the whole block in one launch, G and S in LDS only (tg_attn_tile.hip); timed as the core
+  if (attn_tile_applies(m) && !key_rows && !use_gtab) {  // the whole block in one launch, G and S in LDS only (tg_attn_tile.hip); timed as the core
     prof_mark(pf, stage++, st);
     prof_mark(pf, stage++, st);
     prof_mark(pf, stage++, st);
@@ -522,17 +524,20 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
     return check_launch("tg_temporal_attn_fwd(tile)");
   }
   GemmArgs g{};
-  // G = c Wqk^T + gconst   (scaled query folded through the key projection, all heads at once)
+  // G = c Wqk^T + gconst   (scaled query folded through the key projection, all heads at once) - or, with eager query
+  // rows, nothing: the core reads G of a centre from the per-node table
   prof_mark(pf, stage++, st);
-  g.m_cap = Q; g.n = f.nk; g.k = d; g.a0 = ASeg{w.cc, d, d, nullptr};
-  g.w = f.wqk; g.ldw = d; g.bias = f.gconst; g.c = w.g; g.ldc = f.nk; g.alpha = 1.f; g.nbatch = 1;
-  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  if (!use_gtab) {
+    g.m_cap = Q; g.n = f.nk; g.k = d; g.a0 = ASeg{w.cc, d, d, nullptr};
+    g.w = f.wqk; g.ldw = d; g.bias = f.gconst; g.c = w.g; g.ldc = f.nk; g.alpha = 1.f; g.nbatch = 1;
+    if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  }
   prof_mark(pf, stage++, st);
   prof_mark(pf, stage++, st);
   tg_model mc = *m;  // without an edge table the fused weights are compact: the key rows have no edge segment
   if (!m->efeats) mc.d_e = 0;
   launch_attn_core(&mc, Q, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, w, DropCfg{}, st, &rc, da ? 1 : 0, da ? pos : nullptr,
-                   key_rows);
+                   key_rows, use_gtab ? m->g_table : nullptr, nids);
   if (rc != TG_OK) return rc;
   prof_mark(pf, stage++, st);
   prof_mark(pf, stage++, st);
@@ -566,14 +571,14 @@ int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float*
                  const int64_t* l1_eids, const float* l1_ts, const float* reprs, const uint64_t* bm,
                  const uint32_t* rank, float* out, const AttnWs& w, hipStream_t st, tg_profiler* pf = nullptr,
                  const DropCfg* drop = nullptr, const PosArgs* pos = nullptr, const DirectArgs* da = nullptr,
-                 const float* key_rows = nullptr, bool centres_done = false) {
+                 const float* key_rows = nullptr, bool centres_done = false, bool use_gtab = false) {
   const DropCfg dc = drop ? *drop : DropCfg{};
   int stage = ST_ATTN_FIRST;
   prof_mark(pf, stage++, st);
   const int d = m->d, d_e = m->d_e, kvw = 2 * d + d_e, nh = m->n_head, dh = 2 * d / nh, E = 2 * d;
   if (m->attn_fused && dc.p == 0.f)  // (the pre-multiplied weights do not care where the node part of a key row comes from)
     return attn_forward_fused(m, Q, nids, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, out, w, st, pf, pos, da, centres_done,
-                              key_rows);
+                              key_rows, use_gtab && m->g_table && !key_rows);
   const int qblocks = (int)cdiv(2 * d, 4);
   if (da) {  // the constant half of the query projection from the rank-form kernel (no centre rows), then the direct centres
     hipLaunchKernelGGL(k_attn_centres, dim3(1 + qblocks), dim3(256), 0, st, (int64_t)0, d / 4, nids, (const float4*)reprs, bm,
@@ -845,6 +850,44 @@ extern "C" int tg_apply_messages(const tg_model* m, const int64_t* outdated, con
   return apply_messages(m, outdated, out_pos, n_outdated, cap, reprs, err, ws, ws_bytes, as_stream(stream));
 }
 
+// ---- eager query rows (tiger_hip.h: tg_model.g_table) -------------------------------------------------------------
+namespace tg {
+__global__ void k_ids32(int64_t n, const int64_t* __restrict__ ids, int32_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (int32_t)ids[i];
+}
+// G rows of the nodes nids[0 .. min(cap, *n_dev)) into m->g_table: c = e(v) + nfeat(v) as the attention centres read it
+// (into `crows`, cap x d floats), then the same product the forward pass runs, scattered to the nodes' table rows
+int gtab_rows(const tg_model* m, int64_t cap, const int64_t* nids, const int32_t* rows32, const int32_t* n_dev, float* crows,
+              hipStream_t st) {
+  if (!m->g_table || !m->attn_fused || !m->pending_vals) return TG_EINVAL;
+  if (m->row_of) return TG_EUNSUPPORTED;  // (rows32 are node ids)
+  const int d = m->d;
+  const FusedView f = fused_view(m, m->attn_fused);
+  hipLaunchKernelGGL(k_attn_centres_direct, dim3(flat_grid(cap * (d / 4), 256)), dim3(256), 0, st, *m, cap, nids,
+                     (const float4*)m->nfeats, (float4*)crows, DirectArgs{}, PosArgs{});
+  GemmArgs g{};
+  g.m_cap = cap; g.m_dev = n_dev; g.n = f.nk; g.k = d; g.a0 = ASeg{crows, d, d, nullptr};
+  g.w = f.wqk; g.ldw = d; g.bias = f.gconst; g.c = m->g_table; g.ldc = f.nk; g.c_rows = rows32; g.alpha = 1.f; g.nbatch = 1;
+  return gemm_launch(g, st);
+}
+}  // namespace tg
+
+extern "C" int tg_attn_gtab_rows(const tg_model* m, int64_t n, const int64_t* nids, const int32_t* n_dev, void* ws,
+                                 size_t ws_bytes, void* stream) {
+  if (!attn_dims_ok(m) || n < 0) return TG_EINVAL;
+  if (n == 0) return TG_OK;
+  if (!nids || !ws) return TG_EINVAL;
+  Carver cv(ws, ws_bytes);
+  float* crows = cv.take<float>((size_t)n * m->d);
+  int32_t* rows32 = cv.take<int32_t>((size_t)n);
+  if (!cv.ok) return TG_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(k_ids32, dim3(flat_grid(n, 256)), dim3(256), 0, st, n, nids, rows32);
+  const int rc = gtab_rows(m, n, nids, rows32, n_dev, crows, st);
+  return rc != TG_OK ? rc : check_launch("tg_attn_gtab_rows");
+}
+
 // ---------------------------------------------------------------------------------
 // Fused streaming step
 // ---------------------------------------------------------------------------------
@@ -852,13 +895,13 @@ namespace tg {
 enum Stage : int {
   ST_QUERIES = 0, ST_SAMPLE, ST_COMPACT, ST_GATHER, ST_UPDATE, ST_ATTN_PREP, ST_ATTN_Q, ST_ATTN_G, ST_ATTN_CORE,
   ST_ATTN_V, ST_ATTN_O, ST_ATTN_FC1, ST_ATTN_FC2, ST_DEDUP, ST_WRITE_RIGHT, ST_STORE_EVENTS, ST_WRITE_LEFT, ST_EAGER,
-  ST_COUNT
+  ST_GTAB, ST_COUNT
 };
 static const char* const kStageNames[ST_COUNT] = {
     "zero_flags", "sample_recent_edges", "unique_compact", "gather_right_memory", "apply_messages(gru)",
     "attn_centres+qconst", "attn_gemm_q", "attn_gemm_g", "attn_core(gather+softmax)", "attn_gemm_v", "attn_gemm_out",
     "attn_gemm_fc1", "attn_gemm_fc2", "dedup_positive", "writeback_phase0", "restarter_targets", "writeback_phase1",
-    "eager_updater(gru)"};
+    "eager_updater(gru)", "eager_query_rows(G)"};
 static_assert(ST_ATTN_PREP == ST_ATTN_FIRST, "attention stage numbering");
 }  // namespace tg
 
@@ -1092,8 +1135,10 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
       return rc;
     key_rows = w.emb2;
   }
+  // eager query rows: a full eager step of a model that carries the table (it refreshes the table at its end)
+  w.gtab = eager && m->g_table && m->attn_fused && !lz && !inner && !io->embed_only && !io->collate_only && !drop;
   if ((rc = attn_forward(m, Q, w.nids3, w.ts3f, w.l1n, w.l1e, w.l1t, w.reprs, w.bm, w.rank, io->h, w.attn, st, pf,
-                         drop, pp, w.direct ? &da : nullptr, key_rows, w.lean && !recent_nodes)) != TG_OK)
+                         drop, pp, w.direct ? &da : nullptr, key_rows, w.lean && !recent_nodes, w.gtab)) != TG_OK)
     return rc;
   prof_mark(pf, ST_DEDUP, st);
   if (io->h_new) {  // h(t'+) rows of cat[src, dst]: reprs[local(node)], or the table rows themselves
@@ -1181,6 +1226,12 @@ int step_writeback_b(const tg_model* m, const tg_step_io* io, StepWs& w, hipStre
     if ((rc = apply_messages(m, w.upos, w.upos32, w.counts + 2, P, m->pending_vals, io->err, w.apply_ws, w.apply_bytes, st,
                              true, nullptr, bound)) != TG_OK)
       return rc;
+  }
+  prof_mark(pf, ST_GTAB, st);
+  if (w.gtab) {
+    // ... and with them their query rows: the effective rows of exactly these nodes have just changed (tg_model.g_table).
+    // The centre-row buffer of the forward pass is free again: it takes the P rows e(v) + nfeat(v)
+    if ((rc = gtab_rows(m, 2 * io->B, w.upos, w.upos32, w.counts + 2, w.attn.cc, st)) != TG_OK) return rc;
   }
   prof_mark(pf, ST_COUNT, st);
   if (pf) pf->armed = true;

@@ -66,6 +66,7 @@ struct StepWs {
   bool lean;        // no involved / outdated sets are formed (tg_step_io.lean)
   bool fused_wb;    // STEP 4-6 run as one launch (needs the snapshot taken by the direct centres launch)
   bool direct;      // ... and no compact copy of the involved rows was made (centres / neighbours read the tables)
+  bool gtab;        // the folded queries come from the per-node table; the step refreshes its positive nodes' rows at the end
   // --n_layers 2: second-hop lists of the Q*K neighbour slots, the slots' query times (the roots'), their embeddings
   int64_t *h2n, *h2e;
   float *h2t, *ts2, *emb2;
@@ -74,6 +75,8 @@ struct StepWs {
 
 bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w, int n_layers = 1);
 int attn_dims_ok(const tg_model* m);
+int gtab_rows(const tg_model* m, int64_t cap, const int64_t* nids, const int32_t* rows32, const int32_t* n_dev, float* crows,
+              hipStream_t st);
 // collate + STEP 1-3 (+ io->h_new); `gates` (nullable) receives the GRU gate activations
 // eager: take the outdated nodes' rows from m->pending_vals instead of running the updater (tg_stream_step only)
 int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, StepWs& w, float* gates, hipStream_t st,

@@ -690,6 +690,7 @@ class HipPartitionEngine:
                                              ptr(self.err), ptr(ws), ws.numel(), self._stream()),
                        'tg_apply_messages(pending)')
         m._pending_stamp = m._state_stamp()  # the table is current again
+        m._gtab_stamp = None                 # (the per-node query table, if the model has one, is not maintained here)
 
     def check_invariants(self):
         self.hip_ops.raise_if_err(self.err)

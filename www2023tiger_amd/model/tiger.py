@@ -145,6 +145,8 @@ class TIGE(nn.Module):
     def _apply(self, fn, *a, **kw):  # .to() / .cuda() move every tensor: pointers change
         eager, fused = self._pending is not None, self._fused is not None
         self._plists = None
+        self._gtab = None
+        self._gtab_stamp = None
         self._struct_cache = None
         self._fused = None
         self._fused_l1 = None
@@ -225,7 +227,8 @@ class TIGE(nn.Module):
                     lin(mha.out_proj), lin(att.merger.fc1), lin(att.merger.fc2),
                     ptr(self._fused) if self._fused is not None else None,
                     ptr(self._pending) if self._pending is not None else None,
-                    ptr(self._row_of) if getattr(self, '_row_of', None) is not None else None)
+                    ptr(self._row_of) if getattr(self, '_row_of', None) is not None else None,
+                    ptr(self._gtab) if getattr(self, '_gtab', None) is not None else None)
         self._struct_cache = m
         return m
 
@@ -284,6 +287,7 @@ class TIGE(nn.Module):
         if oldP is not None:
             self._pending = torch.zeros(n_rows, self.memory_dim, dtype=torch.float32, device=dev)
             self._pending[rows] = oldP[keep]
+        self._gtab = None
         self._struct_cache = None
         self._pending_stamp = None
         self._touch()
@@ -291,6 +295,41 @@ class TIGE(nn.Module):
 
     def invalidate_pending(self):
         self._pending_stamp = None
+        self._gtab_stamp = None
+
+    # ---- eager query rows (tiger_hip.h: tg_model.g_table) --------------------------------------------------------------
+    def _gtab_wanted(self) -> bool:
+        import os
+        return (self._pending is not None and self._fused is not None and self.n_layers == 1
+                and getattr(self, '_row_of', None) is None and os.environ.get('TG_GTAB', '1') != '0')
+
+    def _sync_gtab(self):
+        """The per-node table of folded attention queries G_v (one row per node; the fused eager step refreshes the rows of
+        a batch's positive nodes itself): allocated when the model streams with eager updates AND pre-multiplied weights,
+        rebuilt - all rows - whenever state or parameters changed outside that step."""
+        if not self._gtab_wanted():
+            if getattr(self, '_gtab', None) is not None:
+                self._gtab = None
+                self._struct_cache = None
+            return
+        stamp = (self._state_stamp(), tuple(self._attn_stamp()), id(self._fused))
+        if getattr(self, '_gtab', None) is not None and stamp == getattr(self, '_gtab_stamp', None):
+            return
+        if self.device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('eager query rows: run one step eagerly before capturing it into a graph')
+        dev, n = self.device, self.msg_store.n
+        nk = self.n_head * (2 * self.memory_dim + (self.efeat_dim if self.raw_feat_getter.efeats is not None else 0))
+        if getattr(self, '_gtab', None) is None or self._gtab.shape != (n, nk):
+            self._gtab = torch.empty(n, nk, dtype=torch.float32, device=dev)
+            self._struct_cache = None
+        m = self.model_struct()
+        chunk = 262144
+        ws = self._ws('gtab', min(n, chunk) * (4 * self.memory_dim + 4) + 64)
+        for lo in range(0, n, chunk):
+            ids = torch.arange(lo, min(n, lo + chunk), dtype=torch.int64, device=dev)
+            check(lib.tg_attn_gtab_rows(C.byref(m), ids.numel(), ptr(ids), None, ptr(ws), ws.numel(), stream_ptr(dev)),
+                  'tg_attn_gtab_rows')
+        self._gtab_stamp = stamp
 
     def _touch(self):
         self._state_version += 1
@@ -741,9 +780,13 @@ class TIGE(nn.Module):
             buf.lazy_batch += 1
         if self._pending is not None and not buf.embed_only:
             self._sync_pending()
+            if not buf.io.lazy:  # (a step with the in-step restart loop runs the G product: it does not read the table)
+                self._sync_gtab()
         m = self.model_struct()
         check(lib.tg_stream_step(C.byref(m), C.byref(g), C.byref(buf.io), ptr(buf.ws), buf.ws.numel(),
                                  stream_ptr(self.device)), 'tg_stream_step')
+        if buf.io.lazy and getattr(self, '_gtab', None) is not None:
+            self._gtab_stamp = None  # the in-step restart loop re-initialises rows the table does not follow
 
     @torch.no_grad()
     def stream_step(self, src, dst, neg, ts, eids, want_prev: bool = False, check_invariants: bool = True,
