@@ -81,6 +81,10 @@ struct GruArgs {
   int64_t ldo;
   const int32_t* out_rows;  // nullable
   float* gates;             // nullable [cap, 4, d]: r, z, n, h_n (+bias) per live row, for the backward pass
+  // nullable: a second copy of the new rows, dense by launch row m ([cap, d]), plus add2[out_rows[m], :] when add2 is given
+  // (the eager updater hands the attention-centre form of its rows, h + node features, to the query-row product)
+  float* out2;
+  const float* add2;
   int dbg;                  // diagnostic bits, 0 in production
   int64_t rows_hint;        // upper bound of live rows known on the host (0 = unknown), picks the tile height
   int tail_blocks;          // set by gru_launch: leading blocks that run the 16-column tail (k_gru<3, 4> only)

@@ -911,7 +911,9 @@ __device__ __forceinline__ void gru_tail16(const GruArgs& g, int tb, int j0, flo
       const float zgate = fast_sigmoid(acc_z[rt][r] + bz);
       const float hn = acc_hn[rt][r] + bhn;
       const float ng = fast_tanh(acc_in[rt][r] + bin + rgate * hn);
-      g.out[(int64_t)orow_s[lr] * g.ldo + j] = (1.f - zgate) * ng + zgate * Hs[lr][li];
+      const float hv = (1.f - zgate) * ng + zgate * Hs[lr][li];
+      g.out[(int64_t)orow_s[lr] * g.ldo + j] = hv;
+      if (g.out2) g.out2[m * (int64_t)d + j] = g.add2 ? hv + g.add2[(int64_t)orow_s[lr] * d + j] : hv;
       if (g.gates) {
         float* gp = g.gates + m * 4 * (int64_t)d + j;
         gp[0] = rgate; gp[d] = zgate; gp[2 * d] = ng; gp[3 * d] = hn;
@@ -1157,7 +1159,9 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
     const float hn = ahn_ + bhn;
     const float ng = fast_tanh(ain_ + bin + rg * hn);
     if (jok && m < M) {
-      g.out[orow * g.ldo + j] = (1.f - zg) * ng + zg * hold;
+      const float hv = (1.f - zg) * ng + zg * hold;
+      g.out[orow * g.ldo + j] = hv;
+      if (g.out2) g.out2[m * (int64_t)d + j] = g.add2 ? hv + g.add2[orow * d + j] : hv;
       if (g.gates) {
         float* gp = g.gates + m * 4 * (int64_t)d + j;
         gp[0] = rg; gp[d] = zg; gp[2 * d] = ng; gp[3 * d] = hn;
@@ -1467,7 +1471,9 @@ __global__ void __launch_bounds__(256) k_gru_direct(GruArgs g) {
     const float hn = o_hn[q] + bhn;
     const float ng = fast_tanh(o_in[q] + bin + rg * hn);
     if (jok && m < M) {
-      g.out[orow[q] * g.ldo + j0 + fr] = (1.f - zg) * ng + zg * hold[q];
+      const float hv = (1.f - zg) * ng + zg * hold[q];
+      g.out[orow[q] * g.ldo + j0 + fr] = hv;
+      if (g.out2) g.out2[m * (int64_t)d + j0 + fr] = g.add2 ? hv + g.add2[orow[q] * d + j0 + fr] : hv;
       if (g.gates) {
         float* gp = g.gates + m * 4 * (int64_t)d + j0 + fr;
         gp[0] = rg; gp[d] = zg; gp[2 * d] = ng; gp[3 * d] = hn;

@@ -664,7 +664,8 @@ static size_t apply_ws_bytes(const tg_model* m, int64_t cap) {
 
 int apply_messages(const tg_model* m, const int64_t* outdated, const int32_t* out_pos, const int32_t* n_dev,
                    int64_t cap, float* reprs, uint32_t* err, void* ws, size_t ws_bytes, hipStream_t st,
-                   bool checked_already = false, float* gates = nullptr, int64_t rows_bound = 0) {
+                   bool checked_already = false, float* gates = nullptr, int64_t rows_bound = 0, float* out2 = nullptr,
+                   const float* add2 = nullptr) {
   const int d = m->d, mw = 3 * m->d + m->d_e;
   Carver cv(ws, ws_bytes);
   ApplyWs w{};
@@ -698,7 +699,7 @@ int apply_messages(const tg_model* m, const int64_t* outdated, const int32_t* ou
     GruArgs a{};
     a.cap = cap; a.n_dev = n_dev; a.d = d; a.xw = mw; a.x = x; a.h = h;
     a.w_ih = m->gru_w_ih; a.w_hh = m->gru_w_hh; a.b_ih = m->gru_b_ih; a.b_hh = m->gru_b_hh;
-    a.out = reprs; a.ldo = d; a.out_rows = out_pos; a.gates = gates;
+    a.out = reprs; a.ldo = d; a.out_rows = out_pos; a.gates = gates; a.out2 = out2; a.add2 = add2;
     if (!m->efeats && m->tsfm == TG_TSFM_ID) {
       // raw mailbox rows [own | other | edge | time] without an edge table: the edge segment [2d, 2d + d_e) is zeros
       // (memory.py:91 over feature_getter.py:95-99); the k-tiles that lie entirely inside it are skipped
@@ -859,13 +860,14 @@ __global__ void k_ids32(int64_t n, const int64_t* __restrict__ ids, int32_t* __r
 // G rows of the nodes nids[0 .. min(cap, *n_dev)) into m->g_table: c = e(v) + nfeat(v) as the attention centres read it
 // (into `crows`, cap x d floats), then the same product the forward pass runs, scattered to the nodes' table rows
 int gtab_rows(const tg_model* m, int64_t cap, const int64_t* nids, const int32_t* rows32, const int32_t* n_dev, float* crows,
-              hipStream_t st) {
+              hipStream_t st, bool crows_ready) {
   if (!m->g_table || !m->attn_fused || !m->pending_vals) return TG_EINVAL;
   if (m->row_of) return TG_EUNSUPPORTED;  // (rows32 are node ids)
   const int d = m->d;
   const FusedView f = fused_view(m, m->attn_fused);
-  hipLaunchKernelGGL(k_attn_centres_direct, dim3(flat_grid(cap * (d / 4), 256)), dim3(256), 0, st, *m, cap, nids,
-                     (const float4*)m->nfeats, (float4*)crows, DirectArgs{}, PosArgs{});
+  if (!crows_ready)  // (the GRU updater writes these rows itself, GruArgs.out2)
+    hipLaunchKernelGGL(k_attn_centres_direct, dim3(flat_grid(cap * (d / 4), 256)), dim3(256), 0, st, *m, cap, nids,
+                       (const float4*)m->nfeats, (float4*)crows, DirectArgs{}, PosArgs{});
   GemmArgs g{};
   g.m_cap = cap; g.m_dev = n_dev; g.n = f.nk; g.k = d; g.a0 = ASeg{crows, d, d, nullptr};
   g.w = f.wqk; g.ldw = d; g.bias = f.gconst; g.c = m->g_table; g.ldc = f.nk; g.c_rows = rows32; g.alpha = 1.f; g.nbatch = 1;
@@ -884,7 +886,7 @@ extern "C" int tg_attn_gtab_rows(const tg_model* m, int64_t n, const int64_t* ni
   if (!cv.ok) return TG_EWORKSPACE;
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(k_ids32, dim3(flat_grid(n, 256)), dim3(256), 0, st, n, nids, rows32);
-  const int rc = gtab_rows(m, n, nids, rows32, n_dev, crows, st);
+  const int rc = gtab_rows(m, n, nids, rows32, n_dev, crows, st, false);
   return rc != TG_OK ? rc : check_launch("tg_attn_gtab_rows");
 }
 
@@ -1223,15 +1225,18 @@ int step_writeback_b(const tg_model* m, const tg_step_io* io, StepWs& w, hipStre
     const int64_t P = 2 * io->B;
     // rows_hint (eager steps): the caller's bound on the unique positive nodes of a batch; performance only
     const int64_t bound = io->rows_hint > 0 ? std::min<int64_t>(P, io->rows_hint) : P;
+    // With eager query rows the GRU epilogue also leaves the attention-centre form of its rows (h + node features) in the
+    // centre-row buffer of the forward pass, which is free again
+    const bool cr = w.gtab && m->upd_fn == TG_UPD_GRU;
     if ((rc = apply_messages(m, w.upos, w.upos32, w.counts + 2, P, m->pending_vals, io->err, w.apply_ws, w.apply_bytes, st,
-                             true, nullptr, bound)) != TG_OK)
+                             true, nullptr, bound, cr ? w.attn.cc : nullptr, cr ? m->nfeats : nullptr)) != TG_OK)
       return rc;
   }
   prof_mark(pf, ST_GTAB, st);
   if (w.gtab) {
-    // ... and with them their query rows: the effective rows of exactly these nodes have just changed (tg_model.g_table).
-    // The centre-row buffer of the forward pass is free again: it takes the P rows e(v) + nfeat(v)
-    if ((rc = gtab_rows(m, 2 * io->B, w.upos, w.upos32, w.counts + 2, w.attn.cc, st)) != TG_OK) return rc;
+    // ... and the query rows of the same nodes: their effective rows have just changed (tg_model.g_table)
+    if ((rc = gtab_rows(m, 2 * io->B, w.upos, w.upos32, w.counts + 2, w.attn.cc, st, m->upd_fn == TG_UPD_GRU)) != TG_OK)
+      return rc;
   }
   prof_mark(pf, ST_COUNT, st);
   if (pf) pf->armed = true;
