@@ -10,7 +10,7 @@ set -e
 python bench.py --steps 100 --warmup 20 > $O/r03_bench_c2_$TAG.json 2> $O/err.log && echo bench ok
 python bench.py --steps 20 --warmup 5 --no-c5s-leg --no-dist-leg --no-cpu-baseline > $O/r03_bench_c2_driver_steps_$TAG.json 2>> $O/err.log
 python bench.py --steps 100 --warmup 20 --no-eager --no-cpu-baseline --no-c5s-leg --no-dist-leg > $O/r03_bench_c2_lazy_$TAG.json 2>> $O/err.log
-TG_ATTN_TILE=1 python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-c5s-leg --no-dist-leg > $O/r03_bench_c2_attn_tile_$TAG.json 2>> $O/err.log
+TG_GTAB=0 TG_ATTN_TILE=1 python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-c5s-leg --no-dist-leg > $O/r03_bench_c2_attn_tile_$TAG.json 2>> $O/err.log
 python bench.py --workload c1 --steps 300 --warmup 50 --no-cpu-baseline > $O/r03_bench_c1_$TAG.json 2>> $O/err.log
 python bench.py --workload c3 --steps 100 --warmup 20 --no-cpu-baseline > $O/r03_bench_c3_$TAG.json 2>> $O/err.log
 python bench.py --workload c4 --steps 100 --warmup 20 --no-cpu-baseline > $O/r03_bench_c4_$TAG.json 2>> $O/err.log
