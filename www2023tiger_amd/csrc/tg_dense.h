@@ -81,8 +81,9 @@ struct GruArgs {
   int64_t ldo;
   const int32_t* out_rows;  // nullable
   float* gates;             // nullable [cap, 4, d]: r, z, n, h_n (+bias) per live row, for the backward pass
-  // nullable: a second copy of the new rows, dense by launch row m ([cap, d]), plus add2[out_rows[m], :] when add2 is given
-  // (the eager updater hands the attention-centre form of its rows, h + node features, to the query-row product)
+  // nullable: a second copy of the new rows, dense by launch row m ([cap, d]), plus row add2[node(m), :] when add2 is given,
+  // node(m) = the row's output / memory-gather index (the eager updater, where both are the node id, hands the
+  // attention-centre form of its rows, h + node features, to the query-row product)
   float* out2;
   const float* add2;
   int dbg;                  // diagnostic bits, 0 in production

@@ -1304,12 +1304,14 @@ __global__ void __launch_bounds__(256) k_gru_direct(GruArgs g) {
   const float* wh = g.w_hh + (int64_t)jc * d;
   const int64_t wi_ps = (int64_t)d * xw, wh_ps = (int64_t)d * d;  // plane strides
   // epilogue operands of the rows this wavefront finishes (accumulator registers [4 ks, 4 ks + 4))
-  float hold[OWN];
+  float hold[OWN], addv[OWN];  // (addv: GruArgs.add2 of the row's node, requested with the old memory value - same depth)
   int64_t orow[OWN];
 #pragma unroll
   for (int q = 0; q < OWN; ++q) {
     const int64_t mm = min(m0 + 8 * ks + q + 4 * fk, M - 1);
-    hold[q] = g.h.p[(g.h.idx ? g.h.idx[mm] : mm) * g.h.ld + jc];
+    const int64_t node = g.h.idx ? g.h.idx[mm] : mm;
+    hold[q] = g.h.p[node * g.h.ld + jc];
+    addv[q] = (g.out2 && g.add2) ? g.add2[node * d + jc] : 0.f;
     orow[q] = g.out_rows ? (int64_t)g.out_rows[mm] : mm;
   }
   const float br = g.b_ih[jc] + g.b_hh[jc];
@@ -1473,7 +1475,7 @@ __global__ void __launch_bounds__(256) k_gru_direct(GruArgs g) {
     if (jok && m < M) {
       const float hv = (1.f - zg) * ng + zg * hold[q];
       g.out[orow[q] * g.ldo + j0 + fr] = hv;
-      if (g.out2) g.out2[m * (int64_t)d + j0 + fr] = g.add2 ? hv + g.add2[orow[q] * d + j0 + fr] : hv;
+      if (g.out2) g.out2[m * (int64_t)d + j0 + fr] = hv + addv[q];
       if (g.gates) {
         float* gp = g.gates + m * 4 * (int64_t)d + j0 + fr;
         gp[0] = rg; gp[d] = zg; gp[2 * d] = ng; gp[3 * d] = hn;
