@@ -350,7 +350,9 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
         model.fuse_attention()
     if eager:   # ... and the updater run once per stored message (TIGE.eager_updates)
         model.eager_updates()
-    buf = model.StepBuffers(model, B, False, resident=resident)
+    # prefetch: the next batch's sampler + centres ride on the step's last launch (tg_step_io.prefetch_state; honoured by
+    # lean eager steps with eager query rows only); the self-check's second model runs without it
+    buf = model.StepBuffers(model, B, False, resident=resident, prefetch=not args.no_prefetch)
     if args.eager_copy:
         buf.io.eager_copy = 1
     restart_prob = float(cfg.get('restart_prob', 0.0))
@@ -650,6 +652,8 @@ def main():
     ap.add_argument('--no-c5s-leg', action='store_true', help='default C2 run: skip the short HBM-roofline leg')
     ap.add_argument('--no-dist-leg', action='store_true',
                     help='default C2 run: skip the one-rank leg of the multi-GPU code path (partitioned_form_1rank)')
+    ap.add_argument('--no-prefetch', action='store_true',
+                    help='do not run the next batch\'s sampler + centres as riders of the step\'s last launch')
     ap.add_argument('--no-lean', action='store_true',
                     help='form the involved / outdated sets in every step even where nothing reads them')
     ap.add_argument('--no-graph', action='store_true', help='launch steps eagerly instead of replaying a hipGraph')

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 4
+#define TG_ABI_VERSION 5
 
 /* status codes */
 #define TG_OK 0
@@ -479,6 +479,24 @@ typedef struct tg_step_io {
    * (temporal_agg_modules.py:57-66) and feeds their embeddings to the first layer as the node part of its keys.
    * Workspace: tg_stream_step_workspace_bytes2(m, B, 2). */
   const struct tg_model* inner;
+  /* Collate prefetch (resident-stream mode; both fields 0 / NULL = off).  The collate part of a batch - temporal
+   * neighbour sampling (data_loader.py:77-131, graph.py:94-127), the centre rows, the first dedup pass and the pre-batch
+   * snapshot - reads the graph and state that is final once the previous batch's updater has run.  With prefetch_state
+   * set, a full lean eager step of a model with eager query rows runs that part for the NEXT batch (the events at the
+   * advanced offset) as extra workgroups of its own last launch, and the next call starts with its attention core: one
+   * launch per batch less, same results.  The neighbour lists then live in the workspace only: l1_nids / l1_eids / l1_ts
+   * must be NULL (as outputs they would hold the NEXT batch's lists when the call returns).
+   *   stream_len:      number of events in the resident stream arrays (a batch past the end is not prefetched: the
+   *                    rider does nothing and the batch must not be run);
+   *   *prefetch_state: HOST int, in / out.  In: 1 - the previous call on this workspace prefetched this batch and
+   *                    neither state, graph, offset nor workspace were touched since (the caller's promise); 2 - it
+   *                    prefetched, but that work must be discarded (the step then clears the dedup slots the prefetch
+   *                    marked and collates itself; a step that cannot use a prefetch - not lean, no eager query rows -
+   *                    treats 1 the same way); 0 - nothing was prefetched.  Out: 1 - this call prefetched the next
+   *                    batch, else 0.  A captured hipGraph replays whatever the capturing call did: capture with
+   *                    *prefetch_state == 1 on entry and exit. */
+  int64_t stream_len;
+  int32_t* prefetch_state;
 } tg_step_io;
 
 /* The reference loop draws `np.random.rand() < restart_prob` before every batch but the first; a hit sets

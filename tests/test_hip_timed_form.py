@@ -34,8 +34,9 @@ def _capture(model, buf, extra=()):
     return graph
 
 
+@pytest.mark.parametrize('prefetch', [False, True], ids=['collate_in_step', 'collate_prefetched'])
 @pytest.mark.parametrize('n_eager', [3, 0], ids=['after_eager_steps', 'first_step_replayed'])
-def test_c2_graph_replay_of_the_resident_lean_step_matches_oracle(n_eager):
+def test_c2_graph_replay_of_the_resident_lean_step_matches_oracle(n_eager, prefetch):
     """BASELINE configs[1] in bench.py's timed form: n_eager eager steps (state pre-roll; they also give the model the
     row bound that selects k_gru_direct), then the captured step replayed 12 times - embeddings compared after every
     replay, memories / mailbox / has-message set at the end."""
@@ -50,7 +51,9 @@ def test_c2_graph_replay_of_the_resident_lean_step_matches_oracle(n_eager):
     model, orc = bench.build_models(stream, d, K, c['msg_src'], c['upd_src'], with_oracle=True)
     model.fuse_attention()
     model.eager_updates()
-    buf = model.StepBuffers(model, B, False, resident=_resident(stream))
+    # prefetch (bench.py's default): sampler + centres of the next batch ride on the step's last launch (tg_step_io.
+    # prefetch_state); the neighbour lists are then not an output of the step
+    buf = model.StepBuffers(model, B, False, resident=_resident(stream), prefetch=prefetch)
     buf.io.lean = 1
     _ = model.graph.tcsr, model.model_struct()
 
@@ -61,7 +64,10 @@ def test_c2_graph_replay_of_the_resident_lean_step_matches_oracle(n_eager):
         a = [stream[k][b * B:(b + 1) * B] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
         cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], K, 'static')
         ref = orc.stream_step(*a, cg).numpy()
-        np.testing.assert_array_equal(buf.l1_nids.cpu().numpy(), cg['l1_nids'])
+        if not prefetch:
+            np.testing.assert_array_equal(buf.l1_nids.cpu().numpy(), cg['l1_nids'])
+        elif b >= 1 and n_eager:  # (a graph captured at the very first step replays collate + prefetch: the flag stays 0)
+            assert buf._pf_state.value == 1  # every step after the first started with its attention core
         cnt = buf.counts.tolist()
         assert cnt[0] == -1 and cnt[2] == len(cg['rd_nids'])  # lean form taken; unique positives still counted
         assert_close(buf.h[:2 * B].cpu().numpy(), ref, f'h_left, batch {b}', TOL)
@@ -183,3 +189,68 @@ def test_graph_replay_and_eager_launches_are_bit_identical():
                        ('mailbox ts', a.msg_store.node_msg_ts, b.msg_store.node_msg_ts),
                        ('has_msg', a.msg_store.has_msg_bits, b.msg_store.has_msg_bits)]:
         assert torch.equal(x, y), f'{name} differs between graph replay and eager launches'
+
+
+def test_prefetched_collate_is_discarded_when_state_offset_or_form_change():
+    """tg_step_io.prefetch_state: the next batch's sampler + centres run on the step's last launch.  Whatever invalidates
+    that work between two steps - state written outside the step (flush_msg, restart), a step of another form in between
+    (full step: involved set formed), the stream offset moved, another buffer's step - must make the next step discard it
+    (dedup slots cleared) and collate itself; the embeddings and the final state follow the oracle throughout."""
+    import bench
+    from oracle import tiger_oracle as O
+    from test_hip_parity import compare_state_with_oracle
+    c = bench.C2
+    B, K, d = 256, c['K'], c['d']
+    nb = 14
+    E = (nb + 2) * B
+    stream = bench.make_stream(c['n_u'], c['n_i'], E, c['T'] * E / c['E'], seed=31, d_e=d)
+    model, orc = bench.build_models(stream, d, K, c['msg_src'], c['upd_src'], with_oracle=True)
+    model.fuse_attention()
+    model.eager_updates()
+    res = _resident(stream)
+    buf = model.StepBuffers(model, B, False, resident=res, prefetch=True)
+    buf.io.lean = 1
+    other = model.StepBuffers(model, B, False, resident=res)  # a second buffer on the same model (no prefetch)
+    other.io.lean = 1
+    used = []
+
+    def step(b, which=buf):
+        which.offset.fill_(b * B)
+        model.launch_step(which)
+        torch.cuda.synchronize()
+        assert int(which.err.item()) == 0
+        a = [stream[k][b * B:(b + 1) * B] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], K, 'static')
+        ref = orc.stream_step(*a, cg).numpy()
+        assert_close(which.h[:2 * B].cpu().numpy(), ref, f'h_left, batch {b}', TOL)
+
+    def run(b):  # consecutive batch on the prefetching buffer WITHOUT touching the offset tensor
+        before = buf._pf_state.value
+        model.launch_step(buf)
+        torch.cuda.synchronize()
+        used.append(before)
+        assert int(buf.err.item()) == 0 and int(buf.offset.item()) == (b + 1) * B
+        a = [stream[k][b * B:(b + 1) * B] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], K, 'static')
+        ref = orc.stream_step(*a, cg).numpy()
+        assert_close(buf.h[:2 * B].cpu().numpy(), ref, f'h_left, batch {b}', TOL)
+
+    step(0)
+    run(1); run(2)
+    model.flush_msg(); orc.flush_msg()           # state written outside the step
+    run(3); run(4)
+    step(5, other)                               # another buffer's step on the same model
+    buf.offset.fill_(6 * B)
+    run(6); run(7)
+    buf.io.lean = 0                              # a full step (involved set formed): cannot use the prefetch
+    run(8)
+    buf.io.lean = 1
+    run(9); run(10)
+    r = np.unique(stream['src'][11 * B:12 * B])[:40].astype(np.int64)   # TIGER.restart on some nodes of the next batch
+    rt = np.full(len(r), float(np.float32(stream['ts'][11 * B])), dtype=np.float32)
+    model.restart(torch.from_numpy(r).to(dev()), torch.from_numpy(rt).to(dev())); orc.restart(r, rt)
+    run(11); run(12); run(13)
+    # batches 2, 4, 7, 10, 12, 13 started from a valid prefetch; 3 (flush), 6 (other buffer + offset), 8 (full step),
+    # 9 (after the full step: nothing was prefetched), 11 (restart) did not
+    assert model._step_serial == 14 and used.count(1) >= 6
+    compare_state_with_oracle(model, orc)

@@ -268,6 +268,10 @@ struct PosArgs {
   int32_t* upos32;  // nullable: the winners' node ids once more as int32 (output rows of the eager updater launch)
   uint32_t* chk_err;  // lean steps: the core launch checks the time invariants of every neighbour with a pending message
   int64_t* advance_off;  // lean embed-only steps: the core launch advances the stream offset by B when it is done with it
+  // nullable: [2B] the winners pass also leaves, for EVERY position of cat[src, dst], the node whose STEP 6 row it is
+  // (the winner of its node) or -1 - the scatter list of the product that writes h(t-) straight into the left memory
+  // (write-back rider, below)
+  int32_t* win_row;
 };
 // dedup slot of a node: its rank in the involved set, or (lean steps: no involved set) the node id itself
 __device__ __forceinline__ int64_t pos_slot(const PosArgs& a, int64_t node) {
@@ -309,12 +313,14 @@ __device__ __forceinline__ void pos_winners_pass(const PosArgs& a, int64_t tid, 
     const int64_t e = i < a.B ? i : i - a.B;
     const int64_t node = a.nids3[i];
     const unsigned long long key = (orderable(a.ts[e]) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)i);
-    if (a.best[pos_slot(a, node)] == key) {
+    const bool win = a.best[pos_slot(a, node)] == key;
+    if (win) {
       const int slot = atomicAdd(a.count, 1);
       a.upos[slot] = node;
       a.index[slot] = i;
       if (a.upos32) a.upos32[slot] = (int32_t)node;
     }
+    if (a.win_row) a.win_row[i] = win ? (int32_t)node : -1;
   }
 }
 // Eager updates, direct form: the centre row is read from the state tables themselves,
@@ -353,27 +359,52 @@ __device__ __forceinline__ void centres_direct_body(const tg_model& m, int64_t Q
   const float4* right = reinterpret_cast<const float4*>(m.right_vals);
   const float4* pend = reinterpret_cast<const float4*>(m.pending_vals);
   const int64_t total = Q * d4;
-  for (int64_t t = tid; t < total; t += nth) {
-    const int64_t i = t / d4;
-    const int c = (int)(t - i * d4);
-    const int64_t id = ids.id(i);
-    const int64_t r = state_row(m, id);  // state by row, features by node id
-    const bool pending = bm_test(m.has_msg, r);
-    float4 v = (pending ? pend : right)[r * d4 + c];
-    float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (nf) f = nf[id * d4 + c];
-    v.x += f.x; v.y += f.y; v.z += f.z; v.w += f.w;
-    out[t] = v;
-    if (da.per_row_checks && c == 0 && pending) check_msg_times(m, r, da.err);
-    if (da.snap && i < da.n_snap) {
-      if (m.msg_src == TG_SRC_LEFT) {
-        float4 l = reinterpret_cast<const float4*>(m.left_vals)[r * d4 + c];
-        l.x += f.x; l.y += f.y; l.z += f.z; l.w += f.w;
-        da.snap[t] = l;
-        if (c == 0) da.snap_ts[i] = m.left_ts[r];
-      } else {
-        da.snap[t] = v;
-        if (c == 0) da.snap_ts[i] = pending ? m.msg_ts[r] : m.right_ts[r];
+  // U elements per thread in flight: with fewer threads than elements (the centres as riders of another launch) the
+  // three dependent round trips per element (id -> has-message bit -> row) are paid once per U elements, not per element
+  constexpr int U = 4;
+  for (int64_t t0 = tid; t0 < total; t0 += U * nth) {
+    int64_t i[U], id[U], r[U];
+    int c[U];
+    bool live[U], pending[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t t = t0 + u * nth;
+      live[u] = t < total;
+      const int64_t tc = live[u] ? t : tid;
+      i[u] = tc / d4;
+      c[u] = (int)(tc - i[u] * d4);
+      id[u] = ids.id(i[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      r[u] = state_row(m, id[u]);  // state by row, features by node id
+      pending[u] = bm_test(m.has_msg, r[u]);
+    }
+    float4 v[U], f[U], l[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      v[u] = (pending[u] ? pend : right)[r[u] * d4 + c[u]];
+      f[u] = nf ? nf[id[u] * d4 + c[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+      l[u] = v[u];
+      if (da.snap && i[u] < da.n_snap && m.msg_src == TG_SRC_LEFT)
+        l[u] = reinterpret_cast<const float4*>(m.left_vals)[r[u] * d4 + c[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!live[u]) continue;
+      const int64_t t = t0 + u * nth;
+      v[u].x += f[u].x; v[u].y += f[u].y; v[u].z += f[u].z; v[u].w += f[u].w;
+      out[t] = v[u];
+      if (da.per_row_checks && c[u] == 0 && pending[u]) check_msg_times(m, r[u], da.err);
+      if (da.snap && i[u] < da.n_snap) {
+        if (m.msg_src == TG_SRC_LEFT) {
+          l[u].x += f[u].x; l[u].y += f[u].y; l[u].z += f[u].z; l[u].w += f[u].w;
+          da.snap[t] = l[u];
+          if (c[u] == 0) da.snap_ts[i[u]] = m.left_ts[r[u]];
+        } else {
+          da.snap[t] = v[u];
+          if (c[u] == 0) da.snap_ts[i[u]] = pending[u] ? m.msg_ts[r[u]] : m.right_ts[r[u]];
+        }
       }
     }
   }
@@ -443,5 +474,131 @@ struct WritebackArgs {
 };
 // phase 0 / 1: the two launches of tg_memory.hip's hazard analysis; phase 2: STEP 4-6 in one launch (needs a.snap)
 int writeback_launch(const tg_model* m, const WritebackArgs& a, int phase, hipStream_t st);
+
+// ---- STEP 4-6 in ONE pass (eager updates, direct form), as a device function so that it can also RIDE on another launch.
+// The hazard that forces two launches (tg_memory.hip) is STEP 5 reading message-memory rows that STEP 4 / STEP 6 of other
+// wavefronts write.  Every row STEP 5 reads belongs to a positive node of the batch, so the launch that reads the centres
+// takes a copy of exactly those 2B rows (a.snap: row + node features, a.snap_ts) before anything is written, and STEP 5
+// builds the message from the copy:
+//   mailbox[own] = [snap[own pos] | snap[other pos] | efeat | TE(t - snap_ts[own pos])]
+// (msg_src = right: the copy is the right memory as STEP 4 leaves it, pending-or-right, as the reference reads it).
+// Workgroup `bid` of `nblk`, any number of whole wavefronts per workgroup; one wavefront per unique positive node.
+// ROWS6 = false: the VALUES of STEP 6 (left[v] <- h(t-), tiger.py:253-255) are written by somebody else - the epilogue of
+// the product that computes h (GemmArgs.c2) - and only its bookkeeping (time, flags, invariant) happens here; nothing
+// else in this pass depends on h, which is what lets it share that product's launch (WbRider).
+template <bool ROWS6>
+__device__ __forceinline__ void writeback_fused_body(const tg_model& m, const WritebackArgs& a, unsigned bid, unsigned nblk) {
+  const int lane = lane_id();
+  const int wpb = blockDim.x / TG_WAVE;
+  const int64_t B = a.B;
+  const int64_t n = min((int64_t)*a.n_upos, 2 * B);
+  const int64_t wave0 = (int64_t)bid * wpb + (threadIdx.x / TG_WAVE), nwave = (int64_t)nblk * wpb;
+  for (int64_t i = wave0 * TG_WAVE + lane; i < 2 * B; i += nwave * TG_WAVE) {  // tiger.py:437-438 over all 2B positions
+    const int64_t e = i < B ? i : i - B;
+    if (a.snap_ts[i] > a.ts[e]) atomicOr(a.err, TG_ERR_EVENT_BEFORE_MEM);
+  }
+  const int d4 = m.d / 4, e4 = m.d_e / 4;
+  const int row4 = 3 * d4 + e4;
+  const float4* snap = reinterpret_cast<const float4*>(a.snap);
+  const float4* ef = reinterpret_cast<const float4*>(m.efeats);
+  const float4* fq = reinterpret_cast<const float4*>(m.te_freq);
+  const float4* ph = reinterpret_cast<const float4*>(m.te_phase);
+  float4* box = reinterpret_cast<float4*>(m.msg_vals);
+  const float4* pend = reinterpret_cast<const float4*>(m.pending_vals);
+  const float4* hrow = reinterpret_cast<const float4*>(a.h);
+  float4* right = reinterpret_cast<float4*>(m.right_vals);
+  float4* left = reinterpret_cast<float4*>(m.left_vals);
+  for (int64_t p = wave0; p < n; p += nwave) {
+    // every load of the three steps is independent of every store: request them together (one wavefront has nothing
+    // else to hide a dependent chain of five row fetches behind), then write
+    const int64_t id = a.upos[p], idx = a.index[p];
+    const int64_t e = idx < B ? idx : idx - B;
+    const int64_t other_pos = idx < B ? B + e : e;
+    const bool consume = bm_test(m.has_msg, id);  // STEP 4 applies (wave-uniform)
+    const float t = a.ts[e];
+    const float own_ts = a.snap_ts[idx];
+    const int64_t eid = a.eids[e];
+    const float mts = m.msg_ts[id], rts = m.right_ts[id], lts = m.left_ts[id];
+    for (int c0 = 0; c0 < row4; c0 += TG_WAVE) {
+      const int c = c0 + lane;
+      float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), hv = pv, v = pv;
+      if (c < d4) {
+        if (consume) pv = pend[id * d4 + c];
+        if (ROWS6) hv = hrow[idx * d4 + c];
+        v = snap[idx * d4 + c];
+      } else if (c < 2 * d4) {
+        v = snap[other_pos * d4 + (c - d4)];
+      } else if (c < 2 * d4 + e4) {
+        if (ef) v = ef[eid * e4 + (c - 2 * d4)];
+      } else if (c < row4) {
+        const int cc = c - 2 * d4 - e4;
+        const float4 w = fq[cc], q = ph[cc];
+        const float dt = t - own_ts;
+        v = make_float4(time_enc(dt, w.x, q.x), time_enc(dt, w.y, q.y), time_enc(dt, w.z, q.z), time_enc(dt, w.w, q.w));
+      }
+      if (c < d4) {
+        if (consume) right[id * d4 + c] = pv;    // STEP 4: right <- pending (tiger.py:236-241)
+        if (ROWS6) left[id * d4 + c] = hv;       // STEP 6: left <- h(t-)  (tiger.py:253-255)
+      }
+      if (c < row4) box[id * row4 + c] = v;      // STEP 5: [own | other | edge | time] (memory.py:89-106)
+    }
+    if (lane == 0) {
+      if (consume) {
+        if (rts > mts) atomicOr(a.err, TG_ERR_PAST_MEMORY);
+        m.right_ts[id] = mts;
+        if (m.right_active) m.right_active[id] = 1;
+      }
+      const uint64_t bit = 1ull << (id & 63);  // consumed (if it was set) and set again by the new message: stays / becomes set
+      if (!consume) atomicOr((unsigned long long*)(m.has_msg + (id >> 6)), bit);
+      m.msg_ts[id] = t;
+      const float nt = a.ts[idx];
+      if (lts > nt) atomicOr(a.err, TG_ERR_PAST_MEMORY);
+      m.left_ts[id] = nt;
+      if (m.left_active) m.left_active[id] = 1;
+    }
+  }
+  {  // leave the step workspace zeroed for the next step
+    const int64_t tid = (int64_t)bid * blockDim.x + threadIdx.x, nth = (int64_t)nblk * blockDim.x;
+    if (a.clean_flags) {
+      uint4* f = reinterpret_cast<uint4*>(a.clean_flags);
+      for (int64_t i = tid; i < a.flag_bytes / 16; i += nth) f[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (a.clean_best && a.clean_best_by_pos) {
+      for (int64_t i = tid; i < 2 * B; i += nth) a.clean_best[i < B ? a.src[i] : a.dst[i - B]] = 0ull;
+    } else if (a.clean_best) {
+      const int64_t nb = a.clean_counts[0];
+      for (int64_t i = tid; i < nb; i += nth) a.clean_best[i] = 0ull;
+    }
+  }
+  if (bid == 0 && threadIdx.x == 0) {
+    if (a.counts_dst) {
+      for (int i = 0; i < 4; ++i) a.counts_dst[i] = a.counts_src[i];
+      if (a.clean_best_by_pos) a.counts_dst[0] = a.counts_dst[1] = -1;  // lean step: the sets were not formed
+    }
+    if (a.clean_counts) {
+      a.clean_counts[3] = a.clean_counts[4] = 0;
+      // the updater and the query-row product that follow read the number of unique positive nodes from here: slot 2
+      // itself is reset by the first dedup pass of the NEXT batch, which may share a launch with them (collate prefetch)
+      a.clean_counts[5] = *a.n_upos;
+    }
+    if (a.offset_dev) *a.offset_dev += B;
+    if (a.lazy_batch) *a.lazy_batch += 1;
+  }
+}
+
+// Write-back rider.  STEP 4 (right <- pending), STEP 5 (the new raw messages, built from the pre-batch snapshot) and the
+// bookkeeping of STEP 6 depend on nothing the attention block computes; only the VALUES of STEP 6 are h(t-).  So the pass
+// above (ROWS6 = false) runs as the FIRST `blocks` workgroups of the launch of the block's last product (fc2), on CUs that
+// product leaves idle at C2 sizes and beside its matrix work at large sizes, and that product's epilogue stores the rows
+// of the winning positions a second time, into the left memory (GemmArgs.c2 / c2_rows = PosArgs.win_row): the step has no
+// write-back launch at all.  Hazards: nothing in the product's launch reads what the rider writes (right memory, mailbox,
+// has-message bits, times) or what the epilogue scatters (left memory: STEP 5 reads the snapshot, not the table).
+struct WbRider {
+  tg_model m;
+  WritebackArgs a;
+  unsigned blocks;  // set by the launcher (a multiple of 8: the XCD map of the product's own blocks is unchanged)
+  unsigned last;    // riders behind the product's blocks in the grid (else in front of them); set by the launcher
+  __device__ __forceinline__ void run(unsigned bid) const { writeback_fused_body<false>(m, a, bid, blocks); }
+};
 
 }  // namespace tg

@@ -56,9 +56,16 @@ struct GemmArgs {
   const uint8_t* ask_valid;
   int ask_relu;
   float ask_alpha;
+  // second, scattered destination of the plain epilogue (nullable): output row m < c2_m with c2_rows[m] >= 0 is ALSO
+  // written to row c2_rows[m] of c2.  The write-back rider (tg_common.h: WbRider) uses it to store h(t-) of the winning
+  // positions straight into the left memory (STEP 6, tiger.py:253-255).
+  float* c2;
+  const int32_t* c2_rows;
+  int64_t c2_m, ldc2;
 };
-constexpr int TG_SK_WORKERS = 256;
-constexpr size_t TG_SK_WS_FLOATS = (size_t)TG_SK_WORKERS * 2 * 4096;
+constexpr int TG_SK_WORKERS = 256;      // default number of workers (one per CU)
+constexpr int TG_SK_WORKERS_MAX = 512;  // the workspace is sized for this many (TG_SK_WORKERS env knob)
+constexpr size_t TG_SK_WS_FLOATS = (size_t)TG_SK_WORKERS_MAX * 2 * 4096;
 // stream-K plan of a product that cannot fill the chip (see tg_gemm.hip)
 struct SkPlan {
   int U, nkt, tiles, NT, MT, pieces;  // units per worker, k-tiles per tile, tiles, column tiles, row tiles, max pieces per tile
@@ -68,7 +75,12 @@ struct SkPlan {
 // returns true, or returns false (nothing launched) when the shape does not call for it.
 bool gemm_sk_partials(const GemmArgs& g, float* ws, size_t ws_floats, hipStream_t st, SkPlan* plan);
 
-int gemm_launch(const GemmArgs& g, hipStream_t st);
+// Riders (nullable, one at most): work that shares the launch as its FIRST workgroups - the one-pass write-back (WbRider,
+// tg_common.h) or the collate part of the next batch (CollateRider, tg_sample.h).  Not every kernel hosts them: *rode
+// tells the caller whether the rider was launched - otherwise the caller launches that work itself.
+struct CollateRider;
+int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider = nullptr, bool* rode = nullptr,
+                const CollateRider* collate = nullptr);
 
 struct GruArgs {
   int64_t cap;

@@ -14,6 +14,7 @@
 #include <type_traits>
 
 #include "tg_dense.h"
+#include "tg_sample.h"
 
 namespace tg {
 
@@ -279,6 +280,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16& a
   float* cp = g.c + (int64_t)bz * g.c_bs;
   const bool plain = !g.bias_rs && !g.bias2 && !g.row_valid && !g.relu_mask && !g.c_rows && !g.accumulate;
   if (plain) {
+    // second destination (write-back rider: h(t-) of the winning positions -> left memory): the 16 row numbers are
+    // requested together; wave tiles past the last listed row skip all of it
+    const bool two = g.c2 && m0 + wm * 32 < g.c2_m;  // wave-uniform
+    int c2r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+      c2r[r] = two ? g.c2_rows[min(m, g.c2_m - 1)] : -1;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
@@ -286,6 +296,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16& a
       float v = g.alpha * (acc[r] + bias);
       if (g.relu) v = fmaxf(v, 0.f);
       cp[m * g.ldc + n] = v;
+      if (two && m < g.c2_m && c2r[r] >= 0) g.c2[(int64_t)c2r[r] * g.ldc2 + n] = v;
     }
   } else {
     // Optional per-row / per-element operands (row scale of the bias, validity bytes, ReLU mask, output
@@ -346,14 +357,28 @@ extern "C" int tg_debug_gemm_trace(unsigned long long* out_host, int n_blocks) {
 }
 
 template <int WM, int WN, int KS, int D, bool ASK = false, int AP = 3>
-__global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
+__device__ __forceinline__ void gemm_block(const GemmArgs& g, unsigned bid) {
   constexpr int BN = 32 * WN;
   const int NT = (g.n + BN - 1) / BN;
   const int per = NT * g.nbatch;
-  const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
+  const int xcd = bid & 7, s = bid >> 3;
   const int64_t mt = (int64_t)(s / per) * 8 + xcd;
   const int rem = s % per;
-  gemm_tile<WM, WN, KS, D, ASK, AP>(g, mt, rem % NT, rem / NT, 0, (g.k + BK - 1) / BK, nullptr, (int)blockIdx.x);
+  gemm_tile<WM, WN, KS, D, ASK, AP>(g, mt, rem % NT, rem / NT, 0, (g.k + BK - 1) / BK, nullptr, (int)bid);
+}
+template <int WM, int WN, int KS, int D, bool ASK = false, int AP = 3>
+__global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
+  gemm_block<WM, WN, KS, D, ASK, AP>(g, blockIdx.x);
+}
+// ... with a rider as the first r.blocks workgroups (WbRider: tg_common.h; CollateRider: tg_sample.h)
+template <class R, int WM, int WN, int KS, int D, bool ASK = false, int AP = 3>
+__global__ void __launch_bounds__(256 * KS) k_gemm_r(GemmArgs g, R r) {
+  const unsigned own = gridDim.x - r.blocks;  // the product's blocks: before the riders (r.last) or after them
+  if (r.last ? blockIdx.x >= own : blockIdx.x < r.blocks) {
+    r.run(r.last ? blockIdx.x - own : blockIdx.x);
+    return;
+  }
+  gemm_block<WM, WN, KS, D, ASK, AP>(g, r.last ? blockIdx.x : blockIdx.x - r.blocks);
 }
 
 // ---- register-blocked tiles for plain products ----------------------------------------------------------------------
@@ -365,7 +390,7 @@ __global__ void __launch_bounds__(256 * KS) k_gemm(GemmArgs g) {
 // MFMAs instead of one.  Same pipeline as gemm_tile (two register sets, two LDS buffers, one barrier per k-tile, the
 // loads of tile t + 2 and the LDS writes of tile t + 1 threaded between the MFMAs of tile t); plain epilogue only.
 template <int RM, int RN>
-__global__ void __launch_bounds__(256) k_gemm_rb(GemmArgs g) {
+__device__ __forceinline__ void gemm_rb_block(const GemmArgs& g, unsigned bid) {
   constexpr int BM = 64 * RM, BN = 64 * RN;
   constexpr int RP = 32;                 // tile rows staged per pass (8 threads per 32-float row)
   constexpr int NA = BM / RP, NB = BN / RP, NOPS = NA + NB;
@@ -379,7 +404,7 @@ __global__ void __launch_bounds__(256) k_gemm_rb(GemmArgs g) {
   int64_t M = g.m_cap;
   if (g.m_dev) M = min(M, (int64_t)*g.m_dev);
   const int NT = (N + BN - 1) / BN;
-  const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
+  const int xcd = bid & 7, s = bid >> 3;
   const int64_t mt = (int64_t)(s / NT) * 8 + xcd;
   const int nt = s % NT;
   const int64_t m0 = mt * BM;
@@ -478,11 +503,14 @@ __global__ void __launch_bounds__(256) k_gemm_rb(GemmArgs g) {
       if (n >= N) continue;
       uint8_t v2[16];  // the second bias is added on rows whose validity byte is set; all 16 bytes requested together
       int crow[16];    // ... and the output rows (c_rows: scattered)
+      int c2r[16];     // ... and the rows of the second destination (c2: the write-back rider's STEP 6)
+      const bool two = g.c2 && m0 + (wm * RM + u) * 32 < g.c2_m;  // wave-uniform
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t m = min(m0 + (wm * RM + u) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk, M - 1);
         v2[r] = g.bias2 ? g.bias2_valid[m] : 0;
         crow[r] = g.c_rows ? g.c_rows[m] : (int)m;
+        c2r[r] = two ? g.c2_rows[min(m, g.c2_m - 1)] : -1;
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -491,8 +519,22 @@ __global__ void __launch_bounds__(256) k_gemm_rb(GemmArgs g) {
         float x = g.alpha * (acc[u][v][r] + bias[v] + (v2[r] ? bias2[v] : 0.f));
         if (g.relu) x = fmaxf(x, 0.f);
         g.c[(int64_t)crow[r] * g.ldc + n] = x;
+        if (two && m < g.c2_m && c2r[r] >= 0) g.c2[(int64_t)c2r[r] * g.ldc2 + n] = x;
       }
     }
+}
+template <int RM, int RN>
+__global__ void __launch_bounds__(256) k_gemm_rb(GemmArgs g) {
+  gemm_rb_block<RM, RN>(g, blockIdx.x);
+}
+template <class R, int RM, int RN>
+__global__ void __launch_bounds__(256) k_gemm_rb_r(GemmArgs g, R r) {
+  const unsigned own = gridDim.x - r.blocks;  // the product's blocks: before the riders (r.last) or after them
+  if (r.last ? blockIdx.x >= own : blockIdx.x < r.blocks) {
+    r.run(r.last ? blockIdx.x - own : blockIdx.x);
+    return;
+  }
+  gemm_rb_block<RM, RN>(g, r.last ? blockIdx.x : blockIdx.x - r.blocks);
 }
 
 // ---- activation-stationary blocks for short-K, wide-N products ------------------------------------------------------
@@ -504,7 +546,7 @@ __global__ void __launch_bounds__(256) k_gemm_rb(GemmArgs g) {
 // drains between column tiles (the next tile's first weight tile is already in LDS when a tile's outputs are stored),
 // and per k-tile half as much is staged.  NKT is a template parameter so that the tile walk is straight-line.
 template <int NKT>
-__global__ void __launch_bounds__(256) k_gemm_astat(GemmArgs g, int cpb) {
+__device__ __forceinline__ void gemm_astat_block(const GemmArgs& g, int cpb, unsigned bid) {
   static_assert(NKT % 2 == 0, "the LDS buffer of a weight tile follows from its k-tile index");
   constexpr int SA = NKT * BK + 1;  // panel row stride (odd)
   __shared__ float As[64][SA];
@@ -516,7 +558,7 @@ __global__ void __launch_bounds__(256) k_gemm_astat(GemmArgs g, int cpb) {
   int64_t M = g.m_cap;
   if (g.m_dev) M = min(M, (int64_t)*g.m_dev);
   const int NT = (N + 63) / 64, NG = (NT + cpb - 1) / cpb;  // column tiles, column groups
-  const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
+  const int xcd = bid & 7, s = bid >> 3;
   const int64_t mt = (int64_t)(s / NG) * 8 + xcd;
   const int c0 = (s % NG) * cpb, c1 = min(c0 + cpb, NT);
   const int64_t m0 = mt * 64;
@@ -605,6 +647,19 @@ __global__ void __launch_bounds__(256) k_gemm_astat(GemmArgs g, int cpb) {
     }
   }
 }
+template <int NKT>
+__global__ void __launch_bounds__(256) k_gemm_astat(GemmArgs g, int cpb) {
+  gemm_astat_block<NKT>(g, cpb, blockIdx.x);
+}
+template <class R, int NKT>
+__global__ void __launch_bounds__(256) k_gemm_astat_r(GemmArgs g, int cpb, R r) {
+  const unsigned own = gridDim.x - r.blocks;  // the product's blocks: before the riders (r.last) or after them
+  if (r.last ? blockIdx.x >= own : blockIdx.x < r.blocks) {
+    r.run(r.last ? blockIdx.x - own : blockIdx.x);
+    return;
+  }
+  gemm_astat_block<NKT>(g, cpb, r.last ? blockIdx.x : blockIdx.x - r.blocks);
+}
 
 // ---- stream-K for launches that cannot fill the chip --------------------------------------------------
 // A product with fewer 64x64 tiles than CUs and a long K (the merged value/out/fc1 product of the fused
@@ -646,10 +701,11 @@ bool gemm_sk_partials(const GemmArgs& g, float* ws, size_t ws_floats, hipStream_
   p.MT = (int)cdiv(g.m_cap, 64);
   p.tiles = p.MT * p.NT;
   p.nkt = (int)cdiv(g.k, BK);
+  static const int wk_knob = getenv("TG_SK_WORKERS") ? atoi(getenv("TG_SK_WORKERS")) : TG_SK_WORKERS;  // tuning knob
+  const int workers = std::min(std::max(wk_knob & ~7, 8), TG_SK_WORKERS_MAX);
   if (p.tiles >= TG_SK_WORKERS || p.nkt < 16) return false;  // (also covers few tiles: then a tile is cut into more pieces)
   const int64_t units_xcd = cdiv((int64_t)p.MT, 8) * p.NT * p.nkt;  // of the fullest XCD
-  p.U = (int)cdiv(units_xcd, (int64_t)(TG_SK_WORKERS / 8));
-  const int workers = TG_SK_WORKERS;
+  p.U = (int)cdiv(units_xcd, (int64_t)(workers / 8));
   p.pieces = (int)cdiv(p.nkt, p.U) + 1;  // most pieces a tile can be cut into (its range may start mid-worker)
   if (p.U >= p.nkt || p.pieces > 8 || p.U < 3 || ws_floats < (size_t)workers * 2 * 4096) return false;
   p.part = ws;
@@ -661,7 +717,36 @@ bool gemm_sk_partials(const GemmArgs& g, float* ws, size_t ws_floats, hipStream_
   return true;
 }
 
-int gemm_launch(const GemmArgs& g, hipStream_t st) {
+// Workgroups of the write-back rider (WbRider) in a launch of `grid` product blocks of `threads` threads: the CUs an
+// under-filled launch leaves idle (C2: 144 product blocks + 112 riders, one block per CU either way), else two riders per
+// CU beside the matrix work; never more wavefronts than listed rows; a multiple of 8 (the product's XCD map stays).
+static unsigned rider_blocks(int64_t grid, int threads, int64_t rows) {
+  const int64_t want = cdiv(rows, (int64_t)(threads / 64));
+  const int64_t room = grid <= 248 ? 256 - grid : 512;
+  return (unsigned)std::max<int64_t>(8, std::min(want, room) & ~(int64_t)7);
+}
+// Riders go BEHIND the product's blocks when the whole launch is resident at once anyway (the dispatcher then starts the
+// product's blocks - the critical path - first), and IN FRONT of them in a launch of many rounds (behind, they would run
+// when the product is done: no overlap)
+static unsigned riders_last(int64_t grid, unsigned riders) { return grid + riders <= 768 ? 1u : 0u; }
+
+// Workgroups of the collate rider (CollateRider): the sampler is a chain of dependent memory round trips per query and
+// wants many wavefronts; the centres are a gather.  Under-filled host launch (the C2-sized query-row product: ~150 live
+// blocks, two per CU): the sampler's own grid up to 192 blocks + 128 for the centres; otherwise two riders per CU.
+static void collate_blocks(CollateRider& c, int64_t grid) {
+  const int64_t Q = 3 * c.s.B;
+  const int64_t sg = cdiv(Q, (int64_t)16), cg = cdiv(Q * (c.cr.m.d / 4), (int64_t)256);
+  c.sblocks = (unsigned)std::min<int64_t>(sg, grid <= 512 ? 192 : 384);
+  c.cr.blocks = (unsigned)std::min<int64_t>(cdiv(cg, (int64_t)4), 160);  // (four elements per thread in flight)
+  c.blocks = (c.sblocks + c.cr.blocks + 7u) & ~7u;
+  c.last = riders_last(grid, c.blocks);
+}
+
+int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* rode, const CollateRider* collate) {
+  if (rode) *rode = false;
+  if ((rider || collate) && (!rode || (rider && collate))) return TG_EINVAL;
+  if (g.c2 && (g.bias_rs || g.bias2 || g.row_valid || g.relu_mask || g.c_rows || g.accumulate || !g.c2_rows || g.nbatch != 1))
+    return TG_EINVAL;  // the second destination exists in the plain epilogue only
   if (g.m_cap <= 0) return TG_OK;
   if (g.n <= 0 || g.k <= 0 || (g.k % 4) || (g.a0.w % 4) || (g.ldw % 4) || g.nbatch <= 0) return TG_EINVAL;
   if (g.w_kmajor && (g.n % 4)) return TG_EINVAL;
@@ -687,6 +772,19 @@ int gemm_launch(const GemmArgs& g, hipStream_t st) {
       !g.accumulate && cdiv(g.m_cap, 128) * NT >= 4096) {
     if (rb_knob == 2 && g.n >= 512) {
       hipLaunchKernelGGL((k_gemm_rb<2, 2>), dim3((unsigned)(8 * cdiv(cdiv(g.m_cap, 128), 8) * cdiv(g.n, 128))), dim3(256), 0, st, gd);
+    } else if (rider) {
+      WbRider wr = *rider;
+      const int64_t gb = 8 * cdiv(cdiv(g.m_cap, 128), 8) * NT;
+      wr.blocks = rider_blocks(gb, 256, 2 * wr.a.B);
+      wr.last = riders_last(gb, wr.blocks);
+      hipLaunchKernelGGL((k_gemm_rb_r<WbRider, 2, 1>), dim3((unsigned)(gb + wr.blocks)), dim3(256), 0, st, gd, wr);
+      *rode = true;
+    } else if (collate) {
+      CollateRider co = *collate;
+      const int64_t gb = 8 * cdiv(cdiv(g.m_cap, 128), 8) * NT;
+      collate_blocks(co, gb);
+      hipLaunchKernelGGL((k_gemm_rb_r<CollateRider, 2, 1>), dim3((unsigned)(gb + co.blocks)), dim3(256), 0, st, gd, co);
+      *rode = true;
     } else {
       hipLaunchKernelGGL((k_gemm_rb<2, 1>), dim3((unsigned)(8 * cdiv(cdiv(g.m_cap, 128), 8) * NT)), dim3(256), 0, st, gd);
     }
@@ -702,8 +800,20 @@ int gemm_launch(const GemmArgs& g, hipStream_t st) {
       // two column tiles per block (measured at C2, 48 x 17 tiles: 21.6 us; three: 28.1, four: 24.6, six: 29.8, nine:
       // 40.8; separate 64 x 64 blocks: 24.4): two such blocks share a CU and cover each other's barriers, which matters
       // more than the shared panel
-      const int cpb = as_knob > 1 ? std::min(as_knob, NT) : 2;
-      const dim3 grid_as((unsigned)(8 * cdiv(MT, 8) * cdiv(NT, cpb)));
+      static const int cpb_knob = getenv("TG_GEMM_ASTAT_CPB") ? atoi(getenv("TG_GEMM_ASTAT_CPB")) : 0;
+      const int cpb = cpb_knob > 0 ? std::min(cpb_knob, NT) : as_knob > 1 ? std::min(as_knob, NT) : 2;
+      const int64_t gb = 8 * cdiv(MT, 8) * cdiv(NT, cpb);
+      if (collate) {
+        CollateRider co = *collate;
+        collate_blocks(co, gb);
+        const dim3 grid_r((unsigned)(gb + co.blocks));
+        if (nkt == 4) hipLaunchKernelGGL((k_gemm_astat_r<CollateRider, 4>), grid_r, dim3(256), 0, st, gd, cpb, co);
+        else if (nkt == 6) hipLaunchKernelGGL((k_gemm_astat_r<CollateRider, 6>), grid_r, dim3(256), 0, st, gd, cpb, co);
+        else hipLaunchKernelGGL((k_gemm_astat_r<CollateRider, 8>), grid_r, dim3(256), 0, st, gd, cpb, co);
+        *rode = true;
+        return check_launch("gemm(astat+collate)");
+      }
+      const dim3 grid_as((unsigned)gb);
       if (nkt == 4) hipLaunchKernelGGL((k_gemm_astat<4>), grid_as, dim3(256), 0, st, gd, cpb);
       else if (nkt == 6) hipLaunchKernelGGL((k_gemm_astat<6>), grid_as, dim3(256), 0, st, gd, cpb);
       else hipLaunchKernelGGL((k_gemm_astat<8>), grid_as, dim3(256), 0, st, gd, cpb);
@@ -715,13 +825,33 @@ int gemm_launch(const GemmArgs& g, hipStream_t st) {
     static const int ask_depth = getenv("TG_GEMM_ASK_DEPTH") ? atoi(getenv("TG_GEMM_ASK_DEPTH")) : 2;  // tuning knob: 2 / 4
     gd.ask_rcpU = 1.0f / (float)g.ask_U;
     static const int ask_ks = getenv("TG_GEMM_ASK_KS") ? atoi(getenv("TG_GEMM_ASK_KS")) : 2;  // tuning knob: 1 / 2 (measured 12.6 / 11.1 us)
-    if (g.ask_pieces > 3) hipLaunchKernelGGL((k_gemm<2, 2, 2, 2, true, 8>), dim3((unsigned)grid), dim3(512), 0, st, gd);
+    WbRider wr = rider ? *rider : WbRider{};
+    if (rider && (g.ask_pieces > 3 || ask_ks == 2)) {
+      wr.blocks = rider_blocks(grid, 512, 2 * wr.a.B);
+      wr.last = riders_last(grid, wr.blocks);
+      if (g.ask_pieces > 3)
+        hipLaunchKernelGGL((k_gemm_r<WbRider, 2, 2, 2, 2, true, 8>), dim3((unsigned)grid + wr.blocks), dim3(512), 0, st, gd, wr);
+      else
+        hipLaunchKernelGGL((k_gemm_r<WbRider, 2, 2, 2, 2, true>), dim3((unsigned)grid + wr.blocks), dim3(512), 0, st, gd, wr);
+      *rode = true;
+    } else if (g.ask_pieces > 3) hipLaunchKernelGGL((k_gemm<2, 2, 2, 2, true, 8>), dim3((unsigned)grid), dim3(512), 0, st, gd);
     else if (ask_ks == 2) hipLaunchKernelGGL((k_gemm<2, 2, 2, 2, true>), dim3((unsigned)grid), dim3(512), 0, st, gd);
     else if (ask_depth == 4) hipLaunchKernelGGL((k_gemm<2, 2, 1, 4, true>), dim3((unsigned)grid), dim3(256), 0, st, gd);
     else hipLaunchKernelGGL((k_gemm<2, 2, 1, 2, true>), dim3((unsigned)grid), dim3(256), 0, st, gd);
   } else if (split)
     hipLaunchKernelGGL((k_gemm<2, 2, 2, 2>), dim3((unsigned)grid), dim3(512), 0, st, gd);
-  else if (depth_knob == 2)
+  else if (depth_knob == 2 && rider) {
+    WbRider wr = *rider;
+    wr.blocks = rider_blocks(grid, 256, 2 * wr.a.B);
+    wr.last = riders_last(grid, wr.blocks);
+    hipLaunchKernelGGL((k_gemm_r<WbRider, 2, 2, 1, 2>), dim3((unsigned)grid + wr.blocks), dim3(256), 0, st, gd, wr);
+    *rode = true;
+  } else if (depth_knob == 2 && collate) {
+    CollateRider co = *collate;
+    collate_blocks(co, grid);
+    hipLaunchKernelGGL((k_gemm_r<CollateRider, 2, 2, 1, 2>), dim3((unsigned)grid + co.blocks), dim3(256), 0, st, gd, co);
+    *rode = true;
+  } else if (depth_knob == 2)
     hipLaunchKernelGGL((k_gemm<2, 2, 1, 2>), dim3((unsigned)grid), dim3(256), 0, st, gd);
   else
     hipLaunchKernelGGL((k_gemm<2, 2, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, gd);

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "tg_common.h"
+#include "tg_sample.h"
 
 namespace tg {
 
@@ -95,55 +96,6 @@ extern "C" int tg_tcsr_build_host(int64_t E, const int64_t* src, const int64_t* 
 
 namespace tg {
 
-// number of entries of node `nid` with ts < t  (np.searchsorted(..., side='left'), graph.py:51)
-__device__ __forceinline__ int64_t prefix_end(const tg_tcsr& g, int64_t nid, double t, int64_t* start) {
-  if (nid < 0 || nid >= g.num_node) {
-    *start = 0;
-    return 0;
-  }
-  int64_t lo = g.indptr[nid], hi = g.indptr[nid + 1];
-  *start = lo;
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (g.ts[mid] < t)
-      lo = mid + 1;
-    else
-      hi = mid;
-  }
-  return lo;
-}
-
-// The same count, searched by the G lanes of a query group together: every round the lanes probe G
-// evenly spaced positions of the remaining interval and the group's ballot bits (timestamps are sorted,
-// so "ts[p] < t" is a run of ones followed by zeros) pick the sub-interval - log_{G+1}(deg) dependent
-// memory round trips instead of log_2(deg); for a popular item with thousands of events that is 3 instead
-// of 12, and the longest search sets the duration of the sampling kernel.  All lanes of the wavefront run
-// the loop together (the ballot is a wavefront operation); finished groups idle.
-template <int G>
-__device__ __forceinline__ int64_t prefix_end_group(const tg_tcsr& g, int64_t nid, double t, int64_t* start, int sub) {
-  int64_t lo = 0, hi = 0;
-  if (nid >= 0 && nid < g.num_node) {
-    lo = g.indptr[nid];
-    hi = g.indptr[nid + 1];
-  }
-  *start = lo;
-  const int shift = G == 64 ? 0 : (lane_id() / G) * G;
-  const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
-  while (__any(lo < hi)) {
-    const int64_t n = hi - lo;
-    const int64_t pos = lo + ((int64_t)(sub + 1) * n) / (G + 1);  // in [lo, hi) when n > 0
-    const bool pred = n > 0 && g.ts[pos] < t;
-    const int c = __popcll((__ballot(pred) >> shift) & gmask);  // probes 0 .. c-1 are below t
-    if (n > 0) {
-      const int64_t below = lo + ((int64_t)c * n) / (G + 1);        // probe c-1 (for c > 0)
-      const int64_t above = lo + ((int64_t)(c + 1) * n) / (G + 1);  // probe c   (for c < G)
-      if (c < G) hi = above;
-      if (c > 0) lo = below + 1;
-    }
-  }
-  return lo;
-}
-
 // G lanes cooperate on one query: they search the prefix end together (above), then copy
 // the K-entry tail with one lane per slot.
 template <int G>
@@ -181,70 +133,19 @@ __global__ void __launch_bounds__(256) k_sample_recent_edges(tg_tcsr g, int64_t 
   }
 }
 
-// Fused form used by tg_stream_step: query q of cat[src,dst,neg] is built on the fly from the
-// batch arrays (optionally at a device-resident stream offset) and also written out for the
-// later stages (ids, float32 times, edge ids).
+// Fused form used by tg_stream_step (body: tg_sample.h, sample_batch_body): query q of cat[src,dst,neg] is built on the
+// fly from the batch arrays (optionally at a device-resident stream offset) and also written out for the later stages
+// (ids, float32 times, edge ids); the centres of a lean step ride on the launch as extra workgroups at its end.
 template <int G>
-__global__ void __launch_bounds__(256) k_sample_batch(tg_tcsr g, int64_t B, const int64_t* __restrict__ src,
-                                                      const int64_t* __restrict__ dst, const int64_t* __restrict__ neg,
-                                                      const double* __restrict__ ts, const int64_t* __restrict__ eids,
-                                                      const int64_t* __restrict__ off, int K,
-                                                      int64_t* __restrict__ nids3, float* __restrict__ ts3f,
-                                                      int64_t* __restrict__ eids_b, int64_t* __restrict__ o_nbr,
-                                                      int64_t* __restrict__ o_eid, float* __restrict__ o_ts,
-                                                      uint8_t* __restrict__ mark, uint32_t* __restrict__ tmin_key,
-                                                      CentresRider cr) {
-  constexpr int GPB = 256 / G;
-  const int sub = threadIdx.x % G;
-  const int64_t o = off ? *off : 0;
-  const int64_t Q = 3 * B;
+__global__ void __launch_bounds__(256) k_sample_batch(SampleBatchArgs a, CentresRider cr) {
   const unsigned sblocks = gridDim.x - cr.blocks;  // the sampler's share of the grid
+  const int64_t o = a.off ? *a.off : 0;
   if (blockIdx.x >= sblocks) {  // rider: the attention centres of a lean step (tg_common.h)
-    centres_direct_body(cr.m, Q, RawIds{src, dst, neg, ts, o, B}, cr.nf, cr.out, cr.da, cr.pos,
+    centres_direct_body(cr.m, 3 * a.B, RawIds{a.src, a.dst, a.neg, a.ts, o, a.B}, cr.nf, cr.out, cr.da, cr.pos,
                         (int64_t)(blockIdx.x - sblocks) * blockDim.x + threadIdx.x, (int64_t)cr.blocks * blockDim.x);
     return;
   }
-  float tmin = INFINITY;  // earliest event time of the batch in float32 (`ts.min()` of train_self_supervised.py:162)
-  for (int64_t q = (int64_t)blockIdx.x * GPB + threadIdx.x / G; q < Q; q += (int64_t)sblocks * GPB) {
-    const int64_t e = q % B;
-    const int r = (int)(q / B);
-    const int64_t nid = r == 0 ? src[o + e] : (r == 1 ? dst[o + e] : neg[o + e]);
-    const double t = ts[o + e];
-    if (r == 0) tmin = fminf(tmin, (float)t);
-    if (sub == 0) {
-      nids3[q] = nid;
-      ts3f[q] = (float)t;
-      if (r == 0) eids_b[e] = eids[o + e];
-    }
-    int64_t start;
-    const int64_t end = prefix_end_group<G>(g, nid, t, &start, sub);
-    for (int j = sub; j < K; j += G) {
-      const int64_t p = end - K + j;
-      int64_t nb = 0, ed = 0;
-      float tt = 0.f;
-      if (p >= start) {
-        nb = g.nbr[p];
-        ed = (int64_t)((uint32_t)g.eid[p] & 0x7fffffffu);
-        tt = (float)g.ts[p];
-      }
-      const int64_t w = q * K + j;
-      o_nbr[w] = nb;
-      o_eid[w] = ed;
-      o_ts[w] = tt;
-      if (mark) mark[nb] = 1;
-    }
-    if (mark && sub == 0 && nid >= 0 && nid < g.num_node) mark[nid] = 1;
-  }
-  if (tmin_key) {  // lazy restart only: one atomic per block on the complemented order-preserving key (slot starts at 0)
-    __shared__ float s_tmin[4];
-    for (int sh = 32; sh > 0; sh >>= 1) tmin = fminf(tmin, __shfl_xor(tmin, sh, TG_WAVE));
-    if (lane_id() == 0) s_tmin[threadIdx.x >> 6] = tmin;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const float v = fminf(fminf(s_tmin[0], s_tmin[1]), fminf(s_tmin[2], s_tmin[3]));
-      if (v < INFINITY) atomicMax(tmin_key, ~(uint32_t)orderable(v));
-    }
-  }
+  sample_batch_body<G>(a, o, blockIdx.x, sblocks);
 }
 
 // ---- lazy restart with the static restarter (train_self_supervised.py:152-163, tiger.py:594-609,
@@ -333,12 +234,11 @@ int sample_batch_launch(const tg_tcsr* g, int64_t B, const int64_t* src, const i
                         hipStream_t st, uint32_t* tmin_key, const CentresRider* rider) {
   const int64_t Q = 3 * B;
   const CentresRider cr = rider ? *rider : CentresRider{};
+  const SampleBatchArgs a{*g, B, src, dst, neg, ts, eids, off, K, nids3, ts3f, eids_b, o_nbr, o_eid, o_ts, mark, tmin_key};
   if (K <= 16)
-    hipLaunchKernelGGL(k_sample_batch<16>, dim3(flat_grid(Q, 16) + cr.blocks), dim3(256), 0, st, *g, B, src, dst, neg, ts,
-                       eids, off, K, nids3, ts3f, eids_b, o_nbr, o_eid, o_ts, mark, tmin_key, cr);
+    hipLaunchKernelGGL(k_sample_batch<16>, dim3(flat_grid(Q, 16) + cr.blocks), dim3(256), 0, st, a, cr);
   else
-    hipLaunchKernelGGL(k_sample_batch<64>, dim3(flat_grid(Q, 4) + cr.blocks), dim3(256), 0, st, *g, B, src, dst, neg, ts,
-                       eids, off, K, nids3, ts3f, eids_b, o_nbr, o_eid, o_ts, mark, tmin_key, cr);
+    hipLaunchKernelGGL(k_sample_batch<64>, dim3(flat_grid(Q, 4) + cr.blocks), dim3(256), 0, st, a, cr);
   return check_launch("sample_batch");
 }
 

@@ -320,103 +320,10 @@ __global__ void __launch_bounds__(256) k_writeback(tg_model m, WritebackArgs a) 
   }
 }
 
-// ---- STEP 4-6 in ONE launch (eager updates, direct form).  The hazard that forces two launches above is STEP 5 reading
-// message-memory rows that STEP 4 / STEP 6 of other wavefronts write.  Every row STEP 5 reads belongs to a positive node
-// of the batch, so the launch that reads the centres takes a copy of exactly those 2B rows (a.snap: row + node
-// features, a.snap_ts) before anything is written, and STEP 5 builds the message from the copy:
-//   mailbox[own] = [snap[own pos] | snap[other pos] | efeat | TE(t - snap_ts[own pos])]
-// (msg_src = right: the copy is the right memory as STEP 4 leaves it, pending-or-right, as the reference reads it).
+// ---- STEP 4-6 in ONE launch (eager updates, direct form): writeback_fused_body (tg_common.h), which can also ride on
+// the launch of the attention block's last product (WbRider)
 __global__ void __launch_bounds__(256) k_writeback_fused(tg_model m, WritebackArgs a) {
-  const int lane = lane_id();
-  const int64_t B = a.B;
-  const int64_t n = min((int64_t)*a.n_upos, 2 * B);
-  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (int64_t)gridDim.x * 4;
-  for (int64_t i = wave0 * TG_WAVE + lane; i < 2 * B; i += nwave * TG_WAVE) {  // tiger.py:437-438 over all 2B positions
-    const int64_t e = i < B ? i : i - B;
-    if (a.snap_ts[i] > a.ts[e]) atomicOr(a.err, TG_ERR_EVENT_BEFORE_MEM);
-  }
-  const int d4 = m.d / 4, e4 = m.d_e / 4;
-  const int row4 = 3 * d4 + e4;
-  const float4* snap = reinterpret_cast<const float4*>(a.snap);
-  const float4* ef = reinterpret_cast<const float4*>(m.efeats);
-  const float4* fq = reinterpret_cast<const float4*>(m.te_freq);
-  const float4* ph = reinterpret_cast<const float4*>(m.te_phase);
-  float4* box = reinterpret_cast<float4*>(m.msg_vals);
-  const float4* pend = reinterpret_cast<const float4*>(m.pending_vals);
-  const float4* hrow = reinterpret_cast<const float4*>(a.h);
-  float4* right = reinterpret_cast<float4*>(m.right_vals);
-  float4* left = reinterpret_cast<float4*>(m.left_vals);
-  for (int64_t p = wave0; p < n; p += nwave) {
-    // every load of the three steps is independent of every store: request them together (one wavefront has nothing
-    // else to hide a dependent chain of five row fetches behind), then write
-    const int64_t id = a.upos[p], idx = a.index[p];
-    const int64_t e = idx < B ? idx : idx - B;
-    const int64_t other_pos = idx < B ? B + e : e;
-    const bool consume = bm_test(m.has_msg, id);  // STEP 4 applies (wave-uniform)
-    const float t = a.ts[e];
-    const float own_ts = a.snap_ts[idx];
-    const int64_t eid = a.eids[e];
-    const float mts = m.msg_ts[id], rts = m.right_ts[id], lts = m.left_ts[id];
-    for (int c0 = 0; c0 < row4; c0 += TG_WAVE) {
-      const int c = c0 + lane;
-      float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), hv = pv, v = pv;
-      if (c < d4) {
-        if (consume) pv = pend[id * d4 + c];
-        hv = hrow[idx * d4 + c];
-        v = snap[idx * d4 + c];
-      } else if (c < 2 * d4) {
-        v = snap[other_pos * d4 + (c - d4)];
-      } else if (c < 2 * d4 + e4) {
-        if (ef) v = ef[eid * e4 + (c - 2 * d4)];
-      } else if (c < row4) {
-        const int cc = c - 2 * d4 - e4;
-        const float4 w = fq[cc], q = ph[cc];
-        const float dt = t - own_ts;
-        v = make_float4(time_enc(dt, w.x, q.x), time_enc(dt, w.y, q.y), time_enc(dt, w.z, q.z), time_enc(dt, w.w, q.w));
-      }
-      if (c < d4) {
-        if (consume) right[id * d4 + c] = pv;  // STEP 4: right <- pending (tiger.py:236-241)
-        left[id * d4 + c] = hv;                // STEP 6: left <- h(t-)  (tiger.py:253-255)
-      }
-      if (c < row4) box[id * row4 + c] = v;    // STEP 5: [own | other | edge | time] (memory.py:89-106)
-    }
-    if (lane == 0) {
-      if (consume) {
-        if (rts > mts) atomicOr(a.err, TG_ERR_PAST_MEMORY);
-        m.right_ts[id] = mts;
-        if (m.right_active) m.right_active[id] = 1;
-      }
-      const uint64_t bit = 1ull << (id & 63);  // consumed (if it was set) and set again by the new message: stays / becomes set
-      if (!consume) atomicOr((unsigned long long*)(m.has_msg + (id >> 6)), bit);
-      m.msg_ts[id] = t;
-      const float nt = a.ts[idx];
-      if (lts > nt) atomicOr(a.err, TG_ERR_PAST_MEMORY);
-      m.left_ts[id] = nt;
-      if (m.left_active) m.left_active[id] = 1;
-    }
-  }
-  {  // leave the step workspace zeroed for the next step
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
-    if (a.clean_flags) {
-      uint4* f = reinterpret_cast<uint4*>(a.clean_flags);
-      for (int64_t i = tid; i < a.flag_bytes / 16; i += nth) f[i] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    if (a.clean_best && a.clean_best_by_pos) {
-      for (int64_t i = tid; i < 2 * B; i += nth) a.clean_best[i < B ? a.src[i] : a.dst[i - B]] = 0ull;
-    } else if (a.clean_best) {
-      const int64_t nb = a.clean_counts[0];
-      for (int64_t i = tid; i < nb; i += nth) a.clean_best[i] = 0ull;
-    }
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (a.counts_dst) {
-      for (int i = 0; i < 4; ++i) a.counts_dst[i] = a.counts_src[i];
-      if (a.clean_best_by_pos) a.counts_dst[0] = a.counts_dst[1] = -1;  // lean step: the sets were not formed
-    }
-    if (a.clean_counts) a.clean_counts[3] = a.clean_counts[4] = 0;
-    if (a.offset_dev) *a.offset_dev += B;
-    if (a.lazy_batch) *a.lazy_batch += 1;
-  }
+  writeback_fused_body<true>(m, a, blockIdx.x, gridDim.x);
 }
 
 int consume_gather_check_launch(const tg_model* m, const int64_t* involved, const int32_t* n_involved, int64_t cap,

@@ -10,6 +10,7 @@
 // Mathematically identical, ~5x fewer flops, and the K*3d key rows are touched once by
 // a gather kernel instead of being materialised for a GEMM.
 #include "tg_step.h"
+#include "tg_sample.h"
 #include "tg_tile.h"
 
 namespace tg {
@@ -506,7 +507,7 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
                               const int64_t* l1_nids, const int64_t* l1_eids, const float* l1_ts, const float* reprs,
                               const uint64_t* bm, const uint32_t* rank, float* out, const AttnWs& w, hipStream_t st,
                               tg_profiler* pf, const PosArgs* pos, const DirectArgs* da, bool centres_done,
-                              const float* key_rows, bool use_gtab) {
+                              const float* key_rows, bool use_gtab, const WbRider* wbr, bool* wb_rode) {
   // stage numbering of the profiler is kept: q -> "merged q+g", g -> skipped, v/out -> skipped, fc1 -> fused
   int stage = ST_ATTN_FIRST + 1;
   const int d = m->d;
@@ -563,7 +564,14 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
   }
   g.w = m->attn_fc2.w; g.ldw = d; g.bias = m->attn_fc2.b;
   g.c = out; g.ldc = d; g.alpha = 1.f; g.nbatch = 1;
-  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  bool rode = false;
+  if (wbr && pos && pos->win_row) {  // STEP 6's rows leave this product's epilogue; STEP 4-5 ride on its launch (WbRider)
+    g.c2 = m->left_vals; g.c2_rows = pos->win_row; g.c2_m = 2 * wbr->a.B; g.ldc2 = d;
+  } else {
+    wbr = nullptr;
+  }
+  if ((rc = gemm_launch(g, st, wbr, &rode)) != TG_OK) return rc;
+  if (wb_rode) *wb_rode = rode;
   return check_launch("tg_temporal_attn_fwd(fused)");
 }
 
@@ -571,14 +579,16 @@ int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float*
                  const int64_t* l1_eids, const float* l1_ts, const float* reprs, const uint64_t* bm,
                  const uint32_t* rank, float* out, const AttnWs& w, hipStream_t st, tg_profiler* pf = nullptr,
                  const DropCfg* drop = nullptr, const PosArgs* pos = nullptr, const DirectArgs* da = nullptr,
-                 const float* key_rows = nullptr, bool centres_done = false, bool use_gtab = false) {
+                 const float* key_rows = nullptr, bool centres_done = false, bool use_gtab = false,
+                 const WbRider* wbr = nullptr, bool* wb_rode = nullptr) {
+  if (wb_rode) *wb_rode = false;
   const DropCfg dc = drop ? *drop : DropCfg{};
   int stage = ST_ATTN_FIRST;
   prof_mark(pf, stage++, st);
   const int d = m->d, d_e = m->d_e, kvw = 2 * d + d_e, nh = m->n_head, dh = 2 * d / nh, E = 2 * d;
   if (m->attn_fused && dc.p == 0.f)  // (the pre-multiplied weights do not care where the node part of a key row comes from)
     return attn_forward_fused(m, Q, nids, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, out, w, st, pf, pos, da, centres_done,
-                              key_rows, use_gtab && m->g_table && !key_rows);
+                              key_rows, use_gtab && m->g_table && !key_rows, wbr, wb_rode);
   const int qblocks = (int)cdiv(2 * d, 4);
   if (da) {  // the constant half of the query projection from the rank-form kernel (no centre rows), then the direct centres
     hipLaunchKernelGGL(k_attn_centres, dim3(1 + qblocks), dim3(256), 0, st, (int64_t)0, d / 4, nids, (const float4*)reprs, bm,
@@ -644,7 +654,14 @@ int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float*
   g.a0 = ASeg{w.t, d, d, nullptr};
   g.w = m->attn_fc2.w; g.ldw = d; g.bias = m->attn_fc2.b;
   g.c = out; g.ldc = d; g.alpha = 1.f; g.nbatch = 1;
-  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  bool rode = false;
+  if (wbr && pos && pos->win_row && dc.p == 0.f) {  // the write-back rider (see attn_forward_fused)
+    g.c2 = m->left_vals; g.c2_rows = pos->win_row; g.c2_m = 2 * wbr->a.B; g.ldc2 = d;
+  } else {
+    wbr = nullptr;
+  }
+  if ((rc = gemm_launch(g, st, wbr, &rode)) != TG_OK) return rc;
+  if (wb_rode) *wb_rode = rode;
   return check_launch("tg_temporal_attn_fwd");
 }
 
@@ -860,7 +877,8 @@ __global__ void k_ids32(int64_t n, const int64_t* __restrict__ ids, int32_t* __r
 // G rows of the nodes nids[0 .. min(cap, *n_dev)) into m->g_table: c = e(v) + nfeat(v) as the attention centres read it
 // (into `crows`, cap x d floats), then the same product the forward pass runs, scattered to the nodes' table rows
 int gtab_rows(const tg_model* m, int64_t cap, const int64_t* nids, const int32_t* rows32, const int32_t* n_dev, float* crows,
-              hipStream_t st, bool crows_ready) {
+              hipStream_t st, bool crows_ready, const CollateRider* collate, bool* rode) {
+  if (rode) *rode = false;
   if (!m->g_table || !m->attn_fused || !m->pending_vals) return TG_EINVAL;
   if (m->row_of) return TG_EUNSUPPORTED;  // (rows32 are node ids)
   const int d = m->d;
@@ -871,7 +889,7 @@ int gtab_rows(const tg_model* m, int64_t cap, const int64_t* nids, const int32_t
   GemmArgs g{};
   g.m_cap = cap; g.m_dev = n_dev; g.n = f.nk; g.k = d; g.a0 = ASeg{crows, d, d, nullptr};
   g.w = f.wqk; g.ldw = d; g.bias = f.gconst; g.c = m->g_table; g.ldc = f.nk; g.c_rows = rows32; g.alpha = 1.f; g.nbatch = 1;
-  return gemm_launch(g, st);
+  return gemm_launch(g, st, nullptr, rode, collate);
 }
 }  // namespace tg
 
@@ -970,6 +988,7 @@ bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w, int n_layer
   w.rank = cv.take<uint32_t>((size_t)W + 1);
   w.rank_out = cv.take<uint32_t>((size_t)W + 1);
   w.upos32 = cv.take<int32_t>((size_t)2 * B);
+  w.win_row = cv.take<int32_t>((size_t)2 * B);
   w.snap = cv.take<float>((size_t)2 * B * m->d);
   w.snap_ts = cv.take<float>((size_t)2 * B);
   w.nids3 = cv.take<int64_t>((size_t)Q);
@@ -1011,7 +1030,7 @@ extern "C" size_t tg_stream_step_workspace_bytes(const tg_model* m, int64_t B) {
 extern "C" size_t tg_stream_step_workspace_bytes2(const tg_model* m, int64_t B, int32_t n_layers) {
   if (!attn_dims_ok(m) || B <= 0 || m->n_nodes <= 0 || (n_layers != 1 && n_layers != 2)) return 0;
   const size_t Q = 3 * (size_t)B, K = m->n_neighbors, cap = (size_t)involved_cap(m, B, n_layers), W = (m->n_nodes + 63) / 64;
-  size_t b = align16(W * 64) + align16(W * 8) + align16(cap * 8) + 32 + 2 * align16((W + 1) * 4) + align16(2 * B * 4) +
+  size_t b = align16(W * 64) + align16(W * 8) + align16(cap * 8) + 32 + 2 * align16((W + 1) * 4) + align16(2 * B * 4) * 2 +
              align16(2 * B * m->d * 4) + align16(2 * B * 4) + align16(Q * 8) * 2 + align16(B * 8) +
              align16(Q * 4) + align16(Q * K * 8) * 2 + align16(Q * K * 4) + align16(cap * 8) * 2 + align16(cap * 4) +
              align16(2 * B * 8) * 2 + align16(cap * m->d * 4) + align16(tg_unique_compact_workspace_bytes(m->n_nodes)) +
@@ -1034,9 +1053,12 @@ __global__ void k_slot_times(int64_t n, int K, const float* __restrict__ ts, flo
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = ts[i / K];
 }
 
+static WritebackArgs writeback_args(const tg_model* m, const tg_step_io* io, StepWs& w);
+
 int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, StepWs& w, float* gates, hipStream_t st,
                  tg_profiler* pf, const DropCfg* drop, bool eager) {
   w.eager = eager;
+  w.wb_rode = false;
   const tg_model* inner = w.h2n ? io->inner : nullptr;  // two attention layers (the workspace was carved for them)
   const int64_t B = io->B, Q = 3 * B, K = m->n_neighbors, cap = involved_cap(m, B, inner ? 2 : 1);
   prof_mark(pf, ST_QUERIES, st);
@@ -1073,15 +1095,43 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
     pos.best = nullptr;
     pos.advance_off = (io->offset_dev && io->advance) ? io->offset_dev : nullptr;
   }
+  // write-back rider (tg_common.h: WbRider): STEP 4-5 share the launch of the attention block's last product, whose
+  // epilogue stores STEP 6's rows; TG_WB_RIDER=0 keeps the write-back launch
+  static const int wbr_knob = getenv("TG_WB_RIDER") ? atoi(getenv("TG_WB_RIDER")) : 1;
+  // (not with io->h_new: those rows are read from the tables after the attention block, i.e. before STEP 4 must run)
+  const bool want_rider = w.fused_wb && wbr_knob != 0 && !drop && !io->h_new;
+  if (want_rider) pos.win_row = w.win_row;
   const PosArgs* pp = (io->embed_only && !untouched) ? nullptr : &pos;
+  // eager query rows: a full eager step of a model that carries the table (it refreshes the table at its end)
+  w.gtab = eager && m->g_table && m->attn_fused && !lz && !inner && !io->embed_only && !io->collate_only && !drop;
+  // collate prefetch (tg_step_io.prefetch_state): this step runs the NEXT batch's sampler + centres on its last launch;
+  // `prefetched`: the previous call did that for this batch (a repeated collate would be harmless, just wasted)
+  static const int pf_knob = getenv("TG_PREFETCH") ? atoi(getenv("TG_PREFETCH")) : 1;
+  w.prefetch = pf_knob != 0 && io->prefetch_state && io->stream_len > 0 && io->offset_dev && io->advance && io->ws_is_clean &&
+               w.lean && w.gtab && w.fused_wb && io->strategy == 0 && K <= 16 && !io->l1_nids && !io->l1_eids && !io->l1_ts;
+  const int pf_in = io->prefetch_state ? *io->prefetch_state : 0;
+  const bool prefetched = w.prefetch && pf_in == 1;
+  if (io->prefetch_state) *io->prefetch_state = 0;  // set again by the end of the step, once the rider is enqueued
+  if (pf_in != 0 && !prefetched) {
+    // a prefetch that is not used (stale, or this step takes another form): its first dedup pass left maxima in the
+    // node-indexed slot table, which only the write-back of THAT batch's lean step would have cleared
+    if ((e = hipMemsetAsync(w.best_id, 0, (size_t)m->n_nodes * 8, st)) != hipSuccess) {
+      set_hip_error(e, "tg_stream_step memset (discarded prefetch)");
+      return TG_EHIP;
+    }
+  }
   const DirectArgs da{w.lean ? nullptr : w.outdated, w.counts + 1, cap, io->err, w.fused_wb ? (float4*)w.snap : nullptr,
                       w.snap_ts, 2 * B, w.lean ? 1 : 0};
   // lean: the centres need nothing the sampler produces and share its launch
   const CentresRider rider{*m, (const float4*)m->nfeats, (float4*)w.attn.cc, da, pp ? pos : PosArgs{},
                            flat_grid(Q * (m->d / 4), 256)};
+  w.pos_args = pp ? pos : PosArgs{};
+  w.da_args = da;
   const bool recent_nodes = io->strategy == 1;
   if (io->strategy != 0 && !recent_nodes) return TG_EUNSUPPORTED;
-  if (recent_nodes) {  // query arrays first, then the wave-per-query sampler of graph.py:129-143 and the involved flags
+  if (prefetched) {
+    // sampler, centres, first dedup pass and snapshot of this batch rode on the previous step's last launch
+  } else if (recent_nodes) {  // query arrays first, then the wave-per-query sampler of graph.py:129-143 and the involved flags
     if (lz || inner) return TG_EUNSUPPORTED;
     hipLaunchKernelGGL(k_build_queries, dim3(flat_grid(Q, 256)), dim3(256), 0, st, B, io->src, io->dst, io->neg, io->ts,
                        io->eids, (const int64_t*)io->offset_dev, w.nids3, w.ts3, w.ts3f, w.eids);
@@ -1137,10 +1187,16 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
       return rc;
     key_rows = w.emb2;
   }
-  // eager query rows: a full eager step of a model that carries the table (it refreshes the table at its end)
-  w.gtab = eager && m->g_table && m->attn_fused && !lz && !inner && !io->embed_only && !io->collate_only && !drop;
+  WbRider wbr{};
+  if (want_rider) {
+    wbr.m = *m;
+    wbr.a = writeback_args(m, io, w);
+    wbr.a.snap = w.snap;
+    wbr.a.snap_ts = w.snap_ts;
+  }
   if ((rc = attn_forward(m, Q, w.nids3, w.ts3f, w.l1n, w.l1e, w.l1t, w.reprs, w.bm, w.rank, io->h, w.attn, st, pf,
-                         drop, pp, w.direct ? &da : nullptr, key_rows, w.lean && !recent_nodes, w.gtab)) != TG_OK)
+                         drop, pp, w.direct ? &da : nullptr, key_rows, w.lean && !recent_nodes, w.gtab,
+                         want_rider ? &wbr : nullptr, &w.wb_rode)) != TG_OK)
     return rc;
   prof_mark(pf, ST_DEDUP, st);
   if (io->h_new) {  // h(t'+) rows of cat[src, dst]: reprs[local(node)], or the table rows themselves
@@ -1208,7 +1264,18 @@ int step_writeback_a(const tg_model* m, const tg_step_io* io, StepWs& w, hipStre
   return TG_OK;
 }
 
-int step_writeback_b(const tg_model* m, const tg_step_io* io, StepWs& w, hipStream_t st, tg_profiler* pf) {
+// the collate part of a batch as a launch of its own (collate prefetch when the last product's kernel hosts no rider)
+__global__ void __launch_bounds__(256) k_collate(CollateRider co) { co.run(blockIdx.x); }
+static void collate_blocks_standalone(CollateRider& c) {
+  const int64_t Q = 3 * c.s.B;
+  c.sblocks = flat_grid(Q, 16);
+  c.cr.blocks = flat_grid(Q * (c.cr.m.d / 4), 256);
+  c.blocks = c.sblocks + c.cr.blocks;
+}
+
+int step_writeback_b(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, StepWs& w, hipStream_t st, tg_profiler* pf) {
+  // unique positive nodes of the batch: slot 2 of the counts, or - one-pass write-back - its copy (see writeback_fused_body)
+  const int32_t* n_upos = w.fused_wb ? w.counts + 5 : w.counts + 2;
   WritebackArgs wa = writeback_args(m, io, w);
   prof_mark(pf, ST_WRITE_LEFT, st);
   int rc;
@@ -1216,7 +1283,8 @@ int step_writeback_b(const tg_model* m, const tg_step_io* io, StepWs& w, hipStre
     wa.snap = w.snap;
     wa.snap_ts = w.snap_ts;
   }
-  if ((rc = writeback_launch(m, wa, w.fused_wb ? 2 : 1, st)) != TG_OK) return rc;
+  // (rider: STEP 4-6 already ran inside the launch of the attention block's last product)
+  if (!(w.fused_wb && w.wb_rode) && (rc = writeback_launch(m, wa, w.fused_wb ? 2 : 1, st)) != TG_OK) return rc;
   prof_mark(pf, ST_EAGER, st);
   if (w.eager && !io->embed_only) {
     // every unique positive node has just received a message (STEP 5) and its memories are final for this batch
@@ -1227,16 +1295,32 @@ int step_writeback_b(const tg_model* m, const tg_step_io* io, StepWs& w, hipStre
     const int64_t bound = io->rows_hint > 0 ? std::min<int64_t>(P, io->rows_hint) : P;
     // With eager query rows the GRU epilogue also leaves the attention-centre form of its rows (h + node features) in the
     // centre-row buffer of the forward pass, which is free again
+    // (centre-row buffer of these launches: the block's fc1 output buffer, free since fc2 - NOT the centre rows of the
+    // forward pass, which the prefetched centres of the next batch overwrite during the query-row launch)
     const bool cr = w.gtab && m->upd_fn == TG_UPD_GRU;
-    if ((rc = apply_messages(m, w.upos, w.upos32, w.counts + 2, P, m->pending_vals, io->err, w.apply_ws, w.apply_bytes, st,
-                             true, nullptr, bound, cr ? w.attn.cc : nullptr, cr ? m->nfeats : nullptr)) != TG_OK)
+    if ((rc = apply_messages(m, w.upos, w.upos32, n_upos, P, m->pending_vals, io->err, w.apply_ws, w.apply_bytes, st,
+                             true, nullptr, bound, cr ? w.attn.t : nullptr, cr ? m->nfeats : nullptr)) != TG_OK)
       return rc;
   }
   prof_mark(pf, ST_GTAB, st);
   if (w.gtab) {
     // ... and the query rows of the same nodes: their effective rows have just changed (tg_model.g_table)
-    if ((rc = gtab_rows(m, 2 * io->B, w.upos, w.upos32, w.counts + 2, w.attn.cc, st, m->upd_fn == TG_UPD_GRU)) != TG_OK)
+    CollateRider co{};
+    bool rode = false;
+    if (w.prefetch) {  // the next batch's collate part rides on this launch (tg_sample.h: CollateRider)
+      co.s = SampleBatchArgs{*g, io->B, io->src, io->dst, io->neg, io->ts, io->eids, (const int64_t*)io->offset_dev,
+                             (int)m->n_neighbors, w.nids3, w.ts3f, w.eids, w.l1n, w.l1e, w.l1t, nullptr, nullptr};
+      co.cr = CentresRider{*m, (const float4*)m->nfeats, (float4*)w.attn.cc, w.da_args, w.pos_args, 0u};
+      co.stream_len = io->stream_len;
+    }
+    if ((rc = gtab_rows(m, 2 * io->B, w.upos, w.upos32, n_upos, w.attn.t, st, m->upd_fn == TG_UPD_GRU,
+                        w.prefetch ? &co : nullptr, &rode)) != TG_OK)
       return rc;
+    if (w.prefetch && !rode) {  // this product's kernel does not host riders: the same work as a launch of its own
+      collate_blocks_standalone(co);
+      hipLaunchKernelGGL(k_collate, dim3(co.blocks), dim3(256), 0, st, co);
+    }
+    if (w.prefetch) *io->prefetch_state = 1;
   }
   prof_mark(pf, ST_COUNT, st);
   if (pf) pf->armed = true;
@@ -1280,7 +1364,7 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
     return check_launch("tg_stream_step(embed_only)");
   }
   if ((rc = step_writeback_a(m, io, w, st, pf)) != TG_OK) return rc;
-  return step_writeback_b(m, io, w, st, pf);
+  return step_writeback_b(m, g, io, w, st, pf);
 }
 
 // ---------------------------------------------------------------------------------

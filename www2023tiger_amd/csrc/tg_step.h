@@ -51,6 +51,8 @@ struct StepWs {
   int64_t *l1_nids, *l1_eids;
   int32_t* out_pos;
   int32_t* upos32;
+  int32_t* win_row;  // [2B] per position of cat[src, dst]: its node if the position wins the node's dedup, else -1 (write-back rider)
+  bool wb_rode;      // STEP 4-6 rode on the launch of the attention block's last product: no write-back launch
   float *snap, *snap_ts;  // one-launch write-back: message-source rows (+ node features) / times of cat[src, dst], pre-batch
   void* scan_ws;
   size_t scan_bytes;
@@ -67,6 +69,9 @@ struct StepWs {
   bool fused_wb;    // STEP 4-6 run as one launch (needs the snapshot taken by the direct centres launch)
   bool direct;      // ... and no compact copy of the involved rows was made (centres / neighbours read the tables)
   bool gtab;        // the folded queries come from the per-node table; the step refreshes its positive nodes' rows at the end
+  bool prefetch;    // the step runs the collate part of the NEXT batch on its last launch (tg_step_io.prefetch_state)
+  PosArgs pos_args;   // the step's dedup arguments / direct-centres arguments (the prefetch builds the next batch's
+  DirectArgs da_args; // centres rider from them at the end of the step)
   // --n_layers 2: second-hop lists of the Q*K neighbour slots, the slots' query times (the roots'), their embeddings
   int64_t *h2n, *h2e;
   float *h2t, *ts2, *emb2;
@@ -76,7 +81,7 @@ struct StepWs {
 bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w, int n_layers = 1);
 int attn_dims_ok(const tg_model* m);
 int gtab_rows(const tg_model* m, int64_t cap, const int64_t* nids, const int32_t* rows32, const int32_t* n_dev, float* crows,
-              hipStream_t st, bool crows_ready);
+              hipStream_t st, bool crows_ready, const CollateRider* collate = nullptr, bool* rode = nullptr);
 // collate + STEP 1-3 (+ io->h_new); `gates` (nullable) receives the GRU gate activations
 // eager: take the outdated nodes' rows from m->pending_vals instead of running the updater (tg_stream_step only)
 int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, StepWs& w, float* gates, hipStream_t st,
@@ -84,7 +89,7 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
 // positive-node dedup + STEP 4/5 + restarter targets
 int step_writeback_a(const tg_model* m, const tg_step_io* io, StepWs& w, hipStream_t st, tg_profiler* pf);
 // STEP 6 + workspace clean-up + offset advance
-int step_writeback_b(const tg_model* m, const tg_step_io* io, StepWs& w, hipStream_t st, tg_profiler* pf);
+int step_writeback_b(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, StepWs& w, hipStream_t st, tg_profiler* pf);
 
 // mutual-learning half of the training step (tg_restart.hip)
 size_t mutual_ws_bytes(const tg_model* m, const tg_seq_restarter* r, int64_t B);

@@ -979,7 +979,7 @@ extern "C" int tg_train_step(const tg_model* m_in, const tg_tcsr* g, const tg_tr
     if ((rc = step_forward(m, g, sio, w, nullptr, st, nullptr, nullptr)) != TG_OK) return rc;
     if ((rc = score_forward(m, io, w, t, st)) != TG_OK) return rc;
     if ((rc = step_writeback_a(m, sio, w, st, nullptr)) != TG_OK) return rc;
-    return step_writeback_b(m, sio, w, st, nullptr);
+    return step_writeback_b(m, g, sio, w, st, nullptr);
   }
   if (io->dropout_p < 0.f || io->dropout_p >= 1.f || (io->dropout_p > 0.f && !io->rng)) return TG_EINVAL;
   const DropCfg dc = make_drop(io->dropout_p, io->rng);
@@ -997,7 +997,7 @@ extern "C" int tg_train_step(const tg_model* m_in, const tg_tcsr* g, const tg_tr
     (void)hipMemsetAsync(io->flags + 2, 0, sizeof(int32_t), st);
   }
   if (dc.p > 0.f) hipLaunchKernelGGL(k_rng_tick, dim3(1), dim3(64), 0, st, io->rng);
-  return step_writeback_b(m, sio, w, st, nullptr);
+  return step_writeback_b(m, g, sio, w, st, nullptr);
 }
 
 extern "C" int tg_adam_step(const tg_adam_seg* segs_dev, int32_t n_segs, int32_t n_groups, const int32_t* enabled_dev,

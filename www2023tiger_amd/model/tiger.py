@@ -620,11 +620,14 @@ class TIGE(nn.Module):
         tg_stream_step; reused every step so the call sequence can be graph-captured."""
 
         def __init__(self, model: 'TIGE', B: int, want_prev: bool, resident=None, embed_only: bool = False,
-                     h_out=None, h_new_out=None, want_h_new: bool = True, lean: bool = False):
+                     h_out=None, h_new_out=None, want_h_new: bool = True, lean: bool = False, prefetch: bool = False):
             """resident = (src, dst, neg, ts64, eids) device tensors of the WHOLE stream: the
             step then reads batch [offset, offset+B) and advances `offset` on device.
             lean: the caller does not read `involved` nor counts[0:2] (tiger_hip.h: tg_step_io.lean) - an eager
-            step then skips forming those sets; same results otherwise."""
+            step then skips forming those sets; same results otherwise.
+            prefetch (resident streams): the caller does not read the neighbour lists either (l1_* are not outputs then) - a
+            lean eager step of a model with eager query rows then runs the NEXT batch's sampler and centres as riders of its
+            own last launch (tiger_hip.h: tg_step_io.prefetch_state); same results otherwise."""
             dev, d, K = model.device, model.memory_dim, model.n_neighbors
             self.B = B
             self.embed_only = embed_only
@@ -660,6 +663,16 @@ class TIGE(nn.Module):
                                ptr(self.offset), 1 if resident is not None else 0, 1 if embed_only else 0, None,
                                ptr(self.h_new), 0 if embed_only else 1, 0)
             self.io.lean = 1 if lean else 0
+            # collate prefetch (tiger_hip.h: tg_step_io.prefetch_state): a lean step over a resident stream runs the next
+            # batch's sampler + centres on its own last launch; TIGE.launch_step keeps the promise the flag stands for
+            self._pf_state = C.c_int32(0)
+            self._pf_stamp = None
+            if prefetch:
+                if resident is None or embed_only:
+                    raise ValueError('prefetch needs a resident stream and a full step')
+                self.io.stream_len = int(self.src.numel())
+                self.io.prefetch_state = C.addressof(self._pf_state)
+                self.io.l1_nids = self.io.l1_eids = self.io.l1_ts = None
 
         def attach_profiler(self, prof):
             self.io.profiler = prof
@@ -783,10 +796,27 @@ class TIGE(nn.Module):
             if not buf.io.lazy:  # (a step with the in-step restart loop runs the G product: it does not read the table)
                 self._sync_gtab()
         m = self.model_struct()
+        pf = bool(buf.io.prefetch_state)
+        if pf:  # is the collate part this buffer's previous step prefetched still the one this step needs?
+            if buf._pf_state.value == 1 and buf._pf_stamp != self._prefetch_stamp(buf, g):
+                buf._pf_state.value = 2  # made, but for another state / offset / graph: the step discards it
+            before = buf._pf_state.value
+        self._step_serial = getattr(self, '_step_serial', 0) + 1
         check(lib.tg_stream_step(C.byref(m), C.byref(g), C.byref(buf.io), ptr(buf.ws), buf.ws.numel(),
                                  stream_ptr(self.device)), 'tg_stream_step')
+        if pf:
+            if self.device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+                buf._pf_state.value = before  # nothing ran: the device is where it was before the capturing call
+            buf._pf_stamp = self._prefetch_stamp(buf, g)
         if buf.io.lazy and getattr(self, '_gtab', None) is not None:
             self._gtab_stamp = None  # the in-step restart loop re-initialises rows the table does not follow
+
+    def _prefetch_stamp(self, buf, g):
+        """Everything the prefetched collate part of a batch is a function of, as far as the host can see it: the state
+        (as for the eager-update table), that no other step ran on this model since, the stream offset tensor and the
+        graph.  (Graph replays change none of these: a graph captured with the flag set on entry and exit keeps it
+        valid by construction.)"""
+        return (self._state_stamp(), getattr(self, '_step_serial', 0), buf.offset._version, id(buf.offset), C.addressof(g))
 
     @torch.no_grad()
     def stream_step(self, src, dst, neg, ts, eids, want_prev: bool = False, check_invariants: bool = True,
