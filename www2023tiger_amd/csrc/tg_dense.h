@@ -19,6 +19,7 @@ struct ASeg {
 struct GemmArgs {
   int64_t m_cap;
   const int32_t* m_dev;  // nullable: live row count on device (<= m_cap)
+  int64_t m_hint;        // 0, or the caller's estimate of *m_dev (performance only: sizes the riders of the launch)
   int n, k;
   ASeg a0, a1;
   const float* w;

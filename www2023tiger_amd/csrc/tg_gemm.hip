@@ -527,16 +527,6 @@ template <int RM, int RN>
 __global__ void __launch_bounds__(256) k_gemm_rb(GemmArgs g) {
   gemm_rb_block<RM, RN>(g, blockIdx.x);
 }
-template <class R, int RM, int RN>
-__global__ void __launch_bounds__(256) k_gemm_rb_r(GemmArgs g, R r) {
-  const unsigned own = gridDim.x - r.blocks;  // the product's blocks: before the riders (r.last) or after them
-  if (r.last ? blockIdx.x >= own : blockIdx.x < r.blocks) {
-    r.run(r.last ? blockIdx.x - own : blockIdx.x);
-    return;
-  }
-  gemm_rb_block<RM, RN>(g, r.last ? blockIdx.x : blockIdx.x - r.blocks);
-}
-
 // ---- activation-stationary blocks for short-K, wide-N products ------------------------------------------------------
 // The G product of the fused attention (K = d, N = n_head (2d + d_e)) has NKT = 4 .. 8 k-tiles per output tile and many
 // column tiles per row tile.  As separate 64 x 64 blocks every column tile re-stages the same 64 x K activation panel
@@ -717,29 +707,34 @@ bool gemm_sk_partials(const GemmArgs& g, float* ws, size_t ws_floats, hipStream_
   return true;
 }
 
-// Workgroups of the write-back rider (WbRider) in a launch of `grid` product blocks of `threads` threads: the CUs an
-// under-filled launch leaves idle (C2: 144 product blocks + 112 riders, one block per CU either way), else two riders per
-// CU beside the matrix work; never more wavefronts than listed rows; a multiple of 8 (the product's XCD map stays).
-static unsigned rider_blocks(int64_t grid, int threads, int64_t rows) {
+// Riders (WbRider, CollateRider) pay where the product's launch is small: its live blocks leave CUs idle (C2: 144 blocks of
+// fc2 + 112 write-back riders, one block per CU either way) or fill the chip for a round or so.  Large launches take no
+// rider - measured at C5 shape: the write-back as 512 riders of fc2 costs 240 us where its own launch takes 180 us, and
+// the collate riders of the query-row product change nothing - the caller then launches that work itself.  `live`: the
+// product's blocks that have rows (a launch may be sized for a capacity several times its live rows: GemmArgs.m_hint).
+// Riders sit BEHIND the product's blocks in the grid: the dispatcher starts the product - the critical path - first, the
+// riders take what is left.
+constexpr int64_t RIDER_MAX_LIVE = 1024;
+static int64_t live_blocks(const GemmArgs& g, int64_t grid, int bm) {
+  if (g.m_hint <= 0 || g.m_hint >= g.m_cap) return grid;
+  return std::max<int64_t>(1, grid * cdiv(g.m_hint, (int64_t)bm) / std::max<int64_t>(1, cdiv(g.m_cap, (int64_t)bm)));
+}
+// write-back riders: one wavefront per listed row at most; the idle CUs of an under-filled launch, else two per CU; a
+// multiple of 8 (the product's XCD map stays)
+static unsigned rider_blocks(int64_t live, int threads, int64_t rows) {
   const int64_t want = cdiv(rows, (int64_t)(threads / 64));
-  const int64_t room = grid <= 248 ? 256 - grid : 512;
+  const int64_t room = live <= 248 ? 256 - live : 512;
   return (unsigned)std::max<int64_t>(8, std::min(want, room) & ~(int64_t)7);
 }
-// Riders go BEHIND the product's blocks when the whole launch is resident at once anyway (the dispatcher then starts the
-// product's blocks - the critical path - first), and IN FRONT of them in a launch of many rounds (behind, they would run
-// when the product is done: no overlap)
-static unsigned riders_last(int64_t grid, unsigned riders) { return grid + riders <= 768 ? 1u : 0u; }
-
-// Workgroups of the collate rider (CollateRider): the sampler is a chain of dependent memory round trips per query and
-// wants many wavefronts; the centres are a gather.  Under-filled host launch (the C2-sized query-row product: ~150 live
-// blocks, two per CU): the sampler's own grid up to 192 blocks + 128 for the centres; otherwise two riders per CU.
-static void collate_blocks(CollateRider& c, int64_t grid) {
+// collate riders: the sampler is a chain of dependent memory round trips per query and wants many wavefronts (its own
+// launch has one group of 16 lanes per query); the centres are a gather with four elements per thread in flight
+static void collate_blocks(CollateRider& c) {
   const int64_t Q = 3 * c.s.B;
   const int64_t sg = cdiv(Q, (int64_t)16), cg = cdiv(Q * (c.cr.m.d / 4), (int64_t)256);
-  c.sblocks = (unsigned)std::min<int64_t>(sg, grid <= 512 ? 192 : 384);
-  c.cr.blocks = (unsigned)std::min<int64_t>(cdiv(cg, (int64_t)4), 160);  // (four elements per thread in flight)
+  c.sblocks = (unsigned)std::min<int64_t>(sg, 1024);
+  c.cr.blocks = (unsigned)std::min<int64_t>(cdiv(cg, (int64_t)4), 512);
   c.blocks = (c.sblocks + c.cr.blocks + 7u) & ~7u;
-  c.last = riders_last(grid, c.blocks);
+  c.last = 1u;
 }
 
 int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* rode, const CollateRider* collate) {
@@ -763,6 +758,9 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
   GemmArgs gd = g;
   gd.dbg = gdbg;
   static const int depth_knob = getenv("TG_GEMM_DEPTH") ? atoi(getenv("TG_GEMM_DEPTH")) : 2;  // tuning knob: 2 / 4
+  // a write-back rider that is not hosted: the caller runs the whole write-back itself, STEP 6's rows included - this
+  // launch then stores no second copy of them
+  auto no_ride = [&]() { if (rider) gd.c2 = nullptr; };
   // plain row-major products with MANY rows: register-blocked 128 x 64 blocks (three quarters of the staged bytes per
   // MFMA, half the fragment reads).  Measured: C5 shape (24 576 / 6 144 / 6 144 blocks) G 1.00 -> 0.96 ms, fc1 1.19 ->
   // 1.08 ms, fc2 0.261 -> 0.253 ms; at C3 / C4 sizes (288 .. 2 500 blocks) 3 .. 17 % SLOWER than the 64 x 64 blocks (whose
@@ -770,21 +768,9 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
   static const int rb_knob = getenv("TG_GEMM_RB") ? atoi(getenv("TG_GEMM_RB")) : 1;  // tuning knob: 0 = off, 2 = 128 x 128
   if (rb_knob && !g.ask_part && g.nbatch == 1 && !g.w_kmajor && !g.bias_rs && !g.row_valid && !g.relu_mask &&
       !g.accumulate && cdiv(g.m_cap, 128) * NT >= 4096) {
+    no_ride();
     if (rb_knob == 2 && g.n >= 512) {
       hipLaunchKernelGGL((k_gemm_rb<2, 2>), dim3((unsigned)(8 * cdiv(cdiv(g.m_cap, 128), 8) * cdiv(g.n, 128))), dim3(256), 0, st, gd);
-    } else if (rider) {
-      WbRider wr = *rider;
-      const int64_t gb = 8 * cdiv(cdiv(g.m_cap, 128), 8) * NT;
-      wr.blocks = rider_blocks(gb, 256, 2 * wr.a.B);
-      wr.last = riders_last(gb, wr.blocks);
-      hipLaunchKernelGGL((k_gemm_rb_r<WbRider, 2, 1>), dim3((unsigned)(gb + wr.blocks)), dim3(256), 0, st, gd, wr);
-      *rode = true;
-    } else if (collate) {
-      CollateRider co = *collate;
-      const int64_t gb = 8 * cdiv(cdiv(g.m_cap, 128), 8) * NT;
-      collate_blocks(co, gb);
-      hipLaunchKernelGGL((k_gemm_rb_r<CollateRider, 2, 1>), dim3((unsigned)(gb + co.blocks)), dim3(256), 0, st, gd, co);
-      *rode = true;
     } else {
       hipLaunchKernelGGL((k_gemm_rb<2, 1>), dim3((unsigned)(8 * cdiv(cdiv(g.m_cap, 128), 8) * NT)), dim3(256), 0, st, gd);
     }
@@ -803,9 +789,9 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
       static const int cpb_knob = getenv("TG_GEMM_ASTAT_CPB") ? atoi(getenv("TG_GEMM_ASTAT_CPB")) : 0;
       const int cpb = cpb_knob > 0 ? std::min(cpb_knob, NT) : as_knob > 1 ? std::min(as_knob, NT) : 2;
       const int64_t gb = 8 * cdiv(MT, 8) * cdiv(NT, cpb);
-      if (collate) {
+      if (collate && live_blocks(g, gb, 64) <= RIDER_MAX_LIVE) {
         CollateRider co = *collate;
-        collate_blocks(co, gb);
+        collate_blocks(co);
         const dim3 grid_r((unsigned)(gb + co.blocks));
         if (nkt == 4) hipLaunchKernelGGL((k_gemm_astat_r<CollateRider, 4>), grid_r, dim3(256), 0, st, gd, cpb, co);
         else if (nkt == 6) hipLaunchKernelGGL((k_gemm_astat_r<CollateRider, 6>), grid_r, dim3(256), 0, st, gd, cpb, co);
@@ -813,6 +799,7 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
         *rode = true;
         return check_launch("gemm(astat+collate)");
       }
+      no_ride();
       const dim3 grid_as((unsigned)gb);
       if (nkt == 4) hipLaunchKernelGGL((k_gemm_astat<4>), grid_as, dim3(256), 0, st, gd, cpb);
       else if (nkt == 6) hipLaunchKernelGGL((k_gemm_astat<6>), grid_as, dim3(256), 0, st, gd, cpb);
@@ -826,35 +813,42 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
     gd.ask_rcpU = 1.0f / (float)g.ask_U;
     static const int ask_ks = getenv("TG_GEMM_ASK_KS") ? atoi(getenv("TG_GEMM_ASK_KS")) : 2;  // tuning knob: 1 / 2 (measured 12.6 / 11.1 us)
     WbRider wr = rider ? *rider : WbRider{};
-    if (rider && (g.ask_pieces > 3 || ask_ks == 2)) {
+    if (rider && (g.ask_pieces > 3 || ask_ks == 2)) {  // (stream-K consumers: the producer had fewer tiles than CUs)
       wr.blocks = rider_blocks(grid, 512, 2 * wr.a.B);
-      wr.last = riders_last(grid, wr.blocks);
+      wr.last = 1u;
       if (g.ask_pieces > 3)
         hipLaunchKernelGGL((k_gemm_r<WbRider, 2, 2, 2, 2, true, 8>), dim3((unsigned)grid + wr.blocks), dim3(512), 0, st, gd, wr);
       else
         hipLaunchKernelGGL((k_gemm_r<WbRider, 2, 2, 2, 2, true>), dim3((unsigned)grid + wr.blocks), dim3(512), 0, st, gd, wr);
       *rode = true;
-    } else if (g.ask_pieces > 3) hipLaunchKernelGGL((k_gemm<2, 2, 2, 2, true, 8>), dim3((unsigned)grid), dim3(512), 0, st, gd);
-    else if (ask_ks == 2) hipLaunchKernelGGL((k_gemm<2, 2, 2, 2, true>), dim3((unsigned)grid), dim3(512), 0, st, gd);
-    else if (ask_depth == 4) hipLaunchKernelGGL((k_gemm<2, 2, 1, 4, true>), dim3((unsigned)grid), dim3(256), 0, st, gd);
-    else hipLaunchKernelGGL((k_gemm<2, 2, 1, 2, true>), dim3((unsigned)grid), dim3(256), 0, st, gd);
-  } else if (split)
+    } else {
+      no_ride();
+      if (g.ask_pieces > 3) hipLaunchKernelGGL((k_gemm<2, 2, 2, 2, true, 8>), dim3((unsigned)grid), dim3(512), 0, st, gd);
+      else if (ask_ks == 2) hipLaunchKernelGGL((k_gemm<2, 2, 2, 2, true>), dim3((unsigned)grid), dim3(512), 0, st, gd);
+      else if (ask_depth == 4) hipLaunchKernelGGL((k_gemm<2, 2, 1, 4, true>), dim3((unsigned)grid), dim3(256), 0, st, gd);
+      else hipLaunchKernelGGL((k_gemm<2, 2, 1, 2, true>), dim3((unsigned)grid), dim3(256), 0, st, gd);
+    }
+  } else if (split) {
+    no_ride();
     hipLaunchKernelGGL((k_gemm<2, 2, 2, 2>), dim3((unsigned)grid), dim3(512), 0, st, gd);
-  else if (depth_knob == 2 && rider) {
+  } else if (depth_knob == 2 && rider && live_blocks(g, grid, 64) <= RIDER_MAX_LIVE) {
     WbRider wr = *rider;
-    wr.blocks = rider_blocks(grid, 256, 2 * wr.a.B);
-    wr.last = riders_last(grid, wr.blocks);
+    wr.blocks = rider_blocks(live_blocks(g, grid, 64), 256, 2 * wr.a.B);
+    wr.last = 1u;
     hipLaunchKernelGGL((k_gemm_r<WbRider, 2, 2, 1, 2>), dim3((unsigned)grid + wr.blocks), dim3(256), 0, st, gd, wr);
     *rode = true;
-  } else if (depth_knob == 2 && collate) {
+  } else if (depth_knob == 2 && collate && live_blocks(g, grid, 64) <= RIDER_MAX_LIVE) {
     CollateRider co = *collate;
-    collate_blocks(co, grid);
+    collate_blocks(co);
     hipLaunchKernelGGL((k_gemm_r<CollateRider, 2, 2, 1, 2>), dim3((unsigned)grid + co.blocks), dim3(256), 0, st, gd, co);
     *rode = true;
-  } else if (depth_knob == 2)
+  } else if (depth_knob == 2) {
+    no_ride();
     hipLaunchKernelGGL((k_gemm<2, 2, 1, 2>), dim3((unsigned)grid), dim3(256), 0, st, gd);
-  else
+  } else {
+    no_ride();
     hipLaunchKernelGGL((k_gemm<2, 2, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, gd);
+  }
   return check_launch("gemm");
 }
 
@@ -1620,6 +1614,257 @@ __global__ void __launch_bounds__(256) k_gru_direct(GruArgs g) {
   }
 }
 
+// ---- LDS-free updater blocks on 16 x 16 MFMA tiles: 16 RT rows x 16 hidden columns ------------------------------------
+// k_gru_direct's 32 x 32 blocks leave CUs idle whenever (row tiles x column tiles) is not close to 256: C2's ~1 060 rows at
+// d = 172 are 34 x 6 = 204 blocks, and the launch lasts as long as ONE block.  On v_mfma_f32_16x16x4_f32 (same flops per
+// cycle) the hidden width is cut into 16-column tiles (172 -> 11 tiles, 2 % padding instead of 10 %) and a block owns 16,
+// 32 or 48 rows: the kernel picks, from the LIVE row count, the smallest of the three whose blocks all fit the chip at
+// once (least work per block; C2: 23 x 11 = 253 blocks of 48 rows, three quarters of the work of a 32 x 32 block each;
+// the batch-of-200 workload: 32-row blocks).  Same scheme otherwise: no LDS in the k-loop, a lane feeds the matrix unit
+// from what it loads (lane (row i, quarter kq) reads the 32 contiguous bytes A[i][k0 + 8 kq ..] of each of its RT rows
+// and of its weight row in each plane; MFMA step (q, j) multiplies element j of float4 q on both operands - the sum over
+// k does not care which k values share a step), the k-tiles are dealt to the four wavefronts, whose accumulators meet
+// in a reduce-scatter through LDS (k-group order: bit-reproducible).  Blocks are dealt to the XCDs in contiguous chunks of
+// the (row tile, column tile) sequence - balanced to within one block, and a row tile's gathered rows are fetched by one
+// XCD's L2, two at a chunk border.
+template <int RT>
+__device__ __forceinline__ void gru_direct16_body(const GruArgs& g, int64_t M, int64_t mt, int nt, float* sc_raw) {
+  constexpr int KS = 4;
+  float (*sc)[KS - 1][4][RT][64] = reinterpret_cast<float (*)[KS - 1][4][RT][64]>(sc_raw);  // [owner][slot][plane][row tile]
+  const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int d = g.d, xw = g.xw;
+  const int64_t m0 = mt * (16 * RT);
+  const int j0 = nt * 16;
+  const int jc = min(j0 + li, d - 1);
+  const bool jok = j0 + li < d;
+  const float* xrow[RT];
+  const float* hrow[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int64_t mrow = min(m0 + 16 * rt + li, M - 1);
+    xrow[rt] = g.x.p + (g.x.idx ? g.x.idx[mrow] : mrow) * g.x.ld;
+    hrow[rt] = g.h.p + (g.h.idx ? g.h.idx[mrow] : mrow) * g.h.ld;
+  }
+  const float* wi = g.w_ih + (int64_t)jc * xw;
+  const float* wh = g.w_hh + (int64_t)jc * d;
+  const int64_t wi_ps = (int64_t)d * xw, wh_ps = (int64_t)d * d;  // plane strides
+  // epilogue operands of the rows this wavefront finishes: accumulator register ks of every row tile (row 4 lk + ks)
+  float hold[RT], addv[RT];
+  int64_t orow[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int64_t mm = min(m0 + 16 * rt + 4 * lk + ks, M - 1);
+    const int64_t node = g.h.idx ? g.h.idx[mm] : mm;
+    hold[rt] = g.h.p[node * g.h.ld + jc];
+    addv[rt] = (g.out2 && g.add2) ? g.add2[node * d + jc] : 0.f;
+    orow[rt] = g.out_rows ? (int64_t)g.out_rows[mm] : mm;
+  }
+  const float br = g.b_ih[jc] + g.b_hh[jc];
+  const float bz = g.b_ih[d + jc] + g.b_hh[d + jc];
+  const float bin = g.b_ih[2 * d + jc], bhn = g.b_hh[2 * d + jc];
+  const int nkx = (xw + BK - 1) / BK - g.x_skip_n, nkh = (d + BK - 1) / BK;
+  const int nkt = nkx + nkh;
+  const int xs_at = g.x_skip_at, xs_sh = g.x_skip_n * BK, xwe = xw - xs_sh;  // zero k-tiles skipped (see k_gru)
+  // this wavefront's tiles: message tiles ks, ks + 4, ... < nkx, then memory tiles th0, th0 + 4, ... < nkt
+  const int nx = ks < nkx ? (nkx - ks + 3) / 4 : 0;
+  const int th0 = nkx + ((ks - nkx) % 4 + 4) % 4;
+  const int nh = th0 < nkt ? (nkt - th0 + 3) / 4 : 0;
+  const int n_my = nx + nh;
+  auto tile_of = [&](int i) { return i < nx ? ks + 4 * i : th0 + 4 * (i - nx); };
+  struct Tile {
+    float4 a[RT][2], w0[2], w1[2], w2[2];
+  };
+  auto load_tile = [&](int i, Tile& T, unsigned& live) {  // raw loads from clamped addresses (see k_gru_direct)
+    const int t = tile_of(max(0, min(i, n_my - 1)));
+    const bool hp = t >= nkx;
+    const int kb = (hp ? t - nkx : t) * BK + 8 * lk;
+    const int sh = (!hp && t >= xs_at) ? xs_sh : 0;
+    const int wid = hp ? d : xwe;
+    const float* wr = hp ? wh : wi;
+    const int64_t ps = hp ? wh_ps : wi_ps;
+    live = 0u;
+    int kc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int k = kb + 4 * q;
+      if (k < wid) live |= 1u << q;
+      kc[q] = (k < wid ? k : 0) + sh;
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) T.a[rt][q] = ldg4((hp ? hrow[rt] : xrow[rt]) + kc[q]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) T.w0[q] = ldg4(wr + kc[q]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) T.w1[q] = ldg4(wr + ps + kc[q]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) T.w2[q] = ldg4(wr + 2 * ps + kc[q]);
+  };
+  f32x4m acc_r[RT], acc_z[RT], acc_in[RT], acc_hn[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) acc_r[rt] = acc_z[rt] = acc_in[rt] = acc_hn[rt] = f32x4m{0.f, 0.f, 0.f, 0.f};
+  auto mma_tile = [&](auto hp_tag, const Tile& T, unsigned live) {
+    constexpr bool HP = decltype(hp_tag)::value;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float av[RT][4];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const float4 a = ((live >> q) & 1u) ? T.a[rt][q] : zero4();
+        av[rt][0] = a.x; av[rt][1] = a.y; av[rt][2] = a.z; av[rt][3] = a.w;
+      }
+      const float b0[4] = {T.w0[q].x, T.w0[q].y, T.w0[q].z, T.w0[q].w};
+      const float b1[4] = {T.w1[q].x, T.w1[q].y, T.w1[q].z, T.w1[q].w};
+      const float b2[4] = {T.w2[q].x, T.w2[q].y, T.w2[q].z, T.w2[q].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc_r[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][j], b0[j], acc_r[rt], 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc_z[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][j], b1[j], acc_z[rt], 0, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          if (HP) acc_hn[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][j], b2[j], acc_hn[rt], 0, 0, 0);
+          else acc_in[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][j], b2[j], acc_in[rt], 0, 0, 0);
+        }
+      }
+    }
+  };
+  using HP0 = std::integral_constant<bool, false>;
+  using HP1 = std::integral_constant<bool, true>;
+  Tile T0, T1;
+  unsigned l0 = 0u, l1 = 0u;
+  load_tile(0, T0, l0);
+#define TG_STEP(HPT, CUR, LCUR, NXT, LNXT, INEXT)     \
+  do {                                                \
+    load_tile(INEXT, NXT, LNXT);                      \
+    __builtin_amdgcn_sched_barrier(0);                \
+    mma_tile(HPT{}, CUR, LCUR);                       \
+    __builtin_amdgcn_sched_barrier(0);                \
+  } while (0)
+  int i = 0;
+  for (; i + 2 <= nx; i += 2) {
+    TG_STEP(HP0, T0, l0, T1, l1, i + 1);
+    TG_STEP(HP0, T1, l1, T0, l0, i + 2);
+  }
+  if (i < nx) {  // odd number of message tiles: the memory tiles start in the other register set
+    TG_STEP(HP0, T0, l0, T1, l1, i + 1);
+    for (++i; i + 2 <= n_my; i += 2) {
+      TG_STEP(HP1, T1, l1, T0, l0, i + 1);
+      TG_STEP(HP1, T0, l0, T1, l1, i + 2);
+    }
+    if (i < n_my) mma_tile(HP1{}, T1, l1);
+  } else {
+    for (; i + 2 <= n_my; i += 2) {
+      TG_STEP(HP1, T0, l0, T1, l1, i + 1);
+      TG_STEP(HP1, T1, l1, T0, l0, i + 2);
+    }
+    if (i < n_my) mma_tile(HP1{}, T0, l0);
+  }
+#undef TG_STEP
+  // reduce-scatter over the four wavefronts: wavefront v finishes accumulator register v of every row tile; the others'
+  // registers are parked in LDS (one round, one barrier)
+#pragma unroll
+  for (int v = 0; v < KS; ++v) {
+    if (v != ks) {  // wave-uniform
+      const int slot = (ks - v - 1 + KS) % KS;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        sc[v][slot][0][rt][lane] = acc_r[rt][v];
+        sc[v][slot][1][rt][lane] = acc_z[rt][v];
+        sc[v][slot][2][rt][lane] = acc_in[rt][v];
+        sc[v][slot][3][rt][lane] = acc_hn[rt][v];
+      }
+    }
+  }
+  __syncthreads();
+  // partial sums are added in wavefront order 0..3 whichever wavefront owns the row (k_gru: a row's result must not
+  // depend on its place in the tile)
+  float o_r[RT], o_z[RT], o_in[RT], o_hn[RT];
+#pragma unroll
+  for (int gsrc = 0; gsrc < KS; ++gsrc) {
+    float t_r[RT], t_z[RT], t_in[RT], t_hn[RT];
+    if (gsrc == ks) {  // wave-uniform
+#pragma unroll
+      for (int v = 0; v < KS; ++v)
+        if (v == ks) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            t_r[rt] = acc_r[rt][v]; t_z[rt] = acc_z[rt][v]; t_in[rt] = acc_in[rt][v]; t_hn[rt] = acc_hn[rt][v];
+          }
+        }
+    } else {
+      const int sl = (gsrc - ks - 1 + KS) % KS;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        t_r[rt] = sc[ks][sl][0][rt][lane]; t_z[rt] = sc[ks][sl][1][rt][lane];
+        t_in[rt] = sc[ks][sl][2][rt][lane]; t_hn[rt] = sc[ks][sl][3][rt][lane];
+      }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      o_r[rt] = gsrc == 0 ? t_r[rt] : o_r[rt] + t_r[rt];
+      o_z[rt] = gsrc == 0 ? t_z[rt] : o_z[rt] + t_z[rt];
+      o_in[rt] = gsrc == 0 ? t_in[rt] : o_in[rt] + t_in[rt];
+      o_hn[rt] = gsrc == 0 ? t_hn[rt] : o_hn[rt] + t_hn[rt];
+    }
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int64_t m = m0 + 16 * rt + 4 * lk + ks;
+    const float rg = fast_sigmoid(o_r[rt] + br);
+    const float zg = fast_sigmoid(o_z[rt] + bz);
+    const float hn = o_hn[rt] + bhn;
+    const float ng = fast_tanh(o_in[rt] + bin + rg * hn);
+    if (jok && m < M) {
+      const float hv = (1.f - zg) * ng + zg * hold[rt];
+      g.out[orow[rt] * g.ldo + j0 + li] = hv;
+      if (g.out2) g.out2[m * (int64_t)d + j0 + li] = hv + addv[rt];
+      if (g.gates) {
+        float* gp = g.gates + m * 4 * (int64_t)d + j0 + li;
+        gp[0] = rg; gp[d] = zg; gp[2 * d] = ng; gp[3 * d] = hn;
+      }
+    }
+  }
+}
+
+constexpr int GRU16_RT_MAX = 6;
+// RTM: the most rows / 16 this instance offers (3: 16 / 32 / 48 rows, 176 + 72 registers; 6: also 64 / 96, 254 + 144 - the
+// bigger register file costs the 48-row blocks 5 %, so launches whose bound fits 48-row blocks take the small instance)
+template <int RTM>
+__global__ void __launch_bounds__(256) k_gru_direct16(GruArgs g) {
+  __shared__ float sc_raw[4 * 3 * 4 * RTM * 64];
+  int64_t M = g.cap;
+  if (g.n_dev) M = min(M, (int64_t)*g.n_dev);
+  if (M <= 0) return;
+  const int NT = (g.d + 15) / 16;
+  // rows per block from the LIVE row count: the smallest of 16 / 32 / 48 (/ 64 / 96) whose blocks fit the 256 CUs at once
+  int rt = RTM;
+  if (((M + 15) / 16) * NT <= 256) rt = 1;
+  else if (((M + 31) / 32) * NT <= 256) rt = 2;
+  else if (RTM > 3 && ((M + 47) / 48) * NT <= 256) rt = 3;
+  else if (RTM > 3 && ((M + 63) / 64) * NT <= 256) rt = 4;
+  const int64_t total = ((M + 16 * rt - 1) / (16 * rt)) * NT;
+  // XCD x (blockIdx % 8) works through the chunk [x per, (x + 1) per) of the tile sequence.  The grid is 256 blocks whatever
+  // the capacity (no tail of dead blocks: the row CAPACITY of the eager updater is twice its live rows and more); a row
+  // count beyond the largest blocks' single round makes blocks take a second tile
+  const int64_t per = (total + 7) / 8;
+  for (int64_t jx = blockIdx.x >> 3; jx < per; jx += gridDim.x >> 3) {
+    const int64_t b = (int64_t)(blockIdx.x & 7) * per + jx;
+    if (b >= total) break;
+    const int64_t mt = b / NT;
+    const int nt = (int)(b - mt * NT);
+    if (rt == 1) gru_direct16_body<1>(g, M, mt, nt, sc_raw);
+    else if (rt == 2) gru_direct16_body<2>(g, M, mt, nt, sc_raw);
+    else if (RTM == 3 || rt == 3) gru_direct16_body<3>(g, M, mt, nt, sc_raw);
+    else if (rt == 4) gru_direct16_body<(RTM > 3 ? 4 : 3)>(g, M, mt, nt, sc_raw);
+    else gru_direct16_body<RTM>(g, M, mt, nt, sc_raw);
+    __syncthreads();  // the fold's LDS is re-used by the next tile
+  }
+}
+
 extern "C" int tg_debug_gru_trace(unsigned long long* out_host, int n_blocks) {
   return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_gru_trace), sizeof(unsigned long long) * 4 * n_blocks) == hipSuccess ? 0 : -4;
 }
@@ -1658,6 +1903,21 @@ int gru_launch(const GruArgs& g, hipStream_t st) {
     micro = cdiv(cdiv(rows, 32), 8) * NT <= 40;
   }
   static const int micro_knob = getenv("TG_GRU_MICRO") ? atoi(getenv("TG_GRU_MICRO")) : 1;  // tuning knob: 0 = off
+  {
+    // LDS-free blocks of 16 hidden columns x 16 .. 96 rows (k_gru_direct16 picks the rows per block from the live row
+    // count): whenever the caller's bound on the rows says that the 96-row blocks fit the chip at once.  Measured against
+    // the kernels below (d = 172): 380 rows 18.5 -> 11.3 us, 1 060 rows 19.9 -> 16.1 us; d = 100, 1 060 rows 14.7 -> 9.3 us
+    static const int d16_knob = getenv("TG_GRU_D16") ? atoi(getenv("TG_GRU_D16")) : 1;  // tuning knob: 0 = off, 3 = always
+    const int64_t rows_b = g.rows_hint > 0 ? std::min<int64_t>(g.rows_hint, g.cap) : g.cap;
+    const int NT16 = (g.d + 15) / 16;
+    if (force_nw == 0 && d16_knob && (d16_knob == 3 || cdiv(rows_b, 16 * GRU16_RT_MAX) * NT16 <= 256)) {
+      a.tail_blocks = 0;
+      const dim3 grid16((unsigned)std::min<int64_t>(256, 8 * cdiv(cdiv(g.cap, 16) * NT16, 8)));
+      if (cdiv(rows_b, 48) * NT16 <= 256) hipLaunchKernelGGL(k_gru_direct16<3>, grid16, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL(k_gru_direct16<GRU16_RT_MAX>, grid16, dim3(256), 0, st, a);
+      return check_launch("gru(16 x 16)");
+    }
+  }
   if (force_nw == 1 || (force_nw == 0 && micro && micro_knob)) {
     a.tail_blocks = 0;
     static const int direct_knob = getenv("TG_GRU_DIRECT") ? atoi(getenv("TG_GRU_DIRECT")) : 1;  // tuning knob: 0 = LDS-staged

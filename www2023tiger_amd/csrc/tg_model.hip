@@ -877,7 +877,7 @@ __global__ void k_ids32(int64_t n, const int64_t* __restrict__ ids, int32_t* __r
 // G rows of the nodes nids[0 .. min(cap, *n_dev)) into m->g_table: c = e(v) + nfeat(v) as the attention centres read it
 // (into `crows`, cap x d floats), then the same product the forward pass runs, scattered to the nodes' table rows
 int gtab_rows(const tg_model* m, int64_t cap, const int64_t* nids, const int32_t* rows32, const int32_t* n_dev, float* crows,
-              hipStream_t st, bool crows_ready, const CollateRider* collate, bool* rode) {
+              hipStream_t st, bool crows_ready, const CollateRider* collate, bool* rode, int64_t rows_hint) {
   if (rode) *rode = false;
   if (!m->g_table || !m->attn_fused || !m->pending_vals) return TG_EINVAL;
   if (m->row_of) return TG_EUNSUPPORTED;  // (rows32 are node ids)
@@ -887,7 +887,7 @@ int gtab_rows(const tg_model* m, int64_t cap, const int64_t* nids, const int32_t
     hipLaunchKernelGGL(k_attn_centres_direct, dim3(flat_grid(cap * (d / 4), 256)), dim3(256), 0, st, *m, cap, nids,
                        (const float4*)m->nfeats, (float4*)crows, DirectArgs{}, PosArgs{});
   GemmArgs g{};
-  g.m_cap = cap; g.m_dev = n_dev; g.n = f.nk; g.k = d; g.a0 = ASeg{crows, d, d, nullptr};
+  g.m_cap = cap; g.m_dev = n_dev; g.m_hint = rows_hint; g.n = f.nk; g.k = d; g.a0 = ASeg{crows, d, d, nullptr};
   g.w = f.wqk; g.ldw = d; g.bias = f.gconst; g.c = m->g_table; g.ldc = f.nk; g.c_rows = rows32; g.alpha = 1.f; g.nbatch = 1;
   return gemm_launch(g, st, nullptr, rode, collate);
 }
@@ -1108,7 +1108,8 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   // `prefetched`: the previous call did that for this batch (a repeated collate would be harmless, just wasted)
   static const int pf_knob = getenv("TG_PREFETCH") ? atoi(getenv("TG_PREFETCH")) : 1;
   w.prefetch = pf_knob != 0 && io->prefetch_state && io->stream_len > 0 && io->offset_dev && io->advance && io->ws_is_clean &&
-               w.lean && w.gtab && w.fused_wb && io->strategy == 0 && K <= 16 && !io->l1_nids && !io->l1_eids && !io->l1_ts;
+               w.lean && w.gtab && w.fused_wb && io->strategy == 0 && K <= 16 && !io->l1_nids && !io->l1_eids && !io->l1_ts &&
+               B <= 16384;  // (large batches: the last product's launch takes no riders - nothing to gain, see gemm_launch)
   const int pf_in = io->prefetch_state ? *io->prefetch_state : 0;
   const bool prefetched = w.prefetch && pf_in == 1;
   if (io->prefetch_state) *io->prefetch_state = 0;  // set again by the end of the step, once the rider is enqueued
@@ -1314,7 +1315,7 @@ int step_writeback_b(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, 
       co.stream_len = io->stream_len;
     }
     if ((rc = gtab_rows(m, 2 * io->B, w.upos, w.upos32, n_upos, w.attn.t, st, m->upd_fn == TG_UPD_GRU,
-                        w.prefetch ? &co : nullptr, &rode)) != TG_OK)
+                        w.prefetch ? &co : nullptr, &rode, io->rows_hint)) != TG_OK)
       return rc;
     if (w.prefetch && !rode) {  // this product's kernel does not host riders: the same work as a launch of its own
       collate_blocks_standalone(co);

@@ -81,7 +81,8 @@ struct StepWs {
 bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w, int n_layers = 1);
 int attn_dims_ok(const tg_model* m);
 int gtab_rows(const tg_model* m, int64_t cap, const int64_t* nids, const int32_t* rows32, const int32_t* n_dev, float* crows,
-              hipStream_t st, bool crows_ready, const CollateRider* collate = nullptr, bool* rode = nullptr);
+              hipStream_t st, bool crows_ready, const CollateRider* collate = nullptr, bool* rode = nullptr,
+              int64_t rows_hint = 0);
 // collate + STEP 1-3 (+ io->h_new); `gates` (nullable) receives the GRU gate activations
 // eager: take the outdated nodes' rows from m->pending_vals instead of running the updater (tg_stream_step only)
 int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, StepWs& w, float* gates, hipStream_t st,

@@ -19,6 +19,8 @@ import ctypes as C
 from typing import Tuple, Union
 
 import numpy as np
+import os
+
 import torch
 from torch import Tensor, nn
 
@@ -750,8 +752,10 @@ class TIGE(nn.Module):
         grows while the graph behind the stream fills up (C2: 3200 at batch 20, 4550 at batch 120), hence the
         generous margin; the bound follows the counts as they are read back."""
         if self._pending is not None:  # eager updates: the updater runs on the unique positive nodes of a batch
+            # (their count barely moves from batch to batch - C2: 1 040 .. 1 070 - and the updater kernels this selects
+            # size their blocks from the LIVE count: a batch above the bound costs that batch some speed, nothing else)
             seen = getattr(self, '_pos_seen', 0)
-            return int(1.25 * seen) + 32 if seen else 0
+            return int(1.03 * seen) + 1 if seen else 0
         seen = getattr(self, '_rows_seen', 0)
         return int(1.5 * seen) + 64 if seen else 0
 
@@ -799,6 +803,8 @@ class TIGE(nn.Module):
         pf = bool(buf.io.prefetch_state)
         if pf:  # is the collate part this buffer's previous step prefetched still the one this step needs?
             if buf._pf_state.value == 1 and buf._pf_stamp != self._prefetch_stamp(buf, g):
+                if os.environ.get('TG_PF_DEBUG'):
+                    print('prefetch discarded:', buf._pf_stamp, '->', self._prefetch_stamp(buf, g), flush=True)
                 buf._pf_state.value = 2  # made, but for another state / offset / graph: the step discards it
             before = buf._pf_state.value
         self._step_serial = getattr(self, '_step_serial', 0) + 1
