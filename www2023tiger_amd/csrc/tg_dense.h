@@ -7,6 +7,8 @@
 
 namespace tg {
 
+struct CollateRider;
+
 // one K-slice of the A operand: rows optionally gathered through `idx`
 struct ASeg {
   const float* p;
@@ -79,7 +81,6 @@ bool gemm_sk_partials(const GemmArgs& g, float* ws, size_t ws_floats, hipStream_
 // Riders (nullable, one at most): work that shares the launch as its FIRST workgroups - the one-pass write-back (WbRider,
 // tg_common.h) or the collate part of the next batch (CollateRider, tg_sample.h).  Not every kernel hosts them: *rode
 // tells the caller whether the rider was launched - otherwise the caller launches that work itself.
-struct CollateRider;
 int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider = nullptr, bool* rode = nullptr,
                 const CollateRider* collate = nullptr);
 

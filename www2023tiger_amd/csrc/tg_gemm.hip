@@ -19,6 +19,7 @@
 namespace tg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4m __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 1;
@@ -651,6 +652,135 @@ __global__ void __launch_bounds__(256) k_gemm_astat_r(GemmArgs g, int cpb, R r) 
   gemm_astat_block<NKT>(g, cpb, r.last ? blockIdx.x : blockIdx.x - r.blocks);
 }
 
+// ---- LDS-free blocks for short-K products with few rows ---------------------------------------------------------------
+// The query-row product of the eager step (G_v = c_v Wqk^T + gconst for the ~1 000 positive nodes of a C2 batch: K = d,
+// N = n_head (2d + d_e)) is 0.37 GFLOP - 3 us of the matrix pipe - but took 12.8 us as activation-stationary blocks: panel
+// through LDS, twelve weight tiles through the two-buffer pipeline, a barrier per tile.  With K this short a wavefront can
+// hold its WHOLE operands in registers: lane (i, kq) of a 16 x 16 x 4 MFMA loads the 16-byte chunks kq, kq + 4, kq + 8, ..
+// of row i - every chunk of a row exactly once over the four lane quarters - for each of its RW row sets and CW weight-row
+// sets, all loads issued back to back (ONE exposed memory latency per block), then NS x 4 x RW x CW MFMAs (step (s, j)
+// multiplies element j of chunk slot s on both operands: the sum over k does not care which k values share a step).  No
+// LDS, no barrier.  Four wavefronts per block own 2 x 2 wave tiles; a row tile's blocks run on one XCD (chunks of the tile
+// sequence, as k_gru_direct16); the grid is 256 persistent blocks sized for the live rows.  Plain epilogue (bias, alpha,
+// ReLU, scattered rows).
+template <int NS, int RW, int CW>
+__device__ __forceinline__ void gemm_direct_tile(const GemmArgs& g, int64_t M, int64_t m0, int n0) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int K = g.k, N = g.n;
+  const int nch = K / 4;  // 16-byte chunks per row
+  float4 a[RW][NS], w[CW][NS];
+  unsigned livem = 0u;    // bit s: chunk slot s of this lane quarter lies inside K
+#pragma unroll
+  for (int s_ = 0; s_ < NS; ++s_)
+    if (lk + 4 * s_ < nch) livem |= 1u << s_;
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int64_t m = min(m0 + 16 * r + li, M - 1);
+    const float* row = g.a0.p + (g.a0.idx ? g.a0.idx[m] : m) * g.a0.ld;
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) a[r][s_] = ldg4(row + 4 * min(lk + 4 * s_, nch - 1));
+  }
+#pragma unroll
+  for (int c = 0; c < CW; ++c) {
+    const float* row = g.w + (int64_t)min(n0 + 16 * c + li, N - 1) * g.ldw;
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) w[c][s_] = ldg4(row + 4 * min(lk + 4 * s_, nch - 1));
+  }
+  float bias[CW];
+  int crow[RW][4];
+  f32x4m acc[RW][CW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int c = 0; c < CW; ++c) acc[r][c] = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s_ = 0; s_ < NS; ++s_) {
+    if (s_ == NS / 2) {
+      // epilogue operands (bias of this lane's column in each column set, output rows): requested here, behind half of the
+      // MFMAs - early enough to arrive before the epilogue, late enough that the operand registers of the slots already
+      // consumed are free (requested with the operands they push the kernel past 256 registers: one block per CU)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < CW; ++c) bias[c] = g.bias ? g.bias[min(n0 + 16 * c + li, N - 1)] : 0.f;
+#pragma unroll
+      for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t m = min(m0 + 16 * r + 4 * lk + q, M - 1);
+          crow[r][q] = g.c_rows ? g.c_rows[m] : (int)m;
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const bool lv = (livem >> s_) & 1u;
+    float av[RW][4], wv[CW][4];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const float4 x = lv ? a[r][s_] : zero4();  // (a clamped chunk past K repeats the last one: it must not count twice)
+      av[r][0] = x.x; av[r][1] = x.y; av[r][2] = x.z; av[r][3] = x.w;
+    }
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      wv[c][0] = w[c][s_].x; wv[c][1] = w[c][s_].y; wv[c][2] = w[c][s_].z; wv[c][3] = w[c][s_].w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int c = 0; c < CW; ++c)
+          acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][j], wv[c][j], acc[r][c], 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      const int n = n0 + 16 * c + li;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t m = m0 + 16 * r + 4 * lk + q;
+        float x = g.alpha * (acc[r][c][q] + bias[c]);
+        if (g.relu) x = fmaxf(x, 0.f);
+        if (n < N && m < M) g.c[(int64_t)crow[r][q] * g.ldc + n] = x;
+      }
+    }
+}
+
+// block = 2 x 2 wavefronts of (16 RW) x (16 CW) wave tiles; `own` persistent blocks (riders, if any, sit behind them)
+template <int NS, int RW, int CW>
+__device__ __forceinline__ void gemm_direct_block(const GemmArgs& g, unsigned bid, unsigned own) {
+  int64_t M = g.m_cap;
+  if (g.m_dev) M = min(M, (int64_t)*g.m_dev);
+  if (M <= 0) return;
+  constexpr int BM = 32 * RW, BN = 32 * CW;
+  const int NT = (g.n + BN - 1) / BN;
+  const int64_t total = ((M + BM - 1) / BM) * NT;
+  const int64_t per = (total + 7) / 8;  // XCD x works through the chunk [x per, (x + 1) per) of the tile sequence
+  const int wave = threadIdx.x >> 6;
+  for (int64_t jx = bid >> 3; jx < per; jx += own >> 3) {
+    const int64_t b = (int64_t)(bid & 7) * per + jx;
+    if (b >= total) break;
+    const int64_t mt = b / NT;
+    const int nt = (int)(b - mt * NT);
+    const int64_t m0 = mt * BM + (wave >> 1) * (16 * RW);
+    const int n0 = nt * BN + (wave & 1) * (16 * CW);
+    if (m0 < M && n0 < g.n) gemm_direct_tile<NS, RW, CW>(g, M, m0, n0);
+  }
+}
+template <int NS, int RW, int CW>
+__global__ void __launch_bounds__(256) k_gemm_direct(GemmArgs g) {
+  gemm_direct_block<NS, RW, CW>(g, blockIdx.x, gridDim.x);
+}
+template <class R, int NS, int RW, int CW>
+__global__ void __launch_bounds__(256) k_gemm_direct_r(GemmArgs g, R r) {
+  const unsigned own = gridDim.x - r.blocks;  // riders behind the product's blocks
+  if (blockIdx.x >= own) {
+    r.run(blockIdx.x - own);
+    return;
+  }
+  gemm_direct_block<NS, RW, CW>(g, blockIdx.x, own);
+}
+
 // ---- stream-K for launches that cannot fill the chip --------------------------------------------------
 // A product with fewer 64x64 tiles than CUs and a long K (the merged value/out/fc1 product of the fused
 // attention: 144 tiles x 38 k-tiles on 256 CUs) leaves CUs idle for its whole duration.  Here the
@@ -776,6 +906,35 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
     }
     return check_launch("gemm(rb)");
   }
+  // short K and few (live) rows: whole operands in registers (see gemm_direct_tile).  Wave tiles of 32 x 32, or 32 x 48
+  // when that brings the blocks of the estimated live rows under the CU count
+  static const int dir_knob = getenv("TG_GEMM_DIRECT") ? atoi(getenv("TG_GEMM_DIRECT")) : 1;  // tuning knob: 0 = off
+  {
+    const int nsl = (int)cdiv(cdiv(g.k, 4), 4);  // chunk slots per lane quarter
+    const int64_t rows_e = g.m_hint > 0 ? std::min(g.m_hint, g.m_cap) : g.m_cap;
+    const bool plain_d = !g.ask_part && g.nbatch == 1 && !g.a1.p && !g.w_kmajor && !g.bias_rs && !g.bias2 && !g.row_valid &&
+                         !g.relu_mask && !g.accumulate && !g.c2 && g.a0.w == g.k && !rider;
+    if (dir_knob && plain_d && nsl <= 12 && cdiv(rows_e, 64) * cdiv(g.n, 64) <= 512) {
+      const bool wide = cdiv(rows_e, 64) * cdiv(g.n, 64) > 256 && nsl <= 11;  // (32 x 48 wave tiles: 5 x 44 operand registers)
+      const unsigned own = 256;
+      CollateRider co = collate ? *collate : CollateRider{};
+      if (collate) collate_blocks(co);
+      const dim3 gr(own + (collate ? co.blocks : 0u));
+#define TG_DIRECT(NS_)                                                                                                  \
+  do {                                                                                                                  \
+    if (collate && wide) hipLaunchKernelGGL((k_gemm_direct_r<CollateRider, NS_, 2, 3>), gr, dim3(256), 0, st, gd, co);  \
+    else if (collate) hipLaunchKernelGGL((k_gemm_direct_r<CollateRider, NS_, 2, 2>), gr, dim3(256), 0, st, gd, co);     \
+    else if (wide) hipLaunchKernelGGL((k_gemm_direct<NS_, 2, 3>), gr, dim3(256), 0, st, gd);                            \
+    else hipLaunchKernelGGL((k_gemm_direct<NS_, 2, 2>), gr, dim3(256), 0, st, gd);                                      \
+  } while (0)
+      if (nsl <= 7) TG_DIRECT(7);
+      else if (nsl <= 11) TG_DIRECT(11);
+      else hipLaunchKernelGGL((k_gemm_direct<12, 2, 2>), dim3(own), dim3(256), 0, st, gd);
+#undef TG_DIRECT
+      if (collate && nsl <= 11) *rode = true;
+      return check_launch("gemm(direct)");
+    }
+  }
   // short K, many column tiles, a launch of a few blocks per CU: activation-stationary blocks (see k_gemm_astat)
   static const int as_knob = getenv("TG_GEMM_ASTAT") ? atoi(getenv("TG_GEMM_ASTAT")) : 1;  // tuning knob: 0 = off, n = column tiles per block
   {
@@ -857,8 +1016,6 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
 // columns and accumulates four planes per column: r and z over K = [x | h], i_n over x
 // only, h_n over h only (no wasted MFMAs on the zero blocks of a packed [4d, 5d] weight).
 // ---------------------------------------------------------------------------------
-typedef float f32x4m __attribute__((ext_vector_type(4)));
-
 // The last hidden columns of the GRU when d is not a multiple of 32: a 16-column tile on
 // v_mfma_f32_16x16x4_f32 instead of a 32-column tile that is mostly padding (d = 172: 12 columns of 32).
 // One block owns 144 rows x 16 columns x 3 planes - three quarters of the MFMA work of a 96 x 32 block of
@@ -1912,6 +2069,8 @@ int gru_launch(const GruArgs& g, hipStream_t st) {
     const int NT16 = (g.d + 15) / 16;
     if (force_nw == 0 && d16_knob && (d16_knob == 3 || cdiv(rows_b, 16 * GRU16_RT_MAX) * NT16 <= 256)) {
       a.tail_blocks = 0;
+      // (the sampler riders of the collate prefetch were tried here too - the sampler reads the graph only - and cost the
+      // updater more than they saved the query-row launch: C2 updater +4.6 us, launch behind it -0.7 us; C4 +22 us)
       const dim3 grid16((unsigned)std::min<int64_t>(256, 8 * cdiv(cdiv(g.cap, 16) * NT16, 8)));
       if (cdiv(rows_b, 48) * NT16 <= 256) hipLaunchKernelGGL(k_gru_direct16<3>, grid16, dim3(256), 0, st, a);
       else hipLaunchKernelGGL(k_gru_direct16<GRU16_RT_MAX>, grid16, dim3(256), 0, st, a);

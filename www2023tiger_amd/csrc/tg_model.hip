@@ -1280,6 +1280,7 @@ int step_writeback_b(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, 
   WritebackArgs wa = writeback_args(m, io, w);
   prof_mark(pf, ST_WRITE_LEFT, st);
   int rc;
+  CollateRider co{};
   if (w.fused_wb) {
     wa.snap = w.snap;
     wa.snap_ts = w.snap_ts;
@@ -1299,6 +1300,12 @@ int step_writeback_b(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, 
     // (centre-row buffer of these launches: the block's fc1 output buffer, free since fc2 - NOT the centre rows of the
     // forward pass, which the prefetched centres of the next batch overwrite during the query-row launch)
     const bool cr = w.gtab && m->upd_fn == TG_UPD_GRU;
+    if (w.prefetch) {  // the next batch's collate part rides on the step's last launch (tg_sample.h: CollateRider)
+      co.s = SampleBatchArgs{*g, io->B, io->src, io->dst, io->neg, io->ts, io->eids, (const int64_t*)io->offset_dev,
+                             (int)m->n_neighbors, w.nids3, w.ts3f, w.eids, w.l1n, w.l1e, w.l1t, nullptr, nullptr};
+      co.cr = CentresRider{*m, (const float4*)m->nfeats, (float4*)w.attn.cc, w.da_args, w.pos_args, 0u};
+      co.stream_len = io->stream_len;
+    }
     if ((rc = apply_messages(m, w.upos, w.upos32, n_upos, P, m->pending_vals, io->err, w.apply_ws, w.apply_bytes, st,
                              true, nullptr, bound, cr ? w.attn.t : nullptr, cr ? m->nfeats : nullptr)) != TG_OK)
       return rc;
@@ -1306,14 +1313,7 @@ int step_writeback_b(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, 
   prof_mark(pf, ST_GTAB, st);
   if (w.gtab) {
     // ... and the query rows of the same nodes: their effective rows have just changed (tg_model.g_table)
-    CollateRider co{};
     bool rode = false;
-    if (w.prefetch) {  // the next batch's collate part rides on this launch (tg_sample.h: CollateRider)
-      co.s = SampleBatchArgs{*g, io->B, io->src, io->dst, io->neg, io->ts, io->eids, (const int64_t*)io->offset_dev,
-                             (int)m->n_neighbors, w.nids3, w.ts3f, w.eids, w.l1n, w.l1e, w.l1t, nullptr, nullptr};
-      co.cr = CentresRider{*m, (const float4*)m->nfeats, (float4*)w.attn.cc, w.da_args, w.pos_args, 0u};
-      co.stream_len = io->stream_len;
-    }
     if ((rc = gtab_rows(m, 2 * io->B, w.upos, w.upos32, n_upos, w.attn.t, st, m->upd_fn == TG_UPD_GRU,
                         w.prefetch ? &co : nullptr, &rode, io->rows_hint)) != TG_OK)
       return rc;
