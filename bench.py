@@ -258,11 +258,11 @@ def stage_work(cfg, U, O_, P, eager, fused, n_nodes, E, tile=False, gtab=False):
         # eager: every involved row is a live copy (pending-or-right row -> reprs); lazy: only rows without a pending message
         'gather_right_memory': (None, 2.0 * 4 * d * (U if eager else max(U - O_, 0)) + 12 * O_, 'tg::k_consume_gather_check'),
         'apply_messages(gru)': gru + ('tg::k_gru',),
-        'eager_updater(gru)': gru + ('tg::k_gru',),
+        'eager_updater(gru)': gru + ('tg::k_gru_direct16 / tg::k_gru_direct / tg::k_gru',),
         'attn_centres+qconst': (None, Q * 4 * d * (2 + fe), 'tg::k_attn_centres'),
         'attn_core(gather+softmax)': (None, U * 4 * d * (1 + fe) + Q * K * 4 * d_e * fe + 2.0 * Q * nk * 4 + Q * K * 20,
                                       'tg::k_attn_core'),
-        'attn_gemm_fc2': (2.0 * Q * d * d, Q * d * 8 + d * d * 4, 'tg::k_gemm'),
+        'attn_gemm_fc2': (2.0 * Q * d * d, Q * d * 8 + d * d * 4, 'tg::k_gemm_r / tg::k_gemm'),
         'writeback_phase0': (None, P * (4 * mw + 4) + P * 4 * d * 2 + 2 * B * 4 * d + B * 4 * d_e * fe, 'tg::k_writeback<0>'),
         'writeback_phase1': (None, 2 * P * (4 * d + 5) + n_nodes, 'tg::k_writeback<1>'),
     }
@@ -277,8 +277,9 @@ def stage_work(cfg, U, O_, P, eager, fused, n_nodes, E, tile=False, gtab=False):
     elif fused:
         w['attn_gemm_q'] = (2.0 * Q * nk * d, Q * d * 4 + Q * nk * 4 + nk * d * 4, 'tg::k_gemm')           # G = c Wqk^T + gconst
         if gtab:  # eager query rows: the product runs on the P positive nodes at the end of the step instead of on Q centres
-            w['eager_query_rows(G)'] = (2.0 * P * nk * d, P * d * 4 * (2 + fe) + P * nk * 4 + nk * d * 4, 'tg::k_gemm')
-        w['attn_gemm_fc1'] = (2.0 * Q * d * (nk + d), Q * (nk + d) * 4 + Q * d * 4 + d * (nk + d) * 4, 'tg::k_gemm_sk / k_gemm')
+            w['eager_query_rows(G)'] = (2.0 * P * nk * d, P * d * 4 * (2 + fe) + P * nk * 4 + nk * d * 4,
+                                        'tg::k_gemm_direct_r / tg::k_gemm_direct / tg::k_gemm_astat_r / tg::k_gemm_astat / tg::k_gemm_rb / tg::k_gemm')
+        w['attn_gemm_fc1'] = (2.0 * Q * d * (nk + d), Q * (nk + d) * 4 + Q * d * 4 + d * (nk + d) * 4, 'tg::k_gemm_sk / tg::k_gemm_rb / tg::k_gemm')
     else:
         w['attn_gemm_q'] = (2.0 * Q * 2 * d * d, Q * d * 4 + Q * 2 * d * 4, 'tg::k_gemm')
         w['attn_gemm_g'] = (2.0 * Q * kvw * 2 * d, Q * 2 * d * 4 + Q * nk * 4, 'tg::k_gemm')
@@ -307,9 +308,13 @@ def load_traffic(tag):
 
 
 def kernel_traffic(traffic, kname):
-    for k, v in traffic.items():  # template arguments vary with the shape: match on the kernel's base name
-        if k.split('<')[0] == kname.split('<')[0].split(' ')[0]:
-            return v.get('bytes_per_launch')
+    """kname: one device kernel, or candidates separated by ' / ' in order of preference (which of them a stage launches
+    depends on shape and form); template arguments vary with the shape: match on the kernel's base name"""
+    for cand in kname.split(' / '):
+        base = cand.strip().split('<')[0].split(' ')[0]
+        for k, v in traffic.items():
+            if k.split('<')[0] == base:
+                return v.get('bytes_per_launch')
     return None
 
 
@@ -450,6 +455,18 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
         empty |= {'attn_gemm_q'}
     else:
         empty |= {'eager_query_rows(G)'}
+    # riders: where they apply the step has no write-back launch (STEP 4-5 ride on fc2's launch, STEP 6's rows
+    # leave its epilogue) and no collate launch (sampler + centres of the NEXT batch ride on the query-row product's)
+    wb_rides = direct and fused and B <= 16384 and os.environ.get('TG_WB_RIDER', '1') != '0'
+    prefetch = bool(buf.io.prefetch_state) and lean and gtab and B <= 16384 and os.environ.get('TG_PREFETCH', '1') != '0'
+    if wb_rides and stage_ms[names.index('writeback_phase1')] < 0.5 * stage_ms[names.index('attn_gemm_fc2')]:
+        empty |= {'writeback_phase1'}
+    else:
+        wb_rides = False
+    if prefetch and stage_ms[names.index('sample_recent_edges')] < 0.5 * stage_ms[names.index('eager_query_rows(G)')]:
+        empty |= {'sample_recent_edges'}
+    else:
+        prefetch = False
     overhead = float(np.median([v for n, v in zip(names, stage_ms) if n in empty]))  # cost of an empty event pair
     stages = {n: float(v) for n, v in zip(names, stage_ms) if n not in empty}
     dom = max(stages, key=stages.get)
@@ -463,6 +480,10 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
                            query_rows=('eager: per-node table of folded queries, refreshed for the batch\'s positive nodes at the end of '
                                        'the step (tg_model.g_table)' if gtab else 'G product over the 3B centres of the batch'),
                            involved_set=('not formed (tg_step_io.lean: nothing in a direct-form eager step reads it)' if lean else 'formed (sorted unique ids + ranks)'),
+                           write_back=('rides on the launch of fc2 (STEP 4-5 as its extra workgroups, STEP 6 rows from its epilogue): '
+                                       'stage attn_gemm_fc2 includes it' if wb_rides else 'own launch'),
+                           collate=('sampler + centres of the NEXT batch ride on the query-row launch (tg_step_io.prefetch_state): '
+                                    'stage eager_query_rows(G) includes them; every replay runs exactly one collate' if prefetch else 'first launch of the step'),
                            state_preroll_batches=preroll, involved_per_batch=float(U),
                            involved_before_timed_region=[dict(batch=b, involved=u) for b, u in u_trace],
                            outdated_per_batch=float(O_),
