@@ -77,6 +77,10 @@ struct SkPlan {
 // Launches the piece kernel for `g` (bias / activation of g are NOT applied: the consumer applies them) and
 // returns true, or returns false (nothing launched) when the shape does not call for it.
 bool gemm_sk_partials(const GemmArgs& g, float* ws, size_t ws_floats, hipStream_t st, SkPlan* plan);
+// Launches the LDS-free K-split kernel for `g` (bias / activation applied: final values) and returns true, or returns
+// false (nothing launched) when the shape does not call for it (tg_gemm.hip: k_gemm_ks16).
+// rider (nullable): the write-back rider shares the launch (*rode tells whether)
+bool gemm_ks16_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider = nullptr, bool* rode = nullptr);
 
 // Riders (nullable, one at most): work that shares the launch as its FIRST workgroups - the one-pass write-back (WbRider,
 // tg_common.h) or the collate part of the next batch (CollateRider, tg_sample.h).  Not every kernel hosts them: *rode

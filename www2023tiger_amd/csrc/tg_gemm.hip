@@ -688,7 +688,8 @@ __device__ __forceinline__ void gemm_direct_tile(const GemmArgs& g, int64_t M, i
     for (int s_ = 0; s_ < NS; ++s_) w[c][s_] = ldg4(row + 4 * min(lk + 4 * s_, nch - 1));
   }
   float bias[CW];
-  int crow[RW][4];
+  int crow[RW][4], c2r[RW][4];
+  const bool two = g.c2 && m0 < g.c2_m;  // second destination (write-back rider: STEP 6's rows), wave-uniform
   f32x4m acc[RW][CW];
 #pragma unroll
   for (int r = 0; r < RW; ++r)
@@ -709,6 +710,7 @@ __device__ __forceinline__ void gemm_direct_tile(const GemmArgs& g, int64_t M, i
         for (int q = 0; q < 4; ++q) {
           const int64_t m = min(m0 + 16 * r + 4 * lk + q, M - 1);
           crow[r][q] = g.c_rows ? g.c_rows[m] : (int)m;
+          c2r[r][q] = two ? g.c2_rows[min(m, g.c2_m - 1)] : -1;
         }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -741,7 +743,10 @@ __device__ __forceinline__ void gemm_direct_tile(const GemmArgs& g, int64_t M, i
         const int64_t m = m0 + 16 * r + 4 * lk + q;
         float x = g.alpha * (acc[r][c][q] + bias[c]);
         if (g.relu) x = fmaxf(x, 0.f);
-        if (n < N && m < M) g.c[(int64_t)crow[r][q] * g.ldc + n] = x;
+        if (n < N && m < M) {
+          g.c[(int64_t)crow[r][q] * g.ldc + n] = x;
+          if (two && m < g.c2_m && c2r[r][q] >= 0) g.c2[(int64_t)c2r[r][q] * g.ldc2 + n] = x;
+        }
       }
     }
 }
@@ -779,6 +784,236 @@ __global__ void __launch_bounds__(256) k_gemm_direct_r(GemmArgs g, R r) {
     return;
   }
   gemm_direct_block<NS, RW, CW>(g, blockIdx.x, own);
+}
+
+// ---- LDS-free K-split blocks for long-K products with few tiles ------------------------------------------------------
+// The merged value / out / fc1 product of the fused attention (C2: M = 3 072, N = 172, K = 1 204) has 144 tiles of 64 x 64
+// for 256 CUs; as stream-K pieces (below) it fills the chip but leaves its result in two or three pieces per element for
+// the consumer to sum.  This is k_gru_direct16's scheme with one plane: a block owns (16 RT) x (16 CT) outputs - 48 x 48
+// makes 64 x 4 = 256 blocks of exactly that product - the 32-k tiles are dealt to NW wavefronts, lane (i, kq) of a
+// 16 x 16 x 4 MFMA feeds the matrix unit from the 32 contiguous bytes A[i][k0 + 8 kq ..] / W[j][k0 + 8 kq ..] it loads
+// itself (no LDS in the k-loop; A may be two column segments, rows optionally gathered), the wavefronts' accumulators meet
+// in one reduce-scatter round through LDS (summed in wavefront order: bit-reproducible) and the first four wavefronts
+// run the epilogue (bias, second bias on valid rows, alpha, ReLU) - the product leaves its final values, so its consumer
+// is a plain product.  256 persistent blocks, XCD chunks of the tile sequence.
+template <int RT, int CT, int NW>
+__device__ __forceinline__ void gemm_ks16_tile(const GemmArgs& g, int64_t M, int64_t m0, int n0, float* sc_raw) {
+  constexpr int NS = RT * CT;  // 16 x 16 subtiles of the block
+  float (*sc)[NW - 1][NS][64] = reinterpret_cast<float (*)[NW - 1][NS][64]>(sc_raw);  // [owner 0..3][slot][subtile][lane]
+  const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int K = g.k, N = g.n, kw0 = g.a0.w;
+  const float* ar0[RT];
+  const float* ar1[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int64_t m = min(m0 + 16 * rt + li, M - 1);
+    ar0[rt] = g.a0.p + (g.a0.idx ? g.a0.idx[m] : m) * g.a0.ld;
+    ar1[rt] = g.a1.p ? g.a1.p + (g.a1.idx ? g.a1.idx[m] : m) * g.a1.ld - kw0 : ar0[rt];
+  }
+  const float* wr[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) wr[ct] = g.w + (int64_t)min(n0 + 16 * ct + li, N - 1) * g.ldw;
+  const int nkt = (K + BK - 1) / BK;
+  const int n_my = ks < nkt ? (nkt - ks + NW - 1) / NW : 0;
+  struct Tile {
+    float4 a[RT][2], w[CT][2];
+  };
+  auto load_tile = [&](int i, Tile& T, unsigned& live) {  // raw loads from clamped addresses (see k_gru_direct)
+    const int t = ks + NW * max(0, min(i, n_my - 1));
+    const int kb = min(t, nkt - 1) * BK + 8 * lk;
+    live = 0u;
+    int kc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int k = kb + 4 * q;
+      if (k < K && ks < nkt) live |= 1u << q;
+      kc[q] = k < K ? k : 0;
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) T.a[rt][q] = ldg4((kc[q] < kw0 ? ar0[rt] : ar1[rt]) + kc[q]);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) T.w[ct][q] = ldg4(wr[ct] + kc[q]);
+  };
+  f32x4m acc[RT][CT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4m{0.f, 0.f, 0.f, 0.f};
+  auto mma_tile = [&](const Tile& T, unsigned live) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float av[RT][4], wv[CT][4];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const float4 a = ((live >> q) & 1u) ? T.a[rt][q] : zero4();
+        av[rt][0] = a.x; av[rt][1] = a.y; av[rt][2] = a.z; av[rt][3] = a.w;
+      }
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        wv[ct][0] = T.w[ct][q].x; wv[ct][1] = T.w[ct][q].y; wv[ct][2] = T.w[ct][q].z; wv[ct][3] = T.w[ct][q].w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][j], wv[ct][j], acc[rt][ct], 0, 0, 0);
+    }
+  };
+  // epilogue operands of the outputs wavefront ks < 4 finishes (accumulator register ks of every subtile: row 4 lk + ks),
+  // requested before the loop
+  float bias[CT], bias2[CT];
+  uint8_t v2[RT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int n = min(n0 + 16 * ct + li, N - 1);
+    bias[ct] = g.bias ? g.bias[n] : 0.f;
+    bias2[ct] = g.bias2 ? g.bias2[n] : 0.f;
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) v2[rt] = g.bias2 ? g.bias2_valid[min(m0 + 16 * rt + 4 * lk + (ks & 3), M - 1)] : 0;
+  Tile T0, T1;
+  unsigned l0 = 0u, l1 = 0u;
+  load_tile(0, T0, l0);
+  int i = 0;
+  for (; i + 2 <= n_my; i += 2) {  // request tile i + 1, THEN multiply tile i (order pinned, see k_gru_direct)
+    load_tile(i + 1, T1, l1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_tile(T0, l0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_tile(i + 2, T0, l0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_tile(T1, l1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (i < n_my) mma_tile(T0, l0);
+  // reduce-scatter: wavefront v < 4 finishes accumulator register v of every subtile; everybody parks the registers the
+  // others own (one round, one barrier); sums run in wavefront order 0 .. NW - 1
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    if (v != ks) {  // wave-uniform
+      const int slot = ks < v ? ks : ks - 1;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) sc[v][slot][rt * CT + ct][lane] = acc[rt][ct][v];
+    }
+  }
+  __syncthreads();
+  if (ks >= 4) return;
+  float o[RT][CT];
+#pragma unroll
+  for (int src = 0; src < NW; ++src) {
+    float t[RT][CT];
+    if (src == ks) {  // wave-uniform
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (v == ks) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) t[rt][ct] = acc[rt][ct][v];
+        }
+    } else {
+      const int slot = src < ks ? src : src - 1;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) t[rt][ct] = sc[ks][slot][rt * CT + ct][lane];
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) o[rt][ct] = src == 0 ? t[rt][ct] : o[rt][ct] + t[rt][ct];
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int64_t m = m0 + 16 * rt + 4 * lk + ks;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int n = n0 + 16 * ct + li;
+      float x = g.alpha * (o[rt][ct] + bias[ct] + (v2[rt] ? bias2[ct] : 0.f));
+      if (g.relu) x = fmaxf(x, 0.f);
+      if (n < N && m < M) g.c[m * g.ldc + n] = x;
+    }
+  }
+}
+
+template <class R, int RT, int CT, int NW>
+__global__ void __launch_bounds__(64 * NW) k_gemm_ks16(GemmArgs g, R r) {
+  __shared__ float sc_raw[4 * (NW - 1) * RT * CT * 64];
+  const unsigned own = gridDim.x - r.blocks;  // persistent blocks of the product; riders (if any) sit behind them
+  if (blockIdx.x >= own) {
+    r.run(blockIdx.x - own);
+    return;
+  }
+  int64_t M = g.m_cap;
+  if (g.m_dev) M = min(M, (int64_t)*g.m_dev);
+  if (M <= 0) return;
+  constexpr int BM = 16 * RT, BN = 16 * CT;
+  const int NT = (g.n + BN - 1) / BN;
+  const int64_t total = ((M + BM - 1) / BM) * NT;
+  const int64_t per = (total + 7) / 8;
+  for (int64_t jx = blockIdx.x >> 3; jx < per; jx += own >> 3) {
+    const int64_t b = (int64_t)(blockIdx.x & 7) * per + jx;
+    if (b >= total) break;
+    const int64_t mt = b / NT;
+    const int nt = (int)(b - mt * NT);
+    gemm_ks16_tile<RT, CT, NW>(g, M, mt * BM, nt * BN, sc_raw);
+    __syncthreads();  // the fold's LDS is re-used by the next tile
+  }
+}
+
+// Is the product one for k_gemm_ks16?  Long K, plain epilogue (+ second bias), few enough 48 x 48 tiles that the blocks
+// fit the chip in one round or two.  TG_GEMM_KS16: 0 = off, 8 = eight wavefronts per block.
+static unsigned rider_blocks(int64_t live, int threads, int64_t rows);  // (below, with gemm_launch)
+struct NoRider {  // (k_gemm_ks16 without riders)
+  unsigned blocks;
+  __device__ __forceinline__ void run(unsigned) const {}
+};
+bool gemm_ks16_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* rode) {
+  static const int knob = getenv("TG_GEMM_KS16") ? atoi(getenv("TG_GEMM_KS16")) : 1;
+  if (rode) *rode = false;
+  if (!knob || g.m_cap <= 0 || g.nbatch != 1 || g.w_kmajor || g.bias_rs || g.row_valid || g.relu_mask || g.c_rows || g.accumulate ||
+      g.c2 || g.ask_part || (g.k % 4) || (g.a0.w % 4) || (g.ldw % 4) || g.a0.w + (g.a1.p ? g.a1.w : 0) != g.k || g.k < 512)
+    return false;
+  const int64_t nt48 = cdiv(g.n, 48);
+  if (cdiv(g.m_cap, 48) * nt48 > 320) return false;
+  GemmArgs gd = g;
+  gd.dbg = 0;
+  // rows per block: the smallest of 16 / 32 / 48 whose blocks fit the chip at once (fewer rows = a shorter block)
+  const int rt = cdiv(g.m_cap, 16) * nt48 <= 256 ? 1 : cdiv(g.m_cap, 32) * nt48 <= 256 ? 2 : 3;
+  if (rider && rode && knob != 8) {
+    // the write-back rider (STEP 4-5 depend on nothing the attention block computes) on THIS launch, the longest of the
+    // block: its chain of dependent round trips (~9 us) hides behind the product instead of extending fc2's launch
+    // (C2: fc1 22.9 -> 25.8 us, fc2 + riders 16.8 -> 12.9 us; with the short blocks of a small batch fc2's launch hides the
+    // rider as well and fc1 only gets longer: C1 13.1 -> 14.5 us)
+    static const int here = getenv("TG_WB_RIDER_FC1") ? atoi(getenv("TG_WB_RIDER_FC1")) : 1;  // tuning knob: 0 = on fc2
+    if (here && rt == 3) {
+      WbRider wr = *rider;
+      const int64_t live = std::min<int64_t>(256, cdiv(g.m_cap, 16 * rt) * nt48);
+      wr.blocks = rider_blocks(live, 256, 2 * wr.a.B);
+      wr.last = 1u;
+      const dim3 gr(256 + wr.blocks);
+      if (rt == 1) hipLaunchKernelGGL((k_gemm_ks16<WbRider, 1, 3, 4>), gr, dim3(256), 0, st, gd, wr);
+      else if (rt == 2) hipLaunchKernelGGL((k_gemm_ks16<WbRider, 2, 3, 4>), gr, dim3(256), 0, st, gd, wr);
+      else hipLaunchKernelGGL((k_gemm_ks16<WbRider, 3, 3, 4>), gr, dim3(256), 0, st, gd, wr);
+      *rode = true;
+      return true;
+    }
+  }
+  const NoRider nr{0u};
+  if (knob == 8) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 3, 3, 8>), dim3(256), dim3(512), 0, st, gd, nr);
+  else if (rt == 1) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 1, 3, 4>), dim3(256), dim3(256), 0, st, gd, nr);
+  else if (rt == 2) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 2, 3, 4>), dim3(256), dim3(256), 0, st, gd, nr);
+  else hipLaunchKernelGGL((k_gemm_ks16<NoRider, 3, 3, 4>), dim3(256), dim3(256), 0, st, gd, nr);
+  return true;
 }
 
 // ---- stream-K for launches that cannot fill the chip --------------------------------------------------
@@ -853,7 +1088,7 @@ static int64_t live_blocks(const GemmArgs& g, int64_t grid, int bm) {
 // multiple of 8 (the product's XCD map stays)
 static unsigned rider_blocks(int64_t live, int threads, int64_t rows) {
   const int64_t want = cdiv(rows, (int64_t)(threads / 64));
-  const int64_t room = live <= 248 ? 256 - live : 512;
+  const int64_t room = live <= 248 ? (256 - live) * (threads <= 256 ? 2 : 1) : 512;  // (idle CUs host two 4-wave blocks)
   return (unsigned)std::max<int64_t>(8, std::min(want, room) & ~(int64_t)7);
 }
 // collate riders: the sampler is a chain of dependent memory round trips per query and wants many wavefronts (its own
@@ -876,6 +1111,8 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
   if (g.n <= 0 || g.k <= 0 || (g.k % 4) || (g.a0.w % 4) || (g.ldw % 4) || g.nbatch <= 0) return TG_EINVAL;
   if (g.w_kmajor && (g.n % 4)) return TG_EINVAL;
   if (g.a0.w + (g.a1.p ? g.a1.w : 0) != g.k) return TG_EINVAL;
+  // long K, few tiles: LDS-free K-split blocks (k_gemm_ks16)
+  if (!rider && !collate && !g.bias2 && gemm_ks16_launch(g, st)) return check_launch("gemm(ks16)");
   constexpr int BM = 64, BN = 64;
   const int64_t MT = cdiv(g.m_cap, BM);
   const int NT = (int)cdiv(g.n, BN);
@@ -913,17 +1150,28 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
     const int nsl = (int)cdiv(cdiv(g.k, 4), 4);  // chunk slots per lane quarter
     const int64_t rows_e = g.m_hint > 0 ? std::min(g.m_hint, g.m_cap) : g.m_cap;
     const bool plain_d = !g.ask_part && g.nbatch == 1 && !g.a1.p && !g.w_kmajor && !g.bias_rs && !g.bias2 && !g.row_valid &&
-                         !g.relu_mask && !g.accumulate && !g.c2 && g.a0.w == g.k && !rider;
+                         !g.relu_mask && !g.accumulate && (!g.c2 || !g.c_rows) && g.a0.w == g.k;
     if (dir_knob && plain_d && nsl <= 12 && cdiv(rows_e, 64) * cdiv(g.n, 64) <= 512) {
-      const bool wide = cdiv(rows_e, 64) * cdiv(g.n, 64) > 256 && nsl <= 11;  // (32 x 48 wave tiles: 5 x 44 operand registers)
+      const int64_t tiles64 = cdiv(rows_e, 64) * cdiv(g.n, 64);
+      const bool wide = tiles64 > 256 && nsl <= 11;  // (32 x 48 wave tiles: 5 x 44 operand registers)
       const unsigned own = 256;
-      CollateRider co = collate ? *collate : CollateRider{};
-      if (collate) collate_blocks(co);
-      const dim3 gr(own + (collate ? co.blocks : 0u));
+      const bool ride = nsl <= 11;  // (the K <= 192 instance hosts no riders)
+      CollateRider co = (collate && ride) ? *collate : CollateRider{};
+      WbRider wr = (rider && ride) ? *rider : WbRider{};
+      if (collate && ride) collate_blocks(co);
+      if (rider && ride) {
+        wr.blocks = rider_blocks(std::min<int64_t>(tiles64, 256), 256, 2 * wr.a.B);
+        wr.last = 1u;
+      } else {
+        no_ride();
+      }
+      const dim3 gr(own + co.blocks + wr.blocks);
 #define TG_DIRECT(NS_)                                                                                                  \
   do {                                                                                                                  \
-    if (collate && wide) hipLaunchKernelGGL((k_gemm_direct_r<CollateRider, NS_, 2, 3>), gr, dim3(256), 0, st, gd, co);  \
-    else if (collate) hipLaunchKernelGGL((k_gemm_direct_r<CollateRider, NS_, 2, 2>), gr, dim3(256), 0, st, gd, co);     \
+    if (wr.blocks && wide) hipLaunchKernelGGL((k_gemm_direct_r<WbRider, NS_, 2, 3>), gr, dim3(256), 0, st, gd, wr);      \
+    else if (wr.blocks) hipLaunchKernelGGL((k_gemm_direct_r<WbRider, NS_, 2, 2>), gr, dim3(256), 0, st, gd, wr);        \
+    else if (co.blocks && wide) hipLaunchKernelGGL((k_gemm_direct_r<CollateRider, NS_, 2, 3>), gr, dim3(256), 0, st, gd, co); \
+    else if (co.blocks) hipLaunchKernelGGL((k_gemm_direct_r<CollateRider, NS_, 2, 2>), gr, dim3(256), 0, st, gd, co);   \
     else if (wide) hipLaunchKernelGGL((k_gemm_direct<NS_, 2, 3>), gr, dim3(256), 0, st, gd);                            \
     else hipLaunchKernelGGL((k_gemm_direct<NS_, 2, 2>), gr, dim3(256), 0, st, gd);                                      \
   } while (0)
@@ -931,7 +1179,7 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
       else if (nsl <= 11) TG_DIRECT(11);
       else hipLaunchKernelGGL((k_gemm_direct<12, 2, 2>), dim3(own), dim3(256), 0, st, gd);
 #undef TG_DIRECT
-      if (collate && nsl <= 11) *rode = true;
+      if ((collate || rider) && ride) *rode = true;
       return check_launch("gemm(direct)");
     }
   }

@@ -551,9 +551,13 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
   g.c = w.t; g.ldc = d; g.relu = 1; g.alpha = 1.f; g.nbatch = 1;
   // C2-sized batches leave this product with fewer tiles than CUs: dealt as stream-K pieces, which fc2 sums
   // (+ b1 + valid * c1, ReLU) while it stages its A operand; otherwise the plain product writes t
+  // ... or, with few enough 48 x 48 tiles, LDS-free K-split blocks that leave t itself (k_gemm_ks16): fc2 is then a plain
+  // short-K product
   SkPlan sk{};
-  const bool pieces = gemm_sk_partials(g, w.sk, TG_SK_WS_FLOATS, st, &sk);
-  if (!pieces && (rc = gemm_launch(g, st)) != TG_OK) return rc;
+  bool wb_on_fc1 = false;  // the write-back rider on the fc1 launch: then fc2 only stores STEP 6's rows (c2)
+  const bool ks16 = gemm_ks16_launch(g, st, (wbr && pos && pos->win_row) ? wbr : nullptr, &wb_on_fc1);
+  const bool pieces = !ks16 && gemm_sk_partials(g, w.sk, TG_SK_WS_FLOATS, st, &sk);
+  if (!ks16 && !pieces && (rc = gemm_launch(g, st)) != TG_OK) return rc;
   prof_mark(pf, stage++, st);
   g = GemmArgs{};
   g.m_cap = Q; g.n = d; g.k = d;
@@ -570,7 +574,12 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
   } else {
     wbr = nullptr;
   }
-  if ((rc = gemm_launch(g, st, wbr, &rode)) != TG_OK) return rc;
+  if (wb_on_fc1) {  // ... or rode on fc1's already
+    if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+    rode = true;
+  } else if ((rc = gemm_launch(g, st, wbr, &rode)) != TG_OK) {
+    return rc;
+  }
   if (wb_rode) *wb_rode = rode;
   return check_launch("tg_temporal_attn_fwd(fused)");
 }
