@@ -156,7 +156,12 @@ def test_empty_inputs():
 @pytest.mark.parametrize('n,in_f,out_f', [(1, 8, 4), (37, 172, 344), (300, 516, 172), (129, 860, 516), (64, 64, 64),
                                           (140001, 44, 300),    # 1 094 x 5 blocks of 128 x 64: the register-blocked form, ragged edges
                                           # activation-stationary blocks (short K of 4 / 6 / 8 k-tiles, >= 8 column tiles), ragged edges
-                                          (500, 172, 1032), (70, 100, 600), (129, 256, 520)])
+                                          (500, 172, 1032), (70, 100, 600), (129, 256, 520),
+                                          # LDS-free short-K blocks (k_gemm_direct: K <= 192, chunk slots 7 / 11 / 12; wave
+                                          # tiles 32 x 32 and 32 x 48; rows / columns / K not multiples of the tile sizes)
+                                          (1060, 172, 1032), (3, 4, 5), (33, 20, 17), (1815, 100, 400), (257, 192, 70), (40, 180, 1000),
+                                          # LDS-free K-split blocks (k_gemm_ks16: K >= 512, 16 / 32 / 48-row blocks), ragged everything
+                                          (3072, 1204, 172), (600, 1204, 172), (1500, 516, 172), (47, 1028, 50), (100, 700, 9)])
 def test_linear_fwd_vs_torch(n, in_f, out_f):
     from www2023tiger_amd.model.dense import linear_forward
     torch.manual_seed(n)
@@ -173,7 +178,11 @@ def test_linear_fwd_vs_torch(n, in_f, out_f):
     # round, 128-row blocks otherwise; hidden widths with no partial tile (32, 160), a tail of 4 / 12 / 16 columns
     # (100, 44, 172, 176) and one above 16 (180: padded 32-column tile); row counts at tile and XCD-dealing edges
     (97, 32, 64), (96, 44, 128), (1000, 160, 640), (1153, 176, 256), (600, 180, 360), (4174, 172, 688),
-    (4400, 172, 688), (2305, 100, 400), (145, 12, 48)])
+    (4400, 172, 688), (2305, 100, 400), (145, 12, 48),
+    # 16-column blocks (k_gru_direct16): 16 / 32 / 48-row blocks (first instance) and 64 / 96-row blocks (second), row counts
+    # at the switch points of d = 172 (368 / 736 / 1104 / 1472 rows), one past the largest single round (two tiles per block)
+    (368, 172, 688), (369, 172, 688), (737, 172, 688), (1060, 172, 688), (1105, 172, 688), (1473, 172, 688), (2209, 172, 688),
+    (1815, 100, 300), (50, 256, 768)])
 def test_gru_fwd_vs_torch(n, d, xw):
     from www2023tiger_amd.model.dense import gru_forward
     torch.manual_seed(d)

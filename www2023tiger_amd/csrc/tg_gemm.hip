@@ -819,38 +819,44 @@ __device__ __forceinline__ void gemm_ks16_tile(const GemmArgs& g, int64_t M, int
   struct Tile {
     float4 a[RT][2], w[CT][2];
   };
-  auto load_tile = [&](int i, Tile& T, unsigned& live) {  // raw loads from clamped addresses (see k_gru_direct)
+  // raw loads from clamped addresses (see k_gru_direct), split in two: the addresses of a tile, then its 2 (RT + CT)
+  // loads one at a time - threaded between the MFMAs of the tile before (a burst of twelve loads in front of a tile's 72
+  // MFMAs holds the matrix pipe for the time it takes to issue them)
+  struct Addr {
+    int kc[2];
+    unsigned live;
+  };
+  auto tile_addr = [&](int i, Addr& A) {
     const int t = ks + NW * max(0, min(i, n_my - 1));
     const int kb = min(t, nkt - 1) * BK + 8 * lk;
-    live = 0u;
-    int kc[2];
+    A.live = 0u;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int k = kb + 4 * q;
-      if (k < K && ks < nkt) live |= 1u << q;
-      kc[q] = k < K ? k : 0;
+      if (k < K && ks < nkt) A.live |= 1u << q;
+      A.kc[q] = k < K ? k : 0;
     }
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) T.a[rt][q] = ldg4((kc[q] < kw0 ? ar0[rt] : ar1[rt]) + kc[q]);
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) T.w[ct][q] = ldg4(wr[ct] + kc[q]);
+  };
+  auto load_one = [&](int l, const Addr& A, Tile& T) {  // l = 0 .. 2 (RT + CT) - 1
+    const int q = l & 1, r = l >> 1;
+    if (r < RT) T.a[r][q] = ldg4((A.kc[q] < kw0 ? ar0[r] : ar1[r]) + A.kc[q]);
+    else T.w[r - RT][q] = ldg4(wr[r - RT] + A.kc[q]);
   };
   f32x4m acc[RT][CT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4m{0.f, 0.f, 0.f, 0.f};
-  auto mma_tile = [&](const Tile& T, unsigned live) {
+  constexpr int NL = 2 * (RT + CT), NM = 8 * RT * CT;  // loads / MFMAs per tile
+  // multiply tile T (live mask lv) and, threaded through it, request the next tile (addresses An) into Tn
+  auto mma_tile = [&](const Tile& T, unsigned lv, const Addr& An, Tile& Tn, bool prefetch) {
+    int mi = 0, li_ = 0;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       float av[RT][4], wv[CT][4];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        const float4 a = ((live >> q) & 1u) ? T.a[rt][q] : zero4();
+        const float4 a = ((lv >> q) & 1u) ? T.a[rt][q] : zero4();
         av[rt][0] = a.x; av[rt][1] = a.y; av[rt][2] = a.z; av[rt][3] = a.w;
       }
 #pragma unroll
@@ -862,8 +868,15 @@ __device__ __forceinline__ void gemm_ks16_tile(const GemmArgs& g, int64_t M, int
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
+          for (int rt = 0; rt < RT; ++rt) {
             acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][j], wv[ct][j], acc[rt][ct], 0, 0, 0);
+            ++mi;
+            if (prefetch && li_ < NL && mi * NL >= (li_ + 1) * NM / 2) {  // the loads ride in the first half of the tile
+              load_one(li_, An, Tn);
+              ++li_;
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
     }
   };
   // epilogue operands of the outputs wavefront ks < 4 finishes (accumulator register ks of every subtile: row 4 lk + ks),
@@ -878,21 +891,26 @@ __device__ __forceinline__ void gemm_ks16_tile(const GemmArgs& g, int64_t M, int
   }
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) v2[rt] = g.bias2 ? g.bias2_valid[min(m0 + 16 * rt + 4 * lk + (ks & 3), M - 1)] : 0;
+  // (ablations at C2's fc1 shape, 3 072 x 1 204 -> 172: loads alone 7.2 us, MFMAs alone 16.6 us, both 19.6 us - the block is
+  // bound by its four wavefronts' MFMA streams, 720 dependent-free MFMAs of 32 cycles each; a third register set, two
+  // tiles ahead, costs the second block per CU and is slower: 20.4 us)
   Tile T0, T1;
-  unsigned l0 = 0u, l1 = 0u;
-  load_tile(0, T0, l0);
+  Addr A0, A1;
+  tile_addr(0, A0);
+#pragma unroll
+  for (int l = 0; l < NL; ++l) load_one(l, A0, T0);
   int i = 0;
-  for (; i + 2 <= n_my; i += 2) {  // request tile i + 1, THEN multiply tile i (order pinned, see k_gru_direct)
-    load_tile(i + 1, T1, l1);
+  for (; i + 2 <= n_my; i += 2) {
+    tile_addr(i + 1, A1);
     __builtin_amdgcn_sched_barrier(0);
-    mma_tile(T0, l0);
+    mma_tile(T0, A0.live, A1, T1, true);
     __builtin_amdgcn_sched_barrier(0);
-    load_tile(i + 2, T0, l0);
+    tile_addr(i + 2, A0);
     __builtin_amdgcn_sched_barrier(0);
-    mma_tile(T1, l1);
+    mma_tile(T1, A1.live, A0, T0, true);
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (i < n_my) mma_tile(T0, l0);
+  if (i < n_my) mma_tile(T0, A0.live, A1, T1, false);
   // reduce-scatter: wavefront v < 4 finishes accumulator register v of every subtile; everybody parks the registers the
   // others own (one round, one barrier); sums run in wavefront order 0 .. NW - 1
 #pragma unroll
