@@ -1002,7 +1002,8 @@ bool gemm_ks16_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, b
       g.c2 || g.ask_part || (g.k % 4) || (g.a0.w % 4) || (g.ldw % 4) || g.a0.w + (g.a1.p ? g.a1.w : 0) != g.k || g.k < 512)
     return false;
   const int64_t nt48 = cdiv(g.n, 48);
-  if (cdiv(g.m_cap, 48) * nt48 > 320) return false;
+  static const int64_t max_tiles = getenv("TG_GEMM_KS16_TILES") ? atoi(getenv("TG_GEMM_KS16_TILES")) : 1100;  // tuning knob (measured, K = 1 204, N = 172: 6 144 rows 54.5 -> 37.1 us, 12 288 rows 78.2 -> 72.1 us, 24 576 rows 123 -> 129 us)
+  if (cdiv(g.m_cap, 48) * nt48 > max_tiles) return false;
   GemmArgs gd = g;
   gd.dbg = 0;
   // rows per block: the smallest of 16 / 32 / 48 whose blocks fit the chip at once (fewer rows = a shorter block)
