@@ -262,7 +262,7 @@ def stage_work(cfg, U, O_, P, eager, fused, n_nodes, E, tile=False, gtab=False):
         'attn_centres+qconst': (None, Q * 4 * d * (2 + fe), 'tg::k_attn_centres'),
         'attn_core(gather+softmax)': (None, U * 4 * d * (1 + fe) + Q * K * 4 * d_e * fe + 2.0 * Q * nk * 4 + Q * K * 20,
                                       'tg::k_attn_core'),
-        'attn_gemm_fc2': (2.0 * Q * d * d, Q * d * 8 + d * d * 4, 'tg::k_gemm_r / tg::k_gemm'),
+        'attn_gemm_fc2': (2.0 * Q * d * d, Q * d * 8 + d * d * 4, 'tg::k_gemm_direct_r / tg::k_gemm_direct / tg::k_gemm_r / tg::k_gemm'),
         'writeback_phase0': (None, P * (4 * mw + 4) + P * 4 * d * 2 + 2 * B * 4 * d + B * 4 * d_e * fe, 'tg::k_writeback<0>'),
         'writeback_phase1': (None, 2 * P * (4 * d + 5) + n_nodes, 'tg::k_writeback<1>'),
     }
@@ -279,7 +279,7 @@ def stage_work(cfg, U, O_, P, eager, fused, n_nodes, E, tile=False, gtab=False):
         if gtab:  # eager query rows: the product runs on the P positive nodes at the end of the step instead of on Q centres
             w['eager_query_rows(G)'] = (2.0 * P * nk * d, P * d * 4 * (2 + fe) + P * nk * 4 + nk * d * 4,
                                         'tg::k_gemm_direct_r / tg::k_gemm_direct / tg::k_gemm_astat_r / tg::k_gemm_astat / tg::k_gemm_rb / tg::k_gemm')
-        w['attn_gemm_fc1'] = (2.0 * Q * d * (nk + d), Q * (nk + d) * 4 + Q * d * 4 + d * (nk + d) * 4, 'tg::k_gemm_sk / tg::k_gemm_rb / tg::k_gemm')
+        w['attn_gemm_fc1'] = (2.0 * Q * d * (nk + d), Q * (nk + d) * 4 + Q * d * 4 + d * (nk + d) * 4, 'tg::k_gemm_ks16 / tg::k_gemm_sk / tg::k_gemm_rb / tg::k_gemm')
     else:
         w['attn_gemm_q'] = (2.0 * Q * 2 * d * d, Q * d * 4 + Q * 2 * d * 4, 'tg::k_gemm')
         w['attn_gemm_g'] = (2.0 * Q * kvw * 2 * d, Q * 2 * d * 4 + Q * nk * 4, 'tg::k_gemm')
@@ -480,8 +480,8 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
                            query_rows=('eager: per-node table of folded queries, refreshed for the batch\'s positive nodes at the end of '
                                        'the step (tg_model.g_table)' if gtab else 'G product over the 3B centres of the batch'),
                            involved_set=('not formed (tg_step_io.lean: nothing in a direct-form eager step reads it)' if lean else 'formed (sorted unique ids + ranks)'),
-                           write_back=('rides on the launch of fc2 (STEP 4-5 as its extra workgroups, STEP 6 rows from its epilogue): '
-                                       'stage attn_gemm_fc2 includes it' if wb_rides else 'own launch'),
+                           write_back=('rides on the launch of fc1 or fc2 (STEP 4-5 as extra workgroups, STEP 6 rows from the epilogue of '
+                                       'fc2): the stage times of the two products include it' if wb_rides else 'own launch'),
                            collate=('sampler + centres of the NEXT batch ride on the query-row launch (tg_step_io.prefetch_state): '
                                     'stage eager_query_rows(G) includes them; every replay runs exactly one collate' if prefetch else 'first launch of the step'),
                            state_preroll_batches=preroll, involved_per_batch=float(U),
