@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 5
+#define TG_ABI_VERSION 6
 
 /* status codes */
 #define TG_OK 0
@@ -250,6 +250,14 @@ typedef struct tg_model {
    * row lookup by node id.  Same arithmetic per row, so the same bits.  Honoured only by such steps (not with `lazy`,
    * `inner`, embed_only); contract as for pending_vals: rebuilt (all rows) when state or parameters change elsewhere. */
   float* g_table;
+  /* Optional, with g_table (NULL = off): CENTRE ROWS.  c_table [n_nodes, d] holds c_v = e(v) + nfeat(v) for every node -
+   * what the attention reads of a node both as a centre (the `c` segment of the merger's fc1, tiger.py:196-221 via
+   * temporal_agg_modules.py:48-50) and as the node part of a key row (temporal_agg_modules.py:52-66).  It changes exactly
+   * when g_table's row does and is kept the same way: the step's eager updater writes the rows of the batch's positive
+   * nodes (they are its outputs plus the node features), everything else rebuilds all rows (tg_attn_gtab_rows).  A step
+   * that uses the query-row table then gathers ONE row per neighbour for the node part of a key (no has-message test, no
+   * pending / right choice, no feature add) and forms no per-batch copy of the centre rows. */
+  float* c_table;
 } tg_model;
 
 /* Inference-time algebra on the attention weights (parameters only, no data):

@@ -51,7 +51,7 @@ class TgModel(C.Structure):
         ('upd_fc1', TgLinear), ('upd_fc2', TgLinear),
         ('attn_wq', vp), ('attn_wk', vp), ('attn_wv', vp), ('attn_b_in', vp),
         ('attn_out', TgLinear), ('attn_fc1', TgLinear), ('attn_fc2', TgLinear), ('attn_fused', vp),
-        ('pending_vals', vp), ('row_of', vp), ('g_table', vp),
+        ('pending_vals', vp), ('row_of', vp), ('g_table', vp), ('c_table', vp),
     ]
 
 
@@ -189,7 +189,7 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the library does not export the symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.tg_abi_version() != 5:
+    if lib.tg_abi_version() != 6:
         raise TigerHipError('libtiger_hip.so ABI version mismatch')
     return lib
 

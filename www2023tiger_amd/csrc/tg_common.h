@@ -358,7 +358,16 @@ __device__ __forceinline__ void centres_direct_body(const tg_model& m, int64_t Q
   const int d4 = m.d / 4;
   const float4* right = reinterpret_cast<const float4*>(m.right_vals);
   const float4* pend = reinterpret_cast<const float4*>(m.pending_vals);
-  const int64_t total = Q * d4;
+  // without a copy of the centre rows (out == nullptr) only the snapshot positions need their rows walked; the other
+  // centres keep their time-invariant check (one thread per centre, below)
+  const int64_t rows_full = out ? Q : min(Q, da.snap ? da.n_snap : (int64_t)0);
+  const int64_t total = rows_full * d4;
+  if (da.per_row_checks) {
+    for (int64_t i = rows_full + tid; i < Q; i += nth) {
+      const int64_t r = state_row(m, ids.id(i));
+      if (bm_test(m.has_msg, r)) check_msg_times(m, r, da.err);
+    }
+  }
   // U elements per thread in flight: with fewer threads than elements (the centres as riders of another launch) the
   // three dependent round trips per element (id -> has-message bit -> row) are paid once per U elements, not per element
   constexpr int U = 4;
@@ -381,20 +390,23 @@ __device__ __forceinline__ void centres_direct_body(const tg_model& m, int64_t Q
       pending[u] = bm_test(m.has_msg, r[u]);
     }
     float4 v[U], f[U], l[U];
+    // (out == nullptr - the centre rows live in a per-node table, tg_model.c_table: only the snapshot rows are read)
+    const bool left_snap = da.snap && m.msg_src == TG_SRC_LEFT;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      v[u] = (pending[u] ? pend : right)[r[u] * d4 + c[u]];
-      f[u] = nf ? nf[id[u] * d4 + c[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool snap_u = da.snap && i[u] < da.n_snap;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (out || (snap_u && !left_snap)) v[u] = (pending[u] ? pend : right)[r[u] * d4 + c[u]];
+      f[u] = (nf && (out || snap_u)) ? nf[id[u] * d4 + c[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
       l[u] = v[u];
-      if (da.snap && i[u] < da.n_snap && m.msg_src == TG_SRC_LEFT)
-        l[u] = reinterpret_cast<const float4*>(m.left_vals)[r[u] * d4 + c[u]];
+      if (snap_u && left_snap) l[u] = reinterpret_cast<const float4*>(m.left_vals)[r[u] * d4 + c[u]];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (!live[u]) continue;
       const int64_t t = t0 + u * nth;
       v[u].x += f[u].x; v[u].y += f[u].y; v[u].z += f[u].z; v[u].w += f[u].w;
-      out[t] = v[u];
+      if (out) out[t] = v[u];
       if (da.per_row_checks && c[u] == 0 && pending[u]) check_msg_times(m, r[u], da.err);
       if (da.snap && i[u] < da.n_snap) {
         if (m.msg_src == TG_SRC_LEFT) {

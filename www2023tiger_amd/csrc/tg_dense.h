@@ -104,6 +104,7 @@ struct GruArgs {
   // attention-centre form of its rows, h + node features, to the query-row product)
   float* out2;
   const float* add2;
+  int out2_by_row;          // out2 is a per-node table (tg_model.c_table): row m goes to its output row, not to row m
   int dbg;                  // diagnostic bits, 0 in production
   int64_t rows_hint;        // upper bound of live rows known on the host (0 = unknown), picks the tile height
   int tail_blocks;          // set by gru_launch: leading blocks that run the 16-column tail (k_gru<3, 4> only)

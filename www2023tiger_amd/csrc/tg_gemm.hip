@@ -1461,7 +1461,7 @@ __device__ __forceinline__ void gru_tail16(const GruArgs& g, int tb, int j0, flo
       const float ng = fast_tanh(acc_in[rt][r] + bin + rgate * hn);
       const float hv = (1.f - zgate) * ng + zgate * Hs[lr][li];
       g.out[(int64_t)orow_s[lr] * g.ldo + j] = hv;
-      if (g.out2) g.out2[m * (int64_t)d + j] = g.add2 ? hv + g.add2[(int64_t)orow_s[lr] * d + j] : hv;
+      if (g.out2) g.out2[(g.out2_by_row ? (int64_t)orow_s[lr] : m) * (int64_t)d + j] = g.add2 ? hv + g.add2[(int64_t)orow_s[lr] * d + j] : hv;
       if (g.gates) {
         float* gp = g.gates + m * 4 * (int64_t)d + j;
         gp[0] = rgate; gp[d] = zgate; gp[2 * d] = ng; gp[3 * d] = hn;
@@ -1709,7 +1709,7 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
     if (jok && m < M) {
       const float hv = (1.f - zg) * ng + zg * hold;
       g.out[orow * g.ldo + j] = hv;
-      if (g.out2) g.out2[m * (int64_t)d + j] = g.add2 ? hv + g.add2[orow * d + j] : hv;
+      if (g.out2) g.out2[(g.out2_by_row ? orow : m) * (int64_t)d + j] = g.add2 ? hv + g.add2[orow * d + j] : hv;
       if (g.gates) {
         float* gp = g.gates + m * 4 * (int64_t)d + j;
         gp[0] = rg; gp[d] = zg; gp[2 * d] = ng; gp[3 * d] = hn;
@@ -2023,7 +2023,7 @@ __global__ void __launch_bounds__(256) k_gru_direct(GruArgs g) {
     if (jok && m < M) {
       const float hv = (1.f - zg) * ng + zg * hold[q];
       g.out[orow[q] * g.ldo + j0 + fr] = hv;
-      if (g.out2) g.out2[m * (int64_t)d + j0 + fr] = hv + addv[q];
+      if (g.out2) g.out2[(g.out2_by_row ? orow[q] : m) * (int64_t)d + j0 + fr] = hv + addv[q];
       if (g.gates) {
         float* gp = g.gates + m * 4 * (int64_t)d + j0 + fr;
         gp[0] = rg; gp[d] = zg; gp[2 * d] = ng; gp[3 * d] = hn;
@@ -2245,7 +2245,7 @@ __device__ __forceinline__ void gru_direct16_body(const GruArgs& g, int64_t M, i
     if (jok && m < M) {
       const float hv = (1.f - zg) * ng + zg * hold[rt];
       g.out[orow[rt] * g.ldo + j0 + li] = hv;
-      if (g.out2) g.out2[m * (int64_t)d + j0 + li] = hv + addv[rt];
+      if (g.out2) g.out2[(g.out2_by_row ? orow[rt] : m) * (int64_t)d + j0 + li] = hv + addv[rt];
       if (g.gates) {
         float* gp = g.gates + m * 4 * (int64_t)d + j0 + li;
         gp[0] = rg; gp[d] = zg; gp[2 * d] = ng; gp[3 * d] = hn;

@@ -182,7 +182,9 @@ __device__ __forceinline__ RowVec<W> row_load_raw(const float* __restrict__ p) {
 //  * the softmax exponentials are v_exp_f32 (arguments <= 0; ~2 ulp).
 //  * FT = false: the model has neither a node-feature nor an edge-feature table (C4, C5): one gather per key instead of
 //    three, and twice as many keys in flight.
-template <int NH, int NV, int W, bool FT>
+// FS: feature streams gathered per key beside the node row - 2: node features + edge features, 1: edge features only
+// (no node table, or the node part of a key comes from tg_model.c_table, which has the features folded in), 0: none
+template <int NH, int NV, int W, int FS>
 __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const float* __restrict__ ts,
                                                    const int64_t* __restrict__ l1_nids,
                                                    const int64_t* __restrict__ l1_eids, const float* __restrict__ l1_ts,
@@ -191,7 +193,9 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
                                                    float* __restrict__ S, uint8_t* __restrict__ valid, DropCfg dc,
                                                    float* __restrict__ rsum, int direct, PosArgs pos,
                                                    const float* __restrict__ key_rows, const float* __restrict__ zl,
-                                                   const float* __restrict__ gtab, const int64_t* __restrict__ cnids) {
+                                                   const float* __restrict__ gtab, const int64_t* __restrict__ cnids,
+                                                   const float* __restrict__ ctab) {
+  constexpr bool FT = FS > 0;
   using V = RowVec<W>;
   const int lane = lane_id();
   // direct (eager updates): neighbour rows come from the state tables, row(v) = has_msg[v] ? pending[v] : right[v];
@@ -222,7 +226,7 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
     wmax = fmaxf(wmax, __shfl_xor(wmax, o, TG_WAVE));
     pmax = fmaxf(pmax, __shfl_xor(pmax, o, TG_WAVE));
   }
-  const bool feat = m.nfeats && !key_rows;
+  const bool feat = FS == 2 && m.nfeats && !key_rows && !ctab;
   const float fmask = feat ? 1.f : 0.f;
   const float emask = m.efeats ? 1.f : 0.f;  // no edge table: the edge segment of a key row is zeros (feature_getter.py:95-99)
   for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < Q; i += (int64_t)gridDim.x * 4) {
@@ -235,7 +239,9 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
       eid_l = l1_eids[i * K + lane];
       dt_l = ts[i] - l1_ts[i * K + lane];
       if (nb_l != 0) {
-        if (direct) {
+        if (ctab) {  // the node row comes from the per-node table: the has-message bit only feeds the invariant check
+          if (pos.chk_err && bm_test(m.has_msg, nb_l)) check_msg_times(m, nb_l, pos.chk_err);
+        } else if (direct) {
           const int64_t r = state_row(m, nb_l);
           u_l = (int)(2 * r + (bm_test(m.has_msg, r) ? 1 : 0));
           if (pos.chk_err && (u_l & 1)) check_msg_times(m, r, pos.chk_err);
@@ -249,6 +255,7 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
     // A padding key (id 0) addresses row 0 of every table, which exists; its rows are fetched and never used.
     const int kk = lane < K ? lane : 0;
     const float* pn_l = key_rows ? key_rows + (i * K + kk) * d
+                        : ctab   ? ctab + nb_l * d
                                  : (direct ? ((u_l & 1) ? m.pending_vals : m.right_vals) + (int64_t)(u_l >> 1) * d
                                            : reprs + (int64_t)u_l * d);
     const float* pf_l = feat ? m.nfeats + nb_l * d : pn_l;
@@ -278,21 +285,23 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
     // reduced in list order whatever PD is, so the result does not depend on it.
     // (measured: narrow rows, W = 2, gain from a fourth slot - C4 core 84 -> 78 us - and nothing from a fifth or sixth,
     // eight are slower; W = 4 is the same with three and four)
-    constexpr int PD = FT ? (NV == 1 ? (W == 2 ? 4 : 3) : 2) : (NV == 1 ? 6 : 3);
-    constexpr int PF = FT ? PD : 1;  // slots of the feature rows (none without tables)
-    V ya[PD][NV], yn[PF][NV], yb[PF][NV];
+    constexpr int PD = FS == 2 ? (NV == 1 ? (W == 2 ? 4 : 3) : 2) : FS == 1 ? (NV == 1 ? 4 : 2) : (NV == 1 ? 6 : 3);
+    constexpr int PF = FT ? PD : 1;       // slots of the edge-feature rows (none without tables)
+    constexpr int PN = FS == 2 ? PD : 1;  // ... of the node-feature rows
+    V ya[PD][NV], yn[PN][NV], yb[PF][NV];
     auto fetch = [&](int slot, int k) {
       const float* pn = bcast_ptr(pn_l, k);
 #pragma unroll
       for (int v = 0; v < NV; ++v) ya[slot][v] = row_load_raw<W>(pn + coff[v]);
-      if (FT) {
+      if (FS == 2) {
         const float* pf = bcast_ptr(pf_l, k);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) yn[slot][v] = row_load_raw<W>(pf + coff[v]);
+      }
+      if (FT) {
         const float* pe = bcast_ptr(pe_l, k);
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-          yn[slot][v] = row_load_raw<W>(pf + coff[v]);
-          yb[slot][v] = row_load_raw<W>(pe + eoff[v]);
-        }
+        for (int v = 0; v < NV; ++v) yb[slot][v] = row_load_raw<W>(pe + eoff[v]);
       }
     };
     auto reduce = [&](int slot, int k) {
@@ -305,7 +314,7 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
         const int c = (lane + v * TG_WAVE) * W;
 #pragma unroll
         for (int j = 0; j < W; ++j) {
-          x[0][v].a[j] = FT ? fmaf(fmask, yn[slot][v].a[j], ya[slot][v].a[j]) : ya[slot][v].a[j];
+          x[0][v].a[j] = FS == 2 ? fmaf(fmask, yn[slot][v].a[j], ya[slot][v].a[j]) : ya[slot][v].a[j];
           x[1][v].a[j] = FT ? emask * yb[slot][v].a[j] : 0.f;
         }
         if (small) {
@@ -451,7 +460,8 @@ int attn_tile_launch(const tg_model* m, int64_t Q, const float* cc, const float*
 void launch_attn_core(const tg_model* m, int64_t Q, const float* ts, const int64_t* l1_nids, const int64_t* l1_eids,
                       const float* l1_ts, const float* reprs, const uint64_t* bm, const uint32_t* rank, const AttnWs& w,
                       const DropCfg& dc, hipStream_t st, int* rc_out, int direct = 0, const PosArgs* pos = nullptr,
-                      const float* key_rows = nullptr, const float* gtab = nullptr, const int64_t* cnids = nullptr) {
+                      const float* key_rows = nullptr, const float* gtab = nullptr, const int64_t* cnids = nullptr,
+                      const float* ctab = nullptr) {
   const int d = m->d, d_e = m->d_e, nh = m->n_head;
   *rc_out = TG_OK;
   // Columns per lane: float4 (three columns per lane fill 58 of 64 lanes at d = 172 instead of 43 but measured SLOWER,
@@ -467,17 +477,18 @@ void launch_attn_core(const tg_model* m, int64_t Q, const float* ts, const int64
   const unsigned cgrid = flat_grid(Q, 4);
   const float* zl = zero_line();
   if (!zl) { *rc_out = TG_EHIP; return; }
-  const bool ft = (m->nfeats && !key_rows) || m->efeats;
-#define TG_CORE(NH_, NV_, W_)                                                                                              \
-  do {                                                                                                                     \
-    if (ft)                                                                                                                \
-      hipLaunchKernelGGL((k_attn_core<NH_, NV_, W_, true>), dim3(cgrid), dim3(256), 0, st, *m, Q, ts, l1_nids, l1_eids,    \
-                         l1_ts, reprs, bm, rank, (const float*)w.g, w.s, w.valid, dc,                                      \
-                         dc.p > 0.f ? w.rsum : (float*)nullptr, direct, pos ? *pos : PosArgs{}, key_rows, zl, gtab, cnids); \
-    else                                                                                                                   \
-      hipLaunchKernelGGL((k_attn_core<NH_, NV_, W_, false>), dim3(cgrid), dim3(256), 0, st, *m, Q, ts, l1_nids, l1_eids,   \
-                         l1_ts, reprs, bm, rank, (const float*)w.g, w.s, w.valid, dc,                                      \
-                         dc.p > 0.f ? w.rsum : (float*)nullptr, direct, pos ? *pos : PosArgs{}, key_rows, zl, gtab, cnids); \
+  // feature streams per key: node + edge tables (2), the edge table alone - no node table, or the node rows come from the
+  // per-node table of centre rows with the features folded in (1) - or none (0)
+  const int fs = (m->nfeats && !key_rows && !ctab) ? 2 : (m->efeats ? 1 : 0);
+#define TG_CORE_FS(NH_, NV_, W_, FS_)                                                                                      \
+  hipLaunchKernelGGL((k_attn_core<NH_, NV_, W_, FS_>), dim3(cgrid), dim3(256), 0, st, *m, Q, ts, l1_nids, l1_eids, l1_ts,  \
+                     reprs, bm, rank, (const float*)w.g, w.s, w.valid, dc, dc.p > 0.f ? w.rsum : (float*)nullptr, direct,  \
+                     pos ? *pos : PosArgs{}, key_rows, zl, gtab, cnids, ctab)
+#define TG_CORE(NH_, NV_, W_)                  \
+  do {                                         \
+    if (fs == 2) TG_CORE_FS(NH_, NV_, W_, 2);  \
+    else if (fs == 1) TG_CORE_FS(NH_, NV_, W_, 1); \
+    else TG_CORE_FS(NH_, NV_, W_, 0);          \
   } while (0)
   if (nh == 2 && nv == 1 && W == 2) TG_CORE(2, 1, 2);
   else if (nh == 1 && nv == 1 && W == 2) TG_CORE(1, 1, 2);
@@ -487,6 +498,7 @@ void launch_attn_core(const tg_model* m, int64_t Q, const float* ts, const int64
   else if (nh == 1 && nv == 1) TG_CORE(1, 1, 4);
   else if (nh == 4 && nv == 1) TG_CORE(4, 1, 4);
   else *rc_out = TG_EUNSUPPORTED;
+#undef TG_CORE_FS
 #undef TG_CORE
 }
 
@@ -538,7 +550,7 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
   tg_model mc = *m;  // without an edge table the fused weights are compact: the key rows have no edge segment
   if (!m->efeats) mc.d_e = 0;
   launch_attn_core(&mc, Q, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, w, DropCfg{}, st, &rc, da ? 1 : 0, da ? pos : nullptr,
-                   key_rows, use_gtab ? m->g_table : nullptr, nids);
+                   key_rows, use_gtab ? m->g_table : nullptr, nids, (use_gtab && da) ? m->c_table : nullptr);
   if (rc != TG_OK) return rc;
   prof_mark(pf, stage++, st);
   prof_mark(pf, stage++, st);
@@ -546,7 +558,8 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
   prof_mark(pf, stage++, st);
   g = GemmArgs{};
   g.m_cap = Q; g.n = d; g.k = f.nk + d;
-  g.a0 = ASeg{w.s, f.nk, f.nk, nullptr}; g.a1 = ASeg{w.cc, d, d, nullptr};
+  g.a0 = ASeg{w.s, f.nk, f.nk, nullptr};
+  g.a1 = (use_gtab && m->c_table) ? ASeg{m->c_table, d, d, nids} : ASeg{w.cc, d, d, nullptr};  // centre rows: table or copy
   g.w = f.w1f; g.ldw = f.nk + d; g.bias = f.b1; g.bias2 = f.c1; g.bias2_valid = w.valid;
   g.c = w.t; g.ldc = d; g.relu = 1; g.alpha = 1.f; g.nbatch = 1;
   // C2-sized batches leave this product with fewer tiles than CUs: dealt as stream-K pieces, which fc2 sums
@@ -691,7 +704,7 @@ static size_t apply_ws_bytes(const tg_model* m, int64_t cap) {
 int apply_messages(const tg_model* m, const int64_t* outdated, const int32_t* out_pos, const int32_t* n_dev,
                    int64_t cap, float* reprs, uint32_t* err, void* ws, size_t ws_bytes, hipStream_t st,
                    bool checked_already = false, float* gates = nullptr, int64_t rows_bound = 0, float* out2 = nullptr,
-                   const float* add2 = nullptr) {
+                   const float* add2 = nullptr, bool out2_by_row = false) {
   const int d = m->d, mw = 3 * m->d + m->d_e;
   Carver cv(ws, ws_bytes);
   ApplyWs w{};
@@ -726,6 +739,7 @@ int apply_messages(const tg_model* m, const int64_t* outdated, const int32_t* ou
     a.cap = cap; a.n_dev = n_dev; a.d = d; a.xw = mw; a.x = x; a.h = h;
     a.w_ih = m->gru_w_ih; a.w_hh = m->gru_w_hh; a.b_ih = m->gru_b_ih; a.b_hh = m->gru_b_hh;
     a.out = reprs; a.ldo = d; a.out_rows = out_pos; a.gates = gates; a.out2 = out2; a.add2 = add2;
+    a.out2_by_row = out2_by_row ? 1 : 0;
     if (!m->efeats && m->tsfm == TG_TSFM_ID) {
       // raw mailbox rows [own | other | edge | time] without an edge table: the edge segment [2d, 2d + d_e) is zeros
       // (memory.py:91 over feature_getter.py:95-99); the k-tiles that lie entirely inside it are skipped
@@ -885,6 +899,18 @@ __global__ void k_ids32(int64_t n, const int64_t* __restrict__ ids, int32_t* __r
 }
 // G rows of the nodes nids[0 .. min(cap, *n_dev)) into m->g_table: c = e(v) + nfeat(v) as the attention centres read it
 // (into `crows`, cap x d floats), then the same product the forward pass runs, scattered to the nodes' table rows
+// rows of a compact [n, d] buffer -> rows ids[i] of a table (the centre rows of a rebuild into tg_model.c_table)
+__global__ void __launch_bounds__(256) k_scatter_rows(int64_t cap, const int32_t* __restrict__ n_dev, int d4,
+                                                      const int64_t* __restrict__ ids, const float4* __restrict__ rows,
+                                                      float4* __restrict__ table) {
+  const int64_t n = n_dev ? min((int64_t)*n_dev, cap) : cap;
+  const int64_t total = n * d4;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / d4;
+    table[ids[i] * d4 + (t - i * d4)] = rows[t];
+  }
+}
+
 int gtab_rows(const tg_model* m, int64_t cap, const int64_t* nids, const int32_t* rows32, const int32_t* n_dev, float* crows,
               hipStream_t st, bool crows_ready, const CollateRider* collate, bool* rode, int64_t rows_hint) {
   if (rode) *rode = false;
@@ -892,11 +918,17 @@ int gtab_rows(const tg_model* m, int64_t cap, const int64_t* nids, const int32_t
   if (m->row_of) return TG_EUNSUPPORTED;  // (rows32 are node ids)
   const int d = m->d;
   const FusedView f = fused_view(m, m->attn_fused);
-  if (!crows_ready)  // (the GRU updater writes these rows itself, GruArgs.out2)
+  if (!crows_ready) {  // (the GRU updater writes these rows itself, GruArgs.out2 - into the per-node table when there is one)
     hipLaunchKernelGGL(k_attn_centres_direct, dim3(flat_grid(cap * (d / 4), 256)), dim3(256), 0, st, *m, cap, nids,
                        (const float4*)m->nfeats, (float4*)crows, DirectArgs{}, PosArgs{});
+    if (m->c_table)
+      hipLaunchKernelGGL(k_scatter_rows, dim3(flat_grid(cap * (d / 4), 256)), dim3(256), 0, st, cap, n_dev, d / 4, nids,
+                         (const float4*)crows, (float4*)m->c_table);
+  }
   GemmArgs g{};
-  g.m_cap = cap; g.m_dev = n_dev; g.m_hint = rows_hint; g.n = f.nk; g.k = d; g.a0 = ASeg{crows, d, d, nullptr};
+  g.m_cap = cap; g.m_dev = n_dev; g.m_hint = rows_hint; g.n = f.nk; g.k = d;
+  // the centre rows: this launch's compact copy, or - gathered by node id - the rows of the per-node table
+  g.a0 = m->c_table ? ASeg{m->c_table, d, d, nids} : ASeg{crows, d, d, nullptr};
   g.w = f.wqk; g.ldw = d; g.bias = f.gconst; g.c = m->g_table; g.ldc = f.nk; g.c_rows = rows32; g.alpha = 1.f; g.nbatch = 1;
   return gemm_launch(g, st, nullptr, rode, collate);
 }
@@ -1133,8 +1165,11 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   const DirectArgs da{w.lean ? nullptr : w.outdated, w.counts + 1, cap, io->err, w.fused_wb ? (float4*)w.snap : nullptr,
                       w.snap_ts, 2 * B, w.lean ? 1 : 0};
   // lean: the centres need nothing the sampler produces and share its launch
-  const CentresRider rider{*m, (const float4*)m->nfeats, (float4*)w.attn.cc, da, pp ? pos : PosArgs{},
-                           flat_grid(Q * (m->d / 4), 256)};
+  // (with the per-node table of centre rows - tg_model.c_table, a step that uses the query-row table - no per-batch copy
+  // of the centre rows is made: the centres pass keeps its checks, the first dedup pass and the snapshot)
+  const bool ctab = w.gtab && m->c_table;
+  const CentresRider rider{*m, (const float4*)m->nfeats, ctab ? (float4*)nullptr : (float4*)w.attn.cc, da, pp ? pos : PosArgs{},
+                           flat_grid((ctab ? 2 * B : Q) * (m->d / 4), 256)};
   w.pos_args = pp ? pos : PosArgs{};
   w.da_args = da;
   const bool recent_nodes = io->strategy == 1;
@@ -1312,11 +1347,14 @@ int step_writeback_b(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, 
     if (w.prefetch) {  // the next batch's collate part rides on the step's last launch (tg_sample.h: CollateRider)
       co.s = SampleBatchArgs{*g, io->B, io->src, io->dst, io->neg, io->ts, io->eids, (const int64_t*)io->offset_dev,
                              (int)m->n_neighbors, w.nids3, w.ts3f, w.eids, w.l1n, w.l1e, w.l1t, nullptr, nullptr};
-      co.cr = CentresRider{*m, (const float4*)m->nfeats, (float4*)w.attn.cc, w.da_args, w.pos_args, 0u};
+      co.cr = CentresRider{*m, (const float4*)m->nfeats, m->c_table ? (float4*)nullptr : (float4*)w.attn.cc, w.da_args,
+                           w.pos_args, 0u};
       co.stream_len = io->stream_len;
     }
+    const bool ctab = cr && m->c_table;  // ... or straight into the per-node table of centre rows
     if ((rc = apply_messages(m, w.upos, w.upos32, n_upos, P, m->pending_vals, io->err, w.apply_ws, w.apply_bytes, st,
-                             true, nullptr, bound, cr ? w.attn.t : nullptr, cr ? m->nfeats : nullptr)) != TG_OK)
+                             true, nullptr, bound, cr ? (ctab ? m->c_table : w.attn.t) : nullptr, cr ? m->nfeats : nullptr,
+                             ctab)) != TG_OK)
       return rc;
   }
   prof_mark(pf, ST_GTAB, st);

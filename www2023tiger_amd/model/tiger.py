@@ -148,6 +148,7 @@ class TIGE(nn.Module):
         eager, fused = self._pending is not None, self._fused is not None
         self._plists = None
         self._gtab = None
+        self._ctab = None
         self._gtab_stamp = None
         self._struct_cache = None
         self._fused = None
@@ -230,7 +231,8 @@ class TIGE(nn.Module):
                     ptr(self._fused) if self._fused is not None else None,
                     ptr(self._pending) if self._pending is not None else None,
                     ptr(self._row_of) if getattr(self, '_row_of', None) is not None else None,
-                    ptr(self._gtab) if getattr(self, '_gtab', None) is not None else None)
+                    ptr(self._gtab) if getattr(self, '_gtab', None) is not None else None,
+                    ptr(self._ctab) if getattr(self, '_ctab', None) is not None else None)
         self._struct_cache = m
         return m
 
@@ -290,6 +292,7 @@ class TIGE(nn.Module):
             self._pending = torch.zeros(n_rows, self.memory_dim, dtype=torch.float32, device=dev)
             self._pending[rows] = oldP[keep]
         self._gtab = None
+        self._ctab = None
         self._struct_cache = None
         self._pending_stamp = None
         self._touch()
@@ -312,6 +315,7 @@ class TIGE(nn.Module):
         if not self._gtab_wanted():
             if getattr(self, '_gtab', None) is not None:
                 self._gtab = None
+                self._ctab = None
                 self._struct_cache = None
             return
         stamp = (self._state_stamp(), tuple(self._attn_stamp()), id(self._fused))
@@ -323,6 +327,9 @@ class TIGE(nn.Module):
         nk = self.n_head * (2 * self.memory_dim + (self.efeat_dim if self.raw_feat_getter.efeats is not None else 0))
         if getattr(self, '_gtab', None) is None or self._gtab.shape != (n, nk):
             self._gtab = torch.empty(n, nk, dtype=torch.float32, device=dev)
+            # ... and the centre rows c_v = e(v) + nfeat(v) beside them (tg_model.c_table; TG_CTAB=0: without)
+            self._ctab = (torch.empty(n, self.memory_dim, dtype=torch.float32, device=dev)
+                          if os.environ.get('TG_CTAB', '1') != '0' else None)
             self._struct_cache = None
         m = self.model_struct()
         chunk = 262144
