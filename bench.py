@@ -318,20 +318,27 @@ def kernel_traffic(traffic, kname):
     return None
 
 
-def roofline_of(name, ms, work, traffic):
+def roofline_of(name, ms, work, traffic, overhead=0.0):
+    """ms: HIP-event interval around the stage's launch; overhead: what an EMPTY interval of the same pass measures (the
+    event pair itself, ~5 us on this stack) - the launch duration is the difference, which is what the rocprofv3 average
+    of the kernel agrees with (profiles/); both are reported"""
     flops, nbytes, kname = work.get(name, (None, None, name))
+    raw_ms = float(ms)
+    ms = max(raw_ms - overhead, 0.25 * raw_ms)
     t_s = ms * 1e-3
     tr = kernel_traffic(traffic, kname)
     if flops:
         ach = flops / t_s / 1e12
         return dict(bound='mfma', kernel=name, device_kernel=kname, achieved=ach, peak=MFMA_F32_PEAK_TFLOPS,
                     unit='TFLOP/s', frac=ach / MFMA_F32_PEAK_TFLOPS, traffic=tr, avg_ms=float(ms),
+                    avg_ms_event_interval=raw_ms, event_pair_ms=float(overhead),
                     algorithmic_flops=float(flops), algorithmic_bytes=float(nbytes),
                     hbm_gbs=nbytes / t_s / 1e9, hbm_frac=nbytes / t_s / 1e9 / HBM_PEAK_GBS)
     if nbytes:
         ach = nbytes / t_s / 1e9
         return dict(bound='hbm', kernel=name, device_kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s',
-                    frac=ach / HBM_PEAK_GBS, traffic=tr, avg_ms=float(ms), algorithmic_bytes=float(nbytes))
+                    frac=ach / HBM_PEAK_GBS, traffic=tr, avg_ms=float(ms), avg_ms_event_interval=raw_ms,
+                    event_pair_ms=float(overhead), algorithmic_bytes=float(nbytes))
     return dict(bound='hbm', kernel=name, achieved=None, peak=HBM_PEAK_GBS, unit='GB/s', frac=None, traffic=tr,
                 avg_ms=float(ms))
 
@@ -375,7 +382,7 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     # lean step (tg_step_io.lean): the benchmark reads neither the involved set nor its size, so a direct-form eager step
     # does not form it (the library ignores the flag everywhere else, e.g. with the in-step lazy restart of C3)
     direct = eager and os.environ.get('TG_EAGER_DIRECT', '1') != '0' and not args.eager_copy  # no compact copy
-    lean = direct and not args.no_lean and restart_prob == 0
+    lean = direct and not args.no_lean  # (with the in-step restart loop of C3: the flags are marked, no sorted set is formed)
     buf.io.lean = 1 if lean else 0
 
     # ---- untimed: state pre-roll, then the contract's warm-up steps.  All eager launches but the last two warm-up
@@ -437,7 +444,8 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
         U, O_ = cf[0], cf[1]
     from www2023tiger_amd._lib import lib as _tg
     tile = bool(fused and _tg.tg_attn_tile_applies(C.byref(model.model_struct())))
-    gtab = getattr(model, '_gtab', None) is not None and restart_prob == 0  # eager query rows (tg_model.g_table) in use
+    # eager query rows (tg_model.g_table) in use; with the in-step restart loop only in a lean step with the centre-row table
+    gtab = getattr(model, '_gtab', None) is not None and (restart_prob == 0 or (lean and getattr(model, '_ctab', None) is not None))
     work = stage_work(cfg, U, O_, P, eager, fused, stream['n_nodes'], E, tile, gtab)
     traffic = load_traffic(traffic_tag)
     empty = {'zero_flags', 'dedup_positive', 'restarter_targets', 'apply_messages(gru)' if eager else 'eager_updater(gru)'}
@@ -488,7 +496,7 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
                            involved_before_timed_region=[dict(batch=b, involved=u) for b, u in u_trace],
                            outdated_per_batch=float(O_),
                            unique_pos_per_batch=float(P)),
-               roofline=roofline_of(dom, stages[dom], work, traffic),
+               roofline=roofline_of(dom, stages[dom], work, traffic, overhead),
                stages_ms={n: round(v, 5) for n, v in stages.items()}, stage_event_overhead_ms=round(overhead, 5))
     if self_check is not None:
         out['replay_self_check'] = self_check
@@ -502,7 +510,7 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     # those bytes (the gather and the updater launch), and the updater launch on both rooflines
     g_name, u_name = 'attn_core(gather+softmax)' if direct else 'gather_right_memory', \
         'eager_updater(gru)' if eager else 'apply_messages(gru)'
-    mg = roofline_of(g_name, stages[g_name], work, traffic)
+    mg = roofline_of(g_name, stages[g_name], work, traffic, overhead)
     if direct:
         # the direct form fuses the gather into the attention core.  The stand-alone memory-gather launch (the copy form of
         # the same step: tg_step_io.eager_copy, reprs[u] = pending-or-right row) is timed on a few more batches of the
@@ -521,7 +529,7 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
                   note='stand-alone gather launch of the copy form of the eager step (tg_step_io.eager_copy = 1), timed on 4 '
                        'further batches; the benchmarked step is the direct form, in which the attention core gathers these rows '
                        'itself (no reprs copy): fused_into = that launch on the same roofline',
-                  fused_into=roofline_of(g_name, stages[g_name], work, traffic))
+                  fused_into=roofline_of(g_name, stages[g_name], work, traffic, overhead))
     mw = 4 * d
     not_right = 0 if cfg['upd_src'] == 'right' else 1
     survey_bytes = U * 4 * d + O_ * (4 * mw + 4) + O_ * (4 * d + 4) * not_right + U * 4 * d
@@ -536,8 +544,8 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     out['roofline_memory_gather'] = mg
     for r in (out['roofline'], mg):
         r['traffic_source'] = TRAFFIC_SOURCE.get(traffic_tag) if r.get('traffic') is not None else None
-    out['roofline_updater'] = roofline_of(u_name, stages[u_name], work, traffic)
-    out['roofline_neighbour_gather'] = roofline_of('attn_core(gather+softmax)', stages['attn_core(gather+softmax)'], work, traffic)
+    out['roofline_updater'] = roofline_of(u_name, stages[u_name], work, traffic, overhead)
+    out['roofline_neighbour_gather'] = roofline_of('attn_core(gather+softmax)', stages['attn_core(gather+softmax)'], work, traffic, overhead)
     if want_cpu:
         out['cpu_baseline'] = cpu_baseline(stream, cfg, model)
     del buf, graph, model, resident

@@ -97,7 +97,7 @@ def test_c3_reddit_shape_b4096_static_lazy_restart(eager):
     compare_state_with_oracle(model, orc)
 
 
-@pytest.mark.parametrize('eager', [False, True], ids=['lazy', 'eager'])
+@pytest.mark.parametrize('eager', [False, True, 'lean'], ids=['lazy', 'eager', 'eager-lean-tables'])
 def test_c3_in_step_lazy_restart_equals_the_reference_loop(eager):
     """BASELINE configs[2] as written: the restart draws of train_self_supervised.py:152-163 are made up front
     and the loop body (forget / clear mailbox on a hit, re-initialise the involved nodes that are not up to date
@@ -116,11 +116,17 @@ def test_c3_in_step_lazy_restart_equals_the_reference_loop(eager):
             tbl = getattr(model.restarter_fn, nm).weight
             tbl.normal_(0.0, 0.5)
             orc.p[f'restarter_fn.{nm}.weight'] = tbl.detach().cpu().clone()
+    lean = eager == 'lean'
     if eager:
         model.eager_updates()
+    if lean:
+        # bench.py --workload c3's form: pre-multiplied weights and the per-node query-row / centre-row tables, which the
+        # restart loop's kernel keeps current itself (rows of the re-initialised nodes); the involved flags are marked,
+        # no sorted set is formed
+        model.fuse_attention()
     trigger = np.zeros(nb, dtype=np.uint8)
     trigger[[2, 6]] = 1          # two hits: the second one forgets the nodes restarted after the first
-    buf = model.step_buffers(B).enable_lazy_restart(model, trigger)
+    buf = model.step_buffers(B, lean=lean).enable_lazy_restart(model, trigger)
     restarting, uptodate = False, set()
     for b in range(nb):
         a = _batch(stream, b, B)
@@ -134,11 +140,13 @@ def test_c3_in_step_lazy_restart_equals_the_reference_loop(eager):
             orc.restart(r, np.full(len(r), np.float32(a[3].min()), dtype=np.float32))
             uptodate.update(r.tolist())
             n_r = len(r)
-        got = model.stream_step(*a)
+        got = model.stream_step(*a, lean=lean)
         assert got is buf
         ref = orc.stream_step(*a, cg).numpy()
         counts = _compare_indices(buf, cg)
         assert counts[3] == n_r, (b, counts, n_r)
+        if lean:
+            assert counts[0] == -1 and model._gtab is not None and model._ctab is not None and model._gtab_stamp is not None
         assert_close(buf.h[:2 * B].cpu().numpy(), ref, 'h_left', TOL)
         if b in (2, 3, 6):
             compare_state_with_oracle(model, orc)

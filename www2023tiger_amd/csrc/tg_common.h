@@ -251,8 +251,10 @@ int sample_nodes_launch(const tg_tcsr* g, int64_t Q, const int64_t* nids, const 
                         int64_t* o_eid, float* o_ts, uint8_t* mark, hipStream_t st);
 // the lazy-restart loop body of train_self_supervised.py:152-163 with the static restarter (tiger_hip.h: tg_lazy_restart);
 // runs between the sampler (flags, *tmin_key) and the compaction
+// rlist / rlist32 (nullable, static form only): also list the re-initialised nodes and rewrite their rows of m->c_table
 int lazy_restart_launch(const tg_tcsr* g, const tg_model* m, const tg_lazy_restart* lz, const uint8_t* flags,
-                        const uint32_t* tmin_key, int32_t* n_restarted, hipStream_t st);
+                        const uint32_t* tmin_key, int32_t* n_restarted, hipStream_t st, int64_t* rlist = nullptr,
+                        int32_t* rlist32 = nullptr);
 // positive-node dedup of the fused step (select_latest_nids on float32 ts): best[rank(node)] =
 // max over positions of (ts_key << 32 | ~pos), then the winners.  The two passes ride on other
 // launches of the step (they are ~2B threads of work each, not worth a launch of their own).

@@ -154,10 +154,14 @@ __global__ void __launch_bounds__(256) k_sample_batch(SampleBatchArgs a, Centres
 // their node's last event before the batch's earliest time (float32 query, as the reference's history call),
 // then the wavefront copies the surrogate rows of each needing node.  The word's has-message and uptodate
 // bits have a single writer (this wavefront): plain stores.
+// rlist / rlist32 (nullable; static form): the re-initialised nodes are also listed (compacted through *n_restarted) and
+// their rows of the per-node centre-row table (tg_model.c_table) rewritten - c_v = right_static[v] + nfeat[v], the node
+// has no pending message any more - so that the step can refresh their query rows (tg_model.g_table) right behind
 __global__ void __launch_bounds__(256) k_lazy_restart(tg_tcsr g, tg_model m, tg_lazy_restart lz,
                                                       const uint8_t* __restrict__ flags,
                                                       const uint32_t* __restrict__ tmin_key,
-                                                      int32_t* __restrict__ n_restarted) {
+                                                      int32_t* __restrict__ n_restarted, int64_t* __restrict__ rlist,
+                                                      int32_t* __restrict__ rlist32) {
   const int lane = lane_id();
   const int64_t W = (m.n_nodes + 63) / 64;
   const int64_t b = lz.batch_dev ? *lz.batch_dev : 0;
@@ -194,13 +198,31 @@ __global__ void __launch_bounds__(256) k_lazy_restart(tg_tcsr g, tg_model m, tg_
       const int64_t end = prefix_end(g, node, t, &start);
       if (end > start) pt_l = (float)g.ts[end - 1];
     }
+    int lbase = 0;
+    if (rlist && need) {
+      if (lane == 0) lbase = atomicAdd(n_restarted, __popcll(need));
+      lbase = __shfl(lbase, 0, TG_WAVE);
+      if (need_l) {
+        const int at = lbase + __popcll(need & ((1ull << lane) - 1ull));
+        rlist[at] = node;
+        rlist32[at] = (int32_t)node;
+      }
+    }
+    float4* ctab = reinterpret_cast<float4*>(m.c_table);
+    const float4* nf4 = reinterpret_cast<const float4*>(m.nfeats);
     for (unsigned long long todo = need; todo; todo &= todo - 1) {
       const int k = __ffsll(todo) - 1;
       const int64_t v = w * 64 + k;
       const float pt = __shfl(pt_l, k, TG_WAVE);
       for (int c = lane; c < w4; c += TG_WAVE) {
+        const float4 rv = sr[v * w4 + c];
         left[v * w4 + c] = sl[v * w4 + c];
-        right[v * w4 + c] = sr[v * w4 + c];
+        right[v * w4 + c] = rv;
+        if (rlist && ctab) {
+          float4 cv = rv;
+          if (nf4) { const float4 f = nf4[v * w4 + c]; cv.x += f.x; cv.y += f.y; cv.z += f.z; cv.w += f.w; }
+          ctab[v * w4 + c] = cv;
+        }
       }
       if (lane == 0) {
         m.left_ts[v] = pt;
@@ -212,7 +234,7 @@ __global__ void __launch_bounds__(256) k_lazy_restart(tg_tcsr g, tg_model m, tg_
     if (lane == 0 && (trig || need)) {
       lz.uptodate[w] = upd | need;
       m.has_msg[w] = msg & ~need;
-      if (need) atomicAdd(n_restarted, __popcll(need));
+      if (need && !rlist) atomicAdd(n_restarted, __popcll(need));
     }
   }
   if (trig && blockIdx.x == 0 && threadIdx.x == 0) *lz.restarting_dev = 1;
@@ -220,11 +242,13 @@ __global__ void __launch_bounds__(256) k_lazy_restart(tg_tcsr g, tg_model m, tg_
 }
 
 int lazy_restart_launch(const tg_tcsr* g, const tg_model* m, const tg_lazy_restart* lz, const uint8_t* flags,
-                        const uint32_t* tmin_key, int32_t* n_restarted, hipStream_t st) {
+                        const uint32_t* tmin_key, int32_t* n_restarted, hipStream_t st, int64_t* rlist, int32_t* rlist32) {
   if (!lz->trigger || !lz->restarting_dev || !lz->uptodate) return TG_EINVAL;
   if (lz->list ? (lz->static_left || lz->static_right) : (!lz->static_left || !lz->static_right)) return TG_EINVAL;
+  if (lz->list && rlist) return TG_EINVAL;
   const int64_t W = (m->n_nodes + 63) / 64;
-  hipLaunchKernelGGL(k_lazy_restart, dim3(flat_grid(W, 4)), dim3(256), 0, st, *g, *m, *lz, flags, tmin_key, n_restarted);
+  hipLaunchKernelGGL(k_lazy_restart, dim3(flat_grid(W, 4)), dim3(256), 0, st, *g, *m, *lz, flags, tmin_key, n_restarted,
+                     rlist, rlist32);
   return check_launch("lazy_restart");
 }
 

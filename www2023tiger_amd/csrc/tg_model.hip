@@ -503,11 +503,14 @@ void launch_attn_core(const tg_model* m, int64_t Q, const float* ts, const int64
 }
 
 static void launch_centres(const tg_model* m, int64_t Q, const int64_t* nids, const float* reprs, const uint64_t* bm,
-                           const uint32_t* rank, const AttnWs& w, const PosArgs* pos, const DirectArgs* da, hipStream_t st) {
+                           const uint32_t* rank, const AttnWs& w, const PosArgs* pos, const DirectArgs* da, hipStream_t st,
+                           bool no_copy = false) {
   const int d = m->d;
   if (da)  // rows from the state tables; checks + first dedup pass ride along (the second one rides on the core)
-    hipLaunchKernelGGL(k_attn_centres_direct, dim3(flat_grid(Q * (d / 4), 256)), dim3(256), 0, st, *m, Q, nids,
-                       (const float4*)m->nfeats, (float4*)w.cc, *da, pos ? *pos : PosArgs{});
+    // (no_copy: the centre rows are read from the per-node table, tg_model.c_table - only checks, dedup and snapshot)
+    hipLaunchKernelGGL(k_attn_centres_direct, dim3(flat_grid((no_copy ? std::max<int64_t>(da->n_snap, 1) : Q) * (d / 4), 256)),
+                       dim3(256), 0, st, *m, Q, nids, (const float4*)m->nfeats, no_copy ? (float4*)nullptr : (float4*)w.cc, *da,
+                       pos ? *pos : PosArgs{});
   else
     hipLaunchKernelGGL(k_attn_centres, dim3(flat_grid(Q * (d / 4), 256)), dim3(256), 0, st, Q, d / 4, nids,
                        (const float4*)reprs, bm, rank, (const float4*)m->nfeats, (float4*)w.cc, 0, (const float*)nullptr,
@@ -524,7 +527,8 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
   int stage = ST_ATTN_FIRST + 1;
   const int d = m->d;
   const FusedView f = fused_view(m, m->attn_fused);
-  if (!centres_done) launch_centres(m, Q, nids, reprs, bm, rank, w, pos, da, st);  // else: rode on the sampler's launch
+  if (!centres_done)  // else: rode on the sampler's launch (or on the previous step's last one)
+    launch_centres(m, Q, nids, reprs, bm, rank, w, pos, da, st, use_gtab && m->c_table && da);
   int rc;
   if (attn_tile_applies(m) && !key_rows && !use_gtab) {  // the whole block in one launch, G and S in LDS only (tg_attn_tile.hip); timed as the core
     prof_mark(pf, stage++, st);
@@ -1120,7 +1124,11 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   w.fused_wb = w.direct && !io->embed_only && !io->h_prev_left && !io->h_prev_right;
   // lean: nothing in such a step needs the involved / outdated sets, so they are not formed (tiger_hip.h, tg_step_io.lean)
   // (an embed-only step has no write-back to clean up after: lean, it touches none of the self-cleaning state at all)
-  w.lean = io->lean && w.direct && !lz && (w.fused_wb || io->embed_only);
+  // With the in-step restart loop of the STATIC restarter a lean step still marks the involved flags (the loop's only
+  // input) but forms no sorted set; the list form (any other restarter) keeps the full step
+  const bool lz_static = lz && !lz->list;
+  w.lean = io->lean && w.direct && (!lz || lz_static) && (w.fused_wb || io->embed_only);
+  const bool need_flags = !w.lean || lz != nullptr;
   const bool untouched = w.lean && io->embed_only;  // no flags, no dedup slots, no counts
   if ((!io->ws_is_clean || io->embed_only || io->collate_only) && !untouched) e = hipMemsetAsync(w.flags, 0, w.zero_bytes, st);
   if (e == hipSuccess && w.lean && !io->embed_only && !io->ws_is_clean)
@@ -1144,12 +1152,15 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   if (want_rider) pos.win_row = w.win_row;
   const PosArgs* pp = (io->embed_only && !untouched) ? nullptr : &pos;
   // eager query rows: a full eager step of a model that carries the table (it refreshes the table at its end)
-  w.gtab = eager && m->g_table && m->attn_fused && !lz && !inner && !io->embed_only && !io->collate_only && !drop;
+  // (with the in-step restart loop: only with the centre-row table, whose rows of the re-initialised nodes the loop's
+  // kernel rewrites itself - their query rows are refreshed right behind it)
+  w.gtab = eager && m->g_table && m->attn_fused && (!lz || (lz_static && m->c_table && w.lean)) && !inner && !io->embed_only &&
+           !io->collate_only && !drop;
   // collate prefetch (tg_step_io.prefetch_state): this step runs the NEXT batch's sampler + centres on its last launch;
   // `prefetched`: the previous call did that for this batch (a repeated collate would be harmless, just wasted)
   static const int pf_knob = getenv("TG_PREFETCH") ? atoi(getenv("TG_PREFETCH")) : 1;
   w.prefetch = pf_knob != 0 && io->prefetch_state && io->stream_len > 0 && io->offset_dev && io->advance && io->ws_is_clean &&
-               w.lean && w.gtab && w.fused_wb && io->strategy == 0 && K <= 16 && !io->l1_nids && !io->l1_eids && !io->l1_ts &&
+               w.lean && w.gtab && w.fused_wb && !lz && io->strategy == 0 && K <= 16 && !io->l1_nids && !io->l1_eids && !io->l1_ts &&
                B <= 16384;  // (large batches: the last product's launch takes no riders - nothing to gain, see gemm_launch)
   const int pf_in = io->prefetch_state ? *io->prefetch_state : 0;
   const bool prefetched = w.prefetch && pf_in == 1;
@@ -1180,21 +1191,27 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
     if (lz || inner) return TG_EUNSUPPORTED;
     hipLaunchKernelGGL(k_build_queries, dim3(flat_grid(Q, 256)), dim3(256), 0, st, B, io->src, io->dst, io->neg, io->ts,
                        io->eids, (const int64_t*)io->offset_dev, w.nids3, w.ts3, w.ts3f, w.eids);
-    if ((rc = sample_nodes_launch(g, Q, w.nids3, w.ts3, (int32_t)K, w.l1n, w.l1e, w.l1t, w.lean ? nullptr : w.flags, st)) !=
+    if ((rc = sample_nodes_launch(g, Q, w.nids3, w.ts3, (int32_t)K, w.l1n, w.l1e, w.l1t, need_flags ? w.flags : nullptr, st)) !=
         TG_OK)
       return rc;
   } else if ((rc = sample_batch_launch(g, B, io->src, io->dst, io->neg, io->ts, io->eids, io->offset_dev, (int32_t)K,
-                                       w.nids3, w.ts3f, w.eids, w.l1n, w.l1e, w.l1t, w.lean ? nullptr : w.flags, st,
+                                       w.nids3, w.ts3f, w.eids, w.l1n, w.l1e, w.l1t, need_flags ? w.flags : nullptr, st,
                                        lz ? reinterpret_cast<uint32_t*>(w.counts + 4) : nullptr,
-                                       w.lean ? &rider : nullptr)) != TG_OK)
+                                       (w.lean && !lz) ? &rider : nullptr)) != TG_OK)  // (centres: behind the restart loop)
     return rc;
   // second hop (data_loader.py:128-131): every neighbour slot (padding included) queried at its own float32 timestamp
   if (inner && (rc = sample_edges_f32_launch(g, Q * K, w.l1n, w.l1t, (int32_t)K, w.h2n, w.h2e, w.h2t,
-                                             w.lean ? nullptr : w.flags, st)) != TG_OK)
+                                             need_flags ? w.flags : nullptr, st)) != TG_OK)
     return rc;
   // lazy restart (train_self_supervised.py:152-163): before STEP 1, because a restarted node loses its pending message
-  if (lz && (rc = lazy_restart_launch(g, m, lz, w.flags, reinterpret_cast<const uint32_t*>(w.counts + 4), w.counts + 3,
-                                      st)) != TG_OK)
+  const bool lz_tables = lz && w.gtab;  // the loop also keeps the per-node tables current (lists what it re-initialised)
+  if (lz && (rc = lazy_restart_launch(g, m, lz, w.flags, reinterpret_cast<const uint32_t*>(w.counts + 4), w.counts + 3, st,
+                                      lz_tables ? w.outdated : nullptr, lz_tables ? w.out_pos : nullptr)) != TG_OK)
+    return rc;
+  // ... their query rows: one product over the listed nodes (usually none or a handful; everybody involved right after
+  // a trigger).  Nodes that lost their message at a trigger and are not involved keep stale rows - they are not up to
+  // date either, so they are re-initialised (and refreshed here) before any batch reads them
+  if (lz_tables && (rc = gtab_rows(m, cap, w.outdated, w.out_pos, w.counts + 3, nullptr, st, true, nullptr, nullptr, 1024)) != TG_OK)
     return rc;
   prof_mark(pf, ST_COMPACT, st);
   w.inv = io->involved ? io->involved : w.involved;
@@ -1240,7 +1257,7 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
     wbr.a.snap_ts = w.snap_ts;
   }
   if ((rc = attn_forward(m, Q, w.nids3, w.ts3f, w.l1n, w.l1e, w.l1t, w.reprs, w.bm, w.rank, io->h, w.attn, st, pf,
-                         drop, pp, w.direct ? &da : nullptr, key_rows, w.lean && !recent_nodes, w.gtab,
+                         drop, pp, w.direct ? &da : nullptr, key_rows, w.lean && !recent_nodes && !lz, w.gtab,
                          want_rider ? &wbr : nullptr, &w.wb_rode)) != TG_OK)
     return rc;
   prof_mark(pf, ST_DEDUP, st);
@@ -1269,7 +1286,7 @@ static WritebackArgs writeback_args(const tg_model* m, const tg_step_io* io, Ste
   wa.n_upos = w.counts + 2; wa.reprs = w.reprs; wa.bm = w.bm; wa.rank = w.rank; wa.h = io->h; wa.err = io->err;
   wa.counts_src = io->counts ? w.counts : nullptr; wa.counts_dst = io->counts;
   wa.offset_dev = (io->offset_dev && io->advance) ? io->offset_dev : nullptr;
-  wa.clean_flags = w.lean ? nullptr : w.flags; wa.flag_bytes = (int64_t)((m->n_nodes + 63) / 64) * 64;
+  wa.clean_flags = (w.lean && !io->lazy) ? nullptr : w.flags; wa.flag_bytes = (int64_t)((m->n_nodes + 63) / 64) * 64;
   wa.clean_best = w.lean ? w.best_id : w.best; wa.clean_best_by_pos = w.lean ? 1 : 0;
   wa.clean_counts = w.counts;
   wa.lazy_batch = (io->lazy && io->lazy->batch_dev) ? io->lazy->batch_dev : nullptr;

@@ -804,7 +804,12 @@ class TIGE(nn.Module):
             buf.lazy_batch += 1
         if self._pending is not None and not buf.embed_only:
             self._sync_pending()
-            if not buf.io.lazy:  # (a step with the in-step restart loop runs the G product: it does not read the table)
+            # (a step with the in-step restart loop keeps the per-node tables itself when it is lean, the restarter static
+            # and the centre-row table there - tiger_hip.h: tg_model.c_table; any other such step runs the G product and
+            # does not read the tables)
+            buf._lazy_tables = (bool(buf.io.lazy) and cb is None and bool(buf.io.lean) and self._gtab_wanted()
+                                and os.environ.get('TG_CTAB', '1') != '0')
+            if not buf.io.lazy or buf._lazy_tables:
                 self._sync_gtab()
         m = self.model_struct()
         pf = bool(buf.io.prefetch_state)
@@ -821,8 +826,8 @@ class TIGE(nn.Module):
             if self.device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
                 buf._pf_state.value = before  # nothing ran: the device is where it was before the capturing call
             buf._pf_stamp = self._prefetch_stamp(buf, g)
-        if buf.io.lazy and getattr(self, '_gtab', None) is not None:
-            self._gtab_stamp = None  # the in-step restart loop re-initialises rows the table does not follow
+        if buf.io.lazy and getattr(self, '_gtab', None) is not None and not getattr(buf, '_lazy_tables', False):
+            self._gtab_stamp = None  # the in-step restart loop re-initialised rows the tables did not follow
 
     def _prefetch_stamp(self, buf, g):
         """Everything the prefetched collate part of a batch is a function of, as far as the host can see it: the state
