@@ -161,7 +161,10 @@ def test_empty_inputs():
                                           # tiles 32 x 32 and 32 x 48; rows / columns / K not multiples of the tile sizes)
                                           (1060, 172, 1032), (3, 4, 5), (33, 20, 17), (1815, 100, 400), (257, 192, 70), (40, 180, 1000),
                                           # LDS-free K-split blocks (k_gemm_ks16: K >= 512, 16 / 32 / 48-row blocks), ragged everything
-                                          (3072, 1204, 172), (600, 1204, 172), (1500, 516, 172), (47, 1028, 50), (100, 700, 9)])
+                                          (3072, 1204, 172), (600, 1204, 172), (1500, 516, 172), (47, 1028, 50), (100, 700, 9),
+                                          # panel-stationary blocks of eight wavefronts (k_gemm_astat8: 4 / 6 / 8 k-tiles, >= 4 096
+                                          # tiles of 128 x 64), ragged rows and columns
+                                          (70001, 172, 1032), (140001, 100, 300), (33000, 256, 1024)])
 def test_linear_fwd_vs_torch(n, in_f, out_f):
     from www2023tiger_amd.model.dense import linear_forward
     torch.manual_seed(n)

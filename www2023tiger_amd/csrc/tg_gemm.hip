@@ -638,6 +638,107 @@ __device__ __forceinline__ void gemm_astat_block(const GemmArgs& g, int cpb, uns
     }
   }
 }
+// ... and for LARGE launches of such products (C5 shape: the query rows of 81 k positive nodes, K = 256 -> N = 1 024; fc2,
+// K = N = 256 over 197 k rows), where the register-blocked 128 x 64 blocks re-stage their activation tile for every
+// column tile and drain between tiles: eight wavefronts (4 row x 2 column) around a 128-row panel that stays in LDS
+// (131 KB at K = 256) while `cpb` column tiles of weights stream through the two-buffer pipeline - 8 KB staged per
+// k-tile instead of 24 KB, one float4 per thread.  One block per CU, two wavefronts per SIMD.
+template <int NKT>
+__global__ void __launch_bounds__(512) k_gemm_astat8(GemmArgs g, int cpb) {
+  static_assert(NKT % 2 == 0, "the LDS buffer of a weight tile follows from its k-tile index");
+  constexpr int SA = NKT * BK + 1;  // panel row stride (odd)
+  __shared__ float As[128][SA];
+  __shared__ float Bs[2][64][LDK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 31, fk = lane >> 5;
+  const int K = g.k, N = g.n;
+  int64_t M = g.m_cap;
+  if (g.m_dev) M = min(M, (int64_t)*g.m_dev);
+  const int NT = (N + 63) / 64, NG = (NT + cpb - 1) / cpb;
+  const int xcd = blockIdx.x & 7, s_ = blockIdx.x >> 3;
+  const int64_t mt = (int64_t)(s_ / NG) * 8 + xcd;
+  const int c0 = (s_ % NG) * cpb, c1 = min(c0 + cpb, NT);
+  const int64_t m0 = mt * 128;
+  if (m0 >= M) return;
+  const int ar = tid >> 3, ac4 = (tid & 7) * 4;  // 64 rows x 8 float4 per pass
+  int crow[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t m = min(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk, M - 1);
+    crow[r] = g.c_rows ? g.c_rows[m] : (int)m;
+  }
+  {  // the activation panel, once
+    float4 pa[2][NKT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t m = min(m0 + ar + 64 * i, M - 1);
+      const float* row = g.a0.p + (g.a0.idx ? g.a0.idx[m] : m) * g.a0.ld;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        const int k = kt * BK + ac4;
+        pa[i][kt] = ldg4(row + (k < K ? k : 0));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) sts4(As[ar + 64 * i], kt * BK + ac4, kt * BK + ac4 < K ? pa[i][kt] : zero4());
+  }
+  float4 rb[2];  // weight tiles in flight: two register sets / two LDS buffers by the parity of the k-tile
+  auto load_w = [&](int c, int j, float4& q) {
+    const int cc = min(c, c1 - 1);
+    const int k = j * BK + ac4;
+    q = ldg4(g.w + (int64_t)min(cc * 64 + ar, N - 1) * g.ldw + (k < K ? k : 0));
+  };
+  auto store_w = [&](int buf, int j, const float4& q) { sts4(Bs[buf][ar], ac4, j * BK + ac4 < K ? q : zero4()); };
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  load_w(c0, 0, rb[0]);
+  load_w(c0, 1, rb[1]);
+  store_w(0, 0, rb[0]);
+  __syncthreads();
+  for (int c = c0; c < c1; ++c) {
+    const int n_out = min(c * 64 + wn * 32 + fr, N - 1);
+    const float bias = g.bias ? g.bias[n_out] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NKT; ++j) {
+      constexpr int PP = 8;
+      const int buf = j & 1;
+      const int lc = j + 2 < NKT ? c : c + 1, lj = (j + 2) % NKT, sj = (j + 1) % NKT;
+      const float* ap = &As[wm * 32 + fr][j * BK + fk];
+      const float* bp = &Bs[buf][wn * 32 + fr][fk];
+      float a0 = ap[0], a1 = ap[2], b0 = bp[0], b1 = bp[2];
+#pragma unroll
+      for (int pr = 0; pr < PP; ++pr) {
+        float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+        if (pr < PP - 1) {
+          na0 = ap[4 * pr + 4]; na1 = ap[4 * pr + 6];
+          nb0 = bp[4 * pr + 4]; nb1 = bp[4 * pr + 6];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
+        if (pr == 0) load_w(lc, lj, rb[j & 1]);
+        else if (pr == 4) store_w(buf ^ 1, sj, rb[(j + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+      }
+      __syncthreads();
+    }
+    const int n = c * 64 + wn * 32 + fr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+      float x = g.alpha * (acc[r] + bias);
+      if (g.relu) x = fmaxf(x, 0.f);
+      if (n < N && m < M) g.c[(int64_t)crow[r] * g.ldc + n] = x;
+      acc[r] = 0.f;
+    }
+  }
+}
+
 template <int NKT>
 __global__ void __launch_bounds__(256) k_gemm_astat(GemmArgs g, int cpb) {
   gemm_astat_block<NKT>(g, cpb, blockIdx.x);
@@ -1152,6 +1253,24 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
   // 1.08 ms, fc2 0.261 -> 0.253 ms; at C3 / C4 sizes (288 .. 2 500 blocks) 3 .. 17 % SLOWER than the 64 x 64 blocks (whose
   // several co-resident blocks per CU cover each other's prologue and epilogue); 128 x 128 blocks are slower still there
   static const int rb_knob = getenv("TG_GEMM_RB") ? atoi(getenv("TG_GEMM_RB")) : 1;  // tuning knob: 0 = off, 2 = 128 x 128
+  // short K (4 / 6 / 8 k-tiles), plain epilogue, MANY rows: panel-stationary blocks of eight wavefronts (k_gemm_astat8)
+  // (measured, 81 000 x 256 -> 1 024: 434 us as register-blocked blocks, 396 / 375 / 434 us with 4 / 8 / 16 column tiles per
+  // panel block; 196 608 x 256 -> 256: 267 us with 4 against 260-280)
+  static const int as8_knob = getenv("TG_GEMM_ASTAT8") ? atoi(getenv("TG_GEMM_ASTAT8")) : 8;  // tuning knob: column tiles per block, 0 = off
+  {
+    const int nkt8 = (int)cdiv(g.k, BK);
+    const bool plain8 = !g.ask_part && g.nbatch == 1 && !g.a1.p && !g.w_kmajor && !g.bias_rs && !g.bias2 && !g.row_valid &&
+                        !g.relu_mask && !g.accumulate && !g.c2 && g.a0.w == g.k;
+    if (as8_knob && plain8 && (nkt8 == 4 || nkt8 == 6 || nkt8 == 8) && cdiv(g.m_cap, 128) * NT >= 4096) {
+      no_ride();
+      const int cpb = std::min(as8_knob, NT);
+      const dim3 gr((unsigned)(8 * cdiv(cdiv(g.m_cap, 128), 8) * cdiv(NT, cpb)));
+      if (nkt8 == 4) hipLaunchKernelGGL((k_gemm_astat8<4>), gr, dim3(512), 0, st, gd, cpb);
+      else if (nkt8 == 6) hipLaunchKernelGGL((k_gemm_astat8<6>), gr, dim3(512), 0, st, gd, cpb);
+      else hipLaunchKernelGGL((k_gemm_astat8<8>), gr, dim3(512), 0, st, gd, cpb);
+      return check_launch("gemm(astat8)");
+    }
+  }
   if (rb_knob && !g.ask_part && g.nbatch == 1 && !g.w_kmajor && !g.bias_rs && !g.row_valid && !g.relu_mask &&
       !g.accumulate && cdiv(g.m_cap, 128) * NT >= 4096) {
     no_ride();
