@@ -162,6 +162,7 @@ def test_empty_inputs():
                                           (1060, 172, 1032), (3, 4, 5), (33, 20, 17), (1815, 100, 400), (257, 192, 70), (40, 180, 1000),
                                           # LDS-free K-split blocks (k_gemm_ks16: K >= 512, 16 / 32 / 48-row blocks), ragged everything
                                           (3072, 1204, 172), (600, 1204, 172), (1500, 516, 172), (47, 1028, 50), (100, 700, 9),
+                                          (6144, 500, 100), (3071, 400, 64), (601, 500, 100), (700, 388, 112), (333, 404, 33),
                                           # panel-stationary blocks of eight wavefronts (k_gemm_astat8: 4 / 6 / 8 k-tiles, >= 4 096
                                           # tiles of 128 x 64), ragged rows and columns
                                           (70001, 172, 1032), (140001, 100, 300), (33000, 256, 1024)])

@@ -1100,13 +1100,33 @@ bool gemm_ks16_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, b
   static const int knob = getenv("TG_GEMM_KS16") ? atoi(getenv("TG_GEMM_KS16")) : 1;
   if (rode) *rode = false;
   if (!knob || g.m_cap <= 0 || g.nbatch != 1 || g.w_kmajor || g.bias_rs || g.row_valid || g.relu_mask || g.c_rows || g.accumulate ||
-      g.c2 || g.ask_part || (g.k % 4) || (g.a0.w % 4) || (g.ldw % 4) || g.a0.w + (g.a1.p ? g.a1.w : 0) != g.k || g.k < 512)
+      g.c2 || g.ask_part || (g.k % 4) || (g.a0.w % 4) || (g.ldw % 4) || g.a0.w + (g.a1.p ? g.a1.w : 0) != g.k)
     return false;
-  const int64_t nt48 = cdiv(g.n, 48);
+  // column tiles of 48 (CT = 3), or - narrow outputs (N <= 112, e.g. LastFM's --dim 100: 64-column tiles waste 28 % of the
+  // MFMAs, 48-column tiles 44 %) - ONE column tile of 16 CT = 64 / 112 columns with 32-row blocks
+  const int ct = g.n <= 64 ? 4 : g.n <= 112 ? 7 : 3;
+  // (measured, N = 100: 24 576 x 500 42.2 -> 39.6 us, 6 144 x 500 17.7 -> 13.3 us, 600 x 500 16.6 -> 9.2 us; 3 072 x 400 -> 64
+  // 14.5 -> 6.4 us; at K = 300 the 64 x 64 blocks are faster: 27.9 against 30.9 us)
+  if (g.k < (ct == 3 ? 512 : 384)) return false;
+  const int64_t ntc = cdiv(g.n, 16 * ct);
   static const int64_t max_tiles = getenv("TG_GEMM_KS16_TILES") ? atoi(getenv("TG_GEMM_KS16_TILES")) : 1100;  // tuning knob (measured, K = 1 204, N = 172: 6 144 rows 54.5 -> 37.1 us, 12 288 rows 78.2 -> 72.1 us, 24 576 rows 123 -> 129 us)
-  if (cdiv(g.m_cap, 48) * nt48 > max_tiles) return false;
+  if (cdiv(g.m_cap, ct == 3 ? 48 : 32) * ntc > max_tiles) return false;
   GemmArgs gd = g;
   gd.dbg = 0;
+  const NoRider nr{0u};
+  if (ct != 3) {
+    // (rows per block: 16 when that fits the chip at once, else 32)
+    const bool r1 = cdiv(g.m_cap, 16) * ntc <= 256;
+    if (ct == 4) {
+      if (r1) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 1, 4, 4>), dim3(256), dim3(256), 0, st, gd, nr);
+      else hipLaunchKernelGGL((k_gemm_ks16<NoRider, 2, 4, 4>), dim3(256), dim3(256), 0, st, gd, nr);
+    } else {
+      if (r1) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 1, 7, 4>), dim3(256), dim3(256), 0, st, gd, nr);
+      else hipLaunchKernelGGL((k_gemm_ks16<NoRider, 2, 7, 4>), dim3(256), dim3(256), 0, st, gd, nr);
+    }
+    return true;
+  }
+  const int64_t nt48 = ntc;
   // rows per block: the smallest of 16 / 32 / 48 whose blocks fit the chip at once (fewer rows = a shorter block)
   const int rt = cdiv(g.m_cap, 16) * nt48 <= 256 ? 1 : cdiv(g.m_cap, 32) * nt48 <= 256 ? 2 : 3;
   if (rider && rode && knob != 8) {
@@ -1115,20 +1135,17 @@ bool gemm_ks16_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, b
     // (C2: fc1 22.9 -> 25.8 us, fc2 + riders 16.8 -> 12.9 us; with the short blocks of a small batch fc2's launch hides the
     // rider as well and fc1 only gets longer: C1 13.1 -> 14.5 us)
     static const int here = getenv("TG_WB_RIDER_FC1") ? atoi(getenv("TG_WB_RIDER_FC1")) : 1;  // tuning knob: 0 = on fc2
-    if (here && rt == 3) {
+    if (here && rt == 3 && cdiv(g.m_cap, 48) * nt48 <= 256) {
       WbRider wr = *rider;
       const int64_t live = std::min<int64_t>(256, cdiv(g.m_cap, 16 * rt) * nt48);
       wr.blocks = rider_blocks(live, 256, 2 * wr.a.B);
       wr.last = 1u;
       const dim3 gr(256 + wr.blocks);
-      if (rt == 1) hipLaunchKernelGGL((k_gemm_ks16<WbRider, 1, 3, 4>), gr, dim3(256), 0, st, gd, wr);
-      else if (rt == 2) hipLaunchKernelGGL((k_gemm_ks16<WbRider, 2, 3, 4>), gr, dim3(256), 0, st, gd, wr);
-      else hipLaunchKernelGGL((k_gemm_ks16<WbRider, 3, 3, 4>), gr, dim3(256), 0, st, gd, wr);
+      hipLaunchKernelGGL((k_gemm_ks16<WbRider, 3, 3, 4>), gr, dim3(256), 0, st, gd, wr);
       *rode = true;
       return true;
     }
   }
-  const NoRider nr{0u};
   if (knob == 8) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 3, 3, 8>), dim3(256), dim3(512), 0, st, gd, nr);
   else if (rt == 1) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 1, 3, 4>), dim3(256), dim3(256), 0, st, gd, nr);
   else if (rt == 2) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 2, 3, 4>), dim3(256), dim3(256), 0, st, gd, nr);
