@@ -388,7 +388,22 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     # ---- untimed: state pre-roll, then the contract's warm-up steps.  All eager launches but the last two warm-up
     # steps, which are replays of the graph the timed region replays (the first replay of a fresh graph pays its upload)
     n_untimed = preroll + warmup
-    n_replay_warm = 0 if (args.no_graph or n_untimed < 6) else min(2, warmup)
+    # steps per captured graph: consecutive replays of a graph are ~9 us apart on the device (tools/rocpd_gaps.py: the kernels
+    # inside a replay follow each other within 0-2 us, the first kernel of the next replay starts 8.7 us after the last of
+    # this one), so the timed region replays graphs of several steps - the step reads its batch at a device-side offset and
+    # advances it, a graph of g steps is g copies of the same five launches.  g: the largest divisor of K up to 25; one
+    # untimed replay uploads the graph (its g batches are the last of the untimed pre-roll + warm-up batches)
+    gsteps = 1
+    if not args.no_graph and n_untimed >= 6:
+        for gcand in range(min(25, steps, n_untimed - 4), 0, -1):
+            if steps % gcand == 0:
+                gsteps = gcand
+                break
+        if args.graph_steps:
+            gsteps = max(1, min(args.graph_steps, steps, n_untimed - 4))
+            while steps % gsteps:
+                gsteps -= 1
+    n_replay_warm = 0 if (args.no_graph or n_untimed < 6) else (gsteps if gsteps > 1 else min(2, warmup))
     u_trace = []
     for b in range(n_untimed - n_replay_warm):
         full_form = lean and b in (n_untimed // 2, n_untimed - n_replay_warm - 2)  # two full steps: the involved set's size
@@ -411,15 +426,16 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
         snap = [t.clone() for t in (buf.offset,) + ((buf.lazy_batch,) if restart_prob > 0 else ())]
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=side):
-            model.launch_step(buf)
+            for _ in range(gsteps):
+                model.launch_step(buf)
         buf.offset.copy_(snap[0])  # capture does not execute: offset unchanged; make sure
         if restart_prob > 0:
             buf.lazy_batch.copy_(snap[1])
-        for _ in range(n_replay_warm):
+        for _ in range(n_replay_warm // gsteps):
             graph.replay()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(steps // gsteps if graph is not None else steps):
         if graph is not None:
             graph.replay()
         else:
@@ -481,7 +497,7 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     out = dict(value=steps * B / dt, ms_per_step=dt / steps * 1e3,
                config=dict(workload=cfg['name'], batch=B, dim=d, n_neighbors=K, msg_src=cfg['msg_src'],
                            upd_src=cfg['upd_src'], n_nodes=stream['n_nodes'], events=E, mode='stream (no_grad) STEP 1-6',
-                           launch='hipGraph replay' if graph is not None else 'eager',
+                           launch=(f'hipGraph replay, {gsteps} step{"s" if gsteps > 1 else ""} per captured graph' if graph is not None else 'eager'),
                            attention_weights=('pre-multiplied (tg_attn_fuse)' + (', whole block in one launch with G / S in LDS (k_attn_tile)' if tile else '')) if fused else 'as stored',
                            updater=('eager: once per stored message (TIGE.eager_updates)' + (', rows read from the tables directly' if direct else ', compact reprs copy')) if eager else
                                    'lazy: on the fly for every involved node with a pending message',
@@ -681,6 +697,8 @@ def main():
     ap.add_argument('--no-c5s-leg', action='store_true', help='default C2 run: skip the short HBM-roofline leg')
     ap.add_argument('--no-dist-leg', action='store_true',
                     help='default C2 run: skip the one-rank leg of the multi-GPU code path (partitioned_form_1rank)')
+    ap.add_argument('--graph-steps', type=int, default=0,
+                    help='steps per captured hipGraph (default: the largest divisor of --steps up to 25)')
     ap.add_argument('--no-prefetch', action='store_true',
                     help='do not run the next batch\'s sampler + centres as riders of the step\'s last launch')
     ap.add_argument('--no-lean', action='store_true',

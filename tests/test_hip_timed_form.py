@@ -87,6 +87,56 @@ def test_c2_graph_replay_of_the_resident_lean_step_matches_oracle(n_eager, prefe
     compare_state_with_oracle(model, orc)
 
 
+def test_c2_graph_of_several_steps_matches_oracle():
+    """bench.py's timed region replays graphs of SEVERAL steps (consecutive replays are ~9 us apart on the device): four
+    steps per captured graph here, with the collate prefetch chaining them inside the graph; the embeddings of the last
+    step of every replay and the final state against the oracle."""
+    import bench
+    from oracle import tiger_oracle as O
+    from test_hip_parity import compare_state_with_oracle
+    c = bench.C2
+    B, K, d = c['B'], c['K'], c['d']
+    n_eager, gsteps, n_replays = 3, 4, 3
+    nb = n_eager + gsteps * n_replays
+    E = (nb + 2) * B
+    stream = bench.make_stream(c['n_u'], c['n_i'], E, c['T'] * E / c['E'], seed=37, d_e=d)
+    model, orc = bench.build_models(stream, d, K, c['msg_src'], c['upd_src'], with_oracle=True)
+    model.fuse_attention()
+    model.eager_updates()
+    buf = model.StepBuffers(model, B, False, resident=_resident(stream), prefetch=True)
+    buf.io.lean = 1
+    _ = model.graph.tcsr, model.model_struct()
+
+    def oracle_step(b):
+        a = [stream[k][b * B:(b + 1) * B] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        return orc.stream_step(*a, O.collate(orc.graph, a[0], a[1], a[2], a[3], K, 'static')).numpy()
+
+    for b in range(n_eager):
+        model.launch_step(buf)
+        torch.cuda.synchronize()
+        ref = oracle_step(b)
+        cnt = buf.counts.tolist()
+        model.note_rows(cnt[1], cnt[2])
+    side = torch.cuda.Stream()
+    snap = buf.offset.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        for _ in range(gsteps):
+            model.launch_step(buf)
+    buf.offset.copy_(snap)
+    torch.cuda.synchronize()
+    b = n_eager
+    for r in range(n_replays):
+        graph.replay()
+        torch.cuda.synchronize()
+        for _ in range(gsteps):
+            ref = oracle_step(b)
+            b += 1
+        assert int(buf.err.item()) == 0 and int(buf.offset.item()) == b * B
+        assert_close(buf.h[:2 * B].cpu().numpy(), ref, f'h_left, replay {r}', TOL)
+    compare_state_with_oracle(model, orc)
+
+
 @pytest.mark.parametrize('lean', [False, True], ids=['full_step', 'lean_tables'])
 def test_c3_graph_replay_with_lazy_restart_triggers_inside_matches_reference_loop(lean):
     """BASELINE configs[2] as bench.py --workload c3 times it: static restarter, the restart draws made up front, the
