@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-3 measurement set (1x MI355X): bench lines, rocprofv3 kernel statistics, PMC traffic passes -> gpurun_out/r03_final/
 # usage (on the GPU box): bash tools/measure_r03.sh [TAG]   (files are named r03_*_TAG)
-TAG=${1:-v5}
+TAG=${1:-v6}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r03_final
 mkdir -p $O
