@@ -649,7 +649,16 @@ def train_main(args, cfg):
     resident = tuple(torch.from_numpy(stream[k]).to(dev) for k in ('src', 'dst', 'neg', 'ts', 'eids'))
     tr = FusedTrainer(model, B, lr=1e-4, resident=resident, mutual=rkind != 'none', mutual_coef=1.0)
     _ = model.graph.tcsr, model.model_struct()  # lazy device-side builds happen here, not inside a capture (--warmup 0)
-    for _ in range(args.warmup):
+    # graphs of several iterations (consecutive graph replays are ~9 us apart on the device, see run_stream_leg); the last
+    # warm-up iterations are one untimed replay of the graph (uploads it)
+    gsteps = 1
+    if not args.no_graph:
+        for gcand in range(min(10, args.steps, args.warmup), 0, -1):
+            if args.steps % gcand == 0:
+                gsteps = gcand
+                break
+    n_warm_replay = gsteps if (not args.no_graph and gsteps > 1) else 0
+    for _ in range(args.warmup - n_warm_replay):
         tr.launch()
     torch.cuda.synchronize()
     assert int(tr.buf.sb.err.item()) == 0
@@ -659,11 +668,14 @@ def train_main(args, cfg):
         off0 = tr.buf.sb.offset.clone()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=side):
-            tr.launch()
+            for _ in range(gsteps):
+                tr.launch()
         tr.buf.sb.offset.copy_(off0)
+        if n_warm_replay:
+            graph.replay()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps // gsteps if graph is not None else args.steps):
         if graph is not None:
             graph.replay()
         else:
@@ -682,7 +694,7 @@ def train_main(args, cfg):
                                       mode='train (contrast only)' if rkind == 'none' else
                                       f'train (contrast + mutual, {rkind} restarter, hist_len {args.hist_len})',
                                       last_mutual_loss=float(tr.buf.losses[1]),
-                                      launch='hipGraph replay' if graph is not None else 'eager', last_loss=loss))))
+                                      launch=(f'hipGraph replay, {gsteps} iteration{"s" if gsteps > 1 else ""} per captured graph' if graph is not None else 'eager'), last_loss=loss))))
 
 
 def main():
