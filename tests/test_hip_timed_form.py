@@ -3,6 +3,8 @@ step reading its batch at a device-side offset and advancing it, ONE captured hi
 direct-form eager step with pre-multiplied attention weights and the row bound that selects the small updater
 blocks - against the oracle after every replay, and the final state.  C3: the lazy-restart triggers fire INSIDE
 the replayed graph (train_self_supervised.py:152-163 with the static restarter, restarters.py:254-277)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -66,7 +68,8 @@ def test_c2_graph_replay_of_the_resident_lean_step_matches_oracle(n_eager, prefe
         ref = orc.stream_step(*a, cg).numpy()
         if not prefetch:
             np.testing.assert_array_equal(buf.l1_nids.cpu().numpy(), cg['l1_nids'])
-        elif b >= 1 and n_eager:  # (a graph captured at the very first step replays collate + prefetch: the flag stays 0)
+        elif b >= 1 and n_eager and os.environ.get('TG_PREFETCH', '1') != '0' and os.environ.get('TG_GTAB', '1') != '0':
+            # (a graph captured at the very first step replays collate + prefetch: the flag stays 0; the knobs switch it off)
             assert buf._pf_state.value == 1  # every step after the first started with its attention core
         cnt = buf.counts.tolist()
         assert cnt[0] == -1 and cnt[2] == len(cg['rd_nids'])  # lean form taken; unique positives still counted
@@ -306,5 +309,7 @@ def test_prefetched_collate_is_discarded_when_state_offset_or_form_change():
     run(11); run(12); run(13)
     # batches 2, 4, 7, 10, 12, 13 started from a valid prefetch; 3 (flush), 6 (other buffer + offset), 8 (full step),
     # 9 (after the full step: nothing was prefetched), 11 (restart) did not
-    assert model._step_serial == 14 and used.count(1) >= 6
+    assert model._step_serial == 14
+    if os.environ.get('TG_PREFETCH', '1') != '0' and os.environ.get('TG_GTAB', '1') != '0':  # (knobs that switch it off)
+        assert used.count(1) >= 6
     compare_state_with_oracle(model, orc)
