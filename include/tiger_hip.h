@@ -551,8 +551,10 @@ int tg_profiler_read(tg_profiler* p, float* ms_out);
 
 size_t tg_stream_step_workspace_bytes(const tg_model* m, int64_t B);
 size_t tg_stream_step_workspace_bytes2(const tg_model* m, int64_t B, int32_t n_layers); /* n_layers 1 or 2 */
-/* size of the leading workspace region that must be zero when a step starts */
+/* size of the leading workspace region that must be zero when a step starts (a caller that sets ws_is_clean clears
+ * exactly this prefix; with io->inner - two layers - the region is larger: use the second form) */
 size_t tg_stream_step_zero_bytes(const tg_model* m, int64_t B);
+size_t tg_stream_step_zero_bytes2(const tg_model* m, int64_t B, int32_t n_layers); /* n_layers 1 or 2 */
 int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, void* ws, size_t ws_bytes,
                    void* stream);
 

@@ -274,6 +274,11 @@ struct PosArgs {
   // (the winner of its node) or -1 - the scatter list of the product that writes h(t-) straight into the left memory
   // (write-back rider, below)
   int32_t* win_row;
+  // nullable (split updater, tg_step.h: GruSplit): per winner slot the position of the event's OTHER endpoint in
+  // cat[src, dst] and the event's edge id - with `index` the row indices of the four segments of the winner's raw message
+  // [snap[index] | snap[oth] | efeat[weid] | snap_te[index]] (memory.py:89-106), gathered by the product that forms W_ih msg
+  const int64_t* eids;  // [B] edge ids of the batch
+  int64_t *oth, *weid;
 };
 // dedup slot of a node: its rank in the involved set, or (lean steps: no involved set) the node id itself
 __device__ __forceinline__ int64_t pos_slot(const PosArgs& a, int64_t node) {
@@ -321,6 +326,10 @@ __device__ __forceinline__ void pos_winners_pass(const PosArgs& a, int64_t tid, 
       a.upos[slot] = node;
       a.index[slot] = i;
       if (a.upos32) a.upos32[slot] = (int32_t)node;
+      if (a.oth) {
+        a.oth[slot] = i < a.B ? i + a.B : i - a.B;
+        a.weid[slot] = a.eids[e];
+      }
     }
     if (a.win_row) a.win_row[i] = win ? (int32_t)node : -1;
   }
@@ -345,6 +354,10 @@ struct DirectArgs {
   // lean step (no outdated list): the invariants are checked per centre here and per neighbour in the core launch -
   // the same node set, involved & has-message, some nodes more than once
   int per_row_checks;
+  // nullable, with snap: TE(t_i - snap_ts[i]) of the same positions (the time segment of the raw message position i would
+  // store in STEP 5, memory.py:89-106; the same rounding as the mailbox row: time_enc) - the split updater multiplies the
+  // messages of the winning positions by W_ih while the attention block is still running (tg_step.h: GruSplit)
+  float4* snap_te;
 };
 // (`id`: the node's ROW in the state tables, state_row)
 __device__ __forceinline__ void check_msg_times(const tg_model& m, int64_t id, uint32_t* err) {
@@ -411,13 +424,21 @@ __device__ __forceinline__ void centres_direct_body(const tg_model& m, int64_t Q
       if (out) out[t] = v[u];
       if (da.per_row_checks && c[u] == 0 && pending[u]) check_msg_times(m, r[u], da.err);
       if (da.snap && i[u] < da.n_snap) {
+        float mem_ts;
         if (m.msg_src == TG_SRC_LEFT) {
           l[u].x += f[u].x; l[u].y += f[u].y; l[u].z += f[u].z; l[u].w += f[u].w;
           da.snap[t] = l[u];
-          if (c[u] == 0) da.snap_ts[i[u]] = m.left_ts[r[u]];
+          mem_ts = m.left_ts[r[u]];
         } else {
           da.snap[t] = v[u];
-          if (c[u] == 0) da.snap_ts[i[u]] = pending[u] ? m.msg_ts[r[u]] : m.right_ts[r[u]];
+          mem_ts = pending[u] ? m.msg_ts[r[u]] : m.right_ts[r[u]];
+        }
+        if (c[u] == 0) da.snap_ts[i[u]] = mem_ts;
+        if (da.snap_te) {
+          const int64_t hb = da.n_snap >> 1, ev = i[u] < hb ? i[u] : i[u] - hb;  // (n_snap = 2B positions of cat[src, dst])
+          const float dt = ids.tf(ev) - mem_ts;
+          const float4 w = reinterpret_cast<const float4*>(m.te_freq)[c[u]], q = reinterpret_cast<const float4*>(m.te_phase)[c[u]];
+          da.snap_te[t] = make_float4(time_enc(dt, w.x, q.x), time_enc(dt, w.y, q.y), time_enc(dt, w.z, q.z), time_enc(dt, w.w, q.w));
         }
       }
     }

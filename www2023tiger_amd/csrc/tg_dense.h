@@ -65,7 +65,42 @@ struct GemmArgs {
   float* c2;
   const int32_t* c2_rows;
   int64_t c2_m, ldc2;
+  // third and fourth K-slice of A (k_gemm_ks16's second problem only: the raw messages of the split updater are four
+  // gathered segments).  a2.p == nullptr with a2.w > 0: a slice of zeros (no edge table, feature_getter.py:95-99)
+  ASeg a2, a3;
 };
+
+// ---- split updater (streaming with fixed parameters; GRU, raw messages, upd_src = left) --------------------------------
+// The eager updater's row of a positive node v, pending[v] = GRU(msg_v, left[v]) (update_modules.py:33-37 once per stored
+// message, tiger_hip.h: tg_model.pending_vals), has two halves.  gi = W_ih msg_v + b_ih (80 % of the flops) reads the raw
+// message only, which STEP 5 builds from the PRE-batch snapshot (tiger.py:422-442): it does not depend on the attention
+// block and runs as a second problem of fc1's launch (k_gemm_ks16, A = four gathered segments).  gh = W_hh h + b_hh needs
+// h = left[v] = h(t-) of the winning position = fc2's row = W2 t + b2 (basic_modules.py:16-19), which is linear in fc1's
+// output t: with the parameter product W_hh W2 (tg_attn_fuse, the blob's tail) the tail
+//   [h | gh_r | gh_z | gh_n] = t [W2 ; W_hh W2]^T + [b2 ; W_hh b2 + b_hh],   K = d
+// no longer waits for fc2 - it SHARES fc2's launch (GruTail as a rider of k_gemm_direct_r) and finishes the gates.  The
+// step has no updater launch.  h of the tail is bit-identical to fc2's row (same kernel scheme, same k order).
+struct GruTail {
+  int64_t cap;
+  const int32_t* n_dev;     // live rows (the batch's unique positive nodes)
+  int d;
+  const float* t;           // fc1's output [Q, d]
+  const int64_t* t_rows;    // row of t per tail row (the winner's position in cat[src, dst])
+  const float *w, *b;       // [4d, d], [4d]
+  const float* gi;          // [cap, 3d]
+  float* out;               // pending_vals
+  const int32_t* out_rows;  // node (row) per tail row
+  float* out2;              // nullable: c_table, row = out + add2[node]
+  const float* add2;        // nullable: node features
+  int64_t rows_hint;        // 0, or the caller's bound on the live rows (performance only: sizes the blocks)
+  // direct != 0 (the tail as a launch of its own, BEHIND fc2): the rows are read as the reference reads them - t = the
+  // updater-source memory (rows t_rows = node ids), w / b = weight_hh / bias_hh as stored [3d, d]; three planes and h itself
+  int direct;
+  unsigned blocks;          // set by the launcher
+  template <int NS>
+  __device__ void run(unsigned bid) const;
+};
+int gru_tail_launch(const GruTail& t, hipStream_t st);  // the tail as a launch of its own
 constexpr int TG_SK_WORKERS = 256;      // default number of workers (one per CU)
 constexpr int TG_SK_WORKERS_MAX = 512;  // the workspace is sized for this many (TG_SK_WORKERS env knob)
 constexpr size_t TG_SK_WS_FLOATS = (size_t)TG_SK_WORKERS_MAX * 2 * 4096;
@@ -80,13 +115,18 @@ bool gemm_sk_partials(const GemmArgs& g, float* ws, size_t ws_floats, hipStream_
 // Launches the LDS-free K-split kernel for `g` (bias / activation applied: final values) and returns true, or returns
 // false (nothing launched) when the shape does not call for it (tg_gemm.hip: k_gemm_ks16).
 // rider (nullable): the write-back rider shares the launch (*rode tells whether)
-bool gemm_ks16_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider = nullptr, bool* rode = nullptr);
+// second (nullable): another product of the same kind (A of up to four segments) as further persistent blocks of the launch;
+// *second_rode tells whether it was taken (only together with the write-back rider)
+bool gemm_ks16_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider = nullptr, bool* rode = nullptr,
+                      const GemmArgs* second = nullptr, bool* second_rode = nullptr);
 
 // Riders (nullable, one at most): work that shares the launch as its FIRST workgroups - the one-pass write-back (WbRider,
 // tg_common.h) or the collate part of the next batch (CollateRider, tg_sample.h).  Not every kernel hosts them: *rode
 // tells the caller whether the rider was launched - otherwise the caller launches that work itself.
+// tail (nullable, instead of a rider): the split updater's tail shares the launch (LDS-free short-K products only)
+// second (nullable, instead of a rider): a long-K product with A of up to four segments (k_gemm_ks16's blocks) shares it
 int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider = nullptr, bool* rode = nullptr,
-                const CollateRider* collate = nullptr);
+                const CollateRider* collate = nullptr, const GruTail* tail = nullptr, const GemmArgs* second = nullptr);
 
 struct GruArgs {
   int64_t cap;

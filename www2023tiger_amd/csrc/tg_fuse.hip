@@ -84,6 +84,35 @@ __global__ void k_fuse_compact(int d, int de, int nh, const float* __restrict__ 
 
 size_t attn_fused_floats_of(size_t d, size_t nk) { return nk * d + nk + d * (nk + d) + 2 * d; }
 
+// ---- the blob's tail for the split updater (tg_dense.h: GruTail): [W2 ; W_hh W2] [4d, d], then [b2 ; W_hh b2 + b_hh] [4d]
+// (GRUCell weight_hh / bias_hh, update_modules.py:33; the merger's fc2, basic_modules.py:16-19).  Present whenever the model
+// has a GRU updater; tg_stream_step decides whether the step can use it.
+static size_t gru_tail_floats(const tg_model* m) {
+  return (m->upd_fn == TG_UPD_GRU && m->gru_w_hh && m->gru_b_hh && m->attn_fc2.w && m->attn_fc2.b) ? (size_t)4 * m->d * (m->d + 1) : 0;
+}
+static size_t gru_tail_offset(const tg_model* m) {
+  const size_t d = m->d, nk = (size_t)m->n_head * (2 * d + (m->efeats ? m->d_e : 0));
+  return attn_fused_floats_of(d, nk) + (tile_waves_for_shape(m) ? tile_dims(m).floats : 0);
+}
+const float* gru_tail_weights(const tg_model* m) {
+  return (m->attn_fused && gru_tail_floats(m)) ? m->attn_fused + gru_tail_offset(m) : nullptr;
+}
+__global__ void k_tail_bias(int d, const float* __restrict__ w_hh, const float* __restrict__ b_hh, const float* __restrict__ b2,
+                            float* __restrict__ out) {
+  const int lane = lane_id();
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);  // 0 .. 4d - 1
+  if (row >= 4 * d) return;
+  if (row < d) {
+    if (lane == 0) out[row] = b2[row];
+    return;
+  }
+  const int r = row - d;
+  float acc = 0.f;
+  for (int k = lane; k < d; k += TG_WAVE) acc += w_hh[(int64_t)r * d + k] * b2[k];
+  acc = wave_sum(acc);
+  if (lane == 0) out[row] = acc + b_hh[r];
+}
+
 // fragment-major copy of K columns [k_src0, k_src0 + K) of W[N][ldw] into k-chunks [kc_off, kc_off + ceil(K / 16)) of a
 // packed weight with KC chunks per column tile (tg_tile.h); zeros where n >= N or k >= K
 __global__ void k_pack_frag(const float* __restrict__ w, int N, int K, int64_t ldw, int k_src0, float* __restrict__ out,
@@ -110,7 +139,7 @@ extern "C" size_t tg_attn_fused_floats(const tg_model* m) {
   if (!attn_dims_ok(m)) return 0;
   const size_t d = m->d, nk = (size_t)m->n_head * (2 * d + (m->efeats ? m->d_e : 0));  // compact without an edge table
   // + the tile form of the same weights and of fc2 (tg_tile.h) where the one-launch attention applies
-  return attn_fused_floats_of(d, nk) + (tile_waves_for_shape(m) ? tile_dims(m).floats : 0);
+  return attn_fused_floats_of(d, nk) + (tile_waves_for_shape(m) ? tile_dims(m).floats : 0) + gru_tail_floats(m);
 }
 
 extern "C" int tg_attn_tile_applies(const tg_model* m) { return (m && attn_dims_ok(m)) ? attn_tile_applies(m) : 0; }
@@ -191,6 +220,20 @@ extern "C" int tg_attn_fuse(const tg_model* m, float* fused, void* ws, size_t ws
     pack(m->attn_fc2.w, d, d, d, 0, tile + t.o_w2, t.NTd, t.KCd, 0);
     pad(m->attn_fc2.b, d, tile + t.o_b2, t.d_p);
     if ((rc = attn_tile_prepare()) != TG_OK) return rc;
+  }
+  if (gru_tail_floats(m)) {
+    float* wt = fused + gru_tail_offset(m);
+    float* bt = wt + (size_t)4 * d * d;
+    hipError_t e = hipMemcpyAsync(wt, m->attn_fc2.w, (size_t)d * d * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) {
+      set_hip_error(e, "tg_attn_fuse (tail)");
+      return TG_EHIP;
+    }
+    g = GemmArgs{};  // (W_hh W2)[m, n] = sum_k W_hh[m, k] W2[k, n]: the k-major view of W2
+    g.m_cap = 3 * d; g.n = d; g.k = d; g.a0 = ASeg{m->gru_w_hh, d, d, nullptr};
+    g.w = m->attn_fc2.w; g.ldw = d; g.w_kmajor = 1; g.c = wt + (size_t)d * d; g.ldc = d; g.alpha = 1.f; g.nbatch = 1;
+    if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+    hipLaunchKernelGGL(k_tail_bias, dim3((unsigned)cdiv(4 * d, 4)), dim3(256), 0, st, d, m->gru_w_hh, m->gru_b_hh, m->attn_fc2.b, bt);
   }
   return check_launch("tg_attn_fuse");
 }

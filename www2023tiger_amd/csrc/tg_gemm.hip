@@ -873,6 +873,188 @@ __device__ __forceinline__ void gemm_direct_block(const GemmArgs& g, unsigned bi
     if (m0 < M && n0 < g.n) gemm_direct_tile<NS, RW, CW>(g, M, m0, n0);
   }
 }
+// ---- the tail of the split updater (tg_dense.h: GruTail) ----------------------------------------------------------------
+// gemm_direct_tile's scheme with RW = 1 and the four column sets being the four PLANES of one 16-column tile: rows of
+// [W2 ; W_hh W2] at n0 + li + {0, d, 2d, 3d}.  A wavefront owns 16 rows x 16 hidden columns: 4 NS x 4 MFMAs after ONE
+// exposed memory latency, then the gates (update_modules.py:33-37 = torch.nn.GRUCell) with gi read from the buffer the
+// second problem of fc1's launch left.  The h plane is the same k-ordered chain as fc2's row of that position.
+template <int NS, bool DIRECT>
+__device__ __forceinline__ void gru_tail_tile(const GruTail& g, int64_t M, int64_t m0, int n0) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int d = g.d;
+  const int nch = d / 4;  // 16-byte chunks per row
+  // Two passes of two planes each: all four planes' operands at once are 4 NS + NS float4 = 220 registers at d = 172 - one
+  // wavefront per SIMD; here the operands of planes 2, 3 are requested, slot by slot, into the registers planes 0, 1 have
+  // just been multiplied from (their latency hides behind the first pass's MFMAs): 3 NS float4, two wavefronts per SIMD.
+  // DIRECT: planes r, z then n alone over weight_hh as stored; h is read, not computed
+  constexpr int P0 = DIRECT ? 0 : 1;  // weight plane of accumulator 1 (r)
+  float4 a[NS], w[2][NS];
+  unsigned livem = 0u;
+#pragma unroll
+  for (int s_ = 0; s_ < NS; ++s_)
+    if (lk + 4 * s_ < nch) livem |= 1u << s_;
+  {
+    const int64_t m = min(m0 + li, M - 1);
+    const float* row = g.t + g.t_rows[m] * (int64_t)d;
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) a[s_] = ldg4(row + 4 * min(lk + 4 * s_, nch - 1));
+  }
+  const int jc = min(n0 + li, d - 1);
+  const float* wrow = g.w + (int64_t)jc * d;
+  const int64_t ps = (int64_t)d * d;  // plane stride
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) w[p][s_] = ldg4(wrow + (P0 + p) * ps + 4 * min(lk + 4 * s_, nch - 1));
+  float bias[4], gi[4][3], addv[4], hold[4];
+  int orow[4];
+  f32x4m acc[4];  // r, z | n, h
+#pragma unroll
+  for (int p = 0; p < 4; ++p) acc[p] = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    constexpr int NP1 = DIRECT ? 1 : 2;  // planes of the second pass
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) {
+      if (pass == 1 && s_ == NS / 2) {  // epilogue operands behind three quarters of the MFMAs (see gemm_direct_tile)
+        __builtin_amdgcn_sched_barrier(0);
+        if (DIRECT) {
+          bias[3] = 0.f;
+#pragma unroll
+          for (int p = 0; p < 3; ++p) bias[p] = g.b[p * d + jc];
+        } else {
+          bias[3] = g.b[jc];  // h
+#pragma unroll
+          for (int p = 0; p < 3; ++p) bias[p] = g.b[(1 + p) * d + jc];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t m = min(m0 + 4 * lk + q, M - 1);
+          orow[q] = g.out_rows[m];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) gi[q][p] = g.gi[m * 3 * (int64_t)d + p * d + jc];
+          hold[q] = DIRECT ? g.t[g.t_rows[m] * (int64_t)d + jc] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) addv[q] = (g.out2 && g.add2) ? g.add2[(int64_t)orow[q] * d + jc] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const bool lv = (livem >> s_) & 1u;
+      const float4 x = lv ? a[s_] : zero4();
+      const float av[4] = {x.x, x.y, x.z, x.w};
+      float wv[2][4];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        wv[p][0] = w[p][s_].x; wv[p][1] = w[p][s_].y; wv[p][2] = w[p][s_].z; wv[p][3] = w[p][s_].w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int p = 0; p < (pass == 0 ? 2 : NP1); ++p)
+          acc[2 * pass + p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wv[p][j], acc[2 * pass + p], 0, 0, 0);
+      if (pass == 0) {  // this slot's registers are free: the same slot of the remaining planes (n; h = plane 0 of the blob)
+        __builtin_amdgcn_sched_barrier(0);
+        w[0][s_] = ldg4(wrow + (P0 + 2) * ps + 4 * min(lk + 4 * s_, nch - 1));
+        if (!DIRECT) w[1][s_] = ldg4(wrow + 4 * min(lk + 4 * s_, nch - 1));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  const int n = n0 + li;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t m = m0 + 4 * lk + q;
+    const float h = DIRECT ? hold[q] : acc[3][q] + bias[3];
+    const float rg = fast_sigmoid(gi[q][0] + (acc[0][q] + bias[0]));
+    const float zg = fast_sigmoid(gi[q][1] + (acc[1][q] + bias[1]));
+    const float ng = fast_tanh(gi[q][2] + rg * (acc[2][q] + bias[2]));
+    const float hv = (1.f - zg) * ng + zg * h;
+    if (n < d && m < M) {
+      g.out[(int64_t)orow[q] * d + n] = hv;
+      if (g.out2) g.out2[(int64_t)orow[q] * d + n] = hv + addv[q];
+    }
+  }
+}
+// block `bid` of g.blocks (a multiple of 8): four wavefronts = four 16-row tiles of one 16-column tile (the weight slab of
+// the tile is shared through the CU's cache); XCD chunks of the (row group, column tile) sequence
+template <int NS>
+__device__ void GruTail::run(unsigned bid) const {
+  int64_t M = cap;
+  if (n_dev) M = min(M, (int64_t)*n_dev);
+  if (M <= 0) return;
+  const int NT = (d + 15) / 16;
+  const int64_t total = ((M + 63) / 64) * NT;
+  const int64_t per = (total + 7) / 8;
+  const int wave = threadIdx.x >> 6;
+  for (int64_t jx = bid >> 3; jx < per; jx += blocks >> 3) {
+    const int64_t b = (int64_t)(bid & 7) * per + jx;
+    if (b >= total) break;
+    const int64_t mt = b / NT;
+    const int nt = (int)(b - mt * NT);
+    const int64_t m0 = mt * 64 + 16 * wave;
+    if (m0 >= M) continue;
+    if (direct) gru_tail_tile<NS, true>(*this, M, m0, nt * 16);
+    else gru_tail_tile<NS, false>(*this, M, m0, nt * 16);
+  }
+}
+template <int NS>
+__global__ void __launch_bounds__(256) k_gru_tail(GruTail g) {
+  g.run<NS>(blockIdx.x);
+}
+// (the launch of its own always reads h directly: an instance without the pre-multiplied form's fourth plane)
+template <int NS>
+__global__ void __launch_bounds__(256) k_gru_tail_direct(GruTail g) {
+  int64_t M = g.cap;
+  if (g.n_dev) M = min(M, (int64_t)*g.n_dev);
+  if (M <= 0) return;
+  const int NT = (g.d + 15) / 16;
+  const int64_t total = ((M + 63) / 64) * NT;
+  const int64_t per = (total + 7) / 8;
+  const int wave = threadIdx.x >> 6;
+  for (int64_t jx = blockIdx.x >> 3; jx < per; jx += gridDim.x >> 3) {
+    const int64_t b = (int64_t)(blockIdx.x & 7) * per + jx;
+    if (b >= total) break;
+    const int64_t mt = b / NT;
+    const int nt = (int)(b - mt * NT);
+    const int64_t m0 = mt * 64 + 16 * wave;
+    if (m0 < M) gru_tail_tile<NS, true>(g, M, m0, nt * 16);
+  }
+}
+static unsigned gru_tail_blocks(const GruTail& t) {
+  const int64_t rows = t.rows_hint > 0 ? std::min(t.rows_hint, t.cap) : t.cap;
+  return (unsigned)std::min<int64_t>(256, 8 * cdiv(cdiv(rows, 64) * cdiv(t.d, 16), 8));
+}
+int gru_tail_launch(const GruTail& t, hipStream_t st) {
+  if (t.cap <= 0) return TG_OK;
+  const int nsl = (int)cdiv(cdiv(t.d, 4), 4);
+  if ((t.d % 4) || nsl > 11) return TG_EUNSUPPORTED;
+  GruTail g = t;
+  g.blocks = gru_tail_blocks(t);
+  if (g.direct) {
+    if (nsl <= 7) hipLaunchKernelGGL(k_gru_tail_direct<7>, dim3(g.blocks), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(k_gru_tail_direct<11>, dim3(g.blocks), dim3(256), 0, st, g);
+  } else if (nsl <= 7) {
+    hipLaunchKernelGGL(k_gru_tail<7>, dim3(g.blocks), dim3(256), 0, st, g);
+  } else {
+    hipLaunchKernelGGL(k_gru_tail<11>, dim3(g.blocks), dim3(256), 0, st, g);
+  }
+  return check_launch("gru_tail");
+}
+
+template <int NS, class R>
+__device__ __forceinline__ void run_rider(const R& r, unsigned bid) {
+  if constexpr (std::is_same<R, GruTail>::value) r.template run<NS>(bid);
+  else r.run(bid);
+}
+// a long-K product (k_gemm_ks16's 48 x 48 blocks, A of up to four segments) behind a short-K product's blocks: the split
+// updater's W_ih msg shares fc2's launch, whose 144 blocks leave 112 CUs idle at C2
+template <int RT, int CT, int NW, int NSEG>
+__device__ __forceinline__ void gemm_ks16_blocks(const GemmArgs& g, unsigned bid, unsigned nblk, float* sc_raw);
+struct GiRider {
+  GemmArgs g;
+  unsigned blocks;
+};
 template <int NS, int RW, int CW>
 __global__ void __launch_bounds__(256) k_gemm_direct(GemmArgs g) {
   gemm_direct_block<NS, RW, CW>(g, blockIdx.x, gridDim.x);
@@ -881,7 +1063,12 @@ template <class R, int NS, int RW, int CW>
 __global__ void __launch_bounds__(256) k_gemm_direct_r(GemmArgs g, R r) {
   const unsigned own = gridDim.x - r.blocks;  // riders behind the product's blocks
   if (blockIdx.x >= own) {
-    r.run(blockIdx.x - own);
+    if constexpr (std::is_same<R, GiRider>::value) {
+      __shared__ float sc_raw[4 * 3 * 9 * 64];
+      gemm_ks16_blocks<3, 3, 4, 4>(r.g, blockIdx.x - own, r.blocks, sc_raw);
+    } else {
+      run_rider<NS>(r, blockIdx.x - own);
+    }
     return;
   }
   gemm_direct_block<NS, RW, CW>(g, blockIdx.x, own);
@@ -897,20 +1084,29 @@ __global__ void __launch_bounds__(256) k_gemm_direct_r(GemmArgs g, R r) {
 // in one reduce-scatter round through LDS (summed in wavefront order: bit-reproducible) and the first four wavefronts
 // run the epilogue (bias, second bias on valid rows, alpha, ReLU) - the product leaves its final values, so its consumer
 // is a plain product.  256 persistent blocks, XCD chunks of the tile sequence.
-template <int RT, int CT, int NW>
+// NSEG = 4: A is four column segments, every one optionally gathered, the third possibly a slice of zeros (GemmArgs.a2 / a3)
+template <int RT, int CT, int NW, int NSEG = 2>
 __device__ __forceinline__ void gemm_ks16_tile(const GemmArgs& g, int64_t M, int64_t m0, int n0, float* sc_raw) {
   constexpr int NS = RT * CT;  // 16 x 16 subtiles of the block
   float (*sc)[NW - 1][NS][64] = reinterpret_cast<float (*)[NW - 1][NS][64]>(sc_raw);  // [owner 0..3][slot][subtile][lane]
   const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int K = g.k, N = g.n, kw0 = g.a0.w;
+  const int kw1 = kw0 + g.a1.w, kw2 = kw1 + (NSEG == 4 ? g.a2.w : 0);  // segment ends (NSEG = 4)
+  const bool zero2 = NSEG == 4 && !g.a2.p;                              // the third segment is zeros
   const float* ar0[RT];
   const float* ar1[RT];
+  const float* ar2[NSEG == 4 ? RT : 1];
+  const float* ar3[NSEG == 4 ? RT : 1];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const int64_t m = min(m0 + 16 * rt + li, M - 1);
     ar0[rt] = g.a0.p + (g.a0.idx ? g.a0.idx[m] : m) * g.a0.ld;
     ar1[rt] = g.a1.p ? g.a1.p + (g.a1.idx ? g.a1.idx[m] : m) * g.a1.ld - kw0 : ar0[rt];
+    if (NSEG == 4) {
+      ar2[rt] = g.a2.p ? g.a2.p + (g.a2.idx ? g.a2.idx[m] : m) * g.a2.ld - kw1 : ar0[rt];
+      ar3[rt] = g.a3.p ? g.a3.p + (g.a3.idx ? g.a3.idx[m] : m) * g.a3.ld - kw2 : ar0[rt];
+    }
   }
   const float* wr[CT];
 #pragma unroll
@@ -934,14 +1130,22 @@ __device__ __forceinline__ void gemm_ks16_tile(const GemmArgs& g, int64_t M, int
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int k = kb + 4 * q;
-      if (k < K && ks < nkt) A.live |= 1u << q;
+      const bool dead = k >= K || (zero2 && k >= kw1 && k < kw2);  // (a chunk of the zero segment: multiplied as zeros)
+      if (!dead && ks < nkt) A.live |= 1u << q;
       A.kc[q] = k < K ? k : 0;
     }
   };
   auto load_one = [&](int l, const Addr& A, Tile& T) {  // l = 0 .. 2 (RT + CT) - 1
     const int q = l & 1, r = l >> 1;
-    if (r < RT) T.a[r][q] = ldg4((A.kc[q] < kw0 ? ar0[r] : ar1[r]) + A.kc[q]);
-    else T.w[r - RT][q] = ldg4(wr[r - RT] + A.kc[q]);
+    if (r < RT) {
+      const int k = A.kc[q];
+      const float* row;
+      if (NSEG == 4) row = k < kw0 ? ar0[r] : k < kw1 ? ar1[r] : k < kw2 ? ar2[r] : ar3[r];
+      else row = k < kw0 ? ar0[r] : ar1[r];
+      T.a[r][q] = ldg4(row + k);
+    } else {
+      T.w[r - RT][q] = ldg4(wr[r - RT] + A.kc[q]);
+    }
   };
   f32x4m acc[RT][CT];
 #pragma unroll
@@ -1064,14 +1268,9 @@ __device__ __forceinline__ void gemm_ks16_tile(const GemmArgs& g, int64_t M, int
   }
 }
 
-template <class R, int RT, int CT, int NW>
-__global__ void __launch_bounds__(64 * NW) k_gemm_ks16(GemmArgs g, R r) {
-  __shared__ float sc_raw[4 * (NW - 1) * RT * CT * 64];
-  const unsigned own = gridDim.x - r.blocks;  // persistent blocks of the product; riders (if any) sit behind them
-  if (blockIdx.x >= own) {
-    r.run(blockIdx.x - own);
-    return;
-  }
+// persistent blocks of one product: block `bid` of `nblk` (a multiple of 8) works through its XCD's chunk of the tile sequence
+template <int RT, int CT, int NW, int NSEG>
+__device__ __forceinline__ void gemm_ks16_blocks(const GemmArgs& g, unsigned bid, unsigned nblk, float* sc_raw) {
   int64_t M = g.m_cap;
   if (g.m_dev) M = min(M, (int64_t)*g.m_dev);
   if (M <= 0) return;
@@ -1079,26 +1278,60 @@ __global__ void __launch_bounds__(64 * NW) k_gemm_ks16(GemmArgs g, R r) {
   const int NT = (g.n + BN - 1) / BN;
   const int64_t total = ((M + BM - 1) / BM) * NT;
   const int64_t per = (total + 7) / 8;
-  for (int64_t jx = blockIdx.x >> 3; jx < per; jx += own >> 3) {
-    const int64_t b = (int64_t)(blockIdx.x & 7) * per + jx;
+  for (int64_t jx = bid >> 3; jx < per; jx += nblk >> 3) {
+    const int64_t b = (int64_t)(bid & 7) * per + jx;
     if (b >= total) break;
     const int64_t mt = b / NT;
     const int nt = (int)(b - mt * NT);
-    gemm_ks16_tile<RT, CT, NW>(g, M, mt * BM, nt * BN, sc_raw);
+    gemm_ks16_tile<RT, CT, NW, NSEG>(g, M, mt * BM, nt * BN, sc_raw);
     __syncthreads();  // the fold's LDS is re-used by the next tile
+  }
+}
+// A second product in the same launch (S2 = Ks16Second): `blocks` further persistent blocks behind the first product's, in
+// front of the riders.  Two resident blocks per CU then interleave their MFMA streams (one block's four wavefronts - one
+// per SIMD, issuing in order - keep the matrix pipe ~40 % busy).
+struct NoSecond {
+  unsigned blocks;
+};
+struct Ks16Second {
+  GemmArgs g;
+  unsigned blocks;
+  unsigned seq;  // 1: no further blocks - the first product's blocks work through the second product's tiles afterwards
+};
+template <class R, int RT, int CT, int NW, class S2 = NoSecond>
+__global__ void __launch_bounds__(64 * NW) k_gemm_ks16(GemmArgs g, R r, S2 s2) {
+  __shared__ float sc_raw[4 * (NW - 1) * RT * CT * 64];
+  const unsigned own = gridDim.x - r.blocks - s2.blocks;  // persistent blocks of the product; second product, then riders
+  if (blockIdx.x >= own + s2.blocks) {
+    r.run(blockIdx.x - own - s2.blocks);
+    return;
+  }
+  if constexpr (std::is_same<S2, Ks16Second>::value) {
+    if (blockIdx.x >= own) {
+      gemm_ks16_blocks<RT, CT, NW, 4>(s2.g, blockIdx.x - own, s2.blocks, sc_raw);
+      return;
+    }
+  }
+  gemm_ks16_blocks<RT, CT, NW, 2>(g, blockIdx.x, own, sc_raw);
+  if constexpr (std::is_same<S2, Ks16Second>::value) {
+    if (s2.seq) gemm_ks16_blocks<RT, CT, NW, 4>(s2.g, blockIdx.x, own, sc_raw);
   }
 }
 
 // Is the product one for k_gemm_ks16?  Long K, plain epilogue (+ second bias), few enough 48 x 48 tiles that the blocks
 // fit the chip in one round or two.  TG_GEMM_KS16: 0 = off, 8 = eight wavefronts per block.
 static unsigned rider_blocks(int64_t live, int threads, int64_t rows);  // (below, with gemm_launch)
+static bool ks16_second_ok(const GemmArgs* s);
+static unsigned ks16_second_blocks(const GemmArgs& s);
 struct NoRider {  // (k_gemm_ks16 without riders)
   unsigned blocks;
   __device__ __forceinline__ void run(unsigned) const {}
 };
-bool gemm_ks16_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* rode) {
+bool gemm_ks16_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* rode, const GemmArgs* second,
+                      bool* second_rode) {
   static const int knob = getenv("TG_GEMM_KS16") ? atoi(getenv("TG_GEMM_KS16")) : 1;
   if (rode) *rode = false;
+  if (second_rode) *second_rode = false;
   if (!knob || g.m_cap <= 0 || g.nbatch != 1 || g.w_kmajor || g.bias_rs || g.row_valid || g.relu_mask || g.c_rows || g.accumulate ||
       g.c2 || g.ask_part || (g.k % 4) || (g.a0.w % 4) || (g.ldw % 4) || g.a0.w + (g.a1.p ? g.a1.w : 0) != g.k)
     return false;
@@ -1114,15 +1347,16 @@ bool gemm_ks16_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, b
   GemmArgs gd = g;
   gd.dbg = 0;
   const NoRider nr{0u};
+  const NoSecond ns{0u};
   if (ct != 3) {
     // (rows per block: 16 when that fits the chip at once, else 32)
     const bool r1 = cdiv(g.m_cap, 16) * ntc <= 256;
     if (ct == 4) {
-      if (r1) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 1, 4, 4>), dim3(256), dim3(256), 0, st, gd, nr);
-      else hipLaunchKernelGGL((k_gemm_ks16<NoRider, 2, 4, 4>), dim3(256), dim3(256), 0, st, gd, nr);
+      if (r1) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 1, 4, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
+      else hipLaunchKernelGGL((k_gemm_ks16<NoRider, 2, 4, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
     } else {
-      if (r1) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 1, 7, 4>), dim3(256), dim3(256), 0, st, gd, nr);
-      else hipLaunchKernelGGL((k_gemm_ks16<NoRider, 2, 7, 4>), dim3(256), dim3(256), 0, st, gd, nr);
+      if (r1) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 1, 7, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
+      else hipLaunchKernelGGL((k_gemm_ks16<NoRider, 2, 7, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
     }
     return true;
   }
@@ -1140,16 +1374,30 @@ bool gemm_ks16_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, b
       const int64_t live = std::min<int64_t>(256, cdiv(g.m_cap, 16 * rt) * nt48);
       wr.blocks = rider_blocks(live, 256, 2 * wr.a.B);
       wr.last = 1u;
-      const dim3 gr(256 + wr.blocks);
-      hipLaunchKernelGGL((k_gemm_ks16<WbRider, 3, 3, 4>), gr, dim3(256), 0, st, gd, wr);
+      // (second product: plain epilogue, A of up to four segments, K a multiple of 4, final values)
+      const bool two = second_rode && ks16_second_ok(second);
+      if (two) {
+        Ks16Second s2{*second, 0u, 0u};
+        s2.g.dbg = 0;
+        // TG_KS16_SECOND (tuning knob): 0 = co-resident blocks of the second product, 1 = the same blocks, afterwards
+        static const int seq_knob = getenv("TG_KS16_SECOND") ? atoi(getenv("TG_KS16_SECOND")) : 1;
+        s2.seq = seq_knob == 1 ? 1u : 0u;
+        s2.blocks = s2.seq ? 0u : ks16_second_blocks(*second);
+        const dim3 gr2(256 + s2.blocks + wr.blocks);
+        hipLaunchKernelGGL((k_gemm_ks16<WbRider, 3, 3, 4, Ks16Second>), gr2, dim3(256), 0, st, gd, wr, s2);
+        *second_rode = true;
+      } else {
+        const dim3 gr(256 + wr.blocks);
+        hipLaunchKernelGGL((k_gemm_ks16<WbRider, 3, 3, 4>), gr, dim3(256), 0, st, gd, wr, ns);
+      }
       *rode = true;
       return true;
     }
   }
-  if (knob == 8) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 3, 3, 8>), dim3(256), dim3(512), 0, st, gd, nr);
-  else if (rt == 1) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 1, 3, 4>), dim3(256), dim3(256), 0, st, gd, nr);
-  else if (rt == 2) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 2, 3, 4>), dim3(256), dim3(256), 0, st, gd, nr);
-  else hipLaunchKernelGGL((k_gemm_ks16<NoRider, 3, 3, 4>), dim3(256), dim3(256), 0, st, gd, nr);
+  if (knob == 8) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 3, 3, 8>), dim3(256), dim3(512), 0, st, gd, nr, ns);
+  else if (rt == 1) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 1, 3, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
+  else if (rt == 2) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 2, 3, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
+  else hipLaunchKernelGGL((k_gemm_ks16<NoRider, 3, 3, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
   return true;
 }
 
@@ -1239,9 +1487,22 @@ static void collate_blocks(CollateRider& c) {
   c.last = 1u;
 }
 
-int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* rode, const CollateRider* collate) {
+// may the product ride as k_gemm_ks16 blocks (plain epilogue, final values, A of two to four segments)?
+static bool ks16_second_ok(const GemmArgs* s) {
+  return s && s->m_cap > 0 && s->nbatch == 1 && !s->w_kmajor && !s->bias_rs && !s->row_valid && !s->relu_mask && !s->c_rows &&
+         !s->accumulate && !s->c2 && !s->ask_part && !(s->k % 4) && !(s->a0.w % 4) && !(s->a1.w % 4) && !(s->a2.w % 4) &&
+         !(s->ldw % 4) && s->a0.w + s->a1.w + s->a2.w + s->a3.w == s->k && s->a0.p && (s->a1.p || !s->a1.w) && (s->a3.p || !s->a3.w);
+}
+static unsigned ks16_second_blocks(const GemmArgs& s) {
+  const int64_t rows2 = s.m_hint > 0 ? std::min(s.m_hint, s.m_cap) : s.m_cap;
+  return (unsigned)std::min<int64_t>(256, 8 * cdiv(cdiv(rows2, 48) * cdiv(s.n, 48), 8));
+}
+int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* rode, const CollateRider* collate,
+                const GruTail* tail, const GemmArgs* second) {
   if (rode) *rode = false;
-  if ((rider || collate) && (!rode || (rider && collate))) return TG_EINVAL;
+  if ((rider || collate || tail || second) &&
+      (!rode || ((rider != nullptr) + (collate != nullptr) + (tail != nullptr) + (second != nullptr) > 1)))
+    return TG_EINVAL;
   if (g.c2 && (g.bias_rs || g.bias2 || g.row_valid || g.relu_mask || g.c_rows || g.accumulate || !g.c2_rows || g.nbatch != 1))
     return TG_EINVAL;  // the second destination exists in the plain epilogue only
   if (g.m_cap <= 0) return TG_OK;
@@ -1249,7 +1510,7 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
   if (g.w_kmajor && (g.n % 4)) return TG_EINVAL;
   if (g.a0.w + (g.a1.p ? g.a1.w : 0) != g.k) return TG_EINVAL;
   // long K, few tiles: LDS-free K-split blocks (k_gemm_ks16)
-  if (!rider && !collate && !g.bias2 && gemm_ks16_launch(g, st)) return check_launch("gemm(ks16)");
+  if (!rider && !collate && !tail && !second && !g.bias2 && gemm_ks16_launch(g, st)) return check_launch("gemm(ks16)");
   constexpr int BM = 64, BN = 64;
   const int64_t MT = cdiv(g.m_cap, BM);
   const int NT = (int)cdiv(g.n, BN);
@@ -1313,6 +1574,14 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
       const bool ride = nsl <= 11;  // (the K <= 192 instance hosts no riders)
       CollateRider co = (collate && ride) ? *collate : CollateRider{};
       WbRider wr = (rider && ride) ? *rider : WbRider{};
+      GruTail tl = (tail && ride && (int)cdiv(cdiv(tail->d, 4), 4) == nsl) ? *tail : GruTail{};
+      if (tl.cap > 0) tl.blocks = gru_tail_blocks(tl);
+      GiRider gi{};
+      if (ride && ks16_second_ok(second)) {
+        gi.g = *second;
+        gi.g.dbg = 0;
+        gi.blocks = ks16_second_blocks(*second);
+      }
       if (collate && ride) collate_blocks(co);
       if (rider && ride) {
         wr.blocks = rider_blocks(std::min<int64_t>(tiles64, 256), 256, 2 * wr.a.B);
@@ -1320,10 +1589,14 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
       } else {
         no_ride();
       }
-      const dim3 gr(own + co.blocks + wr.blocks);
+      const dim3 gr(own + co.blocks + wr.blocks + tl.blocks + gi.blocks);
 #define TG_DIRECT(NS_)                                                                                                  \
   do {                                                                                                                  \
-    if (wr.blocks && wide) hipLaunchKernelGGL((k_gemm_direct_r<WbRider, NS_, 2, 3>), gr, dim3(256), 0, st, gd, wr);      \
+    if (gi.blocks && wide) hipLaunchKernelGGL((k_gemm_direct_r<GiRider, NS_, 2, 3>), gr, dim3(256), 0, st, gd, gi);       \
+    else if (gi.blocks) hipLaunchKernelGGL((k_gemm_direct_r<GiRider, NS_, 2, 2>), gr, dim3(256), 0, st, gd, gi);         \
+    else if (tl.blocks && wide) hipLaunchKernelGGL((k_gemm_direct_r<GruTail, NS_, 2, 3>), gr, dim3(256), 0, st, gd, tl);  \
+    else if (tl.blocks) hipLaunchKernelGGL((k_gemm_direct_r<GruTail, NS_, 2, 2>), gr, dim3(256), 0, st, gd, tl);         \
+    else if (wr.blocks && wide) hipLaunchKernelGGL((k_gemm_direct_r<WbRider, NS_, 2, 3>), gr, dim3(256), 0, st, gd, wr);      \
     else if (wr.blocks) hipLaunchKernelGGL((k_gemm_direct_r<WbRider, NS_, 2, 2>), gr, dim3(256), 0, st, gd, wr);        \
     else if (co.blocks && wide) hipLaunchKernelGGL((k_gemm_direct_r<CollateRider, NS_, 2, 3>), gr, dim3(256), 0, st, gd, co); \
     else if (co.blocks) hipLaunchKernelGGL((k_gemm_direct_r<CollateRider, NS_, 2, 2>), gr, dim3(256), 0, st, gd, co);   \
@@ -1334,7 +1607,7 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
       else if (nsl <= 11) TG_DIRECT(11);
       else hipLaunchKernelGGL((k_gemm_direct<12, 2, 2>), dim3(own), dim3(256), 0, st, gd);
 #undef TG_DIRECT
-      if ((collate || rider) && ride) *rode = true;
+      if (((collate || rider) && ride) || tl.blocks || gi.blocks) *rode = true;
       return check_launch("gemm(direct)");
     }
   }

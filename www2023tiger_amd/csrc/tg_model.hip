@@ -522,7 +522,7 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
                               const int64_t* l1_nids, const int64_t* l1_eids, const float* l1_ts, const float* reprs,
                               const uint64_t* bm, const uint32_t* rank, float* out, const AttnWs& w, hipStream_t st,
                               tg_profiler* pf, const PosArgs* pos, const DirectArgs* da, bool centres_done,
-                              const float* key_rows, bool use_gtab, const WbRider* wbr, bool* wb_rode) {
+                              const float* key_rows, bool use_gtab, const WbRider* wbr, bool* wb_rode, GruSplit* gs) {
   // stage numbering of the profiler is kept: q -> "merged q+g", g -> skipped, v/out -> skipped, fc1 -> fused
   int stage = ST_ATTN_FIRST + 1;
   const int d = m->d;
@@ -572,7 +572,9 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
   // short-K product
   SkPlan sk{};
   bool wb_on_fc1 = false;  // the write-back rider on the fc1 launch: then fc2 only stores STEP 6's rows (c2)
-  const bool ks16 = gemm_ks16_launch(g, st, (wbr && pos && pos->win_row) ? wbr : nullptr, &wb_on_fc1);
+  bool gi_rode = false;  // the split updater's input-side product as a second problem of this launch (variant 1)
+  const bool ks16 = gemm_ks16_launch(g, st, (wbr && pos && pos->win_row) ? wbr : nullptr, &wb_on_fc1,
+                                     (gs && gs->variant == 1) ? &gs->gi : nullptr, &gi_rode);
   const bool pieces = !ks16 && gemm_sk_partials(g, w.sk, TG_SK_WS_FLOATS, st, &sk);
   if (!ks16 && !pieces && (rc = gemm_launch(g, st)) != TG_OK) return rc;
   prof_mark(pf, stage++, st);
@@ -591,7 +593,20 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
   } else {
     wbr = nullptr;
   }
-  if (wb_on_fc1) {  // ... or rode on fc1's already
+  if (wb_on_fc1 && gs && gs->variant == 2) {
+    // ... and the split updater's W_ih msg shares THIS launch (variant 2): fc2's 144 blocks leave 112 CUs idle at C2 and its
+    // other blocks finish early; the tail then is a short launch of its own behind it (step_writeback_b)
+    bool gi_here = false;
+    if ((rc = gemm_launch(g, st, nullptr, &gi_here, nullptr, nullptr, &gs->gi)) != TG_OK) return rc;
+    gs->gi_done = gi_here;
+    rode = true;
+  } else if (wb_on_fc1 && gi_rode) {  // ... and the updater's tail shares this launch (it reads t, like fc2)
+    bool tail_rode = false;
+    if ((rc = gemm_launch(g, st, nullptr, &tail_rode, nullptr, &gs->tail)) != TG_OK) return rc;
+    if (!tail_rode && (rc = gru_tail_launch(gs->tail, st)) != TG_OK) return rc;
+    gs->done = true;
+    rode = true;
+  } else if (wb_on_fc1) {  // ... or rode on fc1's already
     if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
     rode = true;
   } else if ((rc = gemm_launch(g, st, wbr, &rode)) != TG_OK) {
@@ -606,15 +621,16 @@ int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float*
                  const uint32_t* rank, float* out, const AttnWs& w, hipStream_t st, tg_profiler* pf = nullptr,
                  const DropCfg* drop = nullptr, const PosArgs* pos = nullptr, const DirectArgs* da = nullptr,
                  const float* key_rows = nullptr, bool centres_done = false, bool use_gtab = false,
-                 const WbRider* wbr = nullptr, bool* wb_rode = nullptr) {
+                 const WbRider* wbr = nullptr, bool* wb_rode = nullptr, GruSplit* gs = nullptr) {
   if (wb_rode) *wb_rode = false;
+  if (gs) gs->done = false;
   const DropCfg dc = drop ? *drop : DropCfg{};
   int stage = ST_ATTN_FIRST;
   prof_mark(pf, stage++, st);
   const int d = m->d, d_e = m->d_e, kvw = 2 * d + d_e, nh = m->n_head, dh = 2 * d / nh, E = 2 * d;
   if (m->attn_fused && dc.p == 0.f)  // (the pre-multiplied weights do not care where the node part of a key row comes from)
     return attn_forward_fused(m, Q, nids, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, out, w, st, pf, pos, da, centres_done,
-                              key_rows, use_gtab && m->g_table && !key_rows, wbr, wb_rode);
+                              key_rows, use_gtab && m->g_table && !key_rows, wbr, wb_rode, gs);
   const int qblocks = (int)cdiv(2 * d, 4);
   if (da) {  // the constant half of the query projection from the rank-form kernel (no centre rows), then the direct centres
     hipLaunchKernelGGL(k_attn_centres, dim3(1 + qblocks), dim3(256), 0, st, (int64_t)0, d / 4, nids, (const float4*)reprs, bm,
@@ -1064,7 +1080,21 @@ bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w, int n_layer
     w.emb2 = cv.take<float>(Q2 * m->d);
     if (!carve_attn(m, (int64_t)Q2, cv, w.attn2)) return false;
   }
+  w.snap_te = cv.take<float>((size_t)2 * B * m->d);
+  w.oth = cv.take<int64_t>((size_t)2 * B);
+  w.weid = cv.take<int64_t>((size_t)2 * B);
+  w.gi = cv.take<float>((size_t)2 * B * 3 * m->d);
   return cv.ok;
+}
+// the carve above on a dry run: workspace size and the must-be-zero prefix without a second copy of the layout
+static bool carve_dry(const tg_model* m, int64_t B, int n_layers, size_t* bytes, size_t* zero_bytes) {
+  char* const base = reinterpret_cast<char*>((uintptr_t)1 << 20);  // never dereferenced
+  Carver cv(base, (size_t)1 << 60);
+  StepWs w{};
+  if (!carve_step(m, B, cv, w, n_layers)) return false;
+  if (bytes) *bytes = (size_t)(cv.p - base);
+  if (zero_bytes) *zero_bytes = w.zero_bytes;
+  return true;
 }
 }  // namespace tg
 
@@ -1074,24 +1104,16 @@ extern "C" size_t tg_stream_step_workspace_bytes(const tg_model* m, int64_t B) {
 }
 extern "C" size_t tg_stream_step_workspace_bytes2(const tg_model* m, int64_t B, int32_t n_layers) {
   if (!attn_dims_ok(m) || B <= 0 || m->n_nodes <= 0 || (n_layers != 1 && n_layers != 2)) return 0;
-  const size_t Q = 3 * (size_t)B, K = m->n_neighbors, cap = (size_t)involved_cap(m, B, n_layers), W = (m->n_nodes + 63) / 64;
-  size_t b = align16(W * 64) + align16(W * 8) + align16(cap * 8) + 32 + 2 * align16((W + 1) * 4) + align16(2 * B * 4) * 2 +
-             align16(2 * B * m->d * 4) + align16(2 * B * 4) + align16(Q * 8) * 2 + align16(B * 8) +
-             align16(Q * 4) + align16(Q * K * 8) * 2 + align16(Q * K * 4) + align16(cap * 8) * 2 + align16(cap * 4) +
-             align16(2 * B * 8) * 2 + align16(cap * m->d * 4) + align16(tg_unique_compact_workspace_bytes(m->n_nodes)) +
-             attn_ws_bytes(m, Q) + align16(apply_ws_bytes(m, cap)) + align16((size_t)m->n_nodes * 8);
-  if (n_layers == 2) {
-    const size_t Q2 = Q * K;
-    b += align16(Q2 * K * 8) * 2 + align16(Q2 * K * 4) + align16(Q2 * 4) + align16(Q2 * m->d * 4) + attn_ws_bytes(m, Q2);
-  }
-  return b + 256;
+  size_t b = 0;
+  return tg::carve_dry(m, B, n_layers, &b, nullptr) ? b + 256 : 0;
 }
 
-extern "C" size_t tg_stream_step_zero_bytes(const tg_model* m, int64_t B) {
-  if (!attn_dims_ok(m) || B <= 0 || m->n_nodes <= 0) return 0;
-  const size_t cap = 3 * (size_t)B * (m->n_neighbors + 1), W = (m->n_nodes + 63) / 64;
-  return align16(W * 64) + align16(cap * 8) + 32;
+extern "C" size_t tg_stream_step_zero_bytes2(const tg_model* m, int64_t B, int32_t n_layers) {
+  if (!attn_dims_ok(m) || B <= 0 || m->n_nodes <= 0 || (n_layers != 1 && n_layers != 2)) return 0;
+  size_t z = 0;
+  return tg::carve_dry(m, B, n_layers, nullptr, &z) ? z : 0;
 }
+extern "C" size_t tg_stream_step_zero_bytes(const tg_model* m, int64_t B) { return tg_stream_step_zero_bytes2(m, B, 1); }
 
 namespace tg {
 __global__ void k_slot_times(int64_t n, int K, const float* __restrict__ ts, float* __restrict__ out) {
@@ -1104,6 +1126,7 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
                  tg_profiler* pf, const DropCfg* drop, bool eager) {
   w.eager = eager;
   w.wb_rode = false;
+  w.upd_done = false;
   const tg_model* inner = w.h2n ? io->inner : nullptr;  // two attention layers (the workspace was carved for them)
   const int64_t B = io->B, Q = 3 * B, K = m->n_neighbors, cap = involved_cap(m, B, inner ? 2 : 1);
   prof_mark(pf, ST_QUERIES, st);
@@ -1150,6 +1173,19 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   // (not with io->h_new: those rows are read from the tables after the attention block, i.e. before STEP 4 must run)
   const bool want_rider = w.fused_wb && wbr_knob != 0 && !drop && !io->h_new;
   if (want_rider) pos.win_row = w.win_row;
+  // split updater (tg_dense.h: GruTail; VERDICT r03 task 1a): the updater's input-side product W_ih msg - 80 % of its flops,
+  // independent of the attention block - leaves the updater launch.  Needs the raw messages as gathered segments of the
+  // snapshot (GRU, no message transform), h = this batch's h(t-) (upd_src = left: fc2's rows), the per-node tables and the
+  // write-back rider's winner lists.  TG_GRU_SPLIT: 1 = W_ih msg as a second problem of fc1's launch + the tail (W_hh h
+  // through the parameter product W_hh W2, gates) on fc2's launch: NO updater launch; 2 = W_ih msg on fc2's launch + the
+  // tail as a short launch behind it.  Both parity-green, both measured NOT faster at C2 (MI355X, 100 replays; 0 / 1 / 2:
+  // 83.7-86.4 / 83.7-85.0 / 86.5-87.8 us per step on three boxes): a 48 x 48 x 688 tile costs its launch 11-14 us wherever
+  // it rides (fc1 25.0 -> 39.5 us, fc2 13.0 -> 24.2 us by HIP events) against the 16.3 us the updater launch gives back,
+  // and one fork / join inside the captured graph costs more than the product (tools/micro/fork_join.py).  Default 0.
+  static const int split_knob = getenv("TG_GRU_SPLIT") ? atoi(getenv("TG_GRU_SPLIT")) : 0;
+  const float* tail_w = gru_tail_weights(m);
+  const bool split_ok = tail_w && m->upd_fn == TG_UPD_GRU && m->tsfm == TG_TSFM_ID && m->upd_src == TG_SRC_LEFT;
+  if (want_rider && split_ok) { pos.eids = w.eids; pos.oth = w.oth; pos.weid = w.weid; }
   const PosArgs* pp = (io->embed_only && !untouched) ? nullptr : &pos;
   // eager query rows: a full eager step of a model that carries the table (it refreshes the table at its end)
   // (with the in-step restart loop: only with the centre-row table, whose rows of the re-initialised nodes the loop's
@@ -1173,8 +1209,10 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
       return TG_EHIP;
     }
   }
-  const DirectArgs da{w.lean ? nullptr : w.outdated, w.counts + 1, cap, io->err, w.fused_wb ? (float4*)w.snap : nullptr,
-                      w.snap_ts, 2 * B, w.lean ? 1 : 0};
+  DirectArgs da{w.lean ? nullptr : w.outdated, w.counts + 1, cap, io->err, w.fused_wb ? (float4*)w.snap : nullptr,
+                w.snap_ts, 2 * B, w.lean ? 1 : 0};
+  if (w.fused_wb && split_ok) da.snap_te = (float4*)w.snap_te;  // (whenever the snapshot is taken: a prefetched collate of
+                                                                //  this batch ran before this step chose its form)
   // lean: the centres need nothing the sampler produces and share its launch
   // (with the per-node table of centre rows - tg_model.c_table, a step that uses the query-row table - no per-batch copy
   // of the centre rows is made: the centres pass keeps its checks, the first dedup pass and the snapshot)
@@ -1256,10 +1294,39 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
     wbr.a.snap = w.snap;
     wbr.a.snap_ts = w.snap_ts;
   }
+  GruSplit gs{};
+  gs.variant = split_knob;
+  const bool gsplit = split_knob != 0 && split_ok && want_rider && pp && w.gtab && m->c_table && !lz && !inner && !key_rows;
+  if (gsplit) {
+    const int d = m->d, mw = 3 * d + m->d_e;
+    GemmArgs& gi = gs.gi;  // gi = [snap[index] | snap[oth] | efeat[weid] | snap_te[index]] W_ih^T + b_ih over the winners
+    gi.m_cap = 2 * B; gi.m_dev = w.counts + 2; gi.m_hint = io->rows_hint; gi.n = 3 * d; gi.k = mw;
+    gi.a0 = ASeg{w.snap, d, d, w.index};
+    gi.a1 = ASeg{w.snap, d, d, w.oth};
+    gi.a2 = ASeg{m->efeats, m->d_e, m->d_e, w.weid};  // (no edge table: a slice of zeros)
+    gi.a3 = ASeg{w.snap_te, d, d, w.index};
+    gi.w = m->gru_w_ih; gi.ldw = mw; gi.bias = m->gru_b_ih; gi.c = w.gi; gi.ldc = 3 * d; gi.alpha = 1.f; gi.nbatch = 1;
+    GruTail& t = gs.tail;
+    t.cap = 2 * B; t.n_dev = w.counts + 2; t.d = d; t.t = w.attn.t; t.t_rows = w.index;
+    t.w = tail_w; t.b = tail_w + (size_t)4 * d * d; t.gi = w.gi;
+    t.out = m->pending_vals; t.out_rows = w.upos32; t.out2 = m->c_table; t.add2 = m->nfeats; t.rows_hint = io->rows_hint;
+    if (gs.variant == 2) {  // the tail behind fc2, reading what the reference reads: left[v] and weight_hh / bias_hh
+      t.direct = 1; t.t = m->left_vals; t.t_rows = w.upos; t.w = m->gru_w_hh; t.b = m->gru_b_hh;
+      // ... and W_ih msg over the mailbox rows the write-back rider has just stored (on fc1's launch)
+      static const int box_knob = getenv("TG_GRU_SPLIT_BOX") ? atoi(getenv("TG_GRU_SPLIT_BOX")) : 1;
+      if (box_knob) {
+        gi.a0 = ASeg{m->msg_vals, mw, mw, w.upos};
+        gi.a1 = gi.a2 = gi.a3 = ASeg{};
+      }
+    }
+  }
   if ((rc = attn_forward(m, Q, w.nids3, w.ts3f, w.l1n, w.l1e, w.l1t, w.reprs, w.bm, w.rank, io->h, w.attn, st, pf,
                          drop, pp, w.direct ? &da : nullptr, key_rows, w.lean && !recent_nodes && !lz, w.gtab,
-                         want_rider ? &wbr : nullptr, &w.wb_rode)) != TG_OK)
+                         want_rider ? &wbr : nullptr, &w.wb_rode, gsplit ? &gs : nullptr)) != TG_OK)
     return rc;
+  w.upd_done = gs.done;
+  w.tail_pending = gsplit && gs.variant == 2 && gs.gi_done;
+  if (w.tail_pending) w.tail = gs.tail;
   prof_mark(pf, ST_DEDUP, st);
   if (io->h_new) {  // h(t'+) rows of cat[src, dst]: reprs[local(node)], or the table rows themselves
     if (w.direct)
@@ -1369,7 +1436,9 @@ int step_writeback_b(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, 
       co.stream_len = io->stream_len;
     }
     const bool ctab = cr && m->c_table;  // ... or straight into the per-node table of centre rows
-    if ((rc = apply_messages(m, w.upos, w.upos32, n_upos, P, m->pending_vals, io->err, w.apply_ws, w.apply_bytes, st,
+    if (w.tail_pending && (rc = gru_tail_launch(w.tail, st)) != TG_OK) return rc;  // (split updater, variant 2)
+    if (!w.upd_done && !w.tail_pending &&  // (split updater: these rows were finished on fc2's launch)
+        (rc = apply_messages(m, w.upos, w.upos32, n_upos, P, m->pending_vals, io->err, w.apply_ws, w.apply_bytes, st,
                              true, nullptr, bound, cr ? (ctab ? m->c_table : w.attn.t) : nullptr, cr ? m->nfeats : nullptr,
                              ctab)) != TG_OK)
       return rc;

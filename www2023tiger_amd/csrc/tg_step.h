@@ -76,7 +76,23 @@ struct StepWs {
   int64_t *h2n, *h2e;
   float *h2t, *ts2, *emb2;
   AttnWs attn2;
+  // split updater (tg_dense.h: GruTail): time segments of the 2B snapshot positions, the winners' other-endpoint positions
+  // and edge ids, W_ih msg + b_ih of the winners
+  float *snap_te, *gi;
+  int64_t *oth, *weid;
+  bool upd_done;  // the eager updater's rows of this batch were finished inside the attention block's launches
+  bool tail_pending;  // ... or their input-side product was (on fc2's launch): the tail is launched where the updater was
+  GruTail tail;
 };
+// one step's plan of the split updater: the second problem of fc1's launch and the tail on fc2's (attn_forward_fused)
+struct GruSplit {
+  GemmArgs gi;
+  GruTail tail;
+  int variant;   // 1: gi on fc1's launch + tail on fc2's (pre-multiplied W_hh W2); 2: gi on fc2's launch + the tail behind it
+  bool gi_done;  // variant 2: gi rode on fc2's launch
+  bool done;     // variant 1: the rows are finished
+};
+const float* gru_tail_weights(const tg_model* m);  // the tail of the tg_attn_fuse blob, or nullptr (tg_fuse.hip)
 
 bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w, int n_layers = 1);
 int attn_dims_ok(const tg_model* m);

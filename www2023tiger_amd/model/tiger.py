@@ -367,8 +367,10 @@ class TIGE(nn.Module):
         return pl
 
     def _attn_stamp(self):
-        """versions of everything the pre-multiplied attention weights are made of"""
-        return [p._version for p in self._param_lists()[1]]
+        """versions of everything the pre-multiplied weights are made of: attention + time encoder, and - the blob's tail
+        for the split updater, W_hh W2 (csrc/tg_dense.h: GruTail) - the updater's parameters"""
+        pl = self._param_lists()
+        return [p._version for p in pl[1]] + [p._version for p in pl[0]]
 
     def _sync_pending(self):
         """Rebuild the table of precomputed updater rows if state changed outside the eager step:
