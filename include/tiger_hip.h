@@ -238,7 +238,11 @@ typedef struct tg_model {
    * the rows pulled from other owners (the caller points row_of at them before the step).  Node ids everywhere else - the
    * T-CSR, the batch arrays, neighbour lists, feature tables, the owner table - stay global.  Honoured by the embedding
    * step (tg_stream_step with embed_only + lean on a model with pending_vals) and by the planned, owner-filtered
-   * tg_stream_writeback; every other entry point addresses state by node id and refuses a model that carries it. */
+   * tg_stream_writeback.  Row-addressed by contract (their id lists are ROWS of this process's tables on such a model -
+   * the caller translates its node lists once, when it plans a batch): tg_serve_rows, tg_adopt_rows, tg_gather_eff_rows,
+   * tg_apply_messages.  Every other entry point that addresses state by node id - tg_mailbox_consume_gather,
+   * tg_consume_update_right(_rows), tg_store_events, tg_restart_seq_fwd(_train), tg_restart_apply, tg_train_step, the full
+   * tg_stream_step, tg_attn_gtab_rows - returns TG_EUNSUPPORTED for a model that carries it. */
   const int32_t* row_of;
   /* Optional (NULL = off; needs attn_fused and pending_vals): EAGER QUERY ROWS for streaming with FIXED parameters.
    * g_table [n_nodes, n_head * kvw'] (kvw' as in attn_fused) holds, for every node v, the folded query of the first
@@ -557,6 +561,17 @@ size_t tg_stream_step_zero_bytes(const tg_model* m, int64_t B);
 size_t tg_stream_step_zero_bytes2(const tg_model* m, int64_t B, int32_t n_layers); /* n_layers 1 or 2 */
 int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, void* ws, size_t ws_bytes,
                    void* stream);
+/* The form tg_stream_step(m, ., io, ..) takes, as a mask of TG_FORM_*: the library's own decision (field values AND its
+ * tuning knobs), so that a host that keeps derived tables does not have to restate it.  TG_FORM_TABLES: the step reads
+ * the per-node tables (tg_model.g_table / c_table) and leaves them current - rows of the batch's positive nodes and, with
+ * the in-step restart loop, of the nodes it re-initialises; a step WITHOUT the bit on a model that carries the tables
+ * leaves them stale wherever it changes state (the in-step restart loop, tg_lazy_restart), and the host must rebuild
+ * them (tg_attn_gtab_rows) before a later step that has the bit. */
+#define TG_FORM_DIRECT 1   /* rows read from pending / right by node id: no compact copy of the involved rows */
+#define TG_FORM_FUSED_WB 2 /* STEP 4-6 as one pass (possibly riding on the attention block's launches) */
+#define TG_FORM_LEAN 4     /* no involved / outdated sets are formed */
+#define TG_FORM_TABLES 8   /* reads and maintains g_table / c_table */
+int32_t tg_stream_step_form(const tg_model* m, const tg_step_io* io);
 
 /* ------------------------------------------------------------------------- */
 /* Training tail: STEP 7, backward pass, Adam            */

@@ -161,6 +161,7 @@ SIGNATURES = {
     'tg_stream_step_workspace_bytes2': (sz, [P(TgModel), i64, i32]),
     'tg_stream_step_zero_bytes': (sz, [P(TgModel), i64]),
     'tg_stream_step_zero_bytes2': (sz, [P(TgModel), i64, i32]),
+    'tg_stream_step_form': (i32, [P(TgModel), P(TgStepIo)]),
     'tg_stream_step': (C.c_int, [P(TgModel), P(TgTcsr), P(TgStepIo), vp, sz, vp]),
     'tg_train_step_workspace_bytes': (sz, [P(TgModel), P(TgScoreParams), i32, vp, i64]),
     'tg_train_step': (C.c_int, [P(TgModel), P(TgTcsr), P(TgTrainIo), vp, sz, vp]),

@@ -430,6 +430,7 @@ extern "C" int tg_memory_scatter2(int64_t n, const int32_t* n_dev, const int64_t
 
 extern "C" int tg_mailbox_consume_gather(const tg_model* m, const int64_t* involved, const int32_t* n_involved,
                                          int64_t cap, float* reprs, void* stream) {
+  if (m && m->row_of) return TG_EUNSUPPORTED;  // state addressed by node id: not on physically partitioned tables (tg_model.row_of)
   if (!model_ok(m) || cap < 0) return TG_EINVAL;
   if (cap == 0) return TG_OK;
   if (!involved || !n_involved || !reprs) return TG_EINVAL;
@@ -442,6 +443,7 @@ extern "C" int tg_mailbox_consume_gather(const tg_model* m, const int64_t* invol
 extern "C" int tg_consume_update_right(const tg_model* m, const int64_t* upos, const int32_t* n_upos, int64_t cap,
                                        const float* reprs, const uint64_t* bitmap, const uint32_t* rank, uint32_t* err,
                                        void* stream) {
+  if (m && m->row_of) return TG_EUNSUPPORTED;  // state addressed by node id: not on physically partitioned tables (tg_model.row_of)
   if (!model_ok(m) || cap < 0) return TG_EINVAL;
   if (cap == 0) return TG_OK;
   if (!upos || !n_upos || !reprs || !bitmap || !rank || !err) return TG_EINVAL;
@@ -452,6 +454,7 @@ extern "C" int tg_consume_update_right(const tg_model* m, const int64_t* upos, c
 
 extern "C" int tg_consume_update_right_rows(const tg_model* m, const int64_t* upos, const int32_t* n_upos, int64_t cap,
                                             const float* rows, const int64_t* row_index, uint32_t* err, void* stream) {
+  if (m && m->row_of) return TG_EUNSUPPORTED;  // state addressed by node id: not on physically partitioned tables (tg_model.row_of)
   if (!model_ok(m) || cap < 0) return TG_EINVAL;
   if (cap == 0) return TG_OK;
   if (!upos || !n_upos || !rows || !row_index || !err) return TG_EINVAL;
@@ -565,6 +568,7 @@ extern "C" int tg_gather_eff_rows(const tg_model* m, int64_t n, const int64_t* i
 extern "C" int tg_store_events(const tg_model* m, int64_t B, const int64_t* src, const int64_t* dst, const float* ts,
                                const int64_t* eids, const int64_t* upos, const int64_t* index, const int32_t* n_upos,
                                uint32_t* err, void* stream) {
+  if (m && m->row_of) return TG_EUNSUPPORTED;  // state addressed by node id: not on physically partitioned tables (tg_model.row_of)
   if (!model_ok(m) || B < 0) return TG_EINVAL;
   if (B == 0) return TG_OK;
   if (!src || !dst || !ts || !eids || !upos || !index || !n_upos || !err) return TG_EINVAL;
@@ -575,6 +579,7 @@ extern "C" int tg_store_events(const tg_model* m, int64_t B, const int64_t* src,
 
 extern "C" int tg_restart_apply(const tg_model* m, int64_t n, const int64_t* nids, const float* h_left,
                                 const float* h_right, const float* prev_ts, void* stream) {
+  if (m && m->row_of) return TG_EUNSUPPORTED;  // state addressed by node id: not on physically partitioned tables (tg_model.row_of)
   if (!model_ok(m) || n < 0) return TG_EINVAL;
   if (n == 0) return TG_OK;
   if (!nids || !h_left || !h_right || !prev_ts) return TG_EINVAL;

@@ -1122,6 +1122,35 @@ __global__ void k_slot_times(int64_t n, int K, const float* __restrict__ ts, flo
 
 static WritebackArgs writeback_args(const tg_model* m, const tg_step_io* io, StepWs& w);
 
+// Which form a step takes: one place, shared by step_forward and tg_stream_step_form (the host asks before / after a step
+// whether the per-node tables are read and kept by it).
+struct StepForm {
+  bool direct, fused_wb, lean, gtab, lz_static;
+};
+static StepForm step_form(const tg_model* m, const tg_step_io* io, bool eager, bool drop, bool inner) {
+  StepForm f{};
+  const tg_lazy_restart* lz = (io->lazy && !io->embed_only) ? io->lazy : nullptr;
+  // eager updates, direct form (default; TG_EAGER_DIRECT=0 keeps the compact copy): centres and neighbour rows are read
+  // from pending / right themselves, so there is no gather launch and no reprs buffer
+  static const int direct_knob = getenv("TG_EAGER_DIRECT") ? atoi(getenv("TG_EAGER_DIRECT")) : 1;
+  f.direct = eager && direct_knob != 0 && !io->eager_copy && !io->collate_only;
+  // the one-launch write-back needs the snapshot; the restarter targets (h_prev_*) are read between STEP 4 and STEP 6,
+  // so a step that outputs them keeps the two-phase write-back
+  f.fused_wb = f.direct && !io->embed_only && !io->h_prev_left && !io->h_prev_right;
+  // lean: nothing in such a step needs the involved / outdated sets, so they are not formed (tiger_hip.h, tg_step_io.lean)
+  // (an embed-only step has no write-back to clean up after: lean, it touches none of the self-cleaning state at all)
+  // With the in-step restart loop of the STATIC restarter a lean step still marks the involved flags (the loop's only
+  // input) but forms no sorted set; the list form (any other restarter) keeps the full step
+  f.lz_static = lz && !lz->list;
+  f.lean = io->lean && f.direct && (!lz || f.lz_static) && (f.fused_wb || io->embed_only);
+  // eager query rows: a full eager step of a model that carries the table (it refreshes the table at its end)
+  // (with the in-step restart loop: only with the centre-row table, whose rows of the re-initialised nodes the loop's
+  // kernel rewrites itself - their query rows are refreshed right behind it)
+  f.gtab = eager && m->g_table && m->attn_fused && (!lz || (f.lz_static && m->c_table && f.lean)) && !inner && !io->embed_only &&
+           !io->collate_only && !drop;
+  return f;
+}
+
 int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, StepWs& w, float* gates, hipStream_t st,
                  tg_profiler* pf, const DropCfg* drop, bool eager) {
   w.eager = eager;
@@ -1138,19 +1167,10 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   w.l1e = io->l1_eids ? io->l1_eids : w.l1_eids;
   w.l1t = io->l1_ts ? io->l1_ts : w.l1_ts;
   const tg_lazy_restart* lz = (io->lazy && !io->embed_only) ? io->lazy : nullptr;
-  // eager updates, direct form (default; TG_EAGER_DIRECT=0 keeps the compact copy): centres and neighbour rows are read
-  // from pending / right themselves, so there is no gather launch and no reprs buffer
-  static const int direct_knob = getenv("TG_EAGER_DIRECT") ? atoi(getenv("TG_EAGER_DIRECT")) : 1;
-  w.direct = eager && direct_knob != 0 && !io->eager_copy && !io->collate_only;
-  // the one-launch write-back needs the snapshot; the restarter targets (h_prev_*) are read between STEP 4 and STEP 6,
-  // so a step that outputs them keeps the two-phase write-back
-  w.fused_wb = w.direct && !io->embed_only && !io->h_prev_left && !io->h_prev_right;
-  // lean: nothing in such a step needs the involved / outdated sets, so they are not formed (tiger_hip.h, tg_step_io.lean)
-  // (an embed-only step has no write-back to clean up after: lean, it touches none of the self-cleaning state at all)
-  // With the in-step restart loop of the STATIC restarter a lean step still marks the involved flags (the loop's only
-  // input) but forms no sorted set; the list form (any other restarter) keeps the full step
-  const bool lz_static = lz && !lz->list;
-  w.lean = io->lean && w.direct && (!lz || lz_static) && (w.fused_wb || io->embed_only);
+  const StepForm form = step_form(m, io, eager, drop != nullptr, inner != nullptr);
+  w.direct = form.direct;
+  w.fused_wb = form.fused_wb;
+  w.lean = form.lean;
   const bool need_flags = !w.lean || lz != nullptr;
   const bool untouched = w.lean && io->embed_only;  // no flags, no dedup slots, no counts
   if ((!io->ws_is_clean || io->embed_only || io->collate_only) && !untouched) e = hipMemsetAsync(w.flags, 0, w.zero_bytes, st);
@@ -1187,11 +1207,7 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   const bool split_ok = tail_w && m->upd_fn == TG_UPD_GRU && m->tsfm == TG_TSFM_ID && m->upd_src == TG_SRC_LEFT;
   if (want_rider && split_ok) { pos.eids = w.eids; pos.oth = w.oth; pos.weid = w.weid; }
   const PosArgs* pp = (io->embed_only && !untouched) ? nullptr : &pos;
-  // eager query rows: a full eager step of a model that carries the table (it refreshes the table at its end)
-  // (with the in-step restart loop: only with the centre-row table, whose rows of the re-initialised nodes the loop's
-  // kernel rewrites itself - their query rows are refreshed right behind it)
-  w.gtab = eager && m->g_table && m->attn_fused && (!lz || (lz_static && m->c_table && w.lean)) && !inner && !io->embed_only &&
-           !io->collate_only && !drop;
+  w.gtab = form.gtab;
   // collate prefetch (tg_step_io.prefetch_state): this step runs the NEXT batch's sampler + centres on its last launch;
   // `prefetched`: the previous call did that for this batch (a repeated collate would be harmless, just wasted)
   static const int pf_knob = getenv("TG_PREFETCH") ? atoi(getenv("TG_PREFETCH")) : 1;
@@ -1461,6 +1477,13 @@ int step_writeback_b(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, 
   return check_launch("tg_stream_step");
 }
 }  // namespace tg
+
+extern "C" int32_t tg_stream_step_form(const tg_model* m, const tg_step_io* io) {
+  if (!m || !io) return 0;
+  const tg::StepForm f = tg::step_form(m, io, m->pending_vals != nullptr, false, io->inner != nullptr);
+  return (f.direct ? TG_FORM_DIRECT : 0) | (f.fused_wb ? TG_FORM_FUSED_WB : 0) | (f.lean ? TG_FORM_LEAN : 0) |
+         (f.gtab ? TG_FORM_TABLES : 0);
+}
 
 extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, void* ws, size_t ws_bytes,
                               void* stream) {

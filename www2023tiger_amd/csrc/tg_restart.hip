@@ -806,6 +806,7 @@ extern "C" int tg_restart_seq_fwd(const tg_model* m, const tg_seq_restarter* r, 
                                   const int64_t* h_n, const int64_t* anon, const int64_t* h_e, const float* h_t,
                                   const int64_t* h_d, float* h_left, float* h_right, float* prev_ts, void* ws,
                                   size_t ws_bytes, void* stream) {
+  if (m && m->row_of) return TG_EUNSUPPORTED;  // state addressed by node id: not on physically partitioned tables (tg_model.row_of)
   if (!seq_ok(m, r) || n < 0) return TG_EINVAL;
   if (r->hist_len > 64) return TG_EUNSUPPORTED;
   if (n == 0) return TG_OK;
@@ -826,6 +827,7 @@ extern "C" int tg_restart_seq_fwd_train(const tg_model* m, const tg_seq_restarte
                                         const int64_t* h_n, const int64_t* anon, const int64_t* h_e, const float* h_t,
                                         const int64_t* h_d, float* h_left, float* h_right, float* prev_ts,
                                         float dropout_p, uint64_t* rng, void* ws, size_t ws_bytes, void* stream) {
+  if (m && m->row_of) return TG_EUNSUPPORTED;  // state addressed by node id: not on physically partitioned tables (tg_model.row_of)
   if (!seq_ok(m, r) || n < 0 || dropout_p < 0.f || dropout_p >= 1.f || (dropout_p > 0.f && !rng)) return TG_EINVAL;
   if (r->hist_len > 64) return TG_EUNSUPPORTED;
   if (n == 0) return TG_OK;

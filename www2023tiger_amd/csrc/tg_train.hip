@@ -958,6 +958,7 @@ extern "C" size_t tg_train_step_workspace_bytes(const tg_model* m, const tg_scor
 
 extern "C" int tg_train_step(const tg_model* m_in, const tg_tcsr* g, const tg_train_io* io, void* ws,
                              size_t ws_bytes, void* stream) {
+  if (m_in && m_in->row_of) return TG_EUNSUPPORTED;  // state addressed by node id: not on physically partitioned tables (tg_model.row_of)
   if (!m_in || !io) return TG_EINVAL;
   const bool eval_only = !io->grads;  // evaluation: forward + STEP 7 scores + write-back, nothing else
   tg_model m_local = *m_in;

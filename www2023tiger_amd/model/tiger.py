@@ -157,6 +157,8 @@ class TIGE(nn.Module):
         self._pending_stamp = None
         self._step_ws = {}
         out = super()._apply(fn, *a, **kw)
+        if getattr(self, '_row_of', None) is not None:  # the row map of a partitioned model follows its tables
+            self._row_of = fn(self._row_of)
         # derived tables follow the tensors to their new home: a model that streamed with eager updates / pre-multiplied
         # weights keeps doing so (silently falling back to the lazy forms would change nothing but the speed - and would
         # break engines that rely on the table, e.g. the partitioned multi-GPU layout)
@@ -301,6 +303,14 @@ class TIGE(nn.Module):
     def invalidate_pending(self):
         self._pending_stamp = None
         self._gtab_stamp = None
+
+    def _refuse_partitioned(self, what: str):
+        """The model's own methods address state by NODE ID; on physically partitioned tables (partition_state: fewer rows
+        than nodes) that would read and write other nodes' rows.  Only the partitioned engine's entry points (dist.py:
+        embed-only lean step, serve / adopt / planned write-back / apply_messages on row lists) may run on such a model."""
+        if getattr(self, '_row_of', None) is not None:
+            raise RuntimeError(f'{what}: the model\'s state is physically partitioned (partition_state); only '
+                               'www2023tiger_amd.dist.HipPartitionEngine may drive it')
 
     # ---- eager query rows (tiger_hip.h: tg_model.g_table) --------------------------------------------------------------
     def _gtab_wanted(self) -> bool:
@@ -448,6 +458,7 @@ class TIGE(nn.Module):
 
     def compute_messages(self, node_ids: Union[Tensor, np.ndarray, None] = None):
         """tiger.py:292-337 standalone form: (outdated ids, transformed messages, message ts)."""
+        self._refuse_partitioned('compute_messages')
         outdated = self.msg_store.get_outdated_node_ids(node_ids).to(self.device)
         if len(outdated) == 0:
             return outdated, None, None
@@ -523,6 +534,7 @@ class TIGE(nn.Module):
     def contrast_learning(self, src_ids: Tensor, dst_ids: Tensor, neg_dst_ids: Tensor, ts: Tensor, eids: Tensor,
                           computation_graph) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
         """tiger.py:174-290 -> (contrast_loss, h_left, pos_scores, neg_scores, h_prev_left, h_prev_right)"""
+        self._refuse_partitioned('contrast_learning')
         if self.training and torch.is_grad_enabled():
             losses, *rest = self._train_forward(src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph, False)
             return (losses[0], *rest)
@@ -774,6 +786,8 @@ class TIGE(nn.Module):
 
     def launch_step(self, buf: 'TIGE.StepBuffers'):
         """Enqueue collate + STEP 1-6 for the batch already in `buf` (no host sync)."""
+        if not (buf.embed_only or buf.io.collate_only):
+            self._refuse_partitioned('stream_step / launch_step (a full step)')
         strategy = getattr(self.graph, 'strategy', 'recent_edges')
         if strategy not in ('recent_edges', 'recent_nodes'):
             raise NotImplementedError(f"the fused step samples 'recent_edges' or 'recent_nodes'; strategy={strategy!r} (its "
@@ -806,13 +820,16 @@ class TIGE(nn.Module):
             buf.lazy_batch += 1
         if self._pending is not None and not buf.embed_only:
             self._sync_pending()
-            # (a step with the in-step restart loop keeps the per-node tables itself when it is lean, the restarter static
-            # and the centre-row table there - tiger_hip.h: tg_model.c_table; any other such step runs the G product and
-            # does not read the tables)
-            buf._lazy_tables = (bool(buf.io.lazy) and cb is None and bool(buf.io.lean) and self._gtab_wanted()
-                                and os.environ.get('TG_CTAB', '1') != '0')
-            if not buf.io.lazy or buf._lazy_tables:
+            # the per-node tables: every step without the in-step restart loop reads them; one with the loop only in the form
+            # the LIBRARY reports for this very call (tg_stream_step_form: lean, static restarter, centre-row table, no
+            # h_prev outputs, no compact copy ... - its decision, not a restatement of it here)
+            if not buf.io.lazy:
                 self._sync_gtab()
+            elif self._gtab_wanted():
+                if getattr(self, '_gtab', None) is None:
+                    self._sync_gtab()  # (allocates: the form is a function of the struct the step will see)
+                if lib.tg_stream_step_form(C.byref(self.model_struct()), C.byref(buf.io)) & 8:
+                    self._sync_gtab()
         m = self.model_struct()
         pf = bool(buf.io.prefetch_state)
         if pf:  # is the collate part this buffer's previous step prefetched still the one this step needs?
@@ -828,7 +845,8 @@ class TIGE(nn.Module):
             if self.device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
                 buf._pf_state.value = before  # nothing ran: the device is where it was before the capturing call
             buf._pf_stamp = self._prefetch_stamp(buf, g)
-        if buf.io.lazy and getattr(self, '_gtab', None) is not None and not getattr(buf, '_lazy_tables', False):
+        if (buf.io.lazy and getattr(self, '_gtab', None) is not None
+                and not (lib.tg_stream_step_form(C.byref(m), C.byref(buf.io)) & 8)):
             self._gtab_stamp = None  # the in-step restart loop re-initialised rows the tables did not follow
 
     def _prefetch_stamp(self, buf, g):
@@ -873,6 +891,7 @@ class TIGE(nn.Module):
     @torch.no_grad()
     def flush_msg(self):
         """tiger.py:444-455: consume every pending message into the right memory."""
+        self._refuse_partitioned('flush_msg')
         self._poll_train_errors()
         self._touch()
         dev = self.device
@@ -967,6 +986,7 @@ class TIGER(TIGE):
     @torch.no_grad()
     def restart(self, nids: Tensor, ts: Tensor, mix: float = 0.):
         """tiger.py:594-609: fill both memories with the surrogate state."""
+        self._refuse_partitioned('restart')
         if len(nids) == 0:
             return
         self._touch()

@@ -162,6 +162,7 @@ class TrainBuffers:
         eval_only=True: no gradient storage; the step computes embeddings, scores, loss and the
         write-back (the forward of tiger/eval_utils.py:29-48)."""
         check_trainable(model)
+        model._refuse_partitioned('tg_train_step')
         dev = model.device
         self.model, self.B, self.mutual, self.eval_only = model, B, mutual and not eval_only, eval_only
         self.sb = model.StepBuffers(model, B, want_prev=True, resident=resident)
