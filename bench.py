@@ -214,7 +214,7 @@ def cpu_baseline(stream, cfg, model, budget_s=45.0, batches=100, warm=10):
                 host_threads_visible=ncpu, reference_measured=REFERENCE_MEASURED)
 
 
-def profile_stages(model, buf, steps):
+def profile_stages(model, buf, steps, record=True):
     """Eager steps on the next batches of the stream with the library's per-stage HIP-event timer attached
     (events are recorded on the stream the kernels are launched on)."""
     from www2023tiger_amd._lib import lib
@@ -226,15 +226,42 @@ def profile_stages(model, buf, steps):
     acc = np.zeros(n)
     counts = np.zeros(4)
     ms = (C.c_float * n)()
+    # kernel-bound durations (event pairs bound to the dispatches of the step's main kernels: what rocprofv3 reports)
+    nk = lib.tg_profiler_num_kernel_slots()
+    kms, knames = (C.c_float * nk)(), (C.c_char_p * nk)()
+    kacc, khits = np.zeros(nk), np.zeros(nk)
     for _ in range(steps):
         model.launch_step(buf)
         rc = lib.tg_profiler_read(prof, ms)
         assert rc == 0
         acc += np.array(ms[:])
+        assert lib.tg_profiler_kernel_ms(prof, kms, knames) == 0
+        for i in range(nk):
+            if kms[i] >= 0:
+                kacc[i] += kms[i]
+                khits[i] += 1
         counts += buf.counts.cpu().numpy()
+    if record:  # (side passes - set sizes, the copy form's gather - do not replace the main pass's kernels)
+        KERNEL_MS.clear()
+        for i in range(nk):
+            if khits[i]:
+                KERNEL_MS[lib.tg_profiler_kernel_slot_name(i).decode()] = (kacc[i] / khits[i], norm_kernel(knames[i].decode()))
     buf.attach_profiler(None)
     lib.tg_profiler_destroy(prof)
     return names, acc / steps, counts / steps
+
+
+KERNEL_MS = {}   # slot -> (kernel-bound average ms, launch expression) of the last profile_stages pass
+SLOT_OF_STAGE = {'attn_core(gather+softmax)': 'attn_core', 'attn_gemm_fc1': 'fc1', 'attn_gemm_fc2': 'fc2',
+                 'eager_updater(gru)': 'updater', 'apply_messages(gru)': 'updater', 'eager_query_rows(G)': 'query_rows',
+                 'sample_recent_edges': 'collate(sampler+centres)', 'writeback_phase1': 'writeback',
+                 'gather_right_memory': 'gather'}
+
+
+def norm_kernel(expr):
+    """'(k_gemm_ks16<WbRider, 3, 3, 4>)' / 'tg::k_gemm_ks16<tg::WbRider, 3, 3, 4, tg::NoSecond>' -> comparable form"""
+    e = expr.strip().strip('()').replace('tg::', '').replace(' ', '')
+    return e
 
 
 def stage_work(cfg, U, O_, P, eager, fused, n_nodes, E, tile=False, gtab=False):
@@ -293,10 +320,11 @@ TRAFFIC_SOURCE = {}
 
 
 def load_traffic(tag):
-    """HBM / fabric bytes per launch from the committed PMC passes (profiles/r03_hbm_traffic_<tag>.json, else the
-    r02 file: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command, tools/pmc_traffic.py); {} if not recorded.
+    """HBM / fabric bytes per launch from the committed PMC passes (profiles/r04_hbm_traffic_<tag>.json, else an earlier
+    round's: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command, tools/pmc_traffic.py; with the rocprofv3
+    --kernel-trace average duration of the same kernels beside them when recorded); {} if not recorded.
     A stored, builder-run measurement - the profiler cannot wrap the driver's run - and named as such in the line."""
-    for rnd in ('r03', 'r02'):
+    for rnd in ('r04', 'r03', 'r02'):
         path = os.path.join('profiles', f'{rnd}_hbm_traffic_{tag}.json')
         try:
             k = json.load(open(os.path.join(ROOT, path)))['kernels']
@@ -307,15 +335,29 @@ def load_traffic(tag):
     return {}
 
 
-def kernel_traffic(traffic, kname):
-    """kname: one device kernel, or candidates separated by ' / ' in order of preference (which of them a stage launches
-    depends on shape and form); template arguments vary with the shape: match on the kernel's base name"""
+def kernel_entry(traffic, kname, launched=None):
+    """The stored PMC / rocprof entry of a stage's kernel.  launched: the launch expression the profiler recorded for the
+    stage in THIS run (norm_kernel form) - the entry must be that very instantiation (a stored name may carry further,
+    defaulted template arguments); without it (no kernel-bound timing) kname lists candidates separated by ' / ' in
+    order of preference and the first base-name match counts."""
+    if launched:
+        base, args = (launched.split('<', 1) + [''])[:2]
+        args = args.rstrip('>')
+        for k, v in traffic.items():
+            kb, ka = (norm_kernel(k).split('<', 1) + [''])[:2]
+            if kb == base and (ka.rstrip('>') == args or ka.startswith(args + ',')):
+                return k, v
+        return None, None
     for cand in kname.split(' / '):
         base = cand.strip().split('<')[0].split(' ')[0]
         for k, v in traffic.items():
             if k.split('<')[0] == base:
-                return v.get('bytes_per_launch')
-    return None
+                return k, v
+    return None, None
+
+
+def kernel_traffic(traffic, kname, launched=None):
+    return (kernel_entry(traffic, kname, launched)[1] or {}).get('bytes_per_launch')
 
 
 def roofline_of(name, ms, work, traffic, overhead=0.0):
@@ -324,23 +366,32 @@ def roofline_of(name, ms, work, traffic, overhead=0.0):
     of the kernel agrees with (profiles/); both are reported"""
     flops, nbytes, kname = work.get(name, (None, None, name))
     raw_ms = float(ms)
-    ms = max(raw_ms - overhead, 0.25 * raw_ms)
+    # the launch's duration: the event pair BOUND to the dispatch (its begin / end timestamps, as rocprofv3 reports them)
+    # when the profiler timed this stage's kernel; else the interval less an empty pair, never less than 0.8 of it (the
+    # subtraction over-corrects: part of the records overlaps the kernel's start)
+    kb = KERNEL_MS.get(SLOT_OF_STAGE.get(name, ''))
+    launched = kb[1] if kb else None
+    ms = float(kb[0]) if kb else max(raw_ms - overhead, 0.8 * raw_ms)
+    timing = 'kernel-bound HIP events (hipExtLaunchKernelGGL start / stop)' if kb else 'HIP-event interval less an empty pair'
     t_s = ms * 1e-3
-    tr = kernel_traffic(traffic, kname)
+    ekey, entry = kernel_entry(traffic, kname, launched)
+    tr = (entry or {}).get('bytes_per_launch')
+    extra = dict(avg_ms=float(ms), timing=timing, avg_ms_event_interval=raw_ms, event_pair_ms=float(overhead),
+                 launched=launched, traffic=tr, traffic_kernel=ekey,
+                 rocprof_avg_ms_stored=(entry or {}).get('rocprof_avg_us', None) and entry['rocprof_avg_us'] * 1e-3)
+    if tr and nbytes:
+        extra['traffic_over_algorithmic'] = tr / nbytes
     if flops:
         ach = flops / t_s / 1e12
-        return dict(bound='mfma', kernel=name, device_kernel=kname, achieved=ach, peak=MFMA_F32_PEAK_TFLOPS,
-                    unit='TFLOP/s', frac=ach / MFMA_F32_PEAK_TFLOPS, traffic=tr, avg_ms=float(ms),
-                    avg_ms_event_interval=raw_ms, event_pair_ms=float(overhead),
-                    algorithmic_flops=float(flops), algorithmic_bytes=float(nbytes),
-                    hbm_gbs=nbytes / t_s / 1e9, hbm_frac=nbytes / t_s / 1e9 / HBM_PEAK_GBS)
+        return dict(bound='mfma', kernel=name, device_kernel=launched or kname, achieved=ach, peak=MFMA_F32_PEAK_TFLOPS,
+                    unit='TFLOP/s', frac=ach / MFMA_F32_PEAK_TFLOPS, algorithmic_flops=float(flops),
+                    algorithmic_bytes=float(nbytes), hbm_gbs=nbytes / t_s / 1e9,
+                    hbm_frac=nbytes / t_s / 1e9 / HBM_PEAK_GBS, **extra)
     if nbytes:
         ach = nbytes / t_s / 1e9
-        return dict(bound='hbm', kernel=name, device_kernel=kname, achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s',
-                    frac=ach / HBM_PEAK_GBS, traffic=tr, avg_ms=float(ms), avg_ms_event_interval=raw_ms,
-                    event_pair_ms=float(overhead), algorithmic_bytes=float(nbytes))
-    return dict(bound='hbm', kernel=name, achieved=None, peak=HBM_PEAK_GBS, unit='GB/s', frac=None, traffic=tr,
-                avg_ms=float(ms))
+        return dict(bound='hbm', kernel=name, device_kernel=launched or kname, achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s',
+                    frac=ach / HBM_PEAK_GBS, algorithmic_bytes=float(nbytes), **extra)
+    return dict(bound='hbm', kernel=name, achieved=None, peak=HBM_PEAK_GBS, unit='GB/s', frac=None, **extra)
 
 
 def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_cpu=False):
@@ -348,7 +399,10 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     torch.cuda.set_device(0)
     dev = torch.device('cuda', 0)
     B, K, d = cfg['B'], cfg['K'], cfg['d']
-    n_batches = preroll + warmup + steps + n_prof + 8  # + 4 batches for the copy-form gather timing, + 2 for the set sizes of a lean run, + 2 spare
+    # the timed region is K steps, once (the contract); `reps` further, separately timed repetitions of the same K steps
+    # on the following batches give its spread (a K = 20 region is ONE 1.7 ms graph replay)
+    reps = args.repeats if (B <= 8192 and not args.no_graph) else 0
+    n_batches = preroll + warmup + steps * (1 + reps) + n_prof + 8  # + 4 batches for the copy-form gather timing, + 2 for the set sizes of a lean run, + 2 spare
     E = max(cfg['E'], n_batches * B) if not cfg.get('counter_stream') else n_batches * B
     no_feats = bool(cfg.get('no_feats'))
     stream = make_stream(cfg['n_u'], cfg['n_i'], E, cfg['T'] * E / cfg['E'], seed=0, d_e=d,
@@ -444,10 +498,19 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     dt = time.perf_counter() - t0
     assert int(buf.err.item()) == 0, f'invariant word {int(buf.err.item())}'
     assert int(buf.offset.item()) == (preroll + warmup + steps) * B
+    rep_ms = []
+    for _ in range(reps if graph is not None else 0):
+        torch.cuda.synchronize()
+        r0 = time.perf_counter()
+        for _ in range(steps // gsteps):
+            graph.replay()
+        torch.cuda.synchronize()
+        rep_ms.append((time.perf_counter() - r0) / steps * 1e3)
+    assert int(buf.offset.item()) == (preroll + warmup + steps * (1 + len(rep_ms))) * B
     self_check = None
     if graph is not None and not args.no_self_check and stream['n_nodes'] <= 2_000_000:
         self_check = replay_self_check(cfg, args, stream, resident, model, buf, n_untimed - n_replay_warm,
-                                       steps + n_replay_warm, cnt, trig if restart_prob > 0 else None, lean)
+                                       steps * (1 + len(rep_ms)) + n_replay_warm, cnt, trig if restart_prob > 0 else None, lean)
 
     # ---- per-stage timing on the next unseen batches, live (HIP events on the launch stream)
     names, stage_ms, counts = profile_stages(model, buf, n_prof)
@@ -455,7 +518,7 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     U, O_, P = counts[0], counts[1], counts[2]
     if lean:  # the sets were not formed in the timed form: their sizes (for the algorithmic byte counts) from two full steps
         buf.io.lean = 0
-        _, _, cf = profile_stages(model, buf, 2)
+        _, _, cf = profile_stages(model, buf, 2, record=False)
         buf.io.lean = 1
         U, O_ = cf[0], cf[1]
     from www2023tiger_amd._lib import lib as _tg
@@ -494,8 +557,20 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
     overhead = float(np.median([v for n, v in zip(names, stage_ms) if n in empty]))  # cost of an empty event pair
     stages = {n: float(v) for n, v in zip(names, stage_ms) if n not in empty}
     dom = max(stages, key=stages.get)
+    all_ms = [dt / steps * 1e3] + rep_ms
+    tables = {k: (int(t.numel()) * 4 if t is not None else 0) for k, t in
+              (('g_table', getattr(model, '_gtab', None)), ('c_table', getattr(model, '_ctab', None)),
+               ('pending_vals', model._pending))}
     out = dict(value=steps * B / dt, ms_per_step=dt / steps * 1e3,
-               config=dict(workload=cfg['name'], batch=B, dim=d, n_neighbors=K, msg_src=cfg['msg_src'],
+               timed_region=dict(steps=steps, graph_replays=(steps // gsteps if graph is not None else 0),
+                                 repeats_after=len(rep_ms), ms_per_step_all=[round(v, 5) for v in all_ms],
+                                 ms_per_step_min=round(min(all_ms), 5), ms_per_step_max=round(max(all_ms), 5),
+                                 note='value / ms_per_step are the FIRST K steps (the contract\'s timed region); the repeats '
+                                      'are the same K-step replay on the following batches of the stream'),
+               config=dict(derived_tables_bytes=dict(tables, total=sum(tables.values()),
+                                                     note='per GPU, on top of the reference\'s state (memories, mailbox): '
+                                                          'query rows, centre rows, eager-update rows'),
+                           workload=cfg['name'], batch=B, dim=d, n_neighbors=K, msg_src=cfg['msg_src'],
                            upd_src=cfg['upd_src'], n_nodes=stream['n_nodes'], events=E, mode='stream (no_grad) STEP 1-6',
                            launch=(f'hipGraph replay, {gsteps} step{"s" if gsteps > 1 else ""} per captured graph' if graph is not None else 'eager'),
                            attention_weights=('pre-multiplied (tg_attn_fuse)' + (', whole block in one launch with G / S in LDS (k_attn_tile)' if tile else '')) if fused else 'as stored',
@@ -513,7 +588,11 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
                            outdated_per_batch=float(O_),
                            unique_pos_per_batch=float(P)),
                roofline=roofline_of(dom, stages[dom], work, traffic, overhead),
-               stages_ms={n: round(v, 5) for n, v in stages.items()}, stage_event_overhead_ms=round(overhead, 5))
+               stages_ms={n: round(v, 5) for n, v in stages.items()}, stage_event_overhead_ms=round(overhead, 5),
+               kernels_ms={k: dict(avg_ms=round(float(v[0]), 5), launched=v[1]) for k, v in KERNEL_MS.items()},
+               kernels_ms_note='kernel-bound HIP events of the step\'s main launches in the per-stage pass (eager launches; the '
+                               'dispatch\'s own begin / end timestamps); stages_ms are event INTERVALS around the same '
+                               'launches: each includes its two event records and, for a timed kernel, the bound pair')
     if self_check is not None:
         out['replay_self_check'] = self_check
     if restart_prob > 0:
@@ -532,7 +611,7 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
         # the same step: tg_step_io.eager_copy, reprs[u] = pending-or-right row) is timed on a few more batches of the
         # stream so that the HBM-roofline figure of THAT kernel sits next to the fused one
         buf.io.eager_copy = 1
-        n2, st2, c2 = profile_stages(model, buf, 4)
+        n2, st2, c2 = profile_stages(model, buf, 4, record=False)
         buf.io.eager_copy = 0
         assert int(buf.err.item()) == 0
         U2, O2 = c2[0], c2[1]
@@ -562,6 +641,23 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
         r['traffic_source'] = TRAFFIC_SOURCE.get(traffic_tag) if r.get('traffic') is not None else None
     out['roofline_updater'] = roofline_of(u_name, stages[u_name], work, traffic, overhead)
     out['roofline_neighbour_gather'] = roofline_of('attn_core(gather+softmax)', stages['attn_core(gather+softmax)'], work, traffic, overhead)
+    # the three byte counts of the neighbour gather side by side: what a fused form could not avoid
+    # (every involved node's row once, the edge rows, the lists), what THIS design moves on top (the per-centre G-row in /
+    # S-row out streams between the core and the products around it), and what the counters saw
+    fe = 0 if cfg.get('no_feats') else 1
+    nk_ = 2 * (2 * d + (d if (fe or not fused) else 0))
+    Qn = 3 * B
+    byts = dict(unique_node_rows=float(U * 4 * d * (1 + fe)), edge_rows=float(Qn * K * 4 * d * fe),
+                neighbour_lists=float(Qn * K * 20), g_s_streams=float(2.0 * Qn * nk_ * 4))
+    byts['compulsory'] = byts['unique_node_rows'] + byts['edge_rows'] + byts['neighbour_lists']
+    byts['design'] = byts['compulsory'] + byts['g_s_streams']
+    for r in [out['roofline_neighbour_gather']] + ([mg['fused_into']] if 'fused_into' in mg else []):
+        t_s = r['avg_ms'] * 1e-3
+        r['bytes_three_ways'] = dict(byts, pmc=r.get('traffic'),
+                                     frac_of_hbm_peak=dict(compulsory=byts['compulsory'] / t_s / 1e9 / HBM_PEAK_GBS,
+                                                           design=byts['design'] / t_s / 1e9 / HBM_PEAK_GBS,
+                                                           pmc=(r['traffic'] / t_s / 1e9 / HBM_PEAK_GBS) if r.get('traffic') else None),
+                                     note='frac / achieved of this object are priced with the DESIGN bytes')
     if want_cpu:
         out['cpu_baseline'] = cpu_baseline(stream, cfg, model)
     del buf, graph, model, resident
@@ -615,6 +711,45 @@ def replay_self_check(cfg, args, stream, resident, model, buf, n_before, n_repla
     return dict(compared='memories, update times, mailbox rows / times, has-message set, last embeddings: hipGraph replay '
                          'of the timed region vs a second model driven by eager launches over the same batches',
                 batches=n_before + n_replayed, replayed=n_replayed, max_abs_diff=worst)
+
+
+def reference_api_loop(cfg, batch_sizes=(200, 1024), n_batches=60):
+    """What INTEGRATION.md Option A delivers: the reference's own evaluation harness - the Python loop of
+    tiger/eval_utils.py:15-68 (`eval_edge_prediction`: DataLoader -> collator -> contrast_learning -> scores -> AP / AUC)
+    - on this package's drop-in classes, at the reference's evaluation batch size (200) and at C2's (1024).  Not the
+    headline metric: the loop pays Python, the collator's host side and one call per batch."""
+    from www2023tiger_amd.data.data_loader import BatchLoader, GraphCollator, InteractionData
+    from www2023tiger_amd.eval_utils import eval_edge_prediction
+    out = {}
+    n = n_batches * max(batch_sizes)
+    E = max(cfg['E'], n)
+    st = make_stream(cfg['n_u'], cfg['n_i'], E, cfg['T'] * E / cfg['E'], seed=0, d_e=cfg['d'])
+    model, _ = build_models(st, cfg['d'], cfg['K'], cfg['msg_src'], cfg['upd_src'], restarter='static', dropout=0.1)
+    model.eval()
+    dev = model.device
+    coll = GraphCollator(model.graph, cfg['K'], 1, restarter='static', hist_len=1)
+    rs = np.random.RandomState(1)
+    for bs in batch_sizes:
+        m = n_batches * bs
+        ev = InteractionData(st['src'][:m], st['dst'][:m], st['ts'][:m], st['eids'][:m], np.zeros(m, dtype=np.int64), seed=0,
+                             eval=True, neg_dst=rs.randint(cfg['n_u'] + 1, cfg['n_u'] + cfg['n_i'] + 1, m))
+        dl = BatchLoader(ev, bs, coll)
+        times = []
+        for _ in range(3):  # first pass warms allocations up; best of the next two
+            model.reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ap_, auc_ = eval_edge_prediction(model, dl, dev, restart_mode=False)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        best = min(times[1:])
+        out[f'bs{bs}'] = dict(value=m / best, unit='events/s', ms_per_batch=best / n_batches * 1e3, batches=n_batches,
+                              ap=ap_, auc=auc_)
+    out['what'] = ('www2023tiger_amd.eval_utils.eval_edge_prediction (the loop of the reference\'s tiger/eval_utils.py:15-68) over a '
+                   'BatchLoader on the drop-in TIGER: collation, embedding, scores, loss and AP / AUC per batch, host loop included')
+    del model
+    torch.cuda.empty_cache()
+    return out
 
 
 def spawn_ranks(args):
@@ -707,8 +842,12 @@ def main():
     ap.add_argument('--preroll', type=int, default=None,
                     help=f'untimed state pre-roll batches before --warmup (default {PREROLL}; 96 for c5s / c5)')
     ap.add_argument('--no-c5s-leg', action='store_true', help='default C2 run: skip the short HBM-roofline leg')
+    ap.add_argument('--no-api-loop', action='store_true',
+                    help='default C2 run: skip the reference_api_loop leg (eval_edge_prediction on the drop-in API)')
     ap.add_argument('--no-dist-leg', action='store_true',
                     help='default C2 run: skip the one-rank leg of the multi-GPU code path (partitioned_form_1rank)')
+    ap.add_argument('--repeats', type=int, default=4,
+                    help='further, separately timed repetitions of the K-step region (spread; not part of `value`)')
     ap.add_argument('--graph-steps', type=int, default=0,
                     help='steps per captured hipGraph (default: the largest divisor of --steps up to 25)')
     ap.add_argument('--no-prefetch', action='store_true',
@@ -767,6 +906,11 @@ def main():
                               config=c5['config'], roofline_memory_gather=c5['roofline_memory_gather'],
                               roofline_updater=c5['roofline_updater'],
                               roofline_neighbour_gather=c5['roofline_neighbour_gather'], stages_ms=c5['stages_ms'])
+    if args.workload == 'c2' and not args.no_api_loop:
+        try:
+            out['reference_api_loop'] = reference_api_loop(cfg)
+        except Exception as e:  # a side leg: the headline line does not depend on it
+            out['reference_api_loop'] = dict(error=repr(e))
     if args.workload == 'c2' and not args.no_dist_leg:
         # the N = 1 point of the multi-GPU code path (partitioned state, hipGraph segments around two RCCL
         # all_to_all_single with one rank) next to the single-GPU graph line, so that a scaling curve whose N > 1 points

@@ -552,6 +552,13 @@ void tg_profiler_destroy(tg_profiler* p);
 int tg_profiler_num_stages(void);
 const char* tg_profiler_stage_name(int stage);
 int tg_profiler_read(tg_profiler* p, float* ms_out);
+/* Kernel-bound durations of the same step: while the profiler is attached the step's main kernels are launched with an
+ * event pair bound to the dispatch (its own begin / end timestamps, what rocprofv3 reports), one slot per kernel:
+ * tg_profiler_kernel_slot_name(i), i < tg_profiler_num_kernel_slots().  ms_out[slot] < 0: the step made no launch under
+ * the slot; names_out (nullable) receives the launch expression of the timed kernel (template arguments included). */
+int tg_profiler_num_kernel_slots(void);
+const char* tg_profiler_kernel_slot_name(int slot);
+int tg_profiler_kernel_ms(tg_profiler* p, float* ms_out, const char** names_out);
 
 size_t tg_stream_step_workspace_bytes(const tg_model* m, int64_t B);
 size_t tg_stream_step_workspace_bytes2(const tg_model* m, int64_t B, int32_t n_layers); /* n_layers 1 or 2 */

@@ -5,7 +5,7 @@
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -o f -- python bench.py --steps 10 --warmup 25 --no-cpu-baseline --no-graph
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -o w -- python bench.py --steps 10 --warmup 25 --no-cpu-baseline --no-graph
   # anywhere:
-  tools/pmc_traffic.py gpurun_out/pmc_f/f_counter_collection.csv gpurun_out/pmc_w/w_counter_collection.csv out.json
+  tools/pmc_traffic.py gpurun_out/pmc_f/f_counter_collection.csv gpurun_out/pmc_w/w_counter_collection.csv out.json [kernel_stats.csv]
 
 bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024  (gfx950: FETCH_SIZE counts half of a wide coalesced
 read, MI355X_MICROARCH.md HBM section); averages over the LAST `n` launches of each kernel."""
@@ -25,8 +25,19 @@ def per_kernel(path, last=10):
     return {k: sum(v[-last:]) / len(v[-last:]) for k, v in rows.items()}
 
 
+def kernel_stats(path):
+    """rocprofv3 --kernel-trace averages of the same command (tools/rocpd_stats.py csv): name -> (average us, calls)"""
+    out = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            name = re.sub(r'\(.*', '', r['Name']).replace('void ', '')
+            out[name] = (float(r['AverageNs']) / 1e3, int(r['Calls']))
+    return out
+
+
 def main():
     fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
+    stats = kernel_stats(sys.argv[4]) if len(sys.argv) > 4 else {}
     out = {'method': __doc__.split('\n\n')[2].strip().replace('\n', ' '), 'kernels': {}}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith('tg::'):
@@ -34,6 +45,8 @@ def main():
         f, w = fetch.get(k, 0.0), write.get(k, 0.0)
         out['kernels'][k] = {'FETCH_SIZE_KB': round(f, 1), 'WRITE_SIZE_KB': round(w, 1),
                              'bytes_per_launch': int(2 * f * 1024 + w * 1024)}
+        if k in stats:  # duration of the same kernel in the graph-replayed bench (kernel-trace pass of the same session)
+            out['kernels'][k].update(rocprof_avg_us=round(stats[k][0], 2), rocprof_calls=stats[k][1])
     json.dump(out, open(sys.argv[3], 'w'), indent=1)
     for k, v in out['kernels'].items():
         print('%-50s %12d B/launch' % (k, v['bytes_per_launch']))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # quick check on the GPU box: C2 bench lines under knob settings given as arguments ("NAME=VAL,NAME=VAL" per run)
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/q; mkdir -p $O; cd $R
-P="--no-cpu-baseline --no-c5s-leg --no-dist-leg"
+P="--no-cpu-baseline --no-c5s-leg --no-dist-leg --no-api-loop"
 i=0
 for cfg in "$@"; do
   i=$((i+1))

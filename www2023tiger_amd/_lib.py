@@ -157,6 +157,9 @@ SIGNATURES = {
     'tg_profiler_num_stages': (C.c_int, []),
     'tg_profiler_stage_name': (C.c_char_p, [C.c_int]),
     'tg_profiler_read': (C.c_int, [vp, vp]),
+    'tg_profiler_num_kernel_slots': (C.c_int, []),
+    'tg_profiler_kernel_slot_name': (C.c_char_p, [C.c_int]),
+    'tg_profiler_kernel_ms': (C.c_int, [vp, P(C.c_float), P(C.c_char_p)]),
     'tg_stream_step_workspace_bytes': (sz, [P(TgModel), i64]),
     'tg_stream_step_workspace_bytes2': (sz, [P(TgModel), i64, i32]),
     'tg_stream_step_zero_bytes': (sz, [P(TgModel), i64]),

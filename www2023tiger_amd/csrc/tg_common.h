@@ -1,6 +1,7 @@
 // Shared device helpers for libtiger_hip (gfx950 only: 64-wide wavefronts).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "tiger_hip.h"
@@ -21,6 +22,38 @@ inline int check_launch(const char* what) {
 }
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- kernel-bound timing (tg_profiler, eager launches only) ----------------------------------------------------------
+// A HIP-event pair AROUND a launch measures the launch plus the two event records (~4.5 us on this stack); an event pair
+// BOUND to the dispatch (hipExtLaunchKernelGGL's start / stop events: the dispatch's own begin / end timestamps) measures
+// the kernel as rocprofv3 does.  While tg_stream_step runs with a profiler attached, the launches of the step's main
+// kernels go through TG_KLAUNCH with a slot selected by the caller (KSlot): the last launch made under a slot is timed
+// and its kernel's name (the launch expression) recorded.  Without a profiler TG_KLAUNCH is hipLaunchKernelGGL.
+enum KtSlot : int { KT_NONE = -1, KT_COLLATE = 0, KT_CORE, KT_FC1, KT_FC2, KT_UPDATER, KT_QROWS, KT_WRITEBACK, KT_GATHER, KT_COUNT };
+struct KTimer {
+  hipEvent_t ev[KT_COUNT][2];
+  const char* name[KT_COUNT];
+  bool hit[KT_COUNT];
+};
+extern thread_local KTimer* g_kt;
+extern thread_local int g_kt_slot;
+struct KSlot {  // selects the slot for the launches made in its scope
+  int prev;
+  explicit KSlot(int s) : prev(g_kt_slot) { g_kt_slot = s; }
+  ~KSlot() { g_kt_slot = prev; }
+};
+#define TG_KLAUNCH(kern, grid, block, shmem, st, ...)                                                               \
+  do {                                                                                                              \
+    ::tg::KTimer* kt__ = ::tg::g_kt;                                                                                \
+    const int ks__ = ::tg::g_kt_slot;                                                                               \
+    if (kt__ && ks__ >= 0) {                                                                                        \
+      hipExtLaunchKernelGGL(kern, grid, block, shmem, st, kt__->ev[ks__][0], kt__->ev[ks__][1], 0, __VA_ARGS__);    \
+      kt__->name[ks__] = #kern;                                                                                     \
+      kt__->hit[ks__] = true;                                                                                       \
+    } else {                                                                                                        \
+      hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__);                                                \
+    }                                                                                                               \
+  } while (0)
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -1032,12 +1032,12 @@ int gru_tail_launch(const GruTail& t, hipStream_t st) {
   GruTail g = t;
   g.blocks = gru_tail_blocks(t);
   if (g.direct) {
-    if (nsl <= 7) hipLaunchKernelGGL(k_gru_tail_direct<7>, dim3(g.blocks), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL(k_gru_tail_direct<11>, dim3(g.blocks), dim3(256), 0, st, g);
+    if (nsl <= 7) TG_KLAUNCH(k_gru_tail_direct<7>, dim3(g.blocks), dim3(256), 0, st, g);
+    else TG_KLAUNCH(k_gru_tail_direct<11>, dim3(g.blocks), dim3(256), 0, st, g);
   } else if (nsl <= 7) {
-    hipLaunchKernelGGL(k_gru_tail<7>, dim3(g.blocks), dim3(256), 0, st, g);
+    TG_KLAUNCH(k_gru_tail<7>, dim3(g.blocks), dim3(256), 0, st, g);
   } else {
-    hipLaunchKernelGGL(k_gru_tail<11>, dim3(g.blocks), dim3(256), 0, st, g);
+    TG_KLAUNCH(k_gru_tail<11>, dim3(g.blocks), dim3(256), 0, st, g);
   }
   return check_launch("gru_tail");
 }
@@ -1352,11 +1352,11 @@ bool gemm_ks16_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, b
     // (rows per block: 16 when that fits the chip at once, else 32)
     const bool r1 = cdiv(g.m_cap, 16) * ntc <= 256;
     if (ct == 4) {
-      if (r1) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 1, 4, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
-      else hipLaunchKernelGGL((k_gemm_ks16<NoRider, 2, 4, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
+      if (r1) TG_KLAUNCH((k_gemm_ks16<NoRider, 1, 4, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
+      else TG_KLAUNCH((k_gemm_ks16<NoRider, 2, 4, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
     } else {
-      if (r1) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 1, 7, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
-      else hipLaunchKernelGGL((k_gemm_ks16<NoRider, 2, 7, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
+      if (r1) TG_KLAUNCH((k_gemm_ks16<NoRider, 1, 7, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
+      else TG_KLAUNCH((k_gemm_ks16<NoRider, 2, 7, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
     }
     return true;
   }
@@ -1384,20 +1384,20 @@ bool gemm_ks16_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, b
         s2.seq = seq_knob == 1 ? 1u : 0u;
         s2.blocks = s2.seq ? 0u : ks16_second_blocks(*second);
         const dim3 gr2(256 + s2.blocks + wr.blocks);
-        hipLaunchKernelGGL((k_gemm_ks16<WbRider, 3, 3, 4, Ks16Second>), gr2, dim3(256), 0, st, gd, wr, s2);
+        TG_KLAUNCH((k_gemm_ks16<WbRider, 3, 3, 4, Ks16Second>), gr2, dim3(256), 0, st, gd, wr, s2);
         *second_rode = true;
       } else {
         const dim3 gr(256 + wr.blocks);
-        hipLaunchKernelGGL((k_gemm_ks16<WbRider, 3, 3, 4>), gr, dim3(256), 0, st, gd, wr, ns);
+        TG_KLAUNCH((k_gemm_ks16<WbRider, 3, 3, 4>), gr, dim3(256), 0, st, gd, wr, ns);
       }
       *rode = true;
       return true;
     }
   }
-  if (knob == 8) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 3, 3, 8>), dim3(256), dim3(512), 0, st, gd, nr, ns);
-  else if (rt == 1) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 1, 3, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
-  else if (rt == 2) hipLaunchKernelGGL((k_gemm_ks16<NoRider, 2, 3, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
-  else hipLaunchKernelGGL((k_gemm_ks16<NoRider, 3, 3, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
+  if (knob == 8) TG_KLAUNCH((k_gemm_ks16<NoRider, 3, 3, 8>), dim3(256), dim3(512), 0, st, gd, nr, ns);
+  else if (rt == 1) TG_KLAUNCH((k_gemm_ks16<NoRider, 1, 3, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
+  else if (rt == 2) TG_KLAUNCH((k_gemm_ks16<NoRider, 2, 3, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
+  else TG_KLAUNCH((k_gemm_ks16<NoRider, 3, 3, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
   return true;
 }
 
@@ -1452,7 +1452,7 @@ bool gemm_sk_partials(const GemmArgs& g, float* ws, size_t ws_floats, hipStream_
   static const int gdbg = getenv("TG_GEMM_DBG") ? atoi(getenv("TG_GEMM_DBG")) : 0;
   GemmArgs gd = g;
   gd.dbg = gdbg & ~16;
-  hipLaunchKernelGGL((k_gemm_sk<2, 2>), dim3(workers), dim3(512), 0, st, gd, p);
+  TG_KLAUNCH((k_gemm_sk<2, 2>), dim3(workers), dim3(512), 0, st, gd, p);
   *plan = p;
   return true;
 }
@@ -1543,9 +1543,9 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
       no_ride();
       const int cpb = std::min(as8_knob, NT);
       const dim3 gr((unsigned)(8 * cdiv(cdiv(g.m_cap, 128), 8) * cdiv(NT, cpb)));
-      if (nkt8 == 4) hipLaunchKernelGGL((k_gemm_astat8<4>), gr, dim3(512), 0, st, gd, cpb);
-      else if (nkt8 == 6) hipLaunchKernelGGL((k_gemm_astat8<6>), gr, dim3(512), 0, st, gd, cpb);
-      else hipLaunchKernelGGL((k_gemm_astat8<8>), gr, dim3(512), 0, st, gd, cpb);
+      if (nkt8 == 4) TG_KLAUNCH((k_gemm_astat8<4>), gr, dim3(512), 0, st, gd, cpb);
+      else if (nkt8 == 6) TG_KLAUNCH((k_gemm_astat8<6>), gr, dim3(512), 0, st, gd, cpb);
+      else TG_KLAUNCH((k_gemm_astat8<8>), gr, dim3(512), 0, st, gd, cpb);
       return check_launch("gemm(astat8)");
     }
   }
@@ -1553,9 +1553,9 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
       !g.accumulate && cdiv(g.m_cap, 128) * NT >= 4096) {
     no_ride();
     if (rb_knob == 2 && g.n >= 512) {
-      hipLaunchKernelGGL((k_gemm_rb<2, 2>), dim3((unsigned)(8 * cdiv(cdiv(g.m_cap, 128), 8) * cdiv(g.n, 128))), dim3(256), 0, st, gd);
+      TG_KLAUNCH((k_gemm_rb<2, 2>), dim3((unsigned)(8 * cdiv(cdiv(g.m_cap, 128), 8) * cdiv(g.n, 128))), dim3(256), 0, st, gd);
     } else {
-      hipLaunchKernelGGL((k_gemm_rb<2, 1>), dim3((unsigned)(8 * cdiv(cdiv(g.m_cap, 128), 8) * NT)), dim3(256), 0, st, gd);
+      TG_KLAUNCH((k_gemm_rb<2, 1>), dim3((unsigned)(8 * cdiv(cdiv(g.m_cap, 128), 8) * NT)), dim3(256), 0, st, gd);
     }
     return check_launch("gemm(rb)");
   }
@@ -1592,20 +1592,20 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
       const dim3 gr(own + co.blocks + wr.blocks + tl.blocks + gi.blocks);
 #define TG_DIRECT(NS_)                                                                                                  \
   do {                                                                                                                  \
-    if (gi.blocks && wide) hipLaunchKernelGGL((k_gemm_direct_r<GiRider, NS_, 2, 3>), gr, dim3(256), 0, st, gd, gi);       \
-    else if (gi.blocks) hipLaunchKernelGGL((k_gemm_direct_r<GiRider, NS_, 2, 2>), gr, dim3(256), 0, st, gd, gi);         \
-    else if (tl.blocks && wide) hipLaunchKernelGGL((k_gemm_direct_r<GruTail, NS_, 2, 3>), gr, dim3(256), 0, st, gd, tl);  \
-    else if (tl.blocks) hipLaunchKernelGGL((k_gemm_direct_r<GruTail, NS_, 2, 2>), gr, dim3(256), 0, st, gd, tl);         \
-    else if (wr.blocks && wide) hipLaunchKernelGGL((k_gemm_direct_r<WbRider, NS_, 2, 3>), gr, dim3(256), 0, st, gd, wr);      \
-    else if (wr.blocks) hipLaunchKernelGGL((k_gemm_direct_r<WbRider, NS_, 2, 2>), gr, dim3(256), 0, st, gd, wr);        \
-    else if (co.blocks && wide) hipLaunchKernelGGL((k_gemm_direct_r<CollateRider, NS_, 2, 3>), gr, dim3(256), 0, st, gd, co); \
-    else if (co.blocks) hipLaunchKernelGGL((k_gemm_direct_r<CollateRider, NS_, 2, 2>), gr, dim3(256), 0, st, gd, co);   \
-    else if (wide) hipLaunchKernelGGL((k_gemm_direct<NS_, 2, 3>), gr, dim3(256), 0, st, gd);                            \
-    else hipLaunchKernelGGL((k_gemm_direct<NS_, 2, 2>), gr, dim3(256), 0, st, gd);                                      \
+    if (gi.blocks && wide) TG_KLAUNCH((k_gemm_direct_r<GiRider, NS_, 2, 3>), gr, dim3(256), 0, st, gd, gi);       \
+    else if (gi.blocks) TG_KLAUNCH((k_gemm_direct_r<GiRider, NS_, 2, 2>), gr, dim3(256), 0, st, gd, gi);         \
+    else if (tl.blocks && wide) TG_KLAUNCH((k_gemm_direct_r<GruTail, NS_, 2, 3>), gr, dim3(256), 0, st, gd, tl);  \
+    else if (tl.blocks) TG_KLAUNCH((k_gemm_direct_r<GruTail, NS_, 2, 2>), gr, dim3(256), 0, st, gd, tl);         \
+    else if (wr.blocks && wide) TG_KLAUNCH((k_gemm_direct_r<WbRider, NS_, 2, 3>), gr, dim3(256), 0, st, gd, wr);      \
+    else if (wr.blocks) TG_KLAUNCH((k_gemm_direct_r<WbRider, NS_, 2, 2>), gr, dim3(256), 0, st, gd, wr);        \
+    else if (co.blocks && wide) TG_KLAUNCH((k_gemm_direct_r<CollateRider, NS_, 2, 3>), gr, dim3(256), 0, st, gd, co); \
+    else if (co.blocks) TG_KLAUNCH((k_gemm_direct_r<CollateRider, NS_, 2, 2>), gr, dim3(256), 0, st, gd, co);   \
+    else if (wide) TG_KLAUNCH((k_gemm_direct<NS_, 2, 3>), gr, dim3(256), 0, st, gd);                            \
+    else TG_KLAUNCH((k_gemm_direct<NS_, 2, 2>), gr, dim3(256), 0, st, gd);                                      \
   } while (0)
       if (nsl <= 7) TG_DIRECT(7);
       else if (nsl <= 11) TG_DIRECT(11);
-      else hipLaunchKernelGGL((k_gemm_direct<12, 2, 2>), dim3(own), dim3(256), 0, st, gd);
+      else TG_KLAUNCH((k_gemm_direct<12, 2, 2>), dim3(own), dim3(256), 0, st, gd);
 #undef TG_DIRECT
       if (((collate || rider) && ride) || tl.blocks || gi.blocks) *rode = true;
       return check_launch("gemm(direct)");
@@ -1628,17 +1628,17 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
         CollateRider co = *collate;
         collate_blocks(co);
         const dim3 grid_r((unsigned)(gb + co.blocks));
-        if (nkt == 4) hipLaunchKernelGGL((k_gemm_astat_r<CollateRider, 4>), grid_r, dim3(256), 0, st, gd, cpb, co);
-        else if (nkt == 6) hipLaunchKernelGGL((k_gemm_astat_r<CollateRider, 6>), grid_r, dim3(256), 0, st, gd, cpb, co);
-        else hipLaunchKernelGGL((k_gemm_astat_r<CollateRider, 8>), grid_r, dim3(256), 0, st, gd, cpb, co);
+        if (nkt == 4) TG_KLAUNCH((k_gemm_astat_r<CollateRider, 4>), grid_r, dim3(256), 0, st, gd, cpb, co);
+        else if (nkt == 6) TG_KLAUNCH((k_gemm_astat_r<CollateRider, 6>), grid_r, dim3(256), 0, st, gd, cpb, co);
+        else TG_KLAUNCH((k_gemm_astat_r<CollateRider, 8>), grid_r, dim3(256), 0, st, gd, cpb, co);
         *rode = true;
         return check_launch("gemm(astat+collate)");
       }
       no_ride();
       const dim3 grid_as((unsigned)gb);
-      if (nkt == 4) hipLaunchKernelGGL((k_gemm_astat<4>), grid_as, dim3(256), 0, st, gd, cpb);
-      else if (nkt == 6) hipLaunchKernelGGL((k_gemm_astat<6>), grid_as, dim3(256), 0, st, gd, cpb);
-      else hipLaunchKernelGGL((k_gemm_astat<8>), grid_as, dim3(256), 0, st, gd, cpb);
+      if (nkt == 4) TG_KLAUNCH((k_gemm_astat<4>), grid_as, dim3(256), 0, st, gd, cpb);
+      else if (nkt == 6) TG_KLAUNCH((k_gemm_astat<6>), grid_as, dim3(256), 0, st, gd, cpb);
+      else TG_KLAUNCH((k_gemm_astat<8>), grid_as, dim3(256), 0, st, gd, cpb);
       return check_launch("gemm(astat)");
     }
   }
@@ -1652,37 +1652,37 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
       wr.blocks = rider_blocks(grid, 512, 2 * wr.a.B);
       wr.last = 1u;
       if (g.ask_pieces > 3)
-        hipLaunchKernelGGL((k_gemm_r<WbRider, 2, 2, 2, 2, true, 8>), dim3((unsigned)grid + wr.blocks), dim3(512), 0, st, gd, wr);
+        TG_KLAUNCH((k_gemm_r<WbRider, 2, 2, 2, 2, true, 8>), dim3((unsigned)grid + wr.blocks), dim3(512), 0, st, gd, wr);
       else
-        hipLaunchKernelGGL((k_gemm_r<WbRider, 2, 2, 2, 2, true>), dim3((unsigned)grid + wr.blocks), dim3(512), 0, st, gd, wr);
+        TG_KLAUNCH((k_gemm_r<WbRider, 2, 2, 2, 2, true>), dim3((unsigned)grid + wr.blocks), dim3(512), 0, st, gd, wr);
       *rode = true;
     } else {
       no_ride();
-      if (g.ask_pieces > 3) hipLaunchKernelGGL((k_gemm<2, 2, 2, 2, true, 8>), dim3((unsigned)grid), dim3(512), 0, st, gd);
-      else if (ask_ks == 2) hipLaunchKernelGGL((k_gemm<2, 2, 2, 2, true>), dim3((unsigned)grid), dim3(512), 0, st, gd);
-      else if (ask_depth == 4) hipLaunchKernelGGL((k_gemm<2, 2, 1, 4, true>), dim3((unsigned)grid), dim3(256), 0, st, gd);
-      else hipLaunchKernelGGL((k_gemm<2, 2, 1, 2, true>), dim3((unsigned)grid), dim3(256), 0, st, gd);
+      if (g.ask_pieces > 3) TG_KLAUNCH((k_gemm<2, 2, 2, 2, true, 8>), dim3((unsigned)grid), dim3(512), 0, st, gd);
+      else if (ask_ks == 2) TG_KLAUNCH((k_gemm<2, 2, 2, 2, true>), dim3((unsigned)grid), dim3(512), 0, st, gd);
+      else if (ask_depth == 4) TG_KLAUNCH((k_gemm<2, 2, 1, 4, true>), dim3((unsigned)grid), dim3(256), 0, st, gd);
+      else TG_KLAUNCH((k_gemm<2, 2, 1, 2, true>), dim3((unsigned)grid), dim3(256), 0, st, gd);
     }
   } else if (split) {
     no_ride();
-    hipLaunchKernelGGL((k_gemm<2, 2, 2, 2>), dim3((unsigned)grid), dim3(512), 0, st, gd);
+    TG_KLAUNCH((k_gemm<2, 2, 2, 2>), dim3((unsigned)grid), dim3(512), 0, st, gd);
   } else if (depth_knob == 2 && rider && live_blocks(g, grid, 64) <= RIDER_MAX_LIVE) {
     WbRider wr = *rider;
     wr.blocks = rider_blocks(live_blocks(g, grid, 64), 256, 2 * wr.a.B);
     wr.last = 1u;
-    hipLaunchKernelGGL((k_gemm_r<WbRider, 2, 2, 1, 2>), dim3((unsigned)grid + wr.blocks), dim3(256), 0, st, gd, wr);
+    TG_KLAUNCH((k_gemm_r<WbRider, 2, 2, 1, 2>), dim3((unsigned)grid + wr.blocks), dim3(256), 0, st, gd, wr);
     *rode = true;
   } else if (depth_knob == 2 && collate && live_blocks(g, grid, 64) <= RIDER_MAX_LIVE) {
     CollateRider co = *collate;
     collate_blocks(co);
-    hipLaunchKernelGGL((k_gemm_r<CollateRider, 2, 2, 1, 2>), dim3((unsigned)grid + co.blocks), dim3(256), 0, st, gd, co);
+    TG_KLAUNCH((k_gemm_r<CollateRider, 2, 2, 1, 2>), dim3((unsigned)grid + co.blocks), dim3(256), 0, st, gd, co);
     *rode = true;
   } else if (depth_knob == 2) {
     no_ride();
-    hipLaunchKernelGGL((k_gemm<2, 2, 1, 2>), dim3((unsigned)grid), dim3(256), 0, st, gd);
+    TG_KLAUNCH((k_gemm<2, 2, 1, 2>), dim3((unsigned)grid), dim3(256), 0, st, gd);
   } else {
     no_ride();
-    hipLaunchKernelGGL((k_gemm<2, 2, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, gd);
+    TG_KLAUNCH((k_gemm<2, 2, 1, 4>), dim3((unsigned)grid), dim3(256), 0, st, gd);
   }
   return check_launch("gemm");
 }
@@ -2748,8 +2748,8 @@ int gru_launch(const GruArgs& g, hipStream_t st) {
       // (the sampler riders of the collate prefetch were tried here too - the sampler reads the graph only - and cost the
       // updater more than they saved the query-row launch: C2 updater +4.6 us, launch behind it -0.7 us; C4 +22 us)
       const dim3 grid16((unsigned)std::min<int64_t>(256, 8 * cdiv(cdiv(g.cap, 16) * NT16, 8)));
-      if (cdiv(rows_b, 48) * NT16 <= 256) hipLaunchKernelGGL(k_gru_direct16<3>, grid16, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL(k_gru_direct16<GRU16_RT_MAX>, grid16, dim3(256), 0, st, a);
+      if (cdiv(rows_b, 48) * NT16 <= 256) TG_KLAUNCH(k_gru_direct16<3>, grid16, dim3(256), 0, st, a);
+      else TG_KLAUNCH(k_gru_direct16<GRU16_RT_MAX>, grid16, dim3(256), 0, st, a);
       return check_launch("gru(16 x 16)");
     }
   }
@@ -2757,13 +2757,13 @@ int gru_launch(const GruArgs& g, hipStream_t st) {
     a.tail_blocks = 0;
     static const int direct_knob = getenv("TG_GRU_DIRECT") ? atoi(getenv("TG_GRU_DIRECT")) : 1;  // tuning knob: 0 = LDS-staged
     const dim3 grid32((unsigned)(8 * cdiv(cdiv(g.cap, 32), 8) * NT));
-    if (direct_knob) hipLaunchKernelGGL(k_gru_direct, grid32, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_gru<1, 4>), grid32, dim3(256), 0, st, a);
+    if (direct_knob) TG_KLAUNCH(k_gru_direct, grid32, dim3(256), 0, st, a);
+    else TG_KLAUNCH((k_gru<1, 4>), grid32, dim3(256), 0, st, a);
     return check_launch("gru(32)");
   }
   if (force_nw == 2 || (force_nw == 0 && tiny)) {
     a.tail_blocks = 0;
-    hipLaunchKernelGGL((k_gru<2, 4>), dim3((unsigned)(8 * cdiv(cdiv(g.cap, 64), 8) * NT)), dim3(512), 0, st, a);
+    TG_KLAUNCH((k_gru<2, 4>), dim3((unsigned)(8 * cdiv(cdiv(g.cap, 64), 8) * NT)), dim3(512), 0, st, a);
     return check_launch("gru(64)");
   }
   if (force_nw == 3 || (force_nw == 0 && small)) {
@@ -2773,14 +2773,14 @@ int gru_launch(const GruArgs& g, hipStream_t st) {
     const int ntm = NT - (use_tail ? 1 : 0);
     // per XCD: its row tiles x column tiles, then at most NT + ceil(tails / 8) + 1 tail slots (see the kernel's map)
     const int64_t per_xcd = cdiv(cdiv(g.cap, 96), 8) * ntm + (use_tail ? ntm + cdiv(a.tail_blocks, 8) + 1 : 0);
-    hipLaunchKernelGGL((k_gru<3, 4>), dim3((unsigned)(8 * per_xcd)), dim3(768), 0, st, a);
+    TG_KLAUNCH((k_gru<3, 4>), dim3((unsigned)(8 * per_xcd)), dim3(768), 0, st, a);
     return check_launch("gru(96)");
   }
   const int64_t grid = 8 * cdiv(cdiv(g.cap, 128), 8) * NT;
   if (ks_knob == 2)
-    hipLaunchKernelGGL((k_gru<4, 2>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    TG_KLAUNCH((k_gru<4, 2>), dim3((unsigned)grid), dim3(512), 0, st, a);
   else
-    hipLaunchKernelGGL((k_gru<4, 1>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    TG_KLAUNCH((k_gru<4, 1>), dim3((unsigned)grid), dim3(256), 0, st, a);
   return check_launch("gru");
 }
 
@@ -2972,8 +2972,8 @@ int gemm_tn_launch(const TnArgs& a, hipStream_t st) {
   const int64_t fit = (int64_t)(a.part_floats / ((size_t)a.nbatch * a.n * (a.k + 1)));
   if (fit < 1) return TG_EWORKSPACE;
   splits = std::min(splits, fit);
-  hipLaunchKernelGGL(k_gemm_tn, dim3((unsigned)(tiles * splits)), dim3(256), 0, st, a, (int)splits);
-  hipLaunchKernelGGL(k_tn_reduce, dim3(flat_grid((int64_t)a.n * a.k * a.nbatch, 256)), dim3(256), 0, st, a, (int)splits);
+  TG_KLAUNCH(k_gemm_tn, dim3((unsigned)(tiles * splits)), dim3(256), 0, st, a, (int)splits);
+  TG_KLAUNCH(k_tn_reduce, dim3(flat_grid((int64_t)a.n * a.k * a.nbatch, 256)), dim3(256), 0, st, a, (int)splits);
   return check_launch("gemm_tn");
 }
 
@@ -3007,8 +3007,8 @@ int gemm_tn_group_launch(const TnArgs* list, int n, float* part, size_t part_flo
     g.first_block[p + 1] = g.first_block[p] + (int)(tiles * sp);
     g.first_rblock[p + 1] = g.first_rblock[p] + (int)std::min<int64_t>(cdiv((int64_t)a.n * a.k * a.nbatch, 256), 256);
   }
-  hipLaunchKernelGGL(k_gemm_tn_group, dim3((unsigned)g.first_block[n]), dim3(256), 0, st, g);
-  hipLaunchKernelGGL(k_tn_reduce_group, dim3((unsigned)g.first_rblock[n]), dim3(256), 0, st, g);
+  TG_KLAUNCH(k_gemm_tn_group, dim3((unsigned)g.first_block[n]), dim3(256), 0, st, g);
+  TG_KLAUNCH(k_tn_reduce_group, dim3((unsigned)g.first_rblock[n]), dim3(256), 0, st, g);
   return check_launch("gemm_tn_group");
 }
 
@@ -3046,8 +3046,8 @@ int colsum_launch(int64_t m_cap, const int32_t* m_dev, int n, const float* y, in
   int64_t splits = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(cdiv(512, ct), 16), cdiv(m_cap, 64)));
   splits = std::min<int64_t>(splits, (int64_t)(part_floats / (size_t)n));
   if (splits < 1) return TG_EWORKSPACE;
-  hipLaunchKernelGGL(k_colsum, dim3((unsigned)(ct * splits)), dim3(256), 0, st, m_cap, m_dev, n, y, ldy, part, (int)splits);
-  hipLaunchKernelGGL(k_colsum_reduce, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, n, part, (int)splits, alpha, out,
+  TG_KLAUNCH(k_colsum, dim3((unsigned)(ct * splits)), dim3(256), 0, st, m_cap, m_dev, n, y, ldy, part, (int)splits);
+  TG_KLAUNCH(k_colsum_reduce, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, n, part, (int)splits, alpha, out,
                      accumulate);
   return check_launch("colsum");
 }

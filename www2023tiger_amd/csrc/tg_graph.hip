@@ -260,9 +260,9 @@ int sample_batch_launch(const tg_tcsr* g, int64_t B, const int64_t* src, const i
   const CentresRider cr = rider ? *rider : CentresRider{};
   const SampleBatchArgs a{*g, B, src, dst, neg, ts, eids, off, K, nids3, ts3f, eids_b, o_nbr, o_eid, o_ts, mark, tmin_key};
   if (K <= 16)
-    hipLaunchKernelGGL(k_sample_batch<16>, dim3(flat_grid(Q, 16) + cr.blocks), dim3(256), 0, st, a, cr);
+    TG_KLAUNCH(k_sample_batch<16>, dim3(flat_grid(Q, 16) + cr.blocks), dim3(256), 0, st, a, cr);
   else
-    hipLaunchKernelGGL(k_sample_batch<64>, dim3(flat_grid(Q, 4) + cr.blocks), dim3(256), 0, st, a, cr);
+    TG_KLAUNCH(k_sample_batch<64>, dim3(flat_grid(Q, 4) + cr.blocks), dim3(256), 0, st, a, cr);
   return check_launch("sample_batch");
 }
 

@@ -331,10 +331,10 @@ int consume_gather_check_launch(const tg_model* m, const int64_t* involved, cons
                                 hipStream_t st, const PosArgs* pos, bool eager) {
   if (eager && !m->pending_vals) return TG_EINVAL;
   if (eager)
-    hipLaunchKernelGGL(k_consume_gather_check<true>, dim3(flat_grid(cap * (m->d / 4), 256)), dim3(256), 0, st, *m,
+    TG_KLAUNCH(k_consume_gather_check<true>, dim3(flat_grid(cap * (m->d / 4), 256)), dim3(256), 0, st, *m,
                        involved, n_involved, cap, (float4*)reprs, outdated, n_outdated, err, pos ? *pos : PosArgs{});
   else
-    hipLaunchKernelGGL(k_consume_gather_check<false>, dim3(flat_grid(cap * (m->d / 4), 256)), dim3(256), 0, st, *m,
+    TG_KLAUNCH(k_consume_gather_check<false>, dim3(flat_grid(cap * (m->d / 4), 256)), dim3(256), 0, st, *m,
                        involved, n_involved, cap, (float4*)reprs, outdated, n_outdated, err, pos ? *pos : PosArgs{});
   return check_launch("consume_gather_check");
 }
@@ -343,11 +343,11 @@ int writeback_launch(const tg_model* m, const WritebackArgs& a, int phase, hipSt
   const unsigned grid = flat_grid(2 * a.B, 4);
   if (phase == 2 && (!a.snap || !a.snap_ts || !m->pending_vals || a.rows || a.owner)) return TG_EINVAL;
   if (phase == 0)
-    hipLaunchKernelGGL(k_writeback<0>, dim3(grid), dim3(256), 0, st, *m, a);
+    TG_KLAUNCH(k_writeback<0>, dim3(grid), dim3(256), 0, st, *m, a);
   else if (phase == 1)
-    hipLaunchKernelGGL(k_writeback<1>, dim3(grid), dim3(256), 0, st, *m, a);
+    TG_KLAUNCH(k_writeback<1>, dim3(grid), dim3(256), 0, st, *m, a);
   else
-    hipLaunchKernelGGL(k_writeback_fused, dim3(grid), dim3(256), 0, st, *m, a);
+    TG_KLAUNCH(k_writeback_fused, dim3(grid), dim3(256), 0, st, *m, a);
   return check_launch("writeback");
 }
 
@@ -388,7 +388,7 @@ extern "C" int tg_time_encode(int64_t n, const float* ts, int32_t d, const float
   if (n < 0 || d <= 0) return TG_EINVAL;
   if (n == 0) return TG_OK;
   if (!ts || !freq || !phase || !out) return TG_EINVAL;
-  hipLaunchKernelGGL(k_time_encode, dim3(flat_grid(n * d, 256)), dim3(256), 0, as_stream(stream), n, ts, d, freq,
+  TG_KLAUNCH(k_time_encode, dim3(flat_grid(n * d, 256)), dim3(256), 0, as_stream(stream), n, ts, d, freq,
                      phase, out);
   return check_launch("tg_time_encode");
 }
@@ -398,7 +398,7 @@ extern "C" int tg_gather_rows(int64_t n, const int64_t* ids, int32_t width, cons
   if (n < 0 || width <= 0 || (width % 4) != 0) return TG_EINVAL;
   if (n == 0) return TG_OK;
   if (!ids || !table || !out || (ts_out && !ts_table)) return TG_EINVAL;
-  hipLaunchKernelGGL(k_gather_rows, dim3(flat_grid(n * (width / 4), 256)), dim3(256), 0, as_stream(stream), n,
+  TG_KLAUNCH(k_gather_rows, dim3(flat_grid(n * (width / 4), 256)), dim3(256), 0, as_stream(stream), n,
                      (const int32_t*)nullptr, ids, width / 4, (const float4*)table, (float4*)out, ts_table, ts_out);
   return check_launch("tg_gather_rows");
 }
@@ -409,7 +409,7 @@ extern "C" int tg_memory_scatter(int64_t n, const int32_t* n_dev, const int64_t*
   if (n < 0 || width <= 0 || (width % 4) != 0) return TG_EINVAL;
   if (n == 0) return TG_OK;
   if (!ids || !vals || !ts || !table || !ts_table || (check && !err)) return TG_EINVAL;
-  hipLaunchKernelGGL(k_memory_scatter, dim3(flat_grid(n * (width / 4), 256)), dim3(256), 0, as_stream(stream), n, n_dev,
+  TG_KLAUNCH(k_memory_scatter, dim3(flat_grid(n * (width / 4), 256)), dim3(256), 0, as_stream(stream), n, n_dev,
                      ids, src_index, (const int64_t*)nullptr, width / 4, (const float4*)vals, ts, (float4*)table, ts_table,
                      active, check, err);
   return check_launch("tg_memory_scatter");
@@ -422,7 +422,7 @@ extern "C" int tg_memory_scatter2(int64_t n, const int32_t* n_dev, const int64_t
   if (n < 0 || width <= 0 || (width % 4) != 0) return TG_EINVAL;
   if (n == 0) return TG_OK;
   if (!ids || !vals || !ts || !table || !ts_table || (check && !err)) return TG_EINVAL;
-  hipLaunchKernelGGL(k_memory_scatter, dim3(flat_grid(n * (width / 4), 256)), dim3(256), 0, as_stream(stream), n, n_dev,
+  TG_KLAUNCH(k_memory_scatter, dim3(flat_grid(n * (width / 4), 256)), dim3(256), 0, as_stream(stream), n, n_dev,
                      ids, val_index, ts_index, width / 4, (const float4*)vals, ts, (float4*)table, ts_table, active, check,
                      err);
   return check_launch("tg_memory_scatter2");
@@ -434,7 +434,7 @@ extern "C" int tg_mailbox_consume_gather(const tg_model* m, const int64_t* invol
   if (!model_ok(m) || cap < 0) return TG_EINVAL;
   if (cap == 0) return TG_OK;
   if (!involved || !n_involved || !reprs) return TG_EINVAL;
-  hipLaunchKernelGGL(k_gather_rows, dim3(flat_grid(cap * (m->d / 4), 256)), dim3(256), 0, as_stream(stream), cap,
+  TG_KLAUNCH(k_gather_rows, dim3(flat_grid(cap * (m->d / 4), 256)), dim3(256), 0, as_stream(stream), cap,
                      n_involved, involved, m->d / 4, (const float4*)m->right_vals, (float4*)reprs,
                      (const float*)nullptr, (float*)nullptr);
   return check_launch("tg_mailbox_consume_gather");
@@ -447,7 +447,7 @@ extern "C" int tg_consume_update_right(const tg_model* m, const int64_t* upos, c
   if (!model_ok(m) || cap < 0) return TG_EINVAL;
   if (cap == 0) return TG_OK;
   if (!upos || !n_upos || !reprs || !bitmap || !rank || !err) return TG_EINVAL;
-  hipLaunchKernelGGL(k_consume_update_right, dim3(flat_grid(cap, 4)), dim3(256), 0, as_stream(stream), *m, upos, n_upos,
+  TG_KLAUNCH(k_consume_update_right, dim3(flat_grid(cap, 4)), dim3(256), 0, as_stream(stream), *m, upos, n_upos,
                      cap, (const float4*)reprs, bitmap, rank, (const int64_t*)nullptr, err);
   return check_launch("tg_consume_update_right");
 }
@@ -458,7 +458,7 @@ extern "C" int tg_consume_update_right_rows(const tg_model* m, const int64_t* up
   if (!model_ok(m) || cap < 0) return TG_EINVAL;
   if (cap == 0) return TG_OK;
   if (!upos || !n_upos || !rows || !row_index || !err) return TG_EINVAL;
-  hipLaunchKernelGGL(k_consume_update_right, dim3(flat_grid(cap, 4)), dim3(256), 0, as_stream(stream), *m, upos, n_upos,
+  TG_KLAUNCH(k_consume_update_right, dim3(flat_grid(cap, 4)), dim3(256), 0, as_stream(stream), *m, upos, n_upos,
                      cap, (const float4*)rows, (const uint64_t*)nullptr, (const uint32_t*)nullptr, row_index, err);
   return check_launch("tg_consume_update_right_rows");
 }
@@ -539,7 +539,7 @@ extern "C" int tg_serve_rows(const tg_model* m, int64_t n_eff, const int64_t* ef
   if (!model_ok(m) || n_eff < 0 || n_msg < 0 || !m->pending_vals) return TG_EINVAL;
   if (n_eff + n_msg == 0) return TG_OK;
   if (!out || (n_eff && (!eff_ids || !eff_pos)) || (n_msg && (!msg_ids || !msg_pos))) return TG_EINVAL;
-  hipLaunchKernelGGL(k_serve_rows, dim3(flat_grid((n_eff + n_msg) * (m->d / 4), 256)), dim3(256), 0, as_stream(stream), *m,
+  TG_KLAUNCH(k_serve_rows, dim3(flat_grid((n_eff + n_msg) * (m->d / 4), 256)), dim3(256), 0, as_stream(stream), *m,
                      n_eff, eff_ids, eff_pos, n_msg, msg_ids, msg_pos, out);
   return check_launch("tg_serve_rows");
 }
@@ -550,7 +550,7 @@ extern "C" int tg_adopt_rows(const tg_model* m, int64_t n_eff, const int64_t* ef
   if (!model_ok(m) || n_eff < 0 || n_msg < 0) return TG_EINVAL;
   if (n_eff + n_msg == 0) return TG_OK;
   if (!rows || (n_eff && (!eff_ids || !eff_pos)) || (n_msg && (!msg_ids || !msg_pos))) return TG_EINVAL;
-  hipLaunchKernelGGL(k_adopt_rows, dim3(flat_grid((n_eff + n_msg) * (m->d / 4), 256)), dim3(256), 0, as_stream(stream), *m,
+  TG_KLAUNCH(k_adopt_rows, dim3(flat_grid((n_eff + n_msg) * (m->d / 4), 256)), dim3(256), 0, as_stream(stream), *m,
                      n_eff, eff_ids, eff_pos, n_msg, msg_ids, msg_pos, rows);
   return check_launch("tg_adopt_rows");
 }
@@ -560,7 +560,7 @@ extern "C" int tg_gather_eff_rows(const tg_model* m, int64_t n, const int64_t* i
   if (!model_ok(m) || n < 0 || !m->pending_vals) return TG_EINVAL;
   if (n == 0) return TG_OK;
   if (!ids || !out) return TG_EINVAL;
-  hipLaunchKernelGGL(k_gather_eff_rows, dim3(flat_grid(n * (m->d / 4), 256)), dim3(256), 0, as_stream(stream), *m, n, ids,
+  TG_KLAUNCH(k_gather_eff_rows, dim3(flat_grid(n * (m->d / 4), 256)), dim3(256), 0, as_stream(stream), *m, n, ids,
                      (float4*)out, ts_out);
   return check_launch("tg_gather_eff_rows");
 }
@@ -572,7 +572,7 @@ extern "C" int tg_store_events(const tg_model* m, int64_t B, const int64_t* src,
   if (!model_ok(m) || B < 0) return TG_EINVAL;
   if (B == 0) return TG_OK;
   if (!src || !dst || !ts || !eids || !upos || !index || !n_upos || !err) return TG_EINVAL;
-  hipLaunchKernelGGL(k_store_events, dim3(flat_grid(2 * B, 4)), dim3(256), 0, as_stream(stream), *m, B, src, dst, ts,
+  TG_KLAUNCH(k_store_events, dim3(flat_grid(2 * B, 4)), dim3(256), 0, as_stream(stream), *m, B, src, dst, ts,
                      eids, upos, index, n_upos, err);
   return check_launch("tg_store_events");
 }
@@ -583,7 +583,7 @@ extern "C" int tg_restart_apply(const tg_model* m, int64_t n, const int64_t* nid
   if (!model_ok(m) || n < 0) return TG_EINVAL;
   if (n == 0) return TG_OK;
   if (!nids || !h_left || !h_right || !prev_ts) return TG_EINVAL;
-  hipLaunchKernelGGL(k_restart_apply, dim3(flat_grid(n * (m->d / 4), 256)), dim3(256), 0, as_stream(stream), *m, n, nids,
+  TG_KLAUNCH(k_restart_apply, dim3(flat_grid(n * (m->d / 4), 256)), dim3(256), 0, as_stream(stream), *m, n, nids,
                      (const float4*)h_left, (const float4*)h_right, prev_ts);
   return check_launch("tg_restart_apply");
 }

@@ -481,7 +481,7 @@ void launch_attn_core(const tg_model* m, int64_t Q, const float* ts, const int64
   // per-node table of centre rows with the features folded in (1) - or none (0)
   const int fs = (m->nfeats && !key_rows && !ctab) ? 2 : (m->efeats ? 1 : 0);
 #define TG_CORE_FS(NH_, NV_, W_, FS_)                                                                                      \
-  hipLaunchKernelGGL((k_attn_core<NH_, NV_, W_, FS_>), dim3(cgrid), dim3(256), 0, st, *m, Q, ts, l1_nids, l1_eids, l1_ts,  \
+  TG_KLAUNCH((k_attn_core<NH_, NV_, W_, FS_>), dim3(cgrid), dim3(256), 0, st, *m, Q, ts, l1_nids, l1_eids, l1_ts,          \
                      reprs, bm, rank, (const float*)w.g, w.s, w.valid, dc, dc.p > 0.f ? w.rsum : (float*)nullptr, direct,  \
                      pos ? *pos : PosArgs{}, key_rows, zl, gtab, cnids, ctab)
 #define TG_CORE(NH_, NV_, W_)                  \
@@ -553,8 +553,11 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
   prof_mark(pf, stage++, st);
   tg_model mc = *m;  // without an edge table the fused weights are compact: the key rows have no edge segment
   if (!m->efeats) mc.d_e = 0;
-  launch_attn_core(&mc, Q, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, w, DropCfg{}, st, &rc, da ? 1 : 0, da ? pos : nullptr,
-                   key_rows, use_gtab ? m->g_table : nullptr, nids, (use_gtab && da) ? m->c_table : nullptr);
+  {
+    KSlot ks_(KT_CORE);
+    launch_attn_core(&mc, Q, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, w, DropCfg{}, st, &rc, da ? 1 : 0, da ? pos : nullptr,
+                     key_rows, use_gtab ? m->g_table : nullptr, nids, (use_gtab && da) ? m->c_table : nullptr);
+  }
   if (rc != TG_OK) return rc;
   prof_mark(pf, stage++, st);
   prof_mark(pf, stage++, st);
@@ -571,6 +574,7 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
   // ... or, with few enough 48 x 48 tiles, LDS-free K-split blocks that leave t itself (k_gemm_ks16): fc2 is then a plain
   // short-K product
   SkPlan sk{};
+  KSlot ks_fc1(KT_FC1);
   bool wb_on_fc1 = false;  // the write-back rider on the fc1 launch: then fc2 only stores STEP 6's rows (c2)
   bool gi_rode = false;  // the split updater's input-side product as a second problem of this launch (variant 1)
   const bool ks16 = gemm_ks16_launch(g, st, (wbr && pos && pos->win_row) ? wbr : nullptr, &wb_on_fc1,
@@ -578,6 +582,7 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
   const bool pieces = !ks16 && gemm_sk_partials(g, w.sk, TG_SK_WS_FLOATS, st, &sk);
   if (!ks16 && !pieces && (rc = gemm_launch(g, st)) != TG_OK) return rc;
   prof_mark(pf, stage++, st);
+  KSlot ks_fc2(KT_FC2);
   g = GemmArgs{};
   g.m_cap = Q; g.n = d; g.k = d;
   g.a0 = ASeg{w.t, d, d, nullptr};
@@ -662,7 +667,10 @@ int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float*
   if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
   // gather + scores + softmax + weighted raw sum
   prof_mark(pf, stage++, st);
-  launch_attn_core(m, Q, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, w, dc, st, &rc, da ? 1 : 0, da ? pos : nullptr, key_rows);
+  {
+    KSlot ks_(KT_CORE);
+    launch_attn_core(m, Q, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, w, dc, st, &rc, da ? 1 : 0, da ? pos : nullptr, key_rows);
+  }
   if (rc != TG_OK) return rc;
   // o_h = Wv_h s_h + bv_h
   prof_mark(pf, stage++, st);
@@ -689,8 +697,12 @@ int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float*
   g.a0 = ASeg{w.hh, E, E, nullptr}; g.a1 = ASeg{w.cc, d, d, nullptr};
   g.w = m->attn_fc1.w; g.ldw = E + d; g.bias = m->attn_fc1.b;
   g.c = w.t; g.ldc = d; g.relu = 1; g.alpha = 1.f; g.nbatch = 1;
-  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  {
+    KSlot ks_(KT_FC1);
+    if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  }
   prof_mark(pf, stage++, st);
+  KSlot ks_fc2(KT_FC2);
   g = GemmArgs{};
   g.m_cap = Q; g.n = d; g.k = d;
   g.a0 = ASeg{w.t, d, d, nullptr};
@@ -989,7 +1001,14 @@ static_assert(ST_ATTN_PREP == ST_ATTN_FIRST, "attention stage numbering");
 struct tg_profiler {
   hipEvent_t ev[tg::ST_COUNT + 1];
   bool armed;
+  tg::KTimer kt;
 };
+namespace tg {
+thread_local KTimer* g_kt = nullptr;
+thread_local int g_kt_slot = KT_NONE;
+static const char* const kSlotNames[KT_COUNT] = {"collate(sampler+centres)", "attn_core", "fc1", "fc2", "updater", "query_rows",
+                                                 "writeback", "gather"};
+}  // namespace tg
 
 static inline void prof_mark(tg_profiler* p, int i, hipStream_t st) {
   if (p) (void)hipEventRecord(p->ev[i], st);
@@ -1003,11 +1022,22 @@ extern "C" tg_profiler* tg_profiler_create(void) {
       delete p;
       return nullptr;
     }
+  for (int i = 0; i < KT_COUNT; ++i) {
+    p->kt.name[i] = "";
+    p->kt.hit[i] = false;
+    for (int j = 0; j < 2; ++j)
+      if (hipEventCreate(&p->kt.ev[i][j]) != hipSuccess) {
+        delete p;
+        return nullptr;
+      }
+  }
   return p;
 }
 extern "C" void tg_profiler_destroy(tg_profiler* p) {
   if (!p) return;
   for (int i = 0; i <= ST_COUNT; ++i) (void)hipEventDestroy(p->ev[i]);
+  for (int i = 0; i < KT_COUNT; ++i)
+    for (int j = 0; j < 2; ++j) (void)hipEventDestroy(p->kt.ev[i][j]);
   delete p;
 }
 extern "C" int tg_profiler_num_stages(void) { return ST_COUNT; }
@@ -1025,6 +1055,26 @@ extern "C" int tg_profiler_read(tg_profiler* p, float* ms_out) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]);
     ms_out[i] = ms;
+  }
+  return TG_OK;
+}
+
+extern "C" int tg_profiler_num_kernel_slots(void) { return KT_COUNT; }
+extern "C" const char* tg_profiler_kernel_slot_name(int slot) { return (slot >= 0 && slot < KT_COUNT) ? kSlotNames[slot] : ""; }
+// kernel-bound durations of the last profiled step: ms_out[slot] (< 0: no launch was made under the slot),
+// names_out[slot] (nullable) = the launch expression of the timed kernel
+extern "C" int tg_profiler_kernel_ms(tg_profiler* p, float* ms_out, const char** names_out) {
+  if (!p || !ms_out || !p->armed) return TG_EINVAL;
+  hipError_t e = hipEventSynchronize(p->ev[ST_COUNT]);
+  if (e != hipSuccess) {
+    set_hip_error(e, "tg_profiler_kernel_ms");
+    return TG_EHIP;
+  }
+  for (int i = 0; i < KT_COUNT; ++i) {
+    float ms = -1.f;
+    if (p->kt.hit[i] && hipEventElapsedTime(&ms, p->kt.ev[i][0], p->kt.ev[i][1]) != hipSuccess) ms = -1.f;
+    ms_out[i] = ms;
+    if (names_out) names_out[i] = p->kt.hit[i] ? p->kt.name[i] : "";
   }
   return TG_OK;
 }
@@ -1248,7 +1298,7 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
     if ((rc = sample_nodes_launch(g, Q, w.nids3, w.ts3, (int32_t)K, w.l1n, w.l1e, w.l1t, need_flags ? w.flags : nullptr, st)) !=
         TG_OK)
       return rc;
-  } else if ((rc = sample_batch_launch(g, B, io->src, io->dst, io->neg, io->ts, io->eids, io->offset_dev, (int32_t)K,
+  } else if (KSlot ks_(KT_COLLATE); (rc = sample_batch_launch(g, B, io->src, io->dst, io->neg, io->ts, io->eids, io->offset_dev, (int32_t)K,
                                        w.nids3, w.ts3f, w.eids, w.l1n, w.l1e, w.l1t, need_flags ? w.flags : nullptr, st,
                                        lz ? reinterpret_cast<uint32_t*>(w.counts + 4) : nullptr,
                                        (w.lean && !lz) ? &rider : nullptr)) != TG_OK)  // (centres: behind the restart loop)
@@ -1279,12 +1329,12 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   prof_mark(pf, ST_GATHER, st);
   w.dedup_done = pp != nullptr && pp->best != nullptr;
   // ---- STEP 1-2: reprs = right_memory[involved] (+ invariants); outdated rows <- updater(...)
-  if (!w.direct &&
+  if (KSlot ks_(KT_GATHER); !w.direct &&
       (rc = consume_gather_check_launch(m, w.inv, w.counts + 0, cap, w.reprs, w.outdated, w.counts + 1, io->err, st, pp,
                                         eager)) != TG_OK)
     return rc;
   prof_mark(pf, ST_UPDATE, st);
-  if (!eager &&  // eager: the rows were gathered from the table of precomputed updater rows just now
+  if (KSlot ks_(KT_UPDATER); !eager &&  // eager: the rows were gathered from the table of precomputed updater rows just now
       (rc = apply_messages(m, w.outdated, w.out_pos, w.counts + 1, cap, w.reprs, io->err, w.apply_ws, w.apply_bytes,
                            st, true, gates, io->rows_hint)) != TG_OK)
     return rc;
@@ -1430,7 +1480,7 @@ int step_writeback_b(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, 
     wa.snap_ts = w.snap_ts;
   }
   // (rider: STEP 4-6 already ran inside the launch of the attention block's last product)
-  if (!(w.fused_wb && w.wb_rode) && (rc = writeback_launch(m, wa, w.fused_wb ? 2 : 1, st)) != TG_OK) return rc;
+  if (KSlot ks_(KT_WRITEBACK); !(w.fused_wb && w.wb_rode) && (rc = writeback_launch(m, wa, w.fused_wb ? 2 : 1, st)) != TG_OK) return rc;
   prof_mark(pf, ST_EAGER, st);
   if (w.eager && !io->embed_only) {
     // every unique positive node has just received a message (STEP 5) and its memories are final for this batch
@@ -1452,6 +1502,7 @@ int step_writeback_b(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, 
       co.stream_len = io->stream_len;
     }
     const bool ctab = cr && m->c_table;  // ... or straight into the per-node table of centre rows
+    KSlot ks_upd(KT_UPDATER);
     if (w.tail_pending && (rc = gru_tail_launch(w.tail, st)) != TG_OK) return rc;  // (split updater, variant 2)
     if (!w.upd_done && !w.tail_pending &&  // (split updater: these rows were finished on fc2's launch)
         (rc = apply_messages(m, w.upos, w.upos32, n_upos, P, m->pending_vals, io->err, w.apply_ws, w.apply_bytes, st,
@@ -1463,6 +1514,7 @@ int step_writeback_b(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, 
   if (w.gtab) {
     // ... and the query rows of the same nodes: their effective rows have just changed (tg_model.g_table)
     bool rode = false;
+    KSlot ks_q(KT_QROWS);
     if ((rc = gtab_rows(m, 2 * io->B, w.upos, w.upos32, n_upos, w.attn.t, st, m->upd_fn == TG_UPD_GRU,
                         w.prefetch ? &co : nullptr, &rode, io->rows_hint)) != TG_OK)
       return rc;
@@ -1495,6 +1547,14 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
   if (m->row_of && !io->collate_only && !(io->embed_only && io->lean && m->pending_vals && !io->inner)) return TG_EUNSUPPORTED;
   hipStream_t st = as_stream(stream);
   tg_profiler* pf = (tg_profiler*)io->profiler;
+  struct KtScope {  // kernel-bound timing of the step's main launches while a profiler is attached (tg_common.h)
+    explicit KtScope(tg_profiler* p) {
+      if (p)
+        for (int i = 0; i < KT_COUNT; ++i) p->kt.hit[i] = false;
+      g_kt = p ? &p->kt : nullptr;
+    }
+    ~KtScope() { g_kt = nullptr; }
+  } kt_scope(pf);
   Carver cv(ws, ws_bytes);
   StepWs w{};
   if (!carve_step(m, io->B, cv, w, io->inner ? 2 : 1)) return TG_EWORKSPACE;
