@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 6
+#define TG_ABI_VERSION 7
 
 /* status codes */
 #define TG_OK 0
@@ -509,6 +509,13 @@ typedef struct tg_step_io {
    *                    *prefetch_state == 1 on entry and exit. */
   int64_t stream_len;
   int32_t* prefetch_state;
+  /* Debug outputs (ABI 7; NULL = off): the neighbour lists of the batch THIS call consumes - [3B, K] each, as l1_nids /
+   * l1_eids / l1_ts - copied out of the workspace before the step's last launch replaces them with the next batch's.
+   * They let the collate-prefetch form, whose l1_* outputs must be NULL, be checked for bit-exact neighbour indices
+   * (graph.py:67-148) exactly as it is timed. */
+  int64_t* dbg_l1_nids;
+  int64_t* dbg_l1_eids;
+  float* dbg_l1_ts;
 } tg_step_io;
 
 /* The reference loop draws `np.random.rand() < restart_prob` before every batch but the first; a hit sets

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, n), f'{n} declared in tiger_hip.h but not exported'
         assert n in _lib.SIGNATURES, f'{n} has no ctypes signature'
     assert set(_lib.SIGNATURES) == set(names)
-    assert _lib.lib.tg_abi_version() == 6
+    assert _lib.lib.tg_abi_version() == 7
 
 
 def test_struct_layouts_match_header():
@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.TgTcsr) == 6 * 8
     assert ctypes.sizeof(_lib.TgLinear) == 16
     assert ctypes.sizeof(_lib.TgModel) == 8 + 8 * 4 + 8 * 13 + 2 * 16 + 4 * 8 + 2 * 16 + 4 * 8 + 3 * 16 + 8 + 8 + 8 + 8 + 8
-    assert ctypes.sizeof(_lib.TgStepIo) == 26 * 8
+    assert ctypes.sizeof(_lib.TgStepIo) == 29 * 8
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):

@@ -55,7 +55,7 @@ def test_c2_graph_replay_of_the_resident_lean_step_matches_oracle(n_eager, prefe
     model.eager_updates()
     # prefetch (bench.py's default): sampler + centres of the next batch ride on the step's last launch (tg_step_io.
     # prefetch_state); the neighbour lists are then not an output of the step
-    buf = model.StepBuffers(model, B, False, resident=_resident(stream), prefetch=prefetch)
+    buf = model.StepBuffers(model, B, False, resident=_resident(stream), prefetch=prefetch, debug_lists=prefetch)
     buf.io.lean = 1
     _ = model.graph.tcsr, model.model_struct()
 
@@ -68,6 +68,12 @@ def test_c2_graph_replay_of_the_resident_lean_step_matches_oracle(n_eager, prefe
         ref = orc.stream_step(*a, cg).numpy()
         if not prefetch:
             np.testing.assert_array_equal(buf.l1_nids.cpu().numpy(), cg['l1_nids'])
+        else:  # the lists the step consumed (prefetched by the previous step's last launch): bit-exact (graph.py:67-148)
+            np.testing.assert_array_equal(buf.dbg_l1_nids.cpu().numpy(), cg['l1_nids'])
+            np.testing.assert_array_equal(buf.dbg_l1_eids.cpu().numpy(), cg['l1_eids'])
+            np.testing.assert_array_equal(buf.dbg_l1_ts.cpu().numpy(), cg['l1_ts'])
+        if not prefetch:
+            pass
         elif b >= 1 and n_eager and os.environ.get('TG_PREFETCH', '1') != '0' and os.environ.get('TG_GTAB', '1') != '0':
             # (a graph captured at the very first step replays collate + prefetch: the flag stays 0; the knobs switch it off)
             assert buf._pf_state.value == 1  # every step after the first started with its attention core
@@ -106,13 +112,16 @@ def test_c2_graph_of_several_steps_matches_oracle():
     model, orc = bench.build_models(stream, d, K, c['msg_src'], c['upd_src'], with_oracle=True)
     model.fuse_attention()
     model.eager_updates()
-    buf = model.StepBuffers(model, B, False, resident=_resident(stream), prefetch=True)
+    buf = model.StepBuffers(model, B, False, resident=_resident(stream), prefetch=True, debug_lists=True)
     buf.io.lean = 1
     _ = model.graph.tcsr, model.model_struct()
+    last_cg = {}
 
     def oracle_step(b):
         a = [stream[k][b * B:(b + 1) * B] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
-        return orc.stream_step(*a, O.collate(orc.graph, a[0], a[1], a[2], a[3], K, 'static')).numpy()
+        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], K, 'static')
+        last_cg.update(cg)
+        return orc.stream_step(*a, cg).numpy()
 
     for b in range(n_eager):
         model.launch_step(buf)
@@ -137,6 +146,10 @@ def test_c2_graph_of_several_steps_matches_oracle():
             b += 1
         assert int(buf.err.item()) == 0 and int(buf.offset.item()) == b * B
         assert_close(buf.h[:2 * B].cpu().numpy(), ref, f'h_left, replay {r}', TOL)
+        # the neighbour lists the LAST step of the replay consumed (prefetched inside the graph): bit-exact
+        np.testing.assert_array_equal(buf.dbg_l1_nids.cpu().numpy(), last_cg['l1_nids'])
+        np.testing.assert_array_equal(buf.dbg_l1_eids.cpu().numpy(), last_cg['l1_eids'])
+        np.testing.assert_array_equal(buf.dbg_l1_ts.cpu().numpy(), last_cg['l1_ts'])
     compare_state_with_oracle(model, orc)
 
 

@@ -1303,6 +1303,12 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
                                        lz ? reinterpret_cast<uint32_t*>(w.counts + 4) : nullptr,
                                        (w.lean && !lz) ? &rider : nullptr)) != TG_OK)  // (centres: behind the restart loop)
     return rc;
+  if (io->dbg_l1_nids || io->dbg_l1_eids || io->dbg_l1_ts) {  // the lists this step consumes, before its last launch prefetches the next
+    const size_t n = (size_t)Q * K;
+    if (io->dbg_l1_nids && (e = hipMemcpyAsync(io->dbg_l1_nids, w.l1n, n * 8, hipMemcpyDeviceToDevice, st)) != hipSuccess) return TG_EHIP;
+    if (io->dbg_l1_eids && (e = hipMemcpyAsync(io->dbg_l1_eids, w.l1e, n * 8, hipMemcpyDeviceToDevice, st)) != hipSuccess) return TG_EHIP;
+    if (io->dbg_l1_ts && (e = hipMemcpyAsync(io->dbg_l1_ts, w.l1t, n * 4, hipMemcpyDeviceToDevice, st)) != hipSuccess) return TG_EHIP;
+  }
   // second hop (data_loader.py:128-131): every neighbour slot (padding included) queried at its own float32 timestamp
   if (inner && (rc = sample_edges_f32_launch(g, Q * K, w.l1n, w.l1t, (int32_t)K, w.h2n, w.h2e, w.h2t,
                                              need_flags ? w.flags : nullptr, st)) != TG_OK)

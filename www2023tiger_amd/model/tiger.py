@@ -643,7 +643,8 @@ class TIGE(nn.Module):
         tg_stream_step; reused every step so the call sequence can be graph-captured."""
 
         def __init__(self, model: 'TIGE', B: int, want_prev: bool, resident=None, embed_only: bool = False,
-                     h_out=None, h_new_out=None, want_h_new: bool = True, lean: bool = False, prefetch: bool = False):
+                     h_out=None, h_new_out=None, want_h_new: bool = True, lean: bool = False, prefetch: bool = False,
+                     debug_lists: bool = False):
             """resident = (src, dst, neg, ts64, eids) device tensors of the WHOLE stream: the
             step then reads batch [offset, offset+B) and advances `offset` on device.
             lean: the caller does not read `involved` nor counts[0:2] (tiger_hip.h: tg_step_io.lean) - an eager
@@ -696,6 +697,15 @@ class TIGE(nn.Module):
                 self.io.stream_len = int(self.src.numel())
                 self.io.prefetch_state = C.addressof(self._pf_state)
                 self.io.l1_nids = self.io.l1_eids = self.io.l1_ts = None
+            # debug_lists: the neighbour lists of the batch a step CONSUMES, copied out before its last launch replaces them
+            # (tiger_hip.h: tg_step_io.dbg_l1_*) - the collate-prefetch form has no other way to show them
+            self.dbg_l1_nids = self.dbg_l1_eids = self.dbg_l1_ts = None
+            if debug_lists:
+                self.dbg_l1_nids = torch.zeros(3 * B, K, **i64)
+                self.dbg_l1_eids = torch.zeros(3 * B, K, **i64)
+                self.dbg_l1_ts = torch.zeros(3 * B, K, dtype=torch.float32, device=dev)
+                self.io.dbg_l1_nids, self.io.dbg_l1_eids, self.io.dbg_l1_ts = (ptr(self.dbg_l1_nids), ptr(self.dbg_l1_eids),
+                                                                               ptr(self.dbg_l1_ts))
 
         def attach_profiler(self, prof):
             self.io.profiler = prof
