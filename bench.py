@@ -860,6 +860,9 @@ def main():
     ap.add_argument('--force-dist', action='store_true', help='run the multi-GPU code path even with one rank')
     ap.add_argument('--dist-graphs', action='store_true',
                     help='multi-GPU: replay captured hipGraphs around the exchange (experimental; default eager)')
+    ap.add_argument('--dist-exchange', default='ipc', choices=['ipc', 'rccl'],
+                    help='partitioned layout: ipc = one library call per step whose exchanges are kernels storing into the peers\' '
+                         'exported windows (one node; graphs of several steps); rccl = eager launches around two all_to_all_single')
     ap.add_argument('--dist-mode', default='partitioned', choices=['partitioned', 'replicated'],
                     help='multi-GPU state layout (www2023tiger_amd/dist.py)')
     ap.add_argument('--dist-full-tables', action='store_true',

@@ -51,6 +51,7 @@ extern "C" {
 #define TG_ERR_MSG_BEFORE_MEM 8u   /* message_modules.py:158-159 */
 #define TG_ERR_MSG_TS_MISMATCH 16u /* tiger.py:325-327 (msg_src == left) */
 #define TG_ERR_EVENT_BEFORE_MEM 32u /* tiger.py:437-438 */
+#define TG_ERR_XCHG_TIMEOUT 64u    /* tg_part_step: a peer's rows did not arrive within the bounded wait (no reference counterpart) */
 
 int tg_abi_version(void);
 /* text of the last HIP runtime error seen by this thread ("" if none) */
@@ -739,6 +740,73 @@ int tg_adopt_rows(const tg_model* m, int64_t n_eff, const int64_t* eff_ids, cons
 
 size_t tg_stream_writeback_workspace_bytes(const tg_model* m, int64_t Bg);
 int tg_stream_writeback(const tg_model* m, const tg_writeback_io* io, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Multi-GPU, partitioned state: one global batch on one rank as ONE call     */
+/* (www2023tiger_amd/dist.py: ResidentPartitionedStream; no reference          */
+/* counterpart - per batch the owners' rows equal tiger.py:196-255 on the      */
+/* global batch)                                                               */
+/* ------------------------------------------------------------------------- */
+/* The two exchanges of a step - PULL: owners -> users, the effective right-memory rows of remote involved nodes and the
+ * message-source rows of remote "other" endpoints; PUSH: users -> owners, h(t-) of winning positions of nodes owned
+ * elsewhere - are kernels that store straight into the PEER's window (memory every rank allocates with tg_xchg_alloc and
+ * exports once with tg_ipc_export; peers map it with tg_ipc_import; ranks of one node: the stores travel over xGMI) and
+ * raise an epoch flag there; the consuming kernels wait for the flags of all peers (bounded: TG_ERR_XCHG_TIMEOUT).  No
+ * collective call, no host work inside a step: tg_part_step can be captured into a hipGraph, several steps per graph -
+ * every per-step array below is a table over ALL steps of a resident stream, slice s = *step_dev, and the call ends by
+ * advancing *step_dev.  Windows are double-buffered by step parity; every rank waits for every peer in every step, so a
+ * rank is never more than one step ahead of a peer's reads.
+ * Launches per step: begin (stage the plan slices, serve rows, signal) | adopt (wait, arena mapping, rows into the
+ * tables) | the embedding step (tg_stream_step, embed_only + lean: sampler + centres, G, core, fc1, fc2) | push (rows,
+ * signal) | STEP 4+5 of the owner's winners | recv (wait, pushed rows behind the embeddings) | STEP 6 | eager updater. */
+#define TG_MAX_RANKS 16
+typedef struct tg_part {
+  int32_t world, rank;
+  int64_t n_steps, Bg;      /* steps in the tables; events of a global batch */
+  int64_t* step_dev;        /* device step counter (in / out) */
+  int64_t* cur_step;        /* device scratch [1] */
+  /* windows: pull_in[q] / push_in[q] / flags[q] = rank q's window as mapped HERE (q == rank: this rank's own).
+   * pull inbox [2][world][pull_max] rows of d + 4 floats (row | time, 3 spare); push inbox [2][world][push_max] rows of d
+   * floats; flags uint32 [2][TG_MAX_RANKS]: flags[kind][q] = last epoch (step + 1) rank q completed for `kind` */
+  float* pull_in[TG_MAX_RANKS];
+  float* push_in[TG_MAX_RANKS];
+  uint32_t* flags[TG_MAX_RANKS];
+  int64_t pull_max, push_max;
+  uint32_t* ticket;         /* device [2], zero: block counters of the two producing kernels */
+  uint32_t* err;            /* invariant word (TG_ERR_*) */
+  /* plan tables (device; stride per step in brackets) */
+  const int64_t *g_src, *g_dst, *g_eids;  /* the global batches [Bg] */
+  const float* ts32;                      /* float32 event times tiled over cat[src, dst] [2 Bg] */
+  const int64_t* left_row;                /* row of h(t-) per position of cat[src, dst] [2 Bg]: own rows of the rank's
+                                           * [3B | world * push_max] output buffer, received rows behind them */
+  int64_t serve_cap;                      /* PULL, owner side [serve_cap]: n_serve[s] live entries */
+  const int32_t *n_serve, *serve_row, *serve_kind, *serve_peer, *serve_slot;
+  const int32_t *adopt_row, *adopt_kind;  /* PULL, user side [world * pull_max]: inbox slot -> state row (-1: unused), kind */
+  int64_t req_cap;                        /* arena mapping [req_cap]: row_of[req_node] = req_row for this step */
+  const int32_t* n_req;
+  const int64_t* req_node;
+  const int32_t* req_row;
+  int64_t push_cap;                       /* PUSH, user side [push_cap] */
+  const int32_t *n_push, *push_src, *push_peer, *push_slot;
+  int64_t mine_cap;                       /* the winners this rank writes [mine_cap]: node, position, state row */
+  const int32_t* n_mine;
+  const int64_t *mine_node, *mine_index, *mine_row;
+  /* staging (device, fixed addresses): this step's slices as the write-back / updater launches read them */
+  int64_t *st_src, *st_dst, *st_eids, *st_left_row, *st_mine_node, *st_mine_index, *st_mine_row;
+  float* st_ts32;
+  int32_t *st_mine32, *st_n_mine;
+  const int32_t* owner;     /* [n_nodes] */
+  int32_t* row_of;          /* the model's row_of, writable (NULL: full-height tables) */
+} tg_part;
+/* io: an embed_only + lean step over the rank's resident events (h with room for 3 B + world * push_max rows);
+ * ws: its workspace; aws: tg_apply_messages_workspace_bytes(m, mine_cap). */
+int tg_part_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, const tg_part* p, void* ws, size_t ws_bytes,
+                 void* aws, size_t aws_bytes, void* stream);
+int tg_xchg_alloc(size_t bytes, void** out);  /* zero-filled device memory peers may store into */
+int tg_xchg_free(void* p);
+int tg_ipc_export(void* p, uint8_t* handle64);            /* hipIpcGetMemHandle */
+int tg_ipc_import(const uint8_t* handle64, void** out);   /* hipIpcOpenMemHandle (another process's window) */
+int tg_ipc_close(void* p);
 
 #ifdef __cplusplus
 }

@@ -93,7 +93,8 @@ def test_struct_layouts_match_the_header(tmp_path):
     pairs = {'tg_tcsr': _lib.TgTcsr, 'tg_linear': _lib.TgLinear, 'tg_model': _lib.TgModel,
              'tg_seq_restarter': _lib.TgSeqRestarter, 'tg_step_io': _lib.TgStepIo,
              'tg_writeback_io': _lib.TgWritebackIo, 'tg_score_params': _lib.TgScoreParams,
-             'tg_train_io': _lib.TgTrainIo, 'tg_adam_seg': _lib.TgAdamSeg, 'tg_lazy_restart': _lib.TgLazyRestart}
+             'tg_train_io': _lib.TgTrainIo, 'tg_adam_seg': _lib.TgAdamSeg, 'tg_lazy_restart': _lib.TgLazyRestart,
+             'tg_part': _lib.TgPart}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "tiger_hip.h"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')

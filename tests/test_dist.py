@@ -459,7 +459,8 @@ def test_partitioned_state_equals_single_process_cpu_gloo(tmp_path, world, balan
     same(got['msg'][ref.has_msg], ref.msg_vals.numpy()[ref.has_msg], err_msg='mailbox')
 
 
-def _partitioned_gpu_worker(rank, world, port, name, B, n_steps, resident, out_dir, lopsided=False, physical=False):
+def _partitioned_gpu_worker(rank, world, port, name, B, n_steps, resident, out_dir, lopsided=False, physical=False,
+                            exchange='rccl', graph_steps=0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
@@ -477,11 +478,25 @@ def _partitioned_gpu_worker(rank, world, port, name, B, n_steps, resident, out_d
         owner = np.zeros_like(owner)
     keys = ('src', 'dst', 'neg', 'ts', 'eids')
     if resident:  # all plans up front, balanced shards (the benchmarked form)
-        rs = ResidentPartitionedStream(model, {k: z[k] for k in keys}, owner, rank, world, B, n_steps, physical=physical)
+        rs = ResidentPartitionedStream(model, {k: z[k] for k in keys}, owner, rank, world, B, n_steps, physical=physical,
+                                       exchange=exchange)
         eng = rs.engine
-        for _ in range(n_steps):
+        if graph_steps:  # one eager step, then graphs of `graph_steps` steps (the window form: tg_part_step)
             rs.step()
+            tdist.barrier()
+            rs.capture_steps(graph_steps)
+            tdist.barrier()
+            while rs.steps_done + graph_steps <= n_steps:
+                rs.replay()
+            torch.cuda.synchronize()
+            while rs.steps_done < n_steps:
+                rs.step()
+        else:
+            for _ in range(n_steps):
+                rs.step()
+        torch.cuda.synchronize()
         rs.check_invariants()
+        tdist.barrier()  # nobody unmaps a window a peer may still be storing into
     else:         # plan + run per batch, events on the owner of their destination
         eng = HipPartitionEngine(model, cap=Bg)
         if physical:
@@ -492,7 +507,7 @@ def _partitioned_gpu_worker(rank, world, port, name, B, n_steps, resident, out_d
         eng.check_invariants()
     if physical:  # this rank's tables hold its own rows (+ an arena): scattered back to node ids for the comparison
         assert model.left_memory.vals.shape[0] == 1 + eng.n_own + max(eng.arena_rows, 1)  # row 0 | own rows | arena
-        assert eng.n_own < int(z['n_nodes']) - 1                                            # (the ranks really share the nodes)
+        assert world == 1 or eng.n_own < int(z['n_nodes']) - 1                              # (the ranks really share the nodes)
         f = eng.export_full()
         _save_owned(os.path.join(out_dir, f'rank{rank}.npz'), owner, rank, f['left'], f['right'], f['left_ts'], f['right_ts'],
                     f['msg'], f['msg_ts'], f['has'])
@@ -518,6 +533,40 @@ def test_partitioned_state_equals_single_gpu(tmp_path, name, world, B, resident,
     n_steps = min(6, len(load(name)['src']) // (B * world))
     mp.spawn(_partitioned_gpu_worker, args=(world, free_port(), name, B, n_steps, resident, str(tmp_path), False, physical),
              nprocs=world, join=True)
+    z = load(name)
+    cfg = parse_cfg(z)
+    model, _, _ = build_hip_model(z, cfg)
+    model.fuse_attention()
+    model.eager_updates()
+    Bg = B * world
+    for b in range(n_steps):
+        sl = slice(b * Bg, (b + 1) * Bg)
+        model.stream_step(*(z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')))
+    got, _ = _assemble_owned(str(tmp_path), world)
+    has = model.msg_store.has_msg_mask().cpu().numpy()
+    np.testing.assert_array_equal(got['has'], has)
+    np.testing.assert_array_equal(got['left_ts'], model.left_memory.update_ts.cpu().numpy())
+    np.testing.assert_array_equal(got['right_ts'], model.right_memory.update_ts.cpu().numpy())
+    np.testing.assert_array_equal(got['msg_ts'][has], model.msg_store.node_msg_ts.cpu().numpy()[has])
+    assert rel_err(got['left'], model.left_memory.vals.cpu().numpy()) < 1e-6
+    assert rel_err(got['right'], model.right_memory.vals.cpu().numpy()) < 1e-6
+    assert rel_err(got['msg'][has], model.msg_store.node_msg_vals.cpu().numpy()[has]) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,world,B,physical,graph_steps', [
+    ('static_ll_d16', 2, 48, True, 0), ('static_ll_d16', 4, 24, True, 0), ('seq_rr_d8_nofeat', 2, 50, False, 0),
+    ('static_ll_d16', 2, 48, True, 2), ('static_ll_d16', 4, 24, False, 2), ('static_ll_d16', 1, 96, True, 2)])
+def test_partitioned_window_exchange_equals_single_gpu(tmp_path, name, world, B, physical, graph_steps):
+    """The partitioned step as ONE library call per global batch (tg_part_step): the two exchanges are kernels that store
+    into the peers' exported windows (hipIpcGetMemHandle; the ranks are processes sharing the test box's one GPU) and
+    signal with epoch flags - no collective in the step.  Eager calls and replays of a captured graph of two steps, two
+    and four ranks (and the one-rank point of the form), physical partition and full-height tables: the owners' rows
+    against the single-GPU fused step on the same global batches."""
+    from test_hip_parity import build_hip_model
+    n_steps = min(6, len(load(name)['src']) // (B * world))
+    mp.spawn(_partitioned_gpu_worker, args=(world, free_port(), name, B, n_steps, True, str(tmp_path), False, physical, 'ipc',
+                                            graph_steps), nprocs=world, join=True)
     z = load(name)
     cfg = parse_cfg(z)
     model, _, _ = build_hip_model(z, cfg)

@@ -80,6 +80,27 @@ class TgLazyRestart(C.Structure):
                 ('restarting_dev', vp), ('uptodate', vp), ('list', vp), ('tmin', vp)]
 
 
+TG_MAX_RANKS = 16
+
+
+class TgPart(C.Structure):
+    """tiger_hip.h: tg_part - one rank's view of the partitioned multi-GPU step (windows, plan tables, staging)"""
+    _fields_ = [
+        ('world', i32), ('rank', i32), ('n_steps', i64), ('Bg', i64), ('step_dev', vp), ('cur_step', vp),
+        ('pull_in', vp * TG_MAX_RANKS), ('push_in', vp * TG_MAX_RANKS), ('flags', vp * TG_MAX_RANKS),
+        ('pull_max', i64), ('push_max', i64), ('ticket', vp), ('err', vp),
+        ('g_src', vp), ('g_dst', vp), ('g_eids', vp), ('ts32', vp), ('left_row', vp),
+        ('serve_cap', i64), ('n_serve', vp), ('serve_row', vp), ('serve_kind', vp), ('serve_peer', vp), ('serve_slot', vp),
+        ('adopt_row', vp), ('adopt_kind', vp),
+        ('req_cap', i64), ('n_req', vp), ('req_node', vp), ('req_row', vp),
+        ('push_cap', i64), ('n_push', vp), ('push_src', vp), ('push_peer', vp), ('push_slot', vp),
+        ('mine_cap', i64), ('n_mine', vp), ('mine_node', vp), ('mine_index', vp), ('mine_row', vp),
+        ('st_src', vp), ('st_dst', vp), ('st_eids', vp), ('st_left_row', vp), ('st_mine_node', vp), ('st_mine_index', vp),
+        ('st_mine_row', vp), ('st_ts32', vp), ('st_mine32', vp), ('st_n_mine', vp),
+        ('owner', vp), ('row_of', vp),
+    ]
+
+
 class TgWritebackIo(C.Structure):
     _fields_ = [
         ('Bg', i64), ('src', vp), ('dst', vp), ('ts', vp), ('eids', vp), ('offset_dev', vp), ('advance', i32),
@@ -166,6 +187,12 @@ SIGNATURES = {
     'tg_stream_step_zero_bytes': (sz, [P(TgModel), i64]),
     'tg_stream_step_zero_bytes2': (sz, [P(TgModel), i64, i32]),
     'tg_stream_step_form': (i32, [P(TgModel), P(TgStepIo)]),
+    'tg_part_step': (C.c_int, [P(TgModel), P(TgTcsr), P(TgStepIo), P(TgPart), vp, sz, vp, sz, vp]),
+    'tg_xchg_alloc': (C.c_int, [sz, P(vp)]),
+    'tg_xchg_free': (C.c_int, [vp]),
+    'tg_ipc_export': (C.c_int, [vp, vp]),
+    'tg_ipc_import': (C.c_int, [vp, P(vp)]),
+    'tg_ipc_close': (C.c_int, [vp]),
     'tg_stream_step': (C.c_int, [P(TgModel), P(TgTcsr), P(TgStepIo), vp, sz, vp]),
     'tg_train_step_workspace_bytes': (sz, [P(TgModel), P(TgScoreParams), i32, vp, i64]),
     'tg_train_step': (C.c_int, [P(TgModel), P(TgTcsr), P(TgTrainIo), vp, sz, vp]),

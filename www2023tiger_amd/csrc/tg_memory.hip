@@ -3,7 +3,10 @@
 // tiger/model/tiger.py:229-255,396-442,594-609, tiger/model/time_encoding.py:24-26.
 // All HBM-bound: rows are moved as float4 (16 B per lane), one wavefront per row where a
 // row also carries scalar state (timestamp, has-message bit), flat otherwise.
+#include <algorithm>
+
 #include "tg_common.h"
+#include "tg_part.h"
 
 namespace tg {
 
@@ -249,12 +252,13 @@ __device__ __forceinline__ void wb_step5(const tg_model& m, int64_t B, const int
   }
 }
 
+template <bool SYS = false>  // SYS: h is a window other GPUs store into (tg_part.h: system-scope loads)
 __device__ __forceinline__ void wb_step6(const tg_model& m, int64_t id, int64_t idx, int64_t hrow,
-                                         const float4* __restrict__ h, const float* __restrict__ ts, uint32_t* err,
+                                         const float4* h, const float* __restrict__ ts, uint32_t* err,
                                          int lane) {
   const int w4 = m.d / 4;
   float4* left = reinterpret_cast<float4*>(m.left_vals);
-  for (int c = lane; c < w4; c += TG_WAVE) left[id * w4 + c] = h[hrow * w4 + c];
+  for (int c = lane; c < w4; c += TG_WAVE) left[id * w4 + c] = SYS ? ld_sys(h + hrow * w4 + c) : h[hrow * w4 + c];
   if (lane == 0) {
     const float nt = ts[idx];
     if (m.left_ts[id] > nt) atomicOr(err, TG_ERR_PAST_MEMORY);
@@ -263,12 +267,15 @@ __device__ __forceinline__ void wb_step6(const tg_model& m, int64_t id, int64_t 
   }
 }
 
+// workgroup `bid` of `nblk`; rows_hi (nullable): the rows of index >= hi_from of a.left_row live in a peer-written window
+// (tg_part_step: the push inbox) and are read there with system-scope loads
 template <int PHASE>
-__global__ void __launch_bounds__(256) k_writeback(tg_model m, WritebackArgs a) {
+__device__ __forceinline__ void writeback_body(const tg_model& m, const WritebackArgs& a, unsigned bid, unsigned nblk,
+                                               const float4* rows_hi = nullptr, int64_t hi_from = 0) {
   const int lane = lane_id();
   const int64_t B = a.B;
   const int64_t n = min((int64_t)*a.n_upos, 2 * B);
-  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (int64_t)gridDim.x * 4;
+  const int64_t wave0 = (int64_t)bid * 4 + (threadIdx.x >> 6), nwave = (int64_t)nblk * 4;
   const bool left_src = m.msg_src == TG_SRC_LEFT;
   const bool do5 = (PHASE == 0) ? left_src : !left_src;
   if (do5) {  // tiger.py:437-438 over all 2B positions
@@ -295,22 +302,25 @@ __global__ void __launch_bounds__(256) k_writeback(tg_model m, WritebackArgs a) 
     }
     if (do5) wb_step5(m, B, a.src, a.dst, a.ts, a.eids, id, idx, a.err, lane);
     if (PHASE == 1) {
-      if (a.rows)
-        wb_step6(m, id, idx, a.left_row[po + idx], reinterpret_cast<const float4*>(a.rows), a.ts, a.err, lane);
+      if (a.rows) {
+        const int64_t hr = a.left_row[po + idx];
+        if (rows_hi && hr >= hi_from) wb_step6<true>(m, id, idx, hr - hi_from, rows_hi, a.ts, a.err, lane);
+        else wb_step6(m, id, idx, hr, reinterpret_cast<const float4*>(a.rows), a.ts, a.err, lane);
+      }
       else
         wb_step6(m, id, idx, idx, reinterpret_cast<const float4*>(a.h), a.ts, a.err, lane);
     }
   }
   if (PHASE == 1) {
     if (a.clean_flags) {  // leave the step workspace zeroed for the next step (saves its memset launch)
-      const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+      const int64_t tid = (int64_t)bid * blockDim.x + threadIdx.x, nth = (int64_t)nblk * blockDim.x;
       uint4* f = reinterpret_cast<uint4*>(a.clean_flags);
       for (int64_t i = tid; i < a.flag_bytes / 16; i += nth) f[i] = make_uint4(0u, 0u, 0u, 0u);
       const int64_t nb = a.clean_counts[0];  // involved count: only ranks below it were touched
       for (int64_t i = tid; i < nb; i += nth) a.clean_best[i] = 0ull;
     }
     // counts need no reset: the compaction overwrites [0] and [1], k_pos_max zeroes [2]
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (bid == 0 && threadIdx.x == 0) {
       if (a.counts_dst)
         for (int i = 0; i < 4; ++i) a.counts_dst[i] = a.counts_src[i];
       if (a.clean_counts) a.clean_counts[3] = a.clean_counts[4] = 0;  // restarted-node count, batch-min-time key
@@ -318,6 +328,53 @@ __global__ void __launch_bounds__(256) k_writeback(tg_model m, WritebackArgs a) 
       if (a.lazy_batch) *a.lazy_batch += 1;
     }
   }
+}
+
+template <int PHASE>
+__global__ void __launch_bounds__(256) k_writeback(tg_model m, WritebackArgs a) {
+  writeback_body<PHASE>(m, a, blockIdx.x, gridDim.x);
+}
+
+// ---- tg_part_step (tg_part.hip): the two write-back launches of a rank's own winners with the PUSH exchange folded in
+__global__ void __launch_bounds__(256) k_part_push_wb0(tg_model m, WritebackArgs a, tg_part p, const float* __restrict__ h,
+                                                       unsigned push_blocks) {
+  if (blockIdx.x < push_blocks) {  // h(t-) of the winning positions of nodes owned elsewhere -> their owners' windows
+    const int64_t s = p.cur_step[0];
+    if (s < p.n_steps) {
+      const int w4 = m.d / 4;
+      const int64_t n = p.n_push[s], par = s & 1;
+      const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)push_blocks * blockDim.x;
+      for (int64_t t = tid; t < n * w4; t += nth) {
+        const int64_t i = t / w4;
+        const int c = (int)(t - i * w4);
+        const int64_t e = s * p.push_cap + i;
+        float4* inbox = reinterpret_cast<float4*>(p.push_in[p.push_peer[e]]) +
+                        ((par * p.world + p.rank) * p.push_max + p.push_slot[e]) * w4;
+        st_sys(inbox + c, reinterpret_cast<const float4*>(h)[(int64_t)p.push_src[e] * w4 + c]);
+      }
+    }
+    signal_peers(p, 1, (uint32_t)(s + 1), push_blocks);
+    return;
+  }
+  if (p.cur_step[0] < p.n_steps) writeback_body<0>(m, a, blockIdx.x - push_blocks, gridDim.x - push_blocks);
+}
+__global__ void __launch_bounds__(256) k_part_wb1(tg_model m, WritebackArgs a, tg_part p, int64_t hi_from) {
+  const int64_t s = p.cur_step[0];
+  if (s >= p.n_steps) return;
+  wait_peers(p, 1, (uint32_t)(s + 1));
+  const int64_t slots = (int64_t)p.world * p.push_max;
+  const float4* inbox = reinterpret_cast<const float4*>(p.push_in[p.rank]) + (s & 1) * slots * (m.d / 4);
+  writeback_body<1>(m, a, blockIdx.x, gridDim.x, inbox, hi_from);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *p.step_dev = s + 1;  // (every launch of this step reads cur_step)
+}
+int part_push_wb0_launch(const tg_model* m, const WritebackArgs& a, const tg_part* p, const float* h, hipStream_t st) {
+  const unsigned pb = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, cdiv(p->push_cap * (m->d / 4), 256)));
+  hipLaunchKernelGGL(k_part_push_wb0, dim3(pb + flat_grid(2 * a.B, 4)), dim3(256), 0, st, *m, a, *p, h, pb);
+  return check_launch("tg_part_step(push + write-back 0)");
+}
+int part_wb1_launch(const tg_model* m, const WritebackArgs& a, const tg_part* p, int64_t hi_from, hipStream_t st) {
+  hipLaunchKernelGGL(k_part_wb1, dim3(flat_grid(2 * a.B, 4)), dim3(256), 0, st, *m, a, *p, hi_from);
+  return check_launch("tg_part_step(write-back 1)");
 }
 
 // ---- STEP 4-6 in ONE launch (eager updates, direct form): writeback_fused_body (tg_common.h), which can also ride on

@@ -792,6 +792,13 @@ int apply_messages(const tg_model* m, const int64_t* outdated, const int32_t* ou
   return gemm_launch(g, st);
 }
 
+int apply_messages_rows(const tg_model* m, const int64_t* rows, const int32_t* rows32, const int32_t* n_dev, int64_t cap,
+                        uint32_t* err, void* ws, size_t ws_bytes, hipStream_t st) {
+  // (checked_already: the rows have just been written by STEP 5 / 6 of this very batch - the message / memory time
+  //  invariants hold by construction, as for the single-GPU step's eager updater)
+  return apply_messages(m, rows, rows32, n_dev, cap, m->pending_vals, err, ws, ws_bytes, st, true);
+}
+
 // unified positive-node dedup of the fused step: float32 timestamps, winner = latest ts,
 // first position among ties.  best[rank(node)] = max over positions of (ts_key << 32 | ~pos).
 __global__ void k_pos_max(int64_t B, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,

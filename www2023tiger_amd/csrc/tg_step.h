@@ -92,7 +92,10 @@ struct GruSplit {
   bool gi_done;  // variant 2: gi rode on fc2's launch
   bool done;     // variant 1: the rows are finished
 };
-const float* gru_tail_weights(const tg_model* m);  // the tail of the tg_attn_fuse blob, or nullptr (tg_fuse.hip)
+const float* gru_tail_weights(const tg_model* m);
+// the eager updater over a list of state rows (tg_part_step): pending[rows32[i]] = updater(upd memory, mailbox)[rows[i]]
+int apply_messages_rows(const tg_model* m, const int64_t* rows, const int32_t* rows32, const int32_t* n_dev, int64_t cap,
+                        uint32_t* err, void* ws, size_t ws_bytes, hipStream_t st);  // the tail of the tg_attn_fuse blob, or nullptr (tg_fuse.hip)
 
 bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w, int n_layers = 1);
 int attn_dims_ok(const tg_model* m);

@@ -714,8 +714,14 @@ class ResidentPartitionedStream:
     nothing switches it on.)"""
 
     def __init__(self, model, stream: dict, owner: np.ndarray, rank: int, world: int, B: int, n_steps: int,
-                 group=None, use_graphs: bool = False, capture_collectives: bool = False, physical: bool = False):
+                 group=None, use_graphs: bool = False, capture_collectives: bool = False, physical: bool = False,
+                 exchange: str = 'rccl'):
+        """exchange = 'ipc': the step is ONE library call (tg_part_step) whose two exchanges are kernels storing into the
+        peers' exported windows - no collective, no host work per step, capturable several steps per hipGraph
+        (capture_steps); 'rccl': eager launches around two all_to_all_single calls (works across nodes; the reference
+        result the window form is tested against)."""
         Bg = B * world
+        self.exchange = exchange
         keys = ('src', 'dst', 'neg', 'ts', 'eids')
         rank_ofs, local = [], {k: [] for k in keys}
         for b in range(n_steps):  # capacity-balanced shards: every rank embeds exactly B events of every global batch
@@ -765,6 +771,176 @@ class ResidentPartitionedStream:
         self.capture_collectives = bool(capture_collectives) and self.use_graphs
         self.graphs = {}
         self.stream = torch.cuda.Stream(device=dev) if self.use_graphs else None
+        self.part = None
+        self.part_graph = None
+        if exchange == 'ipc':
+            self._build_part(owner)
+
+    # ---- the window form (tiger_hip.h: tg_part): plan tables over all steps, windows, one call per step
+    def _build_part(self, owner):
+        from ._lib import TgPart, check, lib, ptr
+        eng, model, plans = self.engine, self.model, self.plans
+        dev, world, rank, B, S = model.device, self.world, self.rank, self.B, self.n_steps
+        Bg, d = B * world, model.memory_dim
+        pm, qm = self.pull_max, self.push_max
+        phys = self.physical
+        i32 = dict(dtype=torch.int32, device=dev)
+        i64 = dict(dtype=torch.int64, device=dev)
+        ph_of = (lambda p: eng._phys(p)) if phys else (lambda p: None)
+        cap = lambda xs: max([1] + [int(x) for x in xs])
+        serve_cap = cap(p.serve_eff.numel() + p.serve_msg.numel() for p in plans)
+        req_cap = cap(ph_of(p)['req_nodes'].numel() for p in plans) if phys else 1
+        push_cap = cap(sum(p.push_in) for p in plans)
+        mine_cap = cap(p.mine.numel() for p in plans)
+        T = self._tables = dict(
+            g_src=torch.zeros(S * Bg, **i64), g_dst=torch.zeros(S * Bg, **i64), g_eids=torch.zeros(S * Bg, **i64),
+            ts32=torch.zeros(S * 2 * Bg, dtype=torch.float32, device=dev), left_row=torch.zeros(S * 2 * Bg, **i64),
+            n_serve=torch.zeros(S, **i32), serve_row=torch.zeros(S * serve_cap, **i32), serve_kind=torch.zeros(S * serve_cap, **i32),
+            serve_peer=torch.zeros(S * serve_cap, **i32), serve_slot=torch.zeros(S * serve_cap, **i32),
+            adopt_row=torch.full((S * world * pm,), -1, **i32), adopt_kind=torch.zeros(S * world * pm, **i32),
+            n_req=torch.zeros(S, **i32), req_node=torch.zeros(S * req_cap, **i64), req_row=torch.zeros(S * req_cap, **i32),
+            n_push=torch.zeros(S, **i32), push_src=torch.zeros(S * push_cap, **i32), push_peer=torch.zeros(S * push_cap, **i32),
+            push_slot=torch.zeros(S * push_cap, **i32),
+            n_mine=torch.zeros(S, **i32), mine_node=torch.zeros(S * mine_cap, **i64), mine_index=torch.zeros(S * mine_cap, **i64),
+            mine_row=torch.zeros(S * mine_cap, **i64))
+
+        def padded(counts, width):  # compact peer-major position -> (peer, slot) of the padded layout
+            c = torch.tensor(list(counts), dtype=torch.int64)
+            peer = torch.repeat_interleave(torch.arange(len(c)), c)
+            first = torch.cumsum(torch.cat([torch.zeros(1, dtype=torch.int64), c]), 0)[:-1]
+            slot = torch.arange(int(c.sum())) - torch.repeat_interleave(first, c)
+            return peer.to(dev), slot.to(dev)
+        for s, p in enumerate(plans):
+            ph = ph_of(p)
+            g_src, g_dst, g_ts, g_eids = p.glob
+            T['g_src'][s * Bg:(s + 1) * Bg], T['g_dst'][s * Bg:(s + 1) * Bg], T['g_eids'][s * Bg:(s + 1) * Bg] = g_src, g_dst, g_eids
+            T['ts32'][s * 2 * Bg:(s + 1) * 2 * Bg] = p.ts32
+            T['left_row'][s * 2 * Bg:(s + 1) * 2 * Bg] = p.left_row
+            # PULL, owner side (positions are padded peer-major already: requester q's block starts at q * pull_max)
+            rows = torch.cat([ph['serve_eff'], ph['serve_msg']]) if phys else torch.cat([p.serve_eff, p.serve_msg])
+            pos = torch.cat([p.serve_eff_pos, p.serve_msg_pos])
+            n = int(rows.numel())
+            o = s * serve_cap
+            T['n_serve'][s] = n
+            T['serve_row'][o:o + n] = rows.to(torch.int32)
+            T['serve_kind'][o + int(p.serve_eff.numel()):o + n] = 1
+            T['serve_peer'][o:o + n] = (pos // pm).to(torch.int32)
+            T['serve_slot'][o:o + n] = (pos % pm).to(torch.int32)
+            # PULL, user side: the reply of owner q to this rank has the shape of the request to q
+            a = s * world * pm
+            ar = torch.cat([ph['adopt_eff'], ph['adopt_msg']]) if phys else torch.cat([p.req_eff, p.req_msg])
+            ap = torch.cat([p.reply_eff_pos, p.reply_msg_pos])
+            T['adopt_row'][a + ap] = ar.to(torch.int32)
+            T['adopt_kind'][a + p.reply_msg_pos] = 1
+            if phys:
+                nr = int(ph['req_nodes'].numel())
+                T['n_req'][s] = nr
+                T['req_node'][s * req_cap:s * req_cap + nr] = ph['req_nodes']
+                T['req_row'][s * req_cap:s * req_cap + nr] = ph['req_rows']
+            # PUSH, user side
+            npush = int(sum(p.push_in))
+            if npush:
+                peer, slot = padded(p.push_in, qm)
+                o = s * push_cap
+                T['n_push'][s] = npush
+                T['push_src'][o:o + npush] = p.push_rows.to(torch.int32)
+                T['push_peer'][o:o + npush] = peer.to(torch.int32)
+                T['push_slot'][o:o + npush] = slot.to(torch.int32)
+            nm = int(p.mine.numel())
+            o = s * mine_cap
+            T['n_mine'][s] = nm
+            T['mine_node'][o:o + nm] = p.mine
+            T['mine_index'][o:o + nm] = p.mine_index
+            T['mine_row'][o:o + nm] = ph['mine'] if phys else p.mine
+        # staging + counters
+        Z = self._staging = dict(
+            st_src=torch.zeros(Bg, **i64), st_dst=torch.zeros(Bg, **i64), st_eids=torch.zeros(Bg, **i64),
+            st_left_row=torch.zeros(2 * Bg, **i64), st_mine_node=torch.zeros(mine_cap, **i64),
+            st_mine_index=torch.zeros(mine_cap, **i64), st_mine_row=torch.zeros(mine_cap, **i64),
+            st_ts32=torch.zeros(2 * Bg, dtype=torch.float32, device=dev), st_mine32=torch.zeros(mine_cap, **i32),
+            st_n_mine=torch.zeros(1, **i32), step_dev=torch.zeros(1, **i64), cur_step=torch.zeros(1, **i64),
+            ticket=torch.zeros(2, **i32), owner=torch.as_tensor(np.asarray(owner)).to(dev, torch.int32).contiguous())
+        # ---- windows: [flags 256 B | pull inbox 2 x world x pull_max x (d + 4) | push inbox 2 x world x push_max x d] floats
+        n_pull, n_push_f = 2 * world * pm * (d + 4), 2 * world * qm * d
+        self._win_bytes = 256 + 4 * (n_pull + n_push_f)
+        win = C.c_void_p()
+        check(lib.tg_xchg_alloc(self._win_bytes, C.byref(win)), 'tg_xchg_alloc')
+        self._win = win.value
+        bases = [None] * world
+        bases[rank] = self._win
+        self._imported = []
+        if world > 1:
+            h = (C.c_uint8 * 64)()
+            check(lib.tg_ipc_export(self._win, h), 'tg_ipc_export')
+            handles = [None] * world
+            tdist.all_gather_object(handles, bytes(h), group=self.group)
+            for q in range(world):
+                if q != rank:
+                    hq = (C.c_uint8 * 64).from_buffer_copy(handles[q])
+                    out = C.c_void_p()
+                    check(lib.tg_ipc_import(hq, C.byref(out)), 'tg_ipc_import')
+                    bases[q] = out.value
+                    self._imported.append(out.value)
+        part = TgPart()
+        part.world, part.rank, part.n_steps, part.Bg = world, rank, S, Bg
+        part.step_dev, part.cur_step, part.ticket = ptr(Z['step_dev']), ptr(Z['cur_step']), ptr(Z['ticket'])
+        for q in range(world):
+            part.flags[q] = bases[q]
+            part.pull_in[q] = bases[q] + 256
+            part.push_in[q] = bases[q] + 256 + 4 * n_pull
+        part.pull_max, part.push_max = pm, qm
+        part.err = ptr(eng.err)
+        for k in ('g_src', 'g_dst', 'g_eids', 'ts32', 'left_row', 'n_serve', 'serve_row', 'serve_kind', 'serve_peer',
+                  'serve_slot', 'adopt_row', 'adopt_kind', 'n_req', 'req_node', 'req_row', 'n_push', 'push_src', 'push_peer',
+                  'push_slot', 'n_mine', 'mine_node', 'mine_index', 'mine_row'):
+            setattr(part, k, ptr(T[k]))
+        part.serve_cap, part.req_cap, part.push_cap, part.mine_cap = serve_cap, req_cap, push_cap, mine_cap
+        for k in ('st_src', 'st_dst', 'st_eids', 'st_left_row', 'st_mine_node', 'st_mine_index', 'st_mine_row', 'st_ts32',
+                  'st_mine32', 'st_n_mine', 'owner'):
+            setattr(part, k, ptr(Z[k]))
+        part.row_of = ptr(eng.row_of) if phys else None
+        self.part = part
+        ms = model.model_struct()
+        nbytes = int(lib.tg_apply_messages_workspace_bytes(C.byref(ms), mine_cap))
+        self._aws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        if world > 1:
+            tdist.barrier(group=self.group)  # every window is mapped before anybody stores into one
+
+    def _launch_part(self):
+        """one global batch: the library call (host work: one ctypes call)"""
+        from ._lib import check, lib, ptr
+        m, buf = self.model, self.engine.buf
+        buf.io.rows_hint = m.rows_bound()
+        ms = m.model_struct()
+        g = m.graph.tcsr
+        check(lib.tg_part_step(C.byref(ms), C.byref(g), C.byref(buf.io), C.byref(self.part), ptr(buf.ws), buf.ws.numel(),
+                               ptr(self._aws), self._aws.numel(), self.engine.hip_ops.stream_ptr(m.device)), 'tg_part_step')
+
+    def capture_steps(self, gsteps: int):
+        """capture `gsteps` consecutive steps into ONE hipGraph (the step reads its slices at the device-side step counter and
+        advances it: every replay runs the next gsteps global batches).  Call after at least one eager step."""
+        assert self.part is not None
+        Z = self._staging
+        snap = (Z['step_dev'].clone(), self.engine.buf.offset.clone())
+        side = torch.cuda.Stream(device=self.model.device)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
+            for _ in range(gsteps):
+                self._launch_part()
+        Z['step_dev'].copy_(snap[0])  # capture does not execute; be explicit
+        self.engine.buf.offset.copy_(snap[1])
+        torch.cuda.synchronize()
+        self.part_graph, self.part_gsteps = g, gsteps
+
+    def replay(self):
+        """the next part_gsteps global batches (one graph replay)"""
+        assert self.steps_done + self.part_gsteps <= self.n_steps, 'resident stream exhausted'
+        self.part_graph.replay()
+        self.steps_done += self.part_gsteps
+        m = self.model
+        m._touch()
+        m._pending_stamp = m._state_stamp()
 
     def _pad(self, p):
         """positions of plan p inside the padded, peer-major exchange buffers"""
@@ -849,6 +1025,13 @@ class ResidentPartitionedStream:
     def step(self):
         s = self.steps_done
         assert s < self.n_steps, 'resident stream exhausted'
+        if self.part is not None:  # the window form: one library call
+            self._launch_part()
+            m = self.model
+            m._touch()
+            m._pending_stamp = m._state_stamp()
+            self.steps_done += 1
+            return self.engine.hbuf[:3 * self.B]
         p = self.plans[s]
         gs = self.graphs.get(s)
         if gs is None:  # eager launches on the current stream
@@ -969,9 +1152,13 @@ def run_dist_leg(args, cfg, make_stream, build_models, rank, local_rank, world, 
         # collectives are SLOWER than the ten eager launches they replace (0.207 vs 0.156 ms per step; a graph replay
         # costs 10-16 us of host time, as much as the launches it stands for), and a capture that includes the
         # collectives never finished.  --dist-graphs selects the segments.
-        use_graphs = nccl and bool(getattr(args, 'dist_graphs', False)) and not args.no_graph
+        # --dist-exchange ipc (default): the step is one library call whose exchanges are kernels storing into the peers'
+        # exported windows (tg_part_step) - graphs of several steps, no collective in the timed region; rccl: eager launches
+        # around two all_to_all_single (the form that also works across nodes)
+        exch = getattr(args, 'dist_exchange', 'ipc')
+        use_graphs = nccl and bool(getattr(args, 'dist_graphs', False)) and not args.no_graph and exch != 'ipc'
         rs = ResidentPartitionedStream(model, stream, owner, rank, world, B, n_steps, use_graphs=use_graphs,
-                                       physical=physical)
+                                       physical=physical, exchange=exch)
     else:
         use_graphs = bool(getattr(args, 'dist_graphs', False)) and not args.no_graph
         rs = ResidentShardedStream(model, stream, owner, rank, world, B, n_steps, use_graphs=use_graphs)
@@ -985,19 +1172,38 @@ def run_dist_leg(args, cfg, make_stream, build_models, rank, local_rank, world, 
     for _ in range(n_eager):
         rs.step()
     torch.cuda.synchronize()
-    if use_graphs:
-        if mode == 'partitioned':
-            rs.capture(n_eager, n_steps - n_prof)  # (the profiled steps at the end stay eager)
-        else:
-            rs.capture()
-    for _ in range(preroll + args.warmup - n_eager):
-        rs.step()
+    part = mode == 'partitioned' and rs.part is not None
+    gsteps = 0
+    if part and not args.no_graph:  # graphs of several steps, as in the single-GPU line (the largest divisor of K up to 25)
+        n_untimed = preroll + args.warmup - n_eager
+        for gcand in range(min(25, args.steps, max(n_untimed, 1)), 0, -1):
+            if args.steps % gcand == 0:
+                gsteps = gcand
+                break
+        tdist.barrier()
+        rs.capture_steps(gsteps)
+        tdist.barrier()
+        for _ in range(n_untimed - gsteps):
+            rs.step()
+        rs.replay()  # the last untimed steps: one replay (uploads the graph)
+    else:
+        if use_graphs:
+            if mode == 'partitioned':
+                rs.capture(n_eager, n_steps - n_prof)  # (the profiled steps at the end stay eager)
+            else:
+                rs.capture()
+        for _ in range(preroll + args.warmup - n_eager):
+            rs.step()
     torch.cuda.synchronize()
     tdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rs.step()
+    if gsteps:
+        for _ in range(args.steps // gsteps):
+            rs.replay()
+    else:
+        for _ in range(args.steps):
+            rs.step()
     t_host = time.perf_counter() - t0  # the host has enqueued everything; the GPU may still be working
     torch.cuda.synchronize()
     tdist.barrier()
@@ -1015,7 +1221,18 @@ def run_dist_leg(args, cfg, make_stream, build_models, rank, local_rank, world, 
         acc = np.zeros(ns)
         ms_buf = (C.c_float * ns)()
         for _ in range(n_prof):
-            one = rs.step_profiled(prof)
+            if part:  # the window form is one call: the embedding step's stages from the library's timer, the rest of the
+                t_ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]  # step as one interval
+                if prof is not None:
+                    rs.engine.buf.attach_profiler(prof)
+                t_ev[0].record()
+                rs.step()
+                t_ev[1].record()
+                rs.engine.buf.attach_profiler(None)
+                torch.cuda.synchronize()
+                one = {'whole_step(eager call)': t_ev[0].elapsed_time(t_ev[1])}
+            else:
+                one = rs.step_profiled(prof)
             for k, v in one.items():
                 seg_ms[k] = seg_ms.get(k, 0.0) + v / n_prof
             if prof is not None:
@@ -1040,6 +1257,10 @@ def run_dist_leg(args, cfg, make_stream, build_models, rank, local_rank, world, 
             launch = ('one hipGraph per step incl. both collectives' if rs.capture_collectives else
                       '3 hipGraph segments + 2 all_to_all_single per step') if use_graphs else \
                 'eager launches + 2 all_to_all_single per step'
+            if part:
+                launch = (f'hipGraph replay, {gsteps} steps per captured graph; ' if gsteps else 'eager; ') + \
+                    'one library call per step (tg_part_step), exchanges = kernels storing into the peers\' exported windows ' \
+                    '(hipIpc), epoch flags, no collective'
             launch += ' (plans made before the timed region)'
             try:  # rank 0's dominant embedding kernel against its roofline, as in the 1-GPU line
                 import bench as _b
@@ -1047,7 +1268,8 @@ def run_dist_leg(args, cfg, make_stream, build_models, rank, local_rank, world, 
                          'gather_right_memory', 'writeback_phase0', 'writeback_phase1', 'eager_updater(gru)',
                          'attn_gemm_g', 'attn_gemm_v', 'attn_gemm_out', 'attn_centres+qconst'}
                 emb = {n: float(v) for n, v in zip(stage_names, stage_ms) if n not in empty}
-                emb['eager_updater(gru)'] = seg_ms['eager_updater(gru)']
+                if 'eager_updater(gru)' in seg_ms:
+                    emb['eager_updater(gru)'] = seg_ms['eager_updater(gru)']
                 tile = bool(fused and _lib.tg_attn_tile_applies(C.byref(model.model_struct())))
                 work = _b.stage_work(dict(cfg, B=B), tr['involved'], 0.0, tr['own_winners'], True, fused, stream['n_nodes'], E, tile)
                 dom = max(emb, key=emb.get)
