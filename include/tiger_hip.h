@@ -756,9 +756,10 @@ int tg_stream_writeback(const tg_model* m, const tg_writeback_io* io, void* ws, 
  * every per-step array below is a table over ALL steps of a resident stream, slice s = *step_dev, and the call ends by
  * advancing *step_dev.  Windows are double-buffered by step parity; every rank waits for every peer in every step, so a
  * rank is never more than one step ahead of a peer's reads.
- * Launches per step: begin (stage the plan slices, serve rows, signal) | adopt (wait, arena mapping, rows into the
- * tables) | the embedding step (tg_stream_step, embed_only + lean: sampler + centres, G, core, fc1, fc2) | push (rows,
- * signal) | STEP 4+5 of the owner's winners | recv (wait, pushed rows behind the embeddings) | STEP 6 | eager updater. */
+ * Launches per step: begin (stage the plan slices, serve rows, signal; wait, arena mapping, adopt the pulled rows) | the
+ * embedding step (tg_stream_step, embed_only + lean: sampler + centres, G, core, fc1, fc2; STEP 4 + 5 of the owner's own
+ * winners ride on fc1's launch where it hosts riders) | push (rows, signal; else with STEP 4 + 5) | wait + STEP 6 (pushed rows
+ * read in the window) | eager updater. */
 #define TG_MAX_RANKS 16
 typedef struct tg_part {
   int32_t world, rank;
@@ -767,12 +768,13 @@ typedef struct tg_part {
   int64_t* cur_step;        /* device scratch [1] */
   /* windows: pull_in[q] / push_in[q] / flags[q] = rank q's window as mapped HERE (q == rank: this rank's own).
    * pull inbox [2][world][pull_max] rows of d + 4 floats (row | time, 3 spare); push inbox [2][world][push_max] rows of d
-   * floats; flags uint32 [2][TG_MAX_RANKS]: flags[kind][q] = last epoch (step + 1) rank q completed for `kind` */
+   * floats; flags uint32 [4][TG_MAX_RANKS]: flags[kind][q] = last epoch (step + 1) rank q completed for `kind` (0 pull,
+   * 1 push; 2, 3: tg_xchg_selftest) */
   float* pull_in[TG_MAX_RANKS];
   float* push_in[TG_MAX_RANKS];
   uint32_t* flags[TG_MAX_RANKS];
   int64_t pull_max, push_max;
-  uint32_t* ticket;         /* device [2], zero: block counters of the two producing kernels */
+  uint32_t* ticket;         /* device [4], zero: block counters of the two producing kernels, gate words of the two waits */
   uint32_t* err;            /* invariant word (TG_ERR_*) */
   /* plan tables (device; stride per step in brackets) */
   const int64_t *g_src, *g_dst, *g_eids;  /* the global batches [Bg] */
@@ -782,10 +784,12 @@ typedef struct tg_part {
   int64_t serve_cap;                      /* PULL, owner side [serve_cap]: n_serve[s] live entries */
   const int32_t *n_serve, *serve_row, *serve_kind, *serve_peer, *serve_slot;
   const int32_t *adopt_row, *adopt_kind;  /* PULL, user side [world * pull_max]: inbox slot -> state row (-1: unused), kind */
-  int64_t req_cap;                        /* arena mapping [req_cap]: row_of[req_node] = req_row for this step */
-  const int32_t* n_req;
-  const int64_t* req_node;
+  int64_t req_cap;                        /* arena mapping [req_cap]: row_of[req_node] = req_row for this step; */
+  const int32_t* n_req;                   /* row_of[unmap_node] = -1 first: the previous step's pulled nodes that this */
+  const int64_t* req_node;                /* step does not pull (their arena rows hold other nodes from now on)        */
   const int32_t* req_row;
+  const int32_t* n_unmap;
+  const int64_t* unmap_node;
   int64_t push_cap;                       /* PUSH, user side [push_cap] */
   const int32_t *n_push, *push_src, *push_peer, *push_slot;
   int64_t mine_cap;                       /* the winners this rank writes [mine_cap]: node, position, state row */
@@ -802,7 +806,13 @@ typedef struct tg_part {
  * ws: its workspace; aws: tg_apply_messages_workspace_bytes(m, mine_cap). */
 int tg_part_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, const tg_part* p, void* ws, size_t ws_bytes,
                  void* aws, size_t aws_bytes, void* stream);
+/* `rounds` ping rounds through the mapped windows with the step's own store / load / flag forms (collective: every rank
+ * calls it; flags of kind 2 / 3, the push inboxes' first slots): *result_dev (device int32, zeroed by the caller) stays 0
+ * when every word every peer stored here arrived - bit 0: a flag timed out, bit 1: a wrong word, bit 2: the second
+ * hand-shake timed out.  The caller zeroes the window afterwards. */
+int tg_xchg_selftest(const tg_part* p, int32_t d, int32_t rounds, int32_t* result_dev, void* stream);
 int tg_xchg_alloc(size_t bytes, void** out);  /* zero-filled device memory peers may store into */
+int tg_xchg_clear(void* p, size_t bytes);      /* zero it again (synchronous) */
 int tg_xchg_free(void* p);
 int tg_ipc_export(void* p, uint8_t* handle64);            /* hipIpcGetMemHandle */
 int tg_ipc_import(const uint8_t* handle64, void** out);   /* hipIpcOpenMemHandle (another process's window) */

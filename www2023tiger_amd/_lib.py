@@ -92,7 +92,7 @@ class TgPart(C.Structure):
         ('g_src', vp), ('g_dst', vp), ('g_eids', vp), ('ts32', vp), ('left_row', vp),
         ('serve_cap', i64), ('n_serve', vp), ('serve_row', vp), ('serve_kind', vp), ('serve_peer', vp), ('serve_slot', vp),
         ('adopt_row', vp), ('adopt_kind', vp),
-        ('req_cap', i64), ('n_req', vp), ('req_node', vp), ('req_row', vp),
+        ('req_cap', i64), ('n_req', vp), ('req_node', vp), ('req_row', vp), ('n_unmap', vp), ('unmap_node', vp),
         ('push_cap', i64), ('n_push', vp), ('push_src', vp), ('push_peer', vp), ('push_slot', vp),
         ('mine_cap', i64), ('n_mine', vp), ('mine_node', vp), ('mine_index', vp), ('mine_row', vp),
         ('st_src', vp), ('st_dst', vp), ('st_eids', vp), ('st_left_row', vp), ('st_mine_node', vp), ('st_mine_index', vp),
@@ -188,7 +188,9 @@ SIGNATURES = {
     'tg_stream_step_zero_bytes2': (sz, [P(TgModel), i64, i32]),
     'tg_stream_step_form': (i32, [P(TgModel), P(TgStepIo)]),
     'tg_part_step': (C.c_int, [P(TgModel), P(TgTcsr), P(TgStepIo), P(TgPart), vp, sz, vp, sz, vp]),
+    'tg_xchg_selftest': (C.c_int, [P(TgPart), i32, i32, vp, vp]),
     'tg_xchg_alloc': (C.c_int, [sz, P(vp)]),
+    'tg_xchg_clear': (C.c_int, [vp, sz]),
     'tg_xchg_free': (C.c_int, [vp]),
     'tg_ipc_export': (C.c_int, [vp, vp]),
     'tg_ipc_import': (C.c_int, [vp, P(vp)]),

@@ -543,6 +543,168 @@ struct WritebackArgs {
 // phase 0 / 1: the two launches of tg_memory.hip's hazard analysis; phase 2: STEP 4-6 in one launch (needs a.snap)
 int writeback_launch(const tg_model* m, const WritebackArgs& a, int phase, hipStream_t st);
 
+// system-scope 16-byte accesses (tg_part.h: windows other GPUs store into)
+__device__ __forceinline__ void st_sys(float4* p, float4 v) {
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+  const unsigned long long a = ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
+  const unsigned long long b = ((unsigned long long)__float_as_uint(v.w) << 32) | __float_as_uint(v.z);
+  __hip_atomic_store(q, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(q + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ float4 ld_sys(const float4* p) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b),
+                     __uint_as_float((unsigned)(b >> 32)));
+}
+
+// ---- fused write-back (tiger.py:229-255).  Hazards: STEP 5 reads the message memory
+// rows of BOTH endpoints, STEP 4 writes right-memory rows and STEP 6 left-memory rows of
+// other nodes in other waves, so a kernel boundary must separate STEP 5 from whichever
+// step writes the message memory:  msg_src=left  -> [4 + 5] | [6],  msg_src=right -> [4] | [5 + 6].
+// (`id`, `own`, `other` below: ROWS of the state tables - state_row(node) - where the tables are physically partitioned;
+// feature tables are addressed by node id)
+__device__ __forceinline__ void wb_step4(const tg_model& m, int64_t id, int64_t u, const float4* __restrict__ reprs,
+                                         uint32_t* err, int lane) {
+  if (!bm_test(m.has_msg, id)) return;  // wave-uniform
+  const int w4 = m.d / 4;
+  float4* right = reinterpret_cast<float4*>(m.right_vals);
+  for (int c = lane; c < w4; c += TG_WAVE) right[id * w4 + c] = reprs[u * w4 + c];
+  if (lane == 0) {
+    const float mts = m.msg_ts[id];
+    if (m.right_ts[id] > mts) atomicOr(err, TG_ERR_PAST_MEMORY);
+    m.right_ts[id] = mts;
+    if (m.right_active) m.right_active[id] = 1;
+    atomicAnd((unsigned long long*)(m.has_msg + (id >> 6)), ~(1ull << (id & 63)));
+  }
+}
+
+__device__ __forceinline__ void wb_step5(const tg_model& m, int64_t B, const int64_t* __restrict__ src,
+                                         const int64_t* __restrict__ dst, const float* __restrict__ ts,
+                                         const int64_t* __restrict__ eids, int64_t own, int64_t idx, uint32_t* err,
+                                         int lane) {
+  const int d4 = m.d / 4, e4 = m.d_e / 4;
+  const int row4 = 3 * d4 + e4;
+  const float* mem_ts = (m.msg_src == TG_SRC_LEFT) ? m.left_ts : m.right_ts;
+  const float4* mem = reinterpret_cast<const float4*>((m.msg_src == TG_SRC_LEFT) ? m.left_vals : m.right_vals);
+  const float4* nf = reinterpret_cast<const float4*>(m.nfeats);
+  const float4* ef = reinterpret_cast<const float4*>(m.efeats);
+  const float4* fq = reinterpret_cast<const float4*>(m.te_freq);
+  const float4* ph = reinterpret_cast<const float4*>(m.te_phase);
+  float4* box = reinterpret_cast<float4*>(m.msg_vals);
+  const int64_t e = idx < B ? idx : idx - B;
+  const int64_t own_id = idx < B ? src[e] : dst[e], other_id = idx < B ? dst[e] : src[e];  // node ids (features)
+  const int64_t other = state_row(m, other_id);
+  const float t = ts[e];
+  const float dt = t - mem_ts[own];
+  const int64_t eid = eids[e];
+  for (int c = lane; c < row4; c += TG_WAVE) {
+    float4 v;
+    if (c < 2 * d4) {
+      const int64_t node = c < d4 ? own : other;
+      const int cc = c < d4 ? c : c - d4;
+      v = mem[node * d4 + cc];
+      if (nf) {
+        const float4 f = nf[(c < d4 ? own_id : other_id) * d4 + cc];
+        v.x += f.x; v.y += f.y; v.z += f.z; v.w += f.w;
+      }
+    } else if (c < 2 * d4 + e4) {
+      v = ef ? ef[eid * e4 + (c - 2 * d4)] : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      const int cc = c - 2 * d4 - e4;
+      const float4 w = fq[cc], q = ph[cc];
+      v = make_float4(time_enc(dt, w.x, q.x), time_enc(dt, w.y, q.y), time_enc(dt, w.z, q.z), time_enc(dt, w.w, q.w));
+    }
+    box[own * row4 + c] = v;
+  }
+  if (lane == 0) {
+    const uint64_t bit = 1ull << (own & 63);
+    const unsigned long long old = atomicOr((unsigned long long*)(m.has_msg + (own >> 6)), bit);
+    if (old & bit) atomicOr(err, TG_ERR_UNUSED_MESSAGE);
+    m.msg_ts[own] = t;
+  }
+}
+
+template <bool SYS = false>  // SYS: h is a window other GPUs store into (tg_part.h: system-scope loads)
+__device__ __forceinline__ void wb_step6(const tg_model& m, int64_t id, int64_t idx, int64_t hrow,
+                                         const float4* h, const float* __restrict__ ts, uint32_t* err,
+                                         int lane) {
+  const int w4 = m.d / 4;
+  float4* left = reinterpret_cast<float4*>(m.left_vals);
+  for (int c = lane; c < w4; c += TG_WAVE) left[id * w4 + c] = SYS ? ld_sys(h + hrow * w4 + c) : h[hrow * w4 + c];
+  if (lane == 0) {
+    const float nt = ts[idx];
+    if (m.left_ts[id] > nt) atomicOr(err, TG_ERR_PAST_MEMORY);
+    m.left_ts[id] = nt;
+    if (m.left_active) m.left_active[id] = 1;
+  }
+}
+
+// workgroup `bid` of `nblk`; rows_hi (nullable): the rows of index >= hi_from of a.left_row live in a peer-written window
+// (tg_part_step: the push inbox) and are read there with system-scope loads
+template <int PHASE>
+__device__ __forceinline__ void writeback_body(const tg_model& m, const WritebackArgs& a, unsigned bid, unsigned nblk,
+                                               const float4* rows_hi = nullptr, int64_t hi_from = 0) {
+  const int lane = lane_id();
+  const int64_t B = a.B;
+  const int64_t n = min((int64_t)*a.n_upos, 2 * B);
+  const int64_t wave0 = (int64_t)bid * 4 + (threadIdx.x >> 6), nwave = (int64_t)nblk * 4;
+  const bool left_src = m.msg_src == TG_SRC_LEFT;
+  const bool do5 = (PHASE == 0) ? left_src : !left_src;
+  if (do5) {  // tiger.py:437-438 over all 2B positions
+    const float* mem_ts = left_src ? m.left_ts : m.right_ts;
+    for (int64_t i = wave0 * TG_WAVE + lane; i < 2 * B; i += nwave * TG_WAVE) {
+      const int64_t e = i < B ? i : i - B;
+      const int64_t node = i < B ? a.src[e] : a.dst[e];
+      if (a.owner && a.owner[node] != a.my_rank) continue;  // another rank's node: its time is not kept here
+      if (mem_ts[state_row(m, node)] > a.ts[e]) atomicOr(a.err, TG_ERR_EVENT_BEFORE_MEM);
+    }
+  }
+  const int64_t po = a.plan_off ? 2 * *a.plan_off : 0;
+  for (int64_t p = wave0; p < n; p += nwave) {
+    const int64_t node_id = a.upos[p], idx = a.index[p];
+    if (a.owner && a.owner[node_id] != a.my_rank) continue;  // partitioned state: the owner writes (wave-uniform)
+    const int64_t id = state_row(m, node_id);
+    if (PHASE == 0) {
+      if (a.new_from_pending)
+        wb_step4(m, id, id, reinterpret_cast<const float4*>(m.pending_vals), a.err, lane);
+      else if (a.rows)
+        wb_step4(m, id, a.new_row[po + idx], reinterpret_cast<const float4*>(a.rows), a.err, lane);
+      else
+        wb_step4(m, id, (int64_t)bm_rank(a.bm, a.rank, node_id), reinterpret_cast<const float4*>(a.reprs), a.err, lane);
+    }
+    if (do5) wb_step5(m, B, a.src, a.dst, a.ts, a.eids, id, idx, a.err, lane);
+    if (PHASE == 1) {
+      if (a.rows) {
+        const int64_t hr = a.left_row[po + idx];
+        if (rows_hi && hr >= hi_from) wb_step6<true>(m, id, idx, hr - hi_from, rows_hi, a.ts, a.err, lane);
+        else wb_step6(m, id, idx, hr, reinterpret_cast<const float4*>(a.rows), a.ts, a.err, lane);
+      }
+      else
+        wb_step6(m, id, idx, idx, reinterpret_cast<const float4*>(a.h), a.ts, a.err, lane);
+    }
+  }
+  if (PHASE == 1) {
+    if (a.clean_flags) {  // leave the step workspace zeroed for the next step (saves its memset launch)
+      const int64_t tid = (int64_t)bid * blockDim.x + threadIdx.x, nth = (int64_t)nblk * blockDim.x;
+      uint4* f = reinterpret_cast<uint4*>(a.clean_flags);
+      for (int64_t i = tid; i < a.flag_bytes / 16; i += nth) f[i] = make_uint4(0u, 0u, 0u, 0u);
+      const int64_t nb = a.clean_counts[0];  // involved count: only ranks below it were touched
+      for (int64_t i = tid; i < nb; i += nth) a.clean_best[i] = 0ull;
+    }
+    // counts need no reset: the compaction overwrites [0] and [1], k_pos_max zeroes [2]
+    if (bid == 0 && threadIdx.x == 0) {
+      if (a.counts_dst)
+        for (int i = 0; i < 4; ++i) a.counts_dst[i] = a.counts_src[i];
+      if (a.clean_counts) a.clean_counts[3] = a.clean_counts[4] = 0;  // restarted-node count, batch-min-time key
+      if (a.offset_dev) *a.offset_dev += B;
+      if (a.lazy_batch) *a.lazy_batch += 1;
+    }
+  }
+}
+
+
 // ---- STEP 4-6 in ONE pass (eager updates, direct form), as a device function so that it can also RIDE on another launch.
 // The hazard that forces two launches (tg_memory.hip) is STEP 5 reading message-memory rows that STEP 4 / STEP 6 of other
 // wavefronts write.  Every row STEP 5 reads belongs to a positive node of the batch, so the launch that reads the centres
@@ -666,7 +828,13 @@ struct WbRider {
   WritebackArgs a;
   unsigned blocks;  // set by the launcher (a multiple of 8: the XCD map of the product's own blocks is unchanged)
   unsigned last;    // riders behind the product's blocks in the grid (else in front of them); set by the launcher
-  __device__ __forceinline__ void run(unsigned bid) const { writeback_fused_body<false>(m, a, bid, blocks); }
+  // planned0 != 0 (tg_part_step): the rider is the FIRST launch of the planned, owner-filtered two-launch write-back (STEP 4 + 5,
+  // or STEP 4 alone with msg_src = right: it reads no h(t-)); the product that hosts it stores no second copy of its rows
+  int planned0;
+  __device__ __forceinline__ void run(unsigned bid) const {
+    if (planned0) writeback_body<0>(m, a, bid, blocks);
+    else writeback_fused_body<false>(m, a, bid, blocks);
+  }
 };
 
 }  // namespace tg

@@ -577,7 +577,8 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
   KSlot ks_fc1(KT_FC1);
   bool wb_on_fc1 = false;  // the write-back rider on the fc1 launch: then fc2 only stores STEP 6's rows (c2)
   bool gi_rode = false;  // the split updater's input-side product as a second problem of this launch (variant 1)
-  const bool ks16 = gemm_ks16_launch(g, st, (wbr && pos && pos->win_row) ? wbr : nullptr, &wb_on_fc1,
+  const bool ext = wbr && wbr->planned0;  // a caller's rider (tg_part_step): hosted like the write-back rider, no second row copy
+  const bool ks16 = gemm_ks16_launch(g, st, (ext || (wbr && pos && pos->win_row)) ? wbr : nullptr, &wb_on_fc1,
                                      (gs && gs->variant == 1) ? &gs->gi : nullptr, &gi_rode);
   const bool pieces = !ks16 && gemm_sk_partials(g, w.sk, TG_SK_WS_FLOATS, st, &sk);
   if (!ks16 && !pieces && (rc = gemm_launch(g, st)) != TG_OK) return rc;
@@ -593,7 +594,9 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
   g.w = m->attn_fc2.w; g.ldw = d; g.bias = m->attn_fc2.b;
   g.c = out; g.ldc = d; g.alpha = 1.f; g.nbatch = 1;
   bool rode = false;
-  if (wbr && pos && pos->win_row) {  // STEP 6's rows leave this product's epilogue; STEP 4-5 ride on its launch (WbRider)
+  if (ext) {
+    // (no second destination; hosted by fc1 already, or by this launch, or not at all)
+  } else if (wbr && pos && pos->win_row) {  // STEP 6's rows leave this product's epilogue; STEP 4-5 ride on its launch (WbRider)
     g.c2 = m->left_vals; g.c2_rows = pos->win_row; g.c2_m = 2 * wbr->a.B; g.ldc2 = d;
   } else {
     wbr = nullptr;
@@ -1401,7 +1404,7 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   }
   if ((rc = attn_forward(m, Q, w.nids3, w.ts3f, w.l1n, w.l1e, w.l1t, w.reprs, w.bm, w.rank, io->h, w.attn, st, pf,
                          drop, pp, w.direct ? &da : nullptr, key_rows, w.lean && !recent_nodes && !lz, w.gtab,
-                         want_rider ? &wbr : nullptr, &w.wb_rode, gsplit ? &gs : nullptr)) != TG_OK)
+                         want_rider ? &wbr : w.ext_rider, &w.wb_rode, gsplit ? &gs : nullptr)) != TG_OK)
     return rc;
   w.upd_done = gs.done;
   w.tail_pending = gsplit && gs.variant == 2 && gs.gi_done;
@@ -1550,15 +1553,16 @@ extern "C" int32_t tg_stream_step_form(const tg_model* m, const tg_step_io* io) 
          (f.gtab ? TG_FORM_TABLES : 0);
 }
 
-extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, void* ws, size_t ws_bytes,
-                              void* stream) {
+namespace tg {
+int stream_step_ext(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, void* ws, size_t ws_bytes, hipStream_t st,
+                    const WbRider* ext_rider, bool* ext_rode) {
+  if (ext_rode) *ext_rode = false;
   if (!attn_dims_ok(m) || !g || !io || io->B <= 0) return TG_EINVAL;
   if (!io->src || !io->dst || !io->neg || !io->ts || !io->eids || (!io->h && !io->collate_only) || !io->err)
     return TG_EINVAL;
   if (g->num_node != m->n_nodes) return TG_EINVAL;
   // physically partitioned state (tg_model.row_of): only the forms that address state by row
   if (m->row_of && !io->collate_only && !(io->embed_only && io->lean && m->pending_vals && !io->inner)) return TG_EUNSUPPORTED;
-  hipStream_t st = as_stream(stream);
   tg_profiler* pf = (tg_profiler*)io->profiler;
   struct KtScope {  // kernel-bound timing of the step's main launches while a profiler is attached (tg_common.h)
     explicit KtScope(tg_profiler* p) {
@@ -1571,12 +1575,14 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
   Carver cv(ws, ws_bytes);
   StepWs w{};
   if (!carve_step(m, io->B, cv, w, io->inner ? 2 : 1)) return TG_EWORKSPACE;
+  w.ext_rider = ext_rider;
   int rc;
   // eager updates need the full step (the updater launch at its end keeps the table current)
   // embed_only still GATHERS the precomputed rows when the table is there (the partitioned multi-GPU path keeps it
   // current through tg_apply_messages after its own write-back); only a full step runs the updater at its end
   const bool eager = m->pending_vals != nullptr;
   if ((rc = step_forward(m, g, io, w, nullptr, st, pf, nullptr, eager)) != TG_OK) return rc;
+  if (ext_rode) *ext_rode = ext_rider && w.wb_rode;
   if (pf && (io->embed_only || io->collate_only)) {  // no write-back stages: close the timer's remaining intervals
     for (int i = ST_WRITE_RIGHT; i <= ST_COUNT; ++i) prof_mark(pf, i, st);
     pf->armed = true;
@@ -1595,6 +1601,12 @@ extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step
   }
   if ((rc = step_writeback_a(m, io, w, st, pf)) != TG_OK) return rc;
   return step_writeback_b(m, g, io, w, st, pf);
+}
+}  // namespace tg
+
+extern "C" int tg_stream_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, void* ws, size_t ws_bytes,
+                              void* stream) {
+  return tg::stream_step_ext(m, g, io, ws, ws_bytes, tg::as_stream(stream), nullptr, nullptr);
 }
 
 // ---------------------------------------------------------------------------------

@@ -10,20 +10,6 @@
 
 namespace tg {
 
-__device__ __forceinline__ void st_sys(float4* p, float4 v) {
-  unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
-  const unsigned long long a = ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
-  const unsigned long long b = ((unsigned long long)__float_as_uint(v.w) << 32) | __float_as_uint(v.z);
-  __hip_atomic_store(q, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store(q + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ float4 ld_sys(const float4* p) {
-  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
-  const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b),
-                     __uint_as_float((unsigned)(b >> 32)));
-}
 // bounded wait for `flag >= epoch` (one lane).  The peer's kernel that raises the flag precedes, in that peer's stream,
 // every wait of that peer for this step, so the wait ends unless a peer died: then the timeout bit is raised and the step
 // goes on (wrong rows, no hang; the caller reads the error word)
@@ -34,13 +20,25 @@ __device__ __forceinline__ bool wait_flag(const uint32_t* flag, uint32_t epoch) 
   }
   return false;
 }
-// every workgroup of a consuming kernel, before it loads (ld_sys) what the peers stored for `kind`
-__device__ __forceinline__ void wait_peers(const tg_part& p, int kind, uint32_t epoch) {
+// every workgroup `bid` of a consuming kernel, before it loads (ld_sys) what the peers stored for `kind`.  ONE lane of the
+// kernel (workgroup 0's) polls the flags the peers raise - system-scope loads that go to memory every time: a thousand
+// workgroups polling them (four ranks rehearsed on one GPU) starve the very kernels they wait for - and opens a gate
+// word of this GPU (p.ticket[2 + kind], agent scope) that the other workgroups poll in the L2
+__device__ __forceinline__ void wait_peers(const tg_part& p, int kind, uint32_t epoch, unsigned bid) {
   if (threadIdx.x == 0) {
-    const uint32_t* mine = p.flags[p.rank] + (size_t)kind * TG_MAX_RANKS;
-    bool ok = true;
-    for (int q = 0; q < p.world; ++q) ok = wait_flag(mine + q, epoch) && ok;
-    if (!ok) atomicOr(p.err, TG_ERR_XCHG_TIMEOUT);
+    uint32_t* gate = p.ticket + 2 + kind;
+    if (bid == 0) {
+      const uint32_t* mine = p.flags[p.rank] + (size_t)kind * TG_MAX_RANKS;
+      bool ok = true;
+      for (int q = 0; q < p.world; ++q) ok = wait_flag(mine + q, epoch) && ok;
+      if (!ok) atomicOr(p.err, TG_ERR_XCHG_TIMEOUT);
+      __hip_atomic_store(gate, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      for (unsigned spin = 0; spin < (1u << 26); ++spin) {  // (workgroup 0 gives up first and opens the gate anyway)
+        if (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
   }
   __syncthreads();
 }
@@ -61,7 +59,8 @@ __device__ __forceinline__ void signal_peers(const tg_part& p, int kind, uint32_
 // launches of tg_part_step that live beside the write-back kernels (tg_memory.hip):
 // PUSH (h(t-) of winning positions of nodes owned elsewhere -> their owners' windows, signal) together with the first
 // write-back launch of the owner's own winners (STEP 4 + 5, or STEP 4 alone with msg_src = right: neither reads h(t-))
-int part_push_wb0_launch(const tg_model* m, const WritebackArgs& a, const tg_part* p, const float* h, hipStream_t st);
+int part_push_wb0_launch(const tg_model* m, const WritebackArgs& a, const tg_part* p, const float* h, bool with_wb0,
+                         hipStream_t st);
 // the second write-back launch (STEP 6, or STEP 5 + 6) behind the wait for the pushed rows, which it reads in the window
 // (rows >= hi_from of a.left_row); ends the step: advances the step counter
 int part_wb1_launch(const tg_model* m, const WritebackArgs& a, const tg_part* p, int64_t hi_from, hipStream_t st);

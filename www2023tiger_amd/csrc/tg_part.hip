@@ -16,7 +16,8 @@
 namespace tg {
 
 // ---- launch 1: stage this step's plan slices at fixed addresses (the write-back / updater launches of the single-GPU
-// engine read them there), forget the previous step's arena mappings, serve the rows peers pull, signal.
+// engine read them there), forget the previous step's arena mappings, serve the rows peers pull, signal; then wait for the
+// rows this rank pulls and adopt them.  The grid is at most 256 workgroups: all resident at once.
 __global__ void __launch_bounds__(256) k_part_begin(tg_model m, tg_part p) {
   const int64_t s = *p.step_dev;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
@@ -40,9 +41,9 @@ __global__ void __launch_bounds__(256) k_part_begin(tg_model m, tg_part p) {
       p.st_mine32[i] = (int32_t)r;
     }
     if (tid == 0) *p.st_n_mine = nm;
-    if (p.row_of && s > 0) {  // the previous batch's pulled nodes: their arena rows will hold other nodes from now on
-      const int np = p.n_req[s - 1];
-      for (int64_t i = tid; i < np; i += nth) p.row_of[p.req_node[(s - 1) * p.req_cap + i]] = -1;
+    if (p.row_of) {  // the previous batch's pulled nodes that this batch does not pull: their arena rows hold other nodes now
+      const int np = p.n_unmap[s];
+      for (int64_t i = tid; i < np; i += nth) p.row_of[p.unmap_node[s * p.req_cap + i]] = -1;
     }
     // PULL, owner side: row -> the requester's inbox (this rank's block, the slot the plan agreed on)
     const int d = m.d, w4 = d / 4, ld4 = w4 + 1;  // inbox rows: d floats + [time, 3 spare] = d / 4 + 1 float4
@@ -69,16 +70,10 @@ __global__ void __launch_bounds__(256) k_part_begin(tg_model m, tg_part p) {
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) p.cur_step[0] = s;  // what the later launches of this step read
   signal_peers(p, 0, (uint32_t)(s + 1), gridDim.x);
-  // (the LAST block to pass the ticket could advance the counter here; it is advanced by k_part_recv instead, the last
-  //  launch of the step that reads cur_step - a replayed graph then runs step after step)
-}
-
-// ---- launch 2: wait for the pulled rows, point row_of at this batch's arena rows, adopt the rows
-__global__ void __launch_bounds__(256) k_part_adopt(tg_model m, tg_part p) {
-  const int64_t s = p.cur_step[0];
   if (s >= p.n_steps) return;
-  wait_peers(p, 0, (uint32_t)(s + 1));
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+  // ---- the same launch, user side: wait for the pulled rows (every rank serves before it waits, and the whole grid is
+  // resident: no rank's serving workgroups wait for anything), point row_of at this batch's arena rows, adopt the rows
+  wait_peers(p, 0, (uint32_t)(s + 1), blockIdx.x);
   if (p.row_of) {
     const int nr = p.n_req[s];
     for (int64_t i = tid; i < nr; i += nth) p.row_of[p.req_node[s * p.req_cap + i]] = p.req_row[s * p.req_cap + i];
@@ -98,9 +93,43 @@ __global__ void __launch_bounds__(256) k_part_adopt(tg_model m, tg_part p) {
   }
 }
 
+// ---- self-test of the windows (before a stream is driven through them): `rounds` ping rounds, one workgroup per rank.
+// Round r: lane q stores (rank << 16 | r) into peer q's push inbox (this rank's block, slot 0, parity r & 1) with the
+// step's own store form, the rank's flag of kind 2 goes up; after the wait for every peer's flag lane q checks what peer q
+// stored here; a second hand-shake (kind 3) keeps a fast rank from overwriting a word a slow one has not read yet.
+__global__ void __launch_bounds__(64) k_xchg_selftest(tg_part p, int d, int rounds, int32_t* result) {
+  const int q = threadIdx.x;
+  const int w4 = d / 4;
+  int bad = 0;
+  for (int r = 1; r <= rounds; ++r) {
+    const int64_t par = r & 1;
+    if (q < p.world) {
+      float4* slot = reinterpret_cast<float4*>(p.push_in[q]) + ((par * p.world + p.rank) * p.push_max) * w4;
+      st_sys(slot, make_float4(__int_as_float((p.rank << 16) | r), 0.f, 0.f, 0.f));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (q < p.world)
+      __hip_atomic_store(p.flags[q] + 2 * TG_MAX_RANKS + p.rank, (uint32_t)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (q < p.world) {
+      if (!wait_flag(p.flags[p.rank] + 2 * TG_MAX_RANKS + q, (uint32_t)r)) bad |= 1;
+      const float4* slot = reinterpret_cast<const float4*>(p.push_in[p.rank]) + ((par * p.world + q) * p.push_max) * w4;
+      if (__float_as_int(ld_sys(slot).x) != ((q << 16) | r)) bad |= 2;
+      __hip_atomic_store(p.flags[q] + 3 * TG_MAX_RANKS + p.rank, (uint32_t)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (!wait_flag(p.flags[p.rank] + 3 * TG_MAX_RANKS + q, (uint32_t)r)) bad |= 4;
+    }
+  }
+  if (bad) atomicOr(reinterpret_cast<unsigned*>(result), (unsigned)bad);
+}
+
 }  // namespace tg
 
 using namespace tg;
+
+extern "C" int tg_xchg_selftest(const tg_part* p, int32_t d, int32_t rounds, int32_t* result_dev, void* stream) {
+  if (!p || !result_dev || p->world < 1 || p->world > TG_MAX_RANKS || rounds < 1 || d < 4 || (d % 4) || p->push_max < 1) return TG_EINVAL;
+  hipLaunchKernelGGL(k_xchg_selftest, dim3(1), dim3(64), 0, as_stream(stream), *p, (int)d, (int)rounds, result_dev);
+  return check_launch("tg_xchg_selftest");
+}
 
 extern "C" int tg_part_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, const tg_part* p, void* ws,
                             size_t ws_bytes, void* aws, size_t aws_bytes, void* stream) {
@@ -114,18 +143,21 @@ extern "C" int tg_part_step(const tg_model* m, const tg_tcsr* g, const tg_step_i
   const int64_t pull_rows = std::max<int64_t>(p->serve_cap, (int64_t)p->world * p->pull_max);
   const unsigned g1 = (unsigned)std::min<int64_t>(256, std::max<int64_t>(8, cdiv(std::max<int64_t>(pull_rows * (d / 4 + 1), 2 * p->Bg), 256)));
   hipLaunchKernelGGL(k_part_begin, dim3(g1), dim3(256), 0, st, *m, *p);
-  const unsigned g2 = (unsigned)std::min<int64_t>(256, std::max<int64_t>(1, cdiv((int64_t)p->world * p->pull_max * (d / 4), 256)));
-  hipLaunchKernelGGL(k_part_adopt, dim3(g2), dim3(256), 0, st, *m, *p);
-  int rc;
-  if ((rc = tg_stream_step(m, g, io, ws, ws_bytes, stream)) != TG_OK) return rc;
   // STEP 4-6 for this rank's own winners (planned, owner-filtered: tg_stream_writeback's kernels on the staged slices).
-  // The first launch (STEP 4 + 5, or STEP 4 alone with msg_src = right) reads no h(t-): it shares its launch with the
-  // PUSH of this rank's rows and runs while the peers' rows are on their way; the second waits for them
+  // The first launch (STEP 4 + 5, or STEP 4 alone with msg_src = right) reads no h(t-) and nothing the attention block
+  // writes: it rides on the embedding step's fc1 / fc2 launch where that launch hosts riders (else it shares the launch
+  // of the PUSH); the second waits for the pushed rows
   WritebackArgs wa{};
   wa.B = p->Bg; wa.src = p->st_src; wa.dst = p->st_dst; wa.eids = p->st_eids; wa.upos = p->st_mine_node; wa.index = p->st_mine_index;
   wa.ts = p->st_ts32; wa.n_upos = p->st_n_mine; wa.err = io->err;
   wa.rows = io->h; wa.left_row = p->st_left_row; wa.owner = p->owner; wa.my_rank = p->rank; wa.new_from_pending = 1;
-  if ((rc = part_push_wb0_launch(m, wa, p, io->h, st)) != TG_OK) return rc;
+  static const int ride_knob = getenv("TG_PART_WB_RIDER") ? atoi(getenv("TG_PART_WB_RIDER")) : 1;  // tuning knob: 0 = own launch
+  WbRider wr{};
+  wr.m = *m; wr.a = wa; wr.planned0 = 1;
+  bool rode = false;
+  int rc;
+  if ((rc = stream_step_ext(m, g, io, ws, ws_bytes, st, ride_knob ? &wr : nullptr, &rode)) != TG_OK) return rc;
+  if ((rc = part_push_wb0_launch(m, wa, p, io->h, !rode, st)) != TG_OK) return rc;
   if ((rc = part_wb1_launch(m, wa, p, 3 * io->B, st)) != TG_OK) return rc;
   // the eager updater for the nodes that have just received a message: pending[row] = updater(upd memory, mailbox)
   if ((rc = apply_messages_rows(m, p->st_mine_row, p->st_mine32, p->st_n_mine, p->mine_cap, io->err, aws, aws_bytes, st)) != TG_OK)
@@ -152,6 +184,16 @@ extern "C" int tg_xchg_alloc(size_t bytes, void** out) {
     return TG_EHIP;
   }
   *out = p;
+  return TG_OK;
+}
+extern "C" int tg_xchg_clear(void* p, size_t bytes) {
+  if (!p) return TG_EINVAL;
+  hipError_t e = hipMemset(p, 0, bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    set_hip_error(e, "tg_xchg_clear");
+    return TG_EHIP;
+  }
   return TG_OK;
 }
 extern "C" int tg_xchg_free(void* p) {

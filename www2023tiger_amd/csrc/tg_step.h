@@ -81,6 +81,7 @@ struct StepWs {
   float *snap_te, *gi;
   int64_t *oth, *weid;
   bool upd_done;  // the eager updater's rows of this batch were finished inside the attention block's launches
+  const WbRider* ext_rider;  // tg_part_step: the planned write-back's first launch rides on the embedding step's fc1 / fc2
   bool tail_pending;  // ... or their input-side product was (on fc2's launch): the tail is launched where the updater was
   GruTail tail;
 };
@@ -93,6 +94,9 @@ struct GruSplit {
   bool done;     // variant 1: the rows are finished
 };
 const float* gru_tail_weights(const tg_model* m);
+// tg_stream_step with a rider handed in by the caller (tg_part_step; *rode: whether a launch of the step hosted it)
+int stream_step_ext(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, void* ws, size_t ws_bytes, hipStream_t st,
+                    const WbRider* ext_rider, bool* rode);
 // the eager updater over a list of state rows (tg_part_step): pending[rows32[i]] = updater(upd memory, mailbox)[rows[i]]
 int apply_messages_rows(const tg_model* m, const int64_t* rows, const int32_t* rows32, const int32_t* n_dev, int64_t cap,
                         uint32_t* err, void* ws, size_t ws_bytes, hipStream_t st);  // the tail of the tg_attn_fuse blob, or nullptr (tg_fuse.hip)

@@ -698,6 +698,10 @@ class HipPartitionEngine:
         self.hip_ops.raise_if_err(self.cbuf.err)
 
 
+class WindowExchangeUnavailable(RuntimeError):
+    """the ranks cannot store into each other's windows (tg_part): raised collectively, the caller falls back to RCCL"""
+
+
 class ResidentPartitionedStream:
     """The partitioned mode for a stream that is resident in HBM: every step is planned up front (plans are
     functions of the graph and the stream only; the planning pass also tells every owner what it will be asked
@@ -774,7 +778,11 @@ class ResidentPartitionedStream:
         self.part = None
         self.part_graph = None
         if exchange == 'ipc':
-            self._build_part(owner)
+            try:
+                self._build_part(owner)
+            except WindowExchangeUnavailable as e:  # raised on EVERY rank or on none: the collectives take over
+                self.part = None
+                self.exchange = f'rccl (window exchange unavailable: {e})'
 
     # ---- the window form (tiger_hip.h: tg_part): plan tables over all steps, windows, one call per step
     def _build_part(self, owner):
@@ -799,6 +807,7 @@ class ResidentPartitionedStream:
             serve_peer=torch.zeros(S * serve_cap, **i32), serve_slot=torch.zeros(S * serve_cap, **i32),
             adopt_row=torch.full((S * world * pm,), -1, **i32), adopt_kind=torch.zeros(S * world * pm, **i32),
             n_req=torch.zeros(S, **i32), req_node=torch.zeros(S * req_cap, **i64), req_row=torch.zeros(S * req_cap, **i32),
+            n_unmap=torch.zeros(S, **i32), unmap_node=torch.zeros(S * req_cap, **i64),
             n_push=torch.zeros(S, **i32), push_src=torch.zeros(S * push_cap, **i32), push_peer=torch.zeros(S * push_cap, **i32),
             push_slot=torch.zeros(S * push_cap, **i32),
             n_mine=torch.zeros(S, **i32), mine_node=torch.zeros(S * mine_cap, **i64), mine_index=torch.zeros(S * mine_cap, **i64),
@@ -837,6 +846,11 @@ class ResidentPartitionedStream:
                 T['n_req'][s] = nr
                 T['req_node'][s * req_cap:s * req_cap + nr] = ph['req_nodes']
                 T['req_row'][s * req_cap:s * req_cap + nr] = ph['req_rows']
+                if s > 0:  # the previous step's pulled nodes that this step does not pull again lose their mapping
+                    prev = ph_of(plans[s - 1])['req_nodes']
+                    gone = prev[~torch.isin(prev, ph['req_nodes'])]
+                    T['n_unmap'][s] = int(gone.numel())
+                    T['unmap_node'][s * req_cap:s * req_cap + int(gone.numel())] = gone
             # PUSH, user side
             npush = int(sum(p.push_in))
             if npush:
@@ -859,7 +873,7 @@ class ResidentPartitionedStream:
             st_mine_index=torch.zeros(mine_cap, **i64), st_mine_row=torch.zeros(mine_cap, **i64),
             st_ts32=torch.zeros(2 * Bg, dtype=torch.float32, device=dev), st_mine32=torch.zeros(mine_cap, **i32),
             st_n_mine=torch.zeros(1, **i32), step_dev=torch.zeros(1, **i64), cur_step=torch.zeros(1, **i64),
-            ticket=torch.zeros(2, **i32), owner=torch.as_tensor(np.asarray(owner)).to(dev, torch.int32).contiguous())
+            ticket=torch.zeros(4, **i32), owner=torch.as_tensor(np.asarray(owner)).to(dev, torch.int32).contiguous())
         # ---- windows: [flags 256 B | pull inbox 2 x world x pull_max x (d + 4) | push inbox 2 x world x push_max x d] floats
         n_pull, n_push_f = 2 * world * pm * (d + 4), 2 * world * qm * d
         self._win_bytes = 256 + 4 * (n_pull + n_push_f)
@@ -869,18 +883,31 @@ class ResidentPartitionedStream:
         bases = [None] * world
         bases[rank] = self._win
         self._imported = []
+        fail = 0
         if world > 1:
-            h = (C.c_uint8 * 64)()
-            check(lib.tg_ipc_export(self._win, h), 'tg_ipc_export')
             handles = [None] * world
-            tdist.all_gather_object(handles, bytes(h), group=self.group)
+            try:
+                h = (C.c_uint8 * 64)()
+                check(lib.tg_ipc_export(self._win, h), 'tg_ipc_export')
+                mine = bytes(h)
+            except Exception:
+                mine, fail = None, 1
+            tdist.all_gather_object(handles, mine, group=self.group)
             for q in range(world):
-                if q != rank:
-                    hq = (C.c_uint8 * 64).from_buffer_copy(handles[q])
-                    out = C.c_void_p()
-                    check(lib.tg_ipc_import(hq, C.byref(out)), 'tg_ipc_import')
-                    bases[q] = out.value
-                    self._imported.append(out.value)
+                if q != rank and not fail and handles[q] is not None:
+                    try:
+                        hq = (C.c_uint8 * 64).from_buffer_copy(handles[q])
+                        out = C.c_void_p()
+                        check(lib.tg_ipc_import(hq, C.byref(out)), 'tg_ipc_import')
+                        bases[q] = out.value
+                        self._imported.append(out.value)
+                    except Exception:
+                        fail = 1
+            fail = max([fail] + [1 for x in handles if x is None])
+            flags = [None] * world
+            tdist.all_gather_object(flags, fail, group=self.group)
+            if max(flags):  # some rank could not export / map a window (peers on another node, no peer access): every rank agrees
+                raise WindowExchangeUnavailable('a rank could not export or map a window')
         part = TgPart()
         part.world, part.rank, part.n_steps, part.Bg = world, rank, S, Bg
         part.step_dev, part.cur_step, part.ticket = ptr(Z['step_dev']), ptr(Z['cur_step']), ptr(Z['ticket'])
@@ -891,7 +918,7 @@ class ResidentPartitionedStream:
         part.pull_max, part.push_max = pm, qm
         part.err = ptr(eng.err)
         for k in ('g_src', 'g_dst', 'g_eids', 'ts32', 'left_row', 'n_serve', 'serve_row', 'serve_kind', 'serve_peer',
-                  'serve_slot', 'adopt_row', 'adopt_kind', 'n_req', 'req_node', 'req_row', 'n_push', 'push_src', 'push_peer',
+                  'serve_slot', 'adopt_row', 'adopt_kind', 'n_req', 'req_node', 'req_row', 'n_unmap', 'unmap_node', 'n_push', 'push_src', 'push_peer',
                   'push_slot', 'n_mine', 'mine_node', 'mine_index', 'mine_row'):
             setattr(part, k, ptr(T[k]))
         part.serve_cap, part.req_cap, part.push_cap, part.mine_cap = serve_cap, req_cap, push_cap, mine_cap
@@ -905,6 +932,25 @@ class ResidentPartitionedStream:
         self._aws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
         if world > 1:
             tdist.barrier(group=self.group)  # every window is mapped before anybody stores into one
+        # self-test: a few ping rounds with the step's own store / load / flag forms; every rank must see every peer's words
+        res = torch.zeros(1, **i32)
+        check(lib.tg_xchg_selftest(C.byref(part), d, 8, ptr(res), eng.hip_ops.stream_ptr(dev)), 'tg_xchg_selftest')
+        torch.cuda.synchronize()
+        bad = res.clone()
+        if world > 1:
+            if tdist.get_backend(self.group) == 'nccl':
+                tdist.all_reduce(bad, op=tdist.ReduceOp.MAX, group=self.group)
+            else:
+                b = bad.cpu()
+                tdist.all_reduce(b, op=tdist.ReduceOp.MAX, group=self.group)
+                bad = b
+        self.selftest = int(bad.item())
+        if self.selftest:
+            raise WindowExchangeUnavailable(f'self-test failed on some rank (bits {self.selftest}: 1 flag timeout, 2 wrong word, '
+                                            '4 hand-shake timeout)')
+        check(lib.tg_xchg_clear(self._win, self._win_bytes), 'tg_xchg_clear')  # (flags of kinds 2 / 3 and the pinged slots)
+        if world > 1:
+            tdist.barrier(group=self.group)
 
     def _launch_part(self):
         """one global batch: the library call (host work: one ctypes call)"""
@@ -1156,6 +1202,11 @@ def run_dist_leg(args, cfg, make_stream, build_models, rank, local_rank, world, 
         # exported windows (tg_part_step) - graphs of several steps, no collective in the timed region; rccl: eager launches
         # around two all_to_all_single (the form that also works across nodes)
         exch = getattr(args, 'dist_exchange', 'ipc')
+        if rehearsal and world > 2:
+            # more than two processes on ONE GPU: the device does not run all their kernels at once, a waiting kernel then
+            # keeps the peer it waits for from starting and every wait runs into its bound (measured: ~13 s per step with
+            # four ranks; two ranks rehearse the window form fine).  One process per GPU - the real layout - has no such peer
+            exch = 'rccl'
         use_graphs = nccl and bool(getattr(args, 'dist_graphs', False)) and not args.no_graph and exch != 'ipc'
         rs = ResidentPartitionedStream(model, stream, owner, rank, world, B, n_steps, use_graphs=use_graphs,
                                        physical=physical, exchange=exch)
@@ -1168,10 +1219,18 @@ def run_dist_leg(args, cfg, make_stream, build_models, rank, local_rank, world, 
         p = ShardPlan(stream['dst'][sl], owner, world, B, balance=True)
         spilled += float((p.rank_of != owner[stream['dst'][sl]]).mean())
     spilled /= min(n_steps, 50)
+    t_dbg = time.perf_counter()
+
+    def dbg(what):  # TG_DIST_DEBUG=1: phase marks on stderr (a multi-rank run that stalls says where)
+        if os.environ.get('TG_DIST_DEBUG'):
+            import sys
+            print(f'[dist rank {rank}] {what}: {time.perf_counter() - t_dbg:.1f} s', file=sys.stderr, flush=True)
+    dbg('plans + tables + windows ready')
     n_eager = min(2, n_steps - args.steps - n_prof)
     for _ in range(n_eager):
         rs.step()
     torch.cuda.synchronize()
+    dbg('first eager steps done')
     part = mode == 'partitioned' and rs.part is not None
     gsteps = 0
     if part and not args.no_graph:  # graphs of several steps, as in the single-GPU line (the largest divisor of K up to 25)
@@ -1185,7 +1244,11 @@ def run_dist_leg(args, cfg, make_stream, build_models, rank, local_rank, world, 
         tdist.barrier()
         for _ in range(n_untimed - gsteps):
             rs.step()
+        torch.cuda.synchronize()
+        dbg('untimed eager steps done')
         rs.replay()  # the last untimed steps: one replay (uploads the graph)
+        torch.cuda.synchronize()
+        dbg('first replay done')
     else:
         if use_graphs:
             if mode == 'partitioned':
@@ -1206,6 +1269,7 @@ def run_dist_leg(args, cfg, make_stream, build_models, rank, local_rank, world, 
             rs.step()
     t_host = time.perf_counter() - t0  # the host has enqueued everything; the GPU may still be working
     torch.cuda.synchronize()
+    dbg('timed region done')
     tdist.barrier()
     torch.cuda.synchronize()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
@@ -1302,6 +1366,7 @@ def run_dist_leg(args, cfg, make_stream, build_models, rank, local_rank, world, 
                                state_layout=mode + (f' (physical: {model.msg_store.n} of {stream["n_nodes"]} table rows on rank 0)'
                                                     if physical else ''),
                                parallelism=par, exchange_rows_per_step_rank0=tr,
+                               exchange=(getattr(rs, 'exchange', None) if mode == 'partitioned' else 'all-gather'),
                                spilled_event_fraction=round(spilled, 4), launch=launch,
                                semantics='one global batch = one batch of the single-GPU engine (exchange period 1): '
                                          f'events of a batch do not see each other, and that batch has {Bg} events here'),
