@@ -481,8 +481,8 @@ typedef struct tg_step_io {
   int32_t lean;
   /* Graph.sample_temporal_neighbor's strategy for the neighbours of the batch (graph.py:94-148; init_utils.py:40):
    * 0 = recent_edges (the default recipe), 1 = recent_nodes (last occurrence of each distinct neighbour, graph.py:129-143).
-   * `uniform` consumes the graph's MT19937 stream query by query (graph.py:101-108) and is served by tg_sample_uniform on
-   * the operator path only.  recent_nodes: not together with `lazy` or `inner`. */
+   * 2 = uniform (graph.py:101-115): K draws of numpy's legacy randint per non-empty query, consumed from the graph's
+   * MT19937 stream (`mt_state` below) in query order, sorted by time.  1 and 2: not together with `lazy` or `inner`. */
   int32_t strategy;
   /* --n_layers 2 (tiger.py:29; data_loader.py:105-131; temporal_agg_modules.py:29-83).  NULL: one attention layer.
    * Otherwise a tg_model that differs from the step's model only in its attention block: the weights of the SECOND
@@ -517,6 +517,10 @@ typedef struct tg_step_io {
   int64_t* dbg_l1_nids;
   int64_t* dbg_l1_eids;
   float* dbg_l1_ts;
+  /* strategy == 2 (`uniform`, graph.py:101-115): the graph's numpy RandomState on the device - uint32 [625]: the 624 key
+   * words and the position, as tg_sample_uniform takes it; the step draws from it in query order (cat[src, dst, neg]) and
+   * leaves it where the reference's generator would stand after the batch. */
+  uint32_t* mt_state;
 } tg_step_io;
 
 /* The reference loop draws `np.random.rand() < restart_prob` before every batch but the first; a hit sets

@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.TgTcsr) == 6 * 8
     assert ctypes.sizeof(_lib.TgLinear) == 16
     assert ctypes.sizeof(_lib.TgModel) == 8 + 8 * 4 + 8 * 13 + 2 * 16 + 4 * 8 + 2 * 16 + 4 * 8 + 3 * 16 + 8 + 8 + 8 + 8 + 8
-    assert ctypes.sizeof(_lib.TgStepIo) == 29 * 8
+    assert ctypes.sizeof(_lib.TgStepIo) == 30 * 8
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):

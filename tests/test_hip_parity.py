@@ -710,9 +710,45 @@ def test_fused_step_with_the_recent_nodes_strategy_matches_oracle(lean):
         differs = differs or not np.array_equal(edges, cg['l1_nids'])
     assert differs  # the two strategies really sample different lists on this stream
     compare_state_with_oracle(model, orc)
-    model.graph.strategy = 'uniform'
-    with pytest.raises(NotImplementedError):
-        model.stream_step(*a)
+
+
+@pytest.mark.parametrize('lean', [False, True], ids=['full', 'lean'])
+def test_fused_step_with_the_uniform_strategy_matches_oracle(lean):
+    """--strategy uniform (graph.py:101-115) inside tg_stream_step (tg_step_io.strategy = 2): K draws of numpy's legacy
+    randint per non-empty query, consumed from the graph's MT19937 stream in query order (cat[src, dst, neg]) and sorted by
+    time.  The oracle's graph carries a numpy RandomState with the same seed: every batch's neighbour lists must be the very
+    same draws (node ids / edge ids / times equal as time-sorted multisets - numpy's argsort leaves the order of equal times
+    open), the generator must stand where numpy's stands after the stream, and embeddings and state follow."""
+    import bench
+    from oracle import tiger_oracle as O
+    from www2023tiger_amd.data.graph import Graph
+    c = bench.C2
+    B, K, d, nb = 256, c['K'], 32, 6
+    stream = bench.make_stream(400, 60, (nb + 1) * B, 2.0e4, seed=43, d_e=d)
+    model, orc = bench.build_models(stream, d, K, c['msg_src'], c['upd_src'], with_oracle=True)
+    model.graph = Graph.from_arrays(stream['src'], stream['dst'], stream['ts'], stream['eids'], strategy='uniform',
+                                    seed=5, max_node_id=stream['n_nodes'] - 1, device=dev())
+    orc.graph = O.OracleGraph(stream['src'], stream['dst'], stream['ts'], stream['eids'], strategy='uniform', seed=5,
+                              max_node_id=stream['n_nodes'] - 1)
+    model.fuse_attention()
+    model.eager_updates()
+    for b in range(nb):
+        a = [stream[k][b * B:(b + 1) * B] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], K, 'static')
+        ref = orc.stream_step(*a, cg).numpy()
+        buf = model.stream_step(*a, lean=lean)
+        got_t, got_n, got_e = (x.cpu().numpy() for x in (buf.l1_ts, buf.l1_nids, buf.l1_eids))
+        np.testing.assert_array_equal(got_t, cg['l1_ts'])  # times are sorted: equal as arrays
+        np.testing.assert_array_equal(np.sort(got_e, axis=1), np.sort(cg['l1_eids'], axis=1))  # the same draws
+        key = lambda n, e: np.sort(n.astype(np.int64) * (int(stream['eids'].max()) + 1) + e, axis=1)
+        np.testing.assert_array_equal(key(got_n, got_e), key(cg['l1_nids'], cg['l1_eids']))
+        assert_close(buf.h[:2 * B].cpu().numpy(), ref, f'h_left, batch {b}', TOL)
+    # the generator stands where numpy's stands: the next draws of both agree
+    st = model.graph._mt_state().cpu().numpy().view(np.uint32)
+    ref_state = orc.graph.rng.get_state()
+    np.testing.assert_array_equal(st[:624], ref_state[1])
+    assert int(st[624]) == int(ref_state[2])
+    compare_state_with_oracle(model, orc)
 
 
 @pytest.mark.parametrize('mc', ['12', '16'])

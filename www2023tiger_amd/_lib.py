@@ -71,7 +71,7 @@ class TgStepIo(C.Structure):
         ('offset_dev', vp), ('advance', i32), ('embed_only', i32), ('profiler', vp), ('h_new', vp),
         ('ws_is_clean', i32), ('rows_hint', i32), ('lazy', vp), ('collate_only', i32), ('eager_copy', i32), ('lean', i32), ('strategy', i32),
         ('inner', vp), ('stream_len', i64), ('prefetch_state', vp),
-        ('dbg_l1_nids', vp), ('dbg_l1_eids', vp), ('dbg_l1_ts', vp),
+        ('dbg_l1_nids', vp), ('dbg_l1_eids', vp), ('dbg_l1_ts', vp), ('mt_state', vp),
     ]
 
 

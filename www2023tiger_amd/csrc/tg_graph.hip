@@ -399,24 +399,40 @@ __global__ void __launch_bounds__(64) k_sample_uniform(tg_tcsr g, int64_t Q, con
     mask |= mask >> 4;
     mask |= mask >> 8;
     mask |= mask >> 16;
-    for (int k = 0; k < K; ++k) {
-      uint32_t val = 0;
-      if (rng != 0) {
-        bool done = false;  // wave-uniform via LDS
-        while (!done) {
-          if (s_pos == 624) {
-            mt_regen(key, lane);
-            if (lane == 0) s_pos = 0;
-            __builtin_amdgcn_wave_barrier();
-          }
-          val = mt_temper(key[s_pos]) & mask;
+    if (rng == 0) {  // one entry: randint draws nothing
+      if (lane < K) s_sel[lane] = start;
+    } else {
+      // The next words of the stream are judged 64 at a time: word j is accepted iff (tempered & mask) <= rng, the query
+      // takes its first K accepted words in order and consumes the stream up to the K-th (the words behind it in the
+      // window stay for the next query) - the same draws, in the same order, as K calls of the scalar rejection loop
+      int got = 0;
+      while (got < K) {  // wave-uniform
+        int pos = s_pos;
+        __builtin_amdgcn_wave_barrier();
+        if (pos == 624) {
+          mt_regen(key, lane);
+          pos = 0;
           __builtin_amdgcn_wave_barrier();
-          if (lane == 0) s_pos = s_pos + 1;
-          __builtin_amdgcn_wave_barrier();
-          done = val <= (uint32_t)rng;
         }
+        const int avail = min(TG_WAVE, 624 - pos);
+        const uint32_t v = lane < avail ? (mt_temper(key[pos + lane]) & mask) : 0xffffffffu;
+        const bool acc = lane < avail && v <= (uint32_t)rng;
+        const unsigned long long bal = __ballot(acc);
+        const int r = __popcll(bal & ((1ull << lane) - 1ull));  // accepted words in front of this lane
+        const int need = K - got;
+        if (acc && r < need) s_sel[got + r] = start + (int64_t)v;
+        int used = avail;
+        if (__popcll(bal) >= need) {  // the need-th accepted word ends the query
+          const unsigned long long last = __ballot(acc && r == need - 1);
+          used = (int)__ffsll((long long)last);  // its lane + 1
+          got = K;
+        } else {
+          got += __popcll(bal);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) s_pos = pos + used;
+        __builtin_amdgcn_wave_barrier();
       }
-      if (lane == 0) s_sel[k] = start + (int64_t)val;
     }
     __builtin_amdgcn_wave_barrier();
     // stable insertion sort by time (numpy's argsort on <= 16 elements is insertion sort)
@@ -636,6 +652,28 @@ extern "C" int tg_sample_recent_nodes(const tg_tcsr* g, int64_t Q, const int64_t
                      K, o_nbr, o_eid, o_ts, o_dir);
   return check_launch("tg_sample_recent_nodes");
 }
+
+namespace tg {
+__global__ void k_mark_queries(int64_t Q, int K, const int64_t* __restrict__ nids, const int64_t* __restrict__ nbr,
+                               uint8_t* __restrict__ mark) {
+  const int64_t n = Q * (K + 1);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = i < Q ? nids[i] : nbr[i - Q];
+    mark[v] = 1;
+  }
+}
+// uniform sampler over prepared query arrays (the fused step, tg_step_io.strategy = 2); marks queries and neighbours in
+// `mark` when given.  ONE wavefront walks the queries: the reference consumes its random stream in query order
+int sample_uniform_launch(const tg_tcsr* g, int64_t Q, const int64_t* nids, const double* ts, int32_t K, uint32_t* mt_state,
+                          int64_t* o_nbr, int64_t* o_eid, float* o_ts, uint8_t* mark, hipStream_t st) {
+  if (!mt_state) return TG_EINVAL;
+  if (K > 16) return TG_EUNSUPPORTED;  // (numpy's argsort is a stable insertion sort only up to 16 elements)
+  hipLaunchKernelGGL(k_sample_uniform, dim3(1), dim3(64), 0, st, *g, Q, nids, ts, (int)K, mt_state, o_nbr, o_eid, o_ts,
+                     (int64_t*)nullptr);
+  if (mark) hipLaunchKernelGGL(k_mark_queries, dim3(flat_grid(Q * (K + 1), 256)), dim3(256), 0, st, Q, (int)K, nids, o_nbr, mark);
+  return check_launch("sample_uniform");
+}
+}  // namespace tg
 
 extern "C" int tg_sample_uniform(const tg_tcsr* g, int64_t Q, const int64_t* nids, const double* ts, int32_t K,
                                  uint32_t* mt_state, int64_t* o_nbr, int64_t* o_eid, float* o_ts, int64_t* o_dir,

@@ -1297,16 +1297,20 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
                            flat_grid((ctab ? 2 * B : Q) * (m->d / 4), 256)};
   w.pos_args = pp ? pos : PosArgs{};
   w.da_args = da;
-  const bool recent_nodes = io->strategy == 1;
-  if (io->strategy != 0 && !recent_nodes) return TG_EUNSUPPORTED;
+  const bool recent_nodes = io->strategy == 1, uniform = io->strategy == 2;
+  if (io->strategy < 0 || io->strategy > 2 || (uniform && !io->mt_state)) return TG_EUNSUPPORTED;
   if (prefetched) {
     // sampler, centres, first dedup pass and snapshot of this batch rode on the previous step's last launch
-  } else if (recent_nodes) {  // query arrays first, then the wave-per-query sampler of graph.py:129-143 and the involved flags
+  } else if (recent_nodes || uniform) {  // query arrays first, then the sampler of graph.py:129-143 / :101-115 and the involved flags
     if (lz || inner) return TG_EUNSUPPORTED;
     hipLaunchKernelGGL(k_build_queries, dim3(flat_grid(Q, 256)), dim3(256), 0, st, B, io->src, io->dst, io->neg, io->ts,
                        io->eids, (const int64_t*)io->offset_dev, w.nids3, w.ts3, w.ts3f, w.eids);
-    if ((rc = sample_nodes_launch(g, Q, w.nids3, w.ts3, (int32_t)K, w.l1n, w.l1e, w.l1t, need_flags ? w.flags : nullptr, st)) !=
-        TG_OK)
+    // uniform: the graph's MT19937 stream is consumed per non-empty query, in query order (src, dst, neg of the batch, as
+    // data_loader.py:79-81 concatenates them): one wavefront walks the queries, 64 words of the stream at a time
+    if ((rc = uniform ? sample_uniform_launch(g, Q, w.nids3, w.ts3, (int32_t)K, io->mt_state, w.l1n, w.l1e, w.l1t,
+                                              need_flags ? w.flags : nullptr, st)
+                      : sample_nodes_launch(g, Q, w.nids3, w.ts3, (int32_t)K, w.l1n, w.l1e, w.l1t, need_flags ? w.flags : nullptr,
+                                            st)) != TG_OK)
       return rc;
   } else if (KSlot ks_(KT_COLLATE); (rc = sample_batch_launch(g, B, io->src, io->dst, io->neg, io->ts, io->eids, io->offset_dev, (int32_t)K,
                                        w.nids3, w.ts3f, w.eids, w.l1n, w.l1e, w.l1t, need_flags ? w.flags : nullptr, st,
@@ -1403,7 +1407,7 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
     }
   }
   if ((rc = attn_forward(m, Q, w.nids3, w.ts3f, w.l1n, w.l1e, w.l1t, w.reprs, w.bm, w.rank, io->h, w.attn, st, pf,
-                         drop, pp, w.direct ? &da : nullptr, key_rows, w.lean && !recent_nodes && !lz, w.gtab,
+                         drop, pp, w.direct ? &da : nullptr, key_rows, w.lean && io->strategy == 0 && !lz, w.gtab,
                          want_rider ? &wbr : w.ext_rider, &w.wb_rode, gsplit ? &gs : nullptr)) != TG_OK)
     return rc;
   w.upd_done = gs.done;

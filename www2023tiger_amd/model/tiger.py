@@ -799,10 +799,14 @@ class TIGE(nn.Module):
         if not (buf.embed_only or buf.io.collate_only):
             self._refuse_partitioned('stream_step / launch_step (a full step)')
         strategy = getattr(self.graph, 'strategy', 'recent_edges')
-        if strategy not in ('recent_edges', 'recent_nodes'):
-            raise NotImplementedError(f"the fused step samples 'recent_edges' or 'recent_nodes'; strategy={strategy!r} (its "
-                                      'draws walk the graph\'s MT19937 stream query by query) runs on the operator path')
-        buf.io.strategy = 1 if strategy == 'recent_nodes' else 0
+        if strategy not in ('recent_edges', 'recent_nodes', 'uniform'):
+            raise NotImplementedError(f"the fused step samples 'recent_edges', 'recent_nodes' or 'uniform'; strategy={strategy!r} "
+                                      '(graph.py:104-110, alpha != 0) is not built')
+        buf.io.strategy = {'recent_edges': 0, 'recent_nodes': 1, 'uniform': 2}[strategy]
+        if strategy == 'uniform':  # the graph's RandomState lives on the device and is consumed in query order
+            if self.n_layers != 1:
+                raise NotImplementedError("strategy='uniform' with two layers runs on the operator path")
+            buf.io.mt_state = ptr(self.graph._mt_state())
         if self.n_layers == 2:  # the second attention layer's weights travel in a tg_model of their own
             buf._inner = self.model_struct(1)
             buf.io.inner = C.addressof(buf._inner)
