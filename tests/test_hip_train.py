@@ -122,6 +122,45 @@ def test_c2_shape_gradients_match_oracle():
         assert worst[0] < 3e-4, worst
 
 
+@pytest.mark.parametrize('strategy', ['recent_nodes', 'uniform'])
+def test_training_step_with_other_sampling_strategies(strategy):
+    """--strategy recent_nodes / uniform in the device training step (tg_step_io.strategy = 1 / 2): the neighbourhoods follow
+    the graph's strategy (graph.py:94-148) while the hit windows of STEP 7 stay recent-edges lists (data_loader.py:61-66:
+    one more sampler launch); loss and every gradient against the oracle's autograd over the same collation - with
+    `uniform`, the same draws of the graph's MT19937 stream."""
+    import bench
+    from oracle import tiger_oracle as O
+    from www2023tiger_amd.data.graph import Graph
+    from www2023tiger_amd.model.training import TrainBuffers
+    B, K, d, nb = 256, 10, 32, 5
+    st = bench.make_stream(300, 50, (nb + 1) * B, 2.0e4, seed=9, d_e=d)
+    model, orc = bench.build_models(st, d, K, 'left', 'left', with_oracle=True, dropout=0.0)
+    model.graph = Graph.from_arrays(st['src'], st['dst'], st['ts'], st['eids'], strategy=strategy, seed=4,
+                                    max_node_id=st['n_nodes'] - 1, device=dev())
+    orc.graph = O.OracleGraph(st['src'], st['dst'], st['ts'], st['eids'], strategy=strategy, seed=4, max_node_id=st['n_nodes'] - 1)
+    model.train()
+    tb = TrainBuffers(model, B)
+    to = lambda x, dt: torch.as_tensor(x).to(dev(), dt)
+    differs = False
+    for b in range(nb):
+        a = [st[k][b * B:(b + 1) * B] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], K, 'static')
+        sync_params(model, orc)
+        c, _, grads = orc.train_step(*a, cg, lr=1e-3, contrast_only=True)
+        tb.sb.load(to(a[0], torch.int64), to(a[1], torch.int64), to(a[2], torch.int64), to(a[3], torch.float64),
+                   to(a[4], torch.int64))
+        tb.launch()
+        assert int(tb.sb.err.item()) == 0
+        assert abs(float(tb.losses[0]) - c) < TOL * max(1.0, abs(c)), b
+        worst = max((grad_err(g.cpu().numpy(), grads[k].numpy()), k) for k, g in tb.grads.items())
+        assert worst[0] < 2e-4, (b, worst)
+        edges = orc.graph.sample_temporal_neighbor(np.concatenate(a[:3]), np.tile(a[3], 3), K, strategy='recent_edges')[0]
+        differs = differs or not np.array_equal(edges, cg['l1_nids'])
+    assert differs  # the strategy really samples other lists than the hit windows use
+    assert rel_err(model.left_memory.vals.cpu().numpy(), orc.left_vals.numpy()) < TOL
+    assert rel_err(model.right_memory.vals.cpu().numpy(), orc.right_vals.numpy()) < TOL
+
+
 @pytest.mark.parametrize('name', ['train_seq_lr_d8', 'train_static_ll_d16', 'train_mlp_merge_d8', 'train_linear_gru_d8'])
 def test_mutual_gradients_match_oracle(name):
     """contrast + mutual loss (tiger.py:547-592): restarter gradients and both losses."""

@@ -626,6 +626,10 @@ struct TrainWs {
   size_t part_floats;
   int32_t* hit_idx;
   int64_t rows_cap;
+  // hit windows when the step samples with another strategy than recent_edges (the windows are recent-edges lists always,
+  // data_loader.py:61-66): lists of cat[src, dst, neg] + the sampler's other outputs (unused)
+  int64_t *hit_nbr, *hit_eid;
+  float* hit_ts;
 };
 
 
@@ -673,6 +677,9 @@ static bool carve_train(const tg_model* m, const tg_score_params* sp, int64_t B,
   w.part_floats = part_floats_for(m, sp);
   w.part = cv.take<float>(w.part_floats);
   w.hit_idx = cv.take<int32_t>((size_t)4 * B);
+  w.hit_nbr = cv.take<int64_t>((size_t)Q * K);
+  w.hit_eid = cv.take<int64_t>((size_t)Q * K);
+  w.hit_ts = cv.take<float>((size_t)Q * K);
   return cv.ok;
 }
 
@@ -682,7 +689,7 @@ static size_t train_ws_bytes(const tg_model* m, const tg_score_params* sp, int64
   const size_t rows = std::min<size_t>(Q * (K + 1), (size_t)m->n_nodes);
   return align16(rows * 4 * d * 4) + align16(2 * B * 2 * W * 4) * 2 + align16(2 * B * d * 4) + align16(Q * d * 4) * 3 +
          align16(Q * E * 4) * 3 + align16(Q * nh * kvw * 4) * 2 + align16(rows * d * 4) + align16(rows * 3 * d * 4) * 2 +
-         align16(E * 4) + align16(1024 * 2 * d * 4) + align16(part_floats_for(m, sp) * 4) + align16(4 * B * 4) + 256 +
+         align16(E * 4) + align16(1024 * 2 * d * 4) + align16(part_floats_for(m, sp) * 4) + align16(4 * B * 4) + 256 + 2 * align16(Q * K * 8) + align16(Q * K * 4) +
          (m->tsfm != TG_TSFM_ID ? align16(rows * (3 * d + m->d_e) * 4) : 0) +
          (m->tsfm == TG_TSFM_MLP ? align16(rows * ((3 * d + m->d_e) / 2) * 4) : 0) +
          (m->upd_fn == TG_UPD_MERGE ? 2 * align16(rows * d * 4) : 0);
@@ -700,8 +707,20 @@ static int train_supported(const tg_model* m, const tg_score_params* sp) {
   return 1;
 }
 
+// the recent-edges lists of cat[src, dst, neg] the hit windows are made of (data_loader.py:61-66: strategy='recent_edges'
+// whatever the graph's own strategy): the step's own lists, or - another strategy - one more sampler launch over the
+// step's query arrays (float64 times)
+static const int64_t* hit_lists(const tg_tcsr* g, const tg_model* m, const tg_step_io* sio, StepWs& w, TrainWs& t, hipStream_t st,
+                                int* rc) {
+  *rc = TG_OK;
+  if (sio->strategy == 0) return w.l1n;
+  const int64_t Q = 3 * sio->B;
+  *rc = tg_sample_recent_edges(g, Q, w.nids3, w.ts3, m->n_neighbors, t.hit_nbr, t.hit_eid, t.hit_ts, nullptr, nullptr, (void*)st);
+  return t.hit_nbr;
+}
+
 // STEP 7 forward only (evaluation): scores and the BCE loss, no gradients
-static int score_forward(const tg_model* m, const tg_train_io* io, StepWs& w, TrainWs& t, hipStream_t st) {
+static int score_forward(const tg_model* m, const tg_tcsr* gr, const tg_train_io* io, StepWs& w, TrainWs& t, hipStream_t st) {
   const tg_score_params* sp = io->score;
   const int64_t B = io->step.B;
   const int d = m->d, K = m->n_neighbors;
@@ -711,12 +730,14 @@ static int score_forward(const tg_model* m, const tg_train_io* io, StepWs& w, Tr
     set_hip_error(e, "tg_train_step memset");
     return TG_EHIP;
   }
+  int rc;
+  const int64_t* hl = hit_lists(gr, m, &io->step, w, t, st, &rc);
+  if (rc != TG_OK) return rc;
   hipLaunchKernelGGL(k_build_pairs, dim3(flat_grid(2 * B, 4)), dim3(256), 0, st, B, d, K, sp->hit_type, io->step.h,
-                     w.nids3, w.l1n, sp->hit_emb, t.P, t.hit_idx);
+                     w.nids3, hl, sp->hit_emb, t.P, t.hit_idx);
   GemmArgs g{};
   g.m_cap = 2 * B; g.n = d; g.k = W2; g.a0 = ASeg{t.P, W2, W2, nullptr};
   g.w = sp->fc1.w; g.ldw = W2; g.bias = sp->fc1.b; g.c = t.T1; g.ldc = d; g.relu = 1; g.alpha = 1.f; g.nbatch = 1;
-  int rc;
   if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
   hipLaunchKernelGGL(k_score_loss, dim3(std::min<unsigned>(flat_grid(2 * B, 4), 256)), dim3(256), 0, st, B, d, t.T1,
                      sp->fc2.w, sp->fc2.b, io->pos_scores, io->neg_scores, io->losses, (float*)nullptr, (float*)nullptr,
@@ -725,8 +746,8 @@ static int score_forward(const tg_model* m, const tg_train_io* io, StepWs& w, Tr
 }
 
 // backward of the contrastive loss; everything it reads is still in the step workspace
-static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w, TrainWs& t, const DropCfg& dc,
-                             hipStream_t st) {
+static int contrast_backward(const tg_model* m, const tg_tcsr* gr, const tg_train_io* io, StepWs& w, TrainWs& t,
+                             const DropCfg& dc, hipStream_t st) {
   const tg_score_params* sp = io->score;
   const tg_model* gm = io->grads;
   const tg_score_params* gs = io->score_grads;
@@ -745,8 +766,10 @@ static int contrast_backward(const tg_model* m, const tg_train_io* io, StepWs& w
   }
   auto F = [](const float* p) { return const_cast<float*>(p); };
   // ---- STEP 7 forward
+  const int64_t* hl = hit_lists(gr, m, &io->step, w, t, st, &rc);
+  if (rc != TG_OK) return rc;
   hipLaunchKernelGGL(k_build_pairs, dim3(flat_grid(2 * B, 4)), dim3(256), 0, st, B, d, K, sp->hit_type, io->step.h,
-                     w.nids3, w.l1n, sp->hit_emb, t.P, t.hit_idx);
+                     w.nids3, hl, sp->hit_emb, t.P, t.hit_idx);
   GemmArgs g{};
   g.m_cap = 2 * B; g.n = d; g.k = W2; g.a0 = ASeg{t.P, W2, W2, nullptr};
   g.w = sp->fc1.w; g.ldw = W2; g.bias = sp->fc1.b; g.c = t.T1; g.ldc = d; g.relu = 1; g.alpha = 1.f; g.nbatch = 1;
@@ -978,14 +1001,14 @@ extern "C" int tg_train_step(const tg_model* m_in, const tg_tcsr* g, const tg_tr
   int rc;
   if (eval_only) {
     if ((rc = step_forward(m, g, sio, w, nullptr, st, nullptr, nullptr)) != TG_OK) return rc;
-    if ((rc = score_forward(m, io, w, t, st)) != TG_OK) return rc;
+    if ((rc = score_forward(m, g, io, w, t, st)) != TG_OK) return rc;
     if ((rc = step_writeback_a(m, sio, w, st, nullptr)) != TG_OK) return rc;
     return step_writeback_b(m, g, sio, w, st, nullptr);
   }
   if (io->dropout_p < 0.f || io->dropout_p >= 1.f || (io->dropout_p > 0.f && !io->rng)) return TG_EINVAL;
   const DropCfg dc = make_drop(io->dropout_p, io->rng);
   if ((rc = step_forward(m, g, sio, w, t.gates, st, nullptr, &dc)) != TG_OK) return rc;
-  if ((rc = contrast_backward(m, io, w, t, dc, st)) != TG_OK) return rc;
+  if ((rc = contrast_backward(m, g, io, w, t, dc, st)) != TG_OK) return rc;
   if ((rc = step_writeback_a(m, sio, w, st, nullptr)) != TG_OK) return rc;
   if (io->restarter != TG_RESTARTER_NONE) {  // needs the targets of STEP 4/5 and the step's bitmap-free inputs
     const bool seq = io->restarter == TG_RESTARTER_SEQ;

@@ -79,7 +79,7 @@ class GraphCollator:
         """collate_arrays for a batch that already lives on the collator's device (int64 ids, float64 times)"""
         cg = ComputationGraph.lazy(self, src, dst, neg, ts64)
         cg.ts64 = ts64
-        cg.graph = self.graph if self.graph.strategy == 'recent_edges' else None
+        cg.graph = self.graph if self.graph.strategy in ('recent_edges', 'recent_nodes') else None
         return src, dst, neg, ts64.float(), eids, labels, cg
 
     def collate_arrays(self, src, dst, neg, ts, eids, labels=None):
@@ -106,7 +106,8 @@ class GraphCollator:
             s_d, d_d, n_d, t32 = s, d_, n_, t_dev.float()
         cg = ComputationGraph.lazy(self, s_d, d_d, n_d, t_dev)  # pieces are collated on first access
         cg.ts64 = t_dev  # float64 event times for the one-call steps (which collate on device themselves)
-        cg.graph = self.graph if self.graph.strategy == 'recent_edges' else None  # None: one-call steps do not apply
+        # None: the one-call steps do not apply ('uniform' draws from the graph's random stream: the collator has drawn)
+        cg.graph = self.graph if self.graph.strategy in ('recent_edges', 'recent_nodes') else None
         return s, d_, n_, t32, e, lab, cg
 
 

@@ -132,9 +132,8 @@ def check_trainable(model):
         raise NotImplementedError('dropout inside the message transform is not built (the reference never sets it)')
     if model.n_layers != 1:
         raise NotImplementedError('training on device supports n_layers == 1')
-    if getattr(model.graph, 'strategy', 'recent_edges') != 'recent_edges':
-        # tg_train_step collates by itself with the recent-edges sampler (the CLI default, init_utils.py:41)
-        raise NotImplementedError("training on device samples with strategy='recent_edges'")
+    if getattr(model.graph, 'strategy', 'recent_edges') not in ('recent_edges', 'recent_nodes', 'uniform'):
+        raise NotImplementedError("training on device samples with strategy 'recent_edges', 'recent_nodes' or 'uniform'")
     if model.temporal_embedding_fn.fns[0].merger.dropout.p > 0:
         raise NotImplementedError('dropout inside the embedding merger is not built (the reference never sets it)')
     dropout_p(model)
@@ -243,6 +242,10 @@ class TrainBuffers:
         m = model.model_struct()
         self.io.step.rows_hint = model.rows_bound()
         graph = model.graph if graph is None else graph
+        # the neighbourhoods follow the graph's strategy (graph.py:94-148); the hit windows are recent-edges lists always
+        strategy = getattr(graph, 'strategy', 'recent_edges')
+        self.io.step.strategy = {'recent_edges': 0, 'recent_nodes': 1, 'uniform': 2}[strategy]
+        self.io.step.mt_state = ptr(graph._mt_state()) if strategy == 'uniform' else None
         model.check_graph(graph)
         model._touch()  # state changes outside the eager streaming step
         g = graph.tcsr
