@@ -653,6 +653,10 @@ typedef struct tg_train_io {
   float dropout_p;                    /* 0 <= p < 1; 0 = off */
   int32_t reserved2;
   uint64_t* rng;                      /* device uint64[2]; required when dropout_p > 0 */
+  /* --n_layers 2 (step.inner != NULL; tiger.py:29, temporal_agg_modules.py:29-83): gradient buffers of the SECOND
+   * attention layer's parameters (temporal_embedding_fn.fns[1]) in the layout of `grads`' attention block (+=); the
+   * other fields of this tg_model are ignored.  Required for training with two layers. */
+  const tg_model* inner_grads;
 } tg_train_io;
 
 #define TG_RESTARTER_NONE 0
@@ -662,6 +666,8 @@ typedef struct tg_train_io {
 /* seq: the SeqRestarter when restarter == TG_RESTARTER_SEQ (sizes only), else NULL */
 size_t tg_train_step_workspace_bytes(const tg_model* m, const tg_score_params* sp, int32_t restarter,
                                      const tg_seq_restarter* seq, int64_t B);
+size_t tg_train_step_workspace_bytes2(const tg_model* m, const tg_score_params* sp, int32_t restarter,
+                                      const tg_seq_restarter* seq, int64_t B, int32_t n_layers); /* n_layers 1 or 2 */
 int tg_train_step(const tg_model* m, const tg_tcsr* g, const tg_train_io* io, void* ws, size_t ws_bytes,
                   void* stream);
 

@@ -311,7 +311,7 @@ def gen_train(name, cfg):
     data = InteractionData(src, dst, ts, eids, labels, seed=0, eval=True, neg_dst=neg)
     graph = Graph.from_data(data, strategy='recent_edges', seed=0)
     model, pnames, pshapes = build_reference_model(cfg, nfeats, efeats, graph, E, dropout=0.0)
-    collator = GraphCollator(graph, cfg['K'], 1, restarter=cfg['restarter'], hist_len=cfg.get('H'))
+    collator = GraphCollator(graph, cfg['K'], cfg.get('L', 1), restarter=cfg['restarter'], hist_len=cfg.get('H'))
     out = {'versions': VERSIONS, 'src': src, 'dst': dst, 'ts': ts, 'eids': eids, 'neg': neg,
            'n_nodes': np.int64(n_nodes), 'param_names': np.array(pnames),
            'param_shapes': np.array([','.join(map(str, s)) for s in pshapes]),
@@ -533,6 +533,13 @@ TRAIN_SCENARIOS = {
     'train_contrast_rr_d8': dict(d=8, n_u=30, n_i=30, E=400, T=500.0, B=50, n_batches=6, K=10, H=6, seed=23,
                                  wseed=23, integer_ts=False, restarter='seq', msg_src='right', upd_src='right',
                                  hit='none', contrast_only=1, lr=1e-2, mutual_coef=1.0, grad_batches=(1, 4)),
+    # --n_layers 2 (the constructor default, tiger.py:29): gradients through both attention layers
+    'train_static_lr_d8_L2': dict(d=8, n_u=30, n_i=12, E=300, T=200.0, B=30, n_batches=8, K=4, L=2, seed=26, wseed=26,
+                                  restarter='static', msg_src='left', upd_src='right', hit='bin', restart_at=5,
+                                  lr=1e-2, mutual_coef=1.0, grad_batches=(1, 3, 6)),
+    'train_contrast_ll_d16_L2': dict(d=16, n_u=40, n_i=15, E=320, T=240.0, B=40, n_batches=6, K=6, H=6, L=2, seed=27,
+                                     wseed=27, restarter='seq', msg_src='left', upd_src='left', hit='vec',
+                                     contrast_only=1, lr=1e-2, mutual_coef=1.0, grad_batches=(1, 4)),
 }
 
 CKPT_SCENARIOS = {

@@ -145,7 +145,7 @@ def test_fused_eval_samples_from_the_collators_graph():
                                     strategy='recent_edges', seed=0, max_node_id=int(z['n_nodes']) - 1, device=dev())
     coll = GraphCollator(train_graph, cfg['K'], 1, restarter=cfg['restarter'], hist_len=cfg.get('H'))
     ref, _, _ = build_hip_model(z, cfg, dropout=0.0)
-    ref._fused_eval_ok = lambda: False  # operator path: uses the collated layers as they are
+    ref._fused_eval_ok = lambda *a: False  # operator path: uses the collated layers as they are
     model.eval(); ref.eval()
     assert model.graph is not train_graph
     B = cfg['B']

@@ -265,7 +265,7 @@ def run_stream(name, fused, op_path=False, eager=False):
     if eager:  # updater rows precomputed when a message is stored; restart / flush below force rebuilds of the table
         model.eager_updates()
     if op_path:  # operator-by-operator evaluation (one C call per reference method) instead of the one-call step
-        model._fused_eval_ok = lambda: False
+        model._fused_eval_ok = lambda *a: False
     B = cfg['B']
     restarting, uptodate = False, set()
     for b in range(n_batches(z)):
@@ -381,17 +381,23 @@ def test_stream_fused_step_with_the_lazy_restart_loop_on_the_device(name, eager)
             check_state(model, z, tag)
 
 
-def test_two_layer_model_trains_on_the_operator_path_only():
-    """--n_layers 2 streams through the fused step (and with pre-multiplied weights, one blob per layer); the device
-    training step is built for one layer and says so instead of computing something else"""
-    z = load('static_lr_d8_L2')
+def test_two_layer_model_trains_through_the_drop_in_api():
+    """--n_layers 2 (the constructor default, tiger.py:29) in training mode on the reference call sequence: the loss of
+    contrast_learning carries the autograd node that hands the device step's gradients over - for BOTH attention layers
+    (temporal_embedding_fn.fns.0 / fns.1); the first batch's loss and gradients of the reference's own two-layer run."""
+    z = load('train_static_lr_d8_L2')
     cfg = parse_cfg(z)
-    model, _, coll = build_hip_model(z, cfg)
+    model, _, coll = build_hip_model(z, cfg, dropout=0.0)
     a = [z[k][:cfg['B']] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
     model.train()
     s_t, d_t, n_t, t_t, e_t, _, cg = coll.collate_arrays(*a)
-    with pytest.raises(NotImplementedError):
-        model.contrast_learning(s_t, d_t, n_t, t_t, e_t, cg)
+    loss, *_ = model.contrast_learning(s_t, d_t, n_t, t_t, e_t, cg)
+    loss.backward()
+    assert abs(float(loss) - float(z['b0_contrast_loss'])) < 1e-4
+    named = dict(model.named_parameters())
+    for k in ('temporal_embedding_fn.fns.0.merger.fc1.weight', 'temporal_embedding_fn.fns.1.merger.fc1.weight',
+              'temporal_embedding_fn.fns.1.mha_fn.k_proj_weight'):
+        assert named[k].grad is not None and float(named[k].grad.abs().max()) > 0, k
 
 
 @pytest.mark.parametrize('form', ['lazy', 'eager', 'eager-fused', 'eager-fused-lean'])

@@ -6,7 +6,7 @@ import torch
 
 from _util import load, parse_cfg, rel_err
 from test_hip_parity import build_hip_model, dev
-from test_oracle_golden import build_oracle, grad_err, TRAIN_FIXTURES
+from test_oracle_golden import build_oracle, grad_err, TRAIN_FIXTURES, TRAIN_FIXTURES_L2
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -39,7 +39,7 @@ def lazy_restart(model, orc, cfg, b, a, cg, state):
         state['uptodate'].update(r_nodes.tolist())
 
 
-@pytest.mark.parametrize('name', TRAIN_FIXTURES)
+@pytest.mark.parametrize('name', TRAIN_FIXTURES + TRAIN_FIXTURES_L2)
 def test_contrast_gradients_match_oracle(name):
     from oracle import tiger_oracle as O
     from www2023tiger_amd.model.training import TrainBuffers
@@ -52,7 +52,8 @@ def test_contrast_gradients_match_oracle(name):
     state = {}
     for b in range(cfg['n_batches']):
         a = batch(z, cfg, b)
-        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], cfg['K'], cfg['restarter'], hist_len=cfg.get('H'))
+        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], cfg['K'], cfg['restarter'], hist_len=cfg.get('H'),
+                       n_layers=cfg.get('L', 1))
         sync_params(model, orc)
         lazy_restart(model, orc, cfg, b, a, cg, state)
         c, _, grads = orc.train_step(*a, cg, lr=cfg['lr'], contrast_only=True)
@@ -161,7 +162,8 @@ def test_training_step_with_other_sampling_strategies(strategy):
     assert rel_err(model.right_memory.vals.cpu().numpy(), orc.right_vals.numpy()) < TOL
 
 
-@pytest.mark.parametrize('name', ['train_seq_lr_d8', 'train_static_ll_d16', 'train_mlp_merge_d8', 'train_linear_gru_d8'])
+@pytest.mark.parametrize('name', ['train_seq_lr_d8', 'train_static_ll_d16', 'train_mlp_merge_d8', 'train_linear_gru_d8',
+                                  'train_static_lr_d8_L2'])
 def test_mutual_gradients_match_oracle(name):
     """contrast + mutual loss (tiger.py:547-592): restarter gradients and both losses."""
     from oracle import tiger_oracle as O
@@ -174,7 +176,8 @@ def test_mutual_gradients_match_oracle(name):
     bufs, state = {}, {}
     for b in range(cfg['n_batches']):
         a = batch(z, cfg, b)
-        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], cfg['K'], cfg['restarter'], hist_len=cfg.get('H'))
+        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], cfg['K'], cfg['restarter'], hist_len=cfg.get('H'),
+                       n_layers=cfg.get('L', 1))
         sync_params(model, orc)
         lazy_restart(model, orc, cfg, b, a, cg, state)
         rkey = next(k for k in orc.p if k.startswith('restarter_fn.') and 'time_encoder' not in k)

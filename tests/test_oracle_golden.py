@@ -146,6 +146,7 @@ def test_stream_matches_reference(name):
 # --------------------------------------------------------------------------- training tail
 TRAIN_FIXTURES = ['train_seq_lr_d8', 'train_static_ll_d16', 'train_contrast_rr_d8', 'train_mlp_merge_d8',
                   'train_linear_gru_d8']
+TRAIN_FIXTURES_L2 = ['train_static_lr_d8_L2', 'train_contrast_ll_d16_L2']  # --n_layers 2
 
 
 def grad_err(a, b):
@@ -159,7 +160,7 @@ def oracle_train_batch(m, z, cfg, b, state):
     B = cfg['B']
     lo, hi = b * B, min((b + 1) * B, len(z['src']))
     a = [z[k][lo:hi] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
-    cg = O.collate(m.graph, a[0], a[1], a[2], a[3], cfg['K'], cfg['restarter'], hist_len=cfg.get('H'))
+    cg = O.collate(m.graph, a[0], a[1], a[2], a[3], cfg['K'], cfg['restarter'], hist_len=cfg.get('H'), n_layers=cfg.get('L', 1))
     if b == cfg.get('restart_at', -1):
         state['restarting'], state['uptodate'] = True, set()
         m.clear_msgs()
@@ -171,7 +172,7 @@ def oracle_train_batch(m, z, cfg, b, state):
                         contrast_only=bool(cfg.get('contrast_only', 0)))
 
 
-@pytest.mark.parametrize('name', TRAIN_FIXTURES)
+@pytest.mark.parametrize('name', TRAIN_FIXTURES + TRAIN_FIXTURES_L2)
 def test_training_matches_reference(name):
     z = load(name)
     cfg = parse_cfg(z)

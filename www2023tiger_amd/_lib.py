@@ -120,7 +120,7 @@ class TgTrainIo(C.Structure):
         ('pos_scores', vp), ('neg_scores', vp), ('flags', vp), ('restarter', i32), ('reserved', i32),
         ('seq', vp), ('seq_grads', vp), ('static_left', vp), ('static_right', vp),
         ('static_left_grad', vp), ('static_right_grad', vp),
-        ('dropout_p', C.c_float), ('reserved2', i32), ('rng', vp),
+        ('dropout_p', C.c_float), ('reserved2', i32), ('rng', vp), ('inner_grads', vp),
     ]
 
 
@@ -197,6 +197,7 @@ SIGNATURES = {
     'tg_ipc_close': (C.c_int, [vp]),
     'tg_stream_step': (C.c_int, [P(TgModel), P(TgTcsr), P(TgStepIo), vp, sz, vp]),
     'tg_train_step_workspace_bytes': (sz, [P(TgModel), P(TgScoreParams), i32, vp, i64]),
+    'tg_train_step_workspace_bytes2': (sz, [P(TgModel), P(TgScoreParams), i32, vp, i64, i32]),
     'tg_train_step': (C.c_int, [P(TgModel), P(TgTcsr), P(TgTrainIo), vp, sz, vp]),
     'tg_adam_step': (C.c_int, [vp, i32, i32, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
     'tg_attn_fused_floats': (sz, [P(TgModel)]),

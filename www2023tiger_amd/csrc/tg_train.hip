@@ -218,7 +218,11 @@ __global__ void __launch_bounds__(256) k_attn_core_bwd(tg_model m, int64_t Q, co
                                                        float4* __restrict__ dG, float* __restrict__ dreprs,
                                                        float* __restrict__ tepart,
                                                        DropCfg dc, const float* __restrict__ dO,
-                                                       const float* __restrict__ bv) {
+                                                       const float* __restrict__ bv, const float4* __restrict__ key_rows,
+                                                       float* __restrict__ dkey_rows) {
+  // key_rows (the OUTER layer of --n_layers 2): the node part of key k of centre i is row i*K + k of a dense tensor - the
+  // neighbour's embedding by the inner layer, no feature add - and its gradient goes to the same row of dkey_rows (plain
+  // stores: every slot has one writer; slots of padding keys keep the zeros the caller put there)
   __shared__ float4 tred[4][2][NV][64];
   __shared__ float xp[4][NV * 256];
   const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -276,8 +280,13 @@ __global__ void __launch_bounds__(256) k_attn_core_bwd(tg_model m, int64_t Q, co
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const int c = lane + v * TG_WAVE;
-        ya[slot][v] = c < d4 ? reprs[u * d4 + c] : z4;
-        yn[slot][v] = (nf && c < d4) ? nf[nb * d4 + c] : z4;
+        if (key_rows) {
+          ya[slot][v] = c < d4 ? key_rows[(i * K + k) * d4 + c] : z4;
+          yn[slot][v] = z4;
+        } else {
+          ya[slot][v] = c < d4 ? reprs[u * d4 + c] : z4;
+          yn[slot][v] = (nf && c < d4) ? nf[nb * d4 + c] : z4;
+        }
         yb[slot][v] = (ef && c < e4) ? ef[eid * e4 + c] : z4;
       }
     };
@@ -404,7 +413,10 @@ __global__ void __launch_bounds__(256) k_attn_core_bwd(tg_model m, int64_t Q, co
         const int c = lane + v * TG_WAVE;
         if (c < d4) *reinterpret_cast<float4*>(&xp[wave][4 * c]) = dxn[v];
       }
-      {
+      if (dkey_rows) {
+        float* dr = dkey_rows + (i * K + k) * d;
+        for (int c = lane; c < d; c += TG_WAVE) dr[c] = xp[wave][c];
+      } else {
         float* dr = dreprs + u * d;
         for (int c = lane; c < d; c += TG_WAVE) atomicAdd(dr + c, xp[wave][c]);
       }
@@ -630,6 +642,7 @@ struct TrainWs {
   // data_loader.py:61-66): lists of cat[src, dst, neg] + the sampler's other outputs (unused)
   int64_t *hit_nbr, *hit_eid;
   float* hit_ts;
+  float* demb2;  // --n_layers 2: gradient of the neighbour slots' embeddings [Q*K, d]
 };
 
 
@@ -646,15 +659,19 @@ static size_t part_floats_for(const tg_model* m, const tg_score_params* sp) {
   return std::max<size_t>(16 * total + 64, (size_t)1280 * 4096);
 }
 
-static bool carve_train(const tg_model* m, const tg_score_params* sp, int64_t B, Carver& cv, TrainWs& w) {
-  const int64_t Q = 3 * B, K = m->n_neighbors;
+// n_layers 2: the attention backward's temporaries serve both layers, one after the other, and are sized for the inner
+// one (its centres are the Q*K neighbour slots)
+static bool carve_train(const tg_model* m, const tg_score_params* sp, int64_t B, Carver& cv, TrainWs& w, int n_layers = 1) {
+  const int64_t Q0 = 3 * B, K = m->n_neighbors;
+  const int64_t Q = n_layers == 2 ? Q0 * K : Q0;  // rows of the attention backward's temporaries
   const int d = m->d, E = 2 * d, kvw = 2 * d + m->d_e, nh = m->n_head, W = score_width(m, sp);
-  w.rows_cap = std::min<int64_t>(Q * (K + 1), m->n_nodes);
+  w.rows_cap = n_layers == 2 ? std::min<int64_t>(Q0 * (1 + K + K * K), std::max<int64_t>(m->n_nodes, 1))
+                             : std::min<int64_t>(Q0 * (K + 1), m->n_nodes);
   w.gates = cv.take<float>((size_t)w.rows_cap * 4 * d);
   w.P = cv.take<float>((size_t)2 * B * 2 * W);
   w.T1 = cv.take<float>((size_t)2 * B * d);
   w.dP = cv.take<float>((size_t)2 * B * 2 * W);
-  w.dH = cv.take<float>((size_t)Q * d);
+  w.dH = cv.take<float>((size_t)Q0 * d);
   w.dT = cv.take<float>((size_t)Q * d);
   w.dhh = cv.take<float>((size_t)Q * E);
   w.dcc = cv.take<float>((size_t)Q * d);
@@ -677,22 +694,18 @@ static bool carve_train(const tg_model* m, const tg_score_params* sp, int64_t B,
   w.part_floats = part_floats_for(m, sp);
   w.part = cv.take<float>(w.part_floats);
   w.hit_idx = cv.take<int32_t>((size_t)4 * B);
-  w.hit_nbr = cv.take<int64_t>((size_t)Q * K);
-  w.hit_eid = cv.take<int64_t>((size_t)Q * K);
-  w.hit_ts = cv.take<float>((size_t)Q * K);
+  w.hit_nbr = cv.take<int64_t>((size_t)Q0 * K);
+  w.hit_eid = cv.take<int64_t>((size_t)Q0 * K);
+  w.hit_ts = cv.take<float>((size_t)Q0 * K);
+  w.demb2 = n_layers == 2 ? cv.take<float>((size_t)Q * d) : nullptr;
   return cv.ok;
 }
 
-static size_t train_ws_bytes(const tg_model* m, const tg_score_params* sp, int64_t B) {
-  const size_t Q = 3 * (size_t)B, K = m->n_neighbors;
-  const size_t d = m->d, E = 2 * d, kvw = 2 * d + m->d_e, nh = m->n_head, W = score_width(m, sp);
-  const size_t rows = std::min<size_t>(Q * (K + 1), (size_t)m->n_nodes);
-  return align16(rows * 4 * d * 4) + align16(2 * B * 2 * W * 4) * 2 + align16(2 * B * d * 4) + align16(Q * d * 4) * 3 +
-         align16(Q * E * 4) * 3 + align16(Q * nh * kvw * 4) * 2 + align16(rows * d * 4) + align16(rows * 3 * d * 4) * 2 +
-         align16(E * 4) + align16(1024 * 2 * d * 4) + align16(part_floats_for(m, sp) * 4) + align16(4 * B * 4) + 256 + 2 * align16(Q * K * 8) + align16(Q * K * 4) +
-         (m->tsfm != TG_TSFM_ID ? align16(rows * (3 * d + m->d_e) * 4) : 0) +
-         (m->tsfm == TG_TSFM_MLP ? align16(rows * ((3 * d + m->d_e) / 2) * 4) : 0) +
-         (m->upd_fn == TG_UPD_MERGE ? 2 * align16(rows * d * 4) : 0);
+static size_t train_ws_bytes(const tg_model* m, const tg_score_params* sp, int64_t B, int n_layers = 1) {
+  char* const base = reinterpret_cast<char*>((uintptr_t)1 << 20);  // dry run of the carve above: never dereferenced
+  Carver cv(base, (size_t)1 << 60);
+  TrainWs w{};
+  return carve_train(m, sp, B, cv, w, n_layers) ? (size_t)(cv.p - base) + 256 : 0;
 }
 
 static int train_supported(const tg_model* m, const tg_score_params* sp) {
@@ -745,63 +758,43 @@ static int score_forward(const tg_model* m, const tg_tcsr* gr, const tg_train_io
   return check_launch("tg_train_step(scores)");
 }
 
-// backward of the contrastive loss; everything it reads is still in the step workspace
-static int contrast_backward(const tg_model* m, const tg_tcsr* gr, const tg_train_io* io, StepWs& w, TrainWs& t,
-                             const DropCfg& dc, hipStream_t st) {
-  const tg_score_params* sp = io->score;
-  const tg_model* gm = io->grads;
-  const tg_score_params* gs = io->score_grads;
-  const int64_t B = io->step.B, Q = 3 * B;
-  const int d = m->d, d_e = m->d_e, E = 2 * d, kvw = 2 * d + d_e, nh = m->n_head, dh = E / nh, K = m->n_neighbors;
-  const int W = score_width(m, sp), W2 = 2 * W;
-  const int mw = 3 * d + d_e;
+// Backward of ONE attention layer (temporal_agg_modules.py:186-235 + the merger, basic_modules.py:16-19) from the gradient
+// of its output rows: weight-gradient products are appended to `tns` (the caller launches them grouped - they read the
+// temporaries of this call, which the next layer's call re-uses), input-row gradients are added to t.dreprs (centres;
+// neighbours unless the layer's keys were rows of a dense tensor: then into dkey_rows), TimeEncode gradients into the
+// layer-independent gm->te_*.  dqconst: what k_qconst_bwd needs after the grouped launch.
+struct AttnBwdIn {
+  const tg_model *m, *gm;
+  const AttnWs* a;
+  int64_t Q;
+  const int64_t* nids;
+  const float* ts;
+  const int64_t *l1n, *l1e;
+  const float* l1t;
+  const float* dH;        // [Q, d]
+  const float* key_rows;  // nullable
+  float* dkey_rows;       // nullable, with key_rows
+};
+static int attn_layer_backward(const AttnBwdIn& in, StepWs& w, TrainWs& t, const DropCfg& dc, std::vector<TnArgs>& tns,
+                               hipStream_t st) {
+  const tg_model* m = in.m;
+  const tg_model* gm = in.gm;
+  const AttnWs& a = *in.a;
+  const int64_t Q = in.Q;
+  const int d = m->d, d_e = m->d_e, E = 2 * d, kvw = 2 * d + d_e, nh = m->n_head, dh = E / nh;
   const float alpha = 1.0f / sqrtf((float)dh);
-  int rc;
-  std::vector<TnArgs> tns;  // weight-gradient products, launched together at the end
-  hipError_t e = hipMemsetAsync(t.dreprs, 0, (size_t)t.rows_cap * d * sizeof(float), st);
-  if (e == hipSuccess) e = hipMemsetAsync(io->losses, 0, 2 * sizeof(float), st);
-  if (e != hipSuccess) {
-    set_hip_error(e, "tg_train_step memset");
-    return TG_EHIP;
-  }
   auto F = [](const float* p) { return const_cast<float*>(p); };
-  // ---- STEP 7 forward
-  const int64_t* hl = hit_lists(gr, m, &io->step, w, t, st, &rc);
-  if (rc != TG_OK) return rc;
-  hipLaunchKernelGGL(k_build_pairs, dim3(flat_grid(2 * B, 4)), dim3(256), 0, st, B, d, K, sp->hit_type, io->step.h,
-                     w.nids3, hl, sp->hit_emb, t.P, t.hit_idx);
+  int rc;
   GemmArgs g{};
-  g.m_cap = 2 * B; g.n = d; g.k = W2; g.a0 = ASeg{t.P, W2, W2, nullptr};
-  g.w = sp->fc1.w; g.ldw = W2; g.bias = sp->fc1.b; g.c = t.T1; g.ldc = d; g.relu = 1; g.alpha = 1.f; g.nbatch = 1;
-  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
-  // fc1 input gradient needs relu(T1) as the mask, and k_score_loss overwrites T1 with dT1: since
-  // dT1 is zero exactly where T1 <= 0, the masked gradient IS dT1 and no copy of T1 is needed
-  hipLaunchKernelGGL(k_score_loss, dim3(std::min<unsigned>(flat_grid(2 * B, 4), 256)), dim3(256), 0, st, B, d, t.T1,
-                     sp->fc2.w, sp->fc2.b, io->pos_scores, io->neg_scores, io->losses, F(gs->fc2.w), F(gs->fc2.b), dc);
-  // ---- STEP 7 backward: score MergeLayer
   TnArgs tn{};
-  tn.m_cap = 2 * B; tn.n = d; tn.k = W2; tn.y = t.T1; tn.ldy = d; tn.x0 = ASeg{t.P, W2, W2, nullptr};
-  tn.out = F(gs->fc1.w); tn.ldo = W2; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = 1; tn.part = t.part;
-  tn.part_floats = t.part_floats; tn.bias_out = F(gs->fc1.b); tn.bias_accumulate = 1;
-  tns.push_back(tn);
-  g = GemmArgs{};
-  g.m_cap = 2 * B; g.n = W2; g.k = d; g.a0 = ASeg{t.T1, d, d, nullptr};
-  g.w = sp->fc1.w; g.ldw = W2; g.w_kmajor = 1; g.c = t.dP; g.ldc = W2; g.alpha = 1.f; g.nbatch = 1;
-  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
-  const bool emb = sp->hit_type == TG_HIT_BIN || sp->hit_type == TG_HIT_COUNT;
-  const size_t lbytes = emb ? (size_t)sp->n_hit_rows * d * sizeof(float) : 0;
-  if (lbytes > 60 * 1024) return TG_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_pairs_bwd, dim3(std::min<unsigned>(flat_grid(B, 4), 256)), dim3(256), lbytes, st, B, d, W,
-                     sp->hit_type, sp->n_hit_rows, t.dP, t.hit_idx, t.dH, emb ? F(gs->hit_emb) : (float*)nullptr);
   // ---- embedding merger (basic_modules.py:16-19): z = fc2(relu(fc1([hh | cc])))
-  const AttnWs& a = w.attn;
   tn = TnArgs{};
-  tn.m_cap = Q; tn.n = d; tn.k = d; tn.y = t.dH; tn.ldy = d; tn.x0 = ASeg{a.t, d, d, nullptr};
+  tn.m_cap = Q; tn.n = d; tn.k = d; tn.y = in.dH; tn.ldy = d; tn.x0 = ASeg{a.t, d, d, nullptr};
   tn.out = F(gm->attn_fc2.w); tn.ldo = d; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = 1; tn.part = t.part;
   tn.part_floats = t.part_floats; tn.bias_out = F(gm->attn_fc2.b); tn.bias_accumulate = 1;
   tns.push_back(tn);
   g = GemmArgs{};
-  g.m_cap = Q; g.n = d; g.k = d; g.a0 = ASeg{t.dH, d, d, nullptr};
+  g.m_cap = Q; g.n = d; g.k = d; g.a0 = ASeg{in.dH, d, d, nullptr};
   g.w = m->attn_fc2.w; g.ldw = d; g.w_kmajor = 1; g.c = t.dT; g.ldc = d; g.alpha = 1.f; g.nbatch = 1;
   g.relu_mask = a.t; g.ld_mask = d;
   if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
@@ -849,9 +842,9 @@ static int contrast_backward(const tg_model* m, const tg_tcsr* gr, const tg_trai
   const int nv = (int)cdiv(std::max(d, d_e) / 4, TG_WAVE);
   const unsigned cgrid = std::min<unsigned>(flat_grid(Q, 4), 1024);
 #define TG_CORE_BWD(NH_, NV_)                                                                                       \
-  hipLaunchKernelGGL((k_attn_core_bwd<NH_, NV_>), dim3(cgrid), dim3(256), 0, st, *m, Q, w.ts3f, w.l1n, w.l1e, w.l1t, \
+  hipLaunchKernelGGL((k_attn_core_bwd<NH_, NV_>), dim3(cgrid), dim3(256), 0, st, *m, Q, in.ts, in.l1n, in.l1e, in.l1t, \
                      (const float4*)w.reprs, w.bm, w.rank, (const float4*)a.g, (const float4*)t.dS, (float4*)t.dG,    \
-                     t.dreprs, t.tepart, dc, t.dO, m->attn_b_in + 2 * E)
+                     t.dreprs, t.tepart, dc, t.dO, m->attn_b_in + 2 * E, (const float4*)in.key_rows, in.dkey_rows)
   if (nh == 2 && nv == 1) TG_CORE_BWD(2, 1);
   else if (nh == 2 && nv == 2) TG_CORE_BWD(2, 2);
   else if (nh == 1 && nv == 1) TG_CORE_BWD(1, 1);
@@ -882,8 +875,81 @@ static int contrast_backward(const tg_model* m, const tg_tcsr* gr, const tg_trai
   g.m_cap = Q; g.n = d; g.k = E; g.a0 = ASeg{t.dqp, E, E, nullptr};
   g.w = m->attn_wq; g.ldw = E; g.w_kmajor = 1; g.c = t.dcc; g.ldc = d; g.alpha = alpha; g.nbatch = 1; g.accumulate = 1;
   if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
-  hipLaunchKernelGGL(k_centre_scatter, dim3(flat_grid(Q * d, 256)), dim3(256), 0, st, Q, d, w.nids3, w.bm, w.rank, t.dcc,
+  hipLaunchKernelGGL(k_centre_scatter, dim3(flat_grid(Q * d, 256)), dim3(256), 0, st, Q, d, in.nids, w.bm, w.rank, t.dcc,
                      t.dreprs);
+  return TG_OK;
+}
+
+// backward of the contrastive loss; everything it reads is still in the step workspace
+static int contrast_backward(const tg_model* m, const tg_tcsr* gr, const tg_train_io* io, StepWs& w, TrainWs& t,
+                             const DropCfg& dc, hipStream_t st) {
+  const tg_score_params* sp = io->score;
+  const tg_model* gm = io->grads;
+  const tg_score_params* gs = io->score_grads;
+  const int64_t B = io->step.B, Q = 3 * B;
+  const int d = m->d, d_e = m->d_e, K = m->n_neighbors;
+  const int W = score_width(m, sp), W2 = 2 * W;
+  const int mw = 3 * d + d_e;
+  int rc;
+  std::vector<TnArgs> tns;  // weight-gradient products, launched together at the end
+  hipError_t e = hipMemsetAsync(t.dreprs, 0, (size_t)t.rows_cap * d * sizeof(float), st);
+  if (e == hipSuccess) e = hipMemsetAsync(io->losses, 0, 2 * sizeof(float), st);
+  if (e != hipSuccess) {
+    set_hip_error(e, "tg_train_step memset");
+    return TG_EHIP;
+  }
+  auto F = [](const float* p) { return const_cast<float*>(p); };
+  // ---- STEP 7 forward
+  const int64_t* hl = hit_lists(gr, m, &io->step, w, t, st, &rc);
+  if (rc != TG_OK) return rc;
+  hipLaunchKernelGGL(k_build_pairs, dim3(flat_grid(2 * B, 4)), dim3(256), 0, st, B, d, K, sp->hit_type, io->step.h,
+                     w.nids3, hl, sp->hit_emb, t.P, t.hit_idx);
+  GemmArgs g{};
+  g.m_cap = 2 * B; g.n = d; g.k = W2; g.a0 = ASeg{t.P, W2, W2, nullptr};
+  g.w = sp->fc1.w; g.ldw = W2; g.bias = sp->fc1.b; g.c = t.T1; g.ldc = d; g.relu = 1; g.alpha = 1.f; g.nbatch = 1;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  // fc1 input gradient needs relu(T1) as the mask, and k_score_loss overwrites T1 with dT1: since
+  // dT1 is zero exactly where T1 <= 0, the masked gradient IS dT1 and no copy of T1 is needed
+  hipLaunchKernelGGL(k_score_loss, dim3(std::min<unsigned>(flat_grid(2 * B, 4), 256)), dim3(256), 0, st, B, d, t.T1,
+                     sp->fc2.w, sp->fc2.b, io->pos_scores, io->neg_scores, io->losses, F(gs->fc2.w), F(gs->fc2.b), dc);
+  // ---- STEP 7 backward: score MergeLayer
+  TnArgs tn{};
+  tn.m_cap = 2 * B; tn.n = d; tn.k = W2; tn.y = t.T1; tn.ldy = d; tn.x0 = ASeg{t.P, W2, W2, nullptr};
+  tn.out = F(gs->fc1.w); tn.ldo = W2; tn.alpha = 1.f; tn.accumulate = 1; tn.nbatch = 1; tn.part = t.part;
+  tn.part_floats = t.part_floats; tn.bias_out = F(gs->fc1.b); tn.bias_accumulate = 1;
+  tns.push_back(tn);
+  g = GemmArgs{};
+  g.m_cap = 2 * B; g.n = W2; g.k = d; g.a0 = ASeg{t.T1, d, d, nullptr};
+  g.w = sp->fc1.w; g.ldw = W2; g.w_kmajor = 1; g.c = t.dP; g.ldc = W2; g.alpha = 1.f; g.nbatch = 1;
+  if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  const bool emb = sp->hit_type == TG_HIT_BIN || sp->hit_type == TG_HIT_COUNT;
+  const size_t lbytes = emb ? (size_t)sp->n_hit_rows * d * sizeof(float) : 0;
+  if (lbytes > 60 * 1024) return TG_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_pairs_bwd, dim3(std::min<unsigned>(flat_grid(B, 4), 256)), dim3(256), lbytes, st, B, d, W,
+                     sp->hit_type, sp->n_hit_rows, t.dP, t.hit_idx, t.dH, emb ? F(gs->hit_emb) : (float*)nullptr);
+  // ---- the attention layer(s).  --n_layers 2: the outer layer (fns[0]) over the batch's Q centres with the neighbour
+  // slots' embeddings as key rows, then the inner layer (fns[1]) over the Q*K slots at the roots' query times
+  // (temporal_agg_modules.py:57-66); the outer layer's weight-gradient products are launched before the inner layer
+  // re-uses the temporaries they read
+  const tg_model* inner = w.h2n ? io->step.inner : nullptr;
+  AttnBwdIn ab{m, gm, &w.attn, Q, w.nids3, w.ts3f, w.l1n, w.l1e, w.l1t, t.dH, nullptr, nullptr};
+  if (inner) {
+    if (!io->inner_grads || !t.demb2) return TG_EINVAL;
+    if ((e = hipMemsetAsync(t.demb2, 0, (size_t)Q * K * d * sizeof(float), st)) != hipSuccess) return TG_EHIP;
+    ab.key_rows = w.emb2;
+    ab.dkey_rows = t.demb2;
+  }
+  if ((rc = attn_layer_backward(ab, w, t, dc, tns, st)) != TG_OK) return rc;
+  if (inner) {
+    if ((rc = gemm_tn_group_launch(tns.data(), (int)tns.size(), t.part, t.part_floats, st)) != TG_OK) return rc;
+    tns.clear();
+    hipLaunchKernelGGL(k_qconst_bwd, dim3((unsigned)cdiv(d, 64), 16), dim3(256), 0, st, d, t.dqconst, m->attn_wq, m->te_freq,
+                       m->te_phase, F(gm->attn_wq), F(gm->attn_b_in), F(gm->te_phase));
+    const AttnBwdIn ab2{inner, io->inner_grads, &w.attn2, Q * K, w.l1n, w.ts2, w.h2n, w.h2e, w.h2t, t.demb2, nullptr, nullptr};
+    if ((rc = attn_layer_backward(ab2, w, t, dc, tns, st)) != TG_OK) return rc;
+  }
+  const tg_model* m_last = inner ? inner : m;        // the layer whose dqconst is pending
+  const tg_model* gm_last = inner ? io->inner_grads : gm;
   // ---- updater (update_modules.py:30-47) and message transform (message_modules.py:20-55)
   const float* upd_vals = (m->upd_src == TG_SRC_LEFT) ? m->left_vals : m->right_vals;
   const int32_t* n_out = w.counts + 1;
@@ -961,8 +1027,8 @@ static int contrast_backward(const tg_model* m, const tg_tcsr* gr, const tg_trai
     tns.push_back(tn);
   }
   if ((rc = gemm_tn_group_launch(tns.data(), (int)tns.size(), t.part, t.part_floats, st)) != TG_OK) return rc;
-  hipLaunchKernelGGL(k_qconst_bwd, dim3((unsigned)cdiv(d, 64), 16), dim3(256), 0, st, d, t.dqconst, m->attn_wq, m->te_freq,
-                     m->te_phase, F(gm->attn_wq), F(gm->attn_b_in), F(gm->te_phase));
+  hipLaunchKernelGGL(k_qconst_bwd, dim3((unsigned)cdiv(d, 64), 16), dim3(256), 0, st, d, t.dqconst, m_last->attn_wq, m->te_freq,
+                     m->te_phase, F(gm_last->attn_wq), F(gm_last->attn_b_in), F(gm->te_phase));
   return check_launch("tg_train_step(backward)");
 }
 
@@ -972,9 +1038,13 @@ using namespace tg;
 
 extern "C" size_t tg_train_step_workspace_bytes(const tg_model* m, const tg_score_params* sp, int32_t restarter,
                                                 const tg_seq_restarter* seq, int64_t B) {
-  if (!m || !train_supported(m, sp) || B <= 0 || m->n_nodes <= 0) return 0;
+  return tg_train_step_workspace_bytes2(m, sp, restarter, seq, B, 1);
+}
+extern "C" size_t tg_train_step_workspace_bytes2(const tg_model* m, const tg_score_params* sp, int32_t restarter,
+                                                 const tg_seq_restarter* seq, int64_t B, int32_t n_layers) {
+  if (!m || !train_supported(m, sp) || B <= 0 || m->n_nodes <= 0 || (n_layers != 1 && n_layers != 2)) return 0;
   if (restarter < TG_RESTARTER_NONE || restarter > TG_RESTARTER_STATIC || (restarter == TG_RESTARTER_SEQ && !seq)) return 0;
-  size_t b = tg_stream_step_workspace_bytes(m, B) + train_ws_bytes(m, sp, B);
+  size_t b = tg_stream_step_workspace_bytes2(m, B, n_layers) + train_ws_bytes(m, sp, B, n_layers);
   if (restarter != TG_RESTARTER_NONE) b += mutual_ws_bytes(m, restarter == TG_RESTARTER_SEQ ? seq : nullptr, B);
   return b;
 }
@@ -997,7 +1067,17 @@ extern "C" int tg_train_step(const tg_model* m_in, const tg_tcsr* g, const tg_tr
   Carver cv(ws, ws_bytes);
   StepWs w{};
   TrainWs t{};
-  if (!carve_step(m, sio->B, cv, w) || !carve_train(m, io->score, sio->B, cv, t)) return TG_EWORKSPACE;
+  const int n_layers = sio->inner ? 2 : 1;
+  tg_model inner_local{};
+  tg_step_io sio_local = *sio;
+  if (sio->inner) {  // the second layer's weights; as for the first, the backward pass needs the unfused forward
+    inner_local = *sio->inner;
+    if (!eval_only) inner_local.attn_fused = nullptr;
+    sio_local.inner = &inner_local;
+    sio = &sio_local;
+    if (!eval_only && !io->inner_grads) return TG_EINVAL;
+  }
+  if (!carve_step(m, sio->B, cv, w, n_layers) || !carve_train(m, io->score, sio->B, cv, t, n_layers)) return TG_EWORKSPACE;
   int rc;
   if (eval_only) {
     if ((rc = step_forward(m, g, sio, w, nullptr, st, nullptr, nullptr)) != TG_OK) return rc;

@@ -474,9 +474,6 @@ class TIGE(nn.Module):
         write-back) runs as one tg_train_step; the returned losses carry an autograd node that
         hands the finished gradients to the parameters when `.backward()` is called."""
         from .training import TrainBuffers, hand_over
-        if self.n_layers != 1:
-            raise NotImplementedError('training on device is built for n_layers == 1 (--n_layers 2 evaluates / streams '
-                                      'through the operator path)')
         self._touch()
         dev = self.device
         B = len(src_ids)
@@ -540,16 +537,17 @@ class TIGE(nn.Module):
             return (losses[0], *rest)
         with torch.no_grad():
             if (getattr(computation_graph, 'ts64', None) is not None
-                    and getattr(computation_graph, 'graph', None) is not None and self._fused_eval_ok()):
+                    and getattr(computation_graph, 'graph', None) is not None and self._fused_eval_ok(computation_graph.graph)):
                 return self._contrast_learning_fused_eval(src_ids, dst_ids, neg_dst_ids, eids, computation_graph)
             return self._contrast_learning_eval(src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph)
 
-    def _fused_eval_ok(self) -> bool:
-        """the one-call evaluation step samples with the default recent-edges strategy; graphs built with
-        another strategy take the operator-by-operator path below"""
+    def _fused_eval_ok(self, graph=None) -> bool:
+        """does the one-call evaluation step (tg_train_step without gradient buffers) apply?  One or two layers; two
+        layers only with the default recent-edges strategy (the other strategies' second hop runs on the operator path)"""
         if self.hit_type == 'vec' and (2 * (self.nfeat_dim + self.n_neighbors)) % 4:
             return False  # the score head's pair rows must be float4-aligned
-        return self.n_layers == 1  # two embedding layers run on the operator path
+        strategy = getattr(graph if graph is not None else self.graph, 'strategy', 'recent_edges')
+        return self.n_layers == 1 or (self.n_layers == 2 and strategy == 'recent_edges')
 
     def _contrast_learning_fused_eval(self, src_ids, dst_ids, neg_dst_ids, eids, computation_graph):
         """no_grad / eval(): collate, STEP 1-7 and the write-back as ONE device call (tg_train_step without

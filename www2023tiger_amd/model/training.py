@@ -63,7 +63,26 @@ def contrast_parameters(model) -> List[Tuple[str, Tensor, int]]:
     ]
     if model.hit_type in ('bin', 'count'):
         out.append(('hit_embedding.weight', model.hit_embedding.weight, 0))
+    if model.n_layers == 2:  # the second attention layer (fns[1]: the neighbours' embeddings, temporal_agg_modules.py:57-66)
+        att1 = model.temporal_embedding_fn.fns[1]
+        out += attention_parameters('temporal_embedding_fn.fns.1.', att1)
     return out
+
+
+def attention_parameters(pre, att):
+    mha = att.mha_fn
+    return [
+        (pre + 'mha_fn.q_proj_weight', mha.q_proj_weight, 0),
+        (pre + 'mha_fn.k_proj_weight', mha.k_proj_weight, 0),
+        (pre + 'mha_fn.v_proj_weight', mha.v_proj_weight, 0),
+        (pre + 'mha_fn.in_proj_bias', mha.in_proj_bias, 0),
+        (pre + 'mha_fn.out_proj.weight', mha.out_proj.weight, 0),
+        (pre + 'mha_fn.out_proj.bias', mha.out_proj.bias, 0),
+        (pre + 'merger.fc1.weight', att.merger.fc1.weight, 0),
+        (pre + 'merger.fc1.bias', att.merger.fc1.bias, 0),
+        (pre + 'merger.fc2.weight', att.merger.fc2.weight, 0),
+        (pre + 'merger.fc2.bias', att.merger.fc2.bias, 0),
+    ]
 
 
 def restarter_parameters(model) -> List[Tuple[str, Tensor, int]]:
@@ -106,10 +125,11 @@ def score_struct(model, tensors=None) -> TgScoreParams:
                          TgLinear(ptr(t['score_fn.fc2.weight']), ptr(t['score_fn.fc2.bias'])))
 
 
-def grads_struct(model, g) -> TgModel:
-    """A tg_model whose parameter pointers address gradient buffers (sizes copied, state NULL)."""
+def grads_struct(model, g, layer: int = 0) -> TgModel:
+    """A tg_model whose parameter pointers address gradient buffers (sizes copied, state NULL).  layer: whose attention
+    block the struct carries (1: the second layer's, tg_train_io.inner_grads)."""
     m = model.model_struct()
-    pre = 'temporal_embedding_fn.fns.0.'
+    pre = f'temporal_embedding_fn.fns.{layer}.'
     nul = TgLinear(None, None)
     lin = lambda stem: TgLinear(ptr(g[stem + '.weight']), ptr(g[stem + '.bias'])) if stem + '.weight' in g else nul
     gp = lambda name: ptr(g.get(name))
@@ -130,8 +150,12 @@ def grads_struct(model, g) -> TgModel:
 def check_trainable(model):
     if model.msg_tsfm_type != 'id' and any(isinstance(l, torch.nn.Dropout) and l.p > 0 for l in model.msg_transform_fn.fn):
         raise NotImplementedError('dropout inside the message transform is not built (the reference never sets it)')
-    if model.n_layers != 1:
-        raise NotImplementedError('training on device supports n_layers == 1')
+    if model.n_layers not in (1, 2):
+        raise NotImplementedError('training on device supports n_layers 1 and 2')
+    if model.n_layers == 2 and getattr(model.graph, 'strategy', 'recent_edges') != 'recent_edges':
+        raise NotImplementedError("training on device with two layers samples with strategy='recent_edges'")
+    if model.n_layers == 2 and model.temporal_embedding_fn.fns[1].merger.dropout.p > 0:
+        raise NotImplementedError('dropout inside the embedding merger is not built (the reference never sets it)')
     if getattr(model.graph, 'strategy', 'recent_edges') not in ('recent_edges', 'recent_nodes', 'uniform'):
         raise NotImplementedError("training on device samples with strategy 'recent_edges', 'recent_nodes' or 'uniform'")
     if model.temporal_embedding_fn.fns[0].merger.dropout.p > 0:
@@ -194,6 +218,8 @@ class TrainBuffers:
         model, B = self.model, self.B
         self._score = score_struct(model)
         self._gmodel = None if self.eval_only else grads_struct(model, self.grads)
+        self._gmodel1 = grads_struct(model, self.grads, 1) if (model.n_layers == 2 and not self.eval_only) else None
+        self._inner = model.model_struct(1) if model.n_layers == 2 else None
         self._gscore = None if self.eval_only else score_struct(model, self.grads)
         m = model.model_struct()
         from .restarters import SeqRestarter
@@ -204,8 +230,9 @@ class TrainBuffers:
                 kind, self._seq, self._gseq = 1, seq_struct(r), seq_struct(r, self.grads)
             else:
                 kind = 2
-        nbytes = int(lib.tg_train_step_workspace_bytes(C.byref(m), C.byref(self._score), kind,
-                                                       C.addressof(self._seq) if self._seq is not None else None, B))
+        nbytes = int(lib.tg_train_step_workspace_bytes2(C.byref(m), C.byref(self._score), kind,
+                                                        C.addressof(self._seq) if self._seq is not None else None, B,
+                                                        model.n_layers))
         if nbytes == 0:
             raise RuntimeError('tg_train_step: unsupported model configuration')
         if getattr(self, 'ws', None) is None or self.ws.numel() < nbytes:
@@ -213,6 +240,10 @@ class TrainBuffers:
         io = TgTrainIo()
         C.memmove(C.addressof(io.step), C.addressof(self.sb.io), C.sizeof(TgStepIo))
         io.score = C.addressof(self._score)
+        if self._inner is not None:  # --n_layers 2: the second attention layer's weights (and gradient buffers)
+            io.step.inner = C.addressof(self._inner)
+            if self._gmodel1 is not None:
+                io.inner_grads = C.addressof(self._gmodel1)
         if not self.eval_only:
             io.grads = C.addressof(self._gmodel)
             io.score_grads = C.addressof(self._gscore)
