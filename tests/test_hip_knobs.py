@@ -17,7 +17,7 @@ SETTINGS = [
     'TG_GEMM_DIRECT=0', 'TG_GEMM_DIRECT=0 TG_GEMM_ASTAT=0', 'TG_GEMM_DIRECT=0 TG_GEMM_ASTAT=0 TG_GEMM_DEPTH=4',
     'TG_GEMM_DIRECT=0 TG_GEMM_ASTAT=0 TG_GEMM_KS=2', 'TG_GEMM_DIRECT=0 TG_GEMM_ASTAT=4', 'TG_GEMM_DIRECT=0 TG_GEMM_ASTAT_CPB=1',
     # riders and the forms they need
-    'TG_WB_RIDER=0', 'TG_WB_RIDER_FC1=0', 'TG_PREFETCH=0', 'TG_CTAB=0', 'TG_GTAB=0', 'TG_GTAB=0 TG_ATTN_TILE=1',
+    'TG_WB_RIDER=0', 'TG_WB_RIDER_FC1=0', 'TG_PREFETCH=0', 'TG_PREFETCH_SPLIT=1', 'TG_CTAB=0', 'TG_GTAB=0', 'TG_GTAB=0 TG_ATTN_TILE=1',
     'TG_EAGER_DIRECT=0',
     # the updater: 16-column LDS-free blocks (default) -> 32-row LDS-free -> LDS-staged 32 / 64 / 96 / 128-row blocks
     'TG_GRU_D16=0', 'TG_GRU_D16=0 TG_GRU_DIRECT=0', 'TG_GRU_D16=0 TG_GRU_MICRO=0', 'TG_GRU_D16=0 TG_GRU_NW=3',

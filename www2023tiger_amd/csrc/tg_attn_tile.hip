@@ -450,15 +450,19 @@ __global__ void __launch_bounds__(64 * NWV) k_attn_tile(tg_model m, TileArgs a) 
 // dynamic LDS beyond the default limit has to be requested once per kernel
 template <int NH, int W, int NWV, int CPW>
 static int tile_attr() {
-  static bool attr_set = false;
-  if (!attr_set) {
+  // (the attribute is per device: set once for every device this process launches the kernel on)
+  constexpr int MAXD = 64;
+  static bool attr_set[MAXD] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXD) dev = -1;
+  if (dev < 0 || !attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_tile<NH, W, NWV, CPW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_LDS_MAX);
     if (e != hipSuccess) {
       set_hip_error(e, "k_attn_tile: hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
       return TG_EHIP;
     }
-    attr_set = true;
+    if (dev >= 0) attr_set[dev] = true;
   }
   return TG_OK;
 }
@@ -468,7 +472,7 @@ static int launch_tile(const tg_model* m, const TileArgs& a, size_t lds, hipStre
   if ((rc = tile_attr<NH, W, NWV, CPW>()) != TG_OK) return rc;
   const unsigned grid = (unsigned)std::min<int64_t>(cdiv(a.Q, NWV * CPW), 256 * 64);
   hipLaunchKernelGGL((k_attn_tile<NH, W, NWV, CPW>), dim3(grid), dim3(64 * NWV), lds, st, *m, a);
-  return TG_OK;
+  return check_launch("attn_tile");
 }
 // called by tg_attn_fuse (never inside a stream capture): the first launch may then happen inside one
 int attn_tile_prepare() {

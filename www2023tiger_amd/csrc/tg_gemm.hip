@@ -1481,8 +1481,8 @@ static unsigned rider_blocks(int64_t live, int threads, int64_t rows) {
 static void collate_blocks(CollateRider& c) {
   const int64_t Q = 3 * c.s.B;
   const int64_t sg = cdiv(Q, (int64_t)16), cg = cdiv(Q * (c.cr.m.d / 4), (int64_t)256);
-  c.sblocks = (unsigned)std::min<int64_t>(sg, 1024);
-  c.cr.blocks = (unsigned)std::min<int64_t>(cdiv(cg, (int64_t)4), 512);
+  c.sblocks = (c.parts == 2) ? 0u : (unsigned)std::min<int64_t>(sg, 1024);
+  c.cr.blocks = (c.parts == 1) ? 0u : (unsigned)std::min<int64_t>(cdiv(cg, (int64_t)4), 512);
   c.blocks = (c.sblocks + c.cr.blocks + 7u) & ~7u;
   c.last = 1u;
 }

@@ -22,12 +22,16 @@ void set_hip_error(hipError_t e, const char* what) {
 namespace tg {
 __device__ float4 g_zero16_store = {0.f, 0.f, 0.f, 0.f};
 const float* zero_line() {
-  static const float* p = nullptr;
-  if (!p) {
-    void* a = nullptr;
-    if (hipGetSymbolAddress(&a, HIP_SYMBOL(g_zero16_store)) == hipSuccess) p = (const float*)a;
-  }
-  return p;
+  // a device symbol has one address PER DEVICE: cached per device (a process may drive several GPUs)
+  constexpr int MAXD = 64;
+  static const float* cache[MAXD] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXD) dev = -1;
+  if (dev >= 0 && cache[dev]) return cache[dev];
+  void* a = nullptr;
+  if (hipGetSymbolAddress(&a, HIP_SYMBOL(g_zero16_store)) != hipSuccess) return nullptr;
+  if (dev >= 0) cache[dev] = (const float*)a;
+  return (const float*)a;
 }
 }  // namespace tg
 

@@ -522,7 +522,8 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
                               const int64_t* l1_nids, const int64_t* l1_eids, const float* l1_ts, const float* reprs,
                               const uint64_t* bm, const uint32_t* rank, float* out, const AttnWs& w, hipStream_t st,
                               tg_profiler* pf, const PosArgs* pos, const DirectArgs* da, bool centres_done,
-                              const float* key_rows, bool use_gtab, const WbRider* wbr, bool* wb_rode, GruSplit* gs) {
+                              const float* key_rows, bool use_gtab, const WbRider* wbr, bool* wb_rode, GruSplit* gs,
+                              const CollateRider* sampler, bool* sampler_rode) {
   // stage numbering of the profiler is kept: q -> "merged q+g", g -> skipped, v/out -> skipped, fc1 -> fused
   int stage = ST_ATTN_FIRST + 1;
   const int d = m->d;
@@ -614,8 +615,18 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
     if (!tail_rode && (rc = gru_tail_launch(gs->tail, st)) != TG_OK) return rc;
     gs->done = true;
     rode = true;
-  } else if (wb_on_fc1) {  // ... or rode on fc1's already
-    if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  } else if (wb_on_fc1) {  // ... or rode on fc1's already: this launch is free to host the NEXT batch's sampler (collate
+    // prefetch; the stream offset has been advanced on fc1's launch, nothing from here on reads this batch's query arrays
+    // or neighbour lists)
+    bool srode = false;
+    if (sampler && !ext) {
+      CollateRider cs = *sampler;
+      cs.parts = 1u;
+      if ((rc = gemm_launch(g, st, nullptr, &srode, &cs)) != TG_OK) return rc;
+    } else if ((rc = gemm_launch(g, st)) != TG_OK) {
+      return rc;
+    }
+    if (sampler_rode) *sampler_rode = srode;
     rode = true;
   } else if ((rc = gemm_launch(g, st, wbr, &rode)) != TG_OK) {
     return rc;
@@ -629,8 +640,10 @@ int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float*
                  const uint32_t* rank, float* out, const AttnWs& w, hipStream_t st, tg_profiler* pf = nullptr,
                  const DropCfg* drop = nullptr, const PosArgs* pos = nullptr, const DirectArgs* da = nullptr,
                  const float* key_rows = nullptr, bool centres_done = false, bool use_gtab = false,
-                 const WbRider* wbr = nullptr, bool* wb_rode = nullptr, GruSplit* gs = nullptr) {
+                 const WbRider* wbr = nullptr, bool* wb_rode = nullptr, GruSplit* gs = nullptr,
+                 const CollateRider* sampler = nullptr, bool* sampler_rode = nullptr) {
   if (wb_rode) *wb_rode = false;
+  if (sampler_rode) *sampler_rode = false;
   if (gs) gs->done = false;
   const DropCfg dc = drop ? *drop : DropCfg{};
   int stage = ST_ATTN_FIRST;
@@ -638,7 +651,7 @@ int attn_forward(const tg_model* m, int64_t Q, const int64_t* nids, const float*
   const int d = m->d, d_e = m->d_e, kvw = 2 * d + d_e, nh = m->n_head, dh = 2 * d / nh, E = 2 * d;
   if (m->attn_fused && dc.p == 0.f)  // (the pre-multiplied weights do not care where the node part of a key row comes from)
     return attn_forward_fused(m, Q, nids, ts, l1_nids, l1_eids, l1_ts, reprs, bm, rank, out, w, st, pf, pos, da, centres_done,
-                              key_rows, use_gtab && m->g_table && !key_rows, wbr, wb_rode, gs);
+                              key_rows, use_gtab && m->g_table && !key_rows, wbr, wb_rode, gs, sampler, sampler_rode);
   const int qblocks = (int)cdiv(2 * d, 4);
   if (da) {  // the constant half of the query projection from the rank-form kernel (no centre rows), then the direct centres
     hipLaunchKernelGGL(k_attn_centres, dim3(1 + qblocks), dim3(256), 0, st, (int64_t)0, d / 4, nids, (const float4*)reprs, bm,
@@ -1406,9 +1419,22 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
       }
     }
   }
+  // collate prefetch: TG_PREFETCH_SPLIT=1 lets the sampler half of the NEXT batch's collate share fc2's launch (it reads the
+  // graph and the stream only) and leaves the centres on the step's last launch.  Parity-green, measured SLOWER at C2 (87.2
+  // against 85.2 us per step on the same box: fc2's launch grows by more than the last launch gives back); default 0
+  static const int pfs_knob = getenv("TG_PREFETCH_SPLIT") ? atoi(getenv("TG_PREFETCH_SPLIT")) : 0;
+  CollateRider co_s{};
+  if (w.prefetch && pfs_knob != 0 && !gsplit) {
+    co_s.s = SampleBatchArgs{*g, io->B, io->src, io->dst, io->neg, io->ts, io->eids, (const int64_t*)io->offset_dev,
+                             (int)m->n_neighbors, w.nids3, w.ts3f, w.eids, w.l1n, w.l1e, w.l1t, nullptr, nullptr};
+    co_s.cr = CentresRider{*m, (const float4*)m->nfeats, nullptr, DirectArgs{}, PosArgs{}, 0u};
+    co_s.stream_len = io->stream_len;
+  }
+  w.sampler_rode = false;
   if ((rc = attn_forward(m, Q, w.nids3, w.ts3f, w.l1n, w.l1e, w.l1t, w.reprs, w.bm, w.rank, io->h, w.attn, st, pf,
                          drop, pp, w.direct ? &da : nullptr, key_rows, w.lean && io->strategy == 0 && !lz, w.gtab,
-                         want_rider ? &wbr : w.ext_rider, &w.wb_rode, gsplit ? &gs : nullptr)) != TG_OK)
+                         want_rider ? &wbr : w.ext_rider, &w.wb_rode, gsplit ? &gs : nullptr,
+                         (w.prefetch && pfs_knob != 0 && !gsplit) ? &co_s : nullptr, &w.sampler_rode)) != TG_OK)
     return rc;
   w.upd_done = gs.done;
   w.tail_pending = gsplit && gs.variant == 2 && gs.gi_done;
@@ -1483,8 +1509,8 @@ int step_writeback_a(const tg_model* m, const tg_step_io* io, StepWs& w, hipStre
 __global__ void __launch_bounds__(256) k_collate(CollateRider co) { co.run(blockIdx.x); }
 static void collate_blocks_standalone(CollateRider& c) {
   const int64_t Q = 3 * c.s.B;
-  c.sblocks = flat_grid(Q, 16);
-  c.cr.blocks = flat_grid(Q * (c.cr.m.d / 4), 256);
+  c.sblocks = c.parts == 2 ? 0u : flat_grid(Q, 16);
+  c.cr.blocks = c.parts == 1 ? 0u : flat_grid(Q * (c.cr.m.d / 4), 256);
   c.blocks = c.sblocks + c.cr.blocks;
 }
 
@@ -1520,6 +1546,7 @@ int step_writeback_b(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, 
       co.cr = CentresRider{*m, (const float4*)m->nfeats, m->c_table ? (float4*)nullptr : (float4*)w.attn.cc, w.da_args,
                            w.pos_args, 0u};
       co.stream_len = io->stream_len;
+      co.parts = w.sampler_rode ? 2u : 0u;  // (the sampler half rode on fc2's launch already)
     }
     const bool ctab = cr && m->c_table;  // ... or straight into the per-node table of centre rows
     KSlot ks_upd(KT_UPDATER);

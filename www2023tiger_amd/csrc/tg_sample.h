@@ -136,6 +136,10 @@ struct CollateRider {
   unsigned sblocks;    // the sampler's workgroups
   unsigned blocks;     // sblocks + cr.blocks rounded up to a multiple of 8 (the host launch's XCD map stays)
   unsigned last;       // riders behind the host launch's own blocks (else in front); set by the launcher
+  // which halves ride on THIS launch (0 = both): 1 = the sampler alone - it reads the graph and the stream only, so it can
+  // share an earlier launch than the centres (fc2's, once the write-back rider on fc1's launch has advanced the offset);
+  // 2 = the centres alone (the sampler rode elsewhere)
+  unsigned parts;
   __device__ __forceinline__ void run(unsigned bid) const {
     const int64_t o = *s.off;
     if (o + s.B > stream_len) return;

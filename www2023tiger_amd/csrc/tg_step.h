@@ -81,6 +81,7 @@ struct StepWs {
   float *snap_te, *gi;
   int64_t *oth, *weid;
   bool upd_done;  // the eager updater's rows of this batch were finished inside the attention block's launches
+  bool sampler_rode;  // collate prefetch: the next batch's sampler rode on fc2's launch already (its centres follow on the last)
   const WbRider* ext_rider;  // tg_part_step: the planned write-back's first launch rides on the embedding step's fc1 / fc2
   bool tail_pending;  // ... or their input-side product was (on fc2's launch): the tail is launched where the updater was
   GruTail tail;

@@ -633,8 +633,12 @@ class HipPartitionEngine:
         eff, msg = p.req_eff, p.req_msg
         if self.row_of is not None:  # the pulled nodes live in arena rows for this batch: point the translation at them
             ph = self._phys(p)
+            prev = getattr(self, '_mapped', None)
+            if prev is not None and prev.numel():  # the previous batch's arena rows hold other nodes from now on: a node that
+                self.row_of[prev] = -1             # this batch does not pull must not resolve to one of them
             if ph['req_nodes'].numel():
                 self.row_of[ph['req_nodes']] = ph['req_rows']
+            self._mapped = ph['req_nodes']
             eff, msg = ph['adopt_eff'], ph['adopt_msg']
         self.check(lib.tg_adopt_rows(C.byref(ms), p.req_eff.numel(), ptr(eff), ptr(p.reply_eff_pos), p.req_msg.numel(),
                                      ptr(msg), ptr(p.reply_msg_pos), ptr(got), self._stream()),
