@@ -166,6 +166,8 @@ def build_models(stream, d, K, msg_src, upd_src, restarter='static', hist_len=40
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32 MFMA (MI355X_MICROARCH.md)
 PREROLL = 150                 # untimed batches before --warmup (state reaches steady U / O / P after ~100 at C2)
+C5S_PREROLL = 300             # ... of the C5-shaped leg (19.7 M events: the involved set per batch has flattened out; its
+                              # sizes at the middle and the end of the pre-roll are in the leg's config)
 REFERENCE_MEASURED = ('5730 events/s @ 8 cores: the reference\'s own CPU stream (collate + contrast_learning, no_grad), '
                       'd=172 B=1024, measured by importing it in the survey container (BASELINE.md s2)')
 
@@ -244,7 +246,7 @@ def profile_stages(model, buf, steps, record=True):
     if record:  # (side passes - set sizes, the copy form's gather - do not replace the main pass's kernels)
         KERNEL_MS.clear()
         for i in range(nk):
-            if khits[i]:
+            if khits[i] and knames[i]:
                 KERNEL_MS[lib.tg_profiler_kernel_slot_name(i).decode()] = (kacc[i] / khits[i], norm_kernel(knames[i].decode()))
     buf.attach_profiler(None)
     lib.tg_profiler_destroy(prof)
@@ -891,7 +893,7 @@ def main():
         from www2023tiger_amd import dist as tdist
         return tdist.bench_main(args, cfg, make_stream, build_models, rank, local_rank, world)
 
-    preroll = args.preroll if args.preroll is not None else (96 if args.workload in ('c5s', 'c5') else PREROLL)
+    preroll = args.preroll if args.preroll is not None else (C5S_PREROLL if args.workload in ('c5s', 'c5') else PREROLL)
     n_prof = max(4, min(args.steps, 30 if cfg['B'] <= 8192 else 6))
     leg = run_stream_leg(cfg, args, preroll, args.warmup, args.steps, n_prof, traffic_tag=args.workload,
                          want_cpu=not args.no_cpu_baseline and args.workload == 'c2')
@@ -904,8 +906,8 @@ def main():
         # at C2 every table is cache resident (150 MB): the HBM-roofline claim for the memory-gather kernel is made
         # on the C5-shaped tables (10 M nodes, d=256, B=65536: 70 GB of state), 100 untimed batches (6.5 M events) and 30 timed steps; the involved set still grows slowly
         # there (its sizes before and after the timed region are in the line)
-        c5 = run_stream_leg(dict(WORKLOADS['c5s']), args, 96, 4, 30, 4, traffic_tag='c5s')
-        out['c5s_leg'] = dict(value=c5['value'], unit='events/s', ms_per_step=c5['ms_per_step'], steps=30, warmup=100,
+        c5 = run_stream_leg(dict(WORKLOADS['c5s']), args, C5S_PREROLL, 4, 30, 4, traffic_tag='c5s')
+        out['c5s_leg'] = dict(value=c5['value'], unit='events/s', ms_per_step=c5['ms_per_step'], steps=30, warmup=C5S_PREROLL + 4,
                               config=c5['config'], roofline_memory_gather=c5['roofline_memory_gather'],
                               roofline_updater=c5['roofline_updater'],
                               roofline_neighbour_gather=c5['roofline_neighbour_gather'], stages_ms=c5['stages_ms'])
