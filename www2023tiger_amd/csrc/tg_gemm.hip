@@ -1882,7 +1882,7 @@ __device__ __forceinline__ void gru_tail16(const GruArgs& g, int tb, int j0, flo
 __device__ unsigned long long g_gru_trace[2048 * 4];
 
 template <int NW, int KS>
-__global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
+__global__ void __launch_bounds__(64 * NW * KS, (NW == 4 && KS == 1) ? 2 : 1) k_gru(GruArgs g) {
   // NW wavefronts stack 32-row MFMA tiles (BM = 32 NW rows per block); with KS = 2 a second
   // group of NW wavefronts takes the other half of every tile's k-steps into its own
   // accumulators (summed through LDS at the end), which puts two independent instruction
@@ -1914,8 +1914,13 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
   // epilogue operands staged while the loop runs (no global load is left for the epilogue, where its
   // latency would be exposed): the old-memory tile h[m, j0..j0+32) is one of the A tiles the loop
   // streams anyway, the output rows are fetched at block start
-  constexpr int HS_FLOATS = TAIL && T16_ROWS * 17 > BM * LDK ? T16_ROWS * 17 : BM * LDK;
+  // (128-row blocks: a lane captures the old-memory values of ITS accumulator rows in registers when that tile passes -
+  // 17 KB of LDS less, which is what lets two k_gru<4, 1> blocks share a CU)
+  constexpr bool HREG = NW == 4;
+  constexpr int NHOLD = KS == 1 ? 16 : OWN;
+  constexpr int HS_FLOATS = HREG ? 4 : TAIL && T16_ROWS * 17 > BM * LDK ? T16_ROWS * 17 : BM * LDK;
   __shared__ float hs_raw[HS_FLOATS];
+  float hold_r[HREG ? NHOLD : 1];
   __shared__ int orow_s[TAIL ? T16_ROWS : BM];
   float (*Hs)[LDK] = reinterpret_cast<float (*)[LDK]>(hs_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2063,7 +2068,15 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
       cur = nxt;
     }
     if (HP && t == nkx + nt) {  // this A tile is h[m0.., j0..j0+32): keep it for the epilogue
-      for (int f = tid; f < BM * 32; f += THREADS) Hs[f >> 5][f & 31] = As[buf][f >> 5][f & 31];
+      if constexpr (HREG) {
+#pragma unroll
+        for (int q = 0; q < NHOLD; ++q) {
+          const int r = KS == 1 ? q : ks * OWN + q;
+          hold_r[q] = As[buf][rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk][fr];
+        }
+      } else {
+        for (int f = tid; f < BM * 32; f += THREADS) Hs[f >> 5][f & 31] = As[buf][f >> 5][f & 31];
+      }
     }
     __syncthreads();
   };
@@ -2106,10 +2119,10 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
   const unsigned long long t_loop1 = (dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
   const int j = min(j0 + fr, d - 1);
   const bool jok = j0 + fr < d;
-  auto finish = [&](int r, float ar_, float az_, float ain_, float ahn_) {  // gates + blend of accumulator row r
+  auto finish = [&](int r, int hq, float ar_, float az_, float ain_, float ahn_) {  // gates + blend of accumulator row r (hq: its slot in hold_r)
     const int lr = rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
     const int64_t m = m0 + lr;
-    const float hold = Hs[lr][fr];
+    const float hold = HREG ? hold_r[HREG ? hq : 0] : Hs[lr][fr];
     const int64_t orow = orow_s[lr];
     const float rg = fast_sigmoid(ar_ + br);
     const float zg = fast_sigmoid(az_ + bz);
@@ -2179,7 +2192,7 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
       }
     }
 #pragma unroll
-    for (int q = 0; q < OWN; ++q) finish(ks * OWN + q, o_r[q], o_z[q], o_in[q], o_hn[q]);
+    for (int q = 0; q < OWN; ++q) finish(ks * OWN + q, q, o_r[q], o_z[q], o_in[q], o_hn[q]);
   } else {
   // fold the k-groups' partial sums into group 0, halving the number of live groups per round: groups
   // [half, 2 half) write, groups [0, half) add (the last tile's barrier has retired every read of the tiles)
@@ -2208,7 +2221,7 @@ __global__ void __launch_bounds__(64 * NW * KS) k_gru(GruArgs g) {
   }
   if (ks == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) finish(r, acc_r[r], acc_z[r], acc_in[r], acc_hn[r]);
+    for (int r = 0; r < 16; ++r) finish(r, r, acc_r[r], acc_z[r], acc_in[r], acc_hn[r]);
   }
   }
   if ((dbg & 16) && tid == 0 && blockIdx.x < 2048) {
@@ -2712,7 +2725,7 @@ int gru_launch(const GruArgs& g, hipStream_t st) {
   const int NT = (g.d + 31) / 32;
   // small problems (at most ~64k live rows): 64-row blocks double the block count so that two
   // blocks share a CU and cover each other's stalls; large ones keep 128 rows (half the weight traffic)
-  static const int ks_knob = getenv("TG_GRU_KS") ? atoi(getenv("TG_GRU_KS")) : 2;  // tuning knob
+  static const int ks_knob = getenv("TG_GRU_KS") ? atoi(getenv("TG_GRU_KS")) : 0;  // tuning knob: 0 = by the grid (below)
   // 96-row blocks (four k-groups of three row waves: 12 wavefronts, three per SIMD) with the partial column tile
   // as 16-column blocks: a quarter less work per block and no padded columns, which pays exactly when the whole
   // launch fits the chip in ONE round - every CU runs at most one block, so the duration is one block's duration
@@ -2776,8 +2789,15 @@ int gru_launch(const GruArgs& g, hipStream_t st) {
     TG_KLAUNCH((k_gru<3, 4>), dim3((unsigned)(8 * per_xcd)), dim3(768), 0, st, a);
     return check_launch("gru(96)");
   }
+  // 128-row blocks.  More blocks than CUs: four wavefronts per block and TWO blocks per CU (k_gru<4, 1>: 58 KB of LDS - the
+  // old-memory tile of the epilogue lives in registers - and at most 256 registers), so that one block's prologue (first
+  // tiles exposed) and epilogue (gates, scattered stores) run under the other's k-loop, and there is no k-group fold.
+  // Measured against the eight-wavefront blocks (k_gru<4, 2>, one per CU), rows x message width -> d:
+  // 65 536 x 1 024 -> 256 1 200 -> 1 073 us (120 TF/s); 49 152 x 688 -> 172 485 -> 435 us; 8 192 x 1 024 -> 256 152 -> 140 us;
+  // a launch of at most one block per CU keeps the eight wavefronts (4 096 x 1 024 -> 256: 77 against 81 us).
   const int64_t grid = 8 * cdiv(cdiv(g.cap, 128), 8) * NT;
-  if (ks_knob == 2)
+  const int64_t live = g.rows_hint > 0 ? cdiv(std::min<int64_t>(g.rows_hint, g.cap), 128) * NT : grid;
+  if (ks_knob == 2 || (ks_knob == 0 && live <= 256))
     TG_KLAUNCH((k_gru<4, 2>), dim3((unsigned)grid), dim3(512), 0, st, a);
   else
     TG_KLAUNCH((k_gru<4, 1>), dim3((unsigned)grid), dim3(256), 0, st, a);
