@@ -205,3 +205,96 @@ def test_deferred_invariant_check_still_raises():
     model.reset()
     ap, auc = eval_edge_prediction(model, dl, dev(), restart_mode=False)  # clean again after a reset
     assert np.isfinite(ap) and np.isfinite(auc)
+
+
+@pytest.mark.parametrize('eval_split', [True, False])
+def test_resident_eval_equals_the_per_batch_loop(eval_split, monkeypatch):
+    """eval_edge_prediction over a BatchLoader takes the resident-stream form (columns uploaded once, one call per
+    batch at a device-side offset, scores left in place).  With the model's own forms (TG_EVAL_STREAM=0) AP / AUC and
+    the memories after the pass equal the literal per-batch loop's bit for bit; by default the pass streams with eager
+    updates and pre-multiplied weights (put back afterwards), which agrees to float32 rounding.  Full batches plus a
+    ragged tail, an evaluation split (fixed negatives) and a training split (negatives drawn from the sampler's
+    RandomState stream, on the device)."""
+    from www2023tiger_amd import eval_utils
+    from www2023tiger_amd.data.data_loader import BatchLoader, InteractionData
+    z = load('eval_static_ll_d16')
+    cfg = parse_cfg(z)
+    model, _, coll = build_hip_model(z, cfg, dropout=0.0)
+    B = cfg['B']
+    n = 3 * B + B // 3
+    mk = lambda: BatchLoader(InteractionData(z['src'][:n], z['dst'][:n], z['ts'][:n], z['eids'][:n], np.zeros(n, dtype=np.int64),
+                                             seed=5, eval=eval_split), B, coll)
+    taken = []
+    real = eval_utils._eval_resident
+    monkeypatch.setattr(eval_utils, '_eval_resident', lambda *a: (taken.append(1), real(*a))[1])
+    out = {}
+    for form, env in (('loop', dict(TG_EVAL_RESIDENT='0')), ('resident', dict(TG_EVAL_RESIDENT='1', TG_EVAL_STREAM='0')),
+                      ('stream', dict(TG_EVAL_RESIDENT='1', TG_EVAL_STREAM='1'))):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        model.reset()
+        res = eval_utils.eval_edge_prediction(model, mk(), dev(), restart_mode=False, mean_over_n_samples=cfg['chunk'])
+        assert model._pending is None and model._fused is None  # the switches of the streaming form are put back
+        out[form] = (res, model.left_memory.vals.clone(), model.right_memory.vals.clone(), model.left_memory.update_ts.clone(),
+                     model.msg_store.node_msg_vals.clone())
+    assert len(taken) == 2
+    assert out['loop'][0] == out['resident'][0]
+    for a, b in zip(out['loop'][1:], out['resident'][1:]):
+        assert torch.equal(a, b)
+    assert abs(out['loop'][0][0] - out['stream'][0][0]) < 2e-4 and abs(out['loop'][0][1] - out['stream'][0][1]) < 2e-4
+    assert torch.equal(out['loop'][3], out['stream'][3])
+    for a, b in zip(out['loop'][1:], out['stream'][1:]):
+        assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
+
+
+def test_eval_loop_on_a_model_that_streams_with_eager_updates():
+    """contrast_learning under no_grad on a model with eager_updates() + fuse_attention(): the one-call evaluation
+    step takes the streaming step's eager forward and keeps the per-node tables current (no rebuild per batch); scores
+    and state agree with the lazy, unfused model, and a streaming step afterwards finds consistent tables."""
+    from www2023tiger_amd.data.data_loader import BatchLoader, InteractionData
+    z = load('eval_static_ll_d16')
+    cfg = parse_cfg(z)
+    B = cfg['B']
+    n = 4 * B
+    outs = []
+    for eager in (False, True):
+        model, _, coll = build_hip_model(z, cfg, dropout=0.0)
+        model.eval()
+        if eager:
+            model.eager_updates(True).fuse_attention(True)
+        model.reset()
+        dl = BatchLoader(InteractionData(z['src'][:n], z['dst'][:n], z['ts'][:n], z['eids'][:n], np.zeros(n, dtype=np.int64),
+                                         seed=0, eval=True), B, coll)
+        sc = []
+        for k, (s, d_, ng, t, e, _, cg) in enumerate(dl):
+            if k == 3:  # the last batch as a plain streaming step: reads the tables the evaluation steps kept
+                buf = model.stream_step(s, d_, ng, cg.ts64, e)
+                sc.append(buf.h.clone())
+            else:
+                out = model.contrast_learning(s, d_, ng, t, e, cg)
+                sc.append(torch.cat([out[2], out[3]]))
+        model._poll_train_errors()
+        outs.append((sc, model.left_memory.vals.clone(), model.right_memory.vals.clone()))
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
+
+
+def test_resident_eval_raises_the_invariant_errors():
+    from www2023tiger_amd.data.data_loader import BatchLoader, InteractionData
+    from www2023tiger_amd.eval_utils import eval_edge_prediction
+    z = load('eval_static_ll_d16')
+    cfg = parse_cfg(z)
+    model, _, coll = build_hip_model(z, cfg, dropout=0.0)
+    B = cfg['B']
+    n = 2 * B
+    dl = BatchLoader(InteractionData(z['src'][:n], z['dst'][:n], z['ts'][:n], z['eids'][:n], np.zeros(n, dtype=np.int64), seed=0,
+                                     eval=True), B, coll)
+    model.reset()
+    eval_edge_prediction(model, dl, dev(), restart_mode=False)
+    with pytest.raises(ValueError):  # the same batches again: events older than what the memories have seen
+        eval_edge_prediction(model, dl, dev(), restart_mode=False)
+    model.reset()
+    ap, auc = eval_edge_prediction(model, dl, dev(), restart_mode=False)
+    assert np.isfinite(ap) and np.isfinite(auc)

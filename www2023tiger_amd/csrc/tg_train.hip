@@ -1080,7 +1080,10 @@ extern "C" int tg_train_step(const tg_model* m_in, const tg_tcsr* g, const tg_tr
   if (!carve_step(m, sio->B, cv, w, n_layers) || !carve_train(m, io->score, sio->B, cv, t, n_layers)) return TG_EWORKSPACE;
   int rc;
   if (eval_only) {
-    if ((rc = step_forward(m, g, sio, w, nullptr, st, nullptr, nullptr)) != TG_OK) return rc;
+    // a model that streams with eager updates (tg_model.pending_vals): the evaluation step is the streaming step's
+    // forward in whatever form tg_stream_step would take for this io (table-backed, lean, riders ...) + STEP 7
+    const bool eager = m->pending_vals != nullptr;
+    if ((rc = step_forward(m, g, sio, w, nullptr, st, nullptr, nullptr, eager)) != TG_OK) return rc;
     if ((rc = score_forward(m, g, io, w, t, st)) != TG_OK) return rc;
     if ((rc = step_writeback_a(m, sio, w, st, nullptr)) != TG_OK) return rc;
     return step_writeback_b(m, g, sio, w, st, nullptr);

@@ -5,9 +5,11 @@ device path as in training; scores stay on the GPU until the end, where AP / AUC
 Node classification and trajectory encoding (eval_utils.py:71-99,132-183) are downstream tasks
 outside the scope table."""
 import math
+import os
 import warnings
 from typing import Optional
 
+import numpy as np
 import torch
 
 from ._lib import check, lib, ptr
@@ -38,12 +40,121 @@ def _lazy_restart(model, comp_graph, ts, uptodate_nodes: set, device):
     uptodate_nodes.update(restart_nodes)
 
 
+def _resident_plan(model, dl, restart_mode: bool):
+    """Can the loop below run as a resident stream?  It can when `dl` is this package's BatchLoader over an
+    InteractionData (batches are contiguous index ranges in order, negatives a deterministic stream), the batches
+    would take the one-call evaluation step anyway (TIGE._fused_eval_ok, a collator graph whose strategy the step
+    samples itself) and no lazy restart runs between them (eval_utils.py:37-42 needs the host-side node sets).
+    TG_EVAL_RESIDENT=0 switches the form off (the per-batch loop is what the reference's harness does literally)."""
+    from .data.data_loader import BatchLoader, GraphCollator, InteractionData
+    if restart_mode or os.environ.get('TG_EVAL_RESIDENT', '1') == '0':
+        return None
+    if type(dl) is not BatchLoader or not isinstance(dl.dataset, InteractionData) or type(dl.collate_fn) is not GraphCollator:
+        return None
+    graph = dl.collate_fn.graph
+    if getattr(graph, 'strategy', None) not in ('recent_edges', 'recent_nodes') or graph.device.type != 'cuda':
+        return None
+    if not hasattr(model, '_fused_eval_ok') or not model._fused_eval_ok(graph) or model.device != graph.device:
+        return None
+    if dl.collate_fn.n_neighbors != model.n_neighbors or dl.collate_fn.n_layers != model.n_layers:
+        return None
+    lo, hi = dl._range()
+    return (lo, hi, graph) if hi > lo and dl.batch_size > 0 else None
+
+
+def _eval_resident(model, dl, plan, mean_over_n_samples: int):
+    """eval_edge_prediction's loop (eval_utils.py:29-57) over a RESIDENT stream: the loader's event columns and
+    negatives are uploaded once, every batch is one `tg_train_step` call without gradient buffers - the very call
+    `contrast_learning` makes per batch under no_grad - that reads its rows at a device-side offset and leaves its
+    scores in place in the [N] score columns; nothing else runs on the host per batch (no collation objects, no
+    per-column transfers, no per-batch clones / sigmoid / invariant read-back).  With the model's own forms
+    (TG_EVAL_STREAM=0) these are the same kernels on the same inputs in the same order as the per-batch loop: scores
+    equal bit for bit; by default the pass also streams with eager updates and pre-multiplied weights (below), equal
+    to float32 rounding (tests/test_hip_eval.py: test_resident_eval_equals_the_per_batch_loop)."""
+    from .model.training import TrainBuffers
+    lo, hi, graph = plan
+    ds, bs, dev = dl.dataset, dl.batch_size, model.device
+    N = hi - lo
+    # Parameters are fixed for the whole pass: stream it as INTEGRATION.md's inference recipe does - eager updates and
+    # pre-multiplied attention weights (TIGE.eager_updates / fuse_attention: same results as the lazy, unfused forms to
+    # float32 rounding) - unless the per-node tables they bring would be large (TG_EVAL_TABLE_BYTES, default 8 GiB:
+    # pending rows, query rows, centre rows = n_nodes (2 d + n_head (2 d + d_e)) floats); both switches are put back.
+    had = (model._pending is not None, model._fused is not None)
+    d, de = model.memory_dim, (model.efeat_dim if model.raw_feat_getter.efeats is not None else 0)
+    need = 4 * model.msg_store.n * (2 * d + model.n_head * (2 * d + de))
+    budget = int(os.environ.get('TG_EVAL_TABLE_BYTES', str(8 << 30)))
+    stream_form = all(had) or (os.environ.get('TG_EVAL_STREAM', '1') != '0' and need <= budget
+                               and need <= torch.cuda.mem_get_info(dev)[0] // 2)
+    try:
+        if stream_form and not all(had):
+            if not had[0]:
+                model.eager_updates(True)
+            if not had[1]:
+                model.fuse_attention(True)
+        return _eval_resident_run(model, ds, bs, dev, N, lo, hi, graph, TrainBuffers, lean=stream_form)
+    finally:
+        if stream_form and not all(had):
+            if not had[0]:
+                model.eager_updates(False)
+            if not had[1]:
+                model.fuse_attention(False)
+
+
+def _eval_resident_run(model, ds, bs, dev, N, lo, hi, graph, TrainBuffers, lean):
+    c = getattr(ds, '_dev', None)
+    if c is not None and c['device'] == dev:
+        src, dst, ts64, eids = (c[k][lo:hi] for k in ('src', 'dst', 'ts', 'eids'))
+        neg = c['neg'][lo:hi] if ds.eval else None
+    else:
+        i64 = lambda a: torch.from_numpy(np.ascontiguousarray(a[lo:hi], dtype=np.int64)).to(dev)
+        src, dst, eids = i64(ds.src), i64(ds.dst), i64(ds.eids)
+        ts64 = torch.from_numpy(np.ascontiguousarray(ds.ts[lo:hi], dtype=np.float64)).to(dev)
+        neg = i64(ds.neg_dst) if ds.eval else None
+    if neg is None:  # a training split: the N draws the per-event __getitem__ calls would make, on the device
+        neg = ds.neg_dst_sampler.sample_pairs_device(N, dev)[1]
+    resident = tuple(t.contiguous() for t in (src, dst, neg, ts64, eids))
+    pos_all = torch.empty(N, dtype=torch.float32, device=dev)
+    neg_all = torch.empty(N, dtype=torch.float32, device=dev)
+    n_full, rem = divmod(N, bs)
+    bufs = []
+    for B, first, count in ((bs, 0, n_full), (rem, n_full * bs, 1 if rem else 0)):
+        if not count:
+            continue
+        tb = TrainBuffers(model, B, resident=resident, eval_only=True, want_prev=not lean, lean=lean)
+        tb.sb.offset.fill_(first)
+        tb.err_host = None  # one read-back at the end (below)
+        bufs.append(tb)
+        p0, n0 = pos_all.data_ptr() + 4 * first, neg_all.data_ptr() + 4 * first
+        for k in range(count):
+            tb.io.pos_scores, tb.io.neg_scores = p0 + 4 * k * B, n0 + 4 * k * B
+            tb.launch(graph=graph)
+            if k == 0 and count > 8:  # one early read-back: the updater's launches are sized by the counts seen so far
+                cnt = tb.sb.counts.tolist()
+                model.note_rows(cnt[1], cnt[2])
+    words = [(int(tb.sb.err.item()), tb.sb.counts.tolist()) for tb in bufs]  # (also drains the stream)
+    for word, cnt in words:
+        model.note_rows(cnt[1], cnt[2])
+        if word:
+            from ._lib import raise_invariants
+            raise_invariants(word & 0xFFFFFFFF)
+    return pos_all.sigmoid_(), neg_all.sigmoid_()
+
+
 def eval_edge_prediction(model, dl, device: torch.device, restart_mode: bool, uptodate_nodes: Optional[set] = None,
                          mean_over_n_samples: int = 200):
     """-> (mean AP, mean AUC) over windows of `mean_over_n_samples` events.  `uptodate_nodes` is
     updated in place when given (as in the reference)."""
     model.eval()
     uptodate_nodes = set() if uptodate_nodes is None else uptodate_nodes
+    plan = _resident_plan(model, dl, restart_mode)
+    if plan is not None:
+        with torch.no_grad():
+            model._poll_train_errors()
+            pos_pred, neg_pred = _eval_resident(model, dl, plan, mean_over_n_samples)
+        ap, auc, bad = ap_auc_windows(pos_pred, neg_pred, mean_over_n_samples)
+        if int(bad.item()):
+            warnings.warn(f'Encounter invalid values: {int(bad.item())} non-finite predictions were dropped')
+        return float(ap.mean().item()), float(auc.mean().item())
     pos_all, neg_all = [], []
     with torch.no_grad():
         for src_ids, dst_ids, neg_dst_ids, ts, eids, _, comp_graph in BackgroundThreadGenerator(dl):

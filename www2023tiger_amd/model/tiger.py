@@ -554,7 +554,6 @@ class TIGE(nn.Module):
         gradient buffers).  The computation graph only contributes the float64 event times: the step
         samples the same neighbourhoods itself."""
         from .training import TrainBuffers
-        self._touch()
         dev = self.device
         B = len(src_ids)
         key = ('eval', B)

@@ -179,16 +179,22 @@ class TrainBuffers:
     """Static buffers of one batch size for tg_train_step: the step's inputs/outputs
     (a TIGE.StepBuffers), flat gradient storage with one view per parameter, losses, scores."""
 
-    def __init__(self, model, B: int, resident=None, mutual: bool = False, eval_only: bool = False):
+    def __init__(self, model, B: int, resident=None, mutual: bool = False, eval_only: bool = False,
+                 want_prev: bool = True, lean: bool = False):
         """mutual=True adds the restarter's mutual-learning loss (tiger.py:574-590) and its
         gradients; False is the reference's contrast_only (restart_prob == 0).
         eval_only=True: no gradient storage; the step computes embeddings, scores, loss and the
-        write-back (the forward of tiger/eval_utils.py:29-48)."""
+        write-back (the forward of tiger/eval_utils.py:29-48).
+        want_prev=False / lean=True (evaluation only): no h_prev_left / h_prev_right outputs, no involved set - what an
+        evaluation loop that only reads the scores needs; on a model that streams with eager updates and pre-multiplied
+        weights the forward then takes the table-backed lean form of the streaming step (TIGE.StepBuffers)."""
+        if (not want_prev or lean) and not eval_only:
+            raise ValueError('a training step hands h_prev_left / h_prev_right to the restarter: want_prev / lean are evaluation-only')
         check_trainable(model)
         model._refuse_partitioned('tg_train_step')
         dev = model.device
         self.model, self.B, self.mutual, self.eval_only = model, B, mutual and not eval_only, eval_only
-        self.sb = model.StepBuffers(model, B, want_prev=True, resident=resident)
+        self.sb = model.StepBuffers(model, B, want_prev=want_prev, resident=resident, lean=lean)
         self.params = [] if eval_only else (contrast_parameters(model) + (restarter_parameters(model) if mutual else []))
         n = sum(p.numel() for _, p, _ in self.params)
         self.gflat = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -278,7 +284,17 @@ class TrainBuffers:
         self.io.step.strategy = {'recent_edges': 0, 'recent_nodes': 1, 'uniform': 2}[strategy]
         self.io.step.mt_state = ptr(graph._mt_state()) if strategy == 'uniform' else None
         model.check_graph(graph)
-        model._touch()  # state changes outside the eager streaming step
+        if self.eval_only and model._pending is not None:
+            # a model that streams with eager updates: the evaluation step IS the streaming step (+ STEP 7) and keeps the
+            # per-node tables current itself - same protocol as TIGE.launch_step (tables synchronised before, no touch)
+            if model._fused is not None and model._fused_stamp != model._attn_stamp():
+                model.fuse_attention()
+            model._sync_pending()
+            model._sync_gtab()
+            m = model.model_struct()
+            model._step_serial = getattr(model, '_step_serial', 0) + 1
+        else:
+            model._touch()  # state changes outside the eager streaming step
         g = graph.tcsr
         check(lib.tg_train_step(C.byref(m), C.byref(g), C.byref(self.io), ptr(self.ws), self.ws.numel(),
                                 stream_ptr(model.device)), 'tg_train_step')
