@@ -221,7 +221,7 @@ def test_resident_eval_equals_the_per_batch_loop(eval_split, monkeypatch):
     cfg = parse_cfg(z)
     model, _, coll = build_hip_model(z, cfg, dropout=0.0)
     B = cfg['B']
-    n = 3 * B + B // 3
+    n = 12 * B + B // 3
     mk = lambda: BatchLoader(InteractionData(z['src'][:n], z['dst'][:n], z['ts'][:n], z['eids'][:n], np.zeros(n, dtype=np.int64),
                                              seed=5, eval=eval_split), B, coll)
     taken = []

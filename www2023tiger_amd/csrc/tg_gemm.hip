@@ -1340,7 +1340,11 @@ bool gemm_ks16_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, b
   const int ct = g.n <= 64 ? 4 : g.n <= 112 ? 7 : 3;
   // (measured, N = 100: 24 576 x 500 42.2 -> 39.6 us, 6 144 x 500 17.7 -> 13.3 us, 600 x 500 16.6 -> 9.2 us; 3 072 x 400 -> 64
   // 14.5 -> 6.4 us; at K = 300 the 64 x 64 blocks are faster: 27.9 against 30.9 us)
-  if (g.k < (ct == 3 ? 512 : 384)) return false;
+  // (a launch of at most one 48 x 48 block per CU pays from K = 320: the score head's product, 2 B x 2 d -> d, at d = 172
+  // 2 048 rows 13.3 -> 6.8 us, 400 rows 12.9 -> 4.9 us against the 64 x 64 LDS blocks; 4 096 rows and more: no gain)
+  static const int mink_knob = getenv("TG_GEMM_KS16_MINK") ? atoi(getenv("TG_GEMM_KS16_MINK")) : 0;  // tuning knob
+  const bool one_round = ct == 3 && cdiv(g.m_cap, 48) * cdiv(g.n, 48) <= 256;
+  if (g.k < (mink_knob ? mink_knob : (ct == 3 ? (one_round ? 320 : 512) : 384))) return false;
   const int64_t ntc = cdiv(g.n, 16 * ct);
   static const int64_t max_tiles = getenv("TG_GEMM_KS16_TILES") ? atoi(getenv("TG_GEMM_KS16_TILES")) : 1100;  // tuning knob (measured, K = 1 204, N = 172: 6 144 rows 54.5 -> 37.1 us, 12 288 rows 78.2 -> 72.1 us, 24 576 rows 123 -> 129 us)
   if (cdiv(g.m_cap, ct == 3 ? 48 : 32) * ntc > max_tiles) return false;

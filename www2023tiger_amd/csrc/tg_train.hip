@@ -44,8 +44,9 @@ __global__ void __launch_bounds__(256) k_build_pairs(int64_t B, int d, int K, in
                                                      const float* __restrict__ h, const int64_t* __restrict__ nids3,
                                                      const int64_t* __restrict__ l1_nids,
                                                      const float* __restrict__ hit_emb, float* __restrict__ P,
-                                                     int32_t* __restrict__ hit_idx) {
+                                                     int32_t* __restrict__ hit_idx, float* __restrict__ zero2) {
   const int lane = lane_id();
+  if (zero2 && blockIdx.x == 0 && threadIdx.x < 2) zero2[threadIdx.x] = 0.f;  // the loss accumulators (k_score_loss adds)
   const int W = d + (hit_type == TG_HIT_VEC ? K : 0);
   for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < 2 * B; r += (int64_t)gridDim.x * 4) {
     const bool neg = r >= B;
@@ -738,16 +739,11 @@ static int score_forward(const tg_model* m, const tg_tcsr* gr, const tg_train_io
   const int64_t B = io->step.B;
   const int d = m->d, K = m->n_neighbors;
   const int W2 = 2 * score_width(m, sp);
-  hipError_t e = hipMemsetAsync(io->losses, 0, 2 * sizeof(float), st);
-  if (e != hipSuccess) {
-    set_hip_error(e, "tg_train_step memset");
-    return TG_EHIP;
-  }
   int rc;
   const int64_t* hl = hit_lists(gr, m, &io->step, w, t, st, &rc);
   if (rc != TG_OK) return rc;
   hipLaunchKernelGGL(k_build_pairs, dim3(flat_grid(2 * B, 4)), dim3(256), 0, st, B, d, K, sp->hit_type, io->step.h,
-                     w.nids3, hl, sp->hit_emb, t.P, t.hit_idx);
+                     w.nids3, hl, sp->hit_emb, t.P, t.hit_idx, io->losses);  // (zeroes the loss accumulators too)
   GemmArgs g{};
   g.m_cap = 2 * B; g.n = d; g.k = W2; g.a0 = ASeg{t.P, W2, W2, nullptr};
   g.w = sp->fc1.w; g.ldw = W2; g.bias = sp->fc1.b; g.c = t.T1; g.ldc = d; g.relu = 1; g.alpha = 1.f; g.nbatch = 1;
@@ -903,7 +899,7 @@ static int contrast_backward(const tg_model* m, const tg_tcsr* gr, const tg_trai
   const int64_t* hl = hit_lists(gr, m, &io->step, w, t, st, &rc);
   if (rc != TG_OK) return rc;
   hipLaunchKernelGGL(k_build_pairs, dim3(flat_grid(2 * B, 4)), dim3(256), 0, st, B, d, K, sp->hit_type, io->step.h,
-                     w.nids3, hl, sp->hit_emb, t.P, t.hit_idx);
+                     w.nids3, hl, sp->hit_emb, t.P, t.hit_idx, (float*)nullptr);
   GemmArgs g{};
   g.m_cap = 2 * B; g.n = d; g.k = W2; g.a0 = ASeg{t.P, W2, W2, nullptr};
   g.w = sp->fc1.w; g.ldw = W2; g.bias = sp->fc1.b; g.c = t.T1; g.ldc = d; g.relu = 1; g.alpha = 1.f; g.nbatch = 1;

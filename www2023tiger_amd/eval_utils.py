@@ -120,11 +120,14 @@ def _eval_resident_run(model, ds, bs, dev, N, lo, hi, graph, TrainBuffers, lean)
     for B, first, count in ((bs, 0, n_full), (rem, n_full * bs, 1 if rem else 0)):
         if not count:
             continue
-        tb = TrainBuffers(model, B, resident=resident, eval_only=True, want_prev=not lean, lean=lean)
+        tb = TrainBuffers(model, B, resident=resident, eval_only=True, want_prev=not lean, lean=lean,
+                          prefetch=lean and count > 1 and os.environ.get('TG_EVAL_PREFETCH', '1') != '0')
         tb.sb.offset.fill_(first)
         tb.err_host = None  # one read-back at the end (below)
         bufs.append(tb)
         p0, n0 = pos_all.data_ptr() + 4 * first, neg_all.data_ptr() + 4 * first
+        # (replaying captured hipGraphs of several steps was tried here: the pass is bound by the device's dependent launches -
+        # bs 200: 72 us per batch eager, 75 us as 16-step graphs, and a capture costs ~10 ms - so the steps are launched eagerly)
         for k in range(count):
             tb.io.pos_scores, tb.io.neg_scores = p0 + 4 * k * B, n0 + 4 * k * B
             tb.launch(graph=graph)

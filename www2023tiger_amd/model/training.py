@@ -180,21 +180,22 @@ class TrainBuffers:
     (a TIGE.StepBuffers), flat gradient storage with one view per parameter, losses, scores."""
 
     def __init__(self, model, B: int, resident=None, mutual: bool = False, eval_only: bool = False,
-                 want_prev: bool = True, lean: bool = False):
+                 want_prev: bool = True, lean: bool = False, prefetch: bool = False):
         """mutual=True adds the restarter's mutual-learning loss (tiger.py:574-590) and its
         gradients; False is the reference's contrast_only (restart_prob == 0).
         eval_only=True: no gradient storage; the step computes embeddings, scores, loss and the
         write-back (the forward of tiger/eval_utils.py:29-48).
         want_prev=False / lean=True (evaluation only): no h_prev_left / h_prev_right outputs, no involved set - what an
         evaluation loop that only reads the scores needs; on a model that streams with eager updates and pre-multiplied
-        weights the forward then takes the table-backed lean form of the streaming step (TIGE.StepBuffers)."""
+        weights the forward then takes the table-backed lean form of the streaming step (TIGE.StepBuffers);
+        prefetch=True (resident stream, lean): the next batch's sampler + centres ride on the step's last launch."""
         if (not want_prev or lean) and not eval_only:
             raise ValueError('a training step hands h_prev_left / h_prev_right to the restarter: want_prev / lean are evaluation-only')
         check_trainable(model)
         model._refuse_partitioned('tg_train_step')
         dev = model.device
         self.model, self.B, self.mutual, self.eval_only = model, B, mutual and not eval_only, eval_only
-        self.sb = model.StepBuffers(model, B, want_prev=want_prev, resident=resident, lean=lean)
+        self.sb = model.StepBuffers(model, B, want_prev=want_prev, resident=resident, lean=lean, prefetch=prefetch)
         self.params = [] if eval_only else (contrast_parameters(model) + (restarter_parameters(model) if mutual else []))
         n = sum(p.numel() for _, p, _ in self.params)
         self.gflat = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -292,9 +293,22 @@ class TrainBuffers:
             model._sync_pending()
             model._sync_gtab()
             m = model.model_struct()
+            g = graph.tcsr
+            buf = self.sb
+            pf = bool(self.io.step.prefetch_state)
+            if pf:  # is the collate part this buffer's previous step prefetched still the one this step needs?
+                if buf._pf_state.value == 1 and buf._pf_stamp != model._prefetch_stamp(buf, g):
+                    buf._pf_state.value = 2  # made, but for another state / offset / graph: the step discards it
+                before = buf._pf_state.value
             model._step_serial = getattr(model, '_step_serial', 0) + 1
-        else:
-            model._touch()  # state changes outside the eager streaming step
+            check(lib.tg_train_step(C.byref(m), C.byref(g), C.byref(self.io), ptr(self.ws), self.ws.numel(),
+                                    stream_ptr(model.device)), 'tg_train_step')
+            if pf:
+                if model.device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+                    buf._pf_state.value = before  # nothing ran: the device is where it was before the capturing call
+                buf._pf_stamp = model._prefetch_stamp(buf, g)
+            return
+        model._touch()  # state changes outside the eager streaming step
         g = graph.tcsr
         check(lib.tg_train_step(C.byref(m), C.byref(g), C.byref(self.io), ptr(self.ws), self.ws.numel(),
                                 stream_ptr(model.device)), 'tg_train_step')
