@@ -165,7 +165,10 @@ def test_empty_inputs():
                                           (6144, 500, 100), (3071, 400, 64), (601, 500, 100), (700, 388, 112), (333, 404, 33),
                                           # panel-stationary blocks of eight wavefronts (k_gemm_astat8: 4 / 6 / 8 k-tiles, >= 4 096
                                           # tiles of 128 x 64), ragged rows and columns
-                                          (70001, 172, 1032), (140001, 100, 300), (33000, 256, 1024)])
+                                          (70001, 172, 1032), (140001, 100, 300), (33000, 256, 1024),
+                                          # K-split blocks from K = 320 when they fit one round (the score head's product) and
+                                          # the 64 x 64 blocks just past it; 128 x 128 register-blocked blocks (N % 128 == 0, K >= 512)
+                                          (2048, 344, 172), (400, 364, 172), (3073, 344, 172), (140001, 516, 256), (131073, 640, 128)])
 def test_linear_fwd_vs_torch(n, in_f, out_f):
     from www2023tiger_amd.model.dense import linear_forward
     torch.manual_seed(n)
@@ -174,6 +177,24 @@ def test_linear_fwd_vs_torch(n, in_f, out_f):
     ref = torch.relu(layer(x)).detach().numpy()
     out = linear_forward(layer.to(dev()), x.to(dev()), relu=True).cpu().numpy()
     assert rel_err(out, ref) < 1e-5
+
+
+def test_operator_path_modules_run_on_the_library_under_no_grad():
+    """MergeLayer / Linear- / MLPMessageFunction forwards (basic_modules.py:17-19, message_modules.py:36,50): under
+    no_grad on the GPU they run tg_linear_fwd (one backend for the operator path), with autograd or active dropout
+    plain torch; both agree."""
+    from www2023tiger_amd.model.basic_modules import MergeLayer
+    from www2023tiger_amd.model.message_modules import LinearMessageFunction, MLPMessageFunction
+    torch.manual_seed(3)
+    ml = MergeLayer(36, 36, 16, 1, dropout=0.1).to(dev()).eval()
+    lf, mf = LinearMessageFunction(64, dropout=0.1).to(dev()).eval(), MLPMessageFunction(64, dropout=0.1).to(dev()).eval()
+    x1, x2, r = torch.randn(301, 36, device=dev()), torch.randn(301, 36, device=dev()), torch.randn(77, 64, device=dev())
+    ref = (ml(x1, x2), lf(r), mf(r))  # grad mode: torch
+    assert all(t.requires_grad for t in ref)
+    with torch.no_grad():
+        got = (ml(x1, x2), lf(r), mf(r))
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape and rel_err(a.cpu().numpy(), b.detach().cpu().numpy()) < 1e-5
 
 
 @pytest.mark.parametrize('n,d,xw', [
@@ -186,7 +207,10 @@ def test_linear_fwd_vs_torch(n, in_f, out_f):
     # 16-column blocks (k_gru_direct16): 16 / 32 / 48-row blocks (first instance) and 64 / 96-row blocks (second), row counts
     # at the switch points of d = 172 (368 / 736 / 1104 / 1472 rows), one past the largest single round (two tiles per block)
     (368, 172, 688), (369, 172, 688), (737, 172, 688), (1060, 172, 688), (1105, 172, 688), (1473, 172, 688), (2209, 172, 688),
-    (1815, 100, 300), (50, 256, 768)])
+    (1815, 100, 300), (50, 256, 768),
+    # 128-row blocks of four wavefronts, two per CU (k_gru<4, 1>: more blocks than CUs; the old-memory tile of the epilogue
+    # is captured in registers) - ragged rows, padded / tail column tiles
+    (6001, 172, 688), (9000, 256, 1024), (30001, 44, 128), (20000, 100, 300)])
 def test_gru_fwd_vs_torch(n, d, xw):
     from www2023tiger_amd.model.dense import gru_forward
     torch.manual_seed(d)

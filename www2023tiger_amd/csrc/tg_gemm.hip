@@ -1556,7 +1556,9 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
   if (rb_knob && !g.ask_part && g.nbatch == 1 && !g.w_kmajor && !g.bias_rs && !g.row_valid && !g.relu_mask &&
       !g.accumulate && cdiv(g.m_cap, 128) * NT >= 4096) {
     no_ride();
-    if (rb_knob == 2 && g.n >= 512) {
+    // (128 x 128 blocks - four 32 x 32 accumulators per wavefront, twice the MFMAs between barriers - where N is a multiple
+    // of 128 and K long: 196 608 x 1 280 -> 256 1 072 -> 1 041 us; K = 256: no difference)
+    if ((rb_knob == 2 && g.n >= 512) || (rb_knob == 1 && g.n % 128 == 0 && g.k >= 512) || (rb_knob == 3 && g.n >= 128)) {
       TG_KLAUNCH((k_gemm_rb<2, 2>), dim3((unsigned)(8 * cdiv(cdiv(g.m_cap, 128), 8) * cdiv(g.n, 128))), dim3(256), 0, st, gd);
     } else {
       TG_KLAUNCH((k_gemm_rb<2, 1>), dim3((unsigned)(8 * cdiv(cdiv(g.m_cap, 128), 8) * NT)), dim3(256), 0, st, gd);

@@ -8,6 +8,16 @@ from .._lib import TgLinear, check, lib, ptr
 from ..hip_ops import stream_ptr
 
 
+def hip_inference(x: Tensor, dropout: nn.Dropout, *layers: nn.Linear) -> bool:
+    """May a module's forward run on the library's kernels?  Inference only (no autograd graph to build, no active
+    dropout mask), a 2-D float32 input on the GPU, widths the kernels take (multiples of four floats)."""
+    if torch.is_grad_enabled() or not x.is_cuda or x.dim() != 2 or x.dtype != torch.float32:
+        return False
+    if dropout.training and dropout.p > 0:
+        return False
+    return all(l.in_features % 4 == 0 and l.bias is not None and l.weight.is_cuda for l in layers)
+
+
 def linear_forward(layer: nn.Linear, x: Tensor, relu: bool = False) -> Tensor:
     x = x.contiguous().float()
     n, in_f = x.shape

@@ -4,6 +4,7 @@ from typing import Optional, Tuple
 from torch import Tensor, nn
 
 from .. import hip_ops
+from .dense import hip_inference, linear_forward
 
 
 class MessageFunction(nn.Module):
@@ -34,6 +35,8 @@ class LinearMessageFunction(MessageFunction):
         self.fn = nn.Sequential(nn.Dropout(dropout), nn.Linear(raw_msg_dim, out_msg_dim))
 
     def forward(self, raw_messages: Tensor) -> Tensor:
+        if hip_inference(raw_messages, self.fn[0], self.fn[1]):
+            return linear_forward(self.fn[1], raw_messages)
         return self.fn(raw_messages)
 
 
@@ -48,6 +51,8 @@ class MLPMessageFunction(MessageFunction):
                                 nn.Dropout(dropout), nn.Linear(self.hidden_size, self.output_size))
 
     def forward(self, raw_messages: Tensor) -> Tensor:
+        if hip_inference(raw_messages, self.fn[0], self.fn[1], self.fn[4]):
+            return linear_forward(self.fn[4], linear_forward(self.fn[1], raw_messages, relu=True))
         return self.fn(raw_messages)
 
 
