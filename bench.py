@@ -546,8 +546,11 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
         empty |= {'eager_query_rows(G)'}
     # riders: where they apply the step has no write-back launch (STEP 4-5 ride on fc2's launch, STEP 6's rows
     # leave its epilogue) and no collate launch (sampler + centres of the NEXT batch ride on the query-row product's)
-    wb_rides = direct and fused and B <= 16384 and os.environ.get('TG_WB_RIDER', '1') != '0'
-    prefetch = bool(buf.io.prefetch_state) and lean and gtab and B <= 16384 and os.environ.get('TG_PREFETCH', '1') != '0'
+    # (B > 16 384: the same two pieces as launches on the library's side stream - write-back beside fc1, the next batch's
+    # sampler beside the updater: csrc/tg_model.hip, SideLane; opt-in with TG_SIDE_STREAM=1, measured not faster)
+    side = B > 16384 and os.environ.get('TG_SIDE_STREAM', '0') != '0'
+    wb_rides = direct and fused and (B <= 16384 or side) and os.environ.get('TG_WB_RIDER', '1') != '0'
+    prefetch = bool(buf.io.prefetch_state) and lean and gtab and (B <= 16384 or side) and os.environ.get('TG_PREFETCH', '1') != '0'
     if wb_rides and stage_ms[names.index('writeback_phase1')] < 0.5 * stage_ms[names.index('attn_gemm_fc2')]:
         empty |= {'writeback_phase1'}
     else:
@@ -581,10 +584,14 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
                            query_rows=('eager: per-node table of folded queries, refreshed for the batch\'s positive nodes at the end of '
                                        'the step (tg_model.g_table)' if gtab else 'G product over the 3B centres of the batch'),
                            involved_set=('not formed (tg_step_io.lean: nothing in a direct-form eager step reads it)' if lean else 'formed (sorted unique ids + ranks)'),
-                           write_back=('rides on the launch of fc1 or fc2 (STEP 4-5 as extra workgroups, STEP 6 rows from the epilogue of '
-                                       'fc2): the stage times of the two products include it' if wb_rides else 'own launch'),
-                           collate=('sampler + centres of the NEXT batch ride on the query-row launch (tg_step_io.prefetch_state): '
-                                    'stage eager_query_rows(G) includes them; every replay runs exactly one collate' if prefetch else 'first launch of the step'),
+                           write_back=(('STEP 4-5 as a launch on the library\'s side stream beside fc1 (a parallel branch of the captured graph), '
+                                        'STEP 6 rows from the epilogue of fc2' if side else
+                                        'rides on the launch of fc1 or fc2 (STEP 4-5 as extra workgroups, STEP 6 rows from the epilogue of '
+                                        'fc2): the stage times of the two products include it') if wb_rides else 'own launch'),
+                           collate=(('sampler of the NEXT batch on the side stream beside the updater and the query rows, its centres pass '
+                                     'behind them (tg_step_io.prefetch_state); every replay runs exactly one collate' if side else
+                                     'sampler + centres of the NEXT batch ride on the query-row launch (tg_step_io.prefetch_state): '
+                                     'stage eager_query_rows(G) includes them; every replay runs exactly one collate') if prefetch else 'first launch of the step'),
                            state_preroll_batches=preroll, involved_per_batch=float(U),
                            involved_before_timed_region=[dict(batch=b, involved=u) for b, u in u_trace],
                            outdated_per_batch=float(O_),

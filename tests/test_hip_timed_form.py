@@ -326,3 +326,65 @@ def test_prefetched_collate_is_discarded_when_state_offset_or_form_change():
     if os.environ.get('TG_PREFETCH', '1') != '0' and os.environ.get('TG_GTAB', '1') != '0':  # (knobs that switch it off)
         assert used.count(1) >= 6
     compare_state_with_oracle(model, orc)
+
+
+@pytest.mark.parametrize('side', ['1', '0'], ids=['side_stream', 'one_stream'])
+def test_large_batch_side_stream_form_matches_oracle(side, monkeypatch):
+    """Batches above 16 384 events host no riders; with TG_SIDE_STREAM=1 the write-back (STEP 4-5) runs on the library's
+    side stream beside fc1 and the NEXT batch's sampler beside the updater and the query rows (csrc/tg_model.hip:
+    SideLane), as parallel branches of a captured graph too (opt-in: measured not faster).  B = 20 000 on a small graph:
+    two eager steps, then a graph of two steps replayed twice; neighbour lists bit-exact, embeddings and the final
+    state against the oracle - in both forms."""
+    monkeypatch.setenv('TG_SIDE_STREAM', side)
+    import bench
+    from oracle import tiger_oracle as O
+    from test_hip_parity import compare_state_with_oracle
+    B, K, d = 20000, 10, 32
+    n_eager, gsteps, n_replays = 2, 2, 2
+    nb = n_eager + gsteps * n_replays
+    E = (nb + 1) * B
+    stream = bench.make_stream(30000, 8000, E, 4.0e5, seed=11, d_e=d)
+    model, orc = bench.build_models(stream, d, K, 'left', 'left', with_oracle=True)
+    model.fuse_attention()
+    model.eager_updates()
+    buf = model.StepBuffers(model, B, False, resident=_resident(stream), prefetch=True, debug_lists=True)
+    buf.io.lean = 1
+    _ = model.graph.tcsr, model.model_struct()
+    side_on = side == '1' and os.environ.get('TG_PREFETCH', '1') != '0'
+
+    def oracle_step(b, compare):
+        a = [stream[k][b * B:(b + 1) * B] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], K, 'static')
+        ref = orc.stream_step(*a, cg).numpy()
+        if compare:
+            torch.cuda.synchronize()
+            assert int(buf.err.item()) == 0 and int(buf.offset.item()) == (b + 1) * B
+            np.testing.assert_array_equal(buf.dbg_l1_nids.cpu().numpy(), cg['l1_nids'])
+            np.testing.assert_array_equal(buf.dbg_l1_eids.cpu().numpy(), cg['l1_eids'])
+            np.testing.assert_array_equal(buf.dbg_l1_ts.cpu().numpy(), cg['l1_ts'])
+            cnt = buf.counts.tolist()
+            assert cnt[0] == -1 and cnt[2] == len(cg['rd_nids'])
+            assert_close(buf.h[:2 * B].cpu().numpy(), ref, f'h_left, batch {b}', TOL)
+            return cnt
+
+    for b in range(n_eager):
+        model.launch_step(buf)
+        cnt = oracle_step(b, True)
+        model.note_rows(cnt[1], cnt[2])
+        if b >= 1:  # side stream: the step started with its attention core, its sampler ran beside the last updater
+            assert buf._pf_state.value == (1 if side_on else 0)
+    side = torch.cuda.Stream()
+    snap = buf.offset.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        for _ in range(gsteps):
+            model.launch_step(buf)
+    buf.offset.copy_(snap)
+    torch.cuda.synchronize()
+    b = n_eager
+    for _ in range(n_replays):
+        graph.replay()
+        for j in range(gsteps):
+            oracle_step(b, j == gsteps - 1)
+            b += 1
+    compare_state_with_oracle(model, orc)

@@ -502,6 +502,58 @@ void launch_attn_core(const tg_model* m, int64_t Q, const float* ts, const int64
 #undef TG_CORE
 }
 
+// ---- side lane: a second HIP stream per device for work that is independent of the launches beside it -----------------
+// At large batches the step's launches are long and bound by different resources: the products and the updater by the
+// matrix pipe, the write-back and the sampler by memory round trips.  Riders (workgroups of the same launch) were measured
+// to cost such products more than they save (see gemm_launch); a forked stream lets the dispatcher co-schedule the two
+// kernels' workgroups instead.  fork: the lane waits for everything enqueued on `st` so far; join: `st` waits for the lane.
+// Under stream capture (a hipGraph of several steps) the event pair makes the lane part of the capture: a parallel branch
+// of the graph.  The lane is created by the first call outside a capture (every caller runs a step eagerly first).
+// MEASURED at C5 shape (B = 65 536, d = 256, 1x MI355X, 30 steps): NOT faster - 3.905 ms per step against 3.861 ms with
+// everything on one stream: fc1 grows by the write-back's own duration (1.10 -> 1.28 ms), the updater and the query rows
+// by the sampler's (1.13 -> 1.23, 0.40 -> 0.54 ms incl. the centres launch).  The matrix kernels fill the register file
+// (k_gru<4, 1>: 2 x 256 registers per SIMD lane, k_gemm_rb<2, 2>: 2 x 228), so the side kernel's wavefronts only get
+// slots the matrix kernel's blocks give up - time slicing, not overlap.  Hence OFF by default; TG_SIDE_STREAM=1 switches
+// the form on (read at every call: tests/test_hip_timed_form.py runs it against the oracle).
+struct SideLane {
+  hipStream_t s = nullptr;
+  hipEvent_t fork[2] = {nullptr, nullptr}, join[2] = {nullptr, nullptr};
+  bool ok = false;
+};
+static SideLane* side_lane(hipStream_t st) {
+  const char* knob = getenv("TG_SIDE_STREAM");  // tuning knob (read per call; default off, see above)
+  if (!knob || atoi(knob) == 0) return nullptr;
+  static SideLane lanes[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  SideLane& L = lanes[dev];
+  if (L.ok) return &L;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return nullptr;  // not now: no stream / event is created inside a capture
+  }
+  bool good = hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < 2 && good; ++i)
+    good = hipEventCreateWithFlags(&L.fork[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&L.join[i], hipEventDisableTiming) == hipSuccess;
+  if (!good) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  L.ok = true;
+  return &L;
+}
+static bool lane_fork(SideLane* L, int i, hipStream_t st) {
+  return hipEventRecord(L->fork[i], st) == hipSuccess && hipStreamWaitEvent(L->s, L->fork[i], 0) == hipSuccess;
+}
+static bool lane_join(SideLane* L, int i, hipStream_t st) {
+  return hipEventRecord(L->join[i], L->s) == hipSuccess && hipStreamWaitEvent(st, L->join[i], 0) == hipSuccess;
+}
+// the write-back rider's pass (STEP 4-5 and the bookkeeping of STEP 6: writeback_fused_body<false>) as a launch of its own
+__global__ void __launch_bounds__(256) k_wb_rider(WbRider r) { r.run(blockIdx.x); }
+constexpr int64_t SIDE_MIN_B = 16384;  // batches above this: launches that host no riders (gemm_launch, step_forward)
+
 static void launch_centres(const tg_model* m, int64_t Q, const int64_t* nids, const float* reprs, const uint64_t* bm,
                            const uint32_t* rank, const AttnWs& w, const PosArgs* pos, const DirectArgs* da, hipStream_t st,
                            bool no_copy = false) {
@@ -582,7 +634,21 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
   const bool ks16 = gemm_ks16_launch(g, st, (ext || (wbr && pos && pos->win_row)) ? wbr : nullptr, &wb_on_fc1,
                                      (gs && gs->variant == 1) ? &gs->gi : nullptr, &gi_rode);
   const bool pieces = !ks16 && gemm_sk_partials(g, w.sk, TG_SK_WS_FLOATS, st, &sk);
+  // large batch (this product hosts no rider): the write-back rider as a launch of its own on the side lane, beside this
+  // product - STEP 4-5 read the snapshot and the winners the core's launch left, nothing this product touches - joined in
+  // front of fc2, whose epilogue stores STEP 6's rows
+  SideLane* lane = nullptr;
+  bool wb_side = false;
+  if (!ks16 && !pieces && !ext && wbr && pos && pos->win_row && !gs && wbr->a.B > SIDE_MIN_B && (lane = side_lane(st)) != nullptr) {
+    if (!lane_fork(lane, 0, st)) return TG_EHIP;
+    WbRider wr = *wbr;
+    wr.blocks = flat_grid(2 * wr.a.B, 4);
+    wr.last = 0u;
+    hipLaunchKernelGGL(k_wb_rider, dim3(wr.blocks), dim3(256), 0, lane->s, wr);
+    wb_side = true;
+  }
   if (!ks16 && !pieces && (rc = gemm_launch(g, st)) != TG_OK) return rc;
+  if (wb_side && !lane_join(lane, 0, st)) return TG_EHIP;
   prof_mark(pf, stage++, st);
   KSlot ks_fc2(KT_FC2);
   g = GemmArgs{};
@@ -614,6 +680,9 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
     if ((rc = gemm_launch(g, st, nullptr, &tail_rode, nullptr, &gs->tail)) != TG_OK) return rc;
     if (!tail_rode && (rc = gru_tail_launch(gs->tail, st)) != TG_OK) return rc;
     gs->done = true;
+    rode = true;
+  } else if (wb_side) {  // STEP 4-5 ran beside fc1 (side lane): this product only stores STEP 6's rows (c2)
+    if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
     rode = true;
   } else if (wb_on_fc1) {  // ... or rode on fc1's already: this launch is free to host the NEXT batch's sampler (collate
     // prefetch; the stream offset has been advanced on fc1's launch, nothing from here on reads this batch's query arrays
@@ -1286,7 +1355,10 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   static const int pf_knob = getenv("TG_PREFETCH") ? atoi(getenv("TG_PREFETCH")) : 1;
   w.prefetch = pf_knob != 0 && io->prefetch_state && io->stream_len > 0 && io->offset_dev && io->advance && io->ws_is_clean &&
                w.lean && w.gtab && w.fused_wb && !lz && io->strategy == 0 && K <= 16 && !io->l1_nids && !io->l1_eids && !io->l1_ts &&
-               B <= 16384;  // (large batches: the last product's launch takes no riders - nothing to gain, see gemm_launch)
+               // (large batches: the last product's launch takes no riders, see gemm_launch - the sampler half then runs on
+               // the side lane beside the updater, the centres half behind the query rows: step_writeback_b)
+               (B <= SIDE_MIN_B || (m->c_table && side_lane(st) != nullptr));
+  w.prefetch_side = w.prefetch && B > SIDE_MIN_B;
   const int pf_in = io->prefetch_state ? *io->prefetch_state : 0;
   const bool prefetched = w.prefetch && pf_in == 1;
   if (io->prefetch_state) *io->prefetch_state = 0;  // set again by the end of the step, once the rider is enqueued
@@ -1521,6 +1593,7 @@ int step_writeback_b(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, 
   prof_mark(pf, ST_WRITE_LEFT, st);
   int rc;
   CollateRider co{};
+  SideLane* lane = nullptr;
   if (w.fused_wb) {
     wa.snap = w.snap;
     wa.snap_ts = w.snap_ts;
@@ -1549,6 +1622,16 @@ int step_writeback_b(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, 
       co.parts = w.sampler_rode ? 2u : 0u;  // (the sampler half rode on fc2's launch already)
     }
     const bool ctab = cr && m->c_table;  // ... or straight into the per-node table of centre rows
+    if (w.prefetch_side && (lane = side_lane(st)) != nullptr) {
+      // the NEXT batch's sampler (graph + stream only) beside the updater and the query rows; it writes the step's query
+      // arrays and neighbour lists, which nothing from here on reads (as with TG_PREFETCH_SPLIT)
+      if (!lane_fork(lane, 1, st)) return TG_EHIP;
+      CollateRider cs = co;
+      cs.parts = 1u;
+      collate_blocks_standalone(cs);
+      hipLaunchKernelGGL(k_collate, dim3(cs.blocks), dim3(256), 0, lane->s, cs);
+      co.parts = 2u;  // the centres half (reads the state the updater is about to finish, and the sampler's query ids)
+    }
     KSlot ks_upd(KT_UPDATER);
     if (w.tail_pending && (rc = gru_tail_launch(w.tail, st)) != TG_OK) return rc;  // (split updater, variant 2)
     if (!w.upd_done && !w.tail_pending &&  // (split updater: these rows were finished on fc2's launch)
@@ -1563,8 +1646,9 @@ int step_writeback_b(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, 
     bool rode = false;
     KSlot ks_q(KT_QROWS);
     if ((rc = gtab_rows(m, 2 * io->B, w.upos, w.upos32, n_upos, w.attn.t, st, m->upd_fn == TG_UPD_GRU,
-                        w.prefetch ? &co : nullptr, &rode, io->rows_hint)) != TG_OK)
+                        (w.prefetch && !lane) ? &co : nullptr, &rode, io->rows_hint)) != TG_OK)  // (lane: the centres half waits for the join)
       return rc;
+    if (lane && !lane_join(lane, 1, st)) return TG_EHIP;
     if (w.prefetch && !rode) {  // this product's kernel does not host riders: the same work as a launch of its own
       collate_blocks_standalone(co);
       hipLaunchKernelGGL(k_collate, dim3(co.blocks), dim3(256), 0, st, co);

@@ -70,6 +70,7 @@ struct StepWs {
   bool direct;      // ... and no compact copy of the involved rows was made (centres / neighbours read the tables)
   bool gtab;        // the folded queries come from the per-node table; the step refreshes its positive nodes' rows at the end
   bool prefetch;    // the step runs the collate part of the NEXT batch on its last launch (tg_step_io.prefetch_state)
+  bool prefetch_side;  // ... large batch: its sampler half on the side lane beside the updater, its centres half behind the query rows
   PosArgs pos_args;   // the step's dedup arguments / direct-centres arguments (the prefetch builds the next batch's
   DirectArgs da_args; // centres rider from them at the end of the step)
   // --n_layers 2: second-hop lists of the Q*K neighbour slots, the slots' query times (the roots'), their embeddings
