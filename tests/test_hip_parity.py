@@ -168,7 +168,10 @@ def test_empty_inputs():
                                           (70001, 172, 1032), (140001, 100, 300), (33000, 256, 1024),
                                           # K-split blocks from K = 320 when they fit one round (the score head's product) and
                                           # the 64 x 64 blocks just past it; 128 x 128 register-blocked blocks (N % 128 == 0, K >= 512)
-                                          (2048, 344, 172), (400, 364, 172), (3073, 344, 172), (140001, 516, 256), (131073, 640, 128)])
+                                          (2048, 344, 172), (400, 364, 172), (3073, 344, 172), (140001, 516, 256), (131073, 640, 128),
+                                          # weight-stationary LDS-free blocks (k_gemm_wstat: K <= 256, N <= 256, >= 4 096 tiles of
+                                          # 128 x 64): chunk rings of 8 / 11 / 8-of-16 registers, ragged rows, ragged column group
+                                          (196613, 256, 256), (262149, 128, 172), (300001, 172, 100), (140001, 200, 250)])
 def test_linear_fwd_vs_torch(n, in_f, out_f):
     from www2023tiger_amd.model.dense import linear_forward
     torch.manual_seed(n)

@@ -739,6 +739,133 @@ __global__ void __launch_bounds__(512) k_gemm_astat8(GemmArgs g, int cpb) {
   }
 }
 
+// ---- weight-stationary, LDS-free blocks for short-K products with MANY rows ----------------------------------------------
+// C5 shape: fc2 (196 608 x 256 -> 256) and the query rows (81 000 x 256 -> 1 024).  Every LDS-staged form pays a barrier per
+// 32-k tile - 16 .. 32 MFMAs per wavefront between barriers - and reached 0.59 / 0.70 of the matrix peak there.  With K this
+// short a wavefront can keep its WEIGHTS in registers for the whole launch: lane (i, kq) of a 16 x 16 x 4 MFMA holds the
+// 16-byte chunks kq, kq + 4, .. of weight row n0 + i for CW column sets (gemm_direct_tile's operand form: K = 256, 32 columns
+// = 128 registers) and walks row tiles of 16: the tile's activation chunks sit in a ring of NS registers, and the moment
+// the 4 CW MFMAs of slot s have consumed chunk s of this tile the same register receives chunk s of the NEXT tile - a load
+// has a whole tile's MFMAs (128 at K = 256, ~4 000 cycles) to arrive.  No LDS, no barrier, one load per eight MFMAs.
+// A block is four wavefronts = four adjacent 32-column groups over the SAME row tiles (their activation loads meet in the
+// CU's cache); persistent grid of two blocks per CU; the blocks of one row lane sit on one XCD (blockIdx % 8).
+// Plain epilogue (bias, alpha, ReLU, scattered rows), gathered A rows.
+template <int NS, bool CROWS, bool IDX>
+__global__ void __launch_bounds__(256, 2) k_gemm_wstat(GemmArgs g) {
+  constexpr int CW = 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int K = g.k, N = g.n;
+  const int nch = K / 4;
+  int64_t M = g.m_cap;
+  if (g.m_dev) M = min(M, (int64_t)*g.m_dev);
+  if (M <= 0) return;
+  const int NG = (N + 127) / 128;                       // column groups of a block (4 wavefronts x 32 columns)
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int cg = seq % NG;
+  const int64_t lane_row = xcd + 8 * (int64_t)(seq / NG);   // this block's row lane
+  const int64_t n_lanes = 8 * (int64_t)((gridDim.x >> 3) / NG);
+  if (seq / NG >= (int)((gridDim.x >> 3) / NG)) return;     // (grid not a multiple of 8 NG: the surplus blocks idle)
+  const int n0 = cg * 128 + wave * 32;
+  if (n0 >= N) return;
+  const int64_t MT = (M + 15) / 16;
+  auto kc = [&](int s_) { return 4 * min(lk + 4 * s_, nch - 1); };  // element offset of this lane's chunk in slot s (clamped into the row)
+  // ---- the weights, once (a clamped chunk past K repeats the last one: zeroed, it must not count twice)
+  float4 w[CW][NS];
+#pragma unroll
+  for (int c = 0; c < CW; ++c) {
+    const float* row = g.w + (int64_t)min(n0 + 16 * c + li, N - 1) * g.ldw;
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) {
+      const float4 v = ldg4(row + kc(s_));
+      w[c][s_] = (lk + 4 * s_ < nch) ? v : zero4();
+    }
+  }
+  float bias[CW];
+#pragma unroll
+  for (int c = 0; c < CW; ++c) bias[c] = g.bias ? g.bias[min(n0 + 16 * c + li, N - 1)] : 0.f;
+  auto arow_id = [&](int64_t mt) {  // the row of A this lane reads in row tile mt (IDX: gathered - a load)
+    const int64_t m = min(mt * 16 + li, M - 1);
+    if constexpr (IDX) return (int64_t)g.a0.idx[m];
+    else return m;
+  };
+  auto arow = [&](int64_t mt) { return g.a0.p + arow_id(mt) * g.a0.ld; };
+  int64_t mt = lane_row;
+  if (mt >= MT) return;
+  // ring of RS chunk registers: chunk s lives in a[s % RS]; once slot s is multiplied its register receives chunk s + RS - of
+  // this tile, or of the next one (K = 256: half a tile = 64 MFMAs ahead; a full-tile ring spills at 256 registers)
+  constexpr int RS = (NS > 8 && NS % 2 == 0) ? NS / 2 : NS;  // (the ring is consistent only when RS divides NS)
+  float4 a[RS];
+  const float* crow_p = arow(mt);
+#pragma unroll
+  for (int s_ = 0; s_ < RS; ++s_) a[s_] = ldg4(crow_p + kc(s_));
+  // One tile: 4 CW NS MFMAs with the next tile's chunk loads threaded between them, then the stores.  The loop body must
+  // hold NO branch around a memory instruction (a join makes the wait-count pass wait for everything in flight - the ring
+  // lives on loads that stay in flight across a whole tile): full tiles store unconditionally (FULL), the ragged last row
+  // tile / column group takes the predicated copy of the body.
+  auto tile = [&](auto full_tag, int64_t mt_, int64_t mt_next) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const float* const trow = crow_p;  // this tile's rows (the second half of its chunks is still to be requested)
+    // the next tile's row id and this tile's output rows are requested FIRST: loads complete in order, so waiting for
+    // them later must not mean waiting for the chunk loads that follow
+    const int64_t nid = arow_id(mt_next);
+    int orow_[4];
+    if constexpr (CROWS) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) orow_[q] = g.c_rows[min(mt_ * 16 + 4 * lk + q, M - 1)];
+    }
+    const float* nrow = nullptr;
+    f32x4m acc[CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) acc[c] = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) {
+      const float4 x = a[s_ % RS];
+      const float av[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          const float wv = j == 0 ? w[c][s_].x : j == 1 ? w[c][s_].y : j == 2 ? w[c][s_].z : w[c][s_].w;
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wv, acc[c], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      // chunk s + RS into the register this slot has just been multiplied from
+      if (s_ + RS == NS || (RS == NS && s_ == 0)) nrow = g.a0.p + nid * g.a0.ld;
+      a[s_ % RS] = (s_ + RS < NS) ? ldg4(trow + kc(s_ + RS)) : ldg4(nrow + kc(s_ + RS - NS));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    crow_p = nrow;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t m = mt_ * 16 + 4 * lk + q;
+      int64_t orow = m;
+      if constexpr (CROWS) orow = orow_[q];
+      float* dst = g.c + orow * g.ldc + n0 + li;
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {
+        float x = g.alpha * (acc[c][q] + bias[c]);
+        if (g.relu) x = fmaxf(x, 0.f);
+        if (FULL) dst[16 * c] = x;
+        else if (n0 + 16 * c + li < N && m < M) dst[16 * c] = x;
+      }
+    }
+  };
+  using Full = std::integral_constant<bool, true>;
+  using Ragged = std::integral_constant<bool, false>;
+  const bool cols_full = n0 + 32 <= N;  // wave-uniform
+  if (cols_full) {
+    for (; (mt + 1) * 16 <= M; mt += n_lanes) {
+      const int64_t mt_next = mt + n_lanes < MT ? mt + n_lanes : mt;  // past the end: a redundant reload of this tile
+      tile(Full{}, mt, mt_next);
+    }
+  }
+  for (; mt < MT; mt += n_lanes) {
+    const int64_t mt_next = mt + n_lanes < MT ? mt + n_lanes : mt;
+    tile(Ragged{}, mt, mt_next);
+  }
+}
+
 template <int NKT>
 __global__ void __launch_bounds__(256) k_gemm_astat(GemmArgs g, int cpb) {
   gemm_astat_block<NKT>(g, cpb, blockIdx.x);
@@ -1543,6 +1670,31 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
     const int nkt8 = (int)cdiv(g.k, BK);
     const bool plain8 = !g.ask_part && g.nbatch == 1 && !g.a1.p && !g.w_kmajor && !g.bias_rs && !g.bias2 && !g.row_valid &&
                         !g.relu_mask && !g.accumulate && !g.c2 && g.a0.w == g.k;
+    // short K, plain epilogue, MANY rows: weight-stationary LDS-free blocks (k_gemm_wstat; TG_GEMM_WSTAT=0: off)
+    static const int ws_knob = getenv("TG_GEMM_WSTAT") ? atoi(getenv("TG_GEMM_WSTAT")) : 1;  // tuning knob
+    // Measured (1x MI355X): 196 608 x 256 -> 256 (fc2 at C5 shape) 265 -> 245 us (105 TF/s); 81 920 x 256 -> 1 024 383 us against
+    // 378 us for the panel-stationary blocks below, 140 001 x 172 -> 1 032 536 against 568 us.  Ablation: without the chunk
+    // reloads (MFMA stream + epilogue alone) 328 us = 0.83 of the matrix peak - the reloads cost the rest although they
+    // are requested half a tile ahead.  Taken for N <= 256 (TG_GEMM_WSTAT=2: every N).
+    if (ws_knob && plain8 && g.k <= 256 && g.k >= 64 && (g.n <= 256 || ws_knob == 2) && cdiv(g.m_cap, 128) * NT >= 4096) {
+      no_ride();
+      const int NG = (int)cdiv(g.n, 128);
+      const unsigned lanes8 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(512 / 8 / NG, cdiv(cdiv(g.m_cap, 16), 8)));
+      const dim3 gr(8u * (unsigned)NG * lanes8);
+      const int nsl = (int)cdiv(cdiv(g.k, 4), 4);
+#define TG_WSTAT(NS_)                                                                                   \
+  do {                                                                                                  \
+    if (g.c_rows && g.a0.idx) TG_KLAUNCH((k_gemm_wstat<NS_, true, true>), gr, dim3(256), 0, st, gd);    \
+    else if (g.c_rows) TG_KLAUNCH((k_gemm_wstat<NS_, true, false>), gr, dim3(256), 0, st, gd);          \
+    else if (g.a0.idx) TG_KLAUNCH((k_gemm_wstat<NS_, false, true>), gr, dim3(256), 0, st, gd);          \
+    else TG_KLAUNCH((k_gemm_wstat<NS_, false, false>), gr, dim3(256), 0, st, gd);                       \
+  } while (0)
+      if (nsl <= 8) TG_WSTAT(8);
+      else if (nsl <= 11) TG_WSTAT(11);
+      else TG_WSTAT(16);
+#undef TG_WSTAT
+      return check_launch("gemm(wstat)");
+    }
     if (as8_knob && plain8 && (nkt8 == 4 || nkt8 == 6 || nkt8 == 8) && cdiv(g.m_cap, 128) * NT >= 4096) {
       no_ride();
       const int cpb = std::min(as8_knob, NT);
