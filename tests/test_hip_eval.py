@@ -298,3 +298,41 @@ def test_resident_eval_raises_the_invariant_errors():
     model.reset()
     ap, auc = eval_edge_prediction(model, dl, dev(), restart_mode=False)
     assert np.isfinite(ap) and np.isfinite(auc)
+
+
+@pytest.mark.parametrize('name', ['eval_seq_lr_d8', 'eval_static_ll_d16'])
+@pytest.mark.parametrize('stream', ['0', '1'], ids=['own_forms', 'eager_fused'])
+def test_resident_eval_in_restart_mode_equals_the_per_batch_loop(name, stream, monkeypatch):
+    """restart_mode=True (the reference's default recipe: --restart_prob 0.01): the lazy restart of eval_utils.py:37-42
+    with its bookkeeping on the device (involved & ~uptodate listed by a collate-only pass, ONE count read back per
+    batch) against the literal loop with Python sets: AP / AUC, the up-to-date set handed back in place and the state."""
+    from www2023tiger_amd import eval_utils
+    from www2023tiger_amd.data.data_loader import BatchLoader, InteractionData
+    z = load(name)
+    cfg = parse_cfg(z)
+    model, _, coll = build_hip_model(z, cfg, dropout=0.0)
+    B = cfg['B']
+    n_warm, n = cfg['n_warm'], 5 * B + B // 2
+    data = InteractionData(z['src'], z['dst'], z['ts'], z['eids'], np.zeros(len(z['src']), dtype=np.int64), seed=0, eval=True)
+    mk = lambda lo, hi: BatchLoader(data.get_subset(lo, hi), B, coll)
+    monkeypatch.setenv('TG_EVAL_STREAM', stream)
+    out = {}
+    for form in ('0', '1'):
+        monkeypatch.setenv('TG_EVAL_RESIDENT', form)
+        model.reset()
+        up = eval_utils.warmup(model, mk(0, n_warm), dev())
+        n_up = len(up)
+        res = eval_utils.eval_edge_prediction(model, mk(n_warm, n_warm + n), dev(), restart_mode=True, uptodate_nodes=up,
+                                              mean_over_n_samples=cfg['chunk'])
+        assert len(up) > n_up  # handed back in place
+        out[form] = (res, sorted(up), model.left_memory.vals.clone(), model.right_memory.vals.clone(),
+                     model.msg_store.node_msg_vals.clone(), model.msg_store.has_msg_mask().clone())
+    assert out['0'][1] == out['1'][1]
+    assert torch.equal(out['0'][5], out['1'][5])
+    tol = 0.0 if stream == '0' else 2e-4
+    assert abs(out['0'][0][0] - out['1'][0][0]) <= tol and abs(out['0'][0][1] - out['1'][0][1]) <= tol
+    for a, b in zip(out['0'][2:5], out['1'][2:5]):
+        if stream == '0':
+            assert torch.equal(a, b)
+        else:
+            assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-5

@@ -134,7 +134,13 @@ __device__ __forceinline__ RowVec<W> row_load(const float* __restrict__ row, int
 template <int W>
 __device__ __forceinline__ void row_store(float* __restrict__ row, int col, int width, const RowVec<W>& r) {
   if (W == 4) {
+#ifdef TG_ST_NT  // experiment: streaming stores for the S rows (do they shorten the end-of-kernel write-back of the XCD's L2?)
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f x = {r.a[0], r.a[1], r.a[2], r.a[W - 1]};
+    if (col < width) __builtin_nontemporal_store(x, reinterpret_cast<v4f*>(row + col));
+#else
     if (col < width) *reinterpret_cast<float4*>(row + col) = make_float4(r.a[0], r.a[1], r.a[2], r.a[W - 1]);
+#endif
   } else if (W == 2) {
     if (col < width) *reinterpret_cast<float2*>(row + col) = make_float2(r.a[0], r.a[W - 1]);
   } else if (W == 3 && col + 3 <= width) {

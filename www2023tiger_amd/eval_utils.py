@@ -44,10 +44,12 @@ def _resident_plan(model, dl, restart_mode: bool):
     """Can the loop below run as a resident stream?  It can when `dl` is this package's BatchLoader over an
     InteractionData (batches are contiguous index ranges in order, negatives a deterministic stream), the batches
     would take the one-call evaluation step anyway (TIGE._fused_eval_ok, a collator graph whose strategy the step
-    samples itself) and no lazy restart runs between them (eval_utils.py:37-42 needs the host-side node sets).
+    samples itself).  The lazy restart of eval_utils.py:37-42 runs with its bookkeeping on the device (below).
     TG_EVAL_RESIDENT=0 switches the form off (the per-batch loop is what the reference's harness does literally)."""
     from .data.data_loader import BatchLoader, GraphCollator, InteractionData
-    if restart_mode or os.environ.get('TG_EVAL_RESIDENT', '1') == '0':
+    if os.environ.get('TG_EVAL_RESIDENT', '1') == '0':
+        return None
+    if restart_mode and (getattr(model, 'restarter_fn', None) is None or os.environ.get('TG_EVAL_RESIDENT_RESTART', '1') == '0'):
         return None
     if type(dl) is not BatchLoader or not isinstance(dl.dataset, InteractionData) or type(dl.collate_fn) is not GraphCollator:
         return None
@@ -62,7 +64,7 @@ def _resident_plan(model, dl, restart_mode: bool):
     return (lo, hi, graph) if hi > lo and dl.batch_size > 0 else None
 
 
-def _eval_resident(model, dl, plan, mean_over_n_samples: int):
+def _eval_resident(model, dl, plan, mean_over_n_samples: int, restart_mode: bool = False, uptodate_nodes: Optional[set] = None):
     """eval_edge_prediction's loop (eval_utils.py:29-57) over a RESIDENT stream: the loader's event columns and
     negatives are uploaded once, every batch is one `tg_train_step` call without gradient buffers - the very call
     `contrast_learning` makes per batch under no_grad - that reads its rows at a device-side offset and leaves its
@@ -91,7 +93,8 @@ def _eval_resident(model, dl, plan, mean_over_n_samples: int):
                 model.eager_updates(True)
             if not had[1]:
                 model.fuse_attention(True)
-        return _eval_resident_run(model, ds, bs, dev, N, lo, hi, graph, TrainBuffers, lean=stream_form)
+        return _eval_resident_run(model, ds, bs, dev, N, lo, hi, graph, TrainBuffers, lean=stream_form,
+                                  restart_mode=restart_mode, uptodate_nodes=uptodate_nodes)
     finally:
         if stream_form and not all(had):
             if not had[0]:
@@ -100,7 +103,32 @@ def _eval_resident(model, dl, plan, mean_over_n_samples: int):
                 model.fuse_attention(False)
 
 
-def _eval_resident_run(model, ds, bs, dev, N, lo, hi, graph, TrainBuffers, lean):
+def _restart_listed(model, tb, graph):
+    """The lazy restart of one batch (eval_utils.py:37-42) with the bookkeeping on the device: a collate-only pass over
+    the batch the step is about to read flags its involved nodes, lists `involved & ~uptodate`, marks them up to date and
+    leaves the batch's earliest time (tiger_hip.h: tg_lazy_restart, list form); the host reads back ONE count and hands
+    the device-resident list to TIGER.restart - no node set crosses the bus, no Python set arithmetic per batch."""
+    import ctypes as C
+    cb = tb.sb._lazy_collate
+    m = model.model_struct()
+    check(lib.tg_stream_step(C.byref(m), C.byref(graph.tcsr), C.byref(cb.io), ptr(cb.ws), cb.ws.numel(), stream_ptr(model.device)),
+          'tg_stream_step(lazy restart list)')
+    n = int(cb.counts[3].item())
+    if n:
+        nids = tb.sb.lazy_list[:n]
+        # a model that streams with eager updates: were its per-node tables current?  Then they follow the restart - the
+        # restarted nodes have no pending message any more and new memories: their centre / query rows are recomputed -
+        # instead of being rebuilt for every node at the next step
+        current = (model._pending is not None and model._pending_stamp == model._state_stamp()
+                   and (getattr(model, '_gtab', None) is None or getattr(model, '_gtab_stamp', None) is not None))
+        model.restart(nids, tb.sb.lazy_tmin.expand(n))
+        if current:
+            model._tables_follow_restart(nids)
+    tb.sb.lazy_batch += 1
+    return n
+
+
+def _eval_resident_run(model, ds, bs, dev, N, lo, hi, graph, TrainBuffers, lean, restart_mode=False, uptodate_nodes=None):
     c = getattr(ds, '_dev', None)
     if c is not None and c['device'] == dev:
         src, dst, ts64, eids = (c[k][lo:hi] for k in ('src', 'dst', 'ts', 'eids'))
@@ -121,8 +149,21 @@ def _eval_resident_run(model, ds, bs, dev, N, lo, hi, graph, TrainBuffers, lean)
         if not count:
             continue
         tb = TrainBuffers(model, B, resident=resident, eval_only=True, want_prev=not lean, lean=lean,
-                          prefetch=lean and count > 1 and os.environ.get('TG_EVAL_PREFETCH', '1') != '0')
+                          prefetch=(lean and count > 1 and not restart_mode  # (a restart changes state behind a prefetched collate)
+                                    and os.environ.get('TG_EVAL_PREFETCH', '1') != '0'))
         tb.sb.offset.fill_(first)
+        if restart_mode:
+            # restarting from the first batch on, nobody triggers (eval_utils.py:37-42: every batch restarts what is involved
+            # and not yet up to date); the up-to-date set starts as the caller's and is handed from buffer to buffer
+            # (the list form for every restarter: the in-step form of the static one belongs to the streaming step's launcher)
+            tb.sb.enable_lazy_restart(model, np.zeros(count, dtype=np.uint8), force_list=True)
+            tb.sb.lazy_restarting.fill_(1)
+            if bufs:
+                tb.sb.lazy_uptodate.copy_(bufs[-1].sb.lazy_uptodate)
+            elif uptodate_nodes:
+                from . import hip_ops
+                hip_ops.bitmap_mark(torch.tensor(sorted(uptodate_nodes), dtype=torch.int64, device=dev), tb.sb.lazy_uptodate,
+                                    model.n_nodes)
         tb.err_host = None  # one read-back at the end (below)
         bufs.append(tb)
         p0, n0 = pos_all.data_ptr() + 4 * first, neg_all.data_ptr() + 4 * first
@@ -130,6 +171,8 @@ def _eval_resident_run(model, ds, bs, dev, N, lo, hi, graph, TrainBuffers, lean)
         # bs 200: 72 us per batch eager, 75 us as 16-step graphs, and a capture costs ~10 ms - so the steps are launched eagerly)
         for k in range(count):
             tb.io.pos_scores, tb.io.neg_scores = p0 + 4 * k * B, n0 + 4 * k * B
+            if restart_mode:
+                _restart_listed(model, tb, graph)
             tb.launch(graph=graph)
             if k == 0 and count > 8:  # one early read-back: the updater's launches are sized by the counts seen so far
                 cnt = tb.sb.counts.tolist()
@@ -140,6 +183,10 @@ def _eval_resident_run(model, ds, bs, dev, N, lo, hi, graph, TrainBuffers, lean)
         if word:
             from ._lib import raise_invariants
             raise_invariants(word & 0xFFFFFFFF)
+    if restart_mode and uptodate_nodes is not None and bufs:  # updated in place, as in the reference
+        from . import hip_ops
+        comp = hip_ops.unique_compact(bufs[-1].sb.lazy_uptodate, model.n_nodes, model.n_nodes)
+        uptodate_nodes.update(comp['ids'][:int(comp['count'].item())].tolist())
     return pos_all.sigmoid_(), neg_all.sigmoid_()
 
 
@@ -153,7 +200,7 @@ def eval_edge_prediction(model, dl, device: torch.device, restart_mode: bool, up
     if plan is not None:
         with torch.no_grad():
             model._poll_train_errors()
-            pos_pred, neg_pred = _eval_resident(model, dl, plan, mean_over_n_samples)
+            pos_pred, neg_pred = _eval_resident(model, dl, plan, mean_over_n_samples, restart_mode, uptodate_nodes)
         ap, auc, bad = ap_auc_windows(pos_pred, neg_pred, mean_over_n_samples)
         if int(bad.item()):
             warnings.warn(f'Encounter invalid values: {int(bad.item())} non-finite predictions were dropped')

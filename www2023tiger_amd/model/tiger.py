@@ -350,6 +350,22 @@ class TIGE(nn.Module):
                   'tg_attn_gtab_rows')
         self._gtab_stamp = stamp
 
+    def _tables_follow_restart(self, nids: Tensor):
+        """restart(nids) has just run on a model whose per-node tables were current: the restarted nodes have no pending
+        message any more and new memories (tiger.py:603-609), nothing else changed - their centre / query rows are recomputed
+        (tg_attn_gtab_rows) and the tables are declared current again, instead of a rebuild over every node at the next
+        eager step."""
+        if self._pending is None:
+            return
+        if getattr(self, '_gtab', None) is not None:
+            m = self.model_struct()
+            n = int(nids.numel())
+            ws = self._ws('gtab_r', n * (4 * self.memory_dim + 4) + 64)
+            check(lib.tg_attn_gtab_rows(C.byref(m), n, ptr(nids), None, ptr(ws), ws.numel(), stream_ptr(self.device)),
+                  'tg_attn_gtab_rows(restart)')
+            self._gtab_stamp = (self._state_stamp(), tuple(self._attn_stamp()), id(self._fused))
+        self._pending_stamp = self._state_stamp()
+
     def _touch(self):
         self._state_version += 1
 
@@ -707,12 +723,13 @@ class TIGE(nn.Module):
         def attach_profiler(self, prof):
             self.io.profiler = prof
 
-        def enable_lazy_restart(self, model: 'TIGER', trigger):
+        def enable_lazy_restart(self, model: 'TIGER', trigger, force_list: bool = False):
             """The lazy-restart loop of train_self_supervised.py:152-163 inside the step (static restarter only;
             tiger_hip.h: tg_lazy_restart).  trigger[b] != 0 means the reference's `np.random.rand() < restart_prob`
             fired before batch b (the loop never fires before batch 0); the draws are the caller's, made up front,
             so a run is reproducible and the step stays free of host round trips.  counts[3] of every step is the
-            number of nodes re-initialised by it."""
+            number of nodes re-initialised by it.  force_list: the list form below for the static restarter too (a caller
+            that drives another step function than launch_step, e.g. the resident evaluation pass)."""
             from .restarters import StaticRestarter
             r = getattr(model, 'restarter_fn', None)
             if r is None:
@@ -722,7 +739,7 @@ class TIGE(nn.Module):
             self.lazy_batch = torch.zeros(1, dtype=torch.int64, device=dev)
             self.lazy_restarting = torch.zeros(1, dtype=torch.int32, device=dev)
             self.lazy_uptodate = torch.zeros(hip_ops.bitmap_words(model.n_nodes), dtype=torch.int64, device=dev)
-            if isinstance(r, StaticRestarter):  # the whole loop body runs inside the step
+            if isinstance(r, StaticRestarter) and not force_list:  # the whole loop body runs inside the step
                 self._lazy = TgLazyRestart(ptr(r.left_emb.weight), ptr(r.right_emb.weight), ptr(self.lazy_trigger),
                                            self.lazy_trigger.numel(), ptr(self.lazy_batch), ptr(self.lazy_restarting),
                                            ptr(self.lazy_uptodate), None, None)
