@@ -230,6 +230,12 @@ def warmup(model, dl, device: torch.device, uptodate_nodes: Optional[set] = None
     """Only valid in restart mode: stream the loader through the model with lazy restarts."""
     model.eval()
     uptodate_nodes = set() if uptodate_nodes is None else uptodate_nodes
+    plan = _resident_plan(model, dl, True)
+    if plan is not None:  # the same pass as eval_edge_prediction(restart_mode=True), scores unused
+        with torch.no_grad():
+            model._poll_train_errors()
+            _eval_resident(model, dl, plan, 200, True, uptodate_nodes)
+        return uptodate_nodes
     with torch.no_grad():
         for src_ids, dst_ids, neg_dst_ids, ts, eids, _, comp_graph in BackgroundThreadGenerator(dl):
             src_ids, dst_ids, neg_dst_ids = (x.long().to(device) for x in (src_ids, dst_ids, neg_dst_ids))
