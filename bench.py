@@ -762,11 +762,45 @@ def reference_api_loop(cfg, batch_sizes=(200, 1024), n_batches=150):
                              auc=auc_)
         os.environ.pop('TG_EVAL_RESIDENT', None)
         out[f'bs{bs}'] = dict(res['resident'], per_batch_loop=res['per_batch_loop'])
-    out['what'] = ('www2023tiger_amd.eval_utils.eval_edge_prediction (the harness of the reference\'s tiger/eval_utils.py:15-68, same '
-                   'signature) over a BatchLoader on the drop-in TIGER, whole call timed (uploads, table builds, AP / AUC included): '
-                   'the resident form the harness takes by itself, and the literal per-batch loop beside it')
+    # restart_mode=True - what the reference's default recipe runs (--restart_prob 0.01, --restarter_type seq --hist_len 40;
+    # train_self_supervised.py:50,194-200): the lazy restart of eval_utils.py:37-42 before every batch, at the reference's
+    # evaluation batch size
     del model
     torch.cuda.empty_cache()
+    rm = {}
+    for rst, hl in (('static', 1), ('seq', 40)):
+        model, _ = build_models(st, cfg['d'], cfg['K'], cfg['msg_src'], cfg['upd_src'], restarter=rst, hist_len=hl, dropout=0.1)
+        model.eval()
+        coll = GraphCollator(model.graph, cfg['K'], 1, restarter=rst, hist_len=hl)
+        bs, nbr = 200, 100
+        m = nbr * bs
+        ev = InteractionData(st['src'][:m], st['dst'][:m], st['ts'][:m], st['eids'][:m], np.zeros(m, dtype=np.int64), seed=0,
+                             eval=True, neg_dst=rs.randint(cfg['n_u'] + 1, cfg['n_u'] + cfg['n_i'] + 1, m))
+        dl = BatchLoader(ev, bs, coll)
+        res = {}
+        for form, env in (('resident', '1'), ('per_batch_loop', '0')):
+            os.environ['TG_EVAL_RESIDENT'] = env
+            times = []
+            for _ in range(2):
+                model.reset()
+                up = set()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ap_, auc_ = eval_edge_prediction(model, dl, model.device, restart_mode=True, uptodate_nodes=up)
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+            res[form] = dict(value=m / times[-1], unit='events/s', ms_per_batch=times[-1] / nbr * 1e3, batches=nbr, ap=ap_, auc=auc_,
+                             restarted_nodes=len(up))
+        os.environ.pop('TG_EVAL_RESIDENT', None)
+        rm[f'{rst}_bs{bs}'] = dict(res['resident'], per_batch_loop=res['per_batch_loop'])
+        del model
+        torch.cuda.empty_cache()
+    out['restart_mode'] = rm
+    model = None
+    out['what'] = ('www2023tiger_amd.eval_utils.eval_edge_prediction (the harness of the reference\'s tiger/eval_utils.py:15-68, same '
+                   'signature) over a BatchLoader on the drop-in TIGER, whole call timed (uploads, table builds, AP / AUC included): '
+                   'the resident form the harness takes by itself, and the literal per-batch loop beside it; restart_mode: '
+                   'the same with restart_mode=True (lazy restart before every batch, static and seq restarter)')
     return out
 
 

@@ -1639,6 +1639,11 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
   if (g.m_cap <= 0) return TG_OK;
   if (g.n <= 0 || g.k <= 0 || (g.k % 4) || (g.a0.w % 4) || (g.ldw % 4) || g.nbatch <= 0) return TG_EINVAL;
   if (g.w_kmajor && (g.n % 4)) return TG_EINVAL;
+  static const int log_knob = getenv("TG_GEMM_LOG") ? atoi(getenv("TG_GEMM_LOG")) : 0;  // diagnostic: one line per product
+  if (log_knob)
+    fprintf(stderr, "gemm m_cap=%lld m_dev=%d hint=%lld n=%d k=%d nbatch=%d kmajor=%d a1=%d idx=%d relu=%d mask=%d acc=%d c_rows=%d bias2=%d brs=%d\n",
+            (long long)g.m_cap, g.m_dev != nullptr, (long long)g.m_hint, g.n, g.k, g.nbatch, g.w_kmajor, g.a1.p != nullptr,
+            g.a0.idx != nullptr, g.relu, g.relu_mask != nullptr, g.accumulate, g.c_rows != nullptr, g.bias2 != nullptr, g.bias_rs != nullptr);
   if (g.a0.w + (g.a1.p ? g.a1.w : 0) != g.k) return TG_EINVAL;
   // long K, few tiles: LDS-free K-split blocks (k_gemm_ks16)
   if (!rider && !collate && !tail && !second && !g.bias2 && gemm_ks16_launch(g, st)) return check_launch("gemm(ks16)");
