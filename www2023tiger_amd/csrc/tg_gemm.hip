@@ -1730,7 +1730,8 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
     const int64_t rows_e = g.m_hint > 0 ? std::min(g.m_hint, g.m_cap) : g.m_cap;
     const bool plain_d = !g.ask_part && g.nbatch == 1 && !g.a1.p && !g.w_kmajor && !g.bias_rs && !g.bias2 && !g.row_valid &&
                          !g.relu_mask && !g.accumulate && (!g.c2 || !g.c_rows) && g.a0.w == g.k;
-    if (dir_knob && plain_d && nsl <= 12 && cdiv(rows_e, 64) * cdiv(g.n, 64) <= 512) {
+    static const int64_t dir_tiles = getenv("TG_GEMM_DIRECT_TILES") ? atoi(getenv("TG_GEMM_DIRECT_TILES")) : 512;  // tuning knob
+    if (dir_knob && plain_d && nsl <= 12 && cdiv(rows_e, 64) * cdiv(g.n, 64) <= dir_tiles) {
       const int64_t tiles64 = cdiv(rows_e, 64) * cdiv(g.n, 64);
       const bool wide = tiles64 > 256 && nsl <= 11;  // (32 x 48 wave tiles: 5 x 44 operand registers)
       const unsigned own = 256;
