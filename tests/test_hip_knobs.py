@@ -21,7 +21,7 @@ SETTINGS = [
     'TG_EAGER_DIRECT=0',
     # the updater: 16-column LDS-free blocks (default) -> 32-row LDS-free -> LDS-staged 32 / 64 / 96 / 128-row blocks
     'TG_GRU_D16=0', 'TG_GRU_D16=0 TG_GRU_DIRECT=0', 'TG_GRU_D16=0 TG_GRU_MICRO=0', 'TG_GRU_D16=0 TG_GRU_NW=3',
-    'TG_GRU_D16=0 TG_GRU_NW=4', 'TG_GRU_D16=0 TG_GRU_NW=4 TG_GRU_KS=1', 'TG_GRU_D16=3',
+    'TG_GRU_D16=0 TG_GRU_NW=4', 'TG_GRU_D16=0 TG_GRU_NW=4 TG_GRU_KS=1', 'TG_GRU_D16=0 TG_GRU_NW=4 TG_GRU_KS=2', 'TG_GRU_D16=3',
     # the split updater (off by default)
     'TG_GRU_SPLIT=1', 'TG_GRU_SPLIT=1 TG_KS16_SECOND=0', 'TG_GRU_SPLIT=2', 'TG_GRU_SPLIT=2 TG_GRU_SPLIT_BOX=0',
 ]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 measurement set (1x MI355X): bench lines, rocprofv3 kernel statistics, PMC traffic passes -> gpurun_out/r04_final/
 # usage (on the GPU box): bash tools/measure_r04.sh [TAG] [PART]   (files are named r04_*_TAG; PART: a = lines, b = profiles)
-TAG=${1:-v1}; PART=${2:-ab}
+TAG=${1:-v2}; PART=${2:-ab}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r04_final
 mkdir -p $O
