@@ -155,8 +155,17 @@ def _eval_resident_run(model, ds, bs, dev, N, lo, hi, graph, TrainBuffers, lean,
         if restart_mode:
             # restarting from the first batch on, nobody triggers (eval_utils.py:37-42: every batch restarts what is involved
             # and not yet up to date); the up-to-date set starts as the caller's and is handed from buffer to buffer
-            # (the list form for every restarter: the in-step form of the static one belongs to the streaming step's launcher)
-            tb.sb.enable_lazy_restart(model, np.zeros(count, dtype=np.uint8), force_list=True)
+            # The static restarter's loop runs INSIDE the evaluation step when that step takes the lean table-backed form (no
+            # host round trip at all: tg_lazy_restart, static form) and the step's graph is the restarter's own (the in-step
+            # loop looks the previous event time up in the graph the step samples from); every other case: the list form
+            from .model.restarters import StaticRestarter
+            r = model.restarter_fn
+            in_step = (lean and isinstance(r, StaticRestarter) and getattr(r, 'graph', None) is graph
+                       and os.environ.get('TG_EVAL_RESTART_INSTEP', '1') != '0')
+            tb.sb.enable_lazy_restart(model, np.zeros(count, dtype=np.uint8), force_list=not in_step)
+            if in_step:
+                tb.refresh()  # (the step's io is a copy of the buffer's: it now carries the lazy-restart block)
+            tb._restart_in_step = in_step
             tb.sb.lazy_restarting.fill_(1)
             if bufs:
                 tb.sb.lazy_uptodate.copy_(bufs[-1].sb.lazy_uptodate)
@@ -171,7 +180,7 @@ def _eval_resident_run(model, ds, bs, dev, N, lo, hi, graph, TrainBuffers, lean,
         # bs 200: 72 us per batch eager, 75 us as 16-step graphs, and a capture costs ~10 ms - so the steps are launched eagerly)
         for k in range(count):
             tb.io.pos_scores, tb.io.neg_scores = p0 + 4 * k * B, n0 + 4 * k * B
-            if restart_mode:
+            if restart_mode and not tb._restart_in_step:
                 _restart_listed(model, tb, graph)
             tb.launch(graph=graph)
             if k == 0 and count > 8:  # one early read-back: the updater's launches are sized by the counts seen so far

@@ -307,6 +307,9 @@ class TrainBuffers:
                 if model.device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
                     buf._pf_state.value = before  # nothing ran: the device is where it was before the capturing call
                 buf._pf_stamp = model._prefetch_stamp(buf, g)
+            if (self.io.step.lazy and getattr(model, '_gtab', None) is not None
+                    and not (lib.tg_stream_step_form(C.byref(m), C.byref(self.io.step)) & 8)):
+                model._gtab_stamp = None  # the in-step restart loop re-initialised rows the tables did not follow
             return
         model._touch()  # state changes outside the eager streaming step
         g = graph.tcsr
