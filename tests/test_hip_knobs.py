@@ -24,6 +24,8 @@ SETTINGS = [
     'TG_GRU_D16=0 TG_GRU_NW=4', 'TG_GRU_D16=0 TG_GRU_NW=4 TG_GRU_KS=1', 'TG_GRU_D16=0 TG_GRU_NW=4 TG_GRU_KS=2', 'TG_GRU_D16=3',
     # the split updater (off by default)
     'TG_GRU_SPLIT=1', 'TG_GRU_SPLIT=1 TG_KS16_SECOND=0', 'TG_GRU_SPLIT=2', 'TG_GRU_SPLIT=2 TG_GRU_SPLIT_BOX=0',
+    # fc1 + fc2 as one launch of 16-row blocks (off by default)
+    'TG_FC12=1', 'TG_FC12=1 TG_WB_RIDER=0',
 ]
 
 

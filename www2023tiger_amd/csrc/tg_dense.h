@@ -117,6 +117,8 @@ bool gemm_sk_partials(const GemmArgs& g, float* ws, size_t ws_floats, hipStream_
 // rider (nullable): the write-back rider shares the launch (*rode tells whether)
 // second (nullable): another product of the same kind (A of up to four segments) as further persistent blocks of the launch;
 // *second_rode tells whether it was taken (only together with the write-back rider)
+// fc1 + fc2 of the attention block in one launch (tg_gemm.hip: k_gemm_ks16_fc2); false = not applicable, nothing launched
+bool gemm_fc12_launch(const GemmArgs& g, const GemmArgs& g2, hipStream_t st, const WbRider* rider, bool* rode);
 bool gemm_ks16_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider = nullptr, bool* rode = nullptr,
                       const GemmArgs* second = nullptr, bool* second_rode = nullptr);
 

@@ -1445,6 +1445,193 @@ __global__ void __launch_bounds__(64 * NW) k_gemm_ks16(GemmArgs g, R r, S2 s2) {
   }
 }
 
+// ---- fc1 and fc2 of the attention block in ONE launch ------------------------------------------------------------------
+// The block's last two products are t = relu([S | c] W1f^T + b1 + valid c1) (K = n_head kvw + d) and h = t W2^T + b2 (K = d).
+// A block that owns WHOLE rows of t can run fc2 on them as its epilogue: 16 rows x all d columns (CT column subtiles of 16),
+// the k-loop of k_gemm_ks16 (LDS-free, K split over four wavefronts) with 1 x CT subtiles, the fold leaves the tile of t in
+// LDS, and the four wavefronts then share fc2's column subtiles: A fragments from that tile, W2 rows straight from memory
+// (requested before the fold), 4 NS MFMAs per subtile, h stored - and scattered a second time into the left memory for
+// the winning positions (STEP 6, GemmArgs.c2 form).  C2: 192 blocks of 16 rows instead of 256 blocks of 48 x 48 + a launch
+// of 144 blocks; fc2's launch - ten microseconds of which one is matrix work - is gone, the 64 CUs the product leaves idle
+// host the write-back riders.  Measured slower (see gemm_fc12_launch): kept as an opt-in form.
+struct Fc2Fuse {
+  const float* w;    // [n2, ldw] (torch Linear layout), n2 <= 16 CT
+  int64_t ldw;
+  const float* bias;
+  float* c;          // [M, ldc]
+  int64_t ldc;
+  int n;             // output columns of fc2
+  float* c2;         // nullable: second, scattered destination (rows c2_rows[m] for m < c2_m, -1 = none)
+  const int32_t* c2_rows;
+  int64_t c2_m, ldc2;
+};
+template <int CT>
+__device__ __forceinline__ void gemm_ks16_fc2_tile(const GemmArgs& g, const Fc2Fuse& f, int64_t M, int64_t m0, float* t_raw) {
+  // COLUMN split: wavefront ks owns column subtiles CW ks .. CW ks + CW - 1 of the 16-row block over the WHOLE K - no fold,
+  // ~100 registers (a K split over the four wavefronts with all CT subtiles per wavefront needs two tiles of 2 (1 + CT)
+  // operand chunks in flight: 512 registers and spills, 37.5 us at C2 against 33.5 us for the two launches).  The operand
+  // chunks of D = 4 k-tiles are in flight: a tile's registers are reloaded for tile i + D right after its MFMAs.
+  constexpr int NW = 4, CW = (CT + NW - 1) / NW, D = 4;
+  constexpr int TS = 16 * CT + 4;              // row stride of the t tile in LDS
+  constexpr int NS2 = (16 * CT + 15) / 16;     // chunk slots of fc2's K (= columns of t, 16 per slot)
+  float (*ts)[TS] = reinterpret_cast<float (*)[TS]>(t_raw);
+  const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int K = g.k, N = g.n, kw0 = g.a0.w;
+  const int64_t m = min(m0 + li, M - 1);
+  const float* ar0 = g.a0.p + (g.a0.idx ? g.a0.idx[m] : m) * g.a0.ld;
+  const float* ar1 = g.a1.p ? g.a1.p + (g.a1.idx ? g.a1.idx[m] : m) * g.a1.ld - kw0 : ar0;
+  const float* wr[CW];
+#pragma unroll
+  for (int c = 0; c < CW; ++c) wr[c] = g.w + (int64_t)min(16 * (CW * ks + c) + li, N - 1) * g.ldw;
+  const int nkt = (K + BK - 1) / BK;
+  struct Tile {
+    float4 a[2], w[CW][2];
+  };
+  auto load_tile = [&](int t, Tile& T) {  // raw loads from clamped addresses; chunks past K are zeroed when they are used
+    const int kb = min(t, nkt - 1) * BK + 8 * lk;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int k = kb + 4 * q;
+      const int kc = k < K ? k : 0;
+      T.a[q] = ldg4((kc < kw0 ? ar0 : ar1) + kc);
+#pragma unroll
+      for (int c = 0; c < CW; ++c) T.w[c][q] = ldg4(wr[c] + kc);
+    }
+  };
+  f32x4m acc[CW];
+#pragma unroll
+  for (int c = 0; c < CW; ++c) acc[c] = f32x4m{0.f, 0.f, 0.f, 0.f};
+  auto mma_tile = [&](int t, const Tile& T) {
+    const int kb = t * BK + 8 * lk;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float4 a = (kb + 4 * q < K) ? T.a[q] : zero4();
+      const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          const float wv = j == 0 ? T.w[c][q].x : j == 1 ? T.w[c][q].y : j == 2 ? T.w[c][q].z : T.w[c][q].w;
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wv, acc[c], 0, 0, 0);
+        }
+    }
+  };
+  Tile T[D];
+#pragma unroll
+  for (int b = 0; b < D; ++b) load_tile(b, T[b]);
+  // epilogue operands of fc1 and fc2's weights: requested behind the first tiles, long before they are needed
+  float bias[CW], bias2[CW];
+#pragma unroll
+  for (int c = 0; c < CW; ++c) {
+    const int n = min(16 * (CW * ks + c) + li, N - 1);
+    bias[c] = g.bias ? g.bias[n] : 0.f;
+    bias2[c] = g.bias2 ? g.bias2[n] : 0.f;
+  }
+  uint8_t v2[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v2[q] = g.bias2 ? g.bias2_valid[min(m0 + 4 * lk + q, M - 1)] : 0;
+  int t = 0;
+  for (; t + D <= nkt; t += D) {
+#pragma unroll
+    for (int b = 0; b < D; ++b) {
+      mma_tile(t + b, T[b]);
+      __builtin_amdgcn_sched_barrier(0);
+      load_tile(t + b + D, T[b]);  // (past the end: a redundant reload of the last tile)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < D; ++b)
+    if (t + b < nkt) mma_tile(t + b, T[b]);
+  // fc2's operands of this wavefront's column subtiles (the same CW ks .. of fc2's output columns)
+  const int K2 = N, nch2 = K2 / 4;
+  float4 w2[CW][NS2];
+  float b2[CW];
+#pragma unroll
+  for (int c = 0; c < CW; ++c) {
+    const int n2 = min(16 * (CW * ks + c) + li, f.n - 1);
+    const float* row = f.w + (int64_t)n2 * f.ldw;
+    b2[c] = f.bias ? f.bias[n2] : 0.f;
+#pragma unroll
+    for (int s_ = 0; s_ < NS2; ++s_) {
+      const float4 v = ldg4(row + 4 * min(lk + 4 * s_, nch2 - 1));
+      w2[c][s_] = (lk + 4 * s_ < nch2) ? v : zero4();
+    }
+  }
+  int crow2[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t mm = min(m0 + 4 * lk + q, M - 1);
+    crow2[q] = (f.c2 && m0 < f.c2_m) ? f.c2_rows[min(mm, f.c2_m - 1)] : -1;
+  }
+  // t = relu(alpha (acc + b1 + valid c1)); the tile goes to LDS (columns past N: zeros - they are fc2's k range too)
+#pragma unroll
+  for (int c = 0; c < CW; ++c) {
+    const int n = 16 * (CW * ks + c) + li;
+    if (n >= 16 * CT) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float x = g.alpha * (acc[c][q] + bias[c] + (v2[q] ? bias2[c] : 0.f));
+      if (g.relu) x = fmaxf(x, 0.f);
+      ts[4 * lk + q][n] = n < N ? x : 0.f;
+      if (g.c && n < N && m0 + 4 * lk + q < M) g.c[(m0 + 4 * lk + q) * g.ldc + n] = x;  // (t itself, when somebody reads it)
+    }
+  }
+  __syncthreads();
+  // ---- fc2 on the tile: h[16, n2] = t W2^T + b2, this wavefront's column subtiles (their MFMA chains interleaved)
+  f32x4m a2[CW];
+#pragma unroll
+  for (int c = 0; c < CW; ++c) a2[c] = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s_ = 0; s_ < NS2; ++s_) {
+    const int kk = 4 * min(lk + 4 * s_, (16 * CT) / 4 - 1);
+    const float4 x = *reinterpret_cast<const float4*>(&ts[li][kk]);
+    const bool lv = lk + 4 * s_ < nch2;
+    const float av[4] = {lv ? x.x : 0.f, lv ? x.y : 0.f, lv ? x.z : 0.f, lv ? x.w : 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {
+        const float wv = j == 0 ? w2[c][s_].x : j == 1 ? w2[c][s_].y : j == 2 ? w2[c][s_].z : w2[c][s_].w;
+        a2[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wv, a2[c], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < CW; ++c) {
+    const int n2 = 16 * (CW * ks + c) + li;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t mm = m0 + 4 * lk + q;
+      const float hv = a2[c][q] + b2[c];
+      if (n2 < f.n && mm < M) {
+        f.c[mm * f.ldc + n2] = hv;
+        if (crow2[q] >= 0 && mm < f.c2_m) f.c2[(int64_t)crow2[q] * f.ldc2 + n2] = hv;
+      }
+    }
+  }
+}
+template <class R, int CT>
+__global__ void __launch_bounds__(256) k_gemm_ks16_fc2(GemmArgs g, Fc2Fuse f, R r) {
+  __shared__ float t_raw[16 * (16 * CT + 4)];
+  const unsigned own = gridDim.x - r.blocks;  // persistent blocks of the product; riders behind them
+  if (blockIdx.x >= own) {
+    r.run(blockIdx.x - own);
+    return;
+  }
+  int64_t M = g.m_cap;
+  if (g.m_dev) M = min(M, (int64_t)*g.m_dev);
+  if (M <= 0) return;
+  const int64_t total = (M + 15) / 16;
+  const int64_t per = (total + 7) / 8;  // XCD x works through the chunk [x per, (x + 1) per) of the row tiles
+  for (int64_t jx = blockIdx.x >> 3; jx < per; jx += own >> 3) {
+    const int64_t b = (int64_t)(blockIdx.x & 7) * per + jx;
+    if (b >= total) break;
+    gemm_ks16_fc2_tile<CT>(g, f, M, b * 16, t_raw);
+    __syncthreads();  // the LDS tiles are re-used by the next row tile
+  }
+}
+
 // Is the product one for k_gemm_ks16?  Long K, plain epilogue (+ second bias), few enough 48 x 48 tiles that the blocks
 // fit the chip in one round or two.  TG_GEMM_KS16: 0 = off, 8 = eight wavefronts per block.
 static unsigned rider_blocks(int64_t live, int threads, int64_t rows);  // (below, with gemm_launch)
@@ -1529,6 +1716,44 @@ bool gemm_ks16_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, b
   else if (rt == 1) TG_KLAUNCH((k_gemm_ks16<NoRider, 1, 3, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
   else if (rt == 2) TG_KLAUNCH((k_gemm_ks16<NoRider, 2, 3, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
   else TG_KLAUNCH((k_gemm_ks16<NoRider, 3, 3, 4>), dim3(256), dim3(256), 0, st, gd, nr, ns);
+  return true;
+}
+
+// fc1 + fc2 in one launch (k_gemm_ks16_fc2): g = fc1 (long K, plain epilogue + second bias, N <= 176), g2 = fc2 over fc1's
+// output (K = g.n, plain epilogue, optionally the second scattered destination); one round of 16-row blocks that leaves
+// CUs for the riders.  MEASURED at C2 (1x MI355X, 100 replays): parity-green and SLOWER - the launch takes 47 us against
+// 23.2 + 10.3 us for the two (step 0.0994 against 0.0850 ms); as a K split over the four wavefronts with all 11 subtiles per
+// wavefront (512 registers, spills) 37.5 us.  A block of 16 whole rows reads ALL of W1f (828 KB) for 16 x 176 outputs - 1.6 x
+// the operand bytes per flop of the 48 x 48 blocks (159 MB against 118 MB per launch through the CUs' memory paths), and
+// that traffic, not the launch count, bounds fc1 at this size.  Opt-in: TG_FC12=1.
+bool gemm_fc12_launch(const GemmArgs& g, const GemmArgs& g2, hipStream_t st, const WbRider* rider, bool* rode) {
+  static const int knob = getenv("TG_FC12") ? atoi(getenv("TG_FC12")) : 0;  // tuning knob (default off, see above)
+  if (rode) *rode = false;
+  if (!knob || g.m_cap <= 0 || g.nbatch != 1 || g.w_kmajor || g.bias_rs || g.row_valid || g.relu_mask || g.c_rows || g.accumulate ||
+      g.c2 || g.ask_part || (g.k % 4) || (g.a0.w % 4) || (g.ldw % 4) || g.a0.w + (g.a1.p ? g.a1.w : 0) != g.k || g.k < 512)
+    return false;
+  if (g.n > 176 || g.n <= 112 || (g.n % 4)) return false;  // (narrower outputs: the 48 / 112-column blocks of k_gemm_ks16)
+  if (g2.nbatch != 1 || g2.w_kmajor || g2.bias_rs || g2.bias2 || g2.row_valid || g2.relu_mask || g2.c_rows || g2.accumulate ||
+      g2.ask_part || g2.a1.p || g2.a0.idx || g2.relu || g2.alpha != 1.f || g2.k != g.n || g2.n > 176 || (g2.ldw % 4) ||
+      g2.m_cap != g.m_cap || g2.m_dev != g.m_dev || g2.a0.p != g.c)
+    return false;
+  const int64_t tiles = cdiv(g.m_cap, 16);
+  if (tiles > 232 || tiles < 128) return false;  // one round with CUs to spare; few tiles: the 48-column blocks fill more CUs
+  GemmArgs gd = g;
+  gd.dbg = 0;
+  gd.c = nullptr;  // t itself has no other reader
+  Fc2Fuse f{g2.w, g2.ldw, g2.bias, g2.c, g2.ldc, g2.n, g2.c2, g2.c2_rows, g2.c2_m, g2.ldc2};
+  const unsigned own = (unsigned)(8 * cdiv(tiles, 8));
+  if (rider && rode) {
+    WbRider wr = *rider;
+    wr.blocks = rider_blocks(own, 256, 2 * wr.a.B);
+    wr.last = 1u;
+    TG_KLAUNCH((k_gemm_ks16_fc2<WbRider, 11>), dim3(own + wr.blocks), dim3(256), 0, st, gd, f, wr);
+    *rode = true;
+  } else {
+    const NoRider nr{0u};
+    TG_KLAUNCH((k_gemm_ks16_fc2<NoRider, 11>), dim3(own), dim3(256), 0, st, gd, f, nr);
+  }
   return true;
 }
 

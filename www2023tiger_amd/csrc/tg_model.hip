@@ -633,6 +633,25 @@ static int attn_forward_fused(const tg_model* m, int64_t Q, const int64_t* nids,
   // short-K product
   SkPlan sk{};
   KSlot ks_fc1(KT_FC1);
+  {
+    // fc1 and fc2 as ONE launch where the batch makes 128 .. 232 blocks of 16 whole rows (C2: 192; tg_gemm.hip:
+    // k_gemm_ks16_fc2): fc2 runs as the epilogue of the block that owns the rows, STEP 6's rows leave it, the write-back
+    // rider takes the CUs the product leaves idle
+    const bool ext12 = wbr && wbr->planned0;
+    const bool own12 = !ext12 && wbr && pos && pos->win_row;
+    GemmArgs g2{};
+    g2.m_cap = Q; g2.n = d; g2.k = d;
+    g2.a0 = ASeg{w.t, d, d, nullptr};
+    g2.w = m->attn_fc2.w; g2.ldw = d; g2.bias = m->attn_fc2.b;
+    g2.c = out; g2.ldc = d; g2.alpha = 1.f; g2.nbatch = 1;
+    if (own12) { g2.c2 = m->left_vals; g2.c2_rows = pos->win_row; g2.c2_m = 2 * wbr->a.B; g2.ldc2 = d; }
+    bool rode12 = false;
+    if (!gs && !sampler && gemm_fc12_launch(g, g2, st, (ext12 || own12) ? wbr : nullptr, &rode12)) {
+      prof_mark(pf, stage++, st);
+      if (wb_rode) *wb_rode = rode12;
+      return check_launch("tg_temporal_attn_fwd(fused, fc1 + fc2)");
+    }
+  }
   bool wb_on_fc1 = false;  // the write-back rider on the fc1 launch: then fc2 only stores STEP 6's rows (c2)
   bool gi_rode = false;  // the split updater's input-side product as a second problem of this launch (variant 1)
   const bool ext = wbr && wbr->planned0;  // a caller's rider (tg_part_step): hosted like the write-back rider, no second row copy
