@@ -336,3 +336,37 @@ def test_resident_eval_in_restart_mode_equals_the_per_batch_loop(name, stream, m
             assert torch.equal(a, b)
         else:
             assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('name,strategy', [('train_static_lr_d8_L2', 'recent_edges'), ('eval_static_ll_d16', 'recent_nodes')])
+@pytest.mark.parametrize('restart', [False, True], ids=['plain', 'restart_mode'])
+def test_resident_eval_with_two_layers_and_recent_nodes(name, strategy, restart, monkeypatch):
+    """The resident evaluation pass on the forms beside the default one: two attention layers (no per-node tables: the
+    streaming form is the lean eager step without them) and the recent_nodes strategy (hit windows from one more
+    recent-edges sampler launch) - against the literal per-batch loop."""
+    from www2023tiger_amd import eval_utils
+    from www2023tiger_amd.data.data_loader import BatchLoader, InteractionData
+    z = load(name)
+    cfg = parse_cfg(z)
+    model, _, coll = build_hip_model(z, cfg, strategy=strategy, dropout=0.0)
+    B = cfg['B']
+    n = min(len(z['src']), 6 * B + B // 2)
+    rs = np.random.RandomState(4)
+    neg = rs.randint(int(z['dst'].min()), int(z['dst'].max()) + 1, len(z['src']))
+    mk = lambda: BatchLoader(InteractionData(z['src'][:n], z['dst'][:n], z['ts'][:n], z['eids'][:n], np.zeros(n, dtype=np.int64),
+                                             seed=1, eval=True, neg_dst=neg), B, coll)
+    out = {}
+    for form, env in (('loop', dict(TG_EVAL_RESIDENT='0')), ('resident', dict(TG_EVAL_RESIDENT='1', TG_EVAL_STREAM='0')),
+                      ('stream', dict(TG_EVAL_RESIDENT='1', TG_EVAL_STREAM='1'))):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        model.reset()
+        up = set()
+        res = eval_utils.eval_edge_prediction(model, mk(), dev(), restart_mode=restart, uptodate_nodes=up, mean_over_n_samples=50)
+        out[form] = (res, sorted(up), model.left_memory.vals.clone(), model.right_memory.vals.clone())
+    assert out['loop'][0] == out['resident'][0] and out['loop'][1] == out['resident'][1] == out['stream'][1]
+    for a, b in zip(out['loop'][2:], out['resident'][2:]):
+        assert torch.equal(a, b)
+    assert abs(out['loop'][0][0] - out['stream'][0][0]) < 5e-4 and abs(out['loop'][0][1] - out['stream'][0][1]) < 5e-4
+    for a, b in zip(out['loop'][2:], out['stream'][2:]):
+        assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
