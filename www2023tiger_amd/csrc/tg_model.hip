@@ -189,6 +189,18 @@ __device__ __forceinline__ RowVec<W> row_load_raw(const float* __restrict__ p) {
 //    three, and twice as many keys in flight.
 // FS: feature streams gathered per key beside the node row - 2: node features + edge features, 1: edge features only
 // (no node table, or the node part of a key comes from tg_model.c_table, which has the features folded in), 0: none
+// diagnostic only (a build with -DTG_CORE_TRACE and TG_CORE_DBG=1, tools/trace_core.py - the stamps cost 29 registers, i.e. the
+// third wavefront per SIMD, so they are compiled out of the production kernel): per-wavefront s_memtime stamps {entry, lists arrived, first key reduced,
+// keys done, exit}.  C2 (one centre per wavefront, three wavefronts per SIMD): 6 450 ticks from entry to the lists' arrival,
+// 5 600 to the first reduced key, 11 150 for the ten keys, 1 080 to the exit.  Hoisting the list / centre-id loads above the
+// winners pass and the time-encoder rows and the G rows above the lists was tried: 178 registers (two wavefronts per SIMD),
+// and held to 168 it spills and is slower (31 600 ticks against 24 300).
+#ifdef TG_CORE_TRACE
+__device__ unsigned long long g_core_trace[4096 * 5];
+#define TG_CT(...) __VA_ARGS__
+#else
+#define TG_CT(...)
+#endif
 template <int NH, int NV, int W, int FS>
 __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const float* __restrict__ ts,
                                                    const int64_t* __restrict__ l1_nids,
@@ -203,6 +215,11 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
   constexpr bool FT = FS > 0;
   using V = RowVec<W>;
   const int lane = lane_id();
+  TG_CT(const bool trace = (direct & 256) != 0;)
+  direct &= 1;
+  TG_CT(const unsigned gw = blockIdx.x * 4 + (threadIdx.x >> 6);)
+  TG_CT(unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0;)
+  TG_CT(if (trace) tr0 = __builtin_amdgcn_s_memtime();)
   // direct (eager updates): neighbour rows come from the state tables, row(v) = has_msg[v] ? pending[v] : right[v];
   // the second dedup pass of the step rides here (a few thousand threads of work)
   if (pos.best) pos_winners_pass(pos, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
@@ -267,6 +284,7 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
     const float* pe_l = m.efeats ? m.efeats + eid_l * de : pn_l;
     unsigned long long live = __ballot(nb_l != 0);  // padding keys are masked (temporal_agg_modules.py:80)
     const bool any = live != 0ull;
+    TG_CT(if (trace && tr1 == 0) { __builtin_amdgcn_sched_barrier(0); tr1 = __builtin_amdgcn_s_memtime() + (live & 0ull); })
     V g[NH][3][NV], acc[NH][3][NV];
     float mx[NH], l[NH], lk[NH];  // lk: sum of the kept exponentials (dropout), same rescaling as l
 #pragma unroll
@@ -378,9 +396,11 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
       for (int sl = 0; sl < PD; ++sl) {
         const int k = k0 + sl;
         if (k < K && ((live >> k) & 1ull)) reduce(sl, k);
+        TG_CT(if (trace && k == 0 && tr2 == 0) { __builtin_amdgcn_sched_barrier(0); tr2 = __builtin_amdgcn_s_memtime() + (__float_as_uint(l[0]) & 0u); })
         fetch(sl, min(k + PD, K - 1));
       }
     }
+    TG_CT(if (trace && tr3 == 0) { __builtin_amdgcn_sched_barrier(0); tr3 = __builtin_amdgcn_s_memtime() + (__float_as_uint(l[0]) & 0u); })
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const float inv = any ? 1.f / l[h] : 0.f;
@@ -405,7 +425,18 @@ __global__ void __launch_bounds__(256) k_attn_core(tg_model m, int64_t Q, const 
       }
     }
   }
+#ifdef TG_CORE_TRACE
+  if (trace && lane == 0 && gw < 4096) {
+    g_core_trace[gw * 5 + 0] = tr0; g_core_trace[gw * 5 + 1] = tr1; g_core_trace[gw * 5 + 2] = tr2;
+    g_core_trace[gw * 5 + 3] = tr3; g_core_trace[gw * 5 + 4] = __builtin_amdgcn_s_memtime();
+  }
+#endif
 }
+#ifdef TG_CORE_TRACE
+extern "C" int tg_debug_core_trace(unsigned long long* out_host, int n_waves) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_core_trace), sizeof(unsigned long long) * 5 * n_waves) == hipSuccess ? 0 : -4;
+}
+#endif
 
 int attn_dims_ok(const tg_model* m) {
   if (!m || m->d <= 0 || (m->d % 4) || m->d_e <= 0 || (m->d_e % 4) || m->n_neighbors <= 0) return 0;
@@ -480,6 +511,8 @@ void launch_attn_core(const tg_model* m, int64_t Q, const float* ts, const int64
     if (wmax <= 128 && w_knob != 4) { W = 2; nv = 1; }
   }
   const unsigned cgrid = flat_grid(Q, 4);
+  static const int core_dbg = getenv("TG_CORE_DBG") ? atoi(getenv("TG_CORE_DBG")) : 0;  // diagnostic: s_memtime stamps (tools/trace_core.py)
+  if (core_dbg) direct |= 256;
   const float* zl = zero_line();
   if (!zl) { *rc_out = TG_EHIP; return; }
   // feature streams per key: node + edge tables (2), the edge table alone - no node table, or the node rows come from the
