@@ -370,3 +370,26 @@ def test_resident_eval_with_two_layers_and_recent_nodes(name, strategy, restart,
     assert abs(out['loop'][0][0] - out['stream'][0][0]) < 5e-4 and abs(out['loop'][0][1] - out['stream'][0][1]) < 5e-4
     for a, b in zip(out['loop'][2:], out['stream'][2:]):
         assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
+
+
+def test_resident_eval_over_device_resident_columns_and_a_chunk_sampler():
+    """The pass over a dataset whose columns already live on the GPU (InteractionData.to_device) and over a contiguous
+    sub-range of it (ChunkSampler: the reference's time-chunk DDP sampler) - the same scores as over host columns."""
+    from www2023tiger_amd import eval_utils
+    from www2023tiger_amd.data.data_loader import BatchLoader, ChunkSampler, InteractionData
+    z = load('eval_static_ll_d16')
+    cfg = parse_cfg(z)
+    model, _, coll = build_hip_model(z, cfg, dropout=0.0)
+    B = cfg['B']
+    n = 8 * B
+    mk = lambda: InteractionData(z['src'][:n], z['dst'][:n], z['ts'][:n], z['eids'][:n], np.zeros(n, dtype=np.int64), seed=2, eval=True)
+    res = []
+    for on_device in (False, True):
+        ds = mk()
+        if on_device:
+            ds.to_device(dev())
+        for sampler in (None, ChunkSampler(n, rank=1, world_size=2, bs=B, seed=5)):
+            model.reset()
+            res.append(eval_utils.eval_edge_prediction(model, BatchLoader(ds, B, coll, sampler=sampler), dev(), restart_mode=False,
+                                                       mean_over_n_samples=cfg['chunk']))
+    assert res[0] == res[2] and res[1] == res[3] and res[0] != res[1]
