@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 7
+#define TG_ABI_VERSION 8
 
 /* status codes */
 #define TG_OK 0
@@ -391,6 +391,11 @@ typedef struct tg_seq_restarter {
   tg_linear out_proj;     /* [dm, dm] */
   tg_linear out_fn;       /* [d, dm]  */
   tg_linear fc1, fc2;     /* merger: [d, d + dm - d], [d, d] */
+  /* != 0: the caller knows that tg_model.nfeats is all zeros (every JODIE data set: feature_getter.py:25-47 loads a zero
+   * table).  The Q / K projection then skips the two node-feature column blocks and tabulates the anony_emb block
+   * (K = d_e + d instead of dm; csrc/tg_restart.hip).  0 is always correct. */
+  int32_t nfeats_zero;
+  int32_t reserved;
 } tg_seq_restarter;
 
 size_t tg_restart_seq_workspace_bytes(const tg_model* m, const tg_seq_restarter* r, int64_t n);

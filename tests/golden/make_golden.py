@@ -304,6 +304,8 @@ def gen_train(name, cfg):
     rs = np.random.RandomState(cfg['seed'] + 100)
     nfeats = rs.standard_normal((n_nodes, d)).astype(np.float32) * 0.5
     nfeats[0] = 0
+    if cfg.get('nfeat') == 'zero':  # the JODIE sets: an all-zero node-feature table (feature_getter.py:25-47)
+        nfeats = np.zeros((n_nodes, d), dtype=np.float32)
     efeats = rs.standard_normal((E + 1, cfg.get('d_e', d))).astype(np.float32)
     efeats[0] = 0
     labels = np.zeros(E, dtype=np.int64)
@@ -518,6 +520,11 @@ TRAIN_SCENARIOS = {
     'train_seq_lr_d8': dict(d=8, n_u=40, n_i=15, E=480, T=300.0, B=40, n_batches=10, K=5, H=8, seed=21, wseed=21,
                             restarter='seq', msg_src='left', upd_src='right', hit='bin', restart_at=6,
                             lr=1e-2, mutual_coef=1.0, grad_batches=(0, 1, 4, 7)),
+    # the same recipe on an all-zero node-feature table (every JODIE set), longer histories than most nodes have: the
+    # restarter's narrow form (csrc/tg_restart.hip: no node-feature blocks, tabulated anony_emb block, shared padded rows)
+    'train_seq_lr_d8_zeronf': dict(d=8, n_u=40, n_i=15, E=480, T=300.0, B=40, n_batches=9, K=5, H=12, seed=28, wseed=28,
+                                   nfeat='zero', restarter='seq', msg_src='left', upd_src='right', hit='bin', restart_at=5,
+                                   lr=1e-2, mutual_coef=1.0, grad_batches=(0, 1, 4, 7)),
     # C2-shaped: msg=left upd=left, static restarter, 'vec' hits, wider edge features
     'train_static_ll_d16': dict(d=16, d_e=12, n_u=60, n_i=25, E=640, T=500.0, B=64, n_batches=8, K=10, seed=22,
                                 wseed=22, restarter='static', msg_src='left', upd_src='left', hit='vec',

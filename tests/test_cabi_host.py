@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, n), f'{n} declared in tiger_hip.h but not exported'
         assert n in _lib.SIGNATURES, f'{n} has no ctypes signature'
     assert set(_lib.SIGNATURES) == set(names)
-    assert _lib.lib.tg_abi_version() == 7
+    assert _lib.lib.tg_abi_version() == 8
 
 
 def test_struct_layouts_match_header():

@@ -163,7 +163,7 @@ def test_training_step_with_other_sampling_strategies(strategy):
 
 
 @pytest.mark.parametrize('name', ['train_seq_lr_d8', 'train_static_ll_d16', 'train_mlp_merge_d8', 'train_linear_gru_d8',
-                                  'train_static_lr_d8_L2'])
+                                  'train_static_lr_d8_L2', 'train_seq_lr_d8_zeronf'])
 def test_mutual_gradients_match_oracle(name):
     """contrast + mutual loss (tiger.py:547-592): restarter gradients and both losses."""
     from oracle import tiger_oracle as O

@@ -145,7 +145,7 @@ def test_stream_matches_reference(name):
 
 # --------------------------------------------------------------------------- training tail
 TRAIN_FIXTURES = ['train_seq_lr_d8', 'train_static_ll_d16', 'train_contrast_rr_d8', 'train_mlp_merge_d8',
-                  'train_linear_gru_d8']
+                  'train_linear_gru_d8', 'train_seq_lr_d8_zeronf']
 TRAIN_FIXTURES_L2 = ['train_static_lr_d8_L2', 'train_contrast_ll_d16_L2']  # --n_layers 2
 
 

@@ -59,7 +59,7 @@ class TgSeqRestarter(C.Structure):
     _fields_ = [
         ('hist_len', i32), ('n_head', i32), ('te_freq', vp), ('te_phase', vp), ('anony_emb', vp),
         ('in_proj_w', vp), ('in_proj_b', vp), ('out_proj', TgLinear), ('out_fn', TgLinear),
-        ('fc1', TgLinear), ('fc2', TgLinear),
+        ('fc1', TgLinear), ('fc2', TgLinear), ('nfeats_zero', i32), ('reserved', i32),
     ]
 
 
@@ -225,7 +225,7 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the library does not export the symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.tg_abi_version() != 7:
+    if lib.tg_abi_version() != 8:
         raise TigerHipError('libtiger_hip.so ABI version mismatch')
     return lib
 

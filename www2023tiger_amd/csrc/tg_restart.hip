@@ -6,65 +6,182 @@
 // with abar_h[s] = (1/H) sum_t A_h[t,s]  (rows of A sum to one, so bv passes through).
 // Q and K still need every position (H x H scores); V and the output projection collapse
 // to one row per node.  Identical maths, ~half the flops.
+//
+// Round 5: the Q / K projection - 90 % of the restarter's flops - runs on a COMPACT operand.
+//  * rows.  The input row of the LAST event of every node is [0 .. 0 | TE(0)] (restarters.py:98-103 zero its first dm - d
+//    columns, and its time difference to itself is 0): ONE constant row for the whole batch (row 0).  All padded slots of
+//    a node (history shorter than H: id, edge, time, direction 0) hold the same event, hence the same row: ONE row per
+//    node.  Everything else is a row of its own.  slot_row[i * H + t] maps the H x H score grid back onto these rows.
+//  * columns.  x = [nfeat[src] | nfeat[dst] | anony_emb[anon] | efeat[eid] | TE(dt)].  When the node-feature table is all
+//    zeros (every JODIE set: Wikipedia, Reddit, LastFM, MOOC) the first 2d columns meet zeros; the anony_emb block takes
+//    H + 1 values only, so its projection is a table T_a = anony_emb W[:, 2d:3d]^T ([H + 1, 2 dm], per call) that the score
+//    kernels add when they load a q / k row.  The product keeps K = d_e + d of 5d ("narrow" form).  With a non-zero
+//    node-feature table the operand keeps all five blocks ("wide" form) and only the row compaction applies.
+// The same sum in another order: float32 reassociation only (the fixtures hold at 1e-4 as before).
 #include <algorithm>
 
 #include "tg_step.h"
 
 namespace tg {
 
-// X[(i,t), :] = [nfeat[src] | nfeat[dst] | anony_emb[anon] | efeat[eid] | TE_r(ts_last - ts_t)],
-// with the first dm-d columns of the last event zeroed (restarters.py:98-103).
-__global__ void k_seq_build(tg_model m, tg_seq_restarter r, int64_t n, const int64_t* __restrict__ nids,
-                            const int64_t* __restrict__ h_n, const int64_t* __restrict__ anon,
-                            const int64_t* __restrict__ h_e, const float* __restrict__ h_t,
-                            const int64_t* __restrict__ h_d, float4* __restrict__ X, float* __restrict__ prev_ts,
-                            const int32_t* __restrict__ n_dev) {
+__device__ __forceinline__ float4 seq_te4(const float4* __restrict__ fq, const float4* __restrict__ ph, float dt, int cc) {
+  const float4 w = fq[cc], q = ph[cc];
+  return make_float4(time_enc(dt, w.x, q.x), time_enc(dt, w.y, q.y), time_enc(dt, w.z, q.z), time_enc(dt, w.w, q.w));
+}
+
+// compact rows of node i besides the shared constant row: its real events among t < H - 1, plus one row for its padded slots
+__global__ void __launch_bounds__(256) k_seq_count(int64_t n, const int32_t* __restrict__ n_dev, int H,
+                                                   const int64_t* __restrict__ h_n, int32_t* __restrict__ cnt) {
+  const int64_t live = n_dev ? min(n, (int64_t)*n_dev) : n;
+  const int lane = lane_id();
+  for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * 4) {
+    int real = 0;
+    if (i < live)
+      for (int t0 = 0; t0 < H - 1; t0 += TG_WAVE) {
+        const int t = t0 + lane;
+        real += __popcll(__ballot(t < H - 1 && h_n[i * H + t] != 0));
+      }
+    if (lane == 0) cnt[i] = i < live ? real + (real < H - 1 ? 1 : 0) : 0;
+  }
+}
+
+// base[i] = 1 + sum_{j < i} cnt[j] (row 0 is the constant row); rows = {live compact rows, ... without the constant row}
+__global__ void __launch_bounds__(1024) k_seq_scan(int64_t n, const int32_t* __restrict__ cnt, int32_t* __restrict__ base,
+                                                   int32_t* __restrict__ rows) {
+  __shared__ int32_t part[1024];
+  const int tid = threadIdx.x;
+  const int64_t per = (n + 1023) / 1024;
+  const int64_t lo = min(n, (int64_t)tid * per), hi = min(n, lo + per);
+  int32_t s = 0;
+  for (int64_t j = lo; j < hi; ++j) s += cnt[j];
+  part[tid] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int32_t v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int32_t run = 1 + (tid ? part[tid - 1] : 0);
+  for (int64_t j = lo; j < hi; ++j) {
+    base[j] = run;
+    run += cnt[j];
+  }
+  if (tid == 1023) {
+    base[n] = 1 + part[1023];
+    rows[0] = 1 + part[1023];
+    rows[1] = part[1023];
+  }
+}
+
+// One wavefront per node: the slot -> row map, the primary slot of every row, and the operand rows themselves.
+//   narrow: Xc[row] = [efeat[eid] | TE_r(ts_last - ts_t)] (wx = d_e + d) and the one-hot row of the slot's anonymised id
+//           (the weight gradient of the tabulated anony_emb block is a product with it);
+//   WIDE:   Xc[row] = [nfeat[src] | nfeat[dst] | anony_emb[anon] | efeat[eid] | TE_r] (wx = dm).
+template <bool WIDE>
+__global__ void __launch_bounds__(256) k_seq_build_c(tg_model m, tg_seq_restarter r, int64_t n,
+                                                     const int32_t* __restrict__ n_dev, const int64_t* __restrict__ nids,
+                                                     const int64_t* __restrict__ h_n, const int64_t* __restrict__ anon,
+                                                     const int64_t* __restrict__ h_e, const float* __restrict__ h_t,
+                                                     const int64_t* __restrict__ h_d, const int32_t* __restrict__ base,
+                                                     int32_t* __restrict__ slot_row, int32_t* __restrict__ row_slot,
+                                                     float4* __restrict__ Xc, float* __restrict__ oh, int ohw,
+                                                     float* __restrict__ prev_ts) {
   if (n_dev) n = min(n, (int64_t)*n_dev);
   const int H = r.hist_len, d4 = m.d / 4, e4 = m.d_e / 4;
-  const int row4 = 4 * d4 + e4;
-  const int64_t total = n * H * row4;
+  const int wx4 = WIDE ? 4 * d4 + e4 : e4 + d4;
+  const int lane = lane_id();
   const float4* nf = reinterpret_cast<const float4*>(m.nfeats);
   const float4* ef = reinterpret_cast<const float4*>(m.efeats);
   const float4* ae = reinterpret_cast<const float4*>(r.anony_emb);
   const float4* fq = reinterpret_cast<const float4*>(r.te_freq);
   const float4* ph = reinterpret_cast<const float4*>(r.te_phase);
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t rowi = t / row4;
-    const int c = (int)(t - rowi * row4);
-    const int64_t i = rowi / H;
-    const int pos = (int)(rowi - i * H);
-    const bool last = pos == H - 1;
-    float4 v = z;
-    if (c >= 3 * d4 + e4) {
-      const int cc = c - 3 * d4 - e4;
-      const float dt = h_t[i * H + H - 1] - h_t[rowi];
-      const float4 w = fq[cc], q = ph[cc];
-      v = make_float4(time_enc(dt, w.x, q.x), time_enc(dt, w.y, q.y), time_enc(dt, w.z, q.z), time_enc(dt, w.w, q.w));
-    } else if (!last) {
-      if (c < 2 * d4) {
-        if (nf) {
-          const int64_t dir = h_d[rowi];
-          const int64_t self = nids[i], oth = h_n[rowi];
-          // dir == 1: the query node was the destination (graph.py:239-240)
-          const int64_t s_n = dir ? self : oth, d_n = dir ? oth : self;
-          v = c < d4 ? nf[s_n * d4 + c] : nf[d_n * d4 + (c - d4)];
-        }
-      } else if (c < 3 * d4) {
-        v = ae[anon[rowi] * d4 + (c - 2 * d4)];
-      } else if (ef) {
-        v = ef[h_e[rowi] * e4 + (c - 3 * d4)];
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w0 == 0) {  // row 0: the last event of every node, [0 .. 0 | TE(0)]
+    for (int c = lane; c < wx4; c += TG_WAVE) Xc[c] = c >= wx4 - d4 ? seq_te4(fq, ph, 0.f, c - (wx4 - d4)) : z;
+    if (!WIDE)
+      for (int c = lane; c < ohw; c += TG_WAVE) oh[c] = 0.f;
+    if (lane == 0) row_slot[0] = -1;
+  }
+  for (int64_t i = w0; i < n; i += (int64_t)gridDim.x * 4) {
+    const int64_t so = i * H;
+    const int b0 = base[i];
+    int npad = 0, firstpad = -1;
+    for (int t0 = 0; t0 < H - 1; t0 += TG_WAVE) {
+      const int t = t0 + lane;
+      const unsigned long long pm = __ballot(t < H - 1 && h_n[so + t] == 0);
+      if (pm) {
+        if (firstpad < 0) firstpad = t0 + __ffsll((long long)pm) - 1;
+        npad += __popcll(pm);
       }
     }
-    X[t] = v;
-    if (c == 0 && last) prev_ts[i] = h_t[rowi];
+    const int start = b0 + (npad > 0 ? 1 : 0);
+    const float t_last = h_t[so + H - 1];
+    const int64_t self = nids[i];
+    int before = 0;
+    for (int t0 = 0; t0 < H; t0 += TG_WAVE) {
+      const int t = t0 + lane;
+      const bool in = t < H - 1;
+      const bool nz = in && h_n[so + t] != 0;
+      const unsigned long long mask = __ballot(nz);
+      if (t < H) {
+        int row = 0;  // the last slot: the constant row
+        if (nz) row = start + before + __popcll(mask & ((1ull << lane) - 1ull));
+        else if (in) row = b0;
+        slot_row[so + t] = row;
+        if (nz || (in && t == firstpad)) row_slot[row] = (int32_t)(so + t);
+      }
+      // the rows of this chunk's primary slots, one at a time, written by the whole wavefront
+      unsigned long long prim = mask;
+      if (firstpad >= t0 && firstpad < t0 + TG_WAVE) prim |= 1ull << (firstpad - t0);
+      while (prim) {
+        const int b = __ffsll((long long)prim) - 1;
+        prim &= prim - 1ull;
+        const bool pad = !((mask >> b) & 1ull);
+        const int row = pad ? b0 : start + before + __popcll(mask & ((1ull << b) - 1ull));
+        const int64_t s = so + t0 + b;
+        float4* xr = Xc + (int64_t)row * wx4;
+        const float dt = t_last - h_t[s];
+        const int64_t eid = h_e[s];
+        if (WIDE) {
+          const int64_t oth = h_n[s];
+          const bool dir = h_d[s] != 0;  // the query node was the destination (graph.py:239-240)
+          const int64_t s_n = dir ? self : oth, d_n = dir ? oth : self;
+          const int64_t a = anon[s];
+          for (int c = lane; c < wx4; c += TG_WAVE) {
+            float4 v;
+            if (c < d4) v = nf ? nf[s_n * d4 + c] : z;
+            else if (c < 2 * d4) v = nf ? nf[d_n * d4 + (c - d4)] : z;
+            else if (c < 3 * d4) v = ae[a * d4 + (c - 2 * d4)];
+            else if (c < 3 * d4 + e4) v = ef ? ef[eid * e4 + (c - 3 * d4)] : z;
+            else v = seq_te4(fq, ph, dt, c - 3 * d4 - e4);
+            xr[c] = v;
+          }
+        } else {
+          for (int c = lane; c < wx4; c += TG_WAVE) xr[c] = c < e4 ? (ef ? ef[eid * e4 + c] : z) : seq_te4(fq, ph, dt, c - e4);
+          const int a = (int)anon[s];
+          for (int c = lane; c < ohw; c += TG_WAVE) oh[(int64_t)row * ohw + c] = c == a ? 1.f : 0.f;
+        }
+      }
+      before += __popcll(mask);
+    }
+    if (lane == 0) prev_ts[i] = t_last;
   }
 }
 
+// the q / k row of slot (i, row): its compact row, plus (narrow form) the tabulated anony_emb part - not for the last event
+struct SeqRows {
+  const float* qk;              // [rows, 2 dm] compact
+  const int32_t* slot_row;      // [n * H]
+  const float* ta;              // nullable: [H + 1, 2 dm]
+  const int64_t* anon;          // [n * H]
+};
+
 // One block per (node, head): scores = q k^T / sqrt(dh) over the H x H grid, key padding
-// mask, row softmax, column mean.  qk is [n*H, 2*dm] = [q | k].
+// mask, row softmax, column mean.
 template <int HMAX>
-__global__ void __launch_bounds__(256) k_seq_scores(int64_t n, int H, int dm, int nh, const float* __restrict__ qk,
+__global__ void __launch_bounds__(256) k_seq_scores(int64_t n, int H, int dm, int nh, SeqRows sr,
                                                     const int64_t* __restrict__ h_n, float* __restrict__ abar,
                                                     const int32_t* __restrict__ n_dev, DropCfg dc,
                                                     float* __restrict__ rbar) {
@@ -75,20 +192,35 @@ __global__ void __launch_bounds__(256) k_seq_scores(int64_t n, int H, int dm, in
   __shared__ float sq[HMAX][CH + 1], sk[HMAX][CH + 1];
   __shared__ float sc[HMAX][HMAX + 1];
   __shared__ float colm[HMAX];
+  __shared__ int64_t s_off[HMAX], s_toff[HMAX];
   const int64_t i = blockIdx.x / nh;
   const int h = blockIdx.x % nh;
   const int dh = dm / nh;
   const int tid = threadIdx.x;
+  if (tid < H) {
+    s_off[tid] = (int64_t)sr.slot_row[i * H + tid] * 2 * dm + (int64_t)h * dh;
+    s_toff[tid] = (sr.ta && tid != H - 1) ? sr.anon[i * H + tid] * 2 * dm + (int64_t)h * dh : -1;
+  }
+  __syncthreads();
   float acc[PPT];
 #pragma unroll
   for (int j = 0; j < PPT; ++j) acc[j] = 0.f;
-  const float* base = qk + (int64_t)i * H * 2 * dm + (int64_t)h * dh;
   for (int c0 = 0; c0 < dh; c0 += CH) {
     for (int f = tid; f < H * CH; f += 256) {
       const int row = f / CH, cc = f % CH;
-      const bool ok = c0 + cc < dh;
-      sq[row][cc] = ok ? base[(int64_t)row * 2 * dm + c0 + cc] : 0.f;
-      sk[row][cc] = ok ? base[(int64_t)row * 2 * dm + dm + c0 + cc] : 0.f;
+      float q = 0.f, k = 0.f;
+      if (c0 + cc < dh) {
+        const float* b = sr.qk + s_off[row] + c0 + cc;
+        q = b[0];
+        k = b[dm];
+        if (s_toff[row] >= 0) {
+          const float* tb = sr.ta + s_toff[row] + c0 + cc;
+          q += tb[0];
+          k += tb[dm];
+        }
+      }
+      sq[row][cc] = q;
+      sk[row][cc] = k;
     }
     __syncthreads();
 #pragma unroll
@@ -148,9 +280,18 @@ __global__ void __launch_bounds__(256) k_seq_scores(int64_t n, int H, int dm, in
   }
 }
 
-// xbar[i, h, :] = sum_s abar[i, h, s] * X[(i, s), :]
-__global__ void k_seq_mix(int64_t n, int H, int row4, int nh, const float* __restrict__ abar,
-                          const float4* __restrict__ X, float4* __restrict__ xbar, const int32_t* __restrict__ n_dev) {
+// where the columns of the full input row x(i, s) live (see the file header)
+struct SeqCols {
+  const float4* xc;         // compact operand rows
+  int wx4, col0_4;          // their width and first column (float4 units): narrow 3d, wide 0
+  const float4* ae;         // narrow: anony_emb, columns [2d, 3d) of every slot but the last; wide: nullptr (inside xc)
+  const int32_t* slot_row;
+  const int64_t* anon;
+};
+
+// xbar[i, h, :] = sum_s abar[i, h, s] * x(i, s)
+__global__ void k_seq_mix(int64_t n, int H, int row4, int d4, int nh, const float* __restrict__ abar, SeqCols sc,
+                          float4* __restrict__ xbar, const int32_t* __restrict__ n_dev) {
   if (n_dev) n = min(n, (int64_t)*n_dev);
   const int64_t total = n * nh * row4;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -158,10 +299,18 @@ __global__ void k_seq_mix(int64_t n, int H, int row4, int nh, const float* __res
     const int64_t ih = t / row4;
     const int64_t i = ih / nh;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < H; ++s) {
-      const float w = abar[ih * H + s];
-      const float4 x = X[((int64_t)i * H + s) * row4 + c];
-      a.x += w * x.x; a.y += w * x.y; a.z += w * x.z; a.w += w * x.w;
+    if (c >= sc.col0_4 && c < sc.col0_4 + sc.wx4) {
+      for (int s = 0; s < H; ++s) {
+        const float w = abar[ih * H + s];
+        const float4 x = sc.xc[(int64_t)sc.slot_row[i * H + s] * sc.wx4 + (c - sc.col0_4)];
+        a.x += w * x.x; a.y += w * x.y; a.z += w * x.z; a.w += w * x.w;
+      }
+    } else if (sc.ae && c >= 2 * d4 && c < 3 * d4) {
+      for (int s = 0; s < H - 1; ++s) {
+        const float w = abar[ih * H + s];
+        const float4 x = sc.ae[sc.anon[i * H + s] * d4 + (c - 2 * d4)];
+        a.x += w * x.x; a.y += w * x.y; a.z += w * x.z; a.w += w * x.w;
+      }
     }
     xbar[t] = a;
   }
@@ -170,11 +319,11 @@ __global__ void k_seq_mix(int64_t n, int H, int row4, int nh, const float* __res
 // ---------------------------------------------------------------------------------
 // backward kernels (mutual loss, tiger.py:576-590)
 // ---------------------------------------------------------------------------------
-// dabar[i, h, s] = dxbar[i, h, :] . X[(i, s), :]   (one wavefront per (i, h, s))
-__global__ void __launch_bounds__(256) k_seq_mix_bwd(int64_t n, const int32_t* __restrict__ n_dev, int H, int row4,
-                                                     int nh, const float4* __restrict__ dxbar,
-                                                     const float4* __restrict__ X, float* __restrict__ dabar,
-                                                     const float* __restrict__ dO, const float* __restrict__ bv) {
+// dabar[i, h, s] = dxbar[i, h, :] . x(i, s)   (one wavefront per (i, h, s))
+__global__ void __launch_bounds__(256) k_seq_mix_bwd(int64_t n, const int32_t* __restrict__ n_dev, int H, int row4, int d4,
+                                                     int nh, const float4* __restrict__ dxbar, SeqCols sc,
+                                                     float* __restrict__ dabar, const float* __restrict__ dO,
+                                                     const float* __restrict__ bv) {
   // dO / bv non-null (dropout): abar also weights the value bias, d rbar = dO_h . bv_h is added
   if (n_dev) n = min(n, (int64_t)*n_dev);
   const int lane = lane_id();
@@ -184,11 +333,18 @@ __global__ void __launch_bounds__(256) k_seq_mix_bwd(int64_t n, const int32_t* _
     const int64_t ih = t / H;
     const int64_t i = ih / nh;
     const float4* a = dxbar + ih * row4;
-    const float4* b = X + ((int64_t)i * H + sidx) * row4;
+    const float4* b = sc.xc + (int64_t)sc.slot_row[i * H + sidx] * sc.wx4;
     float acc = 0.f;
-    for (int c = lane; c < row4; c += TG_WAVE) {
-      const float4 u = a[c], v = b[c];
+    for (int c = lane; c < sc.wx4; c += TG_WAVE) {
+      const float4 u = a[sc.col0_4 + c], v = b[c];
       acc = fmaf(u.x, v.x, fmaf(u.y, v.y, fmaf(u.z, v.z, fmaf(u.w, v.w, acc))));
+    }
+    if (sc.ae && sidx != H - 1) {
+      const float4* e = sc.ae + sc.anon[i * H + sidx] * d4;
+      for (int c = lane; c < d4; c += TG_WAVE) {
+        const float4 u = a[2 * d4 + c], v = e[c];
+        acc = fmaf(u.x, v.x, fmaf(u.y, v.y, fmaf(u.z, v.z, fmaf(u.w, v.w, acc))));
+      }
     }
     if (dO) {
       const int dm = row4 * 4, dh = dm / nh, h = (int)(ih % nh);
@@ -202,12 +358,14 @@ __global__ void __launch_bounds__(256) k_seq_mix_bwd(int64_t n, const int32_t* _
 // One block per (node, head): recompute the H x H attention (as k_seq_scores), then
 //   dA[t, s] = dabar[s] / H;  dS[t, s] = A[t, s] (dA[t, s] - sum_s' A[t, s'] dA[t, s'])
 //   dq_t = scale sum_s dS[t, s] k_s;   dk_s = scale sum_t dS[t, s] q_t
+// The gradients land on the COMPACT rows: a real slot's on its own row, the padded slots' query gradients summed on the
+// node's padded row (their keys are masked: no key gradient), the last slot's in dqk_last [n, 2 dm] (summed over the nodes
+// into row 0 afterwards).
 template <int HMAX>
 __global__ void __launch_bounds__(256) k_seq_scores_bwd(int64_t n, const int32_t* __restrict__ n_dev, int H, int dm,
-                                                        int nh, const float* __restrict__ qk,
-                                                        const int64_t* __restrict__ h_n,
+                                                        int nh, SeqRows sr, const int64_t* __restrict__ h_n,
                                                         const float* __restrict__ dabar, float* __restrict__ dqk,
-                                                        DropCfg dc) {
+                                                        float* __restrict__ dqk_last, DropCfg dc) {
   if (n_dev && (int64_t)(blockIdx.x / nh) >= (int64_t)*n_dev) return;
   const uint64_t dkey = drop_key(dc);
   constexpr int CH = 32;
@@ -215,21 +373,48 @@ __global__ void __launch_bounds__(256) k_seq_scores_bwd(int64_t n, const int32_t
   constexpr int OPT = (HMAX * CH + 255) / 256;  // (row, column) outputs per thread and chunk
   __shared__ float sq[HMAX][CH + 1], sk[HMAX][CH + 1];
   __shared__ float sc[HMAX][HMAX + 1];
+  __shared__ int64_t s_off[HMAX], s_toff[HMAX];
+  __shared__ uint8_t s_pad[HMAX];
+  __shared__ int s_fp;
   const int64_t i = blockIdx.x / nh;
   const int h = blockIdx.x % nh;
   const int dh = dm / nh;
   const int tid = threadIdx.x;
+  if (tid < H) {
+    s_off[tid] = (int64_t)sr.slot_row[i * H + tid] * 2 * dm + (int64_t)h * dh;
+    s_toff[tid] = (sr.ta && tid != H - 1) ? sr.anon[i * H + tid] * 2 * dm + (int64_t)h * dh : -1;
+    s_pad[tid] = (tid != H - 1) && (h_n[i * H + tid] == 0);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int fp = -1;
+    for (int t = 0; t < H - 1 && fp < 0; ++t)
+      if (s_pad[t]) fp = t;
+    s_fp = fp;
+  }
   float acc[PPT];
 #pragma unroll
   for (int j = 0; j < PPT; ++j) acc[j] = 0.f;
-  const float* base = qk + (int64_t)i * H * 2 * dm + (int64_t)h * dh;
-  for (int c0 = 0; c0 < dh; c0 += CH) {
+  auto stage = [&](int c0) {
     for (int f = tid; f < H * CH; f += 256) {
       const int row = f / CH, cc = f % CH;
-      const bool ok = c0 + cc < dh;
-      sq[row][cc] = ok ? base[(int64_t)row * 2 * dm + c0 + cc] : 0.f;
-      sk[row][cc] = ok ? base[(int64_t)row * 2 * dm + dm + c0 + cc] : 0.f;
+      float q = 0.f, k = 0.f;
+      if (c0 + cc < dh) {
+        const float* b = sr.qk + s_off[row] + c0 + cc;
+        q = b[0];
+        k = b[dm];
+        if (s_toff[row] >= 0) {
+          const float* tb = sr.ta + s_toff[row] + c0 + cc;
+          q += tb[0];
+          k += tb[dm];
+        }
+      }
+      sq[row][cc] = q;
+      sk[row][cc] = k;
     }
+  };
+  for (int c0 = 0; c0 < dh; c0 += CH) {
+    stage(c0);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
@@ -250,8 +435,7 @@ __global__ void __launch_bounds__(256) k_seq_scores_bwd(int64_t n, const int32_t
     const int p = tid + j * 256;
     if (p < H * H) {
       const int t = p / H, s = p % H;
-      const bool masked = (s != H - 1) && (h_n[i * H + s] == 0);
-      sc[t][s] = masked ? -INFINITY : acc[j] * scale;
+      sc[t][s] = s_pad[s] ? -INFINITY : acc[j] * scale;
     }
   }
   __syncthreads();
@@ -281,14 +465,20 @@ __global__ void __launch_bounds__(256) k_seq_scores_bwd(int64_t n, const int32_t
     for (int s = 0; s < H; ++s) sc[tid][s] = sc[tid][s] * (dA(s) - dot) * scale;
   }
   __syncthreads();
-  float* ob = dqk + (int64_t)i * H * 2 * dm + (int64_t)h * dh;
+  // the padded query rows share one operand row: fold their dS rows into the first of them, in slot order
+  const int fp = s_fp;
+  if (fp >= 0 && tid < H) {
+    float a = sc[fp][tid];
+    for (int t = fp + 1; t < H - 1; ++t)
+      if (s_pad[t]) {
+        a += sc[t][tid];
+        sc[t][tid] = 0.f;
+      }
+    sc[fp][tid] = a;
+  }
+  __syncthreads();
   for (int c0 = 0; c0 < dh; c0 += CH) {
-    for (int f = tid; f < H * CH; f += 256) {
-      const int row = f / CH, cc = f % CH;
-      const bool ok = c0 + cc < dh;
-      sq[row][cc] = ok ? base[(int64_t)row * 2 * dm + c0 + cc] : 0.f;
-      sk[row][cc] = ok ? base[(int64_t)row * 2 * dm + dm + c0 + cc] : 0.f;
-    }
+    stage(c0);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < OPT; ++j) {
@@ -300,9 +490,10 @@ __global__ void __launch_bounds__(256) k_seq_scores_bwd(int64_t n, const int32_t
           dq = fmaf(sc[row][s], sk[s][cc], dq);
           dk = fmaf(sc[s][row], sq[s][cc], dk);
         }
-        if (c0 + cc < dh) {
-          ob[(int64_t)row * 2 * dm + c0 + cc] = dq;
-          ob[(int64_t)row * 2 * dm + dm + c0 + cc] = dk;
+        if (c0 + cc < dh && (!s_pad[row] || row == fp)) {
+          float* ob = (row == H - 1 ? dqk_last + i * 2 * dm + (int64_t)h * dh : dqk + s_off[row]) + c0 + cc;
+          ob[0] = dq;
+          ob[dm] = dk;
         }
       }
     }
@@ -312,17 +503,24 @@ __global__ void __launch_bounds__(256) k_seq_scores_bwd(int64_t n, const int32_t
 
 // gradient of the input rows that carry parameters: the anonymised-position embedding
 // (columns [2d, 3d), not for the zeroed last event) and the restarter's TimeEncode (last d
-// columns).  dX = dXs (from the q/k projection) + sum_h abar_h dxbar_h (from the value mix).
+// columns).  dX = dXs (from the q/k projection, per COMPACT row: taken by the row's primary slot - the constant row's by
+// the last slot of node 0) + sum_h abar_h dxbar_h (from the value mix, per slot).  Narrow form: the q/k projection's
+// anony_emb gradient goes through the table T_a (k_seq_anon_grads), dXs holds the TimeEncode block only (ldx = d);
+// wide form: dXs = [anony_emb block | TimeEncode block] (ldx = 2d).
 __global__ void __launch_bounds__(256) k_seq_build_bwd(tg_model m, tg_seq_restarter r, int64_t n,
                                                        const int32_t* __restrict__ n_dev,
                                                        const int64_t* __restrict__ anon, const float* __restrict__ h_t,
-                                                       const float* __restrict__ dXs, const float* __restrict__ abar,
+                                                       const int32_t* __restrict__ slot_row,
+                                                       const int32_t* __restrict__ row_slot,
+                                                       const float* __restrict__ dXs, int wide,
+                                                       const float* __restrict__ abar,
                                                        const float* __restrict__ dxbar, int use_lds,
                                                        float* __restrict__ danon, float* __restrict__ dfreq,
                                                        float* __restrict__ dphase) {
   extern __shared__ float lacc[];  // [2, d] TimeEncode grads, then [(H + 1), d] embedding grads when use_lds
   if (n_dev) n = min(n, (int64_t)*n_dev);
   const int H = r.hist_len, d = m.d, dm = 4 * d + m.d_e, nh = r.n_head;
+  const int ldx = wide ? 2 * d : d, tcol = wide ? d : 0;
   const int nl = 2 * d + (use_lds ? (H + 1) * d : 0);
   for (int c = threadIdx.x; c < nl; c += 256) lacc[c] = 0.f;
   __syncthreads();
@@ -334,7 +532,13 @@ __global__ void __launch_bounds__(256) k_seq_build_bwd(tg_model m, tg_seq_restar
     const int64_t row = t / d;
     const int64_t i = row / H;
     const int pos = (int)(row - i * H);
-    float ga = dXs[row * 2 * d + c], gt = dXs[row * 2 * d + d + c];
+    const int32_t cr = slot_row[row];
+    const bool primary = pos == H - 1 ? i == 0 : row_slot[cr] == (int32_t)row;
+    float ga = 0.f, gt = 0.f;
+    if (primary) {
+      gt = dXs[(int64_t)cr * ldx + tcol + c];
+      if (wide) ga = dXs[(int64_t)cr * ldx + c];
+    }
     for (int h = 0; h < nh; ++h) {
       const float w = abar[((int64_t)i * nh + h) * H + pos];
       const float* dx = dxbar + ((int64_t)i * nh + h) * dm;
@@ -358,6 +562,29 @@ __global__ void __launch_bounds__(256) k_seq_build_bwd(tg_model m, tg_seq_restar
   }
   if (use_lds)
     for (int c = threadIdx.x; c < (H + 1) * d; c += 256) atomicAdd(danon + c, lan[c]);
+}
+
+// narrow form: T_a = anony_emb Wa^T with Wa = in_proj_w[0:2dm, 2d:3d].  dTaT [2 dm, ohw] = d T_a^T (the product of the
+// row gradients with the one-hot rows).  d anony_emb[a, j] += sum_c dTaT[c, a] Wa[c, j];  d Wa[c, j] += sum_a dTaT[c, a] ae[a, j].
+// Every output has one owner and a fixed summation order.
+__global__ void __launch_bounds__(256) k_seq_anon_grads(int H1, int d, int dm, int ohw, const float* __restrict__ dTaT,
+                                                        const float* __restrict__ w_in, const float* __restrict__ ae,
+                                                        float* __restrict__ g_ae, float* __restrict__ g_w) {
+  const int64_t nA = (int64_t)H1 * d, nB = (int64_t)2 * dm * d;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nA + nB; t += (int64_t)gridDim.x * blockDim.x) {
+    if (t < nA) {
+      const int a = (int)(t / d), j = (int)(t % d);
+      float acc = 0.f;
+      for (int c = 0; c < 2 * dm; ++c) acc = fmaf(dTaT[(int64_t)c * ohw + a], w_in[(int64_t)c * dm + 2 * d + j], acc);
+      g_ae[t] += acc;
+    } else {
+      const int64_t u = t - nA;
+      const int c = (int)(u / d), j = (int)(u % d);
+      float acc = 0.f;
+      for (int a = 0; a < H1; ++a) acc = fmaf(dTaT[(int64_t)c * ohw + a], ae[(int64_t)a * d + j], acc);
+      g_w[(int64_t)c * dm + 2 * d + j] += acc;
+    }
+  }
 }
 
 // mutual loss (tiger.py:582-590): MSE over the rows of cat[sur_left, sur_right] whose target
@@ -496,20 +723,46 @@ __global__ void k_restart_pad(int64_t cap, const int32_t* __restrict__ n_dev, in
 }
 
 struct SeqWs {
-  float *x, *qk, *abar, *xbar, *o, *om, *t2, *rbar;
+  float *xc, *qk, *abar, *xbar, *o, *om, *t2, *rbar, *ta, *oh;
+  int32_t *cnt, *base, *slot_row, *row_slot, *rows;  // the compact-row plan (see the file header); rows = {live rows, ...}
+  int64_t rowcap;
+  int wx, ohw;
+  bool wide;
 };
+
+// wide form (all five column blocks in the compact operand): a node-feature table that is not known to be all zeros
+static bool seq_wide(const tg_model* m, const tg_seq_restarter* r) { return m->nfeats && !r->nfeats_zero; }
 
 static bool carve_seq(const tg_model* m, const tg_seq_restarter* r, int64_t n, Carver& cv, SeqWs& w, bool keep_t2) {
   const size_t dm = 4 * (size_t)m->d + m->d_e, H = r->hist_len, nh = r->n_head;
-  w.x = cv.take<float>(n * H * dm);
-  w.qk = cv.take<float>(n * H * 2 * dm);
+  w.wide = seq_wide(m, r);
+  w.rowcap = n * (int64_t)H + 1;
+  w.wx = w.wide ? (int)dm : m->d_e + m->d;
+  w.ohw = (int)((H + 1 + 3) & ~(size_t)3);
+  w.xc = cv.take<float>((size_t)w.rowcap * w.wx);
+  w.qk = cv.take<float>((size_t)w.rowcap * 2 * dm);
   w.abar = cv.take<float>(n * nh * H);
   w.xbar = cv.take<float>(n * nh * dm);
   w.o = cv.take<float>(n * dm);
   w.om = cv.take<float>(n * dm);
   w.t2 = keep_t2 ? cv.take<float>(n * (size_t)m->d) : w.om;
   w.rbar = keep_t2 ? cv.take<float>(n * nh) : nullptr;
+  w.ta = w.wide ? nullptr : cv.take<float>((H + 1) * 2 * dm);
+  w.oh = w.wide ? nullptr : cv.take<float>((size_t)w.rowcap * w.ohw);
+  w.cnt = cv.take<int32_t>(n);
+  w.base = cv.take<int32_t>(n + 1);
+  w.slot_row = cv.take<int32_t>(n * H);
+  w.row_slot = cv.take<int32_t>((size_t)w.rowcap);
+  w.rows = cv.take<int32_t>(4);
   return cv.ok;
+}
+
+// bytes a carve takes: a dry run over an address range that is never touched
+template <typename F>
+static size_t carve_bytes(F&& carve) {
+  Carver cv(reinterpret_cast<void*>((uintptr_t)256), ~(size_t)0 >> 1);
+  carve(cv);
+  return (~(size_t)0 >> 1) - cv.left;
 }
 
 static int seq_ok(const tg_model* m, const tg_seq_restarter* r) {
@@ -520,34 +773,51 @@ static int seq_ok(const tg_model* m, const tg_seq_restarter* r) {
   return 1;
 }
 
-// forward on `cap` rows of which the first *n_dev (nullable: all) are live; counts2 = {n, n*H} on device
-static int seq_forward(const tg_model* m, const tg_seq_restarter* r, int64_t n, const int32_t* counts2,
+// forward on `cap` rows of which the first *n_dev (nullable: all) are live
+static int seq_forward(const tg_model* m, const tg_seq_restarter* r, int64_t n, const int32_t* n_dev,
                        const int64_t* nids, const int64_t* h_n, const int64_t* anon, const int64_t* h_e,
                        const float* h_t, const int64_t* h_d, float* h_left, float* h_right, float* prev_ts,
                        const SeqWs& w, hipStream_t st, const DropCfg& dc = DropCfg{}) {
   const int d = m->d, dm = 4 * m->d + m->d_e, H = r->hist_len, nh = r->n_head, dh = dm / nh;
-  const int32_t* n_dev = counts2;
-  const int32_t* nH_dev = counts2 ? counts2 + 1 : nullptr;
-  hipLaunchKernelGGL(k_seq_build, dim3(flat_grid(n * H * (dm / 4), 256)), dim3(256), 0, st, *m, *r, n, nids, h_n, anon,
-                     h_e, h_t, h_d, (float4*)w.x, prev_ts, n_dev);
+  if ((int64_t)n * H >= ((int64_t)1 << 31) - 1) return TG_EUNSUPPORTED;  // slot indices are int32
+  const unsigned nwg = (unsigned)std::min<int64_t>(cdiv(n, 4), 4096);
+  hipLaunchKernelGGL(k_seq_count, dim3(nwg), dim3(256), 0, st, n, n_dev, H, h_n, w.cnt);
+  hipLaunchKernelGGL(k_seq_scan, dim3(1), dim3(1024), 0, st, n, w.cnt, w.base, w.rows);
+  if (w.wide)
+    hipLaunchKernelGGL((k_seq_build_c<true>), dim3(nwg), dim3(256), 0, st, *m, *r, n, n_dev, nids, h_n, anon, h_e, h_t, h_d,
+                       w.base, w.slot_row, w.row_slot, (float4*)w.xc, w.oh, w.ohw, prev_ts);
+  else
+    hipLaunchKernelGGL((k_seq_build_c<false>), dim3(nwg), dim3(256), 0, st, *m, *r, n, n_dev, nids, h_n, anon, h_e, h_t, h_d,
+                       w.base, w.slot_row, w.row_slot, (float4*)w.xc, w.oh, w.ohw, prev_ts);
   int rc;
   GemmArgs g{};
-  // [q | k] = X Win[0:2dm]^T + b[0:2dm]
-  g.m_cap = n * H; g.m_dev = nH_dev; g.n = 2 * dm; g.k = dm; g.a0 = ASeg{w.x, dm, dm, nullptr};
-  g.w = r->in_proj_w; g.ldw = dm; g.bias = r->in_proj_b; g.c = w.qk; g.ldc = 2 * dm; g.alpha = 1.f; g.nbatch = 1;
+  const int off = w.wide ? 0 : 2 * d;   // first column of the value operand that can be non-zero
+  const int col0 = w.wide ? 0 : 3 * d;  // first column of the compact operand
+  if (!w.wide) {  // T_a = anony_emb Wqk[:, 2d:3d]^T (no bias: it rides on the compact product)
+    g.m_cap = H + 1; g.n = 2 * dm; g.k = d; g.a0 = ASeg{r->anony_emb, d, d, nullptr};
+    g.w = r->in_proj_w + 2 * d; g.ldw = dm; g.c = w.ta; g.ldc = 2 * dm; g.alpha = 1.f; g.nbatch = 1;
+    if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  }
+  // [q | k] of the compact rows = Xc Win[0:2dm, col0:]^T + b[0:2dm]
+  g = GemmArgs{};
+  g.m_cap = w.rowcap; g.m_dev = w.rows; g.n = 2 * dm; g.k = w.wx; g.a0 = ASeg{w.xc, w.wx, w.wx, nullptr};
+  g.w = r->in_proj_w + col0; g.ldw = dm; g.bias = r->in_proj_b; g.c = w.qk; g.ldc = 2 * dm; g.alpha = 1.f; g.nbatch = 1;
   if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  const SeqRows sr{w.qk, w.slot_row, w.ta, anon};
   if (H <= 40)
-    hipLaunchKernelGGL((k_seq_scores<40>), dim3((unsigned)(n * nh)), dim3(256), 0, st, n, H, dm, nh, w.qk, h_n, w.abar,
+    hipLaunchKernelGGL((k_seq_scores<40>), dim3((unsigned)(n * nh)), dim3(256), 0, st, n, H, dm, nh, sr, h_n, w.abar,
                        n_dev, dc, w.rbar);
   else
-    hipLaunchKernelGGL((k_seq_scores<64>), dim3((unsigned)(n * nh)), dim3(256), 0, st, n, H, dm, nh, w.qk, h_n, w.abar,
+    hipLaunchKernelGGL((k_seq_scores<64>), dim3((unsigned)(n * nh)), dim3(256), 0, st, n, H, dm, nh, sr, h_n, w.abar,
                        n_dev, dc, w.rbar);
-  hipLaunchKernelGGL(k_seq_mix, dim3(flat_grid(n * nh * (dm / 4), 256)), dim3(256), 0, st, n, H, dm / 4, nh, w.abar,
-                     (const float4*)w.x, (float4*)w.xbar, n_dev);
-  // o[:, h] = Wv_h xbar_h + bv_h
+  const SeqCols sc{(const float4*)w.xc, w.wx / 4, col0 / 4, w.wide ? nullptr : (const float4*)r->anony_emb, w.slot_row, anon};
+  hipLaunchKernelGGL(k_seq_mix, dim3(flat_grid(n * nh * (dm / 4), 256)), dim3(256), 0, st, n, H, dm / 4, d / 4, nh, w.abar,
+                     sc, (float4*)w.xbar, n_dev);
+  // o[:, h] = Wv_h xbar_h + bv_h   (narrow form: the first 2d columns of xbar are zeros and are skipped)
   g = GemmArgs{};
-  g.m_cap = n; g.m_dev = n_dev; g.n = dh; g.k = dm; g.a0 = ASeg{w.xbar, (int64_t)nh * dm, dm, nullptr}; g.a0_bs = dm;
-  g.w = r->in_proj_w + (int64_t)2 * dm * dm; g.ldw = dm; g.w_bs = (int64_t)dh * dm;
+  g.m_cap = n; g.m_dev = n_dev; g.n = dh; g.k = dm - off; g.a0 = ASeg{w.xbar + off, (int64_t)nh * dm, dm - off, nullptr};
+  g.a0_bs = dm;
+  g.w = r->in_proj_w + (int64_t)2 * dm * dm + off; g.ldw = dm; g.w_bs = (int64_t)dh * dm;
   g.bias = r->in_proj_b + 2 * dm; g.bias_bs = dh; g.c = w.o; g.ldc = dm; g.c_bs = dh; g.alpha = 1.f; g.nbatch = nh;
   if (dc.p > 0.f && w.rbar) { g.bias_rs = w.rbar; g.ld_brs = nh; }
   if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
@@ -584,7 +854,7 @@ static int seq_forward(const tg_model* m, const tg_seq_restarter* r, int64_t n, 
 struct MutualWs {
   double *ts2, *tu;
   int64_t *uniq, *index, *h_n, *h_e, *h_d, *anon;
-  float *h_t, *sl, *sr, *prev_ts, *dsl, *dsr, *dt2, *dom, *dO, *dOm, *dxbar, *dabar, *dqk, *dXs, *acc;
+  float *h_t, *sl, *sr, *prev_ts, *dsl, *dsr, *dt2, *dom, *dO, *dOm, *dxbar, *dabar, *dqk, *dqk_last, *dXs, *dTaT, *acc;
   int32_t *count, *counts2;
   uint8_t* valid;
   void* sel_ws;
@@ -623,25 +893,21 @@ static bool carve_mutual(const tg_model* m, const tg_seq_restarter* r, int64_t B
     w.dOm = cv.take<float>(n * nh * dm);
     w.dxbar = cv.take<float>(n * nh * dm);
     w.dabar = cv.take<float>(n * nh * H);
-    w.dqk = cv.take<float>(n * H * 2 * dm);
-    w.dXs = cv.take<float>(n * H * 2 * d);
     if (!carve_seq(m, r, n, cv, w.seq, true)) return false;
+    w.dqk = cv.take<float>((size_t)w.seq.rowcap * 2 * dm);
+    w.dqk_last = cv.take<float>(n * 2 * dm);
+    w.dXs = cv.take<float>((size_t)w.seq.rowcap * (w.seq.wide ? 2 : 1) * d);
+    w.dTaT = w.seq.wide ? nullptr : cv.take<float>(2 * dm * (size_t)w.seq.ohw);
   }
   return cv.ok;
 }
 
 size_t mutual_ws_bytes(const tg_model* m, const tg_seq_restarter* r, int64_t B) {
-  const size_t n = 2 * (size_t)B, d = m->d;
-  size_t b = align16(n * 8) * 4 + 32 + align16(n * d * 4) * 4 + align16(2 * n) + 16 +
-             align16(tg_select_latest_workspace_bytes(n, m->n_nodes));
-  if (r) {
-    const size_t H = r->hist_len, dm = 4 * d + m->d_e, nh = r->n_head;
-    b += align16(n * H * 8) * 4 + align16(n * H * 4) + align16(n * 4) + align16(n * d * 4) + align16(n * dm * 4) * 2 +
-         align16(n * nh * dm * 4) * 2 + align16(n * nh * H * 4) + align16(n * H * 2 * dm * 4) + align16(n * H * 2 * d * 4);
-    b += align16(n * H * dm * 4) + align16(n * H * 2 * dm * 4) + align16(n * nh * H * 4) + align16(n * nh * dm * 4) +
-         2 * align16(n * dm * 4) + align16(n * d * 4) + align16(n * nh * 4);
-  }
-  return b + 256;
+  return carve_bytes([&](Carver& cv) {
+           MutualWs w{};
+           carve_mutual(m, r, B, cv, w);
+         }) +
+         256;
 }
 
 // Mutual loss and its gradients (tiger.py:574-590), after STEP 4/5 produced the targets
@@ -696,8 +962,9 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
   // ---- SeqRestarter backward
   const int dm = 4 * d + m->d_e, nh = r->n_head;
   const int32_t* n_dev = w.counts2;
-  const int32_t* nH_dev = w.counts2 + 1;
   const SeqWs& q = w.seq;
+  const int32_t* rows_dev = q.rows;
+  const int off = q.wide ? 0 : 2 * d, col0 = q.wide ? 0 : 3 * d;
   TnArgs tn{};
   GemmArgs ga{};
   auto tn_base = [&](int64_t cap, const int32_t* md) {
@@ -746,48 +1013,68 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
   if ((rc = gemm_launch(ga, st)) != TG_OK) return rc;
   // value projection per head.  dh = dm / nh need not be a multiple of 4 (d = 172: dh = 430), so the
   // head slices of dO cannot be addressed as aligned sub-matrices; instead each head uses a copy of
-  // dO with the other heads' columns zeroed and full-width (K = dm) products.
+  // dO with the other heads' columns zeroed and full-width (K = dm) products.  Narrow form: the first 2d input columns
+  // are zeros - no weight gradient there, and their input gradient is not needed.
   hipLaunchKernelGGL(k_head_mask, dim3(flat_grid(n * dm, 256)), dim3(256), 0, st, n, n_dev, dm, nh, w.dO, w.dOm);
   for (int h = 0; h < nh; ++h) {
     const float* dOh = w.dOm + (int64_t)h * n * dm;
     tn = tn_base(n, n_dev);
-    tn.n = dm; tn.k = dm; tn.y = dOh; tn.ldy = dm; tn.x0 = ASeg{q.xbar + (int64_t)h * dm, (int64_t)nh * dm, dm, nullptr};
-    tn.out = F(gr->in_proj_w) + (int64_t)2 * dm * dm; tn.ldo = dm; tn.bias_out = F(gr->in_proj_b) + 2 * dm;
+    tn.n = dm; tn.k = dm - off; tn.y = dOh; tn.ldy = dm;
+    tn.x0 = ASeg{q.xbar + (int64_t)h * dm + off, (int64_t)nh * dm, dm - off, nullptr};
+    tn.out = F(gr->in_proj_w) + (int64_t)2 * dm * dm + off; tn.ldo = dm; tn.bias_out = F(gr->in_proj_b) + 2 * dm;
     if (dc.p > 0.f) { tn.bias_rs = q.rbar; tn.ld_brs = nh; tn.brs_col = h; }
     if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
     ga = GemmArgs{};
-    ga.m_cap = n; ga.m_dev = n_dev; ga.n = dm; ga.k = dm; ga.a0 = ASeg{dOh, dm, dm, nullptr};
-    ga.w = r->in_proj_w + (int64_t)2 * dm * dm; ga.ldw = dm; ga.w_kmajor = 1;
-    ga.c = w.dxbar + (int64_t)h * dm; ga.ldc = (int64_t)nh * dm; ga.alpha = 1.f; ga.nbatch = 1;
+    ga.m_cap = n; ga.m_dev = n_dev; ga.n = dm - off; ga.k = dm; ga.a0 = ASeg{dOh, dm, dm, nullptr};
+    ga.w = r->in_proj_w + (int64_t)2 * dm * dm + off; ga.ldw = dm; ga.w_kmajor = 1;
+    ga.c = w.dxbar + (int64_t)h * dm + off; ga.ldc = (int64_t)nh * dm; ga.alpha = 1.f; ga.nbatch = 1;
     if ((rc = gemm_launch(ga, st)) != TG_OK) return rc;
   }
   // value mix and attention scores
-  hipLaunchKernelGGL(k_seq_mix_bwd, dim3(flat_grid(n * nh * H, 4)), dim3(256), 0, st, n, n_dev, H, dm / 4, nh,
-                     (const float4*)w.dxbar, (const float4*)q.x, w.dabar, dc.p > 0.f ? w.dO : (const float*)nullptr,
+  const SeqCols sc{(const float4*)q.xc, q.wx / 4, col0 / 4, q.wide ? nullptr : (const float4*)r->anony_emb, q.slot_row, w.anon};
+  hipLaunchKernelGGL(k_seq_mix_bwd, dim3(flat_grid(n * nh * H, 4)), dim3(256), 0, st, n, n_dev, H, dm / 4, d / 4, nh,
+                     (const float4*)w.dxbar, sc, w.dabar, dc.p > 0.f ? w.dO : (const float*)nullptr,
                      r->in_proj_b + 2 * dm);
+  const SeqRows sr{q.qk, q.slot_row, q.ta, w.anon};
   if (H <= 40)
-    hipLaunchKernelGGL((k_seq_scores_bwd<40>), dim3((unsigned)(n * nh)), dim3(256), 0, st, n, n_dev, H, dm, nh, q.qk,
-                       w.h_n, w.dabar, w.dqk, dc);
+    hipLaunchKernelGGL((k_seq_scores_bwd<40>), dim3((unsigned)(n * nh)), dim3(256), 0, st, n, n_dev, H, dm, nh, sr,
+                       w.h_n, w.dabar, w.dqk, w.dqk_last, dc);
   else
-    hipLaunchKernelGGL((k_seq_scores_bwd<64>), dim3((unsigned)(n * nh)), dim3(256), 0, st, n, n_dev, H, dm, nh, q.qk,
-                       w.h_n, w.dabar, w.dqk, dc);
-  // q/k projection
-  tn = tn_base(n * H, nH_dev);
-  tn.n = 2 * dm; tn.k = dm; tn.y = w.dqk; tn.ldy = 2 * dm; tn.x0 = ASeg{q.x, dm, dm, nullptr};
-  tn.out = F(gr->in_proj_w); tn.ldo = dm; tn.bias_out = F(gr->in_proj_b);
+    hipLaunchKernelGGL((k_seq_scores_bwd<64>), dim3((unsigned)(n * nh)), dim3(256), 0, st, n, n_dev, H, dm, nh, sr,
+                       w.h_n, w.dabar, w.dqk, w.dqk_last, dc);
+  // row 0 (the last event of every node) collects the last slots' gradients
+  if ((rc = colsum_launch(n, n_dev, 2 * dm, w.dqk_last, 2 * dm, 1.f, w.dqk, 0, part, part_floats, st)) != TG_OK) return rc;
+  // q/k projection: weight columns [col0, dm), bias
+  tn = tn_base(q.rowcap, rows_dev);
+  tn.n = 2 * dm; tn.k = q.wx; tn.y = w.dqk; tn.ldy = 2 * dm; tn.x0 = ASeg{q.xc, q.wx, q.wx, nullptr};
+  tn.out = F(gr->in_proj_w) + col0; tn.ldo = dm; tn.bias_out = F(gr->in_proj_b);
   if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
-  // input-row gradients, only for the two column blocks that carry parameters
+  // input-row gradients, only for the column blocks that carry parameters
+  const int ldx = q.wide ? 2 * d : d;
   ga = GemmArgs{};
-  ga.m_cap = n * H; ga.m_dev = nH_dev; ga.n = d; ga.k = 2 * dm; ga.a0 = ASeg{w.dqk, 2 * dm, 2 * dm, nullptr};
-  ga.w = r->in_proj_w + 2 * d; ga.ldw = dm; ga.w_kmajor = 1; ga.c = w.dXs; ga.ldc = 2 * d; ga.alpha = 1.f; ga.nbatch = 1;
+  ga.m_cap = q.rowcap; ga.m_dev = rows_dev; ga.n = d; ga.k = 2 * dm; ga.a0 = ASeg{w.dqk, 2 * dm, 2 * dm, nullptr};
+  ga.w = r->in_proj_w + 3 * d + m->d_e; ga.ldw = dm; ga.w_kmajor = 1; ga.c = w.dXs + (q.wide ? d : 0); ga.ldc = ldx;
+  ga.alpha = 1.f; ga.nbatch = 1;
   if ((rc = gemm_launch(ga, st)) != TG_OK) return rc;
-  ga.w = r->in_proj_w + 3 * d + m->d_e; ga.c = w.dXs + d;
-  if ((rc = gemm_launch(ga, st)) != TG_OK) return rc;
+  if (q.wide) {
+    ga.w = r->in_proj_w + 2 * d; ga.c = w.dXs;
+    if ((rc = gemm_launch(ga, st)) != TG_OK) return rc;
+  } else {
+    // the tabulated anony_emb block: d T_a^T = dqk^T onehot, then the two small products through the table
+    tn = tn_base(q.rowcap, rows_dev);
+    tn.accumulate = 0; tn.bias_accumulate = 0;
+    tn.n = 2 * dm; tn.k = q.ohw; tn.y = w.dqk; tn.ldy = 2 * dm; tn.x0 = ASeg{q.oh, q.ohw, q.ohw, nullptr};
+    tn.out = w.dTaT; tn.ldo = q.ohw;
+    if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+    hipLaunchKernelGGL(k_seq_anon_grads, dim3(flat_grid((int64_t)(H + 1) * d + (int64_t)2 * dm * d, 256)), dim3(256), 0, st,
+                       H + 1, d, dm, q.ohw, w.dTaT, r->in_proj_w, r->anony_emb, F(gr->anony_emb), F(gr->in_proj_w));
+  }
   const size_t lfull = (size_t)(2 * d + (H + 1) * d) * sizeof(float);
   const int use_lds = lfull <= 60 * 1024;
   hipLaunchKernelGGL(k_seq_build_bwd, dim3(std::min<unsigned>(flat_grid(n * H * d, 256), 512)), dim3(256),
-                     use_lds ? lfull : (size_t)2 * d * sizeof(float), st, *m, *r, n, n_dev, w.anon, w.h_t, w.dXs, q.abar,
-                     w.dxbar, use_lds, F(gr->anony_emb), F(gr->te_freq), F(gr->te_phase));
+                     use_lds ? lfull : (size_t)2 * d * sizeof(float), st, *m, *r, n, n_dev, w.anon, w.h_t, q.slot_row,
+                     q.row_slot, w.dXs, q.wide ? 1 : 0, q.abar, w.dxbar, use_lds, F(gr->anony_emb), F(gr->te_freq),
+                     F(gr->te_phase));
   return check_launch("mutual_step(seq)");
 }
 
@@ -797,9 +1084,11 @@ using namespace tg;
 
 extern "C" size_t tg_restart_seq_workspace_bytes(const tg_model* m, const tg_seq_restarter* r, int64_t n) {
   if (!seq_ok(m, r) || n < 0) return 0;
-  const size_t dm = 4 * (size_t)m->d + m->d_e, H = r->hist_len, nh = r->n_head;
-  return align16(n * H * dm * 4) + align16(n * H * 2 * dm * 4) + align16(n * nh * H * 4) + align16(n * nh * dm * 4) +
-         2 * align16(n * dm * 4) + align16(n * (size_t)m->d * 4) + align16(n * nh * 4) + 64;
+  return carve_bytes([&](Carver& cv) {
+           SeqWs w{};
+           carve_seq(m, r, n, cv, w, true);
+         }) +
+         64;
 }
 
 extern "C" int tg_restart_seq_fwd(const tg_model* m, const tg_seq_restarter* r, int64_t n, const int64_t* nids,

@@ -41,6 +41,19 @@ class NumericalFeature(nn.Module):
         self.nfeat_dim = nd if nd else dim
         self.efeat_dim = ed if ed else dim
 
+    def nfeats_all_zero(self) -> bool:
+        """True when there is no node-feature table or every entry of it is zero (every JODIE data set).  Checked once per
+        table version (one reduction); consumers may then skip the table's column blocks (tg_seq_restarter.nfeats_zero)."""
+        t = self.nfeats
+        if t is None:
+            return True
+        key = (t.data_ptr(), t._version, tuple(t.shape))
+        hit = getattr(self, '_nz_cache', None)
+        if hit is None or hit[0] != key:
+            hit = (key, not bool(torch.count_nonzero(t).item()))
+            self._nz_cache = hit
+        return hit[1]
+
     def _lookup(self, table, ids, width):
         if table is None:
             return torch.zeros(*ids.shape, width, device=ids.device)

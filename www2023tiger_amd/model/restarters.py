@@ -47,7 +47,8 @@ class SeqRestarter(Restarter):
         return TgSeqRestarter(self.hist_len, self.n_head, ptr(self.time_encoder.basis_freq),
                               ptr(self.time_encoder.phase), ptr(self.anony_emb.weight),
                               ptr(self.mha_fn.in_proj_weight), ptr(self.mha_fn.in_proj_bias),
-                              lin(self.mha_fn.out_proj), lin(self.out_fn), lin(self.merger.fc1), lin(self.merger.fc2))
+                              lin(self.mha_fn.out_proj), lin(self.out_fn), lin(self.merger.fc1), lin(self.merger.fc2),
+                              1 if self.raw_feat_getter.nfeats_all_zero() else 0, 0)
 
     def forward(self, nids: Tensor, ts: Tensor, computation_graph=None) -> Tuple[Tensor, Tensor, Tensor]:
         """restarters.py:51-114: surrogate h(t'-), h(t'+) and t' from the last hist_len events."""
