@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(1024) k_seq_scan(int64_t n, const int32_t* __r
   }
 }
 
-// One wavefront per node: the slot -> row map, the primary slot of every row, and the operand rows themselves.
+// One block per node: the slot -> row map, the primary slot of every row, and the operand rows themselves.
 //   narrow: Xc[row] = [efeat[eid] | TE_r(ts_last - ts_t)] (wx = d_e + d) and the one-hot row of the slot's anonymised id
 //           (the weight gradient of the tabulated anony_emb block is a product with it);
 //   WIDE:   Xc[row] = [nfeat[src] | nfeat[dst] | anony_emb[anon] | efeat[eid] | TE_r] (wx = dm).
@@ -97,14 +97,15 @@ __global__ void __launch_bounds__(256) k_seq_build_c(tg_model m, tg_seq_restarte
   const float4* fq = reinterpret_cast<const float4*>(r.te_freq);
   const float4* ph = reinterpret_cast<const float4*>(r.te_phase);
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (w0 == 0) {  // row 0: the last event of every node, [0 .. 0 | TE(0)]
+  const int wv = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && wv == 0) {  // row 0: the last event of every node, [0 .. 0 | TE(0)]
     for (int c = lane; c < wx4; c += TG_WAVE) Xc[c] = c >= wx4 - d4 ? seq_te4(fq, ph, 0.f, c - (wx4 - d4)) : z;
     if (!WIDE)
       for (int c = lane; c < ohw; c += TG_WAVE) oh[c] = 0.f;
     if (lane == 0) row_slot[0] = -1;
   }
-  for (int64_t i = w0; i < n; i += (int64_t)gridDim.x * 4) {
+  // one BLOCK per node: every wavefront derives the map (a few ballots), wavefront 0 stores it, the rows are dealt to the four
+  for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
     const int64_t so = i * H;
     const int b0 = base[i];
     int npad = 0, firstpad = -1;
@@ -119,25 +120,26 @@ __global__ void __launch_bounds__(256) k_seq_build_c(tg_model m, tg_seq_restarte
     const int start = b0 + (npad > 0 ? 1 : 0);
     const float t_last = h_t[so + H - 1];
     const int64_t self = nids[i];
-    int before = 0;
+    int before = 0, deal = 0;
     for (int t0 = 0; t0 < H; t0 += TG_WAVE) {
       const int t = t0 + lane;
       const bool in = t < H - 1;
       const bool nz = in && h_n[so + t] != 0;
       const unsigned long long mask = __ballot(nz);
-      if (t < H) {
+      if (wv == 0 && t < H) {
         int row = 0;  // the last slot: the constant row
         if (nz) row = start + before + __popcll(mask & ((1ull << lane) - 1ull));
         else if (in) row = b0;
         slot_row[so + t] = row;
         if (nz || (in && t == firstpad)) row_slot[row] = (int32_t)(so + t);
       }
-      // the rows of this chunk's primary slots, one at a time, written by the whole wavefront
+      // the rows of this chunk's primary slots, one at a time, each written by one wavefront
       unsigned long long prim = mask;
       if (firstpad >= t0 && firstpad < t0 + TG_WAVE) prim |= 1ull << (firstpad - t0);
       while (prim) {
         const int b = __ffsll((long long)prim) - 1;
         prim &= prim - 1ull;
+        if ((deal++ & 3) != wv) continue;
         const bool pad = !((mask >> b) & 1ull);
         const int row = pad ? b0 : start + before + __popcll(mask & ((1ull << b) - 1ull));
         const int64_t s = so + t0 + b;
@@ -166,7 +168,7 @@ __global__ void __launch_bounds__(256) k_seq_build_c(tg_model m, tg_seq_restarte
       }
       before += __popcll(mask);
     }
-    if (lane == 0) prev_ts[i] = t_last;
+    if (wv == 0 && lane == 0) prev_ts[i] = t_last;
   }
 }
 
@@ -178,82 +180,150 @@ struct SeqRows {
   const int64_t* anon;          // [n * H]
 };
 
-// One block per (node, head): scores = q k^T / sqrt(dh) over the H x H grid, key padding
+typedef float seq_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int SEQ_CH = 32;          // dh chunk staged per iteration
+constexpr int SEQ_LD = SEQ_CH + 1;  // LDS row stride of a staged chunk: conflict-free scalar writes and MFMA operand reads
+
+// dynamic LDS of the score kernels: row offsets, flags, the staged q / k chunks, the HP x HP grid
+template <int HP>
+struct SeqLds {
+  int64_t s_off[HP], s_toff[HP];
+  float sq[HP][SEQ_LD], sk[HP][SEQ_LD];
+  float sc[HP][HP + 1];
+  float colm[HP];
+  uint8_t s_pad[HP];
+  int s_fp;
+};
+
+// chunk c0 of the q / k rows of the H slots: global -> registers (seq_fetch), registers -> LDS (seq_commit), so that the
+// loads of the NEXT chunk are in flight while the matrix cores work on this one.  Every load is unconditional (clamped row
+// and column, the tabulated part read from a valid dummy address and multiplied by 0 where it does not apply).
+template <int HP>
+struct SeqPf {
+  float q[HP / 8], k[HP / 8], tq[HP / 8], tk[HP / 8];
+};
+template <int HP>
+__device__ __forceinline__ void seq_fetch(const SeqRows& sr, const SeqLds<HP>& L, int H, int dh, int dm, int c0, int tid,
+                                          SeqPf<HP>& p) {
+#pragma unroll
+  for (int u = 0; u < HP / 8; ++u) {
+    if (u * 256 < H * SEQ_CH) {  // (block-uniform)
+      const int f = tid + u * 256;
+      const int row = min(f / SEQ_CH, H - 1), col = min(c0 + f % SEQ_CH, dh - 1);
+      const float* b = sr.qk + L.s_off[row] + col;
+      const int64_t to = L.s_toff[row];
+      const float* tb = to >= 0 ? sr.ta + to + col : b;
+      p.q[u] = b[0];
+      p.k[u] = b[dm];
+      p.tq[u] = tb[0];
+      p.tk[u] = tb[dm];
+    }
+  }
+}
+template <int HP>
+__device__ __forceinline__ void seq_commit(SeqLds<HP>& L, int H, int dh, int c0, int tid, const SeqPf<HP>& p) {
+#pragma unroll
+  for (int u = 0; u < HP / 8; ++u) {
+    const int f = tid + u * 256;
+    const int row = f / SEQ_CH, cc = f % SEQ_CH;
+    if (row < H) {
+      const bool ok = c0 + cc < dh;
+      const float tm = L.s_toff[row] >= 0 ? 1.f : 0.f;
+      L.sq[row][cc] = ok ? fmaf(tm, p.tq[u], p.q[u]) : 0.f;
+      L.sk[row][cc] = ok ? fmaf(tm, p.tk[u], p.k[u]) : 0.f;
+    }
+  }
+}
+
+// S = Q K^T over the staged chunks on v_mfma_f32_32x32x2_f32 (lane l feeds A[l & 31][l >> 5], B[l >> 5][l & 31]); the
+// HP x HP grid is NT x NT tiles of 32 x 32, TPW of them per wavefront (one row tile, consecutive column tiles)
+template <int HP>
+__device__ __forceinline__ void seq_qk_tiles(const SeqRows& sr, SeqLds<HP>& L, int H, int dh, int dm, int tid,
+                                             seq_f32x16* acc) {
+  constexpr int NT = HP / 32, TPW = NT * NT / 4;
+  const int wave = tid >> 6, lane = tid & 63, fr = lane & 31, fk = lane >> 5;
+  const int tmi = (wave * TPW) / NT, tn0 = (wave * TPW) % NT;
+#pragma unroll
+  for (int j = 0; j < TPW; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  SeqPf<HP> pf;
+  seq_fetch<HP>(sr, L, H, dh, dm, 0, tid, pf);
+  for (int c0 = 0; c0 < dh; c0 += SEQ_CH) {
+    seq_commit<HP>(L, H, dh, c0, tid, pf);
+    __syncthreads();
+    if (c0 + SEQ_CH < dh) seq_fetch<HP>(sr, L, H, dh, dm, c0 + SEQ_CH, tid, pf);
+    if (tmi * 32 < H) {
+#pragma unroll 4
+      for (int kk = 0; kk < SEQ_CH; kk += 2) {
+        const float a = L.sq[tmi * 32 + fr][kk + fk];
+#pragma unroll
+        for (int j = 0; j < TPW; ++j)
+          if ((tn0 + j) * 32 < H) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, L.sk[(tn0 + j) * 32 + fr][kk + fk], acc[j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int HP>
+__device__ __forceinline__ void seq_lds_init(const SeqRows& sr, SeqLds<HP>& L, const int64_t* __restrict__ h_n, int64_t i,
+                                             int h, int H, int dh, int dm, int tid) {
+  for (int f = tid; f < HP * SEQ_LD; f += 256) {  // rows past H stay zero: they only feed outputs that are never read
+    (&L.sq[0][0])[f] = 0.f;
+    (&L.sk[0][0])[f] = 0.f;
+  }
+  if (tid < H) {
+    L.s_off[tid] = (int64_t)sr.slot_row[i * H + tid] * 2 * dm + (int64_t)h * dh;
+    L.s_toff[tid] = (sr.ta && tid != H - 1) ? sr.anon[i * H + tid] * 2 * dm + (int64_t)h * dh : -1;
+    L.s_pad[tid] = (tid != H - 1) && (h_n[i * H + tid] == 0);  // restarters.py:86-87: padded keys are masked, never the last
+  }
+  __syncthreads();
+}
+
+// scores -> LDS grid, masked keys at -inf
+template <int HP>
+__device__ __forceinline__ void seq_scores_to_lds(SeqLds<HP>& L, int H, int dh, int tid, const seq_f32x16* acc) {
+  constexpr int NT = HP / 32, TPW = NT * NT / 4;
+  const int wave = tid >> 6, lane = tid & 63, fr = lane & 31, fk = lane >> 5;
+  const int tmi = (wave * TPW) / NT, tn0 = (wave * TPW) % NT;
+  const float scale = 1.0f / sqrtf((float)dh);
+#pragma unroll
+  for (int j = 0; j < TPW; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = tmi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk, sidx = (tn0 + j) * 32 + fr;
+      if (t < H && sidx < H) L.sc[t][sidx] = L.s_pad[sidx] ? -INFINITY : acc[j][r] * scale;
+    }
+}
+
+// One block per (node, head): scores = q k^T / sqrt(dh) over the H x H grid (matrix cores), key padding
 // mask, row softmax, column mean.
-template <int HMAX>
+template <int HP>
 __global__ void __launch_bounds__(256) k_seq_scores(int64_t n, int H, int dm, int nh, SeqRows sr,
                                                     const int64_t* __restrict__ h_n, float* __restrict__ abar,
                                                     const int32_t* __restrict__ n_dev, DropCfg dc,
                                                     float* __restrict__ rbar) {
   if (n_dev && (int64_t)(blockIdx.x / nh) >= (int64_t)*n_dev) return;
+  extern __shared__ __align__(16) unsigned char seq_lds_raw[];
+  SeqLds<HP>& L = *reinterpret_cast<SeqLds<HP>*>(seq_lds_raw);
   const uint64_t dkey = drop_key(dc);
-  constexpr int CH = 32;                   // dh chunk staged per iteration
-  constexpr int PPT = (HMAX * HMAX + 255) / 256;  // (t,s) pairs per thread
-  __shared__ float sq[HMAX][CH + 1], sk[HMAX][CH + 1];
-  __shared__ float sc[HMAX][HMAX + 1];
-  __shared__ float colm[HMAX];
-  __shared__ int64_t s_off[HMAX], s_toff[HMAX];
   const int64_t i = blockIdx.x / nh;
   const int h = blockIdx.x % nh;
   const int dh = dm / nh;
   const int tid = threadIdx.x;
-  if (tid < H) {
-    s_off[tid] = (int64_t)sr.slot_row[i * H + tid] * 2 * dm + (int64_t)h * dh;
-    s_toff[tid] = (sr.ta && tid != H - 1) ? sr.anon[i * H + tid] * 2 * dm + (int64_t)h * dh : -1;
-  }
-  __syncthreads();
-  float acc[PPT];
-#pragma unroll
-  for (int j = 0; j < PPT; ++j) acc[j] = 0.f;
-  for (int c0 = 0; c0 < dh; c0 += CH) {
-    for (int f = tid; f < H * CH; f += 256) {
-      const int row = f / CH, cc = f % CH;
-      float q = 0.f, k = 0.f;
-      if (c0 + cc < dh) {
-        const float* b = sr.qk + s_off[row] + c0 + cc;
-        q = b[0];
-        k = b[dm];
-        if (s_toff[row] >= 0) {
-          const float* tb = sr.ta + s_toff[row] + c0 + cc;
-          q += tb[0];
-          k += tb[dm];
-        }
-      }
-      sq[row][cc] = q;
-      sk[row][cc] = k;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      const int p = tid + j * 256;
-      if (p < H * H) {
-        const int t = p / H, s = p % H;
-        float a = acc[j];
-#pragma unroll
-        for (int cc = 0; cc < CH; ++cc) a += sq[t][cc] * sk[s][cc];
-        acc[j] = a;
-      }
-    }
-    __syncthreads();
-  }
-  const float scale = 1.0f / sqrtf((float)dh);
-#pragma unroll
-  for (int j = 0; j < PPT; ++j) {
-    const int p = tid + j * 256;
-    if (p < H * H) {
-      const int t = p / H, s = p % H;
-      const bool masked = (s != H - 1) && (h_n[i * H + s] == 0);  // restarters.py:86-87
-      sc[t][s] = masked ? -INFINITY : acc[j] * scale;
-    }
-  }
+  seq_lds_init<HP>(sr, L, h_n, i, h, H, dh, dm, tid);
+  seq_f32x16 acc[HP / 32 * (HP / 32) / 4];
+  seq_qk_tiles<HP>(sr, L, H, dh, dm, tid, acc);
+  seq_scores_to_lds<HP>(L, H, dh, tid, acc);
   __syncthreads();
   if (tid < H) {  // row softmax
     float mx = -INFINITY;
-    for (int s = 0; s < H; ++s) mx = fmaxf(mx, sc[tid][s]);
+    for (int s = 0; s < H; ++s) mx = fmaxf(mx, L.sc[tid][s]);
     float sum = 0.f;
     for (int s = 0; s < H; ++s) {
-      const float e = expf(sc[tid][s] - mx);
-      sc[tid][s] = e;
+      const float e = expf(L.sc[tid][s] - mx);
+      L.sc[tid][s] = e;
       sum += e;
     }
     const float inv = 1.f / sum;
@@ -261,21 +331,21 @@ __global__ void __launch_bounds__(256) k_seq_scores(int64_t n, int H, int dm, in
       float ms = 1.f;  // attention dropout (nn.MultiheadAttention) on the normalised probabilities
       if (dc.p > 0.f)
         ms = drop_keep(dkey, DROP_SEQ_ATTN, (((uint64_t)i * nh + h) * H + tid) * H + s, dc.thresh) ? dc.scale : 0.f;
-      sc[tid][s] *= inv * ms;
+      L.sc[tid][s] *= inv * ms;
     }
   }
   __syncthreads();
   if (tid < H) {  // column mean
     float a = 0.f;
-    for (int t = 0; t < H; ++t) a += sc[t][tid];
+    for (int t = 0; t < H; ++t) a += L.sc[t][tid];
     a /= (float)H;
     abar[((int64_t)i * nh + h) * H + tid] = a;
-    colm[tid] = a;
+    L.colm[tid] = a;
   }
   __syncthreads();
   if (tid == 0 && rbar) {  // sum of the column means: weight of the value bias (1 without dropout)
     float r = 0.f;
-    for (int s = 0; s < H; ++s) r += colm[s];
+    for (int s = 0; s < H; ++s) r += L.colm[s];
     rbar[(int64_t)i * nh + h] = dc.p > 0.f ? r : 1.f;
   }
 }
@@ -357,95 +427,45 @@ __global__ void __launch_bounds__(256) k_seq_mix_bwd(int64_t n, const int32_t* _
 
 // One block per (node, head): recompute the H x H attention (as k_seq_scores), then
 //   dA[t, s] = dabar[s] / H;  dS[t, s] = A[t, s] (dA[t, s] - sum_s' A[t, s'] dA[t, s'])
-//   dq_t = scale sum_s dS[t, s] k_s;   dk_s = scale sum_t dS[t, s] q_t
+//   dq_t = scale sum_s dS[t, s] k_s;   dk_s = scale sum_t dS[t, s] q_t      (both on the matrix cores, per dh chunk)
 // The gradients land on the COMPACT rows: a real slot's on its own row, the padded slots' query gradients summed on the
 // node's padded row (their keys are masked: no key gradient), the last slot's in dqk_last [n, 2 dm] (summed over the nodes
 // into row 0 afterwards).
-template <int HMAX>
+template <int HP>
 __global__ void __launch_bounds__(256) k_seq_scores_bwd(int64_t n, const int32_t* __restrict__ n_dev, int H, int dm,
                                                         int nh, SeqRows sr, const int64_t* __restrict__ h_n,
                                                         const float* __restrict__ dabar, float* __restrict__ dqk,
                                                         float* __restrict__ dqk_last, DropCfg dc) {
   if (n_dev && (int64_t)(blockIdx.x / nh) >= (int64_t)*n_dev) return;
+  extern __shared__ __align__(16) unsigned char seq_lds_raw[];
+  SeqLds<HP>& L = *reinterpret_cast<SeqLds<HP>*>(seq_lds_raw);
   const uint64_t dkey = drop_key(dc);
-  constexpr int CH = 32;
-  constexpr int PPT = (HMAX * HMAX + 255) / 256;
-  constexpr int OPT = (HMAX * CH + 255) / 256;  // (row, column) outputs per thread and chunk
-  __shared__ float sq[HMAX][CH + 1], sk[HMAX][CH + 1];
-  __shared__ float sc[HMAX][HMAX + 1];
-  __shared__ int64_t s_off[HMAX], s_toff[HMAX];
-  __shared__ uint8_t s_pad[HMAX];
-  __shared__ int s_fp;
   const int64_t i = blockIdx.x / nh;
   const int h = blockIdx.x % nh;
   const int dh = dm / nh;
   const int tid = threadIdx.x;
-  if (tid < H) {
-    s_off[tid] = (int64_t)sr.slot_row[i * H + tid] * 2 * dm + (int64_t)h * dh;
-    s_toff[tid] = (sr.ta && tid != H - 1) ? sr.anon[i * H + tid] * 2 * dm + (int64_t)h * dh : -1;
-    s_pad[tid] = (tid != H - 1) && (h_n[i * H + tid] == 0);
-  }
-  __syncthreads();
+  seq_lds_init<HP>(sr, L, h_n, i, h, H, dh, dm, tid);
   if (tid == 0) {
     int fp = -1;
     for (int t = 0; t < H - 1 && fp < 0; ++t)
-      if (s_pad[t]) fp = t;
-    s_fp = fp;
+      if (L.s_pad[t]) fp = t;
+    L.s_fp = fp;
   }
-  float acc[PPT];
-#pragma unroll
-  for (int j = 0; j < PPT; ++j) acc[j] = 0.f;
-  auto stage = [&](int c0) {
-    for (int f = tid; f < H * CH; f += 256) {
-      const int row = f / CH, cc = f % CH;
-      float q = 0.f, k = 0.f;
-      if (c0 + cc < dh) {
-        const float* b = sr.qk + s_off[row] + c0 + cc;
-        q = b[0];
-        k = b[dm];
-        if (s_toff[row] >= 0) {
-          const float* tb = sr.ta + s_toff[row] + c0 + cc;
-          q += tb[0];
-          k += tb[dm];
-        }
-      }
-      sq[row][cc] = q;
-      sk[row][cc] = k;
-    }
-  };
-  for (int c0 = 0; c0 < dh; c0 += CH) {
-    stage(c0);
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      const int p = tid + j * 256;
-      if (p < H * H) {
-        const int t = p / H, s = p % H;
-        float a = acc[j];
-#pragma unroll
-        for (int cc = 0; cc < CH; ++cc) a += sq[t][cc] * sk[s][cc];
-        acc[j] = a;
-      }
-    }
-    __syncthreads();
-  }
-  const float scale = 1.0f / sqrtf((float)dh);
-#pragma unroll
-  for (int j = 0; j < PPT; ++j) {
-    const int p = tid + j * 256;
-    if (p < H * H) {
-      const int t = p / H, s = p % H;
-      sc[t][s] = s_pad[s] ? -INFINITY : acc[j] * scale;
-    }
+  for (int f = tid; f < HP * (HP + 1); f += 256) (&L.sc[0][0])[f] = 0.f;  // rows / columns past H are MFMA operands below
+  {
+    seq_f32x16 acc[HP / 32 * (HP / 32) / 4];
+    seq_qk_tiles<HP>(sr, L, H, dh, dm, tid, acc);  // (its barriers order the zero fill above)
+    seq_scores_to_lds<HP>(L, H, dh, tid, acc);
   }
   __syncthreads();
+  const float scale = 1.0f / sqrtf((float)dh);
   if (tid < H) {  // row softmax, then the softmax backward of that row, pre-multiplied by the score scale
     float mx = -INFINITY;
-    for (int s = 0; s < H; ++s) mx = fmaxf(mx, sc[tid][s]);
+    for (int s = 0; s < H; ++s) mx = fmaxf(mx, L.sc[tid][s]);
     float sum = 0.f;
     for (int s = 0; s < H; ++s) {
-      const float e = expf(sc[tid][s] - mx);
-      sc[tid][s] = e;
+      const float e = expf(L.sc[tid][s] - mx);
+      L.sc[tid][s] = e;
       sum += e;
     }
     const float inv = 1.f / sum, invH = 1.f / (float)H;
@@ -458,43 +478,60 @@ __global__ void __launch_bounds__(256) k_seq_scores_bwd(int64_t n, const int32_t
     };
     float dot = 0.f;
     for (int s = 0; s < H; ++s) {
-      const float a = sc[tid][s] * inv;
-      sc[tid][s] = a;
+      const float a = L.sc[tid][s] * inv;
+      L.sc[tid][s] = a;
       dot = fmaf(a, dA(s), dot);
     }
-    for (int s = 0; s < H; ++s) sc[tid][s] = sc[tid][s] * (dA(s) - dot) * scale;
+    for (int s = 0; s < H; ++s) L.sc[tid][s] = L.sc[tid][s] * (dA(s) - dot) * scale;
   }
   __syncthreads();
   // the padded query rows share one operand row: fold their dS rows into the first of them, in slot order
-  const int fp = s_fp;
+  const int fp = L.s_fp;
   if (fp >= 0 && tid < H) {
-    float a = sc[fp][tid];
+    float a = L.sc[fp][tid];
     for (int t = fp + 1; t < H - 1; ++t)
-      if (s_pad[t]) {
-        a += sc[t][tid];
-        sc[t][tid] = 0.f;
+      if (L.s_pad[t]) {
+        a += L.sc[t][tid];
+        L.sc[t][tid] = 0.f;
       }
-    sc[fp][tid] = a;
+    L.sc[fp][tid] = a;
   }
   __syncthreads();
-  for (int c0 = 0; c0 < dh; c0 += CH) {
-    stage(c0);
+  // per chunk of 32 columns: dq tile o (rows o * 32 ..) = dS[rows, :] K[:, chunk],  dk tile o = dS[:, rows]^T Q[:, chunk];
+  // 2 NT output tiles of 32 x 32, TPO per wavefront; the contraction runs over the H slots
+  constexpr int NT = HP / 32, TPO = 2 * NT / 4;
+  const int wave = tid >> 6, lane = tid & 63, fr = lane & 31, fk = lane >> 5;
+  const int Hk = (H + 1) & ~1;
+  SeqPf<HP> pf;
+  seq_fetch<HP>(sr, L, H, dh, dm, 0, tid, pf);
+  for (int c0 = 0; c0 < dh; c0 += SEQ_CH) {
+    seq_commit<HP>(L, H, dh, c0, tid, pf);
     __syncthreads();
+    if (c0 + SEQ_CH < dh) seq_fetch<HP>(sr, L, H, dh, dm, c0 + SEQ_CH, tid, pf);
 #pragma unroll
-    for (int j = 0; j < OPT; ++j) {
-      const int p = tid + j * 256;
-      if (p < H * CH) {
-        const int row = p / CH, cc = p % CH;
-        float dq = 0.f, dk = 0.f;
-        for (int s = 0; s < H; ++s) {
-          dq = fmaf(sc[row][s], sk[s][cc], dq);
-          dk = fmaf(sc[s][row], sq[s][cc], dk);
+    for (int j = 0; j < TPO; ++j) {
+      const int o = wave * TPO + j;
+      const bool isk = o >= NT;
+      const int r0 = (isk ? o - NT : o) * 32;
+      if (r0 < H) {
+      seq_f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      if (!isk) {
+        for (int kk = 0; kk < Hk; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(L.sc[r0 + fr][kk + fk], L.sk[kk + fk][fr], acc, 0, 0, 0);
+      } else {
+        for (int kk = 0; kk < Hk; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(L.sc[kk + fk][r0 + fr], L.sq[kk + fk][fr], acc, 0, 0, 0);
+      }
+      if (c0 + fr < dh) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+          if (row < H && (!L.s_pad[row] || row == fp)) {
+            float* ob = (row == H - 1 ? dqk_last + i * 2 * dm + (int64_t)h * dh : dqk + L.s_off[row]) + c0 + fr;
+            ob[isk ? dm : 0] = acc[r];
+          }
         }
-        if (c0 + cc < dh && (!s_pad[row] || row == fp)) {
-          float* ob = (row == H - 1 ? dqk_last + i * 2 * dm + (int64_t)h * dh : dqk + s_off[row]) + c0 + cc;
-          ob[0] = dq;
-          ob[dm] = dk;
-        }
+      }
       }
     }
     __syncthreads();
@@ -515,75 +552,92 @@ __global__ void __launch_bounds__(256) k_seq_build_bwd(tg_model m, tg_seq_restar
                                                        const float* __restrict__ dXs, int wide,
                                                        const float* __restrict__ abar,
                                                        const float* __restrict__ dxbar, int use_lds,
-                                                       float* __restrict__ danon, float* __restrict__ dfreq,
-                                                       float* __restrict__ dphase) {
-  extern __shared__ float lacc[];  // [2, d] TimeEncode grads, then [(H + 1), d] embedding grads when use_lds
+                                                       float* __restrict__ danon, float* __restrict__ bpart) {
+  // A thread OWNS column c = threadIdx.x (+ 256, ...) and walks the block's slots, two at a time: the TimeEncode sums stay
+  // in registers and the embedding rows in LDS, one writer per element - no atomics.  The block leaves its sums in
+  // bpart[block] = [d freq | d phase | (H + 1) x d embedding rows]; k_seq_build_reduce adds the blocks in order.
+  extern __shared__ float lan[];  // [(H + 1), d] embedding grads when use_lds
   if (n_dev) n = min(n, (int64_t)*n_dev);
   const int H = r.hist_len, d = m.d, dm = 4 * d + m.d_e, nh = r.n_head;
   const int ldx = wide ? 2 * d : d, tcol = wide ? d : 0;
-  const int nl = 2 * d + (use_lds ? (H + 1) * d : 0);
-  for (int c = threadIdx.x; c < nl; c += 256) lacc[c] = 0.f;
+  const int nl = use_lds ? (H + 1) * d : 0;
+  for (int c = threadIdx.x; c < nl; c += 256) lan[c] = 0.f;
   __syncthreads();
-  float* lte = lacc;
-  float* lan = lacc + 2 * d;
-  const int64_t total = n * H * d;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(t % d);
-    const int64_t row = t / d;
-    const int64_t i = row / H;
-    const int pos = (int)(row - i * H);
-    const int32_t cr = slot_row[row];
-    const bool primary = pos == H - 1 ? i == 0 : row_slot[cr] == (int32_t)row;
-    float ga = 0.f, gt = 0.f;
-    if (primary) {
-      gt = dXs[(int64_t)cr * ldx + tcol + c];
-      if (wide) ga = dXs[(int64_t)cr * ldx + c];
-    }
-    for (int h = 0; h < nh; ++h) {
-      const float w = abar[((int64_t)i * nh + h) * H + pos];
-      const float* dx = dxbar + ((int64_t)i * nh + h) * dm;
-      ga = fmaf(w, dx[2 * d + c], ga);
-      gt = fmaf(w, dx[3 * d + m.d_e + c], gt);
-    }
-    if (pos != H - 1) {
-      const int64_t a = anon[row];
-      if (use_lds) atomicAdd(&lan[a * d + c], ga);
-      else atomicAdd(danon + a * d + c, ga);
-    }
-    const float dt = h_t[i * H + H - 1] - h_t[row];
-    const float sn = -time_enc_sin(dt, r.te_freq[c], r.te_phase[c]) * gt;
-    atomicAdd(&lte[c], sn * dt);
-    atomicAdd(&lte[d + c], sn);
-  }
-  __syncthreads();
+  const int64_t slots = n * H;
+  const int64_t per = (slots + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = min(slots, (int64_t)blockIdx.x * per), hi = min(slots, lo + per);
+  float* bp = bpart + (int64_t)blockIdx.x * (2 * d + nl);
   for (int c = threadIdx.x; c < d; c += 256) {
-    atomicAdd(dfreq + c, lte[c]);
-    atomicAdd(dphase + c, lte[d + c]);
-  }
-  if (use_lds)
-    for (int c = threadIdx.x; c < (H + 1) * d; c += 256) atomicAdd(danon + c, lan[c]);
-}
-
-// narrow form: T_a = anony_emb Wa^T with Wa = in_proj_w[0:2dm, 2d:3d].  dTaT [2 dm, ohw] = d T_a^T (the product of the
-// row gradients with the one-hot rows).  d anony_emb[a, j] += sum_c dTaT[c, a] Wa[c, j];  d Wa[c, j] += sum_a dTaT[c, a] ae[a, j].
-// Every output has one owner and a fixed summation order.
-__global__ void __launch_bounds__(256) k_seq_anon_grads(int H1, int d, int dm, int ohw, const float* __restrict__ dTaT,
-                                                        const float* __restrict__ w_in, const float* __restrict__ ae,
-                                                        float* __restrict__ g_ae, float* __restrict__ g_w) {
-  const int64_t nA = (int64_t)H1 * d, nB = (int64_t)2 * dm * d;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nA + nB; t += (int64_t)gridDim.x * blockDim.x) {
-    if (t < nA) {
-      const int a = (int)(t / d), j = (int)(t % d);
-      float acc = 0.f;
-      for (int c = 0; c < 2 * dm; ++c) acc = fmaf(dTaT[(int64_t)c * ohw + a], w_in[(int64_t)c * dm + 2 * d + j], acc);
-      g_ae[t] += acc;
-    } else {
-      const int64_t u = t - nA;
-      const int c = (int)(u / d), j = (int)(u % d);
-      float acc = 0.f;
-      for (int a = 0; a < H1; ++a) acc = fmaf(dTaT[(int64_t)c * ohw + a], ae[(int64_t)a * d + j], acc);
-      g_w[(int64_t)c * dm + 2 * d + j] += acc;
+    const float fw = r.te_freq[c], fp = r.te_phase[c];
+    float sf = 0.f, sp = 0.f;
+    auto grads = [&](int64_t row, float& ga, float& gt, float& dt, int64_t& a) {
+      const int64_t i = row / H;
+      const int pos = (int)(row - i * H);
+      const int32_t cr = slot_row[row];
+      const bool primary = pos == H - 1 ? i == 0 : row_slot[cr] == (int32_t)row;
+      const float xt = dXs[(int64_t)cr * ldx + tcol + c], xa = dXs[(int64_t)cr * ldx + c];  // (unconditional loads)
+      gt = primary ? xt : 0.f;
+      ga = (primary && wide) ? xa : 0.f;
+      for (int h = 0; h < nh; ++h) {
+        const float w = abar[((int64_t)i * nh + h) * H + pos];
+        const float* dx = dxbar + ((int64_t)i * nh + h) * dm;
+        ga = fmaf(w, dx[2 * d + c], ga);
+        gt = fmaf(w, dx[3 * d + m.d_e + c], gt);
+      }
+      a = pos != H - 1 ? anon[row] : -1;
+      dt = h_t[i * H + H - 1] - h_t[row];
+    };
+    auto apply = [&](float ga, float gt, float dt, int64_t a) {
+      if (a >= 0) {
+        if (use_lds) lan[a * d + c] += ga;
+        else atomicAdd(danon + a * d + c, ga);
+      }
+      const float sn = -time_enc_sin(dt, fw, fp) * gt;
+      sf = fmaf(sn, dt, sf);
+      sp += sn;
+    };
+    int64_t row = lo;
+    for (; row + 1 < hi; row += 2) {
+      float ga0, gt0, dt0, ga1, gt1, dt1;
+      int64_t a0, a1;
+      grads(row, ga0, gt0, dt0, a0);
+      grads(row + 1, ga1, gt1, dt1, a1);
+      apply(ga0, gt0, dt0, a0);
+      apply(ga1, gt1, dt1, a1);
     }
+    if (row < hi) {
+      float ga0, gt0, dt0;
+      int64_t a0;
+      grads(row, ga0, gt0, dt0, a0);
+      apply(ga0, gt0, dt0, a0);
+    }
+    bp[c] = sf;
+    bp[d + c] = sp;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < nl; c += 256) bp[2 * d + c] = lan[c];
+}
+// dfreq / dphase / danon += the blocks' sums in a fixed order: 64 elements per workgroup, its 16 wavefronts each add a
+// sixteenth of the blocks (lanes = consecutive elements), wavefront sums folded in wavefront order
+__global__ void __launch_bounds__(1024) k_seq_build_reduce(int nb, int d, int nl, const float* __restrict__ bpart,
+                                                           float* __restrict__ dfreq, float* __restrict__ dphase,
+                                                           float* __restrict__ danon) {
+  __shared__ float red[16][64];
+  const int w = 2 * d + nl, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
+  const int per = (nb + 15) / 16, b0 = min(nb, wv * per), b1 = min(nb, b0 + per);
+  float a = 0.f;
+  if (e < w)
+    for (int b = b0; b < b1; ++b) a += bpart[(int64_t)b * w + e];
+  red[wv][lane] = a;
+  __syncthreads();
+  if (wv == 0 && e < w) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += red[j][lane];
+    if (e < d) dfreq[e] += t;
+    else if (e < 2 * d) dphase[e - d] += t;
+    else danon[e - 2 * d] += t;
   }
 }
 
@@ -773,6 +827,23 @@ static int seq_ok(const tg_model* m, const tg_seq_restarter* r) {
   return 1;
 }
 
+// the score kernels' dynamic LDS exceeds the 64 KB default of a launch for histories beyond 64 events
+static int seq_lds_attr() {
+  static int done = 0;  // (per process; the attribute belongs to the function, whichever device runs it)
+  if (done) return TG_OK;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seq_scores<128>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeqLds<128>));
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seq_scores_bwd<128>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeqLds<128>));
+  if (e != hipSuccess) {
+    set_hip_error(e, "seq_lds_attr");
+    return TG_EHIP;
+  }
+  done = 1;
+  return TG_OK;
+}
+
 // forward on `cap` rows of which the first *n_dev (nullable: all) are live
 static int seq_forward(const tg_model* m, const tg_seq_restarter* r, int64_t n, const int32_t* n_dev,
                        const int64_t* nids, const int64_t* h_n, const int64_t* anon, const int64_t* h_e,
@@ -780,14 +851,14 @@ static int seq_forward(const tg_model* m, const tg_seq_restarter* r, int64_t n, 
                        const SeqWs& w, hipStream_t st, const DropCfg& dc = DropCfg{}) {
   const int d = m->d, dm = 4 * m->d + m->d_e, H = r->hist_len, nh = r->n_head, dh = dm / nh;
   if ((int64_t)n * H >= ((int64_t)1 << 31) - 1) return TG_EUNSUPPORTED;  // slot indices are int32
-  const unsigned nwg = (unsigned)std::min<int64_t>(cdiv(n, 4), 4096);
+  const unsigned nwg = (unsigned)std::min<int64_t>(cdiv(n, 4), 4096), nbg = (unsigned)std::min<int64_t>(n, 8192);
   hipLaunchKernelGGL(k_seq_count, dim3(nwg), dim3(256), 0, st, n, n_dev, H, h_n, w.cnt);
   hipLaunchKernelGGL(k_seq_scan, dim3(1), dim3(1024), 0, st, n, w.cnt, w.base, w.rows);
   if (w.wide)
-    hipLaunchKernelGGL((k_seq_build_c<true>), dim3(nwg), dim3(256), 0, st, *m, *r, n, n_dev, nids, h_n, anon, h_e, h_t, h_d,
+    hipLaunchKernelGGL((k_seq_build_c<true>), dim3(nbg), dim3(256), 0, st, *m, *r, n, n_dev, nids, h_n, anon, h_e, h_t, h_d,
                        w.base, w.slot_row, w.row_slot, (float4*)w.xc, w.oh, w.ohw, prev_ts);
   else
-    hipLaunchKernelGGL((k_seq_build_c<false>), dim3(nwg), dim3(256), 0, st, *m, *r, n, n_dev, nids, h_n, anon, h_e, h_t, h_d,
+    hipLaunchKernelGGL((k_seq_build_c<false>), dim3(nbg), dim3(256), 0, st, *m, *r, n, n_dev, nids, h_n, anon, h_e, h_t, h_d,
                        w.base, w.slot_row, w.row_slot, (float4*)w.xc, w.oh, w.ohw, prev_ts);
   int rc;
   GemmArgs g{};
@@ -804,12 +875,13 @@ static int seq_forward(const tg_model* m, const tg_seq_restarter* r, int64_t n, 
   g.w = r->in_proj_w + col0; g.ldw = dm; g.bias = r->in_proj_b; g.c = w.qk; g.ldc = 2 * dm; g.alpha = 1.f; g.nbatch = 1;
   if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
   const SeqRows sr{w.qk, w.slot_row, w.ta, anon};
-  if (H <= 40)
-    hipLaunchKernelGGL((k_seq_scores<40>), dim3((unsigned)(n * nh)), dim3(256), 0, st, n, H, dm, nh, sr, h_n, w.abar,
-                       n_dev, dc, w.rbar);
+  if ((rc = seq_lds_attr()) != TG_OK) return rc;
+  if (H <= 64)
+    hipLaunchKernelGGL((k_seq_scores<64>), dim3((unsigned)(n * nh)), dim3(256), sizeof(SeqLds<64>), st, n, H, dm, nh, sr,
+                       h_n, w.abar, n_dev, dc, w.rbar);
   else
-    hipLaunchKernelGGL((k_seq_scores<64>), dim3((unsigned)(n * nh)), dim3(256), 0, st, n, H, dm, nh, sr, h_n, w.abar,
-                       n_dev, dc, w.rbar);
+    hipLaunchKernelGGL((k_seq_scores<128>), dim3((unsigned)(n * nh)), dim3(256), sizeof(SeqLds<128>), st, n, H, dm, nh, sr,
+                       h_n, w.abar, n_dev, dc, w.rbar);
   const SeqCols sc{(const float4*)w.xc, w.wx / 4, col0 / 4, w.wide ? nullptr : (const float4*)r->anony_emb, w.slot_row, anon};
   hipLaunchKernelGGL(k_seq_mix, dim3(flat_grid(n * nh * (dm / 4), 256)), dim3(256), 0, st, n, H, dm / 4, d / 4, nh, w.abar,
                      sc, (float4*)w.xbar, n_dev);
@@ -854,7 +926,8 @@ static int seq_forward(const tg_model* m, const tg_seq_restarter* r, int64_t n, 
 struct MutualWs {
   double *ts2, *tu;
   int64_t *uniq, *index, *h_n, *h_e, *h_d, *anon;
-  float *h_t, *sl, *sr, *prev_ts, *dsl, *dsr, *dt2, *dom, *dO, *dOm, *dxbar, *dabar, *dqk, *dqk_last, *dXs, *dTaT, *acc;
+  float *h_t, *sl, *sr, *prev_ts, *dsl, *dsr, *dt2, *dom, *dO, *dOm, *dxbar, *dabar, *dqk, *dqk_last, *dXs, *dTaT, *acc, *bpart;
+  int bb_blocks;  // blocks of k_seq_build_bwd = rows of bpart
   int32_t *count, *counts2;
   uint8_t* valid;
   void* sel_ws;
@@ -897,7 +970,9 @@ static bool carve_mutual(const tg_model* m, const tg_seq_restarter* r, int64_t B
     w.dqk = cv.take<float>((size_t)w.seq.rowcap * 2 * dm);
     w.dqk_last = cv.take<float>(n * 2 * dm);
     w.dXs = cv.take<float>((size_t)w.seq.rowcap * (w.seq.wide ? 2 : 1) * d);
-    w.dTaT = w.seq.wide ? nullptr : cv.take<float>(2 * dm * (size_t)w.seq.ohw);
+    w.dTaT = w.seq.wide ? nullptr : cv.take<float>(2 * dm * (size_t)w.seq.ohw);  // d T_a [ohw, 2 dm]
+    w.bb_blocks = (int)std::min<int64_t>(cdiv(n * (int64_t)H, 32), 1024);
+    w.bpart = cv.take<float>((size_t)w.bb_blocks * (2 * d + (H + 1) * d));
   }
   return cv.ok;
 }
@@ -917,7 +992,7 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
                 float* g_left, float* g_right, float* loss_out, int32_t* flag_out, float* part, size_t part_floats,
                 void* ws, size_t ws_bytes, const DropCfg& dc, hipStream_t st) {
   if (!sio->h_prev_left || !sio->h_prev_right) return TG_EINVAL;
-  if (r && (!seq_ok(m, r) || r->hist_len > 64 || !gr)) return TG_EUNSUPPORTED;
+  if (r && (!seq_ok(m, r) || r->hist_len > 128 || !gr)) return TG_EUNSUPPORTED;
   if (!r && (!st_left || !st_right || !g_left || !g_right)) return TG_EINVAL;
   const int64_t B = sio->B, n = 2 * B;
   const int d = m->d;
@@ -1036,12 +1111,12 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
                      (const float4*)w.dxbar, sc, w.dabar, dc.p > 0.f ? w.dO : (const float*)nullptr,
                      r->in_proj_b + 2 * dm);
   const SeqRows sr{q.qk, q.slot_row, q.ta, w.anon};
-  if (H <= 40)
-    hipLaunchKernelGGL((k_seq_scores_bwd<40>), dim3((unsigned)(n * nh)), dim3(256), 0, st, n, n_dev, H, dm, nh, sr,
-                       w.h_n, w.dabar, w.dqk, w.dqk_last, dc);
+  if (H <= 64)
+    hipLaunchKernelGGL((k_seq_scores_bwd<64>), dim3((unsigned)(n * nh)), dim3(256), sizeof(SeqLds<64>), st, n, n_dev, H, dm,
+                       nh, sr, w.h_n, w.dabar, w.dqk, w.dqk_last, dc);
   else
-    hipLaunchKernelGGL((k_seq_scores_bwd<64>), dim3((unsigned)(n * nh)), dim3(256), 0, st, n, n_dev, H, dm, nh, sr,
-                       w.h_n, w.dabar, w.dqk, w.dqk_last, dc);
+    hipLaunchKernelGGL((k_seq_scores_bwd<128>), dim3((unsigned)(n * nh)), dim3(256), sizeof(SeqLds<128>), st, n, n_dev, H,
+                       dm, nh, sr, w.h_n, w.dabar, w.dqk, w.dqk_last, dc);
   // row 0 (the last event of every node) collects the last slots' gradients
   if ((rc = colsum_launch(n, n_dev, 2 * dm, w.dqk_last, 2 * dm, 1.f, w.dqk, 0, part, part_floats, st)) != TG_OK) return rc;
   // q/k projection: weight columns [col0, dm), bias
@@ -1060,21 +1135,32 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
     ga.w = r->in_proj_w + 2 * d; ga.c = w.dXs;
     if ((rc = gemm_launch(ga, st)) != TG_OK) return rc;
   } else {
-    // the tabulated anony_emb block: d T_a^T = dqk^T onehot, then the two small products through the table
+    // the tabulated anony_emb block, T_a = anony_emb Wa^T with Wa = in_proj_w[0:2dm, 2d:3d]:  d T_a = onehot^T dqk
+    // ([ohw, 2 dm]), then  d anony_emb += d T_a Wa  and  d Wa += d T_a^T anony_emb  (rows past H of d T_a are zeros: no slot
+    // carries such an id; the two products read its first H + 1 rows only)
     tn = tn_base(q.rowcap, rows_dev);
     tn.accumulate = 0; tn.bias_accumulate = 0;
-    tn.n = 2 * dm; tn.k = q.ohw; tn.y = w.dqk; tn.ldy = 2 * dm; tn.x0 = ASeg{q.oh, q.ohw, q.ohw, nullptr};
-    tn.out = w.dTaT; tn.ldo = q.ohw;
+    tn.n = q.ohw; tn.k = 2 * dm; tn.y = q.oh; tn.ldy = q.ohw; tn.x0 = ASeg{w.dqk, 2 * dm, 2 * dm, nullptr};
+    tn.out = w.dTaT; tn.ldo = 2 * dm;
     if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
-    hipLaunchKernelGGL(k_seq_anon_grads, dim3(flat_grid((int64_t)(H + 1) * d + (int64_t)2 * dm * d, 256)), dim3(256), 0, st,
-                       H + 1, d, dm, q.ohw, w.dTaT, r->in_proj_w, r->anony_emb, F(gr->anony_emb), F(gr->in_proj_w));
+    ga = GemmArgs{};
+    ga.m_cap = H + 1; ga.n = d; ga.k = 2 * dm; ga.a0 = ASeg{w.dTaT, 2 * dm, 2 * dm, nullptr};
+    ga.w = r->in_proj_w + 2 * d; ga.ldw = dm; ga.w_kmajor = 1; ga.c = F(gr->anony_emb); ga.ldc = d; ga.alpha = 1.f;
+    ga.nbatch = 1; ga.accumulate = 1;
+    if ((rc = gemm_launch(ga, st)) != TG_OK) return rc;
+    tn = tn_base(H + 1, nullptr);
+    tn.n = 2 * dm; tn.k = d; tn.y = w.dTaT; tn.ldy = 2 * dm; tn.x0 = ASeg{r->anony_emb, d, d, nullptr};
+    tn.out = F(gr->in_proj_w) + 2 * d; tn.ldo = dm;
+    if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
   }
-  const size_t lfull = (size_t)(2 * d + (H + 1) * d) * sizeof(float);
+  const size_t lfull = (size_t)((H + 1) * d) * sizeof(float);
   const int use_lds = lfull <= 60 * 1024;
-  hipLaunchKernelGGL(k_seq_build_bwd, dim3(std::min<unsigned>(flat_grid(n * H * d, 256), 512)), dim3(256),
-                     use_lds ? lfull : (size_t)2 * d * sizeof(float), st, *m, *r, n, n_dev, w.anon, w.h_t, q.slot_row,
-                     q.row_slot, w.dXs, q.wide ? 1 : 0, q.abar, w.dxbar, use_lds, F(gr->anony_emb), F(gr->te_freq),
-                     F(gr->te_phase));
+  const int nl = use_lds ? (H + 1) * d : 0;
+  hipLaunchKernelGGL(k_seq_build_bwd, dim3((unsigned)w.bb_blocks), dim3(256), use_lds ? lfull : (size_t)16, st, *m, *r, n,
+                     n_dev, w.anon, w.h_t, q.slot_row, q.row_slot, w.dXs, q.wide ? 1 : 0, q.abar, w.dxbar, use_lds,
+                     F(gr->anony_emb), w.bpart);
+  hipLaunchKernelGGL(k_seq_build_reduce, dim3((unsigned)cdiv(2 * d + nl, 64)), dim3(1024), 0, st, w.bb_blocks, d, nl, w.bpart,
+                     F(gr->te_freq), F(gr->te_phase), F(gr->anony_emb));
   return check_launch("mutual_step(seq)");
 }
 
@@ -1097,7 +1183,7 @@ extern "C" int tg_restart_seq_fwd(const tg_model* m, const tg_seq_restarter* r, 
                                   size_t ws_bytes, void* stream) {
   if (m && m->row_of) return TG_EUNSUPPORTED;  // state addressed by node id: not on physically partitioned tables (tg_model.row_of)
   if (!seq_ok(m, r) || n < 0) return TG_EINVAL;
-  if (r->hist_len > 64) return TG_EUNSUPPORTED;
+  if (r->hist_len > 128) return TG_EUNSUPPORTED;
   if (n == 0) return TG_OK;
   if (!nids || !h_n || !anon || !h_e || !h_t || !h_d || !h_left || !h_right || !prev_ts) return TG_EINVAL;
   Carver cv(ws, ws_bytes);
@@ -1118,7 +1204,7 @@ extern "C" int tg_restart_seq_fwd_train(const tg_model* m, const tg_seq_restarte
                                         float dropout_p, uint64_t* rng, void* ws, size_t ws_bytes, void* stream) {
   if (m && m->row_of) return TG_EUNSUPPORTED;  // state addressed by node id: not on physically partitioned tables (tg_model.row_of)
   if (!seq_ok(m, r) || n < 0 || dropout_p < 0.f || dropout_p >= 1.f || (dropout_p > 0.f && !rng)) return TG_EINVAL;
-  if (r->hist_len > 64) return TG_EUNSUPPORTED;
+  if (r->hist_len > 128) return TG_EUNSUPPORTED;
   if (n == 0) return TG_OK;
   if (!nids || !h_n || !anon || !h_e || !h_t || !h_d || !h_left || !h_right || !prev_ts) return TG_EINVAL;
   Carver cv(ws, ws_bytes);
