@@ -6,5 +6,5 @@ tail -4 $O/pytest.log
 python bench.py --train --train-restarter seq --no-cpu-baseline > $O/train_seq.json 2> $O/train_seq.err; tail -c 400 $O/train_seq.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/prof_seq -o seq -- python $R/bench.py --train --train-restarter seq --steps 30 --warmup 10 --no-cpu-baseline > $O/prof_seq.log 2>&1
-python $R/tools/rocpd_stats.py $(find $O/prof_seq -name '*.db' | head -1) $O/r05_train_c2_seq_kernel_stats_v3.csv > /dev/null && echo stats ok
+python $R/tools/rocpd_stats.py $(find $O/prof_seq -name '*.db' | head -1) $O/r05_train_c2_seq_kernel_stats_v6.csv > /dev/null && echo stats ok
 rm -rf $O/prof_seq

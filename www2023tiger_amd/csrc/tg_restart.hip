@@ -172,134 +172,228 @@ __global__ void __launch_bounds__(256) k_seq_build_c(tg_model m, tg_seq_restarte
   }
 }
 
-// the q / k row of slot (i, row): its compact row, plus (narrow form) the tabulated anony_emb part - not for the last event
+// ---- attention scores on the COMPACT rows of a node -------------------------------------------------------------------
+// Node i owns lc = cnt[i] + 1 operand rows: [its padded row (if it has padded slots) | its real events | the shared last
+// row].  The H x H attention of the reference has only lc x lc distinct entries: the P padded query slots share row 0 (and
+// as keys they are masked), so
+//   abar[s] = (1 / H) sum_r M[r, s] A[r, s],   M[r, s] = multiplicity of query row r (P for the padded row, else 1)
+// and with attention dropout M[r, s] = scale * (number of slots t of row r whose mask entry (t, slot(s)) is kept).
 struct SeqRows {
   const float* qk;              // [rows, 2 dm] compact
   const int32_t* slot_row;      // [n * H]
-  const float* ta;              // nullable: [H + 1, 2 dm]
+  const int32_t* row_slot;      // [rows] primary slot of a compact row
+  const int32_t* base;          // [n + 1] first compact row of a node
+  const float* ta;              // nullable: [H + 1, 2 dm] tabulated anony_emb part of q / k (not for the last event)
   const int64_t* anon;          // [n * H]
 };
 
 typedef float seq_f32x16 __attribute__((ext_vector_type(16)));
-constexpr int SEQ_CH = 32;          // dh chunk staged per iteration
-constexpr int SEQ_LD = SEQ_CH + 1;  // LDS row stride of a staged chunk: conflict-free scalar writes and MFMA operand reads
+constexpr int SQ_CH = 64;  // dh chunk staged per iteration
+constexpr int SQ_LD = 66;  // LDS row stride of a staged chunk: the MFMA operand reads of Q K^T (row = lane & 31, column + (lane >> 5)) are conflict-free
 
-// dynamic LDS of the score kernels: row offsets, flags, the staged q / k chunks, the HP x HP grid
 template <int HP>
 struct SeqLds {
   int64_t s_off[HP], s_toff[HP];
-  float sq[HP][SEQ_LD], sk[HP][SEQ_LD];
-  float sc[HP][HP + 1];
-  float colm[HP];
-  uint8_t s_pad[HP];
-  int s_fp;
+  float sq[HP][SQ_LD], sk[HP][SQ_LD];
+  float sc[HP][HP + 2];
+  float colm[HP], mult[HP];
+  int cslot[HP], padkeep[HP];
+  int lc, haspad;
 };
 
-// chunk c0 of the q / k rows of the H slots: global -> registers (seq_fetch), registers -> LDS (seq_commit), so that the
-// loads of the NEXT chunk are in flight while the matrix cores work on this one.  Every load is unconditional (clamped row
-// and column, the tabulated part read from a valid dummy address and multiplied by 0 where it does not apply).
+// chunk c0 of the q / k rows: global -> registers (seq_fetch), registers -> LDS (seq_commit), so that the loads of the NEXT
+// chunk are in flight while the matrix cores work on this one.  8-byte loads (V2: dh even, so every row piece is 8-byte
+// aligned), unconditional (clamped row and column; the tabulated part from a valid dummy address where it does not apply).
 template <int HP>
 struct SeqPf {
-  float q[HP / 8], k[HP / 8], tq[HP / 8], tk[HP / 8];
+  float2 q[HP / 8], k[HP / 8], tq[HP / 8], tk[HP / 8];
 };
-template <int HP>
-__device__ __forceinline__ void seq_fetch(const SeqRows& sr, const SeqLds<HP>& L, int H, int dh, int dm, int c0, int tid,
+template <int HP, bool V2>
+__device__ __forceinline__ void seq_fetch(const SeqRows& sr, const SeqLds<HP>& L, int lc, int dh, int dm, int c0, int tid,
                                           SeqPf<HP>& p) {
 #pragma unroll
   for (int u = 0; u < HP / 8; ++u) {
-    if (u * 256 < H * SEQ_CH) {  // (block-uniform)
+    if (u * 256 < lc * (SQ_CH / 2)) {  // (block-uniform)
       const int f = tid + u * 256;
-      const int row = min(f / SEQ_CH, H - 1), col = min(c0 + f % SEQ_CH, dh - 1);
-      const float* b = sr.qk + L.s_off[row] + col;
+      const int row = min(f / (SQ_CH / 2), lc - 1), cc = (f % (SQ_CH / 2)) * 2;
       const int64_t to = L.s_toff[row];
-      const float* tb = to >= 0 ? sr.ta + to + col : b;
-      p.q[u] = b[0];
-      p.k[u] = b[dm];
-      p.tq[u] = tb[0];
-      p.tk[u] = tb[dm];
+      if (V2) {
+        const int col = min(c0 + cc, dh - 2);
+        const float* b = sr.qk + L.s_off[row] + col;
+        const float* tb = to >= 0 ? sr.ta + to + col : b;
+        p.q[u] = *reinterpret_cast<const float2*>(b);
+        p.k[u] = *reinterpret_cast<const float2*>(b + dm);
+        p.tq[u] = *reinterpret_cast<const float2*>(tb);
+        p.tk[u] = *reinterpret_cast<const float2*>(tb + dm);
+      } else {
+        const int col0 = min(c0 + cc, dh - 1), col1 = min(c0 + cc + 1, dh - 1);
+        const float* b = sr.qk + L.s_off[row];
+        const float* tb = to >= 0 ? sr.ta + to : b;
+        p.q[u] = make_float2(b[col0], b[col1]);
+        p.k[u] = make_float2(b[dm + col0], b[dm + col1]);
+        p.tq[u] = make_float2(tb[col0], tb[col1]);
+        p.tk[u] = make_float2(tb[dm + col0], tb[dm + col1]);
+      }
     }
   }
 }
 template <int HP>
-__device__ __forceinline__ void seq_commit(SeqLds<HP>& L, int H, int dh, int c0, int tid, const SeqPf<HP>& p) {
+__device__ __forceinline__ void seq_commit(SeqLds<HP>& L, int lc, int dh, int c0, int tid, const SeqPf<HP>& p) {
 #pragma unroll
   for (int u = 0; u < HP / 8; ++u) {
     const int f = tid + u * 256;
-    const int row = f / SEQ_CH, cc = f % SEQ_CH;
-    if (row < H) {
-      const bool ok = c0 + cc < dh;
+    const int row = f / (SQ_CH / 2), cc = (f % (SQ_CH / 2)) * 2;
+    if (row < lc) {
       const float tm = L.s_toff[row] >= 0 ? 1.f : 0.f;
-      L.sq[row][cc] = ok ? fmaf(tm, p.tq[u], p.q[u]) : 0.f;
-      L.sk[row][cc] = ok ? fmaf(tm, p.tk[u], p.k[u]) : 0.f;
+      const bool ok0 = c0 + cc < dh, ok1 = c0 + cc + 1 < dh;
+      L.sq[row][cc] = ok0 ? fmaf(tm, p.tq[u].x, p.q[u].x) : 0.f;
+      L.sq[row][cc + 1] = ok1 ? fmaf(tm, p.tq[u].y, p.q[u].y) : 0.f;
+      L.sk[row][cc] = ok0 ? fmaf(tm, p.tk[u].x, p.k[u].x) : 0.f;
+      L.sk[row][cc + 1] = ok1 ? fmaf(tm, p.tk[u].y, p.k[u].y) : 0.f;
     }
   }
 }
 
-// S = Q K^T over the staged chunks on v_mfma_f32_32x32x2_f32 (lane l feeds A[l & 31][l >> 5], B[l >> 5][l & 31]); the
-// HP x HP grid is NT x NT tiles of 32 x 32, TPW of them per wavefront (one row tile, consecutive column tiles)
-template <int HP>
-__device__ __forceinline__ void seq_qk_tiles(const SeqRows& sr, SeqLds<HP>& L, int H, int dh, int dm, int tid,
-                                             seq_f32x16* acc) {
-  constexpr int NT = HP / 32, TPW = NT * NT / 4;
-  const int wave = tid >> 6, lane = tid & 63, fr = lane & 31, fk = lane >> 5;
-  const int tmi = (wave * TPW) / NT, tn0 = (wave * TPW) % NT;
-#pragma unroll
-  for (int j = 0; j < TPW; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  SeqPf<HP> pf;
-  seq_fetch<HP>(sr, L, H, dh, dm, 0, tid, pf);
-  for (int c0 = 0; c0 < dh; c0 += SEQ_CH) {
-    seq_commit<HP>(L, H, dh, c0, tid, pf);
-    __syncthreads();
-    if (c0 + SEQ_CH < dh) seq_fetch<HP>(sr, L, H, dh, dm, c0 + SEQ_CH, tid, pf);
-    if (tmi * 32 < H) {
-#pragma unroll 4
-      for (int kk = 0; kk < SEQ_CH; kk += 2) {
-        const float a = L.sq[tmi * 32 + fr][kk + fk];
-#pragma unroll
-        for (int j = 0; j < TPW; ++j)
-          if ((tn0 + j) * 32 < H) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, L.sk[(tn0 + j) * 32 + fr][kk + fk], acc[j], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-  }
-}
-
+// the node's rows, their slots and multiplicities
 template <int HP>
 __device__ __forceinline__ void seq_lds_init(const SeqRows& sr, SeqLds<HP>& L, const int64_t* __restrict__ h_n, int64_t i,
                                              int h, int H, int dh, int dm, int tid) {
-  for (int f = tid; f < HP * SEQ_LD; f += 256) {  // rows past H stay zero: they only feed outputs that are never read
+  for (int f = tid; f < HP * SQ_LD; f += 256) {  // rows past lc stay zero: they are multiplied by zeros of the grid
     (&L.sq[0][0])[f] = 0.f;
     (&L.sk[0][0])[f] = 0.f;
   }
-  if (tid < H) {
-    L.s_off[tid] = (int64_t)sr.slot_row[i * H + tid] * 2 * dm + (int64_t)h * dh;
-    L.s_toff[tid] = (sr.ta && tid != H - 1) ? sr.anon[i * H + tid] * 2 * dm + (int64_t)h * dh : -1;
-    L.s_pad[tid] = (tid != H - 1) && (h_n[i * H + tid] == 0);  // restarters.py:86-87: padded keys are masked, never the last
+  for (int f = tid; f < HP * (HP + 2); f += 256) (&L.sc[0][0])[f] = 0.f;
+  const int b0 = sr.base[i], lc = sr.base[i + 1] - b0 + 1;
+  const int s0 = lc > 1 ? sr.row_slot[b0] - (int32_t)(i * H) : H - 1;  // slot of row 0: padded iff the node has padded slots
+  const int haspad = (lc > 1 && s0 != H - 1 && h_n[i * H + s0] == 0) ? 1 : 0;
+  if (tid == 0) {
+    L.lc = lc;
+    L.haspad = haspad;
+  }
+  if (tid < lc) {
+    const int grow = tid < lc - 1 ? b0 + tid : 0;
+    const int slot = tid < lc - 1 ? sr.row_slot[grow] - (int32_t)(i * H) : H - 1;
+    L.s_off[tid] = (int64_t)grow * 2 * dm + (int64_t)h * dh;
+    L.s_toff[tid] = (sr.ta && slot != H - 1) ? sr.anon[i * H + slot] * 2 * dm + (int64_t)h * dh : -1;
+    L.cslot[tid] = slot;
+    L.mult[tid] = (tid == 0 && haspad) ? (float)(H - 1 - (lc - 2)) : 1.f;  // padded slots = (H - 1) - real events
+    L.padkeep[tid] = 0;
   }
   __syncthreads();
 }
 
-// scores -> LDS grid, masked keys at -inf
-template <int HP>
-__device__ __forceinline__ void seq_scores_to_lds(SeqLds<HP>& L, int H, int dh, int tid, const seq_f32x16* acc) {
-  constexpr int NT = HP / 32, TPW = NT * NT / 4;
+// S = Q K^T of the node's rows on v_mfma_f32_32x32x2_f32 (lane l feeds A[l & 31][l >> 5], B[l >> 5][l & 31]), scaled, the
+// padded key (restarters.py:86-87) at -inf, left in L.sc.  HP = 64: every wavefront takes a quarter of each chunk's k-steps
+// for ALL tiles (one tile for most nodes: four wavefronts share its serial MFMA chain), partial grids added in wavefront
+// order; HP = 128: a wavefront owns a row of tiles.
+template <int HP, bool V2>
+__device__ __forceinline__ void seq_scores_to_lds(const SeqRows& sr, SeqLds<HP>& L, int dh, int dm, int tid) {
+  constexpr int NTM = HP / 32;
+  constexpr bool KS = HP == 64;
+  constexpr int NA = KS ? NTM * NTM : NTM;
+  const int lc = L.lc, NT = (lc + 31) / 32;
   const int wave = tid >> 6, lane = tid & 63, fr = lane & 31, fk = lane >> 5;
-  const int tmi = (wave * TPW) / NT, tn0 = (wave * TPW) % NT;
-  const float scale = 1.0f / sqrtf((float)dh);
+  seq_f32x16 acc[NA];
 #pragma unroll
-  for (int j = 0; j < TPW; ++j)
+  for (int j = 0; j < NA; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int t = tmi * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk, sidx = (tn0 + j) * 32 + fr;
-      if (t < H && sidx < H) L.sc[t][sidx] = L.s_pad[sidx] ? -INFINITY : acc[j][r] * scale;
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  SeqPf<HP> pf;
+  seq_fetch<HP, V2>(sr, L, lc, dh, dm, 0, tid, pf);
+  for (int c0 = 0; c0 < dh; c0 += SQ_CH) {
+    seq_commit<HP>(L, lc, dh, c0, tid, pf);
+    __syncthreads();
+    if (c0 + SQ_CH < dh) seq_fetch<HP, V2>(sr, L, lc, dh, dm, c0 + SQ_CH, tid, pf);
+    if (KS) {
+#pragma unroll
+      for (int kq = 0; kq < SQ_CH / 8; ++kq) {
+        const int kk = 2 * (wave + 4 * kq);
+#pragma unroll
+        for (int tm = 0; tm < NTM; ++tm)
+          if (tm < NT) {
+            const float a = L.sq[tm * 32 + fr][kk + fk];
+#pragma unroll
+            for (int tn = 0; tn < NTM; ++tn)
+              if (tn < NT)
+                acc[(KS ? tm * NTM : 0) + tn] =
+                    __builtin_amdgcn_mfma_f32_32x32x2f32(a, L.sk[tn * 32 + fr][kk + fk], acc[(KS ? tm * NTM : 0) + tn], 0, 0, 0);
+          }
+      }
+    } else if (wave < NT) {
+#pragma unroll 4
+      for (int kk = 0; kk < SQ_CH; kk += 2) {
+        const float a = L.sq[wave * 32 + fr][kk + fk];
+#pragma unroll
+        for (int tn = 0; tn < NTM; ++tn)
+          if (tn < NT) acc[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, L.sk[tn * 32 + fr][kk + fk], acc[tn], 0, 0, 0);
+      }
     }
+    __syncthreads();
+  }
+  const float scale = 1.0f / sqrtf((float)dh);
+  if (KS) {
+    for (int wv = 0; wv < 4; ++wv) {
+      if (wave == wv) {
+#pragma unroll
+        for (int tm = 0; tm < NTM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < NTM; ++tn)
+            if (tm < NT && tn < NT) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int t = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk, sidx = tn * 32 + fr;
+                if (t < lc && sidx < lc) L.sc[t][sidx] += acc[(KS ? tm * NTM : 0) + tn][r];
+              }
+            }
+      }
+      __syncthreads();
+    }
+    for (int p = tid; p < lc * lc; p += 256) {
+      const int t = p / lc, sidx = p % lc;
+      L.sc[t][sidx] = (sidx == 0 && L.haspad) ? -INFINITY : L.sc[t][sidx] * scale;
+    }
+  } else {
+    if (wave < NT) {
+#pragma unroll
+      for (int tn = 0; tn < NTM; ++tn)
+        if (tn < NT) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int t = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk, sidx = tn * 32 + fr;
+            if (t < lc && sidx < lc) L.sc[t][sidx] = (sidx == 0 && L.haspad) ? -INFINITY : acc[tn][r] * scale;
+          }
+        }
+    }
+  }
+  __syncthreads();
 }
 
-// One block per (node, head): scores = q k^T / sqrt(dh) over the H x H grid (matrix cores), key padding
-// mask, row softmax, column mean.
+// attention dropout (nn.MultiheadAttention): padkeep[s] = number of padded slots t whose mask entry (t, slot(s)) is kept
 template <int HP>
+__device__ __forceinline__ void seq_padkeep(SeqLds<HP>& L, const int64_t* __restrict__ h_n, int64_t i, int h, int H, int nh,
+                                            uint64_t dkey, const DropCfg& dc, int tid) {
+  if (dc.p > 0.f && L.haspad) {
+    const int lc = L.lc;
+    for (int p = tid; p < (H - 1) * lc; p += 256) {
+      const int t = p / lc, sidx = p % lc;
+      if (h_n[i * H + t] == 0 &&
+          drop_keep(dkey, DROP_SEQ_ATTN, (((uint64_t)i * nh + h) * H + t) * H + L.cslot[sidx], dc.thresh))
+        atomicAdd(&L.padkeep[sidx], 1);
+    }
+  }
+  __syncthreads();
+}
+// M[r, s] (see above)
+template <int HP>
+__device__ __forceinline__ float seq_mult(const SeqLds<HP>& L, int r, int sidx, int64_t i, int h, int H, int nh, uint64_t dkey,
+                                          const DropCfg& dc) {
+  if (dc.p <= 0.f) return L.mult[r];
+  if (r == 0 && L.haspad) return dc.scale * (float)L.padkeep[sidx];
+  return drop_keep(dkey, DROP_SEQ_ATTN, (((uint64_t)i * nh + h) * H + L.cslot[r]) * H + L.cslot[sidx], dc.thresh) ? dc.scale : 0.f;
+}
+
+// One block per (node, head): scores, key padding mask, row softmax, column mean - on the node's own rows.
+template <int HP, bool V2>
 __global__ void __launch_bounds__(256) k_seq_scores(int64_t n, int H, int dm, int nh, SeqRows sr,
                                                     const int64_t* __restrict__ h_n, float* __restrict__ abar,
                                                     const int32_t* __restrict__ n_dev, DropCfg dc,
@@ -313,39 +407,35 @@ __global__ void __launch_bounds__(256) k_seq_scores(int64_t n, int H, int dm, in
   const int dh = dm / nh;
   const int tid = threadIdx.x;
   seq_lds_init<HP>(sr, L, h_n, i, h, H, dh, dm, tid);
-  seq_f32x16 acc[HP / 32 * (HP / 32) / 4];
-  seq_qk_tiles<HP>(sr, L, H, dh, dm, tid, acc);
-  seq_scores_to_lds<HP>(L, H, dh, tid, acc);
-  __syncthreads();
-  if (tid < H) {  // row softmax
+  seq_scores_to_lds<HP, V2>(sr, L, dh, dm, tid);
+  seq_padkeep<HP>(L, h_n, i, h, H, nh, dkey, dc, tid);
+  const int lc = L.lc;
+  if (tid < lc) {  // row softmax, weighted by the row's multiplicity (and dropout mask)
     float mx = -INFINITY;
-    for (int s = 0; s < H; ++s) mx = fmaxf(mx, L.sc[tid][s]);
+    for (int s = 0; s < lc; ++s) mx = fmaxf(mx, L.sc[tid][s]);
     float sum = 0.f;
-    for (int s = 0; s < H; ++s) {
+    for (int s = 0; s < lc; ++s) {
       const float e = expf(L.sc[tid][s] - mx);
       L.sc[tid][s] = e;
       sum += e;
     }
     const float inv = 1.f / sum;
-    for (int s = 0; s < H; ++s) {
-      float ms = 1.f;  // attention dropout (nn.MultiheadAttention) on the normalised probabilities
-      if (dc.p > 0.f)
-        ms = drop_keep(dkey, DROP_SEQ_ATTN, (((uint64_t)i * nh + h) * H + tid) * H + s, dc.thresh) ? dc.scale : 0.f;
-      L.sc[tid][s] *= inv * ms;
-    }
+    for (int s = 0; s < lc; ++s) L.sc[tid][s] *= inv * seq_mult<HP>(L, tid, s, i, h, H, nh, dkey, dc);
   }
   __syncthreads();
-  if (tid < H) {  // column mean
+  if (tid < lc) {  // column mean over the H query slots
     float a = 0.f;
-    for (int t = 0; t < H; ++t) a += L.sc[t][tid];
-    a /= (float)H;
-    abar[((int64_t)i * nh + h) * H + tid] = a;
-    L.colm[tid] = a;
+    for (int t = 0; t < lc; ++t) a += L.sc[t][tid];
+    L.colm[tid] = a / (float)H;
   }
   __syncthreads();
+  if (tid < H) {  // back to slot space: a padded slot reads the padded row's column, which is masked (0)
+    const int r = tid == H - 1 ? lc - 1 : sr.slot_row[i * H + tid] - sr.base[i];
+    abar[((int64_t)i * nh + h) * H + tid] = L.colm[r];
+  }
   if (tid == 0 && rbar) {  // sum of the column means: weight of the value bias (1 without dropout)
     float r = 0.f;
-    for (int s = 0; s < H; ++s) r += L.colm[s];
+    for (int s = 0; s < lc; ++s) r += L.colm[s];
     rbar[(int64_t)i * nh + h] = dc.p > 0.f ? r : 1.f;
   }
 }
@@ -425,13 +515,12 @@ __global__ void __launch_bounds__(256) k_seq_mix_bwd(int64_t n, const int32_t* _
   }
 }
 
-// One block per (node, head): recompute the H x H attention (as k_seq_scores), then
-//   dA[t, s] = dabar[s] / H;  dS[t, s] = A[t, s] (dA[t, s] - sum_s' A[t, s'] dA[t, s'])
-//   dq_t = scale sum_s dS[t, s] k_s;   dk_s = scale sum_t dS[t, s] q_t      (both on the matrix cores, per dh chunk)
-// The gradients land on the COMPACT rows: a real slot's on its own row, the padded slots' query gradients summed on the
-// node's padded row (their keys are masked: no key gradient), the last slot's in dqk_last [n, 2 dm] (summed over the nodes
-// into row 0 afterwards).
-template <int HP>
+// One block per (node, head): recompute the attention of the node's rows (as k_seq_scores), then
+//   dA[r, s] = M[r, s] dabar[s] / H;  dS[r, s] = A[r, s] (dA[r, s] - sum_s' A[r, s'] dA[r, s'])
+//   dq_r = scale sum_s dS[r, s] k_s;   dk_s = scale sum_r dS[r, s] q_r      (both on the matrix cores, per dh chunk)
+// The gradients land on the COMPACT rows directly (the padded row's is the sum over its slots: M carries the multiplicity;
+// its key is masked: zero key gradient), the last row's in dqk_last [n, 2 dm] (summed over the nodes into row 0 afterwards).
+template <int HP, bool V2>
 __global__ void __launch_bounds__(256) k_seq_scores_bwd(int64_t n, const int32_t* __restrict__ n_dev, int H, int dm,
                                                         int nh, SeqRows sr, const int64_t* __restrict__ h_n,
                                                         const float* __restrict__ dabar, float* __restrict__ dqk,
@@ -445,93 +534,64 @@ __global__ void __launch_bounds__(256) k_seq_scores_bwd(int64_t n, const int32_t
   const int dh = dm / nh;
   const int tid = threadIdx.x;
   seq_lds_init<HP>(sr, L, h_n, i, h, H, dh, dm, tid);
-  if (tid == 0) {
-    int fp = -1;
-    for (int t = 0; t < H - 1 && fp < 0; ++t)
-      if (L.s_pad[t]) fp = t;
-    L.s_fp = fp;
-  }
-  for (int f = tid; f < HP * (HP + 1); f += 256) (&L.sc[0][0])[f] = 0.f;  // rows / columns past H are MFMA operands below
-  {
-    seq_f32x16 acc[HP / 32 * (HP / 32) / 4];
-    seq_qk_tiles<HP>(sr, L, H, dh, dm, tid, acc);  // (its barriers order the zero fill above)
-    seq_scores_to_lds<HP>(L, H, dh, tid, acc);
-  }
-  __syncthreads();
+  seq_scores_to_lds<HP, V2>(sr, L, dh, dm, tid);
+  seq_padkeep<HP>(L, h_n, i, h, H, nh, dkey, dc, tid);
+  const int lc = L.lc;
   const float scale = 1.0f / sqrtf((float)dh);
-  if (tid < H) {  // row softmax, then the softmax backward of that row, pre-multiplied by the score scale
+  if (tid < lc) {  // row softmax, then the softmax backward of that row, pre-multiplied by the score scale
     float mx = -INFINITY;
-    for (int s = 0; s < H; ++s) mx = fmaxf(mx, L.sc[tid][s]);
+    for (int s = 0; s < lc; ++s) mx = fmaxf(mx, L.sc[tid][s]);
     float sum = 0.f;
-    for (int s = 0; s < H; ++s) {
+    for (int s = 0; s < lc; ++s) {
       const float e = expf(L.sc[tid][s] - mx);
       L.sc[tid][s] = e;
       sum += e;
     }
     const float inv = 1.f / sum, invH = 1.f / (float)H;
     const float* da = dabar + ((int64_t)i * nh + h) * H;
-    auto dA = [&](int s) {  // d A[t, s]: through the dropout mask of this entry
-      float g = da[s] * invH;
-      if (dc.p > 0.f)
-        g = drop_keep(dkey, DROP_SEQ_ATTN, (((uint64_t)i * nh + h) * H + tid) * H + s, dc.thresh) ? g * dc.scale : 0.f;
-      return g;
-    };
+    auto dA = [&](int s) { return da[L.cslot[s]] * invH * seq_mult<HP>(L, tid, s, i, h, H, nh, dkey, dc); };
     float dot = 0.f;
-    for (int s = 0; s < H; ++s) {
+    for (int s = 0; s < lc; ++s) {
       const float a = L.sc[tid][s] * inv;
       L.sc[tid][s] = a;
       dot = fmaf(a, dA(s), dot);
     }
-    for (int s = 0; s < H; ++s) L.sc[tid][s] = L.sc[tid][s] * (dA(s) - dot) * scale;
+    for (int s = 0; s < lc; ++s) L.sc[tid][s] = L.sc[tid][s] * (dA(s) - dot) * scale;
   }
   __syncthreads();
-  // the padded query rows share one operand row: fold their dS rows into the first of them, in slot order
-  const int fp = L.s_fp;
-  if (fp >= 0 && tid < H) {
-    float a = L.sc[fp][tid];
-    for (int t = fp + 1; t < H - 1; ++t)
-      if (L.s_pad[t]) {
-        a += L.sc[t][tid];
-        L.sc[t][tid] = 0.f;
-      }
-    L.sc[fp][tid] = a;
-  }
-  __syncthreads();
-  // per chunk of 32 columns: dq tile o (rows o * 32 ..) = dS[rows, :] K[:, chunk],  dk tile o = dS[:, rows]^T Q[:, chunk];
-  // 2 NT output tiles of 32 x 32, TPO per wavefront; the contraction runs over the H slots
-  constexpr int NT = HP / 32, TPO = 2 * NT / 4;
+  // per chunk of 64 columns: a wavefront takes dq or dk (wave & 1) of one 32-column half (wave >> 1), row tile by row tile:
+  // dq tile = dS[rows, :] K[:, half],  dk tile = dS[:, rows]^T Q[:, half]; the contraction runs over the lc rows
   const int wave = tid >> 6, lane = tid & 63, fr = lane & 31, fk = lane >> 5;
-  const int Hk = (H + 1) & ~1;
+  const int isk = wave & 1, half = wave >> 1;
+  const int NT = (lc + 31) / 32, Lk = (lc + 1) & ~1;
   SeqPf<HP> pf;
-  seq_fetch<HP>(sr, L, H, dh, dm, 0, tid, pf);
-  for (int c0 = 0; c0 < dh; c0 += SEQ_CH) {
-    seq_commit<HP>(L, H, dh, c0, tid, pf);
+  seq_fetch<HP, V2>(sr, L, lc, dh, dm, 0, tid, pf);
+  for (int c0 = 0; c0 < dh; c0 += SQ_CH) {
+    seq_commit<HP>(L, lc, dh, c0, tid, pf);
     __syncthreads();
-    if (c0 + SEQ_CH < dh) seq_fetch<HP>(sr, L, H, dh, dm, c0 + SEQ_CH, tid, pf);
-#pragma unroll
-    for (int j = 0; j < TPO; ++j) {
-      const int o = wave * TPO + j;
-      const bool isk = o >= NT;
-      const int r0 = (isk ? o - NT : o) * 32;
-      if (r0 < H) {
+    if (c0 + SQ_CH < dh) seq_fetch<HP, V2>(sr, L, lc, dh, dm, c0 + SQ_CH, tid, pf);
+    const int col = c0 + half * 32 + fr;
+    for (int tm = 0; tm < NT; ++tm) {
+      const int r0 = tm * 32;
       seq_f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       if (!isk) {
-        for (int kk = 0; kk < Hk; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(L.sc[r0 + fr][kk + fk], L.sk[kk + fk][fr], acc, 0, 0, 0);
+        for (int kk = 0; kk < Lk; kk += 2)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(L.sc[r0 + fr][kk + fk], L.sk[kk + fk][half * 32 + fr], acc, 0, 0, 0);
       } else {
-        for (int kk = 0; kk < Hk; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(L.sc[kk + fk][r0 + fr], L.sq[kk + fk][fr], acc, 0, 0, 0);
+        for (int kk = 0; kk < Lk; kk += 2)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(L.sc[kk + fk][r0 + fr], L.sq[kk + fk][half * 32 + fr], acc, 0, 0, 0);
       }
-      if (c0 + fr < dh) {
+      if (col < dh) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-          if (row < H && (!L.s_pad[row] || row == fp)) {
-            float* ob = (row == H - 1 ? dqk_last + i * 2 * dm + (int64_t)h * dh : dqk + L.s_off[row]) + c0 + fr;
+          if (row < lc) {
+            float* ob = (row == lc - 1 ? dqk_last + i * 2 * dm + (int64_t)h * dh : dqk + L.s_off[row]) + col;
             ob[isk ? dm : 0] = acc[r];
           }
         }
-      }
       }
     }
     __syncthreads();
@@ -831,11 +891,11 @@ static int seq_ok(const tg_model* m, const tg_seq_restarter* r) {
 static int seq_lds_attr() {
   static int done = 0;  // (per process; the attribute belongs to the function, whichever device runs it)
   if (done) return TG_OK;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seq_scores<128>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeqLds<128>));
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seq_scores_bwd<128>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeqLds<128>));
+  hipError_t e = hipSuccess;
+  const void* fns[4] = {reinterpret_cast<const void*>(&k_seq_scores<128, true>), reinterpret_cast<const void*>(&k_seq_scores<128, false>),
+                        reinterpret_cast<const void*>(&k_seq_scores_bwd<128, true>), reinterpret_cast<const void*>(&k_seq_scores_bwd<128, false>)};
+  for (int j = 0; j < 4 && e == hipSuccess; ++j)
+    e = hipFuncSetAttribute(fns[j], hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SeqLds<128>));
   if (e != hipSuccess) {
     set_hip_error(e, "seq_lds_attr");
     return TG_EHIP;
@@ -874,14 +934,16 @@ static int seq_forward(const tg_model* m, const tg_seq_restarter* r, int64_t n, 
   g.m_cap = w.rowcap; g.m_dev = w.rows; g.n = 2 * dm; g.k = w.wx; g.a0 = ASeg{w.xc, w.wx, w.wx, nullptr};
   g.w = r->in_proj_w + col0; g.ldw = dm; g.bias = r->in_proj_b; g.c = w.qk; g.ldc = 2 * dm; g.alpha = 1.f; g.nbatch = 1;
   if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
-  const SeqRows sr{w.qk, w.slot_row, w.ta, anon};
+  const SeqRows sr{w.qk, w.slot_row, w.row_slot, w.base, w.ta, anon};
   if ((rc = seq_lds_attr()) != TG_OK) return rc;
-  if (H <= 64)
-    hipLaunchKernelGGL((k_seq_scores<64>), dim3((unsigned)(n * nh)), dim3(256), sizeof(SeqLds<64>), st, n, H, dm, nh, sr,
-                       h_n, w.abar, n_dev, dc, w.rbar);
-  else
-    hipLaunchKernelGGL((k_seq_scores<128>), dim3((unsigned)(n * nh)), dim3(256), sizeof(SeqLds<128>), st, n, H, dm, nh, sr,
-                       h_n, w.abar, n_dev, dc, w.rbar);
+#define TG_SEQ_SCORES(HP_, V2_)                                                                                     \
+  hipLaunchKernelGGL((k_seq_scores<HP_, V2_>), dim3((unsigned)(n * nh)), dim3(256), sizeof(SeqLds<HP_>), st, n, H, dm, nh, \
+                     sr, h_n, w.abar, n_dev, dc, w.rbar)
+  if (H <= 64 && dh % 2 == 0) TG_SEQ_SCORES(64, true);
+  else if (H <= 64) TG_SEQ_SCORES(64, false);
+  else if (dh % 2 == 0) TG_SEQ_SCORES(128, true);
+  else TG_SEQ_SCORES(128, false);
+#undef TG_SEQ_SCORES
   const SeqCols sc{(const float4*)w.xc, w.wx / 4, col0 / 4, w.wide ? nullptr : (const float4*)r->anony_emb, w.slot_row, anon};
   hipLaunchKernelGGL(k_seq_mix, dim3(flat_grid(n * nh * (dm / 4), 256)), dim3(256), 0, st, n, H, dm / 4, d / 4, nh, w.abar,
                      sc, (float4*)w.xbar, n_dev);
@@ -926,7 +988,7 @@ static int seq_forward(const tg_model* m, const tg_seq_restarter* r, int64_t n, 
 struct MutualWs {
   double *ts2, *tu;
   int64_t *uniq, *index, *h_n, *h_e, *h_d, *anon;
-  float *h_t, *sl, *sr, *prev_ts, *dsl, *dsr, *dt2, *dom, *dO, *dOm, *dxbar, *dabar, *dqk, *dqk_last, *dXs, *dTaT, *acc, *bpart;
+  float *h_t, *sl, *sr, *prev_ts, *dsl, *dsr, *dt2, *dom, *dO, *dOm, *dxbar, *dabar, *dqk, *dqk_last, *dXs, *dTaT, *acc, *bpart, *cpart;
   int bb_blocks;  // blocks of k_seq_build_bwd = rows of bpart
   int32_t *count, *counts2;
   uint8_t* valid;
@@ -971,6 +1033,7 @@ static bool carve_mutual(const tg_model* m, const tg_seq_restarter* r, int64_t B
     w.dqk_last = cv.take<float>(n * 2 * dm);
     w.dXs = cv.take<float>((size_t)w.seq.rowcap * (w.seq.wide ? 2 : 1) * d);
     w.dTaT = w.seq.wide ? nullptr : cv.take<float>(2 * dm * (size_t)w.seq.ohw);  // d T_a [ohw, 2 dm]
+    w.cpart = cv.take<float>((size_t)16 * 2 * dm);  // partial column sums of the last slots' gradients
     w.bb_blocks = (int)std::min<int64_t>(cdiv(n * (int64_t)H, 32), 1024);
     w.bpart = cv.take<float>((size_t)w.bb_blocks * (2 * d + (H + 1) * d));
   }
@@ -990,7 +1053,10 @@ size_t mutual_ws_bytes(const tg_model* m, const tg_seq_restarter* r, int64_t B) 
 int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, const StepWs& sw,
                 const tg_seq_restarter* r, const tg_seq_restarter* gr, const float* st_left, const float* st_right,
                 float* g_left, float* g_right, float* loss_out, int32_t* flag_out, float* part, size_t part_floats,
-                void* ws, size_t ws_bytes, const DropCfg& dc, hipStream_t st) {
+                void* ws, size_t ws_bytes, const DropCfg& dc, hipStream_t st, int phase, SideCtx* side) {
+  // phase 1: the restarter's forward (restart data, histories, surrogate rows) - reads the batch, the graph and the
+  // restarter's parameters only, so the training step runs it beside the contrast half on a second stream;
+  // phase 2: loss and backward (needs the targets of STEP 4/5); 3: both
   if (!sio->h_prev_left || !sio->h_prev_right) return TG_EINVAL;
   if (r && (!seq_ok(m, r) || r->hist_len > 128 || !gr)) return TG_EUNSUPPORTED;
   if (!r && (!st_left || !st_right || !g_left || !g_right)) return TG_EINVAL;
@@ -1000,12 +1066,14 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
   MutualWs w{};
   if (!carve_mutual(m, r, B, cv, w)) return TG_EWORKSPACE;
   int rc;
+  const int H = r ? r->hist_len : 1;
+  auto F = [](const float* p) { return const_cast<float*>(p); };
+  if (phase & 1) {
   // ---- restart data (data_loader.py:133-165): latest occurrence of every positive node, float64 times
   hipLaunchKernelGGL(k_restart_queries, dim3(flat_grid(n, 256)), dim3(256), 0, st, B, sio->ts, sio->offset_dev, w.ts2);
   if ((rc = tg_select_latest(n, sw.nids3, w.ts2, 1, m->n_nodes, w.uniq, w.index, w.count, w.sel_ws, w.sel_bytes,
                              (void*)st)) != TG_OK)
     return rc;
-  const int H = r ? r->hist_len : 1;
   hipLaunchKernelGGL(k_restart_pad, dim3(flat_grid(n, 256)), dim3(256), 0, st, n, w.count, H, w.uniq, w.index, w.ts2,
                      w.tu, w.counts2);
   hipError_t e = hipMemsetAsync(w.acc, 0, 4 * sizeof(float), st);
@@ -1013,7 +1081,6 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
     set_hip_error(e, "mutual_step memset");
     return TG_EHIP;
   }
-  auto F = [](const float* p) { return const_cast<float*>(p); };
   if (!r) {
     hipLaunchKernelGGL(k_static_rows, dim3(flat_grid(n * d, 256)), dim3(256), 0, st, n, w.counts2, d, w.uniq, st_left,
                        st_right, w.sl, w.sr);
@@ -1025,6 +1092,8 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
                           st, dc)) != TG_OK)
       return rc;
   }
+  }
+  if (!(phase & 2)) return check_launch("mutual_step(forward)");
   hipLaunchKernelGGL(k_mutual_a, dim3(std::min<unsigned>(flat_grid(2 * n, 4), 512)), dim3(256), 0, st, n, w.counts2, d,
                      w.index, sio->h_prev_left, sio->h_prev_right, w.sl, w.sr, w.valid, w.acc);
   hipLaunchKernelGGL(k_mutual_b, dim3(flat_grid(2 * n * d, 256)), dim3(256), 0, st, n, w.counts2, d, w.index,
@@ -1042,6 +1111,34 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
   const int off = q.wide ? 0 : 2 * d, col0 = q.wide ? 0 : 3 * d;
   TnArgs tn{};
   GemmArgs ga{};
+  // The weight-gradient products depend on the gradient chain but nothing depends on them: they are collected and launched
+  // as two groups (gemm_tn_group_launch: one launch + one reduction each) - the value-side ones behind the per-head products,
+  // the q / k projection's behind the score backward - on the side lane when there is one (a fork each, one join before the
+  // parameter sums of the build pass), while the chain goes on on the main stream.
+  const size_t lfull = (size_t)((H + 1) * d) * sizeof(float);
+  const int use_lds = lfull <= 60 * 1024;  // (else the build pass adds to d anony_emb with atomics while it runs: one stream)
+  const bool side_ok = side != nullptr && use_lds && side->used + 3 <= side->n;
+  std::vector<TnArgs> wq, late_heads;
+  auto wgrad = [&](const TnArgs& a) {
+    wq.push_back(a);
+    return (int)TG_OK;
+  };
+  hipStream_t ws_st = st;  // stream of the last flushed group
+  auto flush = [&]() {
+    ws_st = st;
+    if (side_ok) {
+      if (!side->after_main(st)) {
+        set_hip_error(hipGetLastError(), "mutual_step lane fork");
+        return (int)TG_EHIP;
+      }
+      ws_st = side->s;
+    }
+    int rcf = TG_OK;
+    for (size_t o = 0; o < wq.size() && rcf == TG_OK; o += TN_GROUP_MAX)
+      rcf = gemm_tn_group_launch(wq.data() + o, (int)std::min<size_t>(TN_GROUP_MAX, wq.size() - o), part, part_floats, ws_st);
+    wq.clear();
+    return rcf;
+  };
   auto tn_base = [&](int64_t cap, const int32_t* md) {
     TnArgs t{};
     t.m_cap = cap; t.m_dev = md; t.alpha = 1.f; t.accumulate = 1; t.nbatch = 1; t.part = part; t.part_floats = part_floats;
@@ -1052,7 +1149,7 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
   tn = tn_base(n, n_dev);
   tn.n = d; tn.k = d; tn.y = w.dsr; tn.ldy = d; tn.x0 = ASeg{q.t2, d, d, nullptr};
   tn.out = F(gr->fc2.w); tn.ldo = d; tn.bias_out = F(gr->fc2.b);
-  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  if ((rc = wgrad(tn)) != TG_OK) return rc;
   ga = GemmArgs{};
   ga.m_cap = n; ga.m_dev = n_dev; ga.n = d; ga.k = d; ga.a0 = ASeg{w.dsr, d, d, nullptr};
   ga.w = r->fc2.w; ga.ldw = d; ga.w_kmajor = 1; ga.c = w.dt2; ga.ldc = d; ga.nbatch = 1;
@@ -1062,7 +1159,7 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
   tn = tn_base(n, n_dev);
   tn.n = d; tn.k = d; tn.y = w.dt2; tn.ldy = d; tn.x0 = ASeg{w.sl, d, d, nullptr};
   tn.out = F(gr->fc1.w); tn.ldo = dm; tn.bias_out = F(gr->fc1.b);
-  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  if ((rc = wgrad(tn)) != TG_OK) return rc;
   ga = GemmArgs{};  // d h_left += dt2 fc1[:, :d]
   ga.m_cap = n; ga.m_dev = n_dev; ga.n = d; ga.k = d; ga.a0 = ASeg{w.dt2, d, d, nullptr};
   ga.w = r->fc1.w; ga.ldw = dm; ga.w_kmajor = 1; ga.c = w.dsl; ga.ldc = d; ga.alpha = 1.f; ga.nbatch = 1; ga.accumulate = 1;
@@ -1071,7 +1168,7 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
   tn = tn_base(n, n_dev);
   tn.n = d; tn.k = dm; tn.y = w.dsl; tn.ldy = d; tn.x0 = ASeg{q.om, dm, dm, nullptr};
   tn.out = F(gr->out_fn.w); tn.ldo = dm; tn.bias_out = F(gr->out_fn.b);
-  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  if ((rc = wgrad(tn)) != TG_OK) return rc;
   ga = GemmArgs{};
   ga.m_cap = n; ga.m_dev = n_dev; ga.n = dm; ga.k = d; ga.a0 = ASeg{w.dsl, d, d, nullptr};
   ga.w = r->out_fn.w; ga.ldw = dm; ga.w_kmajor = 1; ga.c = w.dom; ga.ldc = dm; ga.alpha = 1.f; ga.nbatch = 1;
@@ -1081,7 +1178,7 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
   tn = tn_base(n, n_dev);
   tn.n = dm; tn.k = dm; tn.y = w.dom; tn.ldy = dm; tn.x0 = ASeg{q.o, dm, dm, nullptr};
   tn.out = F(gr->out_proj.w); tn.ldo = dm; tn.bias_out = F(gr->out_proj.b);
-  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  if ((rc = wgrad(tn)) != TG_OK) return rc;
   ga = GemmArgs{};
   ga.m_cap = n; ga.m_dev = n_dev; ga.n = dm; ga.k = dm; ga.a0 = ASeg{w.dom, dm, dm, nullptr};
   ga.w = r->out_proj.w; ga.ldw = dm; ga.w_kmajor = 1; ga.c = w.dO; ga.ldc = dm; ga.alpha = 1.f; ga.nbatch = 1;
@@ -1098,33 +1195,65 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
     tn.x0 = ASeg{q.xbar + (int64_t)h * dm + off, (int64_t)nh * dm, dm - off, nullptr};
     tn.out = F(gr->in_proj_w) + (int64_t)2 * dm * dm + off; tn.ldo = dm; tn.bias_out = F(gr->in_proj_b) + 2 * dm;
     if (dc.p > 0.f) { tn.bias_rs = q.rbar; tn.ld_brs = nh; tn.brs_col = h; }
-    if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+    // (all heads add to the same rows - each to its own, zeros to the others': one of them per group, the rest behind it)
+    if (h == 0) {
+      if ((rc = wgrad(tn)) != TG_OK) return rc;
+    } else {
+      late_heads.push_back(tn);
+    }
     ga = GemmArgs{};
     ga.m_cap = n; ga.m_dev = n_dev; ga.n = dm - off; ga.k = dm; ga.a0 = ASeg{dOh, dm, dm, nullptr};
     ga.w = r->in_proj_w + (int64_t)2 * dm * dm + off; ga.ldw = dm; ga.w_kmajor = 1;
     ga.c = w.dxbar + (int64_t)h * dm + off; ga.ldc = (int64_t)nh * dm; ga.alpha = 1.f; ga.nbatch = 1;
     if ((rc = gemm_launch(ga, st)) != TG_OK) return rc;
   }
+  if ((rc = flush()) != TG_OK) return rc;
+  for (const TnArgs& a : late_heads)
+    if ((rc = gemm_tn_launch(a, ws_st)) != TG_OK) return rc;
   // value mix and attention scores
   const SeqCols sc{(const float4*)q.xc, q.wx / 4, col0 / 4, q.wide ? nullptr : (const float4*)r->anony_emb, q.slot_row, w.anon};
   hipLaunchKernelGGL(k_seq_mix_bwd, dim3(flat_grid(n * nh * H, 4)), dim3(256), 0, st, n, n_dev, H, dm / 4, d / 4, nh,
                      (const float4*)w.dxbar, sc, w.dabar, dc.p > 0.f ? w.dO : (const float*)nullptr,
                      r->in_proj_b + 2 * dm);
-  const SeqRows sr{q.qk, q.slot_row, q.ta, w.anon};
-  if (H <= 64)
-    hipLaunchKernelGGL((k_seq_scores_bwd<64>), dim3((unsigned)(n * nh)), dim3(256), sizeof(SeqLds<64>), st, n, n_dev, H, dm,
-                       nh, sr, w.h_n, w.dabar, w.dqk, w.dqk_last, dc);
-  else
-    hipLaunchKernelGGL((k_seq_scores_bwd<128>), dim3((unsigned)(n * nh)), dim3(256), sizeof(SeqLds<128>), st, n, n_dev, H,
-                       dm, nh, sr, w.h_n, w.dabar, w.dqk, w.dqk_last, dc);
+  const SeqRows sr{q.qk, q.slot_row, q.row_slot, q.base, q.ta, w.anon};
+#define TG_SEQ_SCORES_BWD(HP_, V2_)                                                                                   \
+  hipLaunchKernelGGL((k_seq_scores_bwd<HP_, V2_>), dim3((unsigned)(n * nh)), dim3(256), sizeof(SeqLds<HP_>), st, n, n_dev, H, \
+                     dm, nh, sr, w.h_n, w.dabar, w.dqk, w.dqk_last, dc)
+  if (H <= 64 && (dm / nh) % 2 == 0) TG_SEQ_SCORES_BWD(64, true);
+  else if (H <= 64) TG_SEQ_SCORES_BWD(64, false);
+  else if ((dm / nh) % 2 == 0) TG_SEQ_SCORES_BWD(128, true);
+  else TG_SEQ_SCORES_BWD(128, false);
+#undef TG_SEQ_SCORES_BWD
   // row 0 (the last event of every node) collects the last slots' gradients
-  if ((rc = colsum_launch(n, n_dev, 2 * dm, w.dqk_last, 2 * dm, 1.f, w.dqk, 0, part, part_floats, st)) != TG_OK) return rc;
+  if ((rc = colsum_launch(n, n_dev, 2 * dm, w.dqk_last, 2 * dm, 1.f, w.dqk, 0, w.cpart, (size_t)16 * 2 * dm, st)) != TG_OK) return rc;
   // q/k projection: weight columns [col0, dm), bias
   tn = tn_base(q.rowcap, rows_dev);
   tn.n = 2 * dm; tn.k = q.wx; tn.y = w.dqk; tn.ldy = 2 * dm; tn.x0 = ASeg{q.xc, q.wx, q.wx, nullptr};
   tn.out = F(gr->in_proj_w) + col0; tn.ldo = dm; tn.bias_out = F(gr->in_proj_b);
-  if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
-  // input-row gradients, only for the column blocks that carry parameters
+  if ((rc = wgrad(tn)) != TG_OK) return rc;
+  if (!q.wide) {
+    // the tabulated anony_emb block, T_a = anony_emb Wa^T with Wa = in_proj_w[0:2dm, 2d:3d]:  d T_a = onehot^T dqk
+    // ([ohw, 2 dm]), then  d anony_emb += d T_a Wa  and  d Wa += d T_a^T anony_emb  (rows past H of d T_a are zeros: no slot
+    // carries such an id; the two products read its first H + 1 rows only)
+    tn = tn_base(q.rowcap, rows_dev);
+    tn.accumulate = 0; tn.bias_accumulate = 0;
+    tn.n = q.ohw; tn.k = 2 * dm; tn.y = q.oh; tn.ldy = q.ohw; tn.x0 = ASeg{w.dqk, 2 * dm, 2 * dm, nullptr};
+    tn.out = w.dTaT; tn.ldo = 2 * dm;
+    if ((rc = wgrad(tn)) != TG_OK) return rc;
+  }
+  if ((rc = flush()) != TG_OK) return rc;
+  if (!q.wide) {
+    ga = GemmArgs{};
+    ga.m_cap = H + 1; ga.n = d; ga.k = 2 * dm; ga.a0 = ASeg{w.dTaT, 2 * dm, 2 * dm, nullptr};
+    ga.w = r->in_proj_w + 2 * d; ga.ldw = dm; ga.w_kmajor = 1; ga.c = F(gr->anony_emb); ga.ldc = d; ga.alpha = 1.f;
+    ga.nbatch = 1; ga.accumulate = 1;
+    if ((rc = gemm_launch(ga, ws_st)) != TG_OK) return rc;  // (reads d T_a: behind the group above, on its stream)
+    tn = tn_base(H + 1, nullptr);
+    tn.n = 2 * dm; tn.k = d; tn.y = w.dTaT; tn.ldy = 2 * dm; tn.x0 = ASeg{r->anony_emb, d, d, nullptr};
+    tn.out = F(gr->in_proj_w) + 2 * d; tn.ldo = dm;
+    if ((rc = gemm_tn_launch(tn, ws_st)) != TG_OK) return rc;
+  }
+  // input-row gradients, only for the column blocks that carry parameters (main stream, beside the products above)
   const int ldx = q.wide ? 2 * d : d;
   ga = GemmArgs{};
   ga.m_cap = q.rowcap; ga.m_dev = rows_dev; ga.n = d; ga.k = 2 * dm; ga.a0 = ASeg{w.dqk, 2 * dm, 2 * dm, nullptr};
@@ -1134,31 +1263,19 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
   if (q.wide) {
     ga.w = r->in_proj_w + 2 * d; ga.c = w.dXs;
     if ((rc = gemm_launch(ga, st)) != TG_OK) return rc;
-  } else {
-    // the tabulated anony_emb block, T_a = anony_emb Wa^T with Wa = in_proj_w[0:2dm, 2d:3d]:  d T_a = onehot^T dqk
-    // ([ohw, 2 dm]), then  d anony_emb += d T_a Wa  and  d Wa += d T_a^T anony_emb  (rows past H of d T_a are zeros: no slot
-    // carries such an id; the two products read its first H + 1 rows only)
-    tn = tn_base(q.rowcap, rows_dev);
-    tn.accumulate = 0; tn.bias_accumulate = 0;
-    tn.n = q.ohw; tn.k = 2 * dm; tn.y = q.oh; tn.ldy = q.ohw; tn.x0 = ASeg{w.dqk, 2 * dm, 2 * dm, nullptr};
-    tn.out = w.dTaT; tn.ldo = 2 * dm;
-    if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
-    ga = GemmArgs{};
-    ga.m_cap = H + 1; ga.n = d; ga.k = 2 * dm; ga.a0 = ASeg{w.dTaT, 2 * dm, 2 * dm, nullptr};
-    ga.w = r->in_proj_w + 2 * d; ga.ldw = dm; ga.w_kmajor = 1; ga.c = F(gr->anony_emb); ga.ldc = d; ga.alpha = 1.f;
-    ga.nbatch = 1; ga.accumulate = 1;
-    if ((rc = gemm_launch(ga, st)) != TG_OK) return rc;
-    tn = tn_base(H + 1, nullptr);
-    tn.n = 2 * dm; tn.k = d; tn.y = w.dTaT; tn.ldy = 2 * dm; tn.x0 = ASeg{r->anony_emb, d, d, nullptr};
-    tn.out = F(gr->in_proj_w) + 2 * d; tn.ldo = dm;
-    if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
   }
-  const size_t lfull = (size_t)((H + 1) * d) * sizeof(float);
-  const int use_lds = lfull <= 60 * 1024;
   const int nl = use_lds ? (H + 1) * d : 0;
   hipLaunchKernelGGL(k_seq_build_bwd, dim3((unsigned)w.bb_blocks), dim3(256), use_lds ? lfull : (size_t)16, st, *m, *r, n,
                      n_dev, w.anon, w.h_t, q.slot_row, q.row_slot, w.dXs, q.wide ? 1 : 0, q.abar, w.dxbar, use_lds,
                      F(gr->anony_emb), w.bpart);
+  if (side) {  // the lane's products are done before the parameter sums (both add to d anony_emb) and before the caller goes on
+    if (side->used >= side->n || hipEventRecord(side->ev[side->used], side->s) != hipSuccess ||
+        hipStreamWaitEvent(st, side->ev[side->used], 0) != hipSuccess) {
+      set_hip_error(hipGetLastError(), "mutual_step lane join");
+      return TG_EHIP;
+    }
+    ++side->used;
+  }
   hipLaunchKernelGGL(k_seq_build_reduce, dim3((unsigned)cdiv(2 * d + nl, 64)), dim3(1024), 0, st, w.bb_blocks, d, nl, w.bpart,
                      F(gr->te_freq), F(gr->te_phase), F(gr->anony_emb));
   return check_launch("mutual_step(seq)");

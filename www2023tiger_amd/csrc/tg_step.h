@@ -117,11 +117,24 @@ int step_writeback_a(const tg_model* m, const tg_step_io* io, StepWs& w, hipStre
 // STEP 6 + workspace clean-up + offset advance
 int step_writeback_b(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, StepWs& w, hipStream_t st, tg_profiler* pf);
 
+// a second stream beside the caller's (tg_train.hip: train_lane) with a pool of events: `after_main` makes the lane wait for
+// everything enqueued on the main stream so far (under capture: a dependency edge of the graph)
+struct SideCtx {
+  hipStream_t s;
+  hipEvent_t ev[16];
+  int n, used;
+  bool after_main(hipStream_t st) {
+    if (used >= n) return false;
+    const bool ok = hipEventRecord(ev[used], st) == hipSuccess && hipStreamWaitEvent(s, ev[used], 0) == hipSuccess;
+    ++used;
+    return ok;
+  }
+};
 // mutual-learning half of the training step (tg_restart.hip)
 size_t mutual_ws_bytes(const tg_model* m, const tg_seq_restarter* r, int64_t B);
 int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, const StepWs& sw,
                 const tg_seq_restarter* r, const tg_seq_restarter* gr, const float* st_left, const float* st_right,
                 float* g_left, float* g_right, float* loss_out, int32_t* flag_out, float* part, size_t part_floats,
-                void* ws, size_t ws_bytes, const DropCfg& dc, hipStream_t st);
+                void* ws, size_t ws_bytes, const DropCfg& dc, hipStream_t st, int phase = 3, SideCtx* side = nullptr);
 
 }  // namespace tg

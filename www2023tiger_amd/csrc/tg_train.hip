@@ -1030,6 +1030,43 @@ static int contrast_backward(const tg_model* m, const tg_tcsr* gr, const tg_trai
 
 }  // namespace tg
 
+namespace tg {
+// A second stream for the mutual half's forward (tg_restart.hip: mutual_step phase 1): the restarter's forward reads the batch,
+// the graph and its own parameters only, the contrast half (STEP 7, backward, STEP 4-5) nothing of the restarter's - two
+// chains of short, latency-bound launches that fill the chip together.  fork / join by events: under stream capture the
+// lane becomes a parallel branch of the graph.  Created by the first call outside a capture; TG_TRAIN_SIDE=0 keeps one stream.
+struct TrainLane {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  hipEvent_t pool[16] = {};  // mutual_step's weight-gradient launches (tg_step.h: SideCtx)
+  bool ok = false;
+};
+static TrainLane* train_lane(hipStream_t st) {
+  static const int knob = getenv("TG_TRAIN_SIDE") ? atoi(getenv("TG_TRAIN_SIDE")) : 1;  // tuning knob
+  if (!knob) return nullptr;
+  static TrainLane lanes[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  TrainLane& L = lanes[dev];
+  if (L.ok) return &L;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return nullptr;  // not now: no stream / event is created inside a capture
+  }
+  bool good = hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&L.fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&L.join, hipEventDisableTiming) == hipSuccess;
+  for (int j = 0; j < 16 && good; ++j) good = hipEventCreateWithFlags(&L.pool[j], hipEventDisableTiming) == hipSuccess;
+  if (!good) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  L.ok = true;
+  return &L;
+}
+}  // namespace tg
+
 using namespace tg;
 
 extern "C" size_t tg_train_step_workspace_bytes(const tg_model* m, const tg_score_params* sp, int32_t restarter,
@@ -1087,15 +1124,34 @@ extern "C" int tg_train_step(const tg_model* m_in, const tg_tcsr* g, const tg_tr
   if (io->dropout_p < 0.f || io->dropout_p >= 1.f || (io->dropout_p > 0.f && !io->rng)) return TG_EINVAL;
   const DropCfg dc = make_drop(io->dropout_p, io->rng);
   if ((rc = step_forward(m, g, sio, w, t.gates, st, nullptr, &dc)) != TG_OK) return rc;
+  const bool seq = io->restarter == TG_RESTARTER_SEQ;
+  if (seq && (!io->seq || !io->seq_grads)) return TG_EINVAL;
+  SideCtx side{};
+  auto mutual = [&](int phase, hipStream_t s, SideCtx* sd) {
+    return mutual_step(m, g, sio, w, seq ? io->seq : nullptr, seq ? io->seq_grads : nullptr, io->static_left,
+                       io->static_right, io->static_left_grad, io->static_right_grad, io->losses + 1,
+                       io->flags ? io->flags + 2 : nullptr, t.part, t.part_floats, cv.p, cv.left, dc, s, phase, sd);
+  };
+  // the SeqRestarter's forward beside the contrast half (it needs the batch's id list, which step_forward has written)
+  TrainLane* lane = seq ? train_lane(st) : nullptr;
+  if (lane && !(hipEventRecord(lane->fork, st) == hipSuccess && hipStreamWaitEvent(lane->s, lane->fork, 0) == hipSuccess)) {
+    (void)hipGetLastError();
+    lane = nullptr;
+  }
+  if (lane && (rc = mutual(1, lane->s, nullptr)) != TG_OK) return rc;
   if ((rc = contrast_backward(m, g, io, w, t, dc, st)) != TG_OK) return rc;
   if ((rc = step_writeback_a(m, sio, w, st, nullptr)) != TG_OK) return rc;
+  if (lane && !(hipEventRecord(lane->join, lane->s) == hipSuccess && hipStreamWaitEvent(st, lane->join, 0) == hipSuccess)) {
+    set_hip_error(hipGetLastError(), "tg_train_step lane join");
+    return TG_EHIP;
+  }
   if (io->restarter != TG_RESTARTER_NONE) {  // needs the targets of STEP 4/5 and the step's bitmap-free inputs
-    const bool seq = io->restarter == TG_RESTARTER_SEQ;
-    if (seq && (!io->seq || !io->seq_grads)) return TG_EINVAL;
-    if ((rc = mutual_step(m, g, sio, w, seq ? io->seq : nullptr, seq ? io->seq_grads : nullptr, io->static_left,
-                          io->static_right, io->static_left_grad, io->static_right_grad, io->losses + 1,
-                          io->flags ? io->flags + 2 : nullptr, t.part, t.part_floats, cv.p, cv.left, dc, st)) != TG_OK)
-      return rc;
+    if (lane) {
+      side.s = lane->s;
+      side.n = 16;
+      for (int j = 0; j < 16; ++j) side.ev[j] = lane->pool[j];
+    }
+    if ((rc = mutual(lane ? 2 : 3, st, lane ? &side : nullptr)) != TG_OK) return rc;
   } else if (io->flags) {
     (void)hipMemsetAsync(io->flags + 2, 0, sizeof(int32_t), st);
   }
