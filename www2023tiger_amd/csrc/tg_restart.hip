@@ -85,8 +85,8 @@ __global__ void __launch_bounds__(256) k_seq_build_c(tg_model m, tg_seq_restarte
                                                      const int64_t* __restrict__ h_e, const float* __restrict__ h_t,
                                                      const int64_t* __restrict__ h_d, const int32_t* __restrict__ base,
                                                      int32_t* __restrict__ slot_row, int32_t* __restrict__ row_slot,
-                                                     float4* __restrict__ Xc, float* __restrict__ oh, int ohw,
-                                                     float* __restrict__ prev_ts) {
+                                                     int32_t* __restrict__ row_anon, float4* __restrict__ Xc,
+                                                     float* __restrict__ oh, int ohw, float* __restrict__ prev_ts) {
   if (n_dev) n = min(n, (int64_t)*n_dev);
   const int H = r.hist_len, d4 = m.d / 4, e4 = m.d_e / 4;
   const int wx4 = WIDE ? 4 * d4 + e4 : e4 + d4;
@@ -102,7 +102,10 @@ __global__ void __launch_bounds__(256) k_seq_build_c(tg_model m, tg_seq_restarte
     for (int c = lane; c < wx4; c += TG_WAVE) Xc[c] = c >= wx4 - d4 ? seq_te4(fq, ph, 0.f, c - (wx4 - d4)) : z;
     if (!WIDE)
       for (int c = lane; c < ohw; c += TG_WAVE) oh[c] = 0.f;
-    if (lane == 0) row_slot[0] = -1;
+    if (lane == 0) {
+      row_slot[0] = -1;
+      row_anon[0] = -1;  // the last event carries no anonymised id (its first dm - d columns are zeroed)
+    }
   }
   // one BLOCK per node: every wavefront derives the map (a few ballots), wavefront 0 stores it, the rows are dealt to the four
   for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
@@ -131,7 +134,10 @@ __global__ void __launch_bounds__(256) k_seq_build_c(tg_model m, tg_seq_restarte
         if (nz) row = start + before + __popcll(mask & ((1ull << lane) - 1ull));
         else if (in) row = b0;
         slot_row[so + t] = row;
-        if (nz || (in && t == firstpad)) row_slot[row] = (int32_t)(so + t);
+        if (nz || (in && t == firstpad)) {
+          row_slot[row] = (int32_t)(so + t);
+          row_anon[row] = (int32_t)anon[so + t];  // 0: the padded row (utils.py:19-27 numbers real ids from 1)
+        }
       }
       // the rows of this chunk's primary slots, one at a time, each written by one wavefront
       unsigned long long prim = mask;
@@ -182,6 +188,7 @@ struct SeqRows {
   const float* qk;              // [rows, 2 dm] compact
   const int32_t* slot_row;      // [n * H]
   const int32_t* row_slot;      // [rows] primary slot of a compact row
+  const int32_t* row_anon;      // [rows] its anonymised id (0: the node's padded row, -1: the shared last row)
   const int32_t* base;          // [n + 1] first compact row of a node
   const float* ta;              // nullable: [H + 1, 2 dm] tabulated anony_emb part of q / k (not for the last event)
   const int64_t* anon;          // [n * H]
@@ -264,17 +271,18 @@ __device__ __forceinline__ void seq_lds_init(const SeqRows& sr, SeqLds<HP>& L, c
   }
   for (int f = tid; f < HP * (HP + 2); f += 256) (&L.sc[0][0])[f] = 0.f;
   const int b0 = sr.base[i], lc = sr.base[i + 1] - b0 + 1;
-  const int s0 = lc > 1 ? sr.row_slot[b0] - (int32_t)(i * H) : H - 1;  // slot of row 0: padded iff the node has padded slots
-  const int haspad = (lc > 1 && s0 != H - 1 && h_n[i * H + s0] == 0) ? 1 : 0;
+  // row 0 is the padded row iff the node has padded slots (its anonymised id is 0; real events count from 1)
+  const int haspad = (lc > 1 && sr.row_anon[b0] == 0) ? 1 : 0;
   if (tid == 0) {
     L.lc = lc;
     L.haspad = haspad;
   }
   if (tid < lc) {
     const int grow = tid < lc - 1 ? b0 + tid : 0;
+    const int an = sr.row_anon[grow];
     const int slot = tid < lc - 1 ? sr.row_slot[grow] - (int32_t)(i * H) : H - 1;
     L.s_off[tid] = (int64_t)grow * 2 * dm + (int64_t)h * dh;
-    L.s_toff[tid] = (sr.ta && slot != H - 1) ? sr.anon[i * H + slot] * 2 * dm + (int64_t)h * dh : -1;
+    L.s_toff[tid] = (sr.ta && an >= 0) ? (int64_t)an * 2 * dm + (int64_t)h * dh : -1;
     L.cslot[tid] = slot;
     L.mult[tid] = (tid == 0 && haspad) ? (float)(H - 1 - (lc - 2)) : 1.f;  // padded slots = (H - 1) - real events
     L.padkeep[tid] = 0;
@@ -289,7 +297,7 @@ __device__ __forceinline__ void seq_lds_init(const SeqRows& sr, SeqLds<HP>& L, c
 template <int HP, bool V2>
 __device__ __forceinline__ void seq_scores_to_lds(const SeqRows& sr, SeqLds<HP>& L, int dh, int dm, int tid) {
   constexpr int NTM = HP / 32;
-  constexpr bool KS = HP == 64;
+  constexpr bool KS = HP <= 64;
   constexpr int NA = KS ? NTM * NTM : NTM;
   const int lc = L.lc, NT = (lc + 31) / 32;
   const int wave = tid >> 6, lane = tid & 63, fr = lane & 31, fk = lane >> 5;
@@ -397,8 +405,12 @@ template <int HP, bool V2>
 __global__ void __launch_bounds__(256) k_seq_scores(int64_t n, int H, int dm, int nh, SeqRows sr,
                                                     const int64_t* __restrict__ h_n, float* __restrict__ abar,
                                                     const int32_t* __restrict__ n_dev, DropCfg dc,
-                                                    float* __restrict__ rbar) {
+                                                    float* __restrict__ rbar, int lc_min) {
   if (n_dev && (int64_t)(blockIdx.x / nh) >= (int64_t)*n_dev) return;
+  {  // this launch serves the nodes with lc_min < rows <= HP (small grids: less LDS, more blocks per CU)
+    const int lc0 = sr.base[blockIdx.x / nh + 1] - sr.base[blockIdx.x / nh] + 1;
+    if (lc0 <= lc_min || lc0 > HP) return;
+  }
   extern __shared__ __align__(16) unsigned char seq_lds_raw[];
   SeqLds<HP>& L = *reinterpret_cast<SeqLds<HP>*>(seq_lds_raw);
   const uint64_t dkey = drop_key(dc);
@@ -445,11 +457,11 @@ struct SeqCols {
   const float4* xc;         // compact operand rows
   int wx4, col0_4;          // their width and first column (float4 units): narrow 3d, wide 0
   const float4* ae;         // narrow: anony_emb, columns [2d, 3d) of every slot but the last; wide: nullptr (inside xc)
-  const int32_t* slot_row;
-  const int64_t* anon;
+  const int32_t *base, *row_slot, *row_anon;  // the node's rows, their primary slots and anonymised ids
 };
 
-// xbar[i, h, :] = sum_s abar[i, h, s] * x(i, s)
+// xbar[i, h, :] = sum_s abar[i, h, s] * x(i, s): over the node's COMPACT rows (a padded slot's weight is 0: its key is
+// masked) and the shared last row
 __global__ void k_seq_mix(int64_t n, int H, int row4, int d4, int nh, const float* __restrict__ abar, SeqCols sc,
                           float4* __restrict__ xbar, const int32_t* __restrict__ n_dev) {
   if (n_dev) n = min(n, (int64_t)*n_dev);
@@ -458,17 +470,23 @@ __global__ void k_seq_mix(int64_t n, int H, int row4, int d4, int nh, const floa
     const int c = (int)(t % row4);
     const int64_t ih = t / row4;
     const int64_t i = ih / nh;
+    const int b0 = sc.base[i], b1 = sc.base[i + 1];
+    const float* ab = abar + ih * H - i * H;  // indexed by the global slot number
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c >= sc.col0_4 && c < sc.col0_4 + sc.wx4) {
-      for (int s = 0; s < H; ++s) {
-        const float w = abar[ih * H + s];
-        const float4 x = sc.xc[(int64_t)sc.slot_row[i * H + s] * sc.wx4 + (c - sc.col0_4)];
+      const int cc = c - sc.col0_4;
+      for (int r = b0; r < b1; ++r) {
+        const float w = ab[sc.row_slot[r]];
+        const float4 x = sc.xc[(int64_t)r * sc.wx4 + cc];
         a.x += w * x.x; a.y += w * x.y; a.z += w * x.z; a.w += w * x.w;
       }
+      const float w = abar[ih * H + H - 1];
+      const float4 x = sc.xc[cc];
+      a.x += w * x.x; a.y += w * x.y; a.z += w * x.z; a.w += w * x.w;
     } else if (sc.ae && c >= 2 * d4 && c < 3 * d4) {
-      for (int s = 0; s < H - 1; ++s) {
-        const float w = abar[ih * H + s];
-        const float4 x = sc.ae[sc.anon[i * H + s] * d4 + (c - 2 * d4)];
+      for (int r = b0; r < b1; ++r) {
+        const float w = ab[sc.row_slot[r]];
+        const float4 x = sc.ae[(int64_t)sc.row_anon[r] * d4 + (c - 2 * d4)];
         a.x += w * x.x; a.y += w * x.y; a.z += w * x.z; a.w += w * x.w;
       }
     }
@@ -479,39 +497,53 @@ __global__ void k_seq_mix(int64_t n, int H, int row4, int d4, int nh, const floa
 // ---------------------------------------------------------------------------------
 // backward kernels (mutual loss, tiger.py:576-590)
 // ---------------------------------------------------------------------------------
-// dabar[i, h, s] = dxbar[i, h, :] . x(i, s)   (one wavefront per (i, h, s))
-__global__ void __launch_bounds__(256) k_seq_mix_bwd(int64_t n, const int32_t* __restrict__ n_dev, int H, int row4, int d4,
+// dabar[i, h, s] = dxbar[i, h, :] . x(i, s)   (one wavefront per (compact row or last slot, head): the score backward
+// reads the entries of the rows' primary slots only)
+__global__ void __launch_bounds__(256) k_seq_mix_bwd(int64_t n, const int32_t* __restrict__ n_dev,
+                                                     const int32_t* __restrict__ rows_dev, int H, int row4, int d4,
                                                      int nh, const float4* __restrict__ dxbar, SeqCols sc,
                                                      float* __restrict__ dabar, const float* __restrict__ dO,
                                                      const float* __restrict__ bv) {
   // dO / bv non-null (dropout): abar also weights the value bias, d rbar = dO_h . bv_h is added
   if (n_dev) n = min(n, (int64_t)*n_dev);
   const int lane = lane_id();
-  const int64_t total = n * nh * H;
+  const int64_t nrow = (int64_t)rows_dev[0] - 1;  // compact rows besides the shared last row
+  const int64_t total = (nrow + n) * nh;
   for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < total; t += (int64_t)gridDim.x * 4) {
-    const int sidx = (int)(t % H);
-    const int64_t ih = t / H;
-    const int64_t i = ih / nh;
+    int64_t i, g;
+    int sidx;
+    const int h = (int)(t % nh);
+    if (t < nrow * nh) {
+      g = 1 + t / nh;
+      const int32_t slot = sc.row_slot[g];
+      i = slot / H;
+      sidx = slot - (int32_t)(i * H);
+    } else {
+      g = 0;
+      i = (t - nrow * nh) / nh;
+      sidx = H - 1;
+    }
+    const int64_t ih = i * nh + h;
     const float4* a = dxbar + ih * row4;
-    const float4* b = sc.xc + (int64_t)sc.slot_row[i * H + sidx] * sc.wx4;
+    const float4* b = sc.xc + g * sc.wx4;
     float acc = 0.f;
     for (int c = lane; c < sc.wx4; c += TG_WAVE) {
       const float4 u = a[sc.col0_4 + c], v = b[c];
       acc = fmaf(u.x, v.x, fmaf(u.y, v.y, fmaf(u.z, v.z, fmaf(u.w, v.w, acc))));
     }
     if (sc.ae && sidx != H - 1) {
-      const float4* e = sc.ae + sc.anon[i * H + sidx] * d4;
+      const float4* e = sc.ae + (int64_t)sc.row_anon[g] * d4;
       for (int c = lane; c < d4; c += TG_WAVE) {
         const float4 u = a[2 * d4 + c], v = e[c];
         acc = fmaf(u.x, v.x, fmaf(u.y, v.y, fmaf(u.z, v.z, fmaf(u.w, v.w, acc))));
       }
     }
     if (dO) {
-      const int dm = row4 * 4, dh = dm / nh, h = (int)(ih % nh);
+      const int dm = row4 * 4, dh = dm / nh;
       for (int c = lane; c < dh; c += TG_WAVE) acc = fmaf(dO[i * dm + h * dh + c], bv[h * dh + c], acc);
     }
     acc = wave_sum(acc);
-    if (lane == 0) dabar[t] = acc;
+    if (lane == 0) dabar[ih * H + sidx] = acc;
   }
 }
 
@@ -524,8 +556,12 @@ template <int HP, bool V2>
 __global__ void __launch_bounds__(256) k_seq_scores_bwd(int64_t n, const int32_t* __restrict__ n_dev, int H, int dm,
                                                         int nh, SeqRows sr, const int64_t* __restrict__ h_n,
                                                         const float* __restrict__ dabar, float* __restrict__ dqk,
-                                                        float* __restrict__ dqk_last, DropCfg dc) {
+                                                        float* __restrict__ dqk_last, DropCfg dc, int lc_min) {
   if (n_dev && (int64_t)(blockIdx.x / nh) >= (int64_t)*n_dev) return;
+  {
+    const int lc0 = sr.base[blockIdx.x / nh + 1] - sr.base[blockIdx.x / nh] + 1;
+    if (lc0 <= lc_min || lc0 > HP) return;
+  }
   extern __shared__ __align__(16) unsigned char seq_lds_raw[];
   SeqLds<HP>& L = *reinterpret_cast<SeqLds<HP>*>(seq_lds_raw);
   const uint64_t dkey = drop_key(dc);
@@ -731,9 +767,19 @@ __global__ void __launch_bounds__(256) k_mutual_a(int64_t cap, const int32_t* __
       nv += 1.f;
     }
   }
-  if (lane == 0 && nv > 0.f) {
-    atomicAdd(acc + 0, se);
-    atomicAdd(acc + 1, nv);
+  // one pair of atomics per workgroup (two per wavefront on one address serialised 2 048 of them: 46 us)
+  __shared__ float red[2][4];
+  if (lane == 0) {
+    red[0][threadIdx.x >> 6] = se;
+    red[1][threadIdx.x >> 6] = nv;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float s = red[0][0] + red[0][1] + red[0][2] + red[0][3], c = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    if (c > 0.f) {
+      atomicAdd(acc + 0, s);
+      atomicAdd(acc + 1, c);
+    }
   }
 }
 __global__ void __launch_bounds__(256) k_mutual_b(int64_t cap, const int32_t* __restrict__ n_dev, int d,
@@ -838,7 +884,7 @@ __global__ void k_restart_pad(int64_t cap, const int32_t* __restrict__ n_dev, in
 
 struct SeqWs {
   float *xc, *qk, *abar, *xbar, *o, *om, *t2, *rbar, *ta, *oh;
-  int32_t *cnt, *base, *slot_row, *row_slot, *rows;  // the compact-row plan (see the file header); rows = {live rows, ...}
+  int32_t *cnt, *base, *slot_row, *row_slot, *row_anon, *rows;  // the compact-row plan (see the file header); rows = {live rows, ...}
   int64_t rowcap;
   int wx, ohw;
   bool wide;
@@ -867,6 +913,7 @@ static bool carve_seq(const tg_model* m, const tg_seq_restarter* r, int64_t n, C
   w.base = cv.take<int32_t>(n + 1);
   w.slot_row = cv.take<int32_t>(n * H);
   w.row_slot = cv.take<int32_t>((size_t)w.rowcap);
+  w.row_anon = cv.take<int32_t>((size_t)w.rowcap);
   w.rows = cv.take<int32_t>(4);
   return cv.ok;
 }
@@ -916,10 +963,10 @@ static int seq_forward(const tg_model* m, const tg_seq_restarter* r, int64_t n, 
   hipLaunchKernelGGL(k_seq_scan, dim3(1), dim3(1024), 0, st, n, w.cnt, w.base, w.rows);
   if (w.wide)
     hipLaunchKernelGGL((k_seq_build_c<true>), dim3(nbg), dim3(256), 0, st, *m, *r, n, n_dev, nids, h_n, anon, h_e, h_t, h_d,
-                       w.base, w.slot_row, w.row_slot, (float4*)w.xc, w.oh, w.ohw, prev_ts);
+                       w.base, w.slot_row, w.row_slot, w.row_anon, (float4*)w.xc, w.oh, w.ohw, prev_ts);
   else
     hipLaunchKernelGGL((k_seq_build_c<false>), dim3(nbg), dim3(256), 0, st, *m, *r, n, n_dev, nids, h_n, anon, h_e, h_t, h_d,
-                       w.base, w.slot_row, w.row_slot, (float4*)w.xc, w.oh, w.ohw, prev_ts);
+                       w.base, w.slot_row, w.row_slot, w.row_anon, (float4*)w.xc, w.oh, w.ohw, prev_ts);
   int rc;
   GemmArgs g{};
   const int off = w.wide ? 0 : 2 * d;   // first column of the value operand that can be non-zero
@@ -934,17 +981,24 @@ static int seq_forward(const tg_model* m, const tg_seq_restarter* r, int64_t n, 
   g.m_cap = w.rowcap; g.m_dev = w.rows; g.n = 2 * dm; g.k = w.wx; g.a0 = ASeg{w.xc, w.wx, w.wx, nullptr};
   g.w = r->in_proj_w + col0; g.ldw = dm; g.bias = r->in_proj_b; g.c = w.qk; g.ldc = 2 * dm; g.alpha = 1.f; g.nbatch = 1;
   if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
-  const SeqRows sr{w.qk, w.slot_row, w.row_slot, w.base, w.ta, anon};
+  const SeqRows sr{w.qk, w.slot_row, w.row_slot, w.row_anon, w.base, w.ta, anon};
   if ((rc = seq_lds_attr()) != TG_OK) return rc;
-#define TG_SEQ_SCORES(HP_, V2_)                                                                                     \
+#define TG_SEQ_SCORES(HP_, V2_, MIN_)                                                                               \
   hipLaunchKernelGGL((k_seq_scores<HP_, V2_>), dim3((unsigned)(n * nh)), dim3(256), sizeof(SeqLds<HP_>), st, n, H, dm, nh, \
-                     sr, h_n, w.abar, n_dev, dc, w.rbar)
-  if (H <= 64 && dh % 2 == 0) TG_SEQ_SCORES(64, true);
-  else if (H <= 64) TG_SEQ_SCORES(64, false);
-  else if (dh % 2 == 0) TG_SEQ_SCORES(128, true);
-  else TG_SEQ_SCORES(128, false);
+                     sr, h_n, w.abar, n_dev, dc, w.rbar, MIN_)
+  // two launches over the same grid for histories of 33 .. 64 events: the nodes with at most 32 rows (most of them: a row
+  // per real event) take the small-grid blocks - 22 KB of LDS, seven blocks per CU - the others the 64-row ones
+  if (H <= 64) {
+    if (dh % 2 == 0) TG_SEQ_SCORES(32, true, 0);
+    else TG_SEQ_SCORES(32, false, 0);
+    if (H > 32) {
+      if (dh % 2 == 0) TG_SEQ_SCORES(64, true, 32);
+      else TG_SEQ_SCORES(64, false, 32);
+    }
+  } else if (dh % 2 == 0) TG_SEQ_SCORES(128, true, 0);
+  else TG_SEQ_SCORES(128, false, 0);
 #undef TG_SEQ_SCORES
-  const SeqCols sc{(const float4*)w.xc, w.wx / 4, col0 / 4, w.wide ? nullptr : (const float4*)r->anony_emb, w.slot_row, anon};
+  const SeqCols sc{(const float4*)w.xc, w.wx / 4, col0 / 4, w.wide ? nullptr : (const float4*)r->anony_emb, w.base, w.row_slot, w.row_anon};
   hipLaunchKernelGGL(k_seq_mix, dim3(flat_grid(n * nh * (dm / 4), 256)), dim3(256), 0, st, n, H, dm / 4, d / 4, nh, w.abar,
                      sc, (float4*)w.xbar, n_dev);
   // o[:, h] = Wv_h xbar_h + bv_h   (narrow form: the first 2d columns of xbar are zeros and are skipped)
@@ -1094,7 +1148,7 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
   }
   }
   if (!(phase & 2)) return check_launch("mutual_step(forward)");
-  hipLaunchKernelGGL(k_mutual_a, dim3(std::min<unsigned>(flat_grid(2 * n, 4), 512)), dim3(256), 0, st, n, w.counts2, d,
+  hipLaunchKernelGGL(k_mutual_a, dim3(std::min<unsigned>(flat_grid(2 * n, 4), 128)), dim3(256), 0, st, n, w.counts2, d,
                      w.index, sio->h_prev_left, sio->h_prev_right, w.sl, w.sr, w.valid, w.acc);
   hipLaunchKernelGGL(k_mutual_b, dim3(flat_grid(2 * n * d, 256)), dim3(256), 0, st, n, w.counts2, d, w.index,
                      sio->h_prev_left, sio->h_prev_right, w.sl, w.sr, w.valid, w.acc, w.dsl, w.dsr, loss_out, flag_out);
@@ -1211,18 +1265,24 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
   for (const TnArgs& a : late_heads)
     if ((rc = gemm_tn_launch(a, ws_st)) != TG_OK) return rc;
   // value mix and attention scores
-  const SeqCols sc{(const float4*)q.xc, q.wx / 4, col0 / 4, q.wide ? nullptr : (const float4*)r->anony_emb, q.slot_row, w.anon};
-  hipLaunchKernelGGL(k_seq_mix_bwd, dim3(flat_grid(n * nh * H, 4)), dim3(256), 0, st, n, n_dev, H, dm / 4, d / 4, nh,
+  const SeqCols sc{(const float4*)q.xc, q.wx / 4, col0 / 4, q.wide ? nullptr : (const float4*)r->anony_emb, q.base, q.row_slot, q.row_anon};
+  hipLaunchKernelGGL(k_seq_mix_bwd, dim3(flat_grid(n * nh * H, 4)), dim3(256), 0, st, n, n_dev, rows_dev, H, dm / 4, d / 4, nh,
                      (const float4*)w.dxbar, sc, w.dabar, dc.p > 0.f ? w.dO : (const float*)nullptr,
                      r->in_proj_b + 2 * dm);
-  const SeqRows sr{q.qk, q.slot_row, q.row_slot, q.base, q.ta, w.anon};
-#define TG_SEQ_SCORES_BWD(HP_, V2_)                                                                                   \
+  const SeqRows sr{q.qk, q.slot_row, q.row_slot, q.row_anon, q.base, q.ta, w.anon};
+#define TG_SEQ_SCORES_BWD(HP_, V2_, MIN_)                                                                             \
   hipLaunchKernelGGL((k_seq_scores_bwd<HP_, V2_>), dim3((unsigned)(n * nh)), dim3(256), sizeof(SeqLds<HP_>), st, n, n_dev, H, \
-                     dm, nh, sr, w.h_n, w.dabar, w.dqk, w.dqk_last, dc)
-  if (H <= 64 && (dm / nh) % 2 == 0) TG_SEQ_SCORES_BWD(64, true);
-  else if (H <= 64) TG_SEQ_SCORES_BWD(64, false);
-  else if ((dm / nh) % 2 == 0) TG_SEQ_SCORES_BWD(128, true);
-  else TG_SEQ_SCORES_BWD(128, false);
+                     dm, nh, sr, w.h_n, w.dabar, w.dqk, w.dqk_last, dc, MIN_)
+  const bool v2 = (dm / nh) % 2 == 0;
+  if (H <= 64) {
+    if (v2) TG_SEQ_SCORES_BWD(32, true, 0);
+    else TG_SEQ_SCORES_BWD(32, false, 0);
+    if (H > 32) {
+      if (v2) TG_SEQ_SCORES_BWD(64, true, 32);
+      else TG_SEQ_SCORES_BWD(64, false, 32);
+    }
+  } else if (v2) TG_SEQ_SCORES_BWD(128, true, 0);
+  else TG_SEQ_SCORES_BWD(128, false, 0);
 #undef TG_SEQ_SCORES_BWD
   // row 0 (the last event of every node) collects the last slots' gradients
   if ((rc = colsum_launch(n, n_dev, 2 * dm, w.dqk_last, 2 * dm, 1.f, w.dqk, 0, w.cpart, (size_t)16 * 2 * dm, st)) != TG_OK) return rc;
