@@ -1044,6 +1044,8 @@ struct MutualWs {
   int64_t *uniq, *index, *h_n, *h_e, *h_d, *anon;
   float *h_t, *sl, *sr, *prev_ts, *dsl, *dsr, *dt2, *dom, *dO, *dOm, *dxbar, *dabar, *dqk, *dqk_last, *dXs, *dTaT, *acc, *bpart, *cpart;
   int bb_blocks;  // blocks of k_seq_build_bwd = rows of bpart
+  float* part2;   // split partials of the tabulated block's two small weight-gradient products
+  size_t part2_floats;
   int32_t *count, *counts2;
   uint8_t* valid;
   void* sel_ws;
@@ -1088,6 +1090,8 @@ static bool carve_mutual(const tg_model* m, const tg_seq_restarter* r, int64_t B
     w.dXs = cv.take<float>((size_t)w.seq.rowcap * (w.seq.wide ? 2 : 1) * d);
     w.dTaT = w.seq.wide ? nullptr : cv.take<float>(2 * dm * (size_t)w.seq.ohw);  // d T_a [ohw, 2 dm]
     w.cpart = cv.take<float>((size_t)16 * 2 * dm);  // partial column sums of the last slots' gradients
+    w.part2_floats = w.seq.wide ? 0 : (size_t)16 * std::max((size_t)w.seq.ohw * (2 * dm + 1), 2 * dm * (d + 1));
+    w.part2 = w.seq.wide ? nullptr : cv.take<float>(w.part2_floats);
     w.bb_blocks = (int)std::min<int64_t>(cdiv(n * (int64_t)H, 32), 1024);
     w.bpart = cv.take<float>((size_t)w.bb_blocks * (2 * d + (H + 1) * d));
   }
@@ -1291,27 +1295,28 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
   tn.n = 2 * dm; tn.k = q.wx; tn.y = w.dqk; tn.ldy = 2 * dm; tn.x0 = ASeg{q.xc, q.wx, q.wx, nullptr};
   tn.out = F(gr->in_proj_w) + col0; tn.ldo = dm; tn.bias_out = F(gr->in_proj_b);
   if ((rc = wgrad(tn)) != TG_OK) return rc;
+  if ((rc = flush()) != TG_OK) return rc;  // the q / k projection's weight gradient: on the lane when there is one
   if (!q.wide) {
     // the tabulated anony_emb block, T_a = anony_emb Wa^T with Wa = in_proj_w[0:2dm, 2d:3d]:  d T_a = onehot^T dqk
     // ([ohw, 2 dm]), then  d anony_emb += d T_a Wa  and  d Wa += d T_a^T anony_emb  (rows past H of d T_a are zeros: no slot
-    // carries such an id; the two products read its first H + 1 rows only)
+    // carries such an id; the two products read its first H + 1 rows only).  On the main stream, with partials of their
+    // own: the lane is the longer branch.
     tn = tn_base(q.rowcap, rows_dev);
+    tn.part = w.part2; tn.part_floats = w.part2_floats;
     tn.accumulate = 0; tn.bias_accumulate = 0;
     tn.n = q.ohw; tn.k = 2 * dm; tn.y = q.oh; tn.ldy = q.ohw; tn.x0 = ASeg{w.dqk, 2 * dm, 2 * dm, nullptr};
     tn.out = w.dTaT; tn.ldo = 2 * dm;
-    if ((rc = wgrad(tn)) != TG_OK) return rc;
-  }
-  if ((rc = flush()) != TG_OK) return rc;
-  if (!q.wide) {
+    if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
     ga = GemmArgs{};
     ga.m_cap = H + 1; ga.n = d; ga.k = 2 * dm; ga.a0 = ASeg{w.dTaT, 2 * dm, 2 * dm, nullptr};
     ga.w = r->in_proj_w + 2 * d; ga.ldw = dm; ga.w_kmajor = 1; ga.c = F(gr->anony_emb); ga.ldc = d; ga.alpha = 1.f;
     ga.nbatch = 1; ga.accumulate = 1;
-    if ((rc = gemm_launch(ga, ws_st)) != TG_OK) return rc;  // (reads d T_a: behind the group above, on its stream)
+    if ((rc = gemm_launch(ga, st)) != TG_OK) return rc;
     tn = tn_base(H + 1, nullptr);
+    tn.part = w.part2; tn.part_floats = w.part2_floats;
     tn.n = 2 * dm; tn.k = d; tn.y = w.dTaT; tn.ldy = 2 * dm; tn.x0 = ASeg{r->anony_emb, d, d, nullptr};
     tn.out = F(gr->in_proj_w) + 2 * d; tn.ldo = dm;
-    if ((rc = gemm_tn_launch(tn, ws_st)) != TG_OK) return rc;
+    if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
   }
   // input-row gradients, only for the column blocks that carry parameters (main stream, beside the products above)
   const int ldx = q.wide ? 2 * d : d;
