@@ -415,6 +415,15 @@ int tg_restart_seq_fwd_train(const tg_model* m, const tg_seq_restarter* r, int64
                              float* prev_ts, float dropout_p, uint64_t* rng, void* ws, size_t ws_bytes,
                              void* stream);
 
+/* TIGER.restart with the SeqRestarter as ONE call over a device-resident node list (tiger.py:594-609 + restarters.py:51-114):
+ * histories of the n nodes at time *t_dev (float32, the batch's earliest time: eval_utils.py:37-42 restarts every node at
+ * ts.min()) sampled with the recent-edges strategy, anonymised ids, the restarter's forward (inference form) and
+ * tg_restart_apply.  Same kernels as the calls it replaces; for loops that restart per batch (the lazy restart of the
+ * evaluation harness), where a dozen library calls per batch were the cost. */
+size_t tg_restart_seq_list_workspace_bytes(const tg_model* m, const tg_seq_restarter* r, int64_t n);
+int tg_restart_seq_list(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, int64_t n, const int64_t* nids,
+                        const float* t_dev, void* ws, size_t ws_bytes, void* stream);
+
 /* TIGER.restart's state update (tiger.py:603,608-609): clear has-message bits of
  * nids, then left/right memory rows and timestamps <- (h_left, h_right, prev_ts)
  * with skip_check semantics. */

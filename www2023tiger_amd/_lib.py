@@ -174,6 +174,8 @@ SIGNATURES = {
     'tg_restart_seq_fwd_train': (C.c_int, [P(TgModel), P(TgSeqRestarter), i64, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                            C.c_float, vp, vp, sz, vp]),
     'tg_restart_apply': (C.c_int, [P(TgModel), i64, vp, vp, vp, vp, vp]),
+    'tg_restart_seq_list_workspace_bytes': (sz, [P(TgModel), P(TgSeqRestarter), i64]),
+    'tg_restart_seq_list': (C.c_int, [P(TgModel), P(TgTcsr), P(TgSeqRestarter), i64, vp, vp, vp, sz, vp]),
     'tg_profiler_create': (vp, []),
     'tg_profiler_destroy': (None, [vp]),
     'tg_profiler_num_stages': (C.c_int, []),

@@ -1375,6 +1375,63 @@ extern "C" int tg_restart_seq_fwd(const tg_model* m, const tg_seq_restarter* r, 
 }
 
 namespace tg {
+// query times of a list restart: every node at the batch's earliest time, float32-rounded (restarters.py:69-70)
+__global__ void k_restart_times(int64_t n, const float* __restrict__ t_dev, double* __restrict__ tu) {
+  const double t = (double)*t_dev;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) tu[i] = t;
+}
+struct ListWs {
+  double* tu;
+  int64_t *h_n, *h_e, *h_d, *anon;
+  float *h_t, *hl, *hr, *pt;
+  SeqWs seq;
+};
+static bool carve_list(const tg_model* m, const tg_seq_restarter* r, int64_t n, Carver& cv, ListWs& w) {
+  const size_t H = r->hist_len, d = m->d;
+  w.tu = cv.take<double>(n);
+  w.h_n = cv.take<int64_t>(n * H);
+  w.h_e = cv.take<int64_t>(n * H);
+  w.h_d = cv.take<int64_t>(n * H);
+  w.anon = cv.take<int64_t>(n * H);
+  w.h_t = cv.take<float>(n * H);
+  w.hl = cv.take<float>(n * d);
+  w.hr = cv.take<float>(n * d);
+  w.pt = cv.take<float>(n);
+  return carve_seq(m, r, n, cv, w.seq, false);
+}
+}  // namespace tg
+
+extern "C" size_t tg_restart_seq_list_workspace_bytes(const tg_model* m, const tg_seq_restarter* r, int64_t n) {
+  if (!seq_ok(m, r) || n < 0) return 0;
+  return carve_bytes([&](Carver& cv) {
+           ListWs w{};
+           carve_list(m, r, n, cv, w);
+         }) +
+         64;
+}
+
+extern "C" int tg_restart_seq_list(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, int64_t n,
+                                   const int64_t* nids, const float* t_dev, void* ws, size_t ws_bytes, void* stream) {
+  if (m && m->row_of) return TG_EUNSUPPORTED;  // state addressed by node id: not on physically partitioned tables (tg_model.row_of)
+  if (!seq_ok(m, r) || !g || n < 0) return TG_EINVAL;
+  if (r->hist_len > 128) return TG_EUNSUPPORTED;
+  if (n == 0) return TG_OK;
+  if (!nids || !t_dev) return TG_EINVAL;
+  Carver cv(ws, ws_bytes);
+  ListWs w{};
+  if (!ws || !carve_list(m, r, n, cv, w)) return TG_EWORKSPACE;
+  hipStream_t st = as_stream(stream);
+  const int H = r->hist_len;
+  int rc;
+  hipLaunchKernelGGL(k_restart_times, dim3(flat_grid(n, 256)), dim3(256), 0, st, n, t_dev, w.tu);
+  if ((rc = tg_sample_recent_edges(g, n, nids, w.tu, H, w.h_n, w.h_e, w.h_t, w.h_d, nullptr, stream)) != TG_OK) return rc;
+  if ((rc = tg_anonymized_reindex(n, H, w.h_n, w.anon, stream)) != TG_OK) return rc;
+  if ((rc = seq_forward(m, r, n, nullptr, nids, w.h_n, w.anon, w.h_e, w.h_t, w.h_d, w.hl, w.hr, w.pt, w.seq, st)) != TG_OK)
+    return rc;
+  return tg_restart_apply(m, n, nids, w.hl, w.hr, w.pt, stream);
+}
+
+namespace tg {
 __global__ void k_rng_tick_r(uint64_t* rng) {
   if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += 1;
 }

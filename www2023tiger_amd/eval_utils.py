@@ -130,6 +130,52 @@ def _restart_listed(model, tb, graph):
     return n
 
 
+class _RestartPipeline:
+    """The list-form lazy restart (see _restart_listed) with the collate-only passes run ONE BATCH AHEAD of the steps.
+    A pass reads the graph, the batch arrays and the up-to-date bitmap only - nothing a step or a restart writes - so pass
+    k + 1 is enqueued before restart k and step k; its count travels to pinned host memory behind it.  When the host
+    needs count k + 1 the device has long passed that point of the stream: the read-back no longer drains the queue (it
+    did: per batch the device then idled for as long as the host took to enqueue the restarter's dozen launches).
+    Two contexts alternate (list, earliest time, count of a pass live until its restart has been enqueued); same lists,
+    same order of marks, same results as _restart_listed."""
+
+    def __init__(self, model, tb, graph, first, count):
+        self.model, self.tb, self.graph, self.count = model, tb, graph, count
+        sb = tb.sb
+        self.ctx = [sb._lazy_collate, sb.lazy_collate_context(model)]
+        self.offsets = first + torch.arange(count, dtype=torch.int64, device=model.device) * sb.B
+        self.host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
+        self.ev = [torch.cuda.Event() for _ in range(2)]
+        self._pass(0)
+
+    def _pass(self, k):
+        import ctypes as C
+        cb = self.ctx[k % 2]
+        cb.io.offset_dev = self.offsets.data_ptr() + 8 * k
+        m = self.model.model_struct()
+        check(lib.tg_stream_step(C.byref(m), C.byref(self.graph.tcsr), C.byref(cb.io), ptr(cb.ws), cb.ws.numel(),
+                                 stream_ptr(self.model.device)), 'tg_stream_step(lazy restart list)')
+        self.host[k % 2].copy_(cb.counts[3:4], non_blocking=True)
+        self.ev[k % 2].record()
+        self.tb.sb.lazy_batch += 1
+
+    def restart(self, k):
+        """Before step k: enqueue pass k + 1, then the restart of batch k's list."""
+        model = self.model
+        if k + 1 < self.count:
+            self._pass(k + 1)
+        self.ev[k % 2].synchronize()
+        n = int(self.host[k % 2][0])
+        if n:
+            cb = self.ctx[k % 2]
+            current = (model._pending is not None and model._pending_stamp == model._state_stamp()
+                       and (getattr(model, '_gtab', None) is None or getattr(model, '_gtab_stamp', None) is not None))
+            model.restart_list(cb.lazy_list[:n], cb.lazy_tmin)
+            if current:
+                model._tables_follow_restart(cb.lazy_list[:n])
+        return n
+
+
 def _eval_resident_run(model, ds, bs, dev, N, lo, hi, graph, TrainBuffers, lean, restart_mode=False, uptodate_nodes=None):
     c = getattr(ds, '_dev', None)
     if c is not None and c['device'] == dev:
@@ -180,9 +226,15 @@ def _eval_resident_run(model, ds, bs, dev, N, lo, hi, graph, TrainBuffers, lean,
         p0, n0 = pos_all.data_ptr() + 4 * first, neg_all.data_ptr() + 4 * first
         # (replaying captured hipGraphs of several steps was tried here: the pass is bound by the device's dependent launches -
         # bs 200: 72 us per batch eager, 75 us as 16-step graphs, and a capture costs ~10 ms - so the steps are launched eagerly)
+        pipe = None
+        if (restart_mode and not tb._restart_in_step and dev.type == 'cuda'
+                and os.environ.get('TG_EVAL_RESTART_PIPELINE', '1') != '0'):
+            pipe = _RestartPipeline(model, tb, graph, first, count)
         for k in range(count):
             tb.io.pos_scores, tb.io.neg_scores = p0 + 4 * k * B, n0 + 4 * k * B
-            if restart_mode and not tb._restart_in_step:
+            if pipe is not None:
+                pipe.restart(k)
+            elif restart_mode and not tb._restart_in_step:
                 _restart_listed(model, tb, graph)
             tb.launch(graph=graph)
             if k == 0 and count > 8:  # one early read-back: the updater's launches are sized by the counts seen so far

@@ -132,6 +132,27 @@ class TIGE(nn.Module):
             raise ValueError(f'Invalid upd_src={self.upd_src}')
 
     # ---- plumbing ---------------------------------------------------------------------
+    def restart_list(self, nids: Tensor, t_dev: Tensor):
+        """`restart(nids, t.expand(n))` for a device-resident id list and ONE device-resident time, with the SeqRestarter
+        in inference mode, as a single library call (tg_restart_seq_list: histories, anonymised ids, the restarter's
+        forward, the state update) - the loops that restart per batch (eval_utils: lazy restart) were bound by the host
+        side of the dozen calls this replaces.  Anything else takes `restart`."""
+        from .restarters import SeqRestarter
+        r = self.restarter_fn
+        n = int(nids.numel())
+        if (n == 0 or not isinstance(r, SeqRestarter) or (r.training and float(r.mha_fn.dropout) > 0)
+                or getattr(self, '_row_of', None) is not None or r.graph.strategy != 'recent_edges'
+                or self.device.type != 'cuda' or t_dev.dtype != torch.float32):
+            return self.restart(nids, t_dev.expand(n))
+        self._touch()
+        m, rs = self.model_struct(), r._struct()
+        nbytes = int(lib.tg_restart_seq_list_workspace_bytes(C.byref(m), C.byref(rs), n))
+        ws = getattr(self, '_restart_list_ws', None)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._restart_list_ws = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=self.device)
+        check(lib.tg_restart_seq_list(C.byref(m), C.byref(r.graph.tcsr), C.byref(rs), n, ptr(nids), ptr(t_dev), ptr(ws),
+                                      ws.numel(), stream_ptr(self.device)), 'tg_restart_seq_list')
+
     @property
     def graph(self):
         return self.temporal_embedding_fn.graph
@@ -749,23 +770,32 @@ class TIGE(nn.Module):
             # The loop's bookkeeping - trigger, uptodate / has-message bitmaps, involved & ~uptodate - runs on the device in
             # a collate-only pass; the host reads back ONE count, runs restarter + tg_restart_apply on the device-resident
             # list and then launches the step (TIGE.launch_step).  No node list crosses the host link, no Python sets.
-            cap = min(3 * self.B * (model.n_neighbors + 1), model.n_nodes)
-            self.lazy_list = torch.zeros(max(cap, 1), dtype=torch.int64, device=dev)
-            self.lazy_tmin = torch.zeros(1, dtype=torch.float32, device=dev)
             self.lazy_restarted = 0  # nodes re-initialised before the last step (the step's own counts[3] stays 0)
-            self._lazy = TgLazyRestart(None, None, ptr(self.lazy_trigger), self.lazy_trigger.numel(), ptr(self.lazy_batch),
-                                       ptr(self.lazy_restarting), ptr(self.lazy_uptodate), ptr(self.lazy_list),
-                                       ptr(self.lazy_tmin))
+            cb = self.lazy_collate_context(model)
+            self.lazy_list, self.lazy_tmin, self._lazy = cb.lazy_list, cb.lazy_tmin, cb._lazy
+            self._lazy_collate = cb
+            self._lazy_host = torch.zeros(2, dtype=torch.float32).pin_memory() if dev.type == 'cuda' else None
+            return self
+
+        def lazy_collate_context(self, model: 'TIGER'):
+            """One collate-only pass of the list form (see enable_lazy_restart): step buffers of its own, its own list /
+            earliest-time / count outputs, the loop variables (trigger, batch counter, restarting flag, up-to-date bitmap) of
+            THIS buffer.  By default it reads the batch at this buffer's device-side offset without advancing it; a caller
+            that runs passes ahead of the steps (eval_utils: the resident restart-mode pass) points `io.offset_dev` elsewhere."""
+            dev = model.device
+            cap = min(3 * self.B * (model.n_neighbors + 1), model.n_nodes)
             cb = TIGE.StepBuffers(model, self.B, False, resident=(self.src, self.dst, self.neg, self.ts, self.eids))
+            cb.lazy_list = torch.zeros(max(cap, 1), dtype=torch.int64, device=dev)
+            cb.lazy_tmin = torch.zeros(1, dtype=torch.float32, device=dev)
+            cb._lazy = TgLazyRestart(None, None, ptr(self.lazy_trigger), self.lazy_trigger.numel(), ptr(self.lazy_batch),
+                                     ptr(self.lazy_restarting), ptr(self.lazy_uptodate), ptr(cb.lazy_list), ptr(cb.lazy_tmin))
             if self.offset is not None:  # the same batch as the step that follows: its device-side offset, not advanced
                 cb.offset = self.offset
                 cb.io.offset_dev = ptr(self.offset)
             cb.io.advance = 0
             cb.io.collate_only = 1
-            cb.io.lazy = C.addressof(self._lazy)
-            self._lazy_collate = cb
-            self._lazy_host = torch.zeros(2, dtype=torch.float32).pin_memory() if dev.type == 'cuda' else None
-            return self
+            cb.io.lazy = C.addressof(cb._lazy)
+            return cb
 
         def load(self, src, dst, neg, ts, eids):
             self.src.copy_(src, non_blocking=True)
