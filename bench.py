@@ -16,8 +16,10 @@ stream (the state keeps moving forward: no batch is replayed).
 Rank 0 prints ONE JSON line (see the task contract) including
   roofline               - the dominant kernel of the step, timed live with HIP events, priced with the
                            algorithmic flops / bytes of SURVEY.md s8(d) and the measured U / O / P of the run;
-  roofline_memory_gather - the memory-gather kernel (STEP 1-2 as one gather, reprs[u] = pending-or-right row)
-                           against the HBM roofline, plus SURVEY's full bytes_gather over gather + updater;
+  roofline_memory_gather - the memory-gather kernel OF THE TIMED STEP (eager direct form: the attention core, which gathers the
+                           involved rows itself) against the HBM roofline on its COMPULSORY bytes, the design's and the
+                           PMC bytes beside it, plus SURVEY's full bytes_gather over gather + updater;
+  roofline_sampler       - the sampler launch on the HBM roofline (SURVEY s8 d bytes_samp) where it has a launch of its own;
   c5s_leg                - (default C2 run only) a short run of the HBM-roofline configuration (10 M nodes,
                            d=256, B=65536): at C2 every table is cache resident, so the HBM claim is made there;
   cpu_baseline           - the CPU oracle (oracle/tiger_oracle.py, "port") on a bounded sample of the same
@@ -166,8 +168,10 @@ def build_models(stream, d, K, msg_src, upd_src, restarter='static', hist_len=40
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32 MFMA (MI355X_MICROARCH.md)
 PREROLL = 150                 # untimed batches before --warmup (state reaches steady U / O / P after ~100 at C2)
-C5S_PREROLL = 300             # ... of the C5-shaped leg (19.7 M events: the involved set per batch has flattened out; its
-                              # sizes at the middle and the end of the pre-roll are in the leg's config)
+C5S_PREROLL = 600             # ... of the C5-shaped leg (39 M events).  The involved set per batch never stops growing there - a
+                              # Zipf(0.8) tail over 9 M users keeps delivering nodes whose histories are shorter than K - but
+                              # its growth over the timed region is below 1 % by then; the sizes at the middle / end of the
+                              # pre-roll and after the timed region are in the leg's config (involved_start_end)
 REFERENCE_MEASURED = ('5730 events/s @ 8 cores: the reference\'s own CPU stream (collate + contrast_learning, no_grad), '
                       'd=172 B=1024, measured by importing it in the survey container (BASELINE.md s2)')
 
@@ -326,7 +330,7 @@ def load_traffic(tag):
     round's: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command, tools/pmc_traffic.py; with the rocprofv3
     --kernel-trace average duration of the same kernels beside them when recorded); {} if not recorded.
     A stored, builder-run measurement - the profiler cannot wrap the driver's run - and named as such in the line."""
-    for rnd in ('r04', 'r03', 'r02'):
+    for rnd in ('r05', 'r04', 'r03', 'r02'):
         path = os.path.join('profiles', f'{rnd}_hbm_traffic_{tag}.json')
         try:
             k = json.load(open(os.path.join(ROOT, path)))['kernels']
@@ -593,6 +597,10 @@ def run_stream_leg(cfg, args, preroll, warmup, steps, n_prof, traffic_tag, want_
                                      'sampler + centres of the NEXT batch ride on the query-row launch (tg_step_io.prefetch_state): '
                                      'stage eager_query_rows(G) includes them; every replay runs exactly one collate') if prefetch else 'first launch of the step'),
                            state_preroll_batches=preroll, involved_per_batch=float(U),
+                           involved_start_end=dict(before_timed_region=(u_trace[-1][1] if u_trace else None), after=float(U),
+                                                   growth=(float(U) / u_trace[-1][1] - 1.0) if u_trace and u_trace[-1][1] > 0 else None,
+                                                   note='involved nodes per batch just before the timed region (a full-form '
+                                                        'step of the pre-roll) and after it (the stage pass)'),
                            involved_before_timed_region=[dict(batch=b, involved=u) for b, u in u_trace],
                            outdated_per_batch=float(O_),
                            unique_pos_per_batch=float(P)),
@@ -984,12 +992,12 @@ def main():
     out.update(leg)
     if args.workload == 'c2' and not args.no_c5s_leg:
         # at C2 every table is cache resident (150 MB): the HBM-roofline claim for the memory-gather kernel is made
-        # on the C5-shaped tables (10 M nodes, d=256, B=65536: 70 GB of state), 100 untimed batches (6.5 M events) and 30 timed steps; the involved set still grows slowly
+        # on the C5-shaped tables (10 M nodes, d=256, B=65536: 70 GB of state), C5S_PREROLL untimed batches and 30 timed steps; the involved set still grows slowly
         # there (its sizes before and after the timed region are in the line)
         c5 = run_stream_leg(dict(WORKLOADS['c5s']), args, C5S_PREROLL, 4, 30, 4, traffic_tag='c5s')
         out['c5s_leg'] = dict(value=c5['value'], unit='events/s', ms_per_step=c5['ms_per_step'], steps=30, warmup=C5S_PREROLL + 4,
                               config=c5['config'], roofline_memory_gather=c5['roofline_memory_gather'],
-                              roofline_updater=c5['roofline_updater'],
+                              roofline_sampler=c5['roofline_sampler'], roofline_updater=c5['roofline_updater'],
                               roofline_neighbour_gather=c5['roofline_neighbour_gather'], stages_ms=c5['stages_ms'])
     if args.workload == 'c2' and not args.no_api_loop:
         try:

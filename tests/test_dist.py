@@ -131,6 +131,27 @@ class OracleBackend:
                    ts2[torch.from_numpy(idx)])  # STEP 6
 
 
+    # ---- PeriodicShardedRunner: state rows of a node list as one [n, W] block (left | ts | right | ts | mailbox | ts)
+    device = torch.device('cpu')
+
+    def row_width(self):
+        m = self.orc
+        return 2 * (m.d + 1) + m.msg_vals.shape[1] + 1
+
+    def export_rows(self, ids):
+        m, i = self.orc, torch.from_numpy(np.asarray(ids, dtype=np.int64))
+        return torch.cat([m.left_vals[i], m.left_ts[i, None], m.right_vals[i], m.right_ts[i, None], m.msg_vals[i],
+                          m.msg_ts[i, None]], 1)
+
+    def import_rows(self, ids, rows):
+        m, ids = self.orc, np.asarray(ids, dtype=np.int64)
+        i, d, mw = torch.from_numpy(ids), self.orc.d, self.orc.msg_vals.shape[1]
+        m.left_vals[i], m.left_ts[i] = rows[:, :d], rows[:, d]
+        m.right_vals[i], m.right_ts[i] = rows[:, d + 1:2 * d + 1], rows[:, 2 * d + 1]
+        m.msg_vals[i], m.msg_ts[i] = rows[:, 2 * d + 2:2 * d + 2 + mw], rows[:, 2 * d + 2 + mw]
+        m.has_msg[ids] = True
+
+
 def _make_oracle(z, cfg):
     from oracle import tiger_oracle as O
     n_nodes, nfeats, efeats = fixture_tables(z, cfg)
@@ -178,6 +199,75 @@ def test_sharded_equals_single_process_cpu_gloo(tmp_path):
         for k, v in want.items():
             np.testing.assert_array_equal(got[k], v, err_msg=f'rank {r} {k}')
         np.testing.assert_array_equal(got['msg'][ref.has_msg], ref.msg_vals.numpy()[ref.has_msg])
+
+
+def _cpu_period_worker(rank, world, port, name, Bg, n_batches, period, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    tdist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from www2023tiger_amd.dist import PeriodicShardedRunner, balanced_owner_table
+    z = load(name)
+    cfg = parse_cfg(z)
+    orc = _make_oracle(z, cfg)
+    owner = balanced_owner_table(int(z['n_nodes']), z['dst'], world)
+    runner = PeriodicShardedRunner(OracleBackend(orc, cfg['K'], 'static'), owner, rank, world, cap=Bg, period=period)
+    for b in range(n_batches):
+        sl = slice(b * Bg, (b + 1) * Bg)
+        runner.step(*(z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')))
+    runner.flush()
+    np.savez(os.path.join(out_dir, f'rank{rank}.npz'), left=orc.left_vals.numpy(), right=orc.right_vals.numpy(),
+             left_ts=orc.left_ts.numpy(), right_ts=orc.right_ts.numpy(), msg=orc.msg_vals.numpy(),
+             msg_ts=orc.msg_ts.numpy(), has=orc.has_msg, sent=np.int64(runner.exchanged_rows))
+    tdist.destroy_process_group()
+
+
+def _single_process_state(name, Bg, n_batches):
+    from oracle import tiger_oracle as O
+    z = load(name)
+    cfg = parse_cfg(z)
+    ref = _make_oracle(z, cfg)
+    for b in range(n_batches):
+        sl = slice(b * Bg, (b + 1) * Bg)
+        a = [z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        ref.contrast_learning(*a, O.collate(ref.graph, a[0], a[1], a[2], a[3], cfg['K'], 'static'))
+    return ref
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_exchange_period_one_equals_single_process_cpu_gloo(tmp_path, world):
+    """period 1 of the periodic exchange (write back the own shard, all-gather the touched rows, latest event wins) is the
+    exact global write-back: every replica equals the single-process engine bit for bit."""
+    name, Bg, n_batches = 'static_ll_d16', 96, 6
+    mp.spawn(_cpu_period_worker, args=(world, free_port(), name, Bg, n_batches, 1, str(tmp_path)), nprocs=world, join=True)
+    ref = _single_process_state(name, Bg, n_batches)
+    want = dict(left=ref.left_vals.numpy(), right=ref.right_vals.numpy(), left_ts=ref.left_ts.numpy(),
+                right_ts=ref.right_ts.numpy(), msg_ts=ref.msg_ts.numpy(), has=ref.has_msg)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f'rank{r}.npz'))
+        for k, v in want.items():
+            np.testing.assert_array_equal(got[k], v, err_msg=f'rank {r} {k}')
+        np.testing.assert_array_equal(got['msg'][ref.has_msg], ref.msg_vals.numpy()[ref.has_msg])
+
+
+@pytest.mark.parametrize('period', [2, 4])
+def test_exchange_period_k_replicas_agree_and_drift_is_bounded_cpu_gloo(tmp_path, period):
+    """period k > 1: after the closing exchange all replicas hold the same state; times, the has-message set and the
+    bookkeeping equal the exact engine's (they do not depend on stale rows), the float rows drift from it by a bounded
+    amount (neighbour rows up to k - 1 batches stale) - and really do drift, i.e. the period is in effect."""
+    name, Bg, n_batches, world = 'static_ll_d16', 96, 8, 2
+    mp.spawn(_cpu_period_worker, args=(world, free_port(), name, Bg, n_batches, period, str(tmp_path)), nprocs=world,
+             join=True)
+    got = [np.load(os.path.join(str(tmp_path), f'rank{r}.npz')) for r in range(world)]
+    for k in ('left', 'right', 'left_ts', 'right_ts', 'msg', 'msg_ts', 'has'):
+        np.testing.assert_array_equal(got[0][k], got[1][k], err_msg=k)
+    ref = _single_process_state(name, Bg, n_batches)
+    np.testing.assert_array_equal(got[0]['left_ts'], ref.left_ts.numpy())
+    np.testing.assert_array_equal(got[0]['has'], ref.has_msg)
+    np.testing.assert_array_equal(got[0]['msg_ts'], ref.msg_ts.numpy())
+    drift = np.abs(got[0]['left'] - ref.left_vals.numpy()).max() / max(1.0, np.abs(ref.left_vals.numpy()).max())
+    assert 0.0 < drift < 0.5, drift
 
 
 # ------------------------------------------------------------------------------ HIP backend (GPU)

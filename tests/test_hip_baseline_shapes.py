@@ -48,6 +48,55 @@ def _compare_indices(buf, cg, node_map=None):
     return counts
 
 
+def test_c1_wikipedia_shape_b200_seq_restarter_collate():
+    """BASELINE configs[0] exactly as bench.WORKLOADS['c1'] has it: Wikipedia-shaped, d = 172, B = 200, msg = left, upd =
+    right, restart_prob 0 with the SEQ restarter's collation (hist_len 40: data_loader.py:82 collates the restart data
+    whatever restart_prob is), 22 consecutive batches through the reference call sequence (collator -> contrast_learning)
+    against the oracle - embeddings, scores, the restart data bit-exact, the final state - and the SeqRestarter's forward
+    on the collated histories of three of the batches (the surrogate rows the mutual loss would read)."""
+    import bench
+    from oracle import tiger_oracle as O
+    from test_hip_parity import compare_state_with_oracle
+    from www2023tiger_amd.data.data_loader import GraphCollator
+    c = bench.WORKLOADS['c1']
+    B, K, d, nb, H = c['B'], c['K'], c['d'], 22, 40
+    assert (B, c['upd_src'], c['msg_src'], d) == (200, 'right', 'left', 172)
+    E = (nb + 1) * B
+    stream = bench.make_stream(c['n_u'], c['n_i'], E, c['T'] * E / c['E'], seed=7, d_e=d)
+    model, orc = bench.build_models(stream, d, K, c['msg_src'], c['upd_src'], restarter='seq', hist_len=H, with_oracle=True)
+    coll = GraphCollator(model.graph, K, 1, restarter='seq', hist_len=H)
+    to = lambda x, dt: torch.as_tensor(x).to(dev(), dt)
+    worst = 0.0
+    for b in range(nb):
+        a = _batch(stream, b, B)
+        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], K, 'seq', hist_len=H)
+        out = coll.collate_arrays(*a)
+        hcg = out[-1]
+        np.testing.assert_array_equal(hcg.layers[1][0].cpu().numpy(), cg['l1_nids'])
+        np.testing.assert_array_equal(hcg.layers[1][1].cpu().numpy(), cg['l1_eids'])
+        np.testing.assert_array_equal(hcg.np_computation_graph_nodes, cg['involved'])
+        rd = hcg.restart_data
+        np.testing.assert_array_equal(rd.index.cpu().numpy(), cg['rd_index'])
+        np.testing.assert_array_equal(rd.nids.cpu().numpy(), cg['rd_nids'])
+        for f, k in (('hist_nids', 'rd_hist_nids'), ('anonymized_ids', 'rd_anon'), ('hist_eids', 'rd_hist_eids'),
+                     ('hist_ts', 'rd_hist_ts'), ('hist_dirs', 'rd_hist_dirs')):
+            np.testing.assert_array_equal(getattr(rd, f).cpu().numpy(), cg[k], err_msg=k)
+        if b in (5, 12, 21):  # the restarter on the collated histories (restarters.py:85-114; zero node features: narrow form)
+            hl, hr, pt = model.restarter_fn(rd.nids, rd.ts, hcg)
+            rl, rr, rp = orc.restarter_forward(cg['rd_nids'], cg['rd_ts'], cg)
+            worst = max(worst, *assert_close(hl.cpu().numpy(), rl.numpy(), 'surrogate h(t-)', TOL),
+                        *assert_close(hr.cpu().numpy(), rr.numpy(), 'surrogate h(t+)', TOL))
+            np.testing.assert_array_equal(pt.cpu().numpy().reshape(-1), np.asarray(rp).reshape(-1))
+        with torch.no_grad():
+            res = model.contrast_learning(to(a[0], torch.int64), to(a[1], torch.int64), to(a[2], torch.int64),
+                                          to(a[3], torch.float32), to(a[4], torch.int64), hcg)
+        ref = orc.contrast_learning(*a, cg)
+        worst = max(worst, *assert_close(res[2].cpu().numpy(), ref['pos_scores'].detach().numpy(), 'positive scores', TOL),
+                    *assert_close(res[3].cpu().numpy(), ref['neg_scores'].detach().numpy(), 'negative scores', TOL))
+        model._poll_train_errors()
+    compare_state_with_oracle(model, orc)
+
+
 @pytest.mark.parametrize('eager', [False, True], ids=['lazy', 'eager'])
 def test_c3_reddit_shape_b4096_static_lazy_restart(eager):
     import bench

@@ -385,3 +385,68 @@ def test_training_other_shapes(d, n_head, hit, K, restarter):
         assert abs(float(tb.losses[1]) - ml) < TOL * max(1.0, abs(ml)), b
         worst = max((grad_err(g_.cpu().numpy(), grads[k].numpy()), k) for k, g_ in tb.grads.items())
         assert worst[0] < 3e-4, (b, worst)
+
+
+@pytest.mark.parametrize('name,H', [('train_seq_lr_d8_zeronf', 100), ('train_seq_lr_d8', 72), ('train_seq_lr_d8_zeronf', 33)])
+def test_long_history_restarter_forward_and_gradients(name, H):
+    """--hist_len beyond 64 (init_utils.py:58 takes any int; the score kernels' 128-row grids need more dynamic LDS than a
+    launch gets by default) and just above 32 (both row classes of the 64-row launch pair): the SeqRestarter's forward on
+    sampled histories and the mutual-learning gradients against the oracle - on a zero node-feature table (narrow form of
+    the Q / K projection) and on a random one (wide form).  The fixtures' streams with parameters regenerated for the
+    longer history (the anony_emb table grows with it)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    from _weights import golden_param
+    from oracle import tiger_oracle as O
+    from _util import fixture_tables
+    from www2023tiger_amd.data.graph import Graph
+    from www2023tiger_amd.model.feature_getter import NumericalFeature
+    from www2023tiger_amd.model.restarters import SeqRestarter
+    from www2023tiger_amd.model.tiger import TIGER
+    from www2023tiger_amd.model.training import TrainBuffers
+    z = load(name)
+    cfg = parse_cfg(z)
+    cfg['H'] = H
+    n_nodes, nfeats, efeats = fixture_tables(z, cfg)
+    g = Graph.from_arrays(z['src'], z['dst'], z['ts'], z['eids'], strategy='recent_edges', seed=0, device=dev())
+    fg = NumericalFeature(None if nfeats is None else torch.from_numpy(nfeats), torch.from_numpy(efeats), dim=cfg['d'], device=dev())
+    fg.n_nodes, fg.n_edges = n_nodes, len(z['src'])
+    rst = SeqRestarter(raw_feat_getter=fg, graph=g, hist_len=H, n_head=2, dropout=0.0)
+    model = TIGER(raw_feat_getter=fg, graph=g, restarter=rst, n_neighbors=cfg['K'], hit_type=cfg.get('hit', 'bin'), n_layers=1,
+                  n_head=2, dropout=0.0, msg_src=cfg['msg_src'], upd_src=cfg['upd_src'])
+    params = {k: golden_param(k, tuple(v.shape), cfg['wseed']) for k, v in model.named_parameters()}
+    with torch.no_grad():
+        for k, v in model.named_parameters():
+            v.copy_(torch.from_numpy(params[k]))
+    model = model.to(dev())
+    og = O.OracleGraph(z['src'], z['dst'], z['ts'], z['eids'], strategy='recent_edges', seed=0)
+    orc = O.OracleTIGER(params, og, n_nodes=n_nodes, dim=cfg['d'], nfeats=nfeats, efeats=efeats, n_neighbors=cfg['K'],
+                        msg_src=cfg['msg_src'], upd_src=cfg['upd_src'], restarter='seq', hist_len=H, hit_type=cfg.get('hit', 'bin'))
+    # forward at the end of the stream: long histories for the popular nodes, short (padded) ones for the others
+    model.eval()
+    nids = np.arange(1, n_nodes, dtype=np.int64)
+    ts = np.full(len(nids), np.float32(z['ts'].max()) + 1.0, dtype=np.float32)
+    hl, hr, pt = model.restarter_fn(torch.from_numpy(nids).to(dev()), torch.from_numpy(ts).to(dev()))
+    rl, rr, rp = orc.restarter_forward(nids, ts)
+    assert rel_err(hl.cpu().numpy(), rl.detach().numpy()) < TOL and rel_err(hr.cpu().numpy(), rr.detach().numpy()) < TOL
+    np.testing.assert_array_equal(pt.cpu().numpy(), rp.numpy())
+    # gradients through the mutual loss
+    model.train()
+    bufs = {}
+    for b in range(4):
+        a = batch(z, cfg, b + 5)  # later batches: histories have filled up
+        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], cfg['K'], 'seq', hist_len=H)
+        sync_params(model, orc)
+        c, ml, grads = orc.train_step(*a, cg, lr=cfg['lr'], mutual_coef=1.0)
+        n = len(a[0])
+        tb = bufs.get(n) or TrainBuffers(model, n, mutual=True)
+        bufs[n] = tb
+        to = lambda x, dt: torch.as_tensor(x).to(dev(), dt)
+        tb.sb.load(to(a[0], torch.int64), to(a[1], torch.int64), to(a[2], torch.int64), to(a[3], torch.float64),
+                   to(a[4], torch.int64))
+        tb.launch()
+        assert int(tb.sb.err.item()) == 0
+        assert abs(float(tb.losses[1]) - ml) < TOL * max(1.0, abs(ml)), (b, float(tb.losses[1]), ml)
+        for k, gv in tb.grads.items():
+            assert grad_err(gv.cpu().numpy(), grads[k].numpy()) < 2e-4, (b, k)

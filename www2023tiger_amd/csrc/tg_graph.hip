@@ -587,6 +587,30 @@ __global__ void __launch_bounds__(256) k_anon_reindex(int64_t n, int H, const in
     if (lane < H) out[r * H + lane] = (v == 0) ? 0 : code;
   }
 }
+// histories of 65 .. 128 events: two columns per lane (lane, lane + 64), the same rule
+__global__ void __launch_bounds__(256) k_anon_reindex2(int64_t n, int H, const int64_t* __restrict__ in,
+                                                       int64_t* __restrict__ out) {
+  const int lane = lane_id();
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.x * 4) {
+    const int64_t v0 = in[r * H + lane];  // (H > 64)
+    const int64_t v1 = lane + 64 < H ? in[r * H + 64 + lane] : -1;
+    int l0 = lane, l1 = lane + 64;
+    for (int i = 0; i < H; ++i) {
+      const int64_t vi = i < 64 ? __shfl(v0, i, TG_WAVE) : __shfl(v1, i - 64, TG_WAVE);
+      if (vi == v0 && i > l0) l0 = i;
+      if (vi == v1 && i > l1) l1 = i;
+    }
+    const unsigned long long m0 = __ballot(l0 == lane);
+    const unsigned long long m1 = __ballot(lane + 64 < H && l1 == lane + 64);
+    auto right_of = [&](int last) {  // distinct ids whose last occurrence lies to the right of column `last`
+      if (last < 63) return __popcll(m0 >> (last + 1)) + __popcll(m1);
+      if (last == 63) return __popcll(m1);
+      return last >= 127 ? 0 : __popcll(m1 >> (last - 64 + 1));
+    };
+    out[r * H + lane] = (v0 == 0) ? 0 : 1 + right_of(l0);
+    if (lane + 64 < H) out[r * H + 64 + lane] = (v1 == 0) ? 0 : 1 + right_of(l1);
+  }
+}
 
 }  // namespace tg
 
@@ -713,10 +737,13 @@ extern "C" int tg_hits(int64_t B, int32_t K, const int64_t* center, const int64_
 
 extern "C" int tg_anonymized_reindex(int64_t n, int32_t H, const int64_t* in, int64_t* out, void* stream) {
   if (n < 0 || H <= 0) return TG_EINVAL;
-  if (H > TG_WAVE) return TG_EUNSUPPORTED;
+  if (H > 2 * TG_WAVE) return TG_EUNSUPPORTED;
   if (n == 0) return TG_OK;
   if (!in || !out) return TG_EINVAL;
-  hipLaunchKernelGGL(k_anon_reindex, dim3(flat_grid(n, 4)), dim3(256), 0, as_stream(stream), n, H, in, out);
+  if (H <= TG_WAVE)
+    hipLaunchKernelGGL(k_anon_reindex, dim3(flat_grid(n, 4)), dim3(256), 0, as_stream(stream), n, H, in, out);
+  else
+    hipLaunchKernelGGL(k_anon_reindex2, dim3(flat_grid(n, 4)), dim3(256), 0, as_stream(stream), n, H, in, out);
   return check_launch("tg_anonymized_reindex");
 }
 

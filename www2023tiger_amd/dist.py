@@ -157,6 +157,99 @@ class ShardedRunner:
         return h_left
 
 
+class PeriodicShardedRunner:
+    """Replicated layout with an exchange PERIOD k ("periodic memory all-gather", SURVEY.md s8 e item 4).
+
+    Between exchanges a rank writes back its OWN shard's events only: its replicas of the nodes other ranks work on
+    go stale, nothing crosses the links.  Every k-th batch (and at `flush`) the ranks all-gather the state rows their
+    write-backs touched since the last exchange - both memory rows with their times, the mailbox row and its time; every
+    touched node has a pending message - and every replica keeps, per node, the version of the node's LATEST event:
+    later batch first, then later time, then the earlier position in the global batch (select_latest's first-index
+    rule, utils.py:10-16).  After an exchange all replicas are equal again.  Traffic per exchange: the distinct nodes a
+    rank touched in k batches x (2 (4d + 4) + 16d + 8) bytes, instead of 4 cap d floats per rank and BATCH.
+    k = 1: every batch starts from synchronised replicas, the touched rows are the ones the exact global write-back
+    (ShardedRunner) would have written: the same state bit for bit (tests/test_dist.py).  k > 1 trades staleness for
+    bandwidth: a rank embeds with neighbour rows that miss up to k - 1 batches of other ranks' updates; the drift is
+    MEASURED (tools/period_drift.py: embeddings and AP / AUC against k = 1), not assumed.
+    `backend` needs embed / writeback as ShardedRunner's plus export_rows(ids) -> [n, W] float32 and
+    import_rows(ids, rows) (W = 2 (d + 1) + msg_width + 1: left | left_ts | right | right_ts | mailbox | mailbox ts)."""
+
+    def __init__(self, backend, owner: np.ndarray, rank: int, world: int, cap: int, period: int, group=None,
+                 balance: bool = False):
+        if period < 1:
+            raise ValueError('exchange period >= 1')
+        self.backend, self.owner, self.rank, self.world, self.cap, self.group = backend, owner, rank, world, cap, group
+        self.period, self.balance = int(period), balance
+        self.batch = 0
+        self._dirty = {}  # node -> (batch, ts, position in the global batch) of its latest local write
+        self.exchanged_rows = 0  # rows this rank has sent so far (traffic accounting)
+
+    def step(self, src, dst, neg, ts, eids):
+        """Arrays of the GLOBAL batch (host numpy).  Returns this rank's local embeddings [2n, d]."""
+        src, dst, neg, eids = (np.asarray(x) for x in (src, dst, neg, eids))
+        ts = np.asarray(ts)
+        plan = ShardPlan(dst, self.owner, self.world, self.cap, balance=self.balance)
+        li = plan.local_idx[self.rank]
+        n = len(li)
+        h_left, h_new = self.backend.embed(src[li], dst[li], neg[li], ts[li], eids[li])
+        if n:
+            rows = torch.cat([h_left[:2 * n], h_new[:2 * n]])
+            ar = np.arange(2 * n, dtype=np.int64)
+            self.backend.writeback(src[li], dst[li], ts[li], eids[li], rows, ar, 2 * n + ar)
+            pos = np.concatenate([src[li], dst[li]])
+            t2 = np.tile(ts[li].astype(np.float32), 2)
+            gpos = np.concatenate([li, len(src) + li])  # positions in cat[src, dst] of the GLOBAL batch
+            # the node's winning event inside the shard: latest time, first index among equals (stream order is kept)
+            order = np.lexsort((np.arange(2 * n), -t2.astype(np.float64), pos))
+            first = np.ones(2 * n, dtype=bool)
+            first[1:] = pos[order][1:] != pos[order][:-1]
+            for j in order[first]:
+                self._dirty[int(pos[j])] = (self.batch, float(t2[j]), int(gpos[j]))
+        self.batch += 1
+        if self.batch % self.period == 0:
+            self.exchange()
+        return h_left
+
+    def flush(self):
+        """exchange whatever is outstanding (end of a stream whose length is not a multiple of the period)"""
+        if self.batch % self.period:
+            self.exchange()
+
+    def exchange(self):
+        world, rank = self.world, self.rank
+        ids = np.array(sorted(self._dirty), dtype=np.int64)
+        key = np.array([self._dirty[int(v)] for v in ids], dtype=np.float64).reshape(-1, 3)
+        self._dirty = {}
+        n = len(ids)
+        self.exchanged_rows += n
+        cap = 2 * self.cap * self.period
+        dev = getattr(self.backend, 'device', torch.device('cpu'))
+        rows = self.backend.export_rows(ids) if n else None
+        W = int(self.backend.row_width())
+        send = torch.zeros(cap, W + 4, dtype=torch.float64, device=dev)  # float64: node ids and positions travel exactly
+        if n:
+            send[:n, 0] = torch.from_numpy(ids.astype(np.float64)).to(dev)
+            send[:n, 1:4] = torch.from_numpy(key).to(dev)
+            send[:n, 4:] = rows.to(torch.float64)
+        send_n = torch.tensor([n], dtype=torch.int64, device=dev)
+        got = all_gather_rows(send, world, self.group)
+        got_n = all_gather_rows(send_n, world, self.group).reshape(-1).tolist()
+        cand = [(got[q, :got_n[q]], q) for q in range(world) if got_n[q]]
+        if not cand:
+            return
+        allr = torch.cat([c for c, _ in cand]).cpu()
+        src_rank = np.concatenate([np.full(got_n[q], q, dtype=np.int64) for _, q in cand])
+        a = allr.numpy()
+        # per node: later batch, then later time, then earlier global position (then lower rank: cannot tie further)
+        order = np.lexsort((src_rank, a[:, 3], -a[:, 2], -a[:, 1], a[:, 0]))
+        first = np.ones(len(order), dtype=bool)
+        first[1:] = a[order][1:, 0] != a[order][:-1, 0]
+        win = order[first]
+        win = win[src_rank[win] != rank]  # the rank's own winners are in place already
+        if len(win):
+            self.backend.import_rows(a[win, 0].astype(np.int64), allr[torch.from_numpy(win), 4:].to(torch.float32))
+
+
 def _refuse_eager_table(model):
     """The replicated layout writes back through tg_stream_writeback, which does not run the eager updater: a model with
     the table of precomputed updater rows (TIGE.eager_updates) would embed from rows that are never refreshed."""
@@ -208,6 +301,39 @@ class HipBackend:
                        ptr(keep[5]), ptr(keep[6]), ptr(self.err))
         self.check(lib.tg_stream_writeback(C.byref(ms), C.byref(io), ptr(self._wb_ws), self._wb_ws.numel(),
                                            self.hip_ops.stream_ptr(m.device)), 'tg_stream_writeback')
+
+    # ---- PeriodicShardedRunner: the state rows of a node list, as one [n, W] float32 block
+    @property
+    def device(self):
+        return self.model.device
+
+    def row_width(self) -> int:
+        m = self.model
+        return 2 * (m.memory_dim + 1) + m.msg_store.node_msg_vals.shape[1] + 1
+
+    def export_rows(self, ids):
+        m = self.model
+        i = self._dev(ids, torch.int64)
+        L, R, S = m.left_memory, m.right_memory, m.msg_store
+        g = self.hip_ops.gather_rows
+        return torch.cat([g(L.vals, i), L.update_ts[i, None], g(R.vals, i), R.update_ts[i, None],
+                          g(S.node_msg_vals, i), S.node_msg_ts[i, None]], 1)
+
+    def import_rows(self, ids, rows):
+        """overwrite the replicas of `ids` (every exported node has a pending message: a write-back stored one)"""
+        m = self.model
+        m._touch()
+        i = self._dev(ids, torch.int64)
+        rows = rows.to(m.device)
+        d, mw = m.memory_dim, m.msg_store.node_msg_vals.shape[1]
+        L, R, S = m.left_memory, m.right_memory, m.msg_store
+        L.vals[i] = rows[:, :d]
+        L.update_ts[i] = rows[:, d]
+        R.vals[i] = rows[:, d + 1:2 * d + 1]
+        R.update_ts[i] = rows[:, 2 * d + 1]
+        S.node_msg_vals[i] = rows[:, 2 * d + 2:2 * d + 2 + mw]
+        S.node_msg_ts[i] = rows[:, 2 * d + 2 + mw]
+        self.hip_ops.bitmap_mark(i, S.has_msg_bits, m.n_nodes)
 
     def check_invariants(self):
         self.hip_ops.raise_if_err(self.err)
