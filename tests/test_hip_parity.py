@@ -471,6 +471,40 @@ def test_stream_fused_step_two_layers(name, form):
     check_state(model, z, 'flushed')
 
 
+@pytest.mark.parametrize('form', ['lazy', 'eager-fused-lean'])
+def test_stream_fused_step_two_layers_recent_nodes_strategy(form):
+    """--n_layers 2 with --strategy recent_nodes inside tg_stream_step: BOTH hops follow the graph's strategy (data_loader.py:
+    128-131 samples every layer with graph.sample_temporal_neighbor), the second at the neighbours' float32 timestamps - lists
+    of both hops bit-exact, embeddings and state against the oracle collating the same way."""
+    from oracle import tiger_oracle as O
+    from test_oracle_golden import build_oracle
+    z = load('static_lr_d8_L2')
+    cfg = parse_cfg(z)
+    model, g, coll = build_hip_model(z, cfg, strategy='recent_nodes')
+    orc = build_oracle(z, cfg)
+    orc.graph = O.OracleGraph(z['src'], z['dst'], z['ts'], z['eids'], strategy='recent_nodes', seed=0)
+    if 'eager' in form:
+        model.eager_updates()
+        model.fuse_attention()
+    B, differs = cfg['B'], False
+    for b in range(n_batches(z)):
+        sl = slice(b * B, min((b + 1) * B, len(z['src'])))
+        a = [z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], cfg['K'], 'static', n_layers=2)
+        ref = orc.contrast_learning(*a, cg)['h_left'].detach().numpy()
+        buf = model.stream_step(*a, lean='lean' in form)
+        np.testing.assert_array_equal(buf.l1_nids.cpu().numpy(), cg['l1_nids'])
+        np.testing.assert_array_equal(buf.l1_eids.cpu().numpy(), cg['l1_eids'])
+        if 'lean' not in form:
+            cnt = buf.counts.cpu().numpy()
+            np.testing.assert_array_equal(buf.involved.cpu().numpy()[:cnt[0]], cg['involved'])  # second hop included
+        assert_close(buf.h[:2 * len(a[0])].cpu().numpy(), ref, 'h_left', TOL)
+        edges = orc.graph.sample_temporal_neighbor(cg['l1_nids'].ravel(), cg['l1_ts'].ravel(), cfg['K'], strategy='recent_edges')[0]
+        differs = differs or not np.array_equal(edges, cg['hop2_nids'])
+    assert differs  # the strategy really changes the second hop on this stream
+    compare_state_with_oracle(model, orc)
+
+
 def test_no_feat_buffer_reads_pinned_host_tables():
     """--no_feat_buffer (feature_getter.py:41-47,86-87): NumericalFeature(register_buffer=False) keeps the feature tables
     in pinned host memory; the kernels read them in place, the stream reproduces the reference like the resident form"""

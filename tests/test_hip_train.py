@@ -162,6 +162,38 @@ def test_training_step_with_other_sampling_strategies(strategy):
     assert rel_err(model.right_memory.vals.cpu().numpy(), orc.right_vals.numpy()) < TOL
 
 
+def test_two_layer_training_step_with_the_recent_nodes_strategy():
+    """--n_layers 2 --strategy recent_nodes in the device training step (init_utils.py:36-41 allows the combination): both
+    hops sampled with the graph's strategy, the hit windows recent-edges lists; loss and the gradients of BOTH attention
+    layers against the oracle's autograd over the same collation."""
+    from oracle import tiger_oracle as O
+    from www2023tiger_amd.model.training import TrainBuffers
+    z = load('train_static_lr_d8_L2')
+    cfg = parse_cfg(z)
+    model, _, _ = build_hip_model(z, cfg, strategy='recent_nodes', dropout=0.0)
+    orc = build_oracle(z, cfg)
+    orc.graph = O.OracleGraph(z['src'], z['dst'], z['ts'], z['eids'], strategy='recent_nodes', seed=0)
+    model.train()
+    bufs = {}
+    for b in range(cfg['n_batches']):
+        a = batch(z, cfg, b)
+        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], cfg['K'], cfg['restarter'], hist_len=cfg.get('H'), n_layers=2)
+        sync_params(model, orc)
+        c, _, grads = orc.train_step(*a, cg, lr=cfg['lr'], contrast_only=True)
+        n = len(a[0])
+        tb = bufs.get(n) or TrainBuffers(model, n)
+        bufs[n] = tb
+        to = lambda x, dt: torch.as_tensor(x).to(dev(), dt)
+        tb.sb.load(to(a[0], torch.int64), to(a[1], torch.int64), to(a[2], torch.int64), to(a[3], torch.float64),
+                   to(a[4], torch.int64))
+        tb.launch()
+        assert int(tb.sb.err.item()) == 0
+        assert abs(float(tb.losses[0]) - c) < TOL * max(1.0, abs(c)), b
+        for k, g in tb.grads.items():
+            assert grad_err(g.cpu().numpy(), grads[k].numpy()) < 2e-4, (b, k)
+    assert rel_err(model.left_memory.vals.cpu().numpy(), orc.left_vals.numpy()) < TOL
+
+
 @pytest.mark.parametrize('name', ['train_seq_lr_d8', 'train_static_ll_d16', 'train_mlp_merge_d8', 'train_linear_gru_d8',
                                   'train_static_lr_d8_L2', 'train_seq_lr_d8_zeronf'])
 def test_mutual_gradients_match_oracle(name):

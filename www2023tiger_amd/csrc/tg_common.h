@@ -279,6 +279,8 @@ int sample_batch_launch(const tg_tcsr* g, int64_t B, const int64_t* src, const i
 // float32 timestamps, data_loader.py:131); marks the sampled ids in `mark` when given
 int sample_edges_f32_launch(const tg_tcsr* g, int64_t Q, const int64_t* nids, const float* ts, int32_t K, int64_t* o_nbr,
                             int64_t* o_eid, float* o_ts, uint8_t* mark, hipStream_t st);
+int sample_nodes_f32_launch(const tg_tcsr* g, int64_t Q, const int64_t* nids, const float* ts, int32_t K, int64_t* o_nbr,
+                            int64_t* o_eid, float* o_ts, uint8_t* mark, hipStream_t st);
 // recent-nodes sampler (graph.py:129-143) over prepared query arrays; marks queries and neighbours in `mark` when given
 int sample_nodes_launch(const tg_tcsr* g, int64_t Q, const int64_t* nids, const double* ts, int32_t K, int64_t* o_nbr,
                         int64_t* o_eid, float* o_ts, uint8_t* mark, hipStream_t st);

@@ -276,13 +276,14 @@ int sample_batch_launch(const tg_tcsr* g, int64_t B, const int64_t* src, const i
 __global__ void __launch_bounds__(256) k_sample_recent_nodes(tg_tcsr g, int64_t Q, const int64_t* __restrict__ nids,
                                                              const double* __restrict__ qts, int K,
                                                              int64_t* __restrict__ o_nbr, int64_t* __restrict__ o_eid,
-                                                             float* __restrict__ o_ts, int64_t* __restrict__ o_dir) {
+                                                             float* __restrict__ o_ts, int64_t* __restrict__ o_dir,
+                                                             const float* __restrict__ qts32 = nullptr) {
   __shared__ int s_new[4][TG_WAVE];
   const int lane = lane_id();
   const int wv = threadIdx.x >> 6;
   for (int64_t q = (int64_t)blockIdx.x * 4 + wv; q < Q; q += (int64_t)gridDim.x * 4) {
     int64_t start;
-    const int64_t end = prefix_end(g, nids[q], qts[q], &start);
+    const int64_t end = prefix_end(g, nids[q], qts ? qts[q] : (double)qts32[q], &start);  // (second hop: float32 query times)
     int c = 0;        // wave-uniform: number collected so far
     int mycol = -1;   // lane j holds the neighbour id of the j-th collected entry
     for (int64_t chunk_end = end; chunk_end > start && c < K; chunk_end -= TG_WAVE) {
@@ -657,6 +658,20 @@ int tg::sample_nodes_launch(const tg_tcsr* g, int64_t Q, const int64_t* nids, co
     hipLaunchKernelGGL(k_mark_lists, dim3(flat_grid(Q * (K + 1), 256)), dim3(256), 0, st, Q, (int)K, nids,
                        (const int64_t*)o_nbr, mark);
   return check_launch("sample_nodes");
+}
+
+// second hop of a two-layer step with --strategy recent_nodes (data_loader.py:128-131: the graph's own strategy at the
+// neighbours' float32 timestamps)
+int tg::sample_nodes_f32_launch(const tg_tcsr* g, int64_t Q, const int64_t* nids, const float* ts, int32_t K, int64_t* o_nbr,
+                                int64_t* o_eid, float* o_ts, uint8_t* mark, hipStream_t st) {
+  if (Q <= 0) return TG_OK;
+  if (K > TG_WAVE) return TG_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_sample_recent_nodes, dim3(flat_grid(Q, 4)), dim3(256), 0, st, *g, Q, nids, (const double*)nullptr, K,
+                     o_nbr, o_eid, o_ts, (int64_t*)nullptr, ts);
+  if (mark)
+    hipLaunchKernelGGL(k_mark_lists, dim3(flat_grid(Q * (K + 1), 256)), dim3(256), 0, st, Q, (int)K, nids,
+                       (const int64_t*)o_nbr, mark);
+  return check_launch("sample_nodes_f32");
 }
 
 int tg::sample_edges_f32_launch(const tg_tcsr* g, int64_t Q, const int64_t* nids, const float* ts, int32_t K, int64_t* o_nbr,

@@ -445,6 +445,10 @@ int attn_dims_ok(const tg_model* m) {
   return 1;
 }
 
+static int gru_split_knob() {
+  static const int k = getenv("TG_GRU_SPLIT") ? atoi(getenv("TG_GRU_SPLIT")) : 0;  // tuning knob (0 = off, the default)
+  return k;
+}
 static bool carve_attn(const tg_model* m, int64_t Q, Carver& cv, AttnWs& w) {
   const int d = m->d, kvw = 2 * m->d + m->d_e, nh = m->n_head;
   w.cc = cv.take<float>((size_t)Q * d);
@@ -1279,10 +1283,15 @@ bool carve_step(const tg_model* m, int64_t B, Carver& cv, StepWs& w, int n_layer
     w.emb2 = cv.take<float>(Q2 * m->d);
     if (!carve_attn(m, (int64_t)Q2, cv, w.attn2)) return false;
   }
-  w.snap_te = cv.take<float>((size_t)2 * B * m->d);
-  w.oth = cv.take<int64_t>((size_t)2 * B);
-  w.weid = cv.take<int64_t>((size_t)2 * B);
-  w.gi = cv.take<float>((size_t)2 * B * 3 * m->d);
+  // the split updater's buffers (TG_GRU_SPLIT, off by default and measured not faster: DESIGN.md s0.1 of round 4) are carved
+  // - and the centres pass stores the 2B time-encoding rows into them - only when the knob is set (static per process, so a
+  // prefetched collate sees the same choice): 0.5 GB of workspace and 2B x d dead stores per step at C5 shape otherwise
+  if (gru_split_knob()) {
+    w.snap_te = cv.take<float>((size_t)2 * B * m->d);
+    w.oth = cv.take<int64_t>((size_t)2 * B);
+    w.weid = cv.take<int64_t>((size_t)2 * B);
+    w.gi = cv.take<float>((size_t)2 * B * 3 * m->d);
+  }
   return cv.ok;
 }
 // the carve above on a dry run: workspace size and the must-be-zero prefix without a second copy of the layout
@@ -1401,9 +1410,9 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   // 83.7-86.4 / 83.7-85.0 / 86.5-87.8 us per step on three boxes): a 48 x 48 x 688 tile costs its launch 11-14 us wherever
   // it rides (fc1 25.0 -> 39.5 us, fc2 13.0 -> 24.2 us by HIP events) against the 16.3 us the updater launch gives back,
   // and one fork / join inside the captured graph costs more than the product (tools/micro/fork_join.py).  Default 0.
-  static const int split_knob = getenv("TG_GRU_SPLIT") ? atoi(getenv("TG_GRU_SPLIT")) : 0;
+  const int split_knob = gru_split_knob();
   const float* tail_w = gru_tail_weights(m);
-  const bool split_ok = tail_w && m->upd_fn == TG_UPD_GRU && m->tsfm == TG_TSFM_ID && m->upd_src == TG_SRC_LEFT;
+  const bool split_ok = split_knob != 0 && tail_w && m->upd_fn == TG_UPD_GRU && m->tsfm == TG_TSFM_ID && m->upd_src == TG_SRC_LEFT;
   if (want_rider && split_ok) { pos.eids = w.eids; pos.oth = w.oth; pos.weid = w.weid; }
   const PosArgs* pp = (io->embed_only && !untouched) ? nullptr : &pos;
   w.gtab = form.gtab;
@@ -1444,7 +1453,7 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   if (prefetched) {
     // sampler, centres, first dedup pass and snapshot of this batch rode on the previous step's last launch
   } else if (recent_nodes || uniform) {  // query arrays first, then the sampler of graph.py:129-143 / :101-115 and the involved flags
-    if (lz || inner) return TG_EUNSUPPORTED;
+    if (lz || (inner && uniform)) return TG_EUNSUPPORTED;
     hipLaunchKernelGGL(k_build_queries, dim3(flat_grid(Q, 256)), dim3(256), 0, st, B, io->src, io->dst, io->neg, io->ts,
                        io->eids, (const int64_t*)io->offset_dev, w.nids3, w.ts3, w.ts3f, w.eids);
     // uniform: the graph's MT19937 stream is consumed per non-empty query, in query order (src, dst, neg of the batch, as
@@ -1466,8 +1475,9 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
     if (io->dbg_l1_ts && (e = hipMemcpyAsync(io->dbg_l1_ts, w.l1t, n * 4, hipMemcpyDeviceToDevice, st)) != hipSuccess) return TG_EHIP;
   }
   // second hop (data_loader.py:128-131): every neighbour slot (padding included) queried at its own float32 timestamp
-  if (inner && (rc = sample_edges_f32_launch(g, Q * K, w.l1n, w.l1t, (int32_t)K, w.h2n, w.h2e, w.h2t,
-                                             need_flags ? w.flags : nullptr, st)) != TG_OK)
+  // - with the graph's own strategy (recent_edges / recent_nodes; uniform's second hop stays on the operator path)
+  if (inner && (rc = (recent_nodes ? sample_nodes_f32_launch : sample_edges_f32_launch)(
+                    g, Q * K, w.l1n, w.l1t, (int32_t)K, w.h2n, w.h2e, w.h2t, need_flags ? w.flags : nullptr, st)) != TG_OK)
     return rc;
   // lazy restart (train_self_supervised.py:152-163): before STEP 1, because a restarted node loses its pending message
   const bool lz_tables = lz && w.gtab;  // the loop also keeps the per-node tables current (lists what it re-initialised)

@@ -12,9 +12,12 @@ namespace tg {
 
 // bounded wait for `flag >= epoch` (one lane).  The peer's kernel that raises the flag precedes, in that peer's stream,
 // every wait of that peer for this step, so the wait ends unless a peer died: then the timeout bit is raised and the step
-// goes on (wrong rows, no hang; the caller reads the error word)
-__device__ __forceinline__ bool wait_flag(const uint32_t* flag, uint32_t epoch) {
-  for (unsigned spin = 0; spin < (1u << 24); ++spin) {
+// goes on (wrong rows, no hang; the caller reads the error word).  The timeout is STICKY: a wait entered with the bit
+// already set does not spin at all, so a dead peer costs ONE bound per run - not two per remaining step -
+// and the host, which reads the word after every replay (dist.py), stops the run there.
+__device__ __forceinline__ bool wait_flag(const uint32_t* flag, uint32_t epoch, const uint32_t* err = nullptr) {
+  if (err && (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & TG_ERR_XCHG_TIMEOUT)) return false;
+  for (unsigned spin = 0; spin < (1u << 22); ++spin) {
     if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= epoch) return true;
     __builtin_amdgcn_s_sleep(8);
   }
@@ -30,12 +33,13 @@ __device__ __forceinline__ void wait_peers(const tg_part& p, int kind, uint32_t 
     if (bid == 0) {
       const uint32_t* mine = p.flags[p.rank] + (size_t)kind * TG_MAX_RANKS;
       bool ok = true;
-      for (int q = 0; q < p.world; ++q) ok = wait_flag(mine + q, epoch) && ok;
+      for (int q = 0; q < p.world; ++q) ok = wait_flag(mine + q, epoch, p.err) && ok;
       if (!ok) atomicOr(p.err, TG_ERR_XCHG_TIMEOUT);
       __hip_atomic_store(gate, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      for (unsigned spin = 0; spin < (1u << 26); ++spin) {  // (workgroup 0 gives up first and opens the gate anyway)
+      for (unsigned spin = 0; spin < (1u << 24); ++spin) {  // (workgroup 0 gives up first and opens the gate anyway)
         if (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch) break;
+        if ((spin & 1023u) == 1023u && (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & TG_ERR_XCHG_TIMEOUT)) break;
         __builtin_amdgcn_s_sleep(2);
       }
     }

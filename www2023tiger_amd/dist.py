@@ -909,10 +909,33 @@ class ResidentPartitionedStream:
         self.part_graph = None
         if exchange == 'ipc':
             try:
+                from ._lib import TG_MAX_RANKS
+                if world > TG_MAX_RANKS:  # (the flag block and tg_part's per-rank arrays hold TG_MAX_RANKS ranks; every rank sees the same world)
+                    raise WindowExchangeUnavailable(f'{world} ranks, the windows are laid out for at most {TG_MAX_RANKS}')
                 self._build_part(owner)
             except WindowExchangeUnavailable as e:  # raised on EVERY rank or on none: the collectives take over
                 self.part = None
                 self.exchange = f'rccl (window exchange unavailable: {e})'
+                self.close_windows()
+                self._tables = self._staging = None  # the all-steps tables of the window form are not needed by the collectives
+
+    def close_windows(self):
+        """unmap the peers' windows, then - once no peer can store into it any more - free this rank's own (nothing
+        did; on the fallback to the collectives the window and the mappings stayed allocated for the whole run)"""
+        from ._lib import lib
+        for p in getattr(self, '_imported', None) or []:
+            lib.tg_ipc_close(p)
+        self._imported = []
+        win = getattr(self, '_win', None)
+        if win:
+            if self.world > 1:
+                try:
+                    tdist.barrier(group=self.group)
+                except Exception:
+                    pass
+            lib.tg_xchg_free(win)
+            self._win = None
+        self.part = None
 
     # ---- the window form (tiger_hip.h: tg_part): plan tables over all steps, windows, one call per step
     def _build_part(self, owner):
@@ -1109,10 +1132,35 @@ class ResidentPartitionedStream:
         torch.cuda.synchronize()
         self.part_graph, self.part_gsteps = g, gsteps
 
+    def _poll_exchange_timeout(self, record: bool):
+        """The window exchange's waits are bounded and the timeout is sticky on the device (csrc/tg_part.h); the host looks
+        at the invariant word WITHOUT draining the queue: after a launch the word is copied to pinned memory behind it and
+        looked at before a later launch, when that copy has landed - a dead or stalled peer ends the run within a replay or
+        two (and one bounded wait), not after every remaining step has run into its bound on garbage rows."""
+        if self.model.device.type != 'cuda':
+            return
+        st = getattr(self, '_xt', None)
+        if st is None:
+            st = self._xt = dict(host=[torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)],
+                                 ev=[torch.cuda.Event() for _ in range(2)], n=0)
+        if torch.cuda.is_current_stream_capturing():
+            return
+        for j in range(min(st['n'], 2)):
+            if st['ev'][j].query() and (int(st['host'][j][0]) & 64):  # TG_ERR_XCHG_TIMEOUT
+                raise RuntimeError(f'rank {self.rank}: a peer\'s rows did not arrive within the exchange\'s bounded wait '
+                                   '(TG_ERR_XCHG_TIMEOUT): a peer died or stalled; state after that step is not valid')
+        if record:
+            j = st['n'] % 2
+            st['host'][j].copy_(self.engine.buf.err.view(torch.int32)[:1], non_blocking=True)
+            st['ev'][j].record()
+            st['n'] += 1
+
     def replay(self):
         """the next part_gsteps global batches (one graph replay)"""
         assert self.steps_done + self.part_gsteps <= self.n_steps, 'resident stream exhausted'
+        self._poll_exchange_timeout(False)
         self.part_graph.replay()
+        self._poll_exchange_timeout(True)
         self.steps_done += self.part_gsteps
         m = self.model
         m._touch()
@@ -1203,6 +1251,8 @@ class ResidentPartitionedStream:
         assert s < self.n_steps, 'resident stream exhausted'
         if self.part is not None:  # the window form: one library call
             self._launch_part()
+            if self.steps_done % 16 == 15:
+                self._poll_exchange_timeout(True)
             m = self.model
             m._touch()
             m._pending_stamp = m._state_stamp()

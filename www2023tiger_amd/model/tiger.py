@@ -580,11 +580,11 @@ class TIGE(nn.Module):
 
     def _fused_eval_ok(self, graph=None) -> bool:
         """does the one-call evaluation step (tg_train_step without gradient buffers) apply?  One or two layers; two
-        layers only with the default recent-edges strategy (the other strategies' second hop runs on the operator path)"""
+        layers with the recent-edges / recent-nodes strategies (uniform's second hop runs on the operator path)"""
         if self.hit_type == 'vec' and (2 * (self.nfeat_dim + self.n_neighbors)) % 4:
             return False  # the score head's pair rows must be float4-aligned
         strategy = getattr(graph if graph is not None else self.graph, 'strategy', 'recent_edges')
-        return self.n_layers == 1 or (self.n_layers == 2 and strategy == 'recent_edges')
+        return self.n_layers == 1 or (self.n_layers == 2 and strategy in ('recent_edges', 'recent_nodes'))
 
     def _contrast_learning_fused_eval(self, src_ids, dst_ids, neg_dst_ids, eids, computation_graph):
         """no_grad / eval(): collate, STEP 1-7 and the write-back as ONE device call (tg_train_step without
