@@ -855,6 +855,58 @@ def spawn_ranks(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+def restarter_roofline(stream, cfg, args, first_batch, n_batches, ms_per_step):
+    """--train --train-restarter seq: the SeqRestarter's kernels on their rooflines.  The dominant product - the Q / K projection
+    of the COMPACT history rows (csrc/tg_restart.hip: one row per real event, one per node for its padded slots, one shared
+    last row; K = d_e + d on a zero node-feature table) - priced with the rows of the timed batches counted from the
+    stream on the host and the rocprofv3 average of its launch from the committed profile of this command (a builder-run
+    measurement, named as such: the training step is not instrumented per kernel); the other restarter kernels with
+    their stored durations and matrix-pipe occupancy (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES) beside it."""
+    import csv
+    import glob
+    B, d, H = cfg['B'], cfg['d'], args.hist_len
+    dm, wx = 5 * d, 2 * d
+    src, dst = stream['src'], stream['dst']
+    rows = []
+    for b in np.linspace(first_batch, first_batch + n_batches - 1, 6).astype(int):
+        lo = int(b) * B
+        deg = np.bincount(np.concatenate([src[:lo], dst[:lo]]), minlength=stream['n_nodes'])  # events before the batch
+        pos = np.unique(np.concatenate([src[lo:lo + B], dst[lo:lo + B]]))
+        dv = deg[pos]
+        rows.append(1 + int(np.minimum(dv, H - 1).sum() + (dv < H - 1).sum()))
+    R = float(np.mean(rows))
+    out = dict(bound='mfma', kernel='q/k projection of the compact history rows (forward)', compact_rows_per_step=R,
+               slots_per_step=float(len(pos) * H), algorithmic_flops=2.0 * R * wx * 2 * dm,
+               note_rows='rows counted on the host from the stream (events before the batch as the history length); the slot '
+                         'grid of the reference is unique positive nodes x hist_len')
+    stats = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r05_train_c2_seq_kernel_stats_v*.csv')))
+    stats = [f for f in stats if 'before' not in f]
+    if stats:
+        per = {}
+        with open(stats[-1]) as f:
+            for r in csv.DictReader(f):
+                per[r['Name']] = (float(r['AverageNs']) * 1e-6, int(r['Calls']))
+        calls = max((c for n, (t, c) in per.items() if 'k_seq_build_c' in n), default=0)
+        qk = [(n, t) for n, (t, c) in per.items() if 'k_gemm_rb<2, 1>' in n]
+        if qk:
+            t = qk[0][1]
+            ach = out['algorithmic_flops'] / (t * 1e-3) / 1e12
+            out.update(device_kernel=norm_kernel(qk[0][0].split('(')[0].replace('void ', '')), avg_ms=t,
+                       timing='rocprofv3 --kernel-trace average, stored (' + os.path.relpath(stats[-1], ROOT) + ')',
+                       achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit='TFLOP/s', frac=ach / MFMA_F32_PEAK_TFLOPS)
+        out['restarter_kernels_ms_stored'] = {
+            norm_kernel(n.split('(')[0].replace('void ', '')): round(t * c / max(calls, 1), 5)
+            for n, (t, c) in per.items() if 'k_seq_' in n or 'k_gemm_tn_group' in n or 'k_gemm_rb<2, 1>' in n}
+        out['restarter_kernels_ms_stored_note'] = 'per training step (average x calls per step); k_gemm_tn_group includes the contrast half\'s group'
+    mf = os.path.join(ROOT, 'profiles', 'r05_pmc_mfma_train_seq.json')
+    if os.path.exists(mf):
+        j = json.load(open(mf))
+        out['mfma_busy_stored'] = {norm_kernel(k): v['mfma_busy_frac'] for k, v in j.items()
+                                   if any(x in k for x in ('k_seq_scores', 'k_gemm_rb<2, 1>', 'k_gemm_tn_group'))}
+    out['ms_per_step'] = ms_per_step
+    return out
+
+
 def train_main(args, cfg):
     """--train: the training iteration of train_self_supervised.py:143-171 (contrast loss only,
     restart_prob == 0) as tg_train_step + tg_adam_step on the resident stream.  Not the headline
@@ -911,7 +963,13 @@ def train_main(args, cfg):
     assert int(tr.buf.sb.offset.item()) == (args.warmup + args.steps) * B
     loss = float(tr.buf.losses[0])
     assert np.isfinite(loss)
-    print(json.dumps(dict(metric='training interaction-events/sec (collate + STEP 1-7 + backward + Adam)',
+    extra = {}
+    if rkind == 'seq':
+        try:
+            extra['roofline_restarter'] = restarter_roofline(stream, cfg, args, args.warmup, args.steps, dt / args.steps * 1e3)
+        except Exception as e:  # a side object: the line does not depend on it
+            extra['roofline_restarter'] = dict(error=repr(e))
+    print(json.dumps(dict(extra, metric='training interaction-events/sec (collate + STEP 1-7 + backward + Adam)',
                           value=args.steps * B / dt, unit='events/s', n_gpus=1, steps=args.steps, warmup=args.warmup,
                           ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='weak', vs_baseline=None,
                           dtype='f32', data='synthetic',

@@ -35,6 +35,21 @@ __device__ __forceinline__ void sts4(float* row, int k, float4 v) {
 
 // diagnostic only (TG_GEMM_DBG=16): per-block s_memtime stamps {entry, loop start, loop end, exit}
 __device__ unsigned long long g_gemm_trace[4096 * 4];
+// The stamps of the LDS-free kernels (k_gemm_ks16, k_gemm_direct, k_gru_direct16) are compiled in with -DTG_PHASE_TRACE only:
+// in the production build they cost k_gemm_direct<11, 2, 2> its second block per CU (188 -> 256 registers).
+#ifdef TG_PHASE_TRACE
+#define TG_PT(...) __VA_ARGS__
+#else
+#define TG_PT(...)
+#endif
+// TG_GEMM_DBG=16 stamps every product of a step into the same slots; TG_PHASE_NK=n,k keeps the stamps of the products with
+// that output width and inner length only (C2: fc1 172,1204; fc2 172,172; query rows 1032,172) - tools/phase_budget.py
+static bool phase_selected(const GemmArgs& g) {
+  static const char* sel = getenv("TG_PHASE_NK");
+  if (!sel) return true;
+  int n = 0, k = 0;
+  return sscanf(sel, "%d,%d", &n, &k) == 2 ? (g.n == n && g.k == k) : true;
+}
 
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16& acc, float bias, float bias2,
                                               int64_t m0, int64_t M, int n0, int wm, int wn, int fr, int fk, int bz);
@@ -893,6 +908,7 @@ __global__ void __launch_bounds__(256) k_gemm_astat_r(GemmArgs g, int cpb, R r) 
 // ReLU, scattered rows).
 template <int NS, int RW, int CW>
 __device__ __forceinline__ void gemm_direct_tile(const GemmArgs& g, int64_t M, int64_t m0, int n0) {
+  TG_PT(const unsigned long long pt_entry = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;)  // (diagnostic, as in gemm_ks16_tile)
   const int lane = threadIdx.x & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int K = g.k, N = g.n;
@@ -923,6 +939,7 @@ __device__ __forceinline__ void gemm_direct_tile(const GemmArgs& g, int64_t M, i
   for (int r = 0; r < RW; ++r)
 #pragma unroll
     for (int c = 0; c < CW; ++c) acc[r][c] = f32x4m{0.f, 0.f, 0.f, 0.f};
+  TG_PT(const unsigned long long pt_loop0 = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;)
 #pragma unroll
   for (int s_ = 0; s_ < NS; ++s_) {
     if (s_ == NS / 2) {
@@ -961,6 +978,10 @@ __device__ __forceinline__ void gemm_direct_tile(const GemmArgs& g, int64_t M, i
         for (int c = 0; c < CW; ++c)
           acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][j], wv[c][j], acc[r][c], 0, 0, 0);
   }
+  TG_PT(unsigned long long pt_loop1 = 0ull; if (g.dbg & 16) {
+    asm volatile("s_nop 0" ::"v"(acc[0][0][0]));
+    pt_loop1 = __builtin_amdgcn_s_memtime();
+  })
 #pragma unroll
   for (int r = 0; r < RW; ++r)
 #pragma unroll
@@ -977,6 +998,12 @@ __device__ __forceinline__ void gemm_direct_tile(const GemmArgs& g, int64_t M, i
         }
       }
     }
+  TG_PT(if ((g.dbg & 16) && threadIdx.x == 0 && blockIdx.x < 4096) {
+    g_gemm_trace[blockIdx.x * 4 + 0] = pt_entry;
+    g_gemm_trace[blockIdx.x * 4 + 1] = pt_loop0;
+    g_gemm_trace[blockIdx.x * 4 + 2] = pt_loop1;
+    g_gemm_trace[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
+  })
 }
 
 // block = 2 x 2 wavefronts of (16 RW) x (16 CW) wave tiles; `own` persistent blocks (riders, if any, sit behind them)
@@ -1215,6 +1242,9 @@ __global__ void __launch_bounds__(256) k_gemm_direct_r(GemmArgs g, R r) {
 template <int RT, int CT, int NW, int NSEG = 2>
 __device__ __forceinline__ void gemm_ks16_tile(const GemmArgs& g, int64_t M, int64_t m0, int n0, float* sc_raw) {
   constexpr int NS = RT * CT;  // 16 x 16 subtiles of the block
+  // diagnostic only (g.dbg & 16; tools/phase_budget.py): s_memtime stamps {entry, first tile requested, k-loop done, exit}
+  // of the block's first tile, wavefront 0
+  TG_PT(const unsigned long long pt_entry = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;)
   float (*sc)[NW - 1][NS][64] = reinterpret_cast<float (*)[NW - 1][NS][64]>(sc_raw);  // [owner 0..3][slot][subtile][lane]
   const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
@@ -1331,6 +1361,7 @@ __device__ __forceinline__ void gemm_ks16_tile(const GemmArgs& g, int64_t M, int
   tile_addr(0, A0);
 #pragma unroll
   for (int l = 0; l < NL; ++l) load_one(l, A0, T0);
+  TG_PT(const unsigned long long pt_loop0 = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;)
   int i = 0;
   for (; i + 2 <= n_my; i += 2) {
     tile_addr(i + 1, A1);
@@ -1343,6 +1374,10 @@ __device__ __forceinline__ void gemm_ks16_tile(const GemmArgs& g, int64_t M, int
     __builtin_amdgcn_sched_barrier(0);
   }
   if (i < n_my) mma_tile(T0, A0.live, A1, T1, false);
+  TG_PT(unsigned long long pt_loop1 = 0ull; if (g.dbg & 16) {  /* the stamp waits for the last MFMA */
+    asm volatile("s_nop 0" ::"v"(acc[0][0][0]));
+    pt_loop1 = __builtin_amdgcn_s_memtime();
+  })
   // reduce-scatter: wavefront v < 4 finishes accumulator register v of every subtile; everybody parks the registers the
   // others own (one round, one barrier); sums run in wavefront order 0 .. NW - 1
 #pragma unroll
@@ -1393,6 +1428,12 @@ __device__ __forceinline__ void gemm_ks16_tile(const GemmArgs& g, int64_t M, int
       if (n < N && m < M) g.c[m * g.ldc + n] = x;
     }
   }
+  TG_PT(if ((g.dbg & 16) && tid == 0 && blockIdx.x < 4096) {
+    g_gemm_trace[blockIdx.x * 4 + 0] = pt_entry;
+    g_gemm_trace[blockIdx.x * 4 + 1] = pt_loop0;
+    g_gemm_trace[blockIdx.x * 4 + 2] = pt_loop1;
+    g_gemm_trace[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
+  })
 }
 
 // persistent blocks of one product: block `bid` of `nblk` (a multiple of 8) works through its XCD's chunk of the tile sequence
@@ -1663,7 +1704,8 @@ bool gemm_ks16_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, b
   static const int64_t max_tiles = getenv("TG_GEMM_KS16_TILES") ? atoi(getenv("TG_GEMM_KS16_TILES")) : 1100;  // tuning knob (measured, K = 1 204, N = 172: 6 144 rows 54.5 -> 37.1 us, 12 288 rows 78.2 -> 72.1 us, 24 576 rows 123 -> 129 us)
   if (cdiv(g.m_cap, ct == 3 ? 48 : 32) * ntc > max_tiles) return false;
   GemmArgs gd = g;
-  gd.dbg = 0;
+  static const int gdbg16 = getenv("TG_GEMM_DBG") ? (atoi(getenv("TG_GEMM_DBG")) & 16) : 0;  // diagnostic: phase stamps
+  gd.dbg = (gdbg16 && phase_selected(g)) ? 16 : 0;
   const NoRider nr{0u};
   const NoSecond ns{0u};
   if (ct != 3) {
@@ -1882,7 +1924,7 @@ int gemm_launch(const GemmArgs& g, hipStream_t st, const WbRider* rider, bool* r
   const bool split = ks_knob ? ks_knob == 2 : (grid <= 256 && g.k >= 512);
   static const int gdbg = getenv("TG_GEMM_DBG") ? atoi(getenv("TG_GEMM_DBG")) : 0;
   GemmArgs gd = g;
-  gd.dbg = gdbg;
+  gd.dbg = phase_selected(g) ? gdbg : (gdbg & ~16);
   static const int depth_knob = getenv("TG_GEMM_DEPTH") ? atoi(getenv("TG_GEMM_DEPTH")) : 2;  // tuning knob: 2 / 4
   // a write-back rider that is not hosted: the caller runs the whole write-back itself, STEP 6's rows included - this
   // launch then stores no second copy of them
@@ -2865,6 +2907,7 @@ __global__ void __launch_bounds__(256) k_gru_direct(GruArgs g) {
 template <int RT>
 __device__ __forceinline__ void gru_direct16_body(const GruArgs& g, int64_t M, int64_t mt, int nt, float* sc_raw) {
   constexpr int KS = 4;
+  TG_PT(const unsigned long long pt_entry = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;)  // (diagnostic, as in gemm_ks16_tile)
   float (*sc)[KS - 1][4][RT][64] = reinterpret_cast<float (*)[KS - 1][4][RT][64]>(sc_raw);  // [owner][slot][plane][row tile]
   const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
@@ -2979,6 +3022,7 @@ __device__ __forceinline__ void gru_direct16_body(const GruArgs& g, int64_t M, i
     mma_tile(HPT{}, CUR, LCUR);                       \
     __builtin_amdgcn_sched_barrier(0);                \
   } while (0)
+  TG_PT(const unsigned long long pt_loop0 = (g.dbg & 16) ? __builtin_amdgcn_s_memtime() : 0ull;)
   int i = 0;
   for (; i + 2 <= nx; i += 2) {
     TG_STEP(HP0, T0, l0, T1, l1, i + 1);
@@ -2999,6 +3043,10 @@ __device__ __forceinline__ void gru_direct16_body(const GruArgs& g, int64_t M, i
     if (i < n_my) mma_tile(HP1{}, T0, l0);
   }
 #undef TG_STEP
+  TG_PT(unsigned long long pt_loop1 = 0ull; if (g.dbg & 16) {
+    asm volatile("s_nop 0" ::"v"(acc_r[0][0]));
+    pt_loop1 = __builtin_amdgcn_s_memtime();
+  })
   // reduce-scatter over the four wavefronts: wavefront v finishes accumulator register v of every row tile; the others'
   // registers are parked in LDS (one round, one barrier)
 #pragma unroll
@@ -3063,6 +3111,12 @@ __device__ __forceinline__ void gru_direct16_body(const GruArgs& g, int64_t M, i
       }
     }
   }
+  TG_PT(if ((g.dbg & 16) && tid == 0 && blockIdx.x < 2048) {
+    g_gru_trace[blockIdx.x * 4 + 0] = pt_entry;
+    g_gru_trace[blockIdx.x * 4 + 1] = pt_loop0;
+    g_gru_trace[blockIdx.x * 4 + 2] = pt_loop1;
+    g_gru_trace[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
+  })
 }
 
 constexpr int GRU16_RT_MAX = 6;
