@@ -396,6 +396,10 @@ typedef struct tg_seq_restarter {
    * (K = d_e + d instead of dm; csrc/tg_restart.hip).  0 is always correct. */
   int32_t nfeats_zero;
   int32_t reserved;
+  /* Optional (NULL = computed per call), with nfeats_zero: T_a = anony_emb in_proj_w[0:2dm, 2d:3d]^T ([hist_len + 1, 2 dm], no
+   * bias) precomputed by the caller for FIXED parameters (inference): one product less per restart.  The caller recomputes
+   * it whenever anony_emb or in_proj_w change; the training entry points ignore it. */
+  const float* ta_cached;
 } tg_seq_restarter;
 
 size_t tg_restart_seq_workspace_bytes(const tg_model* m, const tg_seq_restarter* r, int64_t n);
@@ -423,6 +427,11 @@ int tg_restart_seq_fwd_train(const tg_model* m, const tg_seq_restarter* r, int64
 size_t tg_restart_seq_list_workspace_bytes(const tg_model* m, const tg_seq_restarter* r, int64_t n);
 int tg_restart_seq_list(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, int64_t n, const int64_t* nids,
                         const float* t_dev, void* ws, size_t ws_bytes, void* stream);
+/* The same with the live count on the device: the launches are sized for `cap` entries, the first *n_dev (<= cap) are
+ * restarted; the entries behind them must hold valid node ids.  No host value depends on the count, so the call can be
+ * captured into a hipGraph and replayed for every batch whose count fits the capacity. */
+int tg_restart_seq_list_dev(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, int64_t cap, const int64_t* nids,
+                            const int32_t* n_dev, const float* t_dev, void* ws, size_t ws_bytes, void* stream);
 
 /* TIGER.restart's state update (tiger.py:603,608-609): clear has-message bits of
  * nids, then left/right memory rows and timestamps <- (h_left, h_right, prev_ts)

@@ -301,7 +301,7 @@ def test_resident_eval_raises_the_invariant_errors():
 
 
 @pytest.mark.parametrize('name', ['eval_seq_lr_d8', 'eval_static_ll_d16'])
-@pytest.mark.parametrize('stream', ['0', '1'], ids=['own_forms', 'eager_fused'])
+@pytest.mark.parametrize('stream', ['0', '1', '1g'], ids=['own_forms', 'eager_fused', 'eager_fused_restart_graph'])
 def test_resident_eval_in_restart_mode_equals_the_per_batch_loop(name, stream, monkeypatch):
     """restart_mode=True (the reference's default recipe: --restart_prob 0.01): the lazy restart of eval_utils.py:37-42
     with its bookkeeping on the device (involved & ~uptodate listed by a collate-only pass, ONE count read back per
@@ -315,6 +315,9 @@ def test_resident_eval_in_restart_mode_equals_the_per_batch_loop(name, stream, m
     n_warm, n = cfg['n_warm'], 5 * B + B // 2
     data = InteractionData(z['src'], z['dst'], z['ts'], z['eids'], np.zeros(len(z['src']), dtype=np.int64), seed=0, eval=True)
     mk = lambda lo, hi: BatchLoader(data.get_subset(lo, hi), B, coll)
+    if stream == '1g':  # the restarts of batches with few nodes as a replayed graph (device-side count; off by default)
+        monkeypatch.setenv('TG_EVAL_RESTART_GRAPH', '1')
+        stream = '1'
     monkeypatch.setenv('TG_EVAL_STREAM', stream)
     out = {}
     for form in ('0', '1'):

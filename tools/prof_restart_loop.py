@@ -16,7 +16,7 @@ from www2023tiger_amd.data.data_loader import BatchLoader, GraphCollator, Intera
 from www2023tiger_amd.eval_utils import eval_edge_prediction  # noqa: E402
 
 c = dict(bench.WORKLOADS['c2'])
-bs, nb = 200, 100
+bs, nb = 200, (int(sys.argv[1]) if len(sys.argv) > 1 else 100)
 n = nb * bs
 st = bench.make_stream(c['n_u'], c['n_i'], max(c['E'], n), c['T'], seed=0, d_e=c['d'])
 model, _ = bench.build_models(st, c['d'], c['K'], c['msg_src'], c['upd_src'], restarter='seq', hist_len=40, dropout=0.1)

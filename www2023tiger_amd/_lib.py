@@ -59,7 +59,7 @@ class TgSeqRestarter(C.Structure):
     _fields_ = [
         ('hist_len', i32), ('n_head', i32), ('te_freq', vp), ('te_phase', vp), ('anony_emb', vp),
         ('in_proj_w', vp), ('in_proj_b', vp), ('out_proj', TgLinear), ('out_fn', TgLinear),
-        ('fc1', TgLinear), ('fc2', TgLinear), ('nfeats_zero', i32), ('reserved', i32),
+        ('fc1', TgLinear), ('fc2', TgLinear), ('nfeats_zero', i32), ('reserved', i32), ('ta_cached', vp),
     ]
 
 
@@ -176,6 +176,7 @@ SIGNATURES = {
     'tg_restart_apply': (C.c_int, [P(TgModel), i64, vp, vp, vp, vp, vp]),
     'tg_restart_seq_list_workspace_bytes': (sz, [P(TgModel), P(TgSeqRestarter), i64]),
     'tg_restart_seq_list': (C.c_int, [P(TgModel), P(TgTcsr), P(TgSeqRestarter), i64, vp, vp, vp, sz, vp]),
+    'tg_restart_seq_list_dev': (C.c_int, [P(TgModel), P(TgTcsr), P(TgSeqRestarter), i64, vp, vp, vp, vp, sz, vp]),
     'tg_profiler_create': (vp, []),
     'tg_profiler_destroy': (None, [vp]),
     'tg_profiler_num_stages': (C.c_int, []),

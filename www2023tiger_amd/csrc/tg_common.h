@@ -277,6 +277,9 @@ int sample_batch_launch(const tg_tcsr* g, int64_t B, const int64_t* src, const i
                         hipStream_t st, uint32_t* tmin_key = nullptr, const CentresRider* rider = nullptr);
 // recent-edges sampler over float32 query times (the second hop of --n_layers 2 is sampled at the neighbours' own
 // float32 timestamps, data_loader.py:131); marks the sampled ids in `mark` when given
+// tg_restart_apply on the first *n_dev (nullable: all n) entries of the list (tg_memory.hip)
+int restart_apply_dev(const tg_model* m, int64_t n, const int64_t* nids, const float* h_left, const float* h_right,
+                      const float* prev_ts, const int32_t* n_dev, hipStream_t st);
 int sample_edges_f32_launch(const tg_tcsr* g, int64_t Q, const int64_t* nids, const float* ts, int32_t K, int64_t* o_nbr,
                             int64_t* o_eid, float* o_ts, uint8_t* mark, hipStream_t st);
 int sample_nodes_f32_launch(const tg_tcsr* g, int64_t Q, const int64_t* nids, const float* ts, int32_t K, int64_t* o_nbr,

@@ -267,7 +267,8 @@ int writeback_launch(const tg_model* m, const WritebackArgs& a, int phase, hipSt
 // TIGER.restart state update (tiger.py:603,608-609)
 __global__ void k_restart_apply(tg_model m, int64_t n, const int64_t* __restrict__ nids,
                                 const float4* __restrict__ hl, const float4* __restrict__ hr,
-                                const float* __restrict__ pt) {
+                                const float* __restrict__ pt, const int32_t* __restrict__ n_dev) {
+  if (n_dev) n = min(n, (int64_t)*n_dev);  // (a capacity-sized launch inside a captured graph: the live count is on the device)
   const int w4 = m.d / 4;
   const int64_t total = n * w4;
   float4* left = reinterpret_cast<float4*>(m.left_vals);
@@ -496,7 +497,11 @@ extern "C" int tg_restart_apply(const tg_model* m, int64_t n, const int64_t* nid
   if (!model_ok(m) || n < 0) return TG_EINVAL;
   if (n == 0) return TG_OK;
   if (!nids || !h_left || !h_right || !prev_ts) return TG_EINVAL;
-  TG_KLAUNCH(k_restart_apply, dim3(flat_grid(n * (m->d / 4), 256)), dim3(256), 0, as_stream(stream), *m, n, nids,
-                     (const float4*)h_left, (const float4*)h_right, prev_ts);
+  return tg::restart_apply_dev(m, n, nids, h_left, h_right, prev_ts, nullptr, as_stream(stream));
+}
+int tg::restart_apply_dev(const tg_model* m, int64_t n, const int64_t* nids, const float* h_left, const float* h_right,
+                          const float* prev_ts, const int32_t* n_dev, hipStream_t st) {
+  TG_KLAUNCH(k_restart_apply, dim3(flat_grid(n * (m->d / 4), 256)), dim3(256), 0, st, *m, n, nids, (const float4*)h_left,
+             (const float4*)h_right, prev_ts, n_dev);
   return check_launch("tg_restart_apply");
 }

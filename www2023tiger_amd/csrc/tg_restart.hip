@@ -971,7 +971,10 @@ static int seq_forward(const tg_model* m, const tg_seq_restarter* r, int64_t n, 
   GemmArgs g{};
   const int off = w.wide ? 0 : 2 * d;   // first column of the value operand that can be non-zero
   const int col0 = w.wide ? 0 : 3 * d;  // first column of the compact operand
-  if (!w.wide) {  // T_a = anony_emb Wqk[:, 2d:3d]^T (no bias: it rides on the compact product)
+  const float* ta = w.ta;
+  if (!w.wide && r->ta_cached && dc.p <= 0.f && !w.rbar) {
+    ta = r->ta_cached;  // inference with fixed parameters: the caller's table (tg_seq_restarter.ta_cached)
+  } else if (!w.wide) {  // T_a = anony_emb Wqk[:, 2d:3d]^T (no bias: it rides on the compact product)
     g.m_cap = H + 1; g.n = 2 * dm; g.k = d; g.a0 = ASeg{r->anony_emb, d, d, nullptr};
     g.w = r->in_proj_w + 2 * d; g.ldw = dm; g.c = w.ta; g.ldc = 2 * dm; g.alpha = 1.f; g.nbatch = 1;
     if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
@@ -981,7 +984,7 @@ static int seq_forward(const tg_model* m, const tg_seq_restarter* r, int64_t n, 
   g.m_cap = w.rowcap; g.m_dev = w.rows; g.n = 2 * dm; g.k = w.wx; g.a0 = ASeg{w.xc, w.wx, w.wx, nullptr};
   g.w = r->in_proj_w + col0; g.ldw = dm; g.bias = r->in_proj_b; g.c = w.qk; g.ldc = 2 * dm; g.alpha = 1.f; g.nbatch = 1;
   if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
-  const SeqRows sr{w.qk, w.slot_row, w.row_slot, w.row_anon, w.base, w.ta, anon};
+  const SeqRows sr{w.qk, w.slot_row, w.row_slot, w.row_anon, w.base, ta, anon};
   if ((rc = seq_lds_attr()) != TG_OK) return rc;
 #define TG_SEQ_SCORES(HP_, V2_, MIN_)                                                                               \
   hipLaunchKernelGGL((k_seq_scores<HP_, V2_>), dim3((unsigned)(n * nh)), dim3(256), sizeof(SeqLds<HP_>), st, n, H, dm, nh, \
@@ -1412,6 +1415,12 @@ extern "C" size_t tg_restart_seq_list_workspace_bytes(const tg_model* m, const t
 
 extern "C" int tg_restart_seq_list(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, int64_t n,
                                    const int64_t* nids, const float* t_dev, void* ws, size_t ws_bytes, void* stream) {
+  return tg_restart_seq_list_dev(m, g, r, n, nids, nullptr, t_dev, ws, ws_bytes, stream);
+}
+
+extern "C" int tg_restart_seq_list_dev(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, int64_t n,
+                                       const int64_t* nids, const int32_t* n_dev, const float* t_dev, void* ws,
+                                       size_t ws_bytes, void* stream) {
   if (m && m->row_of) return TG_EUNSUPPORTED;  // state addressed by node id: not on physically partitioned tables (tg_model.row_of)
   if (!seq_ok(m, r) || !g || n < 0) return TG_EINVAL;
   if (r->hist_len > 128) return TG_EUNSUPPORTED;
@@ -1426,9 +1435,11 @@ extern "C" int tg_restart_seq_list(const tg_model* m, const tg_tcsr* g, const tg
   hipLaunchKernelGGL(k_restart_times, dim3(flat_grid(n, 256)), dim3(256), 0, st, n, t_dev, w.tu);
   if ((rc = tg_sample_recent_edges(g, n, nids, w.tu, H, w.h_n, w.h_e, w.h_t, w.h_d, nullptr, stream)) != TG_OK) return rc;
   if ((rc = tg_anonymized_reindex(n, H, w.h_n, w.anon, stream)) != TG_OK) return rc;
-  if ((rc = seq_forward(m, r, n, nullptr, nids, w.h_n, w.anon, w.h_e, w.h_t, w.h_d, w.hl, w.hr, w.pt, w.seq, st)) != TG_OK)
+  // n_dev: the launches are sized for n (a capacity), the first *n_dev entries of the list are live - the entries behind them
+  // must be valid node ids (their histories are sampled and thrown away); nothing is written for them
+  if ((rc = seq_forward(m, r, n, n_dev, nids, w.h_n, w.anon, w.h_e, w.h_t, w.h_d, w.hl, w.hr, w.pt, w.seq, st)) != TG_OK)
     return rc;
-  return tg_restart_apply(m, n, nids, w.hl, w.hr, w.pt, stream);
+  return restart_apply_dev(m, n, nids, w.hl, w.hr, w.pt, n_dev, st);
 }
 
 namespace tg {

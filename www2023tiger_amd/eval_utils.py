@@ -146,6 +146,17 @@ class _RestartPipeline:
         self.offsets = first + torch.arange(count, dtype=torch.int64, device=model.device) * sb.B
         self.host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
         self.ev = [torch.cuda.Event() for _ in range(2)]
+        # TG_EVAL_RESTART_GRAPH=1 (off by default): batches whose count fits the capacity replay ONE captured graph per context
+        # instead of the eager library calls - the restart with the live count on the device (TIGE.restart_list_captured) -
+        # once an eager restart has run (first-use initialisations stay out of a capture).  Measured (C2 shapes, bs 200): no
+        # gain - 0.256 against 0.252 ms per batch over 500 batches, and two captures cost a 100-batch pass 5 ms: the pass is
+        # bound by the DEVICE time of ~38 short kernels per batch (0.26 ms summed), not by their launches.
+        from .model.restarters import SeqRestarter
+        self.graph_cap = 256 if (os.environ.get('TG_EVAL_RESTART_GRAPH', '0') != '0'
+                                 and isinstance(model.restarter_fn, SeqRestarter) and not model.restarter_fn.training
+                                 and model.restarter_fn.graph.strategy == 'recent_edges') else 0
+        self.graphs = [None, None]
+        self.eager_done = False
         self._pass(0)
 
     def _pass(self, k):
@@ -170,10 +181,34 @@ class _RestartPipeline:
             cb = self.ctx[k % 2]
             current = (model._pending is not None and model._pending_stamp == model._state_stamp()
                        and (getattr(model, '_gtab', None) is None or getattr(model, '_gtab_stamp', None) is not None))
-            model.restart_list(cb.lazy_list[:n], cb.lazy_tmin)
-            if current:
-                model._tables_follow_restart(cb.lazy_list[:n])
+            cap = min(self.graph_cap, cb.lazy_list.numel())
+            if cap and n <= cap and self.eager_done:
+                g = self.graphs[k % 2]
+                if g is None:
+                    g = self.graphs[k % 2] = self._capture(cb, cap)
+                model._touch()
+                g.replay()
+                if current:  # what _tables_follow_restart records on the host
+                    if getattr(model, '_gtab', None) is not None:
+                        model._gtab_stamp = (model._state_stamp(), tuple(model._attn_stamp()), id(model._fused))
+                    model._pending_stamp = model._state_stamp()
+            else:
+                model.restart_list(cb.lazy_list[:n], cb.lazy_tmin)
+                if current:
+                    model._tables_follow_restart(cb.lazy_list[:n])
+                self.eager_done = True
         return n
+
+    def _capture(self, cb, cap):
+        model = self.model
+        _ = model.model_struct(), model.restarter_fn._struct()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=model.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
+            model.restart_list_captured(cb.lazy_list[:cap], cb.counts[3:4], cb.lazy_tmin)
+        torch.cuda.synchronize()
+        return g
 
 
 def _eval_resident_run(model, ds, bs, dev, N, lo, hi, graph, TrainBuffers, lean, restart_mode=False, uptodate_nodes=None):

@@ -48,7 +48,27 @@ class SeqRestarter(Restarter):
                               ptr(self.time_encoder.phase), ptr(self.anony_emb.weight),
                               ptr(self.mha_fn.in_proj_weight), ptr(self.mha_fn.in_proj_bias),
                               lin(self.mha_fn.out_proj), lin(self.out_fn), lin(self.merger.fc1), lin(self.merger.fc2),
-                              1 if self.raw_feat_getter.nfeats_all_zero() else 0, 0)
+                              1 if self.raw_feat_getter.nfeats_all_zero() else 0, 0, ptr(self._ta_table()))
+
+    def _ta_table(self):
+        """Inference with fixed parameters on a zero node-feature table: the anony_emb block of the Q / K projection as a table
+        T_a = anony_emb W[0:2dm, 2d:3d]^T (tg_seq_restarter.ta_cached), recomputed when either parameter changes (torch's
+        version counters: any in-place update bumps them).  None in train() mode and with a non-zero node-feature table."""
+        w, e = self.mha_fn.in_proj_weight, self.anony_emb.weight
+        if self.training or torch.is_grad_enabled() or not w.is_cuda or not self.raw_feat_getter.nfeats_all_zero():
+            return None
+        key = (w.data_ptr(), w._version, e.data_ptr(), e._version)
+        hit = getattr(self, '_ta_cache', None)
+        if hit is None or hit[0] != key:
+            d, dm = self.nfeat_dim, self.d_model
+            from .dense import linear_forward
+            lin = nn.Linear(d, 2 * dm, bias=True, device=w.device)
+            with torch.no_grad():
+                lin.weight.copy_(w[:2 * dm, 2 * d:3 * d])
+                lin.bias.zero_()
+                ta = linear_forward(lin, e.detach())
+            hit = self._ta_cache = (key, ta.contiguous())
+        return hit[1]
 
     def forward(self, nids: Tensor, ts: Tensor, computation_graph=None) -> Tuple[Tensor, Tensor, Tensor]:
         """restarters.py:51-114: surrogate h(t'-), h(t'+) and t' from the last hist_len events."""

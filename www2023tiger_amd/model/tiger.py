@@ -153,6 +153,25 @@ class TIGE(nn.Module):
         check(lib.tg_restart_seq_list(C.byref(m), C.byref(r.graph.tcsr), C.byref(rs), n, ptr(nids), ptr(t_dev), ptr(ws),
                                       ws.numel(), stream_ptr(self.device)), 'tg_restart_seq_list')
 
+    def restart_list_captured(self, nids_cap: Tensor, n_dev: Tensor, t_dev: Tensor):
+        """The device half of `restart_list` + `_tables_follow_restart` with the live count ON THE DEVICE (n_dev, int32): launches
+        sized for the capacity len(nids_cap), the first n_dev entries restarted (tg_restart_seq_list_dev, tg_attn_gtab_rows with
+        its device count).  No host value depends on the count: callable under stream capture; the caller replays the graph
+        for every batch whose count fits and does the host-side bookkeeping itself (eval_utils._RestartPipeline)."""
+        r = self.restarter_fn
+        cap = int(nids_cap.numel())
+        m, rs = self.model_struct(), r._struct()
+        nbytes = int(lib.tg_restart_seq_list_workspace_bytes(C.byref(m), C.byref(rs), cap))
+        ws = getattr(self, '_restart_cap_ws', None)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._restart_cap_ws = torch.empty(nbytes + 1024, dtype=torch.uint8, device=self.device)
+        check(lib.tg_restart_seq_list_dev(C.byref(m), C.byref(r.graph.tcsr), C.byref(rs), cap, ptr(nids_cap), ptr(n_dev),
+                                          ptr(t_dev), ptr(ws), ws.numel(), stream_ptr(self.device)), 'tg_restart_seq_list_dev')
+        if self._pending is not None and getattr(self, '_gtab', None) is not None:
+            ws2 = self._ws('gtab_rc', cap * (4 * self.memory_dim + 4) + 64)
+            check(lib.tg_attn_gtab_rows(C.byref(m), cap, ptr(nids_cap), ptr(n_dev), ptr(ws2), ws2.numel(),
+                                        stream_ptr(self.device)), 'tg_attn_gtab_rows(restart, captured)')
+
     @property
     def graph(self):
         return self.temporal_embedding_fn.graph
