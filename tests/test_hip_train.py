@@ -482,3 +482,55 @@ def test_long_history_restarter_forward_and_gradients(name, H):
         assert abs(float(tb.losses[1]) - ml) < TOL * max(1.0, abs(ml)), (b, float(tb.losses[1]), ml)
         for k, gv in tb.grads.items():
             assert grad_err(gv.cpu().numpy(), grads[k].numpy()) < 2e-4, (b, k)
+
+
+@pytest.mark.parametrize('name,H', [('train_seq_lr_d8_zeronf', 1), ('train_seq_lr_d8_zeronf', 2), ('train_seq_lr_d8', 1), ('train_seq_lr_d8', 5)])
+def test_restarter_forward_on_empty_and_minimal_histories(name, H):
+    """Edge cases of the compact-row restarter (csrc/tg_restart.hip): hist_len 1 (only the shared last row exists), 2 and 5;
+    every node restarted at time 0 (no history at all: every slot padded, the last one included), at a mid-stream time and
+    at the end; a single-node call; both operand forms - against the oracle."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    from _weights import golden_param
+    from oracle import tiger_oracle as O
+    from _util import fixture_tables
+    from www2023tiger_amd.data.graph import Graph
+    from www2023tiger_amd.model.feature_getter import NumericalFeature
+    from www2023tiger_amd.model.restarters import SeqRestarter
+    from www2023tiger_amd.model.tiger import TIGER
+    z = load(name)
+    cfg = parse_cfg(z)
+    n_nodes, nfeats, efeats = fixture_tables(z, cfg)
+    g = Graph.from_arrays(z['src'], z['dst'], z['ts'], z['eids'], strategy='recent_edges', seed=0, device=dev())
+    fg = NumericalFeature(None if nfeats is None else torch.from_numpy(nfeats), torch.from_numpy(efeats), dim=cfg['d'], device=dev())
+    fg.n_nodes, fg.n_edges = n_nodes, len(z['src'])
+    rst = SeqRestarter(raw_feat_getter=fg, graph=g, hist_len=H, n_head=2, dropout=0.0)
+    model = TIGER(raw_feat_getter=fg, graph=g, restarter=rst, n_neighbors=cfg['K'], hit_type=cfg.get('hit', 'bin'), n_layers=1,
+                  n_head=2, dropout=0.0, msg_src=cfg['msg_src'], upd_src=cfg['upd_src'])
+    params = {k: golden_param(k, tuple(v.shape), cfg['wseed']) for k, v in model.named_parameters()}
+    with torch.no_grad():
+        for k, v in model.named_parameters():
+            v.copy_(torch.from_numpy(params[k]))
+    model = model.to(dev()).eval()
+    og = O.OracleGraph(z['src'], z['dst'], z['ts'], z['eids'], strategy='recent_edges', seed=0)
+    orc = O.OracleTIGER(params, og, n_nodes=n_nodes, dim=cfg['d'], nfeats=nfeats, efeats=efeats, n_neighbors=cfg['K'],
+                        msg_src=cfg['msg_src'], upd_src=cfg['upd_src'], restarter='seq', hist_len=H, hit_type=cfg.get('hit', 'bin'))
+    tmax = float(np.float32(z['ts'].max()))
+    for nids, t in ((np.arange(n_nodes, dtype=np.int64), 0.0), (np.arange(1, n_nodes, dtype=np.int64), 0.5 * tmax),
+                    (np.arange(1, n_nodes, dtype=np.int64), tmax + 1.0), (np.array([int(z['dst'][0])], dtype=np.int64), tmax + 1.0)):
+        ts = np.full(len(nids), np.float32(t), dtype=np.float32)
+        with torch.no_grad():
+            hl, hr, pt = model.restarter_fn(torch.from_numpy(nids).to(dev()), torch.from_numpy(ts).to(dev()))
+        rl, rr, rp = orc.restarter_forward(nids, ts)
+        assert rel_err(hl.cpu().numpy(), rl.detach().numpy()) < TOL, (H, t)
+        assert rel_err(hr.cpu().numpy(), rr.detach().numpy()) < TOL, (H, t)
+        np.testing.assert_array_equal(pt.cpu().numpy(), rp.numpy())
+        # the list form (one library call, device-resident time) leaves the same memories as restart()
+        ref_model_left = model.left_memory.vals.clone()
+        model.restart(torch.from_numpy(nids).to(dev()), torch.from_numpy(ts).to(dev()))
+        a = (model.left_memory.vals.clone(), model.right_memory.vals.clone(), model.left_memory.update_ts.clone())
+        model.left_memory.vals.copy_(ref_model_left)
+        model.restart_list(torch.from_numpy(nids).to(dev()), torch.tensor([t], dtype=torch.float32, device=dev()))
+        assert torch.equal(a[0], model.left_memory.vals) and torch.equal(a[1], model.right_memory.vals)
+        assert torch.equal(a[2], model.left_memory.update_ts)
