@@ -320,6 +320,62 @@ def test_sharded_equals_single_gpu(tmp_path, name):
         assert rel_err(got['msg'][has], model.msg_store.node_msg_vals.cpu().numpy()[has]) < 1e-6
 
 
+def _gpu_period_worker(rank, world, port, name, Bg, n_batches, period, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    tdist.init_process_group('gloo', rank=rank, world_size=world)
+    from test_hip_parity import build_hip_model
+    from www2023tiger_amd.dist import HipBackend, PeriodicShardedRunner, balanced_owner_table
+    z = load(name)
+    cfg = parse_cfg(z)
+    model, _, _ = build_hip_model(z, cfg)
+    owner = balanced_owner_table(int(z['n_nodes']), z['dst'], world)
+    backend = HipBackend(model, cap=Bg)
+    runner = PeriodicShardedRunner(backend, owner, rank, world, cap=Bg, period=period)
+    for b in range(n_batches):
+        sl = slice(b * Bg, (b + 1) * Bg)
+        runner.step(*(z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')))
+    runner.flush()
+    backend.check_invariants()
+    np.savez(os.path.join(out_dir, f'rank{rank}.npz'), left=model.left_memory.vals.cpu().numpy(),
+             right=model.right_memory.vals.cpu().numpy(), left_ts=model.left_memory.update_ts.cpu().numpy(),
+             right_ts=model.right_memory.update_ts.cpu().numpy(), msg=model.msg_store.node_msg_vals.cpu().numpy(),
+             msg_ts=model.msg_store.node_msg_ts.cpu().numpy(),
+             has=np.array(sorted(model.msg_store.nodes_with_messages), dtype=np.int64))
+    tdist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('period', [1, 3])
+def test_exchange_period_on_the_hip_engine(tmp_path, period):
+    """PeriodicShardedRunner over the HIP backend (two processes sharing the test box's GPU, gloo): period 1 equals the
+    single-GPU engine (times and sets exactly, float rows to 1e-6: the shard's products are the global batch's on fewer rows);
+    period 3: the replicas agree with each other exactly after the closing exchange, times / has-message set equal the exact
+    engine's."""
+    from test_hip_parity import build_hip_model
+    name, Bg, n_batches, world = 'static_ll_d16', 100, 6, 2
+    mp.spawn(_gpu_period_worker, args=(world, free_port(), name, Bg, n_batches, period, str(tmp_path)), nprocs=world, join=True)
+    z = load(name)
+    cfg = parse_cfg(z)
+    model, _, _ = build_hip_model(z, cfg)
+    for b in range(n_batches):
+        sl = slice(b * Bg, (b + 1) * Bg)
+        model.stream_step(*(z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')))
+    has = np.array(sorted(model.msg_store.nodes_with_messages), dtype=np.int64)
+    got = [np.load(os.path.join(str(tmp_path), f'rank{r}.npz')) for r in range(world)]
+    for k in ('left', 'right', 'left_ts', 'right_ts', 'msg_ts', 'has'):
+        np.testing.assert_array_equal(got[0][k], got[1][k], err_msg=k)
+    np.testing.assert_array_equal(got[0]['msg'][has], got[1]['msg'][has])
+    np.testing.assert_array_equal(got[0]['left_ts'], model.left_memory.update_ts.cpu().numpy())
+    np.testing.assert_array_equal(got[0]['has'], has)
+    np.testing.assert_array_equal(got[0]['msg_ts'], model.msg_store.node_msg_ts.cpu().numpy())
+    if period == 1:
+        assert rel_err(got[0]['left'], model.left_memory.vals.cpu().numpy()) < 1e-6
+        assert rel_err(got[0]['right'], model.right_memory.vals.cpu().numpy()) < 1e-6
+        assert rel_err(got[0]['msg'][has], model.msg_store.node_msg_vals.cpu().numpy()[has]) < 1e-6
+
+
 def _gpu_resident_worker(rank, world, port, name, B, n_steps, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
