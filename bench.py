@@ -1013,6 +1013,9 @@ def main():
                          'exported windows (one node; graphs of several steps); rccl = eager launches around two all_to_all_single')
     ap.add_argument('--dist-mode', default='partitioned', choices=['partitioned', 'replicated'],
                     help='multi-GPU state layout (www2023tiger_amd/dist.py)')
+    ap.add_argument('--dist-owner', default='balanced', choices=['balanced', 'hash'],
+                    help='owner table of the multi-GPU shards: balanced from the stream\'s destination histogram (default), or a '
+                         'plain hash of the node id (no knowledge of the stream; the imbalance is reported)')
     ap.add_argument('--dist-full-tables', action='store_true',
                     help='multi-GPU, partitioned layout: every rank allocates full-height state tables (global row addressing) '
                          'instead of its own rows + an arena (tg_model.row_of)')

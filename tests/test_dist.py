@@ -89,6 +89,24 @@ def test_plan_row_maps_of_the_bench_layout_at_eight_ranks():
 
 
 # ------------------------------------------------------------------------------ oracle backend (CPU)
+def test_hash_owner_table_needs_no_stream_and_spreads_the_ids():
+    """the literal "destination-node hash": a function of (node id, world) only; ids spread evenly, a plan over it shards a
+    batch by owner(dst) like the balanced table does"""
+    from www2023tiger_amd.dist import ShardPlan, hash_owner_table
+    for world in (2, 3, 8):
+        o = hash_owner_table(9228, world)
+        assert o.min() == 0 and o.max() == world - 1
+        cnt = np.bincount(o, minlength=world)
+        assert cnt.max() - cnt.min() <= 0.02 * cnt.mean() + 8
+        np.testing.assert_array_equal(o, hash_owner_table(9228, world))  # deterministic
+        np.testing.assert_array_equal(o[:5000], hash_owner_table(5000, world))  # a node's owner does not depend on n_nodes
+    rs = np.random.RandomState(0)
+    dst = rs.randint(8228, 9228, 256)
+    o = hash_owner_table(9228, 4)
+    p = ShardPlan(dst, o, 4, 256)
+    np.testing.assert_array_equal(p.rank_of, o[dst])
+
+
 class OracleBackend:
     """Splits OracleTIGER.contrast_learning (tiger.py:196-255) into the two halves the
     runner needs.  Test-only: uses oracle/ as the compute."""

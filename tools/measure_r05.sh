@@ -43,4 +43,20 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output
 cp $(find $O/pmc_m_seq -name '*counter_collection.csv' | head -1) $O/r05_pmc_mfma_train_seq_$TAG.csv 2>/dev/null || true
 rm -rf $O/prof_seq $O/pmc_m_seq
 fi
+if [[ $PART == *d* ]]; then
+# kernel statistics of the configurations that had none: C3 as written, C4, the evaluation harness in
+# restart mode (seq restarter), and the 2-rank rehearsal with the plain hash owner table
+P="--no-cpu-baseline --no-self-check --repeats 0"
+for W in c3 c4; do
+  rocprofv3 --kernel-trace --stats -d $O/prof_$W -o $W -- python $R/bench.py --workload $W --steps 50 --warmup 10 $P > $O/prof_$W.log 2>&1
+  python $R/tools/rocpd_stats.py $(find $O/prof_$W -name '*.db' | head -1) $O/r05_bench_${W}_kernel_stats_$TAG.csv > /dev/null && echo stats $W ok
+  rm -rf $O/prof_$W
+done
+TG_EVAL_RESTART_GRAPH=0 rocprofv3 --kernel-trace --stats -d $O/prof_ev -o ev -- python $R/tools/prof_restart_loop.py 200 > $O/prof_ev.log 2>&1
+python $R/tools/rocpd_stats.py $(find $O/prof_ev -name '*.db' | head -1) $O/r05_eval_restart_seq_bs200_kernel_stats_$TAG.csv > /dev/null && echo stats eval ok
+rm -rf $O/prof_ev
+cd $R
+TG_BENCH_REHEARSAL=1 python bench.py --gpus 2 --steps 20 --warmup 5 --preroll 40 --no-cpu-baseline > $O/r05_rehearsal_2ranks_one_gpu_windows_$TAG.json 2>> $O/err.log
+TG_BENCH_REHEARSAL=1 python bench.py --gpus 2 --steps 20 --warmup 5 --preroll 40 --no-cpu-baseline --dist-owner hash > $O/r05_rehearsal_2ranks_one_gpu_hash_owner_$TAG.json 2>> $O/err.log && echo rehearsal ok
+fi
 echo done

@@ -64,6 +64,16 @@ def balanced_owner_table(n_nodes: int, dst: np.ndarray, world: int, exact: int =
     return owner
 
 
+def hash_owner_table(n_nodes: int, world: int) -> np.ndarray:
+    """owner[node] = hash(node) mod world with a fixed multiplicative hash: `north_star`'s "destination-node hash" literally.
+    Needs no knowledge of the stream (balanced_owner_table wants the whole stream's destination histogram up front - fine
+    for a resident benchmark stream, not for an online one); the load per rank then is whatever the popular destinations
+    that collide add up to - the benchmark measures and reports it (config.owner_load_imbalance, spilled_event_fraction)."""
+    ids = np.arange(n_nodes, dtype=np.uint64)
+    h = (ids * np.uint64(11400714819323198485)) >> np.uint64(40)
+    return (h % np.uint64(world)).astype(np.int64)
+
+
 class ShardPlan:
     """Where every event of one global batch is embedded and where its rows land in the
     gathered buffer.  Rank r's send buffer holds `rows_per_rank` rows; the h(t-) row of
@@ -1356,7 +1366,9 @@ def run_dist_leg(args, cfg, make_stream, build_models, rank, local_rank, world, 
     stream = make_stream(cfg['n_u'], cfg['n_i'], E, cfg['T'] * E / cfg['E'], seed=0, d_e=d,
                          integer_ts=cfg.get('integer_ts', True), with_efeats=not no_feats,
                          **({'counter': True} if cfg.get('counter_stream') else {}))  # identical on every rank
-    owner = balanced_owner_table(stream['n_nodes'], stream['dst'], world)
+    owner_kind = getattr(args, 'dist_owner', 'balanced')
+    owner = (hash_owner_table(stream['n_nodes'], world) if owner_kind == 'hash'
+             else balanced_owner_table(stream['n_nodes'], stream['dst'], world))
     physical = mode == 'partitioned' and not getattr(args, 'dist_full_tables', False)
     if physical:
         # the model is BORN with this rank's rows only (row 0, its nodes, one provisional arena row): no rank ever
@@ -1394,6 +1406,8 @@ def run_dist_leg(args, cfg, make_stream, build_models, rank, local_rank, world, 
         use_graphs = bool(getattr(args, 'dist_graphs', False)) and not args.no_graph
         rs = ResidentShardedStream(model, stream, owner, rank, world, B, n_steps, use_graphs=use_graphs)
     spilled = 0.0
+    load = np.bincount(owner[stream['dst'][:min(n_steps, 50) * Bg]], minlength=world).astype(np.float64)
+    imbalance = float(load.max() / max(load.mean(), 1.0))  # events by the owner of their destination: largest rank / mean
     for b in range(min(n_steps, 50)):  # how often the owner's shard was full (reported, not timed)
         sl = slice(b * Bg, (b + 1) * Bg)
         p = ShardPlan(stream['dst'][sl], owner, world, B, balance=True)
@@ -1547,7 +1561,8 @@ def run_dist_leg(args, cfg, make_stream, build_models, rank, local_rank, world, 
                                                     if physical else ''),
                                parallelism=par, exchange_rows_per_step_rank0=tr,
                                exchange=(getattr(rs, 'exchange', None) if mode == 'partitioned' else 'all-gather'),
-                               spilled_event_fraction=round(spilled, 4), launch=launch,
+                               spilled_event_fraction=round(spilled, 4), owner_table=owner_kind,
+                               owner_load_imbalance=round(imbalance, 4), launch=launch,
                                semantics='one global batch = one batch of the single-GPU engine (exchange period 1): '
                                          f'events of a batch do not see each other, and that batch has {Bg} events here'),
                    roofline=roofline, stages_ms_rank0=stages, cpu_baseline=cpu)
