@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TG_ABI_VERSION 8
+#define TG_ABI_VERSION 9
 
 /* status codes */
 #define TG_OK 0
@@ -432,6 +432,13 @@ int tg_restart_seq_list(const tg_model* m, const tg_tcsr* g, const tg_seq_restar
  * captured into a hipGraph and replayed for every batch whose count fits the capacity. */
 int tg_restart_seq_list_dev(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, int64_t cap, const int64_t* nids,
                             const int32_t* n_dev, const float* t_dev, void* ws, size_t ws_bytes, void* stream);
+/* The forward alone: h_left, h_right [n,d] and prev_ts [n] of the listed nodes into the caller's buffers, NO state update
+ * (tg_restart_apply is the caller's, on whichever stream the state lives).  It reads the graph, the feature tables and the
+ * restarter's parameters only - nothing a streaming step writes - so a loop that restarts per batch can run it on a second
+ * stream beside the previous batch's step (eval_utils._RestartPipeline).  n_dev as above (NULL: all n).  Same workspace. */
+int tg_restart_seq_list_fwd(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, int64_t n, const int64_t* nids,
+                            const int32_t* n_dev, const float* t_dev, float* h_left, float* h_right, float* prev_ts,
+                            void* ws, size_t ws_bytes, void* stream);
 
 /* TIGER.restart's state update (tiger.py:603,608-609): clear has-message bits of
  * nids, then left/right memory rows and timestamps <- (h_left, h_right, prev_ts)
@@ -575,6 +582,12 @@ typedef struct tg_lazy_restart {
    * (tg_restart_seq_fwd + tg_restart_apply) and then the step itself. */
   int64_t* list;              /* [>= min(3B(K+1), n_nodes)] */
   float* tmin;                /* [1] */
+  /* List form only: != 0 leaves the has-message bitmap alone while no trigger fires - the caller's tg_restart_apply clears
+   * the bits of the listed nodes anyway.  The pass then touches nothing a streaming step reads or writes (graph, batch
+   * arrays, the up-to-date bitmap, its own outputs) and may run on another stream beside one.  A firing trigger still
+   * clears the whole bitmap: a caller that overlaps passes and steps must not pre-draw triggers. */
+  int32_t keep_msg_bits;
+  int32_t reserved;
 } tg_lazy_restart;
 
 /* Per-stage timer of tg_stream_step (HIP events on the step's stream).  Stage names:
@@ -693,6 +706,43 @@ size_t tg_train_step_workspace_bytes2(const tg_model* m, const tg_score_params* 
                                       const tg_seq_restarter* seq, int64_t B, int32_t n_layers); /* n_layers 1 or 2 */
 int tg_train_step(const tg_model* m, const tg_tcsr* g, const tg_train_io* io, void* ws, size_t ws_bytes,
                   void* stream);
+
+/* The evaluation pass in RESTART MODE (eval_utils.py:37-42 inside the loop of :60-75: before every batch, the involved
+ * nodes that are not up to date are re-initialised by TIGER.restart at the batch's earliest time) over `count` consecutive
+ * batches of a device-resident stream as ONE call, SeqRestarter in inference form.  Per batch k: a collate-only pass in the
+ * list form (tg_lazy_restart with keep_msg_bits) lists the nodes, tg_restart_seq_list_fwd computes their rows,
+ * tg_restart_apply writes them, tg_attn_gtab_rows refreshes their query / centre rows (when gtab_ws is given: a model that
+ * streams with current per-node tables), tg_train_step in its evaluation form scores the batch - the calls the host-side
+ * loop makes, on two streams: pass k + 1 and the restarter's forward of batch k run on a stream of the library's own
+ * beside step k - 1 (they read the graph, the batch arrays, the feature tables, the restarter's parameters and the
+ * up-to-date bitmap only), `stream` keeps the state (apply k, table rows, step k); events order the two.  The host reads
+ * one count per batch (pinned memory) to size the restarter's launches: not capturable.  Results are those of the same
+ * calls on one stream.  Three pass contexts rotate (list, earliest time and count of a pass live until its restart has
+ * been applied; the third lets pass k + 1 be enqueued AHEAD of forward k - the host then finds count k + 1 waiting - without
+ * the side stream having to wait for apply k - 1); triggers must not fire (keep_msg_bits).  On return `stream` is ordered behind everything enqueued. */
+#define TG_RUN_CTX 3
+typedef struct tg_restart_run {
+  const tg_step_io* pass_io[TG_RUN_CTX]; /* collate_only + lazy (list form, keep_msg_bits != 0); offset_dev is set per pass */
+  void* pass_ws[TG_RUN_CTX];
+  size_t pass_ws_bytes[TG_RUN_CTX];
+  const tg_tcsr* g_restart;     /* the restarter's graph (histories); the steps and passes sample from `g` */
+  const int64_t* offsets;       /* device [count]: stream offset of batch k */
+  int64_t* batch_dev;           /* device batch counter of the lazy-restart loop, incremented per pass (NULL: none) */
+  int32_t* count_host[TG_RUN_CTX]; /* pinned host memory: the count of the context's last pass */
+  float* h_left[TG_RUN_CTX];    /* [cap, d] per context: the restarter's rows */
+  float* h_right[TG_RUN_CTX];
+  float* prev_ts[TG_RUN_CTX];   /* [cap] */
+  int64_t cap;                  /* capacity of the lists */
+  void* fwd_ws;                 /* tg_restart_seq_list_workspace_bytes(m, r, cap) */
+  size_t fwd_ws_bytes;
+  void* gtab_ws;                /* cap * d floats + 64 bytes, or NULL: no per-node tables to follow */
+  size_t gtab_ws_bytes;
+  float* pos_scores;            /* [count * B]: step k writes its logits at k * B (NULL: where step_io points) */
+  float* neg_scores;
+  int32_t* n_restarted;         /* host [count] out (NULL: not wanted): nodes re-initialised before batch k */
+} tg_restart_run;
+int tg_eval_restart_run(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, const tg_train_io* step_io,
+                        void* step_ws, size_t step_ws_bytes, const tg_restart_run* run, int64_t count, void* stream);
 
 /* torch.optim.Adam (defaults: no weight decay, no amsgrad) over a device-resident table of
  * parameter segments.  Segment i belongs to group `group`; a group whose enabled flag

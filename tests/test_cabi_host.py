@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, n), f'{n} declared in tiger_hip.h but not exported'
         assert n in _lib.SIGNATURES, f'{n} has no ctypes signature'
     assert set(_lib.SIGNATURES) == set(names)
-    assert _lib.lib.tg_abi_version() == 8
+    assert _lib.lib.tg_abi_version() == 9
 
 
 def test_struct_layouts_match_header():
@@ -94,7 +94,7 @@ def test_struct_layouts_match_the_header(tmp_path):
              'tg_seq_restarter': _lib.TgSeqRestarter, 'tg_step_io': _lib.TgStepIo,
              'tg_writeback_io': _lib.TgWritebackIo, 'tg_score_params': _lib.TgScoreParams,
              'tg_train_io': _lib.TgTrainIo, 'tg_adam_seg': _lib.TgAdamSeg, 'tg_lazy_restart': _lib.TgLazyRestart,
-             'tg_part': _lib.TgPart}
+             'tg_part': _lib.TgPart, 'tg_restart_run': _lib.TgRestartRun}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "tiger_hip.h"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')

@@ -301,7 +301,8 @@ def test_resident_eval_raises_the_invariant_errors():
 
 
 @pytest.mark.parametrize('name', ['eval_seq_lr_d8', 'eval_static_ll_d16'])
-@pytest.mark.parametrize('stream', ['0', '1', '1g'], ids=['own_forms', 'eager_fused', 'eager_fused_restart_graph'])
+@pytest.mark.parametrize('stream', ['0', '1', '1g', '1s'],
+                         ids=['own_forms', 'eager_fused', 'eager_fused_restart_graph', 'eager_fused_one_stream'])
 def test_resident_eval_in_restart_mode_equals_the_per_batch_loop(name, stream, monkeypatch):
     """restart_mode=True (the reference's default recipe: --restart_prob 0.01): the lazy restart of eval_utils.py:37-42
     with its bookkeeping on the device (involved & ~uptodate listed by a collate-only pass, ONE count read back per
@@ -316,7 +317,12 @@ def test_resident_eval_in_restart_mode_equals_the_per_batch_loop(name, stream, m
     data = InteractionData(z['src'], z['dst'], z['ts'], z['eids'], np.zeros(len(z['src']), dtype=np.int64), seed=0, eval=True)
     mk = lambda lo, hi: BatchLoader(data.get_subset(lo, hi), B, coll)
     if stream == '1g':  # the restarts of batches with few nodes as a replayed graph (device-side count; off by default)
+        monkeypatch.setenv('TG_EVAL_RESTART_RUN', '0')
         monkeypatch.setenv('TG_EVAL_RESTART_GRAPH', '1')
+        stream = '1'
+    if stream == '1s':  # the host-sequenced pipeline with the restarter's forward on the steps' stream
+        monkeypatch.setenv('TG_EVAL_RESTART_RUN', '0')
+        monkeypatch.setenv('TG_EVAL_RESTART_OVERLAP', '0')
         stream = '1'
     monkeypatch.setenv('TG_EVAL_STREAM', stream)
     out = {}
@@ -339,6 +345,54 @@ def test_resident_eval_in_restart_mode_equals_the_per_batch_loop(name, stream, m
             assert torch.equal(a, b)
         else:
             assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
+
+
+def test_restart_mode_eval_on_two_streams_equals_one_stream(monkeypatch):
+    """The restart-mode pass with the SeqRestarter: passes and the restarter's forward on a side stream beside the previous
+    batch's step - sequenced by the library (tg_eval_restart_run, the default) or by the host (eval_utils._RestartPipeline) -
+    against the same calls on ONE stream and against the pass without the pipeline.  A Wikipedia-shaped stream where restarts
+    go on for many batches (most nodes are met late), 60 batches + a ragged one: scores, the up-to-date set and the final
+    state bit for bit (same kernels on the same inputs, only their order across streams differs)."""
+    import bench
+    from www2023tiger_amd import eval_utils
+    from www2023tiger_amd.data.data_loader import BatchLoader, GraphCollator, InteractionData
+    B, nb, d, K, H = 100, 60, 32, 10, 16
+    n = nb * B + 37  # (+ a ragged last batch: a second pass, whose bitmap is handed over from the first)
+    st = bench.make_stream(1500, 300, n, 1.0e5, seed=5, d_e=d)
+    model, _ = bench.build_models(st, d, K, 'left', 'right', restarter='seq', hist_len=H, dropout=0.1)
+    model.eval()
+    coll = GraphCollator(model.graph, K, 1, restarter='seq', hist_len=H)
+    neg = np.random.RandomState(2).randint(1501, 1801, n)
+    data = InteractionData(st['src'][:n], st['dst'][:n], st['ts'][:n], st['eids'][:n], np.zeros(n, dtype=np.int64), seed=0,
+                           eval=True, neg_dst=neg)
+    out = {}
+    counts = []
+    orig = eval_utils._RestartPipeline.restart
+    monkeypatch.setattr(eval_utils._RestartPipeline, 'restart', lambda self, k: counts.append(orig(self, k)) or counts[-1])
+    orig_run = eval_utils._RestartRun.run
+    monkeypatch.setattr(eval_utils._RestartRun, 'run', lambda self, *a: (orig_run(self, *a), counts.extend(self.counts))[0])
+    knobs = ('TG_EVAL_RESTART_RUN', 'TG_EVAL_RESTART_OVERLAP', 'TG_EVAL_RESTART_PIPELINE')
+    for form, env in (('run', {}), ('two', dict(TG_EVAL_RESTART_RUN='0')),
+                      ('one', dict(TG_EVAL_RESTART_RUN='0', TG_EVAL_RESTART_OVERLAP='0')),
+                      ('plain', dict(TG_EVAL_RESTART_PIPELINE='0'))):
+        for k in knobs:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        model.reset()
+        up = set()
+        del counts[:]
+        res = eval_utils.eval_edge_prediction(model, BatchLoader(data, B, coll), dev(), restart_mode=True, uptodate_nodes=up,
+                                              mean_over_n_samples=200)
+        if form in ('run', 'two'):
+            assert sum(1 for c in counts if c) >= nb // 2  # restarts in most batches: the two streams did meet
+        out[form] = (res, sorted(up), model.left_memory.vals.clone(), model.right_memory.vals.clone(),
+                     model.left_memory.update_ts.clone(), model.msg_store.node_msg_vals.clone(),
+                     model.msg_store.has_msg_mask().clone())
+    for other in ('two', 'one', 'plain'):
+        assert out['run'][0] == out[other][0] and out['run'][1] == out[other][1], other
+        for a, b in zip(out['run'][2:], out[other][2:]):
+            assert torch.equal(a, b), other
 
 
 @pytest.mark.parametrize('name,strategy', [('train_static_lr_d8_L2', 'recent_edges'), ('eval_static_ll_d16', 'recent_nodes')])

@@ -1,7 +1,6 @@
 set -e
-cd $GRAFT_REPO_ROOT
-for v in 0 1 2; do
-  touch www2023tiger_amd/csrc/tg_gemm.hip
-  make -C www2023tiger_amd/csrc -j16 EXTRA=-DTG_RB_VAR=$v > /dev/null 2>&1
-  echo variant $v; python tools/micro/sgemm_ceiling.py | head -2
-done
+mkdir -p gpurun_out
+timeout -k 10 500 python -m pytest tests/test_hip_eval.py -x -q -m gpu -k "restart" 2>&1 | tee gpurun_out/t_eval.log | tail -15
+timeout -k 10 200 python tools/prof_restart_loop.py 200 > gpurun_out/restart_run_prof.log 2>&1
+grep "ms per batch" gpurun_out/restart_run_prof.log
+timeout -k 10 200 python tools/prof_restart_loop.py 500 2>&1 | grep "ms per batch"

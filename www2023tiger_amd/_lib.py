@@ -77,7 +77,16 @@ class TgStepIo(C.Structure):
 
 class TgLazyRestart(C.Structure):
     _fields_ = [('static_left', vp), ('static_right', vp), ('trigger', vp), ('n_trigger', i64), ('batch_dev', vp),
-                ('restarting_dev', vp), ('uptodate', vp), ('list', vp), ('tmin', vp)]
+                ('restarting_dev', vp), ('uptodate', vp), ('list', vp), ('tmin', vp), ('keep_msg_bits', i32),
+                ('reserved', i32)]
+
+
+class TgRestartRun(C.Structure):
+    """tiger_hip.h: tg_restart_run - the restart-mode evaluation pass over consecutive batches as one call"""
+    _fields_ = [('pass_io', vp * 3), ('pass_ws', vp * 3), ('pass_ws_bytes', sz * 3), ('g_restart', vp), ('offsets', vp),
+                ('batch_dev', vp), ('count_host', vp * 3), ('h_left', vp * 3), ('h_right', vp * 3), ('prev_ts', vp * 3),
+                ('cap', i64), ('fwd_ws', vp), ('fwd_ws_bytes', sz), ('gtab_ws', vp), ('gtab_ws_bytes', sz),
+                ('pos_scores', vp), ('neg_scores', vp), ('n_restarted', vp)]
 
 
 TG_MAX_RANKS = 16
@@ -177,6 +186,8 @@ SIGNATURES = {
     'tg_restart_seq_list_workspace_bytes': (sz, [P(TgModel), P(TgSeqRestarter), i64]),
     'tg_restart_seq_list': (C.c_int, [P(TgModel), P(TgTcsr), P(TgSeqRestarter), i64, vp, vp, vp, sz, vp]),
     'tg_restart_seq_list_dev': (C.c_int, [P(TgModel), P(TgTcsr), P(TgSeqRestarter), i64, vp, vp, vp, vp, sz, vp]),
+    'tg_eval_restart_run': (C.c_int, [P(TgModel), P(TgTcsr), P(TgSeqRestarter), vp, vp, sz, P(TgRestartRun), i64, vp]),
+    'tg_restart_seq_list_fwd': (C.c_int, [P(TgModel), P(TgTcsr), P(TgSeqRestarter), i64, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     'tg_profiler_create': (vp, []),
     'tg_profiler_destroy': (None, [vp]),
     'tg_profiler_num_stages': (C.c_int, []),
@@ -228,7 +239,7 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the library does not export the symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.tg_abi_version() != 8:
+    if lib.tg_abi_version() != 9:
         raise TigerHipError('libtiger_hip.so ABI version mismatch')
     return lib
 

@@ -180,8 +180,9 @@ __global__ void __launch_bounds__(256) k_lazy_restart(tg_tcsr g, tg_model m, tg_
   float4* left = reinterpret_cast<float4*>(m.left_vals);
   float4* right = reinterpret_cast<float4*>(m.right_vals);
   for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < W; w += (int64_t)gridDim.x * 4) {
+    const bool keep_msg = lz.list && lz.keep_msg_bits && !trig;  // (the caller's restart clears the listed nodes' bits)
     const uint64_t upd = trig ? 0ull : lz.uptodate[w];  // a trigger forgets who is up to date ...
-    const uint64_t msg = trig ? 0ull : m.has_msg[w];    // ... and drops every pending message (msg_store.clear())
+    const uint64_t msg = (trig || keep_msg) ? 0ull : m.has_msg[w];  // ... and drops every pending message (msg_store.clear())
     const int64_t node = w * 64 + lane;
     const bool need_l = node < m.n_nodes && flags[node] != 0 && !((upd >> lane) & 1ull);
     const unsigned long long need = __ballot(need_l);
@@ -192,7 +193,7 @@ __global__ void __launch_bounds__(256) k_lazy_restart(tg_tcsr g, tg_model m, tg_
       if (need_l) lz.list[base + __popcll(need & ((1ull << lane) - 1ull))] = node;
       if (lane == 0 && (trig || need)) {
         lz.uptodate[w] = upd | need;
-        m.has_msg[w] = msg & ~need;
+        if (!keep_msg) m.has_msg[w] = msg & ~need;
       }
       continue;
     }

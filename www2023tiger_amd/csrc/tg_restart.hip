@@ -1418,17 +1418,19 @@ extern "C" int tg_restart_seq_list(const tg_model* m, const tg_tcsr* g, const tg
   return tg_restart_seq_list_dev(m, g, r, n, nids, nullptr, t_dev, ws, ws_bytes, stream);
 }
 
-extern "C" int tg_restart_seq_list_dev(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, int64_t n,
-                                       const int64_t* nids, const int32_t* n_dev, const float* t_dev, void* ws,
-                                       size_t ws_bytes, void* stream) {
+// histories at the batch's earliest time, anonymised ids and the restarter's forward of a device-resident list: the rows go to
+// (hl, hr, pt) - the caller's, or the workspace's own when NULL; `w` tells where they are
+static int list_forward(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, int64_t n, const int64_t* nids,
+                        const int32_t* n_dev, const float* t_dev, float* hl, float* hr, float* pt, void* ws, size_t ws_bytes,
+                        void* stream, ListWs& w) {
   if (m && m->row_of) return TG_EUNSUPPORTED;  // state addressed by node id: not on physically partitioned tables (tg_model.row_of)
   if (!seq_ok(m, r) || !g || n < 0) return TG_EINVAL;
   if (r->hist_len > 128) return TG_EUNSUPPORTED;
   if (n == 0) return TG_OK;
   if (!nids || !t_dev) return TG_EINVAL;
   Carver cv(ws, ws_bytes);
-  ListWs w{};
   if (!ws || !carve_list(m, r, n, cv, w)) return TG_EWORKSPACE;
+  if (hl) { w.hl = hl; w.hr = hr; w.pt = pt; }
   hipStream_t st = as_stream(stream);
   const int H = r->hist_len;
   int rc;
@@ -1437,9 +1439,24 @@ extern "C" int tg_restart_seq_list_dev(const tg_model* m, const tg_tcsr* g, cons
   if ((rc = tg_anonymized_reindex(n, H, w.h_n, w.anon, stream)) != TG_OK) return rc;
   // n_dev: the launches are sized for n (a capacity), the first *n_dev entries of the list are live - the entries behind them
   // must be valid node ids (their histories are sampled and thrown away); nothing is written for them
-  if ((rc = seq_forward(m, r, n, n_dev, nids, w.h_n, w.anon, w.h_e, w.h_t, w.h_d, w.hl, w.hr, w.pt, w.seq, st)) != TG_OK)
-    return rc;
-  return restart_apply_dev(m, n, nids, w.hl, w.hr, w.pt, n_dev, st);
+  return seq_forward(m, r, n, n_dev, nids, w.h_n, w.anon, w.h_e, w.h_t, w.h_d, w.hl, w.hr, w.pt, w.seq, st);
+}
+
+extern "C" int tg_restart_seq_list_dev(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, int64_t n,
+                                       const int64_t* nids, const int32_t* n_dev, const float* t_dev, void* ws,
+                                       size_t ws_bytes, void* stream) {
+  ListWs w{};
+  const int rc = list_forward(m, g, r, n, nids, n_dev, t_dev, nullptr, nullptr, nullptr, ws, ws_bytes, stream, w);
+  if (rc != TG_OK || n == 0) return rc;
+  return restart_apply_dev(m, n, nids, w.hl, w.hr, w.pt, n_dev, as_stream(stream));
+}
+
+extern "C" int tg_restart_seq_list_fwd(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, int64_t n,
+                                       const int64_t* nids, const int32_t* n_dev, const float* t_dev, float* h_left,
+                                       float* h_right, float* prev_ts, void* ws, size_t ws_bytes, void* stream) {
+  if (n > 0 && (!h_left || !h_right || !prev_ts)) return TG_EINVAL;
+  ListWs w{};
+  return list_forward(m, g, r, n, nids, n_dev, t_dev, h_left, h_right, prev_ts, ws, ws_bytes, stream, w);
 }
 
 namespace tg {

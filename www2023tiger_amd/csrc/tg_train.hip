@@ -1176,6 +1176,123 @@ extern "C" int tg_train_step(const tg_model* m_in, const tg_tcsr* g, const tg_tr
   return step_writeback_b(m, g, sio, w, st, nullptr);
 }
 
+// ---- restart-mode evaluation over consecutive batches as one call (tiger_hip.h: tg_restart_run) -------------------------
+namespace tg {
+__global__ void k_inc_i64(int64_t* p) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *p += 1;
+}
+struct EvalLane {
+  hipStream_t s = nullptr;
+  hipEvent_t counted[TG_RUN_CTX] = {}, fwd_done[TG_RUN_CTX] = {}, applied[TG_RUN_CTX] = {}, join = nullptr;
+  bool ok = false;
+};
+static EvalLane* eval_lane() {
+  static EvalLane lanes[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  EvalLane& L = lanes[dev];
+  if (L.ok) return &L;
+  bool good = hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&L.join, hipEventDisableTiming) == hipSuccess;
+  for (int j = 0; j < TG_RUN_CTX && good; ++j)
+    good = hipEventCreateWithFlags(&L.counted[j], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&L.fwd_done[j], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&L.applied[j], hipEventDisableTiming) == hipSuccess;
+  if (!good) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  L.ok = true;
+  return &L;
+}
+}  // namespace tg
+
+extern "C" int tg_eval_restart_run(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, const tg_train_io* step_io,
+                                   void* step_ws, size_t step_ws_bytes, const tg_restart_run* run, int64_t count,
+                                   void* stream) {
+  if (!m || !g || !r || !step_io || !run || count < 0) return TG_EINVAL;
+  if (count == 0) return TG_OK;
+  if (step_io->grads || !run->g_restart || !run->offsets || run->cap <= 0 || !run->fwd_ws) return TG_EINVAL;
+  for (int j = 0; j < TG_RUN_CTX; ++j) {
+    const tg_step_io* p = run->pass_io[j];
+    if (!p || !p->collate_only || !p->lazy || !p->lazy->list || !p->lazy->tmin || !p->lazy->keep_msg_bits || !p->counts ||
+        !run->pass_ws[j] || !run->count_host[j] || !run->h_left[j] || !run->h_right[j] || !run->prev_ts[j])
+      return TG_EINVAL;
+  }
+  hipStream_t st = as_stream(stream);
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return TG_EUNSUPPORTED;  // the host reads a count per batch
+  }
+  EvalLane* L = eval_lane();
+  if (!L) return TG_EHIP;
+  const int64_t B = step_io->step.B;
+  int rc = TG_OK;
+  hipError_t e = hipSuccess;
+#define TG_RUN_HIP(call)                                     \
+  if (rc == TG_OK && (e = (call)) != hipSuccess) {           \
+    set_hip_error(e, "tg_eval_restart_run: " #call);         \
+    rc = TG_EHIP;                                            \
+  }
+  // pass k (collate-only, list form) of context k % 3 on the side stream; its count follows it to the host
+  auto pass = [&](int64_t k) {
+    const int j = (int)(k % TG_RUN_CTX);
+    tg_step_io pio = *run->pass_io[j];
+    pio.offset_dev = const_cast<int64_t*>(run->offsets + k);
+    pio.advance = 0;
+    if (rc == TG_OK) rc = tg_stream_step(m, g, &pio, run->pass_ws[j], run->pass_ws_bytes[j], L->s);
+    if (rc == TG_OK && run->batch_dev) hipLaunchKernelGGL(k_inc_i64, dim3(1), dim3(64), 0, L->s, run->batch_dev);
+    TG_RUN_HIP(hipMemcpyAsync(run->count_host[j], pio.counts + 3, sizeof(int32_t), hipMemcpyDeviceToHost, L->s));
+    TG_RUN_HIP(hipEventRecord(L->counted[j], L->s));
+  };
+  TG_RUN_HIP(hipEventRecord(L->join, st));  // whatever the caller enqueued (the bitmap it handed over) precedes the passes
+  TG_RUN_HIP(hipStreamWaitEvent(L->s, L->join, 0));
+  pass(0);
+  for (int64_t k = 0; k < count && rc == TG_OK; ++k) {
+    const int j = (int)(k % TG_RUN_CTX);
+    // the count of pass k: enqueued an iteration ago AHEAD of forward k - 1, so the host finds it there
+    TG_RUN_HIP(hipEventSynchronize(L->counted[j]));
+    if (rc != TG_OK) break;
+    const int64_t n = *run->count_host[j];
+    if (run->n_restarted) run->n_restarted[k] = (int32_t)n;
+    if (n < 0 || n > run->cap) {
+      rc = TG_EINVAL;
+      break;
+    }
+    if (k + 1 < count) {
+      // context (k + 1) % 3 is written next: apply k - 2 and the table rows behind it have read its list and rows - long
+      // done in the steady state, so the side stream never waits for the steps
+      if (k >= 2) TG_RUN_HIP(hipStreamWaitEvent(L->s, L->applied[(k + 1) % TG_RUN_CTX], 0));
+      pass(k + 1);
+    }
+    const tg_lazy_restart* lz = run->pass_io[j]->lazy;
+    if (n && rc == TG_OK) {
+      // the restarter's rows of the listed nodes (reads the graph, the features, its parameters) beside step k - 1 ...
+      rc = tg_restart_seq_list_fwd(m, run->g_restart, r, n, lz->list, nullptr, lz->tmin, run->h_left[j], run->h_right[j],
+                                   run->prev_ts[j], run->fwd_ws, run->fwd_ws_bytes, L->s);
+      TG_RUN_HIP(hipEventRecord(L->fwd_done[j], L->s));
+      // ... and the state they go to, on the caller's stream
+      TG_RUN_HIP(hipStreamWaitEvent(st, L->fwd_done[j], 0));
+      if (rc == TG_OK) rc = tg_restart_apply(m, n, lz->list, run->h_left[j], run->h_right[j], run->prev_ts[j], st);
+      if (rc == TG_OK && run->gtab_ws) rc = tg_attn_gtab_rows(m, n, lz->list, nullptr, run->gtab_ws, run->gtab_ws_bytes, st);
+    }
+    TG_RUN_HIP(hipEventRecord(L->applied[j], st));
+    if (rc != TG_OK) break;
+    tg_train_io sio = *step_io;
+    if (run->pos_scores) sio.pos_scores = run->pos_scores + k * B;
+    if (run->neg_scores) sio.neg_scores = run->neg_scores + k * B;
+    rc = tg_train_step(m, g, &sio, step_ws, step_ws_bytes, st);
+  }
+#undef TG_RUN_HIP
+  // the caller's stream is ordered behind the side stream again (the bitmap the passes marked; on an error: whatever is in flight)
+  if (hipEventRecord(L->join, L->s) != hipSuccess || hipStreamWaitEvent(st, L->join, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(L->s);
+  }
+  return rc;
+}
+
 extern "C" int tg_adam_step(const tg_adam_seg* segs_dev, int32_t n_segs, int32_t n_groups, const int32_t* enabled_dev,
                             int32_t* steps_dev, float lr, float beta1, float beta2, float eps, float grad_scale,
                             void* stream) {

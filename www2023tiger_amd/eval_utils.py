@@ -157,7 +157,30 @@ class _RestartPipeline:
                                  and model.restarter_fn.graph.strategy == 'recent_edges') else 0
         self.graphs = [None, None]
         self.eager_done = False
-        self._pass(0)
+        # Two streams (TG_EVAL_RESTART_OVERLAP=0: off).  The restarter's forward of a list reads the graph, the feature tables
+        # and its own parameters - nothing a step writes; a pass reads the batch arrays, the graph and the up-to-date bitmap
+        # (keep_msg_bits: it leaves the has-message bits to tg_restart_apply).  Both run on a side stream: pass k + 1 and
+        # forward k beside step k - 1; the main stream keeps the state: apply k, the table rows of the restarted nodes, step k.
+        # Events order the two: the main stream waits for forward k, the side stream for apply k - 1 before pass k + 1
+        # overwrites that context's list (and forward k + 1 its rows).  Same lists, same rows, same state as one stream.
+        self.overlap = (os.environ.get('TG_EVAL_RESTART_OVERLAP', '1') != '0' and not self.graph_cap
+                        and model.restart_list_split_ok() and not bool(sb.lazy_trigger.any()))
+        if self.overlap:
+            dev, d = model.device, model.memory_dim
+            self.main = torch.cuda.current_stream(dev)
+            self.side = torch.cuda.Stream(device=dev)
+            cap = max(int(cb.lazy_list.numel()) for cb in self.ctx)
+            self.rows = [(torch.empty(cap, d, device=dev), torch.empty(cap, d, device=dev), torch.empty(cap, device=dev))
+                         for _ in range(2)]
+            self.fwd_done = [torch.cuda.Event() for _ in range(2)]
+            self.applied = [torch.cuda.Event() for _ in range(2)]
+            for cb in self.ctx:
+                cb._lazy.keep_msg_bits = 1
+            self.side.wait_stream(self.main)
+            with torch.cuda.stream(self.side):
+                self._pass(0)
+        else:
+            self._pass(0)
 
     def _pass(self, k):
         import ctypes as C
@@ -170,8 +193,41 @@ class _RestartPipeline:
         self.ev[k % 2].record()
         self.tb.sb.lazy_batch += 1
 
+    def close(self):
+        """The passes have marked the up-to-date bitmap on the side stream: whoever reads it next is ordered behind them."""
+        if self.overlap:
+            self.main.wait_stream(self.side)
+            for cb in self.ctx:
+                cb._lazy.keep_msg_bits = 0
+
+    def _restart_overlapped(self, k):
+        model, j = self.model, k % 2
+        self.ev[j].synchronize()
+        n = int(self.host[j][0])
+        cb = self.ctx[j]
+        hl, hr, pt = self.rows[j]
+        with torch.cuda.stream(self.side):
+            if n:
+                model.restart_list_forward(cb.lazy_list[:n], cb.lazy_tmin, hl, hr, pt)
+                self.fwd_done[j].record()
+            if k + 1 < self.count:
+                if k >= 1:
+                    self.side.wait_event(self.applied[1 - j])  # apply k - 1 and its table rows have read that context's list
+                self._pass(k + 1)
+        if n:
+            self.main.wait_event(self.fwd_done[j])
+            current = (model._pending is not None and model._pending_stamp == model._state_stamp()
+                       and (getattr(model, '_gtab', None) is None or getattr(model, '_gtab_stamp', None) is not None))
+            model.restart_list_apply(cb.lazy_list[:n], hl, hr, pt)
+            if current:
+                model._tables_follow_restart(cb.lazy_list[:n])
+        self.applied[j].record()
+        return n
+
     def restart(self, k):
         """Before step k: enqueue pass k + 1, then the restart of batch k's list."""
+        if self.overlap:
+            return self._restart_overlapped(k)
         model = self.model
         if k + 1 < self.count:
             self._pass(k + 1)
@@ -211,6 +267,83 @@ class _RestartPipeline:
         return g
 
 
+class _RestartRun:
+    """Batches [k0, count) of the restart-mode pass as ONE library call (tg_eval_restart_run: the calls of _RestartPipeline's
+    two-stream form - pass, restarter's forward, apply, table rows, step - sequenced by the library, which spends ~3 us of
+    host time per launch where this module spent 0.24 ms per batch; the pass is then bound by the device again).
+    SeqRestarter in inference form, no pre-drawn triggers; the lists' capacity sizes the restarter's workspace, so huge
+    batches over huge graphs stay with _RestartPipeline (WS_LIMIT)."""
+    WS_LIMIT = 6 << 30
+
+    def __init__(self, model, tb, graph, first, count):
+        self.model, self.tb, self.graph, self.first, self.count = model, tb, graph, first, count
+        self.counts = []
+
+    @staticmethod
+    def applies(model, tb, count):
+        if os.environ.get('TG_EVAL_RESTART_RUN', '1') == '0' or count < 2 or not model.restart_list_split_ok():
+            return False
+        if bool(tb.sb.lazy_trigger.any()) or model.n_layers != 1:
+            return False
+        import ctypes as C
+        m, rs = model.model_struct(), model.restarter_fn._struct()
+        cap = int(tb.sb._lazy_collate.lazy_list.numel())
+        return 0 < int(lib.tg_restart_seq_list_workspace_bytes(C.byref(m), C.byref(rs), cap)) <= _RestartRun.WS_LIMIT
+
+    def run(self, k0, pos_ptr, neg_ptr):
+        """Batches k0 .. count - 1; `pos_ptr` / `neg_ptr`: where batch k0's logits go (those of the later ones behind them)."""
+        import ctypes as C
+        from ._lib import TgRestartRun
+        model, tb, sb = self.model, self.tb, self.tb.sb
+        dev, d, nb = model.device, model.memory_dim, self.count - k0
+        ctx = [sb._lazy_collate, sb.lazy_collate_context(model), sb.lazy_collate_context(model)]  # (tg_restart_run: three rotate)
+        cap = int(ctx[0].lazy_list.numel())
+        offsets = self.first + torch.arange(k0, self.count, dtype=torch.int64, device=dev) * sb.B
+        host = torch.zeros(3, 16, dtype=torch.int32).pin_memory()
+        rows = [(torch.empty(cap, d, device=dev), torch.empty(cap, d, device=dev), torch.empty(cap, device=dev))
+                for _ in range(3)]
+        eager = model._pending is not None
+        if eager:  # the protocol of TrainBuffers.launch: tables synchronised before, kept current by the steps themselves
+            if model._fused is not None and model._fused_stamp != model._attn_stamp():
+                model.fuse_attention()
+            model._sync_pending()
+            model._sync_gtab()
+        m, rs = model.model_struct(), model.restarter_fn._struct()
+        nbytes = int(lib.tg_restart_seq_list_workspace_bytes(C.byref(m), C.byref(rs), cap))
+        fwd_ws = torch.empty(nbytes + 1024, dtype=torch.uint8, device=dev)
+        gtab_ws = model._ws('gtab_r', cap * (4 * d + 4) + 64) if (eager and getattr(model, '_gtab', None) is not None) else None
+        n_restarted = np.zeros(nb, dtype=np.int32)
+        run = TgRestartRun()
+        for j, cb in enumerate(ctx):
+            cb._lazy.keep_msg_bits = 1
+            run.pass_io[j], run.pass_ws[j], run.pass_ws_bytes[j] = C.addressof(cb.io), ptr(cb.ws), cb.ws.numel()
+            run.count_host[j] = host[j].data_ptr()
+            run.h_left[j], run.h_right[j], run.prev_ts[j] = (ptr(t) for t in rows[j])
+        run.g_restart = C.addressof(model.restarter_fn.graph.tcsr)
+        run.offsets, run.batch_dev, run.cap = ptr(offsets), ptr(sb.lazy_batch), cap
+        run.fwd_ws, run.fwd_ws_bytes = ptr(fwd_ws), fwd_ws.numel()
+        if gtab_ws is not None:
+            run.gtab_ws, run.gtab_ws_bytes = ptr(gtab_ws), gtab_ws.numel()
+        run.pos_scores, run.neg_scores = pos_ptr, neg_ptr
+        run.n_restarted = n_restarted.ctypes.data
+        tb.io.step.rows_hint = model.rows_bound()
+        try:
+            check(lib.tg_eval_restart_run(C.byref(m), C.byref(self.graph.tcsr), C.byref(rs), C.addressof(tb.io), ptr(tb.ws),
+                                          tb.ws.numel(), C.byref(run), nb, stream_ptr(dev)), 'tg_eval_restart_run')
+        finally:
+            for cb in ctx:
+                cb._lazy.keep_msg_bits = 0
+        self.counts = n_restarted.tolist()
+        model._step_serial = getattr(model, '_step_serial', 0) + nb
+        if not eager or any(self.counts):
+            model._touch()  # state changed outside the eager streaming step (restarts; every step of a model without tables)
+        if eager:  # what _tables_follow_restart records: the restarted nodes' rows were recomputed, the tables are current
+            if getattr(model, '_gtab', None) is not None:
+                model._gtab_stamp = (model._state_stamp(), tuple(model._attn_stamp()), id(model._fused))
+            model._pending_stamp = model._state_stamp()
+        self._keep = (ctx, offsets, host, rows, fwd_ws, run)  # (alive until the caller's read-back has drained the stream)
+
+
 def _eval_resident_run(model, ds, bs, dev, N, lo, hi, graph, TrainBuffers, lean, restart_mode=False, uptodate_nodes=None):
     c = getattr(ds, '_dev', None)
     if c is not None and c['device'] == dev:
@@ -227,7 +360,7 @@ def _eval_resident_run(model, ds, bs, dev, N, lo, hi, graph, TrainBuffers, lean,
     pos_all = torch.empty(N, dtype=torch.float32, device=dev)
     neg_all = torch.empty(N, dtype=torch.float32, device=dev)
     n_full, rem = divmod(N, bs)
-    bufs = []
+    bufs, runs = [], []
     for B, first, count in ((bs, 0, n_full), (rem, n_full * bs, 1 if rem else 0)):
         if not count:
             continue
@@ -261,12 +394,24 @@ def _eval_resident_run(model, ds, bs, dev, N, lo, hi, graph, TrainBuffers, lean,
         p0, n0 = pos_all.data_ptr() + 4 * first, neg_all.data_ptr() + 4 * first
         # (replaying captured hipGraphs of several steps was tried here: the pass is bound by the device's dependent launches -
         # bs 200: 72 us per batch eager, 75 us as 16-step graphs, and a capture costs ~10 ms - so the steps are launched eagerly)
-        pipe = None
+        pipe = runner = None
         if (restart_mode and not tb._restart_in_step and dev.type == 'cuda'
                 and os.environ.get('TG_EVAL_RESTART_PIPELINE', '1') != '0'):
-            pipe = _RestartPipeline(model, tb, graph, first, count)
+            if _RestartRun.applies(model, tb, count):
+                runner = _RestartRun(model, tb, graph, first, count)
+                runs.append(runner)
+            else:
+                pipe = _RestartPipeline(model, tb, graph, first, count)
         for k in range(count):
             tb.io.pos_scores, tb.io.neg_scores = p0 + 4 * k * B, n0 + 4 * k * B
+            if runner is not None:
+                # batch 0 by the calls of the per-batch loop (its counts size the later steps' launches), the others as one call
+                _restart_listed(model, tb, graph)
+                tb.launch(graph=graph)
+                cnt = tb.sb.counts.tolist()
+                model.note_rows(cnt[1], cnt[2])
+                runner.run(1, p0 + 4 * B, n0 + 4 * B)
+                break
             if pipe is not None:
                 pipe.restart(k)
             elif restart_mode and not tb._restart_in_step:
@@ -275,6 +420,8 @@ def _eval_resident_run(model, ds, bs, dev, N, lo, hi, graph, TrainBuffers, lean,
             if k == 0 and count > 8:  # one early read-back: the updater's launches are sized by the counts seen so far
                 cnt = tb.sb.counts.tolist()
                 model.note_rows(cnt[1], cnt[2])
+        if pipe is not None:
+            pipe.close()
     words = [(int(tb.sb.err.item()), tb.sb.counts.tolist()) for tb in bufs]  # (also drains the stream)
     for word, cnt in words:
         model.note_rows(cnt[1], cnt[2])

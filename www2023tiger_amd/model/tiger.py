@@ -153,6 +153,36 @@ class TIGE(nn.Module):
         check(lib.tg_restart_seq_list(C.byref(m), C.byref(r.graph.tcsr), C.byref(rs), n, ptr(nids), ptr(t_dev), ptr(ws),
                                       ws.numel(), stream_ptr(self.device)), 'tg_restart_seq_list')
 
+    def restart_list_split_ok(self) -> bool:
+        """Can `restart_list` be taken apart into `restart_list_forward` (reads graph / features / restarter parameters only)
+        and `restart_list_apply` (the state update)?  The SeqRestarter in inference form over a recent-edges graph."""
+        from .restarters import SeqRestarter
+        r = self.restarter_fn
+        return (isinstance(r, SeqRestarter) and not (r.training and float(r.mha_fn.dropout) > 0)
+                and getattr(self, '_row_of', None) is None and r.graph.strategy == 'recent_edges' and self.device.type == 'cuda')
+
+    def restart_list_forward(self, nids: Tensor, t_dev: Tensor, h_left: Tensor, h_right: Tensor, prev_ts: Tensor, ws_key='a'):
+        """The restarter's rows of `restart_list` WITHOUT the state update (tg_restart_seq_list_fwd), on the current stream,
+        into the caller's buffers.  Nothing a streaming step writes is read: callable on a second stream beside a step."""
+        r = self.restarter_fn
+        n = int(nids.numel())
+        m, rs = self.model_struct(), r._struct()
+        nbytes = int(lib.tg_restart_seq_list_workspace_bytes(C.byref(m), C.byref(rs), n))
+        store = self.__dict__.setdefault('_restart_fwd_ws', {})
+        ws = store.get(ws_key)
+        if ws is None or ws.numel() < nbytes:
+            ws = store[ws_key] = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=self.device)
+        check(lib.tg_restart_seq_list_fwd(C.byref(m), C.byref(r.graph.tcsr), C.byref(rs), n, ptr(nids), None, ptr(t_dev),
+                                          ptr(h_left), ptr(h_right), ptr(prev_ts), ptr(ws), ws.numel(),
+                                          stream_ptr(self.device)), 'tg_restart_seq_list_fwd')
+
+    def restart_list_apply(self, nids: Tensor, h_left: Tensor, h_right: Tensor, prev_ts: Tensor):
+        """The state update of `restart_list` (tiger.py:603,608-609) from rows `restart_list_forward` left."""
+        self._touch()
+        m = self.model_struct()
+        check(lib.tg_restart_apply(C.byref(m), int(nids.numel()), ptr(nids), ptr(h_left), ptr(h_right), ptr(prev_ts),
+                                   stream_ptr(self.device)), 'tg_restart_apply')
+
     def restart_list_captured(self, nids_cap: Tensor, n_dev: Tensor, t_dev: Tensor):
         """The device half of `restart_list` + `_tables_follow_restart` with the live count ON THE DEVICE (n_dev, int32): launches
         sized for the capacity len(nids_cap), the first n_dev entries restarted (tg_restart_seq_list_dev, tg_attn_gtab_rows with
