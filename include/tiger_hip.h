@@ -439,6 +439,15 @@ int tg_restart_seq_list_dev(const tg_model* m, const tg_tcsr* g, const tg_seq_re
 int tg_restart_seq_list_fwd(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, int64_t n, const int64_t* nids,
                             const int32_t* n_dev, const float* t_dev, float* h_left, float* h_right, float* prev_ts,
                             void* ws, size_t ws_bytes, void* stream);
+/* The same forward over SEVERAL lists at once, each with its own time (the lists of consecutive batches: their restarts are
+ * independent of each other and of the steps between them - a node listed for batch k + 1 is not involved in batch k - and
+ * one forward over all of them costs little more than one over the shortest).  The ids go to ids_out concatenated in list
+ * order (empty lists skipped), rows i of h_left / h_right / prev_ts belong to ids_out[i]; workspace for sum(counts) nodes. */
+#define TG_RESTART_MAX_LISTS 8
+int tg_restart_seq_lists_fwd(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, int32_t n_lists,
+                             const int64_t* const* lists, const int64_t* counts, const float* const* t_dev,
+                             int64_t* ids_out, float* h_left, float* h_right, float* prev_ts, void* ws, size_t ws_bytes,
+                             void* stream);
 
 /* TIGER.restart's state update (tiger.py:603,608-609): clear has-message bits of
  * nids, then left/right memory rows and timestamps <- (h_left, h_right, prev_ts)
@@ -709,19 +718,26 @@ int tg_train_step(const tg_model* m, const tg_tcsr* g, const tg_train_io* io, vo
 
 /* The evaluation pass in RESTART MODE (eval_utils.py:37-42 inside the loop of :60-75: before every batch, the involved
  * nodes that are not up to date are re-initialised by TIGER.restart at the batch's earliest time) over `count` consecutive
- * batches of a device-resident stream as ONE call, SeqRestarter in inference form.  Per batch k: a collate-only pass in the
- * list form (tg_lazy_restart with keep_msg_bits) lists the nodes, tg_restart_seq_list_fwd computes their rows,
- * tg_restart_apply writes them, tg_attn_gtab_rows refreshes their query / centre rows (when gtab_ws is given: a model that
- * streams with current per-node tables), tg_train_step in its evaluation form scores the batch - the calls the host-side
- * loop makes, on two streams: pass k + 1 and the restarter's forward of batch k run on a stream of the library's own
- * beside step k - 1 (they read the graph, the batch arrays, the feature tables, the restarter's parameters and the
- * up-to-date bitmap only), `stream` keeps the state (apply k, table rows, step k); events order the two.  The host reads
- * one count per batch (pinned memory) to size the restarter's launches: not capturable.  Results are those of the same
- * calls on one stream.  Three pass contexts rotate (list, earliest time and count of a pass live until its restart has
- * been applied; the third lets pass k + 1 be enqueued AHEAD of forward k - the host then finds count k + 1 waiting - without
- * the side stream having to wait for apply k - 1); triggers must not fire (keep_msg_bits).  On return `stream` is ordered behind everything enqueued. */
-#define TG_RUN_CTX 3
+ * batches of a device-resident stream as ONE call, SeqRestarter in inference form.  Per batch k the host-side loop makes
+ * these calls: a collate-only pass in the list form (tg_lazy_restart) lists the nodes, the restarter's forward computes their
+ * rows, tg_restart_apply writes them, tg_attn_gtab_rows refreshes their query / centre rows (a model that streams with
+ * current per-node tables), tg_train_step in its evaluation form scores the batch.  Here the same calls run on two streams
+ * and in GROUPS of `group` batches:
+ *   - a pass reads the graph, the batch arrays and the up-to-date bitmap (keep_msg_bits: not the has-message bits), the
+ *     restarter's forward the graph, the feature tables and its own parameters - nothing a step writes - so the passes of
+ *     group q + 1 and the forward of group q run on a stream of the library's own beside the steps of group q - 1;
+ *   - the lists of a group's batches are disjoint (a pass marks what it lists) and a node listed for batch k + 1 is not
+ *     involved in batch k (it would have been listed there), so step k neither reads nor writes it: ONE forward over the
+ *     group's lists (tg_restart_seq_lists_fwd, every list at its own time) and ONE apply / table refresh ahead of the
+ *     group's first step leave the state every step sees - and the final state - exactly as the per-batch order does;
+ *   - `stream` keeps the state (apply, table rows, steps); events order the two streams; two halves of 2 * group pass
+ *     contexts and two row sets alternate, so that in the steady state neither stream waits for the other's bookkeeping.
+ * The host reads one count per batch (pinned memory) to size the forward: not capturable.  Triggers must not fire
+ * (keep_msg_bits).  On return `stream` is ordered behind everything enqueued. */
+#define TG_RUN_CTX (2 * TG_RESTART_MAX_LISTS)
 typedef struct tg_restart_run {
+  int32_t group;                /* batches per forward, 1 .. TG_RESTART_MAX_LISTS; 2 * group pass contexts are used */
+  int32_t reserved;
   const tg_step_io* pass_io[TG_RUN_CTX]; /* collate_only + lazy (list form, keep_msg_bits != 0); offset_dev is set per pass */
   void* pass_ws[TG_RUN_CTX];
   size_t pass_ws_bytes[TG_RUN_CTX];
@@ -729,13 +745,15 @@ typedef struct tg_restart_run {
   const int64_t* offsets;       /* device [count]: stream offset of batch k */
   int64_t* batch_dev;           /* device batch counter of the lazy-restart loop, incremented per pass (NULL: none) */
   int32_t* count_host[TG_RUN_CTX]; /* pinned host memory: the count of the context's last pass */
-  float* h_left[TG_RUN_CTX];    /* [cap, d] per context: the restarter's rows */
-  float* h_right[TG_RUN_CTX];
-  float* prev_ts[TG_RUN_CTX];   /* [cap] */
-  int64_t cap;                  /* capacity of the lists */
-  void* fwd_ws;                 /* tg_restart_seq_list_workspace_bytes(m, r, cap) */
+  int64_t cap;                  /* capacity of each context's list */
+  int64_t rows_cap;             /* capacity of a row set: min(group * cap, n_nodes) - the lists of a group are disjoint */
+  int64_t* ids[2];              /* [rows_cap] per set: the group's lists, concatenated */
+  float* h_left[2];             /* [rows_cap, d] per set: the restarter's rows */
+  float* h_right[2];
+  float* prev_ts[2];            /* [rows_cap] */
+  void* fwd_ws;                 /* tg_restart_seq_list_workspace_bytes(m, r, rows_cap) */
   size_t fwd_ws_bytes;
-  void* gtab_ws;                /* cap * d floats + 64 bytes, or NULL: no per-node tables to follow */
+  void* gtab_ws;                /* rows_cap * d floats + 64 bytes, or NULL: no per-node tables to follow */
   size_t gtab_ws_bytes;
   float* pos_scores;            /* [count * B]: step k writes its logits at k * B (NULL: where step_io points) */
   float* neg_scores;

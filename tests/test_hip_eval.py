@@ -371,8 +371,9 @@ def test_restart_mode_eval_on_two_streams_equals_one_stream(monkeypatch):
     monkeypatch.setattr(eval_utils._RestartPipeline, 'restart', lambda self, k: counts.append(orig(self, k)) or counts[-1])
     orig_run = eval_utils._RestartRun.run
     monkeypatch.setattr(eval_utils._RestartRun, 'run', lambda self, *a: (orig_run(self, *a), counts.extend(self.counts))[0])
-    knobs = ('TG_EVAL_RESTART_RUN', 'TG_EVAL_RESTART_OVERLAP', 'TG_EVAL_RESTART_PIPELINE')
-    for form, env in (('run', {}), ('two', dict(TG_EVAL_RESTART_RUN='0')),
+    knobs = ('TG_EVAL_RESTART_RUN', 'TG_EVAL_RESTART_OVERLAP', 'TG_EVAL_RESTART_PIPELINE', 'TG_EVAL_RESTART_GROUP')
+    for form, env in (('run', {}), ('run1', dict(TG_EVAL_RESTART_GROUP='1')), ('run3', dict(TG_EVAL_RESTART_GROUP='3')),
+                      ('two', dict(TG_EVAL_RESTART_RUN='0')),
                       ('one', dict(TG_EVAL_RESTART_RUN='0', TG_EVAL_RESTART_OVERLAP='0')),
                       ('plain', dict(TG_EVAL_RESTART_PIPELINE='0'))):
         for k in knobs:
@@ -389,7 +390,7 @@ def test_restart_mode_eval_on_two_streams_equals_one_stream(monkeypatch):
         out[form] = (res, sorted(up), model.left_memory.vals.clone(), model.right_memory.vals.clone(),
                      model.left_memory.update_ts.clone(), model.msg_store.node_msg_vals.clone(),
                      model.msg_store.has_msg_mask().clone())
-    for other in ('two', 'one', 'plain'):
+    for other in ('run1', 'run3', 'two', 'one', 'plain'):
         assert out['run'][0] == out[other][0] and out['run'][1] == out[other][1], other
         for a, b in zip(out['run'][2:], out[other][2:]):
             assert torch.equal(a, b), other

@@ -83,9 +83,10 @@ class TgLazyRestart(C.Structure):
 
 class TgRestartRun(C.Structure):
     """tiger_hip.h: tg_restart_run - the restart-mode evaluation pass over consecutive batches as one call"""
-    _fields_ = [('pass_io', vp * 3), ('pass_ws', vp * 3), ('pass_ws_bytes', sz * 3), ('g_restart', vp), ('offsets', vp),
-                ('batch_dev', vp), ('count_host', vp * 3), ('h_left', vp * 3), ('h_right', vp * 3), ('prev_ts', vp * 3),
-                ('cap', i64), ('fwd_ws', vp), ('fwd_ws_bytes', sz), ('gtab_ws', vp), ('gtab_ws_bytes', sz),
+    _fields_ = [('group', i32), ('reserved', i32), ('pass_io', vp * 16), ('pass_ws', vp * 16), ('pass_ws_bytes', sz * 16),
+                ('g_restart', vp), ('offsets', vp), ('batch_dev', vp), ('count_host', vp * 16), ('cap', i64), ('rows_cap', i64),
+                ('ids', vp * 2), ('h_left', vp * 2), ('h_right', vp * 2), ('prev_ts', vp * 2),
+                ('fwd_ws', vp), ('fwd_ws_bytes', sz), ('gtab_ws', vp), ('gtab_ws_bytes', sz),
                 ('pos_scores', vp), ('neg_scores', vp), ('n_restarted', vp)]
 
 
@@ -187,6 +188,7 @@ SIGNATURES = {
     'tg_restart_seq_list': (C.c_int, [P(TgModel), P(TgTcsr), P(TgSeqRestarter), i64, vp, vp, vp, sz, vp]),
     'tg_restart_seq_list_dev': (C.c_int, [P(TgModel), P(TgTcsr), P(TgSeqRestarter), i64, vp, vp, vp, vp, sz, vp]),
     'tg_eval_restart_run': (C.c_int, [P(TgModel), P(TgTcsr), P(TgSeqRestarter), vp, vp, sz, P(TgRestartRun), i64, vp]),
+    'tg_restart_seq_lists_fwd': (C.c_int, [P(TgModel), P(TgTcsr), P(TgSeqRestarter), i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     'tg_restart_seq_list_fwd': (C.c_int, [P(TgModel), P(TgTcsr), P(TgSeqRestarter), i64, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     'tg_profiler_create': (vp, []),
     'tg_profiler_destroy': (None, [vp]),

@@ -1383,6 +1383,22 @@ __global__ void k_restart_times(int64_t n, const float* __restrict__ t_dev, doub
   const double t = (double)*t_dev;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) tu[i] = t;
 }
+// several lists (each with its own earliest time) as one: ids concatenated in list order, the query time of every entry
+struct SegLists {
+  const int64_t* ids[TG_RESTART_MAX_LISTS];
+  const float* t[TG_RESTART_MAX_LISTS];
+  int64_t off[TG_RESTART_MAX_LISTS + 1];
+  int n;
+};
+__global__ void k_concat_lists(SegLists sl, int64_t* __restrict__ ids, double* __restrict__ tu) {
+  const int64_t total = sl.off[sl.n];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int s = 0;
+    while (s + 1 < sl.n && i >= sl.off[s + 1]) ++s;
+    ids[i] = sl.ids[s][i - sl.off[s]];
+    tu[i] = (double)*sl.t[s];
+  }
+}
 struct ListWs {
   double* tu;
   int64_t *h_n, *h_e, *h_d, *anon;
@@ -1422,19 +1438,24 @@ extern "C" int tg_restart_seq_list(const tg_model* m, const tg_tcsr* g, const tg
 // (hl, hr, pt) - the caller's, or the workspace's own when NULL; `w` tells where they are
 static int list_forward(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, int64_t n, const int64_t* nids,
                         const int32_t* n_dev, const float* t_dev, float* hl, float* hr, float* pt, void* ws, size_t ws_bytes,
-                        void* stream, ListWs& w) {
+                        void* stream, ListWs& w, const SegLists* segs = nullptr, int64_t* ids_out = nullptr) {
   if (m && m->row_of) return TG_EUNSUPPORTED;  // state addressed by node id: not on physically partitioned tables (tg_model.row_of)
   if (!seq_ok(m, r) || !g || n < 0) return TG_EINVAL;
   if (r->hist_len > 128) return TG_EUNSUPPORTED;
   if (n == 0) return TG_OK;
-  if (!nids || !t_dev) return TG_EINVAL;
+  if (segs ? !ids_out : (!nids || !t_dev)) return TG_EINVAL;
   Carver cv(ws, ws_bytes);
   if (!ws || !carve_list(m, r, n, cv, w)) return TG_EWORKSPACE;
   if (hl) { w.hl = hl; w.hr = hr; w.pt = pt; }
   hipStream_t st = as_stream(stream);
   const int H = r->hist_len;
   int rc;
-  hipLaunchKernelGGL(k_restart_times, dim3(flat_grid(n, 256)), dim3(256), 0, st, n, t_dev, w.tu);
+  if (segs) {
+    hipLaunchKernelGGL(k_concat_lists, dim3(flat_grid(n, 256)), dim3(256), 0, st, *segs, ids_out, w.tu);
+    nids = ids_out;
+  } else {
+    hipLaunchKernelGGL(k_restart_times, dim3(flat_grid(n, 256)), dim3(256), 0, st, n, t_dev, w.tu);
+  }
   if ((rc = tg_sample_recent_edges(g, n, nids, w.tu, H, w.h_n, w.h_e, w.h_t, w.h_d, nullptr, stream)) != TG_OK) return rc;
   if ((rc = tg_anonymized_reindex(n, H, w.h_n, w.anon, stream)) != TG_OK) return rc;
   // n_dev: the launches are sized for n (a capacity), the first *n_dev entries of the list are live - the entries behind them
@@ -1457,6 +1478,26 @@ extern "C" int tg_restart_seq_list_fwd(const tg_model* m, const tg_tcsr* g, cons
   if (n > 0 && (!h_left || !h_right || !prev_ts)) return TG_EINVAL;
   ListWs w{};
   return list_forward(m, g, r, n, nids, n_dev, t_dev, h_left, h_right, prev_ts, ws, ws_bytes, stream, w);
+}
+
+extern "C" int tg_restart_seq_lists_fwd(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, int32_t n_lists,
+                                        const int64_t* const* lists, const int64_t* counts, const float* const* t_dev,
+                                        int64_t* ids_out, float* h_left, float* h_right, float* prev_ts, void* ws,
+                                        size_t ws_bytes, void* stream) {
+  if (n_lists <= 0 || n_lists > TG_RESTART_MAX_LISTS || !lists || !counts || !t_dev) return TG_EINVAL;
+  SegLists sl{};
+  for (int j = 0; j < n_lists; ++j) {
+    if (counts[j] < 0 || (counts[j] > 0 && (!lists[j] || !t_dev[j]))) return TG_EINVAL;
+    if (counts[j] == 0) continue;  // (an empty list takes no segment)
+    sl.ids[sl.n] = lists[j];
+    sl.t[sl.n] = t_dev[j];
+    sl.off[sl.n + 1] = sl.off[sl.n] + counts[j];
+    ++sl.n;
+  }
+  const int64_t n = sl.off[sl.n];
+  if (n > 0 && (!ids_out || !h_left || !h_right || !prev_ts)) return TG_EINVAL;
+  ListWs w{};
+  return list_forward(m, g, r, n, nullptr, nullptr, nullptr, h_left, h_right, prev_ts, ws, ws_bytes, stream, w, &sl, ids_out);
 }
 
 namespace tg {

@@ -1183,7 +1183,7 @@ __global__ void k_inc_i64(int64_t* p) {
 }
 struct EvalLane {
   hipStream_t s = nullptr;
-  hipEvent_t counted[TG_RUN_CTX] = {}, fwd_done[TG_RUN_CTX] = {}, applied[TG_RUN_CTX] = {}, join = nullptr;
+  hipEvent_t counted[TG_RUN_CTX] = {}, fwd_done[2] = {}, applied[2] = {}, join = nullptr;
   bool ok = false;
 };
 static EvalLane* eval_lane() {
@@ -1194,9 +1194,9 @@ static EvalLane* eval_lane() {
   if (L.ok) return &L;
   bool good = hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&L.join, hipEventDisableTiming) == hipSuccess;
-  for (int j = 0; j < TG_RUN_CTX && good; ++j)
-    good = hipEventCreateWithFlags(&L.counted[j], hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&L.fwd_done[j], hipEventDisableTiming) == hipSuccess &&
+  for (int j = 0; j < TG_RUN_CTX && good; ++j) good = hipEventCreateWithFlags(&L.counted[j], hipEventDisableTiming) == hipSuccess;
+  for (int j = 0; j < 2 && good; ++j)
+    good = hipEventCreateWithFlags(&L.fwd_done[j], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&L.applied[j], hipEventDisableTiming) == hipSuccess;
   if (!good) {
     (void)hipGetLastError();
@@ -1212,13 +1212,18 @@ extern "C" int tg_eval_restart_run(const tg_model* m, const tg_tcsr* g, const tg
                                    void* stream) {
   if (!m || !g || !r || !step_io || !run || count < 0) return TG_EINVAL;
   if (count == 0) return TG_OK;
-  if (step_io->grads || !run->g_restart || !run->offsets || run->cap <= 0 || !run->fwd_ws) return TG_EINVAL;
-  for (int j = 0; j < TG_RUN_CTX; ++j) {
+  const int G = run->group;
+  if (G < 1 || G > TG_RESTART_MAX_LISTS || step_io->grads || !run->g_restart || !run->offsets || run->cap <= 0 ||
+      run->rows_cap <= 0 || !run->fwd_ws)
+    return TG_EINVAL;
+  for (int j = 0; j < 2 * G; ++j) {
     const tg_step_io* p = run->pass_io[j];
     if (!p || !p->collate_only || !p->lazy || !p->lazy->list || !p->lazy->tmin || !p->lazy->keep_msg_bits || !p->counts ||
-        !run->pass_ws[j] || !run->count_host[j] || !run->h_left[j] || !run->h_right[j] || !run->prev_ts[j])
+        !run->pass_ws[j] || !run->count_host[j])
       return TG_EINVAL;
   }
+  for (int j = 0; j < 2; ++j)
+    if (!run->ids[j] || !run->h_left[j] || !run->h_right[j] || !run->prev_ts[j]) return TG_EINVAL;
   hipStream_t st = as_stream(stream);
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
@@ -1227,7 +1232,7 @@ extern "C" int tg_eval_restart_run(const tg_model* m, const tg_tcsr* g, const tg
   }
   EvalLane* L = eval_lane();
   if (!L) return TG_EHIP;
-  const int64_t B = step_io->step.B;
+  const int64_t B = step_io->step.B, n_groups = cdiv(count, (int64_t)G);
   int rc = TG_OK;
   hipError_t e = hipSuccess;
 #define TG_RUN_HIP(call)                                     \
@@ -1235,54 +1240,70 @@ extern "C" int tg_eval_restart_run(const tg_model* m, const tg_tcsr* g, const tg
     set_hip_error(e, "tg_eval_restart_run: " #call);         \
     rc = TG_EHIP;                                            \
   }
-  // pass k (collate-only, list form) of context k % 3 on the side stream; its count follows it to the host
-  auto pass = [&](int64_t k) {
-    const int j = (int)(k % TG_RUN_CTX);
-    tg_step_io pio = *run->pass_io[j];
-    pio.offset_dev = const_cast<int64_t*>(run->offsets + k);
-    pio.advance = 0;
-    if (rc == TG_OK) rc = tg_stream_step(m, g, &pio, run->pass_ws[j], run->pass_ws_bytes[j], L->s);
-    if (rc == TG_OK && run->batch_dev) hipLaunchKernelGGL(k_inc_i64, dim3(1), dim3(64), 0, L->s, run->batch_dev);
-    TG_RUN_HIP(hipMemcpyAsync(run->count_host[j], pio.counts + 3, sizeof(int32_t), hipMemcpyDeviceToHost, L->s));
-    TG_RUN_HIP(hipEventRecord(L->counted[j], L->s));
+  auto ctx_of = [&](int64_t k) { return (int)(((k / G) & 1) * G + k % G); };
+  // the passes (collate-only, list form) of group q on the side stream; every count follows its pass to the host
+  auto passes = [&](int64_t q) {
+    for (int64_t k = q * G; k < std::min<int64_t>((q + 1) * G, count) && rc == TG_OK; ++k) {
+      const int c = ctx_of(k);
+      tg_step_io pio = *run->pass_io[c];
+      pio.offset_dev = const_cast<int64_t*>(run->offsets + k);
+      pio.advance = 0;
+      rc = tg_stream_step(m, g, &pio, run->pass_ws[c], run->pass_ws_bytes[c], L->s);
+      if (rc == TG_OK && run->batch_dev) hipLaunchKernelGGL(k_inc_i64, dim3(1), dim3(64), 0, L->s, run->batch_dev);
+      TG_RUN_HIP(hipMemcpyAsync(run->count_host[c], pio.counts + 3, sizeof(int32_t), hipMemcpyDeviceToHost, L->s));
+      TG_RUN_HIP(hipEventRecord(L->counted[c], L->s));
+    }
   };
   TG_RUN_HIP(hipEventRecord(L->join, st));  // whatever the caller enqueued (the bitmap it handed over) precedes the passes
   TG_RUN_HIP(hipStreamWaitEvent(L->s, L->join, 0));
-  pass(0);
-  for (int64_t k = 0; k < count && rc == TG_OK; ++k) {
-    const int j = (int)(k % TG_RUN_CTX);
-    // the count of pass k: enqueued an iteration ago AHEAD of forward k - 1, so the host finds it there
-    TG_RUN_HIP(hipEventSynchronize(L->counted[j]));
+  passes(0);
+  for (int64_t q = 0; q < n_groups && rc == TG_OK; ++q) {
+    const int set = (int)(q & 1);
+    const int64_t k0 = q * G, k1 = std::min<int64_t>(k0 + G, count);
+    // the counts of this group's passes: enqueued a group ago AHEAD of the previous forward, so the host finds them there
+    const int64_t* lists[TG_RESTART_MAX_LISTS];
+    const float* tmins[TG_RESTART_MAX_LISTS];
+    int64_t counts[TG_RESTART_MAX_LISTS], total = 0;
+    for (int64_t k = k0; k < k1 && rc == TG_OK; ++k) {
+      const int c = ctx_of(k);
+      TG_RUN_HIP(hipEventSynchronize(L->counted[c]));
+      if (rc != TG_OK) break;
+      const int64_t n = *run->count_host[c];
+      if (n < 0 || n > run->cap) rc = TG_EINVAL;
+      if (run->n_restarted) run->n_restarted[k] = (int32_t)n;
+      lists[k - k0] = run->pass_io[c]->lazy->list;
+      tmins[k - k0] = run->pass_io[c]->lazy->tmin;
+      counts[k - k0] = n;
+      total += n;
+    }
+    if (rc == TG_OK && total > run->rows_cap) rc = TG_EINVAL;
     if (rc != TG_OK) break;
-    const int64_t n = *run->count_host[j];
-    if (run->n_restarted) run->n_restarted[k] = (int32_t)n;
-    if (n < 0 || n > run->cap) {
-      rc = TG_EINVAL;
-      break;
+    // the next group's passes write the other half of the contexts: last read by the forward before this one, same stream
+    if (q + 1 < n_groups) passes(q + 1);
+    if (total && rc == TG_OK) {
+      // row set `set` was read by the apply of group q - 2 (long done in the steady state: the side stream does not wait)
+      if (q >= 2) TG_RUN_HIP(hipStreamWaitEvent(L->s, L->applied[set], 0));
+      // ONE forward over the group's lists (reads the graph, the features, its parameters) beside the previous group's steps
+      if (rc == TG_OK)
+        rc = tg_restart_seq_lists_fwd(m, run->g_restart, r, (int32_t)(k1 - k0), lists, counts, tmins, run->ids[set],
+                                      run->h_left[set], run->h_right[set], run->prev_ts[set], run->fwd_ws, run->fwd_ws_bytes,
+                                      L->s);
+      TG_RUN_HIP(hipEventRecord(L->fwd_done[set], L->s));
+      // ... and the state the rows go to, on the caller's stream: the whole group at once - a node listed for batch k + 1
+      // is not involved in batch k (it would have been listed there), so step k neither reads nor writes it
+      TG_RUN_HIP(hipStreamWaitEvent(st, L->fwd_done[set], 0));
+      if (rc == TG_OK)
+        rc = tg_restart_apply(m, total, run->ids[set], run->h_left[set], run->h_right[set], run->prev_ts[set], st);
+      if (rc == TG_OK && run->gtab_ws)
+        rc = tg_attn_gtab_rows(m, total, run->ids[set], nullptr, run->gtab_ws, run->gtab_ws_bytes, st);
     }
-    if (k + 1 < count) {
-      // context (k + 1) % 3 is written next: apply k - 2 and the table rows behind it have read its list and rows - long
-      // done in the steady state, so the side stream never waits for the steps
-      if (k >= 2) TG_RUN_HIP(hipStreamWaitEvent(L->s, L->applied[(k + 1) % TG_RUN_CTX], 0));
-      pass(k + 1);
+    TG_RUN_HIP(hipEventRecord(L->applied[set], st));
+    for (int64_t k = k0; k < k1 && rc == TG_OK; ++k) {
+      tg_train_io sio = *step_io;
+      if (run->pos_scores) sio.pos_scores = run->pos_scores + k * B;
+      if (run->neg_scores) sio.neg_scores = run->neg_scores + k * B;
+      rc = tg_train_step(m, g, &sio, step_ws, step_ws_bytes, st);
     }
-    const tg_lazy_restart* lz = run->pass_io[j]->lazy;
-    if (n && rc == TG_OK) {
-      // the restarter's rows of the listed nodes (reads the graph, the features, its parameters) beside step k - 1 ...
-      rc = tg_restart_seq_list_fwd(m, run->g_restart, r, n, lz->list, nullptr, lz->tmin, run->h_left[j], run->h_right[j],
-                                   run->prev_ts[j], run->fwd_ws, run->fwd_ws_bytes, L->s);
-      TG_RUN_HIP(hipEventRecord(L->fwd_done[j], L->s));
-      // ... and the state they go to, on the caller's stream
-      TG_RUN_HIP(hipStreamWaitEvent(st, L->fwd_done[j], 0));
-      if (rc == TG_OK) rc = tg_restart_apply(m, n, lz->list, run->h_left[j], run->h_right[j], run->prev_ts[j], st);
-      if (rc == TG_OK && run->gtab_ws) rc = tg_attn_gtab_rows(m, n, lz->list, nullptr, run->gtab_ws, run->gtab_ws_bytes, st);
-    }
-    TG_RUN_HIP(hipEventRecord(L->applied[j], st));
-    if (rc != TG_OK) break;
-    tg_train_io sio = *step_io;
-    if (run->pos_scores) sio.pos_scores = run->pos_scores + k * B;
-    if (run->neg_scores) sio.neg_scores = run->neg_scores + k * B;
-    rc = tg_train_step(m, g, &sio, step_ws, step_ws_bytes, st);
   }
 #undef TG_RUN_HIP
   // the caller's stream is ordered behind the side stream again (the bitmap the passes marked; on an error: whatever is in flight)

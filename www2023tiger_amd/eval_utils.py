@@ -268,40 +268,50 @@ class _RestartPipeline:
 
 
 class _RestartRun:
-    """Batches [k0, count) of the restart-mode pass as ONE library call (tg_eval_restart_run: the calls of _RestartPipeline's
-    two-stream form - pass, restarter's forward, apply, table rows, step - sequenced by the library, which spends ~3 us of
-    host time per launch where this module spent 0.24 ms per batch; the pass is then bound by the device again).
-    SeqRestarter in inference form, no pre-drawn triggers; the lists' capacity sizes the restarter's workspace, so huge
-    batches over huge graphs stay with _RestartPipeline (WS_LIMIT)."""
+    """Batches [k0, count) of the restart-mode pass as ONE library call (tg_eval_restart_run; contract in tiger_hip.h): the
+    calls of the per-batch loop - pass, restarter's forward, apply, table rows, step - sequenced by the library on two
+    streams, the forward / apply / table rows once per GROUP of batches (their lists are disjoint and a node listed for batch
+    k + 1 is not involved in batch k).  The library spends ~3 us of host time per launch where this module spent 0.24 ms per
+    batch, and the restarter's dozen latency-bound launches are shared by a group.  SeqRestarter in inference form, no
+    pre-drawn triggers; the capacity of a group's lists sizes the restarter's workspace: the group shrinks until it fits
+    WS_LIMIT, huge batches over huge graphs stay with _RestartPipeline."""
     WS_LIMIT = 6 << 30
 
-    def __init__(self, model, tb, graph, first, count):
-        self.model, self.tb, self.graph, self.first, self.count = model, tb, graph, first, count
+    def __init__(self, model, tb, graph, first, count, group):
+        self.model, self.tb, self.graph, self.first, self.count, self.group = model, tb, graph, first, count, group
         self.counts = []
 
     @staticmethod
-    def applies(model, tb, count):
+    def plan(model, tb, count):
+        """-> batches per group (0: the run does not apply)"""
         if os.environ.get('TG_EVAL_RESTART_RUN', '1') == '0' or count < 2 or not model.restart_list_split_ok():
-            return False
+            return 0
         if bool(tb.sb.lazy_trigger.any()) or model.n_layers != 1:
-            return False
+            return 0
         import ctypes as C
         m, rs = model.model_struct(), model.restarter_fn._struct()
         cap = int(tb.sb._lazy_collate.lazy_list.numel())
-        return 0 < int(lib.tg_restart_seq_list_workspace_bytes(C.byref(m), C.byref(rs), cap)) <= _RestartRun.WS_LIMIT
+        G = max(1, min(8, int(os.environ.get('TG_EVAL_RESTART_GROUP', '4'))))
+        while G >= 1:
+            rows_cap = min(G * cap, model.n_nodes)
+            if 0 < int(lib.tg_restart_seq_list_workspace_bytes(C.byref(m), C.byref(rs), rows_cap)) <= _RestartRun.WS_LIMIT:
+                return G
+            G //= 2
+        return 0
 
     def run(self, k0, pos_ptr, neg_ptr):
         """Batches k0 .. count - 1; `pos_ptr` / `neg_ptr`: where batch k0's logits go (those of the later ones behind them)."""
         import ctypes as C
         from ._lib import TgRestartRun
-        model, tb, sb = self.model, self.tb, self.tb.sb
+        model, tb, sb, G = self.model, self.tb, self.tb.sb, self.group
         dev, d, nb = model.device, model.memory_dim, self.count - k0
-        ctx = [sb._lazy_collate, sb.lazy_collate_context(model), sb.lazy_collate_context(model)]  # (tg_restart_run: three rotate)
+        ctx = [sb._lazy_collate] + [sb.lazy_collate_context(model) for _ in range(2 * G - 1)]
         cap = int(ctx[0].lazy_list.numel())
+        rows_cap = min(G * cap, model.n_nodes)
         offsets = self.first + torch.arange(k0, self.count, dtype=torch.int64, device=dev) * sb.B
-        host = torch.zeros(3, 16, dtype=torch.int32).pin_memory()
-        rows = [(torch.empty(cap, d, device=dev), torch.empty(cap, d, device=dev), torch.empty(cap, device=dev))
-                for _ in range(3)]
+        host = torch.zeros(2 * G, 16, dtype=torch.int32).pin_memory()
+        rows = [(torch.empty(rows_cap, dtype=torch.int64, device=dev), torch.empty(rows_cap, d, device=dev),
+                 torch.empty(rows_cap, d, device=dev), torch.empty(rows_cap, device=dev)) for _ in range(2)]
         eager = model._pending is not None
         if eager:  # the protocol of TrainBuffers.launch: tables synchronised before, kept current by the steps themselves
             if model._fused is not None and model._fused_stamp != model._attn_stamp():
@@ -309,18 +319,21 @@ class _RestartRun:
             model._sync_pending()
             model._sync_gtab()
         m, rs = model.model_struct(), model.restarter_fn._struct()
-        nbytes = int(lib.tg_restart_seq_list_workspace_bytes(C.byref(m), C.byref(rs), cap))
+        nbytes = int(lib.tg_restart_seq_list_workspace_bytes(C.byref(m), C.byref(rs), rows_cap))
         fwd_ws = torch.empty(nbytes + 1024, dtype=torch.uint8, device=dev)
-        gtab_ws = model._ws('gtab_r', cap * (4 * d + 4) + 64) if (eager and getattr(model, '_gtab', None) is not None) else None
+        gtab_ws = (model._ws('gtab_r', rows_cap * (4 * d + 4) + 64)
+                   if (eager and getattr(model, '_gtab', None) is not None) else None)
         n_restarted = np.zeros(nb, dtype=np.int32)
         run = TgRestartRun()
+        run.group = G
         for j, cb in enumerate(ctx):
             cb._lazy.keep_msg_bits = 1
             run.pass_io[j], run.pass_ws[j], run.pass_ws_bytes[j] = C.addressof(cb.io), ptr(cb.ws), cb.ws.numel()
             run.count_host[j] = host[j].data_ptr()
-            run.h_left[j], run.h_right[j], run.prev_ts[j] = (ptr(t) for t in rows[j])
+        for j in range(2):
+            run.ids[j], run.h_left[j], run.h_right[j], run.prev_ts[j] = (ptr(t) for t in rows[j])
         run.g_restart = C.addressof(model.restarter_fn.graph.tcsr)
-        run.offsets, run.batch_dev, run.cap = ptr(offsets), ptr(sb.lazy_batch), cap
+        run.offsets, run.batch_dev, run.cap, run.rows_cap = ptr(offsets), ptr(sb.lazy_batch), cap, rows_cap
         run.fwd_ws, run.fwd_ws_bytes = ptr(fwd_ws), fwd_ws.numel()
         if gtab_ws is not None:
             run.gtab_ws, run.gtab_ws_bytes = ptr(gtab_ws), gtab_ws.numel()
@@ -397,8 +410,9 @@ def _eval_resident_run(model, ds, bs, dev, N, lo, hi, graph, TrainBuffers, lean,
         pipe = runner = None
         if (restart_mode and not tb._restart_in_step and dev.type == 'cuda'
                 and os.environ.get('TG_EVAL_RESTART_PIPELINE', '1') != '0'):
-            if _RestartRun.applies(model, tb, count):
-                runner = _RestartRun(model, tb, graph, first, count)
+            group = _RestartRun.plan(model, tb, count)
+            if group:
+                runner = _RestartRun(model, tb, graph, first, count, group)
                 runs.append(runner)
             else:
                 pipe = _RestartPipeline(model, tb, graph, first, count)
