@@ -534,3 +534,22 @@ def test_restarter_forward_on_empty_and_minimal_histories(name, H):
         model.restart_list(torch.from_numpy(nids).to(dev()), torch.tensor([t], dtype=torch.float32, device=dev()))
         assert torch.equal(a[0], model.left_memory.vals) and torch.equal(a[1], model.right_memory.vals)
         assert torch.equal(a[2], model.left_memory.update_ts)
+    # several lists in one forward, each at its own time (tg_restart_seq_lists_fwd; an empty list among them): the rows of the
+    # per-list calls, bit for bit
+    tdev = lambda t: torch.tensor([t], dtype=torch.float32, device=dev())
+    ids_all = torch.arange(1, n_nodes, dtype=torch.int64, device=dev())
+    cut = (n_nodes - 1) // 3
+    lists = [ids_all[:cut], ids_all[:0], ids_all[cut:cut + 1], ids_all[cut + 1:]]
+    times = [tdev(0.3 * tmax), tdev(0.0), tdev(0.0), tdev(tmax + 1.0)]
+    ids, hl, hr, pt = model.restart_lists_forward(lists, times)
+    assert torch.equal(ids, ids_all)
+    at = 0
+    for nl, tl in zip(lists, times):
+        k = int(nl.numel())
+        if not k:
+            continue
+        one = [torch.empty(k, cfg['d'], device=dev()), torch.empty(k, cfg['d'], device=dev()), torch.empty(k, device=dev())]
+        model.restart_list_forward(nl, tl, *one)
+        for a_, b_ in zip(one, (hl[at:at + k], hr[at:at + k], pt[at:at + k])):
+            assert torch.equal(a_, b_)
+        at += k

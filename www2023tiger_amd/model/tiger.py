@@ -176,6 +176,28 @@ class TIGE(nn.Module):
                                           ptr(h_left), ptr(h_right), ptr(prev_ts), ptr(ws), ws.numel(),
                                           stream_ptr(self.device)), 'tg_restart_seq_list_fwd')
 
+    def restart_lists_forward(self, lists, t_devs):
+        """`restart_list_forward` over several device-resident lists at once, each at its own device-resident time
+        (tg_restart_seq_lists_fwd: one forward; at most 8 lists) -> (ids, h_left, h_right, prev_ts): the lists concatenated
+        (empty ones skipped) and their rows.  The lists of consecutive batches of a restart loop are independent of each other."""
+        r, dev, d = self.restarter_fn, self.device, self.memory_dim
+        counts = [int(x.numel()) for x in lists]
+        n = sum(counts)
+        ids = torch.empty(n, dtype=torch.int64, device=dev)
+        hl, hr, pt = torch.empty(n, d, device=dev), torch.empty(n, d, device=dev), torch.empty(n, device=dev)
+        if n == 0:
+            return ids, hl, hr, pt
+        m, rs = self.model_struct(), r._struct()
+        nbytes = int(lib.tg_restart_seq_list_workspace_bytes(C.byref(m), C.byref(rs), n))
+        ws = torch.empty(nbytes + 1024, dtype=torch.uint8, device=dev)
+        k = len(lists)
+        lp = (C.c_void_p * k)(*[ptr(x) for x in lists])
+        tp = (C.c_void_p * k)(*[ptr(t) for t in t_devs])
+        cn = (C.c_int64 * k)(*counts)
+        check(lib.tg_restart_seq_lists_fwd(C.byref(m), C.byref(r.graph.tcsr), C.byref(rs), k, lp, cn, tp, ptr(ids), ptr(hl), ptr(hr),
+                                           ptr(pt), ptr(ws), ws.numel(), stream_ptr(dev)), 'tg_restart_seq_lists_fwd')
+        return ids, hl, hr, pt
+
     def restart_list_apply(self, nids: Tensor, h_left: Tensor, h_right: Tensor, prev_ts: Tensor):
         """The state update of `restart_list` (tiger.py:603,608-609) from rows `restart_list_forward` left."""
         self._touch()
