@@ -751,7 +751,8 @@ typedef struct tg_restart_run {
   float* h_left[2];             /* [rows_cap, d] per set: the restarter's rows */
   float* h_right[2];
   float* prev_ts[2];            /* [rows_cap] */
-  void* fwd_ws;                 /* tg_restart_seq_list_workspace_bytes(m, r, rows_cap) */
+  int64_t fwd_nodes;            /* nodes per forward (> 0; a group with more takes several, each over <= fwd_nodes of them) */
+  void* fwd_ws;                 /* tg_restart_seq_list_workspace_bytes(m, r, fwd_nodes) */
   size_t fwd_ws_bytes;
   void* gtab_ws;                /* rows_cap * d floats + 64 bytes, or NULL: no per-node tables to follow */
   size_t gtab_ws_bytes;

@@ -373,6 +373,7 @@ def test_restart_mode_eval_on_two_streams_equals_one_stream(monkeypatch):
     monkeypatch.setattr(eval_utils._RestartRun, 'run', lambda self, *a: (orig_run(self, *a), counts.extend(self.counts))[0])
     knobs = ('TG_EVAL_RESTART_RUN', 'TG_EVAL_RESTART_OVERLAP', 'TG_EVAL_RESTART_PIPELINE', 'TG_EVAL_RESTART_GROUP')
     for form, env in (('run', {}), ('run1', dict(TG_EVAL_RESTART_GROUP='1')), ('run3', dict(TG_EVAL_RESTART_GROUP='3')),
+                      ('chunks', dict(TG_EVAL_RESTART_GROUP='8')),  # (+ 64 nodes per forward: whole and partial lists per call)
                       ('two', dict(TG_EVAL_RESTART_RUN='0')),
                       ('one', dict(TG_EVAL_RESTART_RUN='0', TG_EVAL_RESTART_OVERLAP='0')),
                       ('plain', dict(TG_EVAL_RESTART_PIPELINE='0'))):
@@ -383,14 +384,17 @@ def test_restart_mode_eval_on_two_streams_equals_one_stream(monkeypatch):
         model.reset()
         up = set()
         del counts[:]
+        monkeypatch.setattr(eval_utils._RestartRun, 'FWD_NODES', 64 if form == 'chunks' else 2048)
         res = eval_utils.eval_edge_prediction(model, BatchLoader(data, B, coll), dev(), restart_mode=True, uptodate_nodes=up,
                                               mean_over_n_samples=200)
+        if form == 'chunks':
+            assert max(counts) > 64  # a single list did exceed a forward's capacity
         if form in ('run', 'two'):
             assert sum(1 for c in counts if c) >= nb // 2  # restarts in most batches: the two streams did meet
         out[form] = (res, sorted(up), model.left_memory.vals.clone(), model.right_memory.vals.clone(),
                      model.left_memory.update_ts.clone(), model.msg_store.node_msg_vals.clone(),
                      model.msg_store.has_msg_mask().clone())
-    for other in ('run1', 'run3', 'two', 'one', 'plain'):
+    for other in ('run1', 'run3', 'chunks', 'two', 'one', 'plain'):
         assert out['run'][0] == out[other][0] and out['run'][1] == out[other][1], other
         for a, b in zip(out['run'][2:], out[other][2:]):
             assert torch.equal(a, b), other

@@ -1,5 +1,4 @@
 set -e
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -x -q -m gpu 2>&1 | tee gpurun_out/t_full.log | tail -8
-timeout -k 10 500 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
-tail -c 600 gpurun_out/bench_default.json
+timeout -k 10 500 python -m pytest tests/test_hip_eval.py tests/test_cabi_host.py -x -q -m gpu -k "restart or layout" 2>&1 | tee gpurun_out/t_eval.log | tail -15
+timeout -k 10 200 python tools/prof_restart_loop.py 500 2>&1 | grep "ms per batch"

@@ -86,7 +86,7 @@ class TgRestartRun(C.Structure):
     _fields_ = [('group', i32), ('reserved', i32), ('pass_io', vp * 16), ('pass_ws', vp * 16), ('pass_ws_bytes', sz * 16),
                 ('g_restart', vp), ('offsets', vp), ('batch_dev', vp), ('count_host', vp * 16), ('cap', i64), ('rows_cap', i64),
                 ('ids', vp * 2), ('h_left', vp * 2), ('h_right', vp * 2), ('prev_ts', vp * 2),
-                ('fwd_ws', vp), ('fwd_ws_bytes', sz), ('gtab_ws', vp), ('gtab_ws_bytes', sz),
+                ('fwd_nodes', i64), ('fwd_ws', vp), ('fwd_ws_bytes', sz), ('gtab_ws', vp), ('gtab_ws_bytes', sz),
                 ('pos_scores', vp), ('neg_scores', vp), ('n_restarted', vp)]
 
 

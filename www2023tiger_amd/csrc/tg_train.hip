@@ -1214,7 +1214,7 @@ extern "C" int tg_eval_restart_run(const tg_model* m, const tg_tcsr* g, const tg
   if (count == 0) return TG_OK;
   const int G = run->group;
   if (G < 1 || G > TG_RESTART_MAX_LISTS || step_io->grads || !run->g_restart || !run->offsets || run->cap <= 0 ||
-      run->rows_cap <= 0 || !run->fwd_ws)
+      run->rows_cap <= 0 || run->fwd_nodes <= 0 || !run->fwd_ws)
     return TG_EINVAL;
   for (int j = 0; j < 2 * G; ++j) {
     const tg_step_io* p = run->pass_io[j];
@@ -1284,10 +1284,36 @@ extern "C" int tg_eval_restart_run(const tg_model* m, const tg_tcsr* g, const tg
       // row set `set` was read by the apply of group q - 2 (long done in the steady state: the side stream does not wait)
       if (q >= 2) TG_RUN_HIP(hipStreamWaitEvent(L->s, L->applied[set], 0));
       // ONE forward over the group's lists (reads the graph, the features, its parameters) beside the previous group's steps
-      if (rc == TG_OK)
-        rc = tg_restart_seq_lists_fwd(m, run->g_restart, r, (int32_t)(k1 - k0), lists, counts, tmins, run->ids[set],
-                                      run->h_left[set], run->h_right[set], run->prev_ts[set], run->fwd_ws, run->fwd_ws_bytes,
-                                      L->s);
+      // (in chunks of fwd_nodes nodes - the workspace's capacity, far below the lists' bound, which only the first batches
+      //  of a stream come near: a chunk is a run of whole and partial lists)
+      int li = 0;
+      int64_t lo = 0, done = 0;
+      while (li < (int)(k1 - k0) && rc == TG_OK) {
+        const int64_t* sub[TG_RESTART_MAX_LISTS];
+        const float* sub_t[TG_RESTART_MAX_LISTS];
+        int64_t sub_n[TG_RESTART_MAX_LISTS], room = run->fwd_nodes;
+        int ns = 0;
+        while (li < (int)(k1 - k0) && room > 0) {
+          const int64_t take = std::min(counts[li] - lo, room);
+          if (take > 0) {
+            sub[ns] = lists[li] + lo;
+            sub_t[ns] = tmins[li];
+            sub_n[ns++] = take;
+            room -= take;
+            lo += take;
+          }
+          if (lo == counts[li]) {
+            ++li;
+            lo = 0;
+          }
+        }
+        const int64_t chunk = run->fwd_nodes - room;
+        if (chunk > 0)
+          rc = tg_restart_seq_lists_fwd(m, run->g_restart, r, ns, sub, sub_n, sub_t, run->ids[set] + done,
+                                        run->h_left[set] + done * m->d, run->h_right[set] + done * m->d,
+                                        run->prev_ts[set] + done, run->fwd_ws, run->fwd_ws_bytes, L->s);
+        done += chunk;
+      }
       TG_RUN_HIP(hipEventRecord(L->fwd_done[set], L->s));
       // ... and the state the rows go to, on the caller's stream: the whole group at once - a node listed for batch k + 1
       // is not involved in batch k (it would have been listed there), so step k neither reads nor writes it

@@ -273,31 +273,38 @@ class _RestartRun:
     streams, the forward / apply / table rows once per GROUP of batches (their lists are disjoint and a node listed for batch
     k + 1 is not involved in batch k).  The library spends ~3 us of host time per launch where this module spent 0.24 ms per
     batch, and the restarter's dozen latency-bound launches are shared by a group.  SeqRestarter in inference form, no
-    pre-drawn triggers; the capacity of a group's lists sizes the restarter's workspace: the group shrinks until it fits
-    WS_LIMIT, huge batches over huge graphs stay with _RestartPipeline."""
-    WS_LIMIT = 6 << 30
+    pre-drawn triggers.  Memory: two row sets for a group's lists at their bound (the group shrinks until they fit ROWS_LIMIT)
+    and the restarter's workspace for FWD_NODES nodes per forward (a group with more takes several forwards)."""
+    WS_LIMIT = 2 << 30   # the restarter's workspace (sized for FWD_NODES nodes per forward, halved until it fits)
+    ROWS_LIMIT = 2 << 30  # the two row sets of a group (ids, both memories' rows, times)
+    FWD_NODES = 2048      # far below the lists' bound (3 B (K + 1) per batch), which only the first batches of a stream approach
 
-    def __init__(self, model, tb, graph, first, count, group):
-        self.model, self.tb, self.graph, self.first, self.count, self.group = model, tb, graph, first, count, group
+    def __init__(self, model, tb, graph, first, count, plan):
+        self.model, self.tb, self.graph, self.first, self.count = model, tb, graph, first, count
+        self.group, self.fwd_nodes = plan
         self.counts = []
 
     @staticmethod
     def plan(model, tb, count):
-        """-> batches per group (0: the run does not apply)"""
+        """-> (batches per group, nodes per forward), or None: the run does not apply"""
         if os.environ.get('TG_EVAL_RESTART_RUN', '1') == '0' or count < 2 or not model.restart_list_split_ok():
-            return 0
+            return None
         if bool(tb.sb.lazy_trigger.any()) or model.n_layers != 1:
-            return 0
+            return None
         import ctypes as C
         m, rs = model.model_struct(), model.restarter_fn._struct()
-        cap = int(tb.sb._lazy_collate.lazy_list.numel())
+        cap, d = int(tb.sb._lazy_collate.lazy_list.numel()), model.memory_dim
         G = max(1, min(8, int(os.environ.get('TG_EVAL_RESTART_GROUP', '4'))))
-        while G >= 1:
-            rows_cap = min(G * cap, model.n_nodes)
-            if 0 < int(lib.tg_restart_seq_list_workspace_bytes(C.byref(m), C.byref(rs), rows_cap)) <= _RestartRun.WS_LIMIT:
-                return G
+        while G > 1 and 2 * min(G * cap, model.n_nodes) * (8 * d + 12) > _RestartRun.ROWS_LIMIT:
             G //= 2
-        return 0
+        if 2 * min(G * cap, model.n_nodes) * (8 * d + 12) > _RestartRun.ROWS_LIMIT:
+            return None
+        nodes = min(_RestartRun.FWD_NODES, min(G * cap, model.n_nodes))
+        while nodes >= 64:
+            if 0 < int(lib.tg_restart_seq_list_workspace_bytes(C.byref(m), C.byref(rs), nodes)) <= _RestartRun.WS_LIMIT:
+                return G, nodes
+            nodes //= 2
+        return None
 
     def run(self, k0, pos_ptr, neg_ptr):
         """Batches k0 .. count - 1; `pos_ptr` / `neg_ptr`: where batch k0's logits go (those of the later ones behind them)."""
@@ -319,7 +326,7 @@ class _RestartRun:
             model._sync_pending()
             model._sync_gtab()
         m, rs = model.model_struct(), model.restarter_fn._struct()
-        nbytes = int(lib.tg_restart_seq_list_workspace_bytes(C.byref(m), C.byref(rs), rows_cap))
+        nbytes = int(lib.tg_restart_seq_list_workspace_bytes(C.byref(m), C.byref(rs), self.fwd_nodes))
         fwd_ws = torch.empty(nbytes + 1024, dtype=torch.uint8, device=dev)
         gtab_ws = (model._ws('gtab_r', rows_cap * (4 * d + 4) + 64)
                    if (eager and getattr(model, '_gtab', None) is not None) else None)
@@ -334,7 +341,7 @@ class _RestartRun:
             run.ids[j], run.h_left[j], run.h_right[j], run.prev_ts[j] = (ptr(t) for t in rows[j])
         run.g_restart = C.addressof(model.restarter_fn.graph.tcsr)
         run.offsets, run.batch_dev, run.cap, run.rows_cap = ptr(offsets), ptr(sb.lazy_batch), cap, rows_cap
-        run.fwd_ws, run.fwd_ws_bytes = ptr(fwd_ws), fwd_ws.numel()
+        run.fwd_nodes, run.fwd_ws, run.fwd_ws_bytes = self.fwd_nodes, ptr(fwd_ws), fwd_ws.numel()
         if gtab_ws is not None:
             run.gtab_ws, run.gtab_ws_bytes = ptr(gtab_ws), gtab_ws.numel()
         run.pos_scores, run.neg_scores = pos_ptr, neg_ptr
@@ -410,9 +417,9 @@ def _eval_resident_run(model, ds, bs, dev, N, lo, hi, graph, TrainBuffers, lean,
         pipe = runner = None
         if (restart_mode and not tb._restart_in_step and dev.type == 'cuda'
                 and os.environ.get('TG_EVAL_RESTART_PIPELINE', '1') != '0'):
-            group = _RestartRun.plan(model, tb, count)
-            if group:
-                runner = _RestartRun(model, tb, graph, first, count, group)
+            plan = _RestartRun.plan(model, tb, count)
+            if plan:
+                runner = _RestartRun(model, tb, graph, first, count, plan)
                 runs.append(runner)
             else:
                 pipe = _RestartPipeline(model, tb, graph, first, count)
