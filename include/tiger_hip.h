@@ -448,6 +448,12 @@ int tg_restart_seq_lists_fwd(const tg_model* m, const tg_tcsr* g, const tg_seq_r
                              const int64_t* const* lists, const int64_t* counts, const float* const* t_dev,
                              int64_t* ids_out, float* h_left, float* h_right, float* prev_ts, void* ws, size_t ws_bytes,
                              void* stream);
+/* The StaticRestarter (restarters.py:254-277) in the same form: h_left / h_right = the rows of its two tables, prev_ts = the
+ * time of the node's last event strictly before the list's time (0: none).  One launch, no workspace. */
+int tg_restart_static_lists_fwd(const tg_model* m, const tg_tcsr* g, const float* static_left, const float* static_right,
+                                int32_t n_lists, const int64_t* const* lists, const int64_t* counts,
+                                const float* const* t_dev, int64_t* ids_out, float* h_left, float* h_right, float* prev_ts,
+                                void* stream);
 
 /* TIGER.restart's state update (tiger.py:603,608-609): clear has-message bits of
  * nids, then left/right memory rows and timestamps <- (h_left, h_right, prev_ts)
@@ -718,7 +724,8 @@ int tg_train_step(const tg_model* m, const tg_tcsr* g, const tg_train_io* io, vo
 
 /* The evaluation pass in RESTART MODE (eval_utils.py:37-42 inside the loop of :60-75: before every batch, the involved
  * nodes that are not up to date are re-initialised by TIGER.restart at the batch's earliest time) over `count` consecutive
- * batches of a device-resident stream as ONE call, SeqRestarter in inference form.  Per batch k the host-side loop makes
+ * batches of a device-resident stream as ONE call, SeqRestarter in inference form (or, r == NULL, the StaticRestarter whose
+ * tables the run carries).  Per batch k the host-side loop makes
  * these calls: a collate-only pass in the list form (tg_lazy_restart) lists the nodes, the restarter's forward computes their
  * rows, tg_restart_apply writes them, tg_attn_gtab_rows refreshes their query / centre rows (a model that streams with
  * current per-node tables), tg_train_step in its evaluation form scores the batch.  Here the same calls run on two streams
@@ -752,8 +759,10 @@ typedef struct tg_restart_run {
   float* h_right[2];
   float* prev_ts[2];            /* [rows_cap] */
   int64_t fwd_nodes;            /* nodes per forward (> 0; a group with more takes several, each over <= fwd_nodes of them) */
-  void* fwd_ws;                 /* tg_restart_seq_list_workspace_bytes(m, r, fwd_nodes) */
+  void* fwd_ws;                 /* tg_restart_seq_list_workspace_bytes(m, r, fwd_nodes); unused with the static restarter */
   size_t fwd_ws_bytes;
+  const float* static_left;     /* r == NULL: the StaticRestarter's tables [n_nodes, d] (tg_restart_static_lists_fwd) */
+  const float* static_right;
   void* gtab_ws;                /* rows_cap * d floats + 64 bytes, or NULL: no per-node tables to follow */
   size_t gtab_ws_bytes;
   float* pos_scores;            /* [count * B]: step k writes its logits at k * B (NULL: where step_io points) */

@@ -347,7 +347,8 @@ def test_resident_eval_in_restart_mode_equals_the_per_batch_loop(name, stream, m
             assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-5
 
 
-def test_restart_mode_eval_on_two_streams_equals_one_stream(monkeypatch):
+@pytest.mark.parametrize('restarter', ['seq', 'static'])
+def test_restart_mode_eval_on_two_streams_equals_one_stream(restarter, monkeypatch):
     """The restart-mode pass with the SeqRestarter: passes and the restarter's forward on a side stream beside the previous
     batch's step - sequenced by the library (tg_eval_restart_run, the default) or by the host (eval_utils._RestartPipeline) -
     against the same calls on ONE stream and against the pass without the pipeline.  A Wikipedia-shaped stream where restarts
@@ -359,9 +360,14 @@ def test_restart_mode_eval_on_two_streams_equals_one_stream(monkeypatch):
     B, nb, d, K, H = 100, 60, 32, 10, 16
     n = nb * B + 37  # (+ a ragged last batch: a second pass, whose bitmap is handed over from the first)
     st = bench.make_stream(1500, 300, n, 1.0e5, seed=5, d_e=d)
-    model, _ = bench.build_models(st, d, K, 'left', 'right', restarter='seq', hist_len=H, dropout=0.1)
+    model, _ = bench.build_models(st, d, K, 'left', 'right', restarter=restarter, hist_len=H, dropout=0.1)
+    if restarter == 'static':  # (the reference initialises the tables with zeros: trained values are what a restart is for)
+        torch.manual_seed(3)
+        with torch.no_grad():
+            model.restarter_fn.left_emb.weight.normal_(0.0, 0.5)
+            model.restarter_fn.right_emb.weight.normal_(0.0, 0.5)
     model.eval()
-    coll = GraphCollator(model.graph, K, 1, restarter='seq', hist_len=H)
+    coll = GraphCollator(model.graph, K, 1, restarter=restarter, hist_len=H)
     neg = np.random.RandomState(2).randint(1501, 1801, n)
     data = InteractionData(st['src'][:n], st['dst'][:n], st['ts'][:n], st['eids'][:n], np.zeros(n, dtype=np.int64), seed=0,
                            eval=True, neg_dst=neg)
@@ -371,25 +377,28 @@ def test_restart_mode_eval_on_two_streams_equals_one_stream(monkeypatch):
     monkeypatch.setattr(eval_utils._RestartPipeline, 'restart', lambda self, k: counts.append(orig(self, k)) or counts[-1])
     orig_run = eval_utils._RestartRun.run
     monkeypatch.setattr(eval_utils._RestartRun, 'run', lambda self, *a: (orig_run(self, *a), counts.extend(self.counts))[0])
-    knobs = ('TG_EVAL_RESTART_RUN', 'TG_EVAL_RESTART_OVERLAP', 'TG_EVAL_RESTART_PIPELINE', 'TG_EVAL_RESTART_GROUP')
+    knobs = ('TG_EVAL_RESTART_RUN', 'TG_EVAL_RESTART_OVERLAP', 'TG_EVAL_RESTART_PIPELINE', 'TG_EVAL_RESTART_GROUP',
+             'TG_EVAL_RESTART_INSTEP')
     for form, env in (('run', {}), ('run1', dict(TG_EVAL_RESTART_GROUP='1')), ('run3', dict(TG_EVAL_RESTART_GROUP='3')),
                       ('chunks', dict(TG_EVAL_RESTART_GROUP='8')),  # (+ 64 nodes per forward: whole and partial lists per call)
                       ('two', dict(TG_EVAL_RESTART_RUN='0')),
-                      ('one', dict(TG_EVAL_RESTART_RUN='0', TG_EVAL_RESTART_OVERLAP='0')),
-                      ('plain', dict(TG_EVAL_RESTART_PIPELINE='0'))):
+                      ('one', dict(TG_EVAL_RESTART_RUN='0', TG_EVAL_RESTART_OVERLAP='0', TG_EVAL_RESTART_INSTEP='0')),
+                      ('plain', dict(TG_EVAL_RESTART_PIPELINE='0'))):  # (static: 'two' and 'plain' are the in-step loop)
         for k in knobs:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
+        if restarter == 'static' and 'TG_EVAL_RESTART_RUN' not in env:
+            monkeypatch.setenv('TG_EVAL_RESTART_RUN', '2')  # (opt-in for the StaticRestarter: the in-step loop is its default)
         model.reset()
         up = set()
         del counts[:]
         monkeypatch.setattr(eval_utils._RestartRun, 'FWD_NODES', 64 if form == 'chunks' else 2048)
         res = eval_utils.eval_edge_prediction(model, BatchLoader(data, B, coll), dev(), restart_mode=True, uptodate_nodes=up,
                                               mean_over_n_samples=200)
-        if form == 'chunks':
+        if form == 'chunks' and restarter == 'seq':
             assert max(counts) > 64  # a single list did exceed a forward's capacity
-        if form in ('run', 'two'):
+        if form in ('run', 'two') and not (form == 'two' and restarter == 'static'):
             assert sum(1 for c in counts if c) >= nb // 2  # restarts in most batches: the two streams did meet
         out[form] = (res, sorted(up), model.left_memory.vals.clone(), model.right_memory.vals.clone(),
                      model.left_memory.update_ts.clone(), model.msg_store.node_msg_vals.clone(),

@@ -86,7 +86,8 @@ class TgRestartRun(C.Structure):
     _fields_ = [('group', i32), ('reserved', i32), ('pass_io', vp * 16), ('pass_ws', vp * 16), ('pass_ws_bytes', sz * 16),
                 ('g_restart', vp), ('offsets', vp), ('batch_dev', vp), ('count_host', vp * 16), ('cap', i64), ('rows_cap', i64),
                 ('ids', vp * 2), ('h_left', vp * 2), ('h_right', vp * 2), ('prev_ts', vp * 2),
-                ('fwd_nodes', i64), ('fwd_ws', vp), ('fwd_ws_bytes', sz), ('gtab_ws', vp), ('gtab_ws_bytes', sz),
+                ('fwd_nodes', i64), ('fwd_ws', vp), ('fwd_ws_bytes', sz), ('static_left', vp), ('static_right', vp),
+                ('gtab_ws', vp), ('gtab_ws_bytes', sz),
                 ('pos_scores', vp), ('neg_scores', vp), ('n_restarted', vp)]
 
 
@@ -187,8 +188,9 @@ SIGNATURES = {
     'tg_restart_seq_list_workspace_bytes': (sz, [P(TgModel), P(TgSeqRestarter), i64]),
     'tg_restart_seq_list': (C.c_int, [P(TgModel), P(TgTcsr), P(TgSeqRestarter), i64, vp, vp, vp, sz, vp]),
     'tg_restart_seq_list_dev': (C.c_int, [P(TgModel), P(TgTcsr), P(TgSeqRestarter), i64, vp, vp, vp, vp, sz, vp]),
-    'tg_eval_restart_run': (C.c_int, [P(TgModel), P(TgTcsr), P(TgSeqRestarter), vp, vp, sz, P(TgRestartRun), i64, vp]),
+    'tg_eval_restart_run': (C.c_int, [P(TgModel), P(TgTcsr), vp, vp, vp, sz, P(TgRestartRun), i64, vp]),
     'tg_restart_seq_lists_fwd': (C.c_int, [P(TgModel), P(TgTcsr), P(TgSeqRestarter), i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'tg_restart_static_lists_fwd': (C.c_int, [P(TgModel), P(TgTcsr), vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     'tg_restart_seq_list_fwd': (C.c_int, [P(TgModel), P(TgTcsr), P(TgSeqRestarter), i64, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     'tg_profiler_create': (vp, []),
     'tg_profiler_destroy': (None, [vp]),

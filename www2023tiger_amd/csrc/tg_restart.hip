@@ -20,6 +20,7 @@
 // The same sum in another order: float32 reassociation only (the fixtures hold at 1e-4 as before).
 #include <algorithm>
 
+#include "tg_sample.h"
 #include "tg_step.h"
 
 namespace tg {
@@ -1399,6 +1400,28 @@ __global__ void k_concat_lists(SegLists sl, int64_t* __restrict__ ids, double* _
     tu[i] = (double)*sl.t[s];
   }
 }
+// the StaticRestarter over several lists (restarters.py:262-277): both table rows of every listed node and the time of its
+// last event strictly before the list's (float32) time - 0 when there is none
+__global__ void k_static_lists(tg_tcsr g, SegLists sl, int d4, const float4* __restrict__ left, const float4* __restrict__ right,
+                               int64_t* __restrict__ ids, float4* __restrict__ hl, float4* __restrict__ hr,
+                               float* __restrict__ pt) {
+  const int64_t total = sl.off[sl.n] * d4;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / d4;
+    const int c = (int)(t - i * d4);
+    int s = 0;
+    while (s + 1 < sl.n && i >= sl.off[s + 1]) ++s;
+    const int64_t v = sl.ids[s][i - sl.off[s]];
+    hl[t] = left[v * d4 + c];
+    hr[t] = right[v * d4 + c];
+    if (c == 0) {
+      int64_t start;
+      const int64_t end = prefix_end(g, v, (double)*sl.t[s], &start);
+      ids[i] = v;
+      pt[i] = end > start ? (float)g.ts[end - 1] : 0.f;
+    }
+  }
+}
 struct ListWs {
   double* tu;
   int64_t *h_n, *h_e, *h_d, *anon;
@@ -1498,6 +1521,30 @@ extern "C" int tg_restart_seq_lists_fwd(const tg_model* m, const tg_tcsr* g, con
   if (n > 0 && (!ids_out || !h_left || !h_right || !prev_ts)) return TG_EINVAL;
   ListWs w{};
   return list_forward(m, g, r, n, nullptr, nullptr, nullptr, h_left, h_right, prev_ts, ws, ws_bytes, stream, w, &sl, ids_out);
+}
+
+extern "C" int tg_restart_static_lists_fwd(const tg_model* m, const tg_tcsr* g, const float* static_left,
+                                           const float* static_right, int32_t n_lists, const int64_t* const* lists,
+                                           const int64_t* counts, const float* const* t_dev, int64_t* ids_out, float* h_left,
+                                           float* h_right, float* prev_ts, void* stream) {
+  if (m && m->row_of) return TG_EUNSUPPORTED;
+  if (!m || !g || m->d <= 0 || (m->d % 4) || !static_left || !static_right) return TG_EINVAL;
+  if (n_lists <= 0 || n_lists > TG_RESTART_MAX_LISTS || !lists || !counts || !t_dev) return TG_EINVAL;
+  SegLists sl{};
+  for (int j = 0; j < n_lists; ++j) {
+    if (counts[j] < 0 || (counts[j] > 0 && (!lists[j] || !t_dev[j]))) return TG_EINVAL;
+    if (counts[j] == 0) continue;
+    sl.ids[sl.n] = lists[j];
+    sl.t[sl.n] = t_dev[j];
+    sl.off[sl.n + 1] = sl.off[sl.n] + counts[j];
+    ++sl.n;
+  }
+  const int64_t n = sl.off[sl.n];
+  if (n == 0) return TG_OK;
+  if (!ids_out || !h_left || !h_right || !prev_ts) return TG_EINVAL;
+  hipLaunchKernelGGL(k_static_lists, dim3(flat_grid(n * (m->d / 4), 256)), dim3(256), 0, as_stream(stream), *g, sl, m->d / 4,
+                     (const float4*)static_left, (const float4*)static_right, ids_out, (float4*)h_left, (float4*)h_right, prev_ts);
+  return check_launch("tg_restart_static_lists_fwd");
 }
 
 namespace tg {

@@ -1210,11 +1210,11 @@ static EvalLane* eval_lane() {
 extern "C" int tg_eval_restart_run(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, const tg_train_io* step_io,
                                    void* step_ws, size_t step_ws_bytes, const tg_restart_run* run, int64_t count,
                                    void* stream) {
-  if (!m || !g || !r || !step_io || !run || count < 0) return TG_EINVAL;
+  if (!m || !g || !step_io || !run || count < 0) return TG_EINVAL;
   if (count == 0) return TG_OK;
   const int G = run->group;
   if (G < 1 || G > TG_RESTART_MAX_LISTS || step_io->grads || !run->g_restart || !run->offsets || run->cap <= 0 ||
-      run->rows_cap <= 0 || run->fwd_nodes <= 0 || !run->fwd_ws)
+      run->rows_cap <= 0 || run->fwd_nodes <= 0 || (r ? !run->fwd_ws : (!run->static_left || !run->static_right)))
     return TG_EINVAL;
   for (int j = 0; j < 2 * G; ++j) {
     const tg_step_io* p = run->pass_io[j];
@@ -1309,9 +1309,12 @@ extern "C" int tg_eval_restart_run(const tg_model* m, const tg_tcsr* g, const tg
         }
         const int64_t chunk = run->fwd_nodes - room;
         if (chunk > 0)
-          rc = tg_restart_seq_lists_fwd(m, run->g_restart, r, ns, sub, sub_n, sub_t, run->ids[set] + done,
-                                        run->h_left[set] + done * m->d, run->h_right[set] + done * m->d,
-                                        run->prev_ts[set] + done, run->fwd_ws, run->fwd_ws_bytes, L->s);
+          rc = r ? tg_restart_seq_lists_fwd(m, run->g_restart, r, ns, sub, sub_n, sub_t, run->ids[set] + done,
+                                            run->h_left[set] + done * m->d, run->h_right[set] + done * m->d,
+                                            run->prev_ts[set] + done, run->fwd_ws, run->fwd_ws_bytes, L->s)
+                 : tg_restart_static_lists_fwd(m, run->g_restart, run->static_left, run->static_right, ns, sub, sub_n, sub_t,
+                                               run->ids[set] + done, run->h_left[set] + done * m->d,
+                                               run->h_right[set] + done * m->d, run->prev_ts[set] + done, L->s);
         done += chunk;
       }
       TG_RUN_HIP(hipEventRecord(L->fwd_done[set], L->s));

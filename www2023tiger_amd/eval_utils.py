@@ -285,14 +285,27 @@ class _RestartRun:
         self.counts = []
 
     @staticmethod
+    def wanted(model, count):
+        """the cheap part of `plan`: a restarter whose forward reads no state (SeqRestarter in inference form over a
+        recent-edges graph, StaticRestarter), one layer, state addressed by node id, more than one batch"""
+        from .model.restarters import StaticRestarter
+        r = model.restarter_fn
+        if os.environ.get('TG_EVAL_RESTART_RUN', '1') == '0' or count < 2 or model.n_layers != 1 or model.device.type != 'cuda':
+            return False
+        if isinstance(r, StaticRestarter):
+            # TG_EVAL_RESTART_RUN=2 only: measured equal to the loop inside the step (bs 200: 0.118 against 0.115 ms per batch
+            # of the whole harness call), which needs neither contexts nor row sets - that one stays the default
+            return os.environ.get('TG_EVAL_RESTART_RUN', '1') == '2' and getattr(model, '_row_of', None) is None
+        return model.restart_list_split_ok()
+
+    @staticmethod
     def plan(model, tb, count):
         """-> (batches per group, nodes per forward), or None: the run does not apply"""
-        if os.environ.get('TG_EVAL_RESTART_RUN', '1') == '0' or count < 2 or not model.restart_list_split_ok():
-            return None
-        if bool(tb.sb.lazy_trigger.any()) or model.n_layers != 1:
+        if not _RestartRun.wanted(model, count) or bool(tb.sb.lazy_trigger.any()):
             return None
         import ctypes as C
-        m, rs = model.model_struct(), model.restarter_fn._struct()
+        from .model.restarters import StaticRestarter
+        static = isinstance(model.restarter_fn, StaticRestarter)
         cap, d = int(tb.sb._lazy_collate.lazy_list.numel()), model.memory_dim
         G = max(1, min(8, int(os.environ.get('TG_EVAL_RESTART_GROUP', '4'))))
         while G > 1 and 2 * min(G * cap, model.n_nodes) * (8 * d + 12) > _RestartRun.ROWS_LIMIT:
@@ -300,6 +313,9 @@ class _RestartRun:
         if 2 * min(G * cap, model.n_nodes) * (8 * d + 12) > _RestartRun.ROWS_LIMIT:
             return None
         nodes = min(_RestartRun.FWD_NODES, min(G * cap, model.n_nodes))
+        if static:  # (one gather launch per forward, no workspace)
+            return G, min(G * cap, model.n_nodes)
+        m, rs = model.model_struct(), model.restarter_fn._struct()
         while nodes >= 64:
             if 0 < int(lib.tg_restart_seq_list_workspace_bytes(C.byref(m), C.byref(rs), nodes)) <= _RestartRun.WS_LIMIT:
                 return G, nodes
@@ -325,9 +341,16 @@ class _RestartRun:
                 model.fuse_attention()
             model._sync_pending()
             model._sync_gtab()
-        m, rs = model.model_struct(), model.restarter_fn._struct()
-        nbytes = int(lib.tg_restart_seq_list_workspace_bytes(C.byref(m), C.byref(rs), self.fwd_nodes))
-        fwd_ws = torch.empty(nbytes + 1024, dtype=torch.uint8, device=dev)
+        from .model.restarters import StaticRestarter
+        r = model.restarter_fn
+        static = isinstance(r, StaticRestarter)
+        m = model.model_struct()
+        if static:
+            rs, fwd_ws = None, None
+        else:
+            rs = r._struct()
+            nbytes = int(lib.tg_restart_seq_list_workspace_bytes(C.byref(m), C.byref(rs), self.fwd_nodes))
+            fwd_ws = torch.empty(nbytes + 1024, dtype=torch.uint8, device=dev)
         gtab_ws = (model._ws('gtab_r', rows_cap * (4 * d + 4) + 64)
                    if (eager and getattr(model, '_gtab', None) is not None) else None)
         n_restarted = np.zeros(nb, dtype=np.int32)
@@ -341,14 +364,19 @@ class _RestartRun:
             run.ids[j], run.h_left[j], run.h_right[j], run.prev_ts[j] = (ptr(t) for t in rows[j])
         run.g_restart = C.addressof(model.restarter_fn.graph.tcsr)
         run.offsets, run.batch_dev, run.cap, run.rows_cap = ptr(offsets), ptr(sb.lazy_batch), cap, rows_cap
-        run.fwd_nodes, run.fwd_ws, run.fwd_ws_bytes = self.fwd_nodes, ptr(fwd_ws), fwd_ws.numel()
+        run.fwd_nodes = self.fwd_nodes
+        if static:
+            run.static_left, run.static_right = ptr(r.left_emb.weight), ptr(r.right_emb.weight)
+        else:
+            run.fwd_ws, run.fwd_ws_bytes = ptr(fwd_ws), fwd_ws.numel()
         if gtab_ws is not None:
             run.gtab_ws, run.gtab_ws_bytes = ptr(gtab_ws), gtab_ws.numel()
         run.pos_scores, run.neg_scores = pos_ptr, neg_ptr
         run.n_restarted = n_restarted.ctypes.data
         tb.io.step.rows_hint = model.rows_bound()
         try:
-            check(lib.tg_eval_restart_run(C.byref(m), C.byref(self.graph.tcsr), C.byref(rs), C.addressof(tb.io), ptr(tb.ws),
+            check(lib.tg_eval_restart_run(C.byref(m), C.byref(self.graph.tcsr), None if static else C.addressof(rs),
+                                          C.addressof(tb.io), ptr(tb.ws),
                                           tb.ws.numel(), C.byref(run), nb, stream_ptr(dev)), 'tg_eval_restart_run')
         finally:
             for cb in ctx:
@@ -396,8 +424,11 @@ def _eval_resident_run(model, ds, bs, dev, N, lo, hi, graph, TrainBuffers, lean,
             # loop looks the previous event time up in the graph the step samples from); every other case: the list form
             from .model.restarters import StaticRestarter
             r = model.restarter_fn
+            # (the list form as one library call on two streams - _RestartRun - where it applies: faster than the in-step loop)
             in_step = (lean and isinstance(r, StaticRestarter) and getattr(r, 'graph', None) is graph
-                       and os.environ.get('TG_EVAL_RESTART_INSTEP', '1') != '0')
+                       and os.environ.get('TG_EVAL_RESTART_INSTEP', '1') != '0'
+                       and not (dev.type == 'cuda' and os.environ.get('TG_EVAL_RESTART_PIPELINE', '1') != '0'
+                                and _RestartRun.wanted(model, count)))
             tb.sb.enable_lazy_restart(model, np.zeros(count, dtype=np.uint8), force_list=not in_step)
             if in_step:
                 tb.refresh()  # (the step's io is a copy of the buffer's: it now carries the lazy-restart block)
