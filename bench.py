@@ -926,6 +926,19 @@ def train_main(args, cfg):
     resident = tuple(torch.from_numpy(stream[k]).to(dev) for k in ('src', 'dst', 'neg', 'ts', 'eids'))
     tr = FusedTrainer(model, B, lr=1e-4, resident=resident, mutual=rkind != 'none', mutual_coef=1.0)
     _ = model.graph.tcsr, model.model_struct()  # lazy device-side builds happen here, not inside a capture (--warmup 0)
+    lazy = None
+    if args.train_restart_prob > 0 and rkind != 'none':
+        # the lazy-restart loop of train_self_supervised.py:152-163 in front of every iteration (FusedTrainer.enable_lazy_restart):
+        # the draws are made up front; one trigger is placed in the warm-up so that the timed iterations run in the state an
+        # epoch is in from its first trigger on (expected at batch 1 / restart_prob) - every batch re-initialises what it
+        # involves and is not up to date.  Iterations are launched eagerly (the seq form reads one count back per iteration).
+        n_it = args.warmup + args.steps
+        trig = (np.random.RandomState(1).rand(n_it) < args.train_restart_prob).astype(np.uint8)
+        trig[0] = 0
+        trig[max(1, args.warmup // 2)] = 1
+        tr.enable_lazy_restart(trig)
+        args.no_graph = True
+        lazy = dict(restart_prob=args.train_restart_prob, triggers_in_timed_region=int(trig[args.warmup:].sum()), restarted=[])
     # graphs of several iterations (consecutive graph replays are ~9 us apart on the device, see run_stream_leg); the last
     # warm-up iterations are one untimed replay of the graph (uploads it)
     gsteps = 1
@@ -957,6 +970,8 @@ def train_main(args, cfg):
             graph.replay()
         else:
             tr.launch()
+            if lazy is not None and rkind == 'seq':
+                lazy['restarted'].append(tr.restarted)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert int(tr.buf.sb.err.item()) == 0
@@ -964,7 +979,12 @@ def train_main(args, cfg):
     loss = float(tr.buf.losses[0])
     assert np.isfinite(loss)
     extra = {}
-    if rkind == 'seq':
+    if lazy is not None:
+        r = lazy.pop('restarted')
+        if r:
+            lazy.update(restarted_nodes_per_iteration_mean=float(np.mean(r)), restarted_nodes_per_iteration_max=int(max(r)))
+        extra['lazy_restart_loop'] = lazy
+    if rkind == 'seq' and lazy is None:
         try:
             extra['roofline_restarter'] = restarter_roofline(stream, cfg, args, args.warmup, args.steps, dt / args.steps * 1e3)
         except Exception as e:  # a side object: the line does not depend on it
@@ -1028,6 +1048,9 @@ def main():
     ap.add_argument('--train', action='store_true', help='measure the training iteration instead (not the headline metric)')
     ap.add_argument('--train-restarter', default='none', choices=['none', 'seq', 'static'],
                     help='--train: add the mutual-learning loss of this restarter (none = contrast_only)')
+    ap.add_argument('--train-restart-prob', type=float, default=0.0,
+                    help='--train with a restarter: the lazy-restart loop of train_self_supervised.py:152-163 in front of every '
+                         'iteration (the reference default is 0.01); 0 = the training step alone')
     ap.add_argument('--hist-len', type=int, default=40, help='--train-restarter seq: history length (reference default 40, init_utils.py:58)')
     args = ap.parse_args()
     cfg = dict(WORKLOADS[args.workload])

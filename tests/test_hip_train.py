@@ -231,18 +231,35 @@ def test_mutual_gradients_match_oracle(name):
         assert int(tb.flags[2]) == had_grad, b
 
 
-def test_fused_trainer_mutual_trajectory():
+@pytest.mark.parametrize('name', ['train_seq_lr_d8', 'train_static_ll_d16'])
+@pytest.mark.parametrize('loop', ['host_sets', 'device'])
+def test_fused_trainer_mutual_trajectory(loop, name):
     """Full reference recipe (seq restarter, mutual learning, lazy restart at batch 6) with no
-    parameter sync: per-batch losses and final parameters of the reference run."""
+    parameter sync: per-batch losses and final parameters of the reference run.  host_sets: the loop's bookkeeping
+    (train_self_supervised.py:152-163) as the reference writes it, with Python sets; device: FusedTrainer.enable_lazy_restart
+    with the trigger pre-drawn - seq restarter: a collate-only pass lists `involved & ~uptodate` on the device, one count is
+    read back; static restarter: the whole loop body inside the training step."""
     from www2023tiger_amd.model.training import FusedTrainer
-    z = load('train_seq_lr_d8')
+    z = load(name)
     cfg = parse_cfg(z)
     model, _, coll = build_hip_model(z, cfg, dropout=0.0)
     model.train()
     tr = FusedTrainer(model, cfg['B'], lr=cfg['lr'], mutual=True, mutual_coef=cfg['mutual_coef'])
     restarting, uptodate = False, set()
+    if loop == 'device':
+        trigger = np.zeros(cfg['n_batches'], dtype=np.uint8)
+        trigger[cfg['restart_at']] = 1
+        tr.enable_lazy_restart(trigger)
+    n_listed = 0
     for b in range(cfg['n_batches']):
         a = batch(z, cfg, b)
+        if loop == 'device':
+            losses = tr.step(*a)
+            n_listed += tr.restarted if cfg['restarter'] == 'seq' else int(tr.buf.sb.counts[3])
+            assert n_listed == 0 or b >= cfg['restart_at']
+            assert abs(float(losses[0]) - float(z[f'b{b}_contrast_loss'])) < 1e-3, b
+            assert abs(float(losses[1]) - float(z[f'b{b}_mutual_loss'])) < 1e-3, b
+            continue
         if b == cfg['restart_at']:
             restarting, uptodate = True, set()
             model.msg_store.clear()
@@ -254,8 +271,48 @@ def test_fused_trainer_mutual_trajectory():
         losses = tr.step(*a)
         assert abs(float(losses[0]) - float(z[f'b{b}_contrast_loss'])) < 1e-3, b
         assert abs(float(losses[1]) - float(z[f'b{b}_mutual_loss'])) < 1e-3, b
+    assert loop != 'device' or n_listed > 0
     for k, p in model.named_parameters():
         assert rel_err(p.detach().cpu().numpy(), z[f'final.{k}']) < 2e-3, k
+
+
+def test_tables_derived_from_parameters_follow_the_device_optimizer():
+    """tg_adam_step updates parameters through raw pointers - torch's version counters, the stamps of everything derived
+    from parameters (the SeqRestarter's tabulated anony_emb block, pre-multiplied attention weights, eager-update and
+    per-node tables), do not move.  train() starts a new parameter epoch instead: after inference -> training with the
+    device optimizer -> inference on the SAME model, the restarter's rows and a streamed batch's embeddings equal those of a
+    fresh model that carries the trained parameters."""
+    from www2023tiger_amd.model.training import FusedTrainer
+    z = load('train_seq_lr_d8_zeronf')
+    cfg = parse_cfg(z)
+    model, _, _ = build_hip_model(z, cfg, dropout=0.0)
+    model.eval()
+    model.fuse_attention()
+    model.eager_updates()
+    nids = torch.arange(1, int(z['n_nodes']), device=dev())
+    ts = torch.full((len(nids),), float(np.float32(z['ts'].max())), device=dev())
+    with torch.no_grad():
+        before = model.restarter_fn(nids, ts)[0].clone()  # (fills the table of the anony_emb block)
+        model.stream_step(*batch(z, cfg, 0), lean=True)    # (builds the eager-update / per-node tables)
+    assert model.restarter_fn._ta_cache is not None
+    model.train()
+    model.reset()
+    tr = FusedTrainer(model, cfg['B'], lr=5e-2, mutual=True)
+    for b in range(4):
+        tr.step(*batch(z, cfg, b))
+    fresh, _, _ = build_hip_model(z, cfg, dropout=0.0)
+    fresh.load_state_dict({k: v.detach().clone() for k, v in model.state_dict().items()})
+    model.eval(), fresh.eval()
+    model.reset(), fresh.reset()
+    with torch.no_grad():
+        own, ref = model.restarter_fn(nids, ts), fresh.restarter_fn(nids, ts)
+        assert float((own[0] - before).abs().max()) > 1e-3  # the parameters did move
+        for a_, b_ in zip(own, ref):
+            assert torch.equal(a_, b_)
+        for b in range(3):
+            h_own = model.stream_step(*batch(z, cfg, b), lean=True).h.clone()
+            h_ref = fresh.stream_step(*batch(z, cfg, b)).h.clone()
+            assert rel_err(h_own.cpu().numpy(), h_ref.cpu().numpy()) < TOL, b
 
 
 @pytest.mark.parametrize('which', ['torch', 'device-flags'])

@@ -50,6 +50,14 @@ class SeqRestarter(Restarter):
                               lin(self.mha_fn.out_proj), lin(self.out_fn), lin(self.merger.fc1), lin(self.merger.fc2),
                               1 if self.raw_feat_getter.nfeats_all_zero() else 0, 0, ptr(self._ta_table()))
 
+    def train(self, mode: bool = True):
+        """Entering train() mode drops the tabulated anony_emb block: the library's optimizer (tg_adam_step, also inside
+        replayed graphs) updates parameters through raw pointers, which torch's version counters - the table's key - do
+        not see; whoever trains passes through train() first."""
+        if mode:
+            self._ta_cache = None
+        return super().train(mode)
+
     def _ta_table(self):
         """Inference with fixed parameters on a zero node-feature table: the anony_emb block of the Q / K projection as a table
         T_a = anony_emb W[0:2dm, 2d:3d]^T (tg_seq_restarter.ta_cached), recomputed when either parameter changes (torch's

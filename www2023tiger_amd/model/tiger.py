@@ -471,7 +471,7 @@ class TIGE(nn.Module):
         tv = (L.vals._version, L.update_ts._version, R.vals._version, R.update_ts._version, S.node_msg_vals._version,
               S.node_msg_ts._version, S.has_msg_bits._version)
         pl = self._param_lists()[0]
-        pv = sum([p._version for p in pl])
+        pv = sum([p._version for p in pl]) + (getattr(self, '_param_epoch', 0) << 32)
         return (self._state_version, id(L), L._version_, id(R), R._version_, id(S), S._version_, tv, pv)
 
     def _param_lists(self):
@@ -484,11 +484,20 @@ class TIGE(nn.Module):
             pl = self._plists = (upd, att)
         return pl
 
+    def train(self, mode: bool = True):
+        """Entering train() mode starts a new parameter epoch: everything derived from parameters (pre-multiplied attention
+        weights, the eager-update and per-node tables) is rebuilt before its next use.  Their stamps are torch's version
+        counters, which the library's optimizer (tg_adam_step - www2023tiger_amd.optim.Adam, FusedTrainer, also inside replayed
+        graphs) does not bump: it writes through raw pointers.  Whoever trains passes through train() first."""
+        if mode:
+            self._param_epoch = getattr(self, '_param_epoch', 0) + 1
+        return super().train(mode)
+
     def _attn_stamp(self):
         """versions of everything the pre-multiplied weights are made of: attention + time encoder, and - the blob's tail
-        for the split updater, W_hh W2 (csrc/tg_dense.h: GruTail) - the updater's parameters"""
+        for the split updater, W_hh W2 (csrc/tg_dense.h: GruTail) - the updater's parameters; + the parameter epoch (train())"""
         pl = self._param_lists()
-        return [p._version for p in pl[1]] + [p._version for p in pl[0]]
+        return [p._version for p in pl[1]] + [p._version for p in pl[0]] + [getattr(self, '_param_epoch', 0)]
 
     def _sync_pending(self):
         """Rebuild the table of precomputed updater rows if state changed outside the eager step:

@@ -402,8 +402,39 @@ class FusedTrainer:
         self.buf.sb.load(to(src, torch.int64), to(dst, torch.int64), to(neg, torch.int64), to(ts, torch.float64),
                          to(eids, torch.int64))
 
-    def launch(self):
-        self.buf.launch()
+    def enable_lazy_restart(self, trigger):
+        """The lazy-restart loop of the training script (train_self_supervised.py:152-163) in front of every iteration:
+        trigger[b] != 0 - the caller's pre-drawn `np.random.rand() < restart_prob` of batch b (never before batch 0) - forgets
+        who is up to date and drops every pending message; from then on every batch re-initialises its involved nodes that are
+        not up to date with TIGER.restart at the batch's earliest time (the restarter in train() mode, as the reference
+        calls it).  StaticRestarter: the whole loop body runs inside the step (no host round trip, capturable).  Any other
+        restarter: the bookkeeping runs on the device in a collate-only pass, the host reads ONE count per iteration and
+        calls the restarter on the device-resident list (not capturable).  The up-to-date set starts empty, `restarting`
+        False - one call per epoch, as the reference re-creates both per epoch."""
+        sb = self.buf.sb
+        sb.enable_lazy_restart(self.model, trigger)
+        if getattr(sb, '_lazy_collate', None) is None:
+            self.buf.refresh()  # (the step's io is a copy of the buffer's: it now carries the lazy-restart block)
+        self.restarted = 0  # nodes re-initialised before the last iteration (list form)
+        return self
+
+    def launch(self, graph=None):
+        sb = self.buf.sb
+        cb = getattr(sb, '_lazy_collate', None)
+        if cb is not None:  # list form: pass -> one count -> TIGER.restart on the device-resident list -> the step
+            model = self.model
+            if model.device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('the lazy-restart loop with a sequence restarter reads one count back per iteration: '
+                                   'it cannot be captured into a graph (the static restarter runs inside the step)')
+            g = (model.graph if graph is None else graph).tcsr
+            m = model.model_struct()
+            check(lib.tg_stream_step(C.byref(m), C.byref(g), C.byref(cb.io), ptr(cb.ws), cb.ws.numel(),
+                                     stream_ptr(model.device)), 'tg_stream_step(lazy restart list)')
+            n = self.restarted = int(cb.counts[3].item())
+            if n:  # (one library call for the SeqRestarter without dropout, TIGER.restart otherwise)
+                model.restart_list(sb.lazy_list[:n], sb.lazy_tmin)
+            sb.lazy_batch += 1
+        self.buf.launch(graph=graph)
         gscale = 1.0
         if self.world_size > 1:
             import torch.distributed as dist
