@@ -736,7 +736,8 @@ int tg_train_step(const tg_model* m, const tg_tcsr* g, const tg_train_io* io, vo
  *   - the lists of a group's batches are disjoint (a pass marks what it lists) and a node listed for batch k + 1 is not
  *     involved in batch k (it would have been listed there), so step k neither reads nor writes it: ONE forward over the
  *     group's lists (tg_restart_seq_lists_fwd, every list at its own time) and ONE apply / table refresh ahead of the
- *     group's first step leave the state every step sees - and the final state - exactly as the per-batch order does;
+ *     group's first step give every step the state the per-batch order gives it - same lists, same marks; the rows bit for
+ *     bit at group 1, to rounding beyond (a forward over more rows takes other blocks for its products);
  *   - `stream` keeps the state (apply, table rows, steps); events order the two streams; two halves of 2 * group pass
  *     contexts and two row sets alternate, so that in the steady state neither stream waits for the other's bookkeeping.
  * The host reads one count per batch (pinned memory) to size the forward: not capturable.  Triggers must not fire

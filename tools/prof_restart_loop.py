@@ -23,7 +23,8 @@ model, _ = bench.build_models(st, c['d'], c['K'], c['msg_src'], c['upd_src'], re
 model.eval()
 coll = GraphCollator(model.graph, c['K'], 1, restarter='seq', hist_len=40)
 rs = np.random.RandomState(1)
-ev = InteractionData(st['src'][:n], st['dst'][:n], st['ts'][:n], st['eids'][:n], np.zeros(n, dtype=np.int64), seed=0, eval=True,
+lo = len(st['src']) - n  # the LAST n events: the restarted nodes have histories (from the first event on they would all be empty)
+ev = InteractionData(st['src'][lo:], st['dst'][lo:], st['ts'][lo:], st['eids'][lo:], np.zeros(n, dtype=np.int64), seed=0, eval=True,
                      neg_dst=rs.randint(c['n_u'] + 1, c['n_u'] + c['n_i'] + 1, n))
 dl = BatchLoader(ev, bs, coll)
 for _ in range(2):
