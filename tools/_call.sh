@@ -1,14 +1,12 @@
 set -e
 mkdir -p gpurun_out
-timeout -k 10 500 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+for r in seq static; do
+python bench.py --train --train-restarter $r --train-restart-prob 0.01 --no-cpu-baseline > gpurun_out/r05_train_c2_${r}_lazy_restart_v2.json 2> gpurun_out/train_${r}_lazy.err
+done
+python bench.py --train --train-restarter seq --no-cpu-baseline > gpurun_out/r05_train_c2_seq_v2.json 2>> gpurun_out/train_seq_lazy.err
 python - <<'PY'
 import json
-d=json.loads(open('gpurun_out/bench_default.json').read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'])
-r=d['reference_api_loop']
-for k,v in r.items():
-    if k=='what': continue
-    if k=='restart_mode':
-        for kk,vv in v.items(): print(kk, round(vv['value']), round(vv['ms_per_batch'],4), 'loop', round(vv['per_batch_loop']['value']), vv['ap'], vv['per_batch_loop']['ap'], vv['restarted_nodes'])
-    else: print(k, round(v['value']), round(v['ms_per_batch'],4), 'loop', round(v['per_batch_loop']['value']))
+for f in ('r05_train_c2_seq_lazy_restart_v2','r05_train_c2_static_lazy_restart_v2','r05_train_c2_seq_v2'):
+    d=json.loads(open(f'gpurun_out/{f}.json').read().strip().splitlines()[-1])
+    print(f,round(d['value']),round(d['ms_per_step'],3),d.get('lazy_restart_loop'))
 PY

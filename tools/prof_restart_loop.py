@@ -40,3 +40,4 @@ eval_edge_prediction(model, dl, model.device, restart_mode=True, uptodate_nodes=
 torch.cuda.synchronize()
 pr.disable()
 pstats.Stats(pr).sort_stats('tottime').print_stats(25)
+pstats.Stats(pr).sort_stats('cumtime').print_stats(45)
