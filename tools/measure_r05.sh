@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 measurement set (1x MI355X): bench lines, rocprofv3 kernel statistics, PMC traffic / MFMA-busy passes -> gpurun_out/r05_final/
-# usage (on the GPU box): bash tools/measure_r05.sh [TAG] [PART]   (files are named r05_*_TAG; PART: a = lines, b = stream profiles, c = restarter profiles)
+# usage (on the GPU box): bash tools/measure_r05.sh [TAG] [PART]   (files are named r05_*_TAG; PART: a = lines, b = stream profiles, c = restarter profiles, d = other workloads, e = restart-mode evaluation run)
 TAG=${1:-v1}; PART=${2:-abc}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r05_final
@@ -58,5 +58,22 @@ rm -rf $O/prof_ev
 cd $R
 TG_BENCH_REHEARSAL=1 python bench.py --gpus 2 --steps 20 --warmup 5 --preroll 40 --no-cpu-baseline > $O/r05_rehearsal_2ranks_one_gpu_windows_$TAG.json 2>> $O/err.log
 TG_BENCH_REHEARSAL=1 python bench.py --gpus 2 --steps 20 --warmup 5 --preroll 40 --no-cpu-baseline --dist-owner hash > $O/r05_rehearsal_2ranks_one_gpu_hash_owner_$TAG.json 2>> $O/err.log && echo rehearsal ok
+fi
+if [[ $PART == *e* ]]; then
+# restart-mode evaluation as one library call on two streams (tg_eval_restart_run): kernel statistics of the pass (the stream's
+# last 200 batches of 200), per-batch time by group size, the training iteration with the lazy-restart loop in front of it
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $O/prof_ev2 -o ev -- python $R/tools/prof_restart_loop.py 200 > $O/prof_ev2.log 2>&1
+python $R/tools/rocpd_stats.py $(find $O/prof_ev2 -name '*.db' | head -1) $O/r05_eval_restart_seq_bs200_kernel_stats_$TAG.csv > /dev/null && echo stats eval ok
+rm -rf $O/prof_ev2
+cd $R
+{
+for G in 1 2 4 8; do echo "tg_eval_restart_run, group $G:"; TG_EVAL_RESTART_GROUP=$G python tools/prof_restart_loop.py 500 2>&1 | grep "ms per batch" | tail -1; done
+echo "host-sequenced pipeline, two streams:"; TG_EVAL_RESTART_RUN=0 python tools/prof_restart_loop.py 500 2>&1 | grep "ms per batch" | tail -1
+echo "host-sequenced pipeline, one stream:"; TG_EVAL_RESTART_RUN=0 TG_EVAL_RESTART_OVERLAP=0 python tools/prof_restart_loop.py 500 2>&1 | grep "ms per batch" | tail -1
+echo "no pipeline (count read back before anything else is enqueued):"; TG_EVAL_RESTART_PIPELINE=0 python tools/prof_restart_loop.py 500 2>&1 | grep "ms per batch" | tail -1
+} > $O/r05_eval_restart_seq_bs200_forms_$TAG.txt
+for r in seq static; do python bench.py --train --train-restarter $r --train-restart-prob 0.01 --no-cpu-baseline > $O/r05_train_c2_${r}_lazy_restart_$TAG.json 2>> $O/err.log; done
+echo part e ok
 fi
 echo done

@@ -307,7 +307,7 @@ class _RestartRun:
         from .model.restarters import StaticRestarter
         static = isinstance(model.restarter_fn, StaticRestarter)
         cap, d = int(tb.sb._lazy_collate.lazy_list.numel()), model.memory_dim
-        G = max(1, min(8, int(os.environ.get('TG_EVAL_RESTART_GROUP', '4'))))
+        G = max(1, min(8, int(os.environ.get('TG_EVAL_RESTART_GROUP', '8'))))
         while G > 1 and 2 * min(G * cap, model.n_nodes) * (8 * d + 12) > _RestartRun.ROWS_LIMIT:
             G //= 2
         if 2 * min(G * cap, model.n_nodes) * (8 * d + 12) > _RestartRun.ROWS_LIMIT:
