@@ -85,6 +85,29 @@ def test_tcsr_build_rejects_bad_ids():
     assert rc == _lib.TG_EINVAL
 
 
+def test_restart_run_entry_points_refuse_bad_arguments_before_any_device_call():
+    """tg_eval_restart_run / tg_restart_seq_lists_fwd / tg_restart_static_lists_fwd (round 5): argument checks come first -
+    callable here, without a GPU."""
+    import ctypes as C
+    from www2023tiger_amd import _lib
+    lib = _lib.lib
+    run = _lib.TgRestartRun()
+    m, g = _lib.TgModel(), _lib.TgTcsr()
+    assert lib.tg_eval_restart_run(None, None, None, None, None, 0, C.byref(run), 3, None) == _lib.TG_EINVAL
+    io = _lib.TgTrainIo()
+    assert lib.tg_eval_restart_run(C.byref(m), C.byref(g), None, C.addressof(io), None, 0, C.byref(run), 0, None) == _lib.TG_OK
+    run.group = 0  # (no group size, no contexts, no row sets)
+    assert lib.tg_eval_restart_run(C.byref(m), C.byref(g), None, C.addressof(io), None, 0, C.byref(run), 2, None) == _lib.TG_EINVAL
+    run.group = 9  # beyond TG_RESTART_MAX_LISTS
+    assert lib.tg_eval_restart_run(C.byref(m), C.byref(g), None, C.addressof(io), None, 0, C.byref(run), 2, None) == _lib.TG_EINVAL
+    rs = _lib.TgSeqRestarter()
+    for n_lists in (0, 9):
+        assert lib.tg_restart_seq_lists_fwd(C.byref(m), C.byref(g), C.byref(rs), n_lists, None, None, None, None, None, None,
+                                            None, None, 0, None) == _lib.TG_EINVAL
+    assert lib.tg_restart_static_lists_fwd(C.byref(m), C.byref(g), None, None, 1, None, None, None, None, None, None, None,
+                                           None) == _lib.TG_EINVAL
+
+
 def test_struct_layouts_match_the_header(tmp_path):
     """sizeof / offsetof of every struct, as gcc lays out include/tiger_hip.h, against the ctypes mirrors."""
     import subprocess
