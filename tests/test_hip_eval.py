@@ -420,7 +420,8 @@ def test_restart_mode_eval_on_two_streams_equals_one_stream(restarter, monkeypat
             assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-5, other
 
 
-@pytest.mark.parametrize('name,strategy', [('train_static_lr_d8_L2', 'recent_edges'), ('eval_static_ll_d16', 'recent_nodes')])
+@pytest.mark.parametrize('name,strategy', [('train_static_lr_d8_L2', 'recent_edges'), ('eval_static_ll_d16', 'recent_nodes'),
+                                           ('eval_seq_lr_d8', 'recent_nodes')])
 @pytest.mark.parametrize('restart', [False, True], ids=['plain', 'restart_mode'])
 def test_resident_eval_with_two_layers_and_recent_nodes(name, strategy, restart, monkeypatch):
     """The resident evaluation pass on the forms beside the default one: two attention layers (no per-node tables: the
@@ -444,6 +445,7 @@ def test_resident_eval_with_two_layers_and_recent_nodes(name, strategy, restart,
             monkeypatch.setenv(k, v)
         model.reset()
         up = set()
+        assert (eval_utils._resident_plan(model, mk(), restart) is None) == (form == 'loop')  # (no silent fall-back to the loop)
         res = eval_utils.eval_edge_prediction(model, mk(), dev(), restart_mode=restart, uptodate_nodes=up, mean_over_n_samples=50)
         out[form] = (res, sorted(up), model.left_memory.vals.clone(), model.right_memory.vals.clone())
     assert out['loop'][0] == out['resident'][0] and out['loop'][1] == out['resident'][1] == out['stream'][1]

@@ -983,8 +983,9 @@ __global__ void k_build_queries(int64_t B, const int64_t* __restrict__ src, cons
                                 const int64_t* __restrict__ neg, const double* __restrict__ ts,
                                 const int64_t* __restrict__ eids, const int64_t* __restrict__ off,
                                 int64_t* __restrict__ nids3, double* __restrict__ ts3, float* __restrict__ ts3f,
-                                int64_t* __restrict__ eids_b) {
+                                int64_t* __restrict__ eids_b, uint32_t* __restrict__ tmin_key) {
   const int64_t o = off ? *off : 0;
+  float tmin = INFINITY;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * B; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t e = i % B;
     const int r = (int)(i / B);
@@ -992,7 +993,20 @@ __global__ void k_build_queries(int64_t B, const int64_t* __restrict__ src, cons
     const double t = ts[o + e];
     ts3[i] = t;
     ts3f[i] = (float)t;
-    if (r == 0) eids_b[e] = eids[o + e];
+    if (r == 0) {
+      eids_b[e] = eids[o + e];
+      tmin = fminf(tmin, (float)t);
+    }
+  }
+  if (tmin_key) {  // lazy restart only: the batch's earliest (float32) time, as sample_batch_body leaves it (tg_sample.h)
+    __shared__ float s_tmin[4];
+    for (int sh = 32; sh > 0; sh >>= 1) tmin = fminf(tmin, __shfl_xor(tmin, sh, TG_WAVE));
+    if (lane_id() == 0) s_tmin[threadIdx.x >> 6] = tmin;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float v = fminf(fminf(s_tmin[0], s_tmin[1]), fminf(s_tmin[2], s_tmin[3]));
+      if (v < INFINITY) atomicMax(tmin_key, ~(uint32_t)orderable(v));
+    }
   }
 }
 
@@ -1453,9 +1467,11 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
   if (prefetched) {
     // sampler, centres, first dedup pass and snapshot of this batch rode on the previous step's last launch
   } else if (recent_nodes || uniform) {  // query arrays first, then the sampler of graph.py:129-143 / :101-115 and the involved flags
-    if (lz || (inner && uniform)) return TG_EUNSUPPORTED;
+    // (the lazy-restart loop with `uniform`: a collate-only pass would consume draws of the graph's stream the step repeats)
+    if ((lz && uniform) || (inner && uniform)) return TG_EUNSUPPORTED;
     hipLaunchKernelGGL(k_build_queries, dim3(flat_grid(Q, 256)), dim3(256), 0, st, B, io->src, io->dst, io->neg, io->ts,
-                       io->eids, (const int64_t*)io->offset_dev, w.nids3, w.ts3, w.ts3f, w.eids);
+                       io->eids, (const int64_t*)io->offset_dev, w.nids3, w.ts3, w.ts3f, w.eids,
+                       lz ? reinterpret_cast<uint32_t*>(w.counts + 4) : nullptr);
     // uniform: the graph's MT19937 stream is consumed per non-empty query, in query order (src, dst, neg of the batch, as
     // data_loader.py:79-81 concatenates them): one wavefront walks the queries, 64 words of the stream at a time
     if ((rc = uniform ? sample_uniform_launch(g, Q, w.nids3, w.ts3, (int32_t)K, io->mt_state, w.l1n, w.l1e, w.l1t,

@@ -53,8 +53,6 @@ def _resident_plan(model, dl, restart_mode: bool):
         return None
     if type(dl) is not BatchLoader or not isinstance(dl.dataset, InteractionData) or type(dl.collate_fn) is not GraphCollator:
         return None  # any other iterable takes the per-batch loop, as in the reference
-    if restart_mode and getattr(dl.collate_fn.graph, 'strategy', None) != 'recent_edges':
-        return None  # (the device-side bookkeeping of the lazy restart flags the involved nodes of recent-edges neighbourhoods only)
     graph = dl.collate_fn.graph
     if getattr(graph, 'strategy', None) not in ('recent_edges', 'recent_nodes') or graph.device.type != 'cuda':
         return None

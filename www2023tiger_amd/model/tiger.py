@@ -140,9 +140,9 @@ class TIGE(nn.Module):
         from .restarters import SeqRestarter
         r = self.restarter_fn
         n = int(nids.numel())
+        # (whatever strategy the restarter's graph samples neighbourhoods with, histories are recent-edges lists: graph.py:150-155)
         if (n == 0 or not isinstance(r, SeqRestarter) or (r.training and float(r.mha_fn.dropout) > 0)
-                or getattr(self, '_row_of', None) is not None or r.graph.strategy != 'recent_edges'
-                or self.device.type != 'cuda' or t_dev.dtype != torch.float32):
+                or getattr(self, '_row_of', None) is not None or self.device.type != 'cuda' or t_dev.dtype != torch.float32):
             return self.restart(nids, t_dev.expand(n))
         self._touch()
         m, rs = self.model_struct(), r._struct()
@@ -155,11 +155,11 @@ class TIGE(nn.Module):
 
     def restart_list_split_ok(self) -> bool:
         """Can `restart_list` be taken apart into `restart_list_forward` (reads graph / features / restarter parameters only)
-        and `restart_list_apply` (the state update)?  The SeqRestarter in inference form over a recent-edges graph."""
+        and `restart_list_apply` (the state update)?  The SeqRestarter in inference form."""
         from .restarters import SeqRestarter
         r = self.restarter_fn
         return (isinstance(r, SeqRestarter) and not (r.training and float(r.mha_fn.dropout) > 0)
-                and getattr(self, '_row_of', None) is None and r.graph.strategy == 'recent_edges' and self.device.type == 'cuda')
+                and getattr(self, '_row_of', None) is None and self.device.type == 'cuda')
 
     def restart_list_forward(self, nids: Tensor, t_dev: Tensor, h_left: Tensor, h_right: Tensor, prev_ts: Tensor, ws_key='a'):
         """The restarter's rows of `restart_list` WITHOUT the state update (tg_restart_seq_list_fwd), on the current stream,
