@@ -527,7 +527,9 @@ typedef struct tg_step_io {
   /* Graph.sample_temporal_neighbor's strategy for the neighbours of the batch (graph.py:94-148; init_utils.py:40):
    * 0 = recent_edges (the default recipe), 1 = recent_nodes (last occurrence of each distinct neighbour, graph.py:129-143).
    * 2 = uniform (graph.py:101-115): K draws of numpy's legacy randint per non-empty query, consumed from the graph's
-   * MT19937 stream (`mt_state` below) in query order, sorted by time.  1 and 2: not together with `lazy` or `inner`. */
+   * MT19937 stream (`mt_state` below) in query order, sorted by time.  With `inner` the second hop follows the same strategy
+   * (uniform: the stream goes on behind the first hop's draws).  2 not together with `lazy` (a collate-only pass would consume
+   * draws the step repeats). */
   int32_t strategy;
   /* --n_layers 2 (tiger.py:29; data_loader.py:105-131; temporal_agg_modules.py:29-83).  NULL: one attention layer.
    * Otherwise a tg_model that differs from the step's model only in its attention block: the weights of the SECOND

@@ -471,18 +471,20 @@ def test_stream_fused_step_two_layers(name, form):
     check_state(model, z, 'flushed')
 
 
+@pytest.mark.parametrize('strategy', ['recent_nodes', 'uniform'])
 @pytest.mark.parametrize('form', ['lazy', 'eager-fused-lean'])
-def test_stream_fused_step_two_layers_recent_nodes_strategy(form):
-    """--n_layers 2 with --strategy recent_nodes inside tg_stream_step: BOTH hops follow the graph's strategy (data_loader.py:
-    128-131 samples every layer with graph.sample_temporal_neighbor), the second at the neighbours' float32 timestamps - lists
-    of both hops bit-exact, embeddings and state against the oracle collating the same way."""
+def test_stream_fused_step_two_layers_recent_nodes_strategy(form, strategy):
+    """--n_layers 2 with --strategy recent_nodes / uniform inside tg_stream_step: BOTH hops follow the graph's strategy
+    (data_loader.py:128-131 samples every layer with graph.sample_temporal_neighbor), the second at the neighbours' float32
+    timestamps - uniform: the graph's MT19937 stream goes on behind the first hop's draws - lists of both hops bit-exact,
+    embeddings and state against the oracle collating the same way."""
     from oracle import tiger_oracle as O
     from test_oracle_golden import build_oracle
     z = load('static_lr_d8_L2')
     cfg = parse_cfg(z)
-    model, g, coll = build_hip_model(z, cfg, strategy='recent_nodes')
+    model, g, coll = build_hip_model(z, cfg, strategy=strategy)
     orc = build_oracle(z, cfg)
-    orc.graph = O.OracleGraph(z['src'], z['dst'], z['ts'], z['eids'], strategy='recent_nodes', seed=0)
+    orc.graph = O.OracleGraph(z['src'], z['dst'], z['ts'], z['eids'], strategy=strategy, seed=0)
     if 'eager' in form:
         model.eager_updates()
         model.fuse_attention()

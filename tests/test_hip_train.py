@@ -162,17 +162,19 @@ def test_training_step_with_other_sampling_strategies(strategy):
     assert rel_err(model.right_memory.vals.cpu().numpy(), orc.right_vals.numpy()) < TOL
 
 
-def test_two_layer_training_step_with_the_recent_nodes_strategy():
-    """--n_layers 2 --strategy recent_nodes in the device training step (init_utils.py:36-41 allows the combination): both
-    hops sampled with the graph's strategy, the hit windows recent-edges lists; loss and the gradients of BOTH attention
-    layers against the oracle's autograd over the same collation."""
+@pytest.mark.parametrize('strategy', ['recent_nodes', 'uniform'])
+def test_two_layer_training_step_with_the_recent_nodes_strategy(strategy):
+    """--n_layers 2 --strategy recent_nodes / uniform in the device training step (init_utils.py:36-41 allows the
+    combinations): both hops sampled with the graph's strategy (uniform: the same draws of the graph's MT19937 stream, first
+    hop then second), the hit windows recent-edges lists; loss and the gradients of BOTH attention layers against the oracle's
+    autograd over the same collation."""
     from oracle import tiger_oracle as O
     from www2023tiger_amd.model.training import TrainBuffers
     z = load('train_static_lr_d8_L2')
     cfg = parse_cfg(z)
-    model, _, _ = build_hip_model(z, cfg, strategy='recent_nodes', dropout=0.0)
+    model, _, _ = build_hip_model(z, cfg, strategy=strategy, dropout=0.0)
     orc = build_oracle(z, cfg)
-    orc.graph = O.OracleGraph(z['src'], z['dst'], z['ts'], z['eids'], strategy='recent_nodes', seed=0)
+    orc.graph = O.OracleGraph(z['src'], z['dst'], z['ts'], z['eids'], strategy=strategy, seed=0)
     model.train()
     bufs = {}
     for b in range(cfg['n_batches']):
@@ -189,8 +191,10 @@ def test_two_layer_training_step_with_the_recent_nodes_strategy():
         tb.launch()
         assert int(tb.sb.err.item()) == 0
         assert abs(float(tb.losses[0]) - c) < TOL * max(1.0, abs(c)), b
+        # (uniform draws reach far back: time-encoding arguments of large time differences, float32 sums in another order -
+        #  3.0e-4 of the largest entry on the second layer's merger, whose gradient entries are ~1e-5)
         for k, g in tb.grads.items():
-            assert grad_err(g.cpu().numpy(), grads[k].numpy()) < 2e-4, (b, k)
+            assert grad_err(g.cpu().numpy(), grads[k].numpy()) < (2e-4 if strategy == 'recent_nodes' else 4e-4), (b, k)
     assert rel_err(model.left_memory.vals.cpu().numpy(), orc.left_vals.numpy()) < TOL
 
 

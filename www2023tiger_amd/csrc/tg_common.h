@@ -290,6 +290,8 @@ int sample_nodes_launch(const tg_tcsr* g, int64_t Q, const int64_t* nids, const 
 // uniform sampler (graph.py:101-115) over prepared query arrays, the graph's MT19937 state on the device
 int sample_uniform_launch(const tg_tcsr* g, int64_t Q, const int64_t* nids, const double* ts, int32_t K, uint32_t* mt_state,
                           int64_t* o_nbr, int64_t* o_eid, float* o_ts, uint8_t* mark, hipStream_t st);
+int sample_uniform_f32_launch(const tg_tcsr* g, int64_t Q, const int64_t* nids, const float* ts, int32_t K, uint32_t* mt_state,
+                              int64_t* o_nbr, int64_t* o_eid, float* o_ts, uint8_t* mark, hipStream_t st);
 // the lazy-restart loop body of train_self_supervised.py:152-163 with the static restarter (tiger_hip.h: tg_lazy_restart);
 // runs between the sampler (flags, *tmin_key) and the compaction
 // rlist / rlist32 (nullable, static form only): also list the re-initialised nodes and rewrite their rows of m->c_table

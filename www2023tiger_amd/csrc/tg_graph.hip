@@ -374,7 +374,8 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 __global__ void __launch_bounds__(64) k_sample_uniform(tg_tcsr g, int64_t Q, const int64_t* __restrict__ nids,
                                                        const double* __restrict__ qts, int K, uint32_t* mt_state,
                                                        int64_t* __restrict__ o_nbr, int64_t* __restrict__ o_eid,
-                                                       float* __restrict__ o_ts, int64_t* __restrict__ o_dir) {
+                                                       float* __restrict__ o_ts, int64_t* __restrict__ o_dir,
+                                                       const float* __restrict__ qts32 = nullptr) {
   __shared__ uint32_t key[624];
   __shared__ int s_pos;
   __shared__ int64_t s_sel[TG_WAVE];
@@ -384,7 +385,7 @@ __global__ void __launch_bounds__(64) k_sample_uniform(tg_tcsr g, int64_t Q, con
   __builtin_amdgcn_wave_barrier();
   for (int64_t q = 0; q < Q; ++q) {
     int64_t start;
-    const int64_t end = prefix_end(g, nids[q], qts[q], &start);
+    const int64_t end = prefix_end(g, nids[q], qts ? qts[q] : (double)qts32[q], &start);  // (second hop: float32 query times)
     const int64_t len = end - start;
     if (len == 0) {
       for (int j = lane; j < K; j += TG_WAVE) {
@@ -716,6 +717,18 @@ int sample_uniform_launch(const tg_tcsr* g, int64_t Q, const int64_t* nids, cons
                      (int64_t*)nullptr);
   if (mark) hipLaunchKernelGGL(k_mark_queries, dim3(flat_grid(Q * (K + 1), 256)), dim3(256), 0, st, Q, (int)K, nids, o_nbr, mark);
   return check_launch("sample_uniform");
+}
+// second hop of a two-layer step with --strategy uniform (data_loader.py:128-131: the graph's own strategy at the neighbours'
+// float32 timestamps): the stream goes on where the first hop left it, per non-empty query in slot order
+int sample_uniform_f32_launch(const tg_tcsr* g, int64_t Q, const int64_t* nids, const float* ts, int32_t K, uint32_t* mt_state,
+                              int64_t* o_nbr, int64_t* o_eid, float* o_ts, uint8_t* mark, hipStream_t st) {
+  if (!mt_state) return TG_EINVAL;
+  if (K > 16) return TG_EUNSUPPORTED;
+  if (Q <= 0) return TG_OK;
+  hipLaunchKernelGGL(k_sample_uniform, dim3(1), dim3(64), 0, st, *g, Q, nids, (const double*)nullptr, (int)K, mt_state, o_nbr,
+                     o_eid, o_ts, (int64_t*)nullptr, ts);
+  if (mark) hipLaunchKernelGGL(k_mark_queries, dim3(flat_grid(Q * (K + 1), 256)), dim3(256), 0, st, Q, (int)K, nids, o_nbr, mark);
+  return check_launch("sample_uniform_f32");
 }
 }  // namespace tg
 

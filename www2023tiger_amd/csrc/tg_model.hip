@@ -1468,7 +1468,7 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
     // sampler, centres, first dedup pass and snapshot of this batch rode on the previous step's last launch
   } else if (recent_nodes || uniform) {  // query arrays first, then the sampler of graph.py:129-143 / :101-115 and the involved flags
     // (the lazy-restart loop with `uniform`: a collate-only pass would consume draws of the graph's stream the step repeats)
-    if ((lz && uniform) || (inner && uniform)) return TG_EUNSUPPORTED;
+    if (lz && uniform) return TG_EUNSUPPORTED;
     hipLaunchKernelGGL(k_build_queries, dim3(flat_grid(Q, 256)), dim3(256), 0, st, B, io->src, io->dst, io->neg, io->ts,
                        io->eids, (const int64_t*)io->offset_dev, w.nids3, w.ts3, w.ts3f, w.eids,
                        lz ? reinterpret_cast<uint32_t*>(w.counts + 4) : nullptr);
@@ -1491,9 +1491,12 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
     if (io->dbg_l1_ts && (e = hipMemcpyAsync(io->dbg_l1_ts, w.l1t, n * 4, hipMemcpyDeviceToDevice, st)) != hipSuccess) return TG_EHIP;
   }
   // second hop (data_loader.py:128-131): every neighbour slot (padding included) queried at its own float32 timestamp
-  // - with the graph's own strategy (recent_edges / recent_nodes; uniform's second hop stays on the operator path)
-  if (inner && (rc = (recent_nodes ? sample_nodes_f32_launch : sample_edges_f32_launch)(
-                    g, Q * K, w.l1n, w.l1t, (int32_t)K, w.h2n, w.h2e, w.h2t, need_flags ? w.flags : nullptr, st)) != TG_OK)
+  // - with the graph's own strategy (uniform: the graph's stream goes on behind the first hop's draws)
+  if (inner && (rc = uniform ? sample_uniform_f32_launch(g, Q * K, w.l1n, w.l1t, (int32_t)K, io->mt_state, w.h2n, w.h2e, w.h2t,
+                                                         need_flags ? w.flags : nullptr, st)
+                             : (recent_nodes ? sample_nodes_f32_launch : sample_edges_f32_launch)(
+                                   g, Q * K, w.l1n, w.l1t, (int32_t)K, w.h2n, w.h2e, w.h2t, need_flags ? w.flags : nullptr, st)) !=
+                   TG_OK)
     return rc;
   // lazy restart (train_self_supervised.py:152-163): before STEP 1, because a restarted node loses its pending message
   const bool lz_tables = lz && w.gtab;  // the loop also keeps the per-node tables current (lists what it re-initialised)

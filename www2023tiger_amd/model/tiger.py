@@ -659,12 +659,12 @@ class TIGE(nn.Module):
             return self._contrast_learning_eval(src_ids, dst_ids, neg_dst_ids, ts, eids, computation_graph)
 
     def _fused_eval_ok(self, graph=None) -> bool:
-        """does the one-call evaluation step (tg_train_step without gradient buffers) apply?  One or two layers; two
-        layers with the recent-edges / recent-nodes strategies (uniform's second hop runs on the operator path)"""
+        """does the one-call evaluation step (tg_train_step without gradient buffers) apply?  One or two layers, the
+        recent-edges / recent-nodes / uniform strategies"""
         if self.hit_type == 'vec' and (2 * (self.nfeat_dim + self.n_neighbors)) % 4:
             return False  # the score head's pair rows must be float4-aligned
         strategy = getattr(graph if graph is not None else self.graph, 'strategy', 'recent_edges')
-        return self.n_layers == 1 or (self.n_layers == 2 and strategy in ('recent_edges', 'recent_nodes'))
+        return self.n_layers in (1, 2) and strategy in ('recent_edges', 'recent_nodes', 'uniform')
 
     def _contrast_learning_fused_eval(self, src_ids, dst_ids, neg_dst_ids, eids, computation_graph):
         """no_grad / eval(): collate, STEP 1-7 and the write-back as ONE device call (tg_train_step without
@@ -928,8 +928,6 @@ class TIGE(nn.Module):
                                       '(graph.py:104-110, alpha != 0) is not built')
         buf.io.strategy = {'recent_edges': 0, 'recent_nodes': 1, 'uniform': 2}[strategy]
         if strategy == 'uniform':  # the graph's RandomState lives on the device and is consumed in query order
-            if self.n_layers != 1:
-                raise NotImplementedError("strategy='uniform' with two layers runs on the operator path")
             buf.io.mt_state = ptr(self.graph._mt_state())
         if self.n_layers == 2:  # the second attention layer's weights travel in a tg_model of their own
             buf._inner = self.model_struct(1)

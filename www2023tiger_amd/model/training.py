@@ -152,8 +152,6 @@ def check_trainable(model):
         raise NotImplementedError('dropout inside the message transform is not built (the reference never sets it)')
     if model.n_layers not in (1, 2):
         raise NotImplementedError('training on device supports n_layers 1 and 2')
-    if model.n_layers == 2 and getattr(model.graph, 'strategy', 'recent_edges') not in ('recent_edges', 'recent_nodes'):
-        raise NotImplementedError("training on device with two layers samples with strategy 'recent_edges' or 'recent_nodes'")
     if model.n_layers == 2 and model.temporal_embedding_fn.fns[1].merger.dropout.p > 0:
         raise NotImplementedError('dropout inside the embedding merger is not built (the reference never sets it)')
     if getattr(model.graph, 'strategy', 'recent_edges') not in ('recent_edges', 'recent_nodes', 'uniform'):
