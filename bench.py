@@ -925,7 +925,7 @@ def train_main(args, cfg):
                          integer_ts=cfg.get('integer_ts', True), with_efeats=not no_feats)
     rkind = args.train_restarter
     model, _ = build_models(stream, d, K, cfg['msg_src'], cfg['upd_src'], restarter='seq' if rkind == 'seq' else 'static',
-                            hist_len=args.hist_len, device='cuda:0', zero_nfeats=not no_feats, dropout=0.0)
+                            hist_len=args.hist_len, device='cuda:0', zero_nfeats=not no_feats, dropout=args.train_dropout)
     model.train()
     resident = tuple(torch.from_numpy(stream[k]).to(dev) for k in ('src', 'dst', 'neg', 'ts', 'eids'))
     tr = FusedTrainer(model, B, lr=1e-4, resident=resident, mutual=rkind != 'none', mutual_coef=1.0)
@@ -1000,7 +1000,7 @@ def train_main(args, cfg):
                           config=dict(workload=cfg['name'], batch=B, dim=d, n_neighbors=K,
                                       mode='train (contrast only)' if rkind == 'none' else
                                       f'train (contrast + mutual, {rkind} restarter, hist_len {args.hist_len})',
-                                      last_mutual_loss=float(tr.buf.losses[1]),
+                                      dropout=args.train_dropout, last_mutual_loss=float(tr.buf.losses[1]),
                                       launch=(f'hipGraph replay, {gsteps} iteration{"s" if gsteps > 1 else ""} per captured graph' if graph is not None else 'eager'), last_loss=loss))))
 
 
@@ -1052,6 +1052,9 @@ def main():
     ap.add_argument('--train', action='store_true', help='measure the training iteration instead (not the headline metric)')
     ap.add_argument('--train-restarter', default='none', choices=['none', 'seq', 'static'],
                     help='--train: add the mutual-learning loss of this restarter (none = contrast_only)')
+    ap.add_argument('--train-dropout', type=float, default=0.0,
+                    help='--train: dropout probability of the model (the reference default is 0.1, init_utils.py; 0 keeps the '
+                         'lines of earlier rounds comparable)')
     ap.add_argument('--train-restart-prob', type=float, default=0.0,
                     help='--train with a restarter: the lazy-restart loop of train_self_supervised.py:152-163 in front of every '
                          'iteration (the reference default is 0.01); 0 = the training step alone')
