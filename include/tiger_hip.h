@@ -427,6 +427,10 @@ int tg_restart_seq_fwd_train(const tg_model* m, const tg_seq_restarter* r, int64
 size_t tg_restart_seq_list_workspace_bytes(const tg_model* m, const tg_seq_restarter* r, int64_t n);
 int tg_restart_seq_list(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, int64_t n, const int64_t* nids,
                         const float* t_dev, void* ws, size_t ws_bytes, void* stream);
+/* The same in train() mode (the reference calls TIGER.restart inside the training loop with the module in train() mode:
+ * attention / merger dropout active, masks as tg_restart_seq_fwd_train draws them; rng[1] is incremented). */
+int tg_restart_seq_list_train(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, int64_t n, const int64_t* nids,
+                              const float* t_dev, float dropout_p, uint64_t* rng, void* ws, size_t ws_bytes, void* stream);
 /* The same with the live count on the device: the launches are sized for `cap` entries, the first *n_dev (<= cap) are
  * restarted; the entries behind them must hold valid node ids.  No host value depends on the count, so the call can be
  * captured into a hipGraph and replayed for every batch whose count fits the capacity. */

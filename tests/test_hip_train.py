@@ -280,6 +280,36 @@ def test_fused_trainer_mutual_trajectory(loop, name):
         assert rel_err(p.detach().cpu().numpy(), z[f'final.{k}']) < 2e-3, k
 
 
+def test_restart_list_in_train_mode_draws_the_masks_of_restart():
+    """TIGER.restart_list with the SeqRestarter in train() mode (the training script's lazy-restart loop calls restart with
+    dropout active): one library call (tg_restart_seq_list_train) - the memories TIGER.restart leaves from the same generator
+    state, bit for bit, the generator advanced alike; and not the rows of the inference form."""
+    z = load('train_seq_lr_d8')
+    cfg = parse_cfg(z)
+    model, _, _ = build_hip_model(z, cfg, dropout=0.1)
+    model.train()
+    nids = torch.arange(1, int(z['n_nodes']), device=dev())
+    t = float(np.float32(z['ts'].max())) * 0.7
+    tdev = torch.tensor([t], dtype=torch.float32, device=dev())
+    rng = model.dropout_rng()
+    start = rng.clone()
+    out = {}
+    for form in ('restart', 'list', 'list_eval'):
+        model.reset()
+        rng.copy_(start)
+        if form == 'list_eval':
+            model.eval()
+        if form == 'restart':
+            model.restart(nids, tdev.expand(len(nids)))
+        else:
+            model.restart_list(nids, tdev)
+        out[form] = (model.left_memory.vals.clone(), model.right_memory.vals.clone(), model.left_memory.update_ts.clone(), rng.clone())
+    for a_, b_ in zip(out['restart'], out['list']):
+        assert torch.equal(a_, b_)
+    assert not torch.equal(out['list'][3], start)                 # the generator moved ...
+    assert not torch.equal(out['list'][1], out['list_eval'][1])   # ... and the masks were applied
+
+
 def test_tables_derived_from_parameters_follow_the_device_optimizer():
     """tg_adam_step updates parameters through raw pointers - torch's version counters, the stamps of everything derived
     from parameters (the SeqRestarter's tabulated anony_emb block, pre-multiplied attention weights, eager-update and

@@ -187,6 +187,7 @@ SIGNATURES = {
     'tg_restart_apply': (C.c_int, [P(TgModel), i64, vp, vp, vp, vp, vp]),
     'tg_restart_seq_list_workspace_bytes': (sz, [P(TgModel), P(TgSeqRestarter), i64]),
     'tg_restart_seq_list': (C.c_int, [P(TgModel), P(TgTcsr), P(TgSeqRestarter), i64, vp, vp, vp, sz, vp]),
+    'tg_restart_seq_list_train': (C.c_int, [P(TgModel), P(TgTcsr), P(TgSeqRestarter), i64, vp, vp, C.c_float, vp, vp, sz, vp]),
     'tg_restart_seq_list_dev': (C.c_int, [P(TgModel), P(TgTcsr), P(TgSeqRestarter), i64, vp, vp, vp, vp, sz, vp]),
     'tg_eval_restart_run': (C.c_int, [P(TgModel), P(TgTcsr), vp, vp, vp, sz, P(TgRestartRun), i64, vp]),
     'tg_restart_seq_lists_fwd': (C.c_int, [P(TgModel), P(TgTcsr), P(TgSeqRestarter), i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),

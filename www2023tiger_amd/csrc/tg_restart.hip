@@ -1428,7 +1428,7 @@ struct ListWs {
   float *h_t, *hl, *hr, *pt;
   SeqWs seq;
 };
-static bool carve_list(const tg_model* m, const tg_seq_restarter* r, int64_t n, Carver& cv, ListWs& w) {
+static bool carve_list(const tg_model* m, const tg_seq_restarter* r, int64_t n, Carver& cv, ListWs& w, bool train = false) {
   const size_t H = r->hist_len, d = m->d;
   w.tu = cv.take<double>(n);
   w.h_n = cv.take<int64_t>(n * H);
@@ -1439,7 +1439,7 @@ static bool carve_list(const tg_model* m, const tg_seq_restarter* r, int64_t n, 
   w.hl = cv.take<float>(n * d);
   w.hr = cv.take<float>(n * d);
   w.pt = cv.take<float>(n);
-  return carve_seq(m, r, n, cv, w.seq, false);
+  return carve_seq(m, r, n, cv, w.seq, train);  // (train() mode: the dropout form keeps two more buffers)
 }
 }  // namespace tg
 
@@ -1447,7 +1447,7 @@ extern "C" size_t tg_restart_seq_list_workspace_bytes(const tg_model* m, const t
   if (!seq_ok(m, r) || n < 0) return 0;
   return carve_bytes([&](Carver& cv) {
            ListWs w{};
-           carve_list(m, r, n, cv, w);
+           carve_list(m, r, n, cv, w, true);  // (the larger of the two forms)
          }) +
          64;
 }
@@ -1461,14 +1461,15 @@ extern "C" int tg_restart_seq_list(const tg_model* m, const tg_tcsr* g, const tg
 // (hl, hr, pt) - the caller's, or the workspace's own when NULL; `w` tells where they are
 static int list_forward(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, int64_t n, const int64_t* nids,
                         const int32_t* n_dev, const float* t_dev, float* hl, float* hr, float* pt, void* ws, size_t ws_bytes,
-                        void* stream, ListWs& w, const SegLists* segs = nullptr, int64_t* ids_out = nullptr) {
+                        void* stream, ListWs& w, const SegLists* segs = nullptr, int64_t* ids_out = nullptr,
+                        const DropCfg& dc = DropCfg{}) {
   if (m && m->row_of) return TG_EUNSUPPORTED;  // state addressed by node id: not on physically partitioned tables (tg_model.row_of)
   if (!seq_ok(m, r) || !g || n < 0) return TG_EINVAL;
   if (r->hist_len > 128) return TG_EUNSUPPORTED;
   if (n == 0) return TG_OK;
   if (segs ? !ids_out : (!nids || !t_dev)) return TG_EINVAL;
   Carver cv(ws, ws_bytes);
-  if (!ws || !carve_list(m, r, n, cv, w)) return TG_EWORKSPACE;
+  if (!ws || !carve_list(m, r, n, cv, w, dc.p > 0.f)) return TG_EWORKSPACE;
   if (hl) { w.hl = hl; w.hr = hr; w.pt = pt; }
   hipStream_t st = as_stream(stream);
   const int H = r->hist_len;
@@ -1483,7 +1484,26 @@ static int list_forward(const tg_model* m, const tg_tcsr* g, const tg_seq_restar
   if ((rc = tg_anonymized_reindex(n, H, w.h_n, w.anon, stream)) != TG_OK) return rc;
   // n_dev: the launches are sized for n (a capacity), the first *n_dev entries of the list are live - the entries behind them
   // must be valid node ids (their histories are sampled and thrown away); nothing is written for them
-  return seq_forward(m, r, n, n_dev, nids, w.h_n, w.anon, w.h_e, w.h_t, w.h_d, w.hl, w.hr, w.pt, w.seq, st);
+  return seq_forward(m, r, n, n_dev, nids, w.h_n, w.anon, w.h_e, w.h_t, w.h_d, w.hl, w.hr, w.pt, w.seq, st, dc);
+}
+
+namespace tg {
+__global__ void k_rng_tick_list(uint64_t* rng) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) rng[1] += 1;
+}
+}  // namespace tg
+
+extern "C" int tg_restart_seq_list_train(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, int64_t n,
+                                         const int64_t* nids, const float* t_dev, float dropout_p, uint64_t* rng, void* ws,
+                                         size_t ws_bytes, void* stream) {
+  if (dropout_p < 0.f || dropout_p >= 1.f || (dropout_p > 0.f && !rng)) return TG_EINVAL;
+  ListWs w{};
+  const DropCfg dc = make_drop(dropout_p, rng);
+  const int rc = list_forward(m, g, r, n, nids, nullptr, t_dev, nullptr, nullptr, nullptr, ws, ws_bytes, stream, w, nullptr,
+                              nullptr, dc);
+  if (rc != TG_OK || n == 0) return rc;
+  if (dc.p > 0.f) hipLaunchKernelGGL(k_rng_tick_list, dim3(1), dim3(64), 0, as_stream(stream), rng);
+  return restart_apply_dev(m, n, nids, w.hl, w.hr, w.pt, nullptr, as_stream(stream));
 }
 
 extern "C" int tg_restart_seq_list_dev(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, int64_t n,

@@ -134,15 +134,19 @@ class TIGE(nn.Module):
     # ---- plumbing ---------------------------------------------------------------------
     def restart_list(self, nids: Tensor, t_dev: Tensor):
         """`restart(nids, t.expand(n))` for a device-resident id list and ONE device-resident time, with the SeqRestarter
-        in inference mode, as a single library call (tg_restart_seq_list: histories, anonymised ids, the restarter's
+        (inference form, or train() mode with its dropout), as a single library call (tg_restart_seq_list(_train): histories, anonymised ids, the restarter's
         forward, the state update) - the loops that restart per batch (eval_utils: lazy restart) were bound by the host
         side of the dozen calls this replaces.  Anything else takes `restart`."""
         from .restarters import SeqRestarter
         r = self.restarter_fn
         n = int(nids.numel())
         # (whatever strategy the restarter's graph samples neighbourhoods with, histories are recent-edges lists: graph.py:150-155)
-        if (n == 0 or not isinstance(r, SeqRestarter) or (r.training and float(r.mha_fn.dropout) > 0)
-                or getattr(self, '_row_of', None) is not None or self.device.type != 'cuda' or t_dev.dtype != torch.float32):
+        if (n == 0 or not isinstance(r, SeqRestarter) or getattr(self, '_row_of', None) is not None
+                or self.device.type != 'cuda' or t_dev.dtype != torch.float32):
+            return self.restart(nids, t_dev.expand(n))
+        p = float(r.mha_fn.dropout)
+        train = r.training and p > 0
+        if train and (r.rng_fn is None or float(r.merger.dropout.p) != p):
             return self.restart(nids, t_dev.expand(n))
         self._touch()
         m, rs = self.model_struct(), r._struct()
@@ -150,6 +154,11 @@ class TIGE(nn.Module):
         ws = getattr(self, '_restart_list_ws', None)
         if ws is None or ws.numel() < nbytes:
             ws = self._restart_list_ws = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=self.device)
+        if train:  # train() mode: attention / merger dropout is active, as when the reference restarts inside its training loop
+            check(lib.tg_restart_seq_list_train(C.byref(m), C.byref(r.graph.tcsr), C.byref(rs), n, ptr(nids), ptr(t_dev), p,
+                                                ptr(r.rng_fn()), ptr(ws), ws.numel(), stream_ptr(self.device)),
+                  'tg_restart_seq_list_train')
+            return
         check(lib.tg_restart_seq_list(C.byref(m), C.byref(r.graph.tcsr), C.byref(rs), n, ptr(nids), ptr(t_dev), ptr(ws),
                                       ws.numel(), stream_ptr(self.device)), 'tg_restart_seq_list')
 
