@@ -747,7 +747,8 @@ int tg_train_step(const tg_model* m, const tg_tcsr* g, const tg_train_io* io, vo
  *   - `stream` keeps the state (apply, table rows, steps); events order the two streams; two halves of 2 * group pass
  *     contexts and two row sets alternate, so that in the steady state neither stream waits for the other's bookkeeping.
  * The host reads one count per batch (pinned memory) to size the forward: not capturable.  Triggers must not fire
- * (keep_msg_bits).  On return `stream` is ordered behind everything enqueued. */
+ * (keep_msg_bits).  On return `stream` is ordered behind everything enqueued.  The side stream and its events belong to
+ * the library, one set per device: one run at a time per device (calls from several host threads must be serialised). */
 #define TG_RUN_CTX (2 * TG_RESTART_MAX_LISTS)
 typedef struct tg_restart_run {
   int32_t group;                /* batches per forward, 1 .. TG_RESTART_MAX_LISTS; 2 * group pass contexts are used */
