@@ -776,6 +776,11 @@ typedef struct tg_restart_run {
   float* pos_scores;            /* [count * B]: step k writes its logits at k * B (NULL: where step_io points) */
   float* neg_scores;
   int32_t* n_restarted;         /* host [count] out (NULL: not wanted): nodes re-initialised before batch k */
+  /* collate prefetch inside a group (0: off): the number of events in the resident stream arrays and the stream offset of
+   * batch 0 of the run (= offsets[0]) - the steps of a group but its last then prefetch the next batch's collate part as the
+   * plain resident pass does (tg_step_io.prefetch_state; the run owns the flag, and the steps' l1_* outputs are dropped) */
+  int64_t stream_len;
+  int64_t first_offset;
 } tg_restart_run;
 int tg_eval_restart_run(const tg_model* m, const tg_tcsr* g, const tg_seq_restarter* r, const tg_train_io* step_io,
                         void* step_ws, size_t step_ws_bytes, const tg_restart_run* run, int64_t count, void* stream);

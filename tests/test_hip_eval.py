@@ -381,9 +381,10 @@ def test_restart_mode_eval_on_two_streams_equals_one_stream(restarter, monkeypat
     orig_run = eval_utils._RestartRun.run
     monkeypatch.setattr(eval_utils._RestartRun, 'run', lambda self, *a: (orig_run(self, *a), counts.extend(self.counts))[0])
     knobs = ('TG_EVAL_RESTART_RUN', 'TG_EVAL_RESTART_OVERLAP', 'TG_EVAL_RESTART_PIPELINE', 'TG_EVAL_RESTART_GROUP',
-             'TG_EVAL_RESTART_INSTEP')
+             'TG_EVAL_RESTART_INSTEP', 'TG_EVAL_PREFETCH')
     for form, env in (('run', {}), ('run1', dict(TG_EVAL_RESTART_GROUP='1')), ('run3', dict(TG_EVAL_RESTART_GROUP='3')),
                       ('chunks', dict(TG_EVAL_RESTART_GROUP='8')),  # (+ 64 nodes per forward: whole and partial lists per call)
+                      ('run_nopf', dict(TG_EVAL_PREFETCH='0')),  # (no collate prefetch inside the groups)
                       ('two', dict(TG_EVAL_RESTART_RUN='0')),
                       ('one', dict(TG_EVAL_RESTART_RUN='0', TG_EVAL_RESTART_OVERLAP='0', TG_EVAL_RESTART_INSTEP='0')),
                       ('plain', dict(TG_EVAL_RESTART_PIPELINE='0'))):  # (static: 'two' and 'plain' are the in-step loop)
@@ -413,6 +414,7 @@ def test_restart_mode_eval_on_two_streams_equals_one_stream(restarter, monkeypat
             assert torch.equal(a, b), other
     # one forward per group / per chunk: other row counts, hence other blocks for its products (their sums in another
     # order) - the same lists, the same has-message bits, rows to rounding
+    assert out['run'][0] == out['run_nopf'][0] and all(torch.equal(a, b) for a, b in zip(out['run'][2:], out['run_nopf'][2:]))
     for other in ('run', 'run3', 'chunks'):
         assert out['run1'][1] == out[other][1] and torch.equal(out['run1'][-1], out[other][-1]), other
         assert abs(out['run1'][0][0] - out[other][0][0]) <= 2e-4 and abs(out['run1'][0][1] - out[other][0][1]) <= 2e-4, other

@@ -88,7 +88,7 @@ class TgRestartRun(C.Structure):
                 ('ids', vp * 2), ('h_left', vp * 2), ('h_right', vp * 2), ('prev_ts', vp * 2),
                 ('fwd_nodes', i64), ('fwd_ws', vp), ('fwd_ws_bytes', sz), ('static_left', vp), ('static_right', vp),
                 ('gtab_ws', vp), ('gtab_ws_bytes', sz),
-                ('pos_scores', vp), ('neg_scores', vp), ('n_restarted', vp)]
+                ('pos_scores', vp), ('neg_scores', vp), ('n_restarted', vp), ('stream_len', i64), ('first_offset', i64)]
 
 
 TG_MAX_RANKS = 16

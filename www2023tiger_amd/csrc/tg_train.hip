@@ -1327,10 +1327,22 @@ extern "C" int tg_eval_restart_run(const tg_model* m, const tg_tcsr* g, const tg
         rc = tg_attn_gtab_rows(m, total, run->ids[set], nullptr, run->gtab_ws, run->gtab_ws_bytes, st);
     }
     TG_RUN_HIP(hipEventRecord(L->applied[set], st));
+    // collate prefetch INSIDE a group (tg_step_io.prefetch_state): between two steps of a group nothing restarts, so step k
+    // may run the sampler + centres of batch k + 1 on its last launch, as in the plain resident pass; the group's last step
+    // must not (the next group's apply changes the state behind a prefetched collate): it is shown a stream that ends with
+    // its own batch - it consumes what step k - 1 prefetched and its rider does nothing
+    int32_t pf_state = 0;
     for (int64_t k = k0; k < k1 && rc == TG_OK; ++k) {
       tg_train_io sio = *step_io;
       if (run->pos_scores) sio.pos_scores = run->pos_scores + k * B;
       if (run->neg_scores) sio.neg_scores = run->neg_scores + k * B;
+      if (run->stream_len > 0) {
+        sio.step.prefetch_state = &pf_state;
+        sio.step.stream_len = (k + 1 < k1) ? run->stream_len : run->first_offset + (k + 1) * B;
+        sio.step.l1_nids = nullptr;
+        sio.step.l1_eids = nullptr;
+        sio.step.l1_ts = nullptr;
+      }
       rc = tg_train_step(m, g, &sio, step_ws, step_ws_bytes, st);
     }
   }

@@ -371,6 +371,8 @@ class _RestartRun:
             run.gtab_ws, run.gtab_ws_bytes = ptr(gtab_ws), gtab_ws.numel()
         run.pos_scores, run.neg_scores = pos_ptr, neg_ptr
         run.n_restarted = n_restarted.ctypes.data
+        if int(tb.sb.io.lean) and os.environ.get('TG_EVAL_PREFETCH', '1') != '0':  # collate prefetch inside the groups (tg_restart_run)
+            run.stream_len, run.first_offset = int(sb.src.numel()), int(self.first + k0 * sb.B)
         tb.io.step.rows_hint = model.rows_bound()
         try:
             check(lib.tg_eval_restart_run(C.byref(m), C.byref(self.graph.tcsr), None if static else C.addressof(rs),
