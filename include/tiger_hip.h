@@ -309,6 +309,12 @@ int tg_memory_scatter2(int64_t n, const int32_t* n_dev, const int64_t* ids, cons
 int tg_linear_fwd(int64_t n, const float* x, int32_t in_f, const tg_linear* lin, int32_t out_f, int32_t relu,
                   float* out, void* stream);
 
+/* Its backward (the operator path under autograd): dx [n, in_f] = dy W (NULL: not wanted), dw [out_f, in_f] = dy^T x and
+ * db [out_f] = column sums of dy (NULL: not wanted; overwritten, not accumulated).  in_f and out_f multiples of 4. */
+size_t tg_linear_bwd_workspace_bytes(int32_t in_f, int32_t out_f);
+int tg_linear_bwd(int64_t n, const float* x, int32_t in_f, const float* w, int32_t out_f, const float* dy, float* dx,
+                  float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
+
 /* torch.nn.GRUCell forward on dense rows (GRUUpdater.forward, update_modules.py:33-37):
  * x [n, xw] messages, h [n, d] old memory, out [n, d]. */
 int tg_gru_fwd(int64_t n, const float* x, int32_t xw, const float* h, int32_t d, const float* w_ih,

@@ -192,12 +192,40 @@ def test_operator_path_modules_run_on_the_library_under_no_grad():
     ml = MergeLayer(36, 36, 16, 1, dropout=0.1).to(dev()).eval()
     lf, mf = LinearMessageFunction(64, dropout=0.1).to(dev()).eval(), MLPMessageFunction(64, dropout=0.1).to(dev()).eval()
     x1, x2, r = torch.randn(301, 36, device=dev()), torch.randn(301, 36, device=dev()), torch.randn(77, 64, device=dev())
-    ref = (ml(x1, x2), lf(r), mf(r))  # grad mode: torch
+    ref = (ml(x1, x2), lf(r), mf(r))  # grad mode: the autograd functions over the same kernels (unfused ReLU)
     assert all(t.requires_grad for t in ref)
     with torch.no_grad():
         got = (ml(x1, x2), lf(r), mf(r))
     for a, b in zip(got, ref):
         assert a.shape == b.shape and rel_err(a.cpu().numpy(), b.detach().cpu().numpy()) < 1e-5
+
+
+def test_operator_path_modules_backward_runs_on_the_library():
+    """The same modules under autograd (someone training through the per-operator API): forward tg_linear_fwd, backward
+    tg_linear_bwd through an autograd function - outputs and every gradient (inputs, weights, biases; the score head's
+    d -> 1 layer on zero-padded weights) against plain torch modules carrying the same parameters."""
+    import copy
+    from www2023tiger_amd.model.basic_modules import MergeLayer
+    from www2023tiger_amd.model.message_modules import LinearMessageFunction, MLPMessageFunction
+    torch.manual_seed(5)
+    for mod, shapes in ((MergeLayer(36, 36, 16, 1, dropout=0.0), ((301, 36), (301, 36))),
+                        (MergeLayer(172, 172, 172, 172, dropout=0.0), ((1061, 172), (1061, 172))),
+                        (LinearMessageFunction(64, dropout=0.0), ((77, 64),)), (MLPMessageFunction(688, dropout=0.0), ((530, 688),))):
+        ref = copy.deepcopy(mod)  # stays on the CPU: plain torch
+        mod = mod.to(dev())
+        xs_ref = [torch.randn(*sh, requires_grad=True) for sh in shapes]
+        xs = [x.detach().to(dev()).requires_grad_(True) for x in xs_ref]
+        y_ref, y = ref(*xs_ref), mod(*xs)
+        g = torch.randn_like(y_ref)
+        y_ref.backward(g)
+        y.backward(g.to(dev()))
+        assert rel_err(y.detach().cpu().numpy(), y_ref.detach().numpy()) < 1e-5
+        for a, b in zip(xs, xs_ref):
+            assert rel_err(a.grad.cpu().numpy(), b.grad.numpy()) < 1e-5
+        for (k, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
+            assert rel_err(p.grad.cpu().numpy(), q.grad.numpy()) < 2e-5, k
+    from www2023tiger_amd.model import dense
+    assert dense.hip_autograd(xs[0], mod.fn[1])  # (the library's path was the one taken)
 
 
 @pytest.mark.parametrize('n,d,xw', [

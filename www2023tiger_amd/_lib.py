@@ -168,6 +168,8 @@ SIGNATURES = {
     'tg_memory_scatter2': (C.c_int, [i64, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp]),
     'tg_consume_update_right_rows': (C.c_int, [P(TgModel), vp, vp, i64, vp, vp, vp, vp]),
     'tg_linear_fwd': (C.c_int, [i64, vp, i32, P(TgLinear), i32, i32, vp, vp]),
+    'tg_linear_bwd_workspace_bytes': (sz, [i32, i32]),
+    'tg_linear_bwd': (C.c_int, [i64, vp, i32, vp, i32, vp, vp, vp, vp, vp, sz, vp]),
     'tg_gru_fwd': (C.c_int, [i64, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp]),
     'tg_mailbox_consume_gather': (C.c_int, [P(TgModel), vp, vp, i64, vp, vp]),
     'tg_apply_messages_workspace_bytes': (sz, [P(TgModel), i64]),

@@ -1065,6 +1065,39 @@ extern "C" int tg_linear_fwd(int64_t n, const float* x, int32_t in_f, const tg_l
   return gemm_launch(g, as_stream(stream));
 }
 
+// torch.nn.Linear backward on dense rows (the operator path under autograd: MergeLayer, message functions)
+extern "C" size_t tg_linear_bwd_workspace_bytes(int32_t in_f, int32_t out_f) {
+  if (in_f <= 0 || out_f <= 0) return 0;
+  return (size_t)16 * out_f * ((size_t)in_f + 1) * sizeof(float) + 256;  // at most 16 split partials of [out_f, in_f + 1]
+}
+extern "C" int tg_linear_bwd(int64_t n, const float* x, int32_t in_f, const float* w, int32_t out_f, const float* dy, float* dx,
+                             float* dw, float* db, void* ws, size_t ws_bytes, void* stream) {
+  if (n < 0 || in_f <= 0 || (in_f % 4) || out_f <= 0 || (out_f % 4)) return TG_EINVAL;
+  if (n == 0) return TG_OK;
+  if (!dy || (dx && !w) || (dw && !x) || ((dw || db) && !ws)) return TG_EINVAL;
+  hipStream_t st = as_stream(stream);
+  int rc;
+  if (dx) {  // dx = dy W
+    GemmArgs g{};
+    g.m_cap = n; g.n = in_f; g.k = out_f; g.a0 = ASeg{dy, out_f, out_f, nullptr};
+    g.w = w; g.ldw = in_f; g.w_kmajor = 1; g.c = dx; g.ldc = in_f; g.alpha = 1.f; g.nbatch = 1;
+    if ((rc = gemm_launch(g, st)) != TG_OK) return rc;
+  }
+  if (dw) {  // dw = dy^T x, db = column sums of dy (same pass)
+    if (ws_bytes < tg_linear_bwd_workspace_bytes(in_f, out_f)) return TG_EWORKSPACE;
+    TnArgs tn{};
+    tn.m_cap = n; tn.n = out_f; tn.k = in_f; tn.y = dy; tn.ldy = out_f; tn.x0 = ASeg{x, in_f, in_f, nullptr};
+    tn.out = dw; tn.ldo = in_f; tn.alpha = 1.f; tn.accumulate = 0; tn.nbatch = 1;
+    tn.part = reinterpret_cast<float*>(ws); tn.part_floats = ws_bytes / sizeof(float);
+    tn.bias_out = db; tn.bias_accumulate = 0;
+    if ((rc = gemm_tn_launch(tn, st)) != TG_OK) return rc;
+  } else if (db) {
+    if ((rc = colsum_launch(n, nullptr, out_f, dy, out_f, 1.f, db, 0, reinterpret_cast<float*>(ws), ws_bytes / sizeof(float), st)) != TG_OK)
+      return rc;
+  }
+  return check_launch("tg_linear_bwd");
+}
+
 extern "C" int tg_gru_fwd(int64_t n, const float* x, int32_t xw, const float* h, int32_t d, const float* w_ih,
                           const float* w_hh, const float* b_ih, const float* b_hh, float* out, void* stream) {
   if (n < 0 || d <= 0 || (d % 4) || xw <= 0 || (xw % 4)) return TG_EINVAL;

@@ -28,6 +28,61 @@ def linear_forward(layer: nn.Linear, x: Tensor, relu: bool = False) -> Tensor:
     return out
 
 
+class _LinearFn(torch.autograd.Function):
+    """nn.Linear on the library's kernels WITH autograd: forward tg_linear_fwd, backward tg_linear_bwd (dx = dy W,
+    dw = dy^T x, db = column sums) - the operator path under autograd stays on one backend."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w, b = x.contiguous(), w.contiguous(), b.contiguous()
+        n, in_f = x.shape
+        out_f = w.shape[0]
+        out = torch.empty(n, out_f, dtype=torch.float32, device=x.device)
+        lin = TgLinear(ptr(w), ptr(b))
+        check(lib.tg_linear_fwd(n, ptr(x), in_f, C.byref(lin), out_f, 0, ptr(out), stream_ptr(x.device)), 'tg_linear_fwd')
+        ctx.save_for_backward(x, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        n, in_f = x.shape
+        out_f = w.shape[0]
+        need_x, need_w, need_b = ctx.needs_input_grad
+        dx = torch.empty_like(x) if need_x else None
+        dw = torch.empty_like(w) if (need_w or need_b) else None  # (db comes out of dw's pass)
+        db = torch.empty(out_f, dtype=torch.float32, device=x.device) if need_b else None
+        if n == 0:
+            return (None if dx is None else dx.zero_(), None if not need_w else dw.zero_(), None if db is None else db.zero_())
+        nbytes = int(lib.tg_linear_bwd_workspace_bytes(in_f, out_f)) if dw is not None else 0
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+        check(lib.tg_linear_bwd(n, ptr(x), in_f, ptr(w), out_f, ptr(dy), ptr(dx), ptr(dw), ptr(db), ptr(ws), ws.numel(),
+                                stream_ptr(x.device)), 'tg_linear_bwd')
+        return dx, (dw if need_w else None), db
+
+
+def hip_autograd(x: Tensor, *layers: nn.Linear) -> bool:
+    """May a module's forward run on the library's kernels under autograd?  A 2-D float32 input on the GPU, input widths
+    that are multiples of four floats (output widths are padded where they are not), biases present."""
+    if not x.is_cuda or x.dim() != 2 or x.dtype != torch.float32:
+        return False
+    return all(l.in_features % 4 == 0 and l.bias is not None and l.weight.is_cuda for l in layers)
+
+
+def linear_autograd(layer: nn.Linear, x: Tensor) -> Tensor:
+    """layer(x) through _LinearFn; an output width that is no multiple of four (the score head's d -> 1) runs on weights
+    padded with zero rows - the padding and the slice are differentiable torch views / copies, the products the library's."""
+    w, b = layer.weight, layer.bias
+    out_f = w.shape[0]
+    pad = (-out_f) % 4
+    if pad:
+        w = torch.cat([w, w.new_zeros(pad, w.shape[1])], 0)
+        b = torch.cat([b, b.new_zeros(pad)], 0)
+    y = _LinearFn.apply(x, w, b)
+    return y[:, :out_f] if pad else y
+
+
 def gru_forward(cell: nn.GRUCell, x: Tensor, h: Tensor) -> Tensor:
     x, h = x.contiguous().float(), h.contiguous().float()
     out = torch.empty_like(h)

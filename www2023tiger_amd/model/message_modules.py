@@ -4,7 +4,7 @@ from typing import Optional, Tuple
 from torch import Tensor, nn
 
 from .. import hip_ops
-from .dense import hip_inference, linear_forward
+from .dense import hip_autograd, hip_inference, linear_autograd, linear_forward
 
 
 class MessageFunction(nn.Module):
@@ -37,6 +37,8 @@ class LinearMessageFunction(MessageFunction):
     def forward(self, raw_messages: Tensor) -> Tensor:
         if hip_inference(raw_messages, self.fn[0], self.fn[1]):
             return linear_forward(self.fn[1], raw_messages)
+        if hip_autograd(raw_messages, self.fn[1]):  # autograd / active dropout: the same kernels, backward included
+            return linear_autograd(self.fn[1], self.fn[0](raw_messages))
         return self.fn(raw_messages)
 
 
@@ -53,6 +55,9 @@ class MLPMessageFunction(MessageFunction):
     def forward(self, raw_messages: Tensor) -> Tensor:
         if hip_inference(raw_messages, self.fn[0], self.fn[1], self.fn[4]):
             return linear_forward(self.fn[4], linear_forward(self.fn[1], raw_messages, relu=True))
+        if hip_autograd(raw_messages, self.fn[1], self.fn[4]):
+            h = self.fn[2](linear_autograd(self.fn[1], self.fn[0](raw_messages)))
+            return linear_autograd(self.fn[4], self.fn[3](h))
         return self.fn(raw_messages)
 
 
