@@ -767,14 +767,17 @@ class TIGE(nn.Module):
 
         def __init__(self, model: 'TIGE', B: int, want_prev: bool, resident=None, embed_only: bool = False,
                      h_out=None, h_new_out=None, want_h_new: bool = True, lean: bool = False, prefetch: bool = False,
-                     debug_lists: bool = False):
+                     debug_lists: bool = False, collate_only: bool = False):
             """resident = (src, dst, neg, ts64, eids) device tensors of the WHOLE stream: the
             step then reads batch [offset, offset+B) and advances `offset` on device.
             lean: the caller does not read `involved` nor counts[0:2] (tiger_hip.h: tg_step_io.lean) - an eager
             step then skips forming those sets; same results otherwise.
             prefetch (resident streams): the caller does not read the neighbour lists either (l1_* are not outputs then) - a
             lean eager step of a model with eager query rows then runs the NEXT batch's sampler and centres as riders of its
-            own last launch (tiger_hip.h: tg_step_io.prefetch_state); same results otherwise."""
+            own last launch (tiger_hip.h: tg_step_io.prefetch_state); same results otherwise.
+            collate_only: buffers of a collate-only pass (tg_step_io.collate_only; the caller sets the flag): no embedding rows,
+            the lists and the involved set stay in the workspace - a third of the allocations (a restart-mode evaluation
+            pass builds sixteen such contexts)."""
             dev, d, K = model.device, model.memory_dim, model.n_neighbors
             self.B = B
             self.embed_only = embed_only
@@ -788,11 +791,15 @@ class TIGE(nn.Module):
                 assert self.ts.dtype == torch.float64 and all(t.is_contiguous() for t in resident)
                 self.offset = torch.zeros(1, **i64)
             # h_out / h_new_out: caller-owned output rows (e.g. slices of an all-gather send buffer)
-            self.h = h_out if h_out is not None else torch.zeros(3 * B, d, dtype=torch.float32, device=dev)
-            self.l1_nids = torch.zeros(3 * B, K, **i64)
-            self.l1_eids = torch.zeros(3 * B, K, **i64)
-            self.l1_ts = torch.zeros(3 * B, K, dtype=torch.float32, device=dev)
-            self.involved = torch.zeros(3 * B * (K + 1), **i64)
+            if collate_only:
+                self.h = self.l1_nids = self.l1_eids = self.l1_ts = self.involved = None
+                want_prev = want_h_new = False
+            else:
+                self.h = h_out if h_out is not None else torch.zeros(3 * B, d, dtype=torch.float32, device=dev)
+                self.l1_nids = torch.zeros(3 * B, K, **i64)
+                self.l1_eids = torch.zeros(3 * B, K, **i64)
+                self.l1_ts = torch.zeros(3 * B, K, dtype=torch.float32, device=dev)
+                self.involved = torch.zeros(3 * B * (K + 1), **i64)
             self.counts = torch.zeros(4, dtype=torch.int32, device=dev)
             self.err = torch.zeros(1, dtype=torch.int32, device=dev)
             self.h_prev_left = torch.zeros(2 * B, d, dtype=torch.float32, device=dev) if want_prev else None
@@ -873,7 +880,8 @@ class TIGE(nn.Module):
             that runs passes ahead of the steps (eval_utils: the resident restart-mode pass) points `io.offset_dev` elsewhere."""
             dev = model.device
             cap = min(3 * self.B * (model.n_neighbors + 1), model.n_nodes)
-            cb = TIGE.StepBuffers(model, self.B, False, resident=(self.src, self.dst, self.neg, self.ts, self.eids))
+            cb = TIGE.StepBuffers(model, self.B, False, resident=(self.src, self.dst, self.neg, self.ts, self.eids),
+                                  collate_only=True)
             cb.lazy_list = torch.zeros(max(cap, 1), dtype=torch.int64, device=dev)
             cb.lazy_tmin = torch.zeros(1, dtype=torch.float32, device=dev)
             cb._lazy = TgLazyRestart(None, None, ptr(self.lazy_trigger), self.lazy_trigger.numel(), ptr(self.lazy_batch),
