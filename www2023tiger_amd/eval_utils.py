@@ -121,7 +121,7 @@ def _restart_listed(model, tb, graph):
         # instead of being rebuilt for every node at the next step
         current = (model._pending is not None and model._pending_stamp == model._state_stamp()
                    and (getattr(model, '_gtab', None) is None or getattr(model, '_gtab_stamp', None) is not None))
-        model.restart(nids, tb.sb.lazy_tmin.expand(n))
+        model.restart_list(nids, tb.sb.lazy_tmin)  # (one library call for the SeqRestarter, TIGER.restart otherwise)
         if current:
             model._tables_follow_restart(nids)
     tb.sb.lazy_batch += 1
