@@ -123,6 +123,40 @@ def test_c2_shape_gradients_match_oracle():
         assert worst[0] < 3e-4, worst
 
 
+def test_c2_width_mutual_gradients_with_the_seq_restarter_match_oracle():
+    """The training iteration of the reference's DEFAULT recipe at the benchmarked widths - d = 172 (d_model 860, two heads),
+    hist_len 40, K = 10, all-zero node features (the narrow operand form) - on a batch of 192 after three streamed batches
+    (its nodes have histories and memories): both losses and every gradient, the SeqRestarter's included, against the
+    oracle's autograd (the fixtures cover d = 8 / 32)."""
+    import bench
+    from oracle import tiger_oracle as O
+    from www2023tiger_amd.model.training import TrainBuffers
+    B, d, K, H = 192, 172, 10, 40
+    st = bench.make_stream(600, 120, 5 * B, 3.0e4, seed=11, d_e=d)
+    model, orc = bench.build_models(st, d, K, 'left', 'right', restarter='seq', hist_len=H, with_oracle=True, dropout=0.0)
+    model.train()
+    assert model.restarter_fn.raw_feat_getter.nfeats_all_zero()
+    tb = TrainBuffers(model, B, mutual=True)
+    to = lambda x, dt: torch.as_tensor(x).to(dev(), dt)
+    for b in range(4):
+        a = [st[k][b * B:(b + 1) * B] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        cg = O.collate(orc.graph, a[0], a[1], a[2], a[3], K, 'seq', hist_len=H)
+        if b < 3:  # stream forward on both sides
+            orc.stream_step(*a, cg)
+            model.stream_step(*a)
+            continue
+        tb.sb.load(to(a[0], torch.int64), to(a[1], torch.int64), to(a[2], torch.int64), to(a[3], torch.float64),
+                   to(a[4], torch.int64))
+        tb.launch()  # (gradients only: the parameters are those the oracle differentiates at)
+        c, ml, grads = orc.train_step(*a, cg, lr=1e-3, mutual_coef=1.0)
+        assert int(tb.sb.err.item()) == 0
+        assert abs(float(tb.losses[0]) - c) < TOL * max(1.0, abs(c))
+        assert abs(float(tb.losses[1]) - ml) < TOL * max(1.0, abs(ml)), (float(tb.losses[1]), ml)
+        worst = max((grad_err(g.cpu().numpy(), grads[k].numpy()), k) for k, g in tb.grads.items())
+        assert worst[0] < 3e-4, worst
+        assert any(k.startswith('restarter_fn.') and float(g.abs().max()) > 0 for k, g in tb.grads.items())
+
+
 @pytest.mark.parametrize('strategy', ['recent_nodes', 'uniform'])
 def test_training_step_with_other_sampling_strategies(strategy):
     """--strategy recent_nodes / uniform in the device training step (tg_step_io.strategy = 1 / 2): the neighbourhoods follow
