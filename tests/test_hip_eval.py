@@ -423,7 +423,8 @@ def test_restart_mode_eval_on_two_streams_equals_one_stream(restarter, monkeypat
 
 
 @pytest.mark.parametrize('name,strategy', [('train_static_lr_d8_L2', 'recent_edges'), ('eval_static_ll_d16', 'recent_nodes'),
-                                           ('eval_seq_lr_d8', 'recent_nodes')])
+                                           ('eval_seq_lr_d8', 'recent_nodes'), ('seq_ll_d16_L2', 'recent_edges'),
+                                           ('seq_ll_d16_L2', 'recent_nodes')])
 @pytest.mark.parametrize('restart', [False, True], ids=['plain', 'restart_mode'])
 def test_resident_eval_with_two_layers_and_recent_nodes(name, strategy, restart, monkeypatch):
     """The resident evaluation pass on the forms beside the default one: two attention layers (no per-node tables: the

@@ -535,6 +535,43 @@ def test_stream_fused_step_two_layers_recent_nodes_strategy(form, strategy):
     compare_state_with_oracle(model, orc)
 
 
+@pytest.mark.parametrize('name,strategy', [('static_lr_d8_L2', 'recent_edges'), ('static_lr_d8_L2', 'recent_nodes'),
+                                           ('seq_lr_d8', 'recent_nodes')])
+def test_collate_only_pass_lists_what_the_step_involves(name, strategy):
+    """The list form of the lazy restart (tg_lazy_restart.list: a collate-only pass lists `involved & ~uptodate`): with nobody
+    up to date the list IS the batch's involved set - the nodes of EVERY layer, sampled with the graph's own strategy
+    (data_loader.py:105-131) - against the oracle's collation; and not the set another strategy / one hop would give."""
+    import ctypes as C
+    from oracle import tiger_oracle as O
+    from www2023tiger_amd._lib import check, lib, ptr
+    from www2023tiger_amd.hip_ops import stream_ptr
+    z = load(name)
+    cfg = parse_cfg(z)
+    L = cfg.get('L', 1)
+    model, g, _ = build_hip_model(z, cfg, strategy=strategy)
+    og = O.OracleGraph(z['src'], z['dst'], z['ts'], z['eids'], strategy=strategy, seed=0)
+    other = O.OracleGraph(z['src'], z['dst'], z['ts'], z['eids'], strategy='recent_edges', seed=0)
+    B, differs = cfg['B'], False
+    for b in range(2, n_batches(z)):
+        sl = slice(b * B, min((b + 1) * B, len(z['src'])))
+        a = [z[k][sl] for k in ('src', 'dst', 'neg', 'ts', 'eids')]
+        buf = model.step_buffers(len(a[0]))
+        buf.enable_lazy_restart(model, np.zeros(1, dtype=np.uint8), force_list=True)
+        buf.lazy_restarting.fill_(1)
+        to = lambda x, dt: torch.as_tensor(x).to(dev(), dt)
+        buf.load(to(a[0], torch.int64), to(a[1], torch.int64), to(a[2], torch.int64), to(a[3], torch.float64), to(a[4], torch.int64))
+        cb = buf._lazy_collate
+        model.prepare_pass(cb, g)
+        m = model.model_struct()
+        check(lib.tg_stream_step(C.byref(m), C.byref(g.tcsr), C.byref(cb.io), ptr(cb.ws), cb.ws.numel(), stream_ptr(dev())), 'pass')
+        got = sorted(cb.lazy_list[:int(cb.counts[3])].tolist())
+        ref = O.collate(og, a[0], a[1], a[2], a[3], cfg['K'], 'static', n_layers=L)['involved']
+        assert got == sorted(set(ref.tolist())), b
+        one_hop = O.collate(other, a[0], a[1], a[2], a[3], cfg['K'], 'static', n_layers=1)['involved']
+        differs = differs or sorted(set(one_hop.tolist())) != got
+    assert differs  # (second hop / strategy do change the set on this stream)
+
+
 def test_no_feat_buffer_reads_pinned_host_tables():
     """--no_feat_buffer (feature_getter.py:41-47,86-87): NumericalFeature(register_buffer=False) keeps the feature tables
     in pinned host memory; the kernels read them in place, the stream reproduces the reference like the resident form"""

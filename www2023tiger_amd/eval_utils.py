@@ -111,6 +111,7 @@ def _restart_listed(model, tb, graph):
     import ctypes as C
     cb = tb.sb._lazy_collate
     m = model.model_struct()
+    model.prepare_pass(cb, graph)
     check(lib.tg_stream_step(C.byref(m), C.byref(graph.tcsr), C.byref(cb.io), ptr(cb.ws), cb.ws.numel(), stream_ptr(model.device)),
           'tg_stream_step(lazy restart list)')
     n = int(cb.counts[3].item())
@@ -185,6 +186,7 @@ class _RestartPipeline:
         cb = self.ctx[k % 2]
         cb.io.offset_dev = self.offsets.data_ptr() + 8 * k
         m = self.model.model_struct()
+        self.model.prepare_pass(cb, self.graph)
         check(lib.tg_stream_step(C.byref(m), C.byref(self.graph.tcsr), C.byref(cb.io), ptr(cb.ws), cb.ws.numel(),
                                  stream_ptr(self.model.device)), 'tg_stream_step(lazy restart list)')
         self.host[k % 2].copy_(cb.counts[3:4], non_blocking=True)
@@ -356,6 +358,7 @@ class _RestartRun:
         run.group = G
         for j, cb in enumerate(ctx):
             cb._lazy.keep_msg_bits = 1
+            model.prepare_pass(cb, self.graph)
             run.pass_io[j], run.pass_ws[j], run.pass_ws_bytes[j] = C.addressof(cb.io), ptr(cb.ws), cb.ws.numel()
             run.count_host[j] = host[j].data_ptr()
         for j in range(2):

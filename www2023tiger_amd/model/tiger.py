@@ -917,6 +917,16 @@ class TIGE(nn.Module):
             raise ValueError(f'graph covers {graph.num_node} node ids, the model {self.n_nodes}: build every graph with '
                              'max_node_id = the largest node id of the full data (init_utils.init_data does)')
 
+    def prepare_pass(self, cb: 'TIGE.StepBuffers', graph=None):
+        """A collate-only pass (StepBuffers.lazy_collate_context) must flag exactly what the step will involve: it samples with
+        the graph's own strategy and, on a two-layer model, both hops (data_loader.py:105-131: `np_computation_graph_nodes`
+        holds the nodes of every layer).  Call before each pass (the structs carry pointers that follow the model)."""
+        strategy = getattr(self.graph if graph is None else graph, 'strategy', 'recent_edges')
+        cb.io.strategy = {'recent_edges': 0, 'recent_nodes': 1, 'uniform': 2}.get(strategy, 0)
+        if self.n_layers == 2:
+            cb._inner = self.model_struct(1)
+            cb.io.inner = C.addressof(cb._inner)
+
     def rows_bound(self) -> int:
         """Bound on the nodes with a pending message per batch handed to the library (tg_step_io.rows_hint):
         1.5 x the largest count read back so far, 0 while nothing has been read back.  Performance only - but a
@@ -964,6 +974,7 @@ class TIGE(nn.Module):
                 raise RuntimeError('the lazy-restart loop with a sequence restarter reads one count back per batch: '
                                    'it cannot be captured into a graph (the static restarter runs inside the step)')
             m = self.model_struct()
+            self.prepare_pass(cb, self.graph)
             check(lib.tg_stream_step(C.byref(m), C.byref(g), C.byref(cb.io), ptr(cb.ws), cb.ws.numel(),
                                      stream_ptr(self.device)), 'tg_stream_step(lazy restart list)')
             n = int(cb.counts[3].item())  # the one read-back of the loop

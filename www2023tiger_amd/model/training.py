@@ -426,6 +426,7 @@ class FusedTrainer:
                                    'it cannot be captured into a graph (the static restarter runs inside the step)')
             g = (model.graph if graph is None else graph).tcsr
             m = model.model_struct()
+            model.prepare_pass(cb, model.graph if graph is None else graph)
             check(lib.tg_stream_step(C.byref(m), C.byref(g), C.byref(cb.io), ptr(cb.ws), cb.ws.numel(),
                                      stream_ptr(model.device)), 'tg_stream_step(lazy restart list)')
             n = self.restarted = int(cb.counts[3].item())
