@@ -261,7 +261,8 @@ __global__ void k_sel_min(int64_t n, const int64_t* __restrict__ nids, const T* 
                           const unsigned long long* __restrict__ best, unsigned int* __restrict__ best_idx) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t r = bm_rank(bm, rank, nids[i]);
-    if ((unsigned long long)orderable(ts[i]) == best[r]) atomicMin(best_idx + r, (unsigned int)i);
+    // (the smallest index wins a tie: kept as the largest complement, so that the slot can start from zero like `best`)
+    if ((unsigned long long)orderable(ts[i]) == best[r]) atomicMax(best_idx + r, ~(unsigned int)i);
   }
 }
 
@@ -269,7 +270,7 @@ __global__ void k_sel_out(const int32_t* __restrict__ count, int64_t cap, const 
                           int64_t* __restrict__ out_index) {
   const int64_t n = *count;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n && i < cap; i += (int64_t)gridDim.x * blockDim.x)
-    out_index[i] = (int64_t)best_idx[i];
+    out_index[i] = (int64_t)(~best_idx[i]);
 }
 
 static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -354,19 +355,19 @@ extern "C" int tg_select_latest(int64_t n, const int64_t* nids, const void* ts, 
   hipStream_t st = as_stream(stream);
   const int64_t W = (n_nodes + 63) / 64;
   char* p = (char*)ws;
+  // flags | best | best_idx first: everything that starts from zero, cleared by ONE memset
   uint8_t* flags = (uint8_t*)p;
   p += align16((size_t)W * 64);
-  uint64_t* bm = (uint64_t*)p;
-  p += align16((size_t)W * 8);
-  uint32_t* rank = (uint32_t*)p;
-  p += align16((size_t)(W + 1) * 4);
   unsigned long long* best = (unsigned long long*)p;
   p += align16((size_t)n * 8);
   unsigned int* best_idx = (unsigned int*)p;
   p += align16((size_t)n * 4);
-  hipError_t e = hipMemsetAsync(flags, 0, (size_t)W * 64, st);
-  if (e == hipSuccess && n > 0) e = hipMemsetAsync(best, 0, (size_t)n * 8, st);
-  if (e == hipSuccess && n > 0) e = hipMemsetAsync(best_idx, 0xff, (size_t)n * 4, st);
+  const size_t zero_bytes = (size_t)(p - (char*)ws);
+  uint64_t* bm = (uint64_t*)p;
+  p += align16((size_t)W * 8);
+  uint32_t* rank = (uint32_t*)p;
+  p += align16((size_t)(W + 1) * 4);
+  hipError_t e = hipMemsetAsync(flags, 0, zero_bytes, st);
   if (e != hipSuccess) {
     set_hip_error(e, "tg_select_latest memset");
     return TG_EHIP;

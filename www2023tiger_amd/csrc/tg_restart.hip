@@ -867,12 +867,13 @@ __global__ void k_restart_queries(int64_t B, const double* __restrict__ ts, cons
 }
 __global__ void k_restart_pad(int64_t cap, const int32_t* __restrict__ n_dev, int H, int64_t* __restrict__ uniq,
                               const int64_t* __restrict__ index, const double* __restrict__ ts2,
-                              double* __restrict__ tu, int32_t* __restrict__ counts2) {
+                              double* __restrict__ tu, int32_t* __restrict__ counts2, float* __restrict__ acc4) {
   const int64_t n = min(cap, (int64_t)*n_dev);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     counts2[0] = (int32_t)n;
     counts2[1] = (int32_t)(n * H);
   }
+  if (acc4 && blockIdx.x == 0 && threadIdx.x < 4) acc4[threadIdx.x] = 0.f;  // the loss accumulators of the mutual step
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (int64_t)gridDim.x * blockDim.x) {
     if (i < n) {
       tu[i] = ts2[index[i]];
@@ -1137,12 +1138,7 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
                              (void*)st)) != TG_OK)
     return rc;
   hipLaunchKernelGGL(k_restart_pad, dim3(flat_grid(n, 256)), dim3(256), 0, st, n, w.count, H, w.uniq, w.index, w.ts2,
-                     w.tu, w.counts2);
-  hipError_t e = hipMemsetAsync(w.acc, 0, 4 * sizeof(float), st);
-  if (e != hipSuccess) {
-    set_hip_error(e, "mutual_step memset");
-    return TG_EHIP;
-  }
+                     w.tu, w.counts2, w.acc);
   if (!r) {
     hipLaunchKernelGGL(k_static_rows, dim3(flat_grid(n * d, 256)), dim3(256), 0, st, n, w.counts2, d, w.uniq, st_left,
                        st_right, w.sl, w.sr);
