@@ -1517,6 +1517,8 @@ int step_forward(const tg_model* m, const tg_tcsr* g, const tg_step_io* io, Step
                                        lz ? reinterpret_cast<uint32_t*>(w.counts + 4) : nullptr,
                                        (w.lean && !lz) ? &rider : nullptr)) != TG_OK)  // (centres: behind the restart loop)
     return rc;
+  // a caller that runs work beside the rest of the forward pass (the training step's restarter: it needs the id list only)
+  if (w.collate_done && hipEventRecord(w.collate_done, st) == hipSuccess) w.collate_recorded = true;
   if (io->dbg_l1_nids || io->dbg_l1_eids || io->dbg_l1_ts) {  // the lists this step consumes, before its last launch prefetches the next
     const size_t n = (size_t)Q * K;
     if (io->dbg_l1_nids && (e = hipMemcpyAsync(io->dbg_l1_nids, w.l1n, n * 8, hipMemcpyDeviceToDevice, st)) != hipSuccess) return TG_EHIP;

@@ -69,6 +69,8 @@ struct StepWs {
   bool fused_wb;    // STEP 4-6 run as one launch (needs the snapshot taken by the direct centres launch)
   bool direct;      // ... and no compact copy of the involved rows was made (centres / neighbours read the tables)
   bool gtab;        // the folded queries come from the per-node table; the step refreshes its positive nodes' rows at the end
+  hipEvent_t collate_done;  // nullable, the caller's: recorded right behind the first-hop sampler (the batch's id list exists)
+  bool collate_recorded;
   bool prefetch;    // the step runs the collate part of the NEXT batch on its last launch (tg_step_io.prefetch_state)
   bool prefetch_side;  // ... large batch: its sampler half on the side lane beside the updater, its centres half behind the query rows
   PosArgs pos_args;   // the step's dedup arguments / direct-centres arguments (the prefetch builds the next batch's

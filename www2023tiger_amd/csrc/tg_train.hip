@@ -1140,18 +1140,23 @@ extern "C" int tg_train_step(const tg_model* m_in, const tg_tcsr* g, const tg_tr
   }
   if (io->dropout_p < 0.f || io->dropout_p >= 1.f || (io->dropout_p > 0.f && !io->rng)) return TG_EINVAL;
   const DropCfg dc = make_drop(io->dropout_p, io->rng);
-  if ((rc = step_forward(m, g, sio, w, t.gates, st, nullptr, &dc)) != TG_OK) return rc;
   const bool seq = io->restarter == TG_RESTARTER_SEQ;
   if (seq && (!io->seq || !io->seq_grads)) return TG_EINVAL;
+  // the SeqRestarter's forward runs beside the contrast half on a second stream.  It needs the batch's id list and nothing
+  // else of the forward pass: the fork is recorded INSIDE step_forward, right behind the sampler's launch, so the lane's
+  // 0.6 ms overlap the forward pass as well as the backward (TG_TRAIN_FORK=0: fork behind the whole forward pass)
+  static const int fork_knob = getenv("TG_TRAIN_FORK") ? atoi(getenv("TG_TRAIN_FORK")) : 1;  // tuning knob
+  TrainLane* lane = seq ? train_lane(st) : nullptr;
+  if (lane && fork_knob) w.collate_done = lane->fork;
+  if ((rc = step_forward(m, g, sio, w, t.gates, st, nullptr, &dc)) != TG_OK) return rc;
   SideCtx side{};
   auto mutual = [&](int phase, hipStream_t s, SideCtx* sd) {
     return mutual_step(m, g, sio, w, seq ? io->seq : nullptr, seq ? io->seq_grads : nullptr, io->static_left,
                        io->static_right, io->static_left_grad, io->static_right_grad, io->losses + 1,
                        io->flags ? io->flags + 2 : nullptr, t.part, t.part_floats, cv.p, cv.left, dc, s, phase, sd);
   };
-  // the SeqRestarter's forward beside the contrast half (it needs the batch's id list, which step_forward has written)
-  TrainLane* lane = seq ? train_lane(st) : nullptr;
-  if (lane && !(hipEventRecord(lane->fork, st) == hipSuccess && hipStreamWaitEvent(lane->s, lane->fork, 0) == hipSuccess)) {
+  if (lane && !((w.collate_recorded || hipEventRecord(lane->fork, st) == hipSuccess) &&
+                hipStreamWaitEvent(lane->s, lane->fork, 0) == hipSuccess)) {
     (void)hipGetLastError();
     lane = nullptr;
   }
