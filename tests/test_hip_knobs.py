@@ -67,3 +67,19 @@ def test_c2_timed_form_under_knob(setting):
     rc, out, err = _result(setting)
     tail = (out + err)[-3000:]
     assert rc == 0 and 'KNOB-CASE OK' in out, f'{setting}:\n{tail}'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('setting', ['TG_TRAIN_SIDE=0', 'TG_TRAIN_FORK=0'])
+def test_training_step_under_lane_knobs(setting):
+    """The training step's second stream (knob table): without the lane, and with the lane forked behind the whole
+    forward pass instead of right behind the sampler - the mutual-loss gradient tests (fixtures, C2 widths, the reference's
+    trajectory) in a child process that reads the knob."""
+    env = dict(os.environ)
+    k, v = setting.split('=')
+    env[k] = v
+    env.setdefault('OMP_NUM_THREADS', '4')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(HERE, 'test_hip_train.py'), '-q', '-x', '-m', 'gpu', '-k',
+                        'mutual_gradients_match_oracle or c2_width or mutual_trajectory', '-p', 'no:cacheprovider'],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0 and ' passed' in r.stdout, (r.stdout + r.stderr)[-3000:]
