@@ -70,7 +70,7 @@ def test_c2_timed_form_under_knob(setting):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('setting', ['TG_TRAIN_SIDE=0', 'TG_TRAIN_FORK=0'])
+@pytest.mark.parametrize('setting', ['TG_TRAIN_SIDE=0', 'TG_TRAIN_FORK=0', 'TG_SEQ_BWD_SPLIT=0'])
 def test_training_step_under_lane_knobs(setting):
     """The training step's second stream (knob table): without the lane, and with the lane forked behind the whole
     forward pass instead of right behind the sampler - the mutual-loss gradient tests (fixtures, C2 widths, the reference's

@@ -1274,19 +1274,36 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
                      (const float4*)w.dxbar, sc, w.dabar, dc.p > 0.f ? w.dO : (const float*)nullptr,
                      r->in_proj_b + 2 * dm);
   const SeqRows sr{q.qk, q.slot_row, q.row_slot, q.row_anon, q.base, q.ta, w.anon};
-#define TG_SEQ_SCORES_BWD(HP_, V2_, MIN_)                                                                             \
-  hipLaunchKernelGGL((k_seq_scores_bwd<HP_, V2_>), dim3((unsigned)(n * nh)), dim3(256), sizeof(SeqLds<HP_>), st, n, n_dev, H, \
+#define TG_SEQ_SCORES_BWD(HP_, V2_, MIN_, ST_)                                                                        \
+  hipLaunchKernelGGL((k_seq_scores_bwd<HP_, V2_>), dim3((unsigned)(n * nh)), dim3(256), sizeof(SeqLds<HP_>), ST_, n, n_dev, H, \
                      dm, nh, sr, w.h_n, w.dabar, w.dqk, w.dqk_last, dc, MIN_)
   const bool v2 = (dm / nh) % 2 == 0;
   if (H <= 64) {
-    if (v2) TG_SEQ_SCORES_BWD(32, true, 0);
-    else TG_SEQ_SCORES_BWD(32, false, 0);
-    if (H > 32) {
-      if (v2) TG_SEQ_SCORES_BWD(64, true, 32);
-      else TG_SEQ_SCORES_BWD(64, false, 32);
+    // histories of 33 .. 64 events: the two row classes are two launches over the same grid that write disjoint rows - the
+    // many short blocks of the 32-row class on the lane (when there is one) beside the few long ones of the 64-row class
+    // (TG_SEQ_BWD_SPLIT=0: one after the other on the main stream)
+    static const int split_knob = getenv("TG_SEQ_BWD_SPLIT") ? atoi(getenv("TG_SEQ_BWD_SPLIT")) : 1;  // tuning knob
+    hipStream_t s32 = st;
+    bool forked = false;
+    if (H > 32 && side_ok && split_knob && side->used + 5 <= side->n && side->after_main(st)) {
+      s32 = side->s;
+      forked = true;
     }
-  } else if (v2) TG_SEQ_SCORES_BWD(128, true, 0);
-  else TG_SEQ_SCORES_BWD(128, false, 0);
+    if (v2) TG_SEQ_SCORES_BWD(32, true, 0, s32);
+    else TG_SEQ_SCORES_BWD(32, false, 0, s32);
+    if (H > 32) {
+      if (v2) TG_SEQ_SCORES_BWD(64, true, 32, st);
+      else TG_SEQ_SCORES_BWD(64, false, 32, st);
+    }
+    if (forked) {  // join: the column sums and the products below read both classes' rows
+      if (hipEventRecord(side->ev[side->used], side->s) != hipSuccess || hipStreamWaitEvent(st, side->ev[side->used], 0) != hipSuccess) {
+        set_hip_error(hipGetLastError(), "mutual_step (score backward join)");
+        return TG_EHIP;
+      }
+      ++side->used;
+    }
+  } else if (v2) TG_SEQ_SCORES_BWD(128, true, 0, st);
+  else TG_SEQ_SCORES_BWD(128, false, 0, st);
 #undef TG_SEQ_SCORES_BWD
   // row 0 (the last event of every node) collects the last slots' gradients
   if ((rc = colsum_launch(n, n_dev, 2 * dm, w.dqk_last, 2 * dm, 1.f, w.dqk, 0, w.cpart, (size_t)16 * 2 * dm, st)) != TG_OK) return rc;
