@@ -1259,12 +1259,14 @@ int mutual_step(const tg_model* m, const tg_tcsr* g, const tg_step_io* sio, cons
     } else {
       late_heads.push_back(tn);
     }
-    ga = GemmArgs{};
-    ga.m_cap = n; ga.m_dev = n_dev; ga.n = dm - off; ga.k = dm; ga.a0 = ASeg{dOh, dm, dm, nullptr};
-    ga.w = r->in_proj_w + (int64_t)2 * dm * dm + off; ga.ldw = dm; ga.w_kmajor = 1;
-    ga.c = w.dxbar + (int64_t)h * dm + off; ga.ldc = (int64_t)nh * dm; ga.alpha = 1.f; ga.nbatch = 1;
-    if ((rc = gemm_launch(ga, st)) != TG_OK) return rc;
   }
+  // d xbar of all heads as ONE batched product (same weights, the heads' masked copies of dO, their column blocks of dxbar):
+  // a head alone is 150 blocks of work on 256 CUs
+  ga = GemmArgs{};
+  ga.m_cap = n; ga.m_dev = n_dev; ga.n = dm - off; ga.k = dm; ga.a0 = ASeg{w.dOm, dm, dm, nullptr}; ga.a0_bs = (int64_t)n * dm;
+  ga.w = r->in_proj_w + (int64_t)2 * dm * dm + off; ga.ldw = dm; ga.w_kmajor = 1; ga.w_bs = 0;
+  ga.c = w.dxbar + off; ga.ldc = (int64_t)nh * dm; ga.c_bs = dm; ga.alpha = 1.f; ga.nbatch = nh;
+  if ((rc = gemm_launch(ga, st)) != TG_OK) return rc;
   if ((rc = flush()) != TG_OK) return rc;
   for (const TnArgs& a : late_heads)
     if ((rc = gemm_tn_launch(a, ws_st)) != TG_OK) return rc;
