@@ -314,6 +314,47 @@ def test_fused_trainer_mutual_trajectory(loop, name):
         assert rel_err(p.detach().cpu().numpy(), z[f'final.{k}']) < 2e-3, k
 
 
+@pytest.mark.parametrize('name,strategy', [('train_seq_lr_d8', 'recent_nodes'), ('train_static_lr_d8_L2', 'recent_edges'),
+                                           ('train_static_lr_d8_L2', 'recent_nodes')])
+def test_fused_trainer_device_loop_equals_host_sets_on_other_forms(name, strategy):
+    """FusedTrainer.enable_lazy_restart beside the loop written with Python sets, where no reference trajectory exists: a
+    `recent_nodes` graph (the list form's collate-only pass must sample with the graph's strategy) and two layers (both hops
+    are involved: in-step loop of the static restarter) - same losses, same parameters after every iteration."""
+    from www2023tiger_amd.model.training import FusedTrainer
+    z = load(name)
+    cfg = parse_cfg(z)
+    out = {}
+    for loop in ('host_sets', 'device'):
+        model, _, coll = build_hip_model(z, cfg, strategy=strategy, dropout=0.0)
+        model.train()
+        tr = FusedTrainer(model, cfg['B'], lr=cfg['lr'], mutual=True, mutual_coef=cfg['mutual_coef'])
+        restarting, uptodate, losses = False, set(), []
+        if loop == 'device':
+            trigger = np.zeros(cfg['n_batches'], dtype=np.uint8)
+            trigger[cfg['restart_at']] = 1
+            tr.enable_lazy_restart(trigger)
+        for b in range(cfg['n_batches']):
+            a = batch(z, cfg, b)
+            if loop == 'host_sets':
+                if b == cfg['restart_at']:
+                    restarting, uptodate = True, set()
+                    model.msg_store.clear()
+                if restarting:
+                    cg = coll.collate_arrays(*a)[-1]
+                    r_nodes = np.array(sorted(set(cg.np_computation_graph_nodes.tolist()) - uptodate), dtype=np.int64)
+                    model.restart(torch.from_numpy(r_nodes), torch.full((len(r_nodes),), float(np.float32(a[3]).min())))
+                    uptodate.update(r_nodes.tolist())
+            losses.append(tr.step(*a).clone())
+        out[loop] = (losses, {k: p.detach().clone() for k, p in model.named_parameters()}, model.left_memory.vals.clone())
+    # (two runs of the same iteration agree to rounding only: the backward pass accumulates with atomics, Adam at lr 1e-2
+    #  carries the last bits on)
+    for la, lb in zip(out['host_sets'][0], out['device'][0]):
+        assert torch.allclose(la, lb, rtol=1e-4, atol=1e-5)
+    for k, p in out['host_sets'][1].items():
+        assert rel_err(out['device'][1][k].cpu().numpy(), p.cpu().numpy()) < TOL, k
+    assert rel_err(out['device'][2].cpu().numpy(), out['host_sets'][2].cpu().numpy()) < TOL
+
+
 def test_restart_list_in_train_mode_draws_the_masks_of_restart():
     """TIGER.restart_list with the SeqRestarter in train() mode (the training script's lazy-restart loop calls restart with
     dropout active): one library call (tg_restart_seq_list_train) - the memories TIGER.restart leaves from the same generator
